@@ -1,0 +1,1085 @@
+// gv_context.cpp — host side of libgarden_vis.so: context, AoS -> SoA device mirror, per-frame
+// dispatch, results. Implements include/garden_vis.h.
+//
+// Replaces (reference paths): the scratch sizing / dispatch / wait of MeshRenderSystem::prepareMeshes
+// (source/system/render/mesh.cpp:331-553), the per-entity Manager::tryGet lookup (mesh.cpp:149) —
+// resolved once into the mirror — and HizRenderSystem::downsampleHiz's per-mip pass loop
+// (source/system/render/hiz.cpp:148-164).
+//
+// There is NO CPU fallback: without a gfx950 device gv_create fails with GV_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/garden_vis.h"
+#include "gv_kernels.hpp"
+
+using namespace gv;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DeviceBuf {  // grow-only device allocation (scratch vectors grow, never shrink: mesh.cpp:377-395)
+    T* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (e == hipSuccess)
+            cap = n;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = n;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct DirtyRange {
+    uint32_t lo = UINT32_MAX, hi = 0;
+    bool any() const { return lo < hi; }
+    void add(uint32_t first, uint32_t count)
+    {
+        lo = std::min(lo, first);
+        hi = std::max(hi, first + count);
+    }
+    void clear()
+    {
+        lo = UINT32_MAX;
+        hi = 0;
+    }
+};
+
+struct TransformBinding {
+    const uint8_t* base = nullptr;
+    size_t stride = 0;
+    uint32_t occupancy = 0;
+    GvTransformLayout layout{};
+    const uint32_t* entity_to_transform = nullptr;
+    uint32_t entity_capacity = 0;
+    bool bound = false;
+};
+
+struct PoolState {
+    uint8_t* base = nullptr;
+    size_t stride = 0;
+    uint32_t occupancy = 0;
+    GvMeshLayout layout{};
+    bool bound = false;
+    bool need_full = false;
+    DirtyRange dirty;
+    // device mirror + pinned staging
+    DeviceBuf<float4> d_a;
+    DeviceBuf<float3> d_b;
+    PinnedBuf<float4> h_a;
+    PinnedBuf<float3> h_b;
+};
+
+struct ViewState {
+    DeviceBuf<unsigned long long> mask;
+    DeviceBuf<uint32_t> block_count, block_offset, draw_count;
+    DeviceBuf<uint8_t> is_visible;
+    DeviceBuf<uint32_t> visible_idx;
+    DeviceBuf<float> baked_model, distance_sq;
+    PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
+    PinnedBuf<float> h_baked_model, h_distance_sq;
+    PinnedBuf<uint8_t> h_is_visible;
+    uint32_t pool_id = 0, occupancy = 0;
+    bool main_pass = false, emitted = false, valid = false;
+};
+
+struct PendingEvent {
+    hipEvent_t start, stop;
+    int kernel;
+};
+
+}  // namespace
+
+struct GvCtx {
+    GvConfig config{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    TransformBinding xf;
+    bool xf_need_full = false;
+    DirtyRange xf_dirty;
+    DeviceBuf<float4> d_xa, d_xb;
+    DeviceBuf<float3> d_xc;
+    PinnedBuf<float4> h_xa, h_xb;
+    PinnedBuf<float3> h_xc;
+    uint32_t max_depth = 0;
+
+    PoolState pools[GV_MAX_POOLS];
+    ViewState views[GV_MAX_VIEWS];
+
+    // world-matrix cache
+    DeviceBuf<float4> d_world;
+    bool world_valid = false;
+
+    // Hi-Z
+    DeviceBuf<float> d_depth;
+    const float* depth_ptr = nullptr;  // d_depth.ptr or caller's device memory
+    DeviceBuf<float2> d_mips;
+    DeviceBuf<uint64_t> d_mip_offset;
+    uint32_t hiz_w = 0, hiz_h = 0, hiz_mips = 0;
+    uint32_t mip_w[GV_MAX_MIPS]{}, mip_h[GV_MAX_MIPS]{};
+    uint64_t mip_off[GV_MAX_MIPS]{};
+    bool hiz_valid = false;
+
+    // profiling
+    std::vector<PendingEvent> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    GvStats stats{};
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what)
+    {
+        return fail(e == hipErrorOutOfMemory ? GV_E_OOM : GV_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+};
+
+#define GV_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess)                              \
+            return (ctx)->hip_fail(e__, #call);             \
+    } while (0)
+
+namespace {
+
+// ---- profiling events ----
+struct KernelTimer {
+    GvCtx* ctx;
+    int kernel;
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool on = false;
+    KernelTimer(GvCtx* c, int k) : ctx(c), kernel(k)
+    {
+        ctx->stats.launches[k]++;
+        if (!(ctx->config.flags & GV_CONFIG_PROFILE_EVENTS))
+            return;
+        if (!ctx->free_events.empty()) {
+            start = ctx->free_events.back().first;
+            stop = ctx->free_events.back().second;
+            ctx->free_events.pop_back();
+        } else if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+            return;
+        }
+        on = hipEventRecord(start, ctx->stream) == hipSuccess;
+    }
+    ~KernelTimer()
+    {
+        if (!on)
+            return;
+        (void)hipEventRecord(stop, ctx->stream);
+        ctx->pending.push_back({start, stop, kernel});
+    }
+};
+
+void drain_events(GvCtx* ctx)
+{
+    for (auto& p : ctx->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess)
+            ctx->stats.device_ms[p.kernel] += ms;
+        ctx->free_events.emplace_back(p.start, p.stop);
+    }
+    ctx->pending.clear();
+}
+
+// ---- host gather: AoS component pools -> SoA staging ----
+template <typename F>
+void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
+{
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t threads = count < (1u << 16) ? 1u : std::min(hw, 16u);
+    if (threads == 1) {
+        fn(first, first + count);
+        return;
+    }
+    const uint32_t per = (count + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; t++) {
+        const uint32_t lo = first + std::min(count, per * t), hi = first + std::min(count, per * (t + 1));
+        if (lo < hi)
+            pool.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    fn(first, first + std::min(count, per));
+    for (auto& th : pool)
+        th.join();
+}
+
+inline uint32_t load_u32(const uint8_t* p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+inline float bits_to_float(uint32_t u)
+{
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+inline uint32_t entity_slot(const TransformBinding& xf, uint32_t entity)
+{
+    if (entity == 0 || entity >= xf.entity_capacity)
+        return kSlotNone;
+    const uint32_t s = xf.entity_to_transform[entity];
+    return (s == GV_NONE || s >= xf.occupancy) ? kSlotNone : s;
+}
+
+void gather_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
+{
+    const TransformBinding& xf = ctx->xf;
+    const GvTransformLayout& L = xf.layout;
+    parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
+        for (uint32_t s = a; s < b; s++) {
+            const uint8_t* t = xf.base + (size_t)s * xf.stride;
+            const float* pos = reinterpret_cast<const float*>(t + L.position);
+            const float* scl = reinterpret_cast<const float*>(t + L.scale);
+            const float* rot = reinterpret_cast<const float*>(t + L.rotation);
+            const uint32_t entity = load_u32(t + L.entity);
+            uint32_t link = entity_slot(xf, load_u32(t + L.parent));
+            if (entity)
+                link |= kXfLive;
+            if (t[L.self_active] && t[L.ancestors_active])
+                link |= kXfActive;
+            if (t[L.model_with_ancestors])
+                link |= kXfWithAncestors;
+            ctx->h_xa.ptr[s] = make_float4(pos[0], pos[1], pos[2], scl[0]);
+            ctx->h_xb.ptr[s] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+            ctx->h_xc.ptr[s] = make_float3(scl[1], scl[2], bits_to_float(link));
+        }
+    });
+}
+
+void gather_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
+{
+    const GvMeshLayout& L = p.layout;
+    const TransformBinding& xf = ctx->xf;
+    parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
+        for (uint32_t i = a; i < b; i++) {
+            const uint8_t* m = p.base + (size_t)i * p.stride;
+            const float* mn = reinterpret_cast<const float*>(m + L.aabb_min);
+            const float* mx = reinterpret_cast<const float*>(m + L.aabb_max);
+            const uint32_t entity = load_u32(m + L.entity);
+            uint32_t link = entity_slot(xf, entity);  // Manager::tryGet<TransformComponent>  mesh.cpp:149
+            if (entity && m[L.is_enabled])
+                link |= kMeshCandidate;
+            p.h_a.ptr[i] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+            p.h_b.ptr[i] = make_float3(mx[1], mx[2], bits_to_float(link));
+        }
+    });
+}
+
+// Longest parent chain; a cycle (the reference asserts against it, transform.cpp:137-143) is an error.
+int compute_max_depth(GvCtx* ctx, uint32_t* out_depth)
+{
+    const uint32_t n = ctx->xf.occupancy;
+    std::vector<uint32_t> depth(n, UINT32_MAX);
+    uint32_t max_depth = 0;
+    std::vector<uint32_t> stack;
+    for (uint32_t s = 0; s < n; s++) {
+        if (depth[s] != UINT32_MAX)
+            continue;
+        stack.clear();
+        uint32_t cur = s;
+        while (cur != kSlotNone && depth[cur] == UINT32_MAX) {
+            stack.push_back(cur);
+            if (stack.size() > n)
+                return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", s);
+            depth[cur] = UINT32_MAX - 1;  // on the current path
+            uint32_t link;
+            memcpy(&link, &ctx->h_xc.ptr[cur].z, 4);
+            cur = link & kSlotMask;
+            if (cur != kSlotNone && depth[cur] == UINT32_MAX - 1)
+                return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", cur);
+        }
+        uint32_t d = cur == kSlotNone ? 0 : depth[cur] + 1;
+        for (size_t k = stack.size(); k-- > 0;) {
+            depth[stack[k]] = d;
+            max_depth = std::max(max_depth, d);
+            d++;
+        }
+    }
+    *out_depth = max_depth;
+    return GV_OK;
+}
+
+int upload_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
+{
+    const size_t n = hi - lo;
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xa.ptr + lo, ctx->h_xa.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xb.ptr + lo, ctx->h_xb.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xc.ptr + lo, ctx->h_xc.ptr + lo, n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
+    ctx->stats.upload_bytes += n * (2 * sizeof(float4) + sizeof(float3));
+    return GV_OK;
+}
+
+int upload_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
+{
+    const size_t n = hi - lo;
+    GV_HIP(ctx, hipMemcpyAsync(p.d_a.ptr + lo, p.h_a.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(p.d_b.ptr + lo, p.h_b.ptr + lo, n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
+    ctx->stats.upload_bytes += n * (sizeof(float4) + sizeof(float3));
+    return GV_OK;
+}
+
+int sync_mirror(GvCtx* ctx)
+{
+    if (!ctx->xf.bound)
+        return ctx->fail(GV_E_STATE, "gv_sync: no transform pool bound");
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->xf.occupancy;
+    bool staged = false;
+    if (ctx->xf_need_full) {
+        // staging is about to be rewritten: make sure earlier async uploads have drained
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        staged = true;
+        const size_t cap = std::max<size_t>(n, 1);
+        GV_HIP(ctx, ctx->d_xa.reserve(cap));
+        GV_HIP(ctx, ctx->d_xb.reserve(cap));
+        GV_HIP(ctx, ctx->d_xc.reserve(cap));
+        GV_HIP(ctx, ctx->h_xa.reserve(cap));
+        GV_HIP(ctx, ctx->h_xb.reserve(cap));
+        GV_HIP(ctx, ctx->h_xc.reserve(cap));
+        if (n) {
+            gather_transforms(ctx, 0, n);
+            uint32_t depth = 0;
+            int rc = compute_max_depth(ctx, &depth);
+            if (rc != GV_OK)
+                return rc;
+            ctx->max_depth = depth;
+            rc = upload_transforms(ctx, 0, n);
+            if (rc != GV_OK)
+                return rc;
+        } else {
+            ctx->max_depth = 0;
+        }
+        ctx->xf_need_full = false;
+        ctx->xf_dirty.clear();
+        ctx->world_valid = false;
+        // transform slots may have moved: every mesh pool's slot column must be re-resolved
+        for (auto& p : ctx->pools)
+            if (p.bound)
+                p.need_full = true;
+    } else if (ctx->xf_dirty.any()) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        staged = true;
+        const uint32_t lo = ctx->xf_dirty.lo, hi = std::min(ctx->xf_dirty.hi, n);
+        if (lo < hi) {
+            gather_transforms(ctx, lo, hi);
+            int rc = upload_transforms(ctx, lo, hi);
+            if (rc != GV_OK)
+                return rc;
+        }
+        ctx->xf_dirty.clear();
+        ctx->world_valid = false;
+    }
+    for (auto& p : ctx->pools) {
+        if (!p.bound)
+            continue;
+        if (p.need_full) {
+            if (!staged) {
+                GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                staged = true;
+            }
+            const size_t cap = std::max<size_t>(p.occupancy, 1);
+            GV_HIP(ctx, p.d_a.reserve(cap));
+            GV_HIP(ctx, p.d_b.reserve(cap));
+            GV_HIP(ctx, p.h_a.reserve(cap));
+            GV_HIP(ctx, p.h_b.reserve(cap));
+            if (p.occupancy) {
+                gather_meshes(ctx, p, 0, p.occupancy);
+                int rc = upload_meshes(ctx, p, 0, p.occupancy);
+                if (rc != GV_OK)
+                    return rc;
+            }
+            p.need_full = false;
+            p.dirty.clear();
+        } else if (p.dirty.any()) {
+            if (!staged) {
+                GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                staged = true;
+            }
+            const uint32_t lo = p.dirty.lo, hi = std::min(p.dirty.hi, p.occupancy);
+            if (lo < hi) {
+                gather_meshes(ctx, p, lo, hi);
+                int rc = upload_meshes(ctx, p, lo, hi);
+                if (rc != GV_OK)
+                    return rc;
+            }
+            p.dirty.clear();
+        }
+    }
+    return GV_OK;
+}
+
+TransformMirror xf_mirror(const GvCtx* ctx)
+{
+    TransformMirror m;
+    m.a = ctx->d_xa.ptr;
+    m.b = ctx->d_xb.ptr;
+    m.c = ctx->d_xc.ptr;
+    m.count = ctx->xf.occupancy;
+    m.max_depth = ctx->max_depth;
+    return m;
+}
+
+// Frustum(viewProj) (mesh.cpp:815,867,869,900,902) — host side, once per view: Gribb-Hartmann rows of
+// the column-major matrix for a [0,1] clip depth, normalised; degenerate planes (|n|^2 < 1e-12, the
+// z >= 0 plane of the infinite reversed-Z projection) are dropped. DESIGN.md §"Canonical arithmetic".
+void build_view_params(const GvView& v, ViewParams* out)
+{
+    float row[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++)
+            row[r][c] = v.view_proj[c * 4 + r];
+    float p[6][4];
+    for (int c = 0; c < 4; c++) {
+        p[0][c] = row[3][c] + row[0][c];
+        p[1][c] = row[3][c] - row[0][c];
+        p[2][c] = row[3][c] + row[1][c];
+        p[3][c] = row[3][c] - row[1][c];
+        p[4][c] = row[2][c];
+        p[5][c] = row[3][c] - row[2][c];
+    }
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 6; i++) {
+        const float len2 = std::fmaf(p[i][2], p[i][2], std::fmaf(p[i][1], p[i][1], p[i][0] * p[i][0]));
+        if (!(len2 >= 1e-12f))
+            continue;
+        const float inv = 1.0f / std::sqrt(len2);
+        float* q = out->planes[out->plane_count++];
+        for (int c = 0; c < 4; c++)
+            q[c] = p[i][c] * inv;
+    }
+    for (int c = 0; c < 3; c++) {
+        out->cam[c] = v.camera_position[c];
+        out->cam_offset[c] = v.camera_offset[c];
+    }
+    memcpy(out->vp, v.view_proj, sizeof(out->vp));
+    out->write_is_visible = v.shadow_pass < 0 ? 1u : 0u;  // isNotShadowPass  mesh.cpp:121
+    out->use_hiz = v.use_hiz ? 1u : 0u;
+    out->distance_2d = v.distance_2d ? 1u : 0u;
+}
+
+int reserve_view(GvCtx* ctx, ViewState& vs, uint32_t occupancy, bool emit)
+{
+    const size_t n = std::max<uint32_t>(occupancy, 1);
+    const size_t blocks = (n + kCullBlock - 1) / kCullBlock;
+    GV_HIP(ctx, vs.mask.reserve(blocks * (kCullBlock / 64)));
+    GV_HIP(ctx, vs.block_count.reserve(blocks));
+    GV_HIP(ctx, vs.block_offset.reserve(blocks));
+    GV_HIP(ctx, vs.draw_count.reserve(4));
+    GV_HIP(ctx, vs.is_visible.reserve(n));
+    GV_HIP(ctx, vs.h_draw_count.reserve(4));
+    if (emit) {
+        GV_HIP(ctx, vs.visible_idx.reserve(n));
+        GV_HIP(ctx, vs.baked_model.reserve(n * 12));
+        GV_HIP(ctx, vs.distance_sq.reserve(n));
+    }
+    return GV_OK;
+}
+
+ViewBuffers view_buffers(ViewState& vs)
+{
+    ViewBuffers b;
+    b.mask = vs.mask.ptr;
+    b.block_count = vs.block_count.ptr;
+    b.block_offset = vs.block_offset.ptr;
+    b.draw_count = vs.draw_count.ptr;
+    b.is_visible = vs.is_visible.ptr;
+    b.visible_idx = vs.visible_idx.ptr;
+    b.baked_model = vs.baked_model.ptr;
+    b.distance_sq = vs.distance_sq.ptr;
+    return b;
+}
+
+int hiz_reduce(GvCtx* ctx)
+{
+    KernelTimer timer(ctx, GV_K_HIZ);
+    uint32_t k = 1;
+    while (k < ctx->hiz_mips) {
+        const uint32_t sw = ctx->mip_w[k - 1], sh = ctx->mip_h[k - 1];
+        const float* src_d = k == 1 ? ctx->depth_ptr : nullptr;
+        const float2* src_p = k == 1 ? nullptr : ctx->d_mips.ptr + ctx->mip_off[k - 1];
+        if (sw % 64 == 0 && sh % 64 == 0 && k + 5 < ctx->hiz_mips) {
+            HizFusedDst dst;
+            for (int l = 0; l < 6; l++)
+                dst.level[l] = ctx->d_mips.ptr + ctx->mip_off[k + l];
+            GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, ctx->stream));
+            k += 6;
+        } else {
+            GV_HIP(ctx, launch_hiz_level(src_d, src_p, ctx->d_mips.ptr + ctx->mip_off[k], sw, sh, ctx->mip_w[k],
+                                         ctx->mip_h[k], ctx->config.hiz_rule, ctx->stream));
+            k += 1;
+        }
+    }
+    return GV_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+uint32_t gv_abi_version(void) { return GV_ABI_VERSION; }
+
+const char* gv_last_error(const GvCtx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int gv_create(const GvConfig* config, GvCtx** out_ctx)
+{
+    if (!out_ctx) {
+        g_create_error = "gv_create: out_ctx is NULL";
+        return GV_E_ARG;
+    }
+    *out_ctx = nullptr;
+    GvConfig cfg{};
+    cfg.struct_size = sizeof(GvConfig);
+    if (config) {
+        if (config->struct_size != sizeof(GvConfig)) {
+            g_create_error = "gv_create: GvConfig.struct_size mismatch (ABI)";
+            return GV_E_ARG;
+        }
+        cfg = *config;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("gv_create: no HIP device (") + hipGetErrorString(e) +
+                         "); libgarden_vis has no CPU fallback";
+        return GV_E_NODEVICE;
+    }
+    if (cfg.device < 0 || cfg.device >= count) {
+        g_create_error = "gv_create: device ordinal out of range";
+        return GV_E_ARG;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg.device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return GV_E_HIP;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("gv_create: device is ") + prop.gcnArchName +
+                         ", kernels are built for gfx950 only (no fallback)";
+        return GV_E_NODEVICE;
+    }
+    GvCtx* ctx = new (std::nothrow) GvCtx();
+    if (!ctx) {
+        g_create_error = "gv_create: out of host memory";
+        return GV_E_OOM;
+    }
+    ctx->config = cfg;
+    ctx->device = cfg.device;
+    if ((e = hipSetDevice(cfg.device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("gv_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return GV_E_HIP;
+    }
+    *out_ctx = ctx;
+    return GV_OK;
+}
+
+void gv_destroy(GvCtx* ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    drain_events(ctx);
+    for (auto& ev : ctx->free_events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release();
+    ctx->h_xa.release(); ctx->h_xb.release(); ctx->h_xc.release();
+    for (auto& p : ctx->pools) {
+        p.d_a.release(); p.d_b.release(); p.h_a.release(); p.h_b.release();
+    }
+    for (auto& v : ctx->views) {
+        v.mask.release(); v.block_count.release(); v.block_offset.release(); v.draw_count.release();
+        v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
+        v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
+        v.h_distance_sq.release(); v.h_is_visible.release();
+    }
+    ctx->d_world.release();
+    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release();
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int gv_transform_bind(GvCtx* ctx, const void* base, size_t stride, uint32_t occupancy,
+                      const GvTransformLayout* layout, const uint32_t* entity_to_transform,
+                      uint32_t entity_capacity)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!layout || (occupancy && !base) || (entity_capacity && !entity_to_transform))
+        return ctx->fail(GV_E_ARG, "gv_transform_bind: NULL argument");
+    if (occupancy >= kSlotNone)
+        return ctx->fail(GV_E_ARG, "gv_transform_bind: occupancy %u exceeds the 28-bit slot range", occupancy);
+    const uint32_t need = std::max({layout->position, layout->scale, layout->rotation}) + 16u;
+    if (occupancy && stride < need)
+        return ctx->fail(GV_E_ARG, "gv_transform_bind: stride %zu smaller than layout (%u)", stride, need);
+    const bool moved = !ctx->xf.bound || ctx->xf.occupancy != occupancy;
+    ctx->xf.base = static_cast<const uint8_t*>(base);
+    ctx->xf.stride = stride;
+    ctx->xf.occupancy = occupancy;
+    ctx->xf.layout = *layout;
+    ctx->xf.entity_to_transform = entity_to_transform;
+    ctx->xf.entity_capacity = entity_capacity;
+    ctx->xf.bound = true;
+    if (moved)
+        ctx->xf_need_full = true;  // first bind or pool resized: rebuild the mirror
+    return GV_OK;
+}
+
+int gv_pool_bind(GvCtx* ctx, uint32_t pool_id, void* base, size_t stride, uint32_t occupancy,
+                 const GvMeshLayout* layout)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !layout || (occupancy && !base))
+        return ctx->fail(GV_E_ARG, "gv_pool_bind: bad argument (pool_id %u)", pool_id);
+    if (occupancy >= kSlotNone)
+        return ctx->fail(GV_E_ARG, "gv_pool_bind: occupancy %u exceeds the 28-bit slot range", occupancy);
+    const uint32_t need = std::max(layout->aabb_min, layout->aabb_max) + 12u;
+    if (occupancy && stride < need)
+        return ctx->fail(GV_E_ARG, "gv_pool_bind: stride %zu smaller than layout (%u)", stride, need);
+    PoolState& p = ctx->pools[pool_id];
+    const bool moved = !p.bound || p.occupancy != occupancy;
+    p.base = static_cast<uint8_t*>(base);
+    p.stride = stride;
+    p.occupancy = occupancy;
+    p.layout = *layout;
+    p.bound = true;
+    if (moved)
+        p.need_full = true;
+    return GV_OK;
+}
+
+int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    switch (kind) {
+    case GV_DIRTY_TRANSFORM:
+        ctx->xf_dirty.add(first, count);
+        return GV_OK;
+    case GV_DIRTY_HIERARCHY:
+        ctx->xf_need_full = true;
+        return GV_OK;
+    case GV_DIRTY_MESH: {
+        const uint32_t pool = first >> 28, lo = first & kSlotMask;
+        if (pool >= GV_MAX_POOLS)
+            return ctx->fail(GV_E_ARG, "gv_mark_dirty: pool id %u", pool);
+        ctx->pools[pool].dirty.add(lo, count);
+        return GV_OK;
+    }
+    default:
+        return ctx->fail(GV_E_ARG, "gv_mark_dirty: unknown kind %u", kind);
+    }
+}
+
+int gv_hierarchy_rebuild(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    ctx->xf_need_full = true;
+    return sync_mirror(ctx);
+}
+
+int gv_sync(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    return sync_mirror(ctx);
+}
+
+int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !views || view_count == 0 || view_count > GV_MAX_VIEWS)
+        return ctx->fail(GV_E_ARG, "gv_cull: bad argument (pool %u, %u views)", pool_id, view_count);
+    PoolState& p = ctx->pools[pool_id];
+    if (!p.bound || !ctx->xf.bound)
+        return ctx->fail(GV_E_STATE, "gv_cull: pools not bound");
+    int rc = sync_mirror(ctx);
+    if (rc != GV_OK)
+        return rc;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.occupancy};
+    const TransformMirror xf = xf_mirror(ctx);
+    HizDevice hz{};
+    for (uint32_t v = 0; v < view_count; v++) {
+        if (views[v].use_hiz && !ctx->hiz_valid)
+            return ctx->fail(GV_E_STATE, "gv_cull: view %u asks for Hi-Z but gv_hiz_build has not run", v);
+    }
+    if (ctx->hiz_valid) {
+        hz.depth = ctx->depth_ptr;
+        hz.mips = ctx->d_mips.ptr;
+        hz.mip_offset = ctx->d_mip_offset.ptr;
+        hz.width = ctx->hiz_w;
+        hz.height = ctx->hiz_h;
+        hz.mip_count = ctx->hiz_mips;
+    }
+    for (uint32_t v = 0; v < view_count; v++) {
+        ViewState& vs = ctx->views[v];
+        const bool emit = views[v].emit_records != 0;
+        rc = reserve_view(ctx, vs, p.occupancy, emit);
+        if (rc != GV_OK)
+            return rc;
+        vs.pool_id = pool_id;
+        vs.occupancy = p.occupancy;
+        vs.main_pass = views[v].shadow_pass < 0;
+        vs.emitted = emit;
+        vs.valid = true;
+        ViewParams vp;
+        build_view_params(views[v], &vp);
+        const ViewBuffers vb = view_buffers(vs);
+        const uint32_t blocks = (p.occupancy + kCullBlock - 1) / kCullBlock;
+        if (p.occupancy == 0) {
+            GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
+            continue;
+        }
+        {
+            KernelTimer t(ctx, GV_K_CULL);
+            GV_HIP(ctx, launch_cull(mesh, xf, hz, vp, vb, ctx->stream));
+        }
+        {
+            KernelTimer t(ctx, GV_K_SCAN);
+            GV_HIP(ctx, launch_scan(vb, blocks, ctx->stream));
+        }
+        if (emit) {
+            KernelTimer t(ctx, GV_K_EMIT);
+            GV_HIP(ctx, launch_emit(mesh, xf, vp, vb, ctx->stream));
+        }
+    }
+    for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
+        ctx->views[v].valid = false;
+    return GV_OK;
+}
+
+int gv_wait(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    return GV_OK;
+}
+
+int gv_result_count(GvCtx* ctx, uint32_t view_index, uint32_t* draw_count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (view_index >= GV_MAX_VIEWS || !draw_count || !ctx->views[view_index].valid)
+        return ctx->fail(GV_E_ARG, "gv_result_count: view %u has no results", view_index);
+    ViewState& vs = ctx->views[view_index];
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipMemcpyAsync(vs.h_draw_count.ptr, vs.draw_count.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    *draw_count = vs.h_draw_count.ptr[0];
+    return GV_OK;
+}
+
+int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* out)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!out)
+        return ctx->fail(GV_E_ARG, "gv_results_fetch: out is NULL");
+    uint32_t count = 0;
+    int rc = gv_result_count(ctx, view_index, &count);
+    if (rc != GV_OK)
+        return rc;
+    ViewState& vs = ctx->views[view_index];
+    memset(out, 0, sizeof(*out));
+    out->draw_count = vs.emitted ? count : count;
+    out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)
+    if (vs.emitted && count) {
+        GV_HIP(ctx, vs.h_visible_idx.reserve(vs.occupancy));
+        GV_HIP(ctx, vs.h_baked_model.reserve((size_t)vs.occupancy * 12));
+        GV_HIP(ctx, vs.h_distance_sq.reserve(vs.occupancy));
+        GV_HIP(ctx, hipMemcpyAsync(vs.h_visible_idx.ptr, vs.visible_idx.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(vs.h_baked_model.ptr, vs.baked_model.ptr, (size_t)count * 48, hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(vs.h_distance_sq.ptr, vs.distance_sq.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (vs.main_pass && vs.occupancy) {
+        GV_HIP(ctx, vs.h_is_visible.reserve(vs.occupancy));
+        GV_HIP(ctx, hipMemcpyAsync(vs.h_is_visible.ptr, vs.is_visible.ptr, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (vs.emitted && count) {
+        out->visible_idx = vs.h_visible_idx.ptr;
+        out->baked_model = vs.h_baked_model.ptr;
+        out->distance_sq = vs.h_distance_sq.ptr;
+    }
+    if (vs.main_pass && vs.occupancy) {
+        out->is_visible = vs.h_is_visible.ptr;
+        if (write_back) {  // meshRenderView->isVisible = ...  mesh.cpp:144,152,161,166
+            PoolState& p = ctx->pools[vs.pool_id];
+            if (!p.bound || p.occupancy != vs.occupancy)
+                return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u rebound since gv_cull", vs.pool_id);
+            const uint8_t* src = vs.h_is_visible.ptr;
+            parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
+                for (uint32_t i = a; i < b; i++)
+                    p.base[(size_t)i * p.stride + p.layout.is_visible] = src[i];
+            });
+        }
+    }
+    return GV_OK;
+}
+
+int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (view_index >= GV_MAX_VIEWS || !out || !ctx->views[view_index].valid)
+        return ctx->fail(GV_E_ARG, "gv_results_device: view %u has no results", view_index);
+    ViewState& vs = ctx->views[view_index];
+    out->visible_idx = vs.emitted ? vs.visible_idx.ptr : nullptr;
+    out->baked_model = vs.emitted ? vs.baked_model.ptr : nullptr;
+    out->distance_sq = vs.emitted ? vs.distance_sq.ptr : nullptr;
+    out->is_visible = vs.main_pass ? vs.is_visible.ptr : nullptr;
+    out->draw_count = vs.draw_count.ptr;
+    return GV_OK;
+}
+
+int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
+                               uint32_t index_base)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
+        return ctx->fail(GV_E_ARG, "gv_results_copy_idx_device: view %u has no emitted records", view_index);
+    ViewState& vs = ctx->views[view_index];
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, launch_copy_idx(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
+                                index_base, ctx->stream));
+    return GV_OK;
+}
+
+int gv_sweep(GvCtx* ctx, uint32_t mode)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (mode != GV_SWEEP_VALU && mode != GV_SWEEP_MFMA)
+        return ctx->fail(GV_E_ARG, "gv_sweep: unknown mode %u", mode);
+    int rc = sync_mirror(ctx);
+    if (rc != GV_OK)
+        return rc;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->xf.occupancy;
+    GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(n, 1u) * 3));
+    {
+        KernelTimer t(ctx, GV_K_SWEEP);
+        if (mode == GV_SWEEP_MFMA)
+            GV_HIP(ctx, launch_sweep_mfma(xf_mirror(ctx), ctx->d_world.ptr, ctx->stream));
+        else
+            GV_HIP(ctx, launch_sweep_valu(xf_mirror(ctx), ctx->d_world.ptr, ctx->stream));
+    }
+    ctx->world_valid = true;
+    return GV_OK;
+}
+
+int gv_get_world(GvCtx* ctx, uint32_t first, uint32_t count, float* out12)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->world_valid)
+        return ctx->fail(GV_E_STATE, "gv_get_world: gv_sweep has not run since the last transform change");
+    if (!out12 || (uint64_t)first + count > ctx->xf.occupancy)
+        return ctx->fail(GV_E_ARG, "gv_get_world: range [%u, +%u) outside the pool", first, count);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipMemcpyAsync(out12, ctx->d_world.ptr + (size_t)first * 3, (size_t)count * 48, hipMemcpyDeviceToHost, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    return GV_OK;
+}
+
+int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height, uint32_t mem_kind)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!depth || width == 0 || height == 0 || width > 32768 || height > 32768)
+        return ctx->fail(GV_E_ARG, "gv_hiz_build: bad depth image %ux%u", width, height);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    // calcMipCount(frameSize) hiz.cpp:27; sizes max(size / 2, 1) hiz.cpp:55
+    uint32_t mips = 0;
+    for (uint32_t m = std::max(width, height); m; m >>= 1)
+        mips++;
+    if (mips > GV_MAX_MIPS)
+        return ctx->fail(GV_E_ARG, "gv_hiz_build: %u mips exceed GV_MAX_MIPS", mips);
+    uint64_t off = 0;
+    uint32_t cw = width, ch = height;
+    for (uint32_t k = 0; k < mips; k++) {
+        ctx->mip_w[k] = cw;
+        ctx->mip_h[k] = ch;
+        ctx->mip_off[k] = off;
+        if (k >= 1)
+            off += (uint64_t)cw * ch;
+        cw = std::max(cw / 2, 1u);
+        ch = std::max(ch / 2, 1u);
+    }
+    ctx->hiz_w = width;
+    ctx->hiz_h = height;
+    ctx->hiz_mips = mips;
+    GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>(off, 1)));
+    GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_mip_offset.ptr, ctx->mip_off, sizeof(uint64_t) * GV_MAX_MIPS, hipMemcpyHostToDevice, ctx->stream));
+    if (mem_kind == GV_MEM_DEVICE) {
+        ctx->depth_ptr = depth;
+    } else {
+        GV_HIP(ctx, ctx->d_depth.reserve((size_t)width * height));
+        GV_HIP(ctx, hipMemcpyAsync(ctx->d_depth.ptr, depth, (size_t)width * height * 4, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's (pageable) buffer may go away
+        ctx->depth_ptr = ctx->d_depth.ptr;
+    }
+    ctx->hiz_valid = true;
+    return hiz_reduce(ctx);
+}
+
+int gv_hiz_rebuild(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->hiz_valid)
+        return ctx->fail(GV_E_STATE, "gv_hiz_rebuild: no depth image resident");
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    return hiz_reduce(ctx);
+}
+
+int gv_hiz_mip_count(GvCtx* ctx, uint32_t* mip_count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->hiz_valid || !mip_count)
+        return ctx->fail(GV_E_STATE, "gv_hiz_mip_count: no pyramid");
+    *mip_count = ctx->hiz_mips;
+    return GV_OK;
+}
+
+int gv_hiz_read_level(GvCtx* ctx, uint32_t level, float* out_pairs, uint32_t* w, uint32_t* h)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->hiz_valid)
+        return ctx->fail(GV_E_STATE, "gv_hiz_read_level: no pyramid");
+    if (level == 0 || level >= ctx->hiz_mips || !out_pairs)
+        return ctx->fail(GV_E_ARG, "gv_hiz_read_level: level %u (valid 1..%u)", level, ctx->hiz_mips - 1);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->mip_w[level] * ctx->mip_h[level];
+    GV_HIP(ctx, hipMemcpyAsync(out_pairs, ctx->d_mips.ptr + ctx->mip_off[level], n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    if (w)
+        *w = ctx->mip_w[level];
+    if (h)
+        *h = ctx->mip_h[level];
+    return GV_OK;
+}
+
+int gv_stats(GvCtx* ctx, GvStats* out)
+{
+    if (!ctx || !out)
+        return GV_E_ARG;
+    if (!ctx->pending.empty()) {
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        drain_events(ctx);
+    }
+    ctx->stats.max_depth = ctx->max_depth;
+    ctx->stats.transform_count = ctx->xf.occupancy;
+    for (uint32_t i = 0; i < GV_MAX_POOLS; i++)
+        ctx->stats.mesh_count[i] = ctx->pools[i].bound ? ctx->pools[i].occupancy : 0;
+    *out = ctx->stats;
+    return GV_OK;
+}
+
+int gv_stats_reset(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->pending.empty()) {
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        drain_events(ctx);
+    }
+    memset(ctx->stats.launches, 0, sizeof(ctx->stats.launches));
+    memset(ctx->stats.device_ms, 0, sizeof(ctx->stats.device_ms));
+    ctx->stats.upload_bytes = 0;
+    return GV_OK;
+}
+
+void* gv_stream(GvCtx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+}  // extern "C"

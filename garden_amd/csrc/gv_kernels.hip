@@ -1,0 +1,621 @@
+// gv_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the visibility pass.
+//
+//   cull_kernel   replaces the body of prepareUnsortedMeshes / prepareSortedMeshes
+//                 (source/system/render/mesh.cpp:137-175 / :213-253): filters, parent-chain model
+//                 (include/garden/system/transform.hpp:197-214), 8-corner frustum test
+//                 (render/mesh.hpp:142-146), optional Hi-Z occlusion query (build-defined), wave ballot.
+//   scan_kernel + emit_kernel   replace drawCount.fetch_add + memcpy into combinedMeshes
+//                 (mesh.cpp:177-183) with an order-stable compaction (ballot words + block prefix).
+//   sweep_*       TransformComponent::calcModel() for every transform slot (transform.hpp:197-214);
+//                 the MFMA form runs the 4x4 chain on v_mfma_f32_4x4x1_16b_f32.
+//   hiz_*         HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167) with the
+//                 reduction rule of shaders/hiz.frag:23-63.
+//
+// All of it is HBM-bound streaming (DESIGN.md has bytes/entity per kernel); loads are 16- or 12-byte
+// per lane over SoA streams so each wave-instruction touches 1 KiB / 768 B contiguous.
+#include "gv_kernels.hpp"
+
+#include "gv_device_math.hpp"
+
+namespace gv {
+
+// ------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Mat34 load_local_model(const TransformMirror& xf, uint32_t s, uint32_t& link)
+{
+    const float4 a = xf.a[s];
+    const float4 b = xf.b[s];
+    const float3 c = xf.c[s];
+    link = __float_as_uint(c.z);
+    return calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
+}
+
+// transform.hpp:197-214: model = calcModel(self); while (parent) model = calcModel(parent) * model.
+// `m`/`link` are the already-loaded self model and link word of the starting slot.
+__device__ __forceinline__ Mat34 chain_model(const TransformMirror& xf, Mat34 m, uint32_t link)
+{
+    if (link & kXfWithAncestors) {
+        uint32_t p = link & kSlotMask;
+        for (uint32_t d = 0; d < xf.max_depth && p != kSlotNone; d++) {
+            uint32_t plink;
+            const Mat34 pm = load_local_model(xf, p, plink);
+            m = mul_affine(pm, m);
+            p = plink & kSlotMask;
+        }
+    }
+    return m;
+}
+
+// XCD-aware workgroup order: hardware deals blocks round-robin over the 8 XCDs, so give each XCD one
+// contiguous eighth of the slot range (neighbouring blocks share ancestor lines in that XCD's L2).
+// Speed only; any placement is correct. Returns the logical block, or >= nblocks for padding blocks.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t per_xcd)
+{
+    return (bid & 7u) * per_xcd + (bid >> 3);
+}
+
+__device__ __forceinline__ float hiz_min_texel(const HizDevice& hz, uint32_t level, uint32_t lw, uint32_t x, uint32_t y)
+{
+    if (level == 0)
+        return hz.depth[(size_t)y * hz.width + x];
+    return hz.mips[hz.mip_offset[level] + (uint64_t)y * lw + x].x;
+}
+
+__device__ __forceinline__ float clamp01(float a)
+{
+    return a > 0.0f ? (a < 1.0f ? a : 1.0f) : 0.0f;
+}
+
+// Build-defined occlusion query (SURVEY.md §8a-7'; the reference has none). Returns true if occluded.
+__device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&vp)[16], const Corners& c)
+{
+    float umin = 0, umax = 0, vmin = 0, vmax = 0, znear = 0;
+    bool bounded = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float clx = fmaf(vp[0], c.x[k], fmaf(vp[4], c.y[k], fmaf(vp[8], c.z[k], vp[12])));
+        const float cly = fmaf(vp[1], c.x[k], fmaf(vp[5], c.y[k], fmaf(vp[9], c.z[k], vp[13])));
+        const float clz = fmaf(vp[2], c.x[k], fmaf(vp[6], c.y[k], fmaf(vp[10], c.z[k], vp[14])));
+        const float clw = fmaf(vp[3], c.x[k], fmaf(vp[7], c.y[k], fmaf(vp[11], c.z[k], vp[15])));
+        bounded = bounded && (clw > 0.0f);
+        const float rcp = 1.0f / clw;  // IEEE-correct division (-fhip-fp32-correctly-rounded-divide-sqrt)
+        const float u = fmaf(clx * rcp, 0.5f, 0.5f);
+        const float v = fmaf(cly * rcp, 0.5f, 0.5f);
+        const float zc = clz * rcp;
+        if (k == 0) {
+            umin = umax = u;
+            vmin = vmax = v;
+            znear = zc;
+        } else {
+            umin = u < umin ? u : umin;
+            umax = u > umax ? u : umax;
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+            znear = zc > znear ? zc : znear;
+        }
+    }
+    if (!bounded)
+        return false;
+    umin = clamp01(umin);
+    umax = clamp01(umax);
+    vmin = clamp01(vmin);
+    vmax = clamp01(vmax);
+    const int W = (int)hz.width, H = (int)hz.height;
+    int ix0 = (int)(umin * (float)W), ix1 = (int)(umax * (float)W);
+    int iy0 = (int)(vmin * (float)H), iy1 = (int)(vmax * (float)H);
+    ix0 = min(ix0, W - 1);
+    ix1 = min(ix1, W - 1);
+    iy0 = min(iy0, H - 1);
+    iy1 = min(iy1, H - 1);
+    uint32_t level = 0;
+    while (level + 1 < hz.mip_count &&
+           (((ix1 >> level) - (ix0 >> level)) > 1 || ((iy1 >> level) - (iy0 >> level)) > 1))
+        level++;
+    const int lw = max((int)(hz.width >> level), 1), lh = max((int)(hz.height >> level), 1);
+    const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
+    const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
+    float zfar = hiz_min_texel(hz, level, lw, tx0, ty0);
+    float a = hiz_min_texel(hz, level, lw, tx1, ty0);
+    zfar = a < zfar ? a : zfar;
+    a = hiz_min_texel(hz, level, lw, tx0, ty1);
+    zfar = a < zfar ? a : zfar;
+    a = hiz_min_texel(hz, level, lw, tx1, ty1);
+    zfar = a < zfar ? a : zfar;
+    return znear < zfar;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: cull — one lane per mesh slot
+// ------------------------------------------------------------------------------------------------
+struct CullArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    HizDevice hiz;
+    ViewParams view;
+    ViewBuffers out;
+    uint32_t nblocks;
+    uint32_t per_xcd;
+};
+
+__global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
+{
+    const uint32_t lb = xcd_block(blockIdx.x, args.per_xcd);
+    if (lb >= args.nblocks)
+        return;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    bool visible = false;
+    if (i < args.mesh.count) {
+        const float4 ma = args.mesh.a[i];
+        const float3 mb = args.mesh.b[i];
+        const uint32_t mlink = __float_as_uint(mb.z);
+        const float mnx = ma.x, mny = ma.y, mnz = ma.z, mxx = ma.w, mxy = mb.x, mxz = mb.y;
+        // mesh.cpp:140-142: skip free slots, disabled meshes and all(size <= 0) boxes
+        const bool empty = (mxx - mnx <= 0.0f) && (mxy - mny <= 0.0f) && (mxz - mnz <= 0.0f);
+        const uint32_t slot = mlink & kSlotMask;
+        if ((mlink & kMeshCandidate) && !empty && slot != kSlotNone) {
+            uint32_t link;
+            Mat34 m = load_local_model(args.xf, slot, link);
+            if (link & kXfActive) {  // mesh.cpp:150, transform.hpp:110
+                m = chain_model(args.xf, m, link);
+                // math::translate(-cameraPosition, model)  transform.hpp:211,213
+                m.c3x = m.c3x - args.view.cam[0];
+                m.c3y = m.c3y - args.view.cam[1];
+                m.c3z = m.c3z - args.view.cam[2];
+                Corners c;
+                aabb_corners(m, mnx, mny, mnz, mxx, mxy, mxz, c);
+                bool behind = false;
+                for (uint32_t p = 0; p < args.view.plane_count; p++) {
+                    const float nx = args.view.planes[p][0], ny = args.view.planes[p][1];
+                    const float nz = args.view.planes[p][2], nw = args.view.planes[p][3];
+                    bool all_behind = true;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float d = fmaf(nx, c.x[k], fmaf(ny, c.y[k], fmaf(nz, c.z[k], nw)));
+                        all_behind = all_behind && (d < 0.0f);
+                    }
+                    behind = behind || all_behind;
+                }
+                visible = !behind;
+                if (visible && args.view.use_hiz)
+                    visible = !hiz_occluded(args.hiz, args.view.vp, c);
+            }
+        }
+        if (args.view.write_is_visible)
+            args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
+    }
+    const unsigned long long word = __ballot(visible);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ uint32_t wave_count[kCullBlock / 64];
+    if (lane == 0) {
+        args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+        wave_count[wave] = (uint32_t)__popcll(word);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCullBlock / 64; w++)
+            total += wave_count[w];
+        args.out.block_count[lb] = total;
+    }
+}
+
+hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                       const ViewBuffers& out, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    CullArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    a.view = vp;
+    a.out = out;
+    a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    a.per_xcd = (a.nblocks + 7) / 8;
+    hipLaunchKernelGGL(cull_kernel, dim3(a.per_xcd * 8), dim3(kCullBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: exclusive scan of the per-block visible counts (one workgroup; <= ~400k blocks at 10^8 slots)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const uint32_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ offsets,
+                                                          uint32_t* __restrict__ total, uint32_t n)
+{
+    __shared__ uint32_t wave_sum[kScanBlock / 64];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kScanBlock) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < n ? counts[idx] : 0u;
+        uint32_t incl = v;  // wave-level inclusive scan
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += up;
+        }
+        if (lane == 63)
+            wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (uint32_t w = 0; w < wave; w++)
+            wave_prefix += wave_sum[w];
+        const uint32_t carry = carry_s;
+        if (idx < n)
+            offsets[idx] = carry + wave_prefix + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1)
+            carry_s = carry + wave_prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *total = carry_s;
+}
+
+hipError_t launch_scan(const ViewBuffers& out, uint32_t block_count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, stream, out.block_count, out.block_offset,
+                       out.draw_count, block_count);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: emit — order-stable compaction of the records of visible slots (mesh.cpp:169-173)
+// ------------------------------------------------------------------------------------------------
+struct EmitArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    ViewParams view;
+    ViewBuffers out;
+    uint32_t nblocks;
+    uint32_t per_xcd;
+};
+
+__global__ __launch_bounds__(kCullBlock) void emit_kernel(const EmitArgs args)
+{
+    const uint32_t lb = xcd_block(blockIdx.x, args.per_xcd);
+    if (lb >= args.nblocks)
+        return;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long* words = args.out.mask + (size_t)lb * (kCullBlock / 64);
+    uint32_t rank = args.out.block_offset[lb];
+    for (uint32_t w = 0; w < wave; w++)
+        rank += (uint32_t)__popcll(words[w]);
+    const unsigned long long word = words[wave];
+    if (!((word >> lane) & 1ull))
+        return;
+    rank += (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
+    const float3 mb = args.mesh.b[i];
+    const uint32_t slot = __float_as_uint(mb.z) & kSlotMask;
+    uint32_t link;
+    Mat34 m = load_local_model(args.xf, slot, link);
+    m = chain_model(args.xf, m, link);
+    m.c3x = m.c3x - args.view.cam[0];
+    m.c3y = m.c3y - args.view.cam[1];
+    m.c3z = m.c3z - args.view.cam[2];
+    args.out.visible_idx[rank] = i;
+    float4* bm = reinterpret_cast<float4*>(args.out.baked_model + (size_t)rank * 12);
+    bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+    bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+    bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    const float tx = m.c3x + args.view.cam_offset[0];
+    const float ty = m.c3y + args.view.cam_offset[1];
+    const float tz = m.c3z + args.view.cam_offset[2];
+    args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+}
+
+hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
+                       hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    EmitArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.view = vp;
+    a.out = out;
+    a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    a.per_xcd = (a.nblocks + 7) / 8;
+    hipLaunchKernelGGL(emit_kernel, dim3(a.per_xcd * 8), dim3(kCullBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_idx_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
+                                                       uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+{
+    const uint32_t n = min(*count, capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = src[i] + base;
+}
+
+hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(copy_idx_kernel, dim3(2048), dim3(256), 0, stream, src, count, dst, capacity, base);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// world-matrix sweep (camera = 0), VALU form: one lane per transform slot
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror xf, float4* __restrict__ world,
+                                                         uint32_t nblocks, uint32_t per_xcd)
+{
+    const uint32_t lb = xcd_block(blockIdx.x, per_xcd);
+    if (lb >= nblocks)
+        return;
+    const uint32_t s = lb * 256 + threadIdx.x;
+    if (s >= xf.count)
+        return;
+    uint32_t link;
+    Mat34 m = load_local_model(xf, s, link);
+    float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
+    if (link & kXfLive) {
+        m = chain_model(xf, m, link);
+        w0 = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+        w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+        w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    }
+    world[(size_t)s * 3 + 0] = w0;
+    world[(size_t)s * 3 + 1] = w1;
+    world[(size_t)s * 3 + 2] = w2;
+}
+
+hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream)
+{
+    if (xf.count == 0)
+        return hipSuccess;
+    const uint32_t nblocks = (xf.count + 255) / 256, per_xcd = (nblocks + 7) / 8;
+    hipLaunchKernelGGL(sweep_valu_kernel, dim3(per_xcd * 8), dim3(256), 0, stream, xf, world, nblocks, per_xcd);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// world-matrix sweep, MFMA form: 4 lanes per transform slot, 16 slots per wave.
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per wave; block = lane >> 2; the A operand of
+// lane (block, i) is A[i][k], the B operand of lane (block, j) is B[k][j], D register r of lane
+// (block, j) is D[r][j]. Four issues k = 0..3 into one accumulator give parentModel * model with the
+// per-element order fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, +0)))) — the canonical chain. Lane j
+// therefore keeps column j of the running product in 4 registers, which is also its B operand for
+// the next ancestor: no lane movement between chain steps.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world,
+                                                         uint32_t nblocks, uint32_t per_xcd)
+{
+    const uint32_t lb = xcd_block(blockIdx.x, per_xcd);
+    if (lb >= nblocks)
+        return;
+    const uint32_t q = threadIdx.x & 3u;                     // column (as B/D) and row (as A) of this lane
+    const uint32_t s = lb * 64 + (threadIdx.x >> 2);         // 64 slots per 256-thread workgroup
+    const bool in_range = s < xf.count;
+    uint32_t link = 0;
+    Mat34 m = {};
+    if (in_range)
+        m = load_local_model(xf, s, link);
+    const bool live = in_range && (link & kXfLive);
+    // column q of the self model, with the bottom-row element
+    float x0 = q == 0 ? m.c0x : q == 1 ? m.c1x : q == 2 ? m.c2x : m.c3x;
+    float x1 = q == 0 ? m.c0y : q == 1 ? m.c1y : q == 2 ? m.c2y : m.c3y;
+    float x2 = q == 0 ? m.c0z : q == 1 ? m.c1z : q == 2 ? m.c2z : m.c3z;
+    float x3 = q == 3 ? 1.0f : 0.0f;
+    uint32_t p = (live && (link & kXfWithAncestors)) ? (link & kSlotMask) : kSlotNone;
+    for (uint32_t d = 0; d < xf.max_depth; d++) {
+        const bool has_parent = p != kSlotNone;
+        if (!__any(has_parent))
+            break;  // wave-uniform exit: MFMA ignores EXEC, so every lane takes every step
+        uint32_t plink = kSlotNone;
+        Mat34 pm = {};
+        if (has_parent)
+            pm = load_local_model(xf, p, plink);
+        // row q of the parent's local model: A[q][k], k = 0..3
+        const float a0 = q == 0 ? pm.c0x : q == 1 ? pm.c0y : q == 2 ? pm.c0z : 0.0f;
+        const float a1 = q == 0 ? pm.c1x : q == 1 ? pm.c1y : q == 2 ? pm.c1z : 0.0f;
+        const float a2 = q == 0 ? pm.c2x : q == 1 ? pm.c2y : q == 2 ? pm.c2z : 0.0f;
+        const float a3 = q == 0 ? pm.c3x : q == 1 ? pm.c3y : q == 2 ? pm.c3z : 1.0f;
+        f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, x1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, x2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, x3, acc, 0, 0, 0);
+        // lanes whose chain has ended keep their product untouched (bit-exact, incl. -0)
+        x0 = has_parent ? acc[0] : x0;
+        x1 = has_parent ? acc[1] : x1;
+        x2 = has_parent ? acc[2] : x2;
+        x3 = has_parent ? acc[3] : x3;
+        p = has_parent ? (plink & kSlotMask) : kSlotNone;
+    }
+    if (in_range) {
+        // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per wave
+        float* dst = world + (size_t)s * 12 + q * 3;
+        dst[0] = live ? x0 : 0.0f;
+        dst[1] = live ? x1 : 0.0f;
+        dst[2] = live ? x2 : 0.0f;
+    }
+}
+
+hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream)
+{
+    if (xf.count == 0)
+        return hipSuccess;
+    const uint32_t nblocks = (xf.count + 63) / 64, per_xcd = (nblocks + 7) / 8;
+    hipLaunchKernelGGL(sweep_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, stream, xf, reinterpret_cast<float*>(world),
+                       nblocks, per_xcd);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hi-Z pyramid
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 hiz_src(const float* d, const float2* p, uint32_t sw, uint32_t x, uint32_t y)
+{
+    if (d) {  // HIZ_VARIANT_FIRST: (d, d)  hiz.frag:57-60
+        const float v = d[(size_t)y * sw + x];
+        return make_float2(v, v);
+    }
+    return p[(size_t)y * sw + x];
+}
+__device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
+{
+    mm.x = t.x < mm.x ? t.x : mm.x;  // MIN_DEPTH  depth.gsl:30-31
+    mm.y = t.y > mm.y ? t.y : mm.y;  // MAX_DEPTH  depth.gsl:32-33
+}
+
+// One destination texel per lane; any size (hiz.frag:27-56 with the odd-size branches).
+__global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict__ src_depth,
+                                                        const float2* __restrict__ src_pairs,
+                                                        float2* __restrict__ dst, uint32_t sw, uint32_t sh, uint32_t dw,
+                                                        uint32_t dh, uint32_t rule)
+{
+    const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63u);
+    const uint32_t py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= dw || py >= dh)
+        return;
+    const bool odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0;
+    const uint32_t x0 = 2 * px, y0 = 2 * py;
+    const uint32_t x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const uint32_t x2 = min(x0 + 2, sw - 1), y2 = min(y0 + 2, sh - 1);
+    float2 mm = hiz_src(src_depth, src_pairs, sw, x0, y0);
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y0));
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y1));
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y1));
+    if (odd_x) {  // hiz.frag:36-41
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y1));
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y0));
+        if (odd_y)  // hiz.frag:43-47
+            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y2));
+    }
+    if (odd_y) {  // hiz.frag:49-55 reads gather components .y/.z = (2p.x+1, 2p.y+2), (2p.x+1, 2p.y+1)
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y2));
+        if (rule == 1u)  // GV_HIZ_RULE_CONSERVATIVE: the whole extra row
+            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y2));
+    }
+    dst[(size_t)py * dw + px] = mm;
+}
+
+hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
+                            uint32_t dw, uint32_t dh, uint32_t rule, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hiz_level_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, stream, src_depth, src_pairs,
+                       dst, sw, sh, dw, dh, rule);
+    return hipGetLastError();
+}
+
+// Fused: one workgroup reduces a 64x64 source tile to 32^2, 16^2, 8^2, 4^2, 2^2 and 1 texel — six
+// levels in one pass, the source read once, intermediate levels staged in LDS instead of re-read
+// from HBM (the reference re-reads every mip in its own render pass, hiz.cpp:155-164).
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict__ src_depth,
+                                                        const float2* __restrict__ src_pairs, const HizFusedDst dst,
+                                                        uint32_t sw, uint32_t sh)
+{
+    __shared__ float2 lds16[16][17];
+    __shared__ float2 lds8[8][9];
+    __shared__ float2 lds4[4][5];
+    __shared__ float2 lds2[2][3];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t ox = blockIdx.x * 64, oy = blockIdx.y * 64;
+    const uint32_t px = ox + 4 * tx, py = oy + 4 * ty;
+    float mn[4][4], mx[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (PAIRS) {
+            const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
+            const float4 lo = row[0], hi = row[1];
+            mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
+            mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px);
+            mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
+            mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
+        }
+    }
+    // level +1: 2x2 texels per lane
+    float2 q[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            float2 mm = make_float2(mn[2 * a][2 * b], mx[2 * a][2 * b]);
+            hiz_acc(mm, make_float2(mn[2 * a][2 * b + 1], mx[2 * a][2 * b + 1]));
+            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b], mx[2 * a + 1][2 * b]));
+            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b + 1], mx[2 * a + 1][2 * b + 1]));
+            q[a][b] = mm;
+        }
+    const uint32_t w1 = sw >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        float4* o = reinterpret_cast<float4*>(dst.level[0] + (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx);
+        *o = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
+    }
+    // level +2: one texel per lane
+    float2 m2 = q[0][0];
+    hiz_acc(m2, q[0][1]);
+    hiz_acc(m2, q[1][0]);
+    hiz_acc(m2, q[1][1]);
+    dst.level[1][(size_t)(oy / 4 + ty) * (sw >> 2) + ox / 4 + tx] = m2;
+    lds16[ty][tx] = m2;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // level +3: 8x8
+        const uint32_t x = threadIdx.x & 7u, y = threadIdx.x >> 3;
+        float2 mm = lds16[2 * y][2 * x];
+        hiz_acc(mm, lds16[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds16[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds16[2 * y + 1][2 * x + 1]);
+        dst.level[2][(size_t)(oy / 8 + y) * (sw >> 3) + ox / 8 + x] = mm;
+        lds8[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {  // level +4: 4x4
+        const uint32_t x = threadIdx.x & 3u, y = threadIdx.x >> 2;
+        float2 mm = lds8[2 * y][2 * x];
+        hiz_acc(mm, lds8[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds8[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds8[2 * y + 1][2 * x + 1]);
+        dst.level[3][(size_t)(oy / 16 + y) * (sw >> 4) + ox / 16 + x] = mm;
+        lds4[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {  // level +5: 2x2
+        const uint32_t x = threadIdx.x & 1u, y = threadIdx.x >> 1;
+        float2 mm = lds4[2 * y][2 * x];
+        hiz_acc(mm, lds4[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds4[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds4[2 * y + 1][2 * x + 1]);
+        dst.level[4][(size_t)(oy / 32 + y) * (sw >> 5) + ox / 32 + x] = mm;
+        lds2[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // level +6: 1 texel
+        float2 mm = lds2[0][0];
+        hiz_acc(mm, lds2[0][1]);
+        hiz_acc(mm, lds2[1][0]);
+        hiz_acc(mm, lds2[1][1]);
+        dst.level[5][(size_t)(oy / 64) * (sw >> 6) + ox / 64] = mm;
+    }
+    (void)sh;
+}
+
+hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
+                            uint32_t sh, hipStream_t stream)
+{
+    const dim3 grid(sw / 64, sh / 64);
+    if (src_depth)
+        hipLaunchKernelGGL(hiz_fused_kernel<false>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    else
+        hipLaunchKernelGGL(hiz_fused_kernel<true>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    return hipGetLastError();
+}
+
+}  // namespace gv

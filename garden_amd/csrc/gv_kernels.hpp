@@ -1,0 +1,85 @@
+// gv_kernels.hpp — host-visible launch interface of the gfx950 kernels (internal to libgarden_vis).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gv {
+
+// ---- device mirror of the component pools (HBM layout, DESIGN.md §"Data layout") ----
+// 28-bit slot + 4 flag bits packed in the third float of the 12-byte streams.
+constexpr uint32_t kSlotMask = 0x0FFFFFFFu;
+constexpr uint32_t kSlotNone = 0x0FFFFFFFu;
+constexpr uint32_t kXfActive = 1u << 28;         // selfActive && ancestorsActive (transform.hpp:110)
+constexpr uint32_t kXfWithAncestors = 1u << 29;  // modelWithAncestors (transform.hpp:60)
+constexpr uint32_t kXfLive = 1u << 30;           // entity != 0
+constexpr uint32_t kMeshCandidate = 1u << 28;    // entity != 0 && isEnabled (mesh.cpp:142)
+
+struct TransformMirror {
+    const float4* a;  // (pos.x, pos.y, pos.z, scale.x)
+    const float4* b;  // quat xyzw
+    const float3* c;  // (scale.y, scale.z, bits: parent slot | kXf* flags)
+    uint32_t count;
+    uint32_t max_depth;  // longest parent chain (bounds the walk; a cycle is rejected at mirror build)
+};
+struct MeshMirror {
+    const float4* a;  // (aabb.min.xyz, aabb.max.x)
+    const float3* b;  // (aabb.max.y, aabb.max.z, bits: transform slot | kMesh* flags)
+    uint32_t count;
+};
+
+struct HizDevice {
+    const float* depth;          // mip 0
+    const float2* mips;          // levels >= 1, (min,max)
+    const uint64_t* mip_offset;  // device array [GV_MAX_MIPS], in float2 elements
+    uint32_t width, height, mip_count;
+};
+
+constexpr uint32_t kCullBlock = 256;  // slots per cull/emit workgroup (4 waves)
+
+struct ViewParams {
+    float planes[6][4];
+    uint32_t plane_count;
+    float cam[3];
+    float cam_offset[3];
+    float vp[16];
+    uint32_t write_is_visible;  // main pass
+    uint32_t use_hiz;
+    uint32_t distance_2d;
+};
+
+struct ViewBuffers {
+    unsigned long long* mask;  // one ballot word per 64 slots
+    uint32_t* block_count;     // visible per kCullBlock slots
+    uint32_t* block_offset;    // exclusive scan of block_count
+    uint32_t* draw_count;      // total
+    uint8_t* is_visible;       // per slot (main pass)
+    uint32_t* visible_idx;
+    float* baked_model;        // 12 floats per record
+    float* distance_sq;
+};
+
+hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                       const ViewBuffers& out, hipStream_t stream);
+hipError_t launch_scan(const ViewBuffers& out, uint32_t block_count, hipStream_t stream);
+hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
+                       hipStream_t stream);
+hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                           hipStream_t stream);
+
+// world matrices (camera = 0) of every transform slot: 3 float4 per slot (float4x3 order)
+hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream);
+hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream);
+
+// Hi-Z pyramid. Level k >= 1 lives at mips + mip_offset[k]; level 0 is the depth image.
+// Generic one-level reduction (any size, shaders/hiz.frag:27-56 incl. the odd-size branches).
+hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
+                            uint32_t dw, uint32_t dh, uint32_t rule, hipStream_t stream);
+// Fused 6-level reduction of 64x64 source tiles through LDS; needs sw % 64 == 0 && sh % 64 == 0.
+// dst[l] = level (src+1+l), l = 0..5.
+struct HizFusedDst {
+    float2* level[6];
+};
+hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
+                            uint32_t sh, hipStream_t stream);
+
+}  // namespace gv

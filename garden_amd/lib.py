@@ -1,0 +1,272 @@
+"""ctypes binding of libgarden_vis.so (C-ABI: include/garden_vis.h).
+
+Plumbing for tests and bench.py. Loading fails loudly when the HIP library is missing; creating a
+context fails loudly (GvError) when there is no gfx950 device — there is no CPU fallback anywhere in
+this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .pools import mesh_layout_offsets, transform_layout_offsets
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgarden_vis.so")
+
+GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 5
+GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
+GV_CONFIG_PROFILE_EVENTS = 1
+GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
+GV_SWEEP_VALU, GV_SWEEP_MFMA = 0, 1
+GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
+KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep"]
+
+
+class GvConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("hiz_rule", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class GvTransformLayout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("entity", "parent", "position", "scale", "rotation", "self_active",
+                                          "ancestors_active", "model_with_ancestors")]
+
+
+class GvMeshLayout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("entity", "is_enabled", "is_visible", "aabb_min", "aabb_max")]
+
+
+class GvView(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("camera_position", C.c_float * 4), ("camera_offset", C.c_float * 4),
+                ("shadow_pass", C.c_int8), ("use_hiz", C.c_uint8), ("distance_2d", C.c_uint8),
+                ("emit_records", C.c_uint8)]
+
+
+class GvResult(C.Structure):
+    _fields_ = [("visible_idx", C.POINTER(C.c_uint32)), ("baked_model", C.POINTER(C.c_float)),
+                ("distance_sq", C.POINTER(C.c_float)), ("is_visible", C.POINTER(C.c_uint8)),
+                ("draw_count", C.c_uint32), ("instance_count", C.c_uint32)]
+
+
+class GvDeviceResult(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("visible_idx", "baked_model", "distance_sq", "is_visible", "draw_count")]
+
+
+class GvStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * GV_K_COUNT), ("device_ms", C.c_double * GV_K_COUNT),
+                ("upload_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("transform_count", C.c_uint32),
+                ("mesh_count", C.c_uint32 * GV_MAX_POOLS)]
+
+
+class GvError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libgarden_vis error {code}: {text}")
+        self.code = code
+
+
+# every symbol include/garden_vis.h declares; tests/test_abi.py checks the .so exports all of them
+EXPORTS = [
+    "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
+    "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
+    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_sweep", "gv_get_world",
+    "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
+    "gv_stream",
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (no compute). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make -C garden_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    P, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    lib.gv_abi_version.restype = u32
+    lib.gv_create.argtypes = [C.POINTER(GvConfig), C.POINTER(P)]
+    lib.gv_destroy.argtypes = [P]
+    lib.gv_destroy.restype = None
+    lib.gv_last_error.argtypes = [P]
+    lib.gv_last_error.restype = C.c_char_p
+    lib.gv_transform_bind.argtypes = [P, P, sz, u32, C.POINTER(GvTransformLayout), P, u32]
+    lib.gv_pool_bind.argtypes = [P, u32, P, sz, u32, C.POINTER(GvMeshLayout)]
+    lib.gv_mark_dirty.argtypes = [P, u32, u32, u32]
+    lib.gv_hierarchy_rebuild.argtypes = [P]
+    lib.gv_sync.argtypes = [P]
+    lib.gv_cull.argtypes = [P, u32, C.POINTER(GvView), u32]
+    lib.gv_wait.argtypes = [P]
+    lib.gv_results_fetch.argtypes = [P, u32, C.c_int, C.POINTER(GvResult)]
+    lib.gv_result_count.argtypes = [P, u32, C.POINTER(u32)]
+    lib.gv_results_device.argtypes = [P, u32, C.POINTER(GvDeviceResult)]
+    lib.gv_results_copy_idx_device.argtypes = [P, u32, P, u32, u32]
+    lib.gv_sweep.argtypes = [P, u32]
+    lib.gv_get_world.argtypes = [P, u32, u32, P]
+    lib.gv_hiz_build.argtypes = [P, P, u32, u32, u32]
+    lib.gv_hiz_rebuild.argtypes = [P]
+    lib.gv_hiz_read_level.argtypes = [P, u32, P, C.POINTER(u32), C.POINTER(u32)]
+    lib.gv_hiz_mip_count.argtypes = [P, C.POINTER(u32)]
+    lib.gv_stats.argtypes = [P, C.POINTER(GvStats)]
+    lib.gv_stats_reset.argtypes = [P]
+    lib.gv_stream.argtypes = [P]
+    lib.gv_stream.restype = P
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def to_gv_view(v):
+    out = GvView()
+    out.view_proj[:] = [float(x) for x in v["view_proj"]]
+    out.camera_position[:] = [float(x) for x in v["camera_position"]]
+    out.camera_offset[:] = [float(x) for x in v["camera_offset"]]
+    out.shadow_pass = v.get("shadow_pass", -1)
+    out.use_hiz = v.get("use_hiz", 0)
+    out.distance_2d = v.get("distance_2d", 0)
+    out.emit_records = v.get("emit_records", 1)
+    return out
+
+
+class GpuVisibility:
+    """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
+
+    def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False):
+        self.lib = load()
+        cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, GV_CONFIG_PROFILE_EVENTS if profile_events else 0)
+        self.ctx = C.c_void_p()
+        rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != GV_OK:
+            self.ctx = C.c_void_p()
+            raise GvError(rc, self.lib.gv_last_error(None).decode())
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.gv_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != GV_OK:
+            raise GvError(rc, self.lib.gv_last_error(self.ctx).decode())
+
+    # ---- binding ----
+    def bind_transforms(self, transforms, entity_to_transform):
+        lay = GvTransformLayout(**transform_layout_offsets(transforms.dtype))
+        e2t = np.ascontiguousarray(entity_to_transform, dtype=np.uint32)
+        self._keep["xf"] = (transforms, e2t)
+        self._check(self.lib.gv_transform_bind(self.ctx, transforms.ctypes.data, transforms.dtype.itemsize,
+                                               transforms.shape[0], C.byref(lay), e2t.ctypes.data, e2t.shape[0]))
+
+    def bind_pool(self, pool_id, meshes):
+        lay = GvMeshLayout(**mesh_layout_offsets(meshes.dtype))
+        self._keep[("pool", pool_id)] = meshes
+        self._check(self.lib.gv_pool_bind(self.ctx, pool_id, meshes.ctypes.data, meshes.dtype.itemsize,
+                                          meshes.shape[0], C.byref(lay)))
+
+    def mark_dirty(self, kind, first, count, pool_id=0):
+        if kind == GV_DIRTY_MESH:
+            first |= pool_id << 28
+        self._check(self.lib.gv_mark_dirty(self.ctx, kind, first, count))
+
+    def hierarchy_rebuild(self):
+        self._check(self.lib.gv_hierarchy_rebuild(self.ctx))
+
+    def sync(self):
+        self._check(self.lib.gv_sync(self.ctx))
+
+    # ---- per frame ----
+    def cull(self, pool_id, views):
+        arr = (GvView * len(views))(*[to_gv_view(v) for v in views])
+        self._check(self.lib.gv_cull(self.ctx, pool_id, arr, len(views)))
+
+    def wait(self):
+        self._check(self.lib.gv_wait(self.ctx))
+
+    def result_count(self, view_index=0):
+        n = C.c_uint32()
+        self._check(self.lib.gv_result_count(self.ctx, view_index, C.byref(n)))
+        return n.value
+
+    def fetch(self, view_index=0, write_back=True, occupancy=None):
+        """Returns copies: dict(visible_idx, baked_model[n,12], distance_sq, is_visible or None, draw_count)."""
+        r = GvResult()
+        self._check(self.lib.gv_results_fetch(self.ctx, view_index, 1 if write_back else 0, C.byref(r)))
+        n = r.draw_count
+        out = dict(draw_count=n, instance_count=r.instance_count, visible_idx=None, baked_model=None,
+                   distance_sq=None, is_visible=None)
+        if n and r.visible_idx:
+            out["visible_idx"] = np.ctypeslib.as_array(r.visible_idx, shape=(n,)).copy()
+            out["baked_model"] = np.ctypeslib.as_array(r.baked_model, shape=(n, 12)).copy()
+            out["distance_sq"] = np.ctypeslib.as_array(r.distance_sq, shape=(n,)).copy()
+        elif n == 0:
+            out["visible_idx"] = np.zeros(0, np.uint32)
+            out["baked_model"] = np.zeros((0, 12), np.float32)
+            out["distance_sq"] = np.zeros(0, np.float32)
+        if r.is_visible and occupancy:
+            out["is_visible"] = np.ctypeslib.as_array(r.is_visible, shape=(occupancy,)).copy()
+        return out
+
+    def results_device(self, view_index=0):
+        d = GvDeviceResult()
+        self._check(self.lib.gv_results_device(self.ctx, view_index, C.byref(d)))
+        return d
+
+    def copy_idx_device(self, view_index, dst_ptr, capacity, index_base=0):
+        self._check(self.lib.gv_results_copy_idx_device(self.ctx, view_index, dst_ptr, capacity, index_base))
+
+    # ---- world matrices ----
+    def sweep(self, mode=GV_SWEEP_VALU):
+        self._check(self.lib.gv_sweep(self.ctx, mode))
+
+    def get_world(self, first, count):
+        out = np.empty((count, 12), dtype=np.float32)
+        self._check(self.lib.gv_get_world(self.ctx, first, count, out.ctypes.data))
+        return out
+
+    # ---- Hi-Z ----
+    def hiz_build(self, depth):
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        self._check(self.lib.gv_hiz_build(self.ctx, d.ctypes.data, d.shape[1], d.shape[0], GV_MEM_HOST))
+
+    def hiz_rebuild(self):
+        self._check(self.lib.gv_hiz_rebuild(self.ctx))
+
+    def hiz_mip_count(self):
+        n = C.c_uint32()
+        self._check(self.lib.gv_hiz_mip_count(self.ctx, C.byref(n)))
+        return n.value
+
+    def hiz_read_level(self, level, w, h):
+        out = np.empty((h, w, 2), dtype=np.float32)
+        rw, rh = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.gv_hiz_read_level(self.ctx, level, out.ctypes.data, C.byref(rw), C.byref(rh)))
+        assert (rw.value, rh.value) == (w, h), (rw.value, rh.value, w, h)
+        return out
+
+    # ---- metrics ----
+    def stats(self):
+        s = GvStats()
+        self._check(self.lib.gv_stats(self.ctx, C.byref(s)))
+        return dict(launches={k: int(s.launches[i]) for i, k in enumerate(KERNEL_NAMES)},
+                    device_ms={k: float(s.device_ms[i]) for i, k in enumerate(KERNEL_NAMES)},
+                    upload_bytes=int(s.upload_bytes), max_depth=int(s.max_depth),
+                    transform_count=int(s.transform_count))
+
+    def stats_reset(self):
+        self._check(self.lib.gv_stats_reset(self.ctx))

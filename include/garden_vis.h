@@ -1,0 +1,209 @@
+/*
+ * garden_vis.h — C-ABI of libgarden_vis.so: the MI355X (gfx950) visibility pass that stands in for
+ * Garden's CPU MeshRenderSystem::prepareMeshes + Vulkan HizRenderSystem::downsampleHiz pair.
+ *
+ * Citations are relative to the reference checkout (cfnptr/garden). The reference has no FFI for
+ * this path — it is C++ calling C++ inside one process — so each entry point below names the
+ * C++ interface it replaces; INTEGRATION.md shows the shim (an ecsm System) a maintainer adds.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (GV_OK) or a negative
+ * GvStatus; no exceptions or abort() cross this boundary (the reference throws GardenError,
+ * include/garden/error.hpp:32-55 — the C++ shim converts). Not re-entrant per context; call from
+ * the thread that runs Manager::update() (source/system/input.cpp:361-379). Matrices are
+ * column-major float[16] (c0..c3), quaternions xyzw, as in include/garden/system/physics-impl.hpp:45-63.
+ */
+#ifndef GARDEN_VIS_H
+#define GARDEN_VIS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GV_ABI_VERSION 1u
+#define GV_NONE 0xFFFFFFFFu
+#define GV_MAX_POOLS 16u
+#define GV_MAX_VIEWS 8u
+#define GV_MAX_MIPS 16u
+
+typedef enum GvStatus {
+    GV_OK = 0,
+    GV_E_ARG = -1,     /* bad argument / unbound pool / capacity exceeded */
+    GV_E_HIP = -2,     /* a HIP runtime call failed (text in gv_last_error) */
+    GV_E_OOM = -3,     /* host or device allocation failed */
+    GV_E_RCCL = -4,    /* collective failed (multi-GPU exchange) */
+    GV_E_STATE = -5,   /* call out of order (e.g. cull before bind, Hi-Z query before build) */
+    GV_E_NODEVICE = -6 /* no gfx950 device / kernels not loadable: there is NO CPU fallback */
+} GvStatus;
+
+typedef struct GvCtx GvCtx;
+
+typedef struct GvConfig {
+    uint32_t struct_size; /* = sizeof(GvConfig) */
+    int32_t device;       /* HIP device ordinal (one context per process per GPU) */
+    uint32_t hiz_rule;    /* GvHizRule */
+    uint32_t flags;       /* GvConfigFlags */
+} GvConfig;
+
+typedef enum GvHizRule {
+    GV_HIZ_RULE_REFERENCE = 0,   /* shaders/hiz.frag:49-55 exactly as written (odd-height row uses gather .y/.z) */
+    GV_HIZ_RULE_CONSERVATIVE = 1 /* full extra row: min/max bound every covered texel */
+} GvHizRule;
+
+typedef enum GvConfigFlags {
+    GV_CONFIG_PROFILE_EVENTS = 1u << 0 /* bracket every kernel with hipEvents; durations via gv_stats */
+} GvConfigFlags;
+
+/* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as
+ * consumed at source/system/render/mesh.cpp:119-120,139,360,411,460 ---- */
+
+/* Field byte offsets inside one TransformComponent (include/garden/system/transform.hpp:31-61). */
+typedef struct GvTransformLayout {
+    uint32_t entity;               /* Component::entity, u32, 0 = free slot */
+    uint32_t parent;               /* ID<Entity> parent, u32, 0 = none */
+    uint32_t position;             /* f32x4 posChildCount (xyz used) */
+    uint32_t scale;                /* f32x4 scaleChildCap (xyz used) */
+    uint32_t rotation;             /* quat xyzw */
+    uint32_t self_active;          /* volatile bool */
+    uint32_t ancestors_active;     /* volatile bool */
+    uint32_t model_with_ancestors; /* volatile bool */
+} GvTransformLayout;
+
+/* Field byte offsets inside one MeshRenderComponent-derived struct (render/mesh.hpp:45-55). */
+typedef struct GvMeshLayout {
+    uint32_t entity;
+    uint32_t is_enabled;
+    uint32_t is_visible; /* written back by gv_results_fetch on main-pass views */
+    uint32_t aabb_min;   /* f32x4 */
+    uint32_t aabb_max;   /* f32x4 */
+} GvMeshLayout;
+
+/* Binds the TransformComponent pool and the entity -> transform-slot map that stands in for
+ * Manager::tryGet<TransformComponent>(entity) (mesh.cpp:149) / Manager::get (transform.hpp:206).
+ * Re-issue whenever getData() may have moved (create() can reallocate: docs/ECS/Entities.md:44-46).
+ * Pointers must stay valid until the next gv_sync()/gv_cull() returns; nothing is retained after. */
+int gv_transform_bind(GvCtx* ctx, const void* base, size_t stride, uint32_t occupancy,
+                      const GvTransformLayout* layout, const uint32_t* entity_to_transform,
+                      uint32_t entity_capacity);
+
+/* Binds one IMeshRenderSystem's component pool (render/mesh.hpp:127-131). pool_id < GV_MAX_POOLS. */
+int gv_pool_bind(GvCtx* ctx, uint32_t pool_id, void* base, size_t stride, uint32_t occupancy,
+                 const GvMeshLayout* layout);
+
+typedef enum GvDirtyKind {
+    GV_DIRTY_TRANSFORM = 0, /* TRS / active flags of transform slots [first, first+count) changed
+                               (setPosition/Scale/Rotation transform.hpp:74-104, setActive transform.cpp:75-127) */
+    GV_DIRTY_HIERARCHY = 1, /* parent links changed (setParent transform.cpp:130-195, destroy :30-73) */
+    GV_DIRTY_MESH = 2       /* mesh slots changed; pool id in the top 4 bits of `first` */
+} GvDirtyKind;
+int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count);
+
+/* Re-derives the whole device mirror (parent slots, transform slot per mesh, flags) from the bound
+ * pools and uploads it. Implied by the first gv_sync after a bind. */
+int gv_hierarchy_rebuild(GvCtx* ctx);
+/* Uploads whatever is dirty (host gather AoS -> SoA staging, then H2D). Called by gv_cull too. */
+int gv_sync(GvCtx* ctx);
+
+/* ---- per-frame inputs: replaces the CommonConstants read at mesh.cpp:866-869,899-902 and the
+ * per-cascade viewProj/cameraOffset of renderShadows (mesh.cpp:795-847) ---- */
+typedef struct GvView {
+    float view_proj[16];      /* cc.viewProj = projection * view, view translation zeroed (graphics.cpp:201,243) */
+    float camera_position[4]; /* cc.cameraPos (graphics.cpp:202); xyz used */
+    float camera_offset[4];   /* shadow cascades (render/mesh.hpp:166); zero for the main camera */
+    int8_t shadow_pass;       /* < 0: main pass, isVisible is produced (mesh.cpp:121) */
+    uint8_t use_hiz;          /* also run the Hi-Z occlusion query (needs gv_hiz_build first) */
+    uint8_t distance_2d;      /* sorted twin key translation.z + 1 (mesh.cpp:250) */
+    uint8_t emit_records;     /* 1: produce visibleIdx/bakedModel/distanceSq; 0: isVisible + count only */
+} GvView;
+
+/* Host-visible results of one view: the SoA form of UnsortedBuffer::combinedMeshes[0..drawCount)
+ * (render/mesh.hpp:191-217). Pointers are library-owned pinned memory, valid until the next
+ * gv_cull on this context. Records are in ascending pool-slot order (deterministic); the
+ * reference's order is fetch_add arrival order (mesh.cpp:177), i.e. unspecified. */
+typedef struct GvResult {
+    const uint32_t* visible_idx; /* pool slot; componentOffset = visible_idx * stride (mesh.cpp:170) */
+    const float* baked_model;    /* 12 floats per record: c0.xyz c1.xyz c2.xyz c3.xyz (float4x3, mesh.cpp:171) */
+    const float* distance_sq;    /* mesh.cpp:172 / :250-251 */
+    const uint8_t* is_visible;   /* one byte per pool slot; NULL for shadow passes */
+    uint32_t draw_count;         /* UnsortedBuffer::drawCount (render/mesh.hpp:210) */
+    uint32_t instance_count;     /* default predicate returns 0/1 (render/mesh.hpp:142-146) => == draw_count */
+} GvResult;
+
+/* Device-side cull of one pool against `view_count` views: frustum test (+ Hi-Z query) + compaction.
+ * Asynchronous: returns once the work is enqueued on the context's stream. Replaces
+ * MeshRenderSystem::prepareMeshes' threaded loop (mesh.cpp:331-553 -> :111-184). */
+int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_count);
+/* Blocks until all enqueued work is done. */
+int gv_wait(GvCtx* ctx);
+/* Waits, copies view `view_index`'s records to pinned host memory, and — for a main-pass view — when
+ * write_back != 0 scatters isVisible into the bound pool (mesh.cpp:144,152,161,166). */
+int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* out);
+/* draw count only (4-byte readback). */
+int gv_result_count(GvCtx* ctx, uint32_t view_index, uint32_t* draw_count);
+/* Device pointers of view `view_index`'s compacted list, for an exchange step that stays on the GPU
+ * (multi-GPU all-gatherv). Valid until the next gv_cull. */
+typedef struct GvDeviceResult {
+    const void* visible_idx; /* uint32_t[draw_count], device memory */
+    const void* baked_model; /* float[12 * draw_count] */
+    const void* distance_sq; /* float[draw_count] */
+    const void* is_visible;  /* uint8_t[occupancy] or NULL */
+    const void* draw_count;  /* uint32_t, device memory */
+} GvDeviceResult;
+int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out);
+/* Copies visible_idx (+ `index_base` added to each) into caller-owned device memory. */
+int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
+                               uint32_t index_base);
+
+/* ---- world matrices: TransformComponent::calcModel() with cameraPosition = 0 for every transform
+ * slot (transform.hpp:197-214), cached on the device ---- */
+typedef enum GvSweepMode {
+    GV_SWEEP_VALU = 0, /* v_fma_f32 chain */
+    GV_SWEEP_MFMA = 1  /* v_mfma_f32_4x4x1_16b_f32 chain (bit-identical; self-tested at gv_create) */
+} GvSweepMode;
+int gv_sweep(GvCtx* ctx, uint32_t mode);
+/* Reads back `count` world matrices (12 floats each, float4x3 order) starting at transform slot `first`. */
+int gv_get_world(GvCtx* ctx, uint32_t first, uint32_t count, float* out12);
+
+/* ---- Hi-Z: replaces HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167,
+ * shaders/hiz.frag:23-63). depth = reversed-Z fp32, row-major, `width` x `height`. ---- */
+typedef enum GvMemKind { GV_MEM_HOST = 0, GV_MEM_DEVICE = 1 } GvMemKind;
+int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height, uint32_t mem_kind);
+/* Re-runs the reduction on the depth image already resident from the last gv_hiz_build. */
+int gv_hiz_rebuild(GvCtx* ctx);
+/* Copies mip `level` (>= 1) back as (min,max) float pairs; *w, *h receive its size. */
+int gv_hiz_read_level(GvCtx* ctx, uint32_t level, float* out_pairs, uint32_t* w, uint32_t* h);
+int gv_hiz_mip_count(GvCtx* ctx, uint32_t* mip_count);
+
+/* ---- lifecycle, errors, metrics ---- */
+int gv_create(const GvConfig* config, GvCtx** out_ctx);
+void gv_destroy(GvCtx* ctx);
+/* Text of the last failure on this context (or of the last failed gv_create when ctx == NULL). */
+const char* gv_last_error(const GvCtx* ctx);
+uint32_t gv_abi_version(void);
+
+typedef enum GvKernelId {
+    GV_K_CULL = 0,     /* frustum (+Hi-Z) test, visibility mask, per-block counts */
+    GV_K_SCAN = 1,     /* block-count scan */
+    GV_K_EMIT = 2,     /* compaction + record emission */
+    GV_K_HIZ = 3,      /* pyramid reduction (all launches of one build) */
+    GV_K_SWEEP = 4,    /* world-matrix sweep */
+    GV_K_COUNT = 5
+} GvKernelId;
+typedef struct GvStats {
+    uint64_t launches[GV_K_COUNT];   /* kernel launches since gv_stats_reset */
+    double device_ms[GV_K_COUNT];    /* summed hipEvent durations (GV_CONFIG_PROFILE_EVENTS only) */
+    uint64_t upload_bytes;           /* H2D mirror bytes since reset */
+    uint32_t max_depth;              /* longest parent chain in the mirror */
+    uint32_t transform_count, mesh_count[GV_MAX_POOLS];
+} GvStats;
+int gv_stats(GvCtx* ctx, GvStats* out);
+int gv_stats_reset(GvCtx* ctx);
+/* The HIP stream all work is enqueued on (hipStream_t as void*), for callers timing with their own events. */
+void* gv_stream(GvCtx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""GPU parity: libgarden_vis (HIP, through the C-ABI) vs the CPU oracle on the same seeded AoS pools.
+
+Bar: bit-exact visible-index set, isVisible bytes, bakedModel and distanceSq (the kernels and the oracle
+use the same written operation order, so the matrices agree to the bit, not just to 1e-5)."""
+import numpy as np
+import pytest
+
+from garden_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(gpu, oracle, sc, views, hiz_depth=None):
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    hz = None
+    if hiz_depth is not None:
+        gpu.hiz_build(hiz_depth)
+        hz = oracle.Hiz(hiz_depth)
+    gpu.cull(0, views)
+    out = []
+    for vi, v in enumerate(views):
+        sc.meshes["isVisible"] = 7  # poison: the main pass must overwrite every slot
+        got = gpu.fetch(vi, write_back=True, occupancy=sc.count)
+        got_vis = sc.meshes["isVisible"].copy()
+        sc.meshes["isVisible"] = 7
+        exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v, hiz=hz if v.get("use_hiz") else None)
+        exp_vis = sc.meshes["isVisible"].copy()
+        out.append((got, got_vis, exp, exp_vis))
+    return out
+
+
+def assert_same(got, got_vis, exp, exp_vis, main_pass=True):
+    assert got["draw_count"] == exp["draw_count"]
+    # the oracle's single-thread order is ascending slot order; the library's is too (stable compaction)
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+    assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+    assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+    if main_pass:
+        assert np.array_equal(got_vis, exp_vis)
+        assert got["is_visible"] is not None and np.array_equal(got["is_visible"], exp_vis)
+    else:
+        assert np.all(got_vis == 7) and np.all(exp_vis == 7)  # shadow passes leave isVisible alone (mesh.cpp:144)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 10_000, 100_003])
+def test_flat_frustum_parity(gpu, oracle, n):
+    sc = scene.flat_scene(n, seed=scene.SEED + n)
+    (got, gv, exp, ev), = run_both(gpu, oracle, sc, [scene.main_camera_view()])
+    assert_same(got, gv, exp, ev)
+
+
+def test_hierarchy_parity(gpu, oracle):
+    sc = scene.hierarchy_scene(50_000, depth=4, fanout=10)
+    (got, gv, exp, ev), = run_both(gpu, oracle, sc, [scene.main_camera_view()])
+    assert exp["draw_count"] > 0
+    assert_same(got, gv, exp, ev)
+    assert gpu.stats()["max_depth"] == 3
+
+
+def test_multi_view_and_shadow_pass(gpu, oracle):
+    sc = scene.flat_scene(20_000)
+    views = [scene.main_camera_view(), scene.cascade_view(index=0), scene.cascade_view(index=1)]
+    res = run_both(gpu, oracle, sc, views)
+    assert_same(*res[0], main_pass=True)
+    assert_same(*res[1], main_pass=False)
+    assert_same(*res[2], main_pass=False)
+
+
+def test_hiz_occlusion_parity(gpu, oracle):
+    sc = scene.flat_scene(50_000)
+    depth = scene.synthetic_depth(512, 256)
+    v = scene.main_camera_view(use_hiz=1)
+    (got, gv, exp, ev), = run_both(gpu, oracle, sc, [v], hiz_depth=depth)
+    frustum_only = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, scene.main_camera_view())
+    assert 0 < exp["draw_count"] < frustum_only["draw_count"]  # the query does cull something
+    assert_same(got, gv, exp, ev)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (5, 3), (7, 7), (135, 77), (1920, 1080), (4096, 4096), (1024, 512)])
+@pytest.mark.parametrize("rule", [0, 1])
+def test_hiz_pyramid_parity(oracle, size, rule):
+    from garden_amd.lib import GpuVisibility
+    w, h = size
+    depth = scene.synthetic_depth(w, h, rects=37)
+    rng = np.random.default_rng(w * 131 + h)
+    depth = np.maximum(depth, (rng.random((h, w)) * 0.01).astype(np.float32))
+    with GpuVisibility(device=0, hiz_rule=rule) as vis:
+        vis.hiz_build(depth)
+        exp = oracle.Hiz(depth, rule=rule)
+        assert vis.hiz_mip_count() == exp.mip_count
+        for k in range(1, exp.mip_count):
+            e = exp.level(k)
+            g = vis.hiz_read_level(k, e.shape[1], e.shape[0])
+            assert np.array_equal(g.view(np.uint32), e.view(np.uint32)), f"mip {k} differs"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_world_matrices(gpu, oracle, mode):
+    sc = scene.hierarchy_scene(30_000, depth=5, fanout=6)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.hierarchy_rebuild()
+    gpu.sweep(mode)
+    got = gpu.get_world(0, sc.count)
+    exp = oracle.world_matrices(sc.transforms, sc.entity_to_transform)
+    assert np.max(np.abs(got - exp)) <= 1e-5  # the north-star tolerance
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # and in fact bit-exact
