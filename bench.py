@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — entity culls/sec of the visibility hot path on N MI355X GPUs (one process per GPU).
+
+A "step" is one frame of the hot path over one batch of resident component pools:
+  cfg2: 1M static entities, flat, frustum-only cull + compaction
+  cfg3: 10M entities, Hi-Z pyramid rebuild (4096^2 depth) + frustum + Hi-Z occlusion cull + compaction  [default]
+  cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep + chain-walk frustum cull + compaction
+For N > 1 each rank owns one spatial tile (same per-GPU entity count: weak scaling), culls it against the
+same view and the ranks all-gatherv the compacted global visible-index lists over RCCL (cfg5 pattern).
+
+Inputs are resident in HBM before the timed region; outputs stay on the device (only a 4-byte count is
+read back per frame). Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "cfg2": dict(entities=1_000_000, hier=False, hiz=False, sweep=False,
+                 name="cfg2: 1M static entities, flat hierarchy, frustum-only AABB cull, fp32"),
+    "cfg3": dict(entities=10_000_000, hier=False, hiz=True, sweep=False,
+                 name="cfg3: 10M entities, frustum + Hi-Z occlusion vs synthetic 4096^2 depth pyramid (rebuilt per frame)"),
+    "cfg4": dict(entities=10_000_000, hier=True, hiz=False, sweep=True,
+                 name="cfg4: 10M entities, 4-deep transform hierarchy recomputed each frame (MFMA 4x4 chain sweep) + cull"),
+}
+HIZ_SIZE = 4096
+
+
+def tile_grid(n):
+    g = [1, 1, 1]
+    i = 0
+    while g[0] * g[1] * g[2] < n:
+        g[i % 3] *= 2
+        i += 1
+    return g
+
+
+def make_tile_scene(wl, n_local, rank, world):
+    """Rank `rank`'s spatial tile of the world cube (side 100 * N_total^(1/3)); camera at the world centre."""
+    from garden_amd import scene
+    sc = scene.hierarchy_scene(n_local, seed=scene.SEED + rank) if wl["hier"] else scene.flat_scene(n_local, seed=scene.SEED + rank)
+    if world > 1:
+        side = 100.0 * (n_local * world) ** (1.0 / 3.0)
+        local_side = 100.0 * n_local ** (1.0 / 3.0)
+        g = tile_grid(world)
+        cell = [rank % g[0], (rank // g[0]) % g[1], rank // (g[0] * g[1])]
+        roots = sc.transforms["parent"] == 0
+        pos = sc.transforms["position"]
+        for a in range(3):
+            ext = side / g[a]
+            lo = -0.5 * side + cell[a] * ext
+            # roots were drawn uniform in [-local_side/2, local_side/2): remap into this tile's box
+            pos[roots, a] = ((pos[roots, a] / local_side + 0.5) * ext + lo).astype(np.float32)
+    return sc
+
+
+def algorithmic_bytes(wl, n, frustum_survivors, visible, depth):
+    """Minimal SoA stream bytes per launch for the cull kernel, and
+    for the whole step (for information)."""
+    cull = n * (65.0 + 1.0 + 0.125)  # TRS 40 + AABB 24 + flags 1 read; isVisible 1 + ballot word 1/8 written
+    if wl["hier"]:
+        cull += n * 4.0  # parent index
+    if wl["hiz"]:
+        cull += frustum_survivors * 32.0  # 4 texels x (min,max) fp32 per frustum-surviving entity
+    emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125
+    hiz = (HIZ_SIZE * HIZ_SIZE * 4 + sum(max(HIZ_SIZE >> k, 1) ** 2 * 8 for k in range(1, 13))) if wl["hiz"] else 0.0
+    sweep = n * (40.0 + 4.0 + 48.0) if wl["sweep"] else 0.0
+    return dict(cull=cull, emit=emit, hiz=float(hiz), sweep=sweep)
+
+
+def cpu_baseline(wl, sc, view, depth, seconds=12.0):
+    """The oracle (scalar C port of mesh.cpp:111-184 + transform.hpp:197-214 + hiz.frag), threaded with the
+    ThreadPool::addItems range split over all host cores, on a bounded sample of the same workload."""
+    from oracle import oracle_py
+    from garden_amd.scene import Scene
+    cores = os.cpu_count() or 1
+    sample_n = min(sc.count, 2_000_000)
+    meshes = sc.meshes[:sample_n].copy()
+    if wl["hier"]:
+        transforms, e2t = sc.transforms, sc.entity_to_transform  # chains may reach any slot
+    else:
+        transforms, e2t = sc.transforms[:sample_n], sc.entity_to_transform
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        hz = oracle_py.Hiz(depth) if wl["hiz"] else None
+        if wl["sweep"]:
+            oracle_py.world_matrices(transforms, e2t, 0, sample_n)
+        oracle_py.prepare_meshes(meshes, transforms, e2t, view, hiz=hz, threads=cores)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and frames >= 2:
+            break
+    return dict(value=sample_n * frames / dt, unit="entity culls/s", cores=cores, kind="port",
+                sample=f"{frames} frames of the first {sample_n} entities of the same scene/view"
+                       f"{' incl. 4096^2 pyramid build per frame' if wl['hiz'] else ''}, scalar C oracle, "
+                       f"{cores} threads split like ThreadPool::addItems, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--entities", type=int, default=0, help="per-GPU entity count override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from garden_amd import scene
+    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA
+    from garden_amd.multi import allgatherv_indices
+
+    wl = WORKLOADS[args.workload]
+    n = args.entities or wl["entities"]
+    sc = make_tile_scene(wl, n, rank, world)
+    view = scene.main_camera_view(use_hiz=1 if wl["hiz"] else 0)
+    depth = scene.synthetic_depth(HIZ_SIZE, HIZ_SIZE) if wl["hiz"] else None
+
+    vis = GpuVisibility(device=local_rank, profile_events=True)
+    t_up = time.perf_counter()
+    vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+    vis.bind_pool(0, sc.meshes)
+    vis.hierarchy_rebuild()
+    vis.wait()
+    upload_s = time.perf_counter() - t_up
+    if wl["hiz"]:
+        vis.hiz_build(depth)
+
+    idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else None
+
+    def step():
+        if wl["hiz"]:
+            vis.hiz_rebuild()
+        if wl["sweep"]:
+            vis.sweep(GV_SWEEP_MFMA)
+        vis.cull(0, [view])
+        if world > 1:
+            count = vis.result_count(0)
+            vis.copy_idx_device(0, idx_buf.data_ptr(), n, index_base=rank * n)
+            vis.wait()
+            return allgatherv_indices(idx_buf, count, dist)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    upload_bytes = vis.stats()["upload_bytes"]
+    vis.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = vis.stats()
+
+    # correctness gate + algorithmic byte counts
+    got = vis.fetch(0, write_back=False, occupancy=n)
+    visible = got["draw_count"]
+    parity = None
+    survivors = visible
+    if rank == 0:
+        from oracle import oracle_py
+        cores = os.cpu_count() or 1
+        threads = max(1, cores // world)
+        frustum_only = dict(view, use_hiz=0)
+        if wl["hiz"]:
+            m2 = sc.meshes.copy()
+            survivors = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, frustum_only, threads=threads)["draw_count"]
+        if not args.no_parity:
+            m2 = sc.meshes.copy()
+            exp = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view,
+                                           hiz=oracle_py.Hiz(depth) if wl["hiz"] else None, threads=threads)
+            order = np.argsort(exp["visible_idx"], kind="stable")
+            same_set = bool(np.array_equal(got["visible_idx"], exp["visible_idx"][order]))
+            same_vis = bool(np.array_equal(got["is_visible"], m2["isVisible"]))
+            same_mat = bool(np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
+            parity = dict(visible_set_bit_identical=same_set, is_visible_identical=same_vis,
+                          baked_model_bit_identical=same_mat, visible=int(visible), checked_entities=int(n))
+            if not (same_set and same_vis):
+                print(json.dumps({"error": "visible set differs from the CPU oracle", "parity": parity}))
+                sys.exit(1)
+
+    if rank == 0:
+        ab = algorithmic_bytes(wl, n, survivors, visible, depth)
+        launches = max(1, st["launches"]["cull"])
+        cull_ms = st["device_ms"]["cull"] / launches
+        achieved = ab["cull"] / (cull_ms * 1e-3) / 1e9 if cull_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("cull_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "entity culls/sec at 10M entities; visible-set bit-match vs CPU ref",
+            "value": n * world * args.steps / elapsed,
+            "unit": "entity culls/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "entities_per_gpu": n, "entities_total": n * world,
+                       "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
+                       "exchange": "all-gatherv of uint32 visible lists (RCCL)" if world > 1 else None,
+                       "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"]},
+                       "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes},
+            "roofline": {"bound": "hbm", "kernel": "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ab["cull"], "avg_launch_ms": cull_ms},
+            "parity": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, sc, view, depth)
+        print(json.dumps(out))
+    vis.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
