@@ -1,0 +1,258 @@
+// garden_host.hpp — host-side mirror of the Garden types on the visibility path, with the reference's byte
+// layouts and member names, so a system written here reads like one written inside the engine.
+//   TransformComponent / TransformSystem    include/garden/system/transform.hpp:31-61,74-110, source/system/transform.cpp:75-195
+//   MeshRenderComponent / IMeshRenderSystem  include/garden/system/render/mesh.hpp:45-55,60-147
+//   UnsortedMesh / MeshBuffer                include/garden/system/render/mesh.hpp:191-218
+//   CommonConstants (viewProj, cameraPos)    include/garden/graphics/constants.hpp:26-56
+//   event chain Update -> Render -> PreDeferredRender   source/system/graphics.cpp:312,409; render/deferred.cpp:441-446
+// The math types are plain PODs (cfnptr/math is absent); all arithmetic of the path lives behind the C-ABI.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "ecsm_lite.hpp"
+
+namespace garden {
+using namespace ecsm;
+
+struct f32x4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    f32x4() = default;
+    f32x4(float x_, float y_, float z_, float w_ = 0) : x(x_), y(y_), z(z_), w(w_) {}
+};
+struct quat {
+    float x = 0, y = 0, z = 0, w = 1;
+    quat() = default;
+    quat(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+};
+struct Aabb {
+    f32x4 min = f32x4(-0.5f, -0.5f, -0.5f), max = f32x4(0.5f, 0.5f, 0.5f);  // Aabb::one
+};
+struct f32x4x4 {
+    float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // column-major c0..c3
+};
+struct float4x3 {
+    float m[12] = {};  // c0.xyz c1.xyz c2.xyz c3.xyz
+};
+
+// transform.hpp:31-61 — 80 bytes in release builds.
+struct alignas(16) TransformComponent final : public Component {
+    ID<Entity> parent = {};
+    uint64_t uid = 0;
+    f32x4 posChildCount = f32x4(0, 0, 0, 0);
+    f32x4 scaleChildCap = f32x4(1, 1, 1, 0);
+    quat rotation;
+    ID<Entity>* childs = nullptr;
+    volatile bool selfActive = true;
+    volatile bool ancestorsActive = true;
+    volatile bool modelWithAncestors = true;
+
+    uint32_t childCount() const noexcept
+    {
+        uint32_t v;
+        memcpy(&v, &posChildCount.w, 4);
+        return v;
+    }
+    void setChildCount(uint32_t v) noexcept { memcpy(&posChildCount.w, &v, 4); }
+    uint32_t childCapacity() const noexcept
+    {
+        uint32_t v;
+        memcpy(&v, &scaleChildCap.w, 4);
+        return v;
+    }
+    void setChildCapacity(uint32_t v) noexcept { memcpy(&scaleChildCap.w, &v, 4); }
+    void setPosition(float x, float y, float z) noexcept { posChildCount.x = x; posChildCount.y = y; posChildCount.z = z; }
+    void setScale(float x, float y, float z) noexcept { scaleChildCap.x = x; scaleChildCap.y = y; scaleChildCap.z = z; }
+    void setRotation(quat r) noexcept { rotation = r; }
+    bool isActive() const noexcept { return selfActive && ancestorsActive; }  // transform.hpp:110
+    ID<Entity> getParent() const noexcept { return parent; }
+};
+static_assert(sizeof(TransformComponent) == 80, "TransformComponent must keep the reference's 80-byte layout");
+
+class TransformSystem final : public ComponentSystem<TransformComponent>, public Singleton<TransformSystem> {
+public:
+    uint64_t hierarchyVersion = 0, transformVersion = 0;  // bumped by the mutators below; consumers re-mirror
+
+    View<TransformComponent> add(ID<Entity> entity) { hierarchyVersion++; return addTo(entity); }
+    // transform.cpp:130-195: unlink from the old parent's childs[], append to the new one, recompute ancestorsActive
+    void setParent(ID<Entity> entity, ID<Entity> newParent)
+    {
+        auto view = tryGetOf(entity);
+        if (!view || view->parent == newParent)
+            return;
+        for (auto p = newParent; p; p = tryGetOf(p)->parent)  // cycle check, transform.cpp:137-143
+            if (p == entity)
+                throw std::runtime_error("setParent: cycle");
+        if (view->parent) {
+            auto old = tryGetOf(view->parent);
+            uint32_t n = old->childCount();
+            for (uint32_t i = 0; i < n; i++)
+                if (old->childs[i] == entity) {
+                    old->childs[i] = old->childs[n - 1];
+                    old->setChildCount(n - 1);
+                    break;
+                }
+        }
+        view->parent = newParent;
+        bool active = true;
+        if (newParent) {
+            auto np = tryGetOf(newParent);
+            uint32_t n = np->childCount(), cap = np->childCapacity();
+            if (n == cap) {
+                cap = cap ? cap * 2 : 1;
+                np->childs = static_cast<ID<Entity>*>(std::realloc(np->childs, sizeof(ID<Entity>) * cap));
+                np->setChildCapacity(cap);
+            }
+            np->childs[n] = entity;
+            np->setChildCount(n + 1);
+            active = np->isActive();
+        }
+        propagateActive(entity, active);
+        hierarchyVersion++;
+    }
+    // transform.cpp:75-127: flips selfActive and pushes ancestorsActive down the subtree
+    void setActive(ID<Entity> entity, bool isActive)
+    {
+        auto view = tryGetOf(entity);
+        if (!view || view->selfActive == isActive)
+            return;
+        view->selfActive = isActive;
+        if (view->ancestorsActive)
+            for (uint32_t i = 0, n = view->childCount(); i < n; i++)
+                propagateActive(view->childs[i], isActive);
+        transformVersion++;
+    }
+    void markTransformsChanged() noexcept { transformVersion++; }
+    ~TransformSystem() override
+    {
+        auto data = components.getData();
+        for (uint32_t i = 0; i < components.getOccupancy(); i++)
+            std::free(data[i].childs);
+    }
+
+private:
+    void propagateActive(ID<Entity> entity, bool ancestors)
+    {
+        std::vector<std::pair<ID<Entity>, bool>> stack{{entity, ancestors}};
+        while (!stack.empty()) {
+            auto [e, a] = stack.back();
+            stack.pop_back();
+            auto v = tryGetOf(e);
+            if (!v)
+                continue;
+            v->ancestorsActive = a;
+            const bool below = a && v->selfActive;
+            for (uint32_t i = 0, n = v->childCount(); i < n; i++)
+                stack.push_back({v->childs[i], below});
+        }
+    }
+};
+
+// render/mesh.hpp:45-55 — 48 bytes; derived components are larger, hence getMeshComponentSize().
+struct alignas(16) MeshRenderComponent : public Component {
+protected:
+    uint32_t reserved0 = 0;
+    uint32_t reserved1 = 0;
+    uint16_t reserved2 = 0;
+
+public:
+    volatile bool isEnabled = true;
+    volatile bool isVisible = false;
+    Aabb aabb;
+};
+static_assert(sizeof(MeshRenderComponent) == 48, "MeshRenderComponent must keep the reference's 48-byte layout");
+
+enum class MeshRenderType : uint8_t { Color, Opaque, Translucent, OIT, Refracted, TransDepth, UI, Count };
+
+// render/mesh.hpp:60-147 (only the members the prepare phase consumes).
+class IMeshRenderSystem {
+public:
+    using MeshRenderPool = LinearPool<MeshRenderComponent, false>;
+    virtual ~IMeshRenderSystem() = default;
+    virtual MeshRenderType getMeshRenderType() const = 0;
+    virtual uint8_t* getMeshComponentData() const = 0;       // getMeshComponentPool().getData()
+    virtual uint32_t getMeshComponentOccupancy() const = 0;  // getMeshComponentPool().getOccupancy()
+    virtual size_t getMeshComponentSize() const = 0;
+};
+
+class OpaqueMeshSystem final : public ComponentSystem<MeshRenderComponent, false>, public IMeshRenderSystem {
+public:
+    uint64_t meshVersion = 0;
+    View<MeshRenderComponent> add(ID<Entity> entity) { meshVersion++; return addTo(entity); }
+    void markMeshesChanged() noexcept { meshVersion++; }
+    MeshRenderType getMeshRenderType() const override { return MeshRenderType::Opaque; }
+    uint8_t* getMeshComponentData() const override { return reinterpret_cast<uint8_t*>(components.getData()); }
+    uint32_t getMeshComponentOccupancy() const override { return components.getOccupancy(); }
+    size_t getMeshComponentSize() const override { return sizeof(MeshRenderComponent); }
+};
+
+// graphics/constants.hpp:26-56 (fields the path reads) + render/mesh.hpp:166 shadow-pass inputs.
+struct CommonConstants {
+    f32x4x4 viewProj;
+    f32x4 cameraPos;
+};
+
+// render/mesh.hpp:191-217
+struct UnsortedMesh final {
+    size_t componentOffset = 0;
+    float4x3 bakedModel;
+    float distanceSq = 0.0f;
+    bool operator<(const UnsortedMesh& m) const noexcept { return distanceSq < m.distanceSq; }
+};
+struct MeshBuffer {
+    IMeshRenderSystem* meshSystem = nullptr;
+    std::atomic<uint32_t> drawCount{0};
+    alignas(64) std::atomic<uint32_t> instanceCount{0};
+};
+struct UnsortedBuffer final : public MeshBuffer {
+    std::vector<UnsortedMesh> combinedMeshes;
+};
+
+// Headless stand-ins for GraphicsSystem ("Update": prepareCommonConstants -> runEvent("Render"),
+// graphics.cpp:312,409) and DeferredRenderSystem ("Render" -> "PreDeferredRender"/"DeferredRender",
+// deferred.cpp:441-489). No Vulkan.
+class GraphicsSystem final : public System, public Singleton<GraphicsSystem> {
+    CommonConstants commonConstants;
+
+public:
+    GraphicsSystem()
+    {
+        auto manager = Manager::Instance::get();
+        manager->registerEvent("Render");
+        ECSM_SUBSCRIBE_TO_EVENT("Update", GraphicsSystem::update);
+    }
+    const CommonConstants& getCommonConstants() const noexcept { return commonConstants; }
+    void setCamera(const f32x4x4& viewProj, f32x4 cameraPos) noexcept
+    {
+        commonConstants.viewProj = viewProj;
+        commonConstants.cameraPos = cameraPos;
+    }
+
+private:
+    void update() { Manager::Instance::get()->runEvent("Render"); }
+};
+
+class DeferredRenderSystem final : public System, public Singleton<DeferredRenderSystem> {
+public:
+    DeferredRenderSystem()
+    {
+        auto manager = Manager::Instance::get();
+        manager->registerEvent("PreDeferredRender");
+        manager->registerEvent("DeferredRender");
+        manager->registerEvent("PreHdrRender");
+        ECSM_SUBSCRIBE_TO_EVENT("Render", DeferredRenderSystem::render);
+    }
+
+private:
+    void render()
+    {
+        auto manager = Manager::Instance::get();
+        manager->runEvent("PreDeferredRender");
+        manager->runEvent("DeferredRender");
+        manager->runEvent("PreHdrRender");
+    }
+};
+
+}  // namespace garden

@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/garden_vis.h declares (no compute calls: there is
+no GPU in the CPU test tier), and the product path fails loudly instead of falling back when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "garden_vis.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gv_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from garden_amd import lib
+    assert header_functions() == sorted(lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from garden_amd import lib
+    handle = lib.load()
+    for name in header_functions():
+        assert hasattr(handle, name), f"libgarden_vis.so does not export {name}"
+    assert handle.gv_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    from garden_amd import lib
+    assert ctypes.sizeof(lib.GvConfig) == 16
+    assert ctypes.sizeof(lib.GvView) == 16 * 4 + 4 * 4 + 4 * 4 + 4
+    assert ctypes.sizeof(lib.GvTransformLayout) == 32 and ctypes.sizeof(lib.GvMeshLayout) == 20
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "garden_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "gv_oracle" not in src and "oracle_py" not in src and "from oracle" not in src, f
+    assert "oracle" not in open(os.path.join(ROOT, "include", "garden_vis.h")).read().replace("oracle/", "")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on the CPU tier")
+    from garden_amd.lib import GV_E_NODEVICE, GpuVisibility, GvError
+    with pytest.raises(GvError) as e:
+        GpuVisibility(device=0)
+    assert e.value.code == GV_E_NODEVICE and "no CPU fallback" in str(e.value)

@@ -1,0 +1,58 @@
+"""The C++ boundary: an ecsm-style headless frame loop (Manager::update -> Update -> Render -> PreDeferredRender)
+with the CPU reference-path system (oracle) and, on the GPU tier, the drop-in GpuVisibilitySystem over the C-ABI,
+compared bit for bit on what they leave for the render phase (isVisible, combinedMeshes, counters)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "build", "headless_tick")
+
+
+@pytest.fixture(scope="module")
+def tick():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+
+    def run(*args, check=True):
+        p = subprocess.run([BIN, *args], capture_output=True, text=True, timeout=600)
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        if check:
+            assert p.returncode == 0 and out["ok"], out
+        return p.returncode, out
+    return run
+
+
+def test_cfg1_cpu_reference_path_headless_tick(tick):
+    """BASELINE.json configs[0]: 10k entities, flat hierarchy, frustum-only cull on the CPU path, no Vulkan."""
+    _, one = tick("--mode", "cpu", "--entities", "10000", "--ticks", "20")
+    assert 0 < one["draw_count"] < 10000 and one["is_visible_set"] == one["draw_count"]
+    _, many = tick("--mode", "cpu", "--entities", "10000", "--ticks", "20", "--threads", "4")
+    assert many["draw_count"] == one["draw_count"]  # range split does not change the set (thread-pool.cpp:173-200)
+
+
+def test_cpu_hierarchy_and_mutations(tick):
+    _, out = tick("--mode", "cpu", "--entities", "5000", "--ticks", "3", "--hier", "--mutate")
+    assert out["draw_count"] > 0
+
+
+def test_gpu_system_fails_loudly_without_device(tick):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out = tick("--mode", "gpu", "--entities", "100", check=False)
+    assert rc == 1 and "no CPU fallback" in out["why"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [
+    ["--entities", "10000"],
+    ["--entities", "10000", "--threads", "8"],
+    ["--entities", "50000", "--hier"],
+    ["--entities", "50000", "--hier", "--mutate"],
+    ["--entities", "1000", "--mutate"],
+])
+def test_gpu_dropin_matches_cpu_system(tick, args):
+    _, out = tick("--mode", "both", "--ticks", "3", *args)
+    assert out["draw_count"] > 0

@@ -1,0 +1,103 @@
+"""Host-side logic that needs no GPU: pool layouts, scene generator, tile partition, the all-gatherv exchange
+over gloo with world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from garden_amd import scene
+from garden_amd.pools import GV_NONE, MESH_DTYPE, TRANSFORM_DTYPE, derived_mesh_dtype
+
+
+def test_pool_layouts_match_reference_structs():
+    assert MESH_DTYPE.itemsize == 48 and TRANSFORM_DTYPE.itemsize == 80  # mesh.hpp:45-55, transform.hpp:31-61
+    assert MESH_DTYPE.fields["aabbMin"][1] == 16 and MESH_DTYPE.fields["isEnabled"][1] == 14
+    assert TRANSFORM_DTYPE.fields["rotation"][1] == 48 and TRANSFORM_DTYPE.fields["selfActive"][1] == 72
+    assert derived_mesh_dtype(32).itemsize == 80
+
+
+def test_scene_is_deterministic_and_well_formed():
+    a, b = scene.flat_scene(5000), scene.flat_scene(5000)
+    assert a.meshes.tobytes() == b.meshes.tobytes() and a.transforms.tobytes() == b.transforms.tobytes()
+    q = a.transforms["rotation"]
+    assert np.allclose(np.sum(q * q, axis=1), 1.0, atol=1e-6)
+    live = a.transforms["entity"] != 0
+    assert 0.005 < 1 - live.mean() < 0.02 and 0.005 < (a.meshes["isEnabled"] == 0).mean() < 0.02
+    assert np.array_equal(a.entity_to_transform[a.transforms["entity"][live]], np.nonzero(live)[0])
+
+
+def test_hierarchy_scene_levels_and_active_flags():
+    sc = scene.hierarchy_scene(11110, depth=4, fanout=10, defects=True)
+    t = sc.transforms
+    depth = np.zeros(sc.count, dtype=np.int32)
+    for s in range(sc.count):
+        p = t["parent"][s]
+        if p:
+            ps = sc.entity_to_transform[p]
+            assert ps != GV_NONE and ps < s  # parents precede children (level order)
+            depth[s] = depth[ps] + 1
+            exp = t["selfActive"][ps] & t["ancestorsActive"][ps]
+            assert t["ancestorsActive"][s] == exp  # setActive propagation (transform.cpp:75-127)
+    assert depth.max() == 3 and (depth == 0).sum() == 10 or (depth == 0).sum() >= 10
+
+
+def test_tile_partition_covers_everything_once():
+    from garden_amd.multi import tile_of_positions
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-50, 50, (10000, 3)).astype(np.float32)
+    for grid in ([2, 1, 1], [2, 2, 1], [2, 2, 2]):
+        t = tile_of_positions(pos, 100.0, grid)
+        n = grid[0] * grid[1] * grid[2]
+        assert t.min() == 0 and t.max() == n - 1
+        assert np.bincount(t, minlength=n).sum() == 10000 and np.bincount(t, minlength=n).min() > 10000 / n * 0.8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _exchange_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import allgatherv_indices
+    from oracle import oracle_py
+    # each rank culls its own tile on the CPU oracle (stand-in for the per-GPU cull), then exchanges
+    n_local = 3000
+    sc = scene.flat_scene(n_local, seed=scene.SEED + rank)
+    view = scene.main_camera_view()
+    r = oracle_py.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, view)
+    buf = torch.zeros(n_local, dtype=torch.int32)
+    k = r["draw_count"]
+    buf[:k] = torch.from_numpy((r["visible_idx"].astype(np.int64) + rank * n_local).astype(np.int32))
+    gathered, counts = allgatherv_indices(buf, k, dist)
+    ret[rank] = (gathered.numpy().copy(), counts.numpy().copy(), k)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgatherv_world_size_2_gloo(oracle):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, port, ret), nprocs=world, join=True)
+    # single-process expectation: concatenation of the per-tile lists in rank order, global indices
+    exp = []
+    for rank in range(world):
+        sc = scene.flat_scene(3000, seed=scene.SEED + rank)
+        r = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, scene.main_camera_view())
+        exp.append(r["visible_idx"].astype(np.int64) + rank * 3000)
+    exp = np.concatenate(exp)
+    for rank in range(world):
+        gathered, counts, k = ret[rank]
+        assert np.array_equal(gathered.astype(np.int64), exp)
+        assert counts.sum() == exp.shape[0] and counts[rank] == k
+    assert len(np.unique(exp)) == exp.shape[0]
