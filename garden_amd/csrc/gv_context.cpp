@@ -113,6 +113,7 @@ struct PoolState {
     GvMeshLayout layout{};
     bool bound = false;
     bool need_full = false;
+    bool identity = false;  // >= 90 % of mesh slots i resolve to transform slot i (chosen at full gather)
     DirtyRange dirty;
     // device mirror + pinned staging
     DeviceBuf<float4> d_a;
@@ -123,7 +124,8 @@ struct PoolState {
 
 struct ViewState {
     DeviceBuf<unsigned long long> mask;
-    DeviceBuf<uint32_t> block_count, block_offset, draw_count;
+    DeviceBuf<uint32_t> chunk_count, chunk_offset, draw_count;
+
     DeviceBuf<uint8_t> is_visible;
     DeviceBuf<uint32_t> visible_idx;
     DeviceBuf<float> baked_model, distance_sq;
@@ -449,6 +451,13 @@ int sync_mirror(GvCtx* ctx)
             GV_HIP(ctx, p.h_b.reserve(cap));
             if (p.occupancy) {
                 gather_meshes(ctx, p, 0, p.occupancy);
+                size_t same = 0;
+                for (uint32_t i = 0; i < p.occupancy; i++) {
+                    uint32_t link;
+                    memcpy(&link, &p.h_b.ptr[i].z, 4);
+                    same += (link & kSlotMask) == i;
+                }
+                p.identity = same * 10 >= (size_t)p.occupancy * 9;
                 int rc = upload_meshes(ctx, p, 0, p.occupancy);
                 if (rc != GV_OK)
                     return rc;
@@ -526,9 +535,14 @@ int reserve_view(GvCtx* ctx, ViewState& vs, uint32_t occupancy, bool emit)
 {
     const size_t n = std::max<uint32_t>(occupancy, 1);
     const size_t blocks = (n + kCullBlock - 1) / kCullBlock;
+    const size_t chunks = (n + kEmitChunk - 1) / kEmitChunk;
     GV_HIP(ctx, vs.mask.reserve(blocks * (kCullBlock / 64)));
-    GV_HIP(ctx, vs.block_count.reserve(blocks));
-    GV_HIP(ctx, vs.block_offset.reserve(blocks));
+    if (chunks > vs.chunk_count.cap) {
+        GV_HIP(ctx, vs.chunk_count.reserve(chunks));
+        // the cull workgroups add into chunk_count and scan re-zeroes it; a fresh allocation starts at zero
+        GV_HIP(ctx, hipMemsetAsync(vs.chunk_count.ptr, 0, vs.chunk_count.cap * sizeof(uint32_t), ctx->stream));
+    }
+    GV_HIP(ctx, vs.chunk_offset.reserve(chunks));
     GV_HIP(ctx, vs.draw_count.reserve(4));
     GV_HIP(ctx, vs.is_visible.reserve(n));
     GV_HIP(ctx, vs.h_draw_count.reserve(4));
@@ -544,8 +558,8 @@ ViewBuffers view_buffers(ViewState& vs)
 {
     ViewBuffers b;
     b.mask = vs.mask.ptr;
-    b.block_count = vs.block_count.ptr;
-    b.block_offset = vs.block_offset.ptr;
+    b.chunk_count = vs.chunk_count.ptr;
+    b.chunk_offset = vs.chunk_offset.ptr;
     b.draw_count = vs.draw_count.ptr;
     b.is_visible = vs.is_visible.ptr;
     b.visible_idx = vs.visible_idx.ptr;
@@ -661,7 +675,7 @@ void gv_destroy(GvCtx* ctx)
         p.d_a.release(); p.d_b.release(); p.h_a.release(); p.h_b.release();
     }
     for (auto& v : ctx->views) {
-        v.mask.release(); v.block_count.release(); v.block_offset.release(); v.draw_count.release();
+        v.mask.release(); v.chunk_count.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release();
@@ -774,7 +788,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     if (rc != GV_OK)
         return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.occupancy};
+    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.occupancy, p.identity ? 1u : 0u};
     const TransformMirror xf = xf_mirror(ctx);
     HizDevice hz{};
     for (uint32_t v = 0; v < view_count; v++) {
@@ -803,7 +817,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         ViewParams vp;
         build_view_params(views[v], &vp);
         const ViewBuffers vb = view_buffers(vs);
-        const uint32_t blocks = (p.occupancy + kCullBlock - 1) / kCullBlock;
+        const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
         if (p.occupancy == 0) {
             GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
             continue;
@@ -814,7 +828,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         }
         {
             KernelTimer t(ctx, GV_K_SCAN);
-            GV_HIP(ctx, launch_scan(vb, blocks, ctx->stream));
+            GV_HIP(ctx, launch_scan(vb, chunks, ctx->stream));
         }
         if (emit) {
             KernelTimer t(ctx, GV_K_EMIT);

@@ -1,10 +1,16 @@
 // gv_device_math.hpp — gfx950 device-side arithmetic of the visibility pass.
 //
 // The reference's math library (cfnptr/math) is an empty submodule in the checkout, so the
-// operation order is fixed here and in DESIGN.md §"Canonical arithmetic": every multiply that feeds
-// an add is an explicit fmaf(), the 4x4 product is a k = 0..3 fmaf chain from +0 (the order a
+// operation order is fixed here and in DESIGN.md §4 "Canonical arithmetic": every multiply that feeds
+// an add is an explicit fma, the 4x4 product is a k = 0..3 fma chain from +0 (the order a
 // v_mfma_f32_4x4x1_16b_f32 chain with a zero C operand produces), and nothing uses rcp/rsq
 // approximations. Compile with -ffp-contract=off -fno-fast-math.
+//
+// The cull kernel is VALU-issue-bound when written with scalar v_fma_f32 (one wave64 instruction per
+// ~4 cycles per SIMD, profiles/r01a_*), so the corner / plane / product arithmetic is written on
+// 2-wide vectors: hipcc lowers __builtin_elementwise_fma on float2 to v_pk_fma_f32 (two IEEE fmas per
+// lane per instruction, SGPR operands broadcast through op_sel). Each element sees exactly the scalar
+// sequence of the oracle, so the bits do not change.
 //
 // Call sites being replaced (reference paths):
 //   math::calcModel        include/garden/system/transform.hpp:199,207,224
@@ -16,6 +22,14 @@
 #include <stdint.h>
 
 namespace gv {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+// NaN-propagating maximum (v_maximum3_f32): "all d < 0" == "maximum(d...) < 0" including the NaN case
+// (a NaN distance makes the comparison false, exactly like the oracle's !(d < 0)).
+__device__ __forceinline__ float max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 
 // Affine 3x4 part of a column-major f32x4x4 whose bottom row is (0,0,0,1): columns c0..c3, rows x,y,z.
 struct Mat34 {
@@ -35,9 +49,13 @@ __device__ __forceinline__ Mat34 calc_model(float px, float py, float pz, float 
     const float r00 = 1.0f - fmaf(qy, y2, zz);
     const float r11 = 1.0f - fmaf(qx, x2, zz);
     const float r22 = 1.0f - fmaf(qx, x2, yy);
-    const float r10 = fmaf(qx, y2, wz), r01 = fmaf(qx, y2, -wz);
-    const float r20 = fmaf(qx, z2, -wy), r02 = fmaf(qx, z2, wy);
-    const float r21 = fmaf(qy, z2, wx), r12 = fmaf(qy, z2, -wx);
+    // (r10, r01) = fma(x, y2, (+wz, -wz)) etc.: one packed fma per off-diagonal pair
+    const v2f p_xy = pk_fma(splat(qx), splat(y2), v2f{wz, -wz});
+    const v2f p_xz = pk_fma(splat(qx), splat(z2), v2f{-wy, wy});
+    const v2f p_yz = pk_fma(splat(qy), splat(z2), v2f{wx, -wx});
+    const float r10 = p_xy.x, r01 = p_xy.y;
+    const float r20 = p_xz.x, r02 = p_xz.y;
+    const float r21 = p_yz.x, r12 = p_yz.y;
     Mat34 m;
     m.c0x = r00 * sx; m.c0y = r10 * sx; m.c0z = r20 * sx;
     m.c1x = r01 * sy; m.c1y = r11 * sy; m.c1z = r21 * sy;
@@ -46,59 +64,85 @@ __device__ __forceinline__ Mat34 calc_model(float px, float py, float pz, float 
     return m;
 }
 
-// One output element of a * b: fmaf chain over k = 0..3 from +0; (b3) is the bottom-row element of
-// b's column (0 for c0..c2, 1 for c3), a3 the element of a's translation column.
-__device__ __forceinline__ float mul_elem(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3)
+// One output column of a * b, rows x,y as a packed pair and row z scalar: per element the fma chain
+// over k = 0..3 from +0; b3 is the bottom-row element of b's column (0 for c0..c2, 1 for c3).
+__device__ __forceinline__ void mul_column(const Mat34& a, float b0, float b1, float b2, float b3, float& ox, float& oy,
+                                           float& oz)
 {
-    float acc = fmaf(a0, b0, 0.0f);
-    acc = fmaf(a1, b1, acc);
-    acc = fmaf(a2, b2, acc);
-    acc = fmaf(a3, b3, acc);
-    return acc;
+    v2f acc = pk_fma(v2f{a.c0x, a.c0y}, splat(b0), splat(0.0f));
+    acc = pk_fma(v2f{a.c1x, a.c1y}, splat(b1), acc);
+    acc = pk_fma(v2f{a.c2x, a.c2y}, splat(b2), acc);
+    acc = pk_fma(v2f{a.c3x, a.c3y}, splat(b3), acc);
+    float z = fmaf(a.c0z, b0, 0.0f);
+    z = fmaf(a.c1z, b1, z);
+    z = fmaf(a.c2z, b2, z);
+    z = fmaf(a.c3z, b3, z);
+    ox = acc.x;
+    oy = acc.y;
+    oz = z;
 }
 
 // parentModel * model, rows 0..2 (row 3 of both operands is exactly (0,0,0,1) and stays so).
 __device__ __forceinline__ Mat34 mul_affine(const Mat34& a, const Mat34& b)
 {
     Mat34 r;
-    r.c0x = mul_elem(a.c0x, a.c1x, a.c2x, a.c3x, b.c0x, b.c0y, b.c0z, 0.0f);
-    r.c0y = mul_elem(a.c0y, a.c1y, a.c2y, a.c3y, b.c0x, b.c0y, b.c0z, 0.0f);
-    r.c0z = mul_elem(a.c0z, a.c1z, a.c2z, a.c3z, b.c0x, b.c0y, b.c0z, 0.0f);
-    r.c1x = mul_elem(a.c0x, a.c1x, a.c2x, a.c3x, b.c1x, b.c1y, b.c1z, 0.0f);
-    r.c1y = mul_elem(a.c0y, a.c1y, a.c2y, a.c3y, b.c1x, b.c1y, b.c1z, 0.0f);
-    r.c1z = mul_elem(a.c0z, a.c1z, a.c2z, a.c3z, b.c1x, b.c1y, b.c1z, 0.0f);
-    r.c2x = mul_elem(a.c0x, a.c1x, a.c2x, a.c3x, b.c2x, b.c2y, b.c2z, 0.0f);
-    r.c2y = mul_elem(a.c0y, a.c1y, a.c2y, a.c3y, b.c2x, b.c2y, b.c2z, 0.0f);
-    r.c2z = mul_elem(a.c0z, a.c1z, a.c2z, a.c3z, b.c2x, b.c2y, b.c2z, 0.0f);
-    r.c3x = mul_elem(a.c0x, a.c1x, a.c2x, a.c3x, b.c3x, b.c3y, b.c3z, 1.0f);
-    r.c3y = mul_elem(a.c0y, a.c1y, a.c2y, a.c3y, b.c3x, b.c3y, b.c3z, 1.0f);
-    r.c3z = mul_elem(a.c0z, a.c1z, a.c2z, a.c3z, b.c3x, b.c3y, b.c3z, 1.0f);
+    mul_column(a, b.c0x, b.c0y, b.c0z, 0.0f, r.c0x, r.c0y, r.c0z);
+    mul_column(a, b.c1x, b.c1y, b.c1z, 0.0f, r.c1x, r.c1y, r.c1z);
+    mul_column(a, b.c2x, b.c2y, b.c2z, 0.0f, r.c2x, r.c2y, r.c2z);
+    mul_column(a, b.c3x, b.c3y, b.c3z, 1.0f, r.c3x, r.c3y, r.c3z);
     return r;
 }
 
-// The 8 local corners (bit0 -> x, bit1 -> y, bit2 -> z selects max) through the model, sharing the
-// partial sums: per row t_z = fma(c2, z, c3); t_yz = fma(c1, y, t_z); p = fma(c0, x, t_yz) — the same
-// bits as evaluating each corner on its own.
-struct Corners {
-    float x[8], y[8], z[8];
-};
-__device__ __forceinline__ void corner_row(float c0, float c1, float c2, float c3, float mnx, float mny, float mnz,
-                                           float mxx, float mxy, float mxz, float (&out)[8])
+// math::translate(-cameraPosition, model): c3.xyz - cam (transform.hpp:211,213). Returns a fresh value so the
+// matrix never lives in memory (in-place field updates made LLVM keep c3 in scratch/LDS).
+__device__ __forceinline__ Mat34 translated(const Mat34& a, float cx, float cy, float cz)
 {
-    const float tz0 = fmaf(c2, mnz, c3), tz1 = fmaf(c2, mxz, c3);
-    const float t00 = fmaf(c1, mny, tz0), t10 = fmaf(c1, mxy, tz0);
-    const float t01 = fmaf(c1, mny, tz1), t11 = fmaf(c1, mxy, tz1);
-    out[0] = fmaf(c0, mnx, t00); out[1] = fmaf(c0, mxx, t00);
-    out[2] = fmaf(c0, mnx, t10); out[3] = fmaf(c0, mxx, t10);
-    out[4] = fmaf(c0, mnx, t01); out[5] = fmaf(c0, mxx, t01);
-    out[6] = fmaf(c0, mnx, t11); out[7] = fmaf(c0, mxx, t11);
+    Mat34 r;
+    r.c0x = a.c0x; r.c0y = a.c0y; r.c0z = a.c0z;
+    r.c1x = a.c1x; r.c1y = a.c1y; r.c1z = a.c1z;
+    r.c2x = a.c2x; r.c2y = a.c2y; r.c2z = a.c2z;
+    r.c3x = a.c3x - cx;
+    r.c3y = a.c3y - cy;
+    r.c3z = a.c3z - cz;
+    return r;
+}
+
+// The 8 local corners (bit0 -> x, bit1 -> y, bit2 -> z selects max) through the model, as 4 packed pairs
+// per coordinate: pair j holds corners (2j, 2j+1), i.e. (x = min, x = max) for one (y, z) choice.
+// Per row: t_z = fma(c2, z, c3); t_yz = fma(c1, y, t_z); p = fma(c0, x, t_yz) — the same bits as
+// evaluating each corner on its own.
+struct Corners {
+    v2f x[4], y[4], z[4];
+};
+__device__ __forceinline__ void corner_row(float c0, float c1, float c2, float c3, v2f xs, v2f ys, v2f zs, v2f (&out)[4])
+{
+    const v2f tz = pk_fma(splat(c2), zs, splat(c3));          // (z = min, z = max)
+    const v2f ty0 = pk_fma(splat(c1), ys, splat(tz.x));        // z = min: (y = min, y = max)
+    const v2f ty1 = pk_fma(splat(c1), ys, splat(tz.y));        // z = max
+    out[0] = pk_fma(splat(c0), xs, splat(ty0.x));              // corners 0,1: y min, z min
+    out[1] = pk_fma(splat(c0), xs, splat(ty0.y));              // corners 2,3: y max, z min
+    out[2] = pk_fma(splat(c0), xs, splat(ty1.x));              // corners 4,5: y min, z max
+    out[3] = pk_fma(splat(c0), xs, splat(ty1.y));              // corners 6,7: y max, z max
 }
 __device__ __forceinline__ void aabb_corners(const Mat34& m, float mnx, float mny, float mnz, float mxx, float mxy,
                                              float mxz, Corners& c)
 {
-    corner_row(m.c0x, m.c1x, m.c2x, m.c3x, mnx, mny, mnz, mxx, mxy, mxz, c.x);
-    corner_row(m.c0y, m.c1y, m.c2y, m.c3y, mnx, mny, mnz, mxx, mxy, mxz, c.y);
-    corner_row(m.c0z, m.c1z, m.c2z, m.c3z, mnx, mny, mnz, mxx, mxy, mxz, c.z);
+    const v2f xs = {mnx, mxx}, ys = {mny, mxy}, zs = {mnz, mxz};
+    corner_row(m.c0x, m.c1x, m.c2x, m.c3x, xs, ys, zs, c.x);
+    corner_row(m.c0y, m.c1y, m.c2y, m.c3y, xs, ys, zs, c.y);
+    corner_row(m.c0z, m.c1z, m.c2z, m.c3z, xs, ys, zs, c.z);
+}
+
+// isBehindFrustum for one plane: all 8 signed distances d = fma(nx,px, fma(ny,py, fma(nz,pz, nw))) < 0.
+__device__ __forceinline__ bool all_behind_plane(const Corners& c, float nx, float ny, float nz, float nw)
+{
+    v2f d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        d[j] = pk_fma(splat(nx), c.x[j], pk_fma(splat(ny), c.y[j], pk_fma(splat(nz), c.z[j], splat(nw))));
+    const float m = max_nan(max_nan(max_nan(d[0].x, d[0].y), max_nan(d[1].x, d[1].y)),
+                            max_nan(max_nan(d[2].x, d[2].y), max_nan(d[3].x, d[3].y)));
+    return m < 0.0f;
 }
 
 }  // namespace gv

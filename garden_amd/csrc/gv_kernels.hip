@@ -22,6 +22,21 @@ namespace gv {
 // ------------------------------------------------------------------------------------------------
 // shared device helpers
 // ------------------------------------------------------------------------------------------------
+// The mirror streams are read once per frame: nontemporal loads (no L2/MALL allocation priority) measured
+// +20 % on this access pattern (tools/kbench.hip: 6.1 -> 7.1 TB/s). Ancestor re-reads use plain loads.
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x3n __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 stream_load(const float4* p)
+{
+    const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float3 stream_load(const float3* p)
+{
+    const float* q = reinterpret_cast<const float*>(p);
+    return make_float3(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2));
+}
+
 __device__ __forceinline__ Mat34 load_local_model(const TransformMirror& xf, uint32_t s, uint32_t& link)
 {
     const float4 a = xf.a[s];
@@ -70,33 +85,35 @@ __device__ __forceinline__ float clamp01(float a)
 // Build-defined occlusion query (SURVEY.md §8a-7'; the reference has none). Returns true if occluded.
 __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&vp)[16], const Corners& c)
 {
-    float umin = 0, umax = 0, vmin = 0, vmax = 0, znear = 0;
+    float u[8], v[8], zc[8];
     bool bounded = true;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const float clx = fmaf(vp[0], c.x[k], fmaf(vp[4], c.y[k], fmaf(vp[8], c.z[k], vp[12])));
-        const float cly = fmaf(vp[1], c.x[k], fmaf(vp[5], c.y[k], fmaf(vp[9], c.z[k], vp[13])));
-        const float clz = fmaf(vp[2], c.x[k], fmaf(vp[6], c.y[k], fmaf(vp[10], c.z[k], vp[14])));
-        const float clw = fmaf(vp[3], c.x[k], fmaf(vp[7], c.y[k], fmaf(vp[11], c.z[k], vp[15])));
-        bounded = bounded && (clw > 0.0f);
-        const float rcp = 1.0f / clw;  // IEEE-correct division (-fhip-fp32-correctly-rounded-divide-sqrt)
-        const float u = fmaf(clx * rcp, 0.5f, 0.5f);
-        const float v = fmaf(cly * rcp, 0.5f, 0.5f);
-        const float zc = clz * rcp;
-        if (k == 0) {
-            umin = umax = u;
-            vmin = vmax = v;
-            znear = zc;
-        } else {
-            umin = u < umin ? u : umin;
-            umax = u > umax ? u : umax;
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-            znear = zc > znear ? zc : znear;
-        }
+    for (int j = 0; j < 4; j++) {
+        const v2f clx = pk_fma(splat(vp[0]), c.x[j], pk_fma(splat(vp[4]), c.y[j], pk_fma(splat(vp[8]), c.z[j], splat(vp[12]))));
+        const v2f cly = pk_fma(splat(vp[1]), c.x[j], pk_fma(splat(vp[5]), c.y[j], pk_fma(splat(vp[9]), c.z[j], splat(vp[13]))));
+        const v2f clz = pk_fma(splat(vp[2]), c.x[j], pk_fma(splat(vp[6]), c.y[j], pk_fma(splat(vp[10]), c.z[j], splat(vp[14]))));
+        const v2f clw = pk_fma(splat(vp[3]), c.x[j], pk_fma(splat(vp[7]), c.y[j], pk_fma(splat(vp[11]), c.z[j], splat(vp[15]))));
+        bounded = bounded && (clw.x > 0.0f) && (clw.y > 0.0f);
+        // IEEE-correct division (-fhip-fp32-correctly-rounded-divide-sqrt), one per corner
+        const v2f rcp = {1.0f / clw.x, 1.0f / clw.y};
+        const v2f uu = pk_fma(clx * rcp, splat(0.5f), splat(0.5f));
+        const v2f vv = pk_fma(cly * rcp, splat(0.5f), splat(0.5f));
+        const v2f zz = clz * rcp;
+        u[2 * j] = uu.x; u[2 * j + 1] = uu.y;
+        v[2 * j] = vv.x; v[2 * j + 1] = vv.y;
+        zc[2 * j] = zz.x; zc[2 * j + 1] = zz.y;
     }
     if (!bounded)
         return false;
+    float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0], znear = zc[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        umin = u[k] < umin ? u[k] : umin;
+        umax = u[k] > umax ? u[k] : umax;
+        vmin = v[k] < vmin ? v[k] : vmin;
+        vmax = v[k] > vmax ? v[k] : vmax;
+        znear = zc[k] > znear ? zc[k] : znear;
+    }
     umin = clamp01(umin);
     umax = clamp01(umax);
     vmin = clamp01(vmin);
@@ -138,54 +155,84 @@ struct CullArgs {
     uint32_t per_xcd;
 };
 
+// One mesh slot through the reference's filter chain (mesh.cpp:140-166): candidate / empty-AABB / transform /
+// isActive checks, parent-chain model, camera translate, 8-corner frustum test. On survival `m` holds the
+// camera-relative model (bakedModel) and `c` its corners.
+template <bool IDENT>
+__device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& view,
+                                              uint32_t i, Mat34& m, Corners& c)
+{
+    const float4 ma = stream_load(&mesh.a[i]);
+    const float3 mb = stream_load(&mesh.b[i]);
+    // Speculative prefetch: when mesh slot i usually maps to transform slot i, issue the transform loads
+    // beside the mesh loads instead of one HBM round trip later; verified against the real slot below.
+    float4 pa = {}, pb = {};
+    float3 pc = {};
+    const bool prefetched = IDENT && i < xf.count;
+    if (prefetched) {
+        pa = stream_load(&xf.a[i]);
+        pb = stream_load(&xf.b[i]);
+        pc = stream_load(&xf.c[i]);
+    }
+    const uint32_t mlink = __float_as_uint(mb.z);
+    const float mnx = ma.x, mny = ma.y, mnz = ma.z, mxx = ma.w, mxy = mb.x, mxz = mb.y;
+    // mesh.cpp:140-142: skip free slots, disabled meshes and all(size <= 0) boxes
+    const bool empty = (mxx - mnx <= 0.0f) && (mxy - mny <= 0.0f) && (mxz - mnz <= 0.0f);
+    const uint32_t slot = mlink & kSlotMask;
+    if (!(mlink & kMeshCandidate) || empty || slot == kSlotNone)
+        return false;
+    if (!(prefetched && slot == i)) {
+        pa = xf.a[slot];
+        pb = xf.b[slot];
+        pc = xf.c[slot];
+    }
+    const uint32_t link = __float_as_uint(pc.z);
+    if (!(link & kXfActive))  // mesh.cpp:150, transform.hpp:110
+        return false;
+    const Mat34 local = calc_model(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z, pb.w, pa.w, pc.x, pc.y);
+    const Mat34 world = chain_model(xf, local, link);
+    // math::translate(-cameraPosition, model)  transform.hpp:211,213
+    m = translated(world, view.cam[0], view.cam[1], view.cam[2]);
+    aabb_corners(m, mnx, mny, mnz, mxx, mxy, mxz, c);
+    // default getReadyMeshesAsync predicate (render/mesh.hpp:142-146). Fully unrolled with a wave-uniform
+    // guard so the plane coefficients stay in SGPRs (a runtime-indexed kernarg array would go to LDS/scratch).
+    bool behind = false;
+#pragma unroll
+    for (uint32_t p = 0; p < 6; p++)
+        if (p < view.plane_count)
+            behind = behind || all_behind_plane(c, view.planes[p][0], view.planes[p][1], view.planes[p][2],
+                                                view.planes[p][3]);
+    return !behind;
+}
+
+// K1: one lane per mesh slot: visibility, isVisible byte, one ballot word per wave, per-chunk counts.
+// Compaction is two-pass (ballot words -> chunk scan -> emit). Measured alternatives, all within a few % of
+// this one in total time or worse (profiles/r01b_compaction_variants.txt): writing 56-byte records from K1
+// into per-tile / per-wave staging segments and copying them (sparse partial sectors, +25..50 us in K1);
+// LDS-staged fused emission with one global atomic per flush (occupancy, barriers); a decoupled look-back
+// scan over 256-slot tiles (inter-workgroup latency and polling traffic dominate such small tiles).
+template <bool HIZ, bool IDENT>
 __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 {
     const uint32_t lb = xcd_block(blockIdx.x, args.per_xcd);
     if (lb >= args.nblocks)
         return;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool visible = false;
     if (i < args.mesh.count) {
-        const float4 ma = args.mesh.a[i];
-        const float3 mb = args.mesh.b[i];
-        const uint32_t mlink = __float_as_uint(mb.z);
-        const float mnx = ma.x, mny = ma.y, mnz = ma.z, mxx = ma.w, mxy = mb.x, mxz = mb.y;
-        // mesh.cpp:140-142: skip free slots, disabled meshes and all(size <= 0) boxes
-        const bool empty = (mxx - mnx <= 0.0f) && (mxy - mny <= 0.0f) && (mxz - mnz <= 0.0f);
-        const uint32_t slot = mlink & kSlotMask;
-        if ((mlink & kMeshCandidate) && !empty && slot != kSlotNone) {
-            uint32_t link;
-            Mat34 m = load_local_model(args.xf, slot, link);
-            if (link & kXfActive) {  // mesh.cpp:150, transform.hpp:110
-                m = chain_model(args.xf, m, link);
-                // math::translate(-cameraPosition, model)  transform.hpp:211,213
-                m.c3x = m.c3x - args.view.cam[0];
-                m.c3y = m.c3y - args.view.cam[1];
-                m.c3z = m.c3z - args.view.cam[2];
-                Corners c;
-                aabb_corners(m, mnx, mny, mnz, mxx, mxy, mxz, c);
-                bool behind = false;
-                for (uint32_t p = 0; p < args.view.plane_count; p++) {
-                    const float nx = args.view.planes[p][0], ny = args.view.planes[p][1];
-                    const float nz = args.view.planes[p][2], nw = args.view.planes[p][3];
-                    bool all_behind = true;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const float d = fmaf(nx, c.x[k], fmaf(ny, c.y[k], fmaf(nz, c.z[k], nw)));
-                        all_behind = all_behind && (d < 0.0f);
-                    }
-                    behind = behind || all_behind;
-                }
-                visible = !behind;
-                if (visible && args.view.use_hiz)
-                    visible = !hiz_occluded(args.hiz, args.view.vp, c);
-            }
-        }
+        Mat34 m;
+        Corners c;
+        visible = evaluate_slot<IDENT>(args.mesh, args.xf, args.view, i, m, c);
+        // Hi-Z occlusion query on the survivors. Measured (profiles/r01b_hiz_ablation.txt): compacting the
+        // survivors across the workgroup through LDS first buys nothing — the stage is bound by the texel
+        // gathers (~4.5 M random 64-B sectors per frame), not by divergent VALU work.
+        if (HIZ && visible)
+            visible = !hiz_occluded(args.hiz, args.view.vp, c);
         if (args.view.write_is_visible)
             args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
     }
     const unsigned long long word = __ballot(visible);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     __shared__ uint32_t wave_count[kCullBlock / 64];
     if (lane == 0) {
         args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
@@ -197,7 +244,8 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 #pragma unroll
         for (uint32_t w = 0; w < kCullBlock / 64; w++)
             total += wave_count[w];
-        args.out.block_count[lb] = total;
+        if (total)  // integer adds commute: the sum is deterministic whatever the arrival order
+            atomicAdd(&args.out.chunk_count[lb / (kEmitChunk / kCullBlock)], total);
     }
 }
 
@@ -214,7 +262,15 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
     a.per_xcd = (a.nblocks + 7) / 8;
-    hipLaunchKernelGGL(cull_kernel, dim3(a.per_xcd * 8), dim3(kCullBlock), 0, stream, a);
+    const dim3 grid(a.per_xcd * 8), block(kCullBlock);
+    if (vp.use_hiz && mesh.identity)
+        hipLaunchKernelGGL((cull_kernel<true, true>), grid, block, 0, stream, a);
+    else if (vp.use_hiz)
+        hipLaunchKernelGGL((cull_kernel<true, false>), grid, block, 0, stream, a);
+    else if (mesh.identity)
+        hipLaunchKernelGGL((cull_kernel<false, true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((cull_kernel<false, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 
@@ -223,19 +279,22 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kScanBlock = 1024;
 
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const uint32_t* __restrict__ counts,
+// n = slots / 4096 chunk totals (2 442 at 10^7 slots): 1024 per pass, coalesced, carry across passes.
+// Reads each count once and writes 0 back so the next frame's cull workgroups can add into it again.
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(uint32_t* __restrict__ counts,
                                                           uint32_t* __restrict__ offsets,
                                                           uint32_t* __restrict__ total, uint32_t n)
 {
     __shared__ uint32_t wave_sum[kScanBlock / 64];
-    __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-        carry_s = 0;
-    __syncthreads();
+    uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += kScanBlock) {
         const uint32_t idx = base + threadIdx.x;
-        const uint32_t v = idx < n ? counts[idx] : 0u;
+        uint32_t v = 0;
+        if (idx < n) {
+            v = counts[idx];
+            counts[idx] = 0;
+        }
         uint32_t incl = v;  // wave-level inclusive scan
 #pragma unroll
         for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -246,25 +305,25 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const uint32_t* __rest
         if (lane == 63)
             wave_sum[wave] = incl;
         __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (uint32_t w = 0; w < wave; w++)
-            wave_prefix += wave_sum[w];
-        const uint32_t carry = carry_s;
+        uint32_t wave_prefix = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanBlock / 64; w++) {
+            wave_prefix += w < wave ? wave_sum[w] : 0u;
+            all += wave_sum[w];
+        }
         if (idx < n)
             offsets[idx] = carry + wave_prefix + incl - v;
-        __syncthreads();
-        if (threadIdx.x == kScanBlock - 1)
-            carry_s = carry + wave_prefix + incl;
+        carry += all;
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        *total = carry_s;
+        *total = carry;
 }
 
-hipError_t launch_scan(const ViewBuffers& out, uint32_t block_count, hipStream_t stream)
+hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, stream, out.block_count, out.block_offset,
-                       out.draw_count, block_count);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, stream, out.chunk_count, out.chunk_offset,
+                       out.draw_count, chunk_count);
     return hipGetLastError();
 }
 
@@ -276,42 +335,80 @@ struct EmitArgs {
     TransformMirror xf;
     ViewParams view;
     ViewBuffers out;
-    uint32_t nblocks;
-    uint32_t per_xcd;
 };
 
-__global__ __launch_bounds__(kCullBlock) void emit_kernel(const EmitArgs args)
+constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slots = 16 ballot words each
+
+// Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
+// chunk's 64 words (512 B, L2), then lane r takes the r-th visible slot of its quarter (binary search over the
+// word prefix + select of the k-th set bit), so the model recompute and the 56-byte record store run on dense
+// waves and only the visible fraction costs instructions. Output rank = chunk_offset[chunk] + r: ascending
+// slot order, whatever order the workgroups run in.
+__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 {
-    const uint32_t lb = xcd_block(blockIdx.x, args.per_xcd);
-    if (lb >= args.nblocks)
-        return;
-    const uint32_t i = lb * kCullBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long* words = args.out.mask + (size_t)lb * (kCullBlock / 64);
-    uint32_t rank = args.out.block_offset[lb];
-    for (uint32_t w = 0; w < wave; w++)
-        rank += (uint32_t)__popcll(words[w]);
-    const unsigned long long word = words[wave];
-    if (!((word >> lane) & 1ull))
-        return;
-    rank += (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
-    const float3 mb = args.mesh.b[i];
-    const uint32_t slot = __float_as_uint(mb.z) & kSlotMask;
-    uint32_t link;
-    Mat34 m = load_local_model(args.xf, slot, link);
-    m = chain_model(args.xf, m, link);
-    m.c3x = m.c3x - args.view.cam[0];
-    m.c3y = m.c3y - args.view.cam[1];
-    m.c3z = m.c3z - args.view.cam[2];
-    args.out.visible_idx[rank] = i;
-    float4* bm = reinterpret_cast<float4*>(args.out.baked_model + (size_t)rank * 12);
-    bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
-    bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
-    bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
-    const float tx = m.c3x + args.view.cam_offset[0];
-    const float ty = m.c3y + args.view.cam_offset[1];
-    const float tz = m.c3z + args.view.cam_offset[2];
-    args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+    __shared__ unsigned long long words[64];
+    __shared__ uint32_t prefix[65];
+    const uint32_t chunk = blockIdx.x / kEmitParts, part = blockIdx.x % kEmitParts;
+    const uint32_t first_word = chunk * 64;
+    const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
+    if (threadIdx.x < 64) {
+        const uint32_t w = first_word + threadIdx.x;
+        const unsigned long long word = w < total_words ? args.out.mask[w] : 0ull;
+        uint32_t incl = (uint32_t)__popcll(word);
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (threadIdx.x >= d)
+                incl += up;
+        }
+        words[threadIdx.x] = word;
+        prefix[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0)
+            prefix[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t wlo = part * (64 / kEmitParts), whi = wlo + 64 / kEmitParts;
+    const uint32_t total = prefix[whi];
+    const uint32_t base = args.out.chunk_offset[chunk];
+    for (uint32_t r = prefix[wlo] + threadIdx.x; r < total; r += 256) {
+        uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
+#pragma unroll
+        for (int step = 0; step < 4; step++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= r)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        unsigned long long word = words[lo];
+        uint32_t k = r - prefix[lo], pos = 0;  // position of the k-th set bit
+#pragma unroll
+        for (uint32_t width = 32; width >= 1; width >>= 1) {
+            const uint32_t c = (uint32_t)__popcll(word & ((1ull << width) - 1ull));
+            if (k >= c) {
+                k -= c;
+                pos += width;
+                word >>= width;
+            }
+        }
+        const uint32_t i = (first_word + lo) * 64 + pos;
+        const float3 mb = args.mesh.b[i];
+        const uint32_t slot = __float_as_uint(mb.z) & kSlotMask;
+        uint32_t link;
+        const Mat34 local = load_local_model(args.xf, slot, link);
+        const Mat34 world = chain_model(args.xf, local, link);
+        const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
+        const size_t rank = (size_t)base + r;
+        args.out.visible_idx[rank] = i;  // componentOffset = i * componentSize  mesh.cpp:170
+        float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
+        bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+        bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+        bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+        const float tx = m.c3x + args.view.cam_offset[0];
+        const float ty = m.c3y + args.view.cam_offset[1];
+        const float tz = m.c3z + args.view.cam_offset[2];
+        args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+    }
 }
 
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
@@ -324,9 +421,8 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.xf = xf;
     a.view = vp;
     a.out = out;
-    a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
-    a.per_xcd = (a.nblocks + 7) / 8;
-    hipLaunchKernelGGL(emit_kernel, dim3(a.per_xcd * 8), dim3(kCullBlock), 0, stream, a);
+    const uint32_t nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    hipLaunchKernelGGL(emit_kernel, dim3(nchunks * kEmitParts), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

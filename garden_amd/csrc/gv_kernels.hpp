@@ -25,6 +25,7 @@ struct MeshMirror {
     const float4* a;  // (aabb.min.xyz, aabb.max.x)
     const float3* b;  // (aabb.max.y, aabb.max.z, bits: transform slot | kMesh* flags)
     uint32_t count;
+    uint32_t identity;  // most mesh slots i map to transform slot i: prefetch xf[i] beside mesh[i] (speed only)
 };
 
 struct HizDevice {
@@ -34,7 +35,8 @@ struct HizDevice {
     uint32_t width, height, mip_count;
 };
 
-constexpr uint32_t kCullBlock = 256;  // slots per cull/emit workgroup (4 waves)
+constexpr uint32_t kCullBlock = 256;   // slots per cull workgroup (4 waves)
+constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
 
 struct ViewParams {
     float planes[6][4];
@@ -49,18 +51,18 @@ struct ViewParams {
 
 struct ViewBuffers {
     unsigned long long* mask;  // one ballot word per 64 slots
-    uint32_t* block_count;     // visible per kCullBlock slots
-    uint32_t* block_offset;    // exclusive scan of block_count
+    uint32_t* chunk_count;     // visible per kEmitChunk slots (atomically summed by the cull workgroups, re-zeroed by scan)
+    uint32_t* chunk_offset;    // exclusive scan of chunk_count
     uint32_t* draw_count;      // total
     uint8_t* is_visible;       // per slot (main pass)
-    uint32_t* visible_idx;
+    uint32_t* visible_idx;     // compact records [0, draw_count), ascending slot order
     float* baked_model;        // 12 floats per record
     float* distance_sq;
 };
 
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream);
-hipError_t launch_scan(const ViewBuffers& out, uint32_t block_count, hipStream_t stream);
+hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
                        hipStream_t stream);
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,

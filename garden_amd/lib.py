@@ -204,7 +204,8 @@ class GpuVisibility:
         return n.value
 
     def fetch(self, view_index=0, write_back=True, occupancy=None):
-        """Returns copies: dict(visible_idx, baked_model[n,12], distance_sq, is_visible or None, draw_count)."""
+        """Returns copies: dict(visible_idx, baked_model[n,12], distance_sq, is_visible or None, draw_count).
+        Records arrive in ascending pool-slot order."""
         r = GvResult()
         self._check(self.lib.gv_results_fetch(self.ctx, view_index, 1 if write_back else 0, C.byref(r)))
         n = r.draw_count

@@ -120,8 +120,9 @@ typedef struct GvView {
 
 /* Host-visible results of one view: the SoA form of UnsortedBuffer::combinedMeshes[0..drawCount)
  * (render/mesh.hpp:191-217). Pointers are library-owned pinned memory, valid until the next
- * gv_cull on this context. Records are in ascending pool-slot order (deterministic); the
- * reference's order is fetch_add arrival order (mesh.cpp:177), i.e. unspecified. */
+ * gv_cull on this context. Records are in ascending pool-slot order, reproducible run to run; the
+ * reference's order is fetch_add arrival order (mesh.cpp:177), i.e. unspecified, and its consumers sort by
+ * distanceSq afterwards (mesh.cpp:548-551). */
 typedef struct GvResult {
     const uint32_t* visible_idx; /* pool slot; componentOffset = visible_idx * stride (mesh.cpp:170) */
     const float* baked_model;    /* 12 floats per record: c0.xyz c1.xyz c2.xyz c3.xyz (float4x3, mesh.cpp:171) */
@@ -184,9 +185,9 @@ const char* gv_last_error(const GvCtx* ctx);
 uint32_t gv_abi_version(void);
 
 typedef enum GvKernelId {
-    GV_K_CULL = 0,     /* frustum (+Hi-Z) test, visibility mask, per-block counts */
-    GV_K_SCAN = 1,     /* block-count scan */
-    GV_K_EMIT = 2,     /* compaction + record emission */
+    GV_K_CULL = 0,     /* frustum (+Hi-Z) test, isVisible, tile-compacted records, per-chunk counts */
+    GV_K_SCAN = 1,     /* chunk-count scan */
+    GV_K_EMIT = 2,     /* order-stable compaction of the record segments */
     GV_K_HIZ = 3,      /* pyramid reduction (all launches of one build) */
     GV_K_SWEEP = 4,    /* world-matrix sweep */
     GV_K_COUNT = 5

@@ -27,3 +27,4 @@ def gpu():
     vis = GpuVisibility(device=0, profile_events=True)
     yield vis
     vis.close()
+

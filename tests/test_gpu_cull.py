@@ -106,3 +106,33 @@ def test_world_matrices(gpu, oracle, mode):
     exp = oracle.world_matrices(sc.transforms, sc.entity_to_transform)
     assert np.max(np.abs(got - exp)) <= 1e-5  # the north-star tolerance
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # and in fact bit-exact
+
+
+def test_records_are_in_ascending_slot_order_on_dense_views(gpu, oracle):
+    """Order-stable compaction: an ortho view that sees most of the cube (many full tiles and chunks)."""
+    sc = scene.flat_scene(200_000, seed=5)
+    v = scene.cascade_view(size=20000.0, depth=40000.0)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [v])
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
+    assert got["draw_count"] == exp["draw_count"] > 100_000
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"])  # no host-side sort anywhere
+    assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+    assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+
+
+def test_count_only_view(gpu, oracle):
+    """emit_records = 0: isVisible + drawCount only (editor statistics path, mesh.cpp:540-544)."""
+    sc = scene.flat_scene(30_000, seed=9)
+    v = dict(scene.main_camera_view(), emit_records=0)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [v])
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
+    assert got["draw_count"] == exp["draw_count"] == gpu.result_count(0)
+    assert np.array_equal(got["is_visible"], sc.meshes["isVisible"])
