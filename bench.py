@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--entities", type=int, default=0, help="per-GPU entity count override")
+    ap.add_argument("--sweep", default="mfma", choices=["mfma", "valu"], help="cfg4 world-matrix sweep form")
+    ap.add_argument("--profile-all", action="store_true", help="hipEvents around every kernel (slower step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -131,7 +133,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from garden_amd import scene
-    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA
+    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU
     from garden_amd.multi import allgatherv_indices
 
     wl = WORKLOADS[args.workload]
@@ -140,7 +142,9 @@ def main():
     view = scene.main_camera_view(use_hiz=1 if wl["hiz"] else 0)
     depth = scene.synthetic_depth(HIZ_SIZE, HIZ_SIZE) if wl["hiz"] else None
 
-    vis = GpuVisibility(device=local_rank, profile_events=True)
+    # hipEvents bracket only the dominant kernel inside the timed region (each event record costs ~2 us of
+    # stream time); --profile-all brackets every kernel for the per-kernel breakdown in config.kernel_ms
+    vis = GpuVisibility(device=local_rank, profile_events=args.profile_all, profile_cull_only=not args.profile_all)
     t_up = time.perf_counter()
     vis.bind_transforms(sc.transforms, sc.entity_to_transform)
     vis.bind_pool(0, sc.meshes)
@@ -156,7 +160,7 @@ def main():
         if wl["hiz"]:
             vis.hiz_rebuild()
         if wl["sweep"]:
-            vis.sweep(GV_SWEEP_MFMA)
+            vis.sweep(GV_SWEEP_MFMA if args.sweep == "mfma" else GV_SWEEP_VALU)
         vis.cull(0, [view])
         if world > 1:
             count = vis.result_count(0)

@@ -216,6 +216,8 @@ struct KernelTimer {
         ctx->stats.launches[k]++;
         if (!(ctx->config.flags & GV_CONFIG_PROFILE_EVENTS))
             return;
+        if ((ctx->config.flags & GV_CONFIG_PROFILE_CULL_ONLY) && k != GV_K_CULL)
+            return;
         if (!ctx->free_events.empty()) {
             start = ctx->free_events.back().first;
             stop = ctx->free_events.back().second;

@@ -45,6 +45,15 @@ __device__ __forceinline__ Mat34 load_local_model(const TransformMirror& xf, uin
     link = __float_as_uint(c.z);
     return calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
 }
+// same, for the once-per-frame streaming read of a slot's own TRS
+__device__ __forceinline__ Mat34 stream_local_model(const TransformMirror& xf, uint32_t s, uint32_t& link)
+{
+    const float4 a = stream_load(&xf.a[s]);
+    const float4 b = stream_load(&xf.b[s]);
+    const float3 c = stream_load(&xf.c[s]);
+    link = __float_as_uint(c.z);
+    return calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
+}
 
 // transform.hpp:197-214: model = calcModel(self); while (parent) model = calcModel(parent) * model.
 // `m`/`link` are the already-loaded self model and link word of the starting slot.
@@ -105,15 +114,13 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
     }
     if (!bounded)
         return false;
-    float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0], znear = zc[0];
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        umin = u[k] < umin ? u[k] : umin;
-        umax = u[k] > umax ? u[k] : umax;
-        vmin = v[k] < vmin ? v[k] : vmin;
-        vmax = v[k] > vmax ? v[k] : vmax;
-        znear = zc[k] > znear ? zc[k] : znear;
-    }
+    // IEEE minNum/maxNum reductions (v_min3_f32 / v_max3_f32), as the oracle's fminf/fmaxf
+    const float umin0 = fminf(fminf(fminf(u[0], u[1]), fminf(u[2], u[3])), fminf(fminf(u[4], u[5]), fminf(u[6], u[7])));
+    const float umax0 = fmaxf(fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3])), fmaxf(fmaxf(u[4], u[5]), fmaxf(u[6], u[7])));
+    const float vmin0 = fminf(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), fminf(fminf(v[4], v[5]), fminf(v[6], v[7])));
+    const float vmax0 = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    const float znear = fmaxf(fmaxf(fmaxf(zc[0], zc[1]), fmaxf(zc[2], zc[3])), fmaxf(fmaxf(zc[4], zc[5]), fmaxf(zc[6], zc[7])));
+    float umin = umin0, umax = umax0, vmin = vmin0, vmax = vmax0;
     umin = clamp01(umin);
     umax = clamp01(umax);
     vmin = clamp01(vmin);
@@ -125,10 +132,17 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
     ix1 = min(ix1, W - 1);
     iy0 = min(iy0, H - 1);
     iy1 = min(iy1, H - 1);
-    uint32_t level = 0;
-    while (level + 1 < hz.mip_count &&
-           (((ix1 >> level) - (ix0 >> level)) > 1 || ((iy1 >> level) - (iy0 >> level)) > 1))
-        level++;
+    // Smallest level at which the pixel rect touches <= 2x2 texels. The oracle walks levels upward; per axis
+    // the condition (i1 >> L) - (i0 >> L) <= 1 is monotone in L and first holds at floor(log2(n)) or one above
+    // (n = i1 - i0 >= 2), so the level is max over the axes of that closed form.
+    auto axis_level = [](int i0, int i1) -> uint32_t {
+        const int n = i1 - i0;
+        if (n <= 1)
+            return 0u;
+        const uint32_t l = 31u - (uint32_t)__clz(n);
+        return ((i1 >> l) - (i0 >> l)) <= 1 ? l : l + 1u;
+    };
+    const uint32_t level = min(max(axis_level(ix0, ix1), axis_level(iy0, iy1)), hz.mip_count - 1u);
     const int lw = max((int)(hz.width >> level), 1), lh = max((int)(hz.height >> level), 1);
     const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
     const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
@@ -393,9 +407,23 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
         }
         const uint32_t i = (first_word + lo) * 64 + pos;
         const float3 mb = args.mesh.b[i];
+        // same speculation as the cull kernel: fetch transform slot i beside the mesh word
+        float4 pa = {}, pb = {};
+        float3 pc = {};
+        const bool prefetched = args.mesh.identity && i < args.xf.count;
+        if (prefetched) {
+            pa = args.xf.a[i];
+            pb = args.xf.b[i];
+            pc = args.xf.c[i];
+        }
         const uint32_t slot = __float_as_uint(mb.z) & kSlotMask;
-        uint32_t link;
-        const Mat34 local = load_local_model(args.xf, slot, link);
+        if (!(prefetched && slot == i)) {
+            pa = args.xf.a[slot];
+            pb = args.xf.b[slot];
+            pc = args.xf.c[slot];
+        }
+        const uint32_t link = __float_as_uint(pc.z);
+        const Mat34 local = calc_model(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z, pb.w, pa.w, pc.x, pc.y);
         const Mat34 world = chain_model(args.xf, local, link);
         const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
         const size_t rank = (size_t)base + r;
@@ -477,67 +505,106 @@ hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream
 }
 
 // ------------------------------------------------------------------------------------------------
-// world-matrix sweep, MFMA form: 4 lanes per transform slot, 16 slots per wave.
-// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per wave; block = lane >> 2; the A operand of
-// lane (block, i) is A[i][k], the B operand of lane (block, j) is B[k][j], D register r of lane
-// (block, j) is D[r][j]. Four issues k = 0..3 into one accumulator give parentModel * model with the
-// per-element order fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, +0)))) — the canonical chain. Lane j
-// therefore keeps column j of the running product in 4 registers, which is also its B operand for
-// the next ancestor: no lane movement between chain steps.
+// world-matrix sweep, MFMA form.
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per wave; block = lane >> 2; the A operand of lane
+// (block, i) is A[i][k], the B operand of lane (block, j) is B[k][j], D register r of lane (block, j) is D[r][j].
+// Four issues k = 0..3 into one accumulator give parentModel * model with the per-element order
+// fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, +0)))) — the canonical chain, bit-identical to the VALU form.
+//
+// Layout: the memory side is one lane per transform slot (coalesced 16/12-byte streams, one calcModel per
+// slot, 64 slots per wave); the matrix side is 4 lanes per slot. Local models cross from one to the other
+// through a per-wave LDS tile (13-word row pitch: conflict-free). A wave's 64 slots are multiplied in 4
+// rounds of 16; lane (e, j) keeps column j of the running product of slot 16r+e in 4 registers per round,
+// which is also its B operand for the next ancestor — no movement between chain steps.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kPitch = 13;
+
+__device__ __forceinline__ void lds_put_model(float* row, const Mat34& m)
+{
+    row[0] = m.c0x; row[1] = m.c0y; row[2] = m.c0z;
+    row[3] = m.c1x; row[4] = m.c1y; row[5] = m.c1z;
+    row[6] = m.c2x; row[7] = m.c2y; row[8] = m.c2z;
+    row[9] = m.c3x; row[10] = m.c3y; row[11] = m.c3z;
+}
 
 __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world,
                                                          uint32_t nblocks, uint32_t per_xcd)
 {
+    __shared__ float tile[4][64 * kPitch];  // one tile per wave
+    __shared__ uint32_t has_parent[4][64];
     const uint32_t lb = xcd_block(blockIdx.x, per_xcd);
     if (lb >= nblocks)
         return;
-    const uint32_t q = threadIdx.x & 3u;                     // column (as B/D) and row (as A) of this lane
-    const uint32_t s = lb * 64 + (threadIdx.x >> 2);         // 64 slots per 256-thread workgroup
-    const bool in_range = s < xf.count;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q = lane & 3u, e = lane >> 2;  // matrix side: column/row q of slot 16r + e
+    const uint32_t s = lb * 256 + threadIdx.x;    // memory side: this lane's slot
+    float* my_tile = tile[wave];
     uint32_t link = 0;
     Mat34 m = {};
+    const bool in_range = s < xf.count;
     if (in_range)
-        m = load_local_model(xf, s, link);
+        m = stream_local_model(xf, s, link);
     const bool live = in_range && (link & kXfLive);
-    // column q of the self model, with the bottom-row element
-    float x0 = q == 0 ? m.c0x : q == 1 ? m.c1x : q == 2 ? m.c2x : m.c3x;
-    float x1 = q == 0 ? m.c0y : q == 1 ? m.c1y : q == 2 ? m.c2y : m.c3y;
-    float x2 = q == 0 ? m.c0z : q == 1 ? m.c1z : q == 2 ? m.c2z : m.c3z;
-    float x3 = q == 3 ? 1.0f : 0.0f;
+    lds_put_model(my_tile + lane * kPitch, m);
+    __syncthreads();
+    float x[4][4];  // [round][row]: column q of the product of slot 16r + e (row 3 = bottom-row element)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float* row = my_tile + (16 * r + e) * kPitch + 3 * q;
+        x[r][0] = row[0];
+        x[r][1] = row[1];
+        x[r][2] = row[2];
+        x[r][3] = q == 3 ? 1.0f : 0.0f;
+    }
     uint32_t p = (live && (link & kXfWithAncestors)) ? (link & kSlotMask) : kSlotNone;
     for (uint32_t d = 0; d < xf.max_depth; d++) {
-        const bool has_parent = p != kSlotNone;
-        if (!__any(has_parent))
-            break;  // wave-uniform exit: MFMA ignores EXEC, so every lane takes every step
+        const bool has = p != kSlotNone;
+        if (!__syncthreads_or(has))
+            break;  // workgroup-uniform exit (MFMA ignores EXEC: every lane takes every step)
         uint32_t plink = kSlotNone;
         Mat34 pm = {};
-        if (has_parent)
+        if (has)
             pm = load_local_model(xf, p, plink);
-        // row q of the parent's local model: A[q][k], k = 0..3
-        const float a0 = q == 0 ? pm.c0x : q == 1 ? pm.c0y : q == 2 ? pm.c0z : 0.0f;
-        const float a1 = q == 0 ? pm.c1x : q == 1 ? pm.c1y : q == 2 ? pm.c1z : 0.0f;
-        const float a2 = q == 0 ? pm.c2x : q == 1 ? pm.c2y : q == 2 ? pm.c2z : 0.0f;
-        const float a3 = q == 0 ? pm.c3x : q == 1 ? pm.c3y : q == 2 ? pm.c3z : 1.0f;
-        f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, x1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, x2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, x3, acc, 0, 0, 0);
-        // lanes whose chain has ended keep their product untouched (bit-exact, incl. -0)
-        x0 = has_parent ? acc[0] : x0;
-        x1 = has_parent ? acc[1] : x1;
-        x2 = has_parent ? acc[2] : x2;
-        x3 = has_parent ? acc[3] : x3;
-        p = has_parent ? (plink & kSlotMask) : kSlotNone;
+        lds_put_model(my_tile + lane * kPitch, pm);
+        has_parent[wave][lane] = has ? 1u : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // row q of the parent's local model of slot 16r + e: A[q][k] = column k, row q
+            const float* prow = my_tile + (16 * r + e) * kPitch;
+            const float a0 = q < 3 ? prow[q] : 0.0f;
+            const float a1 = q < 3 ? prow[3 + q] : 0.0f;
+            const float a2 = q < 3 ? prow[6 + q] : 0.0f;
+            const float a3 = q < 3 ? prow[9 + q] : 1.0f;
+            const bool step = has_parent[wave][16 * r + e] != 0;
+            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x[r][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, x[r][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, x[r][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, x[r][3], acc, 0, 0, 0);
+            // slots whose chain has ended keep their product untouched (bit-exact, incl. -0)
+            x[r][0] = step ? acc[0] : x[r][0];
+            x[r][1] = step ? acc[1] : x[r][1];
+            x[r][2] = step ? acc[2] : x[r][2];
+            x[r][3] = step ? acc[3] : x[r][3];
+        }
+        p = has ? (plink & kSlotMask) : kSlotNone;
     }
-    if (in_range) {
-        // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per wave
-        float* dst = world + (size_t)s * 12 + q * 3;
-        dst[0] = live ? x0 : 0.0f;
-        dst[1] = live ? x1 : 0.0f;
-        dst[2] = live ? x2 : 0.0f;
+    // liveness of slot 16r + e on the matrix side
+    has_parent[wave][lane] = live ? 1u : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t slot = lb * 256 + wave * 64 + 16 * r + e;
+        if (slot < xf.count) {
+            const bool ok = has_parent[wave][16 * r + e] != 0;
+            // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per round
+            float* dst = world + (size_t)slot * 12 + q * 3;
+            dst[0] = ok ? x[r][0] : 0.0f;
+            dst[1] = ok ? x[r][1] : 0.0f;
+            dst[2] = ok ? x[r][2] : 0.0f;
+        }
     }
 }
 
@@ -545,7 +612,7 @@ hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream
 {
     if (xf.count == 0)
         return hipSuccess;
-    const uint32_t nblocks = (xf.count + 63) / 64, per_xcd = (nblocks + 7) / 8;
+    const uint32_t nblocks = (xf.count + 255) / 256, per_xcd = (nblocks + 7) / 8;
     hipLaunchKernelGGL(sweep_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, stream, xf, reinterpret_cast<float*>(world),
                        nblocks, per_xcd);
     return hipGetLastError();
@@ -632,7 +699,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
             mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
             mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
         } else {
-            const float4 v = *reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px);
+            const float4 v = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
             mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
             mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
         }

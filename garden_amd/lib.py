@@ -18,6 +18,7 @@ GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 5
 GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
 GV_CONFIG_PROFILE_EVENTS = 1
+GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA = 0, 1
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
@@ -138,9 +139,12 @@ def to_gv_view(v):
 class GpuVisibility:
     """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
 
-    def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False):
+    def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False):
         self.lib = load()
-        cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, GV_CONFIG_PROFILE_EVENTS if profile_events else 0)
+        flags = GV_CONFIG_PROFILE_EVENTS if (profile_events or profile_cull_only) else 0
+        if profile_cull_only:
+            flags |= GV_CONFIG_PROFILE_CULL_ONLY
+        cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, flags)
         self.ctx = C.c_void_p()
         rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))
         if rc != GV_OK:

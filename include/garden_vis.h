@@ -53,7 +53,9 @@ typedef enum GvHizRule {
 } GvHizRule;
 
 typedef enum GvConfigFlags {
-    GV_CONFIG_PROFILE_EVENTS = 1u << 0 /* bracket every kernel with hipEvents; durations via gv_stats */
+    GV_CONFIG_PROFILE_EVENTS = 1u << 0,   /* bracket every kernel with hipEvents; durations via gv_stats */
+    GV_CONFIG_PROFILE_CULL_ONLY = 1u << 1 /* with PROFILE_EVENTS: only GV_K_CULL is bracketed (2 events per view
+                                             instead of ~10 per frame: each event record costs ~2 us of stream time) */
 } GvConfigFlags;
 
 /* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as

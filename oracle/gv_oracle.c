@@ -290,12 +290,12 @@ int gvo_hiz_occluded(const GvoHiz* hz, const float vp[16], const float mn[3], co
             umin = umax = u;
             vmin = vmax = v;
             znear = zc;
-        } else {
-            umin = u < umin ? u : umin;
-            umax = u > umax ? u : umax;
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-            znear = zc > znear ? zc : znear;
+        } else { /* IEEE minNum/maxNum (a NaN operand is ignored), the semantics of v_min_f32/v_max_f32 */
+            umin = fminf(umin, u);
+            umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v);
+            vmax = fmaxf(vmax, v);
+            znear = fmaxf(znear, zc);
         }
     }
 #define CLAMP01(a) ((a) > 0.0f ? ((a) < 1.0f ? (a) : 1.0f) : 0.0f)
