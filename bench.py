@@ -123,13 +123,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # GV_BENCH_BACKEND=gloo lets N ranks share one GPU (exchange staged through the host): a functional check
+    # of the multi-rank path on a 1-GPU box, never a measurement.
+    backend = os.environ.get("GV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from garden_amd import scene
@@ -169,11 +175,28 @@ def main():
             return allgatherv_indices(idx_buf, count, dist)
         return None
 
+    def check_exchange():
+        """All ranks hold the same concatenated list; every index lies in its owner's tile range."""
+        gathered, counts = step()
+        g = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        c = counts.cpu().numpy()
+        assert g.shape[0] == int(c.sum())
+        off = 0
+        for r in range(world):
+            part = g[off:off + int(c[r])]
+            assert part.size == 0 or (part.min() >= r * n and part.max() < (r + 1) * n), f"rank {r} indices out of its tile"
+            if r == rank:
+                mine = vis.fetch(0, write_back=False, occupancy=n)["visible_idx"].astype(np.int64) + rank * n
+                assert np.array_equal(part, mine), "own shard differs from the local visible list"
+            off += int(c[r])
+        return int(c.sum())
+
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    gathered_total = check_exchange() if world > 1 else None
     for _ in range(args.warmup):
         step()
     fence()
@@ -239,7 +262,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
-                       "exchange": "all-gatherv of uint32 visible lists (RCCL)" if world > 1 else None,
+                       "exchange": f"all-gatherv of uint32 visible lists ({backend}), {gathered_total} indices gathered per rank" if world > 1 else None,
                        "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"]},
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes},
             "roofline": {"bound": "hbm", "kernel": "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -71,14 +71,9 @@ __device__ __forceinline__ Mat34 chain_model(const TransformMirror& xf, Mat34 m,
     return m;
 }
 
-// XCD-aware workgroup order: hardware deals blocks round-robin over the 8 XCDs, so give each XCD one
-// contiguous eighth of the slot range (neighbouring blocks share ancestor lines in that XCD's L2).
-// Speed only; any placement is correct. Returns the logical block, or >= nblocks for padding blocks.
-__device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t per_xcd)
-{
-    return (bid & 7u) * per_xcd + (bid >> 3);
-}
-
+// Workgroup -> slot range is linear. An XCD-contiguous remap (each XCD's L2 owning one eighth of the slot
+// range) was measured with flat and hierarchical scenes, random and Morton slot order: no effect (the streams
+// have no inter-workgroup reuse and ancestor lines are shared through the Infinity Cache anyway).
 __device__ __forceinline__ float hiz_min_texel(const HizDevice& hz, uint32_t level, uint32_t lw, uint32_t x, uint32_t y)
 {
     if (level == 0)
@@ -166,7 +161,6 @@ struct CullArgs {
     ViewParams view;
     ViewBuffers out;
     uint32_t nblocks;
-    uint32_t per_xcd;
 };
 
 // One mesh slot through the reference's filter chain (mesh.cpp:140-166): candidate / empty-AABB / transform /
@@ -228,9 +222,7 @@ __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const Tran
 template <bool HIZ, bool IDENT>
 __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 {
-    const uint32_t lb = xcd_block(blockIdx.x, args.per_xcd);
-    if (lb >= args.nblocks)
-        return;
+    const uint32_t lb = blockIdx.x;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool visible = false;
@@ -275,8 +267,7 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.view = vp;
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
-    a.per_xcd = (a.nblocks + 7) / 8;
-    const dim3 grid(a.per_xcd * 8), block(kCullBlock);
+    const dim3 grid(a.nblocks), block(kCullBlock);
     if (vp.use_hiz && mesh.identity)
         hipLaunchKernelGGL((cull_kernel<true, true>), grid, block, 0, stream, a);
     else if (vp.use_hiz)
@@ -472,12 +463,9 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
 // ------------------------------------------------------------------------------------------------
 // world-matrix sweep (camera = 0), VALU form: one lane per transform slot
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror xf, float4* __restrict__ world,
-                                                         uint32_t nblocks, uint32_t per_xcd)
+__global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror xf, float4* __restrict__ world)
 {
-    const uint32_t lb = xcd_block(blockIdx.x, per_xcd);
-    if (lb >= nblocks)
-        return;
+    const uint32_t lb = blockIdx.x;
     const uint32_t s = lb * 256 + threadIdx.x;
     if (s >= xf.count)
         return;
@@ -499,8 +487,7 @@ hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream
 {
     if (xf.count == 0)
         return hipSuccess;
-    const uint32_t nblocks = (xf.count + 255) / 256, per_xcd = (nblocks + 7) / 8;
-    hipLaunchKernelGGL(sweep_valu_kernel, dim3(per_xcd * 8), dim3(256), 0, stream, xf, world, nblocks, per_xcd);
+    hipLaunchKernelGGL(sweep_valu_kernel, dim3((xf.count + 255) / 256), dim3(256), 0, stream, xf, world);
     return hipGetLastError();
 }
 
@@ -528,14 +515,11 @@ __device__ __forceinline__ void lds_put_model(float* row, const Mat34& m)
     row[9] = m.c3x; row[10] = m.c3y; row[11] = m.c3z;
 }
 
-__global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world,
-                                                         uint32_t nblocks, uint32_t per_xcd)
+__global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world)
 {
     __shared__ float tile[4][64 * kPitch];  // one tile per wave
     __shared__ uint32_t has_parent[4][64];
-    const uint32_t lb = xcd_block(blockIdx.x, per_xcd);
-    if (lb >= nblocks)
-        return;
+    const uint32_t lb = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t q = lane & 3u, e = lane >> 2;  // matrix side: column/row q of slot 16r + e
     const uint32_t s = lb * 256 + threadIdx.x;    // memory side: this lane's slot
@@ -612,9 +596,8 @@ hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream
 {
     if (xf.count == 0)
         return hipSuccess;
-    const uint32_t nblocks = (xf.count + 255) / 256, per_xcd = (nblocks + 7) / 8;
-    hipLaunchKernelGGL(sweep_mfma_kernel, dim3(per_xcd * 8), dim3(256), 0, stream, xf, reinterpret_cast<float*>(world),
-                       nblocks, per_xcd);
+    hipLaunchKernelGGL(sweep_mfma_kernel, dim3((xf.count + 255) / 256), dim3(256), 0, stream, xf,
+                       reinterpret_cast<float*>(world));
     return hipGetLastError();
 }
 

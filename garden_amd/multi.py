@@ -7,6 +7,8 @@ CPU tests), with one broadcast per root.
 """
 import torch
 
+_uneven_all_gather_ok = True
+
 
 def tile_of_positions(positions, side, grid):
     """Spatial tile id of each root position for a `grid` = (gx, gy, gz) cut of the world cube."""
@@ -25,6 +27,11 @@ def allgatherv_indices(idx_buf, count, dist, group=None):
     (gathered 1-D tensor of all ranks' lists in rank order, counts tensor)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    backend = dist.get_backend(group)
+    if backend != "nccl" and idx_buf.is_cuda:
+        # test path only (gloo has no device collectives): stage through host memory
+        out, counts = allgatherv_indices(idx_buf[:count].cpu(), count, dist, group)
+        return out.to(idx_buf.device), counts.to(idx_buf.device)
     dev = idx_buf.device
     my_count = torch.tensor([count], dtype=torch.int64, device=dev)
     counts = torch.empty(world, dtype=torch.int64, device=dev)
@@ -36,16 +43,19 @@ def allgatherv_indices(idx_buf, count, dist, group=None):
     for c in counts_h:
         offs.append(offs[-1] + int(c))
     pieces = [out[offs[r]:offs[r + 1]] for r in range(world)]
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        dist.all_gather(pieces, idx_buf[:count], group=group)  # uneven sizes -> grouped per-root broadcasts
-    else:
-        pieces[rank].copy_(idx_buf[:count])
-        works = []
-        for r in range(world):
-            if counts_h[r]:
-                works.append(dist.broadcast(pieces[r], src=dist.get_global_rank(group, r) if group else r,
-                                            group=group, async_op=True))
-        for w in works:
-            w.wait()
+    global _uneven_all_gather_ok
+    if backend == "nccl" and _uneven_all_gather_ok:
+        try:
+            dist.all_gather(pieces, idx_buf[:count], group=group)  # uneven sizes -> grouped per-root broadcasts
+            return out, counts
+        except (RuntimeError, ValueError):
+            _uneven_all_gather_ok = False  # this torch build wants equal sizes: one broadcast per root instead
+    pieces[rank].copy_(idx_buf[:count])
+    works = []
+    for r in range(world):
+        if counts_h[r]:
+            works.append(dist.broadcast(pieces[r], src=dist.get_global_rank(group, r) if group else r,
+                                        group=group, async_op=True))
+    for w in works:
+        w.wait()
     return out, counts
