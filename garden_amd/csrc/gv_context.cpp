@@ -805,6 +805,14 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         hz.height = ctx->hiz_h;
         hz.mip_count = ctx->hiz_mips;
     }
+    // Views that share cameraPosition (the main camera and its shadow cascades: mesh.cpp:809-843 passes the same
+    // cameraPosition to every prepareMeshes) are culled in ONE pass over the streams; Hi-Z only on view 0.
+    bool batched = view_count > 1 && view_count <= kMaxBatchViews && p.occupancy > 0;
+    for (uint32_t v = 1; v < view_count && batched; v++)
+        batched = memcmp(views[v].camera_position, views[0].camera_position, 12) == 0 && !views[v].use_hiz;
+    ViewParams vps[GV_MAX_VIEWS];
+    ViewBuffers vbs[GV_MAX_VIEWS];
+    const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
     for (uint32_t v = 0; v < view_count; v++) {
         ViewState& vs = ctx->views[v];
         const bool emit = views[v].emit_records != 0;
@@ -816,25 +824,29 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.main_pass = views[v].shadow_pass < 0;
         vs.emitted = emit;
         vs.valid = true;
-        ViewParams vp;
-        build_view_params(views[v], &vp);
-        const ViewBuffers vb = view_buffers(vs);
-        const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
-        if (p.occupancy == 0) {
+        build_view_params(views[v], &vps[v]);
+        vbs[v] = view_buffers(vs);
+        if (p.occupancy == 0)
             GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
-            continue;
-        }
-        {
+    }
+    if (p.occupancy != 0) {
+        if (batched) {
             KernelTimer t(ctx, GV_K_CULL);
-            GV_HIP(ctx, launch_cull(mesh, xf, hz, vp, vb, ctx->stream));
+            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream));
         }
-        {
-            KernelTimer t(ctx, GV_K_SCAN);
-            GV_HIP(ctx, launch_scan(vb, chunks, ctx->stream));
-        }
-        if (emit) {
-            KernelTimer t(ctx, GV_K_EMIT);
-            GV_HIP(ctx, launch_emit(mesh, xf, vp, vb, ctx->stream));
+        for (uint32_t v = 0; v < view_count; v++) {
+            if (!batched) {
+                KernelTimer t(ctx, GV_K_CULL);
+                GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream));
+            }
+            {
+                KernelTimer t(ctx, GV_K_SCAN);
+                GV_HIP(ctx, launch_scan(vbs[v], chunks, ctx->stream));
+            }
+            if (ctx->views[v].emitted) {
+                KernelTimer t(ctx, GV_K_EMIT);
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream));
+            }
         }
     }
     for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)

@@ -163,12 +163,13 @@ struct CullArgs {
     uint32_t nblocks;
 };
 
-// One mesh slot through the reference's filter chain (mesh.cpp:140-166): candidate / empty-AABB / transform /
-// isActive checks, parent-chain model, camera translate, 8-corner frustum test. On survival `m` holds the
-// camera-relative model (bakedModel) and `c` its corners.
+// One mesh slot through the reference's filter chain (mesh.cpp:140-157): candidate / empty-AABB / transform /
+// isActive checks, parent-chain model, camera translate, 8 corners. Returns false when the slot is filtered out;
+// otherwise `m` holds the camera-relative model (bakedModel) and `c` its corners. Nothing here depends on the
+// frustum, so shadow passes that share cameraPosition with the main pass (mesh.cpp:809-843) share this work.
 template <bool IDENT>
-__device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& view,
-                                              uint32_t i, Mat34& m, Corners& c)
+__device__ __forceinline__ bool prepare_slot(const MeshMirror& mesh, const TransformMirror& xf, const float (&cam)[3],
+                                             uint32_t i, Mat34& m, Corners& c)
 {
     const float4 ma = stream_load(&mesh.a[i]);
     const float3 mb = stream_load(&mesh.b[i]);
@@ -200,17 +201,28 @@ __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const Tran
     const Mat34 local = calc_model(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z, pb.w, pa.w, pc.x, pc.y);
     const Mat34 world = chain_model(xf, local, link);
     // math::translate(-cameraPosition, model)  transform.hpp:211,213
-    m = translated(world, view.cam[0], view.cam[1], view.cam[2]);
+    m = translated(world, cam[0], cam[1], cam[2]);
     aabb_corners(m, mnx, mny, mnz, mxx, mxy, mxz, c);
-    // default getReadyMeshesAsync predicate (render/mesh.hpp:142-146). Fully unrolled with a wave-uniform
-    // guard so the plane coefficients stay in SGPRs (a runtime-indexed kernarg array would go to LDS/scratch).
+    return true;
+}
+
+// default getReadyMeshesAsync predicate (render/mesh.hpp:142-146). Fully unrolled with a wave-uniform guard so
+// the plane coefficients stay in SGPRs (a runtime-indexed kernarg array would be copied to LDS/scratch).
+__device__ __forceinline__ bool behind_frustum(const Corners& c, const float (&planes)[6][4], uint32_t plane_count)
+{
     bool behind = false;
 #pragma unroll
     for (uint32_t p = 0; p < 6; p++)
-        if (p < view.plane_count)
-            behind = behind || all_behind_plane(c, view.planes[p][0], view.planes[p][1], view.planes[p][2],
-                                                view.planes[p][3]);
-    return !behind;
+        if (p < plane_count)
+            behind = behind || all_behind_plane(c, planes[p][0], planes[p][1], planes[p][2], planes[p][3]);
+    return behind;
+}
+
+template <bool IDENT>
+__device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& view,
+                                              uint32_t i, Mat34& m, Corners& c)
+{
+    return prepare_slot<IDENT>(mesh, xf, view.cam, i, m, c) && !behind_frustum(c, view.planes, view.plane_count);
 }
 
 // K1: one lane per mesh slot: visibility, isVisible byte, one ballot word per wave, per-chunk counts.
@@ -276,6 +288,103 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
         hipLaunchKernelGGL((cull_kernel<false, true>), grid, block, 0, stream, a);
     else
         hipLaunchKernelGGL((cull_kernel<false, false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// K1, batched over views that share cameraPosition (main camera + shadow cascades, mesh.cpp:795-903): the
+// streams are read and the model / corners computed ONCE; each view then costs its plane tests (+ the Hi-Z query
+// on view 0 only) and its own outputs. The reference re-runs the whole loop per pass (mesh.cpp:809-843).
+struct MultiCullArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    HizDevice hiz;
+    float cam[3];
+    float vp0[16];          // view 0's viewProj (Hi-Z query)
+    uint32_t use_hiz0;
+    uint32_t nviews;
+    MultiViewPlanes planes[kMaxBatchViews];
+    ViewBuffers outs[kMaxBatchViews];
+};
+
+template <bool HIZ, bool IDENT>
+__global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
+{
+    const uint32_t lb = blockIdx.x;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool in_range = i < args.mesh.count;
+    Mat34 m;
+    Corners c;
+    const bool candidate = in_range && prepare_slot<IDENT>(args.mesh, args.xf, args.cam, i, m, c);
+    __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
+#pragma unroll
+    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
+        if (v < args.nviews) {  // uniform
+            bool visible = candidate && !behind_frustum(c, args.planes[v].planes, args.planes[v].plane_count);
+            if (HIZ && v == 0 && visible)
+                visible = !hiz_occluded(args.hiz, args.vp0, c);
+            if (args.planes[v].write_is_visible && in_range)
+                args.outs[v].is_visible[i] = visible ? 1 : 0;
+            const unsigned long long word = __ballot(visible);
+            if (lane == 0) {
+                args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+                wave_count[v][wave] = (uint32_t)__popcll(word);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < args.nviews) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCullBlock / 64; w++)
+            total += wave_count[threadIdx.x][w];
+        if (total) {
+            // outs[] indexed by a lane-varying view: pick the pointer with uniform compares (kernarg stays in SGPRs)
+            uint32_t* counts = nullptr;
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (threadIdx.x == v)
+                    counts = args.outs[v].chunk_count;
+            atomicAdd(&counts[lb / (kEmitChunk / kCullBlock)], total);
+        }
+    }
+}
+
+hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    if (nviews == 0 || nviews > kMaxBatchViews)
+        return hipErrorInvalidValue;
+    MultiCullArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    for (int k = 0; k < 3; k++)
+        a.cam[k] = views[0].cam[k];
+    for (int k = 0; k < 16; k++)
+        a.vp0[k] = views[0].vp[k];
+    a.use_hiz0 = views[0].use_hiz;
+    a.nviews = nviews;
+    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
+        const ViewParams& src = views[v < nviews ? v : 0];
+        for (int p = 0; p < 6; p++)
+            for (int k = 0; k < 4; k++)
+                a.planes[v].planes[p][k] = src.planes[p][k];
+        a.planes[v].plane_count = src.plane_count;
+        a.planes[v].write_is_visible = src.write_is_visible;
+        a.outs[v] = outs[v < nviews ? v : 0];
+    }
+    const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
+    if (a.use_hiz0 && mesh.identity)
+        hipLaunchKernelGGL((cull_multi_kernel<true, true>), grid, block, 0, stream, a);
+    else if (a.use_hiz0)
+        hipLaunchKernelGGL((cull_multi_kernel<true, false>), grid, block, 0, stream, a);
+    else if (mesh.identity)
+        hipLaunchKernelGGL((cull_multi_kernel<false, true>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((cull_multi_kernel<false, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

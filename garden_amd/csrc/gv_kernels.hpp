@@ -62,6 +62,15 @@ struct ViewBuffers {
 
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream);
+// One pass over the streams for up to kMaxBatchViews views that share views[0].cam (Hi-Z only on view 0).
+constexpr uint32_t kMaxBatchViews = 8;
+struct MultiViewPlanes {
+    float planes[6][4];
+    uint32_t plane_count;
+    uint32_t write_is_visible;
+};
+hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream);
 hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
                        hipStream_t stream);

@@ -136,3 +136,35 @@ def test_count_only_view(gpu, oracle):
     exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
     assert got["draw_count"] == exp["draw_count"] == gpu.result_count(0)
     assert np.array_equal(got["is_visible"], sc.meshes["isVisible"])
+
+
+def test_batched_views_equal_separate_passes(gpu, oracle):
+    """Main camera (+ Hi-Z) and 4 shadow cascades in one pass over the streams == each view on its own; and views
+    with different cameraPosition (not batchable) still go through the per-view path."""
+    sc = scene.hierarchy_scene(60_000, depth=4, fanout=10)
+    depth = scene.synthetic_depth(512, 256)
+    hz = oracle.Hiz(depth)
+    views = [scene.main_camera_view(use_hiz=1)] + [scene.cascade_view(index=k, size=3000.0 + 500 * k) for k in range(4)]
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.hiz_build(depth)
+    gpu.stats_reset()
+    gpu.cull(0, views)
+    assert gpu.stats()["launches"]["cull"] == 1  # one batched launch for the 5 views
+    for vi, v in enumerate(views):
+        sc.meshes["isVisible"] = 7
+        got = gpu.fetch(vi, write_back=True, occupancy=sc.count)
+        got_vis = sc.meshes["isVisible"].copy()
+        sc.meshes["isVisible"] = 7
+        exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v, hiz=hz if v["use_hiz"] else None)
+        assert_same(got, got_vis, exp, sc.meshes["isVisible"].copy(), main_pass=v["shadow_pass"] < 0)
+    moved = [scene.main_camera_view(), scene.main_camera_view(camera_position=(100.0, 5.0, -40.0))]
+    gpu.stats_reset()
+    gpu.cull(0, moved)
+    assert gpu.stats()["launches"]["cull"] == 2  # different cameraPosition: corners differ, one pass per view
+    for vi, v in enumerate(moved):
+        got = gpu.fetch(vi, write_back=False, occupancy=sc.count)
+        exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
+        assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
