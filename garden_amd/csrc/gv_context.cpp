@@ -129,6 +129,9 @@ struct ViewState {
     DeviceBuf<uint8_t> is_visible;
     DeviceBuf<uint32_t> visible_idx;
     DeviceBuf<float> baked_model, distance_sq;
+    // gv_sort: alternate record set + radix-sort scratch (allocated on first use)
+    DeviceBuf<uint32_t> alt_idx, sort_keys[2], sort_vals[2], sort_hist;
+    DeviceBuf<float> alt_model, alt_dist;
     PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
     PinnedBuf<float> h_baked_model, h_distance_sq;
     PinnedBuf<uint8_t> h_is_visible;
@@ -679,6 +682,8 @@ void gv_destroy(GvCtx* ctx)
     for (auto& v : ctx->views) {
         v.mask.release(); v.chunk_count.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
+        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release();
+        for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release();
     }
@@ -953,6 +958,51 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, launch_copy_idx(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
                                 index_base, ctx->stream));
+    return GV_OK;
+}
+
+int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
+        return ctx->fail(GV_E_ARG, "gv_sort: view %u has no emitted records", view_index);
+    ViewState& vs = ctx->views[view_index];
+    if (vs.occupancy == 0)
+        return GV_OK;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
+    const size_t nblocks = (n + 4095) / 4096;
+    GV_HIP(ctx, vs.alt_idx.reserve(n));
+    GV_HIP(ctx, vs.alt_model.reserve(n * 12));
+    GV_HIP(ctx, vs.alt_dist.reserve(n));
+    for (int k = 0; k < 2; k++) {
+        GV_HIP(ctx, vs.sort_keys[k].reserve(n));
+        GV_HIP(ctx, vs.sort_vals[k].reserve(n));
+    }
+    GV_HIP(ctx, vs.sort_hist.reserve(256 * nblocks + 256));
+    SortBuffers b;
+    b.count = vs.draw_count.ptr;
+    b.idx_in = vs.visible_idx.ptr;
+    b.model_in = vs.baked_model.ptr;
+    b.dist_in = vs.distance_sq.ptr;
+    b.idx_out = vs.alt_idx.ptr;
+    b.model_out = vs.alt_model.ptr;
+    b.dist_out = vs.alt_dist.ptr;
+    for (int k = 0; k < 2; k++) {
+        b.keys[k] = vs.sort_keys[k].ptr;
+        b.vals[k] = vs.sort_vals[k].ptr;
+    }
+    b.hist = vs.sort_hist.ptr + 256;
+    b.bin_total = vs.sort_hist.ptr;
+    {
+        KernelTimer t(ctx, GV_K_SORT);
+        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending != 0, ctx->stream));
+    }
+    // the sorted records now live in the alternate set: swap it in
+    std::swap(vs.visible_idx, vs.alt_idx);
+    std::swap(vs.baked_model, vs.alt_model);
+    std::swap(vs.distance_sq, vs.alt_dist);
     return GV_OK;
 }
 

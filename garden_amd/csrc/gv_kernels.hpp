@@ -77,6 +77,22 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                            hipStream_t stream);
 
+// sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
+struct SortBuffers {
+    const uint32_t* count;  // device draw_count
+    const uint32_t* idx_in;
+    const float* model_in;
+    const float* dist_in;
+    uint32_t* idx_out;
+    float* model_out;
+    float* dist_out;
+    uint32_t* keys[2];
+    uint32_t* vals[2];
+    uint32_t* hist;       // 256 * ceil(capacity / 4096), bin-major
+    uint32_t* bin_total;  // 256
+};
+hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
+
 // world matrices (camera = 0) of every transform slot: 3 float4 per slot (float4x3 order)
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream);
 hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream);

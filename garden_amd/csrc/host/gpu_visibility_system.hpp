@@ -53,6 +53,9 @@ public:
     bool isEnabled = true;
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
+    // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
+    // (front to back), so the engine's std::sort over combinedMeshes can be dropped
+    bool sortOnDevice = true;
 
     explicit GpuVisibilitySystem(int device = 0, bool profile = false)
     {
@@ -197,6 +200,9 @@ private:
                 views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
                                          (int8_t)s, false, emitRecords));
             check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
+            if (emitRecords && sortOnDevice)
+                for (uint32_t v = 0; v < views.size(); v++)
+                    check(gv_sort(ctx, v, 0), "gv_sort");  // opaque/unsorted: operator< (render/mesh.hpp:196)
             auto& sb = shadowBuffers[p];
             while (sb.size() + 1 < views.size())
                 sb.push_back(new UnsortedBuffer());

@@ -14,7 +14,7 @@ from .pools import mesh_layout_offsets, transform_layout_offsets
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgarden_vis.so")
 
-GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 5
+GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 6
 GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
 GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
 GV_CONFIG_PROFILE_EVENTS = 1
@@ -22,7 +22,7 @@ GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA = 0, 1
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
-KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep"]
+KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep", "sort"]
 
 
 class GvConfig(C.Structure):
@@ -70,7 +70,7 @@ class GvError(RuntimeError):
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
-    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_sweep", "gv_get_world",
+    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream",
 ]
@@ -106,6 +106,7 @@ def load():
     lib.gv_result_count.argtypes = [P, u32, C.POINTER(u32)]
     lib.gv_results_device.argtypes = [P, u32, C.POINTER(GvDeviceResult)]
     lib.gv_results_copy_idx_device.argtypes = [P, u32, P, u32, u32]
+    lib.gv_sort.argtypes = [P, u32, C.c_int]
     lib.gv_sweep.argtypes = [P, u32]
     lib.gv_get_world.argtypes = [P, u32, u32, P]
     lib.gv_hiz_build.argtypes = [P, P, u32, u32, u32]
@@ -234,6 +235,9 @@ class GpuVisibility:
 
     def copy_idx_device(self, view_index, dst_ptr, capacity, index_base=0):
         self._check(self.lib.gv_results_copy_idx_device(self.ctx, view_index, dst_ptr, capacity, index_base))
+
+    def sort(self, view_index=0, descending=False):
+        self._check(self.lib.gv_sort(self.ctx, view_index, 1 if descending else 0))
 
     # ---- world matrices ----
     def sweep(self, mode=GV_SWEEP_VALU):

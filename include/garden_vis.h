@@ -159,6 +159,12 @@ int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out);
 int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                uint32_t index_base);
 
+/* Sorts view `view_index`'s compact records on the device by distanceSq: ascending (descending == 0) as sortMeshes
+ * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
+ * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: ties keep ascending pool-slot order.
+ * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. */
+int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
+
 /* ---- world matrices: TransformComponent::calcModel() with cameraPosition = 0 for every transform
  * slot (transform.hpp:197-214), cached on the device ---- */
 typedef enum GvSweepMode {
@@ -192,7 +198,8 @@ typedef enum GvKernelId {
     GV_K_EMIT = 2,     /* order-stable compaction of the record segments */
     GV_K_HIZ = 3,      /* pyramid reduction (all launches of one build) */
     GV_K_SWEEP = 4,    /* world-matrix sweep */
-    GV_K_COUNT = 5
+    GV_K_SORT = 5,     /* radix sort of the records (all launches of one gv_sort) */
+    GV_K_COUNT = 6
 } GvKernelId;
 typedef struct GvStats {
     uint64_t launches[GV_K_COUNT];   /* kernel launches since gv_stats_reset */

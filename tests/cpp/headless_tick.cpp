@@ -43,6 +43,14 @@ struct Snapshot {
     uint32_t drawCount = 0, instanceCount = 0;
 };
 
+static bool isSortedByDistance(const UnsortedBuffer* buffer)
+{
+    for (uint32_t k = 1; k < buffer->drawCount; k++)
+        if (buffer->combinedMeshes[k] < buffer->combinedMeshes[k - 1])  // operator< render/mesh.hpp:196
+            return false;
+    return true;
+}
+
 static Snapshot snapshot(OpaqueMeshSystem* meshSystem, const UnsortedBuffer* buffer)
 {
     Snapshot s;
@@ -181,8 +189,13 @@ int main(int argc, char** argv)
                 for (uint32_t i = 0; i < meshSystem->getComponents().getOccupancy(); i++)
                     meshSystem->getComponents().getData()[i].isVisible = false;
                 seconds += run(false, true, ticks);
+                const bool sorted = isSortedByDistance(gpu->getUnsortedBuffers()[0]);  // gv_sort == sortMeshes order
                 Snapshot b = snapshot(meshSystem, gpu->getUnsortedBuffers()[0]);
                 ok = same(a, b, why);
+                if (ok && !sorted) {
+                    ok = false;
+                    why = "combinedMeshes not ascending by distanceSq after gv_sort";
+                }
                 drawCount = b.drawCount;
             } else {
                 seconds += run(mode == "cpu", mode == "gpu", ticks);

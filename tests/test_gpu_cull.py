@@ -168,3 +168,25 @@ def test_batched_views_equal_separate_passes(gpu, oracle):
         exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
         assert np.array_equal(got["visible_idx"], exp["visible_idx"])
         assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+
+
+@pytest.mark.parametrize("n,descending,d2", [(100_000, False, 0), (100_000, True, 0), (300_000, False, 0), (5_000, True, 1), (70, False, 0)])
+def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
+    """gv_sort == sortMeshes (mesh.cpp:265-328): ascending distanceSq for unsorted buffers, descending for the
+    sorted ones; the oracle breaks ties by slot, and so does the stable radix sort."""
+    sc = scene.flat_scene(n, seed=3 + n)
+    v = scene.cascade_view(size=30000.0, depth=60000.0) if n >= 100_000 else scene.main_camera_view()
+    v = dict(v, distance_2d=d2)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [v])
+    gpu.sort(0, descending=descending)
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v, sort="descending" if descending else "ascending")
+    assert got["draw_count"] == exp["draw_count"] > 0
+    d = got["distance_sq"]
+    assert np.all(d[:-1] >= d[1:]) if descending else np.all(d[:-1] <= d[1:])
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+    assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+    assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
