@@ -200,3 +200,26 @@ def synthetic_depth(width, height, seed=SEED, rects=256):
         z = np.float32(rng.uniform(0.02, 0.5))
         np.maximum(d[y:y + h, x:x + w], z, out=d[y:y + h, x:x + w])
     return d
+
+
+def shuffled_scene(sc, fraction=1.0, seed=SEED, drop_transforms=0.0):
+    """Same entities, but the transform pool is permuted relative to the mesh pool (ECS pools are independent:
+    an entity's mesh slot and transform slot need not match) for `fraction` of the slots; `drop_transforms`
+    removes that share of transforms altogether (mesh without a TransformComponent: mesh.cpp:149-155)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5F1E))
+    n = sc.count
+    perm = np.arange(n)
+    k = int(n * fraction)
+    if k > 1:
+        chosen = rng.choice(n, size=k, replace=False)
+        perm[chosen] = chosen[rng.permutation(k)]
+    transforms = sc.transforms[perm].copy()  # new transform slot j holds the old slot perm[j]
+    if drop_transforms > 0:
+        gone = rng.random(n) < drop_transforms
+        has_children = np.isin(transforms["entity"], sc.transforms["parent"][sc.transforms["parent"] != 0])
+        gone &= ~has_children
+        transforms["entity"][gone] = 0
+    e2t = np.full(n + 1, GV_NONE, dtype=np.uint32)
+    live = transforms["entity"] != 0
+    e2t[transforms["entity"][live]] = np.nonzero(live)[0].astype(np.uint32)
+    return Scene(sc.meshes.copy(), transforms, e2t)

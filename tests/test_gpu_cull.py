@@ -190,3 +190,88 @@ def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     assert np.array_equal(got["visible_idx"], exp["visible_idx"])
     assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
     assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+
+
+@pytest.mark.parametrize("fraction,hier", [(1.0, False), (1.0, True), (0.05, False), (0.3, True)])
+def test_mesh_and_transform_pools_in_different_order(gpu, oracle, fraction, hier):
+    """ECS pools are independent: mesh slot i need not map to transform slot i. fraction = 1 exercises the
+    non-speculating kernels, small fractions the mis-speculation reload inside the speculating ones; 2 % of the
+    meshes have no TransformComponent at all (mesh.cpp:149-155)."""
+    base = scene.hierarchy_scene(40_000, depth=4, fanout=7) if hier else scene.flat_scene(40_000, seed=21)
+    sc = scene.shuffled_scene(base, fraction=fraction, drop_transforms=0.02)
+    depth = scene.synthetic_depth(256, 256)
+    views = [scene.main_camera_view(use_hiz=1), scene.cascade_view(index=1)]
+    res = run_both(gpu, oracle, sc, views, hiz_depth=depth)
+    assert res[0][2]["draw_count"] > 0
+    assert_same(*res[0], main_pass=True)
+    assert_same(*res[1], main_pass=False)
+    gpu.sweep(1)
+    world = gpu.get_world(0, sc.count)
+    assert np.array_equal(world.view(np.uint32), oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
+
+
+def test_dirty_ranges_and_rebinding(gpu, oracle):
+    """gv_mark_dirty: only the marked transform / mesh ranges are re-gathered; unmarked edits must NOT show up
+    (the mirror is authoritative until told otherwise), a hierarchy mark rebuilds everything."""
+    sc = scene.hierarchy_scene(20_000, depth=3, fanout=8)
+    v = scene.main_camera_view()
+    from garden_amd.lib import GV_DIRTY_HIERARCHY, GV_DIRTY_MESH, GV_DIRTY_TRANSFORM
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+
+    def cull_and_compare(expect_equal=True):
+        gpu.cull(0, [v])
+        got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+        exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v)
+        same = got["draw_count"] == exp["draw_count"] and np.array_equal(got["visible_idx"], exp["visible_idx"]) and \
+            np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+        assert same == expect_equal
+    cull_and_compare()
+    rng = np.random.default_rng(4)
+    sc.transforms["position"][5000:9000, :3] += rng.uniform(-500, 500, (4000, 3)).astype(np.float32)
+    cull_and_compare(expect_equal=False)          # edited but not marked: the mirror still holds the old TRS
+    gpu.mark_dirty(GV_DIRTY_TRANSFORM, 5000, 4000)
+    cull_and_compare()
+    sc.meshes["aabbMax"][100:300, :3] *= 3
+    sc.meshes["isEnabled"][300:350] = 0
+    gpu.mark_dirty(GV_DIRTY_MESH, 100, 250, pool_id=0)
+    cull_and_compare()
+    sc.transforms["parent"][15000:15100] = sc.transforms["entity"][10:110]  # re-parent (setParent, transform.cpp:130-195)
+    gpu.mark_dirty(GV_DIRTY_HIERARCHY, 0, 0)
+    cull_and_compare()
+    assert gpu.stats()["max_depth"] >= 2
+
+
+def test_empty_and_tiny_pools_and_derived_stride(gpu, oracle):
+    from garden_amd.pools import MESH_DTYPE, TRANSFORM_DTYPE
+    v = scene.main_camera_view()
+    empty = scene.Scene(np.zeros(0, MESH_DTYPE), np.zeros(0, TRANSFORM_DTYPE), np.full(1, 0xFFFFFFFF, np.uint32))
+    gpu.bind_transforms(empty.transforms, empty.entity_to_transform)
+    gpu.bind_pool(0, empty.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [v])
+    assert gpu.fetch(0, occupancy=0)["draw_count"] == 0
+    wide = scene.flat_scene(5000, seed=77, stride_extra=32)  # SpriteRenderComponent-like derived struct, 80-byte stride
+    assert wide.meshes.dtype.itemsize == 80
+    (got, gv, exp, ev), = run_both(gpu, oracle, wide, [v])
+    assert_same(got, gv, exp, ev)
+
+
+def test_hierarchy_cycle_is_rejected(gpu):
+    from garden_amd.lib import GV_E_ARG, GvError
+    sc = scene.hierarchy_scene(100, depth=3, fanout=3, defects=False)
+    sc.transforms["parent"][0] = sc.transforms["entity"][50]  # root now hangs under its own descendant
+    chain = []
+    s = 50
+    while sc.transforms["parent"][s]:
+        s = int(sc.entity_to_transform[sc.transforms["parent"][s]])
+        chain.append(s)
+        if len(chain) > 200:
+            break
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    if 0 in chain:  # only a real cycle must be rejected (reference asserts, transform.cpp:137-143)
+        with pytest.raises(GvError) as e:
+            gpu.hierarchy_rebuild()
+        assert e.value.code == GV_E_ARG and "cycle" in str(e.value)
