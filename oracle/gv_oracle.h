@@ -135,6 +135,14 @@ void gvo_prepare_meshes_range(const GvoMeshPool* mp, const GvoTransformPool* tp,
 void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const GvoView* view,
                         const GvoHiz* hiz, uint32_t threads, GvoCullOut* out);
 
+/* ---- AVX2 form (gv_oracle_avx2.c): 8 entities per iteration over an SoA copy of the pools; bit-identical to the
+ * scalar routines above; the timed cpu_baseline of bench.py ---- */
+typedef struct GvoSoa GvoSoa;
+GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp);
+void gvo_soa_free(GvoSoa* soa);
+void gvo_prepare_meshes_avx2(const GvoSoa* soa, const GvoMeshPool* mp, const GvoView* view, const GvoHiz* hiz,
+                             uint32_t threads, GvoCullOut* out);
+
 /* sortMeshes (mesh.cpp:265-328): ascending distanceSq (unsorted buffers) or descending (sorted). */
 void gvo_sort_records(GvoCullOut* out, int descending);
 

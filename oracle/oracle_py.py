@@ -80,6 +80,11 @@ def load():
     lib.gvo_prepare_meshes.argtypes = [C.POINTER(GvoMeshPool), C.POINTER(GvoTransformPool), C.POINTER(GvoView),
                                        C.POINTER(GvoHiz), C.c_uint32, C.POINTER(GvoCullOut)]
     lib.gvo_sort_records.argtypes = [C.POINTER(GvoCullOut), C.c_int]
+    lib.gvo_soa_build.argtypes = [C.POINTER(GvoMeshPool), C.POINTER(GvoTransformPool)]
+    lib.gvo_soa_build.restype = C.c_void_p
+    lib.gvo_soa_free.argtypes = [C.c_void_p]
+    lib.gvo_prepare_meshes_avx2.argtypes = [C.c_void_p, C.POINTER(GvoMeshPool), C.POINTER(GvoView), C.POINTER(GvoHiz),
+                                            C.c_uint32, C.POINTER(GvoCullOut)]
     _lib = lib
     return lib
 
@@ -204,3 +209,34 @@ def prepare_meshes(meshes, transforms, e2t, view, hiz=None, threads=1, sort=None
     k = out.draw_count
     return dict(visible_idx=idx[:k].copy(), baked_model=bm[:k].copy(), distance_sq=ds[:k].copy(), draw_count=k,
                 instance_count=out.instance_count)
+
+
+class Avx2Scene:
+    """SoA copy of the pools for the AVX2 path (built once, like the GPU mirror)."""
+
+    def __init__(self, meshes, transforms, e2t):
+        self.lib = load()
+        self.meshes, self.transforms = meshes, transforms
+        self.e2t = np.ascontiguousarray(e2t, dtype=np.uint32)
+        self.mp, self.tp = mesh_pool(meshes), transform_pool(transforms, self.e2t)
+        self.soa = self.lib.gvo_soa_build(C.byref(self.mp), C.byref(self.tp))
+        n = max(meshes.shape[0], 1)
+        self.idx = np.empty(n, np.uint32)
+        self.bm = np.empty((n, 12), np.float32)
+        self.ds = np.empty(n, np.float32)
+
+    def prepare_meshes(self, view, hiz=None, threads=1):
+        gv = to_view(view)
+        out = GvoCullOut(self.idx.ctypes.data, self.bm.ctypes.data, self.ds.ctypes.data, 0, 0)
+        self.lib.gvo_prepare_meshes_avx2(self.soa, C.byref(self.mp), C.byref(gv),
+                                         C.byref(hiz.c) if hiz is not None else None, threads, C.byref(out))
+        k = out.draw_count
+        return dict(visible_idx=self.idx[:k], baked_model=self.bm[:k], distance_sq=self.ds[:k], draw_count=k,
+                    instance_count=out.instance_count)
+
+    def close(self):
+        if self.soa:
+            self.lib.gvo_soa_free(self.soa)
+            self.soa = None
+
+    __del__ = close
