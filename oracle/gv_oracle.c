@@ -398,6 +398,77 @@ void gvo_prepare_meshes_range(const GvoMeshPool* mp, const GvoTransformPool* tp,
     out->instance_count = instance_count;
 }
 
+/* Persistent worker pool (the reference's foreground ThreadPool is persistent too: source/thread-pool.cpp:56-110;
+ * the calling thread takes part, thread-pool.cpp:203-215). One global pool, grown on demand. */
+typedef struct GvoThreadPool {
+    pthread_t* tids;
+    int workers;
+    pthread_mutex_t mu;
+    pthread_cond_t work_cv, done_cv;
+    void* (*fn)(void*);
+    void** args;
+    int next, total, pending;
+    unsigned generation;
+} GvoThreadPool;
+static GvoThreadPool g_pool = {NULL, 0, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+                               NULL, NULL, 0, 0, 0, 0};
+static pthread_mutex_t g_pool_run = PTHREAD_MUTEX_INITIALIZER;
+
+static void* pool_worker(void* unused)
+{
+    (void)unused;
+    unsigned seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.generation == seen)
+            pthread_cond_wait(&g_pool.work_cv, &g_pool.mu);
+        seen = g_pool.generation;
+        while (g_pool.next < g_pool.total) {
+            const int i = g_pool.next++;
+            pthread_mutex_unlock(&g_pool.mu);
+            g_pool.fn(g_pool.args[i]);
+            pthread_mutex_lock(&g_pool.mu);
+            if (--g_pool.pending == 0)
+                pthread_cond_signal(&g_pool.done_cv);
+        }
+    }
+    return NULL;
+}
+
+/* runs fn(args[i]) for i in [0, count) on up to `threads` threads including the caller */
+void gvo_pool_run(void* (*fn)(void*), void** args, int count, int threads)
+{
+    pthread_mutex_lock(&g_pool_run);
+    const int want = threads - 1;
+    if (want > g_pool.workers) {
+        g_pool.tids = (pthread_t*)realloc(g_pool.tids, sizeof(pthread_t) * (size_t)want);
+        for (int i = g_pool.workers; i < want; i++) {
+            pthread_create(&g_pool.tids[i], NULL, pool_worker, NULL);
+            pthread_detach(g_pool.tids[i]);
+        }
+        g_pool.workers = want;
+    }
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.fn = fn;
+    g_pool.args = args;
+    g_pool.total = count;
+    g_pool.next = 0;
+    g_pool.pending = count;
+    g_pool.generation++;
+    pthread_cond_broadcast(&g_pool.work_cv);
+    while (g_pool.next < g_pool.total) {
+        const int i = g_pool.next++;
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(args[i]);
+        pthread_mutex_lock(&g_pool.mu);
+        --g_pool.pending;
+    }
+    while (g_pool.pending > 0)
+        pthread_cond_wait(&g_pool.done_cv, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool_run);
+}
+
 typedef struct RangeTask {
     const GvoMeshPool* mp;
     const GvoTransformPool* tp;
@@ -459,14 +530,13 @@ void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const
         launched = i + 1;
     }
     /* foreground pool: the calling thread participates (ThreadPool::wait  thread-pool.cpp:203-215) */
-    for (uint32_t i = 1; i < launched; i++)
+    void** argv = (void**)malloc(sizeof(void*) * (launched ? launched : 1));
+    int argc = 0;
+    for (uint32_t i = 0; i < launched; i++)
         if (tasks[i].mp)
-            pthread_create(&tids[i], NULL, range_task_main, &tasks[i]);
-    if (tasks[0].mp)
-        range_task_main(&tasks[0]);
-    for (uint32_t i = 1; i < launched; i++)
-        if (tasks[i].mp)
-            pthread_join(tids[i], NULL);
+            argv[argc++] = &tasks[i];
+    gvo_pool_run(range_task_main, argv, argc, (int)threads);
+    free(argv);
     for (uint32_t i = 0; i < task_count; i++) {
         free(tasks[i].local.visible_idx);
         free(tasks[i].local.baked_model);

@@ -18,6 +18,8 @@
 
 #include "gv_oracle.h"
 
+void gvo_pool_run(void* (*fn)(void*), void** args, int count, int threads); /* gv_oracle.c */
+
 typedef struct GvoSoa {
     uint32_t mesh_count, xf_count;
     /* transforms, indexed by transform slot */
@@ -308,9 +310,11 @@ void gvo_prepare_meshes_avx2(const GvoSoa* s, const GvoMeshPool* mp, const GvoVi
         t->local.baked_model = (float*)malloc((size_t)n * 48);
         t->local.distance_sq = (float*)malloc((size_t)n * 4);
     }
-    for (uint32_t i = 1; i < task_count; i++) if (tasks[i].s) pthread_create(&tids[i], NULL, task8_main, &tasks[i]);
-    if (tasks[0].s) task8_main(&tasks[0]);
-    for (uint32_t i = 1; i < task_count; i++) if (tasks[i].s) pthread_join(tids[i], NULL);
+    void** argv = (void**)malloc(sizeof(void*) * task_count);
+    int argc = 0;
+    for (uint32_t i = 0; i < task_count; i++) if (tasks[i].s) argv[argc++] = &tasks[i];
+    gvo_pool_run(task8_main, argv, argc, (int)threads);
+    free(argv);
     for (uint32_t i = 0; i < task_count; i++) { free(tasks[i].local.visible_idx); free(tasks[i].local.baked_model); free(tasks[i].local.distance_sq); }
     out->draw_count = atomic_load(&draw);
     out->instance_count = atomic_load(&inst);
