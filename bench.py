@@ -164,7 +164,9 @@ def main():
     if wl["hiz"]:
         vis.hiz_build(depth)
 
-    idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if world > 1 else None
+    # two index buffers: the all-gatherv of frame f may still be reading one while frame f+1 fills the other
+    idx_bufs = [torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(2)] if world > 1 else None
+    frame = [0]
 
     def step():
         if wl["hiz"]:
@@ -173,9 +175,10 @@ def main():
             vis.sweep(GV_SWEEP_MFMA if args.sweep == "mfma" else GV_SWEEP_VALU)
         vis.cull(0, [view])
         if world > 1:
-            count = vis.result_count(0)
+            idx_buf = idx_bufs[frame[0] & 1]
+            frame[0] += 1
             vis.copy_idx_device(0, idx_buf.data_ptr(), n, index_base=rank * n)
-            vis.wait()
+            count = vis.result_count(0)  # 4-byte readback on the library's stream: also fences the copy above
             return allgatherv_indices(idx_buf, count, dist)
         return None
 
