@@ -194,7 +194,7 @@ def main():
             assert part.size == 0 or (part.min() >= r * n and part.max() < (r + 1) * n), f"rank {r} indices out of its tile"
             if r == rank:
                 mine = vis.fetch(0, write_back=False, occupancy=n)["visible_idx"].astype(np.int64) + rank * n
-                assert np.array_equal(part, mine), "own shard differs from the local visible list"
+                assert np.array_equal(np.sort(part), mine), "own shard differs from the local visible list"
             off += int(c[r])
         return int(c.sum())
 

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
         const Mat34 world = chain_model(args.xf, local, link);
         const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
         const size_t rank = (size_t)base + r;
-        args.out.visible_idx[rank] = i;  // componentOffset = i * componentSize  mesh.cpp:170
+        args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
         float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
         bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
         bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
@@ -551,6 +551,50 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.out = out;
     const uint32_t nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
     hipLaunchKernelGGL(emit_kernel, dim3(nchunks * kEmitParts), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scatter_records_kernel(const uint32_t* __restrict__ idx, uint32_t count,
+                                                              const float4* __restrict__ src_a, float4* __restrict__ dst_a,
+                                                              const float4* __restrict__ src_b, float4* __restrict__ dst_b,
+                                                              const float3* __restrict__ src_c, float3* __restrict__ dst_c)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const uint32_t j = idx[k];
+        dst_a[j] = src_a[k];
+        if (src_b)
+            dst_b[j] = src_b[k];
+        dst_c[j] = src_c[k];
+    }
+}
+
+hipError_t launch_scatter_records(const uint32_t* idx, uint32_t count, const float4* src_a, float4* dst_a,
+                                  const float4* src_b, float4* dst_b, const float3* src_c, float3* dst_c,
+                                  hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(scatter_records_kernel, dim3(min((count + 255u) / 256u, 4096u)), dim3(256), 0, stream, idx, count,
+                       src_a, dst_a, src_b, dst_b, src_c, dst_c);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_world_kernel(const float4* __restrict__ world, const uint32_t* __restrict__ xinv,
+                                                           uint32_t first, uint32_t count, float4* __restrict__ out)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count * 3; k += gridDim.x * blockDim.x) {
+        const uint32_t s = k / 3, part = k - s * 3;
+        out[k] = world[(size_t)xinv[first + s] * 3 + part];
+    }
+}
+
+hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32_t first, uint32_t count, float4* out,
+                               hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gather_world_kernel, dim3(min((count * 3 + 255u) / 256u, 4096u)), dim3(256), 0, stream, world, xinv,
+                       first, count, out);
     return hipGetLastError();
 }
 

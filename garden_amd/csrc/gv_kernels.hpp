@@ -25,7 +25,8 @@ struct MeshMirror {
     const float4* a;  // (aabb.min.xyz, aabb.max.x)
     const float3* b;  // (aabb.max.y, aabb.max.z, bits: transform slot | kMesh* flags)
     uint32_t count;
-    uint32_t identity;  // most mesh slots i map to transform slot i: prefetch xf[i] beside mesh[i] (speed only)
+    uint32_t identity;  // most mesh entries i map to transform entry i: prefetch xf[i] beside mesh[i] (speed only)
+    const uint32_t* orig;  // mirror entry -> pool slot (null: the mirror is in pool order)
 };
 
 struct HizDevice {
@@ -92,6 +93,14 @@ struct SortBuffers {
     uint32_t* bin_total;  // 256
 };
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
+
+// dirty-range upload into a permuted mirror: dst_x[idx[k]] = src_x[k] (b streams optional)
+hipError_t launch_scatter_records(const uint32_t* idx, uint32_t count, const float4* src_a, float4* dst_a,
+                                  const float4* src_b, float4* dst_b, const float3* src_c, float3* dst_c,
+                                  hipStream_t stream);
+// out[k] = world[xinv[first + k]] (3 float4 per slot)
+hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32_t first, uint32_t count, float4* out,
+                               hipStream_t stream);
 
 // world matrices (camera = 0) of every transform slot: 3 float4 per slot (float4x3 order)
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream);

@@ -19,6 +19,7 @@ GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -
 GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
 GV_CONFIG_PROFILE_EVENTS = 1
 GV_CONFIG_PROFILE_CULL_ONLY = 2
+GV_CONFIG_KEEP_SLOT_ORDER = 4
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA = 0, 1
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
@@ -140,11 +141,14 @@ def to_gv_view(v):
 class GpuVisibility:
     """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
 
-    def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False):
+    def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False,
+                 keep_slot_order=False):
         self.lib = load()
         flags = GV_CONFIG_PROFILE_EVENTS if (profile_events or profile_cull_only) else 0
         if profile_cull_only:
             flags |= GV_CONFIG_PROFILE_CULL_ONLY
+        if keep_slot_order:
+            flags |= GV_CONFIG_KEEP_SLOT_ORDER
         cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, flags)
         self.ctx = C.c_void_p()
         rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))
@@ -208,9 +212,10 @@ class GpuVisibility:
         self._check(self.lib.gv_result_count(self.ctx, view_index, C.byref(n)))
         return n.value
 
-    def fetch(self, view_index=0, write_back=True, occupancy=None):
+    def fetch(self, view_index=0, write_back=True, occupancy=None, order="slot"):
         """Returns copies: dict(visible_idx, baked_model[n,12], distance_sq, is_visible or None, draw_count).
-        Records arrive in ascending pool-slot order."""
+        order="slot": records re-ordered here by pool slot (what the oracle's single-thread loop produces);
+        order="raw": as the library emitted them (mirror order, or distance order after sort())."""
         r = GvResult()
         self._check(self.lib.gv_results_fetch(self.ctx, view_index, 1 if write_back else 0, C.byref(r)))
         n = r.draw_count
@@ -220,6 +225,10 @@ class GpuVisibility:
             out["visible_idx"] = np.ctypeslib.as_array(r.visible_idx, shape=(n,)).copy()
             out["baked_model"] = np.ctypeslib.as_array(r.baked_model, shape=(n, 12)).copy()
             out["distance_sq"] = np.ctypeslib.as_array(r.distance_sq, shape=(n,)).copy()
+            if order == "slot":
+                o = np.argsort(out["visible_idx"], kind="stable")
+                out["visible_idx"], out["baked_model"], out["distance_sq"] = \
+                    out["visible_idx"][o], out["baked_model"][o], out["distance_sq"][o]
         elif n == 0:
             out["visible_idx"] = np.zeros(0, np.uint32)
             out["baked_model"] = np.zeros((0, 12), np.float32)

@@ -54,8 +54,12 @@ typedef enum GvHizRule {
 
 typedef enum GvConfigFlags {
     GV_CONFIG_PROFILE_EVENTS = 1u << 0,   /* bracket every kernel with hipEvents; durations via gv_stats */
-    GV_CONFIG_PROFILE_CULL_ONLY = 1u << 1 /* with PROFILE_EVENTS: only GV_K_CULL is bracketed (2 events per view
+    GV_CONFIG_PROFILE_CULL_ONLY = 1u << 1, /* with PROFILE_EVENTS: only GV_K_CULL is bracketed (2 events per view
                                              instead of ~10 per frame: each event record costs ~2 us of stream time) */
+    GV_CONFIG_KEEP_SLOT_ORDER = 1u << 2   /* keep the device mirror in pool-slot order. Default: entries are ordered
+                                             spatially (Morton code of the root ancestor's position) at every full
+                                             rebuild so that neighbouring lanes touch neighbouring Hi-Z texels; all
+                                             outputs are reported in pool slots either way */
 } GvConfigFlags;
 
 /* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as
@@ -122,9 +126,10 @@ typedef struct GvView {
 
 /* Host-visible results of one view: the SoA form of UnsortedBuffer::combinedMeshes[0..drawCount)
  * (render/mesh.hpp:191-217). Pointers are library-owned pinned memory, valid until the next
- * gv_cull on this context. Records are in ascending pool-slot order, reproducible run to run; the
+ * gv_cull on this context. Record order is deterministic (reproducible run to run): ascending pool slot with
+ * GV_CONFIG_KEEP_SLOT_ORDER, otherwise the mirror's spatial order; gv_sort orders them by distance. The
  * reference's order is fetch_add arrival order (mesh.cpp:177), i.e. unspecified, and its consumers sort by
- * distanceSq afterwards (mesh.cpp:548-551). */
+ * distanceSq afterwards (mesh.cpp:548-551). is_visible is always indexed by pool slot. */
 typedef struct GvResult {
     const uint32_t* visible_idx; /* pool slot; componentOffset = visible_idx * stride (mesh.cpp:170) */
     const float* baked_model;    /* 12 floats per record: c0.xyz c1.xyz c2.xyz c3.xyz (float4x3, mesh.cpp:171) */
@@ -151,7 +156,8 @@ typedef struct GvDeviceResult {
     const void* visible_idx; /* uint32_t[draw_count], device memory */
     const void* baked_model; /* float[12 * draw_count] */
     const void* distance_sq; /* float[draw_count] */
-    const void* is_visible;  /* uint8_t[occupancy] or NULL */
+    const void* is_visible;  /* uint8_t[occupancy] or NULL; indexed by MIRROR entry (pool slot only with
+                                GV_CONFIG_KEEP_SLOT_ORDER) — use gv_results_fetch for the pool-slot view */
     const void* draw_count;  /* uint32_t, device memory */
 } GvDeviceResult;
 int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out);
@@ -161,7 +167,8 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 
 /* Sorts view `view_index`'s compact records on the device by distanceSq: ascending (descending == 0) as sortMeshes
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
- * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: ties keep ascending pool-slot order.
+ * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: equal keys keep the order the records were
+ * emitted in (std::sort in the reference leaves ties unspecified).
  * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. */
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
 

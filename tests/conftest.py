@@ -28,3 +28,12 @@ def gpu():
     yield vis
     vis.close()
 
+
+
+@pytest.fixture(scope="session")
+def gpu_slot_order():
+    """Context with GV_CONFIG_KEEP_SLOT_ORDER (mirror in pool-slot order, no spatial permutation)."""
+    from garden_amd.lib import GpuVisibility
+    vis = GpuVisibility(device=0, keep_slot_order=True)
+    yield vis
+    vis.close()

@@ -108,20 +108,52 @@ def test_world_matrices(gpu, oracle, mode):
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # and in fact bit-exact
 
 
-def test_records_are_in_ascending_slot_order_on_dense_views(gpu, oracle):
-    """Order-stable compaction: an ortho view that sees most of the cube (many full tiles and chunks)."""
+def test_keep_slot_order_gives_ascending_records(gpu_slot_order, oracle):
+    """GV_CONFIG_KEEP_SLOT_ORDER: the mirror stays in pool order and the order-stable compaction returns records
+    in ascending slot order with no host-side sort; an ortho view that sees most of the cube (many full chunks)."""
+    gpu = gpu_slot_order
     sc = scene.flat_scene(200_000, seed=5)
     v = scene.cascade_view(size=20000.0, depth=40000.0)
     gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
     gpu.bind_pool(0, sc.meshes)
     gpu.hierarchy_rebuild()
     gpu.cull(0, [v])
-    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
     exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v)
     assert got["draw_count"] == exp["draw_count"] > 100_000
-    assert np.array_equal(got["visible_idx"], exp["visible_idx"])  # no host-side sort anywhere
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"])
     assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
     assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+
+
+def test_spatial_mirror_order_is_deterministic_and_complete(gpu, oracle):
+    """Default: mirror entries are Morton-ordered by root position; records come out in that order (the same
+    permutation every time), every pool slot exactly once, and isVisible / gv_get_world are indexed by pool slot."""
+    sc = scene.shuffled_scene(scene.hierarchy_scene(80_000, depth=4, fanout=9), fraction=0.2)
+    v = scene.cascade_view(size=9000.0, depth=40000.0)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    raws = []
+    for _ in range(2):
+        gpu.cull(0, [v])
+        raws.append(gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw"))
+    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v)
+    assert np.array_equal(raws[0]["visible_idx"], raws[1]["visible_idx"])            # reproducible
+    assert not np.array_equal(raws[0]["visible_idx"], exp["visible_idx"])            # and not pool order
+    assert np.array_equal(np.sort(raws[0]["visible_idx"]), exp["visible_idx"])       # same set, each slot once
+    gpu.sweep(0)
+    assert np.array_equal(gpu.get_world(1000, 5000).view(np.uint32),
+                          oracle.world_matrices(sc.transforms, sc.entity_to_transform, 1000, 5000).view(np.uint32))
+
+
+@pytest.mark.parametrize("hier", [False, True])
+def test_slot_order_context_full_parity(gpu_slot_order, oracle, hier):
+    sc = scene.hierarchy_scene(50_000) if hier else scene.flat_scene(50_000, seed=8)
+    depth = scene.synthetic_depth(256, 128)
+    res = run_both(gpu_slot_order, oracle, sc, [scene.main_camera_view(use_hiz=1), scene.cascade_view()], hiz_depth=depth)
+    assert_same(*res[0], main_pass=True)
+    assert_same(*res[1], main_pass=False)
 
 
 def test_count_only_view(gpu, oracle):
@@ -182,11 +214,15 @@ def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     gpu.hierarchy_rebuild()
     gpu.cull(0, [v])
     gpu.sort(0, descending=descending)
-    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
     exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v, sort="descending" if descending else "ascending")
     assert got["draw_count"] == exp["draw_count"] > 0
     d = got["distance_sq"]
     assert np.all(d[:-1] >= d[1:]) if descending else np.all(d[:-1] <= d[1:])
+    # equal keys: the stable sort keeps the emitted (mirror) order, the oracle breaks ties by slot, std::sort in the
+    # reference leaves them unspecified -> canonicalise ties by slot before comparing
+    o = np.lexsort((got["visible_idx"], -d if descending else d))
+    got = {k: (v[o] if isinstance(v, np.ndarray) and v.shape[:1] == d.shape else v) for k, v in got.items()}
     assert np.array_equal(got["visible_idx"], exp["visible_idx"])
     assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
     assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
