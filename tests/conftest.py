@@ -8,6 +8,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """A fresh checkout has no binaries (they are git-ignored): build the HIP library, the oracle and the C++ test
+    driver once, exactly as __graft_entry__.build() does (hipcc cross-compiles without a GPU)."""
+    lib = os.path.join(ROOT, "garden_amd", "lib", "libgarden_vis.so")
+    orc = os.path.join(ROOT, "oracle", "build", "libgv_oracle.so")
+    tick = os.path.join(ROOT, "tests", "cpp", "build", "headless_tick")
+    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(tick)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
 
