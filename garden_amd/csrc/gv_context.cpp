@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -113,16 +114,18 @@ struct PoolState {
     GvMeshLayout layout{};
     bool bound = false;
     bool need_full = false;
-    bool identity = false;  // >= 90 % of mirror entries j resolve to transform entry j (chosen at full gather)
+    uint32_t mapping = kMapGeneral;  // MeshMapping, chosen at full gather (kMapExact may only be demoted afterwards)
     DirtyRange dirty;
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
     // device mirror + pinned staging
     DeviceBuf<float4> d_a;
-    DeviceBuf<float3> d_b;
+    DeviceBuf<float2> d_b;
+    DeviceBuf<uint32_t> d_link;
     PinnedBuf<float4> h_a;
-    PinnedBuf<float3> h_b;
+    PinnedBuf<float2> h_b;
+    PinnedBuf<uint32_t> h_link;
 };
 
 struct ViewState {
@@ -159,20 +162,26 @@ struct GvCtx {
     bool xf_need_full = false;
     DirtyRange xf_dirty;
     DeviceBuf<float4> d_xa, d_xb;
-    DeviceBuf<float3> d_xc;
+    DeviceBuf<float2> d_xc;
+    DeviceBuf<uint8_t> d_xflags;
+    DeviceBuf<uint32_t> d_xparent;
     PinnedBuf<float4> h_xa, h_xb;
-    PinnedBuf<float3> h_xc;
+    PinnedBuf<float2> h_xc;
+    PinnedBuf<uint8_t> h_xflags;
+    PinnedBuf<uint32_t> h_xparent;
     uint32_t max_depth = 0;
     // spatial mirror order of the transform pool (empty = slot order)
     std::vector<uint32_t> xperm, xinv;
     DeviceBuf<uint32_t> d_xinv;  // slot -> mirror entry, for gv_get_world
     // scratch of the scattered (dirty-range) upload path
-    PinnedBuf<uint32_t> sc_idx;
+    PinnedBuf<uint32_t> sc_idx, sc_u32;
     PinnedBuf<float4> sc_a, sc_b;
-    PinnedBuf<float3> sc_c;
-    DeviceBuf<uint32_t> dsc_idx;
+    PinnedBuf<float2> sc_c;
+    PinnedBuf<uint8_t> sc_u8;
+    DeviceBuf<uint32_t> dsc_idx, dsc_u32;
     DeviceBuf<float4> dsc_a, dsc_b;
-    DeviceBuf<float3> dsc_c;
+    DeviceBuf<float2> dsc_c;
+    DeviceBuf<uint8_t> dsc_u8;
 
     PoolState pools[GV_MAX_POOLS];
     ViewState views[GV_MAX_VIEWS];
@@ -291,13 +300,6 @@ inline uint32_t load_u32(const uint8_t* p)
     memcpy(&v, p, 4);
     return v;
 }
-inline float bits_to_float(uint32_t u)
-{
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
 inline uint32_t entity_slot(const TransformBinding& xf, uint32_t entity)
 {
     if (entity == 0 || entity >= xf.entity_capacity)
@@ -451,17 +453,19 @@ void gather_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
             const float* scl = reinterpret_cast<const float*>(t + L.scale);
             const float* rot = reinterpret_cast<const float*>(t + L.rotation);
             const uint32_t entity = load_u32(t + L.entity);
-            uint32_t link = xslot_to_mirror(ctx, entity_slot(xf, load_u32(t + L.parent)));
+            uint8_t flags = 0;
             if (entity)
-                link |= kXfLive;
+                flags |= kXfLive;
             if (t[L.self_active] && t[L.ancestors_active])
-                link |= kXfActive;
+                flags |= kXfActive;
             if (t[L.model_with_ancestors])
-                link |= kXfWithAncestors;
+                flags |= kXfWithAncestors;
             const uint32_t j = xslot_to_mirror(ctx, s);
             ctx->h_xa.ptr[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
             ctx->h_xb.ptr[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
-            ctx->h_xc.ptr[j] = make_float3(scl[1], scl[2], bits_to_float(link));
+            ctx->h_xc.ptr[j] = make_float2(scl[1], scl[2]);
+            ctx->h_xflags.ptr[j] = flags;
+            ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, load_u32(t + L.parent)));
         }
     });
 }
@@ -470,20 +474,27 @@ void gather_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
 {
     const GvMeshLayout& L = p.layout;
     const TransformBinding& xf = ctx->xf;
+    std::atomic<bool> demoted{false};
     parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
         for (uint32_t i = a; i < b; i++) {
             const uint8_t* m = p.base + (size_t)i * p.stride;
             const float* mn = reinterpret_cast<const float*>(m + L.aabb_min);
             const float* mx = reinterpret_cast<const float*>(m + L.aabb_max);
             const uint32_t entity = load_u32(m + L.entity);
-            uint32_t link = xslot_to_mirror(ctx, entity_slot(xf, entity));  // Manager::tryGet<TransformComponent>  mesh.cpp:149
-            if (entity && m[L.is_enabled])
-                link |= kMeshCandidate;
+            const uint32_t slot = xslot_to_mirror(ctx, entity_slot(xf, entity));  // Manager::tryGet<TransformComponent>  mesh.cpp:149
+            const bool candidate = entity && m[L.is_enabled] && slot != kSlotNone;
             const uint32_t j = p.inv.empty() ? i : p.inv[i];
-            p.h_a.ptr[j] = make_float4(mn[0], mn[1], mn[2], mx[0]);
-            p.h_b.ptr[j] = make_float3(mx[1], mx[2], bits_to_float(link));
+            // A non-candidate entry (free slot, disabled, no transform) carries an empty box: the all(size <= 0)
+            // filter (mesh.cpp:140-142) then rejects it without the kernel having to read link[] (kMapExact).
+            p.h_a.ptr[j] = candidate ? make_float4(mn[0], mn[1], mn[2], mx[0]) : make_float4(0, 0, 0, 0);
+            p.h_b.ptr[j] = candidate ? make_float2(mx[1], mx[2]) : make_float2(0, 0);
+            p.h_link.ptr[j] = slot | (candidate ? kMeshCandidate : 0u);
+            if (candidate && slot != j && p.mapping == kMapExact)
+                demoted = true;  // an edited mesh no longer pairs with its own index
         }
     });
+    if (demoted)
+        p.mapping = kMapSpeculate;
 }
 
 // Longest parent chain (mirror entries); a cycle (the reference asserts against it, transform.cpp:137-143) is an error.
@@ -503,9 +514,7 @@ int compute_max_depth(GvCtx* ctx, uint32_t* out_depth)
             if (stack.size() > n)
                 return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", s);
             depth[cur] = UINT32_MAX - 1;  // on the current path
-            uint32_t link;
-            memcpy(&link, &ctx->h_xc.ptr[cur].z, 4);
-            cur = link & kSlotMask;
+            cur = ctx->h_xparent.ptr[cur];
             if (cur != kSlotNone && depth[cur] == UINT32_MAX - 1)
                 return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", cur);
         }
@@ -526,8 +535,10 @@ int upload_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
     const size_t n = hi - lo;
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xa.ptr + lo, ctx->h_xa.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xb.ptr + lo, ctx->h_xb.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xc.ptr + lo, ctx->h_xc.ptr + lo, n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
-    ctx->stats.upload_bytes += n * (2 * sizeof(float4) + sizeof(float3));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xc.ptr + lo, ctx->h_xc.ptr + lo, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xflags.ptr + lo, ctx->h_xflags.ptr + lo, n, hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xparent.ptr + lo, ctx->h_xparent.ptr + lo, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stats.upload_bytes += n * 45;
     return GV_OK;
 }
 
@@ -535,21 +546,35 @@ int upload_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
 {
     const size_t n = hi - lo;
     GV_HIP(ctx, hipMemcpyAsync(p.d_a.ptr + lo, p.h_a.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(p.d_b.ptr + lo, p.h_b.ptr + lo, n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
-    ctx->stats.upload_bytes += n * (sizeof(float4) + sizeof(float3));
+    GV_HIP(ctx, hipMemcpyAsync(p.d_b.ptr + lo, p.h_b.ptr + lo, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(p.d_link.ptr + lo, p.h_link.ptr + lo, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stats.upload_bytes += n * 28;
     return GV_OK;
 }
 
 int reserve_scatter(GvCtx* ctx, size_t n)
 {
     GV_HIP(ctx, ctx->sc_idx.reserve(n));
+    GV_HIP(ctx, ctx->sc_u32.reserve(n));
     GV_HIP(ctx, ctx->sc_a.reserve(n));
     GV_HIP(ctx, ctx->sc_b.reserve(n));
     GV_HIP(ctx, ctx->sc_c.reserve(n));
+    GV_HIP(ctx, ctx->sc_u8.reserve(n));
     GV_HIP(ctx, ctx->dsc_idx.reserve(n));
+    GV_HIP(ctx, ctx->dsc_u32.reserve(n));
     GV_HIP(ctx, ctx->dsc_a.reserve(n));
     GV_HIP(ctx, ctx->dsc_b.reserve(n));
     GV_HIP(ctx, ctx->dsc_c.reserve(n));
+    GV_HIP(ctx, ctx->dsc_u8.reserve(n));
+    return GV_OK;
+}
+
+// one stream of a scattered packet: host packet -> device packet -> dst[idx[k]] = packet[k]
+template <typename T>
+int scatter_stream(GvCtx* ctx, const T* host_packet, T* device_packet, T* dst, uint32_t n)
+{
+    GV_HIP(ctx, hipMemcpyAsync(device_packet, host_packet, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, launch_scatter(ctx->dsc_idx.ptr, n, device_packet, dst, (uint32_t)sizeof(T), ctx->stream));
     return GV_OK;
 }
 
@@ -567,15 +592,17 @@ int upload_transforms_scattered(GvCtx* ctx, uint32_t lo, uint32_t hi)
         ctx->sc_a.ptr[k] = ctx->h_xa.ptr[j];
         ctx->sc_b.ptr[k] = ctx->h_xb.ptr[j];
         ctx->sc_c.ptr[k] = ctx->h_xc.ptr[j];
+        ctx->sc_u8.ptr[k] = ctx->h_xflags.ptr[j];
+        ctx->sc_u32.ptr[k] = ctx->h_xparent.ptr[j];
     }
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_a.ptr, ctx->sc_a.ptr, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_b.ptr, ctx->sc_b.ptr, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_c.ptr, ctx->sc_c.ptr, (size_t)n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, launch_scatter_records(ctx->dsc_idx.ptr, n, ctx->dsc_a.ptr, ctx->d_xa.ptr, ctx->dsc_b.ptr, ctx->d_xb.ptr,
-                                       ctx->dsc_c.ptr, ctx->d_xc.ptr, ctx->stream));
+    if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, ctx->d_xa.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_b.ptr, ctx->dsc_b.ptr, ctx->d_xb.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, ctx->d_xc.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_u8.ptr, ctx->dsc_u8.ptr, ctx->d_xflags.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, ctx->d_xparent.ptr, n)) != GV_OK) return rc;
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the packet buffers are reused by the next dirty range
-    ctx->stats.upload_bytes += (size_t)n * (4 + 2 * sizeof(float4) + sizeof(float3));
+    ctx->stats.upload_bytes += (size_t)n * (4 + 45);
     return GV_OK;
 }
 
@@ -590,14 +617,14 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
         ctx->sc_idx.ptr[k] = j;
         ctx->sc_a.ptr[k] = p.h_a.ptr[j];
         ctx->sc_c.ptr[k] = p.h_b.ptr[j];
+        ctx->sc_u32.ptr[k] = p.h_link.ptr[j];
     }
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_a.ptr, ctx->sc_a.ptr, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_c.ptr, ctx->sc_c.ptr, (size_t)n * sizeof(float3), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, launch_scatter_records(ctx->dsc_idx.ptr, n, ctx->dsc_a.ptr, p.d_a.ptr, nullptr, nullptr, ctx->dsc_c.ptr,
-                                       p.d_b.ptr, ctx->stream));
+    if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, p.d_a.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, p.d_b.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, p.d_link.ptr, n)) != GV_OK) return rc;
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stats.upload_bytes += (size_t)n * (4 + sizeof(float4) + sizeof(float3));
+    ctx->stats.upload_bytes += (size_t)n * (4 + 28);
     return GV_OK;
 }
 
@@ -616,9 +643,13 @@ int sync_mirror(GvCtx* ctx)
         GV_HIP(ctx, ctx->d_xa.reserve(cap));
         GV_HIP(ctx, ctx->d_xb.reserve(cap));
         GV_HIP(ctx, ctx->d_xc.reserve(cap));
+        GV_HIP(ctx, ctx->d_xflags.reserve(cap));
+        GV_HIP(ctx, ctx->d_xparent.reserve(cap));
         GV_HIP(ctx, ctx->h_xa.reserve(cap));
         GV_HIP(ctx, ctx->h_xb.reserve(cap));
         GV_HIP(ctx, ctx->h_xc.reserve(cap));
+        GV_HIP(ctx, ctx->h_xflags.reserve(cap));
+        GV_HIP(ctx, ctx->h_xparent.reserve(cap));
         int rc = build_transform_order(ctx);
         if (rc != GV_OK)
             return rc;
@@ -677,18 +708,24 @@ int sync_mirror(GvCtx* ctx)
             const size_t cap = std::max<size_t>(p.occupancy, 1);
             GV_HIP(ctx, p.d_a.reserve(cap));
             GV_HIP(ctx, p.d_b.reserve(cap));
+            GV_HIP(ctx, p.d_link.reserve(cap));
             GV_HIP(ctx, p.h_a.reserve(cap));
             GV_HIP(ctx, p.h_b.reserve(cap));
+            GV_HIP(ctx, p.h_link.reserve(cap));
             build_mesh_order(ctx, p);
+            p.mapping = kMapGeneral;
             if (p.occupancy) {
                 gather_meshes(ctx, p, 0, p.occupancy);
-                size_t same = 0;
+                // how do mesh entries pair with transform entries? (speed only: every mapping is handled)
+                size_t candidates = 0, own = 0;
                 for (uint32_t i = 0; i < p.occupancy; i++) {
-                    uint32_t link;
-                    memcpy(&link, &p.h_b.ptr[i].z, 4);
-                    same += (link & kSlotMask) == i;
+                    const uint32_t link = p.h_link.ptr[i];
+                    if (link & kMeshCandidate) {
+                        candidates++;
+                        own += (link & kSlotMask) == i;
+                    }
                 }
-                p.identity = same * 10 >= (size_t)p.occupancy * 9;
+                p.mapping = own == candidates ? kMapExact : (own * 10 >= candidates * 9 ? kMapSpeculate : kMapGeneral);
                 int rc = upload_meshes(ctx, p, 0, p.occupancy);
                 if (rc != GV_OK)
                     return rc;
@@ -730,6 +767,8 @@ TransformMirror xf_mirror(const GvCtx* ctx)
     m.a = ctx->d_xa.ptr;
     m.b = ctx->d_xb.ptr;
     m.c = ctx->d_xc.ptr;
+    m.flags = ctx->d_xflags.ptr;
+    m.parent = ctx->d_xparent.ptr;
     m.count = ctx->xf.occupancy;
     m.max_depth = ctx->max_depth;
     return m;
@@ -911,10 +950,10 @@ void gv_destroy(GvCtx* ctx)
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release();
-    ctx->h_xa.release(); ctx->h_xb.release(); ctx->h_xc.release();
+    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xparent.release();
+    ctx->h_xa.release(); ctx->h_xb.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
-        p.d_a.release(); p.d_b.release(); p.h_a.release(); p.h_b.release(); p.d_orig.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release();
     }
     for (auto& v : ctx->views) {
         v.mask.release(); v.chunk_count.release(); v.chunk_offset.release(); v.draw_count.release();
@@ -925,8 +964,8 @@ void gv_destroy(GvCtx* ctx)
         v.h_distance_sq.release(); v.h_is_visible.release(); v.h_is_visible_mirror.release();
     }
     ctx->d_world.release();
-    ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_a.release(); ctx->sc_b.release(); ctx->sc_c.release();
-    ctx->dsc_idx.release(); ctx->dsc_a.release(); ctx->dsc_b.release(); ctx->dsc_c.release();
+    ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_b.release(); ctx->sc_c.release(); ctx->sc_u8.release();
+    ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_b.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
     ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release();
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
@@ -1034,7 +1073,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     if (rc != GV_OK)
         return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.occupancy, p.identity ? 1u : 0u, p.perm.empty() ? nullptr : p.d_orig.ptr};
+    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.occupancy, p.mapping, p.perm.empty() ? nullptr : p.d_orig.ptr};
     const TransformMirror xf = xf_mirror(ctx);
     HizDevice hz{};
     for (uint32_t v = 0; v < view_count; v++) {

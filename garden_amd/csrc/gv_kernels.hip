@@ -25,47 +25,59 @@ namespace gv {
 // The mirror streams are read once per frame: nontemporal loads (no L2/MALL allocation priority) measured
 // +20 % on this access pattern (tools/kbench.hip: 6.1 -> 7.1 TB/s). Ancestor re-reads use plain loads.
 typedef float f32x4n __attribute__((ext_vector_type(4)));
-typedef float f32x3n __attribute__((ext_vector_type(3)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 stream_load(const float4* p)
 {
     const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ float3 stream_load(const float3* p)
+__device__ __forceinline__ float2 stream_load(const float2* p)
 {
-    const float* q = reinterpret_cast<const float*>(p);
-    return make_float3(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2));
+    const f32x2n v = __builtin_nontemporal_load(reinterpret_cast<const f32x2n*>(p));
+    return make_float2(v.x, v.y);
 }
+__device__ __forceinline__ uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint32_t stream_load(const uint8_t* p) { return __builtin_nontemporal_load(p); }
 
-__device__ __forceinline__ Mat34 load_local_model(const TransformMirror& xf, uint32_t s, uint32_t& link)
+// one transform entry: TRS + flag bits
+struct XfRecord {
+    float4 a, b;
+    float2 c;
+    uint32_t flags;
+};
+__device__ __forceinline__ XfRecord load_xf(const TransformMirror& xf, uint32_t s)
 {
-    const float4 a = xf.a[s];
-    const float4 b = xf.b[s];
-    const float3 c = xf.c[s];
-    link = __float_as_uint(c.z);
-    return calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
+    XfRecord r;
+    r.a = xf.a[s];
+    r.b = xf.b[s];
+    r.c = xf.c[s];
+    r.flags = xf.flags[s];
+    return r;
 }
-// same, for the once-per-frame streaming read of a slot's own TRS
-__device__ __forceinline__ Mat34 stream_local_model(const TransformMirror& xf, uint32_t s, uint32_t& link)
+__device__ __forceinline__ XfRecord stream_xf(const TransformMirror& xf, uint32_t s)  // the once-per-frame read
 {
-    const float4 a = stream_load(&xf.a[s]);
-    const float4 b = stream_load(&xf.b[s]);
-    const float3 c = stream_load(&xf.c[s]);
-    link = __float_as_uint(c.z);
-    return calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
+    XfRecord r;
+    r.a = stream_load(&xf.a[s]);
+    r.b = stream_load(&xf.b[s]);
+    r.c = stream_load(&xf.c[s]);
+    r.flags = stream_load(&xf.flags[s]);
+    return r;
+}
+__device__ __forceinline__ Mat34 local_model(const XfRecord& r)
+{
+    return calc_model(r.a.x, r.a.y, r.a.z, r.b.x, r.b.y, r.b.z, r.b.w, r.a.w, r.c.x, r.c.y);
 }
 
 // transform.hpp:197-214: model = calcModel(self); while (parent) model = calcModel(parent) * model.
-// `m`/`link` are the already-loaded self model and link word of the starting slot.
-__device__ __forceinline__ Mat34 chain_model(const TransformMirror& xf, Mat34 m, uint32_t link)
+// `m` is the already-built self model of entry `s`; the parent stream is only touched when the pool has chains.
+__device__ __forceinline__ Mat34 chain_model(const TransformMirror& xf, Mat34 m, uint32_t s, uint32_t flags)
 {
-    if (link & kXfWithAncestors) {
-        uint32_t p = link & kSlotMask;
+    if (xf.max_depth != 0 && (flags & kXfWithAncestors)) {
+        uint32_t p = xf.parent[s];
         for (uint32_t d = 0; d < xf.max_depth && p != kSlotNone; d++) {
-            uint32_t plink;
-            const Mat34 pm = load_local_model(xf, p, plink);
-            m = mul_affine(pm, m);
-            p = plink & kSlotMask;
+            const XfRecord pr = load_xf(xf, p);
+            m = mul_affine(local_model(pr), m);
+            p = xf.parent[p];
         }
     }
     return m;
@@ -163,43 +175,49 @@ struct CullArgs {
     uint32_t nblocks;
 };
 
-// One mesh slot through the reference's filter chain (mesh.cpp:140-157): candidate / empty-AABB / transform /
-// isActive checks, parent-chain model, camera translate, 8 corners. Returns false when the slot is filtered out;
+// One mesh entry through the reference's filter chain (mesh.cpp:140-157): candidate / empty-AABB / transform /
+// isActive checks, parent-chain model, camera translate, 8 corners. Returns false when the entry is filtered out;
 // otherwise `m` holds the camera-relative model (bakedModel) and `c` its corners. Nothing here depends on the
 // frustum, so shadow passes that share cameraPosition with the main pass (mesh.cpp:809-843) share this work.
-template <bool IDENT>
+// MAP (MeshMapping) only changes which streams are read and when; the result is the same for any mapping.
+template <uint32_t MAP>
 __device__ __forceinline__ bool prepare_slot(const MeshMirror& mesh, const TransformMirror& xf, const float (&cam)[3],
                                              uint32_t i, Mat34& m, Corners& c)
 {
     const float4 ma = stream_load(&mesh.a[i]);
-    const float3 mb = stream_load(&mesh.b[i]);
-    // Speculative prefetch: when mesh slot i usually maps to transform slot i, issue the transform loads
-    // beside the mesh loads instead of one HBM round trip later; verified against the real slot below.
-    float4 pa = {}, pb = {};
-    float3 pc = {};
-    const bool prefetched = IDENT && i < xf.count;
-    if (prefetched) {
-        pa = stream_load(&xf.a[i]);
-        pb = stream_load(&xf.b[i]);
-        pc = stream_load(&xf.c[i]);
+    const float2 mb = stream_load(&mesh.b[i]);
+    uint32_t slot = i;
+    bool candidate = true;  // kMapExact: non-candidates carry an empty box and fall out below
+    XfRecord r = {};
+    if (MAP == kMapGeneral) {
+        const uint32_t link = stream_load(&mesh.link[i]);
+        slot = link & kSlotMask;
+        candidate = (link & kMeshCandidate) && slot != kSlotNone;
+        if (candidate)
+            r = load_xf(xf, slot);
+    } else {
+        // the transform loads are issued beside the mesh loads instead of one HBM round trip later
+        const bool own = i < xf.count;
+        if (own)
+            r = stream_xf(xf, i);
+        if (MAP == kMapSpeculate) {
+            const uint32_t link = stream_load(&mesh.link[i]);
+            slot = link & kSlotMask;
+            candidate = (link & kMeshCandidate) && slot != kSlotNone;
+            if (candidate && !(own && slot == i))
+                r = load_xf(xf, slot);  // mis-speculated: this entry maps elsewhere
+        } else {
+            candidate = own;
+        }
     }
-    const uint32_t mlink = __float_as_uint(mb.z);
     const float mnx = ma.x, mny = ma.y, mnz = ma.z, mxx = ma.w, mxy = mb.x, mxz = mb.y;
     // mesh.cpp:140-142: skip free slots, disabled meshes and all(size <= 0) boxes
     const bool empty = (mxx - mnx <= 0.0f) && (mxy - mny <= 0.0f) && (mxz - mnz <= 0.0f);
-    const uint32_t slot = mlink & kSlotMask;
-    if (!(mlink & kMeshCandidate) || empty || slot == kSlotNone)
+    if (!candidate || empty)
         return false;
-    if (!(prefetched && slot == i)) {
-        pa = xf.a[slot];
-        pb = xf.b[slot];
-        pc = xf.c[slot];
-    }
-    const uint32_t link = __float_as_uint(pc.z);
-    if (!(link & kXfActive))  // mesh.cpp:150, transform.hpp:110
+    if (!(r.flags & kXfActive))  // mesh.cpp:150, transform.hpp:110
         return false;
-    const Mat34 local = calc_model(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z, pb.w, pa.w, pc.x, pc.y);
-    const Mat34 world = chain_model(xf, local, link);
+    const Mat34 world = chain_model(xf, local_model(r), slot, r.flags);
     // math::translate(-cameraPosition, model)  transform.hpp:211,213
     m = translated(world, cam[0], cam[1], cam[2]);
     aabb_corners(m, mnx, mny, mnz, mxx, mxy, mxz, c);
@@ -218,11 +236,11 @@ __device__ __forceinline__ bool behind_frustum(const Corners& c, const float (&p
     return behind;
 }
 
-template <bool IDENT>
+template <uint32_t MAP>
 __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& view,
                                               uint32_t i, Mat34& m, Corners& c)
 {
-    return prepare_slot<IDENT>(mesh, xf, view.cam, i, m, c) && !behind_frustum(c, view.planes, view.plane_count);
+    return prepare_slot<MAP>(mesh, xf, view.cam, i, m, c) && !behind_frustum(c, view.planes, view.plane_count);
 }
 
 // K1: one lane per mesh slot: visibility, isVisible byte, one ballot word per wave, per-chunk counts.
@@ -231,7 +249,7 @@ __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const Tran
 // into per-tile / per-wave staging segments and copying them (sparse partial sectors, +25..50 us in K1);
 // LDS-staged fused emission with one global atomic per flush (occupancy, barriers); a decoupled look-back
 // scan over 256-slot tiles (inter-workgroup latency and polling traffic dominate such small tiles).
-template <bool HIZ, bool IDENT>
+template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 {
     const uint32_t lb = blockIdx.x;
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
     if (i < args.mesh.count) {
         Mat34 m;
         Corners c;
-        visible = evaluate_slot<IDENT>(args.mesh, args.xf, args.view, i, m, c);
+        visible = evaluate_slot<MAP>(args.mesh, args.xf, args.view, i, m, c);
         // Hi-Z occlusion query on the survivors. Measured (profiles/r01b_hiz_ablation.txt): compacting the
         // survivors across the workgroup through LDS first buys nothing — the stage is bound by the texel
         // gathers (~4.5 M random 64-B sectors per frame), not by divergent VALU work.
@@ -280,14 +298,18 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
     const dim3 grid(a.nblocks), block(kCullBlock);
-    if (vp.use_hiz && mesh.identity)
-        hipLaunchKernelGGL((cull_kernel<true, true>), grid, block, 0, stream, a);
-    else if (vp.use_hiz)
-        hipLaunchKernelGGL((cull_kernel<true, false>), grid, block, 0, stream, a);
-    else if (mesh.identity)
-        hipLaunchKernelGGL((cull_kernel<false, true>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((cull_kernel<false, false>), grid, block, 0, stream, a);
+#define GV_LAUNCH_CULL(HIZ)                                                                       \
+    switch (mesh.mapping) {                                                                      \
+    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a); break;              \
+    }
+    if (vp.use_hiz) {
+        GV_LAUNCH_CULL(true)
+    } else {
+        GV_LAUNCH_CULL(false)
+    }
+#undef GV_LAUNCH_CULL
     return hipGetLastError();
 }
 
@@ -306,7 +328,7 @@ struct MultiCullArgs {
     ViewBuffers outs[kMaxBatchViews];
 };
 
-template <bool HIZ, bool IDENT>
+template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
 {
     const uint32_t lb = blockIdx.x;
@@ -315,7 +337,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
     const bool in_range = i < args.mesh.count;
     Mat34 m;
     Corners c;
-    const bool candidate = in_range && prepare_slot<IDENT>(args.mesh, args.xf, args.cam, i, m, c);
+    const bool candidate = in_range && prepare_slot<MAP>(args.mesh, args.xf, args.cam, i, m, c);
     __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
 #pragma unroll
     for (uint32_t v = 0; v < kMaxBatchViews; v++) {
@@ -377,14 +399,18 @@ hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, 
         a.outs[v] = outs[v < nviews ? v : 0];
     }
     const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
-    if (a.use_hiz0 && mesh.identity)
-        hipLaunchKernelGGL((cull_multi_kernel<true, true>), grid, block, 0, stream, a);
-    else if (a.use_hiz0)
-        hipLaunchKernelGGL((cull_multi_kernel<true, false>), grid, block, 0, stream, a);
-    else if (mesh.identity)
-        hipLaunchKernelGGL((cull_multi_kernel<false, true>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((cull_multi_kernel<false, false>), grid, block, 0, stream, a);
+#define GV_LAUNCH_MULTI(HIZ)                                                                            \
+    switch (mesh.mapping) {                                                                            \
+    case kMapExact: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapExact>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a); break;              \
+    }
+    if (a.use_hiz0) {
+        GV_LAUNCH_MULTI(true)
+    } else {
+        GV_LAUNCH_MULTI(false)
+    }
+#undef GV_LAUNCH_MULTI
     return hipGetLastError();
 }
 
@@ -506,25 +532,21 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
             }
         }
         const uint32_t i = (first_word + lo) * 64 + pos;
-        const float3 mb = args.mesh.b[i];
-        // same speculation as the cull kernel: fetch transform slot i beside the mesh word
-        float4 pa = {}, pb = {};
-        float3 pc = {};
-        const bool prefetched = args.mesh.identity && i < args.xf.count;
-        if (prefetched) {
-            pa = args.xf.a[i];
-            pb = args.xf.b[i];
-            pc = args.xf.c[i];
+        // visible entries passed every filter in K1: only the transform entry and its model are needed here
+        uint32_t slot = i;
+        XfRecord rec = {};
+        if (args.mesh.mapping == kMapGeneral) {  // uniform
+            slot = args.mesh.link[i] & kSlotMask;
+            rec = load_xf(args.xf, slot);
+        } else {
+            rec = load_xf(args.xf, i);  // same speculation as K1: entry i beside (or instead of) the link word
+            if (args.mesh.mapping == kMapSpeculate) {
+                slot = args.mesh.link[i] & kSlotMask;
+                if (slot != i)
+                    rec = load_xf(args.xf, slot);
+            }
         }
-        const uint32_t slot = __float_as_uint(mb.z) & kSlotMask;
-        if (!(prefetched && slot == i)) {
-            pa = args.xf.a[slot];
-            pb = args.xf.b[slot];
-            pc = args.xf.c[slot];
-        }
-        const uint32_t link = __float_as_uint(pc.z);
-        const Mat34 local = calc_model(pa.x, pa.y, pa.z, pb.x, pb.y, pb.z, pb.w, pa.w, pc.x, pc.y);
-        const Mat34 world = chain_model(args.xf, local, link);
+        const Mat34 world = chain_model(args.xf, local_model(rec), slot, rec.flags);
         const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
         const size_t rank = (size_t)base + r;
         args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
@@ -554,28 +576,27 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void scatter_records_kernel(const uint32_t* __restrict__ idx, uint32_t count,
-                                                              const float4* __restrict__ src_a, float4* __restrict__ dst_a,
-                                                              const float4* __restrict__ src_b, float4* __restrict__ dst_b,
-                                                              const float3* __restrict__ src_c, float3* __restrict__ dst_c)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_kernel(const uint32_t* __restrict__ idx, uint32_t count,
+                                                      const T* __restrict__ src, T* __restrict__ dst)
 {
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const uint32_t j = idx[k];
-        dst_a[j] = src_a[k];
-        if (src_b)
-            dst_b[j] = src_b[k];
-        dst_c[j] = src_c[k];
-    }
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+        dst[idx[k]] = src[k];
 }
 
-hipError_t launch_scatter_records(const uint32_t* idx, uint32_t count, const float4* src_a, float4* dst_a,
-                                  const float4* src_b, float4* dst_b, const float3* src_c, float3* dst_c,
-                                  hipStream_t stream)
+hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
+                          hipStream_t stream)
 {
     if (count == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(scatter_records_kernel, dim3(min((count + 255u) / 256u, 4096u)), dim3(256), 0, stream, idx, count,
-                       src_a, dst_a, src_b, dst_b, src_c, dst_c);
+    const dim3 grid(min((count + 255u) / 256u, 4096u)), block(256);
+    switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(scatter_kernel<uint8_t>, grid, block, 0, stream, idx, count, (const uint8_t*)src, (uint8_t*)dst); break;
+    case 4: hipLaunchKernelGGL(scatter_kernel<uint32_t>, grid, block, 0, stream, idx, count, (const uint32_t*)src, (uint32_t*)dst); break;
+    case 8: hipLaunchKernelGGL(scatter_kernel<float2>, grid, block, 0, stream, idx, count, (const float2*)src, (float2*)dst); break;
+    case 16: hipLaunchKernelGGL(scatter_kernel<float4>, grid, block, 0, stream, idx, count, (const float4*)src, (float4*)dst); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -818,11 +839,10 @@ __global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror x
     const uint32_t s = lb * 256 + threadIdx.x;
     if (s >= xf.count)
         return;
-    uint32_t link;
-    Mat34 m = load_local_model(xf, s, link);
+    const XfRecord r = stream_xf(xf, s);
     float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
-    if (link & kXfLive) {
-        m = chain_model(xf, m, link);
+    if (r.flags & kXfLive) {
+        const Mat34 m = chain_model(xf, local_model(r), s, r.flags);
         w0 = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
         w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
         w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
@@ -873,12 +893,15 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
     const uint32_t q = lane & 3u, e = lane >> 2;  // matrix side: column/row q of slot 16r + e
     const uint32_t s = lb * 256 + threadIdx.x;    // memory side: this lane's slot
     float* my_tile = tile[wave];
-    uint32_t link = 0;
+    uint32_t flags = 0;
     Mat34 m = {};
     const bool in_range = s < xf.count;
-    if (in_range)
-        m = stream_local_model(xf, s, link);
-    const bool live = in_range && (link & kXfLive);
+    if (in_range) {
+        const XfRecord r = stream_xf(xf, s);
+        flags = r.flags;
+        m = local_model(r);
+    }
+    const bool live = in_range && (flags & kXfLive);
     lds_put_model(my_tile + lane * kPitch, m);
     __syncthreads();
     float x[4][4];  // [round][row]: column q of the product of slot 16r + e (row 3 = bottom-row element)
@@ -890,15 +913,17 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
         x[r][2] = row[2];
         x[r][3] = q == 3 ? 1.0f : 0.0f;
     }
-    uint32_t p = (live && (link & kXfWithAncestors)) ? (link & kSlotMask) : kSlotNone;
+    uint32_t p = (live && xf.max_depth != 0 && (flags & kXfWithAncestors)) ? xf.parent[s] : kSlotNone;
     for (uint32_t d = 0; d < xf.max_depth; d++) {
         const bool has = p != kSlotNone;
         if (!__syncthreads_or(has))
             break;  // workgroup-uniform exit (MFMA ignores EXEC: every lane takes every step)
-        uint32_t plink = kSlotNone;
+        uint32_t next = kSlotNone;
         Mat34 pm = {};
-        if (has)
-            pm = load_local_model(xf, p, plink);
+        if (has) {
+            pm = local_model(load_xf(xf, p));
+            next = xf.parent[p];
+        }
         lds_put_model(my_tile + lane * kPitch, pm);
         has_parent[wave][lane] = has ? 1u : 0u;
         __syncthreads();
@@ -922,7 +947,7 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
             x[r][2] = step ? acc[2] : x[r][2];
             x[r][3] = step ? acc[3] : x[r][3];
         }
-        p = has ? (plink & kSlotMask) : kSlotNone;
+        p = next;
     }
     // liveness of slot 16r + e on the matrix side
     has_parent[wave][lane] = live ? 1u : 0u;

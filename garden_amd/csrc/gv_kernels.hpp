@@ -5,27 +5,37 @@
 
 namespace gv {
 
-// ---- device mirror of the component pools (HBM layout, DESIGN.md §"Data layout") ----
-// 28-bit slot + 4 flag bits packed in the third float of the 12-byte streams.
+// ---- device mirror of the component pools (HBM layout) ----
+// Streams are split so that a kernel reads only what the pool needs: 65 B per entity for a flat pool whose
+// meshes and transforms pair up 1:1 (TRS 40 + flags 1 + AABB 24: the algorithmic minimum), +4 B parent entry
+// with a hierarchy, +4 B transform entry when mesh and transform pools are ordered independently.
 constexpr uint32_t kSlotMask = 0x0FFFFFFFu;
 constexpr uint32_t kSlotNone = 0x0FFFFFFFu;
-constexpr uint32_t kXfActive = 1u << 28;         // selfActive && ancestorsActive (transform.hpp:110)
-constexpr uint32_t kXfWithAncestors = 1u << 29;  // modelWithAncestors (transform.hpp:60)
-constexpr uint32_t kXfLive = 1u << 30;           // entity != 0
-constexpr uint32_t kMeshCandidate = 1u << 28;    // entity != 0 && isEnabled (mesh.cpp:142)
+constexpr uint32_t kXfActive = 1u;         // selfActive && ancestorsActive (transform.hpp:110)
+constexpr uint32_t kXfWithAncestors = 2u;  // modelWithAncestors (transform.hpp:60)
+constexpr uint32_t kXfLive = 4u;           // entity != 0
+constexpr uint32_t kMeshCandidate = 1u << 28;  // entity != 0 && isEnabled (mesh.cpp:142), in MeshMirror::link
 
 struct TransformMirror {
-    const float4* a;  // (pos.x, pos.y, pos.z, scale.x)
-    const float4* b;  // quat xyzw
-    const float3* c;  // (scale.y, scale.z, bits: parent slot | kXf* flags)
+    const float4* a;         // (pos.x, pos.y, pos.z, scale.x)
+    const float4* b;         // quat xyzw
+    const float2* c;         // (scale.y, scale.z)
+    const uint8_t* flags;    // kXf* bits
+    const uint32_t* parent;  // parent entry or kSlotNone; read only when max_depth > 0
     uint32_t count;
     uint32_t max_depth;  // longest parent chain (bounds the walk; a cycle is rejected at mirror build)
 };
+enum MeshMapping : uint32_t {
+    kMapGeneral = 0,    // read link[], then the transform entry it names
+    kMapSpeculate = 1,  // >= 90 % of the entries map to their own index: prefetch xf[i] beside mesh[i], verify with link[]
+    kMapExact = 2       // every candidate maps to its own index: link[] is not read at all
+};
 struct MeshMirror {
-    const float4* a;  // (aabb.min.xyz, aabb.max.x)
-    const float3* b;  // (aabb.max.y, aabb.max.z, bits: transform slot | kMesh* flags)
+    const float4* a;       // (aabb.min.xyz, aabb.max.x)
+    const float2* b;       // (aabb.max.y, aabb.max.z); non-candidate entries hold an empty box (min == max == 0)
+    const uint32_t* link;  // transform entry | kMeshCandidate
     uint32_t count;
-    uint32_t identity;  // most mesh entries i map to transform entry i: prefetch xf[i] beside mesh[i] (speed only)
+    uint32_t mapping;      // MeshMapping, decided at mirror build (speed only: every mapping is handled correctly)
     const uint32_t* orig;  // mirror entry -> pool slot (null: the mirror is in pool order)
 };
 
@@ -94,10 +104,9 @@ struct SortBuffers {
 };
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 
-// dirty-range upload into a permuted mirror: dst_x[idx[k]] = src_x[k] (b streams optional)
-hipError_t launch_scatter_records(const uint32_t* idx, uint32_t count, const float4* src_a, float4* dst_a,
-                                  const float4* src_b, float4* dst_b, const float3* src_c, float3* dst_c,
-                                  hipStream_t stream);
+// dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
+hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
+                          hipStream_t stream);
 // out[k] = world[xinv[first + k]] (3 float4 per slot)
 hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32_t first, uint32_t count, float4* out,
                                hipStream_t stream);
