@@ -164,6 +164,7 @@ struct GvCtx {
     DeviceBuf<float4> d_xa, d_xb;
     DeviceBuf<float2> d_xc;
     DeviceBuf<uint8_t> d_xflags;
+    DeviceBuf<unsigned long long> d_xactive;  // bit-plane of kXfActive, derived on the device
     DeviceBuf<uint32_t> d_xparent;
     PinnedBuf<float4> h_xa, h_xb;
     PinnedBuf<float2> h_xc;
@@ -644,6 +645,7 @@ int sync_mirror(GvCtx* ctx)
         GV_HIP(ctx, ctx->d_xb.reserve(cap));
         GV_HIP(ctx, ctx->d_xc.reserve(cap));
         GV_HIP(ctx, ctx->d_xflags.reserve(cap));
+        GV_HIP(ctx, ctx->d_xactive.reserve(cap / 64 + 1));
         GV_HIP(ctx, ctx->d_xparent.reserve(cap));
         GV_HIP(ctx, ctx->h_xa.reserve(cap));
         GV_HIP(ctx, ctx->h_xb.reserve(cap));
@@ -671,6 +673,8 @@ int sync_mirror(GvCtx* ctx)
         } else {
             ctx->max_depth = 0;
         }
+        if (n)
+            GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
         ctx->xf_need_full = false;
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
@@ -693,6 +697,7 @@ int sync_mirror(GvCtx* ctx)
                 rc = upload_transforms_scattered(ctx, lo, hi);
             if (rc != GV_OK)
                 return rc;
+            GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
         }
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
@@ -768,6 +773,7 @@ TransformMirror xf_mirror(const GvCtx* ctx)
     m.b = ctx->d_xb.ptr;
     m.c = ctx->d_xc.ptr;
     m.flags = ctx->d_xflags.ptr;
+    m.active_bits = ctx->d_xactive.ptr;
     m.parent = ctx->d_xparent.ptr;
     m.count = ctx->xf.occupancy;
     m.max_depth = ctx->max_depth;
@@ -950,7 +956,7 @@ void gv_destroy(GvCtx* ctx)
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xparent.release();
+    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
     ctx->h_xa.release(); ctx->h_xb.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
         p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release();

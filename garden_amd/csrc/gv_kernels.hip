@@ -198,8 +198,18 @@ __device__ __forceinline__ bool prepare_slot(const MeshMirror& mesh, const Trans
     } else {
         // the transform loads are issued beside the mesh loads instead of one HBM round trip later
         const bool own = i < xf.count;
-        if (own)
-            r = stream_xf(xf, i);
+        if (own) {
+            if (MAP == kMapExact && xf.max_depth == 0) {
+                // flat + exactly paired: only the active bit matters (no chain, so modelWithAncestors is moot) and
+                // the 64 bits of this wave sit in one word
+                r.a = stream_load(&xf.a[i]);
+                r.b = stream_load(&xf.b[i]);
+                r.c = stream_load(&xf.c[i]);
+                r.flags = (uint32_t)((xf.active_bits[i >> 6] >> (i & 63u)) & 1ull) * kXfActive;
+            } else {
+                r = stream_xf(xf, i);
+            }
+        }
         if (MAP == kMapSpeculate) {
             const uint32_t link = stream_load(&mesh.link[i]);
             slot = link & kSlotMask;
@@ -573,6 +583,24 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.out = out;
     const uint32_t nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
     hipLaunchKernelGGL(emit_kernel, dim3(nchunks * kEmitParts), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pack_active_kernel(const uint8_t* __restrict__ flags, uint32_t count,
+                                                          unsigned long long* __restrict__ bits)
+{
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const bool active = e < count && (flags[e] & kXfActive);
+    const unsigned long long word = __ballot(active);
+    if ((threadIdx.x & 63u) == 0 && (e & ~63u) < count)
+        bits[e >> 6] = word;
+}
+
+hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(pack_active_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, flags, count, bits);
     return hipGetLastError();
 }
 

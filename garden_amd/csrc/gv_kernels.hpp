@@ -21,6 +21,9 @@ struct TransformMirror {
     const float4* b;         // quat xyzw
     const float2* c;         // (scale.y, scale.z)
     const uint8_t* flags;    // kXf* bits
+    const unsigned long long* active_bits;  // bit e of word e/64 = kXfActive of entry e (derived from flags[] on the
+                                            // device after every upload); lets a flat, exactly-paired pool fetch its
+                                            // 64 flags with one wave-uniform 8-byte load instead of a byte per lane
     const uint32_t* parent;  // parent entry or kSlotNone; read only when max_depth > 0
     uint32_t count;
     uint32_t max_depth;  // longest parent chain (bounds the walk; a cycle is rejected at mirror build)
@@ -104,6 +107,8 @@ struct SortBuffers {
 };
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 
+// derives TransformMirror::active_bits from flags[]
+hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream);
 // dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
 hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
                           hipStream_t stream);
