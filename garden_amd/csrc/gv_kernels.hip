@@ -37,6 +37,11 @@ __device__ __forceinline__ float2 stream_load(const float2* p)
     return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(float4* p, float4 v)
+{
+    __builtin_nontemporal_store(f32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4n*>(p));
+}
+__device__ __forceinline__ void stream_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ uint32_t stream_load(const uint8_t* p) { return __builtin_nontemporal_load(p); }
 
 // one transform entry: TRS + flag bits
@@ -875,9 +880,9 @@ __global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror x
         w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
         w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
     }
-    world[(size_t)s * 3 + 0] = w0;
-    world[(size_t)s * 3 + 1] = w1;
-    world[(size_t)s * 3 + 2] = w2;
+    stream_store(&world[(size_t)s * 3 + 0], w0);
+    stream_store(&world[(size_t)s * 3 + 1], w1);
+    stream_store(&world[(size_t)s * 3 + 2], w2);
 }
 
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream)
@@ -987,9 +992,9 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
             const bool ok = has_parent[wave][16 * r + e] != 0;
             // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per round
             float* dst = world + (size_t)slot * 12 + q * 3;
-            dst[0] = ok ? x[r][0] : 0.0f;
-            dst[1] = ok ? x[r][1] : 0.0f;
-            dst[2] = ok ? x[r][2] : 0.0f;
+            stream_store(dst + 0, ok ? x[r][0] : 0.0f);
+            stream_store(dst + 1, ok ? x[r][1] : 0.0f);
+            stream_store(dst + 2, ok ? x[r][2] : 0.0f);
         }
     }
 }

@@ -311,3 +311,40 @@ def test_hierarchy_cycle_is_rejected(gpu):
         with pytest.raises(GvError) as e:
             gpu.hierarchy_rebuild()
         assert e.value.code == GV_E_ARG and "cycle" in str(e.value)
+
+
+def test_several_mesh_pools_share_the_transform_pool(gpu, oracle):
+    """Several IMeshRenderSystems (mesh.cpp:69-108) each own a pool; all resolve entities through the one
+    TransformComponent pool. Pool 0: plain 48-byte components for every entity; pool 1: an 80-byte derived
+    component for every third entity, in a different slot order; pool 2: empty."""
+    from garden_amd.pools import MESH_DTYPE, derived_mesh_dtype
+    sc = scene.hierarchy_scene(30_000, depth=3, fanout=9)
+    rng = np.random.default_rng(12)
+    ents = sc.transforms["entity"][sc.transforms["entity"] != 0]
+    chosen = rng.permutation(ents[::3])
+    pool1 = np.zeros(chosen.shape[0] + 50, dtype=derived_mesh_dtype(32))
+    pool1["entity"][:chosen.shape[0]] = chosen          # the last 50 slots stay free (entity 0)
+    pool1["isEnabled"] = 1
+    h = rng.uniform(0.5, 3.0, (pool1.shape[0], 3)).astype(np.float32)
+    pool1["aabbMin"][:, :3] = -h
+    pool1["aabbMax"][:, :3] = h
+    pool2 = np.zeros(0, dtype=MESH_DTYPE)
+    pools = [sc.meshes, pool1, pool2]
+    views = [scene.main_camera_view(), scene.cascade_view(index=3)]
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    for pid, pool in enumerate(pools):
+        gpu.bind_pool(pid, pool)
+    gpu.hierarchy_rebuild()
+    for pid, pool in enumerate(pools):
+        gpu.cull(pid, views)
+        if pool.shape[0] == 0:
+            assert all(gpu.fetch(vi, occupancy=0)["draw_count"] == 0 for vi in range(len(views)))
+            continue
+        for vi, v in enumerate(views):
+            pool["isVisible"] = 7
+            got = gpu.fetch(vi, write_back=True, occupancy=pool.shape[0])
+            got_vis = pool["isVisible"].copy()
+            pool["isVisible"] = 7
+            exp = oracle.prepare_meshes(pool, sc.transforms, sc.entity_to_transform, v)
+            assert_same(got, got_vis, exp, pool["isVisible"].copy(), main_pass=v["shadow_pass"] < 0)
+        assert got["draw_count"] > 0
