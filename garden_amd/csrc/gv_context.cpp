@@ -8,6 +8,7 @@
 //
 // There is NO CPU fallback: without a gfx950 device gv_create fails with GV_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
 #include <atomic>
@@ -230,6 +231,14 @@ struct GvCtx {
     } while (0)
 
 namespace {
+
+// roctx ranges named after the reference's profiler zones (SET_CPU_ZONE_SCOPED / SET_GPU_DEBUG_LABEL:
+// "Meshes Prepare" source/system/render/mesh.cpp:334, "Meshes Sort" :267, "HiZ Downsample" hiz.cpp:146), so a
+// rocprofv3 --marker-trace timeline reads like the engine's Tracy capture.
+struct ZoneScope {
+    explicit ZoneScope(const char* name) { roctxRangePushA(name); }
+    ~ZoneScope() { roctxRangePop(); }
+};
 
 // ---- profiling events ----
 struct KernelTimer {
@@ -857,6 +866,7 @@ ViewBuffers view_buffers(ViewState& vs)
 
 int hiz_reduce(GvCtx* ctx)
 {
+    ZoneScope zone("HiZ Downsample");
     KernelTimer timer(ctx, GV_K_HIZ);
     uint32_t k = 1;
     while (k < ctx->hiz_mips) {
@@ -1072,6 +1082,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         return GV_E_ARG;
     if (pool_id >= GV_MAX_POOLS || !views || view_count == 0 || view_count > GV_MAX_VIEWS)
         return ctx->fail(GV_E_ARG, "gv_cull: bad argument (pool %u, %u views)", pool_id, view_count);
+    ZoneScope zone("Meshes Prepare");
     PoolState& p = ctx->pools[pool_id];
     if (!p.bound || !ctx->xf.bound)
         return ctx->fail(GV_E_STATE, "gv_cull: pools not bound");
@@ -1267,6 +1278,7 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
         return GV_E_ARG;
     if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
         return ctx->fail(GV_E_ARG, "gv_sort: view %u has no emitted records", view_index);
+    ZoneScope zone("Meshes Sort");
     ViewState& vs = ctx->views[view_index];
     if (vs.occupancy == 0)
         return GV_OK;
