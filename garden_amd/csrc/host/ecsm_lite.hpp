@@ -156,7 +156,9 @@ public:
 template <class T>
 class Singleton {
 protected:
-    inline static T* singletonInstance = nullptr;
+    // the base pointer is stored while the derived object is still under construction; the downcast happens at
+    // access time, when the object is a complete T
+    inline static Singleton* singletonInstance = nullptr;
 
 public:
     struct Instance {
@@ -164,11 +166,11 @@ public:
         {
             if (!singletonInstance)
                 throw std::runtime_error("singleton not created");
-            return singletonInstance;
+            return static_cast<T*>(singletonInstance);
         }
-        static T* tryGet() noexcept { return singletonInstance; }
+        static T* tryGet() noexcept { return static_cast<T*>(singletonInstance); }
     };
-    Singleton() { singletonInstance = static_cast<T*>(this); }
+    Singleton() { singletonInstance = this; }
     ~Singleton() { singletonInstance = nullptr; }
 };
 
