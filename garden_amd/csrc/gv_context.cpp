@@ -161,6 +161,7 @@ struct GvCtx {
 
     TransformBinding xf;
     bool xf_need_full = false;
+    bool xf_links_dirty = false;  // a ranged GV_DIRTY_HIERARCHY: parent links changed -> re-validate depth / cycles
     DirtyRange xf_dirty;
     DeviceBuf<float4> d_xa, d_xb;
     DeviceBuf<float2> d_xc;
@@ -685,6 +686,7 @@ int sync_mirror(GvCtx* ctx)
         if (n)
             GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
         ctx->xf_need_full = false;
+        ctx->xf_links_dirty = false;
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
         // transform entries may have moved: every mesh pool's slot column must be re-resolved
@@ -707,7 +709,17 @@ int sync_mirror(GvCtx* ctx)
             if (rc != GV_OK)
                 return rc;
             GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
+            if (ctx->xf_links_dirty) {  // setParent (transform.cpp:130-195): chains changed length, maybe closed a cycle
+                uint32_t depth = 0;
+                rc = compute_max_depth(ctx, &depth);
+                if (rc != GV_OK) {
+                    ctx->xf_need_full = true;  // the mirror now holds a cyclic link: rebuild once the caller has fixed it
+                    return rc;
+                }
+                ctx->max_depth = depth;
+            }
         }
+        ctx->xf_links_dirty = false;
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
     }
@@ -1047,7 +1059,12 @@ int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count)
         ctx->xf_dirty.add(first, count);
         return GV_OK;
     case GV_DIRTY_HIERARCHY:
-        ctx->xf_need_full = true;
+        if (count == 0) {
+            ctx->xf_need_full = true;  // everything: entities came or went; the mirror is re-ordered too
+        } else {
+            ctx->xf_dirty.add(first, count);  // re-parented slots: links re-gathered in place, order kept
+            ctx->xf_links_dirty = true;
+        }
         return GV_OK;
     case GV_DIRTY_MESH: {
         const uint32_t pool = first >> 28, lo = first & kSlotMask;

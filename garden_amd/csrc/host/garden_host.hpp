@@ -7,6 +7,7 @@
 //   event chain Update -> Render -> PreDeferredRender   source/system/graphics.cpp:312,409; render/deferred.cpp:441-446
 // The math types are plain PODs (cfnptr/math is absent); all arithmetic of the path lives behind the C-ABI.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
@@ -74,6 +75,9 @@ static_assert(sizeof(TransformComponent) == 80, "TransformComponent must keep th
 class TransformSystem final : public ComponentSystem<TransformComponent>, public Singleton<TransformSystem> {
 public:
     uint64_t hierarchyVersion = 0, transformVersion = 0;  // bumped by the mutators below; consumers re-mirror
+    uint64_t reparentVersion = 0;  // setParent on existing entities: only links of [reparentLo, reparentHi) changed
+    uint32_t reparentLo = UINT32_MAX, reparentHi = 0;
+    void clearReparentRange() noexcept { reparentLo = UINT32_MAX; reparentHi = 0; }
 
     View<TransformComponent> add(ID<Entity> entity) { hierarchyVersion++; return addTo(entity); }
     // transform.cpp:130-195: unlink from the old parent's childs[], append to the new one, recompute ancestorsActive
@@ -110,7 +114,11 @@ public:
             active = np->isActive();
         }
         propagateActive(entity, active);
-        hierarchyVersion++;
+        const uint32_t slot = (uint32_t)(*view - components.getData());
+        reparentLo = std::min(reparentLo, slot);
+        reparentHi = std::max(reparentHi, slot + 1);
+        reparentVersion++;
+        transformVersion++;  // ancestorsActive of the subtree may have flipped
     }
     // transform.cpp:75-127: flips selfActive and pushes ancestorsActive down the subtree
     void setActive(ID<Entity> entity, bool isActive)

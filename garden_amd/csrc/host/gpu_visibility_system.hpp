@@ -39,7 +39,7 @@ private:
     std::vector<UnsortedBuffer*> unsortedBuffers;
     std::vector<ShadowPass> shadowPasses;
     std::vector<std::vector<UnsortedBuffer*>> shadowBuffers;  // [pool][pass]
-    uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull;
+    uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull, seenReparent = 0;
     std::vector<uint64_t> seenMesh;
     bool useHiz = false;
 
@@ -174,13 +174,20 @@ private:
         check(gv_transform_bind(ctx, pool.getData(), sizeof(TransformComponent), pool.getOccupancy(), &transformLayout,
                                 entityMap.data(), (uint32_t)entityMap.size()), "gv_transform_bind");
         if (seenHierarchy != transformSystem->hierarchyVersion) {
-            check(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, 0, 0), "gv_mark_dirty");
+            check(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, 0, 0), "gv_mark_dirty");  // entities came or went
             seenHierarchy = transformSystem->hierarchyVersion;
             seenTransform = transformSystem->transformVersion;
-        } else if (seenTransform != transformSystem->transformVersion) {
-            check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0, pool.getOccupancy()), "gv_mark_dirty");
-            seenTransform = transformSystem->transformVersion;
+        } else {
+            if (seenReparent != transformSystem->reparentVersion && transformSystem->reparentLo < transformSystem->reparentHi)
+                check(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, transformSystem->reparentLo,
+                                    transformSystem->reparentHi - transformSystem->reparentLo), "gv_mark_dirty");
+            if (seenTransform != transformSystem->transformVersion) {
+                check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0, pool.getOccupancy()), "gv_mark_dirty");
+                seenTransform = transformSystem->transformVersion;
+            }
         }
+        seenReparent = transformSystem->reparentVersion;
+        transformSystem->clearReparentRange();
 
         const auto& cc = graphicsSystem->getCommonConstants();
         for (uint32_t p = 0; p < meshSystems.size(); p++) {

@@ -101,7 +101,10 @@ int gv_pool_bind(GvCtx* ctx, uint32_t pool_id, void* base, size_t stride, uint32
 typedef enum GvDirtyKind {
     GV_DIRTY_TRANSFORM = 0, /* TRS / active flags of transform slots [first, first+count) changed
                                (setPosition/Scale/Rotation transform.hpp:74-104, setActive transform.cpp:75-127) */
-    GV_DIRTY_HIERARCHY = 1, /* parent links changed (setParent transform.cpp:130-195, destroy :30-73) */
+    GV_DIRTY_HIERARCHY = 1, /* count > 0: transform slots [first, first+count) were re-parented (setParent
+                               transform.cpp:130-195): their links are re-gathered in place and depth / cycles
+                               re-validated; count == 0: entities came or went (destroy :30-73, create): rebuild and
+                               re-order the whole mirror */
     GV_DIRTY_MESH = 2       /* mesh slots changed; pool id in the top 4 bits of `first` */
 } GvDirtyKind;
 int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count);

@@ -171,7 +171,7 @@ int main(int argc, char** argv)
                 manager.destroy(ents[i]);
             }
             meshSystem->markMeshesChanged();
-            transformSystem->hierarchyVersion++;
+            transformSystem->hierarchyVersion++;  // entities were destroyed: full rebuild
             graphicsSystem->setCamera(viewProj, f32x4(12.5f, -3.0f, 40.0f));
         };
 

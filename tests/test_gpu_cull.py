@@ -274,9 +274,22 @@ def test_dirty_ranges_and_rebinding(gpu, oracle):
     gpu.mark_dirty(GV_DIRTY_MESH, 100, 250, pool_id=0)
     cull_and_compare()
     sc.transforms["parent"][15000:15100] = sc.transforms["entity"][10:110]  # re-parent (setParent, transform.cpp:130-195)
-    gpu.mark_dirty(GV_DIRTY_HIERARCHY, 0, 0)
+    gpu.mark_dirty(GV_DIRTY_HIERARCHY, 0, 0)          # count == 0: rebuild (and re-order) everything
     cull_and_compare()
     assert gpu.stats()["max_depth"] >= 2
+    # ranged hierarchy mark: only these slots' links are re-gathered, the mirror order is kept, depth re-validated
+    sc.transforms["parent"][16000:16050] = sc.transforms["entity"][15000:15050]   # hang them under the re-parented ones
+    gpu.mark_dirty(GV_DIRTY_HIERARCHY, 16000, 50)
+    cull_and_compare()
+    assert gpu.stats()["max_depth"] >= 2
+    from garden_amd.lib import GV_E_ARG, GvError
+    sc.transforms["parent"][10] = sc.transforms["entity"][16000]                  # closes a cycle 10 -> 16000 -> 15000 -> 10
+    gpu.mark_dirty(GV_DIRTY_HIERARCHY, 10, 1)
+    with pytest.raises(GvError) as e:
+        gpu.cull(0, [v])
+    assert e.value.code == GV_E_ARG and "cycle" in str(e.value)
+    sc.transforms["parent"][10] = 0                                              # caller fixes it: next sync rebuilds
+    cull_and_compare()
 
 
 def test_empty_and_tiny_pools_and_derived_stride(gpu, oracle):
