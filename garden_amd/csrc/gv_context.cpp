@@ -11,6 +11,7 @@
 #include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -331,19 +332,47 @@ inline uint32_t xslot_to_mirror(const GvCtx* ctx, uint32_t slot)
     return (slot == kSlotNone || ctx->xinv.empty()) ? slot : ctx->xinv[slot];
 }
 
-// stable LSD radix sort of `order` by 30-bit keys[order[k]] (3 passes of 10 bits)
+// stable LSD radix sort of `order` by 30-bit keys[order[k]] (3 passes of 10 bits), multi-threaded: every thread
+// owns one contiguous chunk of the input, histograms it, and scatters it to offsets derived from the
+// (digit, thread) prefix — stable because chunks keep their relative order inside each digit.
 void radix_order(const std::vector<uint32_t>& keys, std::vector<uint32_t>& order)
 {
-    std::vector<uint32_t> tmp(order.size());
+    const size_t n = order.size();
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t threads = n < (1u << 16) ? 1u : std::min(hw, 16u);
+    const size_t per = (n + threads - 1) / threads;
+    std::vector<uint32_t> tmp(n);
+    std::vector<size_t> hist((size_t)threads * 1024);
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < threads; t++)
+            pool.emplace_back([&, t] { fn(t); });
+        fn(0u);
+        for (auto& th : pool)
+            th.join();
+    };
     for (int pass = 0; pass < 3; pass++) {
         const int shift = pass * 10;
-        size_t count[1025] = {0};
-        for (uint32_t v : order)
-            count[((keys[v] >> shift) & 1023u) + 1]++;
-        for (int k = 0; k < 1024; k++)
-            count[k + 1] += count[k];
-        for (uint32_t v : order)
-            tmp[count[(keys[v] >> shift) & 1023u]++] = v;
+        std::fill(hist.begin(), hist.end(), 0);
+        run([&](uint32_t t) {
+            size_t* h = hist.data() + (size_t)t * 1024;
+            for (size_t k = std::min(n, per * t), e = std::min(n, per * (t + 1)); k < e; k++)
+                h[(keys[order[k]] >> shift) & 1023u]++;
+        });
+        size_t sum = 0;
+        for (uint32_t d = 0; d < 1024; d++)
+            for (uint32_t t = 0; t < threads; t++) {
+                const size_t c = hist[(size_t)t * 1024 + d];
+                hist[(size_t)t * 1024 + d] = sum;
+                sum += c;
+            }
+        run([&](uint32_t t) {
+            size_t* h = hist.data() + (size_t)t * 1024;
+            for (size_t k = std::min(n, per * t), e = std::min(n, per * (t + 1)); k < e; k++) {
+                const uint32_t v = order[k];
+                tmp[h[(keys[v] >> shift) & 1023u]++] = v;
+            }
+        });
         order.swap(tmp);
     }
 }
@@ -436,6 +465,24 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
     const uint32_t n = p.occupancy;
     if (ctx->xinv.empty() || n < 2)
         return;
+    // 1:1 pools (mesh slot i <-> transform slot i, or no transform at all): the transform permutation IS the mesh
+    // permutation — entries without a transform sort last on both sides, in slot order — so skip the second sort
+    if (n == ctx->xf.occupancy) {
+        std::atomic<bool> paired{true};
+        parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
+            for (uint32_t i = a; i < b && paired.load(std::memory_order_relaxed); i++) {
+                const uint32_t slot = entity_slot(ctx->xf, load_u32(p.base + (size_t)i * p.stride + p.layout.entity));
+                const bool free_xf = !load_u32(ctx->xf.base + (size_t)i * ctx->xf.stride + ctx->xf.layout.entity);
+                if (!(slot == i || (slot == kSlotNone && free_xf)))
+                    paired.store(false, std::memory_order_relaxed);
+            }
+        });
+        if (paired) {
+            p.perm = ctx->xperm;
+            p.inv = ctx->xinv;
+            return;
+        }
+    }
     std::vector<uint32_t> key(n);
     parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
         for (uint32_t i = a; i < b; i++) {
@@ -639,8 +686,22 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
     return GV_OK;
 }
 
+struct PhaseTimer {  // GV_DEBUG_TIMING=1: prints the host phases of a mirror build
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("GV_DEBUG_TIMING") != nullptr;
+    void lap(const char* what)
+    {
+        if (!on)
+            return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gv] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int sync_mirror(GvCtx* ctx)
 {
+    PhaseTimer phase;
     if (!ctx->xf.bound)
         return ctx->fail(GV_E_STATE, "gv_sync: no transform pool bound");
     GV_HIP(ctx, hipSetDevice(ctx->device));
@@ -662,16 +723,20 @@ int sync_mirror(GvCtx* ctx)
         GV_HIP(ctx, ctx->h_xc.reserve(cap));
         GV_HIP(ctx, ctx->h_xflags.reserve(cap));
         GV_HIP(ctx, ctx->h_xparent.reserve(cap));
+        phase.lap("reserve transforms");
         int rc = build_transform_order(ctx);
         if (rc != GV_OK)
             return rc;
+        phase.lap("transform order");
         if (n) {
             gather_transforms(ctx, 0, n);
+            phase.lap("gather transforms");
             uint32_t depth = 0;
             rc = compute_max_depth(ctx, &depth);
             if (rc != GV_OK)
                 return rc;
             ctx->max_depth = depth;
+            phase.lap("max depth");
             rc = upload_transforms(ctx, 0, n);
             if (rc != GV_OK)
                 return rc;
@@ -738,10 +803,13 @@ int sync_mirror(GvCtx* ctx)
             GV_HIP(ctx, p.h_a.reserve(cap));
             GV_HIP(ctx, p.h_b.reserve(cap));
             GV_HIP(ctx, p.h_link.reserve(cap));
+            phase.lap("upload transforms + reserve");
             build_mesh_order(ctx, p);
+            phase.lap("mesh order");
             p.mapping = kMapGeneral;
             if (p.occupancy) {
                 gather_meshes(ctx, p, 0, p.occupancy);
+                phase.lap("gather meshes");
                 // how do mesh entries pair with transform entries? (speed only: every mapping is handled)
                 size_t candidates = 0, own = 0;
                 for (uint32_t i = 0; i < p.occupancy; i++) {
@@ -761,6 +829,7 @@ int sync_mirror(GvCtx* ctx)
                     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
                 }
             }
+            phase.lap("mapping + upload meshes");
             p.need_full = false;
             p.dirty.clear();
         } else if (p.dirty.any()) {
