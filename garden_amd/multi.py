@@ -44,13 +44,15 @@ def allgatherv_indices(idx_buf, count, dist, group=None):
         offs.append(offs[-1] + int(c))
     pieces = [out[offs[r]:offs[r + 1]] for r in range(world)]
     global _uneven_all_gather_ok
-    if backend == "nccl" and _uneven_all_gather_ok:
+    if backend == "nccl" and _uneven_all_gather_ok and min(counts_h) > 0:  # empty shards (a tile behind the camera)
+        # go through the per-root path below, which simply skips them
         try:
             dist.all_gather(pieces, idx_buf[:count], group=group)  # uneven sizes -> grouped per-root broadcasts
             return out, counts
         except (RuntimeError, ValueError):
             _uneven_all_gather_ok = False  # this torch build wants equal sizes: one broadcast per root instead
-    pieces[rank].copy_(idx_buf[:count])
+    if count:
+        pieces[rank].copy_(idx_buf[:count])
     works = []
     for r in range(world):
         if counts_h[r]:
