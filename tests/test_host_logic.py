@@ -101,3 +101,29 @@ def test_allgatherv_world_size_2_gloo(oracle):
         assert np.array_equal(gathered.astype(np.int64), exp)
         assert counts.sum() == exp.shape[0] and counts[rank] == k
     assert len(np.unique(exp)) == exp.shape[0]
+
+
+def _empty_shard_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import allgatherv_indices
+    buf = torch.arange(100, dtype=torch.int32) + 1000 * rank
+    count = 0 if rank == 1 else 40 + rank  # rank 1's tile is entirely behind the camera
+    gathered, counts = allgatherv_indices(buf, count, dist)
+    ret[rank] = (gathered.numpy().copy(), counts.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgatherv_with_an_empty_shard():
+    import torch.multiprocessing as mp
+    world, port = 3, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_empty_shard_worker, args=(world, port, ret), nprocs=world, join=True)
+    exp = np.concatenate([np.arange(40) + 0, np.arange(42) + 2000])
+    for rank in range(world):
+        gathered, counts = ret[rank]
+        assert list(counts) == [40, 0, 42] and np.array_equal(gathered, exp)
