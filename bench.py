@@ -270,7 +270,8 @@ def main():
             "config": {"workload": wl["name"], "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
                        "exchange": f"all-gatherv of uint32 visible lists ({backend}), {gathered_total} indices gathered per rank" if world > 1 else None,
-                       "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"]},
+                       # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
+                       "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"] if st["device_ms"][k] > 0},
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes},
             "roofline": {"bound": "hbm", "kernel": "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -917,6 +917,15 @@ __device__ __forceinline__ void lds_put_model(float* row, const Mat34& m)
     row[9] = m.c3x; row[10] = m.c3y; row[11] = m.c3z;
 }
 
+// Each wave owns its LDS tile, so the matrix/memory-side hand-over only needs wave-level ordering: LDS operations of
+// one wave execute in issue order; the fences keep the compiler from moving them across the hand-over.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world)
 {
     __shared__ float tile[4][64 * kPitch];  // one tile per wave
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
     }
     const bool live = in_range && (flags & kXfLive);
     lds_put_model(my_tile + lane * kPitch, m);
-    __syncthreads();
+    wave_lds_sync();
     float x[4][4];  // [round][row]: column q of the product of slot 16r + e (row 3 = bottom-row element)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -949,8 +958,8 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
     uint32_t p = (live && xf.max_depth != 0 && (flags & kXfWithAncestors)) ? xf.parent[s] : kSlotNone;
     for (uint32_t d = 0; d < xf.max_depth; d++) {
         const bool has = p != kSlotNone;
-        if (!__syncthreads_or(has))
-            break;  // workgroup-uniform exit (MFMA ignores EXEC: every lane takes every step)
+        if (!__any(has))
+            break;  // wave-uniform exit (MFMA ignores EXEC: every lane of the wave takes every step)
         uint32_t next = kSlotNone;
         Mat34 pm = {};
         if (has) {
@@ -959,7 +968,7 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
         }
         lds_put_model(my_tile + lane * kPitch, pm);
         has_parent[wave][lane] = has ? 1u : 0u;
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             // row q of the parent's local model of slot 16r + e: A[q][k] = column k, row q
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
     }
     // liveness of slot 16r + e on the matrix side
     has_parent[wave][lane] = live ? 1u : 0u;
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint32_t slot = lb * 256 + wave * 64 + 16 * r + e;
