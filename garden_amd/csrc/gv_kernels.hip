@@ -987,7 +987,8 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
             x[r][0] = step ? acc[0] : x[r][0];
             x[r][1] = step ? acc[1] : x[r][1];
             x[r][2] = step ? acc[2] : x[r][2];
-            x[r][3] = step ? acc[3] : x[r][3];
+            // acc[3] (the bottom-row element) is not taken: models are affine and x[r][3] stays the constant 0 / 1,
+            // as in every other implementation (it only differs from acc[3] when the operands are non-finite)
         }
         p = next;
     }

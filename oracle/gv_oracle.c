@@ -55,6 +55,28 @@ void gvo_mul4x4(const float a[16], const float b[16], float out[16])
     memcpy(out, r, sizeof(r));
 }
 
+/* The chain product parentModel * model (transform.hpp:209). Model matrices are AFFINE: the bottom row is
+ * (0,0,0,1) by construction (calcModel) and is carried as that constant, never recomputed — for finite inputs exactly
+ * what the full 4x4 chain yields (0*x + ... + 1*1), for non-finite inputs it keeps 0*inf = NaN out of the bottom row.
+ * Rows 0..2: the same fmaf chain as gvo_mul4x4 with b's bottom-row element taken as the constant 0 (columns 0..2) or
+ * 1 (column 3). Every implementation (AVX2, VALU kernel, MFMA kernel) follows this definition. */
+static void mul_affine(const float a[16], const float b[16], float out[16])
+{
+    float r[16];
+    for (int j = 0; j < 4; j++) {
+        const float b3 = j == 3 ? 1.0f : 0.0f;
+        for (int i = 0; i < 3; i++) {
+            float acc = fmaf(a[0 * 4 + i], b[j * 4 + 0], 0.0f);
+            acc = fmaf(a[1 * 4 + i], b[j * 4 + 1], acc);
+            acc = fmaf(a[2 * 4 + i], b[j * 4 + 2], acc);
+            acc = fmaf(a[3 * 4 + i], b3, acc);
+            r[j * 4 + i] = acc;
+        }
+        r[j * 4 + 3] = b3;
+    }
+    memcpy(out, r, sizeof(r));
+}
+
 /* Frustum(viewProj) (mesh.cpp:815,867,869,900,902): Gribb-Hartmann rows of a column-major matrix
  * for a [0,1] clip-space depth: left/right/bottom/top, z >= 0, z <= w. Planes normalised by
  * 1/sqrtf(|n|^2); planes with |n|^2 < 1e-12 are dropped (the z >= 0 plane of the infinite
@@ -154,7 +176,7 @@ void gvo_transform_calc_model(const GvoTransformPool* tp, uint32_t slot, const f
             float parent_model[16];
             gvo_calc_model((const float*)(p + tp->off_position), (const float*)(p + tp->off_rotation),
                            (const float*)(p + tp->off_scale), parent_model);
-            gvo_mul4x4(parent_model, model, model); /* model = parentModel * model;  :209 */
+            mul_affine(parent_model, model, model); /* model = parentModel * model;  :209 */
             memcpy(&next_parent, p + tp->off_parent, 4);
         }
     }

@@ -361,3 +361,39 @@ def test_several_mesh_pools_share_the_transform_pool(gpu, oracle):
             exp = oracle.prepare_meshes(pool, sc.transforms, sc.entity_to_transform, v)
             assert_same(got, got_vis, exp, pool["isVisible"].copy(), main_pass=v["shadow_pass"] < 0)
         assert got["draw_count"] > 0
+
+
+def same_bits_or_both_nan(a, b):
+    """Bit-identical, except that a NaN may carry a different sign/payload (x86 makes 0xFFC00000, gfx950 0x7FC00000)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_non_finite_and_denormal_inputs_agree_with_the_oracle(gpu, oracle):
+    """Garbage in, the SAME garbage out: NaN / Inf / denormal / -0 / huge values in TRS and AABBs must lead to the
+    same visibility decision and the same record bits as the oracle (NaN-propagating plane test, minNum/maxNum
+    reductions in the Hi-Z query, no flush-to-zero)."""
+    sc = scene.hierarchy_scene(20_000, depth=3, fanout=6)
+    rng = np.random.default_rng(99)
+    t, m = sc.transforms, sc.meshes
+    specials = np.array([np.nan, np.inf, -np.inf, 1e-42, -1e-42, -0.0, 3e38, -3e38, 1e-30], dtype=np.float32)
+    for field, width in (("position", 3), ("scale", 3), ("rotation", 4)):
+        rows = rng.choice(sc.count, 400, replace=False)
+        t[field][rows, rng.integers(0, width, 400)] = specials[rng.integers(0, len(specials), 400)]
+    for field in ("aabbMin", "aabbMax"):
+        rows = rng.choice(sc.count, 300, replace=False)
+        m[field][rows, rng.integers(0, 3, 300)] = specials[rng.integers(0, len(specials), 300)]
+    t["scale"][rng.choice(sc.count, 100, replace=False), :3] = 0.0          # degenerate models
+    t["position"][rng.choice(sc.count, 100, replace=False), :3] = 0.0       # entities exactly at the camera
+    depth = scene.synthetic_depth(256, 256)
+    views = [scene.main_camera_view(use_hiz=1), scene.cascade_view(index=0)]
+    res = run_both(gpu, oracle, sc, views, hiz_depth=depth)
+    for (got, gv, exp, ev), main in zip(res, (True, False)):
+        assert got["draw_count"] == exp["draw_count"] and np.array_equal(got["visible_idx"], exp["visible_idx"])
+        assert same_bits_or_both_nan(got["baked_model"], exp["baked_model"])
+        assert same_bits_or_both_nan(got["distance_sq"], exp["distance_sq"])
+        if main:
+            assert np.array_equal(gv, ev)
+    for mode in (0, 1):
+        gpu.sweep(mode)
+        assert same_bits_or_both_nan(gpu.get_world(0, sc.count), oracle.world_matrices(sc.transforms, sc.entity_to_transform)), f"sweep mode {mode}"
