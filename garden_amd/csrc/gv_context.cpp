@@ -203,6 +203,7 @@ struct GvCtx {
     uint32_t mip_w[GV_MAX_MIPS]{}, mip_h[GV_MAX_MIPS]{};
     uint64_t mip_off[GV_MAX_MIPS]{};
     bool hiz_valid = false;
+    bool hiz_nested = false;  // every level bounds all the texels it covers (see HizDevice::nested)
 
     // profiling
     std::vector<PendingEvent> pending;
@@ -1190,6 +1191,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         hz.width = ctx->hiz_w;
         hz.height = ctx->hiz_h;
         hz.mip_count = ctx->hiz_mips;
+        hz.nested = ctx->hiz_nested ? 1u : 0u;
     }
     // Views that share cameraPosition (the main camera and its shadow cascades: mesh.cpp:809-843 passes the same
     // cameraPosition to every prepareMeshes) are culled in ONE pass over the streams; Hi-Z only on view 0.
@@ -1475,6 +1477,15 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
     ctx->hiz_w = width;
     ctx->hiz_h = height;
     ctx->hiz_mips = mips;
+    // The reference rule (hiz.frag:49-55) skips one texel of the extra row on odd heights, so a level is only
+    // guaranteed to bound everything below it when no source level is odd, or under the conservative rule.
+    ctx->hiz_nested = ctx->config.hiz_rule == GV_HIZ_RULE_CONSERVATIVE;
+    if (!ctx->hiz_nested) {
+        ctx->hiz_nested = true;
+        for (uint32_t k = 0; k + 1 < mips; k++)
+            if ((ctx->mip_w[k] > 1 && (ctx->mip_w[k] & 1u)) || (ctx->mip_h[k] > 1 && (ctx->mip_h[k] & 1u)))
+                ctx->hiz_nested = false;
+    }
     GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>(off, 1)));
     GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_mip_offset.ptr, ctx->mip_off, sizeof(uint64_t) * GV_MAX_MIPS, hipMemcpyHostToDevice, ctx->stream));

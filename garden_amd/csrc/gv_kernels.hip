@@ -103,6 +103,8 @@ __device__ __forceinline__ float clamp01(float a)
     return a > 0.0f ? (a < 1.0f ? a : 1.0f) : 0.0f;
 }
 
+constexpr uint32_t kHizCoarseStep = 4;  // early-accept level = query level + 4 (+3..+5 measured equal, +1/+2 slower)
+
 // Build-defined occlusion query (SURVEY.md §8a-7'; the reference has none). Returns true if occluded.
 __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&vp)[16], const Corners& c)
 {
@@ -155,6 +157,25 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
         return ((i1 >> l) - (i0 >> l)) <= 1 ? l : l + 1u;
     };
     const uint32_t level = min(max(axis_level(ix0, ix1), axis_level(iy0, iy1)), hz.mip_count - 1u);
+    // Exact early-accept from a coarse, cache-resident level: its texels' min is <= the min over any finer footprint
+    // they cover, so zNear < coarseMin already implies zNear < zFar. Most occluded boxes are decided here and never
+    // touch the 64 MB / 32 MB levels 0 / 1. (Only for nested pyramids; the decision is unchanged either way.)
+    if (hz.nested && level + kHizCoarseStep < hz.mip_count) {
+        const uint32_t cl = level + kHizCoarseStep;
+        const int cw = max((int)(hz.width >> cl), 1), ch = max((int)(hz.height >> cl), 1);
+        const int cx0 = min(ix0 >> cl, cw - 1), cx1 = min(ix1 >> cl, cw - 1);
+        const int cy0 = min(iy0 >> cl, ch - 1), cy1 = min(iy1 >> cl, ch - 1);
+        float cmin = hiz_min_texel(hz, cl, cw, cx0, cy0);
+        if (cx1 != cx0)
+            cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx1, cy0));
+        if (cy1 != cy0) {
+            cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx0, cy1));
+            if (cx1 != cx0)
+                cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx1, cy1));
+        }
+        if (znear < cmin)
+            return true;
+    }
     const int lw = max((int)(hz.width >> level), 1), lh = max((int)(hz.height >> level), 1);
     const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
     const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
