@@ -1,0 +1,203 @@
+"""Full-size checks at BASELINE.json's configurations (10^6 / 10^7 entities, 4096^2 pyramid).
+
+Two kinds of evidence per configuration:
+  * the CPU oracle (all host cores, seconds) on the same pools -> bit-exact visible set / isVisible / records;
+  * size-independent properties that need no oracle: idempotence, count == popcount(isVisible), unique ascending
+    indices, Hi-Z result is a subset of the frustum-only result, union of tile shards == the whole pool (the
+    cfg5 sharding pattern: a checksum of checksums), sortedness + permutation after gv_sort, MFMA sweep == VALU
+    sweep, identity-parent invariance of the visible set.
+Scenes are built once per module; each 10M scene is ~1.3 GB of host pools."""
+import os
+
+import numpy as np
+import pytest
+
+from garden_amd import scene
+from garden_amd.lib import GV_DIRTY_MESH, GV_SWEEP_MFMA, GV_SWEEP_VALU
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 10_000_000
+HIZ = 4096
+THREADS = max(1, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def flat10m():
+    return scene.flat_scene(N_FULL)
+
+
+@pytest.fixture(scope="module")
+def hier10m():
+    return scene.hierarchy_scene(N_FULL)
+
+
+def bind(gpu, sc):
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+
+
+def check_self_consistent(got, n):
+    idx = got["visible_idx"].astype(np.int64)
+    assert got["draw_count"] == idx.shape[0] == got["instance_count"]
+    assert np.all(np.diff(idx) > 0), "indices must be unique (and ascending after the slot-order fetch)"
+    assert idx.size == 0 or (idx[0] >= 0 and idx[-1] < n)
+    vis = got["is_visible"]
+    assert int(vis.sum(dtype=np.int64)) == got["draw_count"] and set(np.unique(vis)) <= {0, 1}
+    assert np.all(vis[idx] == 1)
+
+
+def same_records(a, b):
+    return (np.array_equal(a["visible_idx"], b["visible_idx"])
+            and np.array_equal(a["baked_model"].view(np.uint32), b["baked_model"].view(np.uint32))
+            and np.array_equal(a["distance_sq"].view(np.uint32), b["distance_sq"].view(np.uint32)))
+
+
+def test_cfg2_1m_frustum_only_against_oracle(gpu, oracle):
+    sc = scene.flat_scene(1_000_000)
+    view = scene.main_camera_view()
+    bind(gpu, sc)
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(got, sc.count)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, threads=THREADS)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    assert same_records(got, exp) and np.array_equal(got["is_visible"], m2["isVisible"])
+
+
+def test_cfg3_10m_hiz_properties_and_oracle(gpu, oracle, flat10m):
+    sc = flat10m
+    depth = scene.synthetic_depth(HIZ, HIZ)
+    frustum_only, with_hiz = scene.main_camera_view(use_hiz=0), scene.main_camera_view(use_hiz=1)
+    bind(gpu, sc)
+    gpu.hiz_build(depth)
+
+    gpu.cull(0, [frustum_only])
+    fo = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(fo, sc.count)
+
+    gpu.hiz_rebuild()
+    gpu.cull(0, [with_hiz])
+    hz1 = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(hz1, sc.count)
+    # occlusion only ever removes entities
+    assert hz1["draw_count"] < fo["draw_count"]
+    assert np.all(np.isin(hz1["visible_idx"], fo["visible_idx"], assume_unique=True))
+    assert np.all(hz1["is_visible"] <= fo["is_visible"])
+
+    # idempotence: pyramid rebuild + cull again -> the same bits
+    gpu.hiz_rebuild()
+    gpu.cull(0, [with_hiz])
+    hz2 = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    assert same_records(hz1, hz2) and np.array_equal(hz1["is_visible"], hz2["is_visible"])
+
+    # the oracle at full size
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, with_hiz, hiz=oracle.Hiz(depth), threads=THREADS)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    assert same_records(hz1, exp) and np.array_equal(hz1["is_visible"], m2["isVisible"])
+
+
+def test_cfg5_tile_shards_union_equals_whole(gpu, flat10m):
+    """cfg5 pattern on one GPU: the pool cut into 8 contiguous shards culled one by one (each as its own
+    mesh pool over the shared transform pool); shard lists + index base concatenate to the unsharded list."""
+    sc = flat10m
+    view = scene.main_camera_view()
+    bind(gpu, sc)
+    gpu.cull(0, [view])
+    whole = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    parts, counts = [], []
+    bounds = np.linspace(0, sc.count, 9).astype(np.int64)
+    for r in range(8):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        shard = np.ascontiguousarray(sc.meshes[lo:hi])
+        gpu.bind_pool(1, shard)
+        if r > 0:  # same occupancy, different components: the caller reports the change (first bind uploads all)
+            gpu.mark_dirty(GV_DIRTY_MESH, 0, hi - lo, pool_id=1)
+        gpu.cull(1, [view])
+        got = gpu.fetch(0, write_back=False, occupancy=hi - lo)
+        counts.append(got["draw_count"])
+        parts.append(got["visible_idx"].astype(np.int64) + lo)
+        assert np.array_equal(got["is_visible"], whole["is_visible"][lo:hi])
+    assert sum(counts) == whole["draw_count"]
+    assert np.array_equal(np.concatenate(parts), whole["visible_idx"].astype(np.int64))
+    gpu.bind_pool(1, sc.meshes[:0])
+
+
+def test_10m_sort_is_sorted_permutation(gpu, flat10m):
+    sc = flat10m
+    view = scene.main_camera_view()
+    bind(gpu, sc)
+    gpu.cull(0, [view])
+    before = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    for descending in (False, True):
+        gpu.cull(0, [view])
+        gpu.sort(0, descending=descending)
+        got = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
+        d = got["distance_sq"]
+        assert np.all(np.diff(d) <= 0) if descending else np.all(np.diff(d) >= 0)
+        o = np.argsort(got["visible_idx"], kind="stable")
+        after = dict(visible_idx=got["visible_idx"][o], baked_model=got["baked_model"][o], distance_sq=d[o])
+        assert same_records(before, after), "sorting must only permute whole records"
+
+
+def test_cfg4_10m_hierarchy_sweep_and_cull(gpu, oracle, hier10m):
+    sc = hier10m
+    view = scene.main_camera_view()
+    bind(gpu, sc)
+    # MFMA and VALU sweeps write the same bits for every one of the 10M world matrices (checked in 1M blocks)
+    gpu.sweep(GV_SWEEP_VALU)
+    valu = [gpu.get_world(f, 1_000_000) for f in range(0, N_FULL, 1_000_000)]
+    gpu.sweep(GV_SWEEP_MFMA)
+    for k, f in enumerate(range(0, N_FULL, 1_000_000)):
+        assert np.array_equal(gpu.get_world(f, 1_000_000).view(np.uint32), valu[k].view(np.uint32))
+    # a sampled block against the scalar chain walk of the oracle (transform.hpp:197-214)
+    first, count = 9_000_000, 200_000
+    exp_w = oracle.world_matrices(sc.transforms, sc.entity_to_transform, first, count)
+    assert np.array_equal(valu[9][:count].view(np.uint32), exp_w.view(np.uint32))
+    del valu
+
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(got, sc.count)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, threads=THREADS)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    assert same_records(got, exp) and np.array_equal(got["is_visible"], m2["isVisible"])
+
+
+def test_identity_parent_leaves_the_visible_set_unchanged(gpu):
+    """M_parent = I: fma(1, a, fma(0, b, ...)) returns a, so hanging every entity under an identity parent must not
+    move a single entity across a frustum plane (only -0 -> +0 can change in the matrices)."""
+    n = 1_000_000
+    sc = scene.flat_scene(n)
+    view = scene.main_camera_view()
+    bind(gpu, sc)
+    gpu.cull(0, [view])
+    flat = gpu.fetch(0, write_back=False, occupancy=n)
+
+    tr = np.concatenate([sc.transforms, np.zeros(1, sc.transforms.dtype)])
+    ident = n  # slot of the identity transform
+    ident_entity = int(sc.transforms["entity"].max()) + 1
+    tr["entity"][ident] = ident_entity
+    tr["rotation"][ident] = (0, 0, 0, 1)
+    tr["scale"][ident, :3] = (1, 1, 1)
+    tr["selfActive"][ident] = tr["ancestorsActive"][ident] = tr["modelWithAncestors"][ident] = 1
+    live = tr["entity"][:n] != 0
+    tr["parent"][:n][live] = ident_entity
+    e2t = np.full(max(sc.entity_to_transform.shape[0], ident_entity + 1), 0xFFFFFFFF, np.uint32)
+    e2t[:sc.entity_to_transform.shape[0]] = sc.entity_to_transform
+    e2t[ident_entity] = ident
+    gpu.bind_transforms(tr, e2t)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [view])
+    hung = gpu.fetch(0, write_back=False, occupancy=n)
+    assert np.array_equal(flat["visible_idx"], hung["visible_idx"])
+    assert np.array_equal(flat["is_visible"], hung["is_visible"])
+    assert np.array_equal(flat["baked_model"] + 0.0, hung["baked_model"] + 0.0)  # equal up to the sign of zero
