@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "ecsm_lite.hpp"
@@ -133,6 +134,37 @@ public:
         transformVersion++;
     }
     void markTransformsChanged() noexcept { transformVersion++; }
+    // TransformComponent::destroy (transform.cpp:29-73): unlink from the parent's childs[] keeping their order,
+    // orphan the children (parent = null, ancestorsActive = true, not pushed further down), free childs[]
+    void removeOf(ID<Entity> entity) override
+    {
+        auto view = tryGetOf(entity);
+        if (view) {
+            if (view->parent) {
+                if (auto parentView = tryGetOf(view->parent)) {
+                    uint32_t n = parentView->childCount();
+                    for (uint32_t i = 0; i < n; i++)
+                        if (parentView->childs[i] == entity) {
+                            for (uint32_t j = i + 1; j < n; j++)
+                                parentView->childs[j - 1] = parentView->childs[j];
+                            parentView->setChildCount(n - 1);
+                            break;
+                        }
+                }
+            }
+            for (uint32_t i = 0, n = view->childCount(); i < n; i++)
+                if (auto child = tryGetOf(view->childs[i])) {
+                    child->parent = {};
+                    child->ancestorsActive = true;
+                }
+            std::free(view->childs);
+            view->childs = nullptr;
+            view->setChildCount(0);
+            view->setChildCapacity(0);
+            hierarchyVersion++;
+        }
+        ComponentSystem<TransformComponent>::removeOf(entity);
+    }
     ~TransformSystem() override
     {
         auto data = components.getData();
@@ -185,16 +217,41 @@ public:
     virtual size_t getMeshComponentSize() const = 0;
 };
 
-class OpaqueMeshSystem final : public ComponentSystem<MeshRenderComponent, false>, public IMeshRenderSystem {
+// One mesh system per component type, as in the engine (ModelRenderSystem, SpriteRenderSystem, ... each own a pool
+// of their MeshRenderComponent-derived struct and report a MeshRenderType, render/mesh.hpp:60-147).
+class VersionedMeshSystem {
 public:
-    uint64_t meshVersion = 0;
-    View<MeshRenderComponent> add(ID<Entity> entity) { meshVersion++; return addTo(entity); }
+    uint64_t meshVersion = 0;  // bumped by add()/markMeshesChanged(); consumers re-mirror the pool
     void markMeshesChanged() noexcept { meshVersion++; }
-    MeshRenderType getMeshRenderType() const override { return MeshRenderType::Opaque; }
-    uint8_t* getMeshComponentData() const override { return reinterpret_cast<uint8_t*>(components.getData()); }
-    uint32_t getMeshComponentOccupancy() const override { return components.getOccupancy(); }
-    size_t getMeshComponentSize() const override { return sizeof(MeshRenderComponent); }
 };
+template <class C, MeshRenderType TYPE>
+class MeshSystemOf : public ComponentSystem<C, false>, public IMeshRenderSystem, public VersionedMeshSystem {
+    static_assert(std::is_base_of<MeshRenderComponent, C>::value, "mesh components derive from MeshRenderComponent");
+
+public:
+    View<C> add(ID<Entity> entity) { meshVersion++; return this->addTo(entity); }
+    MeshRenderType getMeshRenderType() const override { return TYPE; }
+    uint8_t* getMeshComponentData() const override { return reinterpret_cast<uint8_t*>(this->components.getData()); }
+    uint32_t getMeshComponentOccupancy() const override { return this->components.getOccupancy(); }
+    size_t getMeshComponentSize() const override { return sizeof(C); }
+};
+using OpaqueMeshSystem = MeshSystemOf<MeshRenderComponent, MeshRenderType::Opaque>;
+
+// Derived components with the reference's shape: base header + system-specific payload, so pools are walked with a
+// byte stride larger than 48 (sprite.hpp:29-43).
+struct alignas(16) TranslucentMeshComponent final : public MeshRenderComponent {
+    float colorFactor[4] = {1, 1, 1, 1};
+};
+struct alignas(16) OitMeshComponent final : public MeshRenderComponent {
+    float colorFactor[4] = {1, 1, 1, 0.5f};
+    uint64_t descriptorSet = 0;
+};
+struct alignas(16) UiMeshComponent final : public MeshRenderComponent {
+    float uvSize[2] = {1, 1}, uvOffset[2] = {0, 0};
+};
+using TranslucentMeshSystem = MeshSystemOf<TranslucentMeshComponent, MeshRenderType::Translucent>;
+using OitMeshSystem = MeshSystemOf<OitMeshComponent, MeshRenderType::OIT>;
+using UiMeshSystem = MeshSystemOf<UiMeshComponent, MeshRenderType::UI>;
 
 // graphics/constants.hpp:26-56 (fields the path reads) + render/mesh.hpp:166 shadow-pass inputs.
 struct CommonConstants {
@@ -217,6 +274,16 @@ struct MeshBuffer {
 struct UnsortedBuffer final : public MeshBuffer {
     std::vector<UnsortedMesh> combinedMeshes;
 };
+// render/mesh.hpp:198-205,218: translucent / UI meshes of ALL such systems share one array per kind
+// (transSortedMeshes / uiSortedMeshes, mesh.hpp:222-223), drawn back to front; bufferIndex names the system.
+struct SortedMesh final {
+    size_t componentOffset = 0;
+    float4x3 bakedModel;
+    float distanceSq = 0.0f;
+    uint32_t bufferIndex = 0;
+    bool operator<(const SortedMesh& m) const noexcept { return distanceSq > m.distanceSq; }
+};
+struct SortedBuffer final : public MeshBuffer {};
 
 // Headless stand-ins for GraphicsSystem ("Update": prepareCommonConstants -> runEvent("Render"),
 // graphics.cpp:312,409) and DeferredRenderSystem ("Render" -> "PreDeferredRender"/"DeferredRender",

@@ -12,6 +12,7 @@
 // Errors: gv_* status codes are turned into exceptions here, the way GardenError is used upstream
 // (include/garden/error.hpp:32-55).
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -36,9 +37,18 @@ public:
 private:
     GvCtx* ctx = nullptr;
     std::vector<IMeshRenderSystem*> meshSystems;  // prepareSystems(), mesh.cpp:69-108
+    // mesh.hpp:219-223: one UnsortedBuffer per Color/Opaque/OIT/Refracted/TransDepth system; Translucent and UI
+    // systems get a SortedBuffer each (counters) and share transSortedMeshes / uiSortedMeshes (records)
     std::vector<UnsortedBuffer*> unsortedBuffers;
+    std::vector<SortedBuffer*> sortedBuffers;
+    std::vector<SortedMesh> transSortedMeshes, uiSortedMeshes;
+    uint32_t transDrawIndex = 0, uiDrawIndex = 0;
+    uint32_t unsortedBufferCount = 0, sortedBufferCount = 0;
     std::vector<ShadowPass> shadowPasses;
-    std::vector<std::vector<UnsortedBuffer*>> shadowBuffers;  // [pool][pass]
+    std::vector<std::vector<UnsortedBuffer*>> shadowBuffers;    // [unsorted buffer][pass]
+    std::vector<std::vector<SortedMesh>> shadowTransMeshes;     // [pass]: the reference re-runs prepareMeshes per
+    std::vector<uint32_t> shadowTransDrawIndex;                 // pass and draws at once; here every pass is kept
+    f32x4x4 uiViewProj;                                          // calcUiProjView(), mesh.cpp:851-859
     uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull, seenReparent = 0;
     std::vector<uint64_t> seenMesh;
     bool useHiz = false;
@@ -66,11 +76,14 @@ public:
         config.flags = profile ? GV_CONFIG_PROFILE_EVENTS : 0;
         if (gv_create(&config, &ctx) != GV_OK)
             throw GardenError(std::string("GpuVisibilitySystem: ") + gv_last_error(nullptr));
+        setUiSize(1.0f, 1.0f);
         ECSM_SUBSCRIBE_TO_EVENT("Init", GpuVisibilitySystem::init);
     }
     ~GpuVisibilitySystem() override
     {
         for (auto b : unsortedBuffers)
+            delete b;
+        for (auto b : sortedBuffers)
             delete b;
         for (auto& v : shadowBuffers)
             for (auto b : v)
@@ -80,8 +93,31 @@ public:
 
     GvCtx* getContext() const noexcept { return ctx; }
     const std::vector<UnsortedBuffer*>& getUnsortedBuffers() const noexcept { return unsortedBuffers; }
-    const std::vector<UnsortedBuffer*>& getShadowBuffers(uint32_t pool) const { return shadowBuffers.at(pool); }
+    uint32_t getUnsortedBufferCount() const noexcept { return unsortedBufferCount; }
+    const std::vector<SortedBuffer*>& getSortedBuffers() const noexcept { return sortedBuffers; }
+    uint32_t getSortedBufferCount() const noexcept { return sortedBufferCount; }
+    // [0, getTransDrawCount()) back to front over all Translucent systems (mesh.hpp:222, transDrawIndex :226)
+    const std::vector<SortedMesh>& getTransSortedMeshes() const noexcept { return transSortedMeshes; }
+    uint32_t getTransDrawCount() const noexcept { return transDrawIndex; }
+    const std::vector<SortedMesh>& getUiSortedMeshes() const noexcept { return uiSortedMeshes; }
+    uint32_t getUiDrawCount() const noexcept { return uiDrawIndex; }
+    const std::vector<UnsortedBuffer*>& getShadowBuffers(uint32_t unsortedBuffer) const { return shadowBuffers.at(unsortedBuffer); }
+    const std::vector<SortedMesh>& getShadowTransMeshes(uint32_t pass) const { return shadowTransMeshes.at(pass); }
+    uint32_t getShadowTransDrawCount(uint32_t pass) const { return shadowTransDrawIndex.at(pass); }
     void setShadowPasses(std::vector<ShadowPass> passes) { shadowPasses = std::move(passes); }
+    // calcUiProjView (mesh.cpp:851-859): calcOrthoProjRevZ over [-w/2,w/2] x [-h/2,h/2], depth [-1,1]
+    void setUiSize(float width, float height) noexcept
+    {
+        const float nearPlane = -1.0f, farPlane = 1.0f;
+        memset(uiViewProj.m, 0, sizeof(uiViewProj.m));
+        uiViewProj.m[0] = 2.0f / width;
+        uiViewProj.m[5] = -2.0f / height;
+        uiViewProj.m[10] = -1.0f / (farPlane - nearPlane);
+        uiViewProj.m[14] = farPlane / (farPlane - nearPlane);
+        uiViewProj.m[15] = 1.0f;
+    }
+    void setUiViewProj(const f32x4x4& viewProj) noexcept { uiViewProj = viewProj; }
+    const f32x4x4& getUiViewProj() const noexcept { return uiViewProj; }
 
     // HizRenderSystem::downsampleHiz stand-in: hand over this frame's reversed-Z depth (host memory).
     void setHizDepth(const float* depth, uint32_t width, uint32_t height)
@@ -101,7 +137,12 @@ private:
             ECSM_SUBSCRIBE_TO_EVENT("PreDeferredRender", GpuVisibilitySystem::preRender);
     }
 
-    void prepareSystems()  // mesh.cpp:69-108
+    static bool isSortedType(MeshRenderType type) noexcept
+    {
+        return type == MeshRenderType::Translucent || type == MeshRenderType::UI;  // mesh.cpp:358-369,414
+    }
+
+    void prepareSystems()  // mesh.cpp:69-108 + the classification pass of prepareMeshes, mesh.cpp:341-395
     {
         meshSystems.clear();
         for (auto& sys : Manager::Instance::get()->getSystems())
@@ -109,14 +150,19 @@ private:
                 meshSystems.push_back(ms);
         if (meshSystems.size() > GV_MAX_POOLS)
             throw GardenError("GpuVisibilitySystem: more mesh systems than GV_MAX_POOLS");
-        while (unsortedBuffers.size() < meshSystems.size())
+        unsortedBufferCount = sortedBufferCount = 0;
+        for (auto ms : meshSystems)
+            (isSortedType(ms->getMeshRenderType()) ? sortedBufferCount : unsortedBufferCount)++;
+        while (unsortedBuffers.size() < unsortedBufferCount)
             unsortedBuffers.push_back(new UnsortedBuffer());
-        shadowBuffers.resize(meshSystems.size());
+        while (sortedBuffers.size() < sortedBufferCount)
+            sortedBuffers.push_back(new SortedBuffer());
+        shadowBuffers.resize(unsortedBufferCount);
         seenMesh.resize(meshSystems.size(), ~0ull);
     }
 
     static GvView makeView(const f32x4x4& viewProj, f32x4 cameraPos, f32x4 cameraOffset, int8_t shadowPass,
-                           bool hiz, bool emit)
+                           bool hiz, bool emit, bool distance2D = false)
     {
         GvView v{};
         memcpy(v.view_proj, viewProj.m, sizeof(v.view_proj));
@@ -124,6 +170,7 @@ private:
         v.camera_offset[0] = cameraOffset.x; v.camera_offset[1] = cameraOffset.y; v.camera_offset[2] = cameraOffset.z;
         v.shadow_pass = shadowPass;
         v.use_hiz = hiz ? 1 : 0;
+        v.distance_2d = distance2D ? 1 : 0;
         v.emit_records = emit ? 1 : 0;
         return v;
     }
@@ -148,12 +195,47 @@ private:
         }
     }
 
+    // prepareSortedMeshes' tail (mesh.cpp:246-261): this system's records go behind the ones already in the shared
+    // array, tagged with bufferIndex. Returns the number appended.
+    uint32_t append(std::vector<SortedMesh>& combined, uint32_t& drawIndex, MeshBuffer* counters,
+                    IMeshRenderSystem* meshSystem, uint32_t viewIndex, bool writeBack, uint32_t bufferIndex)
+    {
+        GvResult r{};
+        check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+        if (counters) {
+            counters->meshSystem = meshSystem;
+            counters->drawCount = r.draw_count;
+            counters->instanceCount = r.instance_count;
+        }
+        if (!emitRecords)
+            return 0;
+        if (combined.size() < (size_t)drawIndex + r.draw_count)
+            combined.resize((size_t)drawIndex + r.draw_count);
+        const size_t componentSize = meshSystem->getMeshComponentSize();
+        auto meshes = combined.data() + drawIndex;
+        for (uint32_t k = 0; k < r.draw_count; k++) {
+            meshes[k].componentOffset = (size_t)r.visible_idx[k] * componentSize;  // mesh.cpp:247
+            memcpy(meshes[k].bakedModel.m, r.baked_model + (size_t)k * 12, 48);     // mesh.cpp:248
+            meshes[k].distanceSq = r.distance_sq[k];                                // mesh.cpp:249-251
+            meshes[k].bufferIndex = bufferIndex;                                    // mesh.cpp:252
+        }
+        drawIndex += r.draw_count;
+        return r.draw_count;
+    }
+
+    // sortMeshes for a shared array (mesh.cpp:296-326): every system's run arrives back-to-front from gv_sort, so a
+    // merge of the runs is all that is left (one run: nothing to do).
+    static void mergeRuns(std::vector<SortedMesh>& combined, const std::vector<uint32_t>& runEnds)
+    {
+        for (size_t i = 1; i < runEnds.size(); i++)
+            std::inplace_merge(combined.begin(), combined.begin() + runEnds[i - 1], combined.begin() + runEnds[i]);
+    }
+
     // preForwardRender / preDeferredRender, mesh.cpp:860-903: shadows first, then the main camera.
     void preRender()
     {
         if (!isEnabled)
             return;
-        auto manager = Manager::Instance::get();
         auto transformSystem = TransformSystem::Instance::get();
         auto graphicsSystem = GraphicsSystem::Instance::get();
         prepareSystems();
@@ -190,34 +272,77 @@ private:
         transformSystem->clearReparentRange();
 
         const auto& cc = graphicsSystem->getCommonConstants();
+        const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
+        transDrawIndex = uiDrawIndex = 0;
+        shadowTransMeshes.resize(passCount);
+        shadowTransDrawIndex.assign(passCount, 0);
+        std::vector<uint32_t> transRuns, uiRuns;
+        std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
+        uint32_t unsortedBufferIndex = 0, sortedBufferIndex = 0;
+
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
+            const auto renderType = meshSystem->getMeshRenderType();
             check(gv_pool_bind(ctx, p, meshSystem->getMeshComponentData(), meshSystem->getMeshComponentSize(),
                                meshSystem->getMeshComponentOccupancy(), &meshLayout), "gv_pool_bind");
-            if (auto versioned = dynamic_cast<OpaqueMeshSystem*>(meshSystem)) {
+            if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem)) {
                 if (seenMesh[p] != versioned->meshVersion) {
                     check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
                     seenMesh[p] = versioned->meshVersion;
                 }
+            } else {  // unknown writer: re-mirror the pool every frame (always correct)
+                check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
             }
-            // view 0 = main camera (shadowPass -1: writes isVisible), views 1.. = shadow passes (mesh.cpp:809-843)
+
+            // view 0 = main camera (shadowPass -1: writes isVisible), views 1.. = shadow passes (mesh.cpp:809-843).
+            // UI: its own ortho frustum, camera at the origin, 2D distance key, no shadow passes (mesh.cpp:416,436-442)
             std::vector<GvView> views;
-            views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
-            for (size_t s = 0; s < shadowPasses.size() && views.size() < GV_MAX_VIEWS; s++)
-                views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
-                                         (int8_t)s, false, emitRecords));
+            if (renderType == MeshRenderType::UI) {
+                views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
+            } else {
+                views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
+                for (uint32_t s = 0; s < passCount; s++)
+                    views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
+                                             (int8_t)s, false, emitRecords));
+            }
             check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
-            if (emitRecords && sortOnDevice)
-                for (uint32_t v = 0; v < views.size(); v++)
-                    check(gv_sort(ctx, v, 0), "gv_sort");  // opaque/unsorted: operator< (render/mesh.hpp:196)
-            auto& sb = shadowBuffers[p];
-            while (sb.size() + 1 < views.size())
-                sb.push_back(new UnsortedBuffer());
-            for (uint32_t v = 1; v < views.size(); v++)
-                fill(sb[v - 1], meshSystem, v, false);
-            fill(unsortedBuffers[p], meshSystem, 0, true);
+
+            if (isSortedType(renderType)) {
+                if (emitRecords && sortOnDevice)
+                    for (uint32_t v = 0; v < views.size(); v++)
+                        check(gv_sort(ctx, v, 1), "gv_sort");  // back to front: SortedMesh::operator< (mesh.hpp:204)
+                const uint32_t bufferIndex = sortedBufferIndex++;
+                for (uint32_t v = 1; v < views.size(); v++) {
+                    append(shadowTransMeshes[v - 1], shadowTransDrawIndex[v - 1], nullptr, meshSystem, v, false, bufferIndex);
+                    shadowTransRuns[v - 1].push_back(shadowTransDrawIndex[v - 1]);
+                }
+                if (renderType == MeshRenderType::UI) {
+                    append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, 0, true, bufferIndex);
+                    uiRuns.push_back(uiDrawIndex);
+                } else {
+                    append(transSortedMeshes, transDrawIndex, sortedBuffers[bufferIndex], meshSystem, 0, true, bufferIndex);
+                    transRuns.push_back(transDrawIndex);
+                }
+            } else {
+                // sortMeshes, mesh.cpp:270-295: front to back (UnsortedMesh::operator<, mesh.hpp:196); OIT is not sorted
+                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
+                    for (uint32_t v = 0; v < views.size(); v++)
+                        check(gv_sort(ctx, v, 0), "gv_sort");
+                const uint32_t bufferIndex = unsortedBufferIndex++;
+                auto& sb = shadowBuffers[bufferIndex];
+                while (sb.size() + 1 < views.size())
+                    sb.push_back(new UnsortedBuffer());
+                for (uint32_t v = 1; v < views.size(); v++)
+                    fill(sb[v - 1], meshSystem, v, false);
+                fill(unsortedBuffers[bufferIndex], meshSystem, 0, true);
+            }
         }
-        (void)manager;
+        if (emitRecords && sortOnDevice) {
+            mergeRuns(transSortedMeshes, transRuns);
+            mergeRuns(uiSortedMeshes, uiRuns);
+            for (uint32_t s = 0; s < passCount; s++)
+                mergeRuns(shadowTransMeshes[s], shadowTransRuns[s]);
+        }
     }
 };
 

@@ -3,7 +3,9 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed]
+// --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
+// unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
 #include <algorithm>
 #include <chrono>
@@ -37,52 +39,128 @@ struct Rng {  // PCG32
     float uniform(float lo, float hi) { return lo + (hi - lo) * (float)(next() >> 8) * (1.0f / 16777216.0f); }
 };
 
+// a second Translucent system with its own component type (one pool per component type, as in the engine)
+struct alignas(16) GlassMeshComponent final : public MeshRenderComponent {
+    float indexOfRefraction = 1.5f;
+    uint32_t materialId = 0;
+};
+using GlassMeshSystem = MeshSystemOf<GlassMeshComponent, MeshRenderType::Translucent>;
+
+// What a prepare phase leaves behind for the render phase. Record arrays are compared as sets (the reference's order
+// is fetch_add arrival order before sortMeshes and unspecified among equal keys after it): canonical order here is
+// (bufferIndex, componentOffset).
+struct Record {
+    uint32_t bufferIndex;
+    size_t componentOffset;
+    float bakedModel[12];
+    float distanceSq;
+    bool operator<(const Record& r) const noexcept
+    {
+        return bufferIndex != r.bufferIndex ? bufferIndex < r.bufferIndex : componentOffset < r.componentOffset;
+    }
+};
 struct Snapshot {
-    std::vector<uint8_t> isVisible;
-    std::vector<UnsortedMesh> meshes;
-    uint32_t drawCount = 0, instanceCount = 0;
+    std::vector<std::vector<uint8_t>> isVisible;  // [mesh system][slot]
+    std::vector<std::vector<Record>> lists;       // unsorted buffers, their shadow buffers, trans, ui, shadow trans
+    std::vector<uint32_t> counters;               // drawCount / instanceCount of every MeshBuffer, in the same walk
+    bool ordered = true;                          // every list obeys its operator< (mesh.hpp:196,204)
+    std::string disorder;
 };
 
-static bool isSortedByDistance(const UnsortedBuffer* buffer)
+static std::vector<IMeshRenderSystem*> allMeshSystems(Manager& manager)
 {
-    for (uint32_t k = 1; k < buffer->drawCount; k++)
-        if (buffer->combinedMeshes[k] < buffer->combinedMeshes[k - 1])  // operator< render/mesh.hpp:196
-            return false;
-    return true;
+    std::vector<IMeshRenderSystem*> out;
+    for (auto& sys : manager.getSystems())
+        if (auto ms = dynamic_cast<IMeshRenderSystem*>(sys.get()))
+            out.push_back(ms);
+    return out;
 }
 
-static Snapshot snapshot(OpaqueMeshSystem* meshSystem, const UnsortedBuffer* buffer)
+template <class M>
+static void addList(Snapshot& s, const std::vector<M>& meshes, uint32_t count, bool mustBeOrdered, const char* name)
+{
+    std::vector<Record> list(count);
+    for (uint32_t k = 0; k < count; k++) {
+        list[k].componentOffset = meshes[k].componentOffset;
+        memcpy(list[k].bakedModel, meshes[k].bakedModel.m, 48);
+        list[k].distanceSq = meshes[k].distanceSq;
+        if constexpr (std::is_same<M, SortedMesh>::value)
+            list[k].bufferIndex = meshes[k].bufferIndex;
+        else
+            list[k].bufferIndex = 0;
+        if (mustBeOrdered && k > 0 && meshes[k] < meshes[k - 1] && s.ordered) {
+            s.ordered = false;
+            s.disorder = name;
+        }
+    }
+    std::sort(list.begin(), list.end());
+    s.lists.push_back(std::move(list));
+}
+
+template <class SystemT>
+static Snapshot snapshot(Manager& manager, const SystemT* system, uint32_t passCount)
 {
     Snapshot s;
-    auto data = meshSystem->getComponents().getData();
-    for (uint32_t i = 0; i < meshSystem->getComponents().getOccupancy(); i++)
-        s.isVisible.push_back(data[i].isVisible);
-    s.drawCount = buffer->drawCount;
-    s.instanceCount = buffer->instanceCount;
-    s.meshes.assign(buffer->combinedMeshes.begin(), buffer->combinedMeshes.begin() + s.drawCount);
-    // the reference's order is fetch_add arrival order (mesh.cpp:177): compare as a set, keyed by componentOffset
-    std::sort(s.meshes.begin(), s.meshes.end(),
-              [](const UnsortedMesh& a, const UnsortedMesh& b) { return a.componentOffset < b.componentOffset; });
+    for (auto ms : allMeshSystems(manager)) {
+        std::vector<uint8_t> vis(ms->getMeshComponentOccupancy());
+        for (uint32_t i = 0; i < vis.size(); i++)
+            vis[i] = reinterpret_cast<const MeshRenderComponent*>(ms->getMeshComponentData() + (size_t)i * ms->getMeshComponentSize())->isVisible;
+        s.isVisible.push_back(std::move(vis));
+    }
+    for (uint32_t b = 0; b < system->getUnsortedBufferCount(); b++) {
+        auto buffer = system->getUnsortedBuffers()[b];
+        const bool sorted = buffer->meshSystem->getMeshRenderType() != MeshRenderType::OIT;  // mesh.cpp:273-277
+        addList(s, buffer->combinedMeshes, buffer->drawCount, sorted, "unsorted buffer");
+        s.counters.push_back(buffer->drawCount);
+        s.counters.push_back(buffer->instanceCount);
+        for (uint32_t pass = 0; pass < passCount; pass++) {
+            auto shadow = system->getShadowBuffers(b)[pass];
+            addList(s, shadow->combinedMeshes, shadow->drawCount, sorted, "shadow unsorted buffer");
+            s.counters.push_back(shadow->drawCount);
+            s.counters.push_back(shadow->instanceCount);
+        }
+    }
+    for (uint32_t b = 0; b < system->getSortedBufferCount(); b++) {
+        s.counters.push_back(system->getSortedBuffers()[b]->drawCount);
+        s.counters.push_back(system->getSortedBuffers()[b]->instanceCount);
+    }
+    addList(s, system->getTransSortedMeshes(), system->getTransDrawCount(), true, "transSortedMeshes");
+    addList(s, system->getUiSortedMeshes(), system->getUiDrawCount(), true, "uiSortedMeshes");
+    for (uint32_t pass = 0; pass < passCount; pass++)
+        addList(s, system->getShadowTransMeshes(pass), system->getShadowTransDrawCount(pass), true, "shadow transSortedMeshes");
     return s;
 }
 
 static bool same(const Snapshot& a, const Snapshot& b, std::string& why)
 {
     if (a.isVisible != b.isVisible) { why = "isVisible differs"; return false; }
-    if (a.drawCount != b.drawCount || a.instanceCount != b.instanceCount) { why = "counters differ"; return false; }
-    for (uint32_t k = 0; k < a.drawCount; k++) {
-        if (a.meshes[k].componentOffset != b.meshes[k].componentOffset) { why = "componentOffset differs"; return false; }
-        if (memcmp(a.meshes[k].bakedModel.m, b.meshes[k].bakedModel.m, 48) != 0) { why = "bakedModel differs"; return false; }
-        if (memcmp(&a.meshes[k].distanceSq, &b.meshes[k].distanceSq, 4) != 0) { why = "distanceSq differs"; return false; }
+    if (a.counters != b.counters) { why = "counters differ"; return false; }
+    if (a.lists.size() != b.lists.size()) { why = "buffer count differs"; return false; }
+    for (size_t l = 0; l < a.lists.size(); l++) {
+        if (a.lists[l].size() != b.lists[l].size()) { why = "list length differs"; return false; }
+        for (size_t k = 0; k < a.lists[l].size(); k++) {
+            const Record &x = a.lists[l][k], &y = b.lists[l][k];
+            if (x.bufferIndex != y.bufferIndex) { why = "bufferIndex differs"; return false; }
+            if (x.componentOffset != y.componentOffset) { why = "componentOffset differs"; return false; }
+            if (memcmp(x.bakedModel, y.bakedModel, 48) != 0) { why = "bakedModel differs"; return false; }
+            if (memcmp(&x.distanceSq, &y.distanceSq, 4) != 0) { why = "distanceSq differs"; return false; }
+        }
     }
     return true;
+}
+
+static void clearVisible(Manager& manager)
+{
+    for (auto ms : allMeshSystems(manager))
+        for (uint32_t i = 0; i < ms->getMeshComponentOccupancy(); i++)
+            reinterpret_cast<MeshRenderComponent*>(ms->getMeshComponentData() + (size_t)i * ms->getMeshComponentSize())->isVisible = false;
 }
 
 int main(int argc, char** argv)
 {
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
-    bool hier = false, mutate = false;
+    bool hier = false, mutate = false, mixed = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) mode = argv[++i];
@@ -91,6 +169,7 @@ int main(int argc, char** argv)
         else if (a == "--threads" && i + 1 < argc) threads = (uint32_t)atoi(argv[++i]);
         else if (a == "--hier") hier = true;
         else if (a == "--mutate") mutate = true;
+        else if (a == "--mixed") mixed = true;
     }
     try {
         Manager manager;
@@ -100,6 +179,20 @@ int main(int argc, char** argv)
         manager.createSystem<DeferredRenderSystem>();
         auto meshSystem = manager.createSystem<OpaqueMeshSystem>();
         manager.registerComponents<MeshRenderComponent>(meshSystem);
+        OitMeshSystem* oitSystem = nullptr;
+        TranslucentMeshSystem* transSystem = nullptr;
+        GlassMeshSystem* glassSystem = nullptr;
+        UiMeshSystem* uiSystem = nullptr;
+        if (mixed) {  // creation order = order in meshSystems = bufferIndex order (mesh.cpp:69-108)
+            transSystem = manager.createSystem<TranslucentMeshSystem>();
+            manager.registerComponents<TranslucentMeshComponent>(transSystem);
+            oitSystem = manager.createSystem<OitMeshSystem>();
+            manager.registerComponents<OitMeshComponent>(oitSystem);
+            uiSystem = manager.createSystem<UiMeshSystem>();
+            manager.registerComponents<UiMeshComponent>(uiSystem);
+            glassSystem = manager.createSystem<GlassMeshSystem>();
+            manager.registerComponents<GlassMeshComponent>(glassSystem);
+        }
         CpuMeshRenderSystem* cpu = nullptr;
         GpuVisibilitySystem* gpu = nullptr;
         if (mode == "cpu" || mode == "both") {
@@ -125,7 +218,15 @@ int main(int argc, char** argv)
             const float inv = 1.0f / std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + 1e-12f);
             t->setRotation(quat(q[0] * inv, q[1] * inv, q[2] * inv, q[3] * inv));
             t->uid = i + 1;
-            auto m = meshSystem->add(e);
+            MeshRenderComponent* m = nullptr;
+            const uint32_t kind = mixed ? i % 8 : 0;
+            if (kind == 4) m = *oitSystem->add(e);
+            else if (kind == 5) m = *transSystem->add(e);
+            else if (kind == 6) m = *glassSystem->add(e);
+            else if (kind == 7) {
+                m = *uiSystem->add(e);  // UI space: the ortho box of calcUiProjView (mesh.cpp:851-859), some outside
+                t->setPosition(rng.uniform(-1200, 1200), rng.uniform(-600, 600), rng.uniform(-1.5f, 1.5f));
+            } else m = *meshSystem->add(e);
             const float hx = rng.uniform(0.25f, 1.0f), hy = rng.uniform(0.25f, 1.0f), hz = rng.uniform(0.25f, 1.0f);
             m->aabb.min = f32x4(-hx, -hy, -hz);
             m->aabb.max = f32x4(hx, hy, hz);
@@ -135,6 +236,8 @@ int main(int argc, char** argv)
         }
         if (hier)  // every entity beyond the first tenth gets a parent among earlier entities: depth ~4
             for (uint32_t i = entities / 10; i < entities; i++) {
+                if (mixed && i % 8 == 7)
+                    continue;  // UI entities stay in UI space
                 auto t = transformSystem->tryGetOf(ents[i]);
                 t->setPosition(rng.uniform(-40, 40), rng.uniform(-40, 40), rng.uniform(-40, 40));
                 transformSystem->setParent(ents[i], ents[rng.next() % (i / 4 + 1)]);
@@ -147,6 +250,32 @@ int main(int argc, char** argv)
         memset(viewProj.m, 0, sizeof(viewProj.m));
         viewProj.m[0] = 9.0f / 16.0f; viewProj.m[5] = -1.0f; viewProj.m[11] = 1.0f; viewProj.m[14] = 0.01f;
         graphicsSystem->setCamera(viewProj, f32x4(0, 0, 0));
+
+        // --mixed: a 2000 x 1000 UI canvas and two orthographic shadow passes (csm.cpp:260-343 shapes: reversed-Z ortho
+        // boxes around the camera, cameraOffset = light-space shift of the cascade centre)
+        uint32_t passCount = 0;
+        if (mixed) {
+            if (gpu) gpu->setUiSize(2000.0f, 1000.0f);
+            f32x4x4 ui;
+            memset(ui.m, 0, sizeof(ui.m));
+            ui.m[0] = 2.0f / 2000.0f; ui.m[5] = -2.0f / 1000.0f; ui.m[10] = -0.5f; ui.m[14] = 0.5f; ui.m[15] = 1.0f;
+            if (cpu) cpu->uiViewProj = ui;
+            std::vector<GpuVisibilitySystem::ShadowPass> gpuPasses;
+            std::vector<CpuMeshRenderSystem::ShadowPass> cpuPasses;
+            for (int c = 0; c < 2; c++) {
+                const float size = side * (c == 0 ? 0.25f : 0.6f), nearPlane = -side, farPlane = side;
+                f32x4x4 vp;
+                memset(vp.m, 0, sizeof(vp.m));
+                vp.m[0] = 2.0f / size; vp.m[5] = -2.0f / size; vp.m[10] = -1.0f / (farPlane - nearPlane);
+                vp.m[14] = farPlane / (farPlane - nearPlane); vp.m[15] = 1.0f;
+                const f32x4 offset(3.0f * (float)(c + 1), -7.0f, 11.0f);
+                gpuPasses.push_back({vp, offset});
+                cpuPasses.push_back({vp, offset});
+            }
+            if (gpu) gpu->setShadowPasses(gpuPasses);
+            if (cpu) cpu->setShadowPasses(cpuPasses);
+            passCount = 2;
+        }
 
         auto run = [&](bool useCpu, bool useGpu, uint32_t n) {
             if (cpu) cpu->isEnabled = useCpu;
@@ -171,6 +300,10 @@ int main(int argc, char** argv)
                 manager.destroy(ents[i]);
             }
             meshSystem->markMeshesChanged();
+            if (mixed) {
+                transSystem->markMeshesChanged(); oitSystem->markMeshesChanged();
+                uiSystem->markMeshesChanged(); glassSystem->markMeshesChanged();
+            }
             transformSystem->hierarchyVersion++;  // entities were destroyed: full rebuild
             graphicsSystem->setCamera(viewProj, f32x4(12.5f, -3.0f, 40.0f));
         };
@@ -178,36 +311,40 @@ int main(int argc, char** argv)
         bool ok = true;
         std::string why;
         double seconds = 0;
-        uint32_t drawCount = 0;
+        uint32_t drawCount = 0, sortedDrawCount = 0;
         int rounds = mutate ? 2 : 1;
         for (int round = 0; round < rounds && ok; round++) {
             if (round == 1)
                 doMutate();
             if (mode == "both") {
                 run(true, false, 1);
-                Snapshot a = snapshot(meshSystem, cpu->getUnsortedBuffers()[0]);
-                for (uint32_t i = 0; i < meshSystem->getComponents().getOccupancy(); i++)
-                    meshSystem->getComponents().getData()[i].isVisible = false;
+                Snapshot a = snapshot(manager, cpu, passCount);
+                clearVisible(manager);
                 seconds += run(false, true, ticks);
-                const bool sorted = isSortedByDistance(gpu->getUnsortedBuffers()[0]);  // gv_sort == sortMeshes order
-                Snapshot b = snapshot(meshSystem, gpu->getUnsortedBuffers()[0]);
+                Snapshot b = snapshot(manager, gpu, passCount);
                 ok = same(a, b, why);
-                if (ok && !sorted) {
+                if (ok && !a.ordered) {
                     ok = false;
-                    why = "combinedMeshes not ascending by distanceSq after gv_sort";
+                    why = "CPU system: " + a.disorder + " not in sortMeshes order";
                 }
-                drawCount = b.drawCount;
+                if (ok && !b.ordered) {  // gv_sort (+ run merge) == sortMeshes order
+                    ok = false;
+                    why = "GPU system: " + b.disorder + " not in sortMeshes order";
+                }
+                drawCount = gpu->getUnsortedBuffers()[0]->drawCount;
+                sortedDrawCount = gpu->getTransDrawCount() + gpu->getUiDrawCount();
             } else {
                 seconds += run(mode == "cpu", mode == "gpu", ticks);
                 drawCount = (cpu ? cpu->getUnsortedBuffers()[0] : gpu->getUnsortedBuffers()[0])->drawCount;
+                sortedDrawCount = cpu ? cpu->getTransDrawCount() + cpu->getUiDrawCount() : gpu->getTransDrawCount() + gpu->getUiDrawCount();
             }
         }
         uint32_t visibleFlags = 0;
         for (uint32_t i = 0; i < meshSystem->getComponents().getOccupancy(); i++)
             visibleFlags += meshSystem->getComponents().getData()[i].isVisible ? 1 : 0;
         printf("{\"mode\": \"%s\", \"entities\": %u, \"ticks\": %u, \"threads\": %u, \"hier\": %s, \"draw_count\": %u, "
-               "\"is_visible_set\": %u, \"culls_per_s\": %.1f, \"ok\": %s, \"why\": \"%s\"}\n",
-               mode.c_str(), entities, ticks * rounds, threads, hier ? "true" : "false", drawCount, visibleFlags,
+               "\"sorted_draw_count\": %u, \"is_visible_set\": %u, \"culls_per_s\": %.1f, \"ok\": %s, \"why\": \"%s\"}\n",
+               mode.c_str(), entities, ticks * rounds, threads, hier ? "true" : "false", drawCount, sortedDrawCount, visibleFlags,
                (double)entities * ticks * rounds / seconds, ok ? "true" : "false", why.c_str());
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

@@ -37,6 +37,15 @@ def test_cpu_hierarchy_and_mutations(tick):
     assert out["draw_count"] > 0
 
 
+def test_cpu_mixed_mesh_systems_sorted_and_unsorted_buffers(tick):
+    """prepareMeshes' classification (mesh.cpp:341-546): Opaque + OIT unsorted buffers, two Translucent systems sharing
+    transSortedMeshes, one UI system with its own frustum and 2D key; plus two shadow passes."""
+    _, out = tick("--mode", "cpu", "--entities", "8000", "--ticks", "2", "--mixed")
+    assert out["draw_count"] > 0 and out["sorted_draw_count"] > 0
+    _, out = tick("--mode", "cpu", "--entities", "8000", "--ticks", "2", "--mixed", "--hier", "--mutate", "--threads", "3")
+    assert out["draw_count"] > 0 and out["sorted_draw_count"] > 0
+
+
 def test_gpu_system_fails_loudly_without_device(tick):
     import torch
     if torch.cuda.is_available():
@@ -52,6 +61,8 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "50000", "--hier"],
     ["--entities", "50000", "--hier", "--mutate"],
     ["--entities", "1000", "--mutate"],
+    ["--entities", "40000", "--mixed"],
+    ["--entities", "40000", "--mixed", "--hier", "--mutate"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", "--ticks", "3", *args)
