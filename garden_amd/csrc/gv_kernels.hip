@@ -15,6 +15,8 @@
 // per lane over SoA streams so each wave-instruction touches 1 KiB / 768 B contiguous.
 #include "gv_kernels.hpp"
 
+#include <algorithm>
+
 #include "gv_device_math.hpp"
 
 namespace gv {
@@ -57,6 +59,15 @@ __device__ __forceinline__ XfRecord load_xf(const TransformMirror& xf, uint32_t 
     r.b = xf.b[s];
     r.c = xf.c[s];
     r.flags = xf.flags[s];
+    return r;
+}
+__device__ __forceinline__ XfRecord gather_xf(const TransformMirror& xf, uint32_t s, bool with_flags)
+{
+    XfRecord r;
+    r.a = xf.a[s];
+    r.b = xf.b[s];
+    r.c = xf.c[s];
+    r.flags = with_flags ? xf.flags[s] : 0u;
     return r;
 }
 __device__ __forceinline__ XfRecord stream_xf(const TransformMirror& xf, uint32_t s)  // the once-per-frame read
@@ -513,6 +524,55 @@ struct EmitArgs {
     ViewBuffers out;
 };
 
+// The record of visible mirror entry i at output position `rank` (mesh.cpp:169-173). Visible entries passed every
+// filter in K1: only the transform entry and its model are needed here.
+__device__ __forceinline__ void write_record(const EmitArgs& args, uint32_t i, size_t rank)
+{
+    // every gather here is a sparse 64-byte fetch for a few useful bytes: the flag byte is only read when the pool has
+    // chains at all
+    const bool chains = args.xf.max_depth != 0;  // uniform
+    uint32_t slot = i;
+    XfRecord rec = {};
+    if (args.mesh.mapping == kMapGeneral) {  // uniform
+        slot = args.mesh.link[i] & kSlotMask;
+        rec = gather_xf(args.xf, slot, chains);
+    } else {
+        rec = gather_xf(args.xf, i, chains);  // same speculation as K1: entry i beside (or instead of) the link word
+        if (args.mesh.mapping == kMapSpeculate) {
+            slot = args.mesh.link[i] & kSlotMask;
+            if (slot != i)
+                rec = gather_xf(args.xf, slot, chains);
+        }
+    }
+    const Mat34 world = chain_model(args.xf, local_model(rec), slot, rec.flags);
+    const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
+    args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
+    float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
+    bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+    bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+    bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    const float tx = m.c3x + args.view.cam_offset[0];
+    const float ty = m.c3y + args.view.cam_offset[1];
+    const float tz = m.c3z + args.view.cam_offset[2];
+    args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+}
+
+// position of the k-th (0-based) set bit of `word`
+__device__ __forceinline__ uint32_t select_bit(unsigned long long word, uint32_t k)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t width = 32; width >= 1; width >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(word & ((1ull << width) - 1ull));
+        if (k >= c) {
+            k -= c;
+            pos += width;
+            word >>= width;
+        }
+    }
+    return pos;
+}
+
 constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slots = 16 ballot words each
 
 // Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
@@ -556,44 +616,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
             else
                 hi = mid;
         }
-        unsigned long long word = words[lo];
-        uint32_t k = r - prefix[lo], pos = 0;  // position of the k-th set bit
-#pragma unroll
-        for (uint32_t width = 32; width >= 1; width >>= 1) {
-            const uint32_t c = (uint32_t)__popcll(word & ((1ull << width) - 1ull));
-            if (k >= c) {
-                k -= c;
-                pos += width;
-                word >>= width;
-            }
-        }
+        const uint32_t pos = select_bit(words[lo], r - prefix[lo]);
         const uint32_t i = (first_word + lo) * 64 + pos;
-        // visible entries passed every filter in K1: only the transform entry and its model are needed here
-        uint32_t slot = i;
-        XfRecord rec = {};
-        if (args.mesh.mapping == kMapGeneral) {  // uniform
-            slot = args.mesh.link[i] & kSlotMask;
-            rec = load_xf(args.xf, slot);
-        } else {
-            rec = load_xf(args.xf, i);  // same speculation as K1: entry i beside (or instead of) the link word
-            if (args.mesh.mapping == kMapSpeculate) {
-                slot = args.mesh.link[i] & kSlotMask;
-                if (slot != i)
-                    rec = load_xf(args.xf, slot);
-            }
-        }
-        const Mat34 world = chain_model(args.xf, local_model(rec), slot, rec.flags);
-        const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
-        const size_t rank = (size_t)base + r;
-        args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
-        float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
-        bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
-        bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
-        bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
-        const float tx = m.c3x + args.view.cam_offset[0];
-        const float ty = m.c3y + args.view.cam_offset[1];
-        const float tz = m.c3z + args.view.cam_offset[2];
-        args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+        write_record(args, i, (size_t)base + r);
     }
 }
 
