@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Post-processes tools/collect_traffic.sh output (gpurun_out/pmc) into profiles/: traffic.json (HBM bytes per
+launch of the cull kernel from the FETCH_SIZE / WRITE_SIZE passes) and per-workload kernel stats / bench lines.
+  python tools/summarize_traffic.py r01f
+The read side is calibrated on the kernel's own known stream (see _method in traffic.json)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PMC = os.path.join(ROOT, "gpurun_out", "pmc")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01x"
+
+
+def newest(pattern):
+    files = glob.glob(os.path.join(PMC, pattern))
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def counter_mean(workload, counter, kernel_prefix):
+    f = newest(f"{workload}_{counter}/*/*counter_collection.csv")
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"]]
+    return sum(vals) / len(vals), len(vals)
+
+
+N = 10_000_000
+out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_traffic.sh, "
+       "tools/summarize_traffic.py). gfx950 FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md: 1/2 for "
+       "16 B/lane; other widths uncalibrated), so the read side is calibrated on this kernel's own access pattern: the "
+       "frustum-only cull of a flat, exactly-paired pool of 10 M entities streams a known 65 B/entity (+ one 8-byte flag "
+       "word per wave) -> factor = known bytes / (FETCH_SIZE KB * 1024); WRITE_SIZE taken as reported (KB * 1024). Per "
+       "launch of gv::cull_kernel. The factor is applied to all reads of cfg3 too, which over-counts its 8-byte Hi-Z "
+       "texel gathers (narrow reads are reported closer to 1:1): cfg3's figure is an upper bound."}
+f2, n2 = counter_mean("cfg2", "FETCH_SIZE", "cull_kernel")
+w2, _ = counter_mean("cfg2", "WRITE_SIZE", "cull_kernel")
+known = N * 65 + N / 64 * 8
+factor = known / (f2 * 1024)
+out["fetch_calibration_factor"] = factor
+out["cfg2_at_10M"] = {"FETCH_SIZE_KB": f2, "WRITE_SIZE_KB": w2, "launches": n2,
+                      "cull_kernel_hbm_bytes_per_launch": f2 * 1024 * factor + w2 * 1024}
+f3, n3 = counter_mean("cfg3", "FETCH_SIZE", "cull_kernel")
+w3, _ = counter_mean("cfg3", "WRITE_SIZE", "cull_kernel")
+out["cfg3"] = {"FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "launches": n3,
+               "cull_kernel_hbm_bytes_per_launch": f3 * 1024 * factor + w3 * 1024,
+               "cull_kernel_hbm_bytes_per_launch_uncalibrated": f3 * 1024 + w3 * 1024}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+
+with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
+    fo.write("workload,kernel,counter,mean_value_KB,launches\n")
+    for wl in ("cfg2", "cfg3"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = newest(f"{wl}_{counter}/*/*counter_collection.csv")
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            for k, v in sorted(acc.items()):
+                if k.startswith("gv::") or "gv::" in k:
+                    fo.write(f'{wl}{"@10M" if wl == "cfg2" else ""},"{k}",{counter},{sum(v) / len(v):.3f},{len(v)}\n')
+
+for wl in ("cfg2", "cfg3", "cfg4"):
+    ks = newest(f"stats_{wl}/*/*kernel_stats.csv")
+    if ks:
+        shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
+    log = os.path.join(PMC, f"stats_{wl}.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(ROOT, "profiles", f"{tag}_{wl}_bench_line.json"), "w").write(lines[-1])
