@@ -133,9 +133,15 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GV_BENCH_EXCHANGE=1 runs the exchange step with a 1-rank group too (functional check of the RCCL path on a
+    # 1-GPU box; the default N=1 line has no exchange)
+    exchange = world > 1 or os.environ.get("GV_BENCH_EXCHANGE") == "1"
+    if exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -144,7 +150,7 @@ def main():
 
     from garden_amd import scene
     from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU
-    from garden_amd.multi import allgatherv_indices
+    from garden_amd.multi import VisibleListExchange, allgatherv_indices, shard_capacity
 
     wl = WORKLOADS[args.workload]
     n = args.entities or wl["entities"]
@@ -164,27 +170,34 @@ def main():
     if wl["hiz"]:
         vis.hiz_build(depth)
 
-    # two index buffers: the all-gatherv of frame f may still be reading one while frame f+1 fills the other
-    idx_bufs = [torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(2)] if world > 1 else None
-    frame = [0]
+    idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if exchange else None
+    ex = [None]  # VisibleListExchange, created once the shard capacity is known (first, exact exchange)
 
-    def step():
+    def compute():
         if wl["hiz"]:
             vis.hiz_rebuild()
         if wl["sweep"]:
             vis.sweep(GV_SWEEP_MFMA if args.sweep == "mfma" else GV_SWEEP_VALU)
         vis.cull(0, [view])
-        if world > 1:
-            idx_buf = idx_bufs[frame[0] & 1]
-            frame[0] += 1
-            vis.copy_idx_device(0, idx_buf.data_ptr(), n, index_base=rank * n)
-            count = vis.result_count(0)  # 4-byte readback on the library's stream: also fences the copy above
-            return allgatherv_indices(idx_buf, count, dist)
+
+    def step():
+        """One frame. With an exchange: the tile's list goes out as a fixed-capacity shard [count, indices...] and all
+        ranks gather the shards with one equal-size all-gather enqueued behind the library's stream — no host
+        synchronisation, so the next frame is culled while this one's list is still on the links."""
+        compute()
+        if ex[0] is not None:
+            shard = ex[0].next_shard()
+            vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
+            return ex[0].exchange()
         return None
 
     def check_exchange():
-        """All ranks hold the same concatenated list; every index lies in its owner's tile range."""
-        gathered, counts = step()
+        """Exact-size all-gatherv of one frame (host-synchronising form): all ranks hold the same concatenated list;
+        every index lies in its owner's tile range; own shard == local visible list. Sizes the padded shards."""
+        compute()
+        vis.copy_idx_device(0, idx_buf.data_ptr(), n, index_base=rank * n)
+        count = vis.result_count(0)  # 4-byte readback on the library's stream: also fences the copy above
+        gathered, counts = allgatherv_indices(idx_buf, count, dist)
         g = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         c = counts.cpu().numpy()
         assert g.shape[0] == int(c.sum())
@@ -196,24 +209,40 @@ def main():
                 mine = vis.fetch(0, write_back=False, occupancy=n)["visible_idx"].astype(np.int64) + rank * n
                 assert np.array_equal(np.sort(part), mine), "own shard differs from the local visible list"
             off += int(c[r])
-        return int(c.sum())
+        return g, c
+
+    def check_padded(padded, exact, exact_counts):
+        """The per-frame padded exchange delivered the same lists as the exact one (static scene)."""
+        ex[0].drain()  # raises if any frame of the run overflowed its shard
+        dense, counts = ex[0].compact(padded)
+        d = dense.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(counts.numpy(), exact_counts), "padded exchange: counts differ from the exact all-gatherv"
+        assert np.array_equal(d, exact), "padded exchange: lists differ from the exact all-gatherv"
 
     def fence():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered_total = check_exchange() if world > 1 else None
+    gathered_total = None
+    if exchange:
+        exact, exact_counts = check_exchange()
+        gathered_total = int(exact_counts.sum())
+        producer = torch.cuda.ExternalStream(vis.stream(), device=torch.device("cuda", local_rank)) if backend == "nccl" else None
+        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", shard_capacity(int(exact_counts.max())), stream=producer)
     for _ in range(args.warmup):
         step()
     fence()
     upload_bytes = vis.stats()["upload_bytes"]
     vis.stats_reset()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
     fence()
     elapsed = time.perf_counter() - t0
+    if exchange:
+        check_padded(last, exact, exact_counts)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,7 +298,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
-                       "exchange": f"all-gatherv of uint32 visible lists ({backend}), {gathered_total} indices gathered per rank" if world > 1 else None,
+                       "exchange": (f"per frame: one equal-size all-gather of padded shards [count, uint32 indices...] "
+                                    f"(capacity {ex[0].capacity}) behind the cull stream, no host sync ({backend}); "
+                                    f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
                        # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
                        "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"] if st["device_ms"][k] > 0},
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes},
@@ -282,7 +313,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, sc, view, depth)
         print(json.dumps(out))
     vis.close()
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1360,6 +1360,20 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
     return GV_OK;
 }
 
+int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
+                                 uint32_t index_base)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
+        return ctx->fail(GV_E_ARG, "gv_results_copy_shard_device: view %u has no emitted records", view_index);
+    ViewState& vs = ctx->views[view_index];
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
+                                  index_base, ctx->stream));
+    return GV_OK;
+}
+
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
 {
     if (!ctx)

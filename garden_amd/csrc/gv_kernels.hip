@@ -713,6 +713,25 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
     return hipGetLastError();
 }
 
+// exchange shard: [draw_count, idx + base ...]; the header is the true count even when it exceeds `capacity`
+__global__ __launch_bounds__(256) void copy_shard_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
+                                                         uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+{
+    const uint32_t total = *count, n = min(total, capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        dst[0] = total;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[1 + i] = src[i] + base;
+}
+
+hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                             hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 255u) / 256u));
+    hipLaunchKernelGGL(copy_shard_kernel, dim3(blocks), dim3(256), 0, stream, src, count, dst, capacity, base);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // sortMeshes (mesh.cpp:265-328): order the compact records by distanceSq — ascending for unsorted buffers
 // (front to back, operator< at render/mesh.hpp:196), descending for the sorted / translucent ones (:204).

@@ -92,6 +92,8 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
                        hipStream_t stream);
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                            hipStream_t stream);
+hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                             hipStream_t stream);
 
 // sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
 struct SortBuffers {

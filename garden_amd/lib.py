@@ -71,7 +71,7 @@ class GvError(RuntimeError):
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
-    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_sort", "gv_sweep", "gv_get_world",
+    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream",
 ]
@@ -107,6 +107,7 @@ def load():
     lib.gv_result_count.argtypes = [P, u32, C.POINTER(u32)]
     lib.gv_results_device.argtypes = [P, u32, C.POINTER(GvDeviceResult)]
     lib.gv_results_copy_idx_device.argtypes = [P, u32, P, u32, u32]
+    lib.gv_results_copy_shard_device.argtypes = [P, u32, P, u32, u32]
     lib.gv_sort.argtypes = [P, u32, C.c_int]
     lib.gv_sweep.argtypes = [P, u32]
     lib.gv_get_world.argtypes = [P, u32, u32, P]
@@ -244,6 +245,14 @@ class GpuVisibility:
 
     def copy_idx_device(self, view_index, dst_ptr, capacity, index_base=0):
         self._check(self.lib.gv_results_copy_idx_device(self.ctx, view_index, dst_ptr, capacity, index_base))
+
+    def copy_shard_device(self, view_index, dst_ptr, capacity, index_base=0):
+        """dst[0] = draw_count, dst[1:1+min(count, capacity)] = visible_idx + index_base (device memory, no sync)."""
+        self._check(self.lib.gv_results_copy_shard_device(self.ctx, view_index, dst_ptr, capacity, index_base))
+
+    def stream(self):
+        """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return self.lib.gv_stream(self.ctx)
 
     def sort(self, view_index=0, descending=False):
         self._check(self.lib.gv_sort(self.ctx, view_index, 1 if descending else 0))

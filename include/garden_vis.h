@@ -167,6 +167,11 @@ int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out);
 /* Copies visible_idx (+ `index_base` added to each) into caller-owned device memory. */
 int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                uint32_t index_base);
+/* Exchange shard for the multi-GPU all-gather: dst[0] = draw_count (the true count, also when it
+ * exceeds `capacity`), dst[1 .. 1 + min(draw_count, capacity)) = visible_idx + index_base. dst holds 1 + capacity
+ * uint32. No host synchronisation: ranks can gather fixed-size padded shards and read the counts from the headers. */
+int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
+                                 uint32_t index_base);
 
 /* Sorts view `view_index`'s compact records on the device by distanceSq: ascending (descending == 0) as sortMeshes
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /

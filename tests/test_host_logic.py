@@ -127,3 +127,52 @@ def test_allgatherv_with_an_empty_shard():
     for rank in range(world):
         gathered, counts = ret[rank]
         assert list(counts) == [40, 0, 42] and np.array_equal(gathered, exp)
+
+
+def _padded_exchange_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import ShardOverflow, VisibleListExchange, allgatherv_indices, shard_capacity
+    cap = shard_capacity(60, quantum=16)
+    ex = VisibleListExchange(dist, "cpu", cap)
+    ok = True
+    for frame in range(5):  # counts change from frame to frame; slots rotate
+        count = (10 + 7 * frame) * (rank + 1) if not (rank == 1 and frame == 2) else 0
+        idx = torch.arange(count, dtype=torch.int32) + 1000 * rank + frame
+        shard = ex.next_shard()
+        shard[0] = count  # what gv_results_copy_shard_device writes
+        shard[1:1 + count] = idx
+        padded = ex.exchange()
+        dense, counts = ex.compact(padded)
+        ref_buf = torch.zeros(cap, dtype=torch.int32)
+        ref_buf[:count] = idx
+        ref, ref_counts = allgatherv_indices(ref_buf, count, dist)  # the exact-size form gives the same list
+        ok = ok and torch.equal(dense, ref) and torch.equal(counts, ref_counts.to(torch.int64))
+    ex.drain()
+    # a frame that does not fit: detected from the headers, with the capacity it would have needed
+    shard = ex.next_shard()
+    shard[0] = cap + 5 if rank == 0 else 3
+    ex.exchange()
+    try:
+        ex.drain()
+        overflow = None
+    except ShardOverflow as e:
+        overflow = e.needed
+    ret[rank] = (ok, overflow, cap)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_padded_exchange_world_size_2_gloo():
+    """The per-frame, sync-free exchange (fixed-capacity shards, counts in the headers) against the exact all-gatherv,
+    incl. an empty shard, changing counts, slot rotation and overflow detection on every rank."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_padded_exchange_worker, args=(world, port, ret), nprocs=world, join=True)
+    for rank in range(world):
+        ok, overflow, cap = ret[rank]
+        assert ok and overflow == cap + 5
