@@ -88,6 +88,13 @@ def load():
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C garden_amd/csrc` (or __graft_entry__.build()); "
             "there is no CPU fallback")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64, and a process that loads the system one first
+    # (through this library) and torch's second ends up with two runtimes, the second of which finds no GPU. Loading
+    # torch's first makes this library bind to it as well (same SONAME). torch stays optional.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     lib.gv_abi_version.restype = u32

@@ -419,3 +419,40 @@ def test_hiz_query_early_accept_is_exact(oracle, size, rule):
     frustum_only = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, dict(v, use_hiz=0))
     assert 0 < exp["draw_count"] < frustum_only["draw_count"]
     assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+
+
+def test_device_side_result_accessors(gpu, oracle):
+    """gv_results_device / gv_results_copy_idx_device / gv_results_copy_shard_device: the compact list as device
+    consumers (the multi-GPU exchange, an indirect-draw builder) see it, incl. the capacity clamp."""
+    import torch
+    sc = scene.flat_scene(50_000)
+    view = scene.main_camera_view()
+    bind_and_cull = lambda: (gpu.bind_transforms(sc.transforms, sc.entity_to_transform), gpu.bind_pool(0, sc.meshes),
+                             gpu.hierarchy_rebuild(), gpu.cull(0, [view]))
+    bind_and_cull()
+    raw = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
+    k = raw["draw_count"]
+    assert k > 100
+    base = 7_000_000
+    dst = torch.full((sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    gpu.copy_idx_device(0, dst.data_ptr(), sc.count, index_base=base)
+    assert gpu.result_count(0) == k  # readback on the library's stream: fences the copy
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[:k].astype(np.int64), raw["visible_idx"].astype(np.int64) + base) and np.all(got[k:] == -1)
+
+    shard = torch.full((1 + sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    gpu.copy_shard_device(0, shard.data_ptr(), sc.count, index_base=base)
+    gpu.wait()
+    got = shard.cpu().numpy()
+    assert got[0] == k and np.array_equal(got[1:1 + k].astype(np.int64), raw["visible_idx"].astype(np.int64) + base)
+    assert np.all(got[1 + k:] == -1)
+
+    cap = 64  # too small: header still carries the true count, body is clamped
+    small = torch.full((1 + cap + 8,), -1, dtype=torch.int32, device="cuda:0")
+    gpu.copy_shard_device(0, small.data_ptr(), cap, index_base=0)
+    gpu.wait()
+    got = small.cpu().numpy()
+    assert got[0] == k and np.array_equal(got[1:1 + cap], raw["visible_idx"][:cap].astype(np.int32)) and np.all(got[1 + cap:] == -1)
+
+    d = gpu.results_device(0)
+    assert d.visible_idx and d.baked_model and d.distance_sq and d.draw_count
