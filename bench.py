@@ -4,7 +4,8 @@
 A "step" is one frame of the hot path over one batch of resident component pools:
   cfg2: 1M static entities, flat, frustum-only cull + compaction
   cfg3: 10M entities, Hi-Z pyramid rebuild (4096^2 depth) + frustum + Hi-Z occlusion cull + compaction  [default]
-  cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep + chain-walk frustum cull + compaction
+  cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep fused with the frustum cull (one pass) + compaction
+        (--sweep mfma|valu: separate sweep and cull launches; fused-valu: the fused pass with the v_fma chain)
 For N > 1 each rank owns one spatial tile (same per-GPU entity count: weak scaling), culls it against the
 same view and the ranks all-gatherv the compacted global visible-index lists over RCCL (cfg5 pattern).
 
@@ -63,7 +64,7 @@ def make_tile_scene(wl, n_local, rank, world):
     return sc
 
 
-def algorithmic_bytes(wl, n, frustum_survivors, visible, depth):
+def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False):
     """Minimal SoA stream bytes per launch for the cull kernel, and
     for the whole step (for information)."""
     cull = n * (65.0 + 1.0 + 0.125)  # TRS 40 + AABB 24 + flags 1 read; isVisible 1 + ballot word 1/8 written
@@ -74,6 +75,9 @@ def algorithmic_bytes(wl, n, frustum_survivors, visible, depth):
     emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125
     hiz = (HIZ_SIZE * HIZ_SIZE * 4 + sum(max(HIZ_SIZE >> k, 1) ** 2 * 8 for k in range(1, 13))) if wl["hiz"] else 0.0
     sweep = n * (40.0 + 4.0 + 48.0) if wl["sweep"] else 0.0
+    if fused and wl["sweep"]:  # one pass: the TRS streams are read once, the world matrices (48 B) written beside the cull outputs
+        cull += n * 48.0
+        sweep = 0.0
     return dict(cull=cull, emit=emit, hiz=float(hiz), sweep=sweep)
 
 
@@ -116,7 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--entities", type=int, default=0, help="per-GPU entity count override")
-    ap.add_argument("--sweep", default="mfma", choices=["mfma", "valu"], help="cfg4 world-matrix sweep form")
+    ap.add_argument("--sweep", default="fused", choices=["mfma", "valu", "fused", "fused-valu"],
+                    help="cfg4 world-matrix sweep form; fused = MFMA sweep and cull in one pass (GV_SWEEP_WITH_CULL)")
     ap.add_argument("--profile-all", action="store_true", help="hipEvents around every kernel (slower step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -149,7 +154,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from garden_amd import scene
-    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU
+    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
     from garden_amd.multi import VisibleListExchange, allgatherv_indices, shard_capacity
 
     wl = WORKLOADS[args.workload]
@@ -177,7 +182,7 @@ def main():
         if wl["hiz"]:
             vis.hiz_rebuild()
         if wl["sweep"]:
-            vis.sweep(GV_SWEEP_MFMA if args.sweep == "mfma" else GV_SWEEP_VALU)
+            vis.sweep({"mfma": GV_SWEEP_MFMA, "valu": GV_SWEEP_VALU, "fused": GV_SWEEP_WITH_CULL, "fused-valu": GV_SWEEP_WITH_CULL_VALU}[args.sweep])
         vis.cull(0, [view])
 
     def step():
@@ -249,6 +254,18 @@ def main():
         elapsed = float(t.item())
     st = vis.stats()
 
+    # also report the rate when every TRS is re-uploaded each frame (host AoS -> mirror gather + PCIe
+    # + cull). Outside the timed region; never `value`.
+    dirty_rate = None
+    if world == 1:
+        from garden_amd.lib import GV_DIRTY_TRANSFORM
+        frames, t1 = 3, time.perf_counter()
+        for _ in range(frames):
+            vis.mark_dirty(GV_DIRTY_TRANSFORM, 0, n)
+            compute()
+        vis.wait()
+        dirty_rate = n * frames / (time.perf_counter() - t1)
+
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
     visible = got["draw_count"]
@@ -277,7 +294,8 @@ def main():
                 sys.exit(1)
 
     if rank == 0:
-        ab = algorithmic_bytes(wl, n, survivors, visible, depth)
+        fused = wl["sweep"] and args.sweep.startswith("fused")
+        ab = algorithmic_bytes(wl, n, survivors, visible, depth, fused=fused)
         launches = max(1, st["launches"]["cull"])
         cull_ms = st["device_ms"]["cull"] / launches
         achieved = ab["cull"] / (cull_ms * 1e-3) / 1e9 if cull_ms > 0 else 0.0
@@ -296,15 +314,16 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "entities_per_gpu": n, "entities_total": n * world,
+            "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None, "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
                        "exchange": (f"per frame: one equal-size all-gather of padded shards [count, uint32 indices...] "
                                     f"(capacity {ex[0].capacity}) behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
                        # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
                        "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"] if st["device_ms"][k] > 0},
-                       "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes},
-            "roofline": {"bound": "hbm", "kernel": "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes,
+                       "culls_per_s_with_full_trs_upload_each_frame": dirty_rate},
+            "roofline": {"bound": "hbm", "kernel": ("gv::sweep_cull_mfma_kernel" if args.sweep == "fused" else "gv::sweep_cull_valu_kernel") if fused else "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab["cull"], "avg_launch_ms": cull_ms},
             "parity": parity,

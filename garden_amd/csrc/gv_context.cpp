@@ -162,6 +162,8 @@ struct GvCtx {
 
     TransformBinding xf;
     bool xf_need_full = false;
+    bool sweep_with_cull_mfma = true;
+    bool sweep_with_cull = false;  // GV_SWEEP_WITH_CULL requested: the next gv_cull also writes the world matrices
     bool xf_links_dirty = false;  // a ranged GV_DIRTY_HIERARCHY: parent links changed -> re-validate depth / cycles
     DirtyRange xf_dirty;
     DeviceBuf<float4> d_xa, d_xb;
@@ -1217,6 +1219,22 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         if (p.occupancy == 0)
             GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
     }
+    // GV_SWEEP_WITH_CULL: an exactly paired pool takes the fused MFMA sweep + cull for its first view; anything else
+    // gets the same results from the plain MFMA sweep followed by the ordinary cull
+    const bool sweep_requested = ctx->sweep_with_cull;
+    ctx->sweep_with_cull = false;
+    const bool fused = sweep_requested && !batched && p.occupancy != 0 && mesh.mapping == kMapExact && mesh.count <= xf.count;
+    if (sweep_requested) {
+        GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(ctx->xf.occupancy, 1u) * 3));
+        if (!fused) {
+            KernelTimer t(ctx, GV_K_SWEEP);
+            if (ctx->sweep_with_cull_mfma)
+                GV_HIP(ctx, launch_sweep_mfma(xf, ctx->d_world.ptr, ctx->stream));
+            else
+                GV_HIP(ctx, launch_sweep_valu(xf, ctx->d_world.ptr, ctx->stream));
+        }
+        ctx->world_valid = true;
+    }
     if (p.occupancy != 0) {
         if (batched) {
             KernelTimer t(ctx, GV_K_CULL);
@@ -1225,7 +1243,10 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         for (uint32_t v = 0; v < view_count; v++) {
             if (!batched) {
                 KernelTimer t(ctx, GV_K_CULL);
-                GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream));
+                if (fused && v == 0)
+                    GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
+                else
+                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream));
             }
             {
                 KernelTimer t(ctx, GV_K_SCAN);
@@ -1424,6 +1445,11 @@ int gv_sweep(GvCtx* ctx, uint32_t mode)
 {
     if (!ctx)
         return GV_E_ARG;
+    if (mode == GV_SWEEP_WITH_CULL || mode == GV_SWEEP_WITH_CULL_VALU) {  // nothing to launch now: the next gv_cull carries the sweep
+        ctx->sweep_with_cull = true;
+        ctx->sweep_with_cull_mfma = mode == GV_SWEEP_WITH_CULL;
+        return GV_OK;
+    }
     if (mode != GV_SWEEP_VALU && mode != GV_SWEEP_MFMA)
         return ctx->fail(GV_E_ARG, "gv_sweep: unknown mode %u", mode);
     int rc = sync_mirror(ctx);

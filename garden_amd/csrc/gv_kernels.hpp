@@ -123,6 +123,10 @@ hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32
 // world matrices (camera = 0) of every transform slot: 3 float4 per slot (float4x3 order)
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream);
 hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream);
+// Sweep (MFMA or VALU chain) + cull of an exactly paired pool (mesh.mapping == kMapExact) in one pass: world matrices AND the cull
+// outputs of one view; same bits as launch_sweep_* followed by launch_cull.
+hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                             const ViewParams& vp, const ViewBuffers& out, float4* world, bool mfma, hipStream_t stream);
 
 // Hi-Z pyramid. Level k >= 1 lives at mips + mip_offset[k]; level 0 is the depth image.
 // Generic one-level reduction (any size, shaders/hiz.frag:27-56 incl. the odd-size branches).

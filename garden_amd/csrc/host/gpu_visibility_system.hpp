@@ -66,6 +66,9 @@ public:
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
     // (front to back), so the engine's std::sort over combinedMeshes can be dropped
     bool sortOnDevice = true;
+    // true: every frame also leaves the world matrices of all transforms on the device (gv_get_world): the sweep
+    // rides on the first pool's cull (GV_SWEEP_WITH_CULL), fused into one pass when that pool is exactly paired
+    bool sweepWorldMatrices = false;
 
     explicit GpuVisibilitySystem(int device = 0, bool profile = false)
     {
@@ -305,6 +308,8 @@ private:
                     views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
                                              (int8_t)s, false, emitRecords));
             }
+            if (sweepWorldMatrices && p == 0)
+                check(gv_sweep(ctx, GV_SWEEP_WITH_CULL), "gv_sweep");
             check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
 
             if (isSortedType(renderType)) {

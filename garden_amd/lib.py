@@ -21,7 +21,7 @@ GV_CONFIG_PROFILE_EVENTS = 1
 GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_CONFIG_KEEP_SLOT_ORDER = 4
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
-GV_SWEEP_VALU, GV_SWEEP_MFMA = 0, 1
+GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU = 0, 1, 2, 3
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
 KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep", "sort"]
 

@@ -184,7 +184,12 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
  * slot (transform.hpp:197-214), cached on the device ---- */
 typedef enum GvSweepMode {
     GV_SWEEP_VALU = 0, /* v_fma_f32 chain */
-    GV_SWEEP_MFMA = 1  /* v_mfma_f32_4x4x1_16b_f32 chain (bit-identical; self-tested at gv_create) */
+    GV_SWEEP_MFMA = 1, /* v_mfma_f32_4x4x1_16b_f32 chain (bit-identical; self-tested at gv_create) */
+    /* Deferred: the NEXT gv_cull also produces the world matrices. When its pool is exactly paired with the transform
+     * pool (mesh entry i belongs to transform slot i) the MFMA sweep and the cull of view 0 run as one pass over the
+     * streams; otherwise the MFMA sweep is launched in front of the ordinary cull. Same bits either way. */
+    GV_SWEEP_WITH_CULL = 2,
+    GV_SWEEP_WITH_CULL_VALU = 3 /* the same with the v_fma_f32 chain */
 } GvSweepMode;
 int gv_sweep(GvCtx* ctx, uint32_t mode);
 /* Reads back `count` world matrices (12 floats each, float4x3 order) starting at transform slot `first`. */

@@ -456,3 +456,59 @@ def test_device_side_result_accessors(gpu, oracle):
 
     d = gpu.results_device(0)
     assert d.visible_idx and d.baked_model and d.distance_sq and d.draw_count
+
+
+@pytest.mark.parametrize("fused_mode", [2, 3])  # GV_SWEEP_WITH_CULL (MFMA chain), GV_SWEEP_WITH_CULL_VALU
+@pytest.mark.parametrize("hier,hiz", [(True, False), (True, True), (False, False)])
+def test_sweep_with_cull_is_the_same_as_sweep_then_cull(gpu, oracle, hier, hiz, fused_mode):
+    """GV_SWEEP_WITH_CULL: one pass produces the world matrices and the cull outputs of an exactly paired pool;
+    bit-identical to gv_sweep(MFMA) + gv_cull and to the oracle. Unpaired pools and batched views fall back to the
+    two launches with the same results."""
+    from garden_amd.lib import GV_SWEEP_MFMA
+    GV_SWEEP_WITH_CULL = fused_mode
+    sc = scene.hierarchy_scene(70_001, depth=5, fanout=5) if hier else scene.flat_scene(70_001)
+    depth = scene.synthetic_depth(512, 256) if hiz else None
+    view = scene.main_camera_view(use_hiz=1 if hiz else 0)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    if hiz:
+        gpu.hiz_build(depth)
+    gpu.sweep(GV_SWEEP_MFMA)
+    world_ref = gpu.get_world(0, sc.count)
+    gpu.cull(0, [view])
+    ref = gpu.fetch(0, write_back=False, occupancy=sc.count)
+
+    gpu.mark_dirty(0, 0, sc.count)  # GV_DIRTY_TRANSFORM: invalidates the world cache
+    gpu.sweep(GV_SWEEP_WITH_CULL)
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=False, occupancy=sc.count)
+    world = gpu.get_world(0, sc.count)
+    assert np.array_equal(world.view(np.uint32), world_ref.view(np.uint32))
+    for k in ("visible_idx", "baked_model", "distance_sq", "is_visible"):
+        assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), k
+    exp_w = oracle.world_matrices(sc.transforms, sc.entity_to_transform)
+    assert np.array_equal(world.view(np.uint32), exp_w.view(np.uint32))
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, hiz=oracle.Hiz(depth) if hiz else None)
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"]) and np.array_equal(got["is_visible"], m2["isVisible"])
+
+    # fallbacks: two views sharing the camera (batched cull) and a shuffled (not exactly paired) pool
+    views = [view, scene.cascade_view(index=0)]
+    gpu.mark_dirty(0, 0, sc.count)
+    gpu.sweep(GV_SWEEP_WITH_CULL)
+    gpu.cull(0, views)
+    assert np.array_equal(gpu.get_world(0, sc.count).view(np.uint32), world_ref.view(np.uint32))
+    assert np.array_equal(gpu.fetch(0, write_back=False, occupancy=sc.count)["visible_idx"], ref["visible_idx"])
+    sh = scene.shuffled_scene(sc, fraction=1.0)
+    gpu.bind_transforms(sh.transforms, sh.entity_to_transform)
+    gpu.bind_pool(0, sh.meshes)
+    gpu.hierarchy_rebuild()
+    gpu.sweep(GV_SWEEP_WITH_CULL)
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=False, occupancy=sh.count)
+    m2 = sh.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sh.transforms, sh.entity_to_transform, view, hiz=oracle.Hiz(depth) if hiz else None)
+    assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got["is_visible"], m2["isVisible"])
+    assert np.array_equal(gpu.get_world(0, sh.count).view(np.uint32),
+                          oracle.world_matrices(sh.transforms, sh.entity_to_transform).view(np.uint32))
