@@ -79,6 +79,12 @@ public:
     uint64_t reparentVersion = 0;  // setParent on existing entities: only links of [reparentLo, reparentHi) changed
     uint32_t reparentLo = UINT32_MAX, reparentHi = 0;
     void clearReparentRange() noexcept { reparentLo = UINT32_MAX; reparentHi = 0; }
+    // setActive / setParent flip selfActive / ancestorsActive of a subtree: the slots they touched, so consumers can
+    // re-mirror [flagsLo, flagsHi) instead of the pool (flagsVersion bumps with them; transformVersion is left for
+    // writers that do not say what they changed)
+    uint64_t flagsVersion = 0;
+    uint32_t flagsLo = UINT32_MAX, flagsHi = 0;
+    void clearFlagsRange() noexcept { flagsLo = UINT32_MAX; flagsHi = 0; }
 
     View<TransformComponent> add(ID<Entity> entity) { hierarchyVersion++; return addTo(entity); }
     // transform.cpp:130-195: unlink from the old parent's childs[], append to the new one, recompute ancestorsActive
@@ -118,8 +124,7 @@ public:
         const uint32_t slot = (uint32_t)(*view - components.getData());
         reparentLo = std::min(reparentLo, slot);
         reparentHi = std::max(reparentHi, slot + 1);
-        reparentVersion++;
-        transformVersion++;  // ancestorsActive of the subtree may have flipped
+        reparentVersion++;  // ancestorsActive of the subtree may have flipped: propagateActive recorded the slots
     }
     // transform.cpp:75-127: flips selfActive and pushes ancestorsActive down the subtree
     void setActive(ID<Entity> entity, bool isActive)
@@ -128,10 +133,10 @@ public:
         if (!view || view->selfActive == isActive)
             return;
         view->selfActive = isActive;
+        touchFlags((uint32_t)(*view - components.getData()));
         if (view->ancestorsActive)
             for (uint32_t i = 0, n = view->childCount(); i < n; i++)
                 propagateActive(view->childs[i], isActive);
-        transformVersion++;
     }
     void markTransformsChanged() noexcept { transformVersion++; }
     // TransformComponent::destroy (transform.cpp:29-73): unlink from the parent's childs[] keeping their order,
@@ -173,6 +178,12 @@ public:
     }
 
 private:
+    void touchFlags(uint32_t slot) noexcept
+    {
+        flagsLo = std::min(flagsLo, slot);
+        flagsHi = std::max(flagsHi, slot + 1);
+        flagsVersion++;
+    }
     void propagateActive(ID<Entity> entity, bool ancestors)
     {
         std::vector<std::pair<ID<Entity>, bool>> stack{{entity, ancestors}};
@@ -183,6 +194,7 @@ private:
             if (!v)
                 continue;
             v->ancestorsActive = a;
+            touchFlags((uint32_t)(*v - components.getData()));
             const bool below = a && v->selfActive;
             for (uint32_t i = 0, n = v->childCount(); i < n; i++)
                 stack.push_back({v->childs[i], below});

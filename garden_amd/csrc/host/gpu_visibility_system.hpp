@@ -49,7 +49,7 @@ private:
     std::vector<std::vector<SortedMesh>> shadowTransMeshes;     // [pass]: the reference re-runs prepareMeshes per
     std::vector<uint32_t> shadowTransDrawIndex;                 // pass and draws at once; here every pass is kept
     f32x4x4 uiViewProj;                                          // calcUiProjView(), mesh.cpp:851-859
-    uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull, seenReparent = 0;
+    uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull, seenReparent = 0, seenFlags = 0;
     std::vector<uint64_t> seenMesh;
     bool useHiz = false;
 
@@ -269,10 +269,16 @@ private:
             if (seenTransform != transformSystem->transformVersion) {
                 check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0, pool.getOccupancy()), "gv_mark_dirty");
                 seenTransform = transformSystem->transformVersion;
+            } else if (seenFlags != transformSystem->flagsVersion && transformSystem->flagsLo < transformSystem->flagsHi) {
+                // setActive / re-parenting flipped the active flags of some subtrees: only that slot range moves
+                check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, transformSystem->flagsLo,
+                                    transformSystem->flagsHi - transformSystem->flagsLo), "gv_mark_dirty");
             }
         }
         seenReparent = transformSystem->reparentVersion;
+        seenFlags = transformSystem->flagsVersion;
         transformSystem->clearReparentRange();
+        transformSystem->clearFlagsRange();
 
         const auto& cc = graphicsSystem->getCommonConstants();
         const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);

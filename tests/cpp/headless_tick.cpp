@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -160,7 +160,7 @@ int main(int argc, char** argv)
 {
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
-    bool hier = false, mutate = false, mixed = false;
+    bool hier = false, mutate = false, mixed = false, toggle = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) mode = argv[++i];
@@ -170,6 +170,7 @@ int main(int argc, char** argv)
         else if (a == "--hier") hier = true;
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
+        else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
     }
     try {
         Manager manager;
@@ -286,6 +287,16 @@ int main(int argc, char** argv)
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };
         auto doMutate = [&]() {
+            if (toggle) {  // nothing but active-flag and parent-link changes: the systems' ranged update paths
+                for (uint32_t i = 5; i < entities; i += 53)
+                    transformSystem->setActive(ents[i], (i & 1) != 0);
+                for (uint32_t i = 0; i < entities; i += 97)
+                    transformSystem->setActive(ents[i], true);
+                if (hier)
+                    for (uint32_t i = entities / 2; i < entities; i += 31)
+                        transformSystem->setParent(ents[i], ents[i / 8]);
+                return;
+            }
             for (uint32_t i = 3; i < entities; i += 11) {
                 auto t = transformSystem->tryGetOf(ents[i]);
                 if (t) t->setPosition(rng.uniform(-0.5f * side, 0.5f * side), rng.uniform(-50, 50), rng.uniform(0, 0.5f * side));

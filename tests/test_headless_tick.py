@@ -61,6 +61,8 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "50000", "--hier"],
     ["--entities", "50000", "--hier", "--mutate"],
     ["--entities", "1000", "--mutate"],
+    ["--entities", "50000", "--hier", "--toggle"],
+    ["--entities", "20000", "--toggle"],
     ["--entities", "40000", "--mixed"],
     ["--entities", "40000", "--mixed", "--hier", "--mutate"],
 ])
