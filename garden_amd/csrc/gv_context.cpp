@@ -99,21 +99,35 @@ struct DirtyRange {
     }
 };
 
-struct TransformBinding {
-    const uint8_t* base = nullptr;
+// One field of a bound pool: element i lives at ptr + i * stride. An AoS pool binds every field with the component
+// stride and its offset folded into ptr; column (SoA) storage binds each field with its own array and element size.
+struct Column {
+    const uint8_t* ptr = nullptr;
     size_t stride = 0;
+    const uint8_t* at(size_t i) const { return ptr + i * stride; }
+    uint32_t u32(size_t i) const
+    {
+        uint32_t v;
+        memcpy(&v, ptr + i * stride, 4);
+        return v;
+    }
+    const float* f32(size_t i) const { return reinterpret_cast<const float*>(ptr + i * stride); }
+    uint8_t u8(size_t i) const { return ptr[i * stride]; }
+};
+
+struct TransformBinding {
+    Column entity, parent, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
     uint32_t occupancy = 0;
-    GvTransformLayout layout{};
     const uint32_t* entity_to_transform = nullptr;
     uint32_t entity_capacity = 0;
     bool bound = false;
 };
 
 struct PoolState {
-    uint8_t* base = nullptr;
-    size_t stride = 0;
+    Column entity, is_enabled, aabb_min, aabb_max;
+    uint8_t* is_visible = nullptr;  // write-back target (NULL: none), element i at is_visible + i * is_visible_stride
+    size_t is_visible_stride = 0;
     uint32_t occupancy = 0;
-    GvMeshLayout layout{};
     bool bound = false;
     bool need_full = false;
     uint32_t mapping = kMapGeneral;  // MeshMapping, chosen at full gather (kMapExact may only be demoted afterwards)
@@ -309,12 +323,6 @@ void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
         th.join();
 }
 
-inline uint32_t load_u32(const uint8_t* p)
-{
-    uint32_t v;
-    memcpy(&v, p, 4);
-    return v;
-}
 inline uint32_t entity_slot(const TransformBinding& xf, uint32_t entity)
 {
     if (entity == 0 || entity >= xf.entity_capacity)
@@ -383,7 +391,6 @@ void radix_order(const std::vector<uint32_t>& keys, std::vector<uint32_t>& order
 int build_transform_order(GvCtx* ctx)
 {
     const TransformBinding& xf = ctx->xf;
-    const GvTransformLayout& L = xf.layout;
     const uint32_t n = xf.occupancy;
     ctx->xperm.clear();
     ctx->xinv.clear();
@@ -405,8 +412,7 @@ int build_transform_order(GvCtx* ctx)
             path.push_back(cur);
             if (path.size() > n)
                 return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", s);
-            const uint8_t* t = xf.base + (size_t)cur * xf.stride;
-            const uint32_t ps = entity_slot(xf, load_u32(t + L.parent));
+            const uint32_t ps = entity_slot(xf, xf.parent.u32(cur));
             if (ps == kSlotNone)
                 break;
             cur = ps;
@@ -416,10 +422,9 @@ int build_transform_order(GvCtx* ctx)
     }
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t s = 0; s < n; s++) {
-        const uint8_t* t = xf.base + (size_t)s * xf.stride;
-        if (root[s] != s || !load_u32(t + L.entity))
+        if (root[s] != s || !xf.entity.u32(s))
             continue;
-        const float* pos = reinterpret_cast<const float*>(t + L.position);
+        const float* pos = xf.position.f32(s);
         for (int k = 0; k < 3; k++)
             if (std::isfinite(pos[k])) {
                 lo[k] = std::min(lo[k], pos[k]);
@@ -436,12 +441,11 @@ int build_transform_order(GvCtx* ctx)
     std::vector<uint32_t> code(n);
     parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
         for (uint32_t s = a; s < b; s++) {
-            const uint8_t* t = xf.base + (size_t)s * xf.stride;
-            if (!load_u32(t + L.entity)) {
+            if (!xf.entity.u32(s)) {
                 code[s] = 0x3FFFFFFFu;  // free slots last
                 continue;
             }
-            const float* pos = reinterpret_cast<const float*>(xf.base + (size_t)root[s] * xf.stride + L.position);
+            const float* pos = xf.position.f32(root[s]);
             uint32_t q[3];
             for (int k = 0; k < 3; k++) {
                 const float ext = hi[k] - lo[k];
@@ -474,8 +478,8 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
         std::atomic<bool> paired{true};
         parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
             for (uint32_t i = a; i < b && paired.load(std::memory_order_relaxed); i++) {
-                const uint32_t slot = entity_slot(ctx->xf, load_u32(p.base + (size_t)i * p.stride + p.layout.entity));
-                const bool free_xf = !load_u32(ctx->xf.base + (size_t)i * ctx->xf.stride + ctx->xf.layout.entity);
+                const uint32_t slot = entity_slot(ctx->xf, p.entity.u32(i));
+                const bool free_xf = !ctx->xf.entity.u32(i);
                 if (!(slot == i || (slot == kSlotNone && free_xf)))
                     paired.store(false, std::memory_order_relaxed);
             }
@@ -489,7 +493,7 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
     std::vector<uint32_t> key(n);
     parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
         for (uint32_t i = a; i < b; i++) {
-            const uint32_t slot = entity_slot(ctx->xf, load_u32(p.base + (size_t)i * p.stride + p.layout.entity));
+            const uint32_t slot = entity_slot(ctx->xf, p.entity.u32(i));
             key[i] = slot == kSlotNone ? 0x3FFFFFFFu : ctx->xinv[slot];  // < 2^28: fits the 30-bit sort key
         }
     });
@@ -506,44 +510,40 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
 void gather_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
 {
     const TransformBinding& xf = ctx->xf;
-    const GvTransformLayout& L = xf.layout;
     parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
         for (uint32_t s = a; s < b; s++) {
-            const uint8_t* t = xf.base + (size_t)s * xf.stride;
-            const float* pos = reinterpret_cast<const float*>(t + L.position);
-            const float* scl = reinterpret_cast<const float*>(t + L.scale);
-            const float* rot = reinterpret_cast<const float*>(t + L.rotation);
-            const uint32_t entity = load_u32(t + L.entity);
+            const float* pos = xf.position.f32(s);
+            const float* scl = xf.scale.f32(s);
+            const float* rot = xf.rotation.f32(s);
+            const uint32_t entity = xf.entity.u32(s);
             uint8_t flags = 0;
             if (entity)
                 flags |= kXfLive;
-            if (t[L.self_active] && t[L.ancestors_active])
+            if (xf.self_active.u8(s) && xf.ancestors_active.u8(s))
                 flags |= kXfActive;
-            if (t[L.model_with_ancestors])
+            if (xf.model_with_ancestors.u8(s))
                 flags |= kXfWithAncestors;
             const uint32_t j = xslot_to_mirror(ctx, s);
             ctx->h_xa.ptr[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
             ctx->h_xb.ptr[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
             ctx->h_xc.ptr[j] = make_float2(scl[1], scl[2]);
             ctx->h_xflags.ptr[j] = flags;
-            ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, load_u32(t + L.parent)));
+            ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, xf.parent.u32(s)));
         }
     });
 }
 
 void gather_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
 {
-    const GvMeshLayout& L = p.layout;
     const TransformBinding& xf = ctx->xf;
     std::atomic<bool> demoted{false};
     parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
         for (uint32_t i = a; i < b; i++) {
-            const uint8_t* m = p.base + (size_t)i * p.stride;
-            const float* mn = reinterpret_cast<const float*>(m + L.aabb_min);
-            const float* mx = reinterpret_cast<const float*>(m + L.aabb_max);
-            const uint32_t entity = load_u32(m + L.entity);
+            const float* mn = p.aabb_min.f32(i);
+            const float* mx = p.aabb_max.f32(i);
+            const uint32_t entity = p.entity.u32(i);
             const uint32_t slot = xslot_to_mirror(ctx, entity_slot(xf, entity));  // Manager::tryGet<TransformComponent>  mesh.cpp:149
-            const bool candidate = entity && m[L.is_enabled] && slot != kSlotNone;
+            const bool candidate = entity && p.is_enabled.u8(i) && slot != kSlotNone;
             const uint32_t j = p.inv.empty() ? i : p.inv[i];
             // A non-candidate entry (free slot, disabled, no transform) carries an empty box: the all(size <= 0)
             // filter (mesh.cpp:140-142) then rejects it without the kernel having to read link[] (kMapExact).
@@ -1085,11 +1085,46 @@ int gv_transform_bind(GvCtx* ctx, const void* base, size_t stride, uint32_t occu
     const uint32_t need = std::max({layout->position, layout->scale, layout->rotation}) + 16u;
     if (occupancy && stride < need)
         return ctx->fail(GV_E_ARG, "gv_transform_bind: stride %zu smaller than layout (%u)", stride, need);
+    GvTransformColumns c{};
+    const uint8_t* b = static_cast<const uint8_t*>(base);
+    auto col = [&](uint32_t offset) { return GvColumn{b ? b + offset : nullptr, (uint32_t)stride}; };
+    c.entity = col(layout->entity);
+    c.parent = col(layout->parent);
+    c.position = col(layout->position);
+    c.scale = col(layout->scale);
+    c.rotation = col(layout->rotation);
+    c.self_active = col(layout->self_active);
+    c.ancestors_active = col(layout->ancestors_active);
+    c.model_with_ancestors = col(layout->model_with_ancestors);
+    return gv_transform_bind_columns(ctx, &c, occupancy, entity_to_transform, entity_capacity);
+}
+
+int gv_transform_bind_columns(GvCtx* ctx, const GvTransformColumns* columns, uint32_t occupancy,
+                              const uint32_t* entity_to_transform, uint32_t entity_capacity)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!columns || (entity_capacity && !entity_to_transform))
+        return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: NULL argument");
+    if (occupancy >= kSlotNone)
+        return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: occupancy %u exceeds the 28-bit slot range", occupancy);
+    const GvColumn* all[8] = {&columns->entity, &columns->parent, &columns->position, &columns->scale, &columns->rotation,
+                              &columns->self_active, &columns->ancestors_active, &columns->model_with_ancestors};
+    const uint32_t width[8] = {4, 4, 12, 12, 16, 1, 1, 1};
+    for (int k = 0; k < 8; k++)
+        if (occupancy && (!all[k]->data || all[k]->stride < width[k]))
+            return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: column %d is NULL or its stride is below %u bytes", k, width[k]);
+    auto col = [](const GvColumn& g) { return Column{static_cast<const uint8_t*>(g.data), g.stride}; };
     const bool moved = !ctx->xf.bound || ctx->xf.occupancy != occupancy;
-    ctx->xf.base = static_cast<const uint8_t*>(base);
-    ctx->xf.stride = stride;
+    ctx->xf.entity = col(columns->entity);
+    ctx->xf.parent = col(columns->parent);
+    ctx->xf.position = col(columns->position);
+    ctx->xf.scale = col(columns->scale);
+    ctx->xf.rotation = col(columns->rotation);
+    ctx->xf.self_active = col(columns->self_active);
+    ctx->xf.ancestors_active = col(columns->ancestors_active);
+    ctx->xf.model_with_ancestors = col(columns->model_with_ancestors);
     ctx->xf.occupancy = occupancy;
-    ctx->xf.layout = *layout;
     ctx->xf.entity_to_transform = entity_to_transform;
     ctx->xf.entity_capacity = entity_capacity;
     ctx->xf.bound = true;
@@ -1110,12 +1145,43 @@ int gv_pool_bind(GvCtx* ctx, uint32_t pool_id, void* base, size_t stride, uint32
     const uint32_t need = std::max(layout->aabb_min, layout->aabb_max) + 12u;
     if (occupancy && stride < need)
         return ctx->fail(GV_E_ARG, "gv_pool_bind: stride %zu smaller than layout (%u)", stride, need);
+    GvMeshColumns c{};
+    uint8_t* b = static_cast<uint8_t*>(base);
+    auto col = [&](uint32_t offset) { return GvColumn{b ? b + offset : nullptr, (uint32_t)stride}; };
+    c.entity = col(layout->entity);
+    c.is_enabled = col(layout->is_enabled);
+    c.aabb_min = col(layout->aabb_min);
+    c.aabb_max = col(layout->aabb_max);
+    c.is_visible = b ? b + layout->is_visible : nullptr;
+    c.is_visible_stride = (uint32_t)stride;
+    return gv_pool_bind_columns(ctx, pool_id, &c, occupancy);
+}
+
+int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* columns, uint32_t occupancy)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !columns)
+        return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: bad argument (pool_id %u)", pool_id);
+    if (occupancy >= kSlotNone)
+        return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: occupancy %u exceeds the 28-bit slot range", occupancy);
+    const GvColumn* all[4] = {&columns->entity, &columns->is_enabled, &columns->aabb_min, &columns->aabb_max};
+    const uint32_t width[4] = {4, 1, 12, 12};
+    for (int k = 0; k < 4; k++)
+        if (occupancy && (!all[k]->data || all[k]->stride < width[k]))
+            return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: column %d is NULL or its stride is below %u bytes", k, width[k]);
+    if (columns->is_visible && columns->is_visible_stride == 0)
+        return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: is_visible_stride is 0");
+    auto col = [](const GvColumn& g) { return Column{static_cast<const uint8_t*>(g.data), g.stride}; };
     PoolState& p = ctx->pools[pool_id];
     const bool moved = !p.bound || p.occupancy != occupancy;
-    p.base = static_cast<uint8_t*>(base);
-    p.stride = stride;
+    p.entity = col(columns->entity);
+    p.is_enabled = col(columns->is_enabled);
+    p.aabb_min = col(columns->aabb_min);
+    p.aabb_max = col(columns->aabb_max);
+    p.is_visible = static_cast<uint8_t*>(columns->is_visible);
+    p.is_visible_stride = columns->is_visible_stride;
     p.occupancy = occupancy;
-    p.layout = *layout;
     p.bound = true;
     if (moved)
         p.need_full = true;
@@ -1343,10 +1409,11 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
             if (!p.bound || p.occupancy != vs.occupancy)
                 return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u rebound since gv_cull", vs.pool_id);
             const uint8_t* src = vs.h_is_visible.ptr;
-            parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
-                for (uint32_t i = a; i < b; i++)
-                    p.base[(size_t)i * p.stride + p.layout.is_visible] = src[i];
-            });
+            if (p.is_visible)
+                parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
+                    for (uint32_t i = a; i < b; i++)
+                        p.is_visible[(size_t)i * p.is_visible_stride] = src[i];
+                });
         }
     }
     return GV_OK;

@@ -61,6 +61,20 @@ class GvStats(C.Structure):
                 ("mesh_count", C.c_uint32 * GV_MAX_POOLS)]
 
 
+class GvColumn(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_uint32)]
+
+
+class GvTransformColumns(C.Structure):
+    _fields_ = [(n, GvColumn) for n in ("entity", "parent", "position", "scale", "rotation", "self_active",
+                                        "ancestors_active", "model_with_ancestors")]
+
+
+class GvMeshColumns(C.Structure):
+    _fields_ = [("entity", GvColumn), ("is_enabled", GvColumn), ("aabb_min", GvColumn), ("aabb_max", GvColumn),
+                ("is_visible", C.c_void_p), ("is_visible_stride", C.c_uint32)]
+
+
 class GvError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libgarden_vis error {code}: {text}")
@@ -70,6 +84,7 @@ class GvError(RuntimeError):
 # every symbol include/garden_vis.h declares; tests/test_abi.py checks the .so exports all of them
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
+    "gv_transform_bind_columns", "gv_pool_bind_columns",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
     "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
@@ -105,6 +120,8 @@ def load():
     lib.gv_last_error.restype = C.c_char_p
     lib.gv_transform_bind.argtypes = [P, P, sz, u32, C.POINTER(GvTransformLayout), P, u32]
     lib.gv_pool_bind.argtypes = [P, u32, P, sz, u32, C.POINTER(GvMeshLayout)]
+    lib.gv_transform_bind_columns.argtypes = [P, C.POINTER(GvTransformColumns), u32, P, u32]
+    lib.gv_pool_bind_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), u32]
     lib.gv_mark_dirty.argtypes = [P, u32, u32, u32]
     lib.gv_hierarchy_rebuild.argtypes = [P]
     lib.gv_sync.argtypes = [P]
@@ -195,6 +212,31 @@ class GpuVisibility:
         self._keep[("pool", pool_id)] = meshes
         self._check(self.lib.gv_pool_bind(self.ctx, pool_id, meshes.ctypes.data, meshes.dtype.itemsize,
                                           meshes.shape[0], C.byref(lay)))
+
+    @staticmethod
+    def _column(a):
+        """GvColumn of a numpy array whose rows are the elements (C-contiguous rows; any row stride)."""
+        assert a.ndim in (1, 2) and (a.ndim == 1 or a.strides[1] == a.itemsize)
+        return GvColumn(a.ctypes.data, a.strides[0])
+
+    def bind_transform_columns(self, columns, entity_to_transform):
+        """columns: dict of numpy arrays entity/parent (u32[n]), position/scale (f32[n,3+]), rotation (f32[n,4]),
+        self_active/ancestors_active/model_with_ancestors (u8[n]). The caller keeps them alive and unmoved."""
+        self._xf_columns, self._e2t = columns, np.ascontiguousarray(entity_to_transform, dtype=np.uint32)
+        c = GvTransformColumns(*[self._column(columns[n]) for n, _ in GvTransformColumns._fields_])
+        self._check(self.lib.gv_transform_bind_columns(self.ctx, C.byref(c), columns["entity"].shape[0],
+                                                       self._e2t.ctypes.data, self._e2t.shape[0]))
+
+    def bind_pool_columns(self, pool_id, columns):
+        """columns: dict of numpy arrays entity (u32[n]), is_enabled (u8[n]), aabb_min/aabb_max (f32[n,3+]) and
+        optionally is_visible (u8[n], written by fetch(write_back=True))."""
+        self._pool_columns = getattr(self, "_pool_columns", {})
+        self._pool_columns[pool_id] = columns
+        vis = columns.get("is_visible")
+        c = GvMeshColumns(self._column(columns["entity"]), self._column(columns["is_enabled"]),
+                          self._column(columns["aabb_min"]), self._column(columns["aabb_max"]),
+                          vis.ctypes.data if vis is not None else None, vis.strides[0] if vis is not None else 0)
+        self._check(self.lib.gv_pool_bind_columns(self.ctx, pool_id, C.byref(c), columns["entity"].shape[0]))
 
     def mark_dirty(self, kind, first, count, pool_id=0):
         if kind == GV_DIRTY_MESH:

@@ -98,6 +98,27 @@ int gv_transform_bind(GvCtx* ctx, const void* base, size_t stride, uint32_t occu
 int gv_pool_bind(GvCtx* ctx, uint32_t pool_id, void* base, size_t stride, uint32_t occupancy,
                  const GvMeshLayout* layout);
 
+/* Column (SoA) form of the two binds, for engines and loaders whose components are not an array of structs: every
+ * field is its own array, element i at data + i * stride (stride >= the field's width; an AoS pool is the special case
+ * data = base + offsetof(field), stride = sizeof(component), which is what gv_transform_bind / gv_pool_bind pass).
+ * Same lifetime and dirty-range rules as the AoS binds. position/scale: 3 floats, rotation: 4 floats (xyzw),
+ * aabb_min/aabb_max: 3 floats, flags: 1 byte, entity/parent: uint32 entity ids. */
+typedef struct GvColumn {
+    const void* data;
+    uint32_t stride; /* bytes between consecutive elements */
+} GvColumn;
+typedef struct GvTransformColumns {
+    GvColumn entity, parent, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
+} GvTransformColumns;
+typedef struct GvMeshColumns {
+    GvColumn entity, is_enabled, aabb_min, aabb_max;
+    void* is_visible;           /* write-back target of gv_results_fetch (may be NULL) */
+    uint32_t is_visible_stride; /* bytes between consecutive isVisible bytes */
+} GvMeshColumns;
+int gv_transform_bind_columns(GvCtx* ctx, const GvTransformColumns* columns, uint32_t occupancy,
+                              const uint32_t* entity_to_transform, uint32_t entity_capacity);
+int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* columns, uint32_t occupancy);
+
 typedef enum GvDirtyKind {
     GV_DIRTY_TRANSFORM = 0, /* TRS / active flags of transform slots [first, first+count) changed
                                (setPosition/Scale/Rotation transform.hpp:74-104, setActive transform.cpp:75-127) */

@@ -512,3 +512,49 @@ def test_sweep_with_cull_is_the_same_as_sweep_then_cull(gpu, oracle, hier, hiz, 
     assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got["is_visible"], m2["isVisible"])
     assert np.array_equal(gpu.get_world(0, sh.count).view(np.uint32),
                           oracle.world_matrices(sh.transforms, sh.entity_to_transform).view(np.uint32))
+
+
+def soa_columns(sc):
+    """The scene's pools as separately allocated column arrays (what an SoA engine or the scene loader holds)."""
+    t, m = sc.transforms, sc.meshes
+    xf = dict(entity=t["entity"].copy(), parent=t["parent"].copy(), position=np.ascontiguousarray(t["position"][:, :3]),
+              scale=np.ascontiguousarray(t["scale"][:, :3]), rotation=t["rotation"].copy(),
+              self_active=t["selfActive"].copy(), ancestors_active=t["ancestorsActive"].copy(),
+              model_with_ancestors=t["modelWithAncestors"].copy())
+    mesh = dict(entity=m["entity"].copy(), is_enabled=m["isEnabled"].copy(),
+                aabb_min=np.ascontiguousarray(m["aabbMin"][:, :3]), aabb_max=np.ascontiguousarray(m["aabbMax"][:, :3]),
+                is_visible=np.full(m.shape[0], 7, np.uint8))
+    return xf, mesh
+
+
+@pytest.mark.parametrize("hier", [False, True])
+def test_column_binds_give_the_same_results_as_aos_binds(gpu, oracle, hier):
+    """gv_transform_bind_columns / gv_pool_bind_columns: tightly packed SoA columns (12-byte positions, 1-byte flags)
+    instead of the 80/48-byte components; incl. a ranged dirty update and the isVisible write-back column."""
+    sc = scene.hierarchy_scene(30_011, depth=4, fanout=6) if hier else scene.flat_scene(30_011)
+    view = scene.main_camera_view()
+    xf, mesh = soa_columns(sc)
+    gpu.bind_transform_columns(xf, sc.entity_to_transform)
+    gpu.bind_pool_columns(0, mesh)
+    gpu.hierarchy_rebuild()
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=True, occupancy=sc.count)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+    assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+    assert np.array_equal(mesh["is_visible"], m2["isVisible"])  # written through the column
+
+    # move a slice of entities and toggle some flags: only that range is re-mirrored
+    lo, hi = 5_000, 9_000
+    xf["position"][lo:hi] += np.float32(3.5)
+    xf["self_active"][lo:hi:7] ^= 1
+    sc.transforms["position"][lo:hi, :3] = xf["position"][lo:hi]
+    sc.transforms["selfActive"][lo:hi] = xf["self_active"][lo:hi]
+    if not hier:  # (with a hierarchy the host would also have to push ancestorsActive down; flat pools have no children)
+        gpu.mark_dirty(0, lo, hi - lo)
+        gpu.cull(0, [view])
+        got = gpu.fetch(0, write_back=True, occupancy=sc.count)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], exp["visible_idx"]) and np.array_equal(mesh["is_visible"], m2["isVisible"])
