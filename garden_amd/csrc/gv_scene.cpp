@@ -1,0 +1,714 @@
+// gv_scene.cpp — scene ingest: a Garden scene file goes straight into column (SoA) pools that the
+// visibility pass binds with gv_*_bind_columns; the 80-byte TransformComponent / 48+-byte MeshRenderComponent AoS is
+// never materialised (10^8 entities: 4.5 GB of columns instead of 13 GB of components).
+//
+// Restates, for the fields the path reads, what the reference does when it loads a scene:
+//   ResourceSystem::loadScene                 source/system/resource.cpp:2421-2510   entities[] -> components[] -> ".type"
+//   TransformSystem::deserialize              source/system/transform.cpp:517-560    uid / position / rotation / scale /
+//                                                                                    isActive / parent
+//   TransformSystem::postDeserialize          source/system/transform.cpp:561-583    parent uids -> setParent, in file order
+//   TransformComponent::setParent             source/system/transform.cpp:129-195    ancestorsActive taken from the parent
+//                                                                                    AT THAT MOMENT, for this entity only
+//   <Mesh>RenderSystem::deserialize           e.g. source/system/render/sprite.cpp:206-207   "aabb", "isEnabled"
+//   JsonDeserializer::read(f32x4, n) / quat / Aabb / bool / string   source/json-serialize.cpp:873-898,768-781,851-863
+// Numbers follow nlohmann's typing as the reference sees it: only literals with a fraction or an exponent are
+// "number_float" and accepted for float fields (an integer literal leaves the default in place); text -> double
+// (strtod) -> float.
+//
+// Host code only (no HIP): GvScene can be parsed, inspected and destroyed without a device; gv_scene_bind needs a context.
+#include <cerrno>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/garden_vis.h"
+
+namespace {
+
+struct MeshColumnsOwned {
+    std::vector<uint32_t> entity;
+    std::vector<uint8_t> is_enabled, is_visible;
+    std::vector<float> aabb_min, aabb_max;  // 3 per mesh
+    std::string type;
+    bool mapped = false;
+};
+
+}  // namespace
+
+struct GvScene {
+    // transform columns, slot = order of appearance
+    std::vector<uint32_t> entity, parent;
+    std::vector<uint64_t> uid;
+    std::vector<float> position, scale, rotation;  // 3, 3, 4 per transform
+    std::vector<uint8_t> self_active, ancestors_active, model_with_ancestors;
+    std::vector<uint32_t> entity_to_transform;  // [entity id] -> slot or GV_NONE
+    MeshColumnsOwned pools[GV_MAX_POOLS];
+    GvSceneInfo info{};
+};
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct Parser {
+    const char* p;
+    const char* end;
+    std::string error;
+
+    bool fail(const char* fmt, ...)
+    {
+        if (error.empty()) {
+            char buf[256];
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(buf, sizeof(buf), fmt, ap);
+            va_end(ap);
+            error = buf;
+        }
+        return false;
+    }
+    void ws()
+    {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r'))
+            p++;
+    }
+    bool eat(char c)
+    {
+        ws();
+        if (p < end && *p == c) {
+            p++;
+            return true;
+        }
+        return false;
+    }
+    char peek()
+    {
+        ws();
+        return p < end ? *p : '\0';
+    }
+    bool string(std::string* out)
+    {
+        ws();
+        if (p >= end || *p != '"')
+            return fail("expected a string at byte %zu", offset());
+        p++;
+        if (out)
+            out->clear();
+        while (p < end && *p != '"') {
+            char c = *p++;
+            if (c == '\\') {
+                if (p >= end)
+                    break;
+                const char e = *p++;
+                switch (e) {
+                case 'b': c = '\b'; break;
+                case 'f': c = '\f'; break;
+                case 'n': c = '\n'; break;
+                case 'r': c = '\r'; break;
+                case 't': c = '\t'; break;
+                case 'u': {
+                    if (end - p < 4)
+                        return fail("truncated \\u escape");
+                    unsigned cp = 0;
+                    for (int k = 0; k < 4; k++) {
+                        const char h = *p++;
+                        cp = cp * 16 + (unsigned)(h >= '0' && h <= '9' ? h - '0' : (h | 32) >= 'a' && (h | 32) <= 'f' ? (h | 32) - 'a' + 10 : 0);
+                    }
+                    if (out) {  // UTF-8 (surrogate pairs are not combined: names this loader reads are ASCII)
+                        if (cp < 0x80) {
+                            out->push_back((char)cp);
+                        } else if (cp < 0x800) {
+                            out->push_back((char)(0xC0 | (cp >> 6)));
+                            out->push_back((char)(0x80 | (cp & 0x3F)));
+                        } else {
+                            out->push_back((char)(0xE0 | (cp >> 12)));
+                            out->push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+                            out->push_back((char)(0x80 | (cp & 0x3F)));
+                        }
+                    }
+                    continue;
+                }
+                default: c = e; break;  // \" \\ \/
+                }
+            }
+            if (out)
+                out->push_back(c);
+        }
+        if (p >= end)
+            return fail("unterminated string");
+        p++;
+        return true;
+    }
+    // JSON number; is_float = the literal has a fraction or an exponent (nlohmann's number_float)
+    bool number(double* value, bool* is_float)
+    {
+        ws();
+        const char* s = p;
+        if (p < end && (*p == '-' || *p == '+'))
+            p++;
+        bool digits = false, flt = false;
+        while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '-' || *p == '+')) {
+            if (*p >= '0' && *p <= '9')
+                digits = true;
+            if (*p == '.' || *p == 'e' || *p == 'E')
+                flt = true;
+            p++;
+        }
+        if (!digits)
+            return fail("expected a value at byte %zu", (size_t)(s - begin));
+        if (value) {  // correctly rounded text -> double, as strtod / nlohmann's lexer give it
+            const char* first = *s == '+' ? s + 1 : s;
+            const auto res = std::from_chars(first, p, *value);
+            if (res.ec == std::errc::result_out_of_range)
+                *value = (*first == '-') ? -HUGE_VAL : HUGE_VAL;
+            else if (res.ec != std::errc() || res.ptr != p)
+                return fail("malformed number at byte %zu", (size_t)(s - begin));
+        }
+        if (is_float)
+            *is_float = flt;
+        return true;
+    }
+    bool literal(const char* word)
+    {
+        const size_t n = strlen(word);
+        if ((size_t)(end - p) >= n && memcmp(p, word, n) == 0) {
+            p += n;
+            return true;
+        }
+        return fail("unexpected token at byte %zu", offset());
+    }
+    bool skip_value()
+    {
+        const char c = peek();
+        if (c == '{') {
+            p++;
+            if (eat('}'))
+                return true;
+            do {
+                if (!string(nullptr) || !eat(':'))
+                    return fail("malformed object at byte %zu", offset());
+                if (!skip_value())
+                    return false;
+            } while (eat(','));
+            return eat('}') || fail("expected '}' at byte %zu", offset());
+        }
+        if (c == '[') {
+            p++;
+            if (eat(']'))
+                return true;
+            do {
+                if (!skip_value())
+                    return false;
+            } while (eat(','));
+            return eat(']') || fail("expected ']' at byte %zu", offset());
+        }
+        if (c == '"')
+            return string(nullptr);
+        if (c == 't')
+            return literal("true");
+        if (c == 'f')
+            return literal("false");
+        if (c == 'n')
+            return literal("null");
+        return number(nullptr, nullptr);
+    }
+    const char* begin = nullptr;
+    size_t offset() const { return (size_t)(p - begin); }
+};
+
+// JsonDeserializer::read(name, f32x4&, components) (json-serialize.cpp:873-898): a float literal splats, an object
+// sets the components it has as float literals; anything else leaves `v` alone.
+bool read_vector(Parser& ps, float* v, int components)
+{
+    const char c = ps.peek();
+    if (c == '{') {
+        ps.p++;
+        if (ps.eat('}'))
+            return true;
+        std::string key;
+        do {
+            if (!ps.string(&key) || !ps.eat(':'))
+                return ps.fail("malformed vector object at byte %zu", ps.offset());
+            int k = -1;
+            if (key.size() == 1)
+                k = key[0] == 'x' ? 0 : key[0] == 'y' ? 1 : key[0] == 'z' ? 2 : key[0] == 'w' ? 3 : -1;
+            const char v0 = ps.peek();
+            if (k >= 0 && k < components && (v0 == '-' || (v0 >= '0' && v0 <= '9'))) {
+                double d;
+                bool flt;
+                if (!ps.number(&d, &flt))
+                    return false;
+                if (flt)
+                    v[k] = (float)d;
+            } else if (!ps.skip_value()) {
+                return false;
+            }
+        } while (ps.eat(','));
+        return ps.eat('}') || ps.fail("expected '}' at byte %zu", ps.offset());
+    }
+    if (c == '-' || (c >= '0' && c <= '9')) {
+        double d;
+        bool flt;
+        if (!ps.number(&d, &flt))
+            return false;
+        if (flt)
+            for (int k = 0; k < components; k++)
+                v[k] = (float)d;
+        return true;
+    }
+    return ps.skip_value();
+}
+
+// modp_b64 URL alphabet (A-Z a-z 0-9 - _), 11 characters = 8 bytes with the padding character cut off
+// (transform.cpp:473-475,520-523): the stored uint64, little-endian.
+bool decode_uid(const std::string& s, uint64_t* uid)
+{
+    if (s.size() != 11)
+        return false;  // transform.cpp:520: size + 1 == modp_b64_encode_data_len(8)
+    uint8_t bytes[9] = {};
+    uint32_t acc = 0;
+    int bits = 0, n = 0;
+    for (char ch : s) {
+        int v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+        else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+        else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '-') v = 62;
+        else if (ch == '_') v = 63;
+        else return false;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            if (n < 8)
+                bytes[n++] = (uint8_t)(acc >> bits);
+        }
+    }
+    if (n != 8)
+        return false;
+    memcpy(uid, bytes, 8);
+    return true;
+}
+
+struct PendingParent {
+    uint32_t slot;
+    uint64_t parent_uid;
+};
+
+struct Loader {
+    Parser ps;
+    GvScene* sc;
+    std::unordered_map<std::string, uint32_t> pool_of_type;
+    std::unordered_map<uint64_t, uint32_t> entity_of_uid;  // deserializedEntities (transform.cpp:525)
+    std::vector<PendingParent> parents;                    // deserializedParents  (transform.cpp:553)
+
+    // finds ".type" in the component object that starts at ps.p (which is left unchanged)
+    bool component_type(std::string* type)
+    {
+        const char* start = ps.p;
+        type->clear();
+        bool found = false, first_key = true;
+        if (!ps.eat('{'))
+            return ps.fail("component is not an object at byte %zu", ps.offset());
+        if (!ps.eat('}')) {
+            std::string key;
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed component at byte %zu", ps.offset());
+                if (key == ".type" && ps.peek() == '"') {
+                    if (!ps.string(type))
+                        return false;
+                    found = true;
+                    if (first_key) {  // the reference's writer sorts keys: ".type" leads and nothing else needs scanning
+                        ps.p = start;
+                        return true;
+                    }
+                } else if (!ps.skip_value()) {
+                    return false;
+                }
+                first_key = false;
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        ps.p = start;
+        if (!found)
+            type->clear();
+        return true;
+    }
+
+    bool transform(uint32_t entity)  // TransformSystem::deserialize, transform.cpp:517-560
+    {
+        const uint32_t slot = (uint32_t)sc->entity.size();
+        float pos[3] = {0, 0, 0}, scl[3] = {1, 1, 1}, rot[4] = {0, 0, 0, 1};
+        bool self_active = true, have_uid = false, have_parent = false;
+        uint64_t uid = 0, parent_uid = 0;
+        std::string key, text;
+        ps.eat('{');
+        if (!ps.eat('}')) {
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed Transform at byte %zu", ps.offset());
+                const char c = ps.peek();
+                if (key == "uid" && c == '"') {
+                    if (!ps.string(&text))
+                        return false;
+                    have_uid = decode_uid(text, &uid);
+                } else if (key == "parent" && c == '"') {
+                    if (!ps.string(&text))
+                        return false;
+                    have_parent = decode_uid(text, &parent_uid);
+                } else if (key == "position") {
+                    if (!read_vector(ps, pos, 3))
+                        return false;
+                } else if (key == "scale") {
+                    if (!read_vector(ps, scl, 3))
+                        return false;
+                } else if (key == "rotation" && c == '{') {  // quat: objects only (json-serialize.cpp:772)
+                    if (!read_vector(ps, rot, 4))
+                        return false;
+                } else if (key == "isActive" && (c == 't' || c == 'f')) {
+                    self_active = c == 't';
+                    if (!ps.literal(c == 't' ? "true" : "false"))
+                        return false;
+                } else if (!ps.skip_value()) {
+                    return false;
+                }
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        sc->entity.push_back(entity);
+        sc->parent.push_back(0);
+        sc->uid.push_back(have_uid ? uid : 0);
+        sc->position.insert(sc->position.end(), pos, pos + 3);
+        sc->scale.insert(sc->scale.end(), scl, scl + 3);
+        sc->rotation.insert(sc->rotation.end(), rot, rot + 4);
+        sc->self_active.push_back(self_active ? 1 : 0);
+        sc->ancestors_active.push_back(1);
+        sc->model_with_ancestors.push_back(1);
+        if (sc->entity_to_transform.size() <= entity)
+            sc->entity_to_transform.resize((size_t)entity + 1, kNone);
+        sc->entity_to_transform[entity] = slot;
+        if (have_uid && !entity_of_uid.emplace(uid, entity).second)
+            sc->info.duplicate_uids++;  // "Deserialized entity with already existing UID": the first one keeps it
+        if (have_parent) {
+            if (have_uid && parent_uid == uid)
+                sc->info.self_parents++;  // "Deserialized entity with the same parent UID": no link
+            else
+                parents.push_back({slot, parent_uid});
+        }
+        return true;
+    }
+
+    bool aabb(float* mn, float* mx)  // JsonDeserializer::read(name, Aabb&), json-serialize.cpp:851-863
+    {
+        // both start from the component's current min — the reference's quirk (line 856) — and only a valid pair is taken
+        float lo[3] = {mn[0], mn[1], mn[2]}, hi[3] = {mn[0], mn[1], mn[2]};
+        if (ps.peek() != '{')
+            return ps.skip_value();
+        ps.p++;
+        std::string key;
+        if (!ps.eat('}')) {
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed aabb at byte %zu", ps.offset());
+                if (key == "min") {
+                    if (!read_vector(ps, lo, 3))
+                        return false;
+                } else if (key == "max") {
+                    if (!read_vector(ps, hi, 3))
+                        return false;
+                } else if (!ps.skip_value()) {
+                    return false;
+                }
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        // Aabb::trySet (cfnptr/math, absent): build-defined as "min <= max on every axis, else unchanged"
+        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+            memcpy(mn, lo, 12);
+            memcpy(mx, hi, 12);
+        }
+        return true;
+    }
+
+    bool mesh(uint32_t entity, MeshColumnsOwned& pool)  // e.g. SpriteRenderSystem::deserialize, sprite.cpp:206-207
+    {
+        float mn[3] = {-0.5f, -0.5f, -0.5f}, mx[3] = {0.5f, 0.5f, 0.5f};  // Aabb::one (mesh.hpp:54)
+        bool enabled = true;
+        std::string key;
+        ps.eat('{');
+        if (!ps.eat('}')) {
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed mesh component at byte %zu", ps.offset());
+                const char c = ps.peek();
+                if (key == "aabb") {
+                    if (!aabb(mn, mx))
+                        return false;
+                } else if (key == "isEnabled" && (c == 't' || c == 'f')) {
+                    enabled = c == 't';
+                    if (!ps.literal(c == 't' ? "true" : "false"))
+                        return false;
+                } else if (!ps.skip_value()) {
+                    return false;
+                }
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        pool.entity.push_back(entity);
+        pool.is_enabled.push_back(enabled ? 1 : 0);
+        pool.is_visible.push_back(0);
+        pool.aabb_min.insert(pool.aabb_min.end(), mn, mn + 3);
+        pool.aabb_max.insert(pool.aabb_max.end(), mx, mx + 3);
+        return true;
+    }
+
+    bool entity_object(uint32_t* next_entity)  // resource.cpp:2428-2506
+    {
+        if (!ps.eat('{'))
+            return ps.fail("entity is not an object at byte %zu", ps.offset());
+        bool had_components = false;
+        if (!ps.eat('}')) {
+            std::string key, type;
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed entity at byte %zu", ps.offset());
+                if (key != "components" || ps.peek() != '[' || had_components) {
+                    if (!ps.skip_value())
+                        return false;
+                    continue;
+                }
+                had_components = true;
+                ps.p++;
+                if (ps.eat(']')) {
+                    sc->info.skipped_entities++;  // "Missing scene entity components": no entity is created
+                    continue;
+                }
+                const uint32_t entity = (*next_entity)++;  // manager->createEntity()
+                sc->info.entity_count++;
+                uint32_t seen_pools = 0;
+                bool seen_transform = false;
+                do {
+                    if (!component_type(&type))
+                        return false;
+                    if (type == "Transform") {
+                        if (seen_transform)
+                            return ps.fail("entity %u has two Transform components", entity);
+                        seen_transform = true;
+                        if (!transform(entity))
+                            return false;
+                        continue;
+                    }
+                    auto it = pool_of_type.find(type);
+                    if (it != pool_of_type.end()) {
+                        if (seen_pools & (1u << it->second))
+                            return ps.fail("entity %u has two %s components", entity, type.c_str());
+                        seen_pools |= 1u << it->second;
+                        if (!mesh(entity, sc->pools[it->second]))
+                            return false;
+                        continue;
+                    }
+                    sc->info.other_components++;  // a component this pass does not read
+                    if (!ps.skip_value())
+                        return false;
+                } while (ps.eat(','));
+                if (!ps.eat(']'))
+                    return ps.fail("expected ']' at byte %zu", ps.offset());
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        return true;
+    }
+
+    bool run()
+    {
+        if (!ps.eat('{'))
+            return ps.fail("scene is not a JSON object");
+        uint32_t next_entity = 1;
+        if (!ps.eat('}')) {
+            std::string key;
+            do {
+                if (!ps.string(&key) || !ps.eat(':'))
+                    return ps.fail("malformed scene at byte %zu", ps.offset());
+                if (key == "entities" && ps.peek() == '[') {
+                    ps.p++;
+                    if (!ps.eat(']')) {
+                        do {
+                            if (!entity_object(&next_entity))
+                                return false;
+                        } while (ps.eat(','));
+                        if (!ps.eat(']'))
+                            return ps.fail("expected ']' at byte %zu", ps.offset());
+                    }
+                } else if (!ps.skip_value()) {
+                    return false;
+                }
+            } while (ps.eat(','));
+            if (!ps.eat('}'))
+                return ps.fail("expected '}' at byte %zu", ps.offset());
+        }
+        ps.ws();
+        if (ps.p != ps.end)
+            return ps.fail("trailing bytes after the scene object at byte %zu", ps.offset());
+        if (sc->entity_to_transform.size() < next_entity)
+            sc->entity_to_transform.resize(next_entity, kNone);
+        // postDeserialize (transform.cpp:561-583): links in file order; setParent (transform.cpp:129-195) takes
+        // ancestorsActive from the parent's flags as they are at that moment and does not touch descendants
+        for (const PendingParent& pp : parents) {
+            auto it = entity_of_uid.find(pp.parent_uid);
+            if (it == entity_of_uid.end()) {
+                sc->info.unresolved_parents++;  // "Deserialized entity parent does not exist"
+                continue;
+            }
+            const uint32_t parent_entity = it->second;
+            const uint32_t ps_slot = sc->entity_to_transform[parent_entity];
+            if (parent_entity == sc->entity[pp.slot])
+                continue;  // GARDEN_ASSERT(parent != entity): a duplicate uid can point an entity at itself
+            sc->parent[pp.slot] = parent_entity;
+            sc->ancestors_active[pp.slot] = (sc->self_active[ps_slot] && sc->ancestors_active[ps_slot]) ? 1 : 0;
+        }
+        sc->info.transform_count = (uint32_t)sc->entity.size();
+        for (uint32_t k = 0; k < GV_MAX_POOLS; k++)
+            sc->info.mesh_count[k] = (uint32_t)sc->pools[k].entity.size();
+        return true;
+    }
+};
+
+void set_error(char* error, size_t capacity, const std::string& text)
+{
+    if (error && capacity) {
+        snprintf(error, capacity, "%s", text.c_str());
+    }
+}
+
+GvColumn column(const void* data, uint32_t stride) { return GvColumn{data, stride}; }
+
+}  // namespace
+
+extern "C" {
+
+int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count,
+                        GvScene** out_scene, char* error, size_t error_capacity)
+{
+    if (!text || !out_scene || (pool_count && !pools)) {
+        set_error(error, error_capacity, "gv_scene_parse_json: NULL argument");
+        return GV_E_ARG;
+    }
+    *out_scene = nullptr;
+    GvScene* sc = new GvScene();
+    Loader ld;
+    ld.sc = sc;
+    ld.ps.p = ld.ps.begin = text;
+    ld.ps.end = text + length;
+    for (uint32_t k = 0; k < pool_count; k++) {
+        if (!pools[k].component_type || pools[k].pool_id >= GV_MAX_POOLS || sc->pools[pools[k].pool_id].mapped ||
+            strcmp(pools[k].component_type, "Transform") == 0) {
+            set_error(error, error_capacity, "gv_scene_parse_json: bad pool mapping");
+            delete sc;
+            return GV_E_ARG;
+        }
+        sc->pools[pools[k].pool_id].mapped = true;
+        sc->pools[pools[k].pool_id].type = pools[k].component_type;
+        ld.pool_of_type[pools[k].component_type] = pools[k].pool_id;
+    }
+    if (!ld.run()) {
+        set_error(error, error_capacity, ld.ps.error);
+        delete sc;
+        return GV_E_ARG;
+    }
+    *out_scene = sc;
+    return GV_OK;
+}
+
+void gv_scene_destroy(GvScene* scene) { delete scene; }
+
+int gv_scene_info(const GvScene* scene, GvSceneInfo* out)
+{
+    if (!scene || !out)
+        return GV_E_ARG;
+    *out = scene->info;
+    return GV_OK;
+}
+
+int gv_scene_transform_columns(const GvScene* scene, GvTransformColumns* columns, uint32_t* occupancy,
+                               const uint32_t** entity_to_transform, uint32_t* entity_capacity, const uint64_t** uids)
+{
+    if (!scene || !columns)
+        return GV_E_ARG;
+    columns->entity = column(scene->entity.data(), 4);
+    columns->parent = column(scene->parent.data(), 4);
+    columns->position = column(scene->position.data(), 12);
+    columns->scale = column(scene->scale.data(), 12);
+    columns->rotation = column(scene->rotation.data(), 16);
+    columns->self_active = column(scene->self_active.data(), 1);
+    columns->ancestors_active = column(scene->ancestors_active.data(), 1);
+    columns->model_with_ancestors = column(scene->model_with_ancestors.data(), 1);
+    if (occupancy)
+        *occupancy = (uint32_t)scene->entity.size();
+    if (entity_to_transform)
+        *entity_to_transform = scene->entity_to_transform.data();
+    if (entity_capacity)
+        *entity_capacity = (uint32_t)scene->entity_to_transform.size();
+    if (uids)
+        *uids = scene->uid.data();
+    return GV_OK;
+}
+
+int gv_scene_mesh_columns(GvScene* scene, uint32_t pool_id, GvMeshColumns* columns, uint32_t* occupancy)
+{
+    if (!scene || !columns || pool_id >= GV_MAX_POOLS)
+        return GV_E_ARG;
+    MeshColumnsOwned& p = scene->pools[pool_id];
+    columns->entity = column(p.entity.data(), 4);
+    columns->is_enabled = column(p.is_enabled.data(), 1);
+    columns->aabb_min = column(p.aabb_min.data(), 12);
+    columns->aabb_max = column(p.aabb_max.data(), 12);
+    columns->is_visible = p.is_visible.data();
+    columns->is_visible_stride = 1;
+    if (occupancy)
+        *occupancy = (uint32_t)p.entity.size();
+    return GV_OK;
+}
+
+int gv_scene_bind(GvCtx* ctx, GvScene* scene)
+{
+    if (!ctx || !scene)
+        return GV_E_ARG;
+    GvTransformColumns tc;
+    uint32_t n = 0, cap = 0;
+    const uint32_t* e2t = nullptr;
+    gv_scene_transform_columns(scene, &tc, &n, &e2t, &cap, nullptr);
+    int rc = gv_transform_bind_columns(ctx, &tc, n, e2t, cap);
+    if (rc != GV_OK)
+        return rc;
+    rc = gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, 0, 0);  // a new scene: full mirror build
+    if (rc != GV_OK)
+        return rc;
+    for (uint32_t k = 0; k < GV_MAX_POOLS; k++) {
+        if (!scene->pools[k].mapped)
+            continue;
+        GvMeshColumns mc;
+        uint32_t count = 0;
+        gv_scene_mesh_columns(scene, k, &mc, &count);
+        rc = gv_pool_bind_columns(ctx, k, &mc, count);
+        if (rc != GV_OK)
+            return rc;
+        rc = gv_mark_dirty(ctx, GV_DIRTY_MESH, k << 28, count);
+        if (rc != GV_OK)
+            return rc;
+    }
+    return GV_OK;
+}
+
+}  // extern "C"

@@ -87,7 +87,8 @@ public:
     void clearFlagsRange() noexcept { flagsLo = UINT32_MAX; flagsHi = 0; }
 
     View<TransformComponent> add(ID<Entity> entity) { hierarchyVersion++; return addTo(entity); }
-    // transform.cpp:130-195: unlink from the old parent's childs[], append to the new one, recompute ancestorsActive
+    // transform.cpp:129-195: unlink from the old parent's childs[] (order kept), append to the new one, take
+    // ancestorsActive from the new parent — for this entity only: the reference does not push it down the subtree
     void setParent(ID<Entity> entity, ID<Entity> newParent)
     {
         auto view = tryGetOf(entity);
@@ -101,7 +102,8 @@ public:
             uint32_t n = old->childCount();
             for (uint32_t i = 0; i < n; i++)
                 if (old->childs[i] == entity) {
-                    old->childs[i] = old->childs[n - 1];
+                    for (uint32_t j = i + 1; j < n; j++)
+                        old->childs[j - 1] = old->childs[j];
                     old->setChildCount(n - 1);
                     break;
                 }
@@ -120,11 +122,12 @@ public:
             np->setChildCount(n + 1);
             active = np->isActive();
         }
-        propagateActive(entity, active);
+        view->ancestorsActive = active;
         const uint32_t slot = (uint32_t)(*view - components.getData());
+        touchFlags(slot);
         reparentLo = std::min(reparentLo, slot);
         reparentHi = std::max(reparentHi, slot + 1);
-        reparentVersion++;  // ancestorsActive of the subtree may have flipped: propagateActive recorded the slots
+        reparentVersion++;
     }
     // transform.cpp:75-127: flips selfActive and pushes ancestorsActive down the subtree
     void setActive(ID<Entity> entity, bool isActive)

@@ -75,6 +75,16 @@ class GvMeshColumns(C.Structure):
                 ("is_visible", C.c_void_p), ("is_visible_stride", C.c_uint32)]
 
 
+class GvScenePool(C.Structure):
+    _fields_ = [("component_type", C.c_char_p), ("pool_id", C.c_uint32)]
+
+
+class GvSceneInfo(C.Structure):
+    _fields_ = [("entity_count", C.c_uint32), ("transform_count", C.c_uint32), ("mesh_count", C.c_uint32 * GV_MAX_POOLS),
+                ("skipped_entities", C.c_uint32), ("other_components", C.c_uint32), ("duplicate_uids", C.c_uint32),
+                ("self_parents", C.c_uint32), ("unresolved_parents", C.c_uint32)]
+
+
 class GvError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libgarden_vis error {code}: {text}")
@@ -89,6 +99,8 @@ EXPORTS = [
     "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream",
+    "gv_scene_parse_json", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
+    "gv_scene_bind",
 ]
 
 _lib = None
@@ -143,9 +155,17 @@ def load():
     lib.gv_stats_reset.argtypes = [P]
     lib.gv_stream.argtypes = [P]
     lib.gv_stream.restype = P
+    lib.gv_scene_parse_json.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, C.POINTER(P), C.c_char_p, sz]
+    lib.gv_scene_destroy.argtypes = [P]
+    lib.gv_scene_destroy.restype = None
+    lib.gv_scene_info.argtypes = [P, C.POINTER(GvSceneInfo)]
+    lib.gv_scene_transform_columns.argtypes = [P, C.POINTER(GvTransformColumns), C.POINTER(u32), C.POINTER(P),
+                                               C.POINTER(u32), C.POINTER(P)]
+    lib.gv_scene_mesh_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), C.POINTER(u32)]
+    lib.gv_scene_bind.argtypes = [P, P]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream"):
+        if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream", "gv_scene_destroy"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -346,3 +366,66 @@ class GpuVisibility:
 
     def stats_reset(self):
         self._check(self.lib.gv_stats_reset(self.ctx))
+
+
+class Scene:
+    """A Garden scene file ingested straight into column pools (gv_scene_*; no device needed until bind)."""
+
+    def __init__(self, text, pools):
+        """text: the scene JSON (str or bytes); pools: {component ".type": pool id}."""
+        self.lib = load()
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        arr = (GvScenePool * max(len(pools), 1))(*[GvScenePool(k.encode(), v) for k, v in pools.items()])
+        handle, err = C.c_void_p(), C.create_string_buffer(512)
+        rc = self.lib.gv_scene_parse_json(raw, len(raw), arr, len(pools), C.byref(handle), err, len(err))
+        if rc != 0:
+            raise GvError(rc, err.value.decode(errors="replace"))
+        self.handle, self.pools = handle, dict(pools)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gv_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def info(self):
+        i = GvSceneInfo()
+        self.lib.gv_scene_info(self.handle, C.byref(i))
+        out = {n: getattr(i, n) for n, _ in GvSceneInfo._fields_ if n != "mesh_count"}
+        out["mesh_count"] = {pid: i.mesh_count[pid] for pid in self.pools.values()}
+        return out
+
+    @staticmethod
+    def _view(col, n, dtype, width):
+        if n == 0:
+            return np.zeros((0, width) if width > 1 else 0, dtype)
+        a = np.ctypeslib.as_array(C.cast(col.data, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n * width,))
+        return a.reshape(n, width).copy() if width > 1 else a.copy()
+
+    def transform_columns(self):
+        """Copies of the transform columns + entity_to_transform + uids, as numpy arrays."""
+        c, n, cap, e2t, uids = GvTransformColumns(), C.c_uint32(), C.c_uint32(), C.c_void_p(), C.c_void_p()
+        self.lib.gv_scene_transform_columns(self.handle, C.byref(c), C.byref(n), C.byref(e2t), C.byref(cap), C.byref(uids))
+        n = n.value
+        out = dict(entity=self._view(c.entity, n, np.uint32, 1), parent=self._view(c.parent, n, np.uint32, 1),
+                   position=self._view(c.position, n, np.float32, 3), scale=self._view(c.scale, n, np.float32, 3),
+                   rotation=self._view(c.rotation, n, np.float32, 4), self_active=self._view(c.self_active, n, np.uint8, 1),
+                   ancestors_active=self._view(c.ancestors_active, n, np.uint8, 1),
+                   model_with_ancestors=self._view(c.model_with_ancestors, n, np.uint8, 1))
+        out["entity_to_transform"] = self._view(GvColumn(e2t.value, 4), cap.value, np.uint32, 1)
+        out["uid"] = self._view(GvColumn(uids.value, 8), n, np.uint64, 1)
+        return out
+
+    def mesh_columns(self, pool_id):
+        c, n = GvMeshColumns(), C.c_uint32()
+        self.lib.gv_scene_mesh_columns(self.handle, pool_id, C.byref(c), C.byref(n))
+        n = n.value
+        return dict(entity=self._view(c.entity, n, np.uint32, 1), is_enabled=self._view(c.is_enabled, n, np.uint8, 1),
+                    aabb_min=self._view(c.aabb_min, n, np.float32, 3), aabb_max=self._view(c.aabb_max, n, np.float32, 3),
+                    is_visible=self._view(GvColumn(c.is_visible, 1), n, np.uint8, 1))
+
+    def bind(self, vis):
+        """Binds the scene's columns to a GpuVisibility context (the scene must stay alive while bound)."""
+        vis._scene = self
+        vis._check(self.lib.gv_scene_bind(vis.ctx, self.handle))

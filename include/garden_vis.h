@@ -201,6 +201,41 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
  * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. */
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
 
+/* ---- scene ingest: a Garden scene file straight into column pools, no component AoS ----
+ * Reads what ResourceSystem::loadScene (source/system/resource.cpp:2421-2510) hands to TransformSystem::deserialize /
+ * postDeserialize (source/system/transform.cpp:517-583) and to the mesh systems' deserialize ("aabb", "isEnabled",
+ * e.g. source/system/render/sprite.cpp:206-207), with the JSON typing rules of source/json-serialize.cpp. Entity ids
+ * are 1, 2, ... in file order (a fresh Manager); transform / mesh slots are in order of appearance; parents are
+ * resolved by uid after the whole file is read, in file order, with setParent's semantics (ancestorsActive from the
+ * parent at that moment, transform.cpp:129-195). Parsing needs no device. */
+typedef struct GvScene GvScene;
+typedef struct GvScenePool {
+    const char* component_type; /* the component's ".type" string, e.g. "Model", "Sprite" */
+    uint32_t pool_id;           /* the gv_pool_bind id its meshes go to */
+} GvScenePool;
+typedef struct GvSceneInfo {
+    uint32_t entity_count;     /* entities created (1 .. entity_count) */
+    uint32_t transform_count;
+    uint32_t mesh_count[GV_MAX_POOLS];
+    uint32_t skipped_entities;   /* "components": [] — the reference creates no entity for them */
+    uint32_t other_components;   /* components of types this pass does not read */
+    uint32_t duplicate_uids;     /* later transforms with a uid already seen (the first keeps it) */
+    uint32_t self_parents;       /* parent uid == own uid: no link */
+    uint32_t unresolved_parents; /* parent uid not in the file: stays a root */
+} GvSceneInfo;
+/* On failure returns GV_E_ARG and writes a message into `error` (may be NULL). */
+int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count,
+                        GvScene** out_scene, char* error, size_t error_capacity);
+void gv_scene_destroy(GvScene* scene);
+int gv_scene_info(const GvScene* scene, GvSceneInfo* out);
+/* The scene's columns (owned by the scene, valid until gv_scene_destroy); any out pointer may be NULL. */
+int gv_scene_transform_columns(const GvScene* scene, GvTransformColumns* columns, uint32_t* occupancy,
+                               const uint32_t** entity_to_transform, uint32_t* entity_capacity, const uint64_t** uids);
+int gv_scene_mesh_columns(GvScene* scene, uint32_t pool_id, GvMeshColumns* columns, uint32_t* occupancy);
+/* Binds the transform columns and every mapped mesh pool to `ctx` and schedules a full mirror build. The scene must
+ * outlive the binding. */
+int gv_scene_bind(GvCtx* ctx, GvScene* scene);
+
 /* ---- world matrices: TransformComponent::calcModel() with cameraPosition = 0 for every transform
  * slot (transform.hpp:197-214), cached on the device ---- */
 typedef enum GvSweepMode {

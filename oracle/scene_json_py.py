@@ -1,0 +1,174 @@
+"""TEST INFRASTRUCTURE (oracle side of the scene ingest) — never imported by the product.
+
+A Python restatement of how the reference turns a scene file into component pools, and of how it writes one:
+  read:   ResourceSystem::loadScene              source/system/resource.cpp:2421-2510
+          TransformSystem::deserialize           source/system/transform.cpp:517-560
+          TransformSystem::postDeserialize       source/system/transform.cpp:561-583  (setParent, transform.cpp:129-195)
+          mesh systems' deserialize              e.g. source/system/render/sprite.cpp:206-207
+          JsonDeserializer::read(...)            source/json-serialize.cpp:563-571,599-607,768-781,851-863,873-898
+  write:  TransformSystem::serialize             source/system/transform.cpp:459-515
+          JsonSerializer::write(float3/quat/Aabb) source/json-serialize.cpp:249-272,303-310
+The reader produces the AoS pools (TRANSFORM_DTYPE / MESH_DTYPE) the CPU path runs on, so the ingest's columns can be
+compared field by field and its cull results against oracle_py.prepare_meshes on these pools."""
+import base64
+import json
+
+import numpy as np
+
+from garden_amd.pools import GV_NONE, MESH_DTYPE, TRANSFORM_DTYPE
+
+
+def encode_uid(uid):
+    """encodeBase64URL of the 8 uid bytes with the padding character cut (transform.cpp:473-475)."""
+    return base64.urlsafe_b64encode(int(uid).to_bytes(8, "little")).decode()[:11]
+
+
+def decode_uid(text):
+    if not isinstance(text, str) or len(text) != 11:  # transform.cpp:520
+        return None
+    if any(not (ch.isascii() and (ch.isalnum() or ch in "-_")) for ch in text):
+        return None
+    try:
+        raw = base64.urlsafe_b64decode(text + "=")
+    except Exception:
+        return None
+    return int.from_bytes(raw, "little") if len(raw) == 8 else None
+
+
+def _vec(value, n):
+    """JsonSerializer::write(float3): one number when all components are equal, else {x, y, z}."""
+    v = [float(np.float32(c)) for c in value[:n]]
+    if all(c == v[0] for c in v):
+        return v[0]
+    return dict(zip("xyzw", v))
+
+
+def write_scene(transforms, meshes_by_type, e2t):
+    """Scene text for AoS pools: one entity per live transform (in slot order), its mesh components after it.
+    Defaults are omitted exactly as the reference's serialize() functions omit them."""
+    mesh_of_entity = {}
+    for type_name, meshes in meshes_by_type.items():
+        for m in meshes:
+            if m["entity"]:
+                mesh_of_entity.setdefault(int(m["entity"]), []).append((type_name, m))
+    entities = []
+    for t in transforms:
+        if not t["entity"]:
+            continue
+        c = {".type": "Transform", "uid": encode_uid(t["uid"])}
+        pos, scl, rot = t["position"][:3], t["scale"][:3], t["rotation"]
+        if any(float(x) != 0.0 for x in pos):
+            c["position"] = _vec(pos, 3)
+        if not (rot[0] == 0 and rot[1] == 0 and rot[2] == 0 and rot[3] == 1):
+            c["rotation"] = dict(zip("xyzw", [float(x) for x in rot]))
+        if any(float(x) != 1.0 for x in scl):
+            c["scale"] = _vec(scl, 3)
+        if not t["selfActive"]:
+            c["isActive"] = False
+        if t["parent"]:
+            c["parent"] = encode_uid(transforms[e2t[int(t["parent"])]]["uid"])
+        comps = [c]
+        for type_name, m in mesh_of_entity.get(int(t["entity"]), []):
+            mc = {".type": type_name}
+            mn, mx = m["aabbMin"][:3], m["aabbMax"][:3]
+            if not (all(float(x) == -0.5 for x in mn) and all(float(x) == 0.5 for x in mx)):
+                mc["aabb"] = {"min": _vec(mn, 3), "max": _vec(mx, 3)}
+            if not m["isEnabled"]:
+                mc["isEnabled"] = False
+            comps.append(mc)
+        entities.append({"components": comps})
+    return json.dumps({"version": "0.0.1", "entities": entities})
+
+
+def _read_vec(obj, key, out, n):
+    """JsonDeserializer::read(name, f32x4&, components): float literals only (ints are number_integer)."""
+    v = obj.get(key)
+    if isinstance(v, float):
+        out[:n] = np.float32(v)
+    elif isinstance(v, dict):
+        for k, name in enumerate("xyzw"[:n]):
+            if isinstance(v.get(name), float):
+                out[k] = np.float32(v[name])
+
+
+def read_scene(text, pools):
+    """pools: {component type: pool id}. Returns (transforms AoS, {pool id: meshes AoS}, e2t, info dict)."""
+    data = json.loads(text)
+    tr, meshes = [], {pid: [] for pid in pools.values()}
+    info = dict(entity_count=0, skipped_entities=0, other_components=0, duplicate_uids=0, self_parents=0,
+                unresolved_parents=0)
+    entity_of_uid, pending, next_entity = {}, [], 1
+    for ent in data.get("entities", []) if isinstance(data.get("entities"), list) else []:
+        comps = ent.get("components") if isinstance(ent, dict) else None
+        if not isinstance(comps, list):
+            continue
+        if not comps:
+            info["skipped_entities"] += 1
+            continue
+        entity = next_entity
+        next_entity += 1
+        info["entity_count"] += 1
+        for c in comps:
+            ctype = c.get(".type") if isinstance(c, dict) else None
+            if ctype == "Transform":
+                t = np.zeros((), TRANSFORM_DTYPE)
+                t["entity"] = entity
+                t["scale"][:3] = 1
+                t["rotation"] = (0, 0, 0, 1)
+                t["selfActive"] = t["ancestorsActive"] = t["modelWithAncestors"] = 1
+                uid = decode_uid(c.get("uid"))
+                if uid is not None:
+                    t["uid"] = uid
+                    if uid in entity_of_uid:
+                        info["duplicate_uids"] += 1
+                    else:
+                        entity_of_uid[uid] = entity
+                _read_vec(c, "position", t["position"], 3)
+                if isinstance(c.get("rotation"), dict):
+                    _read_vec(c, "rotation", t["rotation"], 4)
+                _read_vec(c, "scale", t["scale"], 3)
+                if isinstance(c.get("isActive"), bool):
+                    t["selfActive"] = 1 if c["isActive"] else 0
+                puid = decode_uid(c.get("parent"))
+                if puid is not None:
+                    if uid is not None and puid == uid:
+                        info["self_parents"] += 1
+                    else:
+                        pending.append((len(tr), puid))
+                tr.append(t)
+            elif ctype in pools:
+                m = np.zeros((), MESH_DTYPE)
+                m["entity"] = entity
+                m["isEnabled"] = 1
+                m["aabbMin"][:3] = -0.5
+                m["aabbMax"][:3] = 0.5
+                box = c.get("aabb")
+                if isinstance(box, dict):
+                    lo = m["aabbMin"][:3].copy()
+                    hi = m["aabbMin"][:3].copy()  # json-serialize.cpp:856: max also starts from the current MIN
+                    _read_vec(box, "min", lo, 3)
+                    _read_vec(box, "max", hi, 3)
+                    if np.all(lo <= hi):  # Aabb::trySet (build-defined, see gv_scene.cpp)
+                        m["aabbMin"][:3] = lo
+                        m["aabbMax"][:3] = hi
+                if isinstance(c.get("isEnabled"), bool):
+                    m["isEnabled"] = 1 if c["isEnabled"] else 0
+                meshes[pools[ctype]].append(m)
+            else:
+                info["other_components"] += 1
+    transforms = np.array(tr, dtype=TRANSFORM_DTYPE) if tr else np.zeros(0, TRANSFORM_DTYPE)
+    e2t = np.full(next_entity, GV_NONE, np.uint32)
+    if len(tr):
+        e2t[transforms["entity"]] = np.arange(len(tr), dtype=np.uint32)
+    for slot, puid in pending:  # postDeserialize + setParent, in file order
+        parent_entity = entity_of_uid.get(puid)
+        if parent_entity is None:
+            info["unresolved_parents"] += 1
+            continue
+        if parent_entity == transforms["entity"][slot]:
+            continue
+        ps = e2t[parent_entity]
+        transforms["parent"][slot] = parent_entity
+        transforms["ancestorsActive"][slot] = 1 if (transforms["selfActive"][ps] and transforms["ancestorsActive"][ps]) else 0
+    out_meshes = {pid: (np.array(v, dtype=MESH_DTYPE) if v else np.zeros(0, MESH_DTYPE)) for pid, v in meshes.items()}
+    return transforms, out_meshes, e2t, info

@@ -1,0 +1,163 @@
+"""Scene ingest: gv_scene_parse_json puts a Garden scene file straight into column pools.
+
+CPU tier: the columns equal, field by field and bit for bit, the AoS pools that a Python restatement of the reference's
+loader (oracle/scene_json_py.py: resource.cpp:2421-2510, transform.cpp:517-583, json-serialize.cpp) builds from the
+same text — on generated scenes and on the loader's edge cases. GPU tier: cull results on the bound scene equal the
+oracle's prepare_meshes on those AoS pools."""
+import json
+
+import numpy as np
+import pytest
+
+from garden_amd import scene
+from garden_amd.lib import GvError, Scene
+from oracle import scene_json_py as sj
+
+POOLS = {"Model": 0, "Sprite": 3}
+
+
+def columns_equal_aos(sc, text, pools=POOLS):
+    tr, meshes, e2t, info = sj.read_scene(text, pools)
+    got = sc.transform_columns()
+    n = tr.shape[0]
+    assert got["entity"].shape[0] == n
+    assert np.array_equal(got["entity"], tr["entity"]) and np.array_equal(got["parent"], tr["parent"])
+    assert np.array_equal(got["uid"], tr["uid"])
+    assert np.array_equal(got["position"].view(np.uint32), np.ascontiguousarray(tr["position"][:, :3]).view(np.uint32))
+    assert np.array_equal(got["scale"].view(np.uint32), np.ascontiguousarray(tr["scale"][:, :3]).view(np.uint32))
+    assert np.array_equal(got["rotation"].view(np.uint32), tr["rotation"].view(np.uint32))
+    assert np.array_equal(got["self_active"], tr["selfActive"])
+    assert np.array_equal(got["ancestors_active"], tr["ancestorsActive"])
+    assert np.array_equal(got["model_with_ancestors"], tr["modelWithAncestors"])
+    assert np.array_equal(got["entity_to_transform"], e2t)
+    for pid, aos in meshes.items():
+        m = sc.mesh_columns(pid)
+        assert np.array_equal(m["entity"], aos["entity"]) and np.array_equal(m["is_enabled"], aos["isEnabled"])
+        assert np.array_equal(m["aabb_min"].view(np.uint32), np.ascontiguousarray(aos["aabbMin"][:, :3]).view(np.uint32))
+        assert np.array_equal(m["aabb_max"].view(np.uint32), np.ascontiguousarray(aos["aabbMax"][:, :3]).view(np.uint32))
+    i = sc.info()
+    for k, v in info.items():
+        assert i[k] == v, k
+    assert i["transform_count"] == n and all(i["mesh_count"][pid] == meshes[pid].shape[0] for pid in meshes)
+    return tr, meshes, e2t
+
+
+def scene_text(n, hier):
+    src = scene.hierarchy_scene(n, depth=4, fanout=5) if hier else scene.flat_scene(n)
+    # some exact defaults and splats so the writer's omission / single-number forms are exercised
+    src.transforms["position"][::17, :3] = 0
+    src.transforms["scale"][::13, :3] = 1
+    src.transforms["scale"][5::13, :3] = np.float32(1.75)
+    src.transforms["rotation"][::19] = (0, 0, 0, 1)
+    src.meshes["aabbMin"][::23, :3] = -0.5
+    src.meshes["aabbMax"][::23, :3] = 0.5
+    half = src.meshes.shape[0] // 2
+    return sj.write_scene(src.transforms, {"Model": src.meshes[:half], "Sprite": src.meshes[half:]}, src.entity_to_transform)
+
+
+@pytest.mark.parametrize("hier", [False, True])
+def test_generated_scene_columns_equal_the_reference_loader(hier):
+    text = scene_text(4000, hier)
+    sc = Scene(text, POOLS)
+    tr, meshes, _ = columns_equal_aos(sc, text)
+    assert tr.shape[0] > 3800 and meshes[0].shape[0] > 1500 and meshes[3].shape[0] > 1500
+    if hier:
+        assert np.count_nonzero(tr["parent"]) > 3000 and np.count_nonzero(tr["ancestorsActive"] == 0) > 0
+    sc.close()
+
+
+U = [sj.encode_uid(0x1000 + k) for k in range(8)]
+
+
+def test_loader_edge_cases():
+    ents = [
+        # 1: integer literals are number_integer -> ignored; splat scale; rotation must be an object
+        {"components": [{".type": "Transform", "uid": U[0], "position": 5, "scale": 2.5, "rotation": 1.0},
+                        {".type": "Model", "aabb": {"min": {"x": -1.0, "y": -2, "z": -3.0}, "max": 4.0}}]},
+        {"components": []},                                   # no entity is created
+        {"name": "no components key"},                        # nor here
+        # 2: child listed BEFORE its parent gets an inactive grandparent: keeps ancestorsActive = 1 (setParent only
+        #    looks at the parent's flags at link time and links run in file order)
+        {"components": [{".type": "Transform", "uid": U[1], "parent": U[2], "position": {"x": 1.5, "y": 0.25}}]},
+        # 3: parent of #2, itself under the inactive #4
+        {"components": [{".type": "Transform", "uid": U[2], "parent": U[3]}, {".type": "Camera", "fov": 1.0}]},
+        # 4: inactive root
+        {"components": [{".type": "Transform", "uid": U[3], "isActive": False}]},
+        # 5: linked after #3 was linked: sees the inactive chain
+        {"components": [{".type": "Sprite", "isEnabled": False, "aabb": {"min": 1.0, "max": 0.5}},   # invalid box: default kept
+                        {".type": "Transform", "uid": U[4], "parent": U[2]}]},
+        # 6: duplicate uid (first keeps it), self parent
+        {"components": [{".type": "Transform", "uid": U[0], "parent": U[0]}]},
+        # 7: unknown parent, malformed uid, escapes in an unread string
+        {"components": [{".type": "Transform", "uid": "short", "parent": sj.encode_uid(0xDEAD), "debugName": 'a"b\\c\u00e9\n\t/'},
+                        {".type": "Model", "aabb": {"max": {"x": 1.0, "y": 1.0, "z": 1.0}}}]},                # min from default -0.5
+        # 8: only components this pass does not read
+        {"components": [{".type": "Light"}, {"noType": 1}]},
+    ]
+    text = json.dumps({"version": "0.1.0", "entities": ents, "extra": [1, {"a": None}, True, -2.5e-3]}, indent=1)
+    assert '\\"' in text and "\\u00e9" in text and "\\n" in text  # the string escapes reach the parser
+    sc = Scene(text, POOLS)
+    tr, meshes, e2t = columns_equal_aos(sc, text)
+    i = sc.info()
+    assert i["entity_count"] == 8 and i["skipped_entities"] == 1 and i["duplicate_uids"] == 1
+    assert i["self_parents"] == 1 and i["unresolved_parents"] == 1 and i["other_components"] == 3
+    t = sc.transform_columns()
+    assert list(t["position"][0]) == [0, 0, 0] and list(t["scale"][0]) == [2.5, 2.5, 2.5] and list(t["rotation"][0]) == [0, 0, 0, 1]
+    assert list(t["position"][1]) == [1.5, 0.25, 0]
+    # slot 1 was linked while its parent (slot 2) still looked active and keeps 1; slot 2 then went under the inactive
+    # slot 3; slot 4, linked after that, sees slot 2's cleared flag
+    assert list(t["ancestors_active"]) == [1, 1, 0, 1, 0, 1, 1]
+    m0, m3 = sc.mesh_columns(0), sc.mesh_columns(3)
+    assert list(m0["aabb_min"][0]) == [-1, -0.5, -3] and list(m0["aabb_max"][0]) == [4, 4, 4]
+    assert list(m0["aabb_min"][1]) == [-0.5] * 3 and list(m0["aabb_max"][1]) == [1, 1, 1]
+    assert list(m3["aabb_min"][0]) == [-0.5] * 3 and list(m3["aabb_max"][0]) == [0.5] * 3 and m3["is_enabled"][0] == 0
+    sc.close()
+
+
+@pytest.mark.parametrize("text,needle", [
+    ('{"entities": [{"components": [{".type": "Transform"}, {".type": "Transform"}]}]}', "two Transform"),
+    ('{"entities": [{"components": [{".type": "Transform", "position": {"x": 1.0,}}]}]}', "byte"),
+    ('{"entities": [', "byte"),
+    ('[]', "not a JSON object"),
+    ('{"entities": []} trailing', "trailing"),
+])
+def test_malformed_scenes_are_rejected_with_a_message(text, needle):
+    with pytest.raises(GvError) as e:
+        Scene(text, POOLS)
+    assert needle in str(e.value)
+
+
+def test_empty_scene():
+    sc = Scene('{"version": "1.0.0"}', POOLS)
+    assert sc.info()["entity_count"] == 0 and sc.transform_columns()["entity"].shape[0] == 0
+    sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hier", [False, True])
+def test_ingested_scene_culls_like_the_reference_pools(gpu, oracle, hier):
+    text = scene_text(60_000, hier)
+    sc = Scene(text, POOLS)
+    tr, meshes, e2t = columns_equal_aos(sc, text)
+    sc.bind(gpu)
+    view = scene.main_camera_view()
+    for pid in (0, 3):
+        gpu.cull(pid, [view])
+        got = gpu.fetch(0, write_back=True, occupancy=meshes[pid].shape[0])
+        aos = meshes[pid].copy()
+        exp = oracle.prepare_meshes(aos, tr, e2t, view)
+        assert exp["draw_count"] > 100
+        assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+        assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+        assert np.array_equal(sc.mesh_columns(pid)["is_visible"], aos["isVisible"])  # written back into the column
+    # world matrices of the ingested transforms
+    gpu.sweep(1)
+    assert np.array_equal(gpu.get_world(0, tr.shape[0]).view(np.uint32), oracle.world_matrices(tr, e2t).view(np.uint32))
+    # rebind ordinary pools afterwards: the context does not keep pointing into the scene
+    flat = scene.flat_scene(1000)
+    gpu.bind_transforms(flat.transforms, flat.entity_to_transform)
+    gpu.bind_pool(0, flat.meshes)
+    gpu.bind_pool(3, flat.meshes[:0])
+    gpu.hierarchy_rebuild()
+    sc.close()
