@@ -558,3 +558,47 @@ def test_column_binds_give_the_same_results_as_aos_binds(gpu, oracle, hier):
         m2 = sc.meshes.copy()
         exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
         assert np.array_equal(got["visible_idx"], exp["visible_idx"]) and np.array_equal(mesh["is_visible"], m2["isVisible"])
+
+
+def test_error_conventions_of_the_c_abi(gpu):
+    """Every gv_* returns a status and leaves a message; nothing aborts or throws across the boundary."""
+    import ctypes as C
+    from garden_amd import lib as L
+    raw, ctx = gpu.lib, gpu.ctx
+    sc = scene.flat_scene(100)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+
+    def failed(rc, needle):
+        assert rc == L.GV_E_ARG or rc == L.GV_E_STATE, rc
+        assert needle in raw.gv_last_error(ctx).decode(), raw.gv_last_error(ctx)
+
+    layout_t = L.GvTransformLayout(*[0] * 8)
+    layout_m = L.GvMeshLayout(0, 14, 15, 16, 32)
+    big = 1 << 28  # slot ids are 28-bit
+    failed(raw.gv_transform_bind(ctx, sc.transforms.ctypes.data, 80, big, C.byref(layout_t), None, 0), "28-bit")
+    failed(raw.gv_pool_bind(ctx, 0, sc.meshes.ctypes.data, 48, big, C.byref(layout_m)), "28-bit")
+    failed(raw.gv_pool_bind(ctx, 16, sc.meshes.ctypes.data, 48, 10, C.byref(layout_m)), "pool_id 16")
+    failed(raw.gv_pool_bind(ctx, 0, sc.meshes.ctypes.data, 20, 10, C.byref(layout_m)), "stride")
+    failed(raw.gv_pool_bind(ctx, 0, None, 48, 10, C.byref(layout_m)), "bad argument")
+    failed(raw.gv_mark_dirty(ctx, 9, 0, 1), "unknown kind")
+    failed(raw.gv_sweep(ctx, 7), "unknown mode")
+    views = (L.GvView * 9)()
+    failed(raw.gv_cull(ctx, 0, views, 9), "view")          # more than GV_MAX_VIEWS
+    failed(raw.gv_cull(ctx, 5, views, 1), "pool")          # never bound
+    n = C.c_uint32()
+    failed(raw.gv_result_count(ctx, 7, C.byref(n)), "no results")
+    res = L.GvResult()
+    failed(raw.gv_results_fetch(ctx, 7, 0, C.byref(res)), "view")
+    failed(raw.gv_sort(ctx, 6, 0), "no emitted records")
+    gpu.mark_dirty(0, 0, 1)  # transforms changed: the world cache is stale
+    gpu.sync()
+    out = np.zeros((1, 12), np.float32)
+    failed(raw.gv_get_world(ctx, 0, 1, out.ctypes.data), "gv_sweep has not run")
+    gpu.sweep(0)
+    failed(raw.gv_get_world(ctx, 90, 20, out.ctypes.data), "outside the pool")
+    assert raw.gv_cull(None, 0, views, 1) == L.GV_E_ARG    # NULL context: status only
+    # the context is still usable afterwards
+    gpu.cull(0, [scene.main_camera_view()])
+    assert gpu.result_count(0) >= 0
