@@ -64,12 +64,15 @@ def make_tile_scene(wl, n_local, rank, world):
     return sc
 
 
-def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False):
+def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False, examined=1.0):
     """Minimal SoA stream bytes per launch for the cull kernel, and
-    for the whole step (for information)."""
-    cull = n * (65.0 + 1.0 + 0.125)  # TRS 40 + AABB 24 + flags 1 read; isVisible 1 + ballot word 1/8 written
+    for the whole step (for information). `examined`: fraction of the 256-entry workgroups whose streams are read
+    (1 without block bounds; with them the rest only write their outputs and read a 32-byte box)."""
+    cull = n * examined * 65.0 + n * (1.0 + 0.125)  # TRS 40 + AABB 24 + flags 1 read; isVisible 1 + ballot word 1/8 written
+    if examined < 1.0:
+        cull += (n / 256.0) * 32.0
     if wl["hier"]:
-        cull += n * 4.0  # parent index
+        cull += n * examined * 4.0  # parent index
     if wl["hiz"]:
         cull += frustum_survivors * 32.0  # 4 texels x (min,max) fp32 per frustum-surviving entity
     emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125
@@ -123,6 +126,9 @@ def main():
     ap.add_argument("--sweep", default="fused", choices=["mfma", "valu", "fused", "fused-valu"],
                     help="cfg4 world-matrix sweep form; fused = MFMA sweep and cull in one pass (GV_SWEEP_WITH_CULL)")
     ap.add_argument("--profile-all", action="store_true", help="hipEvents around every kernel (slower step)")
+    ap.add_argument("--block-bounds", action="store_true",
+                    help="GV_CONFIG_BLOCK_BOUNDS: conservative workgroup-level frustum rejection (same results); the "
+                         "roofline numerator then counts the streams of examined workgroups only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -165,7 +171,8 @@ def main():
 
     # hipEvents bracket only the dominant kernel inside the timed region (each event record costs ~2 us of
     # stream time); --profile-all brackets every kernel for the per-kernel breakdown in config.kernel_ms
-    vis = GpuVisibility(device=local_rank, profile_events=args.profile_all, profile_cull_only=not args.profile_all)
+    vis = GpuVisibility(device=local_rank, profile_events=args.profile_all, profile_cull_only=not args.profile_all,
+                        block_bounds=args.block_bounds)
     t_up = time.perf_counter()
     vis.bind_transforms(sc.transforms, sc.entity_to_transform)
     vis.bind_pool(0, sc.meshes)
@@ -268,6 +275,47 @@ def main():
 
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
+
+    # Same workload through GV_CONFIG_BLOCK_BOUNDS (opt-in: conservative workgroup-level frustum rejection, same
+    # results). Reported beside the headline, never as `value`: the headline stays the linear scan SURVEY.md §8d prices.
+    bounds_variant = None
+    if world == 1 and not args.block_bounds and not (wl["sweep"] and args.sweep.startswith("fused")):
+        vb = GpuVisibility(device=local_rank, profile_cull_only=True, block_bounds=True)
+        vb.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vb.bind_pool(0, sc.meshes)
+        vb.hierarchy_rebuild()
+        if wl["hiz"]:
+            vb.hiz_build(depth)
+
+        def bounded_step():
+            if wl["hiz"]:
+                vb.hiz_rebuild()
+            if wl["sweep"]:
+                vb.sweep({"mfma": GV_SWEEP_MFMA, "valu": GV_SWEEP_VALU}[args.sweep])
+            vb.cull(0, [view])
+
+        for _ in range(5):
+            bounded_step()
+        vb.wait()
+        vb.stats_reset()
+        frames, t2 = 30, time.perf_counter()
+        for _ in range(frames):
+            bounded_step()
+        vb.wait()
+        dt = time.perf_counter() - t2
+        sb = vb.stats()
+        gb = vb.fetch(0, write_back=False, occupancy=n)
+        same = bool(np.array_equal(gb["visible_idx"], got["visible_idx"]) and np.array_equal(gb["is_visible"], got["is_visible"])
+                    and np.array_equal(gb["baked_model"].view(np.uint32), got["baked_model"].view(np.uint32)))
+        bounds_variant = dict(ms_per_step=dt / frames * 1e3, value=n * frames / dt,
+                              cull_kernel_ms=sb["device_ms"]["cull"] / max(1, sb["launches"]["cull"]),
+                              examined_workgroup_fraction=sb["bounds_blocks_examined"] / max(1, sb["bounds_blocks_total"]),
+                              outputs_identical_to_headline=same)
+        vb.close()
+        if not same:
+            print(json.dumps({"error": "block-bounds variant differs from the linear scan", "variant": bounds_variant}))
+            sys.exit(1)
+
     visible = got["draw_count"]
     parity = None
     survivors = visible
@@ -295,7 +343,10 @@ def main():
 
     if rank == 0:
         fused = wl["sweep"] and args.sweep.startswith("fused")
-        ab = algorithmic_bytes(wl, n, survivors, visible, depth, fused=fused)
+        examined = 1.0
+        if args.block_bounds and st["bounds_blocks_total"]:
+            examined = st["bounds_blocks_examined"] / st["bounds_blocks_total"]
+        ab = algorithmic_bytes(wl, n, survivors, visible, depth, fused=fused, examined=examined)
         launches = max(1, st["launches"]["cull"])
         cull_ms = st["device_ms"]["cull"] / launches
         achieved = ab["cull"] / (cull_ms * 1e-3) / 1e9 if cull_ms > 0 else 0.0
@@ -314,7 +365,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None, "entities_per_gpu": n, "entities_total": n * world,
+            "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None,
+                       "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
+                       "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
                        "exchange": (f"per frame: one equal-size all-gather of padded shards [count, uint32 indices...] "
                                     f"(capacity {ex[0].capacity}) behind the cull stream, no host sync ({backend}); "

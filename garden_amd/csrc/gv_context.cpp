@@ -135,6 +135,11 @@ struct PoolState {
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
+    // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
+    DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    uint64_t epoch = 1, bounds_epoch = 0, bounds_xf_epoch = 0;  // epoch: bumped whenever this pool's mirror changes
+    uint64_t seen_epoch = 0, seen_xf_epoch = 0;                 // state at this pool's previous gv_cull
+    bool changed_prev = false;                                  // ... and whether it had changed then too (dynamic pool)
     // device mirror + pinned staging
     DeviceBuf<float4> d_a;
     DeviceBuf<float2> d_b;
@@ -177,6 +182,9 @@ struct GvCtx {
     TransformBinding xf;
     bool xf_need_full = false;
     bool sweep_with_cull_mfma = true;
+    uint64_t xf_epoch = 1;  // bumped whenever the transform mirror changes
+    DeviceBuf<uint8_t> d_examined;  // block-bounds statistics of the LAST bounded cull: 1 byte per workgroup
+    uint64_t bounds_blocks_total = 0;
     bool sweep_with_cull = false;  // GV_SWEEP_WITH_CULL requested: the next gv_cull also writes the world matrices
     bool xf_links_dirty = false;  // a ranged GV_DIRTY_HIERARCHY: parent links changed -> re-validate depth / cycles
     DirtyRange xf_dirty;
@@ -757,6 +765,7 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_links_dirty = false;
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
+        ctx->xf_epoch++;
         // transform entries may have moved: every mesh pool's slot column must be re-resolved
         for (auto& p : ctx->pools)
             if (p.bound)
@@ -790,6 +799,7 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_links_dirty = false;
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
+        ctx->xf_epoch++;
     }
     for (auto& p : ctx->pools) {
         if (!p.bound)
@@ -835,6 +845,7 @@ int sync_mirror(GvCtx* ctx)
             phase.lap("mapping + upload meshes");
             p.need_full = false;
             p.dirty.clear();
+            p.epoch++;
         } else if (p.dirty.any()) {
             if (!staged) {
                 GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -854,6 +865,7 @@ int sync_mirror(GvCtx* ctx)
                     return rc;
             }
             p.dirty.clear();
+            p.epoch++;
         }
     }
     return GV_OK;
@@ -1301,6 +1313,31 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         }
         ctx->world_valid = true;
     }
+    // GV_CONFIG_BLOCK_BOUNDS: workgroup boxes are (re)built when the mirror of this pool is clean, or has just changed
+    // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
+    BlockBounds bounds;
+    bool use_bounds = false;
+    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !batched && !fused) {
+        const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
+        bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
+        if (!current && !(changed && p.changed_prev)) {
+            const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
+            GV_HIP(ctx, p.d_blk_lo.reserve(nb));
+            GV_HIP(ctx, p.d_blk_hi.reserve(nb));
+            KernelTimer t(ctx, GV_K_SWEEP);  // accounted with the other per-change passes
+            GV_HIP(ctx, launch_block_bounds(mesh, xf, p.d_blk_lo.ptr, p.d_blk_hi.ptr, ctx->stream));
+            p.bounds_epoch = p.epoch;
+            p.bounds_xf_epoch = ctx->xf_epoch;
+            current = true;
+        }
+        p.changed_prev = changed;
+        p.seen_epoch = p.epoch;
+        p.seen_xf_epoch = ctx->xf_epoch;
+        if (current) {
+            GV_HIP(ctx, ctx->d_examined.reserve((p.occupancy + kCullBlock - 1) / kCullBlock));
+            use_bounds = true;
+        }
+    }
     if (p.occupancy != 0) {
         if (batched) {
             KernelTimer t(ctx, GV_K_CULL);
@@ -1311,8 +1348,15 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                 KernelTimer t(ctx, GV_K_CULL);
                 if (fused && v == 0)
                     GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
-                else
-                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream));
+                else {
+                    if (use_bounds) {
+                        bounds.lo = p.d_blk_lo.ptr;
+                        bounds.hi = p.d_blk_hi.ptr;
+                        bounds.examined = ctx->d_examined.ptr;
+                        ctx->bounds_blocks_total = (p.occupancy + kCullBlock - 1) / kCullBlock;
+                    }
+                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
+                }
             }
             {
                 KernelTimer t(ctx, GV_K_SCAN);
@@ -1657,6 +1701,16 @@ int gv_stats(GvCtx* ctx, GvStats* out)
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         drain_events(ctx);
     }
+    ctx->stats.bounds_blocks_total = ctx->bounds_blocks_total;
+    ctx->stats.bounds_blocks_examined = 0;
+    if (ctx->d_examined.ptr && ctx->bounds_blocks_total) {
+        std::vector<uint8_t> flags(ctx->bounds_blocks_total);
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        GV_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->d_examined.ptr, flags.size(), hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint8_t f : flags)
+            ctx->stats.bounds_blocks_examined += f;
+    }
     ctx->stats.max_depth = ctx->max_depth;
     ctx->stats.transform_count = ctx->xf.occupancy;
     for (uint32_t i = 0; i < GV_MAX_POOLS; i++)
@@ -1677,6 +1731,7 @@ int gv_stats_reset(GvCtx* ctx)
     memset(ctx->stats.launches, 0, sizeof(ctx->stats.launches));
     memset(ctx->stats.device_ms, 0, sizeof(ctx->stats.device_ms));
     ctx->stats.upload_bytes = 0;
+    ctx->bounds_blocks_total = 0;
     return GV_OK;
 }
 

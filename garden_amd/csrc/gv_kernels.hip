@@ -210,6 +210,7 @@ struct CullArgs {
     ViewParams view;
     ViewBuffers out;
     uint32_t nblocks;
+    BlockBounds bounds;  // BOUNDS variants only
 };
 
 // One mesh entry through the reference's filter chain (mesh.cpp:140-157): candidate / empty-AABB / transform /
@@ -296,10 +297,37 @@ __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const Tran
 // into per-tile / per-wave staging segments and copying them (sparse partial sectors, +25..50 us in K1);
 // LDS-staged fused emission with one global atomic per flush (occupancy, barriers); a decoupled look-back
 // scan over 256-slot tiles (inter-workgroup latency and polling traffic dominate such small tiles).
-template <bool HIZ, uint32_t MAP>
-__global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
+// Conservative workgroup-level frustum rejection. The per-entity test rejects an entity when all 8 of its corners are
+// behind one plane (computed distance < 0). The box holds every such corner of the workgroup's candidates as computed
+// in world space; the per-frame corners are the same products with c3 - cam in place of c3, so a computed distance
+// differs from the box-derived one by rounding only: a few ulps of the coordinate magnitude per chain level
+// (<= ~4e-6 * M * (depth + 1)). The margin is an order of magnitude above that, so "box behind by more than the margin"
+// implies "every computed corner distance < 0" — the rejected workgroup's entities all fail that plane in the exact
+// test too. Boxes with non-finite members are +-inf and never satisfy the comparison (NaN / +inf are not < -margin).
+__device__ __forceinline__ bool block_behind_frustum(const float4 lo, const float4 hi, const ViewParams& view, uint32_t max_depth)
 {
-    const uint32_t lb = blockIdx.x;
+    const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
+                      fabsf(view.cam[0]) + fabsf(view.cam[1]) + fabsf(view.cam[2]);
+    const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
+    bool behind = false;
+#pragma unroll
+    for (uint32_t p = 0; p < 6; p++)
+        if (p < view.plane_count) {
+            const float nx = view.planes[p][0], ny = view.planes[p][1], nz = view.planes[p][2];
+            // the box corner farthest along the normal, camera-relative
+            const float x = (nx >= 0.0f ? hi.x : lo.x) - view.cam[0];
+            const float y = (ny >= 0.0f ? hi.y : lo.y) - view.cam[1];
+            const float z = (nz >= 0.0f ? hi.z : lo.z) - view.cam[2];
+            const float d = fmaf(nx, x, fmaf(ny, y, fmaf(nz, z, view.planes[p][3])));
+            behind = behind || (d < -margin);
+        }
+    return behind;
+}
+
+// The per-entity work of one 256-entry workgroup `lb`.
+template <bool HIZ, uint32_t MAP>
+__device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, uint32_t* wave_count)
+{
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool visible = false;
@@ -316,7 +344,6 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
             args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
     }
     const unsigned long long word = __ballot(visible);
-    __shared__ uint32_t wave_count[kCullBlock / 64];
     if (lane == 0) {
         args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
         wave_count[wave] = (uint32_t)__popcll(word);
@@ -332,8 +359,34 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
     }
 }
 
+// BOUNDS (GV_CONFIG_BLOCK_BOUNDS): the workgroup first tests its box; when the box is behind a plane every entity in it
+// is invisible, the outputs say so and the streams stay untouched.
+template <bool HIZ, uint32_t MAP, bool BOUNDS>
+__global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
+{
+    __shared__ uint32_t wave_count[kCullBlock / 64];
+    const uint32_t lb = blockIdx.x;
+    if (BOUNDS) {  // workgroup-uniform
+        const uint32_t i = lb * kCullBlock + threadIdx.x;
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
+        const bool empty = lo.x > hi.x;  // no candidate at all (+inf / -inf)
+        const bool skip = empty || block_behind_frustum(lo, hi, args.view, args.xf.max_depth);
+        if (threadIdx.x == 0)  // statistics: a plain store per workgroup (a shared counter would serialise ~10^4 atomics)
+            args.bounds.examined[lb] = skip ? 0 : 1;
+        if (skip) {
+            if (args.view.write_is_visible && i < args.mesh.count)
+                args.out.is_visible[i] = 0;
+            if (lane == 0)
+                args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
+            return;
+        }
+    }
+    cull_block<HIZ, MAP>(args, lb, wave_count);
+}
+
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
-                       const ViewBuffers& out, hipStream_t stream)
+                       const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds)
 {
     if (mesh.count == 0)
         return hipSuccess;
@@ -344,19 +397,96 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.view = vp;
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    a.bounds = bounds ? *bounds : BlockBounds{};
     const dim3 grid(a.nblocks), block(kCullBlock);
-#define GV_LAUNCH_CULL(HIZ)                                                                       \
-    switch (mesh.mapping) {                                                                      \
-    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact>), grid, block, 0, stream, a); break;         \
-    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a); break; \
-    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a); break;              \
+#define GV_LAUNCH_CULL(HIZ, BOUNDS)                                                                                       \
+    switch (mesh.mapping) {                                                                                              \
+    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate, BOUNDS>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral, BOUNDS>), grid, block, 0, stream, a); break;              \
     }
-    if (vp.use_hiz) {
-        GV_LAUNCH_CULL(true)
+    if (vp.use_hiz && bounds) {
+        GV_LAUNCH_CULL(true, true)
+    } else if (vp.use_hiz) {
+        GV_LAUNCH_CULL(true, false)
+    } else if (bounds) {
+        GV_LAUNCH_CULL(false, true)
     } else {
-        GV_LAUNCH_CULL(false)
+        GV_LAUNCH_CULL(false, false)
     }
 #undef GV_LAUNCH_CULL
+    return hipGetLastError();
+}
+
+// World-space box of each cull workgroup's candidates (camera at the origin: translate(-0) leaves c3 as it is).
+template <uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirror mesh, const TransformMirror xf,
+                                                                  float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    __shared__ float red[kCullBlock / 64][6];
+    const uint32_t lb = blockIdx.x;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    if (i < mesh.count) {
+        Mat34 m;
+        Corners c;
+        const float cam[3] = {0.0f, 0.0f, 0.0f};
+        if (prepare_slot<MAP>(mesh, xf, cam, i, m, c)) {
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float xs[2] = {c.x[k].x, c.x[k].y}, ys[2] = {c.y[k].x, c.y[k].y}, zs[2] = {c.z[k].x, c.z[k].y};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    finite = finite && isfinite(xs[h]) && isfinite(ys[h]) && isfinite(zs[h]);
+                    lo[0] = fminf(lo[0], xs[h]); hi[0] = fmaxf(hi[0], xs[h]);
+                    lo[1] = fminf(lo[1], ys[h]); hi[1] = fmaxf(hi[1], ys[h]);
+                    lo[2] = fminf(lo[2], zs[h]); hi[2] = fmaxf(hi[2], zs[h]);
+                }
+            }
+            if (!finite)  // a member the box cannot bound: the workgroup is always examined
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = -inf;
+                    hi[k] = inf;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], d, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
+        }
+    if (lane == 0)
+        for (int k = 0; k < 3; k++) {
+            red[wave][k] = lo[k];
+            red[wave][3 + k] = hi[k];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kCullBlock / 64; w++)
+            for (int k = 0; k < 3; k++) {
+                red[0][k] = fminf(red[0][k], red[w][k]);
+                red[0][3 + k] = fmaxf(red[0][3 + k], red[w][3 + k]);
+            }
+        out_lo[lb] = make_float4(red[0][0], red[0][1], red[0][2], 0.0f);
+        out_hi[lb] = make_float4(red[0][3], red[0][4], red[0][5], 0.0f);
+    }
+}
+
+hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
+    switch (mesh.mapping) {
+    case kMapExact: hipLaunchKernelGGL((block_bounds_kernel<kMapExact>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    case kMapSpeculate: hipLaunchKernelGGL((block_bounds_kernel<kMapSpeculate>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    default: hipLaunchKernelGGL((block_bounds_kernel<kMapGeneral>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    }
     return hipGetLastError();
 }
 

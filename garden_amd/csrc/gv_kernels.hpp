@@ -76,8 +76,17 @@ struct ViewBuffers {
     float* distance_sq;
 };
 
+// Block bounds (opt-in, GV_CONFIG_BLOCK_BOUNDS): world-space AABB of all corners of the candidates of each 256-entry
+// cull workgroup, built while the mirror is clean. A workgroup whose box lies behind one frustum plane by more than
+// the rounding margin skips its streams: every entity in it would have failed that plane in the per-entity test.
+struct BlockBounds {
+    const float4* lo = nullptr;   // xyz = min corner (+inf when the block has no candidate; -inf when a member is non-finite)
+    const float4* hi = nullptr;   // xyz = max corner (-inf / +inf likewise)
+    uint8_t* examined = nullptr;  // per workgroup: 1 = ran the per-entity path, 0 = skipped (statistics)
+};
+hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
-                       const ViewBuffers& out, hipStream_t stream);
+                       const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
 // One pass over the streams for up to kMaxBatchViews views that share views[0].cam (Hi-Z only on view 0).
 constexpr uint32_t kMaxBatchViews = 8;
 struct MultiViewPlanes {

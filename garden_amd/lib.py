@@ -20,6 +20,7 @@ GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
 GV_CONFIG_PROFILE_EVENTS = 1
 GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_CONFIG_KEEP_SLOT_ORDER = 4
+GV_CONFIG_BLOCK_BOUNDS = 8
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU = 0, 1, 2, 3
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
@@ -58,7 +59,8 @@ class GvDeviceResult(C.Structure):
 class GvStats(C.Structure):
     _fields_ = [("launches", C.c_uint64 * GV_K_COUNT), ("device_ms", C.c_double * GV_K_COUNT),
                 ("upload_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("transform_count", C.c_uint32),
-                ("mesh_count", C.c_uint32 * GV_MAX_POOLS)]
+                ("mesh_count", C.c_uint32 * GV_MAX_POOLS), ("bounds_blocks_total", C.c_uint64),
+                ("bounds_blocks_examined", C.c_uint64)]
 
 
 class GvColumn(C.Structure):
@@ -187,13 +189,15 @@ class GpuVisibility:
     """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
 
     def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False,
-                 keep_slot_order=False):
+                 keep_slot_order=False, block_bounds=False):
         self.lib = load()
         flags = GV_CONFIG_PROFILE_EVENTS if (profile_events or profile_cull_only) else 0
         if profile_cull_only:
             flags |= GV_CONFIG_PROFILE_CULL_ONLY
         if keep_slot_order:
             flags |= GV_CONFIG_KEEP_SLOT_ORDER
+        if block_bounds:
+            flags |= GV_CONFIG_BLOCK_BOUNDS
         cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, flags)
         self.ctx = C.c_void_p()
         rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))
@@ -362,7 +366,8 @@ class GpuVisibility:
         return dict(launches={k: int(s.launches[i]) for i, k in enumerate(KERNEL_NAMES)},
                     device_ms={k: float(s.device_ms[i]) for i, k in enumerate(KERNEL_NAMES)},
                     upload_bytes=int(s.upload_bytes), max_depth=int(s.max_depth),
-                    transform_count=int(s.transform_count))
+                    transform_count=int(s.transform_count), bounds_blocks_total=int(s.bounds_blocks_total),
+                    bounds_blocks_examined=int(s.bounds_blocks_examined))
 
     def stats_reset(self):
         self._check(self.lib.gv_stats_reset(self.ctx))

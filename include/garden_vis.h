@@ -56,10 +56,16 @@ typedef enum GvConfigFlags {
     GV_CONFIG_PROFILE_EVENTS = 1u << 0,   /* bracket every kernel with hipEvents; durations via gv_stats */
     GV_CONFIG_PROFILE_CULL_ONLY = 1u << 1, /* with PROFILE_EVENTS: only GV_K_CULL is bracketed (2 events per view
                                              instead of ~10 per frame: each event record costs ~2 us of stream time) */
-    GV_CONFIG_KEEP_SLOT_ORDER = 1u << 2   /* keep the device mirror in pool-slot order. Default: entries are ordered
+    GV_CONFIG_KEEP_SLOT_ORDER = 1u << 2,  /* keep the device mirror in pool-slot order. Default: entries are ordered
                                              spatially (Morton code of the root ancestor's position) at every full
                                              rebuild so that neighbouring lanes touch neighbouring Hi-Z texels; all
                                              outputs are reported in pool slots either way */
+    GV_CONFIG_BLOCK_BOUNDS = 1u << 3      /* keep a world-space box per 256-entry cull workgroup (built on the device
+                                             while the pool's mirror is clean) and let a workgroup whose box lies behind
+                                             a frustum plane by more than the rounding margin skip its streams. Same
+                                             results bit for bit (the test is conservative w.r.t. the per-entity one);
+                                             pools that change every frame are culled without boxes. Pays off with the
+                                             default spatial mirror order. Single-view culls only in this version */
 } GvConfigFlags;
 
 /* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as
@@ -283,6 +289,9 @@ typedef struct GvStats {
     uint64_t upload_bytes;           /* H2D mirror bytes since reset */
     uint32_t max_depth;              /* longest parent chain in the mirror */
     uint32_t transform_count, mesh_count[GV_MAX_POOLS];
+    uint64_t bounds_blocks_total;    /* GV_CONFIG_BLOCK_BOUNDS: workgroups of the last cull that ran with boxes (0: none
+                                        since gv_stats_reset) ... */
+    uint64_t bounds_blocks_examined; /* ... and how many of them had to run the per-entity path */
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);

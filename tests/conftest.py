@@ -49,3 +49,12 @@ def gpu_slot_order():
     vis = GpuVisibility(device=0, keep_slot_order=True)
     yield vis
     vis.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_bounds():
+    """Context with GV_CONFIG_BLOCK_BOUNDS (workgroup boxes; conservative block-level frustum rejection)."""
+    from garden_amd.lib import GpuVisibility
+    vis = GpuVisibility(device=0, block_bounds=True)
+    yield vis
+    vis.close()
