@@ -1317,7 +1317,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
     BlockBounds bounds;
     bool use_bounds = false;
-    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !batched && !fused) {
+    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !fused) {
         const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
         if (!current && !(changed && p.changed_prev)) {
@@ -1339,9 +1339,15 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         }
     }
     if (p.occupancy != 0) {
+        if (use_bounds) {
+            bounds.lo = p.d_blk_lo.ptr;
+            bounds.hi = p.d_blk_hi.ptr;
+            bounds.examined = ctx->d_examined.ptr;
+            ctx->bounds_blocks_total = (p.occupancy + kCullBlock - 1) / kCullBlock;
+        }
         if (batched) {
             KernelTimer t(ctx, GV_K_CULL);
-            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream));
+            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
         }
         for (uint32_t v = 0; v < view_count; v++) {
             if (!batched) {
@@ -1349,12 +1355,6 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                 if (fused && v == 0)
                     GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
                 else {
-                    if (use_bounds) {
-                        bounds.lo = p.d_blk_lo.ptr;
-                        bounds.hi = p.d_blk_hi.ptr;
-                        bounds.examined = ctx->d_examined.ptr;
-                        ctx->bounds_blocks_total = (p.occupancy + kCullBlock - 1) / kCullBlock;
-                    }
                     GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
                 }
             }

@@ -304,24 +304,29 @@ __device__ __forceinline__ bool evaluate_slot(const MeshMirror& mesh, const Tran
 // (<= ~4e-6 * M * (depth + 1)). The margin is an order of magnitude above that, so "box behind by more than the margin"
 // implies "every computed corner distance < 0" — the rejected workgroup's entities all fail that plane in the exact
 // test too. Boxes with non-finite members are +-inf and never satisfy the comparison (NaN / +inf are not < -margin).
-__device__ __forceinline__ bool block_behind_frustum(const float4 lo, const float4 hi, const ViewParams& view, uint32_t max_depth)
+__device__ __forceinline__ bool block_behind_planes(const float4 lo, const float4 hi, const float (&planes)[6][4],
+                                                    uint32_t plane_count, const float (&cam)[3], uint32_t max_depth)
 {
     const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
-                      fabsf(view.cam[0]) + fabsf(view.cam[1]) + fabsf(view.cam[2]);
+                      fabsf(cam[0]) + fabsf(cam[1]) + fabsf(cam[2]);
     const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
     bool behind = false;
 #pragma unroll
     for (uint32_t p = 0; p < 6; p++)
-        if (p < view.plane_count) {
-            const float nx = view.planes[p][0], ny = view.planes[p][1], nz = view.planes[p][2];
+        if (p < plane_count) {
+            const float nx = planes[p][0], ny = planes[p][1], nz = planes[p][2];
             // the box corner farthest along the normal, camera-relative
-            const float x = (nx >= 0.0f ? hi.x : lo.x) - view.cam[0];
-            const float y = (ny >= 0.0f ? hi.y : lo.y) - view.cam[1];
-            const float z = (nz >= 0.0f ? hi.z : lo.z) - view.cam[2];
-            const float d = fmaf(nx, x, fmaf(ny, y, fmaf(nz, z, view.planes[p][3])));
+            const float x = (nx >= 0.0f ? hi.x : lo.x) - cam[0];
+            const float y = (ny >= 0.0f ? hi.y : lo.y) - cam[1];
+            const float z = (nz >= 0.0f ? hi.z : lo.z) - cam[2];
+            const float d = fmaf(nx, x, fmaf(ny, y, fmaf(nz, z, planes[p][3])));
             behind = behind || (d < -margin);
         }
     return behind;
+}
+__device__ __forceinline__ bool block_behind_frustum(const float4 lo, const float4 hi, const ViewParams& view, uint32_t max_depth)
+{
+    return block_behind_planes(lo, hi, view.planes, view.plane_count, view.cam, max_depth);
 }
 
 // The per-entity work of one 256-entry workgroup `lb`.
@@ -503,15 +508,40 @@ struct MultiCullArgs {
     uint32_t nviews;
     MultiViewPlanes planes[kMaxBatchViews];
     ViewBuffers outs[kMaxBatchViews];
+    BlockBounds bounds;  // BOUNDS variants only
 };
 
-template <bool HIZ, uint32_t MAP>
+template <bool HIZ, uint32_t MAP, bool BOUNDS>
 __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
 {
     const uint32_t lb = blockIdx.x;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool in_range = i < args.mesh.count;
+    if (BOUNDS) {  // the workgroup is skipped when its box is outside EVERY view of the batch
+        const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
+        bool skip = true;
+        if (!(lo.x > hi.x)) {
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (v < args.nviews)
+                    skip = skip && block_behind_planes(lo, hi, args.planes[v].planes, args.planes[v].plane_count, args.cam,
+                                                       args.xf.max_depth);
+        }
+        if (threadIdx.x == 0)
+            args.bounds.examined[lb] = skip ? 0 : 1;
+        if (skip) {
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (v < args.nviews) {
+                    if (args.planes[v].write_is_visible && in_range)
+                        args.outs[v].is_visible[i] = 0;
+                    if (lane == 0)
+                        args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
+                }
+            return;
+        }
+    }
     Mat34 m;
     Corners c;
     const bool candidate = in_range && prepare_slot<MAP>(args.mesh, args.xf, args.cam, i, m, c);
@@ -550,7 +580,8 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
 }
 
 hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
-                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream)
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
+                             const BlockBounds* bounds)
 {
     if (mesh.count == 0)
         return hipSuccess;
@@ -576,16 +607,21 @@ hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, 
         a.outs[v] = outs[v < nviews ? v : 0];
     }
     const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
-#define GV_LAUNCH_MULTI(HIZ)                                                                            \
-    switch (mesh.mapping) {                                                                            \
-    case kMapExact: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapExact>), grid, block, 0, stream, a); break;         \
-    case kMapSpeculate: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a); break; \
-    default: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a); break;              \
+    a.bounds = bounds ? *bounds : BlockBounds{};
+#define GV_LAUNCH_MULTI(HIZ, BOUNDS)                                                                                            \
+    switch (mesh.mapping) {                                                                                                    \
+    case kMapExact: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapSpeculate, BOUNDS>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapGeneral, BOUNDS>), grid, block, 0, stream, a); break;              \
     }
-    if (a.use_hiz0) {
-        GV_LAUNCH_MULTI(true)
+    if (a.use_hiz0 && bounds) {
+        GV_LAUNCH_MULTI(true, true)
+    } else if (a.use_hiz0) {
+        GV_LAUNCH_MULTI(true, false)
+    } else if (bounds) {
+        GV_LAUNCH_MULTI(false, true)
     } else {
-        GV_LAUNCH_MULTI(false)
+        GV_LAUNCH_MULTI(false, false)
     }
 #undef GV_LAUNCH_MULTI
     return hipGetLastError();

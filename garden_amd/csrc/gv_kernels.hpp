@@ -95,7 +95,8 @@ struct MultiViewPlanes {
     uint32_t write_is_visible;
 };
 hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
-                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream);
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
+                             const BlockBounds* bounds = nullptr);
 hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
                        hipStream_t stream);

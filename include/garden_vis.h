@@ -65,7 +65,7 @@ typedef enum GvConfigFlags {
                                              a frustum plane by more than the rounding margin skip its streams. Same
                                              results bit for bit (the test is conservative w.r.t. the per-entity one);
                                              pools that change every frame are culled without boxes. Pays off with the
-                                             default spatial mirror order. Single-view culls only in this version */
+                                             default spatial mirror order. Batched views skip a workgroup when every view does */
 } GvConfigFlags;
 
 /* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as

@@ -151,3 +151,28 @@ def test_full_size_bounded_cull_matches_the_plain_one(gpu_bounds, gpu, oracle):
             assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
     st = gpu_bounds.stats()
     assert st["bounds_blocks_examined"] < 0.5 * st["bounds_blocks_total"]
+
+
+def test_batched_views_with_boxes(gpu_bounds, oracle):
+    """Main camera + three shadow cascades sharing its position: one pass, a workgroup is skipped only when it is
+    outside all four frusta; every view's outputs equal the per-entity loop's."""
+    gpu = gpu_bounds
+    n = 150_000
+    sc = scene.hierarchy_scene(n, depth=3, fanout=8)
+    bind(gpu, sc)
+    side = 100.0 * n ** (1.0 / 3.0)
+    views = [scene.main_camera_view()] + [scene.cascade_view(size=s * side, depth=3 * side, index=k)
+                                          for k, s in enumerate((0.05, 0.12, 0.3))]
+    gpu.cull(0, views)
+    st = gpu.stats()
+    assert 0 < st["bounds_blocks_examined"] < st["bounds_blocks_total"] == (n + 255) // 256
+    for vi, v in enumerate(views):
+        got = gpu.fetch(vi, write_back=False, occupancy=n)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, v)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])), vi
+        o = np.argsort(exp["visible_idx"], kind="stable")
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+        assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"][o].view(np.uint32))
+        if vi == 0:
+            assert np.array_equal(got["is_visible"], m2["isVisible"])
