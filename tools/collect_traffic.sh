@@ -4,9 +4,10 @@
 # cfg2 @ 10M (frustum-only, known 72 B/entity stream) is the calibration run for this access pattern.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/pmc
 mkdir -p gpurun_out/pmc
-for wl in "cfg3" "cfg2 --entities 10000000"; do
-  tag=$(echo $wl | cut -d" " -f1)
+for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds"; do
+  tag=$(echo $wl | cut -d" " -f1); case "$wl" in *block-bounds*) tag=${tag}bb;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc/${tag}_$c -- python3 bench.py --workload $wl --no-cpu-baseline --no-parity --steps 5 --warmup 2 > gpurun_out/pmc/${tag}_$c.log 2>&1
   done
@@ -14,4 +15,6 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3 -- python3 bench.py --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg4 -- python3 bench.py --workload cfg4 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg2 -- python3 bench.py --workload cfg2 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3bb -- python3 bench.py --block-bounds --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3bb.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg4valu -- python3 bench.py --workload cfg4 --sweep fused-valu --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg4valu.log 2>&1
 ls gpurun_out/pmc

@@ -35,26 +35,34 @@ out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate p
        "word per wave) -> factor = known bytes / (FETCH_SIZE KB * 1024); WRITE_SIZE taken as reported (KB * 1024). Per "
        "launch of gv::cull_kernel. The factor is applied to all reads of cfg3 too, which over-counts its 8-byte Hi-Z "
        "texel gathers (narrow reads are reported closer to 1:1): cfg3's figure is an upper bound."}
-f2, n2 = counter_mean("cfg2", "FETCH_SIZE", "cull_kernel")
-w2, _ = counter_mean("cfg2", "WRITE_SIZE", "cull_kernel")
+PLAIN, BOUNDED = "false>(gv::CullArgs)", "true>(gv::CullArgs)"  # cull_kernel<HIZ, MAP, BOUNDS>
+f2, n2 = counter_mean("cfg2", "FETCH_SIZE", PLAIN)
+w2, _ = counter_mean("cfg2", "WRITE_SIZE", PLAIN)
 known = N * 65 + N / 64 * 8
 factor = known / (f2 * 1024)
 out["fetch_calibration_factor"] = factor
 out["cfg2_at_10M"] = {"FETCH_SIZE_KB": f2, "WRITE_SIZE_KB": w2, "launches": n2,
                       "cull_kernel_hbm_bytes_per_launch": f2 * 1024 * factor + w2 * 1024}
-f3, n3 = counter_mean("cfg3", "FETCH_SIZE", "cull_kernel")
-w3, _ = counter_mean("cfg3", "WRITE_SIZE", "cull_kernel")
+f3, n3 = counter_mean("cfg3", "FETCH_SIZE", PLAIN)
+w3, _ = counter_mean("cfg3", "WRITE_SIZE", PLAIN)
 out["cfg3"] = {"FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "launches": n3,
                "cull_kernel_hbm_bytes_per_launch": f3 * 1024 * factor + w3 * 1024,
                "cull_kernel_hbm_bytes_per_launch_uncalibrated": f3 * 1024 + w3 * 1024}
+if newest("cfg3bb_FETCH_SIZE/*/*counter_collection.csv"):
+    fb, nb = counter_mean("cfg3bb", "FETCH_SIZE", BOUNDED)
+    wb, _ = counter_mean("cfg3bb", "WRITE_SIZE", BOUNDED)
+    out["cfg3_block_bounds"] = {"FETCH_SIZE_KB": fb, "WRITE_SIZE_KB": wb, "launches": nb,
+                                "cull_kernel_hbm_bytes_per_launch": fb * 1024 * factor + wb * 1024}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
     fo.write("workload,kernel,counter,mean_value_KB,launches\n")
-    for wl in ("cfg2", "cfg3"):
+    for wl in ("cfg2", "cfg3", "cfg3bb"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             f = newest(f"{wl}_{counter}/*/*counter_collection.csv")
+            if not f:
+                continue
             acc = {}
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == counter:
@@ -63,7 +71,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
                 if k.startswith("gv::") or "gv::" in k:
                     fo.write(f'{wl}{"@10M" if wl == "cfg2" else ""},"{k}",{counter},{sum(v) / len(v):.3f},{len(v)}\n')
 
-for wl in ("cfg2", "cfg3", "cfg4"):
+for wl in ("cfg2", "cfg3", "cfg4", "cfg3bb", "cfg4valu"):
     ks = newest(f"stats_{wl}/*/*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
