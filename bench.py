@@ -98,22 +98,46 @@ def cpu_baseline(wl, sc, view, depth, seconds=12.0):
     else:
         transforms, e2t = sc.transforms[:sample_n], sc.entity_to_transform
     soa = oracle_py.Avx2Scene(meshes, transforms, e2t)
-    frames, t0 = 0, time.perf_counter()
-    while True:
+
+    def timed(run, seconds):
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds and frames >= 2:
+                return frames, dt
+
+    def frame(threads, avx2):
         hz = oracle_py.Hiz(depth) if wl["hiz"] else None
         if wl["sweep"]:
             oracle_py.world_matrices(transforms, e2t, 0, sample_n)
-        soa.prepare_meshes(view, hiz=hz, threads=cores)
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds and frames >= 2:
-            break
+        if avx2:
+            soa.prepare_meshes(view, hiz=hz, threads=threads)
+        else:
+            oracle_py.prepare_meshes(meshes, transforms, e2t, view, hiz=hz, threads=threads)
+
+    frames, dt = timed(lambda: frame(cores, True), seconds)
+    # also one thread, and the scalar loop over the reference's AoS layouts (short samples)
+    f1, d1 = timed(lambda: frame(1, True), 3.0)
+    fa, da = timed(lambda: frame(cores, False), 3.0)
     soa.close()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return dict(value=sample_n * frames / dt, unit="entity culls/s", cores=cores, kind="port",
                 sample=f"{frames} frames of the first {sample_n} entities of the same scene/view"
                        f"{' incl. 4096^2 pyramid build per frame' if wl['hiz'] else ''}"
                        f"{' incl. scalar world-matrix sweep' if wl['sweep'] else ''}, AVX2+FMA 8-wide SoA path "
-                       f"(bit-identical to the scalar oracle), {cores} threads split like ThreadPool::addItems, {dt:.1f} s")
+                       f"(bit-identical to the scalar oracle), {cores} threads split like ThreadPool::addItems, {dt:.1f} s",
+                cpu_model=model, nproc=cores,
+                avx2_soa_1_thread=sample_n * f1 / d1,
+                scalar_aos_all_threads=sample_n * fa / da)
 
 
 def main():
