@@ -168,24 +168,39 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
         return ((i1 >> l) - (i0 >> l)) <= 1 ? l : l + 1u;
     };
     const uint32_t level = min(max(axis_level(ix0, ix1), axis_level(iy0, iy1)), hz.mip_count - 1u);
-    // Exact early-accept from a coarse, cache-resident level: its texels' min is <= the min over any finer footprint
-    // they cover, so zNear < coarseMin already implies zNear < zFar. Most occluded boxes are decided here and never
-    // touch the 64 MB / 32 MB levels 0 / 1. (Only for nested pyramids; the decision is unchanged either way.)
+    // Exact early decisions from a coarse, cache-resident level (nested pyramids only; the answer is unchanged either
+    // way). Its <= 4 texels cover a superset of the fine footprint, so their min is <= zFar and their max is >= every
+    // fine texel, zFar included:
+    //   zNear <  min(coarse)  =>  zNear < zFar   : occluded  — most occluded boxes end here,
+    //   zNear >= max(coarse)  =>  zNear >= zFar  : visible   — boxes in front of everything around them end here,
+    // and neither touches the 64 MB / 32 MB levels 0 / 1. (A NaN zNear fails both compares and takes the fine path.)
     if (hz.nested && level + kHizCoarseStep < hz.mip_count) {
-        const uint32_t cl = level + kHizCoarseStep;
+        const uint32_t cl = level + kHizCoarseStep;  // >= 4: always a (min, max) level
         const int cw = max((int)(hz.width >> cl), 1), ch = max((int)(hz.height >> cl), 1);
         const int cx0 = min(ix0 >> cl, cw - 1), cx1 = min(ix1 >> cl, cw - 1);
         const int cy0 = min(iy0 >> cl, ch - 1), cy1 = min(iy1 >> cl, ch - 1);
-        float cmin = hiz_min_texel(hz, cl, cw, cx0, cy0);
-        if (cx1 != cx0)
-            cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx1, cy0));
+        const float2* coarse = hz.mips + hz.mip_offset[cl];
+        float2 t = coarse[(uint64_t)cy0 * cw + cx0];
+        float cmin = t.x, cmax = t.y;
+        if (cx1 != cx0) {
+            t = coarse[(uint64_t)cy0 * cw + cx1];
+            cmin = fminf(cmin, t.x);
+            cmax = fmaxf(cmax, t.y);
+        }
         if (cy1 != cy0) {
-            cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx0, cy1));
-            if (cx1 != cx0)
-                cmin = fminf(cmin, hiz_min_texel(hz, cl, cw, cx1, cy1));
+            t = coarse[(uint64_t)cy1 * cw + cx0];
+            cmin = fminf(cmin, t.x);
+            cmax = fmaxf(cmax, t.y);
+            if (cx1 != cx0) {
+                t = coarse[(uint64_t)cy1 * cw + cx1];
+                cmin = fminf(cmin, t.x);
+                cmax = fmaxf(cmax, t.y);
+            }
         }
         if (znear < cmin)
             return true;
+        if (znear >= cmax)
+            return false;
     }
     const int lw = max((int)(hz.width >> level), 1), lh = max((int)(hz.height >> level), 1);
     const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
