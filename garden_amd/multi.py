@@ -1,9 +1,8 @@
 """Multi-GPU exchange step of the visibility pass: one process per GPU, entities sharded by spatial tile,
 no collective on the data path except the all-gatherv of the compacted visible-index lists
 (SURVEY.md §8e). RCCL has no native v-variant: counts are exchanged with one small all-gather, payloads
-either with torch's uneven all_gather (ProcessGroupNCCL lowers it to one grouped broadcast per root — each
-shard then travels over its own xGMI link instead of around a ring) or, on backends without it (gloo in the
-CPU tests), with one broadcast per root.
+with an equal-size all-gather of shards padded to the largest count (nccl) or one broadcast per root (gloo in the
+CPU tests).
 
 Per-frame use goes through `VisibleListExchange`: fixed-capacity padded shards `[count, idx ...]` gathered with ONE
 equal-size all-gather and no host synchronisation (the counts travel in the headers and are checked one round trip
@@ -11,9 +10,6 @@ later), so a rank's next frame is culled while its last list is still on the lin
 exact-size, host-synchronising form (setup, validation, irregular use).
 """
 import torch
-
-_uneven_all_gather_ok = True
-
 
 def tile_of_positions(positions, side, grid):
     """Spatial tile id of each root position for a `grid` = (gx, gy, gz) cut of the world cube."""
@@ -48,14 +44,20 @@ def allgatherv_indices(idx_buf, count, dist, group=None):
     for c in counts_h:
         offs.append(offs[-1] + int(c))
     pieces = [out[offs[r]:offs[r + 1]] for r in range(world)]
-    global _uneven_all_gather_ok
-    if backend == "nccl" and _uneven_all_gather_ok and min(counts_h) > 0:  # empty shards (a tile behind the camera)
-        # go through the per-root path below, which simply skips them
-        try:
-            dist.all_gather(pieces, idx_buf[:count], group=group)  # uneven sizes -> grouped per-root broadcasts
-            return out, counts
-        except (RuntimeError, ValueError):
-            _uneven_all_gather_ok = False  # this torch build wants equal sizes: one broadcast per root instead
+    if backend == "nccl":
+        # RCCL has no v-variant: pad every shard to the largest count and use the plain equal-size all-gather (the most
+        # exercised collective there is), then cut the padding off. Shards are a few MB at most.
+        cap = max(1, int(max(counts_h)))
+        padded = torch.empty(world * cap, dtype=idx_buf.dtype, device=dev)
+        mine = torch.zeros(cap, dtype=idx_buf.dtype, device=dev)
+        if count:
+            mine[:count].copy_(idx_buf[:count])
+        dist.all_gather_into_tensor(padded, mine, group=group)
+        rows = padded.view(world, cap)
+        for r in range(world):
+            if counts_h[r]:
+                pieces[r].copy_(rows[r, :counts_h[r]])
+        return out, counts
     if count:
         pieces[rank].copy_(idx_buf[:count])
     works = []
