@@ -6,8 +6,13 @@
 //                 (render/mesh.hpp:142-146), optional Hi-Z occlusion query (build-defined), wave ballot.
 //   scan_kernel + emit_kernel   replace drawCount.fetch_add + memcpy into combinedMeshes
 //                 (mesh.cpp:177-183) with an order-stable compaction (ballot words + block prefix).
+//   cull_multi_kernel   the same for up to 8 views that share cameraPosition (main camera + shadow cascades,
+//                 mesh.cpp:795-847) in one pass over the streams.
+//   block_bounds_kernel + the BOUNDS variants   opt-in workgroup boxes: conservative block-level frustum rejection.
+//   sort_* / radix_*   sortMeshes (mesh.cpp:265-328): stable radix sort of the compact records by distanceSq.
 //   sweep_*       TransformComponent::calcModel() for every transform slot (transform.hpp:197-214);
 //                 the MFMA form runs the 4x4 chain on v_mfma_f32_4x4x1_16b_f32.
+//   sweep_cull_*  sweep and cull of an exactly paired pool in ONE pass (world matrices + cull outputs).
 //   hiz_*         HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167) with the
 //                 reduction rule of shaders/hiz.frag:23-63.
 //
