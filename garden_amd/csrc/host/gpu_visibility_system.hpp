@@ -70,13 +70,14 @@ public:
     // rides on the first pool's cull (GV_SWEEP_WITH_CULL), fused into one pass when that pool is exactly paired
     bool sweepWorldMatrices = false;
 
-    explicit GpuVisibilitySystem(int device = 0, bool profile = false)
+    // blockBounds: GV_CONFIG_BLOCK_BOUNDS — worth it when most of the world is static (same results either way)
+    explicit GpuVisibilitySystem(int device = 0, bool profile = false, bool blockBounds = false)
     {
         GvConfig config{};
         config.struct_size = sizeof(GvConfig);
         config.device = device;
         config.hiz_rule = GV_HIZ_RULE_REFERENCE;
-        config.flags = profile ? GV_CONFIG_PROFILE_EVENTS : 0;
+        config.flags = (profile ? GV_CONFIG_PROFILE_EVENTS : 0) | (blockBounds ? GV_CONFIG_BLOCK_BOUNDS : 0);
         if (gv_create(&config, &ctx) != GV_OK)
             throw GardenError(std::string("GpuVisibilitySystem: ") + gv_last_error(nullptr));
         setUiSize(1.0f, 1.0f);

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -160,7 +160,7 @@ int main(int argc, char** argv)
 {
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
-    bool hier = false, mutate = false, mixed = false, toggle = false;
+    bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) mode = argv[++i];
@@ -170,6 +170,7 @@ int main(int argc, char** argv)
         else if (a == "--hier") hier = true;
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
+        else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
     }
     try {
@@ -201,7 +202,7 @@ int main(int argc, char** argv)
             cpu->threads = threads;
         }
         if (mode == "gpu" || mode == "both")
-            gpu = manager.createSystem<GpuVisibilitySystem>(0, false);
+            gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
         manager.initialize();
 
         // scene: SURVEY.md §8d distribution (cube side 100 * N^(1/3), scale [0.5,2], half-extent [0.25,1])

@@ -65,6 +65,8 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "20000", "--toggle"],
     ["--entities", "40000", "--mixed"],
     ["--entities", "40000", "--mixed", "--hier", "--mutate"],
+    ["--entities", "60000", "--hier", "--toggle", "--bounds", "--ticks", "4"],
+    ["--entities", "40000", "--mixed", "--bounds"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", "--ticks", "3", *args)
