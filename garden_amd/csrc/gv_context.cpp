@@ -314,6 +314,7 @@ template <typename F>
 void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
 {
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    // 16 threads: measured on the 256-thread box, 64 made the 10 M gather slower (60 vs 34 ms)
     const uint32_t threads = count < (1u << 16) ? 1u : std::min(hw, 16u);
     if (threads == 1) {
         fn(first, first + count);
@@ -655,15 +656,17 @@ int upload_transforms_scattered(GvCtx* ctx, uint32_t lo, uint32_t hi)
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
         return rc;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t j = ctx->xinv[lo + k];
-        ctx->sc_idx.ptr[k] = j;
-        ctx->sc_a.ptr[k] = ctx->h_xa.ptr[j];
-        ctx->sc_b.ptr[k] = ctx->h_xb.ptr[j];
-        ctx->sc_c.ptr[k] = ctx->h_xc.ptr[j];
-        ctx->sc_u8.ptr[k] = ctx->h_xflags.ptr[j];
-        ctx->sc_u32.ptr[k] = ctx->h_xparent.ptr[j];
-    }
+    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
+        for (uint32_t k = a; k < b; k++) {
+            const uint32_t j = ctx->xinv[lo + k];
+            ctx->sc_idx.ptr[k] = j;
+            ctx->sc_a.ptr[k] = ctx->h_xa.ptr[j];
+            ctx->sc_b.ptr[k] = ctx->h_xb.ptr[j];
+            ctx->sc_c.ptr[k] = ctx->h_xc.ptr[j];
+            ctx->sc_u8.ptr[k] = ctx->h_xflags.ptr[j];
+            ctx->sc_u32.ptr[k] = ctx->h_xparent.ptr[j];
+        }
+    });
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, ctx->d_xa.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_b.ptr, ctx->dsc_b.ptr, ctx->d_xb.ptr, n)) != GV_OK) return rc;
@@ -681,13 +684,15 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
         return rc;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t j = p.inv[lo + k];
-        ctx->sc_idx.ptr[k] = j;
-        ctx->sc_a.ptr[k] = p.h_a.ptr[j];
-        ctx->sc_c.ptr[k] = p.h_b.ptr[j];
-        ctx->sc_u32.ptr[k] = p.h_link.ptr[j];
-    }
+    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
+        for (uint32_t k = a; k < b; k++) {
+            const uint32_t j = p.inv[lo + k];
+            ctx->sc_idx.ptr[k] = j;
+            ctx->sc_a.ptr[k] = p.h_a.ptr[j];
+            ctx->sc_c.ptr[k] = p.h_b.ptr[j];
+            ctx->sc_u32.ptr[k] = p.h_link.ptr[j];
+        }
+    });
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, p.d_a.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, p.d_b.ptr, n)) != GV_OK) return rc;
