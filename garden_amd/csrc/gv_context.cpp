@@ -515,30 +515,34 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
         p.inv[p.perm[j]] = j;
 }
 
+// pool slot s -> SoA staging at mirror entry j
+inline void gather_transform(GvCtx* ctx, uint32_t s, uint32_t j)
+{
+    const TransformBinding& xf = ctx->xf;
+    const float* pos = xf.position.f32(s);
+    const float* scl = xf.scale.f32(s);
+    const float* rot = xf.rotation.f32(s);
+    const uint32_t entity = xf.entity.u32(s);
+    uint8_t flags = 0;
+    if (entity)
+        flags |= kXfLive;
+    if (xf.self_active.u8(s) && xf.ancestors_active.u8(s))
+        flags |= kXfActive;
+    if (xf.model_with_ancestors.u8(s))
+        flags |= kXfWithAncestors;
+    ctx->h_xa.ptr[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
+    ctx->h_xb.ptr[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+    ctx->h_xc.ptr[j] = make_float2(scl[1], scl[2]);
+    ctx->h_xflags.ptr[j] = flags;
+    ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, xf.parent.u32(s)));
+}
+
 // AoS slots [lo, hi) -> SoA staging at their mirror entries
 void gather_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
 {
-    const TransformBinding& xf = ctx->xf;
     parallel_ranges(lo, hi - lo, [&](uint32_t a, uint32_t b) {
-        for (uint32_t s = a; s < b; s++) {
-            const float* pos = xf.position.f32(s);
-            const float* scl = xf.scale.f32(s);
-            const float* rot = xf.rotation.f32(s);
-            const uint32_t entity = xf.entity.u32(s);
-            uint8_t flags = 0;
-            if (entity)
-                flags |= kXfLive;
-            if (xf.self_active.u8(s) && xf.ancestors_active.u8(s))
-                flags |= kXfActive;
-            if (xf.model_with_ancestors.u8(s))
-                flags |= kXfWithAncestors;
-            const uint32_t j = xslot_to_mirror(ctx, s);
-            ctx->h_xa.ptr[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
-            ctx->h_xb.ptr[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
-            ctx->h_xc.ptr[j] = make_float2(scl[1], scl[2]);
-            ctx->h_xflags.ptr[j] = flags;
-            ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, xf.parent.u32(s)));
-        }
+        for (uint32_t s = a; s < b; s++)
+            gather_transform(ctx, s, xslot_to_mirror(ctx, s));
     });
 }
 
@@ -609,6 +613,29 @@ int upload_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xflags.ptr + lo, ctx->h_xflags.ptr + lo, n, hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xparent.ptr + lo, ctx->h_xparent.ptr + lo, n * 4, hipMemcpyHostToDevice, ctx->stream));
     ctx->stats.upload_bytes += n * 45;
+    return GV_OK;
+}
+
+// Dense re-mirror of the dirty slots [lo, hi) of a pool whose mirror is mostly dirty: walk the MIRROR in chunks, gather
+// the dirty entries of a chunk, enqueue the chunk's upload, go on gathering — the DMA of one chunk runs under the host
+// gather of the next (gather-all-then-upload-all costs their sum).
+int regather_transforms_pipelined(GvCtx* ctx, uint32_t lo, uint32_t hi)
+{
+    const uint32_t n = ctx->xf.occupancy;
+    constexpr uint32_t kChunk = 1u << 19;
+    for (uint32_t j0 = 0; j0 < n; j0 += kChunk) {
+        const uint32_t j1 = std::min(n, j0 + kChunk);
+        parallel_ranges(j0, j1 - j0, [&](uint32_t a, uint32_t b) {
+            for (uint32_t j = a; j < b; j++) {
+                const uint32_t s = ctx->xperm.empty() ? j : ctx->xperm[j];
+                if (s >= lo && s < hi)
+                    gather_transform(ctx, s, j);
+            }
+        });
+        const int rc = upload_transforms(ctx, j0, j1);
+        if (rc != GV_OK)
+            return rc;
+    }
     return GV_OK;
 }
 
@@ -780,14 +807,13 @@ int sync_mirror(GvCtx* ctx)
         staged = true;
         const uint32_t lo = ctx->xf_dirty.lo, hi = std::min(ctx->xf_dirty.hi, n);
         if (lo < hi) {
-            gather_transforms(ctx, lo, hi);
             int rc;
-            if (ctx->xinv.empty())
-                rc = upload_transforms(ctx, lo, hi);
-            else if ((size_t)(hi - lo) * 2 > n)
-                rc = upload_transforms(ctx, 0, n);  // most of the pool: one dense upload beats a scatter
-            else
-                rc = upload_transforms_scattered(ctx, lo, hi);
+            if ((size_t)(hi - lo) * 2 > n) {
+                rc = regather_transforms_pipelined(ctx, lo, hi);  // most of the pool: dense, chunked, DMA under gather
+            } else {
+                gather_transforms(ctx, lo, hi);
+                rc = ctx->xinv.empty() ? upload_transforms(ctx, lo, hi) : upload_transforms_scattered(ctx, lo, hi);
+            }
             if (rc != GV_OK)
                 return rc;
             GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
