@@ -133,3 +133,27 @@ def test_random_worlds_match_the_oracle(gpu, gpu_slot_order, gpu_bounds, oracle,
         for mode in (0, 1):
             vis.sweep(mode)
             assert np.array_equal(vis.get_world(0, sc.transforms.shape[0]).view(np.uint32), exp_w.view(np.uint32)), mode
+        # sweep riding on the cull (fused when the pool is exactly paired, two launches otherwise)
+        for mode in (2, 3):
+            vis.mark_dirty(0, 0, sc.transforms.shape[0])
+            vis.sweep(mode)
+            check(vis, oracle, sc, [views[0]], hz)
+            assert np.array_equal(vis.get_world(0, sc.transforms.shape[0]).view(np.uint32), exp_w.view(np.uint32)), mode
+        # edits reported as dirty ranges: TRS + flags of a transform range, boxes / enable bits of a mesh range, a few
+        # re-parentings towards lower slots (ranged GV_DIRTY_HIERARCHY)
+        nt, nm = sc.transforms.shape[0], sc.count
+        lo = int(rng.integers(0, nt)); cnt = int(rng.integers(1, nt - lo + 1))
+        sc.transforms["position"][lo:lo + cnt, :3] += rng.normal(0, 0.2 * spread, (cnt, 3)).astype(np.float32)
+        sc.transforms["selfActive"][lo:lo + cnt] ^= (rng.random(cnt) < 0.2).astype(np.uint8)
+        vis.mark_dirty(0, lo, cnt)
+        mlo = int(rng.integers(0, nm)); mcnt = int(rng.integers(1, nm - mlo + 1))
+        sc.meshes["aabbMax"][mlo:mlo + mcnt, :3] += np.float32(0.25)
+        sc.meshes["isEnabled"][mlo:mlo + mcnt] ^= (rng.random(mcnt) < 0.1).astype(np.uint8)
+        vis.mark_dirty(2, mlo, mcnt, pool_id=0)
+        if nt > 4:
+            hlo = int(rng.integers(1, nt - 1)); hcnt = int(rng.integers(1, min(16, nt - hlo) + 1))
+            for s_ in range(hlo, hlo + hcnt):
+                sc.transforms["parent"][s_] = sc.transforms["entity"][int(rng.integers(0, s_))]
+            vis.mark_dirty(1, hlo, hcnt)
+        check(vis, oracle, sc, [views[0]], hz)
+        check(vis, oracle, sc, shared, hz)
