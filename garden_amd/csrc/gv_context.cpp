@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -405,40 +406,75 @@ int build_transform_order(GvCtx* ctx)
     ctx->xinv.clear();
     if ((ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER) || n < 2)
         return GV_OK;
-    // root ancestor of every slot (memoised walk; a cycle is reported here, transform.cpp:137-143)
+    // root ancestor of every slot. Fast path: every slot walks its own chain on the gather threads (chains are short);
+    // a chain longer than kWalkCap — very deep, or a cycle — sends the whole pool through the serial memoised walk,
+    // which also reports cycles (transform.cpp:137-143).
     std::vector<uint32_t> root(n, UINT32_MAX);
-    std::vector<uint32_t> path;
-    for (uint32_t s = 0; s < n; s++) {
-        if (root[s] != UINT32_MAX)
-            continue;
-        path.clear();
-        uint32_t cur = s;
-        for (;;) {
-            if (root[cur] != UINT32_MAX) {
-                cur = root[cur];
-                break;
+    constexpr uint32_t kWalkCap = 1u << 12;
+    std::atomic<bool> capped{false};
+    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
+        for (uint32_t s = a; s < b && !capped.load(std::memory_order_relaxed); s++) {
+            uint32_t cur = s, steps = 0;
+            for (;;) {
+                const uint32_t ps = entity_slot(xf, xf.parent.u32(cur));
+                if (ps == kSlotNone)
+                    break;
+                cur = ps;
+                if (++steps > kWalkCap) {
+                    capped.store(true, std::memory_order_relaxed);
+                    break;
+                }
             }
-            path.push_back(cur);
-            if (path.size() > n)
-                return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", s);
-            const uint32_t ps = entity_slot(xf, xf.parent.u32(cur));
-            if (ps == kSlotNone)
-                break;
-            cur = ps;
+            root[s] = cur;
         }
-        for (uint32_t v : path)
-            root[v] = cur;
-    }
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t s = 0; s < n; s++) {
-        if (root[s] != s || !xf.entity.u32(s))
-            continue;
-        const float* pos = xf.position.f32(s);
-        for (int k = 0; k < 3; k++)
-            if (std::isfinite(pos[k])) {
-                lo[k] = std::min(lo[k], pos[k]);
-                hi[k] = std::max(hi[k], pos[k]);
+    });
+    if (capped) {
+        std::fill(root.begin(), root.end(), UINT32_MAX);
+        std::vector<uint32_t> path;
+        for (uint32_t s = 0; s < n; s++) {
+            if (root[s] != UINT32_MAX)
+                continue;
+            path.clear();
+            uint32_t cur = s;
+            for (;;) {
+                if (root[cur] != UINT32_MAX) {
+                    cur = root[cur];
+                    break;
+                }
+                path.push_back(cur);
+                if (path.size() > n)
+                    return ctx->fail(GV_E_ARG, "transform hierarchy has a cycle through slot %u", s);
+                const uint32_t ps = entity_slot(xf, xf.parent.u32(cur));
+                if (ps == kSlotNone)
+                    break;
+                cur = ps;
             }
+            for (uint32_t v : path)
+                root[v] = cur;
+        }
+    }
+    // bounding box of the live roots (per-thread partial boxes; min / max are order-independent)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    {
+        std::mutex merge;
+        parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
+            float tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t s = a; s < b; s++) {
+                if (root[s] != s || !xf.entity.u32(s))
+                    continue;
+                const float* pos = xf.position.f32(s);
+                for (int k = 0; k < 3; k++)
+                    if (std::isfinite(pos[k])) {
+                        tl[k] = std::min(tl[k], pos[k]);
+                        th[k] = std::max(th[k], pos[k]);
+                    }
+            }
+            std::lock_guard<std::mutex> g(merge);
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], tl[k]);
+                hi[k] = std::max(hi[k], th[k]);
+            }
+        });
     }
     auto spread = [](uint32_t v) {  // 10 bits -> every third bit
         v = (v | (v << 16)) & 0x030000FFu;
@@ -469,8 +505,10 @@ int build_transform_order(GvCtx* ctx)
         ctx->xperm[s] = s;
     radix_order(code, ctx->xperm);
     ctx->xinv.resize(n);
-    for (uint32_t j = 0; j < n; j++)
-        ctx->xinv[ctx->xperm[j]] = j;
+    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
+        for (uint32_t j = a; j < b; j++)
+            ctx->xinv[ctx->xperm[j]] = j;  // a permutation: every write lands on its own element
+    });
     return GV_OK;
 }
 
