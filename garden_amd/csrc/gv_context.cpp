@@ -50,6 +50,32 @@ struct DeviceBuf {  // grow-only device allocation (scratch vectors grow, never 
             cap = n;
         return e;
     }
+    // like reserve, but the first `keep` elements survive (pool growth: the mirror is appended to, not rebuilt);
+    // capacity grows by half so that steady appends do not reallocate every frame
+    hipError_t grow(size_t n, size_t keep, hipStream_t stream)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        const size_t want = std::max(n, cap + cap / 2);
+        T* fresh = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        if (ptr && keep) {
+            e = hipMemcpyAsync(fresh, ptr, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                (void)hipFree(fresh);
+                return e;
+            }
+        }
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
+    }
     void release()
     {
         if (ptr)
@@ -75,6 +101,23 @@ struct PinnedBuf {
         if (e == hipSuccess)
             cap = n;
         return e;
+    }
+    hipError_t grow(size_t n, size_t keep)  // the caller has drained every async copy that reads this buffer
+    {
+        if (n <= cap)
+            return hipSuccess;
+        const size_t want = std::max(n, cap + cap / 2);
+        T* fresh = nullptr;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess)
+            return e;
+        if (ptr && keep)
+            memcpy(fresh, ptr, std::min(keep, cap) * sizeof(T));
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
     }
     void release()
     {
@@ -138,6 +181,7 @@ struct PoolState {
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    uint32_t mirrored = 0, appended = 0;  // entries the mirror holds / of those, appended (unsorted) since the last full build
     uint64_t epoch = 1, bounds_epoch = 0, bounds_xf_epoch = 0;  // epoch: bumped whenever this pool's mirror changes
     uint64_t seen_epoch = 0, seen_xf_epoch = 0;                 // state at this pool's previous gv_cull
     bool changed_prev = false;                                  // ... and whether it had changed then too (dynamic pool)
@@ -184,6 +228,7 @@ struct GvCtx {
     bool xf_need_full = false;
     bool sweep_with_cull_mfma = true;
     uint64_t xf_epoch = 1;  // bumped whenever the transform mirror changes
+    uint32_t xf_mirrored = 0, xf_appended = 0;  // as PoolState::mirrored / appended, for the transform pool
     DeviceBuf<uint8_t> d_examined;  // block-bounds statistics of the LAST bounded cull: 1 byte per workgroup
     uint64_t bounds_blocks_total = 0;
     bool sweep_with_cull = false;  // GV_SWEEP_WITH_CULL requested: the next gv_cull also writes the world matrices
@@ -767,6 +812,84 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
     return GV_OK;
 }
 
+// Pool growth (entities created since the last sync): the new slots [n0, n1) are appended to the mirror as entries
+// [n0, n1) — identity on the tail of the permutation — instead of rebuilding it; they stay outside the spatial order
+// until the next full build, which sync_mirror schedules once the unsorted tail passes 1/8 of the pool.
+int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
+{
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GV_HIP(ctx, ctx->d_xa.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xb.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xc.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xflags.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xparent.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xactive.grow((size_t)n1 / 64 + 1, 0, ctx->stream));  // re-derived below
+    GV_HIP(ctx, ctx->h_xa.grow(n1, n0));
+    GV_HIP(ctx, ctx->h_xb.grow(n1, n0));
+    GV_HIP(ctx, ctx->h_xc.grow(n1, n0));
+    GV_HIP(ctx, ctx->h_xflags.grow(n1, n0));
+    GV_HIP(ctx, ctx->h_xparent.grow(n1, n0));
+    if (!ctx->xperm.empty()) {
+        ctx->xperm.resize(n1);
+        ctx->xinv.resize(n1);
+        for (uint32_t s = n0; s < n1; s++)
+            ctx->xperm[s] = ctx->xinv[s] = s;
+        GV_HIP(ctx, ctx->d_xinv.grow(n1, n0, ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(ctx->d_xinv.ptr + n0, ctx->xinv.data() + n0, (size_t)(n1 - n0) * 4, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
+    }
+    gather_transforms(ctx, n0, n1);
+    bool chained = ctx->max_depth != 0;
+    for (uint32_t j = n0; j < n1 && !chained; j++)
+        chained = ctx->h_xparent.ptr[j] != kSlotNone;
+    if (chained) {  // new slots with parents (or a pool that already has chains): depth / cycle check over the links
+        uint32_t depth = 0;
+        const int rc = compute_max_depth(ctx, &depth);
+        if (rc != GV_OK) {
+            ctx->xf_need_full = true;
+            return rc;
+        }
+        ctx->max_depth = depth;
+    }
+    const int rc = upload_transforms(ctx, n0, n1);
+    if (rc != GV_OK)
+        return rc;
+    GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n1, ctx->d_xactive.ptr, ctx->stream));
+    ctx->xf_mirrored = n1;
+    ctx->xf_appended += n1 - n0;
+    ctx->world_valid = false;
+    ctx->xf_epoch++;
+    return GV_OK;
+}
+
+int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
+{
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GV_HIP(ctx, p.d_a.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, p.d_b.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, p.d_link.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, p.h_a.grow(n1, n0));
+    GV_HIP(ctx, p.h_b.grow(n1, n0));
+    GV_HIP(ctx, p.h_link.grow(n1, n0));
+    if (!p.perm.empty()) {
+        p.perm.resize(n1);
+        p.inv.resize(n1);
+        for (uint32_t i = n0; i < n1; i++)
+            p.perm[i] = p.inv[i] = i;
+        GV_HIP(ctx, p.d_orig.grow(n1, n0, ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(p.d_orig.ptr + n0, p.perm.data() + n0, (size_t)(n1 - n0) * 4, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
+    }
+    gather_meshes(ctx, p, n0, n1);
+    const int rc = upload_meshes(ctx, p, n0, n1);
+    if (rc != GV_OK)
+        return rc;
+    p.mirrored = n1;
+    p.appended += n1 - n0;
+    p.epoch++;
+    return GV_OK;
+}
+
 struct PhaseTimer {  // GV_DEBUG_TIMING=1: prints the host phases of a mirror build
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     bool on = getenv("GV_DEBUG_TIMING") != nullptr;
@@ -788,6 +911,10 @@ int sync_mirror(GvCtx* ctx)
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = ctx->xf.occupancy;
     bool staged = false;
+    const bool spatial = !(ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER);
+    if (!ctx->xf_need_full && n > ctx->xf_mirrored && spatial &&
+        ((uint64_t)ctx->xf_appended + (n - ctx->xf_mirrored)) * 8 > n && n >= 1024)
+        ctx->xf_need_full = true;  // too much of the pool sits in the unsorted tail: re-order everything
     if (ctx->xf_need_full) {
         // staging is about to be rewritten: make sure earlier async uploads have drained
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -836,11 +963,20 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
         ctx->xf_epoch++;
+        ctx->xf_mirrored = n;
+        ctx->xf_appended = 0;
         // transform entries may have moved: every mesh pool's slot column must be re-resolved
         for (auto& p : ctx->pools)
             if (p.bound)
                 p.need_full = true;
-    } else if (ctx->xf_dirty.any()) {
+    } else {
+      if (n > ctx->xf_mirrored) {
+        staged = true;
+        const int rc = grow_transforms(ctx, ctx->xf_mirrored, n);
+        if (rc != GV_OK)
+            return rc;
+      }
+      if (ctx->xf_dirty.any()) {
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         staged = true;
         const uint32_t lo = ctx->xf_dirty.lo, hi = std::min(ctx->xf_dirty.hi, n);
@@ -869,10 +1005,20 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_dirty.clear();
         ctx->world_valid = false;
         ctx->xf_epoch++;
+      }
     }
     for (auto& p : ctx->pools) {
         if (!p.bound)
             continue;
+        if (!p.need_full && p.occupancy > p.mirrored && spatial &&
+            ((uint64_t)p.appended + (p.occupancy - p.mirrored)) * 8 > p.occupancy && p.occupancy >= 1024)
+            p.need_full = true;
+        if (!p.need_full && p.occupancy > p.mirrored) {
+            staged = true;
+            const int rc = grow_meshes(ctx, p, p.mirrored, p.occupancy);
+            if (rc != GV_OK)
+                return rc;
+        }
         if (p.need_full) {
             if (!staged) {
                 GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -915,6 +1061,8 @@ int sync_mirror(GvCtx* ctx)
             p.need_full = false;
             p.dirty.clear();
             p.epoch++;
+            p.mirrored = p.occupancy;
+            p.appended = 0;
         } else if (p.dirty.any()) {
             if (!staged) {
                 GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1196,7 +1344,8 @@ int gv_transform_bind_columns(GvCtx* ctx, const GvTransformColumns* columns, uin
         if (occupancy && (!all[k]->data || all[k]->stride < width[k]))
             return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: column %d is NULL or its stride is below %u bytes", k, width[k]);
     auto col = [](const GvColumn& g) { return Column{static_cast<const uint8_t*>(g.data), g.stride}; };
-    const bool moved = !ctx->xf.bound || ctx->xf.occupancy != occupancy;
+    // first bind or a pool that shrank: rebuild. A pool that GREW keeps its mirror; gv_sync appends the new slots.
+    const bool moved = !ctx->xf.bound || occupancy < ctx->xf.occupancy;
     ctx->xf.entity = col(columns->entity);
     ctx->xf.parent = col(columns->parent);
     ctx->xf.position = col(columns->position);
@@ -1255,7 +1404,7 @@ int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* colu
         return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: is_visible_stride is 0");
     auto col = [](const GvColumn& g) { return Column{static_cast<const uint8_t*>(g.data), g.stride}; };
     PoolState& p = ctx->pools[pool_id];
-    const bool moved = !p.bound || p.occupancy != occupancy;
+    const bool moved = !p.bound || occupancy < p.occupancy;
     p.entity = col(columns->entity);
     p.is_enabled = col(columns->is_enabled);
     p.aabb_min = col(columns->aabb_min);

@@ -100,6 +100,7 @@ public:
     T* getData() const noexcept { return items; }
     uint32_t getOccupancy() const noexcept { return occupancy; }
     uint32_t getCount() const noexcept { return occupancy - (uint32_t)freeItems.size(); }
+    const std::vector<ID<T>>& getGarbage() const noexcept { return garbageItems; }  // destroyed, not yet disposed
 };
 
 class Manager;

@@ -86,7 +86,20 @@ public:
     uint32_t flagsLo = UINT32_MAX, flagsHi = 0;
     void clearFlagsRange() noexcept { flagsLo = UINT32_MAX; flagsHi = 0; }
 
-    View<TransformComponent> add(ID<Entity> entity) { hierarchyVersion++; return addTo(entity); }
+    // hierarchyVersion is left for structural changes nobody itemised (consumers rebuild their mirror); creating and
+    // destroying entities is itemised: the slots involved are recorded like any other change
+    View<TransformComponent> add(ID<Entity> entity)
+    {
+        auto view = addTo(entity);
+        touchFlags((uint32_t)(*view - components.getData()));
+        return view;
+    }
+    void disposeComponents() override  // the slots are wiped (entity = null) here, at the end of the frame
+    {
+        for (auto id : components.getGarbage())
+            touchFlags(*id - 1);
+        ComponentSystem<TransformComponent>::disposeComponents();
+    }
     // transform.cpp:129-195: unlink from the old parent's childs[] (order kept), append to the new one, take
     // ancestorsActive from the new parent — for this entity only: the reference does not push it down the subtree
     void setParent(ID<Entity> entity, ID<Entity> newParent)
@@ -164,12 +177,17 @@ public:
                 if (auto child = tryGetOf(view->childs[i])) {
                     child->parent = {};
                     child->ancestorsActive = true;
+                    const uint32_t childSlot = (uint32_t)(*child - components.getData());
+                    touchFlags(childSlot);
+                    reparentLo = std::min(reparentLo, childSlot);
+                    reparentHi = std::max(reparentHi, childSlot + 1);
+                    reparentVersion++;
                 }
             std::free(view->childs);
             view->childs = nullptr;
             view->setChildCount(0);
             view->setChildCapacity(0);
-            hierarchyVersion++;
+            touchFlags((uint32_t)(*view - components.getData()));
         }
         ComponentSystem<TransformComponent>::removeOf(entity);
     }
@@ -236,15 +254,42 @@ public:
 // of their MeshRenderComponent-derived struct and report a MeshRenderType, render/mesh.hpp:60-147).
 class VersionedMeshSystem {
 public:
-    uint64_t meshVersion = 0;  // bumped by add()/markMeshesChanged(); consumers re-mirror the pool
+    uint64_t meshVersion = 0;  // bumped by markMeshesChanged(): consumers re-mirror the whole pool
     void markMeshesChanged() noexcept { meshVersion++; }
+    // itemised changes (components created / destroyed / edited through touchMesh): only [meshLo, meshHi) moves
+    uint64_t rangeVersion = 0;
+    uint32_t meshLo = UINT32_MAX, meshHi = 0;
+    void touchMesh(uint32_t slot) noexcept
+    {
+        meshLo = std::min(meshLo, slot);
+        meshHi = std::max(meshHi, slot + 1);
+        rangeVersion++;
+    }
+    void clearMeshRange() noexcept { meshLo = UINT32_MAX; meshHi = 0; }
 };
 template <class C, MeshRenderType TYPE>
 class MeshSystemOf : public ComponentSystem<C, false>, public IMeshRenderSystem, public VersionedMeshSystem {
     static_assert(std::is_base_of<MeshRenderComponent, C>::value, "mesh components derive from MeshRenderComponent");
 
 public:
-    View<C> add(ID<Entity> entity) { meshVersion++; return this->addTo(entity); }
+    View<C> add(ID<Entity> entity)
+    {
+        auto view = this->addTo(entity);
+        touchMesh((uint32_t)(*view - this->components.getData()));
+        return view;
+    }
+    void removeOf(ID<Entity> entity) override
+    {
+        if (auto view = this->tryGetOf(entity))
+            touchMesh((uint32_t)(*view - this->components.getData()));
+        ComponentSystem<C, false>::removeOf(entity);
+    }
+    void disposeComponents() override
+    {
+        for (auto id : this->components.getGarbage())
+            touchMesh(*id - 1);
+        ComponentSystem<C, false>::disposeComponents();
+    }
     MeshRenderType getMeshRenderType() const override { return TYPE; }
     uint8_t* getMeshComponentData() const override { return reinterpret_cast<uint8_t*>(this->components.getData()); }
     uint32_t getMeshComponentOccupancy() const override { return this->components.getOccupancy(); }

@@ -299,7 +299,11 @@ private:
                 if (seenMesh[p] != versioned->meshVersion) {
                     check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
                     seenMesh[p] = versioned->meshVersion;
+                } else if (versioned->meshLo < versioned->meshHi) {  // created / destroyed / edited components only
+                    check(gv_mark_dirty(ctx, GV_DIRTY_MESH, (p << 28) | versioned->meshLo, versioned->meshHi - versioned->meshLo),
+                          "gv_mark_dirty");
                 }
+                versioned->clearMeshRange();
             } else {  // unknown writer: re-mirror the pool every frame (always correct)
                 check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
             }

@@ -95,7 +95,10 @@ typedef struct GvMeshLayout {
 /* Binds the TransformComponent pool and the entity -> transform-slot map that stands in for
  * Manager::tryGet<TransformComponent>(entity) (mesh.cpp:149) / Manager::get (transform.hpp:206).
  * Re-issue whenever getData() may have moved (create() can reallocate: docs/ECS/Entities.md:44-46).
- * Pointers must stay valid until the next gv_sync()/gv_cull() returns; nothing is retained after. */
+ * Pointers must stay valid until the next gv_sync()/gv_cull() returns; nothing is retained after.
+ * Occupancy may grow from one bind to the next (entities were created): the new slots are appended to the device
+ * mirror at the next sync — no rebuild; a smaller occupancy rebuilds it. The same holds for gv_pool_bind. Slots whose
+ * contents changed (filled, emptied, edited) are reported with gv_mark_dirty as always. */
 int gv_transform_bind(GvCtx* ctx, const void* base, size_t stride, uint32_t occupancy,
                       const GvTransformLayout* layout, const uint32_t* entity_to_transform,
                       uint32_t entity_capacity);

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -161,6 +161,7 @@ int main(int argc, char** argv)
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false;
+    uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) mode = argv[++i];
@@ -170,6 +171,7 @@ int main(int argc, char** argv)
         else if (a == "--hier") hier = true;
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
+        else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
     }
@@ -209,7 +211,7 @@ int main(int argc, char** argv)
         Rng rng;
         const float side = 100.0f * std::cbrt((float)entities);
         std::vector<ID<Entity>> ents;
-        for (uint32_t i = 0; i < entities; i++) {
+        auto spawn = [&](uint32_t i) {
             auto e = manager.createEntity();
             ents.push_back(e);
             auto t = transformSystem->add(e);
@@ -235,7 +237,10 @@ int main(int argc, char** argv)
             const uint32_t r = rng.next() % 100;
             if (r == 0) m->isEnabled = false;
             if (r == 1) m->aabb.max = m->aabb.min;
-        }
+            return e;
+        };
+        for (uint32_t i = 0; i < entities; i++)
+            spawn(i);
         if (hier)  // every entity beyond the first tenth gets a parent among earlier entities: depth ~4
             for (uint32_t i = entities / 10; i < entities; i++) {
                 if (mixed && i % 8 == 7)
@@ -316,7 +321,7 @@ int main(int argc, char** argv)
                 transSystem->markMeshesChanged(); oitSystem->markMeshesChanged();
                 uiSystem->markMeshesChanged(); glassSystem->markMeshesChanged();
             }
-            transformSystem->hierarchyVersion++;  // entities were destroyed: full rebuild
+            // destroying entities needs no rebuild request: TransformSystem / the mesh systems itemise the slots
             graphicsSystem->setCamera(viewProj, f32x4(12.5f, -3.0f, 40.0f));
         };
 
@@ -324,10 +329,38 @@ int main(int argc, char** argv)
         std::string why;
         double seconds = 0;
         uint32_t drawCount = 0, sortedDrawCount = 0;
-        int rounds = mutate ? 2 : 1;
+        std::vector<bool> gone(entities, false);
+        auto doChurn = [&]() {  // ~1 % destroyed, ~2 % created (some under existing parents), a few flags flipped
+            const uint32_t count = (uint32_t)ents.size();
+            for (uint32_t k = 0; k < count / 100 + 1; k++) {
+                const uint32_t i = rng.next() % count;
+                if (!gone[i]) {
+                    manager.destroy(ents[i]);
+                    gone[i] = true;
+                }
+            }
+            for (uint32_t k = 0; k < count / 50 + 1; k++) {
+                const uint32_t i = (uint32_t)ents.size();
+                auto e = spawn(i);
+                gone.push_back(false);
+                if (hier && (k & 1)) {
+                    const uint32_t parent = rng.next() % count;
+                    if (!gone[parent] && transformSystem->tryGetOf(ents[parent]))
+                        transformSystem->setParent(e, ents[parent]);
+                }
+            }
+            for (uint32_t k = 0; k < 20; k++) {
+                const uint32_t i = rng.next() % (uint32_t)ents.size();
+                if (!gone[i])
+                    transformSystem->setActive(ents[i], (k & 1) != 0);
+            }
+        };
+        int rounds = (mutate ? 2 : 1) + (int)churn;
         for (int round = 0; round < rounds && ok; round++) {
-            if (round == 1)
+            if (round == 1 && mutate)
                 doMutate();
+            else if (round >= 1)
+                doChurn();
             if (mode == "both") {
                 run(true, false, 1);
                 Snapshot a = snapshot(manager, cpu, passCount);

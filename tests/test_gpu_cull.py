@@ -602,3 +602,54 @@ def test_error_conventions_of_the_c_abi(gpu):
     # the context is still usable afterwards
     gpu.cull(0, [scene.main_camera_view()])
     assert gpu.result_count(0) >= 0
+
+
+@pytest.mark.parametrize("hier", [False, True])
+@pytest.mark.parametrize("ctx_name", ["gpu", "gpu_slot_order", "gpu_bounds"])
+def test_pools_that_grow_are_appended_to_the_mirror(request, oracle, hier, ctx_name):
+    """Entities created after the first bind: the pools are re-bound with a larger occupancy (and a moved base, as
+    LinearPool::create reallocates) and NO rebuild request — the new slots are appended to the mirror; once the
+    unsorted tail passes 1/8 of the pool the library re-orders by itself. Also shrinking (a rebuild) and a mesh pool
+    that grows alone."""
+    vis = request.getfixturevalue(ctx_name)
+    full = scene.hierarchy_scene(40_000, depth=4, fanout=5) if hier else scene.flat_scene(40_000)
+    view = scene.main_camera_view()
+
+    def cut(n_t, n_m):
+        """The first n_t transforms / n_m meshes in freshly allocated arrays; links to slots beyond the cut dropped."""
+        tr = full.transforms[:n_t].copy()
+        e2t = full.entity_to_transform.copy()
+        e2t[e2t >= n_t] = 0xFFFFFFFF  # entities whose transform does not exist yet
+        return scene.Scene(full.meshes[:n_m].copy(), tr, e2t)
+
+    def check(sc, dirty_meshes=None):
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        if dirty_meshes:
+            vis.mark_dirty(2, dirty_meshes[0], dirty_meshes[1], pool_id=0)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=sc.count)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
+        o = np.argsort(exp["visible_idx"], kind="stable")
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+        assert np.array_equal(got["is_visible"], m2["isVisible"])
+        vis.sweep(1)
+        assert np.array_equal(vis.get_world(0, sc.transforms.shape[0]).view(np.uint32),
+                              oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
+
+    sc = cut(30_000, 30_000)
+    vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+    vis.bind_pool(0, sc.meshes)
+    vis.hierarchy_rebuild()
+    check(sc)
+    check(cut(30_500, 30_500))     # +500 entities: appended
+    check(cut(31_700, 31_700))     # appended again
+    check(cut(31_700, 32_000))     # meshes of entities whose transforms do not exist yet (no transform: filtered out)
+    # ... which arrive now: those meshes gained a TransformComponent, which the caller reports like any other change
+    check(cut(32_000, 32_000), dirty_meshes=(31_700, 300))
+    check(cut(36_000, 36_000))     # the tail passes 1/8 of the pool: the library re-orders
+    check(cut(40_000, 40_000))
+    check(cut(25_000, 25_000))     # shrink: rebuild
+    check(cut(25_100, 25_100))

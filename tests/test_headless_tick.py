@@ -46,6 +46,12 @@ def test_cpu_mixed_mesh_systems_sorted_and_unsorted_buffers(tick):
     assert out["draw_count"] > 0 and out["sorted_draw_count"] > 0
 
 
+def test_cpu_entity_churn(tick):
+    """Entities destroyed and created between frames (incl. re-parented orphans, re-used slots, pool growth)."""
+    _, out = tick("--mode", "cpu", "--entities", "6000", "--ticks", "2", "--hier", "--mixed", "--churn", "4")
+    assert out["draw_count"] > 0
+
+
 def test_gpu_system_fails_loudly_without_device(tick):
     import torch
     if torch.cuda.is_available():
@@ -66,6 +72,9 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "40000", "--mixed"],
     ["--entities", "40000", "--mixed", "--hier", "--mutate"],
     ["--entities", "60000", "--hier", "--toggle", "--bounds", "--ticks", "4"],
+    ["--entities", "30000", "--churn", "6"],
+    ["--entities", "30000", "--hier", "--mutate", "--churn", "8"],
+    ["--entities", "20000", "--mixed", "--hier", "--churn", "5", "--bounds"],
     ["--entities", "40000", "--mixed", "--bounds"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
