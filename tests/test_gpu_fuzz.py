@@ -157,3 +157,34 @@ def test_random_worlds_match_the_oracle(gpu, gpu_slot_order, gpu_bounds, oracle,
             vis.mark_dirty(1, hlo, hcnt)
         check(vis, oracle, sc, [views[0]], hz)
         check(vis, oracle, sc, shared, hz)
+        # growth: new entities appended to both pools, re-bound with the larger occupancy and no rebuild request
+        add_t, add_m = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        n_ent = sc.entity_to_transform.shape[0] - 1
+        tr2 = np.concatenate([sc.transforms, np.zeros(add_t, sc.transforms.dtype)])
+        # fresh ids, clear of the dangling parent id used above: an existing slot whose parent id starts to resolve is a
+        # hierarchy change the caller would have to report, which is not what this step is about
+        first_id = n_ent + 20
+        new_ids = np.arange(first_id, first_id + add_t, dtype=np.uint32)
+        tr2["entity"][nt:] = new_ids
+        tr2["position"][nt:, :3] = rng.normal(0, spread, (add_t, 3)).astype(np.float32)
+        tr2["scale"][nt:, :3] = 1
+        tr2["rotation"][nt:] = (0, 0, 0, 1)
+        tr2["selfActive"][nt:] = tr2["ancestorsActive"][nt:] = tr2["modelWithAncestors"][nt:] = 1
+        live_old = sc.transforms["entity"][sc.transforms["entity"] != 0]
+        if live_old.size:
+            tr2["parent"][nt::2] = rng.choice(live_old, size=tr2["parent"][nt::2].shape[0])
+        e2t2 = np.concatenate([sc.entity_to_transform, np.full(first_id - n_ent - 1, GV_NONE, np.uint32),
+                               np.arange(nt, nt + add_t, dtype=np.uint32)])
+        me2 = np.concatenate([sc.meshes, np.zeros(add_m, sc.meshes.dtype)])
+        me2["entity"][nm:] = rng.choice(np.concatenate([new_ids, np.arange(1, n_ent + 1, dtype=np.uint32)]), size=add_m)
+        me2["aabbMin"][nm:, :3] = -0.5
+        me2["aabbMax"][nm:, :3] = 0.5
+        me2["isEnabled"][nm:] = 1
+        grown = scene.Scene(me2, tr2, e2t2)
+        vis.bind_transforms(grown.transforms, grown.entity_to_transform)
+        vis.bind_pool(0, grown.meshes)
+        check(vis, oracle, grown, [views[0]], hz)
+        check(vis, oracle, grown, shared, hz)
+        vis.sweep(1)
+        assert np.array_equal(vis.get_world(0, nt + add_t).view(np.uint32),
+                              oracle.world_matrices(grown.transforms, grown.entity_to_transform).view(np.uint32))
