@@ -841,6 +841,50 @@ hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned lon
     return hipGetLastError();
 }
 
+// Dirty TransformComponents shipped as raw AoS bytes (slots [first, first + count) of the caller's pool, copied as they
+// lie): the AoS -> SoA gather that the host otherwise does runs here, at HBM speed. Parent links are not touched
+// (this path serves GV_DIRTY_TRANSFORM; link changes go through the host, which also validates depth and cycles).
+__global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __restrict__ raw, AosTransformLayout L,
+                                                             uint32_t first, uint32_t count,
+                                                             const uint32_t* __restrict__ xinv, float4* __restrict__ a,
+                                                             float4* __restrict__ b, float2* __restrict__ c,
+                                                             uint8_t* __restrict__ flags)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint8_t* t = raw + (size_t)k * L.stride;
+    float pos[3], scl[3], rot[4];
+    uint32_t entity;
+    memcpy(pos, t + L.position, 12);
+    memcpy(scl, t + L.scale, 12);
+    memcpy(rot, t + L.rotation, 16);
+    memcpy(&entity, t + L.entity, 4);
+    uint8_t f = 0;
+    if (entity)
+        f |= kXfLive;
+    if (t[L.self_active] && t[L.ancestors_active])
+        f |= kXfActive;
+    if (t[L.model_with_ancestors])
+        f |= kXfWithAncestors;
+    const uint32_t s = first + k;
+    const uint32_t j = xinv ? xinv[s] : s;
+    a[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
+    b[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+    c[j] = make_float2(scl[1], scl[2]);
+    flags[j] = f;
+}
+
+hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
+                                 const uint32_t* xinv, float4* a, float4* b, float2* c, uint8_t* flags, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(aos_transforms_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, xinv,
+                       a, b, c, flags);
+    return hipGetLastError();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint32_t* __restrict__ idx, uint32_t count,
                                                       const T* __restrict__ src, T* __restrict__ dst)

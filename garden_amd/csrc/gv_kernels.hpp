@@ -122,6 +122,12 @@ struct SortBuffers {
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 
 // derives TransformMirror::active_bits from flags[]
+// Byte layout of one TransformComponent inside a raw AoS copy (all offsets within `stride`).
+struct AosTransformLayout {
+    uint32_t stride, entity, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
+};
+hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
+                                 const uint32_t* xinv, float4* a, float4* b, float2* c, uint8_t* flags, hipStream_t stream);
 hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream);
 // dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
 hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,

@@ -653,3 +653,58 @@ def test_pools_that_grow_are_appended_to_the_mirror(request, oracle, hier, ctx_n
     check(cut(40_000, 40_000))
     check(cut(25_000, 25_000))     # shrink: rebuild
     check(cut(25_100, 25_100))
+
+
+@pytest.mark.parametrize("hier", [False, True])
+@pytest.mark.parametrize("ctx_name", ["gpu", "gpu_slot_order"])
+def test_large_dirty_ranges_take_the_device_side_gather(request, oracle, hier, ctx_name):
+    """GV_DIRTY_TRANSFORM over >= 2 Ki slots of an AoS pool: the raw components are copied and gathered on the device
+    (the host staging of those slots goes stale); small ranges, link changes and dense host re-mirrors afterwards must
+    still see coherent data."""
+    vis = request.getfixturevalue(ctx_name)
+    n = 150_000
+    sc = scene.hierarchy_scene(n, depth=4, fanout=6) if hier else scene.flat_scene(n)
+    view = scene.main_camera_view()
+    rng = np.random.Generator(np.random.PCG64(99))
+    vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+    vis.bind_pool(0, sc.meshes)
+    vis.hierarchy_rebuild()
+
+    def check():
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=n)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
+        o = np.argsort(exp["visible_idx"], kind="stable")
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+        assert np.array_equal(got["is_visible"], m2["isVisible"])
+        vis.sweep(1)
+        assert np.array_equal(vis.get_world(0, n).view(np.uint32),
+                              oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
+
+    def move(lo, cnt):
+        sc.transforms["position"][lo:lo + cnt, :3] += rng.normal(0, 30, (cnt, 3)).astype(np.float32)
+        sc.transforms["rotation"][lo:lo + cnt] = sc.transforms["rotation"][lo:lo + cnt][::-1]
+        sc.transforms["selfActive"][lo:lo + cnt] ^= (rng.random(cnt) < 0.05).astype(np.uint8)
+        vis.mark_dirty(0, lo, cnt)
+
+    check()
+    up0 = vis.stats()["upload_bytes"]
+    move(20_000, 60_000)            # device-side gather: 80 raw bytes per slot
+    check()
+    assert vis.stats()["upload_bytes"] - up0 == 60_000 * 80
+    move(70_000, 300)               # small range inside the stale region: host gather + scatter
+    check()
+    move(0, n)                      # the whole pool
+    check()
+    if hier:                        # link changes go through the host (depth / cycle validation), staging refreshed as needed
+        for s_ in range(100_000, 100_400):
+            sc.transforms["parent"][s_] = sc.transforms["entity"][s_ - 90_000]
+        vis.mark_dirty(1, 100_000, 400)
+        check()
+        sc.transforms["parent"][50_000:130_000:7] = 0
+        vis.mark_dirty(1, 50_000, 80_000)   # a large ranged hierarchy change: dense host path over stale staging
+        check()
+    move(10_000, 20_000)
+    check()
