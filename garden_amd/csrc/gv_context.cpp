@@ -743,7 +743,12 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
     void* span = const_cast<uint8_t*>(base) + (size_t)lo * L.stride;
     if (ctx->d_raw.reserve(bytes) != hipSuccess)
         return GV_E_STATE;
-    if (hipHostRegister(span, bytes, hipHostRegisterDefault) != hipSuccess) {
+    bool locked_here = true;
+    const hipError_t lock = hipHostRegister(span, bytes, hipHostRegisterDefault);
+    if (lock == hipErrorHostMemoryAlreadyRegistered) {
+        (void)hipGetLastError();
+        locked_here = false;  // the caller keeps its pools in pinned memory already: copy straight from it
+    } else if (lock != hipSuccess) {
         (void)hipGetLastError();
         ctx->device_gather = false;  // no page-locking here (memlock limit, exotic memory): host gathers from now on
         return GV_E_STATE;
@@ -753,7 +758,8 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         e = launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xa.ptr,
                                   ctx->d_xb.ptr, ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // the span is unlocked (and may be freed by its owner) after this
-    (void)hipHostUnregister(span);
+    if (locked_here)
+        (void)hipHostUnregister(span);
     if (e != hipSuccess || e2 != hipSuccess)
         return ctx->fail(GV_E_HIP, "device-side transform gather: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     ctx->staging_stale.add(lo, count);

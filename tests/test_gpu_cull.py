@@ -708,3 +708,27 @@ def test_large_dirty_ranges_take_the_device_side_gather(request, oracle, hier, c
         check()
     move(10_000, 20_000)
     check()
+
+
+def test_dirty_ranges_from_pools_in_pinned_memory(gpu, oracle):
+    """Pools that already live in page-locked memory (an engine allocating its ECS pools with hipHostMalloc, a torch
+    pinned tensor): the device-side gather copies straight from them."""
+    import torch
+    n = 50_000
+    sc = scene.flat_scene(n)
+    pinned = torch.empty(sc.transforms.nbytes, dtype=torch.uint8).pin_memory()
+    tr = np.frombuffer(pinned.numpy(), dtype=sc.transforms.dtype)
+    tr[:] = sc.transforms
+    view = scene.main_camera_view()
+    gpu.bind_transforms(tr, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    for lo, cnt in ((0, n), (10_000, 5_000), (100, 3_000)):
+        tr["position"][lo:lo + cnt, 1] += np.float32(2.5)
+        gpu.mark_dirty(0, lo, cnt)
+        gpu.cull(0, [view])
+        got = gpu.fetch(0, write_back=False, occupancy=n)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, tr, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
