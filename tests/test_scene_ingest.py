@@ -161,3 +161,22 @@ def test_ingested_scene_culls_like_the_reference_pools(gpu, oracle, hier):
     gpu.bind_pool(3, flat.meshes[:0])
     gpu.hierarchy_rebuild()
     sc.close()
+
+
+def test_committed_scene_fixture():
+    """tests/golden/scene_golden.{json,npz} (made by tests/golden/make_scene_golden.py): the ingest and the Python
+    restatement of the loader both still produce the committed pools."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    text = open(os.path.join(here, "scene_golden.json")).read()
+    gold = np.load(os.path.join(here, "scene_golden.npz"))
+    sc = Scene(text, POOLS)
+    tr, meshes, e2t = columns_equal_aos(sc, text)  # ingest == loader restatement, today
+    def same_fields(a, b):  # field by field: the structs have padding bytes
+        return a.shape == b.shape and all(np.array_equal(a[f].view(np.uint8), b[f].view(np.uint8)) for f in a.dtype.names)
+    assert same_fields(tr, gold["transforms"]) and np.array_equal(e2t, gold["e2t"])
+    assert same_fields(meshes[0], gold["meshes0"]) and same_fields(meshes[3], gold["meshes3"])
+    i = sc.info()
+    for k, v in zip(gold["info_keys"], gold["info"]):
+        assert i[str(k)] == int(v), k
+    sc.close()
