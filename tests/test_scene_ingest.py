@@ -173,7 +173,7 @@ def test_committed_scene_fixture():
     sc = Scene(text, POOLS)
     tr, meshes, e2t = columns_equal_aos(sc, text)  # ingest == loader restatement, today
     def same_fields(a, b):  # field by field: the structs have padding bytes
-        return a.shape == b.shape and all(np.array_equal(a[f].view(np.uint8), b[f].view(np.uint8)) for f in a.dtype.names)
+        return a.shape == b.shape and all(np.ascontiguousarray(a[f]).tobytes() == np.ascontiguousarray(b[f]).tobytes() for f in a.dtype.names)
     assert same_fields(tr, gold["transforms"]) and np.array_equal(e2t, gold["e2t"])
     assert same_fields(meshes[0], gold["meshes0"]) and same_fields(meshes[3], gold["meshes3"])
     i = sc.info()
