@@ -307,6 +307,8 @@ struct Loader {
     std::unordered_map<std::string, uint32_t> pool_of_type;
     std::unordered_map<uint64_t, uint32_t> entity_of_uid;  // deserializedEntities (transform.cpp:525)
     std::vector<PendingParent> parents;                    // deserializedParents  (transform.cpp:553)
+    bool add_root = false;                                 // loadScene's addRootEntity
+    uint32_t root_entity = 0;
 
     // finds ".type" in the component object that starts at ps.p (which is left unchanged)
     bool component_type(std::string* type)
@@ -524,6 +526,11 @@ struct Loader {
                 } while (ps.eat(','));
                 if (!ps.eat(']'))
                     return ps.fail("expected ']' at byte %zu", ps.offset());
+                if (root_entity && seen_transform) {  // resource.cpp:2497-2502: transformView->setParent(rootEntity)
+                    const uint32_t slot = sc->entity_to_transform[entity];
+                    sc->parent[slot] = root_entity;
+                    sc->ancestors_active[slot] = 1;  // the root is active (default flags)
+                }
             } while (ps.eat(','));
             if (!ps.eat('}'))
                 return ps.fail("expected '}' at byte %zu", ps.offset());
@@ -536,6 +543,22 @@ struct Loader {
         if (!ps.eat('{'))
             return ps.fail("scene is not a JSON object");
         uint32_t next_entity = 1;
+        if (add_root) {  // loadScene(path, addRootEntity = true), resource.cpp:2398-2407: a default transform on top
+            root_entity = next_entity++;
+            sc->info.entity_count++;
+            const float pos[3] = {0, 0, 0}, scl[3] = {1, 1, 1}, rot[4] = {0, 0, 0, 1};
+            sc->entity.push_back(root_entity);
+            sc->parent.push_back(0);
+            sc->uid.push_back(0);
+            sc->position.insert(sc->position.end(), pos, pos + 3);
+            sc->scale.insert(sc->scale.end(), scl, scl + 3);
+            sc->rotation.insert(sc->rotation.end(), rot, rot + 4);
+            sc->self_active.push_back(1);
+            sc->ancestors_active.push_back(1);
+            sc->model_with_ancestors.push_back(1);
+            sc->entity_to_transform.resize((size_t)root_entity + 1, kNone);
+            sc->entity_to_transform[root_entity] = 0;
+        }
         if (!ps.eat('}')) {
             std::string key;
             do {
@@ -598,7 +621,7 @@ GvColumn column(const void* data, uint32_t stride) { return GvColumn{data, strid
 
 extern "C" {
 
-int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count,
+int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
                         GvScene** out_scene, char* error, size_t error_capacity)
 {
     if (!text || !out_scene || (pool_count && !pools)) {
@@ -611,6 +634,7 @@ int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pool
     ld.sc = sc;
     ld.ps.p = ld.ps.begin = text;
     ld.ps.end = text + length;
+    ld.add_root = (flags & GV_SCENE_ADD_ROOT_ENTITY) != 0;
     for (uint32_t k = 0; k < pool_count; k++) {
         if (!pools[k].component_type || pools[k].pool_id >= GV_MAX_POOLS || sc->pools[pools[k].pool_id].mapped ||
             strcmp(pools[k].component_type, "Transform") == 0) {

@@ -157,7 +157,7 @@ def load():
     lib.gv_stats_reset.argtypes = [P]
     lib.gv_stream.argtypes = [P]
     lib.gv_stream.restype = P
-    lib.gv_scene_parse_json.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, C.POINTER(P), C.c_char_p, sz]
+    lib.gv_scene_parse_json.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, u32, C.POINTER(P), C.c_char_p, sz]
     lib.gv_scene_destroy.argtypes = [P]
     lib.gv_scene_destroy.restype = None
     lib.gv_scene_info.argtypes = [P, C.POINTER(GvSceneInfo)]
@@ -376,13 +376,14 @@ class GpuVisibility:
 class Scene:
     """A Garden scene file ingested straight into column pools (gv_scene_*; no device needed until bind)."""
 
-    def __init__(self, text, pools):
-        """text: the scene JSON (str or bytes); pools: {component ".type": pool id}."""
+    def __init__(self, text, pools, add_root_entity=False):
+        """text: the scene JSON (str or bytes); pools: {component ".type": pool id}; add_root_entity: loadScene's
+        addRootEntity (a default transform as entity 1, parent of everything that names no other parent)."""
         self.lib = load()
         raw = text.encode() if isinstance(text, str) else bytes(text)
         arr = (GvScenePool * max(len(pools), 1))(*[GvScenePool(k.encode(), v) for k, v in pools.items()])
         handle, err = C.c_void_p(), C.create_string_buffer(512)
-        rc = self.lib.gv_scene_parse_json(raw, len(raw), arr, len(pools), C.byref(handle), err, len(err))
+        rc = self.lib.gv_scene_parse_json(raw, len(raw), arr, len(pools), 1 if add_root_entity else 0, C.byref(handle), err, len(err))
         if rc != 0:
             raise GvError(rc, err.value.decode(errors="replace"))
         self.handle, self.pools = handle, dict(pools)

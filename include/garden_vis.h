@@ -232,8 +232,11 @@ typedef struct GvSceneInfo {
     uint32_t self_parents;       /* parent uid == own uid: no link */
     uint32_t unresolved_parents; /* parent uid not in the file: stays a root */
 } GvSceneInfo;
-/* On failure returns GV_E_ARG and writes a message into `error` (may be NULL). */
-int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count,
+/* flags: GV_SCENE_ADD_ROOT_ENTITY = loadScene's addRootEntity (resource.cpp:2398-2407,2497-2502): entity 1 is a default
+ * transform and every loaded transform is parented to it before the file's own parent links are applied.
+ * On failure returns GV_E_ARG and writes a message into `error` (may be NULL). */
+#define GV_SCENE_ADD_ROOT_ENTITY 1u
+int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
                         GvScene** out_scene, char* error, size_t error_capacity);
 void gv_scene_destroy(GvScene* scene);
 int gv_scene_info(const GvScene* scene, GvSceneInfo* out);

@@ -91,13 +91,24 @@ def _read_vec(obj, key, out, n):
                 out[k] = np.float32(v[name])
 
 
-def read_scene(text, pools):
-    """pools: {component type: pool id}. Returns (transforms AoS, {pool id: meshes AoS}, e2t, info dict)."""
+def read_scene(text, pools, add_root_entity=False):
+    """pools: {component type: pool id}. Returns (transforms AoS, {pool id: meshes AoS}, e2t, info dict).
+    add_root_entity: loadScene(path, true), resource.cpp:2398-2407,2497-2502."""
     data = json.loads(text)
     tr, meshes = [], {pid: [] for pid in pools.values()}
     info = dict(entity_count=0, skipped_entities=0, other_components=0, duplicate_uids=0, self_parents=0,
                 unresolved_parents=0)
     entity_of_uid, pending, next_entity = {}, [], 1
+    root_entity = 0
+    if add_root_entity:
+        root_entity, next_entity = 1, 2
+        info["entity_count"] += 1
+        t = np.zeros((), TRANSFORM_DTYPE)
+        t["entity"] = 1
+        t["scale"][:3] = 1
+        t["rotation"] = (0, 0, 0, 1)
+        t["selfActive"] = t["ancestorsActive"] = t["modelWithAncestors"] = 1
+        tr.append(t)
     for ent in data.get("entities", []) if isinstance(data.get("entities"), list) else []:
         comps = ent.get("components") if isinstance(ent, dict) else None
         if not isinstance(comps, list):
@@ -108,6 +119,7 @@ def read_scene(text, pools):
         entity = next_entity
         next_entity += 1
         info["entity_count"] += 1
+        first_of_entity = len(tr)
         for c in comps:
             ctype = c.get(".type") if isinstance(c, dict) else None
             if ctype == "Transform":
@@ -156,6 +168,10 @@ def read_scene(text, pools):
                 meshes[pools[ctype]].append(m)
             else:
                 info["other_components"] += 1
+        if root_entity:
+            for t in tr[first_of_entity:]:  # transformView->setParent(rootEntity)
+                t["parent"] = root_entity
+                t["ancestorsActive"] = 1
     transforms = np.array(tr, dtype=TRANSFORM_DTYPE) if tr else np.zeros(0, TRANSFORM_DTYPE)
     e2t = np.full(next_entity, GV_NONE, np.uint32)
     if len(tr):

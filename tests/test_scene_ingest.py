@@ -16,8 +16,8 @@ from oracle import scene_json_py as sj
 POOLS = {"Model": 0, "Sprite": 3}
 
 
-def columns_equal_aos(sc, text, pools=POOLS):
-    tr, meshes, e2t, info = sj.read_scene(text, pools)
+def columns_equal_aos(sc, text, pools=POOLS, add_root_entity=False):
+    tr, meshes, e2t, info = sj.read_scene(text, pools, add_root_entity=add_root_entity)
     got = sc.transform_columns()
     n = tr.shape[0]
     assert got["entity"].shape[0] == n
@@ -55,11 +55,14 @@ def scene_text(n, hier):
     return sj.write_scene(src.transforms, {"Model": src.meshes[:half], "Sprite": src.meshes[half:]}, src.entity_to_transform)
 
 
+@pytest.mark.parametrize("add_root", [False, True])
 @pytest.mark.parametrize("hier", [False, True])
-def test_generated_scene_columns_equal_the_reference_loader(hier):
+def test_generated_scene_columns_equal_the_reference_loader(hier, add_root):
     text = scene_text(4000, hier)
-    sc = Scene(text, POOLS)
-    tr, meshes, _ = columns_equal_aos(sc, text)
+    sc = Scene(text, POOLS, add_root_entity=add_root)
+    tr, meshes, _ = columns_equal_aos(sc, text, add_root_entity=add_root)
+    if add_root:  # loadScene(path, true): entity 1 is the root; whatever names no parent hangs under it
+        assert tr["entity"][0] == 1 and tr["parent"][0] == 0 and np.all(tr["parent"][1:] != 0)
     assert tr.shape[0] > 3800 and meshes[0].shape[0] > 1500 and meshes[3].shape[0] > 1500
     if hier:
         assert np.count_nonzero(tr["parent"]) > 3000 and np.count_nonzero(tr["ancestorsActive"] == 0) > 0
@@ -96,6 +99,9 @@ def test_loader_edge_cases():
     ]
     text = json.dumps({"version": "0.1.0", "entities": ents, "extra": [1, {"a": None}, True, -2.5e-3]}, indent=1)
     assert '\\"' in text and "\\u00e9" in text and "\\n" in text  # the string escapes reach the parser
+    rooted = Scene(text, POOLS, add_root_entity=True)
+    columns_equal_aos(rooted, text, add_root_entity=True)
+    rooted.close()
     sc = Scene(text, POOLS)
     tr, meshes, e2t = columns_equal_aos(sc, text)
     i = sc.info()
@@ -134,11 +140,11 @@ def test_empty_scene():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hier", [False, True])
-def test_ingested_scene_culls_like_the_reference_pools(gpu, oracle, hier):
+@pytest.mark.parametrize("hier,add_root", [(False, False), (True, False), (True, True)])
+def test_ingested_scene_culls_like_the_reference_pools(gpu, oracle, hier, add_root):
     text = scene_text(60_000, hier)
-    sc = Scene(text, POOLS)
-    tr, meshes, e2t = columns_equal_aos(sc, text)
+    sc = Scene(text, POOLS, add_root_entity=add_root)
+    tr, meshes, e2t = columns_equal_aos(sc, text, add_root_entity=add_root)
     sc.bind(gpu)
     view = scene.main_camera_view()
     for pid in (0, 3):
