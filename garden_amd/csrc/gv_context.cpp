@@ -196,7 +196,9 @@ struct PoolState {
 
 struct ViewState {
     DeviceBuf<unsigned long long> mask;
-    DeviceBuf<uint32_t> chunk_count, chunk_offset, draw_count;
+    DeviceBuf<uint32_t> chunk_count, chunk_count2, chunk_offset, draw_count;
+    uint32_t count_parity = 0;  // which totals buffer the next cull adds into (see launch_emit self_prefix)
+    uint32_t stale_chunks[2] = {0, 0};  // entries of each totals buffer that may be non-zero right now
 
     DeviceBuf<uint8_t> is_visible;
     DeviceBuf<uint32_t> visible_idx;
@@ -1235,8 +1237,12 @@ int reserve_view(GvCtx* ctx, ViewState& vs, uint32_t occupancy, bool emit)
     GV_HIP(ctx, vs.mask.reserve(blocks * (kCullBlock / 64)));
     if (chunks > vs.chunk_count.cap) {
         GV_HIP(ctx, vs.chunk_count.reserve(chunks));
-        // the cull workgroups add into chunk_count and scan re-zeroes it; a fresh allocation starts at zero
+        GV_HIP(ctx, vs.chunk_count2.reserve(chunks));
+        // the cull workgroups add into the totals; scan (or the self-prefixing emit) re-zeroes them; fresh ones start at zero
         GV_HIP(ctx, hipMemsetAsync(vs.chunk_count.ptr, 0, vs.chunk_count.cap * sizeof(uint32_t), ctx->stream));
+        GV_HIP(ctx, hipMemsetAsync(vs.chunk_count2.ptr, 0, vs.chunk_count2.cap * sizeof(uint32_t), ctx->stream));
+        vs.count_parity = 0;
+        vs.stale_chunks[0] = vs.stale_chunks[1] = 0;
     }
     GV_HIP(ctx, vs.chunk_offset.reserve(chunks));
     GV_HIP(ctx, vs.draw_count.reserve(4));
@@ -1254,7 +1260,8 @@ ViewBuffers view_buffers(ViewState& vs)
 {
     ViewBuffers b;
     b.mask = vs.mask.ptr;
-    b.chunk_count = vs.chunk_count.ptr;
+    b.chunk_count = vs.count_parity ? vs.chunk_count2.ptr : vs.chunk_count.ptr;
+    b.chunk_count_next = vs.count_parity ? vs.chunk_count.ptr : vs.chunk_count2.ptr;
     b.chunk_offset = vs.chunk_offset.ptr;
     b.draw_count = vs.draw_count.ptr;
     b.is_visible = vs.is_visible.ptr;
@@ -1372,7 +1379,7 @@ void gv_destroy(GvCtx* ctx)
         p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release();
     }
     for (auto& v : ctx->views) {
-        v.mask.release(); v.chunk_count.release(); v.chunk_offset.release(); v.draw_count.release();
+        v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
         v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
@@ -1662,6 +1669,19 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                 else {
                     GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
                 }
+            }
+            static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
+            if (ctx->views[v].emitted && chunks <= self_max) {
+                // no scan launch: emit derives the chunk bases itself and leaves THIS totals buffer as it is; the
+                // next cull of this view adds into the other one, which this emit has cleared
+                ViewState& vs = ctx->views[v];
+                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+                KernelTimer t(ctx, GV_K_EMIT);
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other])));
+                vs.stale_chunks[other] = 0;
+                vs.stale_chunks[cur] = chunks;
+                vs.count_parity = other;
+                continue;
             }
             {
                 KernelTimer t(ctx, GV_K_SCAN);

@@ -708,6 +708,8 @@ struct EmitArgs {
     TransformMirror xf;
     ViewParams view;
     ViewBuffers out;
+    uint32_t nchunks;
+    uint32_t clear_chunks;  // SELF: entries of chunk_count_next to clear (a larger pool may have used it last)
 };
 
 // The record of visible mirror entry i at output position `rank` (mesh.cpp:169-173). Visible entries passed every
@@ -764,12 +766,17 @@ constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slot
 // Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
 // chunk's 64 words (512 B, L2), then lane r takes the r-th visible slot of its quarter (binary search over the
 // word prefix + select of the k-th set bit), so the model recompute and the 56-byte record store run on dense
-// waves and only the visible fraction costs instructions. Output rank = chunk_offset[chunk] + r: ascending
-// slot order, whatever order the workgroups run in.
+// waves and only the visible fraction costs instructions. Output rank = chunk base + r: ascending slot order,
+// whatever order the workgroups run in.
+// SELF: no scan launch in front — while wave 0 prefixes the ballot words, waves 1-3 sum the chunk totals below this
+// chunk (a few KB of L2 reads) to get its base; workgroup 0 also writes the grand total and clears the OTHER totals
+// buffer for the next frame's cull (the two buffers alternate, so nobody is still reading the one being cleared).
+template <bool SELF>
 __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 {
     __shared__ unsigned long long words[64];
     __shared__ uint32_t prefix[65];
+    __shared__ uint32_t below[4];
     const uint32_t chunk = blockIdx.x / kEmitParts, part = blockIdx.x % kEmitParts;
     const uint32_t first_word = chunk * 64;
     const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
@@ -787,11 +794,33 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
         prefix[threadIdx.x + 1] = incl;
         if (threadIdx.x == 0)
             prefix[0] = 0;
+    } else if (SELF) {
+        const uint32_t upto = blockIdx.x == 0 ? args.nchunks : chunk;  // workgroup 0: the grand total
+        uint32_t sum = 0;
+        for (uint32_t c = threadIdx.x - 64; c < upto; c += 192)
+            sum += args.out.chunk_count[c];
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1)
+            sum += __shfl_xor(sum, d, 64);
+        if ((threadIdx.x & 63u) == 0)
+            below[threadIdx.x >> 6] = sum;
     }
     __syncthreads();
+    uint32_t base;
+    if (SELF) {
+        base = below[1] + below[2] + below[3];
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0)
+                *args.out.draw_count = base;
+            for (uint32_t c = threadIdx.x; c < args.clear_chunks; c += 256)
+                args.out.chunk_count_next[c] = 0;
+            base = 0;  // chunk 0 starts the list
+        }
+    } else {
+        base = args.out.chunk_offset[chunk];
+    }
     const uint32_t wlo = part * (64 / kEmitParts), whi = wlo + 64 / kEmitParts;
     const uint32_t total = prefix[whi];
-    const uint32_t base = args.out.chunk_offset[chunk];
     for (uint32_t r = prefix[wlo] + threadIdx.x; r < total; r += 256) {
         uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
 #pragma unroll
@@ -809,7 +838,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 }
 
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream)
+                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks)
 {
     if (mesh.count == 0)
         return hipSuccess;
@@ -818,8 +847,12 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.xf = xf;
     a.view = vp;
     a.out = out;
-    const uint32_t nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
-    hipLaunchKernelGGL(emit_kernel, dim3(nchunks * kEmitParts), dim3(256), 0, stream, a);
+    a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    a.clear_chunks = clear_chunks;
+    if (self_prefix)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

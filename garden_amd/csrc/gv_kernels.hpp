@@ -68,7 +68,8 @@ struct ViewParams {
 struct ViewBuffers {
     unsigned long long* mask;  // one ballot word per 64 slots
     uint32_t* chunk_count;     // visible per kEmitChunk slots (atomically summed by the cull workgroups, re-zeroed by scan)
-    uint32_t* chunk_offset;    // exclusive scan of chunk_count
+    uint32_t* chunk_count_next;  // the other of the two alternating totals buffers (cleared by the self-prefixing emit)
+    uint32_t* chunk_offset;    // exclusive scan of chunk_count (scan path only)
     uint32_t* draw_count;      // total
     uint8_t* is_visible;       // per slot (main pass)
     uint32_t* visible_idx;     // compact records [0, draw_count), ascending slot order
@@ -98,8 +99,11 @@ hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, 
                              const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
                              const BlockBounds* bounds = nullptr);
 hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
+// self_prefix: every emit workgroup derives its chunk's base from the chunk totals itself (no launch_scan in front;
+// pools of up to kSelfPrefixMaxChunks chunks); out.chunk_count / chunk_count_next then alternate from cull to cull.
+constexpr uint32_t kSelfPrefixMaxChunks = 4096;
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream);
+                       hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0);
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                            hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
