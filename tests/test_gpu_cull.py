@@ -732,3 +732,27 @@ def test_dirty_ranges_from_pools_in_pinned_memory(gpu, oracle):
         exp = oracle.prepare_meshes(m2, tr, sc.entity_to_transform, view)
         assert np.array_equal(got["visible_idx"], exp["visible_idx"])
         assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+
+
+def test_pools_of_different_sizes_alternate_on_the_same_view(gpu, oracle):
+    """The per-view chunk-total buffers alternate from cull to cull (the self-prefixing emit clears the other one):
+    a small pool after a large one must not leave stale totals behind, nor must count-only culls (scan path) in between."""
+    big, small = scene.flat_scene(100_000), scene.flat_scene(3_000, seed=scene.SEED + 5)
+    view = scene.main_camera_view()
+    count_only = dict(view, emit_records=0)
+    gpu.bind_transforms(big.transforms, big.entity_to_transform)
+    gpu.bind_pool(0, big.meshes)
+    gpu.bind_pool(1, small.meshes)  # entities 1..3000 of the big scene's transform pool: a second mesh system
+    gpu.hierarchy_rebuild()
+    exp = {}
+    for pid, sc in ((0, big), (1, small)):
+        m2 = sc.meshes.copy()
+        e = oracle.prepare_meshes(m2, big.transforms, big.entity_to_transform, view)
+        exp[pid] = (np.sort(e["visible_idx"]), e["draw_count"])
+    for pid, v in ((0, view), (1, view), (0, count_only), (1, view), (1, count_only), (0, view), (0, view), (1, count_only),
+                   (1, view), (0, view)):
+        gpu.cull(pid, [v])
+        if v["emit_records"]:
+            got = gpu.fetch(0, write_back=False, occupancy=(big if pid == 0 else small).count)
+            assert np.array_equal(got["visible_idx"], exp[pid][0]), pid
+        assert gpu.result_count(0) == exp[pid][1], pid
