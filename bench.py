@@ -76,7 +76,8 @@ def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False, exa
     if wl["hiz"]:
         cull += frustum_survivors * 32.0  # 4 texels x (min,max) fp32 per frustum-surviving entity
     emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125
-    hiz = (HIZ_SIZE * HIZ_SIZE * 4 + sum(max(HIZ_SIZE >> k, 1) ** 2 * 8 for k in range(1, 13))) if wl["hiz"] else 0.0
+    # level 1 is not stored: depth read + levels 2..12 written
+    hiz = (HIZ_SIZE * HIZ_SIZE * 4 + sum(max(HIZ_SIZE >> k, 1) ** 2 * 8 for k in range(2, 13))) if wl["hiz"] else 0.0
     sweep = n * (40.0 + 4.0 + 48.0) if wl["sweep"] else 0.0
     if fused and wl["sweep"]:  # one pass: the TRS streams are read once, the world matrices (48 B) written beside the cull outputs
         cull += n * 48.0

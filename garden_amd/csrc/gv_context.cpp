@@ -229,6 +229,8 @@ struct GvCtx {
     TransformBinding xf;
     bool xf_need_full = false;
     bool sweep_with_cull_mfma = true;
+    bool hiz_level1_virtual = false;  // decided in gv_hiz_build: even sizes whose first six levels take the fused kernel
+    bool hiz_level1_stored = false;   // ... and whether gv_hiz_read_level has materialised it since the last build
     uint64_t xf_epoch = 1;  // bumped whenever the transform mirror changes
     uint32_t xf_mirrored = 0, xf_appended = 0;  // as PoolState::mirrored / appended, for the transform pool
     DeviceBuf<uint8_t> d_raw;      // raw AoS bytes of a dirty slot range (device-side gather path)
@@ -1273,6 +1275,7 @@ ViewBuffers view_buffers(ViewState& vs)
 
 int hiz_reduce(GvCtx* ctx)
 {
+    ctx->hiz_level1_stored = false;
     ZoneScope zone("HiZ Downsample");
     KernelTimer timer(ctx, GV_K_HIZ);
     uint32_t k = 1;
@@ -1284,6 +1287,8 @@ int hiz_reduce(GvCtx* ctx)
             HizFusedDst dst;
             for (int l = 0; l < 6; l++)
                 dst.level[l] = ctx->d_mips.ptr + ctx->mip_off[k + l];
+            if (k == 1 && ctx->hiz_level1_virtual)
+                dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
             GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, ctx->stream));
             k += 6;
         } else {
@@ -1584,6 +1589,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         hz.height = ctx->hiz_h;
         hz.mip_count = ctx->hiz_mips;
         hz.nested = ctx->hiz_nested ? 1u : 0u;
+        hz.level1_virtual = ctx->hiz_level1_virtual ? 1u : 0u;
     }
     // Views that share cameraPosition (the main camera and its shadow cascades: mesh.cpp:809-843 passes the same
     // cameraPosition to every prepareMeshes) are culled in ONE pass over the streams; Hi-Z only on view 0.
@@ -1962,6 +1968,8 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
             if ((ctx->mip_w[k] > 1 && (ctx->mip_w[k] & 1u)) || (ctx->mip_h[k] > 1 && (ctx->mip_h[k] & 1u)))
                 ctx->hiz_nested = false;
     }
+    // level 1 stays virtual when the first six levels come from the fused kernel (sizes divisible by 64: plain 2x2 rule)
+    ctx->hiz_level1_virtual = width % 64 == 0 && height % 64 == 0 && mips > 6 && getenv("GV_DEBUG_STORE_HIZ_LEVEL1") == nullptr;
     GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>(off, 1)));
     GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_mip_offset.ptr, ctx->mip_off, sizeof(uint64_t) * GV_MAX_MIPS, hipMemcpyHostToDevice, ctx->stream));
@@ -2007,6 +2015,11 @@ int gv_hiz_read_level(GvCtx* ctx, uint32_t level, float* out_pairs, uint32_t* w,
         return ctx->fail(GV_E_ARG, "gv_hiz_read_level: level %u (valid 1..%u)", level, ctx->hiz_mips - 1);
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)ctx->mip_w[level] * ctx->mip_h[level];
+    if (level == 1 && ctx->hiz_level1_virtual && !ctx->hiz_level1_stored) {  // on demand: one generic level pass
+        GV_HIP(ctx, launch_hiz_level(ctx->depth_ptr, nullptr, ctx->d_mips.ptr + ctx->mip_off[1], ctx->mip_w[0], ctx->mip_h[0],
+                                     ctx->mip_w[1], ctx->mip_h[1], ctx->config.hiz_rule, ctx->stream));
+        ctx->hiz_level1_stored = true;
+    }
     GV_HIP(ctx, hipMemcpyAsync(out_pairs, ctx->d_mips.ptr + ctx->mip_off[level], n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain_events(ctx);

@@ -111,6 +111,18 @@ __device__ __forceinline__ float hiz_min_texel(const HizDevice& hz, uint32_t lev
 {
     if (level == 0)
         return hz.depth[(size_t)y * hz.width + x];
+    if (level == 1 && hz.level1_virtual) {
+        // Level 1 is the biggest level to write (half of all pyramid bytes) and the least read: with even sizes its
+        // texel is just the 2x2 reduction of the depth image, in the build's own order (hiz.frag:29-33, MIN_DEPTH).
+        const float2* row0 = reinterpret_cast<const float2*>(hz.depth + (size_t)(2 * y) * hz.width + 2 * x);
+        const float2* row1 = reinterpret_cast<const float2*>(hz.depth + (size_t)(2 * y + 1) * hz.width + 2 * x);
+        const float2 a = *row0, b = *row1;
+        float m = a.x;
+        m = a.y < m ? a.y : m;
+        m = b.x < m ? b.x : m;
+        m = b.y < m ? b.y : m;
+        return m;
+    }
     return hz.mips[hz.mip_offset[level] + (uint64_t)y * lw + x].x;
 }
 
@@ -1678,10 +1690,12 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
             q[a][b] = mm;
         }
     const uint32_t w1 = sw >> 1;
+    if (dst.level[0]) {  // null: the level stays virtual (queries reduce the source themselves)
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-        float4* o = reinterpret_cast<float4*>(dst.level[0] + (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx);
-        *o = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
+        for (int a = 0; a < 2; a++) {
+            float4* o = reinterpret_cast<float4*>(dst.level[0] + (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx);
+            *o = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
+        }
     }
     // level +2: one texel per lane
     float2 m2 = q[0][0];

@@ -47,6 +47,7 @@ struct HizDevice {
     const float2* mips;          // levels >= 1, (min,max)
     const uint64_t* mip_offset;  // device array [GV_MAX_MIPS], in float2 elements
     uint32_t width, height, mip_count;
+    uint32_t level1_virtual;  // level 1 is not stored (even sizes, fused build): a query derives its texels from the depth
     uint32_t nested;  // every level's min bounds ALL texels it covers (even sizes all the way, or the conservative rule):
                       // a coarser level may then prove occlusion early (exact shortcut, see hiz_occluded)
 };
