@@ -1,0 +1,383 @@
+// gv_ctx.hpp — the context behind the opaque GvCtx of include/garden_vis.h and the small host-side utilities shared
+// by gv_mirror.cpp (AoS/columns -> device mirror) and gv_context.cpp (the C-ABI, per-frame dispatch, results).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
+
+#include <algorithm>
+#include <chrono>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/garden_vis.h"
+#include "gv_kernels.hpp"
+
+
+namespace gv {
+
+template <typename T>
+struct DeviceBuf {  // grow-only device allocation (scratch vectors grow, never shrink: mesh.cpp:377-395)
+    T* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (e == hipSuccess)
+            cap = n;
+        return e;
+    }
+    // like reserve, but the first `keep` elements survive (pool growth: the mirror is appended to, not rebuilt);
+    // capacity grows by half so that steady appends do not reallocate every frame
+    hipError_t grow(size_t n, size_t keep, hipStream_t stream)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        const size_t want = std::max(n, cap + cap / 2);
+        T* fresh = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T));
+        if (e != hipSuccess)
+            return e;
+        if (ptr && keep) {
+            e = hipMemcpyAsync(fresh, ptr, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                (void)hipFree(fresh);
+                return e;
+            }
+        }
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = n;
+        return e;
+    }
+    hipError_t grow(size_t n, size_t keep)  // the caller has drained every async copy that reads this buffer
+    {
+        if (n <= cap)
+            return hipSuccess;
+        const size_t want = std::max(n, cap + cap / 2);
+        T* fresh = nullptr;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess)
+            return e;
+        if (ptr && keep)
+            memcpy(fresh, ptr, std::min(keep, cap) * sizeof(T));
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct DirtyRange {
+    uint32_t lo = UINT32_MAX, hi = 0;
+    bool any() const { return lo < hi; }
+    void add(uint32_t first, uint32_t count)
+    {
+        lo = std::min(lo, first);
+        hi = std::max(hi, first + count);
+    }
+    void clear()
+    {
+        lo = UINT32_MAX;
+        hi = 0;
+    }
+};
+
+// One field of a bound pool: element i lives at ptr + i * stride. An AoS pool binds every field with the component
+// stride and its offset folded into ptr; column (SoA) storage binds each field with its own array and element size.
+struct Column {
+    const uint8_t* ptr = nullptr;
+    size_t stride = 0;
+    const uint8_t* at(size_t i) const { return ptr + i * stride; }
+    uint32_t u32(size_t i) const
+    {
+        uint32_t v;
+        memcpy(&v, ptr + i * stride, 4);
+        return v;
+    }
+    const float* f32(size_t i) const { return reinterpret_cast<const float*>(ptr + i * stride); }
+    uint8_t u8(size_t i) const { return ptr[i * stride]; }
+};
+
+struct TransformBinding {
+    Column entity, parent, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
+    uint32_t occupancy = 0;
+    const uint32_t* entity_to_transform = nullptr;
+    uint32_t entity_capacity = 0;
+    bool bound = false;
+};
+
+struct PoolState {
+    Column entity, is_enabled, aabb_min, aabb_max;
+    uint8_t* is_visible = nullptr;  // write-back target (NULL: none), element i at is_visible + i * is_visible_stride
+    size_t is_visible_stride = 0;
+    uint32_t occupancy = 0;
+    bool bound = false;
+    bool need_full = false;
+    uint32_t mapping = kMapGeneral;  // MeshMapping, chosen at full gather (kMapExact may only be demoted afterwards)
+    DirtyRange dirty;
+    // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
+    std::vector<uint32_t> perm, inv;
+    DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
+    // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
+    DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    uint32_t mirrored = 0, appended = 0;  // entries the mirror holds / of those, appended (unsorted) since the last full build
+    uint64_t epoch = 1, bounds_epoch = 0, bounds_xf_epoch = 0;  // epoch: bumped whenever this pool's mirror changes
+    uint64_t seen_epoch = 0, seen_xf_epoch = 0;                 // state at this pool's previous gv_cull
+    bool changed_prev = false;                                  // ... and whether it had changed then too (dynamic pool)
+    // device mirror + pinned staging
+    DeviceBuf<float4> d_a;
+    DeviceBuf<float2> d_b;
+    DeviceBuf<uint32_t> d_link;
+    PinnedBuf<float4> h_a;
+    PinnedBuf<float2> h_b;
+    PinnedBuf<uint32_t> h_link;
+};
+
+struct ViewState {
+    DeviceBuf<unsigned long long> mask;
+    DeviceBuf<uint32_t> chunk_count, chunk_count2, chunk_offset, draw_count;
+    uint32_t count_parity = 0;  // which totals buffer the next cull adds into (see launch_emit self_prefix)
+    uint32_t stale_chunks[2] = {0, 0};  // entries of each totals buffer that may be non-zero right now
+
+    DeviceBuf<uint8_t> is_visible;
+    DeviceBuf<uint32_t> visible_idx;
+    DeviceBuf<float> baked_model, distance_sq;
+    // gv_sort: alternate record set + radix-sort scratch (allocated on first use)
+    DeviceBuf<uint32_t> alt_idx, sort_keys[2], sort_vals[2], sort_hist;
+    DeviceBuf<float> alt_model, alt_dist;
+    PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
+    PinnedBuf<float> h_baked_model, h_distance_sq;
+    PinnedBuf<uint8_t> h_is_visible, h_is_visible_mirror;
+    uint32_t pool_id = 0, occupancy = 0;
+    bool main_pass = false, emitted = false, valid = false;
+};
+
+struct PendingEvent {
+    hipEvent_t start, stop;
+    int kernel;
+};
+
+
+// Everything a context owns. The C-ABI's opaque `GvCtx` (a global-scope name) derives from it below.
+struct Context {
+    GvConfig config{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // ---- transform pool: binding, change tracking, device mirror + pinned staging ----
+    TransformBinding xf;
+    bool xf_need_full = false;     // (re)build the whole mirror at the next sync
+    bool xf_links_dirty = false;   // a ranged GV_DIRTY_HIERARCHY: parent links changed -> re-validate depth / cycles
+    DirtyRange xf_dirty;
+    uint64_t xf_epoch = 1;         // bumped whenever the transform mirror changes
+    uint32_t xf_mirrored = 0, xf_appended = 0;  // as PoolState::mirrored / appended, for the transform pool
+    uint32_t max_depth = 0;        // longest parent chain in the mirror
+    DeviceBuf<float4> d_xa, d_xb;
+    DeviceBuf<float2> d_xc;
+    DeviceBuf<uint8_t> d_xflags;
+    DeviceBuf<unsigned long long> d_xactive;  // bit-plane of kXfActive, derived on the device
+    DeviceBuf<uint32_t> d_xparent;
+    PinnedBuf<float4> h_xa, h_xb;
+    PinnedBuf<float2> h_xc;
+    PinnedBuf<uint8_t> h_xflags;
+    PinnedBuf<uint32_t> h_xparent;
+    // spatial mirror order of the transform pool (empty = slot order)
+    std::vector<uint32_t> xperm, xinv;
+    DeviceBuf<uint32_t> d_xinv;    // slot -> mirror entry (gv_get_world, device-side gather)
+    // device-side gather of dirty AoS ranges
+    DeviceBuf<uint8_t> d_raw;      // raw component bytes of the dirty slot range
+    DirtyRange staging_stale;      // slots whose host staging entries lag behind the device (written by that path)
+    bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // turned off after a failed page-lock, or by the env
+    // scratch of the scattered (dirty-range) host upload path
+    PinnedBuf<uint32_t> sc_idx, sc_u32;
+    PinnedBuf<float4> sc_a, sc_b;
+    PinnedBuf<float2> sc_c;
+    PinnedBuf<uint8_t> sc_u8;
+    DeviceBuf<uint32_t> dsc_idx, dsc_u32;
+    DeviceBuf<float4> dsc_a, dsc_b;
+    DeviceBuf<float2> dsc_c;
+    DeviceBuf<uint8_t> dsc_u8;
+
+    PoolState pools[GV_MAX_POOLS];
+    ViewState views[GV_MAX_VIEWS];
+
+    // ---- world-matrix cache (gv_sweep) ----
+    DeviceBuf<float4> d_world;
+    bool world_valid = false;
+    bool sweep_with_cull = false;      // GV_SWEEP_WITH_CULL[_VALU] requested: the next gv_cull also writes the world matrices
+    bool sweep_with_cull_mfma = true;  // ... with the MFMA or the VALU chain
+
+    // ---- block bounds (GV_CONFIG_BLOCK_BOUNDS) statistics ----
+    DeviceBuf<uint8_t> d_examined;     // of the LAST bounded cull: 1 byte per workgroup
+    uint64_t bounds_blocks_total = 0;
+
+    // ---- Hi-Z ----
+    DeviceBuf<float> d_depth;
+    const float* depth_ptr = nullptr;  // d_depth.ptr or caller's device memory
+    DeviceBuf<float2> d_mips;
+    DeviceBuf<uint64_t> d_mip_offset;
+    uint32_t hiz_w = 0, hiz_h = 0, hiz_mips = 0;
+    uint32_t mip_w[GV_MAX_MIPS]{}, mip_h[GV_MAX_MIPS]{};
+    uint64_t mip_off[GV_MAX_MIPS]{};
+    bool hiz_valid = false;
+    bool hiz_nested = false;           // every level bounds all the texels it covers (see HizDevice::nested)
+    bool hiz_level1_virtual = false;   // decided in gv_hiz_build: sizes whose first six levels take the fused kernel
+    bool hiz_level1_stored = false;    // ... and whether gv_hiz_read_level has materialised it since the last build
+
+    // ---- profiling ----
+    std::vector<PendingEvent> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    GvStats stats{};
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what)
+    {
+        return fail(e == hipErrorOutOfMemory ? GV_E_OOM : GV_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+};
+
+}  // namespace gv
+
+struct GvCtx final : gv::Context {};
+
+
+#define GV_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess)                              \
+            return (ctx)->hip_fail(e__, #call);             \
+    } while (0)
+
+namespace gv {
+
+// roctx ranges named after the reference's profiler zones (SET_CPU_ZONE_SCOPED / SET_GPU_DEBUG_LABEL:
+// "Meshes Prepare" source/system/render/mesh.cpp:334, "Meshes Sort" :267, "HiZ Downsample" hiz.cpp:146), so a
+// rocprofv3 --marker-trace timeline reads like the engine's Tracy capture.
+struct ZoneScope {
+    explicit ZoneScope(const char* name) { roctxRangePushA(name); }
+    ~ZoneScope() { roctxRangePop(); }
+};
+
+// ---- profiling events ----
+struct KernelTimer {
+    GvCtx* ctx;
+    int kernel;
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool on = false;
+    KernelTimer(GvCtx* c, int k) : ctx(c), kernel(k)
+    {
+        ctx->stats.launches[k]++;
+        if (!(ctx->config.flags & GV_CONFIG_PROFILE_EVENTS))
+            return;
+        if ((ctx->config.flags & GV_CONFIG_PROFILE_CULL_ONLY) && k != GV_K_CULL)
+            return;
+        if (!ctx->free_events.empty()) {
+            start = ctx->free_events.back().first;
+            stop = ctx->free_events.back().second;
+            ctx->free_events.pop_back();
+        } else if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+            return;
+        }
+        on = hipEventRecord(start, ctx->stream) == hipSuccess;
+    }
+    ~KernelTimer()
+    {
+        if (!on)
+            return;
+        (void)hipEventRecord(stop, ctx->stream);
+        ctx->pending.push_back({start, stop, kernel});
+    }
+};
+
+// ---- host worker threads for the gathers (AoS component pools -> SoA staging) and the isVisible write-back ----
+template <typename F>
+void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
+{
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    // 16 threads: measured on the 256-thread box, 64 made the 10 M gather slower (60 vs 34 ms)
+    const uint32_t threads = count < (1u << 16) ? 1u : std::min(hw, 16u);
+    if (threads == 1) {
+        fn(first, first + count);
+        return;
+    }
+    const uint32_t per = (count + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; t++) {
+        const uint32_t lo = first + std::min(count, per * t), hi = first + std::min(count, per * (t + 1));
+        if (lo < hi)
+            pool.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    fn(first, first + std::min(count, per));
+    for (auto& th : pool)
+        th.join();
+}
+
+void drain_events(GvCtx* ctx);
+
+// gv_mirror.cpp
+int sync_mirror(GvCtx* ctx);                 // brings the device mirror up to date with the bound pools + dirty ranges
+TransformMirror xf_mirror(const GvCtx* ctx);  // the transform mirror as the kernels see it
+
+}  // namespace gv
