@@ -1,0 +1,710 @@
+// gv_cull.hip — hand-written gfx950 (CDNA4, wave64) kernels of the visibility pass: cull, compaction and the mirror
+// maintenance kernels. (Sort: gv_sort.hip; sweeps: gv_sweep.hip; pyramid: gv_hiz.hip; shared helpers: gv_device.hpp.)
+//
+//   cull_kernel   replaces the body of prepareUnsortedMeshes / prepareSortedMeshes
+//                 (source/system/render/mesh.cpp:137-175 / :213-253): filters, parent-chain model
+//                 (include/garden/system/transform.hpp:197-214), 8-corner frustum test
+//                 (render/mesh.hpp:142-146), optional Hi-Z occlusion query (build-defined), wave ballot.
+//   scan_kernel + emit_kernel   replace drawCount.fetch_add + memcpy into combinedMeshes
+//                 (mesh.cpp:177-183) with an order-stable compaction (ballot words + block prefix).
+//   cull_multi_kernel   the same for up to 8 views that share cameraPosition (main camera + shadow cascades,
+//                 mesh.cpp:795-847) in one pass over the streams.
+//   block_bounds_kernel + the BOUNDS variants   opt-in workgroup boxes: conservative block-level frustum rejection.
+//   sort_* / radix_*   sortMeshes (mesh.cpp:265-328): stable radix sort of the compact records by distanceSq.
+//   sweep_*       TransformComponent::calcModel() for every transform slot (transform.hpp:197-214);
+//                 the MFMA form runs the 4x4 chain on v_mfma_f32_4x4x1_16b_f32.
+//   sweep_cull_*  sweep and cull of an exactly paired pool in ONE pass (world matrices + cull outputs).
+//   hiz_*         HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167) with the
+//                 reduction rule of shaders/hiz.frag:23-63.
+//
+// All of it is HBM-bound streaming (DESIGN.md has bytes/entity per kernel); loads are 16- or 12-byte
+// per lane over SoA streams so each wave-instruction touches 1 KiB / 768 B contiguous.
+#include "gv_device.hpp"
+
+namespace gv {
+
+// K1: one lane per mesh slot: visibility, isVisible byte, one ballot word per wave, per-chunk counts.
+// Compaction is two-pass (ballot words -> chunk scan -> emit). Measured alternatives, all within a few % of
+// this one in total time or worse (profiles/r01b_compaction_variants.txt): writing 56-byte records from K1
+// into per-tile / per-wave staging segments and copying them (sparse partial sectors, +25..50 us in K1);
+// LDS-staged fused emission with one global atomic per flush (occupancy, barriers); a decoupled look-back
+// scan over 256-slot tiles (inter-workgroup latency and polling traffic dominate such small tiles).
+// Conservative workgroup-level frustum rejection. The per-entity test rejects an entity when all 8 of its corners are
+// behind one plane (computed distance < 0). The box holds every such corner of the workgroup's candidates as computed
+// in world space; the per-frame corners are the same products with c3 - cam in place of c3, so a computed distance
+// differs from the box-derived one by rounding only: a few ulps of the coordinate magnitude per chain level
+// (<= ~4e-6 * M * (depth + 1)). The margin is an order of magnitude above that, so "box behind by more than the margin"
+// implies "every computed corner distance < 0" — the rejected workgroup's entities all fail that plane in the exact
+// test too. Boxes with non-finite members are +-inf and never satisfy the comparison (NaN / +inf are not < -margin).
+__device__ __forceinline__ bool block_behind_planes(const float4 lo, const float4 hi, const float (&planes)[6][4],
+                                                    uint32_t plane_count, const float (&cam)[3], uint32_t max_depth)
+{
+    const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
+                      fabsf(cam[0]) + fabsf(cam[1]) + fabsf(cam[2]);
+    const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
+    bool behind = false;
+#pragma unroll
+    for (uint32_t p = 0; p < 6; p++)
+        if (p < plane_count) {
+            const float nx = planes[p][0], ny = planes[p][1], nz = planes[p][2];
+            // the box corner farthest along the normal, camera-relative
+            const float x = (nx >= 0.0f ? hi.x : lo.x) - cam[0];
+            const float y = (ny >= 0.0f ? hi.y : lo.y) - cam[1];
+            const float z = (nz >= 0.0f ? hi.z : lo.z) - cam[2];
+            const float d = fmaf(nx, x, fmaf(ny, y, fmaf(nz, z, planes[p][3])));
+            behind = behind || (d < -margin);
+        }
+    return behind;
+}
+__device__ __forceinline__ bool block_behind_frustum(const float4 lo, const float4 hi, const ViewParams& view, uint32_t max_depth)
+{
+    return block_behind_planes(lo, hi, view.planes, view.plane_count, view.cam, max_depth);
+}
+
+// The per-entity work of one 256-entry workgroup `lb`.
+template <bool HIZ, uint32_t MAP>
+__device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, uint32_t* wave_count)
+{
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool visible = false;
+    if (i < args.mesh.count) {
+        Mat34 m;
+        Corners c;
+        visible = evaluate_slot<MAP>(args.mesh, args.xf, args.view, i, m, c);
+        // Hi-Z occlusion query on the survivors. Measured (profiles/r01b_hiz_ablation.txt): compacting the
+        // survivors across the workgroup through LDS first buys nothing — the stage is bound by the texel
+        // gathers (~4.5 M random 64-B sectors per frame), not by divergent VALU work.
+        if (HIZ && visible)
+            visible = !hiz_occluded(args.hiz, args.view.vp, c);
+        if (args.view.write_is_visible)
+            args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
+    }
+    const unsigned long long word = __ballot(visible);
+    if (lane == 0) {
+        args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+        wave_count[wave] = (uint32_t)__popcll(word);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCullBlock / 64; w++)
+            total += wave_count[w];
+        if (total)  // integer adds commute: the sum is deterministic whatever the arrival order
+            atomicAdd(&args.out.chunk_count[lb / (kEmitChunk / kCullBlock)], total);
+    }
+}
+
+// BOUNDS (GV_CONFIG_BLOCK_BOUNDS): the workgroup first tests its box; when the box is behind a plane every entity in it
+// is invisible, the outputs say so and the streams stay untouched.
+template <bool HIZ, uint32_t MAP, bool BOUNDS>
+__global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
+{
+    __shared__ uint32_t wave_count[kCullBlock / 64];
+    const uint32_t lb = blockIdx.x;
+    if (BOUNDS) {  // workgroup-uniform
+        const uint32_t i = lb * kCullBlock + threadIdx.x;
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
+        const bool empty = lo.x > hi.x;  // no candidate at all (+inf / -inf)
+        const bool skip = empty || block_behind_frustum(lo, hi, args.view, args.xf.max_depth);
+        if (threadIdx.x == 0)  // statistics: a plain store per workgroup (a shared counter would serialise ~10^4 atomics)
+            args.bounds.examined[lb] = skip ? 0 : 1;
+        if (skip) {
+            if (args.view.write_is_visible && i < args.mesh.count)
+                args.out.is_visible[i] = 0;
+            if (lane == 0)
+                args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
+            return;
+        }
+    }
+    cull_block<HIZ, MAP>(args, lb, wave_count);
+}
+
+hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                       const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    CullArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    a.view = vp;
+    a.out = out;
+    a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    a.bounds = bounds ? *bounds : BlockBounds{};
+    const dim3 grid(a.nblocks), block(kCullBlock);
+#define GV_LAUNCH_CULL(HIZ, BOUNDS)                                                                                       \
+    switch (mesh.mapping) {                                                                                              \
+    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate, BOUNDS>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral, BOUNDS>), grid, block, 0, stream, a); break;              \
+    }
+    if (vp.use_hiz && bounds) {
+        GV_LAUNCH_CULL(true, true)
+    } else if (vp.use_hiz) {
+        GV_LAUNCH_CULL(true, false)
+    } else if (bounds) {
+        GV_LAUNCH_CULL(false, true)
+    } else {
+        GV_LAUNCH_CULL(false, false)
+    }
+#undef GV_LAUNCH_CULL
+    return hipGetLastError();
+}
+
+// World-space box of each cull workgroup's candidates (camera at the origin: translate(-0) leaves c3 as it is).
+template <uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirror mesh, const TransformMirror xf,
+                                                                  float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    __shared__ float red[kCullBlock / 64][6];
+    const uint32_t lb = blockIdx.x;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    if (i < mesh.count) {
+        Mat34 m;
+        Corners c;
+        const float cam[3] = {0.0f, 0.0f, 0.0f};
+        if (prepare_slot<MAP>(mesh, xf, cam, i, m, c)) {
+            bool finite = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float xs[2] = {c.x[k].x, c.x[k].y}, ys[2] = {c.y[k].x, c.y[k].y}, zs[2] = {c.z[k].x, c.z[k].y};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    finite = finite && isfinite(xs[h]) && isfinite(ys[h]) && isfinite(zs[h]);
+                    lo[0] = fminf(lo[0], xs[h]); hi[0] = fmaxf(hi[0], xs[h]);
+                    lo[1] = fminf(lo[1], ys[h]); hi[1] = fmaxf(hi[1], ys[h]);
+                    lo[2] = fminf(lo[2], zs[h]); hi[2] = fmaxf(hi[2], zs[h]);
+                }
+            }
+            if (!finite)  // a member the box cannot bound: the workgroup is always examined
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = -inf;
+                    hi[k] = inf;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], d, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
+        }
+    if (lane == 0)
+        for (int k = 0; k < 3; k++) {
+            red[wave][k] = lo[k];
+            red[wave][3 + k] = hi[k];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kCullBlock / 64; w++)
+            for (int k = 0; k < 3; k++) {
+                red[0][k] = fminf(red[0][k], red[w][k]);
+                red[0][3 + k] = fmaxf(red[0][3 + k], red[w][3 + k]);
+            }
+        out_lo[lb] = make_float4(red[0][0], red[0][1], red[0][2], 0.0f);
+        out_hi[lb] = make_float4(red[0][3], red[0][4], red[0][5], 0.0f);
+    }
+}
+
+hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
+    switch (mesh.mapping) {
+    case kMapExact: hipLaunchKernelGGL((block_bounds_kernel<kMapExact>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    case kMapSpeculate: hipLaunchKernelGGL((block_bounds_kernel<kMapSpeculate>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    default: hipLaunchKernelGGL((block_bounds_kernel<kMapGeneral>), grid, block, 0, stream, mesh, xf, lo, hi); break;
+    }
+    return hipGetLastError();
+}
+
+// K1, batched over views that share cameraPosition (main camera + shadow cascades, mesh.cpp:795-903): the
+// streams are read and the model / corners computed ONCE; each view then costs its plane tests (+ the Hi-Z query
+// on view 0 only) and its own outputs. The reference re-runs the whole loop per pass (mesh.cpp:809-843).
+struct MultiCullArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    HizDevice hiz;
+    float cam[3];
+    float vp0[16];          // view 0's viewProj (Hi-Z query)
+    uint32_t use_hiz0;
+    uint32_t nviews;
+    MultiViewPlanes planes[kMaxBatchViews];
+    ViewBuffers outs[kMaxBatchViews];
+    BlockBounds bounds;  // BOUNDS variants only
+};
+
+template <bool HIZ, uint32_t MAP, bool BOUNDS>
+__global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
+{
+    const uint32_t lb = blockIdx.x;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool in_range = i < args.mesh.count;
+    if (BOUNDS) {  // the workgroup is skipped when its box is outside EVERY view of the batch
+        const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
+        bool skip = true;
+        if (!(lo.x > hi.x)) {
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (v < args.nviews)
+                    skip = skip && block_behind_planes(lo, hi, args.planes[v].planes, args.planes[v].plane_count, args.cam,
+                                                       args.xf.max_depth);
+        }
+        if (threadIdx.x == 0)
+            args.bounds.examined[lb] = skip ? 0 : 1;
+        if (skip) {
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (v < args.nviews) {
+                    if (args.planes[v].write_is_visible && in_range)
+                        args.outs[v].is_visible[i] = 0;
+                    if (lane == 0)
+                        args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
+                }
+            return;
+        }
+    }
+    Mat34 m;
+    Corners c;
+    const bool candidate = in_range && prepare_slot<MAP>(args.mesh, args.xf, args.cam, i, m, c);
+    __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
+#pragma unroll
+    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
+        if (v < args.nviews) {  // uniform
+            bool visible = candidate && !behind_frustum(c, args.planes[v].planes, args.planes[v].plane_count);
+            if (HIZ && v == 0 && visible)
+                visible = !hiz_occluded(args.hiz, args.vp0, c);
+            if (args.planes[v].write_is_visible && in_range)
+                args.outs[v].is_visible[i] = visible ? 1 : 0;
+            const unsigned long long word = __ballot(visible);
+            if (lane == 0) {
+                args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+                wave_count[v][wave] = (uint32_t)__popcll(word);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < args.nviews) {
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kCullBlock / 64; w++)
+            total += wave_count[threadIdx.x][w];
+        if (total) {
+            // outs[] indexed by a lane-varying view: pick the pointer with uniform compares (kernarg stays in SGPRs)
+            uint32_t* counts = nullptr;
+#pragma unroll
+            for (uint32_t v = 0; v < kMaxBatchViews; v++)
+                if (threadIdx.x == v)
+                    counts = args.outs[v].chunk_count;
+            atomicAdd(&counts[lb / (kEmitChunk / kCullBlock)], total);
+        }
+    }
+}
+
+hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
+                             const BlockBounds* bounds)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    if (nviews == 0 || nviews > kMaxBatchViews)
+        return hipErrorInvalidValue;
+    MultiCullArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    for (int k = 0; k < 3; k++)
+        a.cam[k] = views[0].cam[k];
+    for (int k = 0; k < 16; k++)
+        a.vp0[k] = views[0].vp[k];
+    a.use_hiz0 = views[0].use_hiz;
+    a.nviews = nviews;
+    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
+        const ViewParams& src = views[v < nviews ? v : 0];
+        for (int p = 0; p < 6; p++)
+            for (int k = 0; k < 4; k++)
+                a.planes[v].planes[p][k] = src.planes[p][k];
+        a.planes[v].plane_count = src.plane_count;
+        a.planes[v].write_is_visible = src.write_is_visible;
+        a.outs[v] = outs[v < nviews ? v : 0];
+    }
+    const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
+    a.bounds = bounds ? *bounds : BlockBounds{};
+#define GV_LAUNCH_MULTI(HIZ, BOUNDS)                                                                                            \
+    switch (mesh.mapping) {                                                                                                    \
+    case kMapExact: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapSpeculate, BOUNDS>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_multi_kernel<HIZ, kMapGeneral, BOUNDS>), grid, block, 0, stream, a); break;              \
+    }
+    if (a.use_hiz0 && bounds) {
+        GV_LAUNCH_MULTI(true, true)
+    } else if (a.use_hiz0) {
+        GV_LAUNCH_MULTI(true, false)
+    } else if (bounds) {
+        GV_LAUNCH_MULTI(false, true)
+    } else {
+        GV_LAUNCH_MULTI(false, false)
+    }
+#undef GV_LAUNCH_MULTI
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: exclusive scan of the per-block visible counts (one workgroup; <= ~400k blocks at 10^8 slots)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanBlock = 1024;
+
+// n = slots / 4096 chunk totals (2 442 at 10^7 slots): 1024 per pass, coalesced, carry across passes.
+// Reads each count once and writes 0 back so the next frame's cull workgroups can add into it again.
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(uint32_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ offsets,
+                                                          uint32_t* __restrict__ total, uint32_t n)
+{
+    __shared__ uint32_t wave_sum[kScanBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += kScanBlock) {
+        const uint32_t idx = base + threadIdx.x;
+        uint32_t v = 0;
+        if (idx < n) {
+            v = counts[idx];
+            counts[idx] = 0;
+        }
+        uint32_t incl = v;  // wave-level inclusive scan
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += up;
+        }
+        if (lane == 63)
+            wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kScanBlock / 64; w++) {
+            wave_prefix += w < wave ? wave_sum[w] : 0u;
+            all += wave_sum[w];
+        }
+        if (idx < n)
+            offsets[idx] = carry + wave_prefix + incl - v;
+        carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *total = carry;
+}
+
+hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, stream, out.chunk_count, out.chunk_offset,
+                       out.draw_count, chunk_count);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: emit — order-stable compaction of the records of visible slots (mesh.cpp:169-173)
+// ------------------------------------------------------------------------------------------------
+struct EmitArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    ViewParams view;
+    ViewBuffers out;
+    uint32_t nchunks;
+    uint32_t clear_chunks;  // SELF: entries of chunk_count_next to clear (a larger pool may have used it last)
+};
+
+// The record of visible mirror entry i at output position `rank` (mesh.cpp:169-173). Visible entries passed every
+// filter in K1: only the transform entry and its model are needed here.
+__device__ __forceinline__ void write_record(const EmitArgs& args, uint32_t i, size_t rank)
+{
+    // every gather here is a sparse 64-byte fetch for a few useful bytes: the flag byte is only read when the pool has
+    // chains at all
+    const bool chains = args.xf.max_depth != 0;  // uniform
+    uint32_t slot = i;
+    XfRecord rec = {};
+    if (args.mesh.mapping == kMapGeneral) {  // uniform
+        slot = args.mesh.link[i] & kSlotMask;
+        rec = gather_xf(args.xf, slot, chains);
+    } else {
+        rec = gather_xf(args.xf, i, chains);  // same speculation as K1: entry i beside (or instead of) the link word
+        if (args.mesh.mapping == kMapSpeculate) {
+            slot = args.mesh.link[i] & kSlotMask;
+            if (slot != i)
+                rec = gather_xf(args.xf, slot, chains);
+        }
+    }
+    const Mat34 world = chain_model(args.xf, local_model(rec), slot, rec.flags);
+    const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
+    args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
+    float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
+    bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+    bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+    bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    const float tx = m.c3x + args.view.cam_offset[0];
+    const float ty = m.c3y + args.view.cam_offset[1];
+    const float tz = m.c3z + args.view.cam_offset[2];
+    args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+}
+
+// position of the k-th (0-based) set bit of `word`
+__device__ __forceinline__ uint32_t select_bit(unsigned long long word, uint32_t k)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t width = 32; width >= 1; width >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(word & ((1ull << width) - 1ull));
+        if (k >= c) {
+            k -= c;
+            pos += width;
+            word >>= width;
+        }
+    }
+    return pos;
+}
+
+constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slots = 16 ballot words each
+
+// Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
+// chunk's 64 words (512 B, L2), then lane r takes the r-th visible slot of its quarter (binary search over the
+// word prefix + select of the k-th set bit), so the model recompute and the 56-byte record store run on dense
+// waves and only the visible fraction costs instructions. Output rank = chunk base + r: ascending slot order,
+// whatever order the workgroups run in.
+// SELF: no scan launch in front — while wave 0 prefixes the ballot words, waves 1-3 sum the chunk totals below this
+// chunk (a few KB of L2 reads) to get its base; workgroup 0 also writes the grand total and clears the OTHER totals
+// buffer for the next frame's cull (the two buffers alternate, so nobody is still reading the one being cleared).
+template <bool SELF>
+__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
+{
+    __shared__ unsigned long long words[64];
+    __shared__ uint32_t prefix[65];
+    __shared__ uint32_t below[4];
+    const uint32_t chunk = blockIdx.x / kEmitParts, part = blockIdx.x % kEmitParts;
+    const uint32_t first_word = chunk * 64;
+    const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
+    if (threadIdx.x < 64) {
+        const uint32_t w = first_word + threadIdx.x;
+        const unsigned long long word = w < total_words ? args.out.mask[w] : 0ull;
+        uint32_t incl = (uint32_t)__popcll(word);
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (threadIdx.x >= d)
+                incl += up;
+        }
+        words[threadIdx.x] = word;
+        prefix[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0)
+            prefix[0] = 0;
+    } else if (SELF) {
+        const uint32_t upto = blockIdx.x == 0 ? args.nchunks : chunk;  // workgroup 0: the grand total
+        uint32_t sum = 0;
+        for (uint32_t c = threadIdx.x - 64; c < upto; c += 192)
+            sum += args.out.chunk_count[c];
+#pragma unroll
+        for (uint32_t d = 32; d >= 1; d >>= 1)
+            sum += __shfl_xor(sum, d, 64);
+        if ((threadIdx.x & 63u) == 0)
+            below[threadIdx.x >> 6] = sum;
+    }
+    __syncthreads();
+    uint32_t base;
+    if (SELF) {
+        base = below[1] + below[2] + below[3];
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0)
+                *args.out.draw_count = base;
+            for (uint32_t c = threadIdx.x; c < args.clear_chunks; c += 256)
+                args.out.chunk_count_next[c] = 0;
+            base = 0;  // chunk 0 starts the list
+        }
+    } else {
+        base = args.out.chunk_offset[chunk];
+    }
+    const uint32_t wlo = part * (64 / kEmitParts), whi = wlo + 64 / kEmitParts;
+    const uint32_t total = prefix[whi];
+    for (uint32_t r = prefix[wlo] + threadIdx.x; r < total; r += 256) {
+        uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
+#pragma unroll
+        for (int step = 0; step < 4; step++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= r)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t pos = select_bit(words[lo], r - prefix[lo]);
+        const uint32_t i = (first_word + lo) * 64 + pos;
+        write_record(args, i, (size_t)base + r);
+    }
+}
+
+hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
+                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    EmitArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.view = vp;
+    a.out = out;
+    a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    a.clear_chunks = clear_chunks;
+    if (self_prefix)
+        hipLaunchKernelGGL(emit_kernel<true>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(emit_kernel<false>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pack_active_kernel(const uint8_t* __restrict__ flags, uint32_t count,
+                                                          unsigned long long* __restrict__ bits)
+{
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    const bool active = e < count && (flags[e] & kXfActive);
+    const unsigned long long word = __ballot(active);
+    if ((threadIdx.x & 63u) == 0 && (e & ~63u) < count)
+        bits[e >> 6] = word;
+}
+
+hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(pack_active_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, flags, count, bits);
+    return hipGetLastError();
+}
+
+// Dirty TransformComponents shipped as raw AoS bytes (slots [first, first + count) of the caller's pool, copied as they
+// lie): the AoS -> SoA gather that the host otherwise does runs here, at HBM speed. Parent links are not touched
+// (this path serves GV_DIRTY_TRANSFORM; link changes go through the host, which also validates depth and cycles).
+__global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __restrict__ raw, AosTransformLayout L,
+                                                             uint32_t first, uint32_t count,
+                                                             const uint32_t* __restrict__ xinv, float4* __restrict__ a,
+                                                             float4* __restrict__ b, float2* __restrict__ c,
+                                                             uint8_t* __restrict__ flags)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint8_t* t = raw + (size_t)k * L.stride;
+    float pos[3], scl[3], rot[4];
+    uint32_t entity;
+    memcpy(pos, t + L.position, 12);
+    memcpy(scl, t + L.scale, 12);
+    memcpy(rot, t + L.rotation, 16);
+    memcpy(&entity, t + L.entity, 4);
+    uint8_t f = 0;
+    if (entity)
+        f |= kXfLive;
+    if (t[L.self_active] && t[L.ancestors_active])
+        f |= kXfActive;
+    if (t[L.model_with_ancestors])
+        f |= kXfWithAncestors;
+    const uint32_t s = first + k;
+    const uint32_t j = xinv ? xinv[s] : s;
+    a[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
+    b[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+    c[j] = make_float2(scl[1], scl[2]);
+    flags[j] = f;
+}
+
+hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
+                                 const uint32_t* xinv, float4* a, float4* b, float2* c, uint8_t* flags, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(aos_transforms_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, xinv,
+                       a, b, c, flags);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_kernel(const uint32_t* __restrict__ idx, uint32_t count,
+                                                      const T* __restrict__ src, T* __restrict__ dst)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+        dst[idx[k]] = src[k];
+}
+
+hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
+                          hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    const dim3 grid(min((count + 255u) / 256u, 4096u)), block(256);
+    switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(scatter_kernel<uint8_t>, grid, block, 0, stream, idx, count, (const uint8_t*)src, (uint8_t*)dst); break;
+    case 4: hipLaunchKernelGGL(scatter_kernel<uint32_t>, grid, block, 0, stream, idx, count, (const uint32_t*)src, (uint32_t*)dst); break;
+    case 8: hipLaunchKernelGGL(scatter_kernel<float2>, grid, block, 0, stream, idx, count, (const float2*)src, (float2*)dst); break;
+    case 16: hipLaunchKernelGGL(scatter_kernel<float4>, grid, block, 0, stream, idx, count, (const float4*)src, (float4*)dst); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_world_kernel(const float4* __restrict__ world, const uint32_t* __restrict__ xinv,
+                                                           uint32_t first, uint32_t count, float4* __restrict__ out)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count * 3; k += gridDim.x * blockDim.x) {
+        const uint32_t s = k / 3, part = k - s * 3;
+        out[k] = world[(size_t)xinv[first + s] * 3 + part];
+    }
+}
+
+hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32_t first, uint32_t count, float4* out,
+                               hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gather_world_kernel, dim3(min((count * 3 + 255u) / 256u, 4096u)), dim3(256), 0, stream, world, xinv,
+                       first, count, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_idx_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
+                                                       uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+{
+    const uint32_t n = min(*count, capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = src[i] + base;
+}
+
+hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(copy_idx_kernel, dim3(2048), dim3(256), 0, stream, src, count, dst, capacity, base);
+    return hipGetLastError();
+}
+
+// exchange shard: [draw_count, idx + base ...]; the header is the true count even when it exceeds `capacity`
+__global__ __launch_bounds__(256) void copy_shard_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
+                                                         uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+{
+    const uint32_t total = *count, n = min(total, capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        dst[0] = total;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[1 + i] = src[i] + base;
+}
+
+hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                             hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 255u) / 256u));
+    hipLaunchKernelGGL(copy_shard_kernel, dim3(blocks), dim3(256), 0, stream, src, count, dst, capacity, base);
+    return hipGetLastError();
+}
+
+}  // namespace gv

@@ -1,0 +1,172 @@
+// gv_hiz.hip — Hi-Z pyramid: HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167) with the reduction
+// rule of shaders/hiz.frag:23-63.
+#include "gv_device.hpp"
+
+namespace gv {
+
+// ------------------------------------------------------------------------------------------------
+// Hi-Z pyramid
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 hiz_src(const float* d, const float2* p, uint32_t sw, uint32_t x, uint32_t y)
+{
+    if (d) {  // HIZ_VARIANT_FIRST: (d, d)  hiz.frag:57-60
+        const float v = d[(size_t)y * sw + x];
+        return make_float2(v, v);
+    }
+    return p[(size_t)y * sw + x];
+}
+__device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
+{
+    mm.x = t.x < mm.x ? t.x : mm.x;  // MIN_DEPTH  depth.gsl:30-31
+    mm.y = t.y > mm.y ? t.y : mm.y;  // MAX_DEPTH  depth.gsl:32-33
+}
+
+// One destination texel per lane; any size (hiz.frag:27-56 with the odd-size branches).
+__global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict__ src_depth,
+                                                        const float2* __restrict__ src_pairs,
+                                                        float2* __restrict__ dst, uint32_t sw, uint32_t sh, uint32_t dw,
+                                                        uint32_t dh, uint32_t rule)
+{
+    const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63u);
+    const uint32_t py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= dw || py >= dh)
+        return;
+    const bool odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0;
+    const uint32_t x0 = 2 * px, y0 = 2 * py;
+    const uint32_t x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const uint32_t x2 = min(x0 + 2, sw - 1), y2 = min(y0 + 2, sh - 1);
+    float2 mm = hiz_src(src_depth, src_pairs, sw, x0, y0);
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y0));
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y1));
+    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y1));
+    if (odd_x) {  // hiz.frag:36-41
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y1));
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y0));
+        if (odd_y)  // hiz.frag:43-47
+            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y2));
+    }
+    if (odd_y) {  // hiz.frag:49-55 reads gather components .y/.z = (2p.x+1, 2p.y+2), (2p.x+1, 2p.y+1)
+        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y2));
+        if (rule == 1u)  // GV_HIZ_RULE_CONSERVATIVE: the whole extra row
+            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y2));
+    }
+    dst[(size_t)py * dw + px] = mm;
+}
+
+hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
+                            uint32_t dw, uint32_t dh, uint32_t rule, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hiz_level_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, stream, src_depth, src_pairs,
+                       dst, sw, sh, dw, dh, rule);
+    return hipGetLastError();
+}
+
+// Fused: one workgroup reduces a 64x64 source tile to 32^2, 16^2, 8^2, 4^2, 2^2 and 1 texel — six
+// levels in one pass, the source read once, intermediate levels staged in LDS instead of re-read
+// from HBM (the reference re-reads every mip in its own render pass, hiz.cpp:155-164).
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict__ src_depth,
+                                                        const float2* __restrict__ src_pairs, const HizFusedDst dst,
+                                                        uint32_t sw, uint32_t sh)
+{
+    __shared__ float2 lds16[16][17];
+    __shared__ float2 lds8[8][9];
+    __shared__ float2 lds4[4][5];
+    __shared__ float2 lds2[2][3];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t ox = blockIdx.x * 64, oy = blockIdx.y * 64;
+    const uint32_t px = ox + 4 * tx, py = oy + 4 * ty;
+    float mn[4][4], mx[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (PAIRS) {
+            const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
+            const float4 lo = row[0], hi = row[1];
+            mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
+            mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
+        } else {
+            const float4 v = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
+            mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
+            mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
+        }
+    }
+    // level +1: 2x2 texels per lane
+    float2 q[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            float2 mm = make_float2(mn[2 * a][2 * b], mx[2 * a][2 * b]);
+            hiz_acc(mm, make_float2(mn[2 * a][2 * b + 1], mx[2 * a][2 * b + 1]));
+            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b], mx[2 * a + 1][2 * b]));
+            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b + 1], mx[2 * a + 1][2 * b + 1]));
+            q[a][b] = mm;
+        }
+    const uint32_t w1 = sw >> 1;
+    if (dst.level[0]) {  // null: the level stays virtual (queries reduce the source themselves)
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            float4* o = reinterpret_cast<float4*>(dst.level[0] + (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx);
+            *o = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
+        }
+    }
+    // level +2: one texel per lane
+    float2 m2 = q[0][0];
+    hiz_acc(m2, q[0][1]);
+    hiz_acc(m2, q[1][0]);
+    hiz_acc(m2, q[1][1]);
+    dst.level[1][(size_t)(oy / 4 + ty) * (sw >> 2) + ox / 4 + tx] = m2;
+    lds16[ty][tx] = m2;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // level +3: 8x8
+        const uint32_t x = threadIdx.x & 7u, y = threadIdx.x >> 3;
+        float2 mm = lds16[2 * y][2 * x];
+        hiz_acc(mm, lds16[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds16[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds16[2 * y + 1][2 * x + 1]);
+        dst.level[2][(size_t)(oy / 8 + y) * (sw >> 3) + ox / 8 + x] = mm;
+        lds8[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {  // level +4: 4x4
+        const uint32_t x = threadIdx.x & 3u, y = threadIdx.x >> 2;
+        float2 mm = lds8[2 * y][2 * x];
+        hiz_acc(mm, lds8[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds8[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds8[2 * y + 1][2 * x + 1]);
+        dst.level[3][(size_t)(oy / 16 + y) * (sw >> 4) + ox / 16 + x] = mm;
+        lds4[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {  // level +5: 2x2
+        const uint32_t x = threadIdx.x & 1u, y = threadIdx.x >> 1;
+        float2 mm = lds4[2 * y][2 * x];
+        hiz_acc(mm, lds4[2 * y][2 * x + 1]);
+        hiz_acc(mm, lds4[2 * y + 1][2 * x]);
+        hiz_acc(mm, lds4[2 * y + 1][2 * x + 1]);
+        dst.level[4][(size_t)(oy / 32 + y) * (sw >> 5) + ox / 32 + x] = mm;
+        lds2[y][x] = mm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // level +6: 1 texel
+        float2 mm = lds2[0][0];
+        hiz_acc(mm, lds2[0][1]);
+        hiz_acc(mm, lds2[1][0]);
+        hiz_acc(mm, lds2[1][1]);
+        dst.level[5][(size_t)(oy / 64) * (sw >> 6) + ox / 64] = mm;
+    }
+    (void)sh;
+}
+
+hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
+                            uint32_t sh, hipStream_t stream)
+{
+    const dim3 grid(sw / 64, sh / 64);
+    if (src_depth)
+        hipLaunchKernelGGL(hiz_fused_kernel<false>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    else
+        hipLaunchKernelGGL(hiz_fused_kernel<true>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    return hipGetLastError();
+}
+
+}  // namespace gv
