@@ -197,6 +197,7 @@ void gv_destroy(GvCtx* ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);
+    exchange_release(ctx);
     for (auto& ev : ctx->free_events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);

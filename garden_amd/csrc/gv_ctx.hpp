@@ -277,6 +277,11 @@ struct Context {
     bool hiz_level1_virtual = false;   // decided in gv_hiz_build: sizes whose first six levels take the fused kernel
     bool hiz_level1_stored = false;    // ... and whether gv_hiz_read_level has materialised it since the last build
 
+    // ---- multi-GPU exchange (gv_exchange.cpp) ----
+    void* exchange_comm = nullptr;     // ncclComm_t
+    int exchange_rank = 0, exchange_world = 1;
+    DeviceBuf<uint32_t> d_shard;       // [count, indices...] of this rank
+
     // ---- profiling ----
     std::vector<PendingEvent> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -375,6 +380,9 @@ void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
 }
 
 void drain_events(GvCtx* ctx);
+
+// gv_exchange.cpp
+void exchange_release(GvCtx* ctx);            // destroys the communicator, if any
 
 // gv_mirror.cpp
 int sync_mirror(GvCtx* ctx);                 // brings the device mirror up to date with the bound pools + dirty ranges

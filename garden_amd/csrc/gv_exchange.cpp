@@ -1,0 +1,151 @@
+// gv_exchange.cpp — the multi-GPU exchange step of SURVEY.md §8e in the C-ABI, for hosts without torch.distributed
+// (a C++ engine, one process per GPU): every rank's compact visible list goes out as a fixed-capacity shard
+// [draw_count, global indices ...] and all ranks gather the shards with ONE equal-size ncclAllGather enqueued on the
+// context's stream — no host synchronisation; counts are read from the shard headers. Same wire format as
+// garden_amd/multi.py::VisibleListExchange (which does this through torch.distributed in bench.py).
+//
+// RCCL is bound at run time (dlopen): a process that already carries an RCCL — PyTorch bundles one — keeps using that
+// copy, and libgarden_vis.so has no link-time dependency on it.
+#include <dlfcn.h>
+
+#include "gv_ctx.hpp"
+
+namespace {
+
+struct NcclId {
+    char bytes[GV_EXCHANGE_ID_BYTES];
+};
+using ncclComm_t = void*;
+
+struct Rccl {
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {  // an already loaded copy first
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (h)
+                break;
+        }
+        if (!h)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h)
+                    break;
+            }
+        if (!h) {
+            r.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+            return;
+        }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+        if (!r.ok)
+            r.why = "librccl lacks an expected symbol";
+    });
+    return r;
+}
+
+constexpr int kNcclUint32 = 3;  // ncclUint32 (rccl.h: ncclDataType_t)
+
+}  // namespace
+
+namespace gv {
+
+void exchange_release(GvCtx* ctx)
+{
+    if (ctx->exchange_comm) {
+        Rccl& r = rccl();
+        if (r.ok)
+            (void)r.CommDestroy(ctx->exchange_comm);
+        ctx->exchange_comm = nullptr;
+    }
+    ctx->d_shard.release();
+}
+
+}  // namespace gv
+
+extern "C" {
+
+int gv_exchange_unique_id(void* out_id)
+{
+    if (!out_id)
+        return GV_E_ARG;
+    Rccl& r = rccl();
+    if (!r.ok)
+        return GV_E_RCCL;
+    NcclId id{};
+    if (r.GetUniqueId(&id) != 0)
+        return GV_E_RCCL;
+    memcpy(out_id, id.bytes, GV_EXCHANGE_ID_BYTES);
+    return GV_OK;
+}
+
+int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!unique_id || world_size < 1 || rank < 0 || rank >= world_size)
+        return ctx->fail(GV_E_ARG, "gv_exchange_init: bad rank %d / world %d", rank, world_size);
+    Rccl& r = rccl();
+    if (!r.ok)
+        return ctx->fail(GV_E_RCCL, "gv_exchange_init: %s", r.why.c_str());
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    gv::exchange_release(ctx);
+    NcclId id{};
+    memcpy(id.bytes, unique_id, GV_EXCHANGE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    const int rc = r.CommInitRank(&comm, world_size, id, rank);
+    if (rc != 0)
+        return ctx->fail(GV_E_RCCL, "ncclCommInitRank: %s", r.GetErrorString(rc));
+    ctx->exchange_comm = comm;
+    ctx->exchange_rank = rank;
+    ctx->exchange_world = world_size;
+    return GV_OK;
+}
+
+int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_shards: gv_exchange_init has not run");
+    if (!gathered_device || capacity == 0)
+        return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, ctx->d_shard.reserve((size_t)capacity + 1));
+    const int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, capacity, index_base);
+    if (rc != GV_OK)
+        return rc;
+    Rccl& r = rccl();
+    const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, (size_t)capacity + 1, kNcclUint32, ctx->exchange_comm, ctx->stream);
+    if (nrc != 0)
+        return ctx->fail(GV_E_RCCL, "ncclAllGather: %s", r.GetErrorString(nrc));
+    return GV_OK;
+}
+
+int gv_exchange_shutdown(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    gv::exchange_release(ctx);
+    return GV_OK;
+}
+
+}  // extern "C"

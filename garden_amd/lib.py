@@ -103,6 +103,7 @@ EXPORTS = [
     "gv_stream",
     "gv_scene_parse_json", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown",
 ]
 
 _lib = None
@@ -165,6 +166,10 @@ def load():
                                                C.POINTER(u32), C.POINTER(P)]
     lib.gv_scene_mesh_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), C.POINTER(u32)]
     lib.gv_scene_bind.argtypes = [P, P]
+    lib.gv_exchange_unique_id.argtypes = [P]
+    lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
+    lib.gv_exchange_shards.argtypes = [P, u32, u32, u32, P]
+    lib.gv_exchange_shutdown.argtypes = [P]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream", "gv_scene_destroy"):
@@ -322,6 +327,24 @@ class GpuVisibility:
     def copy_shard_device(self, view_index, dst_ptr, capacity, index_base=0):
         """dst[0] = draw_count, dst[1:1+min(count, capacity)] = visible_idx + index_base (device memory, no sync)."""
         self._check(self.lib.gv_results_copy_shard_device(self.ctx, view_index, dst_ptr, capacity, index_base))
+
+    # ---- native RCCL exchange (C++ engines; bench.py goes through torch.distributed instead) ----
+    @staticmethod
+    def exchange_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load().gv_exchange_unique_id(buf)
+        if rc != GV_OK:
+            raise GvError(rc, "gv_exchange_unique_id failed (RCCL not loadable?)")
+        return buf.raw
+
+    def exchange_init(self, unique_id, rank, world_size):
+        self._check(self.lib.gv_exchange_init(self.ctx, unique_id, rank, world_size))
+
+    def exchange_shards(self, view_index, capacity, index_base, gathered_ptr):
+        self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, index_base, gathered_ptr))
+
+    def exchange_shutdown(self):
+        self._check(self.lib.gv_exchange_shutdown(self.ctx))
 
     def stream(self):
         """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""

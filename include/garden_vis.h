@@ -203,6 +203,20 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                  uint32_t index_base);
 
+/* ---- multi-GPU exchange without torch.distributed (one process per GPU) ----
+ * Rank 0 calls gv_exchange_unique_id and hands the 128 bytes to the other ranks by its own means (the engine's IPC, a
+ * file, MPI ...); every rank then calls gv_exchange_init with its own context. gv_exchange_shards enqueues, on the
+ * context's stream: this rank's shard [draw_count, visible_idx + index_base ...] (capacity + 1 uint32, see
+ * gv_results_copy_shard_device) and ONE ncclAllGather of all shards into gathered_device (world_size * (capacity + 1)
+ * uint32, caller-owned device memory; row r = rank r's shard). No host synchronisation: consumers order themselves
+ * behind gv_stream(ctx) and read the counts from the headers (a header above `capacity` = that rank's list was cut).
+ * RCCL is dlopen'ed at the first call; failures return GV_E_RCCL with the RCCL text in gv_last_error. */
+#define GV_EXCHANGE_ID_BYTES 128
+int gv_exchange_unique_id(void* out_id_128_bytes);
+int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int world_size);
+int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device);
+int gv_exchange_shutdown(GvCtx* ctx);
+
 /* Sorts view `view_index`'s compact records on the device by distanceSq: ascending (descending == 0) as sortMeshes
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
  * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: equal keys keep the order the records were

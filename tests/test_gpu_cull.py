@@ -756,3 +756,31 @@ def test_pools_of_different_sizes_alternate_on_the_same_view(gpu, oracle):
             got = gpu.fetch(0, write_back=False, occupancy=(big if pid == 0 else small).count)
             assert np.array_equal(got["visible_idx"], exp[pid][0]), pid
         assert gpu.result_count(0) == exp[pid][1], pid
+
+
+def test_native_rccl_exchange_single_rank(oracle):
+    """gv_exchange_*: the C-ABI's own all-gather of the visible-list shards (RCCL bound at run time). One rank is all a
+    1-GPU box can run; the multi-rank wire format is the one test_host_logic.py checks through gloo."""
+    import torch
+    from garden_amd.lib import GpuVisibility
+    sc = scene.flat_scene(40_000)
+    view = scene.main_camera_view()
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
+        cap = 16_384
+        gathered = torch.full((1 * (1 + cap),), -1, dtype=torch.int32, device="cuda:0")
+        for frame in range(3):
+            vis.cull(0, [view])
+            vis.exchange_shards(0, cap, 5_000_000, gathered.data_ptr())
+        vis.wait()
+        raw = vis.fetch(0, write_back=False, occupancy=sc.count, order="raw")
+        g = gathered.cpu().numpy()
+        k = raw["draw_count"]
+        assert g[0] == k and 0 < k <= cap
+        assert np.array_equal(g[1:1 + k].astype(np.int64), raw["visible_idx"].astype(np.int64) + 5_000_000)
+        vis.exchange_shutdown()
+        with pytest.raises(Exception):
+            vis.exchange_shards(0, cap, 0, gathered.data_ptr())  # GV_E_STATE after shutdown
