@@ -15,7 +15,8 @@ def _built():
     lib = os.path.join(ROOT, "garden_amd", "lib", "libgarden_vis.so")
     orc = os.path.join(ROOT, "oracle", "build", "libgv_oracle.so")
     tick = os.path.join(ROOT, "tests", "cpp", "build", "headless_tick")
-    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(tick)):
+    ranks = os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks")
+    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(tick) and os.path.exists(ranks)):
         import __graft_entry__
         __graft_entry__.build()
 

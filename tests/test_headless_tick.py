@@ -80,3 +80,17 @@ def test_gpu_system_fails_loudly_without_device(tick):
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", "--ticks", "3", *args)
     assert out["draw_count"] > 0
+
+
+@pytest.mark.gpu
+def test_native_exchange_driver_one_process_per_gpu():
+    """tests/cpp/exchange_ranks: the exchange through the C-ABI alone (fork per rank, unique id over pipes, RCCL bound at
+    run time). The GPU test tier runs on 1-GPU boxes, so this is the 1-rank communicator; on a multi-GPU node run
+    `tests/cpp/build/exchange_ranks --ranks N` by hand (one rank per GPU: RCCL refuses two ranks on one device)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
+    ranks = 1
+    p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks"), "--ranks", str(ranks), "--entities", "200000"],
+                       capture_output=True, text=True, timeout=600)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == ranks and all(l["ok"] and l["visible"] > 0 for l in lines), (p.stdout, p.stderr[-2000:])
+    assert all(l["gathered"] == sum(x["visible"] for x in lines) for l in lines)
