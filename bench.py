@@ -4,6 +4,7 @@
 A "step" is one frame of the hot path over one batch of resident component pools:
   cfg2: 1M static entities, flat, frustum-only cull + compaction
   cfg3: 10M entities, Hi-Z pyramid rebuild (4096^2 depth) + frustum + Hi-Z occlusion cull + compaction  [default]
+  cfg5: 12.5M entities per GPU (100M over 8 GPUs), flat, frustum-only + the exchange (run with --gpus 8)
   cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep fused with the frustum cull (one pass) + compaction
         (--sweep mfma|valu: separate sweep and cull launches; fused-valu: the fused pass with the v_fma chain)
 For N > 1 each rank owns one spatial tile (same per-GPU entity count: weak scaling), culls it against the
@@ -30,6 +31,8 @@ WORKLOADS = {
                  name="cfg2: 1M static entities, flat hierarchy, frustum-only AABB cull, fp32"),
     "cfg3": dict(entities=10_000_000, hier=False, hiz=True, sweep=False,
                  name="cfg3: 10M entities, frustum + Hi-Z occlusion vs synthetic 4096^2 depth pyramid (rebuilt per frame)"),
+    "cfg5": dict(entities=12_500_000, hier=False, hiz=False, sweep=False,
+                 name="cfg5: 100M entities over 8 spatial tiles (12.5M per GPU), frustum-only cull per tile + all-gather of the visible lists"),
     "cfg4": dict(entities=10_000_000, hier=True, hiz=False, sweep=True,
                  name="cfg4: 10M entities, 4-deep transform hierarchy recomputed each frame (MFMA 4x4 chain sweep) + cull"),
 }
