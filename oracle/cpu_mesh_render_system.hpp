@@ -36,6 +36,7 @@ private:
 public:
     bool isEnabled = true;
     bool sortMeshes = true;  // mesh.cpp:548-551: prepareMeshes ends with sortMeshes()
+    bool useAvx2 = false;    // 8-wide AVX2+FMA SoA path instead of the scalar AoS loop (bit-identical)
     uint32_t threads = 1;    // asyncPreparing (mesh.cpp:399): >1 fans out like ThreadPool::addItems
     f32x4x4 uiViewProj;      // calcUiProjView(), mesh.cpp:851-859 (set by the driver)
 
@@ -81,13 +82,22 @@ private:
         return view;
     }
 
-    // one prepareUnsortedMeshes / prepareSortedMeshes dispatch (mesh.cpp:111-262) through the scalar oracle
+    // one prepareUnsortedMeshes / prepareSortedMeshes dispatch (mesh.cpp:111-262) through the oracle: the scalar loop over
+    // the AoS pools, or (useAvx2) the 8-wide AVX2+FMA loop over an SoA copy of them, rebuilt per dispatch — the reference
+    // build targets -march=haswell (cmake/compile-options.cmake:34-36); both give the same bits
     GvoCullOut run(const GvoMeshPool& mp, const GvoTransformPool& tp, const GvoView& view)
     {
         const size_t n = mp.occupancy ? mp.occupancy : 1;
         idx.resize(n); baked.resize(n * 12); dist.resize(n);
         GvoCullOut out{idx.data(), baked.data(), dist.data(), 0, 0};
-        gvo_prepare_meshes(&mp, &tp, &view, nullptr, threads, &out);
+        if (useAvx2) {
+            GvoSoa* soa = gvo_soa_build(&mp, &tp);
+            gvo_prepare_meshes_avx2(soa, &mp, &view, nullptr, threads, &out);
+            gvo_soa_free(soa);
+            // the AVX2 path reports records in slot order per thread range too: same contract as the scalar one
+        } else {
+            gvo_prepare_meshes(&mp, &tp, &view, nullptr, threads, &out);
+        }
         return out;
     }
     void fill(UnsortedBuffer* buffer, IMeshRenderSystem* ms, const GvoCullOut& out, size_t stride)

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -160,7 +160,7 @@ int main(int argc, char** argv)
 {
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
-    bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false;
+    bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -172,6 +172,7 @@ int main(int argc, char** argv)
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
         else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
+        else if (a == "--avx2") avx2 = true;  // CPU system: AVX2+FMA SoA path (bit-identical to the scalar loop)
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
     }
@@ -202,6 +203,7 @@ int main(int argc, char** argv)
         if (mode == "cpu" || mode == "both") {
             cpu = manager.createSystem<CpuMeshRenderSystem>();
             cpu->threads = threads;
+            cpu->useAvx2 = avx2;
         }
         if (mode == "gpu" || mode == "both")
             gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);

@@ -30,6 +30,10 @@ def test_cfg1_cpu_reference_path_headless_tick(tick):
     assert 0 < one["draw_count"] < 10000 and one["is_visible_set"] == one["draw_count"]
     _, many = tick("--mode", "cpu", "--entities", "10000", "--ticks", "20", "--threads", "4")
     assert many["draw_count"] == one["draw_count"]  # range split does not change the set (thread-pool.cpp:173-200)
+    # the AVX2+FMA SoA path (the reference builds for -march=haswell): same visible set, 1 thread and several
+    _, avx = tick("--mode", "cpu", "--entities", "10000", "--ticks", "20", "--avx2")
+    _, avx4 = tick("--mode", "cpu", "--entities", "10000", "--ticks", "20", "--avx2", "--threads", "4")
+    assert avx["draw_count"] == one["draw_count"] == avx4["draw_count"] and avx["is_visible_set"] == one["is_visible_set"]
 
 
 def test_cpu_hierarchy_and_mutations(tick):
@@ -64,6 +68,7 @@ def test_gpu_system_fails_loudly_without_device(tick):
 @pytest.mark.parametrize("args", [
     ["--entities", "10000"],
     ["--entities", "10000", "--threads", "8"],
+    ["--entities", "30000", "--hier", "--mutate", "--avx2"],
     ["--entities", "50000", "--hier"],
     ["--entities", "50000", "--hier", "--mutate"],
     ["--entities", "1000", "--mutate"],
