@@ -178,10 +178,65 @@ __global__ __launch_bounds__(256) void sort_gather_kernel(const uint32_t* __rest
     }
 }
 
+// Small pools (up to kSmallSort records possible): ONE workgroup sorts (key, emission index) pairs in LDS with a
+// bitonic network and gathers the records — one launch instead of fourteen. The emission index as the minor key makes
+// the network's result the stable order, i.e. exactly what the radix passes produce.
+constexpr uint32_t kSmallSort = 4096;
+
+__global__ __launch_bounds__(1024) void sort_small_kernel(const SortBuffers b, uint32_t descending)
+{
+    __shared__ unsigned long long item[kSmallSort];  // (order-preserving key << 32) | emission index
+    const uint32_t n = min(*b.count, kSmallSort);
+    uint32_t m = 1;
+    while (m < n)
+        m <<= 1;  // network size: next power of two, padded with +inf items
+    for (uint32_t j = threadIdx.x; j < m; j += 1024) {
+        unsigned long long v = ~0ull;
+        if (j < n) {
+            const uint32_t u = __float_as_uint(b.dist_in[j]);
+            uint32_t k = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+            if (descending)
+                k = ~k;
+            v = ((unsigned long long)k << 32) | j;
+        }
+        item[j] = v;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (m >> 1); t += 1024) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));  // first element of the pair
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = item[lo], c = item[hi];
+                if ((a > c) == up) {
+                    item[lo] = c;
+                    item[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+        const uint32_t src = (uint32_t)item[j];
+        b.idx_out[j] = b.idx_in[src];
+        b.dist_out[j] = b.dist_in[src];
+        const float4* sm = reinterpret_cast<const float4*>(b.model_in + (size_t)src * 12);
+        float4* dm = reinterpret_cast<float4*>(b.model_out + (size_t)j * 12);
+        const float4 m0 = sm[0], m1 = sm[1], m2 = sm[2];
+        dm[0] = m0;
+        dm[1] = m1;
+        dm[2] = m2;
+    }
+}
+
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream)
 {
     if (capacity == 0)
         return hipSuccess;
+    if (capacity <= kSmallSort) {
+        hipLaunchKernelGGL(sort_small_kernel, dim3(1), dim3(1024), 0, stream, b, descending ? 1u : 0u);
+        return hipGetLastError();
+    }
     const uint32_t stride = (capacity + kSortTile - 1) / kSortTile;  // tiles at full capacity = hist row stride
     const uint32_t wide = min((capacity + 255u) / 256u, 4096u);
     hipLaunchKernelGGL(sort_keys_kernel, dim3(wide), dim3(256), 0, stream, b.dist_in, b.count, b.keys[0], b.vals[0],

@@ -202,7 +202,8 @@ def test_batched_views_equal_separate_passes(gpu, oracle):
         assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
 
 
-@pytest.mark.parametrize("n,descending,d2", [(100_000, False, 0), (100_000, True, 0), (300_000, False, 0), (5_000, True, 1), (70, False, 0)])
+@pytest.mark.parametrize("n,descending,d2", [(100_000, False, 0), (100_000, True, 0), (300_000, False, 0), (5_000, True, 1), (70, False, 0),
+                                            (4096, False, 0), (4000, True, 0), (513, False, 1), (3, True, 0), (40, False, 0)])  # <= 4096: one-launch LDS sort
 def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     """gv_sort == sortMeshes (mesh.cpp:265-328): ascending distanceSq for unsorted buffers, descending for the
     sorted ones; the oracle breaks ties by slot, and so does the stable radix sort."""
