@@ -127,7 +127,10 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint3
     if (!gathered_device || capacity == 0)
         return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
     GV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* before = ctx->d_shard.ptr;
     GV_HIP(ctx, ctx->d_shard.reserve((size_t)capacity + 1));
+    if (ctx->d_shard.ptr != before)  // the collective reads the whole shard: no byte of it is left uninitialised
+        GV_HIP(ctx, hipMemsetAsync(ctx->d_shard.ptr, 0, ctx->d_shard.cap * sizeof(uint32_t), ctx->stream));
     const int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, capacity, index_base);
     if (rc != GV_OK)
         return rc;
