@@ -202,8 +202,8 @@ void gv_destroy(GvCtx* ctx)
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    ctx->d_xa.release(); ctx->d_xb.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
-    ctx->h_xa.release(); ctx->h_xb.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
+    ctx->d_xab.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
+    ctx->h_xab.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
         p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release();
     }
@@ -216,8 +216,8 @@ void gv_destroy(GvCtx* ctx)
         v.h_distance_sq.release(); v.h_is_visible.release(); v.h_is_visible_mirror.release();
     }
     ctx->d_world.release();
-    ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_b.release(); ctx->sc_c.release(); ctx->sc_u8.release();
-    ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_b.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
+    ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
+    ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
     ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release();
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);

@@ -225,12 +225,12 @@ struct Context {
     uint64_t xf_epoch = 1;         // bumped whenever the transform mirror changes
     uint32_t xf_mirrored = 0, xf_appended = 0;  // as PoolState::mirrored / appended, for the transform pool
     uint32_t max_depth = 0;        // longest parent chain in the mirror
-    DeviceBuf<float4> d_xa, d_xb;
+    DeviceBuf<XfAB> d_xab;         // {pos|scale.x, quat} per entry
     DeviceBuf<float2> d_xc;
     DeviceBuf<uint8_t> d_xflags;
     DeviceBuf<unsigned long long> d_xactive;  // bit-plane of kXfActive, derived on the device
     DeviceBuf<uint32_t> d_xparent;
-    PinnedBuf<float4> h_xa, h_xb;
+    PinnedBuf<XfAB> h_xab;
     PinnedBuf<float2> h_xc;
     PinnedBuf<uint8_t> h_xflags;
     PinnedBuf<uint32_t> h_xparent;
@@ -243,11 +243,13 @@ struct Context {
     bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // turned off after a failed page-lock, or by the env
     // scratch of the scattered (dirty-range) host upload path
     PinnedBuf<uint32_t> sc_idx, sc_u32;
-    PinnedBuf<float4> sc_a, sc_b;
+    PinnedBuf<float4> sc_a;
+    PinnedBuf<XfAB> sc_ab;
     PinnedBuf<float2> sc_c;
     PinnedBuf<uint8_t> sc_u8;
     DeviceBuf<uint32_t> dsc_idx, dsc_u32;
-    DeviceBuf<float4> dsc_a, dsc_b;
+    DeviceBuf<float4> dsc_a;
+    DeviceBuf<XfAB> dsc_ab;
     DeviceBuf<float2> dsc_c;
     DeviceBuf<uint8_t> dsc_u8;
 

@@ -591,9 +591,8 @@ hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned lon
 // (this path serves GV_DIRTY_TRANSFORM; link changes go through the host, which also validates depth and cycles).
 __global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __restrict__ raw, AosTransformLayout L,
                                                              uint32_t first, uint32_t count,
-                                                             const uint32_t* __restrict__ xinv, float4* __restrict__ a,
-                                                             float4* __restrict__ b, float2* __restrict__ c,
-                                                             uint8_t* __restrict__ flags)
+                                                             const uint32_t* __restrict__ xinv, XfAB* __restrict__ ab,
+                                                             float2* __restrict__ c, uint8_t* __restrict__ flags)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count)
@@ -614,19 +613,19 @@ __global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __re
         f |= kXfWithAncestors;
     const uint32_t s = first + k;
     const uint32_t j = xinv ? xinv[s] : s;
-    a[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
-    b[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+    ab[j].a = make_float4(pos[0], pos[1], pos[2], scl[0]);
+    ab[j].b = make_float4(rot[0], rot[1], rot[2], rot[3]);
     c[j] = make_float2(scl[1], scl[2]);
     flags[j] = f;
 }
 
 hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
-                                 const uint32_t* xinv, float4* a, float4* b, float2* c, uint8_t* flags, hipStream_t stream)
+                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, hipStream_t stream)
 {
     if (count == 0)
         return hipSuccess;
     hipLaunchKernelGGL(aos_transforms_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, xinv,
-                       a, b, c, flags);
+                       ab, c, flags);
     return hipGetLastError();
 }
 
@@ -649,6 +648,7 @@ hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, 
     case 4: hipLaunchKernelGGL(scatter_kernel<uint32_t>, grid, block, 0, stream, idx, count, (const uint32_t*)src, (uint32_t*)dst); break;
     case 8: hipLaunchKernelGGL(scatter_kernel<float2>, grid, block, 0, stream, idx, count, (const float2*)src, (float2*)dst); break;
     case 16: hipLaunchKernelGGL(scatter_kernel<float4>, grid, block, 0, stream, idx, count, (const float4*)src, (float4*)dst); break;
+    case 32: hipLaunchKernelGGL(scatter_kernel<XfAB>, grid, block, 0, stream, idx, count, (const XfAB*)src, (XfAB*)dst); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -45,8 +45,8 @@ struct XfRecord {
 __device__ __forceinline__ XfRecord load_xf(const TransformMirror& xf, uint32_t s)
 {
     XfRecord r;
-    r.a = xf.a[s];
-    r.b = xf.b[s];
+    r.a = xf.ab[s].a;
+    r.b = xf.ab[s].b;
     r.c = xf.c[s];
     r.flags = xf.flags[s];
     return r;
@@ -54,8 +54,8 @@ __device__ __forceinline__ XfRecord load_xf(const TransformMirror& xf, uint32_t 
 __device__ __forceinline__ XfRecord gather_xf(const TransformMirror& xf, uint32_t s, bool with_flags)
 {
     XfRecord r;
-    r.a = xf.a[s];
-    r.b = xf.b[s];
+    r.a = xf.ab[s].a;
+    r.b = xf.ab[s].b;
     r.c = xf.c[s];
     r.flags = with_flags ? xf.flags[s] : 0u;
     return r;
@@ -63,8 +63,8 @@ __device__ __forceinline__ XfRecord gather_xf(const TransformMirror& xf, uint32_
 __device__ __forceinline__ XfRecord stream_xf(const TransformMirror& xf, uint32_t s)  // the once-per-frame read
 {
     XfRecord r;
-    r.a = stream_load(&xf.a[s]);
-    r.b = stream_load(&xf.b[s]);
+    r.a = stream_load(&xf.ab[s].a);
+    r.b = stream_load(&xf.ab[s].b);
     r.c = stream_load(&xf.c[s]);
     r.flags = stream_load(&xf.flags[s]);
     return r;
@@ -257,8 +257,8 @@ __device__ __forceinline__ bool prepare_slot(const MeshMirror& mesh, const Trans
             if (MAP == kMapExact && xf.max_depth == 0) {
                 // flat + exactly paired: only the active bit matters (no chain, so modelWithAncestors is moot) and
                 // the 64 bits of this wave sit in one word
-                r.a = stream_load(&xf.a[i]);
-                r.b = stream_load(&xf.b[i]);
+                r.a = stream_load(&xf.ab[i].a);
+                r.b = stream_load(&xf.ab[i].b);
                 r.c = stream_load(&xf.c[i]);
                 r.flags = (uint32_t)((xf.active_bits[i >> 6] >> (i & 63u)) & 1ull) * kXfActive;
             } else {

@@ -16,9 +16,15 @@ constexpr uint32_t kXfWithAncestors = 2u;  // modelWithAncestors (transform.hpp:
 constexpr uint32_t kXfLive = 4u;           // entity != 0
 constexpr uint32_t kMeshCandidate = 1u << 28;  // entity != 0 && isEnabled (mesh.cpp:142), in MeshMirror::link
 
+// One 32-byte record per transform entry: {pos.xyz, scale.x | quat xyzw}. Kept together because every reader wants
+// both halves: the streaming kernels read the pair at full rate (tools/stream_probe.hip: 6.8 TB/s interleaved vs
+// 6.7 TB/s as two arrays) and every gather (emit, ancestor walks) pays one 64-byte sector instead of two.
+struct XfAB {
+    float4 a;  // (pos.x, pos.y, pos.z, scale.x)
+    float4 b;  // quat xyzw
+};
 struct TransformMirror {
-    const float4* a;         // (pos.x, pos.y, pos.z, scale.x)
-    const float4* b;         // quat xyzw
+    const XfAB* ab;
     const float2* c;         // (scale.y, scale.z)
     const uint8_t* flags;    // kXf* bits
     const unsigned long long* active_bits;  // bit e of word e/64 = kXfActive of entry e (derived from flags[] on the
@@ -132,7 +138,7 @@ struct AosTransformLayout {
     uint32_t stride, entity, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
 };
 hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
-                                 const uint32_t* xinv, float4* a, float4* b, float2* c, uint8_t* flags, hipStream_t stream);
+                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, hipStream_t stream);
 hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream);
 // dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
 hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,

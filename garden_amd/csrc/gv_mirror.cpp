@@ -254,8 +254,8 @@ inline void gather_transform(GvCtx* ctx, uint32_t s, uint32_t j)
         flags |= kXfActive;
     if (xf.model_with_ancestors.u8(s))
         flags |= kXfWithAncestors;
-    ctx->h_xa.ptr[j] = make_float4(pos[0], pos[1], pos[2], scl[0]);
-    ctx->h_xb.ptr[j] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+    ctx->h_xab.ptr[j].a = make_float4(pos[0], pos[1], pos[2], scl[0]);
+    ctx->h_xab.ptr[j].b = make_float4(rot[0], rot[1], rot[2], rot[3]);
     ctx->h_xc.ptr[j] = make_float2(scl[1], scl[2]);
     ctx->h_xflags.ptr[j] = flags;
     ctx->h_xparent.ptr[j] = xslot_to_mirror(ctx, entity_slot(xf, xf.parent.u32(s)));
@@ -331,8 +331,7 @@ int compute_max_depth(GvCtx* ctx, uint32_t* out_depth)
 int upload_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
 {
     const size_t n = hi - lo;
-    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xa.ptr + lo, ctx->h_xa.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xb.ptr + lo, ctx->h_xb.ptr + lo, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_xab.ptr + lo, ctx->h_xab.ptr + lo, n * sizeof(XfAB), hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xc.ptr + lo, ctx->h_xc.ptr + lo, n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xflags.ptr + lo, ctx->h_xflags.ptr + lo, n, hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_xparent.ptr + lo, ctx->h_xparent.ptr + lo, n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -393,8 +392,8 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
     }
     hipError_t e = hipMemcpyAsync(ctx->d_raw.ptr, span, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xa.ptr,
-                                  ctx->d_xb.ptr, ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream);
+        e = launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xab.ptr,
+                                  ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // the span is unlocked (and may be freed by its owner) after this
     if (locked_here)
         (void)hipHostUnregister(span);
@@ -454,13 +453,13 @@ int reserve_scatter(GvCtx* ctx, size_t n)
     GV_HIP(ctx, ctx->sc_idx.reserve(n));
     GV_HIP(ctx, ctx->sc_u32.reserve(n));
     GV_HIP(ctx, ctx->sc_a.reserve(n));
-    GV_HIP(ctx, ctx->sc_b.reserve(n));
+    GV_HIP(ctx, ctx->sc_ab.reserve(n));
     GV_HIP(ctx, ctx->sc_c.reserve(n));
     GV_HIP(ctx, ctx->sc_u8.reserve(n));
     GV_HIP(ctx, ctx->dsc_idx.reserve(n));
     GV_HIP(ctx, ctx->dsc_u32.reserve(n));
     GV_HIP(ctx, ctx->dsc_a.reserve(n));
-    GV_HIP(ctx, ctx->dsc_b.reserve(n));
+    GV_HIP(ctx, ctx->dsc_ab.reserve(n));
     GV_HIP(ctx, ctx->dsc_c.reserve(n));
     GV_HIP(ctx, ctx->dsc_u8.reserve(n));
     return GV_OK;
@@ -487,16 +486,14 @@ int upload_transforms_scattered(GvCtx* ctx, uint32_t lo, uint32_t hi)
         for (uint32_t k = a; k < b; k++) {
             const uint32_t j = ctx->xinv[lo + k];
             ctx->sc_idx.ptr[k] = j;
-            ctx->sc_a.ptr[k] = ctx->h_xa.ptr[j];
-            ctx->sc_b.ptr[k] = ctx->h_xb.ptr[j];
+            ctx->sc_ab.ptr[k] = ctx->h_xab.ptr[j];
             ctx->sc_c.ptr[k] = ctx->h_xc.ptr[j];
             ctx->sc_u8.ptr[k] = ctx->h_xflags.ptr[j];
             ctx->sc_u32.ptr[k] = ctx->h_xparent.ptr[j];
         }
     });
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, ctx->d_xa.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_b.ptr, ctx->dsc_b.ptr, ctx->d_xb.ptr, n)) != GV_OK) return rc;
+    if ((rc = scatter_stream(ctx, ctx->sc_ab.ptr, ctx->dsc_ab.ptr, ctx->d_xab.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, ctx->d_xc.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_u8.ptr, ctx->dsc_u8.ptr, ctx->d_xflags.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, ctx->d_xparent.ptr, n)) != GV_OK) return rc;
@@ -535,14 +532,12 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
 int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
 {
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    GV_HIP(ctx, ctx->d_xa.grow(n1, n0, ctx->stream));
-    GV_HIP(ctx, ctx->d_xb.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, ctx->d_xab.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xc.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xflags.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xparent.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xactive.grow((size_t)n1 / 64 + 1, 0, ctx->stream));  // re-derived below
-    GV_HIP(ctx, ctx->h_xa.grow(n1, n0));
-    GV_HIP(ctx, ctx->h_xb.grow(n1, n0));
+    GV_HIP(ctx, ctx->h_xab.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xc.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xflags.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xparent.grow(n1, n0));
@@ -639,14 +634,12 @@ int sync_mirror(GvCtx* ctx)
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         staged = true;
         const size_t cap = std::max<size_t>(n, 1);
-        GV_HIP(ctx, ctx->d_xa.reserve(cap));
-        GV_HIP(ctx, ctx->d_xb.reserve(cap));
+        GV_HIP(ctx, ctx->d_xab.reserve(cap));
         GV_HIP(ctx, ctx->d_xc.reserve(cap));
         GV_HIP(ctx, ctx->d_xflags.reserve(cap));
         GV_HIP(ctx, ctx->d_xactive.reserve(cap / 64 + 1));
         GV_HIP(ctx, ctx->d_xparent.reserve(cap));
-        GV_HIP(ctx, ctx->h_xa.reserve(cap));
-        GV_HIP(ctx, ctx->h_xb.reserve(cap));
+        GV_HIP(ctx, ctx->h_xab.reserve(cap));
         GV_HIP(ctx, ctx->h_xc.reserve(cap));
         GV_HIP(ctx, ctx->h_xflags.reserve(cap));
         GV_HIP(ctx, ctx->h_xparent.reserve(cap));
@@ -818,8 +811,7 @@ int sync_mirror(GvCtx* ctx)
 TransformMirror xf_mirror(const GvCtx* ctx)
 {
     TransformMirror m;
-    m.a = ctx->d_xa.ptr;
-    m.b = ctx->d_xb.ptr;
+    m.ab = ctx->d_xab.ptr;
     m.c = ctx->d_xc.ptr;
     m.flags = ctx->d_xflags.ptr;
     m.active_bits = ctx->d_xactive.ptr;
