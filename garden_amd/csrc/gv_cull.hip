@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
     for (uint32_t r = prefix[wlo] + threadIdx.x; r < total; r += 256) {
         uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
 #pragma unroll
-        for (int step = 0; step < 4; step++) {
+        for (uint32_t span = 64 / kEmitParts; span > 1; span >>= 1) {  // log2(words per workgroup) halvings
             const uint32_t mid = (lo + hi) >> 1;
             if (prefix[mid] <= r)
                 lo = mid;
