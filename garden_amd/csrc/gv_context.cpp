@@ -559,34 +559,70 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         return GV_E_ARG;
     if (!out)
         return ctx->fail(GV_E_ARG, "gv_results_fetch: out is NULL");
-    uint32_t count = 0;
-    int rc = gv_result_count(ctx, view_index, &count);
-    if (rc != GV_OK)
-        return rc;
+    if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid)
+        return ctx->fail(GV_E_ARG, "gv_results_fetch: view %u has no results", view_index);
     ViewState& vs = ctx->views[view_index];
-    memset(out, 0, sizeof(*out));
-    out->draw_count = vs.emitted ? count : count;
-    out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)
-    if (vs.emitted && count) {
+    PoolState& pool = ctx->pools[vs.pool_id];
+    const bool permuted = !pool.perm.empty() && pool.perm.size() == vs.occupancy;
+    const bool small = vs.occupancy != 0 && vs.occupancy <= kPublishMaxSlots;
+    auto reserve_records = [&]() -> int {
         GV_HIP(ctx, vs.h_visible_idx.reserve(vs.occupancy));
         GV_HIP(ctx, vs.h_baked_model.reserve((size_t)vs.occupancy * 12));
         GV_HIP(ctx, vs.h_distance_sq.reserve(vs.occupancy));
-        GV_HIP(ctx, hipMemcpyAsync(vs.h_visible_idx.ptr, vs.visible_idx.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
-        GV_HIP(ctx, hipMemcpyAsync(vs.h_baked_model.ptr, vs.baked_model.ptr, (size_t)count * 48, hipMemcpyDeviceToHost, ctx->stream));
-        GV_HIP(ctx, hipMemcpyAsync(vs.h_distance_sq.ptr, vs.distance_sq.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    PoolState& pool = ctx->pools[vs.pool_id];
-    const bool permuted = !pool.perm.empty() && pool.perm.size() == vs.occupancy;
+        return GV_OK;
+    };
+    uint8_t* vis_dst = nullptr;
     if (vs.main_pass && vs.occupancy) {
         GV_HIP(ctx, vs.h_is_visible.reserve(vs.occupancy));
-        uint8_t* dst = vs.h_is_visible.ptr;
+        vis_dst = vs.h_is_visible.ptr;
         if (permuted) {
             GV_HIP(ctx, vs.h_is_visible_mirror.reserve(vs.occupancy));
-            dst = vs.h_is_visible_mirror.ptr;
+            vis_dst = vs.h_is_visible_mirror.ptr;
         }
-        GV_HIP(ctx, hipMemcpyAsync(dst, vs.is_visible.ptr, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
     }
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t count = 0;
+    if (small) {
+        // engine-sized pools are launch- and round-trip-bound: one kernel writes count, records and isVisible straight
+        // into the pinned host buffers, one synchronisation ends the frame
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        PublishArgs a{};
+        a.count = vs.draw_count.ptr;
+        a.idx = vs.visible_idx.ptr;
+        a.model = vs.baked_model.ptr;
+        a.dist = vs.distance_sq.ptr;
+        a.is_visible = vs.is_visible.ptr;
+        a.host_count = vs.h_draw_count.ptr;
+        if (vs.emitted) {
+            if (int rc = reserve_records())
+                return rc;
+            a.host_idx = vs.h_visible_idx.ptr;
+            a.host_model = vs.h_baked_model.ptr;
+            a.host_dist = vs.h_distance_sq.ptr;
+        }
+        a.host_is_visible = vis_dst;
+        a.occupancy = vs.occupancy;
+        GV_HIP(ctx, launch_publish(a, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        drain_events(ctx);
+        count = vs.h_draw_count.ptr[0];
+    } else {
+        int rc = gv_result_count(ctx, view_index, &count);
+        if (rc != GV_OK)
+            return rc;
+        if (vs.emitted && count) {
+            if ((rc = reserve_records()) != GV_OK)
+                return rc;
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_visible_idx.ptr, vs.visible_idx.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_baked_model.ptr, vs.baked_model.ptr, (size_t)count * 48, hipMemcpyDeviceToHost, ctx->stream));
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_distance_sq.ptr, vs.distance_sq.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (vis_dst)
+            GV_HIP(ctx, hipMemcpyAsync(vis_dst, vs.is_visible.ptr, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    memset(out, 0, sizeof(*out));
+    out->draw_count = count;
+    out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)
     if (vs.main_pass && vs.occupancy && permuted) {  // mirror order -> pool-slot order
         const uint8_t* src = vs.h_is_visible_mirror.ptr;
         uint8_t* out_vis = vs.h_is_visible.ptr;

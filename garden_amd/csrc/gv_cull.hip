@@ -473,6 +473,7 @@ __device__ __forceinline__ uint32_t select_bit(unsigned long long word, uint32_t
     return pos;
 }
 
+constexpr uint32_t kSelfPrefixLoads = (kSelfPrefixMaxChunks / 4 + 191) / 192;  // uint4 loads per lane of waves 1-3
 constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slots = 16 ballot words each
 
 // Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
@@ -508,9 +509,20 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
             prefix[0] = 0;
     } else if (SELF) {
         const uint32_t upto = blockIdx.x == 0 ? args.nchunks : chunk;  // workgroup 0: the grand total
-        uint32_t sum = 0;
-        for (uint32_t c = threadIdx.x - 64; c < upto; c += 192)
-            sum += args.out.chunk_count[c];
+        // all loads of the sum are issued before the first is consumed: one L2 round trip for up to 4096 totals, not
+        // one per 192 of them (the serial form took ~13 dependent round trips for the last chunks of a 10 M pool)
+        const uint4* __restrict__ totals4 = reinterpret_cast<const uint4*>(args.out.chunk_count);
+        const uint32_t t = threadIdx.x - 64, groups = upto >> 2;
+        uint4 v[kSelfPrefixLoads];
+#pragma unroll
+        for (uint32_t k = 0; k < kSelfPrefixLoads; k++) {
+            const uint32_t q = t + 192 * k;
+            v[k] = q < groups ? totals4[q] : make_uint4(0, 0, 0, 0);
+        }
+        uint32_t sum = t < (upto & 3u) ? args.out.chunk_count[(groups << 2) + t] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kSelfPrefixLoads; k++)
+            sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
 #pragma unroll
         for (uint32_t d = 32; d >= 1; d >>= 1)
             sum += __shfl_xor(sum, d, 64);
@@ -704,6 +716,43 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
 {
     const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 255u) / 256u));
     hipLaunchKernelGGL(copy_shard_kernel, dim3(blocks), dim3(256), 0, stream, src, count, dst, capacity, base);
+    return hipGetLastError();
+}
+
+// Small pools: every result of a view goes to the caller-visible pinned host buffers in ONE launch — the count, the
+// records [0, count) and (main pass) the isVisible bytes in mirror order — so gv_results_fetch is one launch and one
+// stream synchronisation instead of a count read-back, four copies and a second synchronisation. 16-byte stores:
+// consecutive lanes fill whole PCIe write bursts.
+__global__ __launch_bounds__(256) void publish_kernel(const PublishArgs a)
+{
+    const uint32_t n = *a.count;
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, threads = gridDim.x * 256;
+    if (tid == 0)
+        *a.host_count = n;
+    if (a.host_idx) {
+        for (uint32_t j = tid; j < n; j += threads) {
+            a.host_idx[j] = a.idx[j];
+            a.host_dist[j] = a.dist[j];
+        }
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.model);
+        float4* __restrict__ dst = reinterpret_cast<float4*>(a.host_model);
+        for (uint32_t q = tid; q < 3 * n; q += threads)
+            dst[q] = src[q];
+    }
+    if (a.host_is_visible) {
+        const uint32_t words = a.occupancy >> 2;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.is_visible);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.host_is_visible);
+        for (uint32_t w = tid; w < words; w += threads)
+            dst[w] = src[w];
+        for (uint32_t j = (words << 2) + tid; j < a.occupancy; j += threads)
+            a.host_is_visible[j] = a.is_visible[j];
+    }
+}
+hipError_t launch_publish(const PublishArgs& a, hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(64u, (a.occupancy + 255u) / 256u));
+    hipLaunchKernelGGL(publish_kernel, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -115,6 +115,22 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
                            hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                              hipStream_t stream);
+// gv_results_fetch of a small pool (occupancy <= kPublishMaxSlots): device results -> pinned host buffers in one launch
+constexpr uint32_t kPublishMaxSlots = 16384;
+struct PublishArgs {
+    const uint32_t* count;  // device draw_count
+    const uint32_t* idx;
+    const float* model;
+    const float* dist;
+    const uint8_t* is_visible;  // mirror order
+    uint32_t* host_count;       // pinned host memory from here on (device-accessible: hipHostMalloc)
+    uint32_t* host_idx;         // NULL: no records emitted
+    float* host_model;
+    float* host_dist;
+    uint8_t* host_is_visible;   // NULL: not the main pass
+    uint32_t occupancy;
+};
+hipError_t launch_publish(const PublishArgs& a, hipStream_t stream);
 
 // sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
 struct SortBuffers {
