@@ -213,7 +213,7 @@ void gv_destroy(GvCtx* ctx)
         v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
-        v.h_distance_sq.release(); v.h_is_visible.release(); v.h_is_visible_mirror.release();
+        v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
     }
     ctx->d_world.release();
     ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
@@ -434,6 +434,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.main_pass = views[v].shadow_pass < 0;
         vs.emitted = emit;
         vs.valid = true;
+        vs.published = false;
         build_view_params(views[v], &vps[v]);
         vbs[v] = view_buffers(vs);
         if (p.occupancy == 0)
@@ -571,39 +572,54 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         GV_HIP(ctx, vs.h_distance_sq.reserve(vs.occupancy));
         return GV_OK;
     };
-    uint8_t* vis_dst = nullptr;
-    if (vs.main_pass && vs.occupancy) {
+    const bool want_vis = vs.main_pass && vs.occupancy;
+    if (want_vis)
         GV_HIP(ctx, vs.h_is_visible.reserve(vs.occupancy));
-        vis_dst = vs.h_is_visible.ptr;
-        if (permuted) {
-            GV_HIP(ctx, vs.h_is_visible_mirror.reserve(vs.occupancy));
-            vis_dst = vs.h_is_visible_mirror.ptr;
-        }
-    }
     uint32_t count = 0;
     if (small) {
-        // engine-sized pools are launch- and round-trip-bound: one kernel writes count, records and isVisible straight
-        // into the pinned host buffers, one synchronisation ends the frame
-        GV_HIP(ctx, hipSetDevice(ctx->device));
-        PublishArgs a{};
-        a.count = vs.draw_count.ptr;
-        a.idx = vs.visible_idx.ptr;
-        a.model = vs.baked_model.ptr;
-        a.dist = vs.distance_sq.ptr;
-        a.is_visible = vs.is_visible.ptr;
-        a.host_count = vs.h_draw_count.ptr;
-        if (vs.emitted) {
-            if (int rc = reserve_records())
-                return rc;
-            a.host_idx = vs.h_visible_idx.ptr;
-            a.host_model = vs.h_baked_model.ptr;
-            a.host_dist = vs.h_distance_sq.ptr;
+        // engine-sized pools are launch- and round-trip-bound: one kernel writes count, records and isVisible of EVERY
+        // view of this cull (the main camera and its shadow passes are fetched one after the other, mesh.cpp:809-843)
+        // straight into the pinned host buffers, one synchronisation ends the frame; the sibling views' fetches find
+        // their results already there
+        if (!vs.published) {
+            GV_HIP(ctx, hipSetDevice(ctx->device));
+            static_assert(kMaxPublishViews == GV_MAX_VIEWS, "PublishBatch holds one entry per view");
+            PublishBatch batch{};
+            uint32_t views = 0;
+            ViewState* sent[GV_MAX_VIEWS];
+            for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
+                ViewState& w = ctx->views[v];
+                if (!w.valid || w.published || w.pool_id != vs.pool_id || w.occupancy != vs.occupancy)
+                    continue;
+                PublishArgs& a = batch.view[views];
+                a.count = w.draw_count.ptr;
+                a.idx = w.visible_idx.ptr;
+                a.model = w.baked_model.ptr;
+                a.dist = w.distance_sq.ptr;
+                a.is_visible = w.is_visible.ptr;
+                a.host_count = w.h_draw_count.ptr;
+                if (w.emitted) {
+                    GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
+                    GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
+                    GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
+                    a.host_idx = w.h_visible_idx.ptr;
+                    a.host_model = w.h_baked_model.ptr;
+                    a.host_dist = w.h_distance_sq.ptr;
+                }
+                a.orig = permuted ? pool.d_orig.ptr : nullptr;
+                if (w.main_pass) {
+                    GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
+                    a.host_is_visible = w.h_is_visible.ptr;
+                }
+                a.occupancy = w.occupancy;
+                sent[views++] = &w;
+            }
+            GV_HIP(ctx, launch_publish(batch, views, vs.occupancy, ctx->stream));
+            GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            drain_events(ctx);
+            for (uint32_t k = 0; k < views; k++)
+                sent[k]->published = true;
         }
-        a.host_is_visible = vis_dst;
-        a.occupancy = vs.occupancy;
-        GV_HIP(ctx, launch_publish(a, ctx->stream));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        drain_events(ctx);
         count = vs.h_draw_count.ptr[0];
     } else {
         int rc = gv_result_count(ctx, view_index, &count);
@@ -616,40 +632,43 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
             GV_HIP(ctx, hipMemcpyAsync(vs.h_baked_model.ptr, vs.baked_model.ptr, (size_t)count * 48, hipMemcpyDeviceToHost, ctx->stream));
             GV_HIP(ctx, hipMemcpyAsync(vs.h_distance_sq.ptr, vs.distance_sq.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
-        if (vis_dst)
-            GV_HIP(ctx, hipMemcpyAsync(vis_dst, vs.is_visible.ptr, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
+        if (want_vis) {
+            const uint8_t* src = vs.is_visible.ptr;
+            if (permuted) {  // back into pool-slot order on the device: the random half of the write-back
+                GV_HIP(ctx, vs.is_visible_slots.reserve(vs.occupancy));
+                GV_HIP(ctx, launch_unpermute_bytes(vs.is_visible.ptr, pool.d_orig.ptr, vs.occupancy, vs.is_visible_slots.ptr, ctx->stream));
+                src = vs.is_visible_slots.ptr;
+            }
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_is_visible.ptr, src, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
+        }
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     memset(out, 0, sizeof(*out));
     out->draw_count = count;
     out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)
-    if (vs.main_pass && vs.occupancy && permuted) {  // mirror order -> pool-slot order
-        const uint8_t* src = vs.h_is_visible_mirror.ptr;
-        uint8_t* out_vis = vs.h_is_visible.ptr;
-        const uint32_t* perm = pool.perm.data();
-        parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
-            for (uint32_t j = a; j < b; j++)
-                out_vis[perm[j]] = src[j];
-        });
-    }
     if (vs.emitted && count) {
         out->visible_idx = vs.h_visible_idx.ptr;
         out->baked_model = vs.h_baked_model.ptr;
         out->distance_sq = vs.h_distance_sq.ptr;
     }
     if (vs.main_pass && vs.occupancy) {
-        out->is_visible = vs.h_is_visible.ptr;
-        if (write_back) {  // meshRenderView->isVisible = ...  mesh.cpp:144,152,161,166
-            PoolState& p = ctx->pools[vs.pool_id];
-            if (!p.bound || p.occupancy != vs.occupancy)
+        // the bytes arrive in pool-slot order; write_back streams them into the components themselves:
+        // meshRenderView->isVisible = ...  mesh.cpp:144,152,161,166
+        uint8_t* component_vis = nullptr;
+        size_t component_stride = 0;
+        if (write_back) {
+            if (!pool.bound || pool.occupancy != vs.occupancy)
                 return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u rebound since gv_cull", vs.pool_id);
-            const uint8_t* src = vs.h_is_visible.ptr;
-            if (p.is_visible)
-                parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
-                    for (uint32_t i = a; i < b; i++)
-                        p.is_visible[(size_t)i * p.is_visible_stride] = src[i];
-                });
+            component_vis = pool.is_visible;
+            component_stride = pool.is_visible_stride;
         }
+        uint8_t* out_vis = vs.h_is_visible.ptr;
+        if (component_vis)
+            parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
+                for (uint32_t i = a; i < b; i++)
+                    component_vis[(size_t)i * component_stride] = out_vis[i];
+            });
+        out->is_visible = out_vis;
     }
     return GV_OK;
 }
@@ -736,6 +755,7 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
         KernelTimer t(ctx, GV_K_SORT);
         GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending != 0, ctx->stream));
     }
+    vs.published = false;
     // the sorted records now live in the alternate set: swap it in
     std::swap(vs.visible_idx, vs.alt_idx);
     std::swap(vs.baked_model, vs.alt_model);

@@ -20,6 +20,7 @@
 
 #include "../../include/garden_vis.h"
 #include "gv_kernels.hpp"
+#include "gv_workers.hpp"
 
 
 namespace gv {
@@ -191,7 +192,8 @@ struct ViewState {
     uint32_t count_parity = 0;  // which totals buffer the next cull adds into (see launch_emit self_prefix)
     uint32_t stale_chunks[2] = {0, 0};  // entries of each totals buffer that may be non-zero right now
 
-    DeviceBuf<uint8_t> is_visible;
+    DeviceBuf<uint8_t> is_visible;        // mirror order, written by the cull
+    DeviceBuf<uint8_t> is_visible_slots;  // pool-slot order, filled by gv_results_fetch of a large, spatially ordered pool
     DeviceBuf<uint32_t> visible_idx;
     DeviceBuf<float> baked_model, distance_sq;
     // gv_sort: alternate record set + radix-sort scratch (allocated on first use)
@@ -199,9 +201,10 @@ struct ViewState {
     DeviceBuf<float> alt_model, alt_dist;
     PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
     PinnedBuf<float> h_baked_model, h_distance_sq;
-    PinnedBuf<uint8_t> h_is_visible, h_is_visible_mirror;
+    PinnedBuf<uint8_t> h_is_visible;
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;
+    bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };
 
 struct PendingEvent {
@@ -358,28 +361,7 @@ struct KernelTimer {
     }
 };
 
-// ---- host worker threads for the gathers (AoS component pools -> SoA staging) and the isVisible write-back ----
-template <typename F>
-void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
-{
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    // 16 threads: measured on the 256-thread box, 64 made the 10 M gather slower (60 vs 34 ms)
-    const uint32_t threads = count < (1u << 16) ? 1u : std::min(hw, 16u);
-    if (threads == 1) {
-        fn(first, first + count);
-        return;
-    }
-    const uint32_t per = (count + threads - 1) / threads;
-    std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < threads; t++) {
-        const uint32_t lo = first + std::min(count, per * t), hi = first + std::min(count, per * (t + 1));
-        if (lo < hi)
-            pool.emplace_back([=, &fn] { fn(lo, hi); });
-    }
-    fn(first, first + std::min(count, per));
-    for (auto& th : pool)
-        th.join();
-}
+// host worker threads for the gathers (AoS component pools -> SoA staging) and the isVisible write-back: gv_workers.hpp
 
 void drain_events(GvCtx* ctx);
 

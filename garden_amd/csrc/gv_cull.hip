@@ -719,12 +719,13 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
     return hipGetLastError();
 }
 
-// Small pools: every result of a view goes to the caller-visible pinned host buffers in ONE launch — the count, the
-// records [0, count) and (main pass) the isVisible bytes in mirror order — so gv_results_fetch is one launch and one
+// Small pools: every result of every view of the last cull goes to the caller-visible pinned host buffers in ONE
+// launch (blockIdx.y = view) — the count, the records [0, count) and (main pass) the isVisible bytes — so gv_results_fetch is one launch and one
 // stream synchronisation instead of a count read-back, four copies and a second synchronisation. 16-byte stores:
 // consecutive lanes fill whole PCIe write bursts.
-__global__ __launch_bounds__(256) void publish_kernel(const PublishArgs a)
+__global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
 {
+    const PublishArgs& a = batch.view[blockIdx.y];
     const uint32_t n = *a.count;
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x, threads = gridDim.x * 256;
     if (tid == 0)
@@ -739,7 +740,23 @@ __global__ __launch_bounds__(256) void publish_kernel(const PublishArgs a)
         for (uint32_t q = tid; q < 3 * n; q += threads)
             dst[q] = src[q];
     }
-    if (a.host_is_visible) {
+    if (a.host_is_visible && a.orig) {
+        // spatially ordered mirror: workgroup 0 puts the bytes back into pool-slot order in LDS (the pool is at most
+        // kPublishMaxSlots bytes) and writes them out as whole words — no scattered single-byte stores over PCIe
+        if (blockIdx.x != 0)
+            return;
+        __shared__ uint8_t slots[(kPublishMaxSlots + 3u) & ~3u];
+        for (uint32_t j = threadIdx.x; j < a.occupancy; j += 256)
+            slots[a.orig[j]] = a.is_visible[j];
+        __syncthreads();
+        const uint32_t words = a.occupancy >> 2;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(slots);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.host_is_visible);
+        for (uint32_t w = threadIdx.x; w < words; w += 256)
+            dst[w] = src[w];
+        for (uint32_t j = (words << 2) + threadIdx.x; j < a.occupancy; j += 256)
+            a.host_is_visible[j] = slots[j];
+    } else if (a.host_is_visible) {
         const uint32_t words = a.occupancy >> 2;
         const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.is_visible);
         uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.host_is_visible);
@@ -749,10 +766,25 @@ __global__ __launch_bounds__(256) void publish_kernel(const PublishArgs a)
             a.host_is_visible[j] = a.is_visible[j];
     }
 }
-hipError_t launch_publish(const PublishArgs& a, hipStream_t stream)
+// isVisible bytes of a spatially ordered mirror back into pool-slot order (dst[orig[j]] = src[j]) on the device, where a
+// random byte scatter is cheap; the host then only streams them into the components
+__global__ __launch_bounds__(256) void unpermute_bytes_kernel(const uint8_t* __restrict__ src, const uint32_t* __restrict__ orig,
+                                                              uint32_t count, uint8_t* __restrict__ dst)
 {
-    const uint32_t blocks = std::max(1u, std::min(64u, (a.occupancy + 255u) / 256u));
-    hipLaunchKernelGGL(publish_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256)
+        dst[orig[j]] = src[j];
+}
+hipError_t launch_unpermute_bytes(const uint8_t* src, const uint32_t* orig, uint32_t count, uint8_t* dst, hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(4096u, (count + 255u) / 256u));
+    hipLaunchKernelGGL(unpermute_bytes_kernel, dim3(blocks), dim3(256), 0, stream, src, orig, count, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_publish(const PublishBatch& batch, uint32_t views, uint32_t occupancy, hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(64u, (occupancy + 255u) / 256u));
+    hipLaunchKernelGGL(publish_kernel, dim3(blocks, views), dim3(256), 0, stream, batch);
     return hipGetLastError();
 }
 

@@ -123,14 +123,20 @@ struct PublishArgs {
     const float* model;
     const float* dist;
     const uint8_t* is_visible;  // mirror order
+    const uint32_t* orig;       // mirror entry -> pool slot (NULL: the mirror is in slot order)
     uint32_t* host_count;       // pinned host memory from here on (device-accessible: hipHostMalloc)
     uint32_t* host_idx;         // NULL: no records emitted
     float* host_model;
     float* host_dist;
-    uint8_t* host_is_visible;   // NULL: not the main pass
+    uint8_t* host_is_visible;   // pool-slot order; NULL: not the main pass
     uint32_t occupancy;
 };
-hipError_t launch_publish(const PublishArgs& a, hipStream_t stream);
+constexpr uint32_t kMaxPublishViews = 8;  // == GV_MAX_VIEWS (checked in gv_context.cpp)
+struct PublishBatch {
+    PublishArgs view[kMaxPublishViews];  // blockIdx.y
+};
+hipError_t launch_publish(const PublishBatch& batch, uint32_t views, uint32_t occupancy, hipStream_t stream);
+hipError_t launch_unpermute_bytes(const uint8_t* src, const uint32_t* orig, uint32_t count, uint8_t* dst, hipStream_t stream);
 
 // sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
 struct SortBuffers {

@@ -45,19 +45,11 @@ inline uint32_t xslot_to_mirror(const GvCtx* ctx, uint32_t slot)
 void radix_order(const std::vector<uint32_t>& keys, std::vector<uint32_t>& order)
 {
     const size_t n = order.size();
-    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const uint32_t threads = n < (1u << 16) ? 1u : std::min(hw, 16u);
+    const uint32_t threads = worker_parts(n);
     const size_t per = (n + threads - 1) / threads;
     std::vector<uint32_t> tmp(n);
     std::vector<size_t> hist((size_t)threads * 1024);
-    auto run = [&](auto&& fn) {
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < threads; t++)
-            pool.emplace_back([&, t] { fn(t); });
-        fn(0u);
-        for (auto& th : pool)
-            th.join();
-    };
+    auto run = [&](auto&& fn) { run_parts(threads, fn); };
     for (int pass = 0; pass < 3; pass++) {
         const int shift = pass * 10;
         std::fill(hist.begin(), hist.end(), 0);

@@ -12,6 +12,7 @@
 // Errors: gv_* status codes are turned into exceptions here, the way GardenError is used upstream
 // (include/garden/error.hpp:32-55).
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -60,6 +61,17 @@ private:
     }
 
 public:
+    // host wall time of the prepare phase, accumulated over ticks ("Meshes Prepare" zone of the reference, by step)
+    struct TickSeconds {
+        double total = 0, cull = 0, sort = 0, fetch = 0, records = 0;  // records: filling combinedMeshes from the fetch
+    } tickSeconds;
+    struct Stopwatch {
+        double& sink;
+        std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+        explicit Stopwatch(double& into) : sink(into) {}
+        ~Stopwatch() { sink += std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); }
+    };
+
     bool isEnabled = true;
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
@@ -182,7 +194,11 @@ private:
     void fill(UnsortedBuffer* buffer, IMeshRenderSystem* meshSystem, uint32_t viewIndex, bool writeBack)
     {
         GvResult r{};
-        check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+        {
+            Stopwatch watch(tickSeconds.fetch);
+            check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+        }
+        Stopwatch watch(tickSeconds.records);
         buffer->meshSystem = meshSystem;
         buffer->drawCount = r.draw_count;
         buffer->instanceCount = r.instance_count;
@@ -205,7 +221,11 @@ private:
                     IMeshRenderSystem* meshSystem, uint32_t viewIndex, bool writeBack, uint32_t bufferIndex)
     {
         GvResult r{};
-        check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+        {
+            Stopwatch watch(tickSeconds.fetch);
+            check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+        }
+        Stopwatch watch(tickSeconds.records);
         if (counters) {
             counters->meshSystem = meshSystem;
             counters->drawCount = r.draw_count;
@@ -242,6 +262,7 @@ private:
             return;
         auto transformSystem = TransformSystem::Instance::get();
         auto graphicsSystem = GraphicsSystem::Instance::get();
+        Stopwatch whole(tickSeconds.total);
         prepareSystems();
 
         // Pools may have moved (create() can reallocate): re-bind every frame, as `gv_pool_bind` documents.
@@ -321,12 +342,17 @@ private:
             }
             if (sweepWorldMatrices && p == 0)
                 check(gv_sweep(ctx, GV_SWEEP_WITH_CULL), "gv_sweep");
-            check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
+            {
+                Stopwatch watch(tickSeconds.cull);
+                check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
+            }
 
             if (isSortedType(renderType)) {
-                if (emitRecords && sortOnDevice)
+                if (emitRecords && sortOnDevice) {
+                    Stopwatch watch(tickSeconds.sort);
                     for (uint32_t v = 0; v < views.size(); v++)
                         check(gv_sort(ctx, v, 1), "gv_sort");  // back to front: SortedMesh::operator< (mesh.hpp:204)
+                }
                 const uint32_t bufferIndex = sortedBufferIndex++;
                 for (uint32_t v = 1; v < views.size(); v++) {
                     append(shadowTransMeshes[v - 1], shadowTransDrawIndex[v - 1], nullptr, meshSystem, v, false, bufferIndex);
@@ -341,9 +367,11 @@ private:
                 }
             } else {
                 // sortMeshes, mesh.cpp:270-295: front to back (UnsortedMesh::operator<, mesh.hpp:196); OIT is not sorted
-                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
+                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT) {
+                    Stopwatch watch(tickSeconds.sort);
                     for (uint32_t v = 0; v < views.size(); v++)
                         check(gv_sort(ctx, v, 0), "gv_sort");
+                }
                 const uint32_t bufferIndex = unsortedBufferIndex++;
                 auto& sb = shadowBuffers[bufferIndex];
                 while (sb.size() + 1 < views.size())

@@ -381,6 +381,10 @@ int main(int argc, char** argv)
                 drawCount = gpu->getUnsortedBuffers()[0]->drawCount;
                 sortedDrawCount = gpu->getTransDrawCount() + gpu->getUiDrawCount();
             } else {
+                if (round == 0) {  // untimed first tick: the GPU system builds its device mirror, the CPU system its scratch
+                    run(mode == "cpu", mode == "gpu", 1);
+                    if (gpu) gpu->tickSeconds = {};
+                }
                 seconds += run(mode == "cpu", mode == "gpu", ticks);
                 drawCount = (cpu ? cpu->getUnsortedBuffers()[0] : gpu->getUnsortedBuffers()[0])->drawCount;
                 sortedDrawCount = cpu ? cpu->getTransDrawCount() + cpu->getUiDrawCount() : gpu->getTransDrawCount() + gpu->getUiDrawCount();
@@ -393,6 +397,12 @@ int main(int argc, char** argv)
                "\"sorted_draw_count\": %u, \"is_visible_set\": %u, \"culls_per_s\": %.1f, \"ok\": %s, \"why\": \"%s\"}\n",
                mode.c_str(), entities, ticks * rounds, threads, hier ? "true" : "false", drawCount, sortedDrawCount, visibleFlags,
                (double)entities * ticks * rounds / seconds, ok ? "true" : "false", why.c_str());
+        if (gpu && getenv("GV_TICK_BREAKDOWN")) {
+            const auto& t = gpu->tickSeconds;
+            const double n = (double)ticks * rounds * 1e-6;  // -> microseconds per tick
+            fprintf(stderr, "gpu prepare us/tick: total %.1f = cull %.1f + sort %.1f + fetch %.1f + records %.1f + other %.1f\n", t.total / n,
+                    t.cull / n, t.sort / n, t.fetch / n, t.records / n, (t.total - t.cull - t.sort - t.fetch - t.records) / n);
+        }
         return ok ? 0 : 1;
     } catch (const std::exception& e) {
         printf("{\"ok\": false, \"why\": \"exception: %s\"}\n", e.what());

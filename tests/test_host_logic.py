@@ -176,3 +176,19 @@ def test_padded_exchange_world_size_2_gloo():
     for rank in range(world):
         ok, overflow, cap = ret[rank]
         assert ok and overflow == cap + 5
+
+
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """garden_amd/csrc/gv_workers.*: the persistent host worker pool behind the gathers and the isVisible write-back
+    (the reference's ThreadPool::addItems split, thread-pool.cpp:180-194). Host-only: built here with
+    -fsanitize=thread and stressed (coverage, back-to-back runs, concurrent callers)."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "workers_test_tsan")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                            os.path.join(root, "tests/cpp/workers_test.cpp"), os.path.join(root, "garden_amd/csrc/gv_workers.cpp"),
+                            "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr
+    assert "ThreadSanitizer" not in run.stderr, run.stderr
