@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -161,6 +161,7 @@ int main(int argc, char** argv)
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
+    uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -172,6 +173,7 @@ int main(int argc, char** argv)
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
         else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
+        else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--avx2") avx2 = true;  // CPU system: AVX2+FMA SoA path (bit-identical to the scalar loop)
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
@@ -286,12 +288,21 @@ int main(int argc, char** argv)
             passCount = 2;
         }
 
-        auto run = [&](bool useCpu, bool useGpu, uint32_t n) {
+        uint32_t animateTick = 0;
+        auto run = [&](bool useCpu, bool useGpu, uint32_t n, bool moving = true) {
             if (cpu) cpu->isEnabled = useCpu;
             if (gpu) gpu->isEnabled = useGpu;
             auto t0 = std::chrono::steady_clock::now();
-            for (uint32_t i = 0; i < n; i++)
+            for (uint32_t i = 0; i < n; i++) {
+                if (animate && moving) {  // timed with the tick: the engine's own systems would be doing this
+                    for (uint32_t k = animateTick % animate; k < (uint32_t)ents.size(); k += animate)
+                        if (auto t = transformSystem->tryGetOf(ents[k]))
+                            t->posChildCount.x += 0.25f;
+                    transformSystem->markTransformsChanged();
+                    animateTick++;
+                }
                 manager.update();
+            }
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };
         auto doMutate = [&]() {
@@ -364,12 +375,18 @@ int main(int argc, char** argv)
             else if (round >= 1)
                 doChurn();
             if (mode == "both") {
-                run(true, false, 1);
-                Snapshot a = snapshot(manager, cpu, passCount);
-                clearVisible(manager);
-                seconds += run(false, true, ticks);
-                Snapshot b = snapshot(manager, gpu, passCount);
-                ok = same(a, b, why);
+                // --animate: every tick is compared (the scene moves, the CPU system ticks, the GPU system ticks on the
+                // same state through its dirty-range path); otherwise one CPU tick against `ticks` GPU ticks
+                const uint32_t compared = animate ? ticks : 1;
+                Snapshot a, b;
+                for (uint32_t c = 0; c < compared && ok; c++) {
+                    run(true, false, 1);
+                    a = snapshot(manager, cpu, passCount);
+                    clearVisible(manager);
+                    seconds += run(false, true, animate ? 1 : ticks, false);
+                    b = snapshot(manager, gpu, passCount);
+                    ok = same(a, b, why);
+                }
                 if (ok && !a.ordered) {
                     ok = false;
                     why = "CPU system: " + a.disorder + " not in sortMeshes order";

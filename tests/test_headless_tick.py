@@ -81,9 +81,14 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "30000", "--hier", "--mutate", "--churn", "8"],
     ["--entities", "20000", "--mixed", "--hier", "--churn", "5", "--bounds"],
     ["--entities", "40000", "--mixed", "--bounds"],
+    # a moving scene, compared tick by tick: dense and sparse dirty ranges, small pools (published results) and large
+    ["--entities", "20000", "--animate", "3", "--hier", "--ticks", "6"],
+    ["--entities", "9000", "--animate", "1", "--mixed", "--ticks", "5"],
+    ["--entities", "150000", "--animate", "64", "--ticks", "4"],
+    ["--entities", "12000", "--animate", "5", "--hier", "--mixed", "--bounds", "--ticks", "6"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
-    _, out = tick("--mode", "both", "--ticks", "3", *args)
+    _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
     assert out["draw_count"] > 0
 
 
