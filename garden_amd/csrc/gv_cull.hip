@@ -52,7 +52,7 @@ __device__ __forceinline__ bool block_behind_planes(const float4 lo, const float
             const float y = (ny >= 0.0f ? hi.y : lo.y) - cam[1];
             const float z = (nz >= 0.0f ? hi.z : lo.z) - cam[2];
             const float d = fmaf(nx, x, fmaf(ny, y, fmaf(nz, z, planes[p][3])));
-            behind = behind || (d < -margin);
+            behind = behind || (d < -fmaf(4e-5f, fabsf(planes[p][3]), margin));  // the plane offset rounds too
         }
     return behind;
 }
@@ -70,8 +70,19 @@ __device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, ui
     bool visible = false;
     if (i < args.mesh.count) {
         Mat34 m;
+        float4 box_a;
+        float2 box_b;
         Corners c;
-        visible = evaluate_slot<MAP>(args.mesh, args.xf, args.view, i, m, c);
+        uint32_t where = kSphereOutside;
+        if (prepare_model<MAP>(args.mesh, args.xf, args.view.cam, i, m, box_a, box_b))
+            where = classify_sphere(m, box_a, box_b, args.view.planes, args.view.plane_count);
+        visible = where == kSphereInside;
+        if (where == kSphereUndecided) {  // near a plane (or non-finite): the exact 8-corner test; rare, skipped wave-wide otherwise
+            aabb_corners(m, box_a, box_b, c);
+            visible = !behind_frustum(c, args.view.planes, args.view.plane_count);
+        } else if (HIZ && visible) {
+            aabb_corners(m, box_a, box_b, c);
+        }
         // Hi-Z occlusion query on the survivors. Measured (profiles/r01b_hiz_ablation.txt): compacting the
         // survivors across the workgroup through LDS first buys nothing — the stage is bound by the texel
         // gathers (~4.5 M random 64-B sectors per frame), not by divergent VALU work.
