@@ -290,13 +290,26 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
         }
     }
     Mat34 m;
+    float4 box_a;
+    float2 box_b;
     Corners c;
-    const bool candidate = in_range && prepare_slot<MAP>(args.mesh, args.xf, args.cam, i, m, c);
+    const bool candidate = in_range && prepare_model<MAP>(args.mesh, args.xf, args.cam, i, m, box_a, box_b);
+    const float reach = candidate ? sphere_reach(m, box_a, box_b) : 0.0f;  // one sphere for every view of the batch
+    bool have_corners = false;  // generated once, by the first view that needs them
     __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
 #pragma unroll
     for (uint32_t v = 0; v < kMaxBatchViews; v++) {
         if (v < args.nviews) {  // uniform
-            bool visible = candidate && !behind_frustum(c, args.planes[v].planes, args.planes[v].plane_count);
+            const uint32_t where = candidate ? classify_sphere(m, reach, args.planes[v].planes, args.planes[v].plane_count) : kSphereOutside;
+            bool visible = where == kSphereInside;
+            if (where == kSphereUndecided || (HIZ && v == 0 && visible)) {
+                if (!have_corners) {
+                    aabb_corners(m, box_a, box_b, c);
+                    have_corners = true;
+                }
+                if (where == kSphereUndecided)
+                    visible = !behind_frustum(c, args.planes[v].planes, args.planes[v].plane_count);
+            }
             if (HIZ && v == 0 && visible)
                 visible = !hiz_occluded(args.hiz, args.vp0, c);
             if (args.planes[v].write_is_visible && in_range)

@@ -346,14 +346,18 @@ __device__ __forceinline__ bool prepare_slot(const MeshMirror& mesh, const Trans
 // — a plane within the band, non-finite values (every comparison false) — is "undecided" and takes the exact test.
 // At 10 M entities 0.2-0.5 % of the entries are undecided; 230 -> ~170 VALU instructions per wave with Hi-Z.
 enum : uint32_t { kSphereOutside = 0, kSphereInside = 1, kSphereUndecided = 2 };
-__device__ __forceinline__ uint32_t classify_sphere(const Mat34& m, const float4 a, const float2 b, const float (&planes)[6][4],
-                                                    uint32_t plane_count)
+// r + the magnitude-proportional part of the slack (view independent: shadow passes that share the camera share it)
+__device__ __forceinline__ float sphere_reach(const Mat34& m, const float4 a, const float2 b)
 {
-    const float ax = fmaxf(fabsf(a.x), fabsf(a.w)), ay = fmaxf(fabsf(a.y), fabsf(b.x)), az = fmaxf(fabsf(a.z), fabsf(b.y));
+    // NaN-propagating maxima: a NaN anywhere must reach the comparisons (fmaxf would drop it and decide for the exact test)
+    const float ax = max_nan(fabsf(a.x), fabsf(a.w)), ay = max_nan(fabsf(a.y), fabsf(b.x)), az = max_nan(fabsf(a.z), fabsf(b.y));
     const float r = fmaf(fabsf(m.c0x) + fabsf(m.c0y) + fabsf(m.c0z), ax,
                          fmaf(fabsf(m.c1x) + fabsf(m.c1y) + fabsf(m.c1z), ay, (fabsf(m.c2x) + fabsf(m.c2y) + fabsf(m.c2z)) * az));
-    const float mag = fmaxf(fmaxf(fabsf(m.c3x), fabsf(m.c3y)), fabsf(m.c3z)) + r;
-    const float reach = fmaf(4e-5f, mag, r) + 0.01f;
+    const float mag = max_nan(max_nan(fabsf(m.c3x), fabsf(m.c3y)), fabsf(m.c3z)) + r;
+    return fmaf(4e-5f, mag, r) + 0.01f;
+}
+__device__ __forceinline__ uint32_t classify_sphere(const Mat34& m, float reach, const float (&planes)[6][4], uint32_t plane_count)
+{
     bool outside = false, decided = true;
 #pragma unroll
     for (uint32_t p = 0; p < 6; p++)
@@ -364,6 +368,11 @@ __device__ __forceinline__ uint32_t classify_sphere(const Mat34& m, const float4
             decided = decided & ((d > bound) | (d < -bound));
         }
     return outside ? kSphereOutside : (decided ? kSphereInside : kSphereUndecided);
+}
+__device__ __forceinline__ uint32_t classify_sphere(const Mat34& m, const float4 a, const float2 b, const float (&planes)[6][4],
+                                                    uint32_t plane_count)
+{
+    return classify_sphere(m, sphere_reach(m, a, b), planes, plane_count);
 }
 
 // default getReadyMeshesAsync predicate (render/mesh.hpp:142-146). Fully unrolled with a wave-uniform guard so

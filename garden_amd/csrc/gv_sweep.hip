@@ -271,8 +271,15 @@ __global__ __launch_bounds__(256) void sweep_cull_mfma_kernel(const SweepCullArg
         if (in_range && !empty && (flags & kXfActive)) {
             const Mat34 model = translated(world, args.cull.view.cam[0], args.cull.view.cam[1], args.cull.view.cam[2]);
             Corners c;
-            aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
-            visible = !behind_frustum(c, args.cull.view.planes, args.cull.view.plane_count);
+            // sphere pre-test first (gv_device.hpp): corners and the exact test only for entries near a plane
+            const uint32_t where = classify_sphere(model, ma, mb, args.cull.view.planes, args.cull.view.plane_count);
+            visible = where == kSphereInside;
+            if (where == kSphereUndecided) {
+                aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
+                visible = !behind_frustum(c, args.cull.view.planes, args.cull.view.plane_count);
+            } else if (HIZ && visible) {
+                aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
+            }
             if (HIZ && visible)
                 visible = !hiz_occluded(args.cull.hiz, args.cull.view.vp, c);
         }
@@ -334,8 +341,15 @@ __global__ __launch_bounds__(256) void sweep_cull_valu_kernel(const SweepCullArg
         if (in_range && !empty && (flags & kXfActive)) {
             const Mat34 model = translated(world, args.cull.view.cam[0], args.cull.view.cam[1], args.cull.view.cam[2]);
             Corners c;
-            aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
-            visible = !behind_frustum(c, args.cull.view.planes, args.cull.view.plane_count);
+            // sphere pre-test first (gv_device.hpp): corners and the exact test only for entries near a plane
+            const uint32_t where = classify_sphere(model, ma, mb, args.cull.view.planes, args.cull.view.plane_count);
+            visible = where == kSphereInside;
+            if (where == kSphereUndecided) {
+                aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
+                visible = !behind_frustum(c, args.cull.view.planes, args.cull.view.plane_count);
+            } else if (HIZ && visible) {
+                aabb_corners(model, mnx, mny, mnz, mxx, mxy, mxz, c);
+            }
             if (HIZ && visible)
                 visible = !hiz_occluded(args.cull.hiz, args.cull.view.vp, c);
         }

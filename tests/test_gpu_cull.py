@@ -788,3 +788,43 @@ def test_native_rccl_exchange_single_rank(oracle):
         vis.exchange_shutdown()
         with pytest.raises(Exception):
             vis.exchange_shards(0, cap, 0, gathered.data_ptr())  # GV_E_STATE after shutdown
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hier", [False, True])
+def test_sphere_pretest_agrees_with_the_exact_test_around_every_plane(gpu, oracle, hier):
+    """The cull kernels decide entries away from the planes by a sphere bound and run the exact 8-corner test only in
+    the band around a plane (gv_device.hpp classify_sphere). Here most entities sit IN that band: positions are random
+    points on the planes of a perspective and an orthographic frustum, pushed along the normal by up to +-12 m (boxes
+    reach ~3.5 m), near and far from the camera (1 m .. 90 km: the slack scales with the magnitude), with non-finite
+    and extreme values sprinkled over AABBs and transforms. Single views, a batched pair, Hi-Z on: same visible sets."""
+    n = 120_000
+    sc = scene.hierarchy_scene(n, depth=2, fanout=4) if hier else scene.flat_scene(n, seed=77)
+    n = sc.count
+    rng = np.random.default_rng(2024)
+    main, cascade = scene.main_camera_view(use_hiz=0), scene.cascade_view(index=0, size=6000.0, depth=30000.0)
+    t, m = sc.transforms, sc.meshes
+    roots = np.flatnonzero(t["parent"] == 0) if hier else np.arange(n)
+    planes = np.concatenate([oracle.frustum(main["view_proj"]), oracle.frustum(cascade["view_proj"])])
+    k = rng.integers(0, len(planes), roots.size)
+    nrm, w = planes[k, :3].astype(np.float64), planes[k, 3].astype(np.float64)
+    # a random point, projected onto its plane, then offset along the normal
+    p = rng.normal(size=(roots.size, 3)) * (10.0 ** rng.uniform(0, 4.95, (roots.size, 1)))
+    p -= ((p * nrm).sum(1) + w)[:, None] * nrm
+    p += nrm * rng.uniform(-12, 12, (roots.size, 1))
+    t["position"][roots, :3] = p.astype(np.float32)
+    specials = np.array([np.nan, np.inf, -np.inf, 1e-42, -0.0, 3e38, -3e38, 1e-30], dtype=np.float32)
+    for arr, field, width in ((m, "aabbMin", 3), (m, "aabbMax", 3), (t, "position", 3), (t, "scale", 3), (t, "rotation", 4)):
+        rows = rng.choice(n, 600, replace=False)
+        arr[field][rows, rng.integers(0, width, 600)] = specials[rng.integers(0, len(specials), 600)]
+    lop = rng.choice(n, 3000, replace=False)  # lopsided boxes: the sphere is centred on the translation, not on the box
+    m["aabbMin"][lop, :3] += rng.uniform(-3, 3, (3000, 3)).astype(np.float32)
+    depth = scene.synthetic_depth(512, 256)
+    for views in ([main], [cascade], [dict(main, use_hiz=1), cascade], [dict(main, camera_position=np.array([40.0, -7.0, 3.0, 0.0], np.float32))]):
+        res = run_both(gpu, oracle, sc, views, hiz_depth=depth)
+        for (got, gv, exp, ev), v in zip(res, views):
+            assert exp["draw_count"] > 1000
+            assert got["draw_count"] == exp["draw_count"] and np.array_equal(got["visible_idx"], exp["visible_idx"])
+            assert same_bits_or_both_nan(got["baked_model"], exp["baked_model"])
+            if v["shadow_pass"] < 0:
+                assert np.array_equal(gv, ev)
