@@ -149,7 +149,7 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
     a.bounds = bounds ? *bounds : BlockBounds{};
     // measured: the frustum-only scan gains 6 % from per-XCD runs, the Hi-Z and block-bounds variants do not
-    a.xcd_run = a.nblocks >= kXcdRunMinTiles && !vp.use_hiz && !bounds ? kXcdRun : 0;
+    a.xcd_run = vp.use_hiz || bounds ? 0 : xcd_run_for_tiles(a.nblocks);
     const dim3 grid(grid_for_tiles(a.nblocks, a.xcd_run)), block(kCullBlock);
 #define GV_LAUNCH_CULL(HIZ, BOUNDS)                                                                                       \
     switch (mesh.mapping) {                                                                                              \

@@ -225,12 +225,15 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
 // tiles (8q + x)R .. (8q + x + 1)R - 1 for its q-th run — so it streams contiguous stretches (R * 8 KB of the
 // 32-byte transform stream), while runs still alternate between the XCDs often enough that the expensive part of
 // the pool (the entries inside the frustum are contiguous in the spatial order) stays spread over all of them.
-// Measured at 10 M entities, same box A/B: frustum-only cull 111.7 -> 104.3-105.4 us (R = 32); the Hi-Z variant does
-// not move (125.3 vs 126.1-126.6 us), the block-bounds variant loses (78.7 -> 82.7-85 us), the fused sweep + cull is
-// flat: only the frustum-only scan uses it. One run per XCD (R = tiles / 8) is best without Hi-Z (98.5 us) but piles
-// the Hi-Z queries onto two XCDs (140 us).
-constexpr uint32_t kXcdRun = 32;
-constexpr uint32_t kXcdRunMinTiles = 8 * kXcdRun * 8;  // smaller pools keep the identity mapping (no surplus workgroups)
+// Measured at 10 M entities, same box A/B: frustum-only cull 110-112 -> 102-104 us (R = 32) -> 99 us (R = 256); the
+// Hi-Z variant does not move (R = 32) or loses (R = 256: +4 us; one run per XCD: 134-140 us, the queries pile up on
+// two XCDs), the block-bounds variant loses (78 -> 82 -> 89 us), the fused sweep + cull is flat: only the
+// frustum-only scan uses it (profiles/r01b_kbench.txt).
+// run length for a pool of `tiles` tiles: every XCD gets at least 8 runs (no surplus workgroups to speak of)
+inline uint32_t xcd_run_for_tiles(uint32_t tiles)
+{
+    return tiles >= 8u * 256u * 8u ? 256u : (tiles >= 8u * 32u * 8u ? 32u : 0u);
+}
 
 __device__ __forceinline__ uint32_t tile_of_workgroup(uint32_t b, uint32_t run)
 {
