@@ -123,6 +123,53 @@ int hiz_reduce(GvCtx* ctx)
     return GV_OK;
 }
 
+// gv_sort on a small pool only records the request; the first call that needs the records (fetch, device accessors,
+// gv_wait) sorts every pending view of the pool in ONE launch — main camera + shadow passes cost one launch, not one each.
+int flush_sorts(GvCtx* ctx)
+{
+    for (;;) {
+        uint32_t occupancy = 0, views = 0;
+        ViewState* taken[GV_MAX_VIEWS];
+        SortBatch batch{};
+        for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
+            ViewState& vs = ctx->views[v];
+            if (!vs.valid || !vs.sort_pending || (views && vs.occupancy != occupancy))
+                continue;
+            occupancy = vs.occupancy;
+            const size_t n = vs.occupancy;
+            GV_HIP(ctx, vs.alt_idx.reserve(n));
+            GV_HIP(ctx, vs.alt_model.reserve(n * 12));
+            GV_HIP(ctx, vs.alt_dist.reserve(n));
+            SortBuffers& b = batch.view[views];
+            b.count = vs.draw_count.ptr;
+            b.idx_in = vs.visible_idx.ptr;
+            b.model_in = vs.baked_model.ptr;
+            b.dist_in = vs.distance_sq.ptr;
+            b.idx_out = vs.alt_idx.ptr;
+            b.model_out = vs.alt_model.ptr;
+            b.dist_out = vs.alt_dist.ptr;
+            batch.descending[views] = vs.sort_pending == 2 ? 1u : 0u;
+            taken[views++] = &vs;
+        }
+        if (views == 0)
+            return GV_OK;
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        {
+            ZoneScope zone("Meshes Sort");
+            KernelTimer t(ctx, GV_K_SORT);
+            GV_HIP(ctx, launch_sort_small_batch(batch, views, occupancy, ctx->stream));
+        }
+        for (uint32_t k = 0; k < views; k++) {  // the sorted records now live in the alternate set: swap it in
+            ViewState& vs = *taken[k];
+            std::swap(vs.visible_idx, vs.alt_idx);
+            std::swap(vs.baked_model, vs.alt_model);
+            std::swap(vs.distance_sq, vs.alt_dist);
+            vs.sort_pending = 0;
+            vs.published = false;
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -435,6 +482,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.emitted = emit;
         vs.valid = true;
         vs.published = false;
+        vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
         build_view_params(views[v], &vps[v]);
         vbs[v] = view_buffers(vs);
         if (p.occupancy == 0)
@@ -492,7 +540,25 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
             KernelTimer t(ctx, GV_K_CULL);
             GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
         }
-        for (uint32_t v = 0; v < view_count; v++) {
+        static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
+        // a batched cull whose views all want records: ONE self-prefixing emit launch for all of them
+        bool emit_batched = batched && chunks <= self_max;
+        for (uint32_t v = 0; v < view_count && emit_batched; v++)
+            emit_batched = ctx->views[v].emitted;
+        if (emit_batched) {
+            uint32_t clear[GV_MAX_VIEWS];
+            for (uint32_t v = 0; v < view_count; v++) {
+                ViewState& vs = ctx->views[v];
+                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+                clear[v] = std::max(chunks, vs.stale_chunks[other]);
+                vs.stale_chunks[other] = 0;
+                vs.stale_chunks[cur] = chunks;
+                vs.count_parity = other;
+            }
+            KernelTimer t(ctx, GV_K_EMIT);
+            GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream));
+        }
+        for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
             if (!batched) {
                 KernelTimer t(ctx, GV_K_CULL);
                 if (fused && v == 0)
@@ -501,7 +567,6 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                     GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
                 }
             }
-            static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
             if (ctx->views[v].emitted && chunks <= self_max) {
                 // no scan launch: emit derives the chunk bases itself and leaves THIS totals buffer as it is; the
                 // next cull of this view adds into the other one, which this emit has cleared
@@ -533,6 +598,8 @@ int gv_wait(GvCtx* ctx)
 {
     if (!ctx)
         return GV_E_ARG;
+    if (int rc = flush_sorts(ctx))
+        return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain_events(ctx);
@@ -562,6 +629,8 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         return ctx->fail(GV_E_ARG, "gv_results_fetch: out is NULL");
     if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid)
         return ctx->fail(GV_E_ARG, "gv_results_fetch: view %u has no results", view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
     ViewState& vs = ctx->views[view_index];
     PoolState& pool = ctx->pools[vs.pool_id];
     const bool permuted = !pool.perm.empty() && pool.perm.size() == vs.occupancy;
@@ -679,6 +748,8 @@ int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out)
         return GV_E_ARG;
     if (view_index >= GV_MAX_VIEWS || !out || !ctx->views[view_index].valid)
         return ctx->fail(GV_E_ARG, "gv_results_device: view %u has no results", view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
     ViewState& vs = ctx->views[view_index];
     out->visible_idx = vs.emitted ? vs.visible_idx.ptr : nullptr;
     out->baked_model = vs.emitted ? vs.baked_model.ptr : nullptr;
@@ -695,6 +766,8 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
         return GV_E_ARG;
     if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
         return ctx->fail(GV_E_ARG, "gv_results_copy_idx_device: view %u has no emitted records", view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
     ViewState& vs = ctx->views[view_index];
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, launch_copy_idx(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
@@ -709,6 +782,8 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
         return GV_E_ARG;
     if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
         return ctx->fail(GV_E_ARG, "gv_results_copy_shard_device: view %u has no emitted records", view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
     ViewState& vs = ctx->views[view_index];
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
@@ -726,6 +801,11 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
     ViewState& vs = ctx->views[view_index];
     if (vs.occupancy == 0)
         return GV_OK;
+    if (vs.occupancy <= kSmallSortMaxSlots) {  // launched with the other views' sorts when the records are asked for
+        vs.sort_pending = descending ? 2 : 1;
+        vs.published = false;
+        return GV_OK;
+    }
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
     const size_t nblocks = (n + 4095) / 4096;

@@ -204,6 +204,7 @@ struct ViewState {
     PinnedBuf<uint8_t> h_is_visible;
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;
+    uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };
 

@@ -513,12 +513,12 @@ constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slot
 // chunk (a few KB of L2 reads) to get its base; workgroup 0 also writes the grand total and clears the OTHER totals
 // buffer for the next frame's cull (the two buffers alternate, so nobody is still reading the one being cleared).
 template <bool SELF>
-__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
+__device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t block)
 {
     __shared__ unsigned long long words[64];
     __shared__ uint32_t prefix[65];
     __shared__ uint32_t below[4];
-    const uint32_t chunk = blockIdx.x / kEmitParts, part = blockIdx.x % kEmitParts;
+    const uint32_t chunk = block / kEmitParts, part = block % kEmitParts;
     const uint32_t first_word = chunk * 64;
     const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
     if (threadIdx.x < 64) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
         if (threadIdx.x == 0)
             prefix[0] = 0;
     } else if (SELF) {
-        const uint32_t upto = blockIdx.x == 0 ? args.nchunks : chunk;  // workgroup 0: the grand total
+        const uint32_t upto = block == 0 ? args.nchunks : chunk;  // workgroup 0: the grand total
         // all loads of the sum are issued before the first is consumed: one L2 round trip for up to 4096 totals, not
         // one per 192 of them (the serial form took ~13 dependent round trips for the last chunks of a 10 M pool)
         const uint4* __restrict__ totals4 = reinterpret_cast<const uint4*>(args.out.chunk_count);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
     uint32_t base;
     if (SELF) {
         base = below[1] + below[2] + below[3];
-        if (blockIdx.x == 0) {
+        if (block == 0) {
             if (threadIdx.x == 0)
                 *args.out.draw_count = base;
             for (uint32_t c = threadIdx.x; c < args.clear_chunks; c += 256)
@@ -587,6 +587,53 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
         const uint32_t i = (first_word + lo) * 64 + pos;
         write_record(args, i, (size_t)base + r);
     }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
+{
+    emit_block<SELF>(args, blockIdx.x);
+}
+
+// The views of one batched cull (main camera + shadow passes over a small pool, where every launch counts) emitted by
+// ONE launch: blockIdx.y picks the view, the pool-side arguments are shared.
+struct EmitBatchArgs {
+    MeshMirror mesh;
+    TransformMirror xf;
+    uint32_t nchunks;
+    uint32_t clear_chunks[kMaxBatchViews];
+    ViewParams view[kMaxBatchViews];
+    ViewBuffers out[kMaxBatchViews];
+};
+__global__ __launch_bounds__(256) void emit_batch_kernel(const EmitBatchArgs batch)
+{
+    EmitArgs args;
+    args.mesh = batch.mesh;
+    args.xf = batch.xf;
+    args.view = batch.view[blockIdx.y];
+    args.out = batch.out[blockIdx.y];
+    args.nchunks = batch.nchunks;
+    args.clear_chunks = batch.clear_chunks[blockIdx.y];
+    emit_block<true>(args, blockIdx.x);
+}
+
+hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
+                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream)
+{
+    if (mesh.count == 0 || nviews == 0)
+        return hipSuccess;
+    EmitBatchArgs a;
+    a.mesh = mesh;
+    a.xf = xf;
+    a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
+        const uint32_t k = v < nviews ? v : 0;
+        a.view[v] = views[k];
+        a.out[v] = outs[k];
+        a.clear_chunks[v] = clear_chunks[k];
+    }
+    hipLaunchKernelGGL(emit_batch_kernel, dim3(a.nchunks * kEmitParts, nviews), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,

@@ -111,6 +111,9 @@ hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t
 constexpr uint32_t kSelfPrefixMaxChunks = 4096;
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
                        hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0);
+// all views of a batched cull in one launch (self-prefixing form; views[v] / outs[v] / clear_chunks[v] per view)
+hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
+                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream);
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                            hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
@@ -153,6 +156,14 @@ struct SortBuffers {
     uint32_t* bin_total;  // 256
 };
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
+// pools of up to this many slots sort in one launch (rank sort, gv_sort.hip); gv_sort defers those so that the views of
+// one cull share a single launch (launch_sort_small_batch) when their results are first asked for
+constexpr uint32_t kSmallSortMaxSlots = 16384;
+struct SortBatch {
+    SortBuffers view[kMaxPublishViews];
+    uint32_t descending[kMaxPublishViews];
+};
+hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t capacity, hipStream_t stream);
 
 // derives TransformMirror::active_bits from flags[]
 // Byte layout of one TransformComponent inside a raw AoS copy (all offsets within `stride`).

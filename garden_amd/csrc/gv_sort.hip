@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void sort_gather_kernel(const uint32_t* __rest
 // workgroup owns 64 records; its four waves each count over a quarter of the keys (staged in LDS, read as uniform
 // 16-byte broadcasts) and the partial counts meet in LDS. n^2 / 4 comparisons per wave, all CUs busy, no
 // inter-workgroup step: ~6 us at 2 k records where a one-workgroup bitonic network took 42 us.
-constexpr uint32_t kSmallSort = 16384;
+constexpr uint32_t kSmallSort = kSmallSortMaxSlots;
 
 // records of [jlo, jhi) (multiples of 4) that order before record i with key ki. WHERE: 0 = every j is below the
 // workgroup's records (ties count), 2 = every j is above them (ties do not), 1 = overlapping (compare the pair)
@@ -206,12 +206,12 @@ __device__ __forceinline__ uint32_t count_before(const uint32_t* key, uint32_t j
     return before;
 }
 
-__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending)
+__device__ __forceinline__ void sort_small_block(const SortBuffers& b, uint32_t capacity, uint32_t descending, uint32_t block)
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
     const uint32_t n = min(*b.count, capacity);
-    const uint32_t i0 = blockIdx.x * 64;
+    const uint32_t i0 = block * 64;
     if (i0 >= n)
         return;
     const uint32_t n4 = (n + 3u) & ~3u;
@@ -249,6 +249,17 @@ __global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, ui
     dm[2] = m2;
 }
 
+__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending)
+{
+    sort_small_block(b, capacity, descending, blockIdx.x);
+}
+
+// several views of one small pool (main camera + shadow passes) in one launch: blockIdx.y picks the view
+__global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatch batch, uint32_t capacity)
+{
+    sort_small_block(batch.view[blockIdx.y], capacity, batch.descending[blockIdx.y], blockIdx.x);
+}
+
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream)
 {
     if (capacity == 0)
@@ -276,6 +287,19 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     // 4 passes: the sorted order ends in vals[0]
     hipLaunchKernelGGL(sort_gather_kernel, dim3(wide), dim3(256), 0, stream, b.vals[0], b.count, b.idx_in, b.model_in, b.dist_in,
                        b.idx_out, b.model_out, b.dist_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t capacity, hipStream_t stream)
+{
+    if (capacity == 0 || views == 0)
+        return hipSuccess;
+    const uint32_t lds = ((capacity + 3u) & ~3u) * 4;
+    static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_batch_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
+    if (raised != hipSuccess)
+        return raised;
+    hipLaunchKernelGGL(sort_small_batch_kernel, dim3((capacity + 63) / 64, views), dim3(256), lds, stream, batch, capacity);
     return hipGetLastError();
 }
 

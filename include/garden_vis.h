@@ -221,7 +221,9 @@ int gv_exchange_shutdown(GvCtx* ctx);
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
  * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: equal keys keep the order the records were
  * emitted in (std::sort in the reference leaves ties unspecified).
- * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. */
+ * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. For pools of up to 16384 slots
+ * the launch is deferred to the first call that reads the records (gv_results_*, gv_wait), where the pending sorts of
+ * all views share one launch. */
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
 
 /* ---- scene ingest: a Garden scene file straight into column pools, no component AoS ----
