@@ -828,3 +828,56 @@ def test_sphere_pretest_agrees_with_the_exact_test_around_every_plane(gpu, oracl
             assert same_bits_or_both_nan(got["baked_model"], exp["baked_model"])
             if v["shadow_pass"] < 0:
                 assert np.array_equal(gv, ev)
+
+
+@pytest.mark.gpu
+def test_deferred_sorts_of_a_small_pool_reach_every_reader(gpu, oracle):
+    """gv_sort on a pool of <= 16384 slots is deferred and batched over the views of the cull. Whoever reads the records
+    first — a device accessor, gv_wait, a fetch of ANOTHER view — must see them sorted; a sort nobody read before the
+    next cull is dropped; re-sorting in the other direction after a read works on the published results."""
+    import torch
+    sc = scene.flat_scene(12_000, seed=41)
+    views = [scene.main_camera_view(), dict(scene.cascade_view(index=0, size=9000.0, depth=30000.0)),
+             dict(scene.cascade_view(index=1, size=5000.0, depth=30000.0))]
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    exp = [oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, sort="descending" if k == 1 else "ascending")
+           for k, v in enumerate(views)]
+
+    def canon(got, descending):  # ties: by slot, as the oracle breaks them
+        d = got["distance_sq"]
+        o = np.lexsort((got["visible_idx"], -d if descending else d))
+        return got["visible_idx"][o]
+
+    gpu.cull(0, views)
+    for k in range(3):
+        gpu.sort(k, descending=(k == 1))
+    # 1. a device accessor of view 1 is the first reader
+    dst = torch.full((sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    gpu.copy_idx_device(1, dst.data_ptr(), sc.count)
+    n1 = gpu.result_count(1)
+    got1 = gpu.fetch(1, write_back=False, occupancy=sc.count, order="raw")
+    assert n1 == exp[1]["draw_count"] and np.array_equal(dst[:n1].cpu().numpy().astype(np.uint32), got1["visible_idx"])
+    d = got1["distance_sq"]
+    assert np.all(d[:-1] >= d[1:]) and np.array_equal(canon(got1, True), exp[1]["visible_idx"])
+    # 2. the other views were sorted by the same flush
+    for k in (0, 2):
+        g = gpu.fetch(k, write_back=False, occupancy=sc.count, order="raw")
+        assert np.all(g["distance_sq"][:-1] <= g["distance_sq"][1:]) and np.array_equal(canon(g, False), exp[k]["visible_idx"])
+    # 3. re-sort one view the other way after it has been read
+    gpu.sort(0, descending=True)
+    g = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
+    assert np.all(g["distance_sq"][:-1] >= g["distance_sq"][1:]) and set(g["visible_idx"].tolist()) == set(exp[0]["visible_idx"].tolist())
+    # 4. a sort nobody read is dropped by the next cull: slot order again
+    gpu.sort(2, descending=True)
+    gpu.cull(0, views)
+    g = gpu.fetch(2, write_back=False, occupancy=sc.count)
+    assert np.array_equal(g["visible_idx"], np.sort(exp[2]["visible_idx"]))
+    # 5. gv_wait flushes too
+    gpu.sort(1, descending=True)
+    gpu.wait()
+    dev = gpu.results_device(1)
+    assert dev.visible_idx
+    g = gpu.fetch(1, write_back=False, occupancy=sc.count, order="raw")
+    assert np.array_equal(canon(g, True), exp[1]["visible_idx"]) and np.all(g["distance_sq"][:-1] >= g["distance_sq"][1:])
