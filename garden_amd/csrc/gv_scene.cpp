@@ -92,6 +92,11 @@ struct Parser {
         ws();
         return p < end ? *p : '\0';
     }
+    bool at_number()
+    {
+        const char c = peek();
+        return c == '-' || (c >= '0' && c <= '9') || (allow_nan && c == 'n' && (size_t)(end - p) >= 3 && memcmp(p, "nan", 3) == 0);
+    }
     bool string(std::string* out)
     {
         ws();
@@ -150,6 +155,14 @@ struct Parser {
     {
         ws();
         const char* s = p;
+        if (allow_nan && (size_t)(end - p) >= 3 && memcmp(p, "nan", 3) == 0) {  // only the BSON transcoder writes this
+            p += 3;
+            if (value)
+                *value = NAN;
+            if (is_float)
+                *is_float = true;
+            return true;
+        }
         if (p < end && (*p == '-' || *p == '+'))
             p++;
         bool digits = false, flt = false;
@@ -214,11 +227,14 @@ struct Parser {
             return literal("true");
         if (c == 'f')
             return literal("false");
+        if (c == 'n' && allow_nan && (size_t)(end - p) >= 3 && memcmp(p, "nan", 3) == 0)
+            return number(nullptr, nullptr);
         if (c == 'n')
             return literal("null");
         return number(nullptr, nullptr);
     }
     const char* begin = nullptr;
+    bool allow_nan = false;
     size_t offset() const { return (size_t)(p - begin); }
 };
 
@@ -238,8 +254,7 @@ bool read_vector(Parser& ps, float* v, int components)
             int k = -1;
             if (key.size() == 1)
                 k = key[0] == 'x' ? 0 : key[0] == 'y' ? 1 : key[0] == 'z' ? 2 : key[0] == 'w' ? 3 : -1;
-            const char v0 = ps.peek();
-            if (k >= 0 && k < components && (v0 == '-' || (v0 >= '0' && v0 <= '9'))) {
+            if (k >= 0 && k < components && ps.at_number()) {
                 double d;
                 bool flt;
                 if (!ps.number(&d, &flt))
@@ -252,7 +267,7 @@ bool read_vector(Parser& ps, float* v, int components)
         } while (ps.eat(','));
         return ps.eat('}') || ps.fail("expected '}' at byte %zu", ps.offset());
     }
-    if (c == '-' || (c >= '0' && c <= '9')) {
+    if (ps.at_number()) {
         double d;
         bool flt;
         if (!ps.number(&d, &flt))
@@ -608,6 +623,177 @@ struct Loader {
     }
 };
 
+
+// ---- BSON (packed builds): ResourceSystem::loadScene reads the scene through JsonDeserializer::load(vector<uint8>)
+// = nlohmann::json::from_bson (resource.cpp:2359-2377, json-serialize.cpp:338-344); tools ship it as
+// json::to_bson(text) with "debugName" keys erased (json2bson.cpp:41-66). from_bson maps 0x01 double -> number_float,
+// 0x10 / 0x12 int32 / int64 -> number_integer, 0x11 -> number_unsigned, 0x08 bool, 0x0A null, 0x02 string,
+// 0x03 document, 0x04 array (keys ignored, element order kept), 0x05 binary — the same value categories the text
+// parser distinguishes, so the document is re-written as JSON text for the one loader above: doubles with 17
+// significant digits and always a fraction or exponent (the float / integer distinction IS the typing rule), NaN as
+// the private token `nan`, infinities as an overflowing literal. Everything else nlohmann rejects is rejected here.
+struct BsonReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    std::string* out;
+    std::string error;
+
+    bool fail(const char* what)
+    {
+        if (error.empty())
+            error = std::string("BSON: ") + what;
+        return false;
+    }
+    bool need(size_t n) { return (size_t)(end - p) >= n || fail("truncated document"); }
+    template <typename T>
+    bool get(T* v)
+    {
+        if (!need(sizeof(T)))
+            return false;
+        memcpy(v, p, sizeof(T));  // BSON is little-endian, as is every host this library builds for
+        p += sizeof(T);
+        return true;
+    }
+    bool cstring(std::string* s)
+    {
+        const void* z = memchr(p, 0, (size_t)(end - p));
+        if (!z)
+            return fail("unterminated key");
+        s->assign(reinterpret_cast<const char*>(p), reinterpret_cast<const char*>(z));
+        p = static_cast<const uint8_t*>(z) + 1;
+        return true;
+    }
+    void quoted(const char* s, size_t n)
+    {
+        out->push_back('"');
+        for (size_t k = 0; k < n; k++) {
+            const unsigned char c = (unsigned char)s[k];
+            if (c == '"' || c == '\\') {
+                out->push_back('\\');
+                out->push_back((char)c);
+            } else if (c < 0x20) {
+                char buf[8];
+                snprintf(buf, sizeof(buf), "\\u%04x", c);
+                out->append(buf);
+            } else {
+                out->push_back((char)c);
+            }
+        }
+        out->push_back('"');
+    }
+    bool document(bool as_array, int depth)
+    {
+        if (depth > 256)
+            return fail("nesting deeper than 256 levels");
+        int32_t size;
+        const uint8_t* start = p;
+        if (!get(&size))
+            return false;
+        if (size < 5 || (size_t)size > (size_t)(end - start))
+            return fail("document size out of range");
+        const uint8_t* stop = start + size;
+        out->push_back(as_array ? '[' : '{');
+        bool first = true;
+        std::string key;
+        for (;;) {
+            uint8_t type;
+            if (p >= stop || !get(&type))
+                return fail("document without terminator");
+            if (type == 0)
+                break;
+            if (!cstring(&key))
+                return false;
+            if (!first)
+                out->push_back(',');
+            first = false;
+            if (!as_array) {
+                quoted(key.data(), key.size());
+                out->push_back(':');
+            }
+            char buf[40];
+            switch (type) {
+            case 0x01: {
+                double d;
+                if (!get(&d))
+                    return false;
+                if (d != d) {
+                    out->append("nan");
+                } else if (d == HUGE_VAL || d == -HUGE_VAL) {
+                    out->append(d < 0 ? "-1e999" : "1e999");
+                } else {
+                    snprintf(buf, sizeof(buf), "%.17g", d);
+                    out->append(buf);
+                    if (!strpbrk(buf, ".eE"))
+                        out->append(".0");
+                }
+                break;
+            }
+            case 0x02: {
+                int32_t len;
+                if (!get(&len) || len < 1 || !need((size_t)len))
+                    return fail("bad string length");
+                quoted(reinterpret_cast<const char*>(p), (size_t)len - 1);
+                p += len;
+                break;
+            }
+            case 0x03:
+            case 0x04:
+                if (!document(type == 0x04, depth + 1))
+                    return false;
+                break;
+            case 0x05: {  // binary: no reader of this loader takes one; keep the document well-formed
+                int32_t len;
+                if (!get(&len) || len < 0 || !need((size_t)len + 1))
+                    return fail("bad binary length");
+                p += (size_t)len + 1;
+                out->append("null");
+                break;
+            }
+            case 0x08: {
+                uint8_t b;
+                if (!get(&b))
+                    return false;
+                out->append(b ? "true" : "false");
+                break;
+            }
+            case 0x0A:
+                out->append("null");
+                break;
+            case 0x10: {
+                int32_t v;
+                if (!get(&v))
+                    return false;
+                snprintf(buf, sizeof(buf), "%d", v);
+                out->append(buf);
+                break;
+            }
+            case 0x12: {
+                int64_t v;
+                if (!get(&v))
+                    return false;
+                snprintf(buf, sizeof(buf), "%lld", (long long)v);
+                out->append(buf);
+                break;
+            }
+            case 0x11: {
+                uint64_t v;
+                if (!get(&v))
+                    return false;
+                snprintf(buf, sizeof(buf), "%llu", (unsigned long long)v);
+                out->append(buf);
+                break;
+            }
+            default:
+                return fail("unsupported element type");  // nlohmann: parse_error.114
+            }
+        }
+        if (p != stop)
+            return fail("document size does not match its content");
+        out->push_back(as_array ? ']' : '}');
+        return true;
+    }
+};
+
 void set_error(char* error, size_t capacity, const std::string& text)
 {
     if (error && capacity) {
@@ -619,13 +805,11 @@ GvColumn column(const void* data, uint32_t stride) { return GvColumn{data, strid
 
 }  // namespace
 
-extern "C" {
-
-int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
-                        GvScene** out_scene, char* error, size_t error_capacity)
+static int parse_scene_text(const char* text, size_t length, bool allow_nan, const GvScenePool* pools, uint32_t pool_count,
+                     uint32_t flags, GvScene** out_scene, char* error, size_t error_capacity)
 {
     if (!text || !out_scene || (pool_count && !pools)) {
-        set_error(error, error_capacity, "gv_scene_parse_json: NULL argument");
+        set_error(error, error_capacity, "gv_scene_parse: NULL argument");
         return GV_E_ARG;
     }
     *out_scene = nullptr;
@@ -634,11 +818,12 @@ int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pool
     ld.sc = sc;
     ld.ps.p = ld.ps.begin = text;
     ld.ps.end = text + length;
+    ld.ps.allow_nan = allow_nan;
     ld.add_root = (flags & GV_SCENE_ADD_ROOT_ENTITY) != 0;
     for (uint32_t k = 0; k < pool_count; k++) {
         if (!pools[k].component_type || pools[k].pool_id >= GV_MAX_POOLS || sc->pools[pools[k].pool_id].mapped ||
             strcmp(pools[k].component_type, "Transform") == 0) {
-            set_error(error, error_capacity, "gv_scene_parse_json: bad pool mapping");
+            set_error(error, error_capacity, "gv_scene_parse: bad pool mapping");
             delete sc;
             return GV_E_ARG;
         }
@@ -653,6 +838,33 @@ int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pool
     }
     *out_scene = sc;
     return GV_OK;
+}
+
+
+extern "C" {
+
+int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
+                        GvScene** out_scene, char* error, size_t error_capacity)
+{
+    return parse_scene_text(text, length, false, pools, pool_count, flags, out_scene, error, error_capacity);
+}
+
+int gv_scene_parse_bson(const void* data, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
+                        GvScene** out_scene, char* error, size_t error_capacity)
+{
+    if (!data || !out_scene || (pool_count && !pools)) {
+        set_error(error, error_capacity, "gv_scene_parse_bson: NULL argument");
+        return GV_E_ARG;
+    }
+    *out_scene = nullptr;
+    std::string text;
+    text.reserve(length * 2);
+    BsonReader reader{static_cast<const uint8_t*>(data), static_cast<const uint8_t*>(data) + length, &text, {}};
+    if (!reader.document(false, 0)) {
+        set_error(error, error_capacity, reader.error);
+        return GV_E_ARG;
+    }
+    return parse_scene_text(text.data(), text.size(), true, pools, pool_count, flags, out_scene, error, error_capacity);
 }
 
 void gv_scene_destroy(GvScene* scene) { delete scene; }

@@ -101,7 +101,7 @@ EXPORTS = [
     "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream",
-    "gv_scene_parse_json", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
+    "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown",
 ]
@@ -159,6 +159,7 @@ def load():
     lib.gv_stream.argtypes = [P]
     lib.gv_stream.restype = P
     lib.gv_scene_parse_json.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, u32, C.POINTER(P), C.c_char_p, sz]
+    lib.gv_scene_parse_bson.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, u32, C.POINTER(P), C.c_char_p, sz]
     lib.gv_scene_destroy.argtypes = [P]
     lib.gv_scene_destroy.restype = None
     lib.gv_scene_info.argtypes = [P, C.POINTER(GvSceneInfo)]
@@ -399,14 +400,16 @@ class GpuVisibility:
 class Scene:
     """A Garden scene file ingested straight into column pools (gv_scene_*; no device needed until bind)."""
 
-    def __init__(self, text, pools, add_root_entity=False):
-        """text: the scene JSON (str or bytes); pools: {component ".type": pool id}; add_root_entity: loadScene's
-        addRootEntity (a default transform as entity 1, parent of everything that names no other parent)."""
+    def __init__(self, text, pools, add_root_entity=False, bson=False):
+        """text: the scene JSON (str or bytes), or with bson=True the BSON document packed builds ship (json2bson);
+        pools: {component ".type": pool id}; add_root_entity: loadScene's addRootEntity (a default transform as
+        entity 1, parent of everything that names no other parent)."""
         self.lib = load()
         raw = text.encode() if isinstance(text, str) else bytes(text)
         arr = (GvScenePool * max(len(pools), 1))(*[GvScenePool(k.encode(), v) for k, v in pools.items()])
         handle, err = C.c_void_p(), C.create_string_buffer(512)
-        rc = self.lib.gv_scene_parse_json(raw, len(raw), arr, len(pools), 1 if add_root_entity else 0, C.byref(handle), err, len(err))
+        parse = self.lib.gv_scene_parse_bson if bson else self.lib.gv_scene_parse_json
+        rc = parse(raw, len(raw), arr, len(pools), 1 if add_root_entity else 0, C.byref(handle), err, len(err))
         if rc != 0:
             raise GvError(rc, err.value.decode(errors="replace"))
         self.handle, self.pools = handle, dict(pools)

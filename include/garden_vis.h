@@ -254,6 +254,14 @@ typedef struct GvSceneInfo {
 #define GV_SCENE_ADD_ROOT_ENTITY 1u
 int gv_scene_parse_json(const char* text, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
                         GvScene** out_scene, char* error, size_t error_capacity);
+/* The same scene as the packed builds carry it: the BSON document nlohmann::json::to_bson makes of the scene's JSON
+ * (json2bson.cpp:41-66), which ResourceSystem::loadScene hands to JsonDeserializer::load(vector<uint8>) =
+ * json::from_bson (resource.cpp:2359-2377, json-serialize.cpp:338-344). Same results as gv_scene_parse_json on the
+ * text the document was made from: from_bson keeps the value categories the readers test (double -> float literal,
+ * int32 / int64 / uint64 -> integer, bool, string, document, array by element order). Element types nlohmann's
+ * from_bson rejects are rejected (GV_E_ARG). */
+int gv_scene_parse_bson(const void* data, size_t length, const GvScenePool* pools, uint32_t pool_count, uint32_t flags,
+                        GvScene** out_scene, char* error, size_t error_capacity);
 void gv_scene_destroy(GvScene* scene);
 int gv_scene_info(const GvScene* scene, GvSceneInfo* out);
 /* The scene's columns (owned by the scene, valid until gv_scene_destroy); any out pointer may be NULL. */

@@ -186,3 +186,142 @@ def test_committed_scene_fixture():
     for k, v in zip(gold["info_keys"], gold["info"]):
         assert i[str(k)] == int(v), k
     sc.close()
+
+
+# ---- BSON: what packed builds ship (json2bson.cpp:41-66 = nlohmann::json::to_bson of the scene's JSON, "debugName" erased)
+
+def to_bson(value, strip_debug_names=True):
+    """nlohmann::json::to_bson restated for the test: doubles 0x01, strings 0x02, objects 0x03, arrays 0x04 (keys
+    "0", "1", ...), bool 0x08, null 0x0A, integers 0x10 when they fit int32 else 0x12, unsigned beyond int64 0x11."""
+    import struct
+
+    def element(key, v):
+        name = key.encode() + b"\0"
+        if isinstance(v, bool):
+            return b"\x08" + name + (b"\1" if v else b"\0")
+        if v is None:
+            return b"\x0A" + name
+        if isinstance(v, float):
+            return b"\x01" + name + struct.pack("<d", v)
+        if isinstance(v, int):
+            if -2 ** 31 <= v < 2 ** 31:
+                return b"\x10" + name + struct.pack("<i", v)
+            if v < 2 ** 63:
+                return b"\x12" + name + struct.pack("<q", v)
+            return b"\x11" + name + struct.pack("<Q", v)
+        if isinstance(v, str):
+            raw = v.encode() + b"\0"
+            return b"\x02" + name + struct.pack("<i", len(raw)) + raw
+        if isinstance(v, dict):
+            return b"\x03" + name + document(v)
+        if isinstance(v, list):
+            return b"\x04" + name + document({str(k): item for k, item in enumerate(v)})
+        raise TypeError(type(v))
+
+    def document(d):
+        body = b"".join(element(k, v) for k, v in d.items() if not (strip_debug_names and k == "debugName"))
+        return struct.pack("<i", len(body) + 5) + body + b"\0"
+
+    return document(value)
+
+
+def same_scene(a, b, pools=POOLS):
+    ta, tb = a.transform_columns(), b.transform_columns()
+    assert ta.keys() == tb.keys()
+    for k in ta:
+        x, y = np.asarray(ta[k]), np.asarray(tb[k])
+        assert x.shape == y.shape and x.tobytes() == y.tobytes(), k
+    for pid in pools.values():
+        ma, mb = a.mesh_columns(pid), b.mesh_columns(pid)
+        for k in ma:
+            assert np.asarray(ma[k]).tobytes() == np.asarray(mb[k]).tobytes(), (pid, k)
+    assert a.info() == b.info()
+
+
+@pytest.mark.parametrize("add_root", [False, True])
+@pytest.mark.parametrize("hier", [False, True])
+def test_bson_scene_equals_the_json_scene(hier, add_root):
+    """gv_scene_parse_bson(to_bson(json)) == gv_scene_parse_json(text): from_bson keeps the value categories the
+    deserializer's readers test (json-serialize.cpp:383-898), so a packed build loads the same scene."""
+    text = scene_text(3000, hier)
+    doc = json.loads(text)
+    a = Scene(text, POOLS, add_root_entity=add_root)
+    b = Scene(to_bson(doc), POOLS, add_root_entity=add_root, bson=True)
+    same_scene(a, b)
+    columns_equal_aos(b, text, add_root_entity=add_root)  # and both equal the reference loader's AoS pools
+    a.close()
+    b.close()
+
+
+def test_bson_value_categories_and_edge_cases():
+    ents = [
+        {"components": [{".type": "Transform", "uid": U[0], "position": 5, "scale": 2.5, "rotation": 1.0},   # int32: ignored
+                        {".type": "Model", "aabb": {"min": {"x": -1.0, "y": -2, "z": -3.0}, "max": 4.0}}]},
+        {"components": []},
+        {"components": [{".type": "Transform", "uid": U[1], "parent": U[0], "position": {"x": 1.5, "y": 2 ** 40, "z": 2 ** 63 + 5},
+                         "debugName": 'erased by json2bson: "quotes" \\ and \n control', "isActive": False}]},   # int64 / uint64: ignored
+        {"components": [{".type": "Sprite", "isEnabled": False, "aabb": {"min": {"x": -0.25, "y": -1e-30, "z": -3e38}, "max": {"x": 1e300, "y": 0.5, "z": 0.5}}},
+                        {".type": "Transform", "uid": U[2], "parent": U[1], "scale": {"x": 0.1, "y": 1.0000001, "z": 123456.789}}]},
+        {"components": [{".type": "Light", "color": [1.0, 0.5, None, True, "s", {"k": [1, 2.5]}]}]},
+    ]
+    doc = {"version": "0.1.0", "entities": ents, "extra": [1, {"a": None}, True, -2.5e-3, 'text "with" \\ escapes \t']}
+    text = json.dumps(doc)
+    a, b = Scene(text, POOLS), Scene(to_bson(doc), POOLS, bson=True)
+    same_scene(a, b)
+    t = b.transform_columns()
+    assert list(t["position"][0]) == [0, 0, 0] and list(t["scale"][0]) == [2.5] * 3       # integer literals did not count
+    assert list(t["position"][1]) == [1.5, 0, 0] and t["self_active"][1] == 0                # 2^40 / 2^63+5 are integers
+    assert np.isinf(b.mesh_columns(3)["aabb_max"][0][0])                                     # 1e300 -> float: +inf
+    a.close()
+    b.close()
+    # non-finite doubles exist in BSON only (JSON text cannot carry them): number_float NaN / inf reach the columns
+    doc = {"entities": [{"components": [{".type": "Transform", "uid": U[3], "position": {"x": float("nan"), "y": float("inf"), "z": float("-inf")},
+                                         "scale": float("nan")}]}]}
+    c = Scene(to_bson(doc), POOLS, bson=True)
+    t = c.transform_columns()
+    assert np.isnan(t["position"][0][0]) and t["position"][0][1] == np.inf and t["position"][0][2] == -np.inf and np.all(np.isnan(t["scale"][0]))
+    c.close()
+
+
+def test_malformed_bson_is_rejected():
+    good = to_bson({"entities": [{"components": [{".type": "Transform", "uid": U[0], "position": {"x": 1.5}}]}]})
+    Scene(good, POOLS, bson=True).close()
+    import struct
+    bad = [good[:-1], good[:10], b"", b"\x05\0\0\0", struct.pack("<i", len(good) + 7) + good[4:],       # truncated / wrong sizes
+           good.replace(b"\x01x\0", b"\x07x\0"),                                                           # ObjectId: nlohmann parse_error.114
+           good[:4] + good[4:].replace(b"\x02uid\0", b"\x02uid")]                                           # key without terminator shifts everything
+    for blob in bad:
+        with pytest.raises(GvError):
+            Scene(blob, POOLS, bson=True)
+    # every prefix and a few hundred single-byte mutations: an error or a scene, never a crash / hang
+    rng = np.random.default_rng(5)
+    for cut in range(0, len(good), 3):
+        try:
+            Scene(good[:cut], POOLS, bson=True).close()
+        except GvError:
+            pass
+    for _ in range(400):
+        blob = bytearray(good)
+        blob[int(rng.integers(len(blob)))] = int(rng.integers(256))
+        try:
+            Scene(bytes(blob), POOLS, bson=True).close()
+        except GvError:
+            pass
+
+
+def test_scene_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """gv_scene.cpp is host-only: built here with -fsanitize=address,undefined and fed every prefix and thousands of
+    byte mutations of a JSON scene and of its BSON form (tests/cpp/scene_fuzz.cpp)."""
+    import os
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "scene_fuzz")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            os.path.join(root, "tests/cpp/scene_fuzz.cpp"), os.path.join(root, "garden_amd/csrc/gv_scene.cpp"), "-o", exe],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    text = scene_text(60, True)
+    (tmp_path / "seed.json").write_text(text)
+    (tmp_path / "seed.bson").write_bytes(to_bson(json.loads(text)))
+    run = subprocess.run([exe, str(tmp_path / "seed.json"), str(tmp_path / "seed.bson")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout[-500:] + run.stderr[-3000:]
