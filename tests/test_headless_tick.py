@@ -56,6 +56,16 @@ def test_cpu_entity_churn(tick):
     assert out["draw_count"] > 0
 
 
+def test_csm_cascades_on_the_cpu_reference_path(tick):
+    """csm_lite.hpp restates CsmRenderSystem's calcLightViewProj / slice selection (csm.cpp:262-325): the binary checks
+    that every slice corner lies in its light box; here the three cascades see nested, growing parts of the scene."""
+    _, out = tick("--mode", "cpu", "--entities", "200000", "--ticks", "2", "--csm")
+    a, b, c = out["shadow_draw_counts"]
+    assert 0 < a < b < c < 200000 and out["draw_count"] > 0
+    _, out = tick("--mode", "cpu", "--entities", "20000", "--ticks", "2", "--csm", "--mixed", "--hier")
+    assert all(n > 0 for n in out["shadow_draw_counts"]) and out["sorted_draw_count"] > 0
+
+
 def test_gpu_system_fails_loudly_without_device(tick):
     import torch
     if torch.cuda.is_available():
@@ -86,6 +96,10 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "9000", "--animate", "1", "--mixed", "--ticks", "5"],
     ["--entities", "150000", "--animate", "64", "--ticks", "4"],
     ["--entities", "12000", "--animate", "5", "--hier", "--mixed", "--bounds", "--ticks", "6"],
+    # shadow passes from calcLightViewProj (csm_lite.hpp): three cascades batched with the main camera
+    ["--entities", "150000", "--csm"],
+    ["--entities", "30000", "--csm", "--mixed", "--hier", "--mutate"],
+    ["--entities", "14000", "--csm", "--animate", "2", "--ticks", "4"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
