@@ -252,7 +252,7 @@ void gv_destroy(GvCtx* ctx)
     ctx->d_xab.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
     ctx->h_xab.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
-        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
     }
     for (auto& v : ctx->views) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
@@ -262,7 +262,12 @@ void gv_destroy(GvCtx* ctx)
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
     }
-    ctx->d_world.release();
+    ctx->d_world.release(); ctx->d_raw.release(); ctx->d_examined.release();
+    for (int k = 0; k < 2; k++) {
+        ctx->h_raw[k].release();
+        if (ctx->raw_done[k])
+            (void)hipEventDestroy(ctx->raw_done[k]);
+    }
     ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
     ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
     ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release();

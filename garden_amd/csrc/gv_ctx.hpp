@@ -243,8 +243,10 @@ struct Context {
     DeviceBuf<uint32_t> d_xinv;    // slot -> mirror entry (gv_get_world, device-side gather)
     // device-side gather of dirty AoS ranges
     DeviceBuf<uint8_t> d_raw;      // raw component bytes of the dirty slot range
+    PinnedBuf<uint8_t> h_raw[2];   // the library's own pinned chunks the span travels through (double-buffered)
+    hipEvent_t raw_done[2] = {nullptr, nullptr};  // chunk buffer k may be rewritten once its last copy has run
     DirtyRange staging_stale;      // slots whose host staging entries lag behind the device (written by that path)
-    bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // turned off after a failed page-lock, or by the env
+    bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // the env switches the path off (debugging)
     // scratch of the scattered (dirty-range) host upload path
     PinnedBuf<uint32_t> sc_idx, sc_u32;
     PinnedBuf<float4> sc_a;

@@ -369,28 +369,41 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         return GV_E_STATE;
     const uint32_t count = hi - lo;
     const size_t bytes = (size_t)count * L.stride;
-    void* span = const_cast<uint8_t*>(base) + (size_t)lo * L.stride;
-    if (ctx->d_raw.reserve(bytes) != hipSuccess)
-        return GV_E_STATE;
-    bool locked_here = true;
-    const hipError_t lock = hipHostRegister(span, bytes, hipHostRegisterDefault);
-    if (lock == hipErrorHostMemoryAlreadyRegistered) {
-        (void)hipGetLastError();
-        locked_here = false;  // the caller keeps its pools in pinned memory already: copy straight from it
-    } else if (lock != hipSuccess) {
-        (void)hipGetLastError();
-        ctx->device_gather = false;  // no page-locking here (memlock limit, exotic memory): host gathers from now on
-        return GV_E_STATE;
+    const uint8_t* span = base + (size_t)lo * L.stride;
+    if (bytes > ctx->d_raw.cap) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier gather may still be reading the buffer about to go
+        if (ctx->d_raw.reserve(bytes) != hipSuccess)
+            return GV_E_STATE;
     }
-    hipError_t e = hipMemcpyAsync(ctx->d_raw.ptr, span, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-        e = launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xab.ptr,
-                                  ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream);
-    const hipError_t e2 = hipStreamSynchronize(ctx->stream);  // the span is unlocked (and may be freed by its owner) after this
-    if (locked_here)
-        (void)hipHostUnregister(span);
-    if (e != hipSuccess || e2 != hipSuccess)
-        return ctx->fail(GV_E_HIP, "device-side transform gather: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    // The caller's (pageable) span travels through two pinned chunks of the library's own: worker threads copy chunk k
+    // while chunk k-1 is on the wire. The caller's memory is never page-locked: transient hipHostRegister /
+    // hipHostUnregister of application memory was faster to write (and as fast to run) but left this stack aborting in
+    // LATER pageable copies that touched the same addresses (3 of 10 runs of the GPU suite; 0 of 10 without it).
+    constexpr size_t kChunkBytes = (size_t)8 << 20;
+    const size_t chunk_cap = std::min(bytes, kChunkBytes);
+    for (int k = 0; k < 2; k++) {
+        if (!ctx->raw_done[k])
+            GV_HIP(ctx, hipEventCreateWithFlags(&ctx->raw_done[k], hipEventDisableTiming));
+        if (chunk_cap > ctx->h_raw[k].cap) {
+            GV_HIP(ctx, hipEventSynchronize(ctx->raw_done[k]));
+            GV_HIP(ctx, ctx->h_raw[k].reserve(chunk_cap));
+        }
+    }
+    uint32_t turn = 0;
+    for (size_t off = 0; off < bytes; off += kChunkBytes, turn ^= 1u) {
+        const size_t n = std::min(kChunkBytes, bytes - off);
+        GV_HIP(ctx, hipEventSynchronize(ctx->raw_done[turn]));  // (a never-recorded event is complete)
+        uint8_t* stage = ctx->h_raw[turn].ptr;
+        const uint8_t* src = span + off;
+        parallel_ranges(0, (uint32_t)((n + 63) / 64), [&](uint32_t a, uint32_t b) {  // 64-byte items: 128 Ki of them = 8 MB
+            const size_t lo_b = (size_t)a * 64, hi_b = std::min(n, (size_t)b * 64);
+            memcpy(stage + lo_b, src + lo_b, hi_b - lo_b);
+        });
+        GV_HIP(ctx, hipMemcpyAsync(ctx->d_raw.ptr + off, stage, n, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipEventRecord(ctx->raw_done[turn], ctx->stream));
+    }
+    GV_HIP(ctx, launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xab.ptr,
+                                      ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream));
     ctx->staging_stale.add(lo, count);
     ctx->stats.upload_bytes += bytes;
     return GV_OK;

@@ -4,6 +4,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <new>
+#include <pthread.h>
 #include <vector>
 
 namespace gv {
@@ -86,9 +88,26 @@ struct WorkerPool {
     }
 };
 
+std::atomic<WorkerPool*> g_pool{nullptr};
+std::mutex g_pool_lock;
+
+// A forked child inherits the pool object but none of its threads: start over with a fresh one on first use (the
+// old object is leaked; its mutexes may have been held by threads that do not exist here).
+void forget_pool_in_child() { g_pool.store(nullptr, std::memory_order_release); new (&g_pool_lock) std::mutex(); }
+
 WorkerPool& pool()
 {
-    static WorkerPool* p = new WorkerPool();  // never destroyed: its threads are parked on it until the process exits
+    WorkerPool* p = g_pool.load(std::memory_order_acquire);
+    if (!p) {
+        std::lock_guard<std::mutex> lock(g_pool_lock);
+        p = g_pool.load(std::memory_order_relaxed);
+        if (!p) {
+            static const int registered = pthread_atfork(nullptr, nullptr, forget_pool_in_child);
+            (void)registered;
+            p = new WorkerPool();  // never destroyed: its threads are parked on it until the process exits
+            g_pool.store(p, std::memory_order_release);
+        }
+    }
     return *p;
 }
 

@@ -8,6 +8,9 @@
 #include <thread>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 int main()
 {
     int failures = 0;
@@ -62,6 +65,23 @@ int main()
     for (auto& t : callers)
         t.join();
     failures += bad.load();
+    // 4. a forked child has no worker threads: the pool must start over there instead of waiting for them
+    {
+        const pid_t child = fork();
+        if (child == 0) {
+            std::atomic<uint64_t> sum{0};
+            gv::run_parts(6, [&](uint32_t part) { sum += part + 1; });
+            _exit(sum.load() == 21 ? 0 : 1);
+        }
+        int status = 0;
+        alarm(60);
+        waitpid(child, &status, 0);
+        alarm(0);
+        if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            printf("forked child: status %d\n", status);
+            failures++;
+        }
+    }
     printf("{\"ok\": %s, \"failures\": %d}\n", failures == 0 ? "true" : "false", failures);
     return failures == 0 ? 0 : 1;
 }

@@ -189,6 +189,7 @@ def test_worker_pool_under_thread_sanitizer(tmp_path):
                             os.path.join(root, "tests/cpp/workers_test.cpp"), os.path.join(root, "garden_amd/csrc/gv_workers.cpp"),
                             "-o", exe], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # the fork section starts threads in a child of a multi-threaded process, which TSan refuses by default
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="die_after_fork=0"))
     assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr
     assert "ThreadSanitizer" not in run.stderr, run.stderr
