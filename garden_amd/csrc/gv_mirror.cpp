@@ -377,7 +377,7 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
     }
     // The caller's (pageable) span travels through two pinned chunks of the library's own: worker threads copy chunk k
     // while chunk k-1 is on the wire. The caller's memory is never page-locked: transient hipHostRegister /
-    // hipHostUnregister of application memory was faster to write (and as fast to run) but left this stack aborting in
+    // hipHostUnregister of application memory was a third faster but left this stack aborting in
     // LATER pageable copies that touched the same addresses (3 of 10 runs of the GPU suite; 0 of 10 without it).
     constexpr size_t kChunkBytes = (size_t)8 << 20;
     const size_t chunk_cap = std::min(bytes, kChunkBytes);
