@@ -375,12 +375,13 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         if (ctx->d_raw.reserve(bytes) != hipSuccess)
             return GV_E_STATE;
     }
-    // The caller's (pageable) span travels through two pinned chunks of the library's own: worker threads copy chunk k
+    // The caller's (pageable) span travels through two pinned chunks of the library's own: worker threads fill chunk k
     // while chunk k-1 is on the wire. The caller's memory is never page-locked: transient hipHostRegister /
     // hipHostUnregister of application memory was a third faster but left this stack aborting in
     // LATER pageable copies that touched the same addresses (3 of 10 runs of the GPU suite; 0 of 10 without it).
-    constexpr size_t kChunkBytes = (size_t)8 << 20;
-    const size_t chunk_cap = std::min(bytes, kChunkBytes);
+    // chunk size: at least four chunks so that copying into a chunk overlaps the previous one's DMA, 1 .. 32 MB each
+    const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)1 << 20, ((bytes / 4 + 65535) >> 16) << 16));
+    const size_t chunk_cap = std::min(bytes, chunk_bytes);
     for (int k = 0; k < 2; k++) {
         if (!ctx->raw_done[k])
             GV_HIP(ctx, hipEventCreateWithFlags(&ctx->raw_done[k], hipEventDisableTiming));
@@ -390,14 +391,17 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         }
     }
     uint32_t turn = 0;
-    for (size_t off = 0; off < bytes; off += kChunkBytes, turn ^= 1u) {
-        const size_t n = std::min(kChunkBytes, bytes - off);
+    for (size_t off = 0; off < bytes; off += chunk_bytes, turn ^= 1u) {
+        const size_t n = std::min(chunk_bytes, bytes - off);
         GV_HIP(ctx, hipEventSynchronize(ctx->raw_done[turn]));  // (a never-recorded event is complete)
         uint8_t* stage = ctx->h_raw[turn].ptr;
         const uint8_t* src = span + off;
-        parallel_ranges(0, (uint32_t)((n + 63) / 64), [&](uint32_t a, uint32_t b) {  // 64-byte items: 128 Ki of them = 8 MB
-            const size_t lo_b = (size_t)a * 64, hi_b = std::min(n, (size_t)b * 64);
-            memcpy(stage + lo_b, src + lo_b, hi_b - lo_b);
+        const uint32_t parts = n >= ((size_t)1 << 20) ? worker_parts((size_t)1 << 30) : 1u;  // workers from 1 MB up
+        const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+        run_parts(parts, [&](uint32_t t) {
+            const size_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+            if (a < b)
+                memcpy(stage + a, src + a, b - a);
         });
         GV_HIP(ctx, hipMemcpyAsync(ctx->d_raw.ptr + off, stage, n, hipMemcpyHostToDevice, ctx->stream));
         GV_HIP(ctx, hipEventRecord(ctx->raw_done[turn], ctx->stream));
