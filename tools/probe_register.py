@@ -1,5 +1,7 @@
 """Probe: can caller-owned pageable memory be page-locked (hipHostRegister) on this box, and what does H2D run at
-from pageable / registered / hipHostMalloc'd memory? Dev tool."""
+from pageable / registered / hipHostMalloc'd memory? Dev tool. (History: the library once registered the caller's
+dirty span in place on the strength of these numbers; that was withdrawn — later pageable copies over the same
+addresses aborted intermittently — and the span now travels through the library's own pinned chunks)"""
 import ctypes as C, time, numpy as np, sys
 hip = C.CDLL("libamdhip64.so")
 n = 800 << 20
