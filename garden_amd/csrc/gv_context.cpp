@@ -684,6 +684,12 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
                 if (w.main_pass) {
                     GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
                     a.host_is_visible = w.h_is_visible.ptr;
+                    if (permuted && w.occupancy > kPublishLdsSlots) {  // too large for the in-LDS un-permutation
+                        GV_HIP(ctx, w.is_visible_slots.reserve(w.occupancy));
+                        GV_HIP(ctx, launch_unpermute_bytes(w.is_visible.ptr, pool.d_orig.ptr, w.occupancy, w.is_visible_slots.ptr, ctx->stream));
+                        a.is_visible = w.is_visible_slots.ptr;
+                        a.orig = nullptr;
+                    }
                 }
                 a.occupancy = w.occupancy;
                 sent[views++] = &w;

@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
         // kPublishMaxSlots bytes) and writes them out as whole words — no scattered single-byte stores over PCIe
         if (blockIdx.x != 0)
             return;
-        __shared__ uint8_t slots[(kPublishMaxSlots + 3u) & ~3u];
+        __shared__ uint8_t slots[(kPublishLdsSlots + 3u) & ~3u];
         for (uint32_t j = threadIdx.x; j < a.occupancy; j += 256)
             slots[a.orig[j]] = a.is_visible[j];
         __syncthreads();
@@ -858,7 +858,7 @@ hipError_t launch_unpermute_bytes(const uint8_t* src, const uint32_t* orig, uint
 
 hipError_t launch_publish(const PublishBatch& batch, uint32_t views, uint32_t occupancy, hipStream_t stream)
 {
-    const uint32_t blocks = std::max(1u, std::min(64u, (occupancy + 255u) / 256u));
+    const uint32_t blocks = std::max(1u, std::min(256u, (occupancy + 255u) / 256u));
     hipLaunchKernelGGL(publish_kernel, dim3(blocks, views), dim3(256), 0, stream, batch);
     return hipGetLastError();
 }

@@ -118,8 +118,10 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
                            hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                              hipStream_t stream);
-// gv_results_fetch of a small pool (occupancy <= kPublishMaxSlots): device results -> pinned host buffers in one launch
-constexpr uint32_t kPublishMaxSlots = 16384;
+// gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
+// (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
+constexpr uint32_t kPublishMaxSlots = 262144;
+constexpr uint32_t kPublishLdsSlots = 16384;
 struct PublishArgs {
     const uint32_t* count;  // device draw_count
     const uint32_t* idx;
