@@ -162,6 +162,15 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout. Libraries underneath (RCCL prints a version banner when a communicator
+    # is created) write to file descriptor 1 too, so everything but the result lines is sent to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -342,7 +351,7 @@ def main():
                               outputs_identical_to_headline=same)
         vb.close()
         if not same:
-            print(json.dumps({"error": "block-bounds variant differs from the linear scan", "variant": bounds_variant}))
+            emit({"error": "block-bounds variant differs from the linear scan", "variant": bounds_variant})
             sys.exit(1)
 
     visible = got["draw_count"]
@@ -367,7 +376,7 @@ def main():
             parity = dict(visible_set_bit_identical=same_set, is_visible_identical=same_vis,
                           baked_model_bit_identical=same_mat, visible=int(visible), checked_entities=int(n))
             if not (same_set and same_vis):
-                print(json.dumps({"error": "visible set differs from the CPU oracle", "parity": parity}))
+                emit({"error": "visible set differs from the CPU oracle", "parity": parity})
                 sys.exit(1)
 
     if rank == 0:
@@ -415,7 +424,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, sc, view, depth)
-        print(json.dumps(out))
+        emit(out)
     vis.close()
     if exchange:
         dist.barrier()
