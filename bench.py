@@ -8,7 +8,12 @@ A "step" is one frame of the hot path over one batch of resident component pools
   cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep fused with the frustum cull (one pass) + compaction
         (--sweep mfma|valu: separate sweep and cull launches; fused-valu: the fused pass with the v_fma chain)
 For N > 1 each rank owns one spatial tile (same per-GPU entity count: weak scaling), culls it against the
-same view and the ranks all-gatherv the compacted global visible-index lists over RCCL (cfg5 pattern).
+same view and the ranks all-gatherv the compacted global visible-index lists over RCCL (cfg5 pattern); the default
+workload is then cfg5 (12.5M per GPU, frustum-only + the exchange), for N = 1 it is cfg3.
+
+`python bench.py --gpus N` without a torch.distributed environment (WORLD_SIZE unset) starts the N ranks itself, as
+fresh child processes (python -m torch.distributed.run ... bench.py <same arguments>) BEFORE anything here touches the
+GPU, and relays their one JSON line and exit code.
 
 Inputs are resident in HBM before the timed region; outputs stay on the device (only a 4-byte count is
 read back per frame). Prints ONE JSON line on rank 0.
@@ -25,7 +30,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-MEASURED_STREAM_PEAK_GBS = 7134.0  # read-only kernel over the cull kernel's five streams, nontemporal loads (profiles/r01b_kbench.txt)
+# sources whose hash identifies the dominant kernel's code: profiles/traffic.json records it at PMC-collection time and
+# roofline.traffic is only reported while it still matches (a stale counter figure is worse than none)
+KERNEL_SOURCES = ["garden_amd/csrc/gv_cull.hip", "garden_amd/csrc/gv_device.hpp", "garden_amd/csrc/gv_device_math.hpp",
+                  "garden_amd/csrc/gv_sweep.hip", "garden_amd/csrc/gv_kernels.hpp"]
+
+
+def kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 WORKLOADS = {
     "cfg2": dict(entities=1_000_000, hier=False, hiz=False, sweep=False,
@@ -40,15 +57,6 @@ WORKLOADS = {
 HIZ_SIZE = 4096
 
 
-def tile_grid(n):
-    g = [1, 1, 1]
-    i = 0
-    while g[0] * g[1] * g[2] < n:
-        g[i % 3] *= 2
-        i += 1
-    return g
-
-
 def make_tile_scene(wl, n_local, rank, world):
     """Rank `rank`'s spatial tile of the world cube (side 100 * N_total^(1/3)); camera at the world centre."""
     from garden_amd import scene
@@ -56,6 +64,7 @@ def make_tile_scene(wl, n_local, rank, world):
     if world > 1:
         side = 100.0 * (n_local * world) ** (1.0 / 3.0)
         local_side = 100.0 * n_local ** (1.0 / 3.0)
+        from garden_amd.multi import tile_grid
         g = tile_grid(world)
         cell = [rank % g[0], (rank // g[0]) % g[1], rank // (g[0] * g[1])]
         roots = sc.transforms["parent"] == 0
@@ -89,43 +98,42 @@ def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False, exa
     return dict(cull=cull, emit=emit, hiz=float(hiz), sweep=sweep)
 
 
-def cpu_baseline(wl, sc, view, depth, seconds=12.0):
-    """The AVX2+FMA CPU path (oracle/gv_oracle_avx2.c: 8 entities per iteration over an SoA copy of the pools,
-    bit-identical to the scalar restatement of mesh.cpp:111-184 + transform.hpp:197-214; pyramid by the scalar
-    hiz.frag restatement), threaded with the ThreadPool::addItems range split over all host cores, on a bounded
-    sample of the same workload. A reported baseline, not the optimisation target."""
+def cpu_baseline(wl, sc, view, depth, seconds=10.0):
+    """The CPU path on this box's host cores, same frame as the GPU step, over the WHOLE pool: AVX2+FMA cull
+    (oracle/gv_oracle_avx2.c: 8 entities per iteration over an SoA copy of the pools, bit-identical to the scalar
+    restatement of mesh.cpp:111-184 + transform.hpp:197-214), the pyramid by the scalar hiz.frag restatement and (cfg4)
+    the scalar world-matrix sweep, each threaded with the ThreadPool::addItems range split over all host cores. The
+    stages are timed separately and summed: `value` = entities / (pyramid + sweep + cull) per frame. A reported
+    baseline, not the optimisation target."""
     from oracle import oracle_py
     cores = os.cpu_count() or 1
-    sample_n = min(sc.count, 2_000_000)
-    meshes = sc.meshes[:sample_n].copy()
-    if wl["hier"]:
-        transforms, e2t = sc.transforms, sc.entity_to_transform  # chains may reach any slot
-    else:
-        transforms, e2t = sc.transforms[:sample_n], sc.entity_to_transform
+    n = sc.count
+    meshes, transforms, e2t = sc.meshes.copy(), sc.transforms, sc.entity_to_transform
     soa = oracle_py.Avx2Scene(meshes, transforms, e2t)
+    hz = oracle_py.Hiz(depth, threads=cores) if wl["hiz"] else None
+    world = np.empty((n, 12), dtype=np.float32) if wl["sweep"] else None
 
-    def timed(run, seconds):
+    def timed(run, seconds, min_frames=2):
+        run()  # untimed: first touch of the output arrays, worker threads started
         frames, t0 = 0, time.perf_counter()
         while True:
             run()
             frames += 1
             dt = time.perf_counter() - t0
-            if dt >= seconds and frames >= 2:
-                return frames, dt
+            if dt >= seconds and frames >= min_frames:
+                return dt / frames, frames
 
-    def frame(threads, avx2):
-        hz = oracle_py.Hiz(depth) if wl["hiz"] else None
-        if wl["sweep"]:
-            oracle_py.world_matrices(transforms, e2t, 0, sample_n)
-        if avx2:
-            soa.prepare_meshes(view, hiz=hz, threads=threads)
-        else:
-            oracle_py.prepare_meshes(meshes, transforms, e2t, view, hiz=hz, threads=threads)
-
-    frames, dt = timed(lambda: frame(cores, True), seconds)
+    share = seconds / (1 + (1 if wl["hiz"] else 0) + (1 if wl["sweep"] else 0))
+    cull_s, cull_frames = timed(lambda: soa.prepare_meshes(view, hiz=hz, threads=cores), share)
+    pyramid_s = pyramid_1t_s = sweep_s = 0.0
+    if wl["hiz"]:
+        pyramid_s, _ = timed(lambda: hz.rebuild(cores), share)
+        pyramid_1t_s, _ = timed(lambda: hz.rebuild(1), 0.5, 1)
+    if wl["sweep"]:
+        sweep_s, _ = timed(lambda: oracle_py.world_matrices(transforms, e2t, 0, n, threads=cores, out=world), share)
     # BASELINE.md §3: also one thread, and the scalar loop over the reference's AoS layouts (short samples)
-    f1, d1 = timed(lambda: frame(1, True), 3.0)
-    fa, da = timed(lambda: frame(cores, False), 3.0)
+    cull_1t_s, _ = timed(lambda: soa.prepare_meshes(view, hiz=hz, threads=1), 2.0, 1)
+    scalar_s, _ = timed(lambda: oracle_py.prepare_meshes(meshes, transforms, e2t, view, hiz=hz, threads=cores), 2.0, 1)
     soa.close()
     model = "unknown"
     try:
@@ -135,14 +143,36 @@ def cpu_baseline(wl, sc, view, depth, seconds=12.0):
                 break
     except OSError:
         pass
-    return dict(value=sample_n * frames / dt, unit="entity culls/s", cores=cores, kind="port",
-                sample=f"{frames} frames of the first {sample_n} entities of the same scene/view"
-                       f"{' incl. 4096^2 pyramid build per frame' if wl['hiz'] else ''}"
-                       f"{' incl. scalar world-matrix sweep' if wl['sweep'] else ''}, AVX2+FMA 8-wide SoA path "
-                       f"(bit-identical to the scalar oracle), {cores} threads split like ThreadPool::addItems, {dt:.1f} s",
+    frame_s = cull_s + pyramid_s + sweep_s
+    return dict(value=n / frame_s, unit="entity culls/s", cores=cores, kind="port",
+                sample=f"all {n} entities of the same scene/view; per frame: "
+                       f"{'4096^2 pyramid build (scalar hiz.frag restatement, rows split over the threads) + ' if wl['hiz'] else ''}"
+                       f"{'scalar world-matrix sweep (slot ranges split over the threads) + ' if wl['sweep'] else ''}"
+                       f"AVX2+FMA 8-wide SoA cull (bit-identical to the scalar oracle), {cores} threads split like "
+                       f"ThreadPool::addItems; stages timed separately ({cull_frames} cull frames) and summed",
                 cpu_model=model, nproc=cores,
-                avx2_soa_1_thread=sample_n * f1 / d1,
-                scalar_aos_all_threads=sample_n * fa / da)
+                frame_ms=frame_s * 1e3, cull_ms=cull_s * 1e3, pyramid_ms=pyramid_s * 1e3, sweep_ms=sweep_s * 1e3,
+                cull_culls_per_s=n / cull_s,
+                pyramid_1_thread_ms=pyramid_1t_s * 1e3,
+                avx2_soa_cull_1_thread_culls_per_s=n / cull_1t_s,
+                scalar_aos_cull_all_threads_culls_per_s=n / scalar_s)
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` outside a torch.distributed launch: start the N ranks as a fresh child job. Nothing in this
+    process has touched the GPU yet (no torch import, no HIP call), and the child is a child — never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -150,7 +180,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: cfg3 on one GPU, cfg5 (12.5M entities per GPU, frustum-only + exchange) on several")
     ap.add_argument("--entities", type=int, default=0, help="per-GPU entity count override")
     ap.add_argument("--sweep", default="fused", choices=["mfma", "valu", "fused", "fused-valu"],
                     help="cfg4 world-matrix sweep form; fused = MFMA sweep and cull in one pass (GV_SWEEP_WITH_CULL)")
@@ -158,9 +189,27 @@ def main():
     ap.add_argument("--block-bounds", action="store_true",
                     help="GV_CONFIG_BLOCK_BOUNDS: conservative workgroup-level frustum rejection (same results); the "
                          "roofline numerator then counts the streams of examined workgroups only")
+    ap.add_argument("--exchange", default=os.environ.get("GV_BENCH_EXCHANGE_MODE", "allgather"),
+                    choices=["allgather", "p2p", "broadcast"],
+                    help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
+                         "send/recv to every peer, or one broadcast per root (A/B for the fully connected xGMI node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # ---- launch shape, checked before torch is imported or the GPU is touched ----
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                                   f"torch.distributed.run --nproc-per-node {args.gpus}, or run plain "
+                                   f"`python bench.py --gpus {args.gpus}` (it starts the ranks itself)"}), flush=True)
+        sys.exit(2)
+    if args.workload is None:
+        args.workload = "cfg5" if args.gpus > 1 else "cfg3"
 
     # The contract is ONE JSON line on stdout. Libraries underneath (RCCL prints a version banner when a communicator
     # is created) write to file descriptor 1 too, so everything but the result lines is sent to stderr.
@@ -195,7 +244,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    def leave(code):
+        """Every rank leaves through here, together."""
+        if exchange:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(code)
+
+    def all_agree(ok):
+        """False on every rank when any rank reports a failure (so that nobody is left waiting in a barrier)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) == 0
 
     from garden_amd import scene
     from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
@@ -219,6 +285,7 @@ def main():
     upload_s = time.perf_counter() - t_up
     if wl["hiz"]:
         vis.hiz_build(depth)
+    lib_stream = torch.cuda.ExternalStream(vis.stream(), device=torch.device("cuda", local_rank))
 
     idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if exchange else None
     ex = [None]  # VisibleListExchange, created once the shard capacity is known (first, exact exchange)
@@ -232,8 +299,8 @@ def main():
 
     def step():
         """One frame. With an exchange: the tile's list goes out as a fixed-capacity shard [count, indices...] and all
-        ranks gather the shards with one equal-size all-gather enqueued behind the library's stream — no host
-        synchronisation, so the next frame is culled while this one's list is still on the links."""
+        ranks gather the shards (one equal-size all-gather, or the --exchange alternative) enqueued behind the library's
+        stream — no host synchronisation, so the next frame is culled while this one's list is still on the links."""
         compute()
         if ex[0] is not None:
             shard = ex[0].next_shard()
@@ -250,58 +317,96 @@ def main():
         gathered, counts = allgatherv_indices(idx_buf, count, dist)
         g = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         c = counts.cpu().numpy()
-        assert g.shape[0] == int(c.sum())
+        problem = None
+        if g.shape[0] != int(c.sum()):
+            problem = "gathered length differs from the sum of the counts"
         off = 0
         for r in range(world):
             part = g[off:off + int(c[r])]
-            assert part.size == 0 or (part.min() >= r * n and part.max() < (r + 1) * n), f"rank {r} indices out of its tile"
+            if part.size and not (part.min() >= r * n and part.max() < (r + 1) * n):
+                problem = f"rank {r} indices out of its tile"
             if r == rank:
                 mine = vis.fetch(0, write_back=False, occupancy=n)["visible_idx"].astype(np.int64) + rank * n
-                assert np.array_equal(np.sort(part), mine), "own shard differs from the local visible list"
+                if not np.array_equal(np.sort(part), mine):
+                    problem = "own shard differs from the local visible list"
             off += int(c[r])
-        return g, c
+        return g, c, problem
 
     def check_padded(padded, exact, exact_counts):
         """The per-frame padded exchange delivered the same lists as the exact one (static scene)."""
         ex[0].drain()  # raises if any frame of the run overflowed its shard
         dense, counts = ex[0].compact(padded)
         d = dense.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-        assert np.array_equal(counts.numpy(), exact_counts), "padded exchange: counts differ from the exact all-gatherv"
-        assert np.array_equal(d, exact), "padded exchange: lists differ from the exact all-gatherv"
+        if not np.array_equal(counts.numpy(), exact_counts):
+            return "padded exchange: counts differ from the exact all-gatherv"
+        if not np.array_equal(d, exact):
+            return "padded exchange: lists differ from the exact all-gatherv"
+        return None
 
     def fence():
         if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(run, steps):
+        """Wall clock over `steps` frames between two fences (the contract's number) + one event per frame boundary on
+        the library's stream (K + 1 records: the per-frame durations behind the median)."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        marks[0].record(lib_stream)
+        for k in range(steps):
+            last = run()
+            marks[k + 1].record(lib_stream)
+        fence()
+        elapsed = time.perf_counter() - t0
+        per = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(steps)], dtype=np.float64)  # ms
+        return elapsed, per, last
+
     gathered_total = None
     if exchange:
-        exact, exact_counts = check_exchange()
+        exact, exact_counts, problem = check_exchange()
+        if not all_agree(problem is None):
+            if rank == 0:
+                emit({"error": "exchange check failed", "detail": problem})
+            leave(1)
         gathered_total = int(exact_counts.sum())
-        producer = torch.cuda.ExternalStream(vis.stream(), device=torch.device("cuda", local_rank)) if backend == "nccl" else None
-        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", shard_capacity(int(exact_counts.max())), stream=producer)
+        producer = lib_stream if backend == "nccl" else None
+        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", shard_capacity(int(exact_counts.max())), stream=producer,
+                                    mode=args.exchange)
     for _ in range(args.warmup):
         step()
     fence()
     upload_bytes = vis.stats()["upload_bytes"]
     vis.stats_reset()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if exchange:
-        check_padded(last, exact, exact_counts)
+    elapsed, per_step_ms, last = timed_steps(step, args.steps)
+    st = vis.stats()
+    problem = check_padded(last, exact, exact_counts) if exchange else None
+    if not all_agree(problem is None):
+        if rank == 0:
+            emit({"error": "exchange check failed", "detail": problem})
+        leave(1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    st = vis.stats()
+
+    # N > 1: the same frames without the exchange step (same ranks, same run): what the collective costs
+    no_exchange = None
+    if world > 1:
+        for _ in range(3):
+            compute()
+        e2, per2, _ = timed_steps(compute, args.steps)
+        t = torch.tensor([e2], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        no_exchange = dict(ms_per_step=float(t.item()) / args.steps * 1e3, value=n * world * args.steps / float(t.item()),
+                           ms_per_step_median_rank0=float(np.median(per2)))
 
     # SURVEY.md §8d: also report the rate when every TRS is re-uploaded each frame (host AoS -> mirror gather + PCIe
     # + cull). Outside the timed region; never `value`.
     dirty_rate = None
+    stream_peak = None
     if world == 1:
         from garden_amd.lib import GV_DIRTY_TRANSFORM
         frames, t1 = 3, time.perf_counter()
@@ -310,6 +415,9 @@ def main():
             compute()
         vis.wait()
         dirty_rate = n * frames / (time.perf_counter() - t1)
+    if rank == 0:
+        # this box's read-stream peak on the cull kernel's own access pattern (five streams, 65 B per entity)
+        stream_peak = vis.stream_peak(0, 20)
 
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
@@ -352,11 +460,12 @@ def main():
         vb.close()
         if not same:
             emit({"error": "block-bounds variant differs from the linear scan", "variant": bounds_variant})
-            sys.exit(1)
+            leave(1)
 
     visible = got["draw_count"]
     parity = None
     survivors = visible
+    parity_ok = True
     if rank == 0:
         from oracle import oracle_py
         cores = os.cpu_count() or 1
@@ -368,16 +477,20 @@ def main():
         if not args.no_parity:
             m2 = sc.meshes.copy()
             exp = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view,
-                                           hiz=oracle_py.Hiz(depth) if wl["hiz"] else None, threads=threads)
+                                           hiz=oracle_py.Hiz(depth, threads=threads) if wl["hiz"] else None, threads=threads)
             order = np.argsort(exp["visible_idx"], kind="stable")
             same_set = bool(np.array_equal(got["visible_idx"], exp["visible_idx"][order]))
             same_vis = bool(np.array_equal(got["is_visible"], m2["isVisible"]))
-            same_mat = bool(np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
+            same_mat = same_set and bool(np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
             parity = dict(visible_set_bit_identical=same_set, is_visible_identical=same_vis,
-                          baked_model_bit_identical=same_mat, visible=int(visible), checked_entities=int(n))
-            if not (same_set and same_vis):
-                emit({"error": "visible set differs from the CPU oracle", "parity": parity})
-                sys.exit(1)
+                          baked_model_bit_identical=same_mat, visible=int(visible), checked_entities=int(n),
+                          checked_rank=0)
+            parity_ok = same_set and same_vis and same_mat
+    if not all_agree(parity_ok):
+        if rank == 0:
+            emit({"error": "results differ from the CPU oracle", "parity": parity})
+        vis.close()
+        leave(1)
 
     if rank == 0:
         fused = wl["sweep"] and args.sweep.startswith("fused")
@@ -388,13 +501,29 @@ def main():
         launches = max(1, st["launches"]["cull"])
         cull_ms = st["device_ms"]["cull"] / launches
         achieved = ab["cull"] / (cull_ms * 1e-3) / 1e9 if cull_ms > 0 else 0.0
-        traffic = None
+        # roofline.traffic: PMC bytes of this kernel from profiles/traffic.json — only while the kernel sources still
+        # hash to what they were when the counters were collected
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("cull_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                key = {"cfg5": "cfg2_at_10M", "cfg2": "cfg2_at_10M"}.get(args.workload, args.workload)
+                entry = tj.get(key, {})
+                now = kernel_source_sha()
+                traffic_source = {"file": "profiles/traffic.json", "entry": key, "collected": tj.get("_collected"),
+                                  "kernel_source_sha_at_collection": tj.get("_kernel_source_sha"),
+                                  "kernel_source_sha_now": now,
+                                  "per_entity_scaled": False}
+                if tj.get("_kernel_source_sha") == now and not args.block_bounds and "cull_kernel_hbm_bytes_per_launch" in entry:
+                    traffic = entry["cull_kernel_hbm_bytes_per_launch"]
+                    measured_n = entry.get("entities", 10_000_000)
+                    if measured_n != n:  # counters were taken at another pool size of the same streaming kernel
+                        traffic = traffic * n / measured_n
+                        traffic_source["per_entity_scaled"] = True
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
+        median_ms = float(np.median(per_step_ms))
         out = {
             "metric": "entity culls/sec at 10M entities; visible-set bit-match vs CPU ref",
             "value": n * world * args.steps / elapsed,
@@ -403,32 +532,36 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # per-frame durations from one hipEvent per frame boundary on the library's stream (rank 0)
+            "ms_per_step_median": median_ms, "ms_per_step_min": float(per_step_ms.min()), "ms_per_step_max": float(per_step_ms.max()),
+            "value_at_median_step": n * world / (median_ms * 1e-3),
             "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None,
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
                        "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
-                       "exchange": (f"per frame: one equal-size all-gather of padded shards [count, uint32 indices...] "
-                                    f"(capacity {ex[0].capacity}) behind the cull stream, no host sync ({backend}); "
+                       "exchange": (f"per frame: padded shards [count, uint32 indices...] (capacity {ex[0].capacity}) travel by "
+                                    f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
+                       "exchange_mode": args.exchange if exchange else None,
+                       "same_frames_without_exchange": no_exchange,
                        # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
                        "kernel_ms": {k: (st["device_ms"][k] / max(1, args.steps)) for k in st["device_ms"] if st["device_ms"][k] > 0},
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes,
                        "culls_per_s_with_full_trs_upload_each_frame": dirty_rate},
             "roofline": {"bound": "hbm", "kernel": ("gv::sweep_cull_mfma_kernel" if args.sweep == "fused" else "gv::sweep_cull_valu_kernel") if fused else "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab["cull"], "avg_launch_ms": cull_ms,
-                         # SURVEY.md §8d asks for both peaks: the vendor figure above and what a read-only kernel with this
-                         # kernel's five streams reaches on the box (tools/kbench.hip, profiles/r01b_kbench.txt: 7134 GB/s)
-                         "measured_stream_peak": MEASURED_STREAM_PEAK_GBS, "frac_of_measured_peak": achieved / MEASURED_STREAM_PEAK_GBS},
+                         # SURVEY.md §8d asks for both peaks: the vendor figure above and what a read-only kernel over this
+                         # kernel's five streams reaches on THIS box, measured in this run (gv_debug_stream_peak)
+                         "measured_stream_peak": stream_peak,
+                         "frac_of_measured_peak": (achieved / stream_peak) if stream_peak else None},
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, sc, view, depth)
         emit(out)
     vis.close()
-    if exchange:
-        dist.barrier()
-        dist.destroy_process_group()
+    leave(0)
 
 
 if __name__ == "__main__":

@@ -252,7 +252,7 @@ void gv_destroy(GvCtx* ctx)
     ctx->d_xab.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
     ctx->h_xab.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
-        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
     }
     for (auto& v : ctx->views) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
@@ -781,8 +781,9 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
         return rc;
     ViewState& vs = ctx->views[view_index];
     GV_HIP(ctx, hipSetDevice(ctx->device));
+    const PoolState& pool = ctx->pools[vs.pool_id];
     GV_HIP(ctx, launch_copy_idx(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
-                                index_base, ctx->stream));
+                                index_base, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr, ctx->stream));
     return GV_OK;
 }
 
@@ -797,8 +798,26 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
         return rc;
     ViewState& vs = ctx->views[view_index];
     GV_HIP(ctx, hipSetDevice(ctx->device));
+    const PoolState& pool = ctx->pools[vs.pool_id];
     GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
-                                  index_base, ctx->stream));
+                                  index_base, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr, ctx->stream));
+    return GV_OK;
+}
+
+int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || (count && !global_ids))
+        return ctx->fail(GV_E_ARG, "gv_pool_set_index_map: bad argument (pool %u)", pool_id);
+    PoolState& p = ctx->pools[pool_id];
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (count) {
+        GV_HIP(ctx, p.d_index_map.reserve(count));
+        GV_HIP(ctx, hipMemcpyAsync(p.d_index_map.ptr, global_ids, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's (pageable) table may go away
+    }
+    p.index_map_count = count;
     return GV_OK;
 }
 
@@ -1041,6 +1060,53 @@ int gv_stats_reset(GvCtx* ctx)
     memset(ctx->stats.device_ms, 0, sizeof(ctx->stats.device_ms));
     ctx->stats.upload_bytes = 0;
     ctx->bounds_blocks_total = 0;
+    return GV_OK;
+}
+
+int gv_debug_stream_peak(GvCtx* ctx, uint32_t pool_id, uint32_t launches, double* gb_per_s)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !gb_per_s || launches == 0 || launches > 1000)
+        return ctx->fail(GV_E_ARG, "gv_debug_stream_peak: bad argument");
+    PoolState& p = ctx->pools[pool_id];
+    if (!p.bound || !ctx->xf.bound)
+        return ctx->fail(GV_E_STATE, "gv_debug_stream_peak: pools not bound");
+    if (int rc = sync_mirror(ctx))
+        return rc;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.occupancy, p.mapping, nullptr};
+    const TransformMirror xf = xf_mirror(ctx);
+    const uint32_t n = std::min(mesh.count, xf.count);
+    *gb_per_s = 0.0;
+    if (n == 0)
+        return GV_OK;
+    GV_HIP(ctx, ctx->dsc_c.reserve(1));
+    float* sink = reinterpret_cast<float*>(ctx->dsc_c.ptr);
+    hipEvent_t e0, e1;
+    GV_HIP(ctx, hipEventCreate(&e0));
+    GV_HIP(ctx, hipEventCreate(&e1));
+    std::vector<float> ms;
+    hipError_t err = hipSuccess;
+    for (uint32_t k = 0; k < launches + 3 && err == hipSuccess; k++) {  // three untimed warm-ups
+        (void)hipEventRecord(e0, ctx->stream);
+        err = launch_stream_probe(mesh, xf, sink, ctx->stream);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (err == hipSuccess)
+            err = hipEventSynchronize(e1);
+        float t = 0.0f;
+        if (err == hipSuccess)
+            err = hipEventElapsedTime(&t, e0, e1);
+        if (k >= 3)
+            ms.push_back(t);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess)
+        return ctx->hip_fail(err, "gv_debug_stream_peak");
+    std::sort(ms.begin(), ms.end());
+    const double median = ms[ms.size() / 2];
+    *gb_per_s = median > 0.0 ? 65.0 * n / (median * 1e-3) / 1e9 : 0.0;
     return GV_OK;
 }
 

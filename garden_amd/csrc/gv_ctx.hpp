@@ -125,8 +125,12 @@ struct DirtyRange {
     bool any() const { return lo < hi; }
     void add(uint32_t first, uint32_t count)
     {
+        if (count == 0)
+            return;
         lo = std::min(lo, first);
-        hi = std::max(hi, first + count);
+        // saturating: first + count must not wrap to a tiny `hi` (the mark would be dropped and the mirror go stale);
+        // users clamp `hi` to the pool's occupancy
+        hi = std::max(hi, (uint32_t)std::min<uint64_t>((uint64_t)first + count, UINT32_MAX));
     }
     void clear()
     {
@@ -171,6 +175,8 @@ struct PoolState {
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
+    DeviceBuf<uint32_t> d_index_map;  // gv_pool_set_index_map: pool slot -> the caller's global id (exchange shards)
+    uint32_t index_map_count = 0;     // 0: none
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
     uint32_t mirrored = 0, appended = 0;  // entries the mirror holds / of those, appended (unsorted) since the last full build
@@ -288,6 +294,7 @@ struct Context {
     // ---- multi-GPU exchange (gv_exchange.cpp) ----
     void* exchange_comm = nullptr;     // ncclComm_t
     int exchange_rank = 0, exchange_world = 1;
+    uint32_t exchange_mode = GV_EXCHANGE_ALLGATHER;  // GvExchangeMode
     DeviceBuf<uint32_t> d_shard;       // [count, indices...] of this rank
 
     // ---- profiling ----

@@ -655,6 +655,41 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     return hipGetLastError();
 }
 
+// Read-stream probe (gv_debug_stream_peak): the cull kernel's five input streams of a flat, exactly paired pool —
+// mesh.a 16 B, mesh.b 8 B, xf.ab 32 B, xf.c 8 B, xf.flags 1 B = 65 B per entry — read with the same nontemporal
+// loads, workgroup size and tile mapping, nothing computed and nothing written: what this box's HBM delivers to
+// this access pattern (SURVEY.md §8d asks for the measured read-stream peak beside the vendor figure).
+__global__ __launch_bounds__(kCullBlock) void stream_probe_kernel(const MeshMirror mesh, const TransformMirror xf, uint32_t nblocks,
+                                                                 uint32_t xcd_run, float* __restrict__ sink)
+{
+    const uint32_t lb = tile_of_workgroup(blockIdx.x, xcd_run);
+    if (lb >= nblocks)
+        return;
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    if (i >= mesh.count || i >= xf.count)
+        return;
+    const float4 ma = stream_load(&mesh.a[i]);
+    const float2 mb = stream_load(&mesh.b[i]);
+    const float4 xa = stream_load(&xf.ab[i].a);
+    const float4 xb = stream_load(&xf.ab[i].b);
+    const float2 xc = stream_load(&xf.c[i]);
+    const uint32_t f = stream_load(&xf.flags[i]);
+    const float s = ma.x + ma.y + ma.z + ma.w + mb.x + mb.y + xa.x + xa.y + xa.z + xa.w + xb.x + xb.y + xb.z + xb.w + xc.x + xc.y + (float)f;
+    if (s == 12345.678f)  // never true for real pools: keeps the loads alive
+        sink[0] = s;
+}
+
+hipError_t launch_stream_probe(const MeshMirror& mesh, const TransformMirror& xf, float* sink, hipStream_t stream)
+{
+    const uint32_t n = std::min(mesh.count, xf.count);
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t nblocks = (n + kCullBlock - 1) / kCullBlock;
+    const uint32_t run = xcd_run_for_tiles(nblocks);
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(grid_for_tiles(nblocks, run)), dim3(kCullBlock), 0, stream, mesh, xf, nblocks, run, sink);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void pack_active_kernel(const uint8_t* __restrict__ flags, uint32_t count,
                                                           unsigned long long* __restrict__ bits)
 {
@@ -760,37 +795,41 @@ hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32
     return hipGetLastError();
 }
 
+// `map` (gv_pool_set_index_map; may be NULL): pool slot -> the caller's global id (a spatial tile's slots are not a
+// contiguous range of the world's), applied before `base` is added.
 __global__ __launch_bounds__(256) void copy_idx_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
-                                                       uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+                                                       uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base,
+                                                       const uint32_t* __restrict__ map)
 {
     const uint32_t n = min(*count, capacity);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        dst[i] = src[i] + base;
+        dst[i] = (map ? map[src[i]] : src[i]) + base;
 }
 
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
-                           hipStream_t stream)
+                           const uint32_t* map, hipStream_t stream)
 {
-    hipLaunchKernelGGL(copy_idx_kernel, dim3(2048), dim3(256), 0, stream, src, count, dst, capacity, base);
+    hipLaunchKernelGGL(copy_idx_kernel, dim3(2048), dim3(256), 0, stream, src, count, dst, capacity, base, map);
     return hipGetLastError();
 }
 
 // exchange shard: [draw_count, idx + base ...]; the header is the true count even when it exceeds `capacity`
 __global__ __launch_bounds__(256) void copy_shard_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ count,
-                                                         uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base)
+                                                         uint32_t* __restrict__ dst, uint32_t capacity, uint32_t base,
+                                                         const uint32_t* __restrict__ map)
 {
     const uint32_t total = *count, n = min(total, capacity);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         dst[0] = total;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        dst[1 + i] = src[i] + base;
+        dst[1 + i] = (map ? map[src[i]] : src[i]) + base;
 }
 
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
-                             hipStream_t stream)
+                             const uint32_t* map, hipStream_t stream)
 {
     const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 255u) / 256u));
-    hipLaunchKernelGGL(copy_shard_kernel, dim3(blocks), dim3(256), 0, stream, src, count, dst, capacity, base);
+    hipLaunchKernelGGL(copy_shard_kernel, dim3(blocks), dim3(256), 0, stream, src, count, dst, capacity, base, map);
     return hipGetLastError();
 }
 

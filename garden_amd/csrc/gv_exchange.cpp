@@ -3,6 +3,10 @@
 // [draw_count, global indices ...] and all ranks gather the shards with ONE equal-size ncclAllGather enqueued on the
 // context's stream — no host synchronisation; counts are read from the shard headers. Same wire format as
 // garden_amd/multi.py::VisibleListExchange (which does this through torch.distributed in bench.py).
+// The node's xGMI fabric is fully connected point to point, and a ring all-gather serialises world-1 hops over it, so
+// two direct patterns sit beside the all-gather for an A/B on real hardware (gv_exchange_set_mode, or the environment
+// variable GV_EXCHANGE_MODE = allgather | p2p | broadcast read at gv_exchange_init): one ncclGroup of send/recv pairs
+// with every peer (each shard crosses exactly one link), or one ncclBroadcast per root. Same bytes in the same place.
 //
 // RCCL is bound at run time (dlopen): a process that already carries an RCCL — PyTorch bundles one — keeps using that
 // copy, and libgarden_vis.so has no link-time dependency on it.
@@ -22,6 +26,11 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
     std::string why;
@@ -53,7 +62,13 @@ Rccl& rccl()
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(h, "ncclBroadcast"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString && r.Send && r.Recv &&
+               r.Broadcast && r.GroupStart && r.GroupEnd;
         if (!r.ok)
             r.why = "librccl lacks an expected symbol";
     });
@@ -115,6 +130,26 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
     ctx->exchange_comm = comm;
     ctx->exchange_rank = rank;
     ctx->exchange_world = world_size;
+    if (const char* m = getenv("GV_EXCHANGE_MODE")) {
+        if (!strcmp(m, "p2p"))
+            ctx->exchange_mode = GV_EXCHANGE_P2P;
+        else if (!strcmp(m, "broadcast"))
+            ctx->exchange_mode = GV_EXCHANGE_BROADCAST;
+        else if (!strcmp(m, "allgather"))
+            ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
+        else
+            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast)", m);
+    }
+    return GV_OK;
+}
+
+int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (mode > GV_EXCHANGE_BROADCAST)
+        return ctx->fail(GV_E_ARG, "gv_exchange_set_mode: unknown mode %u", mode);
+    ctx->exchange_mode = mode;
     return GV_OK;
 }
 
@@ -135,9 +170,37 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint3
     if (rc != GV_OK)
         return rc;
     Rccl& r = rccl();
-    const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, (size_t)capacity + 1, kNcclUint32, ctx->exchange_comm, ctx->stream);
+    const size_t words = (size_t)capacity + 1;
+    uint32_t* rows = static_cast<uint32_t*>(gathered_device);
+    const int me = ctx->exchange_rank, world = ctx->exchange_world;
+    if (ctx->exchange_mode == GV_EXCHANGE_ALLGATHER) {
+        const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, words, kNcclUint32, ctx->exchange_comm, ctx->stream);
+        if (nrc != 0)
+            return ctx->fail(GV_E_RCCL, "ncclAllGather: %s", r.GetErrorString(nrc));
+        return GV_OK;
+    }
+    // the direct forms place this rank's own row with a device copy; the peers' rows arrive over the links
+    GV_HIP(ctx, hipMemcpyAsync(rows + (size_t)me * words, ctx->d_shard.ptr, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    int nrc = r.GroupStart();
+    if (ctx->exchange_mode == GV_EXCHANGE_P2P) {
+        // one send/recv pair per peer inside one group: every shard crosses exactly one xGMI link, all links at once
+        for (int d = 1; d < world && nrc == 0; d++) {
+            const int to = (me + d) % world, from = (me - d + world) % world;
+            nrc = r.Send(ctx->d_shard.ptr, words, kNcclUint32, to, ctx->exchange_comm, ctx->stream);
+            if (nrc == 0)
+                nrc = r.Recv(rows + (size_t)from * words, words, kNcclUint32, from, ctx->exchange_comm, ctx->stream);
+        }
+    } else {
+        for (int root = 0; root < world && nrc == 0; root++)
+            nrc = r.Broadcast(root == me ? ctx->d_shard.ptr : rows + (size_t)root * words, rows + (size_t)root * words, words,
+                              kNcclUint32, root, ctx->exchange_comm, ctx->stream);
+    }
+    const int erc = r.GroupEnd();
+    if (nrc == 0)
+        nrc = erc;
     if (nrc != 0)
-        return ctx->fail(GV_E_RCCL, "ncclAllGather: %s", r.GetErrorString(nrc));
+        return ctx->fail(GV_E_RCCL, "%s exchange: %s", ctx->exchange_mode == GV_EXCHANGE_P2P ? "ncclSend/ncclRecv" : "ncclBroadcast",
+                         r.GetErrorString(nrc));
     return GV_OK;
 }
 

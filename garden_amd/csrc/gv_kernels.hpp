@@ -105,6 +105,8 @@ struct MultiViewPlanes {
 hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
                              const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
                              const BlockBounds* bounds = nullptr);
+// read-only pass over the cull kernel's input streams (65 B per entry); gv_debug_stream_peak
+hipError_t launch_stream_probe(const MeshMirror& mesh, const TransformMirror& xf, float* sink, hipStream_t stream);
 hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
 // self_prefix: every emit workgroup derives its chunk's base from the chunk totals itself (no launch_scan in front;
 // pools of up to kSelfPrefixMaxChunks chunks); out.chunk_count / chunk_count_next then alternate from cull to cull.
@@ -114,10 +116,11 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
 // all views of a batched cull in one launch (self-prefixing form; views[v] / outs[v] / clear_chunks[v] per view)
 hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
                              const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream);
+// map: pool slot -> caller's global id (NULL: identity), applied before `base`
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
-                           hipStream_t stream);
+                           const uint32_t* map, hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
-                             hipStream_t stream);
+                             const uint32_t* map, hipStream_t stream);
 // gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
 constexpr uint32_t kPublishMaxSlots = 262144;

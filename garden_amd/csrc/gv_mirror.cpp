@@ -333,7 +333,9 @@ int upload_transforms(GvCtx* ctx, uint32_t lo, uint32_t hi)
 
 // The bound transform fields as one array of structs, if that is what they are: equal strides, every field inside
 // one stride-sized window. (Column bindings with separate arrays are gathered on the host.)
-bool aos_transform_layout(const TransformBinding& xf, const uint8_t** base, AosTransformLayout* L)
+// *extent = bytes from `base` to the end of the last bound field of one element (<= stride): the last element of a span
+// is only read that far (base is the LOWEST bound field, not necessarily the start of the component).
+bool aos_transform_layout(const TransformBinding& xf, const uint8_t** base, AosTransformLayout* L, uint32_t* extent)
 {
     const Column* cols[7] = {&xf.entity, &xf.position, &xf.scale, &xf.rotation, &xf.self_active, &xf.ancestors_active,
                              &xf.model_with_ancestors};
@@ -346,29 +348,34 @@ bool aos_transform_layout(const TransformBinding& xf, const uint8_t** base, AosT
         lo = std::min(lo, c->ptr);
     }
     uint32_t off[7];
+    *extent = 0;
     for (int k = 0; k < 7; k++) {
         const size_t o = (size_t)(cols[k]->ptr - lo);
         if (o + width[k] > stride)
             return false;
         off[k] = (uint32_t)o;
+        *extent = std::max(*extent, off[k] + width[k]);
     }
     *base = lo;
     *L = AosTransformLayout{(uint32_t)stride, off[0], off[1], off[2], off[3], off[4], off[5], off[6]};
     return true;
 }
 
-// GV_DIRTY_TRANSFORM over slots [lo, hi) of an AoS pool, device side: page-lock just that span of the caller's pool for
-// the duration of the copy (measured on the MI355X box: 7 ms per 800 MB to lock, then 57 GB/s instead of 10 GB/s
-// from pageable memory), copy the raw components, gather on the device. The host staging of those slots goes stale
-// and is refreshed only if a host path needs it later. Returns GV_E_STATE when the path is not applicable.
+// GV_DIRTY_TRANSFORM over slots [lo, hi) of an AoS pool, device side: the raw components of the span travel through the
+// library's own pinned chunks (the caller's memory is never page-locked, see below) and a device kernel does the
+// AoS -> SoA gather. Only the bytes between the first and the last bound field are read: (count - 1) strides + the
+// extent of one element, so a layout whose first field sits above offset 0 never reads past the caller's pool. The
+// host staging of those slots goes stale and is refreshed only if a host path needs it later. Returns GV_E_STATE when
+// the path is not applicable.
 int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
 {
     const uint8_t* base = nullptr;
     AosTransformLayout L{};
-    if (!ctx->device_gather || !aos_transform_layout(ctx->xf, &base, &L))
+    uint32_t extent = 0;
+    if (!ctx->device_gather || hi <= lo || !aos_transform_layout(ctx->xf, &base, &L, &extent))
         return GV_E_STATE;
     const uint32_t count = hi - lo;
-    const size_t bytes = (size_t)count * L.stride;
+    const size_t bytes = (size_t)(count - 1) * L.stride + extent;
     const uint8_t* span = base + (size_t)lo * L.stride;
     if (bytes > ctx->d_raw.cap) {
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier gather may still be reading the buffer about to go

@@ -24,6 +24,7 @@ GV_CONFIG_BLOCK_BOUNDS = 8
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU = 0, 1, 2, 3
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
+GV_EXCHANGE_ALLGATHER, GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST = 0, 1, 2
 KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep", "sort"]
 
 
@@ -100,10 +101,10 @@ EXPORTS = [
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
     "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
-    "gv_stream",
+    "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
 ]
 
 _lib = None
@@ -156,6 +157,7 @@ def load():
     lib.gv_hiz_mip_count.argtypes = [P, C.POINTER(u32)]
     lib.gv_stats.argtypes = [P, C.POINTER(GvStats)]
     lib.gv_stats_reset.argtypes = [P]
+    lib.gv_debug_stream_peak.argtypes = [P, u32, u32, C.POINTER(C.c_double)]
     lib.gv_stream.argtypes = [P]
     lib.gv_stream.restype = P
     lib.gv_scene_parse_json.argtypes = [C.c_char_p, sz, C.POINTER(GvScenePool), u32, u32, C.POINTER(P), C.c_char_p, sz]
@@ -171,6 +173,8 @@ def load():
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
     lib.gv_exchange_shards.argtypes = [P, u32, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]
+    lib.gv_exchange_set_mode.argtypes = [P, u32]
+    lib.gv_pool_set_index_map.argtypes = [P, u32, P, u32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream", "gv_scene_destroy"):
@@ -322,6 +326,14 @@ class GpuVisibility:
         self._check(self.lib.gv_results_device(self.ctx, view_index, C.byref(d)))
         return d
 
+    def set_index_map(self, pool_id, global_ids):
+        """Pool slot -> global id table for the exchange shards of `pool_id` (None / empty removes it)."""
+        if global_ids is None or len(global_ids) == 0:
+            self._check(self.lib.gv_pool_set_index_map(self.ctx, pool_id, None, 0))
+            return
+        g = np.ascontiguousarray(global_ids, dtype=np.uint32)
+        self._check(self.lib.gv_pool_set_index_map(self.ctx, pool_id, g.ctypes.data, g.shape[0]))
+
     def copy_idx_device(self, view_index, dst_ptr, capacity, index_base=0):
         self._check(self.lib.gv_results_copy_idx_device(self.ctx, view_index, dst_ptr, capacity, index_base))
 
@@ -343,6 +355,10 @@ class GpuVisibility:
 
     def exchange_shards(self, view_index, capacity, index_base, gathered_ptr):
         self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, index_base, gathered_ptr))
+
+    def exchange_set_mode(self, mode):
+        """0 all-gather, 1 grouped send/recv with every peer, 2 one broadcast per root (GvExchangeMode)."""
+        self._check(self.lib.gv_exchange_set_mode(self.ctx, mode))
 
     def exchange_shutdown(self):
         self._check(self.lib.gv_exchange_shutdown(self.ctx))
@@ -392,6 +408,12 @@ class GpuVisibility:
                     upload_bytes=int(s.upload_bytes), max_depth=int(s.max_depth),
                     transform_count=int(s.transform_count), bounds_blocks_total=int(s.bounds_blocks_total),
                     bounds_blocks_examined=int(s.bounds_blocks_examined))
+
+    def stream_peak(self, pool_id=0, launches=20):
+        """GB/s of a read-only pass over the cull kernel's input streams of `pool_id` (median of `launches`)."""
+        g = C.c_double()
+        self._check(self.lib.gv_debug_stream_peak(self.ctx, pool_id, launches, C.byref(g)))
+        return g.value
 
     def stats_reset(self):
         self._check(self.lib.gv_stats_reset(self.ctx))

@@ -23,6 +23,126 @@ def tile_of_positions(positions, side, grid):
     return t
 
 
+def tile_grid(n):
+    """(gx, gy, gz) with gx * gy * gz >= n, doubling x, y, z in turn: 8 GPUs -> 2 x 2 x 2."""
+    g = [1, 1, 1]
+    i = 0
+    while g[0] * g[1] * g[2] < n:
+        g[i % 3] *= 2
+        i += 1
+    return tuple(g)
+
+
+class WorldPartition:
+    """ONE world cut into spatial tiles (the reference's nearest analogue is the contiguous range split of
+    ThreadPool::addItems, source/thread-pool.cpp:173-200 — here the split is by space, so that a tile is culled as a
+    unit and whole trees stay together).
+
+    tiles[t]            Scene of tile t: its transforms and meshes in ascending global slot order, entity ids
+                        renumbered 1..k per tile (free slots stay 0), parents remapped, entity_to_transform rebuilt
+    transform_global[t] local transform slot -> global transform slot        (int64)
+    mesh_global[t]      local mesh slot -> global mesh slot                  (int64)  <- maps a tile's visible_idx back
+    mesh_tile, mesh_local   global mesh slot -> (tile, local slot)
+    transform_tile, transform_local   the same for transform slots
+    root_slot           global transform slot -> slot of its root ancestor (itself for roots)
+    """
+
+    def __init__(self, tiles, transform_global, mesh_global, mesh_tile, mesh_local, transform_tile, transform_local,
+                 root_slot, grid, side):
+        self.tiles, self.transform_global, self.mesh_global = tiles, transform_global, mesh_global
+        self.mesh_tile, self.mesh_local = mesh_tile, mesh_local
+        self.transform_tile, self.transform_local = transform_tile, transform_local
+        self.root_slot, self.grid, self.side = root_slot, grid, side
+
+    def to_global(self, tile, local_mesh_slots):
+        """Global mesh slots of a tile's local visible_idx list."""
+        import numpy as np
+        return self.mesh_global[tile][np.asarray(local_mesh_slots, dtype=np.int64)]
+
+
+def partition_world(sc, grid, side=None):
+    """Cuts the Scene `sc` (garden_amd.scene.Scene: AoS pools + entity_to_transform) into prod(grid) spatial tiles:
+    every ROOT transform goes to the tile its position falls in (tile_of_positions), every descendant follows its root
+    (a parent chain is never cut, so a tile computes the same world matrices as the whole world does), a mesh follows
+    the transform of its entity. Free slots and meshes whose entity has no transform go to tile 0, where the cull
+    filters them out exactly as it does in the whole world (mesh.cpp:140-155). Within a tile, slots keep their global
+    order and entity ids are renumbered from 1.
+    `side`: edge of the world cube the grid cuts (default 100 * N^(1/3), the synthetic scenes' cube)."""
+    import numpy as np
+
+    from .pools import GV_NONE
+    from .scene import Scene
+    tr, ms, e2t = sc.transforms, sc.meshes, np.asarray(sc.entity_to_transform, dtype=np.uint32)
+    nt, nm = tr.shape[0], ms.shape[0]
+    if side is None:
+        side = 100.0 * max(nm, 1) ** (1.0 / 3.0)
+    ntiles = int(grid[0] * grid[1] * grid[2])
+
+    def slot_of_entity(ent):
+        """transform slot of each entity id (-1: none) — Manager::tryGet<TransformComponent>"""
+        ent = np.asarray(ent, dtype=np.int64)
+        ok = (ent > 0) & (ent < e2t.shape[0])
+        out = np.full(ent.shape, -1, dtype=np.int64)
+        s = e2t[ent[ok]].astype(np.int64)
+        s[s == GV_NONE] = -1
+        out[ok] = s
+        return out
+
+    # root ancestor of every transform slot by pointer jumping (chains are short; cycles cannot occur in a valid pool)
+    parent_slot = slot_of_entity(tr["parent"])
+    parent_slot[tr["entity"] == 0] = -1
+    root = np.arange(nt, dtype=np.int64)
+    up = np.where(parent_slot >= 0, parent_slot, root)
+    for _ in range(64):
+        nxt = up[up]
+        if np.array_equal(nxt, up):
+            break
+        up = nxt
+    else:
+        raise ValueError("partition_world: parent chains deeper than 2^64 or cyclic")
+    root = up
+    tile_of_root = tile_of_positions(tr["position"][:, :3].astype(np.float64), side, grid)
+    xf_tile = tile_of_root[root]
+    xf_tile[tr["entity"] == 0] = 0  # free transform slots: anywhere; tile 0
+    mesh_xf = slot_of_entity(ms["entity"])
+    mesh_tile = np.where(mesh_xf >= 0, xf_tile[np.maximum(mesh_xf, 0)], 0).astype(np.int64)
+
+    tiles, xf_global, mesh_global = [], [], []
+    xf_local = np.zeros(nt, dtype=np.int64)
+    mesh_local = np.zeros(nm, dtype=np.int64)
+    for t in range(ntiles):
+        xs = np.nonzero(xf_tile == t)[0]
+        msl = np.nonzero(mesh_tile == t)[0]
+        xf_local[xs] = np.arange(xs.shape[0])
+        mesh_local[msl] = np.arange(msl.shape[0])
+        ltr, lms = tr[xs].copy(), ms[msl].copy()
+        # new entity ids: live transforms first (1..k in slot order), then meshes whose entity has no transform here
+        live = ltr["entity"] != 0
+        new_id = np.zeros(e2t.shape[0] + 1, dtype=np.uint32)  # global entity id -> tile-local id
+        k = int(live.sum())
+        new_id[ltr["entity"][live]] = np.arange(1, k + 1, dtype=np.uint32)
+        stray = (lms["entity"] != 0) & (new_id[np.minimum(lms["entity"], e2t.shape[0])] == 0)
+        stray_ids = np.unique(lms["entity"][stray])
+        new_id[np.minimum(stray_ids, e2t.shape[0])] = np.arange(k + 1, k + 1 + stray_ids.shape[0], dtype=np.uint32)
+        old_parent = ltr["parent"].copy()
+        ltr["entity"] = new_id[np.minimum(ltr["entity"], e2t.shape[0])]
+        # a parent that has no transform (dangling id) stays dangling: give it an id nothing maps to
+        has_parent = old_parent != 0
+        mapped = new_id[np.minimum(old_parent, e2t.shape[0])]
+        dangling = has_parent & (mapped == 0)
+        ltr["parent"] = mapped
+        lms["entity"] = new_id[np.minimum(lms["entity"], e2t.shape[0])]
+        cap = k + 1 + stray_ids.shape[0] + (1 if dangling.any() else 0)
+        if dangling.any():
+            ltr["parent"][dangling] = cap - 1  # an entity id with no transform: the chain ends there, as in the world
+        le2t = np.full(cap, GV_NONE, dtype=np.uint32)
+        le2t[ltr["entity"][live]] = np.nonzero(live)[0].astype(np.uint32)
+        tiles.append(Scene(lms, ltr, le2t))
+        xf_global.append(xs)
+        mesh_global.append(msl)
+    return WorldPartition(tiles, xf_global, mesh_global, mesh_tile, mesh_local, xf_tile, xf_local, root, tuple(grid), side)
+
+
 def allgatherv_indices(idx_buf, count, dist, group=None):
     """idx_buf[:count] holds this rank's global visible indices (int32 view of uint32). Returns
     (gathered 1-D tensor of all ranks' lists in rank order, counts tensor)."""
@@ -70,6 +190,17 @@ def allgatherv_indices(idx_buf, count, dist, group=None):
     return out, counts
 
 
+class _WorkSet:
+    """Several async works waited on as one (the direct exchange patterns issue one per peer / per root)."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class ShardOverflow(RuntimeError):
     """A rank produced more visible indices than the padded shard holds; `needed` is the largest count seen."""
 
@@ -95,7 +226,15 @@ class VisibleListExchange:
     orders the stream behind that slot's collective and checks its headers (already on the host by then): a count
     above the capacity raises ShardOverflow so the caller can re-exchange that frame with a larger capacity."""
 
-    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2):
+    MODES = ("allgather", "p2p", "broadcast")
+
+    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2, mode="allgather"):
+        """mode: how the shards travel. "allgather" = ONE equal-size all-gather; "p2p" = one group of send/recv pairs
+        with every peer (batch_isend_irecv = ncclGroupStart ... ncclGroupEnd: each shard crosses exactly one xGMI link,
+        all links at once); "broadcast" = one broadcast per root. Same rows in the same place either way — the node's
+        fabric is point to point and fully connected, so ring vs direct is an A/B for real hardware."""
+        assert mode in self.MODES, mode
+        self.mode = mode
         self.dist, self.group, self.device = dist, group, torch.device(device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.backend = dist.get_backend(group)
@@ -110,6 +249,37 @@ class VisibleListExchange:
         self.headers = [torch.zeros(self.world, dtype=torch.int32, pin_memory=self.native) for _ in range(slots)]
         self.header_events = [None] * slots
         self.in_flight = [False] * slots
+
+    def describe(self):
+        return {"allgather": "one equal-size all-gather", "p2p": "one group of send/recv pairs with every peer",
+                "broadcast": "one broadcast per root"}[self.mode]
+
+    def _global(self, r):
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _gather_rows(self, out, shard, async_op):
+        """Fills out[r] with rank r's shard by the configured pattern; returns an object with .wait() (or None)."""
+        n = shard.numel()
+        rows = out.view(self.world, n)
+        if self.mode == "allgather":
+            return self.dist.all_gather_into_tensor(out, shard, group=self.group, async_op=async_op)
+        rows[self.rank].copy_(shard)  # own row: a local copy in stream order
+        works = []
+        if self.mode == "p2p":
+            ops = []
+            for d in range(1, self.world):
+                to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                ops.append(self.dist.P2POp(self.dist.isend, shard, self._global(to), self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, rows[frm], self._global(frm), self.group))
+            works = self.dist.batch_isend_irecv(ops) if ops else []
+        else:
+            for r in range(self.world):
+                works.append(self.dist.broadcast(rows[r], src=self._global(r), group=self.group, async_op=True))
+        ws = _WorkSet(works)
+        if not async_op:
+            ws.wait()
+            return None
+        return ws
 
     def _producer(self):
         import contextlib
@@ -139,7 +309,7 @@ class VisibleListExchange:
         padded = out.view(self.world, 1 + self.capacity)
         if self.native:
             with self._producer():
-                self.works[s] = self.dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
+                self.works[s] = self._gather_rows(out, shard, async_op=True)
             with torch.cuda.stream(self.side):
                 self.works[s].wait()  # side stream behind the collective; the producer stream is not held up
                 self.headers[s].copy_(padded[:, 0], non_blocking=True)
@@ -148,9 +318,14 @@ class VisibleListExchange:
                 self.header_events[s] = ev
         else:  # gloo (CPU tests, or N ranks sharing one GPU): staged through host memory, synchronous
             src = shard.cpu() if shard.is_cuda else shard
-            pieces = [torch.empty_like(src) for _ in range(self.world)]
-            self.dist.all_gather(pieces, src, group=self.group)
-            host = torch.stack(pieces)
+            if self.mode == "allgather":
+                pieces = [torch.empty_like(src) for _ in range(self.world)]
+                self.dist.all_gather(pieces, src, group=self.group)
+                host = torch.stack(pieces)
+            else:
+                host = torch.empty(self.world * src.numel(), dtype=src.dtype)
+                self._gather_rows(host, src, async_op=False)
+                host = host.view(self.world, src.numel())
             padded.copy_(host)
             self.headers[s].copy_(host[:, 0])
         self.in_flight[s] = True

@@ -203,6 +203,13 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                  uint32_t index_base);
 
+/* A spatial tile's pool slots are not a contiguous range of the world's (roots -> tile, descendants
+ * follow): `global_ids[slot]` is the id the exchange should carry for pool slot `slot` (e.g. the mesh slot in the
+ * unpartitioned world, garden_amd/multi.py::partition_world's mesh_global). Uploaded once; from then on
+ * gv_results_copy_idx_device / gv_results_copy_shard_device / gv_exchange_shards write global_ids[visible_idx] +
+ * index_base instead of visible_idx + index_base whenever the table covers the culled pool. count == 0 removes it. */
+int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count);
+
 /* ---- multi-GPU exchange without torch.distributed (one process per GPU) ----
  * Rank 0 calls gv_exchange_unique_id and hands the 128 bytes to the other ranks by its own means (the engine's IPC, a
  * file, MPI ...); every rank then calls gv_exchange_init with its own context. gv_exchange_shards enqueues, on the
@@ -216,6 +223,16 @@ int gv_exchange_unique_id(void* out_id_128_bytes);
 int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int world_size);
 int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device);
 int gv_exchange_shutdown(GvCtx* ctx);
+/* How gv_exchange_shards moves the shards (same result rows either way). The node's xGMI fabric is point to point and
+ * fully connected: a ring all-gather serialises world-1 hops, the direct forms use every link at
+ * once. Default GV_EXCHANGE_ALLGATHER, or the environment variable GV_EXCHANGE_MODE (allgather | p2p | broadcast) read
+ * by gv_exchange_init. */
+typedef enum GvExchangeMode {
+    GV_EXCHANGE_ALLGATHER = 0, /* one equal-size ncclAllGather */
+    GV_EXCHANGE_P2P = 1,       /* one ncclGroup of ncclSend/ncclRecv pairs with every peer */
+    GV_EXCHANGE_BROADCAST = 2  /* one ncclBroadcast per root, grouped */
+} GvExchangeMode;
+int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode);
 
 /* Sorts view `view_index`'s compact records on the device by distanceSq: ascending (descending == 0) as sortMeshes
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
@@ -325,6 +342,11 @@ typedef struct GvStats {
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);
+/* Measurement aid (bench.py `roofline.measured_stream_peak`): `launches` read-only passes over the five input streams
+ * the cull kernel reads from pool `pool_id` (mesh a/b, transform ab/c/flags = 65 bytes per entry), with the cull's own
+ * loads and launch geometry, each timed with hipEvents on the context's stream. *gb_per_s = 65 * entries / median
+ * launch time: the read rate this box's HBM delivers to that access pattern. Synchronises. */
+int gv_debug_stream_peak(GvCtx* ctx, uint32_t pool_id, uint32_t launches, double* gb_per_s);
 /* The HIP stream all work is enqueued on (hipStream_t as void*), for callers timing with their own events. */
 void* gv_stream(GvCtx* ctx);
 

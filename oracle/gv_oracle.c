@@ -204,6 +204,43 @@ void gvo_world_matrices(const GvoTransformPool* tp, uint32_t first, uint32_t cou
     }
 }
 
+/* the same, slot range split over `threads` threads like ThreadPool::addItems (thread-pool.cpp:173-200) */
+typedef struct WorldTask {
+    const GvoTransformPool* tp;
+    uint32_t first, count;
+    float* out12;
+} WorldTask;
+static void* world_task_main(void* arg)
+{
+    const WorldTask* t = (const WorldTask*)arg;
+    gvo_world_matrices(t->tp, t->first, t->count, t->out12);
+    return NULL;
+}
+void gvo_pool_run(void* (*fn)(void*), void** args, int count, int threads);
+void gvo_world_matrices_mt(const GvoTransformPool* tp, uint32_t first, uint32_t count, float* out12, uint32_t threads)
+{
+    if (threads <= 1 || count < 4096u) {
+        gvo_world_matrices(tp, first, count, out12);
+        return;
+    }
+    const uint32_t task_count = count > threads ? threads : count;
+    const uint32_t per = (uint32_t)ceilf((float)count / (float)task_count);
+    WorldTask* tasks = (WorldTask*)calloc(task_count, sizeof(WorldTask));
+    void** argv = (void**)calloc(task_count, sizeof(void*));
+    int argc = 0;
+    for (uint32_t i = 0; i < task_count; i++) {
+        const uint32_t lo = per * i, hi = count < lo + per ? count : lo + per;
+        if (lo >= hi)
+            continue;
+        tasks[argc] = (WorldTask){tp, first + lo, hi - lo, out12 + (size_t)lo * 12};
+        argv[argc] = &tasks[argc];
+        argc++;
+    }
+    gvo_pool_run(world_task_main, argv, argc, (int)threads);
+    free(argv);
+    free(tasks);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Hi-Z pyramid — shaders/hiz.frag:23-63, source/system/render/hiz.cpp:24-57
  * ---------------------------------------------------------------------------------------------- */
@@ -249,46 +286,97 @@ static inline void src_texel(const GvoHiz* hz, const float* mips, uint32_t level
     }
 }
 
+/* rows [py0, py1) of level k from level k - 1 (hiz.frag:23-63) */
+static void hiz_build_rows(const GvoHiz* hz, float* mips, int rule, uint32_t k, uint32_t py0, uint32_t py1)
+{
+    const uint32_t sw = hz->mip_w[k - 1], sh = hz->mip_h[k - 1];
+    const uint32_t dw = hz->mip_w[k];
+    const int odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0; /* isPrevLevelOdd  hiz.frag:35 */
+    for (uint32_t py = py0; py < py1; py++)
+        for (uint32_t px = 0; px < dw; px++) {
+            /* textureGather footprint of the 2x2 quad at 2p (hiz.frag:29-33); clamp-to-edge
+             * sampler semantics for a 1-texel-wide source. */
+            const uint32_t x0 = 2 * px, y0 = 2 * py;
+            const uint32_t x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+            const uint32_t x2 = x0 + 2 < sw ? x0 + 2 : sw - 1, y2 = y0 + 2 < sh ? y0 + 2 : sh - 1;
+            float mn, mx, a, b;
+            src_texel(hz, mips, k - 1, x0, y0, &mn, &mx);
+#define ACC(X, Y) do { src_texel(hz, mips, k - 1, (X), (Y), &a, &b); mn = a < mn ? a : mn; mx = b > mx ? b : mx; } while (0)
+            ACC(x1, y0);
+            ACC(x0, y1);
+            ACC(x1, y1);
+            if (odd_x) { /* hiz.frag:36-41: gatherOffset(1,0) .y .z = column 2p.x+2, rows 2p.y+1, 2p.y */
+                ACC(x2, y1);
+                ACC(x2, y0);
+                if (odd_y) /* hiz.frag:43-47: texel (2p + 2) */
+                    ACC(x2, y2);
+            }
+            if (odd_y) {
+                /* hiz.frag:49-55: gatherOffset(0,1) components .y .z = texels (2p.x+1, 2p.y+2) and
+                 * (2p.x+1, 2p.y+1): the reference as written does NOT read (2p.x, 2p.y+2). */
+                ACC(x1, y2);
+                ACC(x1, y1);
+                if (rule == GVO_HIZ_RULE_CONSERVATIVE)
+                    ACC(x0, y2); /* the full extra row, so that min/max bound every covered texel */
+            }
+#undef ACC
+            float* d = mips + 2 * (hz->mip_offset[k] + (uint64_t)py * dw + px);
+            d[0] = mn;
+            d[1] = mx;
+        }
+}
+
 void gvo_hiz_build(GvoHiz* hz, float* mips, int rule)
 {
     hz->mips = mips;
+    for (uint32_t k = 1; k < hz->mip_count; k++)
+        hiz_build_rows(hz, mips, rule, k, 0, hz->mip_h[k]);
+}
+
+/* The same pyramid with every level's rows split over `threads` threads like ThreadPool::addItems
+ * (thread-pool.cpp:173-200); levels stay sequential (one render pass per mip, hiz.cpp:148-164). Same bits: every
+ * destination texel is computed by exactly one thread from the finished level below. */
+typedef struct HizRowsTask {
+    const GvoHiz* hz;
+    float* mips;
+    int rule;
+    uint32_t k, py0, py1;
+} HizRowsTask;
+static void* hiz_rows_main(void* arg)
+{
+    const HizRowsTask* t = (const HizRowsTask*)arg;
+    hiz_build_rows(t->hz, t->mips, t->rule, t->k, t->py0, t->py1);
+    return NULL;
+}
+void gvo_pool_run(void* (*fn)(void*), void** args, int count, int threads);
+void gvo_hiz_build_mt(GvoHiz* hz, float* mips, int rule, uint32_t threads)
+{
+    hz->mips = mips;
+    if (threads < 1)
+        threads = 1;
+    HizRowsTask* tasks = (HizRowsTask*)calloc(threads, sizeof(HizRowsTask));
+    void** argv = (void**)calloc(threads, sizeof(void*));
     for (uint32_t k = 1; k < hz->mip_count; k++) {
-        const uint32_t sw = hz->mip_w[k - 1], sh = hz->mip_h[k - 1];
-        const uint32_t dw = hz->mip_w[k], dh = hz->mip_h[k];
-        const int odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0; /* isPrevLevelOdd  hiz.frag:35 */
-        for (uint32_t py = 0; py < dh; py++)
-            for (uint32_t px = 0; px < dw; px++) {
-                /* textureGather footprint of the 2x2 quad at 2p (hiz.frag:29-33); clamp-to-edge
-                 * sampler semantics for a 1-texel-wide source. */
-                const uint32_t x0 = 2 * px, y0 = 2 * py;
-                const uint32_t x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
-                const uint32_t x2 = x0 + 2 < sw ? x0 + 2 : sw - 1, y2 = y0 + 2 < sh ? y0 + 2 : sh - 1;
-                float mn, mx, a, b;
-                src_texel(hz, mips, k - 1, x0, y0, &mn, &mx);
-#define ACC(X, Y) do { src_texel(hz, mips, k - 1, (X), (Y), &a, &b); mn = a < mn ? a : mn; mx = b > mx ? b : mx; } while (0)
-                ACC(x1, y0);
-                ACC(x0, y1);
-                ACC(x1, y1);
-                if (odd_x) { /* hiz.frag:36-41: gatherOffset(1,0) .y .z = column 2p.x+2, rows 2p.y+1, 2p.y */
-                    ACC(x2, y1);
-                    ACC(x2, y0);
-                    if (odd_y) /* hiz.frag:43-47: texel (2p + 2) */
-                        ACC(x2, y2);
-                }
-                if (odd_y) {
-                    /* hiz.frag:49-55: gatherOffset(0,1) components .y .z = texels (2p.x+1, 2p.y+2) and
-                     * (2p.x+1, 2p.y+1): the reference as written does NOT read (2p.x, 2p.y+2). */
-                    ACC(x1, y2);
-                    ACC(x1, y1);
-                    if (rule == GVO_HIZ_RULE_CONSERVATIVE)
-                        ACC(x0, y2); /* the full extra row, so that min/max bound every covered texel */
-                }
-#undef ACC
-                float* d = mips + 2 * (hz->mip_offset[k] + (uint64_t)py * dw + px);
-                d[0] = mn;
-                d[1] = mx;
-            }
+        const uint32_t rows = hz->mip_h[k];
+        if (threads == 1 || (uint64_t)rows * hz->mip_w[k] < 16384u) { /* not worth a fan-out */
+            hiz_build_rows(hz, mips, rule, k, 0, rows);
+            continue;
+        }
+        const uint32_t task_count = rows > threads ? threads : rows;
+        const uint32_t per = (uint32_t)ceilf((float)rows / (float)task_count);
+        int argc = 0;
+        for (uint32_t i = 0; i < task_count; i++) {
+            const uint32_t lo = per * i, hi = rows < lo + per ? rows : lo + per;
+            if (lo >= hi)
+                continue;
+            tasks[argc] = (HizRowsTask){hz, mips, rule, k, lo, hi};
+            argv[argc] = &tasks[argc];
+            argc++;
+        }
+        gvo_pool_run(hiz_rows_main, argv, argc, (int)threads);
     }
+    free(argv);
+    free(tasks);
 }
 
 /* Build-defined occlusion query, SURVEY.md §8a-7' (no reference: SURVEY.md F3). */

@@ -113,6 +113,7 @@ int gvo_is_behind_frustum(const GvoFrustum* f, const float aabb_min[3], const fl
 void gvo_transform_calc_model(const GvoTransformPool* tp, uint32_t slot, const float camera_position[3], float out[16]);
 /* World matrices of slots [first, first+count) with cameraPosition = 0; out = 12 floats each. */
 void gvo_world_matrices(const GvoTransformPool* tp, uint32_t first, uint32_t count, float* out12);
+void gvo_world_matrices_mt(const GvoTransformPool* tp, uint32_t first, uint32_t count, float* out12, uint32_t threads);
 
 /* ---- Hi-Z ---- */
 uint32_t gvo_calc_mip_count(uint32_t w, uint32_t h);
@@ -120,6 +121,8 @@ uint32_t gvo_calc_mip_count(uint32_t w, uint32_t h);
 uint64_t gvo_hiz_layout(uint32_t w, uint32_t h, GvoHiz* out);
 /* hiz.frag:23-63: builds levels 1.. into `mips` (hiz->mips must point to writable storage). */
 void gvo_hiz_build(GvoHiz* hiz, float* mips, int rule);
+/* Same pyramid, the rows of each level split over `threads` threads like ThreadPool::addItems (bench.py cpu_baseline). */
+void gvo_hiz_build_mt(GvoHiz* hiz, float* mips, int rule, uint32_t threads);
 /* Build-defined occlusion query (SURVEY.md §8a-7'); returns 1 if occluded. */
 int gvo_hiz_occluded(const GvoHiz* hiz, const float view_proj[16], const float aabb_min[3],
                      const float aabb_max[3], const float model[16]);

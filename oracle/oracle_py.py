@@ -75,6 +75,8 @@ def load():
     lib.gvo_hiz_layout.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(GvoHiz)]
     lib.gvo_hiz_layout.restype = C.c_uint64
     lib.gvo_hiz_build.argtypes = [C.POINTER(GvoHiz), C.c_void_p, C.c_int]
+    lib.gvo_hiz_build_mt.argtypes = [C.POINTER(GvoHiz), C.c_void_p, C.c_int, C.c_uint32]
+    lib.gvo_world_matrices_mt.argtypes = [C.POINTER(GvoTransformPool), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     lib.gvo_hiz_occluded.argtypes = [C.POINTER(GvoHiz), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gvo_hiz_occluded.restype = C.c_int
     lib.gvo_prepare_meshes.argtypes = [C.POINTER(GvoMeshPool), C.POINTER(GvoTransformPool), C.POINTER(GvoView),
@@ -149,7 +151,7 @@ def to_view(v):
 class Hiz:
     """Pyramid built by the oracle (hiz.frag:23-63)."""
 
-    def __init__(self, depth, rule=RULE_REFERENCE):
+    def __init__(self, depth, rule=RULE_REFERENCE, threads=1):
         lib = load()
         self.depth = _f32(depth)
         h, w = self.depth.shape
@@ -157,8 +159,16 @@ class Hiz:
         pairs = lib.gvo_hiz_layout(w, h, C.byref(self.c))
         self.mips = np.zeros((max(int(pairs), 1), 2), dtype=np.float32)
         self.c.depth = self.depth.ctypes.data
-        lib.gvo_hiz_build(C.byref(self.c), self.mips.ctypes.data, rule)
+        self.rule = rule
+        self.rebuild(threads)
         self.mip_count = self.c.mip_count
+
+    def rebuild(self, threads=1):
+        """Re-runs the reduction into the same storage (one pass per mip, rows split over `threads` threads)."""
+        if threads > 1:
+            load().gvo_hiz_build_mt(C.byref(self.c), self.mips.ctypes.data, self.rule, threads)
+        else:
+            load().gvo_hiz_build(C.byref(self.c), self.mips.ctypes.data, self.rule)
 
     def level(self, k):
         w, h, off = self.c.mip_w[k], self.c.mip_h[k], self.c.mip_offset[k]
@@ -172,12 +182,16 @@ class Hiz:
                                             m.ctypes.data))
 
 
-def world_matrices(transforms, e2t, first=0, count=None):
+def world_matrices(transforms, e2t, first=0, count=None, threads=1, out=None):
     count = transforms.shape[0] - first if count is None else count
     e2t = np.ascontiguousarray(e2t, dtype=np.uint32)
     tp = transform_pool(transforms, e2t)
-    out = np.empty((count, 12), dtype=np.float32)
-    load().gvo_world_matrices(C.byref(tp), first, count, out.ctypes.data)
+    if out is None:
+        out = np.empty((count, 12), dtype=np.float32)
+    if threads > 1:
+        load().gvo_world_matrices_mt(C.byref(tp), first, count, out.ctypes.data, threads)
+    else:
+        load().gvo_world_matrices(C.byref(tp), first, count, out.ctypes.data)
     return out
 
 

@@ -697,7 +697,7 @@ def test_large_dirty_ranges_take_the_device_side_gather(request, oracle, hier, c
     up0 = vis.stats()["upload_bytes"]
     move(20_000, 60_000)            # device-side gather: 80 raw bytes per slot
     check()
-    assert vis.stats()["upload_bytes"] - up0 == 60_000 * 80
+    assert vis.stats()["upload_bytes"] - up0 == 59_999 * 80 + 75  # whole strides + the last element up to its last bound field
     move(70_000, 300)               # small range inside the stale region: host gather + scatter
     check()
     move(0, n)                      # the whole pool
@@ -881,3 +881,59 @@ def test_deferred_sorts_of_a_small_pool_reach_every_reader(gpu, oracle):
     assert dev.visible_idx
     g = gpu.fetch(1, write_back=False, occupancy=sc.count, order="raw")
     assert np.array_equal(canon(g, True), exp[1]["visible_idx"]) and np.all(g["distance_sq"][:-1] >= g["distance_sq"][1:])
+
+
+def test_device_gather_never_reads_past_the_callers_pool(oracle):
+    """ADVICE r1 (gv_mirror.cpp): a component whose first bound field sits above offset 0 (a header in front of `entity`),
+    bound so that the pool ENDS at the last byte before an inaccessible page, with a dirty range that reaches the last
+    slot: the device-side AoS gather must read (count - 1) strides + the extent of the bound fields, not count strides
+    from the lowest field (which would run 16 bytes into the guard page and fault). Also: a dirty mark whose
+    first + count wraps around uint32 must not be dropped."""
+    import ctypes
+    import mmap
+
+    from garden_amd.lib import GpuVisibility
+    from garden_amd.pools import TRANSFORM_DTYPE
+    n = 6000
+    sc = scene.flat_scene(n)
+    names = list(TRANSFORM_DTYPE.names)
+    dt = np.dtype(dict(names=names, formats=[TRANSFORM_DTYPE.fields[k][0] for k in names],
+                       offsets=[TRANSFORM_DTYPE.fields[k][1] + 16 for k in names], itemsize=96))
+    page = mmap.PAGESIZE
+    size = n * dt.itemsize
+    pages = (size + page - 1) // page + 1
+    mm = mmap.mmap(-1, pages * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(base + (pages - 1) * page, page, 0) == 0  # PROT_NONE guard page after the pool
+    start = (pages - 1) * page - size  # the pool's last byte is the last accessible byte
+    tr = np.frombuffer(mm, dtype=dt, count=n, offset=start)
+    for k in names:
+        tr[k] = sc.transforms[k]
+    view = scene.main_camera_view()
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(tr, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        tr["position"][1000:, :3] *= np.float32(0.5)
+        sc.transforms["position"][1000:, :3] *= np.float32(0.5)
+        vis.mark_dirty(0, 1000, n - 1000)  # >= 2048 slots, up to the last one: the device-side gather
+        up0 = vis.stats()["upload_bytes"]
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=n)
+        assert vis.stats()["upload_bytes"] - up0 == (n - 1000 - 1) * 96 + 75
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got["is_visible"], m2["isVisible"])
+        # first + count overflows uint32: saturates to "up to the end of the pool" instead of wrapping to nothing
+        tr["position"][3000:, :3] *= np.float32(0.5)
+        sc.transforms["position"][3000:, :3] *= np.float32(0.5)
+        vis.mark_dirty(0, 3000, 0xFFFFFFFF)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=n)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got["is_visible"], m2["isVisible"])
+    del tr
+    assert libc.mprotect(base + (pages - 1) * page, page, 3) == 0

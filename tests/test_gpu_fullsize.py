@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from garden_amd import scene
-from garden_amd.lib import GV_DIRTY_MESH, GV_SWEEP_MFMA, GV_SWEEP_VALU
+from garden_amd.lib import GV_SWEEP_MFMA, GV_SWEEP_VALU
 
 pytestmark = pytest.mark.gpu
 
@@ -102,30 +102,49 @@ def test_cfg3_10m_hiz_properties_and_oracle(gpu, oracle, flat10m):
     assert same_records(hz1, exp) and np.array_equal(hz1["is_visible"], m2["isVisible"])
 
 
-def test_cfg5_tile_shards_union_equals_whole(gpu, flat10m):
-    """cfg5 pattern on one GPU: the pool cut into 8 contiguous shards culled one by one (each as its own
-    mesh pool over the shared transform pool); shard lists + index base concatenate to the unsharded list."""
-    sc = flat10m
+def test_cfg5_one_world_cut_into_spatial_tiles_through_the_exchange(oracle, hier10m):
+    """cfg5 pattern on one GPU: ONE 10 M hierarchical world -> partition_world -> 8 spatial tiles (roots by position,
+    descendants follow, ids remapped), each tile culled as its own pools, its list pushed through the native exchange
+    (1-rank RCCL communicator, every transport pattern) with the tile's slot -> global-slot table applied on the
+    device — the mapped union must be the whole-world ORACLE set, isVisible included."""
+    import torch
+
+    from garden_amd.lib import GpuVisibility
+    from garden_amd.multi import partition_world, shard_capacity
+    sc = hier10m
     view = scene.main_camera_view()
-    bind(gpu, sc)
-    gpu.cull(0, [view])
-    whole = gpu.fetch(0, write_back=False, occupancy=sc.count)
-    parts, counts = [], []
-    bounds = np.linspace(0, sc.count, 9).astype(np.int64)
-    for r in range(8):
-        lo, hi = int(bounds[r]), int(bounds[r + 1])
-        shard = np.ascontiguousarray(sc.meshes[lo:hi])
-        gpu.bind_pool(1, shard)
-        if r > 0:  # same occupancy, different components: the caller reports the change (first bind uploads all)
-            gpu.mark_dirty(GV_DIRTY_MESH, 0, hi - lo, pool_id=1)
-        gpu.cull(1, [view])
-        got = gpu.fetch(0, write_back=False, occupancy=hi - lo)
-        counts.append(got["draw_count"])
-        parts.append(got["visible_idx"].astype(np.int64) + lo)
-        assert np.array_equal(got["is_visible"], whole["is_visible"][lo:hi])
-    assert sum(counts) == whole["draw_count"]
-    assert np.array_equal(np.concatenate(parts), whole["visible_idx"].astype(np.int64))
-    gpu.bind_pool(1, sc.meshes[:0])
+    m2 = sc.meshes.copy()
+    whole = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, threads=THREADS)
+    exp = np.sort(whole["visible_idx"].astype(np.int64))
+    part = partition_world(sc, (2, 2, 2))
+    sizes = [t.count for t in part.tiles]
+    assert sum(sizes) == sc.count and min(sizes) > sc.count // 16  # eight real tiles
+    union, is_visible = [], np.full(sc.count, 255, np.uint8)
+    with GpuVisibility(device=0) as vis:
+        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
+        for t, tile in enumerate(part.tiles):
+            vis.bind_transforms(tile.transforms, tile.entity_to_transform)
+            vis.bind_pool(0, tile.meshes)
+            vis.hierarchy_rebuild()
+            vis.set_index_map(0, part.mesh_global[t])
+            vis.exchange_set_mode(t % 3)  # all-gather, grouped send/recv, per-root broadcast in turn
+            vis.cull(0, [view])
+            got = vis.fetch(0, write_back=False, occupancy=tile.count)
+            cap = shard_capacity(got["draw_count"])
+            gathered = torch.zeros(1 + cap, dtype=torch.int32, device="cuda:0")
+            vis.exchange_shards(0, cap, 0, gathered.data_ptr())
+            vis.wait()
+            row = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            assert row[0] == got["draw_count"]
+            ids = row[1:1 + row[0]]
+            # the device-side table gives what the host-side map gives
+            assert np.array_equal(np.sort(ids), np.sort(part.to_global(t, got["visible_idx"])))
+            union.append(ids)
+            is_visible[part.mesh_global[t]] = got["is_visible"]
+        vis.exchange_shutdown()
+    union = np.sort(np.concatenate(union))
+    assert np.array_equal(union, exp) and exp.shape[0] > 100_000
+    assert np.array_equal(is_visible, m2["isVisible"])
 
 
 def test_10m_sort_is_sorted_permutation(gpu, flat10m):

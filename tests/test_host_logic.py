@@ -193,3 +193,116 @@ def test_worker_pool_under_thread_sanitizer(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="die_after_fork=0"))
     assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr
     assert "ThreadSanitizer" not in run.stderr, run.stderr
+
+
+# ---- world -> spatial tiles: partition_world + the exchange, against the whole-world oracle ----
+def _mixed_world(n=6000):
+    """One hierarchical world with the awkward cases: free slots, dangling parents, meshes without a transform,
+    mesh and transform pools in different orders."""
+    sc = scene.hierarchy_scene(n, depth=4, fanout=6)
+    sc = scene.shuffled_scene(sc, fraction=0.3, drop_transforms=0.02)
+    return sc
+
+
+def test_partition_world_keeps_trees_together_and_maps_back(oracle):
+    from garden_amd.multi import partition_world, tile_of_positions
+    sc = _mixed_world()
+    grid = (2, 2, 2)
+    part = partition_world(sc, grid)
+    tr = sc.transforms
+    n = sc.count
+    # every mesh and transform slot lands in exactly one tile, and the maps invert each other
+    assert sorted(np.concatenate(part.mesh_global).tolist()) == list(range(n))
+    assert sorted(np.concatenate(part.transform_global).tolist()) == list(range(tr.shape[0]))
+    for t, ts in enumerate(part.tiles):
+        assert np.array_equal(part.mesh_local[part.mesh_global[t]], np.arange(ts.count))
+        assert np.all(part.mesh_tile[part.mesh_global[t]] == t)
+        assert np.all(np.diff(part.mesh_global[t]) > 0)  # global slot order kept
+    # roots go to the tile of their position; every live descendant sits in its root's tile
+    live = tr["entity"] != 0
+    side = 100.0 * n ** (1.0 / 3.0)
+    root_tile = tile_of_positions(tr["position"][:, :3].astype(np.float64), side, grid)
+    assert np.array_equal(part.transform_tile[live], root_tile[part.root_slot][live])
+    assert len(set(part.transform_tile[live].tolist())) > 1  # really spread over tiles
+    # a tile computes the same world matrices as the whole world (chains are never cut) ...
+    world = oracle.world_matrices(tr, sc.entity_to_transform)
+    view = scene.main_camera_view()
+    whole = oracle.prepare_meshes(sc.meshes.copy(), tr, sc.entity_to_transform, view)
+    union, models = [], {}
+    for t, ts in enumerate(part.tiles):
+        lw = oracle.world_matrices(ts.transforms, ts.entity_to_transform)
+        assert np.array_equal(lw.view(np.uint32), world[part.transform_global[t]].view(np.uint32))
+        r = oracle.prepare_meshes(ts.meshes.copy(), ts.transforms, ts.entity_to_transform, view)
+        g = part.to_global(t, r["visible_idx"])
+        union.append(g)
+        for slot, bm in zip(g.tolist(), r["baked_model"]):
+            models[slot] = bm
+    # ... and the mapped union of the tiles' visible lists IS the whole-world visible set, records included
+    union = np.sort(np.concatenate(union))
+    order = np.argsort(whole["visible_idx"], kind="stable")
+    assert np.array_equal(union, whole["visible_idx"][order].astype(np.int64)) and whole["draw_count"] > 0
+    for slot, bm in zip(whole["visible_idx"][order].tolist(), whole["baked_model"][order]):
+        assert np.array_equal(models[slot].view(np.uint32), bm.view(np.uint32))
+
+
+def _tile_exchange_worker(rank, world, port, mode, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import VisibleListExchange, partition_world, shard_capacity, tile_grid
+    from oracle import oracle_py
+    sc = _mixed_world()
+    grid = tile_grid(world)
+    if grid[0] * grid[1] * grid[2] != world:  # not a power of two: slabs
+        grid = (world, 1, 1)
+    part = partition_world(sc, grid)  # every rank cuts the same world the same way and keeps its tile
+    ts = part.tiles[rank]
+    r = oracle_py.prepare_meshes(ts.meshes.copy(), ts.transforms, ts.entity_to_transform, scene.main_camera_view())
+    mine = part.to_global(rank, r["visible_idx"])  # GLOBAL mesh slots travel
+    ex = VisibleListExchange(dist, "cpu", shard_capacity(sc.count, quantum=64), mode=mode)
+    out = None
+    for frame in range(3):  # slots rotate; same lists every frame
+        shard = ex.next_shard()
+        shard[0] = mine.shape[0]
+        shard[1:1 + mine.shape[0]] = torch.from_numpy(mine.astype(np.int32))
+        out = ex.exchange()
+    ex.drain()
+    dense, counts = ex.compact(out)
+    ret[rank] = (dense.numpy().copy(), counts.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "p2p"), (2, "broadcast"), (3, "p2p")])
+def test_partitioned_world_through_the_exchange_gloo(oracle, world, mode):
+    """ONE world -> spatial tiles -> per-tile cull -> exchange (each transport pattern) -> every rank holds the
+    whole-world visible set."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_tile_exchange_worker, args=(world, port, mode, ret), nprocs=world, join=True)
+    sc = _mixed_world()
+    whole = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, scene.main_camera_view())
+    exp = np.sort(whole["visible_idx"].astype(np.int64))
+    for rank in range(world):
+        dense, counts = ret[rank]
+        assert counts.shape[0] == world and counts.sum() == exp.shape[0]
+        assert np.array_equal(np.sort(dense.astype(np.int64)), exp)
+        assert np.array_equal(dense, ret[0][0])  # same rows in the same place on every rank
+
+
+def test_bench_launch_shape_is_checked_before_the_gpu_is_touched():
+    """bench.py --gpus N vs WORLD_SIZE: a mismatch is a one-line JSON error and rc 2 — decided before torch is
+    imported, so it is the same on a box without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=env, timeout=120)
+    assert run.returncode == 2
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "error" in json.loads(lines[0])
