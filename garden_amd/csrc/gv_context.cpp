@@ -534,6 +534,10 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
             use_bounds = true;
         }
     }
+    // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
+    // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
+    static const bool emit_from_world = getenv("GV_DEBUG_EMIT_CHAIN") == nullptr;
+    const float4* emit_world = (ctx->world_valid && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
     if (p.occupancy != 0) {
         if (use_bounds) {
             bounds.lo = p.d_blk_lo.ptr;
@@ -561,7 +565,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                 vs.count_parity = other;
             }
             KernelTimer t(ctx, GV_K_EMIT);
-            GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream));
+            GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream, emit_world));
         }
         for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
             if (!batched) {
@@ -578,7 +582,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
                 ViewState& vs = ctx->views[v];
                 const uint32_t cur = vs.count_parity, other = cur ^ 1u;
                 KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other])));
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world));
                 vs.stale_chunks[other] = 0;
                 vs.stale_chunks[cur] = chunks;
                 vs.count_parity = other;
@@ -590,7 +594,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
             }
             if (ctx->views[v].emitted) {
                 KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream));
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world));
             }
         }
     }
@@ -846,7 +850,14 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
         GV_HIP(ctx, vs.sort_keys[k].reserve(n));
         GV_HIP(ctx, vs.sort_vals[k].reserve(n));
     }
-    GV_HIP(ctx, vs.sort_hist.reserve(256 * nblocks + 256));
+    // sort_hist: [2 sets][4 * 256 global digit counters + 4 tile counters, padded to 1280] + look-back words
+    constexpr size_t kSet = 1280;
+    const size_t want = 2 * kSet + 4 * nblocks * 256;
+    if (want > vs.sort_hist.cap) {
+        GV_HIP(ctx, vs.sort_hist.reserve(want));
+        GV_HIP(ctx, hipMemsetAsync(vs.sort_hist.ptr, 0, 2 * kSet * sizeof(uint32_t), ctx->stream));  // both sets start at zero
+        vs.sort_parity = 0;
+    }
     SortBuffers b;
     b.count = vs.draw_count.ptr;
     b.idx_in = vs.visible_idx.ptr;
@@ -858,9 +869,12 @@ int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
     for (int k = 0; k < 2; k++) {
         b.keys[k] = vs.sort_keys[k].ptr;
         b.vals[k] = vs.sort_vals[k].ptr;
+        b.ghist[k] = vs.sort_hist.ptr + k * kSet;
+        b.tile_counter[k] = vs.sort_hist.ptr + k * kSet + 1024;
     }
-    b.hist = vs.sort_hist.ptr + 256;
-    b.bin_total = vs.sort_hist.ptr;
+    b.status = vs.sort_hist.ptr + 2 * kSet;
+    b.parity = vs.sort_parity;
+    vs.sort_parity ^= 1u;  // this sort leaves the other set zeroed for the next one
     {
         KernelTimer t(ctx, GV_K_SORT);
         GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending != 0, ctx->stream));

@@ -210,6 +210,7 @@ struct ViewState {
     PinnedBuf<uint8_t> h_is_visible;
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;
+    uint32_t sort_parity = 0;  // which of the two counter sets in sort_hist the next large sort uses (gv_sort.hip)
     uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };

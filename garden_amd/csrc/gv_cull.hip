@@ -450,39 +450,56 @@ struct EmitArgs {
     ViewBuffers out;
     uint32_t nchunks;
     uint32_t clear_chunks;  // SELF: entries of chunk_count_next to clear (a larger pool may have used it last)
+    uint32_t direct_stores; // debug A/B: every lane stores its own 48-byte model (the round-1 form)
+    const float4* world;    // world matrices of every transform entry (3 float4 each) when a sweep of the CURRENT mirror
+                            // has just written them (gv_sweep / the fused sweep + cull), else NULL
 };
 
-// The record of visible mirror entry i at output position `rank` (mesh.cpp:169-173). Visible entries passed every
-// filter in K1: only the transform entry and its model are needed here.
-__device__ __forceinline__ void write_record(const EmitArgs& args, uint32_t i, size_t rank)
+// The camera-relative model (bakedModel) of visible mirror entry i (mesh.cpp:169-173). Visible entries passed every
+// filter in K1: only the transform entry and its model are needed here. When the world matrices of this mirror are
+// resident (args.world) the record takes world[slot] — the very product chain_model would rebuild, already in HBM as
+// 48 contiguous bytes — instead of re-walking the parent chain (4 x (32 + 8 + 4) bytes of dependent gathers at depth 3).
+__device__ __forceinline__ Mat34 record_model(const EmitArgs& args, uint32_t i)
 {
     // every gather here is a sparse 64-byte fetch for a few useful bytes: the flag byte is only read when the pool has
     // chains at all
     const bool chains = args.xf.max_depth != 0;  // uniform
-    uint32_t slot = i;
-    XfRecord rec = {};
-    if (args.mesh.mapping == kMapGeneral) {  // uniform
-        slot = args.mesh.link[i] & kSlotMask;
-        rec = gather_xf(args.xf, slot, chains);
-    } else {
-        rec = gather_xf(args.xf, i, chains);  // same speculation as K1: entry i beside (or instead of) the link word
-        if (args.mesh.mapping == kMapSpeculate) {
+    Mat34 world;
+    if (args.world) {  // uniform
+        uint32_t slot = i;
+        if (args.mesh.mapping != kMapExact)
             slot = args.mesh.link[i] & kSlotMask;
-            if (slot != i)
-                rec = gather_xf(args.xf, slot, chains);
+        const float4* w = args.world + (size_t)slot * 3;
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+        world.c0x = w0.x; world.c0y = w0.y; world.c0z = w0.z;
+        world.c1x = w0.w; world.c1y = w1.x; world.c1z = w1.y;
+        world.c2x = w1.z; world.c2y = w1.w; world.c2z = w2.x;
+        world.c3x = w2.y; world.c3y = w2.z; world.c3z = w2.w;
+    } else {
+        uint32_t slot = i;
+        XfRecord rec = {};
+        if (args.mesh.mapping == kMapGeneral) {  // uniform
+            slot = args.mesh.link[i] & kSlotMask;
+            rec = gather_xf(args.xf, slot, chains);
+        } else {
+            rec = gather_xf(args.xf, i, chains);  // same speculation as K1: entry i beside (or instead of) the link word
+            if (args.mesh.mapping == kMapSpeculate) {
+                slot = args.mesh.link[i] & kSlotMask;
+                if (slot != i)
+                    rec = gather_xf(args.xf, slot, chains);
+            }
         }
+        world = chain_model(args.xf, local_model(rec), slot, rec.flags);
     }
-    const Mat34 world = chain_model(args.xf, local_model(rec), slot, rec.flags);
-    const Mat34 m = translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
-    args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
-    float4* bm = reinterpret_cast<float4*>(args.out.baked_model + rank * 12);
-    bm[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
-    bm[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
-    bm[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    return translated(world, args.view.cam[0], args.view.cam[1], args.view.cam[2]);
+}
+
+__device__ __forceinline__ float record_distance(const EmitArgs& args, const Mat34& m)
+{
     const float tx = m.c3x + args.view.cam_offset[0];
     const float ty = m.c3y + args.view.cam_offset[1];
     const float tz = m.c3z + args.view.cam_offset[2];
-    args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+    return args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
 }
 
 // position of the k-th (0-based) set bit of `word`
@@ -518,6 +535,7 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     __shared__ unsigned long long words[64];
     __shared__ uint32_t prefix[65];
     __shared__ uint32_t below[4];
+    __shared__ float4 stage[256 * 3];  // the round's 256 models, record-major
     const uint32_t chunk = block / kEmitParts, part = block % kEmitParts;
     const uint32_t first_word = chunk * 64;
     const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
@@ -573,19 +591,40 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     }
     const uint32_t wlo = part * (64 / kEmitParts), whi = wlo + 64 / kEmitParts;
     const uint32_t total = prefix[whi];
-    for (uint32_t r = prefix[wlo] + threadIdx.x; r < total; r += 256) {
-        uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
+    // 256 consecutive output records per round (uniform trip count). Each lane builds one record; the 48-byte models go
+    // through LDS so that they leave as whole rows — lane k stores float4 k, k + 256, k + 512 of the round's contiguous
+    // 12 KB — instead of three 16-byte pieces per lane at a 48-byte stride.
+    for (uint32_t r0 = prefix[wlo]; r0 < total; r0 += 256) {
+        const uint32_t r = r0 + threadIdx.x;
+        if (r < total) {
+            uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
 #pragma unroll
-        for (uint32_t span = 64 / kEmitParts; span > 1; span >>= 1) {  // log2(words per workgroup) halvings
-            const uint32_t mid = (lo + hi) >> 1;
-            if (prefix[mid] <= r)
-                lo = mid;
-            else
-                hi = mid;
+            for (uint32_t span = 64 / kEmitParts; span > 1; span >>= 1) {  // log2(words per workgroup) halvings
+                const uint32_t mid = (lo + hi) >> 1;
+                if (prefix[mid] <= r)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const uint32_t pos = select_bit(words[lo], r - prefix[lo]);
+            const uint32_t i = (first_word + lo) * 64 + pos;
+            const Mat34 m = record_model(args, i);
+            const size_t rank = (size_t)base + r;
+            args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
+            args.out.distance_sq[rank] = record_distance(args, m);
+            float4* row = args.direct_stores ? reinterpret_cast<float4*>(args.out.baked_model) + rank * 3 : stage + threadIdx.x * 3;
+            row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+            row[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+            row[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
         }
-        const uint32_t pos = select_bit(words[lo], r - prefix[lo]);
-        const uint32_t i = (first_word + lo) * 64 + pos;
-        write_record(args, i, (size_t)base + r);
+        if (args.direct_stores)  // uniform (debug A/B: GV_DEBUG_EMIT_DIRECT_STORES)
+            continue;
+        __syncthreads();
+        const uint32_t quads = min(256u, total - r0) * 3u;
+        float4* dst = reinterpret_cast<float4*>(args.out.baked_model) + ((size_t)base + r0) * 3;
+        for (uint32_t q = threadIdx.x; q < quads; q += 256)
+            dst[q] = stage[q];
+        __syncthreads();  // the stage is rewritten by the next round
     }
 }
 
@@ -600,6 +639,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 struct EmitBatchArgs {
     MeshMirror mesh;
     TransformMirror xf;
+    const float4* world;
     uint32_t nchunks;
     uint32_t clear_chunks[kMaxBatchViews];
     ViewParams view[kMaxBatchViews];
@@ -614,17 +654,20 @@ __global__ __launch_bounds__(256) void emit_batch_kernel(const EmitBatchArgs bat
     args.out = batch.out[blockIdx.y];
     args.nchunks = batch.nchunks;
     args.clear_chunks = batch.clear_chunks[blockIdx.y];
+    args.world = batch.world;
+    args.direct_stores = 0;
     emit_block<true>(args, blockIdx.x);
 }
 
 hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
-                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream)
+                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream, const float4* world)
 {
     if (mesh.count == 0 || nviews == 0)
         return hipSuccess;
     EmitBatchArgs a;
     a.mesh = mesh;
     a.xf = xf;
+    a.world = world;
     a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
     for (uint32_t v = 0; v < kMaxBatchViews; v++) {
         const uint32_t k = v < nviews ? v : 0;
@@ -637,11 +680,14 @@ hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, 
 }
 
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks)
+                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks, const float4* world)
 {
     if (mesh.count == 0)
         return hipSuccess;
     EmitArgs a;
+    a.world = world;
+    static const uint32_t direct = getenv("GV_DEBUG_EMIT_DIRECT_STORES") ? 1u : 0u;
+    a.direct_stores = direct;
     a.mesh = mesh;
     a.xf = xf;
     a.view = vp;

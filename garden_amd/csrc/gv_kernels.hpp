@@ -111,11 +111,13 @@ hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t
 // self_prefix: every emit workgroup derives its chunk's base from the chunk totals itself (no launch_scan in front;
 // pools of up to kSelfPrefixMaxChunks chunks); out.chunk_count / chunk_count_next then alternate from cull to cull.
 constexpr uint32_t kSelfPrefixMaxChunks = 4096;
+// world: the resident world matrices of the current transform mirror (3 float4 per entry), or NULL — records then take
+// world[slot] instead of re-walking the parent chain (same bits)
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0);
+                       hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0, const float4* world = nullptr);
 // all views of a batched cull in one launch (self-prefixing form; views[v] / outs[v] / clear_chunks[v] per view)
 hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
-                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream);
+                             const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream, const float4* world = nullptr);
 // map: pool slot -> caller's global id (NULL: identity), applied before `base`
 hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                            const uint32_t* map, hipStream_t stream);
@@ -155,10 +157,13 @@ struct SortBuffers {
     uint32_t* idx_out;
     float* model_out;
     float* dist_out;
-    uint32_t* keys[2];
+    // large pools (onesweep radix sort, gv_sort.hip):
+    uint32_t* keys[2];          // (key, record index) pairs, ping-pong
     uint32_t* vals[2];
-    uint32_t* hist;       // 256 * ceil(capacity / 4096), bin-major
-    uint32_t* bin_total;  // 256
+    uint32_t* ghist[2];         // global digit histograms [4][256], two sets: a sort uses set `parity` (zero on entry)
+    uint32_t* tile_counter[2];  // dynamic tile counters [4] per set         and zeroes the other one for the next sort
+    uint32_t* status;           // decoupled look-back words [4][ceil(capacity / 4096)][256]
+    uint32_t parity;
 };
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 // pools of up to this many slots sort in one launch (rank sort, gv_sort.hip); gv_sort defers those so that the views of

@@ -579,6 +579,47 @@ void gvo_pool_run(void* (*fn)(void*), void** args, int count, int threads)
     pthread_mutex_unlock(&g_pool_run);
 }
 
+/* threadMeshes[threadIndex] (mesh.cpp:127-131): per-task record scratch that persists from frame to frame and only
+ * grows (mesh.cpp:377-395), so a frame costs no allocation and no fresh-page faults. Not re-entrant across concurrent
+ * gvo_prepare_meshes* calls (neither is the reference's MeshRenderSystem). */
+typedef struct Scratch {
+    uint32_t* idx;
+    float* model;
+    float* dist;
+    uint32_t cap;
+} Scratch;
+static Scratch* g_scratch = NULL;
+static uint32_t g_scratch_count = 0;
+static pthread_mutex_t g_scratch_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t g_scratch_owner = PTHREAD_MUTEX_INITIALIZER;
+/* one threaded prepare at a time owns the scratch (lock before the first gvo_thread_scratch, unlock after the run) */
+void gvo_scratch_lock(void) { pthread_mutex_lock(&g_scratch_owner); }
+void gvo_scratch_unlock(void) { pthread_mutex_unlock(&g_scratch_owner); }
+void gvo_thread_scratch(uint32_t index, uint32_t records, GvoCullOut* out)
+{
+    pthread_mutex_lock(&g_scratch_mu);
+    if (index >= g_scratch_count) {
+        const uint32_t want = index + 1;
+        g_scratch = (Scratch*)realloc(g_scratch, sizeof(Scratch) * want);
+        memset(g_scratch + g_scratch_count, 0, sizeof(Scratch) * (want - g_scratch_count));
+        g_scratch_count = want;
+    }
+    Scratch* s = &g_scratch[index];
+    if (records > s->cap) {
+        free(s->idx);
+        free(s->model);
+        free(s->dist);
+        s->idx = (uint32_t*)malloc((size_t)records * 4);
+        s->model = (float*)malloc((size_t)records * 48);
+        s->dist = (float*)malloc((size_t)records * 4);
+        s->cap = records;
+    }
+    out->visible_idx = s->idx;
+    out->baked_model = s->model;
+    out->distance_sq = s->dist;
+    pthread_mutex_unlock(&g_scratch_mu);
+}
+
 typedef struct RangeTask {
     const GvoMeshPool* mp;
     const GvoTransformPool* tp;
@@ -625,6 +666,7 @@ void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const
     pthread_t* tids = (pthread_t*)calloc(task_count, sizeof(pthread_t));
     _Atomic uint32_t draw_count = 0, instance_count = 0;
     uint32_t launched = 0;
+    gvo_scratch_lock();
     for (uint32_t i = 0; i < task_count; i++) {
         RangeTask* t = &tasks[i];
         t->item_offset = count_per_thread * i;
@@ -634,9 +676,7 @@ void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const
         const uint32_t n = t->item_end - t->item_offset;
         t->mp = mp; t->tp = tp; t->view = view; t->frustum = &frustum; t->hiz = hiz;
         t->combined = out; t->draw_count = &draw_count; t->instance_count = &instance_count;
-        t->local.visible_idx = (uint32_t*)malloc((size_t)n * 4);
-        t->local.baked_model = (float*)malloc((size_t)n * 48);
-        t->local.distance_sq = (float*)malloc((size_t)n * 4);
+        gvo_thread_scratch(i, n, &t->local);
         launched = i + 1;
     }
     /* foreground pool: the calling thread participates (ThreadPool::wait  thread-pool.cpp:203-215) */
@@ -647,11 +687,7 @@ void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const
             argv[argc++] = &tasks[i];
     gvo_pool_run(range_task_main, argv, argc, (int)threads);
     free(argv);
-    for (uint32_t i = 0; i < task_count; i++) {
-        free(tasks[i].local.visible_idx);
-        free(tasks[i].local.baked_model);
-        free(tasks[i].local.distance_sq);
-    }
+    gvo_scratch_unlock();
     out->draw_count = atomic_load(&draw_count);
     out->instance_count = atomic_load(&instance_count);
     free(tasks);

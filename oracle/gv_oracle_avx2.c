@@ -265,6 +265,10 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
     out->instance_count = instance_count;
 }
 
+void gvo_thread_scratch(uint32_t index, uint32_t records, GvoCullOut* out);
+void gvo_scratch_lock(void);
+void gvo_scratch_unlock(void);
+
 typedef struct Task8 {
     const GvoSoa* s; const GvoMeshPool* mp; const GvoView* view; const GvoFrustum* fr; const GvoHiz* hiz;
     uint32_t lo, hi; GvoCullOut local; GvoCullOut* combined; _Atomic uint32_t* draw; _Atomic uint32_t* inst;
@@ -300,22 +304,21 @@ void gvo_prepare_meshes_avx2(const GvoSoa* s, const GvoMeshPool* mp, const GvoVi
     Task8* tasks = (Task8*)calloc(task_count, sizeof(Task8));
     pthread_t* tids = (pthread_t*)calloc(task_count, sizeof(pthread_t));
     _Atomic uint32_t draw = 0, inst = 0;
+    gvo_scratch_lock();
     for (uint32_t i = 0; i < task_count; i++) {
         Task8* t = &tasks[i];
         t->lo = per * i; t->hi = count < t->lo + per ? count : t->lo + per;
         if (t->lo >= t->hi) continue;
         const uint32_t n = t->hi - t->lo;
         t->s = s; t->mp = mp; t->view = view; t->fr = &fr; t->hiz = hiz; t->combined = out; t->draw = &draw; t->inst = &inst;
-        t->local.visible_idx = (uint32_t*)malloc((size_t)n * 4);
-        t->local.baked_model = (float*)malloc((size_t)n * 48);
-        t->local.distance_sq = (float*)malloc((size_t)n * 4);
+        gvo_thread_scratch(i, n, &t->local); /* threadMeshes[threadIndex]: persistent, grow-only  mesh.cpp:377-395 */
     }
     void** argv = (void**)malloc(sizeof(void*) * task_count);
     int argc = 0;
     for (uint32_t i = 0; i < task_count; i++) if (tasks[i].s) argv[argc++] = &tasks[i];
     gvo_pool_run(task8_main, argv, argc, (int)threads);
     free(argv);
-    for (uint32_t i = 0; i < task_count; i++) { free(tasks[i].local.visible_idx); free(tasks[i].local.baked_model); free(tasks[i].local.distance_sq); }
+    gvo_scratch_unlock();
     out->draw_count = atomic_load(&draw);
     out->instance_count = atomic_load(&inst);
     free(tasks); free(tids);

@@ -10,7 +10,7 @@ with GpuVisibility(profile_events=True) as vis:
         for _ in range(3):
             vis.cull(0, [v]); vis.sort(0)
         vis.wait(); vis.stats_reset()
-        for _ in range(10):
+        for _ in range(50):
             vis.cull(0, [v]); vis.sort(0)
         vis.wait(); st = vis.stats()
-        print(f"{label}: {vis.result_count(0)} records; gv_sort {st['device_ms']['sort']/10*1e3:.1f} us (cull {st['device_ms']['cull']/10*1e3:.1f}, emit {st['device_ms']['emit']/10*1e3:.1f})")
+        print(f"{label}: {vis.result_count(0)} records; gv_sort {st['device_ms']['sort']/50*1e3:.1f} us (cull {st['device_ms']['cull']/50*1e3:.1f}, emit {st['device_ms']['emit']/50*1e3:.1f})")
