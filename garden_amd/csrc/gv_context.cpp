@@ -96,6 +96,17 @@ ViewBuffers view_buffers(ViewState& vs)
     return b;
 }
 
+// The world-matrix cache has just been brought up to date (any sweep): the re-mirror flags start over.
+int world_current(GvCtx* ctx)
+{
+    if (ctx->xdirty_set && ctx->d_xdirty.ptr)
+        GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr, 0, std::min<size_t>(ctx->d_xdirty.cap, ctx->xf.occupancy), ctx->stream));
+    ctx->xdirty_set = false;
+    ctx->world_partial = false;
+    ctx->world_valid = true;
+    return GV_OK;
+}
+
 int hiz_reduce(GvCtx* ctx)
 {
     ctx->hiz_level1_stored = false;
@@ -262,7 +273,7 @@ void gv_destroy(GvCtx* ctx)
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
     }
-    ctx->d_world.release(); ctx->d_raw.release(); ctx->d_examined.release();
+    ctx->d_world.release(); ctx->d_xdirty.release(); ctx->d_raw.release(); ctx->d_examined.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_raw[k].release();
         if (ctx->raw_done[k])
@@ -507,7 +518,8 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
             else
                 GV_HIP(ctx, launch_sweep_valu(xf, ctx->d_world.ptr, ctx->stream));
         }
-        ctx->world_valid = true;
+        if ((rc = world_current(ctx)) != GV_OK)  // (the fused form below writes every slot of the same buffer)
+            return rc;
     }
     // GV_CONFIG_BLOCK_BOUNDS: workgroup boxes are (re)built when the mirror of this pool is clean, or has just changed
     // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
@@ -537,7 +549,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
     // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
     static const bool emit_from_world = getenv("GV_DEBUG_EMIT_CHAIN") == nullptr;
-    const float4* emit_world = (ctx->world_valid && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
+    const float4* emit_world = (ctx->world_valid && !ctx->world_partial && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
     if (p.occupancy != 0) {
         if (use_bounds) {
             bounds.lo = p.d_blk_lo.ptr;
@@ -896,30 +908,35 @@ int gv_sweep(GvCtx* ctx, uint32_t mode)
         ctx->sweep_with_cull_mfma = mode == GV_SWEEP_WITH_CULL;
         return GV_OK;
     }
-    if (mode != GV_SWEEP_VALU && mode != GV_SWEEP_MFMA)
+    if (mode != GV_SWEEP_VALU && mode != GV_SWEEP_MFMA && mode != GV_SWEEP_INCREMENTAL)
         return ctx->fail(GV_E_ARG, "gv_sweep: unknown mode %u", mode);
     int rc = sync_mirror(ctx);
     if (rc != GV_OK)
         return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = ctx->xf.occupancy;
-    GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(n, 1u) * 3));
+    if (mode == GV_SWEEP_INCREMENTAL && ctx->world_valid && !ctx->world_partial)
+        return GV_OK;  // the cache is current: nothing to launch
+    const bool subtree = mode == GV_SWEEP_INCREMENTAL && ctx->world_valid && ctx->world_partial;
+    if (!subtree)
+        GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(n, 1u) * 3));
     {
         KernelTimer t(ctx, GV_K_SWEEP);
-        if (mode == GV_SWEEP_MFMA)
+        if (subtree)
+            GV_HIP(ctx, launch_sweep_subtree(xf_mirror(ctx), ctx->d_xdirty.ptr, ctx->d_world.ptr, ctx->stream));
+        else if (mode == GV_SWEEP_MFMA)
             GV_HIP(ctx, launch_sweep_mfma(xf_mirror(ctx), ctx->d_world.ptr, ctx->stream));
         else
             GV_HIP(ctx, launch_sweep_valu(xf_mirror(ctx), ctx->d_world.ptr, ctx->stream));
     }
-    ctx->world_valid = true;
-    return GV_OK;
+    return world_current(ctx);
 }
 
 int gv_get_world(GvCtx* ctx, uint32_t first, uint32_t count, float* out12)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!ctx->world_valid)
+    if (!ctx->world_valid || ctx->world_partial)
         return ctx->fail(GV_E_STATE, "gv_get_world: gv_sweep has not run since the last transform change");
     if (!out12 || (uint64_t)first + count > ctx->xf.occupancy)
         return ctx->fail(GV_E_ARG, "gv_get_world: range [%u, +%u) outside the pool", first, count);

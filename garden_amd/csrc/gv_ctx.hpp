@@ -139,6 +139,62 @@ struct DirtyRange {
     }
 };
 
+// Itemised dirty marks of the transform pool (setPosition on scattered entities, transform.hpp:74-104): kept as disjoint
+// ranges instead of one covering range, so a handful of moved entities at opposite ends of a 10 M pool re-mirror a
+// handful of slots, not everything in between. Overlapping and adjacent ranges are merged; beyond kMax ranges, ranges
+// closer than a growing `gap` are merged too until they fit.
+struct DirtyRanges {
+    struct R {
+        uint32_t lo, hi;
+    };
+    std::vector<R> items;
+    static constexpr size_t kMax = 16384;
+    bool any() const { return !items.empty(); }
+    void clear() { items.clear(); }
+    void add(uint32_t first, uint32_t count)
+    {
+        if (count == 0)
+            return;
+        const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)first + count, UINT32_MAX);  // saturating, see DirtyRange
+        if (!items.empty() && first <= items.back().hi && hi >= items.back().lo) {  // extends / overlaps the last mark
+            items.back().lo = std::min(items.back().lo, first);
+            items.back().hi = std::max(items.back().hi, hi);
+            return;
+        }
+        items.push_back({first, hi});
+        if (items.size() > 4 * kMax)
+            normalise(UINT32_MAX, 0);
+    }
+    // sorted, clamped to [0, limit), merged
+    void normalise(uint32_t limit, uint32_t gap)
+    {
+        for (auto& r : items)
+            r.hi = std::min(r.hi, limit);
+        items.erase(std::remove_if(items.begin(), items.end(), [](const R& r) { return r.lo >= r.hi; }), items.end());
+        std::sort(items.begin(), items.end(), [](const R& a, const R& b) { return a.lo < b.lo; });
+        for (;;) {
+            std::vector<R> merged;
+            for (const R& r : items) {
+                if (!merged.empty() && (uint64_t)r.lo <= (uint64_t)merged.back().hi + gap)
+                    merged.back().hi = std::max(merged.back().hi, r.hi);
+                else
+                    merged.push_back(r);
+            }
+            items.swap(merged);
+            if (items.size() <= kMax || gap >= (1u << 30))
+                break;
+            gap = gap ? gap * 2 : 1;
+        }
+    }
+    uint64_t total() const
+    {
+        uint64_t t = 0;
+        for (const R& r : items)
+            t += r.hi - r.lo;
+        return t;
+    }
+};
+
 // One field of a bound pool: element i lives at ptr + i * stride. An AoS pool binds every field with the component
 // stride and its offset folded into ptr; column (SoA) storage binds each field with its own array and element size.
 struct Column {
@@ -232,7 +288,7 @@ struct Context {
     TransformBinding xf;
     bool xf_need_full = false;     // (re)build the whole mirror at the next sync
     bool xf_links_dirty = false;   // a ranged GV_DIRTY_HIERARCHY: parent links changed -> re-validate depth / cycles
-    DirtyRange xf_dirty;
+    DirtyRanges xf_dirty;
     uint64_t xf_epoch = 1;         // bumped whenever the transform mirror changes
     uint32_t xf_mirrored = 0, xf_appended = 0;  // as PoolState::mirrored / appended, for the transform pool
     uint32_t max_depth = 0;        // longest parent chain in the mirror
@@ -271,7 +327,10 @@ struct Context {
 
     // ---- world-matrix cache (gv_sweep) ----
     DeviceBuf<float4> d_world;
-    bool world_valid = false;
+    bool world_valid = false;          // d_world holds the world matrices of the current mirror, except ...
+    bool world_partial = false;        // ... for the chains through entries flagged in d_xdirty (subtree-scoped sweep)
+    bool xdirty_set = false;           // some flag in d_xdirty may be 1
+    DeviceBuf<uint8_t> d_xdirty;       // 1 byte per transform mirror entry: re-mirrored since the cache was brought up to date
     bool sweep_with_cull = false;      // GV_SWEEP_WITH_CULL[_VALU] requested: the next gv_cull also writes the world matrices
     bool sweep_with_cull_mfma = true;  // ... with the MFMA or the VALU chain
 

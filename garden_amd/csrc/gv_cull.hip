@@ -760,7 +760,8 @@ hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned lon
 __global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __restrict__ raw, AosTransformLayout L,
                                                              uint32_t first, uint32_t count,
                                                              const uint32_t* __restrict__ xinv, XfAB* __restrict__ ab,
-                                                             float2* __restrict__ c, uint8_t* __restrict__ flags)
+                                                             float2* __restrict__ c, uint8_t* __restrict__ flags,
+                                                             uint8_t* __restrict__ dirty)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count)
@@ -785,15 +786,31 @@ __global__ __launch_bounds__(256) void aos_transforms_kernel(const uint8_t* __re
     ab[j].b = make_float4(rot[0], rot[1], rot[2], rot[3]);
     c[j] = make_float2(scl[1], scl[2]);
     flags[j] = f;
+    if (dirty)
+        dirty[j] = 1;
 }
 
 hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
-                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, hipStream_t stream)
+                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, uint8_t* dirty, hipStream_t stream)
 {
     if (count == 0)
         return hipSuccess;
     hipLaunchKernelGGL(aos_transforms_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, xinv,
-                       ab, c, flags);
+                       ab, c, flags, dirty);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mark_bytes_kernel(const uint32_t* __restrict__ idx, uint32_t count, uint8_t* __restrict__ dst)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+        dst[idx[k]] = 1;
+}
+
+hipError_t launch_mark_bytes(const uint32_t* idx, uint32_t count, uint8_t* dst, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(mark_bytes_kernel, dim3(min((count + 255u) / 256u, 4096u)), dim3(256), 0, stream, idx, count, dst);
     return hipGetLastError();
 }
 

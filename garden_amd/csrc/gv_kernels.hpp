@@ -180,8 +180,9 @@ hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint3
 struct AosTransformLayout {
     uint32_t stride, entity, position, scale, rotation, self_active, ancestors_active, model_with_ancestors;
 };
+// dirty (may be NULL): set to 1 for every entry written (subtree-scoped world-matrix sweep)
 hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
-                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, hipStream_t stream);
+                                 const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, uint8_t* dirty, hipStream_t stream);
 hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream);
 // dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
 hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
@@ -193,6 +194,10 @@ hipError_t launch_gather_world(const float4* world, const uint32_t* xinv, uint32
 // world matrices (camera = 0) of every transform slot: 3 float4 per slot (float4x3 order)
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream);
 hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream);
+// only the entries whose chain contains an entry flagged in dirty[] (1 byte per mirror entry); same bits
+hipError_t launch_sweep_subtree(const TransformMirror& xf, const uint8_t* dirty, float4* world, hipStream_t stream);
+// dirty[idx[k]] = 1 for k < count (entries re-mirrored through the scattered dirty-range path)
+hipError_t launch_mark_bytes(const uint32_t* idx, uint32_t count, uint8_t* dst, hipStream_t stream);
 // Sweep (MFMA or VALU chain) + cull of an exactly paired pool (mesh.mapping == kMapExact) in one pass: world matrices AND the cull
 // outputs of one view; same bits as launch_sweep_* followed by launch_cull.
 hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,

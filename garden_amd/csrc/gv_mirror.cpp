@@ -367,6 +367,13 @@ bool aos_transform_layout(const TransformBinding& xf, const uint8_t** base, AosT
 // extent of one element, so a layout whose first field sits above offset 0 never reads past the caller's pool. The
 // host staging of those slots goes stale and is refreshed only if a host path needs it later. Returns GV_E_STATE when
 // the path is not applicable.
+// The world-matrix cache (gv_sweep) survives a dirty range when every re-mirrored entry is flagged for the subtree-scoped
+// sweep. True while the cache is valid and the flag array covers the mirror.
+bool track_world_dirty(GvCtx* ctx)
+{
+    return ctx->world_valid && ctx->d_xdirty.ptr && ctx->d_xdirty.cap >= ctx->xf.occupancy;
+}
+
 int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
 {
     const uint8_t* base = nullptr;
@@ -414,7 +421,8 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         GV_HIP(ctx, hipEventRecord(ctx->raw_done[turn], ctx->stream));
     }
     GV_HIP(ctx, launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xab.ptr,
-                                      ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->stream));
+                                      ctx->d_xc.ptr, ctx->d_xflags.ptr, track_world_dirty(ctx) ? ctx->d_xdirty.ptr : nullptr,
+                                      ctx->stream));
     ctx->staging_stale.add(lo, count);
     ctx->stats.upload_bytes += bytes;
     return GV_OK;
@@ -481,6 +489,8 @@ int reserve_scatter(GvCtx* ctx, size_t n)
     return GV_OK;
 }
 
+bool track_world_dirty(GvCtx* ctx);
+
 // one stream of a scattered packet: host packet -> device packet -> dst[idx[k]] = packet[k]
 template <typename T>
 int scatter_stream(GvCtx* ctx, const T* host_packet, T* device_packet, T* dst, uint32_t n)
@@ -490,30 +500,40 @@ int scatter_stream(GvCtx* ctx, const T* host_packet, T* device_packet, T* dst, u
     return GV_OK;
 }
 
-// Dirty pool slots [lo, hi) of a permuted mirror land on scattered entries: ship them as one compact packet
-// {entry, record} and scatter on the device.
-int upload_transforms_scattered(GvCtx* ctx, uint32_t lo, uint32_t hi)
+// Dirty pool slots of a permuted mirror land on scattered entries: ship ALL the dirty ranges of a sync as one compact
+// packet {entry, record} and scatter on the device (one packet, one synchronisation, however many ranges).
+int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& ranges)
 {
-    const uint32_t n = hi - lo;
+    std::vector<uint32_t> start(ranges.size() + 1, 0);
+    for (size_t k = 0; k < ranges.size(); k++)
+        start[k + 1] = start[k] + (ranges[k].hi - ranges[k].lo);
+    const uint32_t n = start.back();
+    if (n == 0)
+        return GV_OK;
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
         return rc;
-    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
-        for (uint32_t k = a; k < b; k++) {
-            const uint32_t j = ctx->xinv[lo + k];
-            ctx->sc_idx.ptr[k] = j;
-            ctx->sc_ab.ptr[k] = ctx->h_xab.ptr[j];
-            ctx->sc_c.ptr[k] = ctx->h_xc.ptr[j];
-            ctx->sc_u8.ptr[k] = ctx->h_xflags.ptr[j];
-            ctx->sc_u32.ptr[k] = ctx->h_xparent.ptr[j];
-        }
-    });
+    for (size_t q = 0; q < ranges.size(); q++) {
+        const uint32_t lo = ranges[q].lo, base = start[q];
+        parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
+            for (uint32_t k = a; k < b; k++) {
+                const uint32_t j = ctx->xinv[lo + k];
+                ctx->sc_idx.ptr[base + k] = j;
+                ctx->sc_ab.ptr[base + k] = ctx->h_xab.ptr[j];
+                ctx->sc_c.ptr[base + k] = ctx->h_xc.ptr[j];
+                ctx->sc_u8.ptr[base + k] = ctx->h_xflags.ptr[j];
+                ctx->sc_u32.ptr[base + k] = ctx->h_xparent.ptr[j];
+            }
+        });
+    }
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = scatter_stream(ctx, ctx->sc_ab.ptr, ctx->dsc_ab.ptr, ctx->d_xab.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, ctx->d_xc.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_u8.ptr, ctx->dsc_u8.ptr, ctx->d_xflags.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, ctx->d_xparent.ptr, n)) != GV_OK) return rc;
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the packet buffers are reused by the next dirty range
+    if (track_world_dirty(ctx))
+        GV_HIP(ctx, launch_mark_bytes(ctx->dsc_idx.ptr, n, ctx->d_xdirty.ptr, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the packet buffers are reused by the next sync
     ctx->stats.upload_bytes += (size_t)n * (4 + 45);
     return GV_OK;
 }
@@ -585,7 +605,10 @@ int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
     GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n1, ctx->d_xactive.ptr, ctx->stream));
     ctx->xf_mirrored = n1;
     ctx->xf_appended += n1 - n0;
-    ctx->world_valid = false;
+    ctx->world_valid = false;  // (d_world is sized at the next sweep; appended entries have no matrix yet)
+    ctx->world_partial = false;
+    GV_HIP(ctx, ctx->d_xdirty.grow(n1, n0, ctx->stream));
+    GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr + n0, 0, ctx->d_xdirty.cap - n0, ctx->stream));
     ctx->xf_epoch++;
     return GV_OK;
 }
@@ -691,6 +714,10 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_dirty.clear();
         ctx->staging_stale.clear();  // everything was gathered afresh
         ctx->world_valid = false;
+        ctx->world_partial = false;
+        GV_HIP(ctx, ctx->d_xdirty.reserve(cap));
+        GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr, 0, ctx->d_xdirty.cap, ctx->stream));
+        ctx->xdirty_set = false;
         ctx->xf_epoch++;
         ctx->xf_mirrored = n;
         ctx->xf_appended = 0;
@@ -708,21 +735,48 @@ int sync_mirror(GvCtx* ctx)
       if (ctx->xf_dirty.any()) {
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         staged = true;
-        const uint32_t lo = ctx->xf_dirty.lo, hi = std::min(ctx->xf_dirty.hi, n);
-        if (lo < hi) {
-            int rc = GV_E_STATE;
-            if (!ctx->xf_links_dirty && hi - lo >= 2048)
-                rc = upload_transforms_device(ctx, lo, hi);  // raw AoS span + device gather (falls through if not applicable)
-            if (rc == GV_OK) {
-                // done on the device
-            } else if (rc != GV_E_STATE) {
-                return rc;
-            } else if ((size_t)(hi - lo) * 2 > n) {
-                refresh_stale_staging(ctx);  // this path re-uploads every entry from the staging arrays
-                rc = regather_transforms_pipelined(ctx, lo, hi);  // most of the pool: dense, chunked, DMA under gather
+        ctx->xf_dirty.normalise(n, 0);  // exact: a re-mirrored slot is a flagged slot (its whole subtree is re-swept)
+        const std::vector<DirtyRanges::R> ranges = ctx->xf_dirty.items;
+        const uint64_t total = ctx->xf_dirty.total();
+        if (total) {
+            const uint32_t lo = ranges.front().lo, hi = ranges.back().hi;  // the covering range
+            int rc = GV_OK;
+            bool dense = false;
+            if (total * 2 > n) {
+                // most of the pool: one pass over the covering range (re-mirroring a clean slot is harmless)
+                rc = GV_E_STATE;
+                if (!ctx->xf_links_dirty)
+                    rc = upload_transforms_device(ctx, lo, hi);  // raw AoS span + device gather (GV_E_STATE: not applicable)
+                if (rc == GV_E_STATE) {
+                    refresh_stale_staging(ctx);  // this path re-uploads every entry from the staging arrays
+                    rc = regather_transforms_pipelined(ctx, lo, hi);  // dense, chunked, DMA under gather
+                }
+                dense = true;
             } else {
-                gather_transforms(ctx, lo, hi);
-                rc = ctx->xinv.empty() ? upload_transforms(ctx, lo, hi) : upload_transforms_scattered(ctx, lo, hi);
+                // itemised: large ranges take the device-side gather, everything else travels as ONE scattered packet
+                // (or as plain ranged copies when the mirror is in slot order)
+                std::vector<DirtyRanges::R> host;
+                for (const auto& r : ranges) {
+                    int one = GV_E_STATE;
+                    if (!ctx->xf_links_dirty && r.hi - r.lo >= 2048)
+                        one = upload_transforms_device(ctx, r.lo, r.hi);
+                    if (one == GV_E_STATE)
+                        host.push_back(r);
+                    else if (one != GV_OK)
+                        return one;
+                }
+                for (const auto& r : host)
+                    gather_transforms(ctx, r.lo, r.hi);
+                if (ctx->xinv.empty()) {
+                    for (const auto& r : host) {
+                        if ((rc = upload_transforms(ctx, r.lo, r.hi)) != GV_OK)
+                            break;
+                        if (track_world_dirty(ctx))
+                            GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr + r.lo, 1, r.hi - r.lo, ctx->stream));
+                    }
+                } else {
+                    rc = upload_transforms_scattered(ctx, host);
+                }
             }
             if (rc != GV_OK)
                 return rc;
@@ -736,11 +790,18 @@ int sync_mirror(GvCtx* ctx)
                 }
                 ctx->max_depth = depth;
             }
+            if (track_world_dirty(ctx) && !dense) {
+                ctx->xdirty_set = true;     // (the upload paths above flagged what they wrote)
+                ctx->world_partial = true;  // the cache stays, minus the chains through the flagged entries
+            } else {
+                if (track_world_dirty(ctx))
+                    ctx->xdirty_set = true;
+                ctx->world_valid = false;   // most of the pool moved: a full sweep is cheaper than walking flags
+            }
+            ctx->xf_epoch++;
         }
         ctx->xf_links_dirty = false;
         ctx->xf_dirty.clear();
-        ctx->world_valid = false;
-        ctx->xf_epoch++;
       }
     }
     for (auto& p : ctx->pools) {

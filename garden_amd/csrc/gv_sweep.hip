@@ -26,6 +26,55 @@ __global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror x
     stream_store(&world[(size_t)s * 3 + 2], w2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Subtree-scoped sweep (the reference recomputes lazily per calcModel call, transform.hpp:197-214, and
+// marks nothing): `dirty[e]` is 1 for every mirror entry whose TRS / flags / parent link were re-mirrored since the
+// world-matrix cache was last brought up to date. An entry's world matrix is stale iff its chain — itself or any
+// ancestor — contains a dirty entry, so every lane walks its chain over the 1-byte flags and the 4-byte links (the
+// ancestors' lines are shared by their whole subtree: cache hits) and only stale entries pay the TRS gathers, the
+// products and the 48-byte store: 5-10 B per clean entry instead of 92. Same bits as the full sweeps (same chain_model).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_subtree_kernel(const TransformMirror xf, const uint8_t* __restrict__ dirty,
+                                                            float4* __restrict__ world)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= xf.count)
+        return;
+    bool stale = dirty[s] != 0;
+    if (xf.max_depth != 0 && !stale) {
+        // (the walk ignores modelWithAncestors: an entry that does not use its chain is merely recomputed to the same value)
+        uint32_t p = xf.parent[s];
+        for (uint32_t d = 0; d < xf.max_depth && p != kSlotNone; d++) {
+            if (dirty[p]) {
+                stale = true;
+                break;
+            }
+            p = xf.parent[p];
+        }
+    }
+    if (!stale)
+        return;
+    const XfRecord r = load_xf(xf, s);
+    float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
+    if (r.flags & kXfLive) {
+        const Mat34 m = chain_model(xf, local_model(r), s, r.flags);
+        w0 = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+        w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+        w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    }
+    world[(size_t)s * 3 + 0] = w0;
+    world[(size_t)s * 3 + 1] = w1;
+    world[(size_t)s * 3 + 2] = w2;
+}
+
+hipError_t launch_sweep_subtree(const TransformMirror& xf, const uint8_t* dirty, float4* world, hipStream_t stream)
+{
+    if (xf.count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(sweep_subtree_kernel, dim3((xf.count + 255) / 256), dim3(256), 0, stream, xf, dirty, world);
+    return hipGetLastError();
+}
+
 hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream_t stream)
 {
     if (xf.count == 0)
@@ -48,14 +97,30 @@ hipError_t launch_sweep_valu(const TransformMirror& xf, float4* world, hipStream
 // which is also its B operand for the next ancestor — no movement between chain steps.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr uint32_t kPitch = 13;
+// Per-wave LDS tile: 64 slots x 20 floats (16 used; the pitch makes the memory side's 16-byte stores conflict-free).
+// Everything crosses it as whole float4s — three or four 16-byte LDS instructions where round 1 issued twelve 4-byte
+// ones (the hand-over was ~150 LDS instructions per lane per slot at depth 3 and the reason the MFMA form lost to the
+// VALU form when fused with the cull; now ~50):
+//   self models go in COLUMN-major, padded with the bottom-row element: quad j = (c_j.x, c_j.y, c_j.z, j == 3) — lane
+//   (e, q) of the matrix side reads quad q = its B operand / running product column in one load;
+//   parent models go in ROW-major: quad i = (c0[i], c1[i], c2[i], c3[i]), quad 3 = the constant bottom row (0,0,0,1) —
+//   lane (e, q) reads quad q = its four A operands in one load, no per-lane selects; "this slot has a parent" lives
+//   in a compact per-wave word array beside the tile (conflict-free 4-byte accesses).
+constexpr uint32_t kPitch4 = 5;            // float4s per slot
 
-__device__ __forceinline__ void lds_put_model(float* row, const Mat34& m)
+__device__ __forceinline__ void lds_put_columns(float4* slot, const Mat34& m)
 {
-    row[0] = m.c0x; row[1] = m.c0y; row[2] = m.c0z;
-    row[3] = m.c1x; row[4] = m.c1y; row[5] = m.c1z;
-    row[6] = m.c2x; row[7] = m.c2y; row[8] = m.c2z;
-    row[9] = m.c3x; row[10] = m.c3y; row[11] = m.c3z;
+    slot[0] = make_float4(m.c0x, m.c0y, m.c0z, 0.0f);
+    slot[1] = make_float4(m.c1x, m.c1y, m.c1z, 0.0f);
+    slot[2] = make_float4(m.c2x, m.c2y, m.c2z, 0.0f);
+    slot[3] = make_float4(m.c3x, m.c3y, m.c3z, 1.0f);
+}
+__device__ __forceinline__ void lds_put_rows(float4* slot, const Mat34& m)
+{
+    slot[0] = make_float4(m.c0x, m.c1x, m.c2x, m.c3x);
+    slot[1] = make_float4(m.c0y, m.c1y, m.c2y, m.c3y);
+    slot[2] = make_float4(m.c0z, m.c1z, m.c2z, m.c3z);
+    slot[3] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
 }
 
 // Each wave owns its LDS tile, so the matrix/memory-side hand-over only needs wave-level ordering: LDS operations of
@@ -67,15 +132,37 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One ancestor step on the matrix side: x[r] = column q of the running product of slot 16r + e (w = bottom-row element),
+// the tile holds the parents' local models row-major. Four issues k = 0..3 into a zero accumulator = the canonical
+// fma chain. Slots whose chain has ended keep their product untouched (bit-exact, incl. -0). acc[3] (the bottom-row
+// element) is not taken: models are affine and x[r].w stays the constant 0 / 1, as in every other implementation (it only
+// differs from acc[3] when the operands are non-finite).
+__device__ __forceinline__ void mfma_chain_step(const float4* tile4, const uint32_t* has_parent, uint32_t e, uint32_t q, float4 (&x)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float4 row = tile4[(16 * r + e) * kPitch4 + q];
+        const bool step = has_parent[16 * r + e] != 0;
+        f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, x[r].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, x[r].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, x[r].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.w, x[r].w, acc, 0, 0, 0);
+        x[r].x = step ? acc[0] : x[r].x;
+        x[r].y = step ? acc[1] : x[r].y;
+        x[r].z = step ? acc[2] : x[r].z;
+    }
+}
+
 __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror xf, float* __restrict__ world)
 {
-    __shared__ float tile[4][64 * kPitch];  // one tile per wave
+    __shared__ float4 tile[4][64 * kPitch4];  // one tile per wave
     __shared__ uint32_t has_parent[4][64];
     const uint32_t lb = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t q = lane & 3u, e = lane >> 2;  // matrix side: column/row q of slot 16r + e
     const uint32_t s = lb * 256 + threadIdx.x;    // memory side: this lane's slot
-    float* my_tile = tile[wave];
+    float4* my_tile = tile[wave];
     uint32_t flags = 0;
     Mat34 m = {};
     const bool in_range = s < xf.count;
@@ -85,17 +172,12 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
         m = local_model(r);
     }
     const bool live = in_range && (flags & kXfLive);
-    lds_put_model(my_tile + lane * kPitch, m);
+    lds_put_columns(my_tile + lane * kPitch4, m);
     wave_lds_sync();
-    float x[4][4];  // [round][row]: column q of the product of slot 16r + e (row 3 = bottom-row element)
+    float4 x[4];  // [round]: column q of the product of slot 16r + e (w = bottom-row element)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float* row = my_tile + (16 * r + e) * kPitch + 3 * q;
-        x[r][0] = row[0];
-        x[r][1] = row[1];
-        x[r][2] = row[2];
-        x[r][3] = q == 3 ? 1.0f : 0.0f;
-    }
+    for (int r = 0; r < 4; r++)
+        x[r] = my_tile[(16 * r + e) * kPitch4 + q];
     uint32_t p = (live && xf.max_depth != 0 && (flags & kXfWithAncestors)) ? xf.parent[s] : kSlotNone;
     for (uint32_t d = 0; d < xf.max_depth; d++) {
         const bool has = p != kSlotNone;
@@ -107,33 +189,15 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
             pm = local_model(load_xf(xf, p));
             next = xf.parent[p];
         }
-        lds_put_model(my_tile + lane * kPitch, pm);
+        wave_lds_sync();  // the previous step's reads of the tile
+        lds_put_rows(my_tile + lane * kPitch4, pm);
         has_parent[wave][lane] = has ? 1u : 0u;
         wave_lds_sync();
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            // row q of the parent's local model of slot 16r + e: A[q][k] = column k, row q
-            const float* prow = my_tile + (16 * r + e) * kPitch;
-            const float a0 = q < 3 ? prow[q] : 0.0f;
-            const float a1 = q < 3 ? prow[3 + q] : 0.0f;
-            const float a2 = q < 3 ? prow[6 + q] : 0.0f;
-            const float a3 = q < 3 ? prow[9 + q] : 1.0f;
-            const bool step = has_parent[wave][16 * r + e] != 0;
-            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x[r][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, x[r][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, x[r][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, x[r][3], acc, 0, 0, 0);
-            // slots whose chain has ended keep their product untouched (bit-exact, incl. -0)
-            x[r][0] = step ? acc[0] : x[r][0];
-            x[r][1] = step ? acc[1] : x[r][1];
-            x[r][2] = step ? acc[2] : x[r][2];
-            // acc[3] (the bottom-row element) is not taken: models are affine and x[r][3] stays the constant 0 / 1,
-            // as in every other implementation (it only differs from acc[3] when the operands are non-finite)
-        }
+        mfma_chain_step(my_tile, has_parent[wave], e, q, x);
         p = next;
     }
     // liveness of slot 16r + e on the matrix side
+    wave_lds_sync();
     has_parent[wave][lane] = live ? 1u : 0u;
     wave_lds_sync();
 #pragma unroll
@@ -143,9 +207,9 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
             const bool ok = has_parent[wave][16 * r + e] != 0;
             // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per round
             float* dst = world + (size_t)slot * 12 + q * 3;
-            stream_store(dst + 0, ok ? x[r][0] : 0.0f);
-            stream_store(dst + 1, ok ? x[r][1] : 0.0f);
-            stream_store(dst + 2, ok ? x[r][2] : 0.0f);
+            stream_store(dst + 0, ok ? x[r].x : 0.0f);
+            stream_store(dst + 1, ok ? x[r].y : 0.0f);
+            stream_store(dst + 2, ok ? x[r].z : 0.0f);
         }
     }
 }
@@ -165,7 +229,7 @@ struct SweepCullArgs {
 template <bool HIZ>
 __global__ __launch_bounds__(256) void sweep_cull_mfma_kernel(const SweepCullArgs args)
 {
-    __shared__ float tile[4][64 * kPitch];  // one tile per wave
+    __shared__ float4 tile[4][64 * kPitch4];  // one tile per wave
     __shared__ uint32_t has_parent[4][64];
     __shared__ uint32_t wave_count[4];
     const TransformMirror& xf = args.cull.xf;
@@ -174,7 +238,7 @@ __global__ __launch_bounds__(256) void sweep_cull_mfma_kernel(const SweepCullArg
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t q = lane & 3u, e = lane >> 2;  // matrix side: column/row q of slot 16r + e
     const uint32_t s = lb * 256 + threadIdx.x;    // memory side: this lane's slot = its mesh entry
-    float* my_tile = tile[wave];
+    float4* my_tile = tile[wave];
     uint32_t flags = 0;
     Mat34 m = {};
     const bool in_range = s < xf.count, has_mesh = s < mesh.count;
@@ -190,67 +254,44 @@ __global__ __launch_bounds__(256) void sweep_cull_mfma_kernel(const SweepCullArg
         m = local_model(r);
     }
     const bool live = in_range && (flags & kXfLive);
-    lds_put_model(my_tile + lane * kPitch, m);
-    wave_lds_sync();
-    float x[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float* row = my_tile + (16 * r + e) * kPitch + 3 * q;
-        x[r][0] = row[0];
-        x[r][1] = row[1];
-        x[r][2] = row[2];
-        x[r][3] = q == 3 ? 1.0f : 0.0f;
-    }
     uint32_t p = (live && xf.max_depth != 0 && (flags & kXfWithAncestors)) ? xf.parent[s] : kSlotNone;
-    for (uint32_t d = 0; d < xf.max_depth; d++) {
-        const bool has = p != kSlotNone;
-        if (!__any(has))
-            break;
-        uint32_t next = kSlotNone;
-        Mat34 pm = {};
-        if (has) {
-            pm = local_model(load_xf(xf, p));
-            next = xf.parent[p];
+    Mat34 world = m;
+    if (__any(p != kSlotNone)) {  // wave-uniform: a wave of roots / flat entries keeps its local models as they are
+        lds_put_columns(my_tile + lane * kPitch4, m);
+        wave_lds_sync();
+        float4 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            x[r] = my_tile[(16 * r + e) * kPitch4 + q];
+        for (uint32_t d = 0; d < xf.max_depth; d++) {
+            const bool has = p != kSlotNone;
+            if (!__any(has))
+                break;
+            uint32_t next = kSlotNone;
+            Mat34 pm = {};
+            if (has) {
+                pm = local_model(load_xf(xf, p));
+                next = xf.parent[p];
+            }
+            wave_lds_sync();  // the previous step's reads of the tile
+            lds_put_rows(my_tile + lane * kPitch4, pm);
+            has_parent[wave][lane] = has ? 1u : 0u;
+            wave_lds_sync();
+            mfma_chain_step(my_tile, has_parent[wave], e, q, x);
+            p = next;
         }
-        lds_put_model(my_tile + lane * kPitch, pm);
-        has_parent[wave][lane] = has ? 1u : 0u;
+        // hand the products back: lane (e, q) holds column q of slot 16r + e
         wave_lds_sync();
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float* prow = my_tile + (16 * r + e) * kPitch;
-            const float a0 = q < 3 ? prow[q] : 0.0f;
-            const float a1 = q < 3 ? prow[3 + q] : 0.0f;
-            const float a2 = q < 3 ? prow[6 + q] : 0.0f;
-            const float a3 = q < 3 ? prow[9 + q] : 1.0f;
-            const bool step = has_parent[wave][16 * r + e] != 0;
-            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x[r][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, x[r][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, x[r][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, x[r][3], acc, 0, 0, 0);
-            x[r][0] = step ? acc[0] : x[r][0];
-            x[r][1] = step ? acc[1] : x[r][1];
-            x[r][2] = step ? acc[2] : x[r][2];
-        }
-        p = next;
-        wave_lds_sync();  // the tile is rewritten by the next step / the hand-back below
-    }
-    // hand the products back: lane (e, q) holds column q of slot 16r + e
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float* row = my_tile + (16 * r + e) * kPitch + 3 * q;
-        row[0] = x[r][0];
-        row[1] = x[r][1];
-        row[2] = x[r][2];
-    }
-    wave_lds_sync();
-    Mat34 world = {};
-    {
-        const float* row = my_tile + lane * kPitch;
-        world.c0x = row[0]; world.c0y = row[1]; world.c0z = row[2];
-        world.c1x = row[3]; world.c1y = row[4]; world.c1z = row[5];
-        world.c2x = row[6]; world.c2y = row[7]; world.c2z = row[8];
-        world.c3x = row[9]; world.c3y = row[10]; world.c3z = row[11];
+        for (int r = 0; r < 4; r++)
+            my_tile[(16 * r + e) * kPitch4 + q] = x[r];
+        wave_lds_sync();
+        const float4* slot = my_tile + lane * kPitch4;
+        const float4 k0 = slot[0], k1 = slot[1], k2 = slot[2], k3 = slot[3];
+        world.c0x = k0.x; world.c0y = k0.y; world.c0z = k0.z;
+        world.c1x = k1.x; world.c1y = k1.y; world.c1z = k1.z;
+        world.c2x = k2.x; world.c2y = k2.y; world.c2z = k2.z;
+        world.c3x = k3.x; world.c3y = k3.y; world.c3z = k3.z;
     }
     if (in_range) {
         float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;

@@ -155,6 +155,21 @@ public:
                 propagateActive(view->childs[i], isActive);
     }
     void markTransformsChanged() noexcept { transformVersion++; }
+    // Itemised form for writers that know what they moved (an animation / physics system walking its own list): the
+    // slots whose position / rotation / scale changed since the consumers last looked. Consumers re-mirror exactly these
+    // (GV_DIRTY_TRANSFORM per range) and, with a kept world-matrix cache, re-sweep only the subtrees under them.
+    std::vector<std::pair<uint32_t, uint32_t>> movedRanges;  // (first slot, count)
+    void markMoved(ID<Entity> entity)
+    {
+        if (*entity >= entityToComponent.size() || entityToComponent[*entity] == none)
+            return;
+        const uint32_t slot = entityToComponent[*entity];
+        if (!movedRanges.empty() && movedRanges.back().first + movedRanges.back().second == slot)
+            movedRanges.back().second++;
+        else
+            movedRanges.push_back({slot, 1u});
+    }
+    void clearMovedRanges() noexcept { movedRanges.clear(); }
     // TransformComponent::destroy (transform.cpp:29-73): unlink from the parent's childs[] keeping their order,
     // orphan the children (parent = null, ancestorsActive = true, not pushed further down), free childs[]
     void removeOf(ID<Entity> entity) override

@@ -81,6 +81,9 @@ public:
     // true: every frame also leaves the world matrices of all transforms on the device (gv_get_world): the sweep
     // rides on the first pool's cull (GV_SWEEP_WITH_CULL), fused into one pass when that pool is exactly paired
     bool sweepWorldMatrices = false;
+    // with sweepWorldMatrices: keep the cache up to date with GV_SWEEP_INCREMENTAL instead (nothing is launched on a
+    // frame without transform changes, only the subtrees under moved / re-parented transforms are re-swept otherwise)
+    bool sweepIncremental = false;
 
     // blockBounds: GV_CONFIG_BLOCK_BOUNDS — worth it when most of the world is static (same results either way)
     explicit GpuVisibilitySystem(int device = 0, bool profile = false, bool blockBounds = false)
@@ -288,6 +291,9 @@ private:
             if (seenReparent != transformSystem->reparentVersion && transformSystem->reparentLo < transformSystem->reparentHi)
                 check(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, transformSystem->reparentLo,
                                     transformSystem->reparentHi - transformSystem->reparentLo), "gv_mark_dirty");
+            // writers that itemise what they moved (TransformSystem::markMoved): exactly those slots
+            for (const auto& moved : transformSystem->movedRanges)
+                check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, moved.first, moved.second), "gv_mark_dirty");
             if (seenTransform != transformSystem->transformVersion) {
                 check(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0, pool.getOccupancy()), "gv_mark_dirty");
                 seenTransform = transformSystem->transformVersion;
@@ -301,6 +307,7 @@ private:
         seenFlags = transformSystem->flagsVersion;
         transformSystem->clearReparentRange();
         transformSystem->clearFlagsRange();
+        transformSystem->clearMovedRanges();
 
         const auto& cc = graphicsSystem->getCommonConstants();
         const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
@@ -341,7 +348,7 @@ private:
                                              (int8_t)s, false, emitRecords));
             }
             if (sweepWorldMatrices && p == 0)
-                check(gv_sweep(ctx, GV_SWEEP_WITH_CULL), "gv_sweep");
+                check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_WITH_CULL), "gv_sweep");
             {
                 Stopwatch watch(tickSeconds.cull);
                 check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");

@@ -12,7 +12,8 @@ import numpy as np
 from .pools import mesh_layout_offsets, transform_layout_offsets
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgarden_vis.so")
+# GV_LIB_PATH: dev A/Bs against another build of the same library (e.g. a previous round's kernels); never a fallback
+LIB_PATH = os.environ.get("GV_LIB_PATH") or os.path.join(_HERE, "lib", "libgarden_vis.so")
 
 GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 6
 GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
@@ -22,7 +23,7 @@ GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_CONFIG_KEEP_SLOT_ORDER = 4
 GV_CONFIG_BLOCK_BOUNDS = 8
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
-GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU = 0, 1, 2, 3
+GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU, GV_SWEEP_INCREMENTAL = 0, 1, 2, 3, 4
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
 GV_EXCHANGE_ALLGATHER, GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST = 0, 1, 2
 KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep", "sort"]

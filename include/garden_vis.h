@@ -298,7 +298,14 @@ typedef enum GvSweepMode {
      * pool (mesh entry i belongs to transform slot i) the MFMA sweep and the cull of view 0 run as one pass over the
      * streams; otherwise the MFMA sweep is launched in front of the ordinary cull. Same bits either way. */
     GV_SWEEP_WITH_CULL = 2,
-    GV_SWEEP_WITH_CULL_VALU = 3 /* the same with the v_fma_f32 chain */
+    GV_SWEEP_WITH_CULL_VALU = 3, /* the same with the v_fma_f32 chain */
+    /* Brings the cache up to date with the least work (same bits as a full sweep): nothing is launched when no transform
+     * changed since the last sweep; after gv_mark_dirty ranges (GV_DIRTY_TRANSFORM, ranged GV_DIRTY_HIERARCHY) only the
+     * slots whose parent chain contains a re-mirrored transform are recomputed — a dirty subtree, not the pool
+     * (setPosition / setParent of the reference invalidate nothing: calcModel is lazy, transform.hpp:197-214; this is the
+     * device-side counterpart for a cache that is kept); a full sweep otherwise (first use, entities created or
+     * destroyed, most of the pool dirty). */
+    GV_SWEEP_INCREMENTAL = 4
 } GvSweepMode;
 int gv_sweep(GvCtx* ctx, uint32_t mode);
 /* Reads back `count` world matrices (12 floats each, float4x3 order) starting at transform slot `first`. */

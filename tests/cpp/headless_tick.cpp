@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--csm]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -164,6 +164,9 @@ int main(int argc, char** argv)
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
+    bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
+                            // checks gv_get_world of every transform slot against the oracle's chain walk, bit for bit
+    bool itemised = false;  // --itemised: --animate reports the moved entities one by one (TransformSystem::markMoved)
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -177,6 +180,8 @@ int main(int argc, char** argv)
         else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
+        else if (a == "--world") world = true;
+        else if (a == "--itemised") itemised = true;
         else if (a == "--avx2") avx2 = true;  // CPU system: AVX2+FMA SoA path (bit-identical to the scalar loop)
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
@@ -212,6 +217,8 @@ int main(int argc, char** argv)
         }
         if (mode == "gpu" || mode == "both")
             gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
+        if (gpu && world)
+            gpu->sweepWorldMatrices = gpu->sweepIncremental = true;
         manager.initialize();
 
         // scene: SURVEY.md §8d distribution (cube side 100 * N^(1/3), scale [0.5,2], half-extent [0.25,1])
@@ -333,9 +340,13 @@ int main(int argc, char** argv)
             for (uint32_t i = 0; i < n; i++) {
                 if (animate && moving) {  // timed with the tick: the engine's own systems would be doing this
                     for (uint32_t k = animateTick % animate; k < (uint32_t)ents.size(); k += animate)
-                        if (auto t = transformSystem->tryGetOf(ents[k]))
+                        if (auto t = transformSystem->tryGetOf(ents[k])) {
                             t->posChildCount.x += 0.25f;
-                    transformSystem->markTransformsChanged();
+                            if (itemised)
+                                transformSystem->markMoved(ents[k]);
+                        }
+                    if (!itemised)
+                        transformSystem->markTransformsChanged();
                     animateTick++;
                 }
                 manager.update();
@@ -423,6 +434,33 @@ int main(int argc, char** argv)
                     seconds += run(false, true, animate ? 1 : ticks, false);
                     b = snapshot(manager, gpu, passCount);
                     ok = same(a, b, why);
+                    if (ok && world) {  // the kept cache == TransformComponent::calcModel() of every slot (transform.hpp:197-214)
+                        auto& tpool = transformSystem->getComponents();
+                        auto& emap = transformSystem->getEntityMap();
+                        GvoTransformPool tp{};
+                        tp.base = reinterpret_cast<const uint8_t*>(tpool.getData());
+                        tp.stride = sizeof(TransformComponent);
+                        tp.occupancy = tpool.getOccupancy();
+                        tp.off_entity = offsetof(TransformComponent, entity);
+                        tp.off_parent = offsetof(TransformComponent, parent);
+                        tp.off_position = offsetof(TransformComponent, posChildCount);
+                        tp.off_scale = offsetof(TransformComponent, scaleChildCap);
+                        tp.off_rotation = offsetof(TransformComponent, rotation);
+                        tp.off_self_active = offsetof(TransformComponent, selfActive);
+                        tp.off_ancestors_active = offsetof(TransformComponent, ancestorsActive);
+                        tp.off_model_with_ancestors = offsetof(TransformComponent, modelWithAncestors);
+                        tp.entity_to_transform = emap.data();
+                        tp.entity_capacity = (uint32_t)emap.size();
+                        std::vector<float> want((size_t)tp.occupancy * 12), got((size_t)tp.occupancy * 12);
+                        gvo_world_matrices(&tp, 0, tp.occupancy, want.data());
+                        if (gv_get_world(gpu->getContext(), 0, tp.occupancy, got.data()) != GV_OK) {
+                            ok = false;
+                            why = std::string("gv_get_world: ") + gv_last_error(gpu->getContext());
+                        } else if (memcmp(want.data(), got.data(), want.size() * 4) != 0) {
+                            ok = false;
+                            why = "world-matrix cache differs from the oracle's chain walk";
+                        }
+                    }
                 }
                 if (ok && !a.ordered) {
                     ok = false;

@@ -937,3 +937,83 @@ def test_device_gather_never_reads_past_the_callers_pool(oracle):
         assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got["is_visible"], m2["isVisible"])
     del tr
     assert libc.mprotect(base + (pages - 1) * page, page, 3) == 0
+
+
+@pytest.mark.parametrize("ctx_name", ["gpu", "gpu_slot_order"])
+def test_incremental_sweep_recomputes_exactly_the_dirty_subtrees(request, oracle, ctx_name):
+    """GV_SWEEP_INCREMENTAL: after dirty ranges only chains through re-mirrored transforms are
+    recomputed — every tick the whole cache must equal the oracle's world matrices bit for bit, whatever path the
+    dirty range took (device-side AoS gather, scattered host packet, contiguous host upload, re-parenting), and a tick
+    without changes must not launch anything."""
+    from garden_amd.lib import GV_DIRTY_HIERARCHY, GV_DIRTY_TRANSFORM, GV_SWEEP_INCREMENTAL, GV_SWEEP_VALU
+    vis = request.getfixturevalue(ctx_name)
+    n = 120_000
+    sc = scene.hierarchy_scene(n, depth=4, fanout=6)
+    tr = sc.transforms
+    rng = np.random.Generator(np.random.PCG64(4242))
+    vis.bind_transforms(tr, sc.entity_to_transform)
+    vis.bind_pool(0, sc.meshes)
+    vis.hierarchy_rebuild()
+
+    def check():
+        exp = oracle.world_matrices(tr, sc.entity_to_transform)
+        got = vis.get_world(0, n)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+    def launches():
+        return vis.stats()["launches"]["sweep"]
+
+    vis.sweep(GV_SWEEP_INCREMENTAL)  # first use: a full sweep
+    check()
+    l0 = launches()
+    vis.sweep(GV_SWEEP_INCREMENTAL)  # nothing changed: nothing launched
+    assert launches() == l0
+    check()
+
+    def move(lo, cnt):
+        tr["position"][lo:lo + cnt, :3] += rng.normal(0, 25, (cnt, 3)).astype(np.float32)
+        tr["scale"][lo:lo + cnt, :3] *= np.float32(1.01)
+        vis.mark_dirty(GV_DIRTY_TRANSFORM, lo, cnt)
+
+    # a few roots (level 0 is the first n / 259 slots): their whole subtrees follow
+    move(3, 40)
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    check()
+    # a large range in the leaves: device-side gather path (>= 2048 slots)
+    move(60_000, 30_000)
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    check()
+    # several ticks of small scattered changes, one incremental sweep per tick
+    for _ in range(4):
+        for lo in rng.integers(0, n - 50, 6):
+            move(int(lo), int(rng.integers(1, 50)))
+        vis.sweep(GV_SWEEP_INCREMENTAL)
+        check()
+    # re-parenting (links through the host path) + moving in the same tick; a cull in between must not disturb the cache
+    for s_ in range(100_000, 100_300):
+        tr["parent"][s_] = tr["entity"][s_ - 99_000]
+    vis.mark_dirty(GV_DIRTY_HIERARCHY, 100_000, 300)
+    move(500, 100)
+    vis.cull(0, [scene.main_camera_view()])
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    check()
+    # most of the pool: falls back to a full sweep; then a full-mode sweep and an incremental no-op agree
+    move(0, n)
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    check()
+    vis.sweep(GV_SWEEP_VALU)
+    l1 = launches()
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    assert launches() == l1
+    check()
+    # records emitted from the cache (emit reads world[] when it is current) are the oracle's
+    move(7, 20)
+    vis.sweep(GV_SWEEP_INCREMENTAL)
+    view = scene.main_camera_view()
+    vis.cull(0, [view])
+    got = vis.fetch(0, write_back=False, occupancy=n)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, tr, sc.entity_to_transform, view)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"][o])
+    assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))

@@ -100,6 +100,13 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "150000", "--csm"],
     ["--entities", "30000", "--csm", "--mixed", "--hier", "--mutate"],
     ["--entities", "14000", "--csm", "--animate", "2", "--ticks", "4"],
+    # the kept world-matrix cache (GV_SWEEP_INCREMENTAL), checked against the oracle's chain walk every tick: itemised moves
+    # (subtree-scoped sweeps), whole-pool marks (full sweeps), re-parenting / destruction / creation in between
+    ["--entities", "40000", "--hier", "--animate", "7", "--itemised", "--world", "--ticks", "6"],
+    ["--entities", "40000", "--hier", "--animate", "3", "--world", "--ticks", "4"],
+    ["--entities", "30000", "--hier", "--animate", "11", "--itemised", "--world", "--mutate", "--ticks", "4"],
+    ["--entities", "20000", "--hier", "--mixed", "--animate", "5", "--itemised", "--world", "--churn", "3", "--ticks", "3"],
+    ["--entities", "9000", "--animate", "4", "--itemised", "--world", "--ticks", "5"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
