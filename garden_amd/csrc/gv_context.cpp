@@ -404,6 +404,21 @@ int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* colu
     return GV_OK;
 }
 
+int gv_pool_bind_ready(GvCtx* ctx, uint32_t pool_id, const void* data, uint32_t stride, uint32_t width)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || (data && ((width != 1 && width != 4) || stride < width)))
+        return ctx->fail(GV_E_ARG, "gv_pool_bind_ready: bad argument (pool %u, width %u, stride %u)", pool_id, width, stride);
+    PoolState& p = ctx->pools[pool_id];
+    const bool had = p.ready.ptr != nullptr;
+    p.ready = Column{static_cast<const uint8_t*>(data), data ? stride : 0};
+    p.ready_width = data ? width : 0;
+    if (had != (data != nullptr) && p.bound)
+        p.dirty.add(0, p.occupancy);  // the candidate bits of the whole pool may change
+    return GV_OK;
+}
+
 int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count)
 {
     if (!ctx)
@@ -746,6 +761,31 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         out->visible_idx = vs.h_visible_idx.ptr;
         out->baked_model = vs.h_baked_model.ptr;
         out->distance_sq = vs.h_distance_sq.ptr;
+    }
+    if (pool.ready.ptr && pool.bound && pool.occupancy == vs.occupancy && count) {
+        // instanceCount += readyCount (mesh.cpp:174): the drawn meshes' own counts, summed over the fetched list (or, for
+        // a count-only main pass, over the isVisible bytes); a count-only shadow view keeps draw_count
+        std::atomic<uint64_t> total{0};
+        if (vs.emitted) {
+            const uint32_t* idx = vs.h_visible_idx.ptr;
+            parallel_ranges(0, count, [&](uint32_t a, uint32_t b) {
+                uint64_t sum = 0;
+                for (uint32_t k = a; k < b; k++)
+                    sum += pool.ready_count(idx[k]);
+                total += sum;
+            });
+            out->instance_count = (uint32_t)total.load();
+        } else if (want_vis) {
+            const uint8_t* vis = vs.h_is_visible.ptr;
+            parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
+                uint64_t sum = 0;
+                for (uint32_t i = a; i < b; i++)
+                    if (vis[i])
+                        sum += pool.ready_count(i);
+                total += sum;
+            });
+            out->instance_count = (uint32_t)total.load();
+        }
     }
     if (vs.main_pass && vs.occupancy) {
         // the bytes arrive in pool-slot order; write_back streams them into the components themselves:

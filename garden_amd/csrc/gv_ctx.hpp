@@ -221,6 +221,9 @@ struct TransformBinding {
 
 struct PoolState {
     Column entity, is_enabled, aabb_min, aabb_max;
+    Column ready;              // gv_pool_bind_ready: per-slot ready count (ptr NULL: none, every slot counts 1)
+    uint32_t ready_width = 0;  // 1 or 4 bytes
+    uint32_t ready_count(size_t i) const { return !ready.ptr ? 1u : (ready_width == 4 ? ready.u32(i) : (uint32_t)ready.u8(i)); }
     uint8_t* is_visible = nullptr;  // write-back target (NULL: none), element i at is_visible + i * is_visible_stride
     size_t is_visible_stride = 0;
     uint32_t occupancy = 0;

@@ -272,7 +272,9 @@ void gather_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
             const float* mx = p.aabb_max.f32(i);
             const uint32_t entity = p.entity.u32(i);
             const uint32_t slot = xslot_to_mirror(ctx, entity_slot(xf, entity));  // Manager::tryGet<TransformComponent>  mesh.cpp:149
-            const bool candidate = entity && p.is_enabled.u8(i) && slot != kSlotNone;
+            // a mesh that is not ready (ready count 0: resources still loading) ends like a disabled one: readyCount == 0 ->
+            // isVisible = false, no record (mesh.cpp:158-165)
+            const bool candidate = entity && p.is_enabled.u8(i) && slot != kSlotNone && p.ready_count(i) != 0;
             const uint32_t j = p.inv.empty() ? i : p.inv[i];
             // A non-candidate entry (free slot, disabled, no transform) carries an empty box: the all(size <= 0)
             // filter (mesh.cpp:140-142) then rejects it without the kernel having to read link[] (kMapExact).

@@ -98,7 +98,7 @@ class GvError(RuntimeError):
 # every symbol include/garden_vis.h declares; tests/test_abi.py checks the .so exports all of them
 EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
-    "gv_transform_bind_columns", "gv_pool_bind_columns",
+    "gv_transform_bind_columns", "gv_pool_bind_columns", "gv_pool_bind_ready",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
     "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
@@ -139,6 +139,7 @@ def load():
     lib.gv_pool_bind.argtypes = [P, u32, P, sz, u32, C.POINTER(GvMeshLayout)]
     lib.gv_transform_bind_columns.argtypes = [P, C.POINTER(GvTransformColumns), u32, P, u32]
     lib.gv_pool_bind_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), u32]
+    lib.gv_pool_bind_ready.argtypes = [P, u32, P, u32, u32]
     lib.gv_mark_dirty.argtypes = [P, u32, u32, u32]
     lib.gv_hierarchy_rebuild.argtypes = [P]
     lib.gv_sync.argtypes = [P]
@@ -272,6 +273,16 @@ class GpuVisibility:
                           self._column(columns["aabb_min"]), self._column(columns["aabb_max"]),
                           vis.ctypes.data if vis is not None else None, vis.strides[0] if vis is not None else 0)
         self._check(self.lib.gv_pool_bind_columns(self.ctx, pool_id, C.byref(c), columns["entity"].shape[0]))
+
+    def bind_ready(self, pool_id, ready):
+        """Per-slot ready counts of `pool_id` (numpy u8 or u32 array, one element per slot; None removes the column)."""
+        if ready is None:
+            self._keep.pop(("ready", pool_id), None)
+            self._check(self.lib.gv_pool_bind_ready(self.ctx, pool_id, None, 0, 0))
+            return
+        assert ready.dtype in (np.uint8, np.uint32) and ready.ndim == 1
+        self._keep[("ready", pool_id)] = ready
+        self._check(self.lib.gv_pool_bind_ready(self.ctx, pool_id, ready.ctypes.data, ready.strides[0], ready.dtype.itemsize))
 
     def mark_dirty(self, kind, first, count, pool_id=0):
         if kind == GV_DIRTY_MESH:

@@ -127,6 +127,15 @@ typedef struct GvMeshColumns {
 int gv_transform_bind_columns(GvCtx* ctx, const GvTransformColumns* columns, uint32_t occupancy,
                               const uint32_t* entity_to_transform, uint32_t entity_capacity);
 int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* columns, uint32_t occupancy);
+/* Optional per-slot READY COUNT of a pool: what a derived system's getReadyMeshesAsync returns for a mesh that passed
+ * the frustum test — 0 while its resources are not loaded (SpriteRenderSystem: descriptorSet, sprite.cpp:90-97;
+ * UiLabelSystem: text data ready, label.cpp:271-276), otherwise the number of instances it draws (1 for the default
+ * predicate, render/mesh.hpp:142-146). Element i at data + i * stride, `width` = 1 (uint8) or 4 (uint32) bytes.
+ * A slot whose count is 0 is treated exactly like the reference treats readyCount == 0 (mesh.cpp:158-165): not drawn,
+ * isVisible = false; GvResult.instance_count becomes the sum of the counts of the drawn meshes (mesh.cpp:174).
+ * Same lifetime rules as gv_pool_bind (re-issue when the storage may have moved); changed counts are reported with
+ * gv_mark_dirty(GV_DIRTY_MESH). data == NULL removes the column (every slot counts 1 again). */
+int gv_pool_bind_ready(GvCtx* ctx, uint32_t pool_id, const void* data, uint32_t stride, uint32_t width);
 
 typedef enum GvDirtyKind {
     GV_DIRTY_TRANSFORM = 0, /* TRS / active flags of transform slots [first, first+count) changed
@@ -169,7 +178,8 @@ typedef struct GvResult {
     const float* distance_sq;    /* mesh.cpp:172 / :250-251 */
     const uint8_t* is_visible;   /* one byte per pool slot; NULL for shadow passes */
     uint32_t draw_count;         /* UnsortedBuffer::drawCount (render/mesh.hpp:210) */
-    uint32_t instance_count;     /* default predicate returns 0/1 (render/mesh.hpp:142-146) => == draw_count */
+    uint32_t instance_count;     /* sum of the drawn meshes' ready counts (mesh.cpp:174): == draw_count unless a ready column
+                                    with counts above 1 is bound (gv_pool_bind_ready) */
 } GvResult;
 
 /* Device-side cull of one pool against `view_count` views: frustum test (+ Hi-Z query) + compaction.

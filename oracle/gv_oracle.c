@@ -485,6 +485,13 @@ void gvo_prepare_meshes_range(const GvoMeshPool* mp, const GvoTransformPool* tp,
         /* build-defined occlusion stage (no reference): only after frustum survival */
         if (ready_count && view->use_hiz && hiz && gvo_hiz_occluded(hiz, view->view_proj, amin, amax, model))
             ready_count = 0;
+        if (ready_count && mp->ready_base) { /* derived predicate: `return descriptorSet ? 1 : 0` sprite.cpp:96 */
+            const uint8_t* r = mp->ready_base + (size_t)i * mp->ready_stride;
+            if (mp->ready_width == 4)
+                memcpy(&ready_count, r, 4);
+            else
+                ready_count = *r;
+        }
         if (ready_count == 0) { /* :159 */
             if (is_not_shadow_pass)
                 *(mesh + mp->off_is_visible) = 0;

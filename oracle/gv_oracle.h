@@ -49,6 +49,11 @@ typedef struct GvoMeshPool {
     uint32_t off_is_visible; /* volatile bool isVisible (written on main pass) */
     uint32_t off_aabb_min;   /* f32x4 */
     uint32_t off_aabb_max;   /* f32x4 */
+    /* optional: what a derived system's getReadyMeshesAsync returns once the frustum test has passed (sprite.cpp:90-97,
+     * ui/label.cpp:271-276): element i at ready_base + i * ready_stride, ready_width 1 or 4 bytes; NULL = 1 for all */
+    const uint8_t* ready_base;
+    size_t ready_stride;
+    uint32_t ready_width;
 } GvoMeshPool;
 
 /* Byte layout of the reference's TransformComponent pool (transform.hpp:31-61). */

@@ -247,6 +247,15 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
                 if (gvo_hiz_occluded(hiz, view->view_proj, amin, amax, model))
                     visible = 0;
             }
+            uint32_t ready_count = 1;
+            if (visible && mp->ready_base) { /* derived predicate's count (sprite.cpp:90-97): 0 = not ready */
+                const uint8_t* r = mp->ready_base + (size_t)(i + l) * mp->ready_stride;
+                if (mp->ready_width == 4)
+                    memcpy(&ready_count, r, 4);
+                else
+                    ready_count = *r;
+                visible = ready_count != 0;
+            }
             if (main_pass)
                 *(mesh + mp->off_is_visible) = (uint8_t)visible;
             if (!visible)
@@ -258,7 +267,7 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
                         tz = mm[11][l] + view->camera_offset[2];
             out->distance_sq[draw_count] = view->distance_2d ? mm[11][l] + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
             draw_count++;
-            instance_count++;
+            instance_count += ready_count;
         }
     }
     out->draw_count = draw_count;

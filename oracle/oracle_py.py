@@ -18,7 +18,8 @@ RULE_REFERENCE, RULE_CONSERVATIVE = 0, 1
 class GvoMeshPool(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride", C.c_size_t), ("occupancy", C.c_uint32), ("off_entity", C.c_uint32),
                 ("off_is_enabled", C.c_uint32), ("off_is_visible", C.c_uint32), ("off_aabb_min", C.c_uint32),
-                ("off_aabb_max", C.c_uint32)]
+                ("off_aabb_max", C.c_uint32), ("ready_base", C.c_void_p), ("ready_stride", C.c_size_t),
+                ("ready_width", C.c_uint32)]
 
 
 class GvoTransformPool(C.Structure):
@@ -124,10 +125,14 @@ def is_behind_frustum(view_proj, aabb_min, aabb_max, model):
     return bool(lib.gvo_is_behind_frustum(C.byref(f), mn.ctypes.data, mx.ctypes.data, m.ctypes.data))
 
 
-def mesh_pool(meshes):
+def mesh_pool(meshes, ready=None):
+    """ready: optional per-slot ready counts (numpy u8 / u32, kept alive by the caller): the derived predicate's result"""
     f = meshes.dtype.fields
-    return GvoMeshPool(meshes.ctypes.data, meshes.dtype.itemsize, meshes.shape[0], f["entity"][1], f["isEnabled"][1],
-                       f["isVisible"][1], f["aabbMin"][1], f["aabbMax"][1])
+    mp = GvoMeshPool(meshes.ctypes.data, meshes.dtype.itemsize, meshes.shape[0], f["entity"][1], f["isEnabled"][1],
+                     f["isVisible"][1], f["aabbMin"][1], f["aabbMax"][1], None, 0, 0)
+    if ready is not None:
+        mp.ready_base, mp.ready_stride, mp.ready_width = ready.ctypes.data, ready.strides[0], ready.dtype.itemsize
+    return mp
 
 
 def transform_pool(transforms, e2t):
@@ -204,13 +209,13 @@ def transform_calc_model(transforms, e2t, slot, camera_position=(0, 0, 0)):
     return out
 
 
-def prepare_meshes(meshes, transforms, e2t, view, hiz=None, threads=1, sort=None):
+def prepare_meshes(meshes, transforms, e2t, view, hiz=None, threads=1, sort=None, ready=None):
     """MeshRenderSystem::prepareMeshes for one pool and one view (mesh.cpp:331-553 -> :111-184).
     Writes isVisible into `meshes` in place on a main pass, exactly as the reference does.
     Returns dict(visible_idx, baked_model[n,12], distance_sq, draw_count, instance_count)."""
     lib = load()
     e2t = np.ascontiguousarray(e2t, dtype=np.uint32)
-    mp, tp, gv = mesh_pool(meshes), transform_pool(transforms, e2t), to_view(view)
+    mp, tp, gv = mesh_pool(meshes, ready), transform_pool(transforms, e2t), to_view(view)
     n = meshes.shape[0]
     idx = np.empty(max(n, 1), np.uint32)
     bm = np.empty((max(n, 1), 12), np.float32)
@@ -228,11 +233,11 @@ def prepare_meshes(meshes, transforms, e2t, view, hiz=None, threads=1, sort=None
 class Avx2Scene:
     """SoA copy of the pools for the AVX2 path (built once, like the GPU mirror)."""
 
-    def __init__(self, meshes, transforms, e2t):
+    def __init__(self, meshes, transforms, e2t, ready=None):
         self.lib = load()
-        self.meshes, self.transforms = meshes, transforms
+        self.meshes, self.transforms, self.ready = meshes, transforms, ready
         self.e2t = np.ascontiguousarray(e2t, dtype=np.uint32)
-        self.mp, self.tp = mesh_pool(meshes), transform_pool(transforms, self.e2t)
+        self.mp, self.tp = mesh_pool(meshes, ready), transform_pool(transforms, self.e2t)
         self.soa = self.lib.gvo_soa_build(C.byref(self.mp), C.byref(self.tp))
         n = max(meshes.shape[0], 1)
         self.idx = np.empty(n, np.uint32)

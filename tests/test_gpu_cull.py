@@ -86,6 +86,13 @@ def test_hiz_pyramid_parity(oracle, size, rule):
     depth = scene.synthetic_depth(w, h, rects=37)
     rng = np.random.default_rng(w * 131 + h)
     depth = np.maximum(depth, (rng.random((h, w)) * 0.01).astype(np.float32))
+    # texels the comparisons treat specially: +0 / -0 (equal, different bits: which one a min / max keeps depends on the
+    # operand order), NaN (every comparison false: a NaN is kept or dropped depending on which side it arrives) and
+    # infinities — the reduction order of hiz.frag:29-60 is part of the contract, so these pin it
+    k = max(1, (w * h) // 23)
+    flat = depth.reshape(-1)
+    for value in (0.0, -0.0, np.nan, np.inf, -np.inf):
+        flat[rng.choice(flat.size, k, replace=False)] = np.float32(value)
     with GpuVisibility(device=0, hiz_rule=rule) as vis:
         vis.hiz_build(depth)
         exp = oracle.Hiz(depth, rule=rule)
@@ -1017,3 +1024,60 @@ def test_incremental_sweep_recomputes_exactly_the_dirty_subtrees(request, oracle
     o = np.argsort(exp["visible_idx"], kind="stable")
     assert np.array_equal(got["visible_idx"], exp["visible_idx"][o])
     assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint32])
+def test_ready_counts_filter_like_the_derived_predicates(gpu, oracle, dtype):
+    """gv_pool_bind_ready: a derived system's getReadyMeshesAsync result per slot (sprite.cpp:90-97: 0 until the
+    descriptor set exists; counts above 1 = instances). Count 0 ends like readyCount == 0 in mesh.cpp:158-165 — not
+    drawn, isVisible = false — and instance_count is the sum of the drawn meshes' counts (mesh.cpp:174)."""
+    from garden_amd.lib import GV_DIRTY_MESH
+    n = 50_000
+    sc = scene.hierarchy_scene(n, depth=3, fanout=5)
+    rng = np.random.default_rng(11)
+    ready = rng.choice(np.array([0, 1, 1, 1, 2, 7], dtype=dtype), n)
+    view = scene.main_camera_view()
+    shadow = scene.cascade_view(index=0, size=5000.0)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.bind_ready(0, ready)
+    gpu.hierarchy_rebuild()
+
+    def check(views):
+        gpu.cull(0, views)
+        for vi, v in enumerate(views):
+            got = gpu.fetch(vi, write_back=False, occupancy=n)
+            m2 = sc.meshes.copy()
+            exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, v, ready=ready)
+            assert exp["draw_count"] > 0 and got["draw_count"] == exp["draw_count"]
+            if v.get("emit_records", 1):
+                assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+                assert got["instance_count"] == exp["instance_count"] != exp["draw_count"]
+            elif v["shadow_pass"] < 0:
+                assert got["instance_count"] == exp["instance_count"]
+            if v["shadow_pass"] < 0:
+                assert np.array_equal(got["is_visible"], m2["isVisible"])
+                assert not np.any(got["is_visible"][ready == 0])
+
+    check([view])
+    check([view, shadow])
+    check([dict(view, emit_records=0)])
+    # resources finish loading / get evicted: counts change, reported as mesh dirt
+    ready[1000:3000] = 1
+    ready[20_000:20_500] = 0
+    gpu.mark_dirty(GV_DIRTY_MESH, 1000, 2000)
+    gpu.mark_dirty(GV_DIRTY_MESH, 20_000, 500)
+    check([view])
+    # the AVX2 form of the oracle applies the same rule
+    soa = oracle.Avx2Scene(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, ready=ready)
+    a = soa.prepare_meshes(view)
+    b = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, ready=ready)
+    assert a["draw_count"] == b["draw_count"] and a["instance_count"] == b["instance_count"]
+    assert np.array_equal(np.sort(a["visible_idx"]), np.sort(b["visible_idx"]))
+    soa.close()
+    # without the column every slot counts 1 again
+    gpu.bind_ready(0, None)
+    gpu.cull(0, [view])
+    got = gpu.fetch(0, write_back=False, occupancy=n)
+    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
+    assert got["draw_count"] == exp["draw_count"] == got["instance_count"]

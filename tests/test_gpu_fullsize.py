@@ -189,6 +189,61 @@ def test_cfg4_10m_hierarchy_sweep_and_cull(gpu, oracle, hier10m):
     exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
     assert same_records(got, exp) and np.array_equal(got["is_visible"], m2["isVisible"])
 
+    # the FUSED sweep + cull (bench.py --workload cfg4's default, and its VALU twin) at full size: records, isVisible
+    # and world-matrix blocks against the oracle; then the same with the Hi-Z stage in the fused kernel
+    from garden_amd.lib import GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
+    blocks = [(0, 100_000), (4_321_000, 150_000), (N_FULL - 120_000, 120_000)]
+    exp_blocks = [oracle.world_matrices(sc.transforms, sc.entity_to_transform, f, c, threads=THREADS) for f, c in blocks]
+    for mode in (GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU):
+        gpu.mark_dirty(0, 0, sc.count)  # forget the cache: the fused kernel must produce every matrix itself
+        gpu.sweep(mode)
+        gpu.cull(0, [view])
+        fused = gpu.fetch(0, write_back=False, occupancy=sc.count)
+        assert same_records(fused, exp) and np.array_equal(fused["is_visible"], m2["isVisible"])
+        for (f, c), e in zip(blocks, exp_blocks):
+            assert np.array_equal(gpu.get_world(f, c).view(np.uint32), e.view(np.uint32))
+    depth = scene.synthetic_depth(HIZ, HIZ)
+    hz_view = scene.main_camera_view(use_hiz=1)
+    gpu.hiz_build(depth)
+    m3 = sc.meshes.copy()
+    exp_hz = oracle.prepare_meshes(m3, sc.transforms, sc.entity_to_transform, hz_view, hiz=oracle.Hiz(depth, threads=THREADS), threads=THREADS)
+    o = np.argsort(exp_hz["visible_idx"], kind="stable")
+    exp_hz = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp_hz.items()}
+    for mode in (GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU):
+        gpu.sweep(mode)
+        gpu.cull(0, [hz_view])
+        fused = gpu.fetch(0, write_back=False, occupancy=sc.count)
+        assert 0 < fused["draw_count"] < got["draw_count"]
+        assert same_records(fused, exp_hz) and np.array_equal(fused["is_visible"], m3["isVisible"])
+
+
+def test_cfg2_shape_at_10_to_the_8_on_one_gpu(oracle):
+    """BASELINE's largest entity count on ONE GPU (the per-GPU share of an 8 x 12.5 M node is an eighth of this): 10^8
+    flat entities, frustum-only — the 7.3 GB mirror, chunk totals beyond the self-prefixing emit's limit (scan launch),
+    21 M records — against the oracle on all 10^8 entities: visible set, isVisible, and a checksum of the records."""
+    import psutil
+
+    from garden_amd.lib import GpuVisibility
+    if psutil.virtual_memory().available < 96 * 2 ** 30:
+        pytest.skip("needs ~60 GB of free host memory")
+    n = 100_000_000
+    sc = scene.flat_scene(n)
+    view = scene.main_camera_view()
+    with GpuVisibility(device=0) as vis:
+        bind(vis, sc)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=n)
+    exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, view, threads=THREADS)  # isVisible written in place
+    assert got["draw_count"] == exp["draw_count"] > 10_000_000
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    assert np.array_equal(got["visible_idx"], exp["visible_idx"][o])
+    assert np.array_equal(got["is_visible"], sc.meshes["isVisible"])
+    # records: bit patterns summed per column (order-independent checksum) + a directly compared slice
+    assert np.array_equal(got["baked_model"].view(np.uint32).sum(axis=0, dtype=np.uint64),
+                          exp["baked_model"].view(np.uint32).sum(axis=0, dtype=np.uint64))
+    assert np.array_equal(got["baked_model"][:500_000].view(np.uint32), exp["baked_model"][o[:500_000]].view(np.uint32))
+    assert np.array_equal(got["distance_sq"].view(np.uint32).sum(dtype=np.uint64), exp["distance_sq"].view(np.uint32).sum(dtype=np.uint64))
+
 
 def test_identity_parent_leaves_the_visible_set_unchanged(gpu):
     """M_parent = I: fma(1, a, fma(0, b, ...)) returns a, so hanging every entity under an identity parent must not

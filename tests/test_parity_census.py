@@ -1,0 +1,33 @@
+"""The parity-risk census (oracle/gv_census.cpp, tools/parity_census.py): variant 0 of the census IS the oracle, and the
+alternative operation orders (float64, root-first association, un-fused, GCC-contracted) can only change a decision for
+an entity whose deciding corner lies within a few float32 ulps of a frustum plane."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_census_variant_0_is_the_oracle_and_ordinary_scenes_do_not_flip(oracle):
+    import parity_census as pc
+    from garden_amd import scene
+    for sc, view, depth in ((scene.flat_scene(60_000), scene.main_camera_view(use_hiz=1), scene.synthetic_depth(256, 128)),
+                            (scene.hierarchy_scene(60_000, depth=4, fanout=6), scene.main_camera_view(), None)):
+        out = pc.census("t", sc, view, depth, threads=4)  # asserts variant 0 == oracle.prepare_meshes inside
+        assert out["visible"] > 0
+        for label, rec in out["variants"].items():
+            # a uniformly random scene of this size has nobody within ulps of a plane
+            assert rec["flips"] <= 2, (label, rec)
+
+
+def test_flips_only_happen_within_ulps_of_a_plane(oracle):
+    import parity_census as pc
+    out = pc.band_census(threads=4, n=120_000)
+    assert sum(out["entities_per_bin"]) == 120_000
+    for label, rec in out["variants"].items():
+        assert rec["flips"] > 0, "the adversarial scene must expose the order dependence"
+        # nothing flips once the deciding corner is farther than 1e-6 of its distance from the plane (8 float32 ulps)
+        assert rec["max_margin_over_distance_of_a_flip"] < 1e-6, (label, rec)
+        assert sum(rec["flips_per_bin"][4:]) == 0
