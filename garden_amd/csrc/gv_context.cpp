@@ -134,41 +134,281 @@ int hiz_reduce(GvCtx* ctx)
     return GV_OK;
 }
 
+HizDevice hiz_device(const GvCtx* ctx)
+{
+    HizDevice hz{};
+    if (ctx->hiz_valid) {
+        hz.depth = ctx->depth_ptr;
+        hz.mips = ctx->d_mips.ptr;
+        hz.mip_offset = ctx->d_mip_offset.ptr;
+        hz.width = ctx->hiz_w;
+        hz.height = ctx->hiz_h;
+        hz.mip_count = ctx->hiz_mips;
+        hz.nested = ctx->hiz_nested ? 1u : 0u;
+        hz.level1_virtual = ctx->hiz_level1_virtual ? 1u : 0u;
+    }
+    return hz;
+}
+
+// The launches of one gv_cull (views already reserved and marked valid by gv_cull): the sweep riding on it, block
+// bounds, the cull itself in the form that fits (fused sweep + cull, cull + emit in one launch, batched views, ...),
+// compaction and emission.
+int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t view_count, bool batched)
+{
+    PoolState& p = ctx->pools[pool_id];
+    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.occupancy, p.mapping, p.perm.empty() ? nullptr : p.d_orig.ptr};
+    const TransformMirror xf = xf_mirror(ctx);
+    const HizDevice hz = hiz_device(ctx);
+    const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
+    ViewBuffers vbs[GV_MAX_VIEWS];
+    for (uint32_t v = 0; v < view_count; v++)
+        vbs[v] = view_buffers(ctx->views[pool_id][v]);
+    int rc = GV_OK;
+    // GV_SWEEP_WITH_CULL: an exactly paired pool takes the fused MFMA sweep + cull for its first view; anything else
+    // gets the same results from the plain MFMA sweep followed by the ordinary cull
+    const bool sweep_requested = ctx->sweep_with_cull;
+    ctx->sweep_with_cull = false;
+    const bool fused = sweep_requested && !batched && p.occupancy != 0 && mesh.mapping == kMapExact && mesh.count <= xf.count;
+    if (sweep_requested) {
+        GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(ctx->xf.occupancy, 1u) * 3));
+        if (!fused) {
+            KernelTimer t(ctx, GV_K_SWEEP);
+            if (ctx->sweep_with_cull_mfma)
+                GV_HIP(ctx, launch_sweep_mfma(xf, ctx->d_world.ptr, ctx->stream));
+            else
+                GV_HIP(ctx, launch_sweep_valu(xf, ctx->d_world.ptr, ctx->stream));
+        }
+        if ((rc = world_current(ctx)) != GV_OK)  // (the fused form below writes every slot of the same buffer)
+            return rc;
+    }
+    // GV_CONFIG_BLOCK_BOUNDS: workgroup boxes are (re)built when the mirror of this pool is clean, or has just changed
+    // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
+    BlockBounds bounds;
+    bool use_bounds = false;
+    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !fused) {
+        const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
+        bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
+        if (!current && !(changed && p.changed_prev)) {
+            const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
+            GV_HIP(ctx, p.d_blk_lo.reserve(nb));
+            GV_HIP(ctx, p.d_blk_hi.reserve(nb));
+            KernelTimer t(ctx, GV_K_SWEEP);  // accounted with the other per-change passes
+            GV_HIP(ctx, launch_block_bounds(mesh, xf, p.d_blk_lo.ptr, p.d_blk_hi.ptr, ctx->stream));
+            p.bounds_epoch = p.epoch;
+            p.bounds_xf_epoch = ctx->xf_epoch;
+            current = true;
+        }
+        p.changed_prev = changed;
+        p.seen_epoch = p.epoch;
+        p.seen_xf_epoch = ctx->xf_epoch;
+        if (current) {
+            GV_HIP(ctx, ctx->d_examined.reserve((p.occupancy + kCullBlock - 1) / kCullBlock));
+            use_bounds = true;
+        }
+    }
+    // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
+    // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
+    static const bool emit_from_world = getenv("GV_DEBUG_EMIT_CHAIN") == nullptr;
+    const float4* emit_world = (ctx->world_valid && !ctx->world_partial && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
+    if (p.occupancy != 0) {
+        if (use_bounds) {
+            bounds.lo = p.d_blk_lo.ptr;
+            bounds.hi = p.d_blk_hi.ptr;
+            bounds.examined = ctx->d_examined.ptr;
+            ctx->bounds_blocks_total = (p.occupancy + kCullBlock - 1) / kCullBlock;
+        }
+        if (batched) {
+            KernelTimer t(ctx, GV_K_CULL);
+            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
+        }
+        static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
+        // a batched cull whose views all want records: ONE self-prefixing emit launch for all of them
+        bool emit_batched = batched && chunks <= self_max;
+        for (uint32_t v = 0; v < view_count && emit_batched; v++)
+            emit_batched = ctx->views[pool_id][v].emitted;
+        if (emit_batched) {
+            uint32_t clear[GV_MAX_VIEWS];
+            for (uint32_t v = 0; v < view_count; v++) {
+                ViewState& vs = ctx->views[pool_id][v];
+                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+                clear[v] = std::max(chunks, vs.stale_chunks[other]);
+                vs.stale_chunks[other] = 0;
+                vs.stale_chunks[cur] = chunks;
+                vs.count_parity = other;
+            }
+            KernelTimer t(ctx, GV_K_EMIT);
+            GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream, emit_world));
+        }
+        // one view, records wanted, pool small enough for the look-back form to win: cull + emit in ONE launch
+        static const uint32_t fused_emit_max = getenv("GV_DEBUG_FUSED_EMIT_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_FUSED_EMIT_MAX")) : kFusedEmitMaxSlots;
+        if (!batched && !fused && !use_bounds && view_count == 1 && ctx->views[pool_id][0].emitted && p.occupancy <= fused_emit_max) {
+            ViewState& vs = ctx->views[pool_id][0];
+            const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
+            if (nb > vs.tile_status.cap || !vs.tile_ticket.ptr) {
+                GV_HIP(ctx, vs.tile_status.reserve(nb));
+                GV_HIP(ctx, vs.tile_ticket.reserve(1));
+                GV_HIP(ctx, hipMemsetAsync(vs.tile_status.ptr, 0, vs.tile_status.cap * sizeof(unsigned long long), ctx->stream));
+                GV_HIP(ctx, hipMemsetAsync(vs.tile_ticket.ptr, 0, sizeof(uint32_t), ctx->stream));
+                vs.tile_ticket_base = 0;
+                vs.tile_epoch = 0;
+            }
+            vs.tile_epoch = vs.tile_epoch == UINT32_MAX ? 1u : vs.tile_epoch + 1u;
+            {
+                KernelTimer t(ctx, GV_K_CULL);
+                GV_HIP(ctx, launch_cull_emit(mesh, xf, hz, vps[0], vbs[0], vs.tile_status.ptr, vs.tile_ticket.ptr, vs.tile_ticket_base,
+                                             vs.tile_epoch, ctx->stream));
+            }
+            vs.tile_ticket_base += (uint32_t)nb;
+            for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
+                ctx->views[pool_id][v].valid = false;
+            ctx->last_pool = pool_id;
+            return GV_OK;
+        }
+        for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
+            if (!batched) {
+                KernelTimer t(ctx, GV_K_CULL);
+                if (fused && v == 0)
+                    GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
+                else {
+                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
+                }
+            }
+            if (ctx->views[pool_id][v].emitted && chunks <= self_max) {
+                // no scan launch: emit derives the chunk bases itself and leaves THIS totals buffer as it is; the
+                // next cull of this view adds into the other one, which this emit has cleared
+                ViewState& vs = ctx->views[pool_id][v];
+                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+                KernelTimer t(ctx, GV_K_EMIT);
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world));
+                vs.stale_chunks[other] = 0;
+                vs.stale_chunks[cur] = chunks;
+                vs.count_parity = other;
+                continue;
+            }
+            {
+                KernelTimer t(ctx, GV_K_SCAN);
+                GV_HIP(ctx, launch_scan(vbs[v], chunks, ctx->stream));
+            }
+            if (ctx->views[pool_id][v].emitted) {
+                KernelTimer t(ctx, GV_K_EMIT);
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world));
+            }
+        }
+    }
+    for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
+        ctx->views[pool_id][v].valid = false;
+    ctx->last_pool = pool_id;
+    return GV_OK;
+}
+
+// The culls recorded since gv_cull_batch_begin: ONE cull launch for all of them (blockIdx.y = job) and ONE emit launch
+// for all their views. Descriptors are built from the pools' CURRENT mirrors and shipped as one small table.
+int flush_culls(GvCtx* ctx)
+{
+    ctx->cull_batching = false;  // the batch ends with its first read
+    if (ctx->cull_jobs.empty())
+        return GV_OK;
+    std::vector<Context::CullJob> jobs;
+    jobs.swap(ctx->cull_jobs);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (jobs.size() == 1) {  // nothing to batch: the ordinary launches (cull + emit in one for a single view) are shorter
+        bool batched = jobs[0].view_count > 1;
+        return cull_launch(ctx, jobs[0].pool_id, jobs[0].vps, jobs[0].view_count, batched);
+    }
+    const size_t cull_bytes = cull_table_entry_bytes(), emit_bytes = emit_table_entry_bytes();
+    uint32_t emit_entries = 0, max_slots = 0;
+    for (const auto& j : jobs)
+        emit_entries += j.view_count;
+    const size_t cull_off = 0, emit_off = (jobs.size() * cull_bytes + 255) & ~(size_t)255;
+    const size_t total = emit_off + (size_t)emit_entries * emit_bytes;
+    const uint32_t turn = ctx->tick_turn;
+    ctx->tick_turn ^= 1u;
+    if (!ctx->tick_done[turn])
+        GV_HIP(ctx, hipEventCreateWithFlags(&ctx->tick_done[turn], hipEventDisableTiming));
+    GV_HIP(ctx, hipEventSynchronize(ctx->tick_done[turn]));  // (a never-recorded event is complete)
+    GV_HIP(ctx, ctx->h_tick[turn].reserve(total));
+    if (total > ctx->d_tick.cap) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // kernels of the previous tick may still read the old table
+        GV_HIP(ctx, ctx->d_tick.reserve(total + total / 2));
+    }
+    uint8_t* host = ctx->h_tick[turn].ptr;
+    const TransformMirror xf = xf_mirror(ctx);
+    const HizDevice hz = hiz_device(ctx);
+    uint32_t e = 0;
+    for (size_t k = 0; k < jobs.size(); k++) {
+        const auto& j = jobs[k];
+        PoolState& p = ctx->pools[j.pool_id];
+        const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.occupancy, p.mapping, p.perm.empty() ? nullptr : p.d_orig.ptr};
+        const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
+        ViewBuffers vbs[GV_MAX_VIEWS];
+        for (uint32_t v = 0; v < j.view_count; v++)
+            vbs[v] = view_buffers(ctx->views[j.pool_id][v]);
+        fill_cull_table_entry(host + cull_off + k * cull_bytes, mesh, xf, hz, j.vps, vbs, j.view_count);
+        for (uint32_t v = 0; v < j.view_count; v++) {
+            ViewState& vs = ctx->views[j.pool_id][v];
+            const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+            fill_emit_table_entry(host + emit_off + (size_t)(e++) * emit_bytes, mesh, xf, j.vps[v], vbs[v],
+                                  std::max(chunks, vs.stale_chunks[other]), nullptr);
+            vs.stale_chunks[other] = 0;
+            vs.stale_chunks[cur] = chunks;
+            vs.count_parity = other;
+        }
+        max_slots = std::max(max_slots, p.occupancy);
+    }
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_tick.ptr, host, total, hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipEventRecord(ctx->tick_done[turn], ctx->stream));
+    {
+        ZoneScope zone("Meshes Prepare");
+        {
+            KernelTimer t(ctx, GV_K_CULL);
+            GV_HIP(ctx, launch_cull_table(ctx->d_tick.ptr + cull_off, (uint32_t)jobs.size(), max_slots, ctx->stream));
+        }
+        KernelTimer t(ctx, GV_K_EMIT);
+        GV_HIP(ctx, launch_emit_table(ctx->d_tick.ptr + emit_off, emit_entries, max_slots, ctx->stream));
+    }
+    return GV_OK;
+}
+
 // gv_sort on a small pool only records the request; the first call that needs the records (fetch, device accessors,
-// gv_wait) sorts every pending view of the pool in ONE launch — main camera + shadow passes cost one launch, not one each.
+// gv_wait) sorts every pending view of EVERY pool in ONE launch — five mesh systems with a main camera and three shadow
+// passes each cost one launch, not twenty.
 int flush_sorts(GvCtx* ctx)
 {
+    if (int rc = flush_culls(ctx))  // the records about to be sorted / read may still be waiting to be culled
+        return rc;
     for (;;) {
-        uint32_t occupancy = 0, views = 0;
-        ViewState* taken[GV_MAX_VIEWS];
+        uint32_t widest = 0, views = 0;
+        ViewState* taken[kMaxPublishViews];
         SortBatch batch{};
-        for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
-            ViewState& vs = ctx->views[v];
-            if (!vs.valid || !vs.sort_pending || (views && vs.occupancy != occupancy))
-                continue;
-            occupancy = vs.occupancy;
-            const size_t n = vs.occupancy;
-            GV_HIP(ctx, vs.alt_idx.reserve(n));
-            GV_HIP(ctx, vs.alt_model.reserve(n * 12));
-            GV_HIP(ctx, vs.alt_dist.reserve(n));
-            SortBuffers& b = batch.view[views];
-            b.count = vs.draw_count.ptr;
-            b.idx_in = vs.visible_idx.ptr;
-            b.model_in = vs.baked_model.ptr;
-            b.dist_in = vs.distance_sq.ptr;
-            b.idx_out = vs.alt_idx.ptr;
-            b.model_out = vs.alt_model.ptr;
-            b.dist_out = vs.alt_dist.ptr;
-            batch.descending[views] = vs.sort_pending == 2 ? 1u : 0u;
-            taken[views++] = &vs;
-        }
+        for (uint32_t pool = 0; pool < GV_MAX_POOLS && views < kMaxPublishViews; pool++)
+            for (uint32_t v = 0; v < GV_MAX_VIEWS && views < kMaxPublishViews; v++) {
+                ViewState& vs = ctx->views[pool][v];
+                if (!vs.valid || !vs.sort_pending)
+                    continue;
+                const size_t n = vs.occupancy;
+                GV_HIP(ctx, vs.alt_idx.reserve(n));
+                GV_HIP(ctx, vs.alt_model.reserve(n * 12));
+                GV_HIP(ctx, vs.alt_dist.reserve(n));
+                SmallSortEntry& b = batch.view[views];
+                b.count = vs.draw_count.ptr;
+                b.idx_in = vs.visible_idx.ptr;
+                b.model_in = vs.baked_model.ptr;
+                b.dist_in = vs.distance_sq.ptr;
+                b.idx_out = vs.alt_idx.ptr;
+                b.model_out = vs.alt_model.ptr;
+                b.dist_out = vs.alt_dist.ptr;
+                b.capacity = vs.occupancy;
+                b.descending = vs.sort_pending == 2 ? 1u : 0u;
+                widest = std::max(widest, vs.occupancy);
+                taken[views++] = &vs;
+            }
         if (views == 0)
             return GV_OK;
         GV_HIP(ctx, hipSetDevice(ctx->device));
         {
             ZoneScope zone("Meshes Sort");
             KernelTimer t(ctx, GV_K_SORT);
-            GV_HIP(ctx, launch_sort_small_batch(batch, views, occupancy, ctx->stream));
+            GV_HIP(ctx, launch_sort_small_batch(batch, views, widest, ctx->stream));
         }
         for (uint32_t k = 0; k < views; k++) {  // the sorted records now live in the alternate set: swap it in
             ViewState& vs = *taken[k];
@@ -179,6 +419,13 @@ int flush_sorts(GvCtx* ctx)
             vs.published = false;
         }
     }
+}
+
+ViewState* view_of(GvCtx* ctx, uint32_t pool_id, uint32_t view_index)
+{
+    if (pool_id >= GV_MAX_POOLS || view_index >= GV_MAX_VIEWS || !ctx->views[pool_id][view_index].valid)
+        return nullptr;
+    return &ctx->views[pool_id][view_index];
 }
 
 }  // namespace
@@ -265,13 +512,15 @@ void gv_destroy(GvCtx* ctx)
     for (auto& p : ctx->pools) {
         p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
     }
-    for (auto& v : ctx->views) {
+    for (auto& per_pool : ctx->views)
+      for (auto& v : per_pool) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
         v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
+        v.tile_status.release(); v.tile_ticket.release();
     }
     ctx->d_world.release(); ctx->d_xdirty.release(); ctx->d_raw.release(); ctx->d_examined.release();
     for (int k = 0; k < 2; k++) {
@@ -281,7 +530,12 @@ void gv_destroy(GvCtx* ctx)
     }
     ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
     ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
-    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release();
+    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release();
+    for (int k = 0; k < 2; k++) {
+        ctx->h_tick[k].release();
+        if (ctx->tick_done[k])
+            (void)hipEventDestroy(ctx->tick_done[k]);
+    }
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -476,22 +730,9 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     if (rc != GV_OK)
         return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    const MeshMirror mesh{p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.occupancy, p.mapping, p.perm.empty() ? nullptr : p.d_orig.ptr};
-    const TransformMirror xf = xf_mirror(ctx);
-    HizDevice hz{};
     for (uint32_t v = 0; v < view_count; v++) {
         if (views[v].use_hiz && !ctx->hiz_valid)
             return ctx->fail(GV_E_STATE, "gv_cull: view %u asks for Hi-Z but gv_hiz_build has not run", v);
-    }
-    if (ctx->hiz_valid) {
-        hz.depth = ctx->depth_ptr;
-        hz.mips = ctx->d_mips.ptr;
-        hz.mip_offset = ctx->d_mip_offset.ptr;
-        hz.width = ctx->hiz_w;
-        hz.height = ctx->hiz_h;
-        hz.mip_count = ctx->hiz_mips;
-        hz.nested = ctx->hiz_nested ? 1u : 0u;
-        hz.level1_virtual = ctx->hiz_level1_virtual ? 1u : 0u;
     }
     // Views that share cameraPosition (the main camera and its shadow cascades: mesh.cpp:809-843 passes the same
     // cameraPosition to every prepareMeshes) are culled in ONE pass over the streams; Hi-Z only on view 0.
@@ -499,10 +740,8 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
     for (uint32_t v = 1; v < view_count && batched; v++)
         batched = memcmp(views[v].camera_position, views[0].camera_position, 12) == 0 && !views[v].use_hiz;
     ViewParams vps[GV_MAX_VIEWS];
-    ViewBuffers vbs[GV_MAX_VIEWS];
-    const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
     for (uint32_t v = 0; v < view_count; v++) {
-        ViewState& vs = ctx->views[v];
+        ViewState& vs = ctx->views[pool_id][v];
         const bool emit = views[v].emit_records != 0;
         rc = reserve_view(ctx, vs, p.occupancy, emit);
         if (rc != GV_OK)
@@ -515,119 +754,53 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.published = false;
         vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
         build_view_params(views[v], &vps[v]);
-        vbs[v] = view_buffers(vs);
         if (p.occupancy == 0)
             GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
     }
-    // GV_SWEEP_WITH_CULL: an exactly paired pool takes the fused MFMA sweep + cull for its first view; anything else
-    // gets the same results from the plain MFMA sweep followed by the ordinary cull
-    const bool sweep_requested = ctx->sweep_with_cull;
-    ctx->sweep_with_cull = false;
-    const bool fused = sweep_requested && !batched && p.occupancy != 0 && mesh.mapping == kMapExact && mesh.count <= xf.count;
-    if (sweep_requested) {
-        GV_HIP(ctx, ctx->d_world.reserve((size_t)std::max(ctx->xf.occupancy, 1u) * 3));
-        if (!fused) {
-            KernelTimer t(ctx, GV_K_SWEEP);
-            if (ctx->sweep_with_cull_mfma)
-                GV_HIP(ctx, launch_sweep_mfma(xf, ctx->d_world.ptr, ctx->stream));
-            else
-                GV_HIP(ctx, launch_sweep_valu(xf, ctx->d_world.ptr, ctx->stream));
-        }
-        if ((rc = world_current(ctx)) != GV_OK)  // (the fused form below writes every slot of the same buffer)
-            return rc;
-    }
-    // GV_CONFIG_BLOCK_BOUNDS: workgroup boxes are (re)built when the mirror of this pool is clean, or has just changed
-    // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
-    BlockBounds bounds;
-    bool use_bounds = false;
-    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !fused) {
-        const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
-        bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
-        if (!current && !(changed && p.changed_prev)) {
-            const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
-            GV_HIP(ctx, p.d_blk_lo.reserve(nb));
-            GV_HIP(ctx, p.d_blk_hi.reserve(nb));
-            KernelTimer t(ctx, GV_K_SWEEP);  // accounted with the other per-change passes
-            GV_HIP(ctx, launch_block_bounds(mesh, xf, p.d_blk_lo.ptr, p.d_blk_hi.ptr, ctx->stream));
-            p.bounds_epoch = p.epoch;
-            p.bounds_xf_epoch = ctx->xf_epoch;
-            current = true;
-        }
-        p.changed_prev = changed;
-        p.seen_epoch = p.epoch;
-        p.seen_xf_epoch = ctx->xf_epoch;
-        if (current) {
-            GV_HIP(ctx, ctx->d_examined.reserve((p.occupancy + kCullBlock - 1) / kCullBlock));
-            use_bounds = true;
+    // gv_cull_batch_begin: an engine-sized pool whose views all want records is only RECORDED here; the first read
+    // launches every recorded cull together (flush_culls)
+    if (ctx->cull_batching) {
+        bool eligible = p.occupancy != 0 && p.occupancy <= kSmallSortMaxSlots && !ctx->sweep_with_cull &&
+                        !(ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && (view_count == 1 || batched) &&
+                        ctx->cull_jobs.size() < GV_MAX_POOLS;
+        for (uint32_t v = 0; v < view_count && eligible; v++)
+            eligible = ctx->views[pool_id][v].emitted;
+        for (const auto& j : ctx->cull_jobs)
+            if (j.pool_id == pool_id) {  // a second cull of a pool inside one batch: run the first one now
+                if ((rc = flush_culls(ctx)) != GV_OK)
+                    return rc;
+                ctx->cull_batching = true;
+                break;
+            }
+        if (eligible) {
+            Context::CullJob job;
+            job.pool_id = pool_id;
+            job.view_count = view_count;
+            for (uint32_t v = 0; v < view_count; v++)
+                job.vps[v] = vps[v];
+            ctx->cull_jobs.push_back(job);
+            for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
+                ctx->views[pool_id][v].valid = false;
+            ctx->last_pool = pool_id;
+            return GV_OK;
         }
     }
-    // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
-    // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
-    static const bool emit_from_world = getenv("GV_DEBUG_EMIT_CHAIN") == nullptr;
-    const float4* emit_world = (ctx->world_valid && !ctx->world_partial && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
-    if (p.occupancy != 0) {
-        if (use_bounds) {
-            bounds.lo = p.d_blk_lo.ptr;
-            bounds.hi = p.d_blk_hi.ptr;
-            bounds.examined = ctx->d_examined.ptr;
-            ctx->bounds_blocks_total = (p.occupancy + kCullBlock - 1) / kCullBlock;
-        }
-        if (batched) {
-            KernelTimer t(ctx, GV_K_CULL);
-            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
-        }
-        static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
-        // a batched cull whose views all want records: ONE self-prefixing emit launch for all of them
-        bool emit_batched = batched && chunks <= self_max;
-        for (uint32_t v = 0; v < view_count && emit_batched; v++)
-            emit_batched = ctx->views[v].emitted;
-        if (emit_batched) {
-            uint32_t clear[GV_MAX_VIEWS];
-            for (uint32_t v = 0; v < view_count; v++) {
-                ViewState& vs = ctx->views[v];
-                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
-                clear[v] = std::max(chunks, vs.stale_chunks[other]);
-                vs.stale_chunks[other] = 0;
-                vs.stale_chunks[cur] = chunks;
-                vs.count_parity = other;
-            }
-            KernelTimer t(ctx, GV_K_EMIT);
-            GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream, emit_world));
-        }
-        for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
-            if (!batched) {
-                KernelTimer t(ctx, GV_K_CULL);
-                if (fused && v == 0)
-                    GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
-                else {
-                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
-                }
-            }
-            if (ctx->views[v].emitted && chunks <= self_max) {
-                // no scan launch: emit derives the chunk bases itself and leaves THIS totals buffer as it is; the
-                // next cull of this view adds into the other one, which this emit has cleared
-                ViewState& vs = ctx->views[v];
-                const uint32_t cur = vs.count_parity, other = cur ^ 1u;
-                KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world));
-                vs.stale_chunks[other] = 0;
-                vs.stale_chunks[cur] = chunks;
-                vs.count_parity = other;
-                continue;
-            }
-            {
-                KernelTimer t(ctx, GV_K_SCAN);
-                GV_HIP(ctx, launch_scan(vbs[v], chunks, ctx->stream));
-            }
-            if (ctx->views[v].emitted) {
-                KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world));
-            }
-        }
-    }
-    for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
-        ctx->views[v].valid = false;
+    return cull_launch(ctx, pool_id, vps, view_count, batched);
+}
+
+int gv_cull_batch_begin(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    ctx->cull_batching = true;
     return GV_OK;
+}
+
+int gv_cull_batch_end(GvCtx* ctx)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    return flush_culls(ctx);
 }
 
 int gv_wait(GvCtx* ctx)
@@ -644,11 +817,18 @@ int gv_wait(GvCtx* ctx)
 
 int gv_result_count(GvCtx* ctx, uint32_t view_index, uint32_t* draw_count)
 {
+    return ctx ? gv_pool_result_count(ctx, ctx->last_pool, view_index, draw_count) : GV_E_ARG;
+}
+
+int gv_pool_result_count(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t* draw_count)
+{
     if (!ctx)
         return GV_E_ARG;
-    if (view_index >= GV_MAX_VIEWS || !draw_count || !ctx->views[view_index].valid)
-        return ctx->fail(GV_E_ARG, "gv_result_count: view %u has no results", view_index);
-    ViewState& vs = ctx->views[view_index];
+    if (!draw_count || !view_of(ctx, pool_id, view_index))
+        return ctx->fail(GV_E_ARG, "gv_result_count: pool %u view %u has no results", pool_id, view_index);
+    if (int rc = flush_culls(ctx))
+        return rc;
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, hipMemcpyAsync(vs.h_draw_count.ptr, vs.draw_count.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -659,15 +839,20 @@ int gv_result_count(GvCtx* ctx, uint32_t view_index, uint32_t* draw_count)
 
 int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* out)
 {
+    return ctx ? gv_pool_results_fetch(ctx, ctx->last_pool, view_index, write_back, out) : GV_E_ARG;
+}
+
+int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int write_back, GvResult* out)
+{
     if (!ctx)
         return GV_E_ARG;
     if (!out)
         return ctx->fail(GV_E_ARG, "gv_results_fetch: out is NULL");
-    if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid)
-        return ctx->fail(GV_E_ARG, "gv_results_fetch: view %u has no results", view_index);
+    if (!view_of(ctx, pool_id, view_index))
+        return ctx->fail(GV_E_ARG, "gv_results_fetch: pool %u view %u has no results", pool_id, view_index);
     if (int rc = flush_sorts(ctx))
         return rc;
-    ViewState& vs = ctx->views[view_index];
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
     PoolState& pool = ctx->pools[vs.pool_id];
     const bool permuted = !pool.perm.empty() && pool.perm.size() == vs.occupancy;
     const bool small = vs.occupancy != 0 && vs.occupancy <= kPublishMaxSlots;
@@ -688,44 +873,53 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         // their results already there
         if (!vs.published) {
             GV_HIP(ctx, hipSetDevice(ctx->device));
-            static_assert(kMaxPublishViews == GV_MAX_VIEWS, "PublishBatch holds one entry per view");
+            static_assert(kMaxPublishViews >= GV_MAX_VIEWS, "PublishBatch holds at least one pool's views");
+            // ... of EVERY pool culled since the last fetch: a frame that culls all its mesh systems first and reads
+            // afterwards (gv_pool_results_fetch) ends with this one launch and one synchronisation
             PublishBatch batch{};
-            uint32_t views = 0;
-            ViewState* sent[GV_MAX_VIEWS];
-            for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
-                ViewState& w = ctx->views[v];
-                if (!w.valid || w.published || w.pool_id != vs.pool_id || w.occupancy != vs.occupancy)
-                    continue;
-                PublishArgs& a = batch.view[views];
-                a.count = w.draw_count.ptr;
-                a.idx = w.visible_idx.ptr;
-                a.model = w.baked_model.ptr;
-                a.dist = w.distance_sq.ptr;
-                a.is_visible = w.is_visible.ptr;
-                a.host_count = w.h_draw_count.ptr;
-                if (w.emitted) {
-                    GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
-                    GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
-                    GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
-                    a.host_idx = w.h_visible_idx.ptr;
-                    a.host_model = w.h_baked_model.ptr;
-                    a.host_dist = w.h_distance_sq.ptr;
-                }
-                a.orig = permuted ? pool.d_orig.ptr : nullptr;
-                if (w.main_pass) {
-                    GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
-                    a.host_is_visible = w.h_is_visible.ptr;
-                    if (permuted && w.occupancy > kPublishLdsSlots) {  // too large for the in-LDS un-permutation
-                        GV_HIP(ctx, w.is_visible_slots.reserve(w.occupancy));
-                        GV_HIP(ctx, launch_unpermute_bytes(w.is_visible.ptr, pool.d_orig.ptr, w.occupancy, w.is_visible_slots.ptr, ctx->stream));
-                        a.is_visible = w.is_visible_slots.ptr;
-                        a.orig = nullptr;
+            uint32_t views = 0, widest = 0;
+            ViewState* sent[kMaxPublishViews];
+            for (uint32_t q = 0; q < GV_MAX_POOLS && views < kMaxPublishViews; q++) {
+                const uint32_t pid = (pool_id + q) % GV_MAX_POOLS;  // the pool asked for first: it always fits
+                PoolState& wp = ctx->pools[pid];
+                for (uint32_t v = 0; v < GV_MAX_VIEWS && views < kMaxPublishViews; v++) {
+                    ViewState& w = ctx->views[pid][v];
+                    if (!w.valid || w.published || w.occupancy == 0 || w.occupancy > kPublishMaxSlots)
+                        continue;
+                    const bool wperm = !wp.perm.empty() && wp.perm.size() == w.occupancy;
+                    PublishArgs& a = batch.view[views];
+                    a.count = w.draw_count.ptr;
+                    a.idx = w.visible_idx.ptr;
+                    a.model = w.baked_model.ptr;
+                    a.dist = w.distance_sq.ptr;
+                    a.is_visible = w.is_visible.ptr;
+                    GV_HIP(ctx, w.h_draw_count.reserve(4));
+                    a.host_count = w.h_draw_count.ptr;
+                    if (w.emitted) {
+                        GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
+                        GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
+                        GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
+                        a.host_idx = w.h_visible_idx.ptr;
+                        a.host_model = w.h_baked_model.ptr;
+                        a.host_dist = w.h_distance_sq.ptr;
                     }
+                    a.orig = wperm ? wp.d_orig.ptr : nullptr;
+                    if (w.main_pass) {
+                        GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
+                        a.host_is_visible = w.h_is_visible.ptr;
+                        if (wperm && w.occupancy > kPublishLdsSlots) {  // too large for the in-LDS un-permutation
+                            GV_HIP(ctx, w.is_visible_slots.reserve(w.occupancy));
+                            GV_HIP(ctx, launch_unpermute_bytes(w.is_visible.ptr, wp.d_orig.ptr, w.occupancy, w.is_visible_slots.ptr, ctx->stream));
+                            a.is_visible = w.is_visible_slots.ptr;
+                            a.orig = nullptr;
+                        }
+                    }
+                    a.occupancy = w.occupancy;
+                    widest = std::max(widest, w.occupancy);
+                    sent[views++] = &w;
                 }
-                a.occupancy = w.occupancy;
-                sent[views++] = &w;
             }
-            GV_HIP(ctx, launch_publish(batch, views, vs.occupancy, ctx->stream));
+            GV_HIP(ctx, launch_publish(batch, views, widest, ctx->stream));
             GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             drain_events(ctx);
             for (uint32_t k = 0; k < views; k++)
@@ -733,7 +927,7 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
         }
         count = vs.h_draw_count.ptr[0];
     } else {
-        int rc = gv_result_count(ctx, view_index, &count);
+        int rc = gv_pool_result_count(ctx, pool_id, view_index, &count);
         if (rc != GV_OK)
             return rc;
         if (vs.emitted && count) {
@@ -811,13 +1005,18 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
 
 int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out)
 {
+    return ctx ? gv_pool_results_device(ctx, ctx->last_pool, view_index, out) : GV_E_ARG;
+}
+
+int gv_pool_results_device(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, GvDeviceResult* out)
+{
     if (!ctx)
         return GV_E_ARG;
-    if (view_index >= GV_MAX_VIEWS || !out || !ctx->views[view_index].valid)
-        return ctx->fail(GV_E_ARG, "gv_results_device: view %u has no results", view_index);
+    if (!out || !view_of(ctx, pool_id, view_index))
+        return ctx->fail(GV_E_ARG, "gv_results_device: pool %u view %u has no results", pool_id, view_index);
     if (int rc = flush_sorts(ctx))
         return rc;
-    ViewState& vs = ctx->views[view_index];
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
     out->visible_idx = vs.emitted ? vs.visible_idx.ptr : nullptr;
     out->baked_model = vs.emitted ? vs.baked_model.ptr : nullptr;
     out->distance_sq = vs.emitted ? vs.distance_sq.ptr : nullptr;
@@ -831,11 +1030,11 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 {
     if (!ctx)
         return GV_E_ARG;
-    if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
+    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index) || !view_of(ctx, ctx->last_pool, view_index)->emitted)
         return ctx->fail(GV_E_ARG, "gv_results_copy_idx_device: view %u has no emitted records", view_index);
     if (int rc = flush_sorts(ctx))
         return rc;
-    ViewState& vs = ctx->views[view_index];
+    ViewState& vs = *view_of(ctx, ctx->last_pool, view_index);
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const PoolState& pool = ctx->pools[vs.pool_id];
     GV_HIP(ctx, launch_copy_idx(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
@@ -848,11 +1047,11 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
 {
     if (!ctx)
         return GV_E_ARG;
-    if (view_index >= GV_MAX_VIEWS || !dst_device || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
+    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index) || !view_of(ctx, ctx->last_pool, view_index)->emitted)
         return ctx->fail(GV_E_ARG, "gv_results_copy_shard_device: view %u has no emitted records", view_index);
     if (int rc = flush_sorts(ctx))
         return rc;
-    ViewState& vs = ctx->views[view_index];
+    ViewState& vs = *view_of(ctx, ctx->last_pool, view_index);
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const PoolState& pool = ctx->pools[vs.pool_id];
     GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
@@ -879,12 +1078,17 @@ int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_i
 
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending)
 {
+    return ctx ? gv_pool_sort(ctx, ctx->last_pool, view_index, descending) : GV_E_ARG;
+}
+
+int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descending)
+{
     if (!ctx)
         return GV_E_ARG;
-    if (view_index >= GV_MAX_VIEWS || !ctx->views[view_index].valid || !ctx->views[view_index].emitted)
-        return ctx->fail(GV_E_ARG, "gv_sort: view %u has no emitted records", view_index);
+    if (!view_of(ctx, pool_id, view_index) || !view_of(ctx, pool_id, view_index)->emitted)
+        return ctx->fail(GV_E_ARG, "gv_sort: pool %u view %u has no emitted records", pool_id, view_index);
     ZoneScope zone("Meshes Sort");
-    ViewState& vs = ctx->views[view_index];
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
     if (vs.occupancy == 0)
         return GV_OK;
     if (vs.occupancy <= kSmallSortMaxSlots) {  // launched with the other views' sorts when the records are asked for
@@ -999,6 +1203,8 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
         return GV_E_ARG;
     if (!depth || width == 0 || height == 0 || width > 32768 || height > 32768)
         return ctx->fail(GV_E_ARG, "gv_hiz_build: bad depth image %ux%u", width, height);
+    if (int rc = flush_culls(ctx))  // recorded culls query the pyramid as it was when they were recorded
+        return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
     // calcMipCount(frameSize) hiz.cpp:27; sizes max(size / 2, 1) hiz.cpp:55
     uint32_t mips = 0;
@@ -1052,6 +1258,8 @@ int gv_hiz_rebuild(GvCtx* ctx)
         return GV_E_ARG;
     if (!ctx->hiz_valid)
         return ctx->fail(GV_E_STATE, "gv_hiz_rebuild: no depth image resident");
+    if (int rc = flush_culls(ctx))
+        return rc;
     GV_HIP(ctx, hipSetDevice(ctx->device));
     return hiz_reduce(ctx);
 }

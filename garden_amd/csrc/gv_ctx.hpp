@@ -269,6 +269,10 @@ struct ViewState {
     PinnedBuf<uint8_t> h_is_visible;
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;
+    // fused cull + emit (launch_cull_emit): look-back words, ticket counter and their running epoch / base
+    DeviceBuf<unsigned long long> tile_status;
+    DeviceBuf<uint32_t> tile_ticket;
+    uint32_t tile_ticket_base = 0, tile_epoch = 0;
     uint32_t sort_parity = 0;  // which of the two counter sets in sort_hist the next large sort uses (gv_sort.hip)
     uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
@@ -326,7 +330,22 @@ struct Context {
     DeviceBuf<uint8_t> dsc_u8;
 
     PoolState pools[GV_MAX_POOLS];
-    ViewState views[GV_MAX_VIEWS];
+    // results are kept per (pool, view): every mesh system's cull can be issued before the first result is read
+    // (gv_pool_results_fetch ...); the view-indexed entry points address the pool of the most recent gv_cull
+    ViewState views[GV_MAX_POOLS][GV_MAX_VIEWS];
+    uint32_t last_pool = 0;
+
+    // ---- a tick of engine-sized pools (gv_cull_batch_begin): culls recorded, launched together at the first read ----
+    struct CullJob {
+        uint32_t pool_id, view_count;
+        ViewParams vps[GV_MAX_VIEWS];
+    };
+    bool cull_batching = false;
+    std::vector<CullJob> cull_jobs;
+    PinnedBuf<uint8_t> h_tick[2];  // descriptor tables on their way to d_tick (double-buffered: the host may run ahead)
+    hipEvent_t tick_done[2] = {nullptr, nullptr};
+    uint32_t tick_turn = 0;
+    DeviceBuf<uint8_t> d_tick;
 
     // ---- world-matrix cache (gv_sweep) ----
     DeviceBuf<float4> d_world;

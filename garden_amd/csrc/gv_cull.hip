@@ -135,6 +135,156 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
     cull_block<HIZ, MAP>(args, lb, wave_count);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1 + K3 in one launch: cull, order-stable compaction and record emission of one view.
+// A workgroup culls its 256-entry tile, learns how many records the tiles before it hold by DECOUPLED LOOK-BACK (a
+// 64-bit status word per tile: epoch | flag | count; wave 0 inspects 64 predecessors per step) and writes its records —
+// the models are still in registers, so the emit kernel's second gather of the TRS streams and its second walk up the
+// parent chain disappear with its launch — through LDS as whole contiguous rows. Same records in the same order as
+// cull_kernel + emit_kernel (ascending mirror entry). Tiles are taken in order of arrival (a ticket per workgroup), so
+// a workgroup only ever waits for tiles whose workgroups are already running. The status words are stamped with the
+// launch's epoch and never cleared. Used where it measures faster than the two launches (gv_context.cpp picks).
+// ------------------------------------------------------------------------------------------------
+struct FusedEmit {
+    unsigned long long* status;  // one word per tile
+    uint32_t* ticket;            // running ticket counter (never reset: ticket_base is its value before this launch)
+    uint32_t ticket_base;
+    uint32_t epoch;              // != 0, different from the previous launches that used these words
+};
+constexpr unsigned long long kTileAggregate = 1ull << 30, kTilePrefix = 2ull << 30, kTileFlagMask = 3ull << 30, kTileCountMask = (1ull << 30) - 1ull;
+
+template <bool HIZ, uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void cull_emit_kernel(const CullArgs args, const FusedEmit fe)
+{
+    __shared__ uint32_t wave_count[kCullBlock / 64];
+    __shared__ uint32_t tile_s, base_s;
+    __shared__ float4 stage[kCullBlock * 3];
+    if (threadIdx.x == 0)
+        tile_s = atomicAdd(fe.ticket, 1u) - fe.ticket_base;
+    __syncthreads();
+    const uint32_t lb = tile_s;  // < nblocks: the grid has exactly nblocks workgroups
+    const uint32_t i = lb * kCullBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool visible = false;
+    Mat34 m = {};
+    if (i < args.mesh.count) {
+        float4 box_a;
+        float2 box_b;
+        Corners c;
+        uint32_t where = kSphereOutside;
+        if (prepare_model<MAP>(args.mesh, args.xf, args.view.cam, i, m, box_a, box_b))
+            where = classify_sphere(m, box_a, box_b, args.view.planes, args.view.plane_count);
+        visible = where == kSphereInside;
+        if (where == kSphereUndecided) {
+            aabb_corners(m, box_a, box_b, c);
+            visible = !behind_frustum(c, args.view.planes, args.view.plane_count);
+        } else if (HIZ && visible) {
+            aabb_corners(m, box_a, box_b, c);
+        }
+        if (HIZ && visible)
+            visible = !hiz_occluded(args.hiz, args.view.vp, c);
+        if (args.view.write_is_visible)
+            args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
+    }
+    const unsigned long long word = __ballot(visible);
+    if (lane == 0)
+        wave_count[wave] = (uint32_t)__popcll(word);
+    __syncthreads();
+    uint32_t total = 0, wave_prefix = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCullBlock / 64; w++) {
+        wave_prefix += w < wave ? wave_count[w] : 0u;
+        total += wave_count[w];
+    }
+    if (wave == 0) {  // look-back: 64 predecessors per step
+        const unsigned long long stamp = (unsigned long long)fe.epoch << 32;
+        uint32_t before = 0;
+        if (lb == 0) {
+            if (lane == 0)
+                __hip_atomic_store(&fe.status[0], stamp | kTilePrefix | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(&fe.status[lb], stamp | kTileAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int32_t p = (int32_t)lb - 1;  // nearest predecessor not consumed yet
+            for (;;) {
+                const int32_t q = p - (int32_t)lane;
+                unsigned long long v = stamp | kTilePrefix;  // in front of tile 0: nothing
+                if (q >= 0)
+                    v = __hip_atomic_load(&fe.status[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long flag = (uint32_t)(v >> 32) == fe.epoch ? (v & kTileFlagMask) : 0ull;  // other epochs: not published yet
+                const unsigned long long empties = __ballot(flag == 0ull), prefixes = __ballot(flag == kTilePrefix);
+                const uint32_t first_empty = empties ? (uint32_t)__builtin_ctzll(empties) : 64u;
+                const uint32_t first_prefix = prefixes ? (uint32_t)__builtin_ctzll(prefixes) : 64u;
+                const uint32_t upto = min(first_empty, first_prefix + 1u);  // lanes [0, upto) can be consumed
+                uint32_t part = lane < upto ? (uint32_t)(v & kTileCountMask) : 0u;
+#pragma unroll
+                for (uint32_t d = 32; d >= 1; d >>= 1)
+                    part += __shfl_xor(part, d, 64);
+                before += part;
+                if (first_prefix < first_empty)
+                    break;
+                p -= (int32_t)upto;
+                if (upto == 0)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0)
+                __hip_atomic_store(&fe.status[lb], stamp | kTilePrefix | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            base_s = before;
+            if (lb + 1 == args.nblocks)
+                *args.out.draw_count = before + total;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = base_s;
+    if (visible) {  // the record of mesh.cpp:169-173, at its final place
+        const uint32_t local = wave_prefix + (uint32_t)__popcll(word & ((1ull << lane) - 1ull));
+        const size_t rank = (size_t)base + local;
+        args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;
+        const float tx = m.c3x + args.view.cam_offset[0], ty = m.c3y + args.view.cam_offset[1], tz = m.c3z + args.view.cam_offset[2];
+        args.out.distance_sq[rank] = args.view.distance_2d ? m.c3z + 1.0f : fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+        float4* row = stage + local * 3;
+        row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+        row[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+        row[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(args.out.baked_model) + (size_t)base * 3;
+    for (uint32_t q = threadIdx.x; q < total * 3u; q += kCullBlock)
+        dst[q] = stage[q];
+}
+
+hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                            const ViewBuffers& out, unsigned long long* status, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch,
+                            hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    CullArgs a{};
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    a.view = vp;
+    a.out = out;
+    a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    const FusedEmit fe{status, ticket, ticket_base, epoch};
+    const dim3 grid(a.nblocks), block(kCullBlock);
+#define GV_LAUNCH_FUSED(HIZ)                                                                                          \
+    switch (mesh.mapping) {                                                                                          \
+    case kMapExact: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapExact>), grid, block, 0, stream, a, fe); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a, fe); break; \
+    default: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a, fe); break;              \
+    }
+    if (vp.use_hiz) {
+        GV_LAUNCH_FUSED(true)
+    } else {
+        GV_LAUNCH_FUSED(false)
+    }
+#undef GV_LAUNCH_FUSED
+    return hipGetLastError();
+}
+
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds)
 {
@@ -259,9 +409,9 @@ struct MultiCullArgs {
 };
 
 template <bool HIZ, uint32_t MAP, bool BOUNDS>
-__global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
+__device__ __forceinline__ void cull_multi_block(const MultiCullArgs& args, const uint32_t lb,
+                                                 uint32_t (&wave_count)[kMaxBatchViews][kCullBlock / 64])
 {
-    const uint32_t lb = blockIdx.x;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool in_range = i < args.mesh.count;
@@ -296,7 +446,6 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
     const bool candidate = in_range && prepare_model<MAP>(args.mesh, args.xf, args.cam, i, m, box_a, box_b);
     const float reach = candidate ? sphere_reach(m, box_a, box_b) : 0.0f;  // one sphere for every view of the batch
     bool have_corners = false;  // generated once, by the first view that needs them
-    __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
 #pragma unroll
     for (uint32_t v = 0; v < kMaxBatchViews; v++) {
         if (v < args.nviews) {  // uniform
@@ -339,15 +488,54 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
     }
 }
 
-hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
-                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
-                             const BlockBounds* bounds)
+template <bool HIZ, uint32_t MAP, bool BOUNDS>
+__global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
 {
-    if (mesh.count == 0)
+    __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
+    cull_multi_block<HIZ, MAP, BOUNDS>(args, blockIdx.x, wave_count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table-driven forms for a TICK of engine-sized pools (gv_cull_batch_begin): the culls of ALL mesh systems of a frame —
+// each with its main camera and shadow passes — in ONE launch (blockIdx.y = job), their emits in ONE launch
+// (blockIdx.y = (job, view)). The job descriptors live in a device table; the kernels read it through the constant
+// address space (uniform index -> scalar loads, exactly what a by-value kernel argument compiles to).
+// ------------------------------------------------------------------------------------------------
+typedef const MultiCullArgs __attribute__((address_space(4))) * ConstCullTable;
+
+__global__ __launch_bounds__(kCullBlock) void cull_table_kernel(const MultiCullArgs* __restrict__ table)
+{
+    __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
+    MultiCullArgs args;  // (a plain struct copy cannot read from an address-space-qualified source: memcpy can)
+    __builtin_memcpy(&args, (ConstCullTable)table + blockIdx.y, sizeof(args));
+    if (blockIdx.x * kCullBlock >= args.mesh.count)
+        return;  // the grid is as wide as the largest pool of the tick
+#define GV_TABLE_CULL(HIZ)                                                                              \
+    switch (args.mesh.mapping) {                                                                        \
+    case kMapExact: cull_multi_block<HIZ, kMapExact, false>(args, blockIdx.x, wave_count); break;       \
+    case kMapSpeculate: cull_multi_block<HIZ, kMapSpeculate, false>(args, blockIdx.x, wave_count); break; \
+    default: cull_multi_block<HIZ, kMapGeneral, false>(args, blockIdx.x, wave_count); break;            \
+    }
+    if (args.use_hiz0) {
+        GV_TABLE_CULL(true)
+    } else {
+        GV_TABLE_CULL(false)
+    }
+#undef GV_TABLE_CULL
+}
+
+hipError_t launch_cull_table(const void* device_table, uint32_t jobs, uint32_t max_slots, hipStream_t stream)
+{
+    if (jobs == 0 || max_slots == 0)
         return hipSuccess;
-    if (nviews == 0 || nviews > kMaxBatchViews)
-        return hipErrorInvalidValue;
-    MultiCullArgs a;
+    hipLaunchKernelGGL(cull_table_kernel, dim3((max_slots + kCullBlock - 1) / kCullBlock, jobs), dim3(kCullBlock), 0, stream,
+                       static_cast<const MultiCullArgs*>(device_table));
+    return hipGetLastError();
+}
+
+static void fill_multi_args(MultiCullArgs& a, const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                            const ViewParams* views, const ViewBuffers* outs, uint32_t nviews)
+{
     a.mesh = mesh;
     a.xf = xf;
     a.hiz = hiz;
@@ -366,6 +554,26 @@ hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, 
         a.planes[v].write_is_visible = src.write_is_visible;
         a.outs[v] = outs[v < nviews ? v : 0];
     }
+    a.bounds = BlockBounds{};
+}
+
+size_t cull_table_entry_bytes() { return sizeof(MultiCullArgs); }
+void fill_cull_table_entry(void* entry, const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                           const ViewParams* views, const ViewBuffers* outs, uint32_t nviews)
+{
+    fill_multi_args(*static_cast<MultiCullArgs*>(entry), mesh, xf, hiz, views, outs, nviews);
+}
+
+hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                             const ViewParams* views, const ViewBuffers* outs, uint32_t nviews, hipStream_t stream,
+                             const BlockBounds* bounds)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    if (nviews == 0 || nviews > kMaxBatchViews)
+        return hipErrorInvalidValue;
+    MultiCullArgs a;
+    fill_multi_args(a, mesh, xf, hiz, views, outs, nviews);
     const dim3 grid((mesh.count + kCullBlock - 1) / kCullBlock), block(kCullBlock);
     a.bounds = bounds ? *bounds : BlockBounds{};
 #define GV_LAUNCH_MULTI(HIZ, BOUNDS)                                                                                            \
@@ -657,6 +865,41 @@ __global__ __launch_bounds__(256) void emit_batch_kernel(const EmitBatchArgs bat
     args.world = batch.world;
     args.direct_stores = 0;
     emit_block<true>(args, blockIdx.x);
+}
+
+// one EmitArgs per (job, view) of a tick; blockIdx.y picks the entry
+typedef const EmitArgs __attribute__((address_space(4))) * ConstEmitTable;
+__global__ __launch_bounds__(256) void emit_table_kernel(const EmitArgs* __restrict__ table)
+{
+    EmitArgs args;
+    __builtin_memcpy(&args, (ConstEmitTable)table + blockIdx.y, sizeof(args));
+    if (blockIdx.x >= args.nchunks * kEmitParts)
+        return;  // the grid is as wide as the largest pool of the tick
+    emit_block<true>(args, blockIdx.x);
+}
+
+size_t emit_table_entry_bytes() { return sizeof(EmitArgs); }
+void fill_emit_table_entry(void* entry, const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp,
+                           const ViewBuffers& out, uint32_t clear_chunks, const float4* world)
+{
+    EmitArgs& a = *static_cast<EmitArgs*>(entry);
+    a.mesh = mesh;
+    a.xf = xf;
+    a.view = vp;
+    a.out = out;
+    a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    a.clear_chunks = clear_chunks;
+    a.direct_stores = 0;
+    a.world = world;
+}
+
+hipError_t launch_emit_table(const void* device_table, uint32_t entries, uint32_t max_slots, hipStream_t stream)
+{
+    if (entries == 0 || max_slots == 0)
+        return hipSuccess;
+    const uint32_t chunks = (max_slots + kEmitChunk - 1) / kEmitChunk;
+    hipLaunchKernelGGL(emit_table_kernel, dim3(chunks * kEmitParts, entries), dim3(256), 0, stream, static_cast<const EmitArgs*>(device_table));
+    return hipGetLastError();
 }
 
 hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,

@@ -59,6 +59,9 @@ struct HizDevice {
 };
 
 constexpr uint32_t kCullBlock = 256;   // slots per cull workgroup (4 waves)
+constexpr uint32_t kFusedEmitMaxSlots = 32768;  // pools up to this size cull + emit in one launch: the look-back chain costs
+                                                // ~16 ns per tile, so it only pays while a launch costs more (6.9 vs 9.8 us at 10 k
+                                                // slots, equal at 100 k, 64 vs 24 us at 1 M; profiles/r02i_fused_emit.txt)
 constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
 
 struct ViewParams {
@@ -95,6 +98,13 @@ struct BlockBounds {
 hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
+// Cull + order-stable compaction + record emission of one view in ONE launch (decoupled look-back over the 256-entry
+// tiles; gv_cull.hip): same outputs as launch_cull + launch_emit except mask / chunk counts, which it does not produce.
+// status: one 64-bit word per tile (zero-initialised once, never cleared: words carry `epoch`); ticket: a running
+// counter whose value before this launch is ticket_base.
+hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                            const ViewBuffers& out, unsigned long long* status, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch,
+                            hipStream_t stream);
 // One pass over the streams for up to kMaxBatchViews views that share views[0].cam (Hi-Z only on view 0).
 constexpr uint32_t kMaxBatchViews = 8;
 struct MultiViewPlanes {
@@ -107,6 +117,16 @@ hipError_t launch_cull_multi(const MeshMirror& mesh, const TransformMirror& xf, 
                              const BlockBounds* bounds = nullptr);
 // read-only pass over the cull kernel's input streams (65 B per entry); gv_debug_stream_peak
 hipError_t launch_stream_probe(const MeshMirror& mesh, const TransformMirror& xf, float* sink, hipStream_t stream);
+// Table-driven tick (gv_cull_batch_begin): the culls of several small pools in one launch, their emits in one launch.
+// The descriptor structs are private to gv_cull.hip: the host fills a table of entries through these.
+size_t cull_table_entry_bytes();
+void fill_cull_table_entry(void* entry, const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz,
+                           const ViewParams* views, const ViewBuffers* outs, uint32_t nviews);
+hipError_t launch_cull_table(const void* device_table, uint32_t jobs, uint32_t max_slots, hipStream_t stream);
+size_t emit_table_entry_bytes();
+void fill_emit_table_entry(void* entry, const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp,
+                           const ViewBuffers& out, uint32_t clear_chunks, const float4* world);
+hipError_t launch_emit_table(const void* device_table, uint32_t entries, uint32_t max_slots, hipStream_t stream);
 hipError_t launch_scan(const ViewBuffers& out, uint32_t chunk_count, hipStream_t stream);
 // self_prefix: every emit workgroup derives its chunk's base from the chunk totals itself (no launch_scan in front;
 // pools of up to kSelfPrefixMaxChunks chunks); out.chunk_count / chunk_count_next then alternate from cull to cull.
@@ -141,7 +161,7 @@ struct PublishArgs {
     uint8_t* host_is_visible;   // pool-slot order; NULL: not the main pass
     uint32_t occupancy;
 };
-constexpr uint32_t kMaxPublishViews = 8;  // == GV_MAX_VIEWS (checked in gv_context.cpp)
+constexpr uint32_t kMaxPublishViews = 32;  // views of SEVERAL pools per launch (>= GV_MAX_VIEWS, checked in gv_context.cpp)
 struct PublishBatch {
     PublishArgs view[kMaxPublishViews];  // blockIdx.y
 };
@@ -169,11 +189,22 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
 // pools of up to this many slots sort in one launch (rank sort, gv_sort.hip); gv_sort defers those so that the views of
 // one cull share a single launch (launch_sort_small_batch) when their results are first asked for
 constexpr uint32_t kSmallSortMaxSlots = 16384;
-struct SortBatch {
-    SortBuffers view[kMaxPublishViews];
-    uint32_t descending[kMaxPublishViews];
+struct SmallSortEntry {  // one view of one small pool
+    const uint32_t* count;  // device draw_count
+    const uint32_t* idx_in;
+    const float* model_in;
+    const float* dist_in;
+    uint32_t* idx_out;
+    float* model_out;
+    float* dist_out;
+    uint32_t capacity;      // the pool's slot count (upper bound of *count)
+    uint32_t descending;
 };
-hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t capacity, hipStream_t stream);
+struct SortBatch {
+    SmallSortEntry view[kMaxPublishViews];  // views of SEVERAL pools per launch
+};
+// max_capacity: the largest entry capacity (sizes the grid and the LDS key table)
+hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t max_capacity, hipStream_t stream);
 
 // derives TransformMirror::active_bits from flags[]
 // Byte layout of one TransformComponent inside a raw AoS copy (all offsets within `stride`).

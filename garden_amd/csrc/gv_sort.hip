@@ -381,7 +381,8 @@ __device__ __forceinline__ uint32_t count_before(const uint32_t* key, uint32_t j
     return before;
 }
 
-__device__ __forceinline__ void sort_small_block(const SortBuffers& b, uint32_t capacity, uint32_t descending, uint32_t block)
+template <class Entry>
+__device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capacity, uint32_t descending, uint32_t block)
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
@@ -430,9 +431,10 @@ __global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, ui
 }
 
 // several views of one small pool (main camera + shadow passes) in one launch: blockIdx.y picks the view
-__global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatch batch, uint32_t capacity)
+__global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatch batch)
 {
-    sort_small_block(batch.view[blockIdx.y], capacity, batch.descending[blockIdx.y], blockIdx.x);
+    const SmallSortEntry& e = batch.view[blockIdx.y];
+    sort_small_block(e, e.capacity, e.descending, blockIdx.x);
 }
 
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream)
@@ -492,12 +494,14 @@ hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint3
 {
     if (capacity == 0 || views == 0)
         return hipSuccess;
+    if (capacity > kSmallSort)
+        return hipErrorInvalidValue;
     const uint32_t lds = ((capacity + 3u) & ~3u) * 4;
     static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_batch_kernel),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
     if (raised != hipSuccess)
         return raised;
-    hipLaunchKernelGGL(sort_small_batch_kernel, dim3((capacity + 63) / 64, views), dim3(256), lds, stream, batch, capacity);
+    hipLaunchKernelGGL(sort_small_batch_kernel, dim3((capacity + 63) / 64, views), dim3(256), lds, stream, batch);
     return hipGetLastError();
 }
 

@@ -194,12 +194,12 @@ private:
         return v;
     }
 
-    void fill(UnsortedBuffer* buffer, IMeshRenderSystem* meshSystem, uint32_t viewIndex, bool writeBack)
+    void fill(UnsortedBuffer* buffer, IMeshRenderSystem* meshSystem, uint32_t pool, uint32_t viewIndex, bool writeBack)
     {
         GvResult r{};
         {
             Stopwatch watch(tickSeconds.fetch);
-            check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+            check(gv_pool_results_fetch(ctx, pool, viewIndex, writeBack ? 1 : 0, &r), "gv_pool_results_fetch");
         }
         Stopwatch watch(tickSeconds.records);
         buffer->meshSystem = meshSystem;
@@ -221,12 +221,12 @@ private:
     // prepareSortedMeshes' tail (mesh.cpp:246-261): this system's records go behind the ones already in the shared
     // array, tagged with bufferIndex. Returns the number appended.
     uint32_t append(std::vector<SortedMesh>& combined, uint32_t& drawIndex, MeshBuffer* counters,
-                    IMeshRenderSystem* meshSystem, uint32_t viewIndex, bool writeBack, uint32_t bufferIndex)
+                    IMeshRenderSystem* meshSystem, uint32_t pool, uint32_t viewIndex, bool writeBack, uint32_t bufferIndex)
     {
         GvResult r{};
         {
             Stopwatch watch(tickSeconds.fetch);
-            check(gv_results_fetch(ctx, viewIndex, writeBack ? 1 : 0, &r), "gv_results_fetch");
+            check(gv_pool_results_fetch(ctx, pool, viewIndex, writeBack ? 1 : 0, &r), "gv_pool_results_fetch");
         }
         Stopwatch watch(tickSeconds.records);
         if (counters) {
@@ -318,6 +318,11 @@ private:
         std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
         uint32_t unsortedBufferIndex = 0, sortedBufferIndex = 0;
 
+        // Phase 1 — every mesh system's cull (and sort request) is issued before any result is read: results are kept
+        // per (pool, view), so the device works through the systems back to back while the host only enqueues; the
+        // reference dispatches every system's tasks to its thread pool and waits once, too (mesh.cpp:408-546, :548).
+        std::vector<uint32_t> viewCounts(meshSystems.size(), 0);
+        check(gv_cull_batch_begin(ctx), "gv_cull_batch_begin");  // engine-sized pools: one cull / emit / sort / publish launch per tick
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
@@ -347,45 +352,48 @@ private:
                     views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
                                              (int8_t)s, false, emitRecords));
             }
+            viewCounts[p] = (uint32_t)views.size();
             if (sweepWorldMatrices && p == 0)
                 check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_WITH_CULL), "gv_sweep");
             {
                 Stopwatch watch(tickSeconds.cull);
                 check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
             }
+            // sortMeshes, mesh.cpp:270-295: unsorted buffers front to back (UnsortedMesh::operator<, mesh.hpp:196), OIT is
+            // not sorted; sorted systems back to front (SortedMesh::operator<, mesh.hpp:204)
+            if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT) {
+                Stopwatch watch(tickSeconds.sort);
+                for (uint32_t v = 0; v < views.size(); v++)
+                    check(gv_pool_sort(ctx, p, v, isSortedType(renderType) ? 1 : 0), "gv_pool_sort");
+            }
+        }
 
+        // Phase 2 — read the results (the first fetch publishes every small pool's views at once).
+        for (uint32_t p = 0; p < meshSystems.size(); p++) {
+            auto meshSystem = meshSystems[p];
+            const auto renderType = meshSystem->getMeshRenderType();
+            const uint32_t viewCount = viewCounts[p];
             if (isSortedType(renderType)) {
-                if (emitRecords && sortOnDevice) {
-                    Stopwatch watch(tickSeconds.sort);
-                    for (uint32_t v = 0; v < views.size(); v++)
-                        check(gv_sort(ctx, v, 1), "gv_sort");  // back to front: SortedMesh::operator< (mesh.hpp:204)
-                }
                 const uint32_t bufferIndex = sortedBufferIndex++;
-                for (uint32_t v = 1; v < views.size(); v++) {
-                    append(shadowTransMeshes[v - 1], shadowTransDrawIndex[v - 1], nullptr, meshSystem, v, false, bufferIndex);
+                for (uint32_t v = 1; v < viewCount; v++) {
+                    append(shadowTransMeshes[v - 1], shadowTransDrawIndex[v - 1], nullptr, meshSystem, p, v, false, bufferIndex);
                     shadowTransRuns[v - 1].push_back(shadowTransDrawIndex[v - 1]);
                 }
                 if (renderType == MeshRenderType::UI) {
-                    append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, 0, true, bufferIndex);
+                    append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, 0, true, bufferIndex);
                     uiRuns.push_back(uiDrawIndex);
                 } else {
-                    append(transSortedMeshes, transDrawIndex, sortedBuffers[bufferIndex], meshSystem, 0, true, bufferIndex);
+                    append(transSortedMeshes, transDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, 0, true, bufferIndex);
                     transRuns.push_back(transDrawIndex);
                 }
             } else {
-                // sortMeshes, mesh.cpp:270-295: front to back (UnsortedMesh::operator<, mesh.hpp:196); OIT is not sorted
-                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT) {
-                    Stopwatch watch(tickSeconds.sort);
-                    for (uint32_t v = 0; v < views.size(); v++)
-                        check(gv_sort(ctx, v, 0), "gv_sort");
-                }
                 const uint32_t bufferIndex = unsortedBufferIndex++;
                 auto& sb = shadowBuffers[bufferIndex];
-                while (sb.size() + 1 < views.size())
+                while (sb.size() + 1 < viewCount)
                     sb.push_back(new UnsortedBuffer());
-                for (uint32_t v = 1; v < views.size(); v++)
-                    fill(sb[v - 1], meshSystem, v, false);
-                fill(unsortedBuffers[bufferIndex], meshSystem, 0, true);
+                for (uint32_t v = 1; v < viewCount; v++)
+                    fill(sb[v - 1], meshSystem, p, v, false);
+                fill(unsortedBuffers[bufferIndex], meshSystem, p, 0, true);
             }
         }
         if (emitRecords && sortOnDevice) {

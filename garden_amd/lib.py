@@ -106,6 +106,8 @@ EXPORTS = [
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
+    "gv_cull_batch_begin", "gv_cull_batch_end",
 ]
 
 _lib = None
@@ -177,6 +179,12 @@ def load():
     lib.gv_exchange_shutdown.argtypes = [P]
     lib.gv_exchange_set_mode.argtypes = [P, u32]
     lib.gv_pool_set_index_map.argtypes = [P, u32, P, u32]
+    lib.gv_pool_results_fetch.argtypes = [P, u32, u32, C.c_int, C.POINTER(GvResult)]
+    lib.gv_pool_result_count.argtypes = [P, u32, u32, C.POINTER(u32)]
+    lib.gv_pool_results_device.argtypes = [P, u32, u32, C.POINTER(GvDeviceResult)]
+    lib.gv_pool_sort.argtypes = [P, u32, u32, C.c_int]
+    lib.gv_cull_batch_begin.argtypes = [P]
+    lib.gv_cull_batch_end.argtypes = [P]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("gv_abi_version", "gv_destroy", "gv_last_error", "gv_stream", "gv_scene_destroy"):
@@ -300,6 +308,13 @@ class GpuVisibility:
         arr = (GvView * len(views))(*[to_gv_view(v) for v in views])
         self._check(self.lib.gv_cull(self.ctx, pool_id, arr, len(views)))
 
+    def cull_batch_begin(self):
+        """Culls of small pools are recorded until the first read and then launched together (one tick, four launches)."""
+        self._check(self.lib.gv_cull_batch_begin(self.ctx))
+
+    def cull_batch_end(self):
+        self._check(self.lib.gv_cull_batch_end(self.ctx))
+
     def wait(self):
         self._check(self.lib.gv_wait(self.ctx))
 
@@ -308,12 +323,16 @@ class GpuVisibility:
         self._check(self.lib.gv_result_count(self.ctx, view_index, C.byref(n)))
         return n.value
 
-    def fetch(self, view_index=0, write_back=True, occupancy=None, order="slot"):
+    def fetch(self, view_index=0, write_back=True, occupancy=None, order="slot", pool_id=None):
         """Returns copies: dict(visible_idx, baked_model[n,12], distance_sq, is_visible or None, draw_count).
         order="slot": records re-ordered here by pool slot (what the oracle's single-thread loop produces);
-        order="raw": as the library emitted them (mirror order, or distance order after sort())."""
+        order="raw": as the library emitted them (mirror order, or distance order after sort()).
+        pool_id: the pool whose results are read (default: the pool of the most recent cull)."""
         r = GvResult()
-        self._check(self.lib.gv_results_fetch(self.ctx, view_index, 1 if write_back else 0, C.byref(r)))
+        if pool_id is None:
+            self._check(self.lib.gv_results_fetch(self.ctx, view_index, 1 if write_back else 0, C.byref(r)))
+        else:
+            self._check(self.lib.gv_pool_results_fetch(self.ctx, pool_id, view_index, 1 if write_back else 0, C.byref(r)))
         n = r.draw_count
         out = dict(draw_count=n, instance_count=r.instance_count, visible_idx=None, baked_model=None,
                    distance_sq=None, is_visible=None)
@@ -379,8 +398,11 @@ class GpuVisibility:
         """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
         return self.lib.gv_stream(self.ctx)
 
-    def sort(self, view_index=0, descending=False):
-        self._check(self.lib.gv_sort(self.ctx, view_index, 1 if descending else 0))
+    def sort(self, view_index=0, descending=False, pool_id=None):
+        if pool_id is None:
+            self._check(self.lib.gv_sort(self.ctx, view_index, 1 if descending else 0))
+        else:
+            self._check(self.lib.gv_pool_sort(self.ctx, pool_id, view_index, 1 if descending else 0))
 
     # ---- world matrices ----
     def sweep(self, mode=GV_SWEEP_VALU):

@@ -220,6 +220,28 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
  * index_base instead of visible_idx + index_base whenever the table covers the culled pool. count == 0 removes it. */
 int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count);
 
+/* Results are kept per (pool, view). The view-indexed calls above address the pool of the most recent gv_cull; these
+ * name the pool, so that a frame can issue the culls (and sort requests) of ALL its mesh systems first and read the
+ * results afterwards — the reference's prepareMeshes does the same with its thread pool (dispatch every system's tasks,
+ * mesh.cpp:408-546, then one wait, :548) — the device works through the systems back to back, and for engine-sized
+ * pools (up to 262144 slots) the first fetch publishes the results of every pool with ONE launch and ONE
+ * synchronisation; the other fetches find theirs in the pinned host buffers. A (pool, view)'s results stay valid until
+ * the next gv_cull of that pool. */
+/* A tick of engine-sized pools (the reference's everyday 10^3..10^4 entities per mesh system) is bound by launches,
+ * not by bytes. Between gv_cull_batch_begin and the first call that reads results (gv_pool_results_* / gv_results_* /
+ * gv_wait, or gv_cull_batch_end), gv_cull of a pool of up to 16384 slots whose views all emit records only RECORDS the
+ * cull; the first read then launches all recorded culls as ONE kernel, their emits as ONE kernel, the requested sorts
+ * (gv_pool_sort) as ONE kernel and publishes every view's results to the host with ONE kernel and ONE synchronisation —
+ * four launches per frame however many mesh systems and shadow passes there are. Other culls (larger pools, count-only
+ * views, GV_SWEEP_WITH_CULL, block bounds) run at once as usual. Same results. Do not re-bind or mark a pool dirty
+ * between its gv_cull and the first read of the batch. */
+int gv_cull_batch_begin(GvCtx* ctx);
+int gv_cull_batch_end(GvCtx* ctx);
+int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int write_back, GvResult* out);
+int gv_pool_result_count(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t* draw_count);
+int gv_pool_results_device(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, GvDeviceResult* out);
+int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descending);
+
 /* ---- multi-GPU exchange without torch.distributed (one process per GPU) ----
  * Rank 0 calls gv_exchange_unique_id and hands the 128 bytes to the other ranks by its own means (the engine's IPC, a
  * file, MPI ...); every rank then calls gv_exchange_init with its own context. gv_exchange_shards enqueues, on the

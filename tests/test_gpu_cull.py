@@ -1081,3 +1081,77 @@ def test_ready_counts_filter_like_the_derived_predicates(gpu, oracle, dtype):
     got = gpu.fetch(0, write_back=False, occupancy=n)
     exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
     assert got["draw_count"] == exp["draw_count"] == got["instance_count"]
+
+
+def test_a_tick_of_small_pools_is_culled_emitted_sorted_and_published_together(oracle):
+    """gv_cull_batch_begin: the culls of several engine-sized pools (different sizes, mappings, hierarchy; main camera
+    + shadow passes, Hi-Z on the main view) are recorded and launched as ONE cull, ONE emit, ONE sort and ONE publish
+    kernel at the first read — results per (pool, view) equal the oracle's, a pool too large for the batch and a
+    count-only view take the ordinary path inside the same tick, and a second tick re-uses everything."""
+    from garden_amd.lib import GpuVisibility
+    rng = np.random.default_rng(5)
+    flat = scene.flat_scene(9_000, seed=3)
+    hier = scene.hierarchy_scene(12_000, depth=4, fanout=5)
+    # three mesh pools over ONE transform pool: slots of `hier`; pool 1 = a shuffled subset, pool 2 = too large for the batch
+    tr, e2t = hier.transforms, hier.entity_to_transform
+    pool0 = hier.meshes
+    pick = rng.permutation(12_000)[:5_000]
+    pool1 = hier.meshes[pick].copy()
+    big = scene.flat_scene(40_000, seed=9)  # own entities: none has a transform in `tr` beyond slot range -> mostly filtered
+    big.meshes["entity"] = (rng.integers(1, 12_000, 40_000)).astype(np.uint32)
+    pool2 = big.meshes
+    depth = scene.synthetic_depth(512, 256)
+    main = scene.main_camera_view(use_hiz=1)
+    shadows = [scene.cascade_view(index=k, size=3000.0 + 800 * k) for k in range(3)]
+    hz = oracle.Hiz(depth)
+    del flat
+
+    def expect(meshes, view):
+        m2 = meshes.copy()
+        r = oracle.prepare_meshes(m2, tr, e2t, view, hiz=hz if view.get("use_hiz") else None)
+        return r, m2["isVisible"]
+
+    with GpuVisibility(device=0, profile_events=True) as vis:
+        vis.bind_transforms(tr, e2t)
+        for pid, meshes in enumerate((pool0, pool1, pool2)):
+            vis.bind_pool(pid, meshes)
+        vis.hierarchy_rebuild()
+        vis.hiz_build(depth)
+        for tick in range(2):
+            vis.stats_reset()
+            vis.cull_batch_begin()
+            vis.cull(0, [main] + shadows)          # recorded: 4 views
+            vis.cull(1, [dict(main, use_hiz=0)])   # recorded: 1 view
+            vis.cull(2, [dict(main, use_hiz=0)])   # 40 k slots: launched at once
+            vis.sort(0, descending=False, pool_id=0)
+            vis.sort(2, descending=True, pool_id=0)
+            vis.sort(0, descending=True, pool_id=1)
+            assert vis.stats()["launches"]["cull"] == 1  # only pool 2 so far
+            got0 = [vis.fetch(v, write_back=False, occupancy=12_000, pool_id=0, order="raw") for v in range(4)]
+            st = vis.stats()["launches"]
+            assert st["cull"] == 2 and st["emit"] == 2 and st["sort"] == 1, st  # pool 2's pair + ONE table launch each
+            got1 = vis.fetch(0, write_back=False, occupancy=5_000, pool_id=1, order="raw")
+            got2 = vis.fetch(0, write_back=False, occupancy=40_000, pool_id=2)
+            assert vis.stats()["launches"] == st  # nothing more was needed
+            for v, view in enumerate([main] + shadows):
+                exp, vis_bytes = expect(pool0, view)
+                g = got0[v]
+                assert g["draw_count"] == exp["draw_count"] > 0
+                o = np.argsort(g["visible_idx"], kind="stable")
+                e = np.argsort(exp["visible_idx"], kind="stable")
+                assert np.array_equal(g["visible_idx"][o], exp["visible_idx"][e])
+                assert np.array_equal(g["baked_model"][o].view(np.uint32), exp["baked_model"][e].view(np.uint32))
+                if v == 0:
+                    assert np.array_equal(g["is_visible"], vis_bytes)
+                    assert np.all(np.diff(g["distance_sq"]) >= 0)  # sorted front to back
+                if v == 2:
+                    assert np.all(np.diff(g["distance_sq"]) <= 0)
+            exp, vis_bytes = expect(pool1, dict(main, use_hiz=0))
+            o = np.argsort(got1["visible_idx"], kind="stable")
+            assert np.array_equal(got1["visible_idx"][o], np.sort(exp["visible_idx"])) and np.array_equal(got1["is_visible"], vis_bytes)
+            assert np.all(np.diff(got1["distance_sq"]) <= 0)
+            exp, vis_bytes = expect(pool2, dict(main, use_hiz=0))
+            assert np.array_equal(got2["visible_idx"], np.sort(exp["visible_idx"])) and np.array_equal(got2["is_visible"], vis_bytes)
+            # something moves between the ticks
+            tr["position"][:3000, :3] += np.float32(3.0)
+            vis.mark_dirty(0, 0, 3000)
