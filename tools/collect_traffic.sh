@@ -6,7 +6,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc
 mkdir -p gpurun_out/pmc
-for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds"; do
+for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds" "cfg4"; do
   tag=$(echo $wl | cut -d" " -f1); case "$wl" in *block-bounds*) tag=${tag}bb;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc/${tag}_$c -- python3 bench.py --workload $wl --no-cpu-baseline --no-parity --steps 5 --warmup 2 > gpurun_out/pmc/${tag}_$c.log 2>&1
@@ -17,4 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg2 -- python3 bench.py --workload cfg2 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3bb -- python3 bench.py --block-bounds --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3bb.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg4valu -- python3 bench.py --workload cfg4 --sweep fused-valu --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg4valu.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg2_10M -- python3 bench.py --workload cfg2 --entities 10000000 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg2_10M.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg5shape -- python3 bench.py --workload cfg5 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg5shape.log 2>&1
+# the driver's own command (N = 1 default, with the CPU baseline and the parity gate), not under the profiler
+python3 bench.py > gpurun_out/pmc/stats_default.log 2> gpurun_out/pmc/default.err
 ls gpurun_out/pmc

@@ -28,7 +28,13 @@ def counter_mean(workload, counter, kernel_prefix):
 
 
 N = 10_000_000
-out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_traffic.sh, "
+sys.path.insert(0, ROOT)
+import datetime  # noqa: E402
+
+from bench import kernel_source_sha  # noqa: E402  (bench.py reports traffic only while this hash still matches)
+
+out = {"_kernel_source_sha": kernel_source_sha(), "_collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ") + f" ({tag})",
+       "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_traffic.sh, "
        "tools/summarize_traffic.py). gfx950 FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md: 1/2 for "
        "16 B/lane; other widths uncalibrated), so the read side is calibrated on this kernel's own access pattern: the "
        "frustum-only cull of a flat, exactly-paired pool of 10 M entities streams a known 65 B/entity (+ one 8-byte flag "
@@ -41,11 +47,11 @@ w2, _ = counter_mean("cfg2", "WRITE_SIZE", PLAIN)
 known = N * 65 + N / 64 * 8
 factor = known / (f2 * 1024)
 out["fetch_calibration_factor"] = factor
-out["cfg2_at_10M"] = {"FETCH_SIZE_KB": f2, "WRITE_SIZE_KB": w2, "launches": n2,
+out["cfg2_at_10M"] = {"entities": N, "FETCH_SIZE_KB": f2, "WRITE_SIZE_KB": w2, "launches": n2,
                       "cull_kernel_hbm_bytes_per_launch": f2 * 1024 * factor + w2 * 1024}
 f3, n3 = counter_mean("cfg3", "FETCH_SIZE", PLAIN)
 w3, _ = counter_mean("cfg3", "WRITE_SIZE", PLAIN)
-out["cfg3"] = {"FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "launches": n3,
+out["cfg3"] = {"entities": N, "FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "launches": n3,
                "cull_kernel_hbm_bytes_per_launch": f3 * 1024 * factor + w3 * 1024,
                "cull_kernel_hbm_bytes_per_launch_uncalibrated": f3 * 1024 + w3 * 1024}
 if newest("cfg3bb_FETCH_SIZE/*/*counter_collection.csv"):
@@ -53,12 +59,17 @@ if newest("cfg3bb_FETCH_SIZE/*/*counter_collection.csv"):
     wb, _ = counter_mean("cfg3bb", "WRITE_SIZE", BOUNDED)
     out["cfg3_block_bounds"] = {"FETCH_SIZE_KB": fb, "WRITE_SIZE_KB": wb, "launches": nb,
                                 "cull_kernel_hbm_bytes_per_launch": fb * 1024 * factor + wb * 1024}
+if newest("cfg4_FETCH_SIZE/*/*counter_collection.csv"):
+    f4, n4 = counter_mean("cfg4", "FETCH_SIZE", "sweep_cull_mfma_kernel")
+    w4, _ = counter_mean("cfg4", "WRITE_SIZE", "sweep_cull_mfma_kernel")
+    out["cfg4"] = {"entities": N, "FETCH_SIZE_KB": f4, "WRITE_SIZE_KB": w4, "launches": n4, "kernel": "gv::sweep_cull_mfma_kernel",
+                   "cull_kernel_hbm_bytes_per_launch": f4 * 1024 * factor + w4 * 1024}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
     fo.write("workload,kernel,counter,mean_value_KB,launches\n")
-    for wl in ("cfg2", "cfg3", "cfg3bb"):
+    for wl in ("cfg2", "cfg3", "cfg3bb", "cfg4"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             f = newest(f"{wl}_{counter}/*/*counter_collection.csv")
             if not f:
@@ -71,7 +82,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
                 if k.startswith("gv::") or "gv::" in k:
                     fo.write(f'{wl}{"@10M" if wl == "cfg2" else ""},"{k}",{counter},{sum(v) / len(v):.3f},{len(v)}\n')
 
-for wl in ("cfg2", "cfg3", "cfg4", "cfg3bb", "cfg4valu"):
+for wl in ("cfg2", "cfg3", "cfg4", "cfg3bb", "cfg4valu", "cfg2_10M", "cfg5shape", "default"):
     ks = newest(f"stats_{wl}/*/*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
