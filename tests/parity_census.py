@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Parity-risk census (CPU only; oracle/gv_census.cpp): how many entities of the BASELINE scenes change their
-visibility decision when the build-defined arithmetic is replaced by the other operation orders a real cfnptr/math
-could have — float64, the other 4x4 association, the un-fused source form, GCC's contraction of it.
-  python tools/parity_census.py [--small]  ->  profiles/r02_parity_census.json
+"""Parity-risk census (CPU only; oracle/gv_census.cpp; test infrastructure like the oracle it drives): how many entities
+of the BASELINE scenes change their visibility decision when the build-defined arithmetic is replaced by the other
+operation orders a real cfnptr/math could have — float64, the other 4x4 association, the un-fused source form, GCC's
+contraction of it.  python tests/parity_census.py [--small]  ->  profiles/r02_parity_census.json
 "Parity unpinned"  becomes a bounded number: the flipped entities all sit within `max_margin` of a
 frustum plane (world units, distance of the deciding corner), i.e. exactly on the silhouette of the frustum."""
 import ctypes as C
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 from garden_amd import scene  # noqa: E402
 from oracle import oracle_py  # noqa: E402

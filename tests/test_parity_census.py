@@ -1,4 +1,4 @@
-"""The parity-risk census (oracle/gv_census.cpp, tools/parity_census.py): variant 0 of the census IS the oracle, and the
+"""The parity-risk census (oracle/gv_census.cpp, tests/parity_census.py): variant 0 of the census IS the oracle, and the
 alternative operation orders (float64, root-first association, un-fused, GCC-contracted) can only change a decision for
 an entity whose deciding corner lies within a few float32 ulps of a frustum plane."""
 import os
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def test_census_variant_0_is_the_oracle_and_ordinary_scenes_do_not_flip(oracle):
