@@ -315,12 +315,14 @@ def main():
     idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if exchange else None
     ex = [None]  # VisibleListExchange, created once the shard capacity is known (first, exact exchange)
 
+    view_array = vis.views_array([view])  # the GvView structs of the frame, built once (the timed loop is the library's, not ctypes')
+
     def compute():
         if wl["hiz"]:
             vis.hiz_rebuild()
         if wl["sweep"]:
             vis.sweep({"mfma": GV_SWEEP_MFMA, "valu": GV_SWEEP_VALU, "fused": GV_SWEEP_WITH_CULL, "fused-valu": GV_SWEEP_WITH_CULL_VALU}[args.sweep])
-        vis.cull(0, [view])
+        vis.cull(0, view_array)
 
     def step():
         """One frame. With an exchange: the tile's list goes out as a fixed-capacity shard [count, indices...] and all

@@ -305,8 +305,14 @@ class GpuVisibility:
 
     # ---- per frame ----
     def cull(self, pool_id, views):
-        arr = (GvView * len(views))(*[to_gv_view(v) for v in views])
-        self._check(self.lib.gv_cull(self.ctx, pool_id, arr, len(views)))
+        """views: a list of view dicts (scene.make_view), or the array views_array() made of one (a frame loop that
+        re-submits the same views need not rebuild the ctypes structs every frame)."""
+        arr = views if isinstance(views, C.Array) else self.views_array(views)
+        self._check(self.lib.gv_cull(self.ctx, pool_id, arr, len(arr)))
+
+    @staticmethod
+    def views_array(views):
+        return (GvView * len(views))(*[to_gv_view(v) for v in views])
 
     def cull_batch_begin(self):
         """Culls of small pools are recorded until the first read and then launched together (one tick, four launches)."""
