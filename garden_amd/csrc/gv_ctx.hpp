@@ -230,7 +230,7 @@ struct PoolState {
     bool bound = false;
     bool need_full = false;
     uint32_t mapping = kMapGeneral;  // MeshMapping, chosen at full gather (kMapExact may only be demoted afterwards)
-    DirtyRange dirty;
+    DirtyRanges dirty;               // itemised (scattered enable / ready / AABB edits re-mirror what they touched)
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots

@@ -540,21 +540,30 @@ int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& r
     return GV_OK;
 }
 
-int upload_meshes_scattered(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
+// all dirty ranges of a pool as ONE packet (see upload_transforms_scattered)
+int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges)
 {
-    const uint32_t n = hi - lo;
+    std::vector<uint32_t> start(ranges.size() + 1, 0);
+    for (size_t k = 0; k < ranges.size(); k++)
+        start[k + 1] = start[k] + (ranges[k].hi - ranges[k].lo);
+    const uint32_t n = start.back();
+    if (n == 0)
+        return GV_OK;
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
         return rc;
-    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) {
-        for (uint32_t k = a; k < b; k++) {
-            const uint32_t j = p.inv[lo + k];
-            ctx->sc_idx.ptr[k] = j;
-            ctx->sc_a.ptr[k] = p.h_a.ptr[j];
-            ctx->sc_c.ptr[k] = p.h_b.ptr[j];
-            ctx->sc_u32.ptr[k] = p.h_link.ptr[j];
-        }
-    });
+    for (size_t q = 0; q < ranges.size(); q++) {
+        const uint32_t lo = ranges[q].lo, base = start[q];
+        parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {
+            for (uint32_t k = a; k < b; k++) {
+                const uint32_t j = p.inv[lo + k];
+                ctx->sc_idx.ptr[base + k] = j;
+                ctx->sc_a.ptr[base + k] = p.h_a.ptr[j];
+                ctx->sc_c.ptr[base + k] = p.h_b.ptr[j];
+                ctx->sc_u32.ptr[base + k] = p.h_link.ptr[j];
+            }
+        });
+    }
     GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, p.d_a.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, p.d_b.ptr, n)) != GV_OK) return rc;
@@ -867,16 +876,25 @@ int sync_mirror(GvCtx* ctx)
                 GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 staged = true;
             }
-            const uint32_t lo = p.dirty.lo, hi = std::min(p.dirty.hi, p.occupancy);
-            if (lo < hi) {
-                gather_meshes(ctx, p, lo, hi);
-                int rc;
-                if (p.inv.empty())
-                    rc = upload_meshes(ctx, p, lo, hi);
-                else if ((size_t)(hi - lo) * 2 > p.occupancy)
+            p.dirty.normalise(p.occupancy, 0);
+            const std::vector<DirtyRanges::R> ranges = p.dirty.items;
+            const uint64_t total = p.dirty.total();
+            if (total) {
+                int rc = GV_OK;
+                if (!p.inv.empty() && total * 2 > p.occupancy) {  // most of a permuted pool: one dense upload
+                    gather_meshes(ctx, p, ranges.front().lo, ranges.back().hi);
                     rc = upload_meshes(ctx, p, 0, p.occupancy);
-                else
-                    rc = upload_meshes_scattered(ctx, p, lo, hi);
+                } else {
+                    for (const auto& r : ranges)
+                        gather_meshes(ctx, p, r.lo, r.hi);
+                    if (p.inv.empty()) {
+                        for (const auto& r : ranges)
+                            if ((rc = upload_meshes(ctx, p, r.lo, r.hi)) != GV_OK)
+                                break;
+                    } else {
+                        rc = upload_meshes_scattered(ctx, p, ranges);
+                    }
+                }
                 if (rc != GV_OK)
                     return rc;
             }
