@@ -1115,6 +1115,7 @@ def test_a_tick_of_small_pools_is_culled_emitted_sorted_and_published_together(o
         vis.bind_transforms(tr, e2t)
         for pid, meshes in enumerate((pool0, pool1, pool2)):
             vis.bind_pool(pid, meshes)
+        vis.bind_pool(3, pool0[:0])  # an empty pool inside the same tick
         vis.hierarchy_rebuild()
         vis.hiz_build(depth)
         for tick in range(2):
@@ -1123,6 +1124,7 @@ def test_a_tick_of_small_pools_is_culled_emitted_sorted_and_published_together(o
             vis.cull(0, [main] + shadows)          # recorded: 4 views
             vis.cull(1, [dict(main, use_hiz=0)])   # recorded: 1 view
             vis.cull(2, [dict(main, use_hiz=0)])   # 40 k slots: launched at once
+            vis.cull(3, [dict(main, use_hiz=0)])   # nothing to cull: draw count 0
             vis.sort(0, descending=False, pool_id=0)
             vis.sort(2, descending=True, pool_id=0)
             vis.sort(0, descending=True, pool_id=1)
@@ -1133,6 +1135,7 @@ def test_a_tick_of_small_pools_is_culled_emitted_sorted_and_published_together(o
             got1 = vis.fetch(0, write_back=False, occupancy=5_000, pool_id=1, order="raw")
             got2 = vis.fetch(0, write_back=False, occupancy=40_000, pool_id=2)
             assert vis.stats()["launches"] == st  # nothing more was needed
+            assert vis.fetch(0, write_back=False, occupancy=0, pool_id=3)["draw_count"] == 0
             for v, view in enumerate([main] + shadows):
                 exp, vis_bytes = expect(pool0, view)
                 g = got0[v]

@@ -245,6 +245,20 @@ def test_partition_world_keeps_trees_together_and_maps_back(oracle):
         assert np.array_equal(models[slot].view(np.uint32), bm.view(np.uint32))
 
 
+def test_partition_world_with_one_tile_is_the_world(oracle):
+    from garden_amd.multi import partition_world
+    sc = _mixed_world(2000)
+    part = partition_world(sc, (1, 1, 1))
+    assert len(part.tiles) == 1 and part.tiles[0].count == sc.count
+    assert np.array_equal(part.mesh_global[0], np.arange(sc.count))
+    view = scene.main_camera_view()
+    a = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
+    t = part.tiles[0]
+    b = oracle.prepare_meshes(t.meshes.copy(), t.transforms, t.entity_to_transform, view)
+    assert np.array_equal(a["visible_idx"], b["visible_idx"]) and a["draw_count"] > 0
+    assert np.array_equal(a["baked_model"].view(np.uint32), b["baked_model"].view(np.uint32))
+
+
 def _tile_exchange_worker(rank, world, port, mode, ret):
     import torch
     import torch.distributed as dist
@@ -306,3 +320,17 @@ def test_bench_launch_shape_is_checked_before_the_gpu_is_touched():
     assert run.returncode == 2
     lines = [l for l in run.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and "error" in json.loads(lines[0])
+
+
+def test_dirty_ranges_under_address_and_ub_sanitizers(tmp_path):
+    """garden_amd/csrc/gv_dirty_ranges.hpp: the itemised dirty marks behind gv_mark_dirty (host-only). Random marks —
+    overlapping, adjacent, empty, wrapping first + count — against a bitmap model, built with
+    -fsanitize=address,undefined."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "dirty_ranges_test")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            os.path.join(root, "tests/cpp/dirty_ranges_test.cpp"), "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: SQ counters of the fused sweep + cull kernels (cfg4), current build vs a build with round 1's gv_sweep.hip
-# (garden_amd/lib/ab_r01sweep.so, made by hand for this A/B). Counter passes are separate runs with --kernel-trace only.
+# (garden_amd/lib/ab_r01sweep.so, made by hand for this A/B: `git show <round-1 commit>:garden_amd/csrc/gv_sweep.hip`, compiled with the
+# Makefile flags and linked with the current objects in place of gv_sweep.o). Counter passes are separate runs with --kernel-trace only.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r02e
