@@ -17,7 +17,9 @@
 //
 // Host code only (no HIP): GvScene can be parsed, inspected and destroyed without a device; gv_scene_bind needs a context.
 #include <cerrno>
+#include <algorithm>
 #include <charconv>
+#include <new>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -50,6 +52,9 @@ struct GvScene {
     std::vector<uint32_t> entity_to_transform;  // [entity id] -> slot or GV_NONE
     MeshColumnsOwned pools[GV_MAX_POOLS];
     GvSceneInfo info{};
+    // a tile cut out of a larger scene (gv_scene_extract_tile): local slot -> slot in the scene it was cut from
+    std::vector<uint32_t> transform_global, mesh_global[GV_MAX_POOLS];
+    bool is_tile = false;
 };
 
 namespace {
@@ -943,7 +948,162 @@ int gv_scene_bind(GvCtx* ctx, GvScene* scene)
         rc = gv_mark_dirty(ctx, GV_DIRTY_MESH, k << 28, count);
         if (rc != GV_OK)
             return rc;
+        // a tile's pool slots are not a contiguous range of the world's: the exchange carries the world's mesh slots
+        rc = gv_pool_set_index_map(ctx, k, scene->is_tile ? scene->mesh_global[k].data() : nullptr,
+                                   scene->is_tile ? (uint32_t)scene->mesh_global[k].size() : 0u);
+        if (rc != GV_OK)
+            return rc;
     }
+    return GV_OK;
+}
+
+// One spatial tile of a scene as a scene of its own (entities shard by spatial tile; the nearest reference
+// analogue is the contiguous range split of ThreadPool::addItems, source/thread-pool.cpp:173-200 — here the cut is by
+// space so that a tile is culled as a unit). Same rule as garden_amd/multi.py::partition_world, which the tests compare
+// it with: every ROOT transform goes to the tile its position falls in (grid cells of a cube of edge `side` centred on
+// the origin), every descendant follows its root (a parent chain is never cut), a mesh follows its entity's transform;
+// free slots and meshes without a transform go to tile 0; inside a tile slots keep their order, entity ids are
+// renumbered from 1 (live transforms in slot order, then mesh entities without a transform in ascending old id), parents
+// are remapped (a parent without a transform stays an id nothing maps to).
+int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double side, uint32_t tile, GvScene** out_tile)
+{
+    if (!scene || !grid || !out_tile || !(side > 0.0) || grid[0] == 0 || grid[1] == 0 || grid[2] == 0 ||
+        (uint64_t)grid[0] * grid[1] * grid[2] > 4096u || tile >= grid[0] * grid[1] * grid[2])
+        return GV_E_ARG;
+    *out_tile = nullptr;
+    const uint32_t nt = (uint32_t)scene->entity.size();
+    const auto& e2t = scene->entity_to_transform;
+    auto slot_of = [&](uint32_t entity) -> uint32_t {
+        return (entity == 0 || entity >= e2t.size()) ? kNone : e2t[entity];
+    };
+    // root ancestor of every transform slot (chains are short; a cycle — the loader cannot produce one — ends at 64 steps)
+    std::vector<uint32_t> xf_tile(nt, 0);
+    for (uint32_t s = 0; s < nt; s++) {
+        if (scene->entity[s] == 0)
+            continue;  // free slot: tile 0
+        uint32_t root = s;
+        for (int hop = 0; hop < 64; hop++) {
+            const uint32_t ps = slot_of(scene->parent[root]);
+            if (ps == kNone || ps >= nt || scene->entity[ps] == 0)
+                break;
+            root = ps;
+        }
+        uint32_t t = 0, mul = 1;
+        for (int a = 0; a < 3; a++) {
+            const double cell = ((double)scene->position[(size_t)root * 3 + a] / side + 0.5) * (double)grid[a];
+            long long c = (long long)cell;  // truncation, as numpy's astype(int64)
+            c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
+            t += (uint32_t)c * mul;
+            mul *= grid[a];
+        }
+        xf_tile[s] = t;
+    }
+    GvScene* out = new (std::nothrow) GvScene();
+    if (!out)
+        return GV_E_OOM;
+    out->is_tile = true;
+    // transforms of the tile, ascending slot; new ids for live ones
+    std::vector<uint32_t> new_id(e2t.size() + 1, 0);
+    uint32_t k = 0;
+    for (uint32_t s = 0; s < nt; s++)
+        if (xf_tile[s] == tile) {
+            out->transform_global.push_back(s);
+            if (scene->entity[s] != 0 && scene->entity[s] < new_id.size())
+                new_id[scene->entity[s]] = ++k;
+        }
+    // meshes of the tile per pool; entities without a transform in this tile get ids behind the transforms'
+    std::vector<uint32_t> stray;
+    for (uint32_t pid = 0; pid < GV_MAX_POOLS; pid++) {
+        const MeshColumnsOwned& src = scene->pools[pid];
+        out->pools[pid].type = src.type;
+        out->pools[pid].mapped = src.mapped;
+        for (uint32_t i = 0; i < src.entity.size(); i++) {
+            const uint32_t ts = slot_of(src.entity[i]);
+            const uint32_t mt = (ts != kNone && ts < nt) ? xf_tile[ts] : 0u;
+            if (mt != tile)
+                continue;
+            out->mesh_global[pid].push_back(i);
+            const uint32_t e = src.entity[i];
+            if (e != 0 && (e >= new_id.size() || new_id[e] == 0))
+                stray.push_back(e);
+        }
+    }
+    std::sort(stray.begin(), stray.end());
+    stray.erase(std::unique(stray.begin(), stray.end()), stray.end());
+    std::unordered_map<uint32_t, uint32_t> stray_id;  // (ids beyond the entity map included)
+    for (size_t q = 0; q < stray.size(); q++) {
+        if (stray[q] < new_id.size())
+            new_id[stray[q]] = k + 1 + (uint32_t)q;
+        stray_id[stray[q]] = k + 1 + (uint32_t)q;
+    }
+    auto mapped_id = [&](uint32_t e) -> uint32_t {
+        if (e == 0)
+            return 0;
+        if (e < new_id.size())
+            return new_id[e];
+        auto it = stray_id.find(e);
+        return it == stray_id.end() ? 0u : it->second;
+    };
+    bool dangling = false;
+    for (uint32_t s : out->transform_global)
+        if (scene->parent[s] != 0 && mapped_id(scene->parent[s]) == 0)
+            dangling = true;
+    const uint32_t cap = k + 1 + (uint32_t)stray.size() + (dangling ? 1u : 0u);
+    out->entity_to_transform.assign(cap, kNone);
+    for (uint32_t local = 0; local < out->transform_global.size(); local++) {
+        const uint32_t s = out->transform_global[local];
+        const uint32_t id = mapped_id(scene->entity[s]);
+        out->entity.push_back(id);
+        uint32_t parent = mapped_id(scene->parent[s]);
+        if (scene->parent[s] != 0 && parent == 0)
+            parent = cap - 1;  // an entity id with no transform: the chain ends there, as in the whole scene
+        out->parent.push_back(parent);
+        out->uid.push_back(scene->uid[s]);
+        for (int c = 0; c < 3; c++) {
+            out->position.push_back(scene->position[(size_t)s * 3 + c]);
+            out->scale.push_back(scene->scale[(size_t)s * 3 + c]);
+        }
+        for (int c = 0; c < 4; c++)
+            out->rotation.push_back(scene->rotation[(size_t)s * 4 + c]);
+        out->self_active.push_back(scene->self_active[s]);
+        out->ancestors_active.push_back(scene->ancestors_active[s]);
+        out->model_with_ancestors.push_back(scene->model_with_ancestors[s]);
+        if (id != 0)
+            out->entity_to_transform[id] = local;
+    }
+    for (uint32_t pid = 0; pid < GV_MAX_POOLS; pid++) {
+        const MeshColumnsOwned& src = scene->pools[pid];
+        MeshColumnsOwned& dst = out->pools[pid];
+        for (uint32_t i : out->mesh_global[pid]) {
+            dst.entity.push_back(mapped_id(src.entity[i]));
+            dst.is_enabled.push_back(src.is_enabled[i]);
+            dst.is_visible.push_back(0);
+            for (int c = 0; c < 3; c++) {
+                dst.aabb_min.push_back(src.aabb_min[(size_t)i * 3 + c]);
+                dst.aabb_max.push_back(src.aabb_max[(size_t)i * 3 + c]);
+            }
+        }
+        out->info.mesh_count[pid] = (uint32_t)dst.entity.size();
+    }
+    out->info.entity_count = cap - 1;
+    out->info.transform_count = (uint32_t)out->entity.size();
+    *out_tile = out;
+    return GV_OK;
+}
+
+int gv_scene_tile_maps(const GvScene* tile, uint32_t pool_id, const uint32_t** transform_global, uint32_t* transform_count,
+                       const uint32_t** mesh_global, uint32_t* mesh_count)
+{
+    if (!tile || !tile->is_tile || pool_id >= GV_MAX_POOLS)
+        return GV_E_ARG;
+    if (transform_global)
+        *transform_global = tile->transform_global.data();
+    if (transform_count)
+        *transform_count = (uint32_t)tile->transform_global.size();
+    if (mesh_global)
+        *mesh_global = tile->mesh_global[pool_id].data();
+    if (mesh_count)
+        *mesh_count = (uint32_t)tile->mesh_global[pool_id].size();
     return GV_OK;
 }
 

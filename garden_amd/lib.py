@@ -104,7 +104,7 @@ EXPORTS = [
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
-    "gv_scene_bind",
+    "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end",
@@ -173,6 +173,8 @@ def load():
                                                C.POINTER(u32), C.POINTER(P)]
     lib.gv_scene_mesh_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), C.POINTER(u32)]
     lib.gv_scene_bind.argtypes = [P, P]
+    lib.gv_scene_extract_tile.argtypes = [P, C.POINTER(C.c_uint32 * 3), C.c_double, u32, C.POINTER(P)]
+    lib.gv_scene_tile_maps.argtypes = [P, u32, C.POINTER(P), C.POINTER(u32), C.POINTER(P), C.POINTER(u32)]
     lib.gv_exchange_unique_id.argtypes = [P]
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
     lib.gv_exchange_shards.argtypes = [P, u32, u32, u32, P]
@@ -518,6 +520,25 @@ class Scene:
         return dict(entity=self._view(c.entity, n, np.uint32, 1), is_enabled=self._view(c.is_enabled, n, np.uint8, 1),
                     aabb_min=self._view(c.aabb_min, n, np.float32, 3), aabb_max=self._view(c.aabb_max, n, np.float32, 3),
                     is_visible=self._view(GvColumn(c.is_visible, 1), n, np.uint8, 1))
+
+    def extract_tile(self, grid, side, tile):
+        """One spatial tile of this scene as a Scene of its own (gv_scene_extract_tile)."""
+        handle = C.c_void_p()
+        g = (C.c_uint32 * 3)(*[int(x) for x in grid])
+        rc = self.lib.gv_scene_extract_tile(self.handle, C.byref(g), float(side), int(tile), C.byref(handle))
+        if rc != 0:
+            raise GvError(rc, "gv_scene_extract_tile failed")
+        t = Scene.__new__(Scene)
+        t.lib, t.handle, t.pools = self.lib, handle, dict(self.pools)
+        return t
+
+    def tile_maps(self, pool_id):
+        """(transform_global, mesh_global) of a tile: local slot -> slot in the scene it was cut from."""
+        tg, tn, mg, mn = C.c_void_p(), C.c_uint32(), C.c_void_p(), C.c_uint32()
+        rc = self.lib.gv_scene_tile_maps(self.handle, pool_id, C.byref(tg), C.byref(tn), C.byref(mg), C.byref(mn))
+        if rc != 0:
+            raise GvError(rc, "gv_scene_tile_maps: not a tile")
+        return (self._view(GvColumn(tg.value, 4), tn.value, np.uint32, 1), self._view(GvColumn(mg.value, 4), mn.value, np.uint32, 1))
 
     def bind(self, vis):
         """Binds the scene's columns to a GpuVisibility context (the scene must stay alive while bound)."""

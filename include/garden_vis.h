@@ -318,8 +318,21 @@ int gv_scene_transform_columns(const GvScene* scene, GvTransformColumns* columns
                                const uint32_t** entity_to_transform, uint32_t* entity_capacity, const uint64_t** uids);
 int gv_scene_mesh_columns(GvScene* scene, uint32_t pool_id, GvMeshColumns* columns, uint32_t* occupancy);
 /* Binds the transform columns and every mapped mesh pool to `ctx` and schedules a full mirror build. The scene must
- * outlive the binding. */
+ * outlive the binding. For a tile (gv_scene_extract_tile) the pools' slot -> world-slot tables are installed too
+ * (gv_pool_set_index_map), so exchange shards carry the world's mesh slots. */
 int gv_scene_bind(GvCtx* ctx, GvScene* scene);
+/* One spatial tile of a scene as a scene of its own (one process per GPU, entities sharded by spatial
+ * tile; nearest reference analogue: the contiguous range split of ThreadPool::addItems, source/thread-pool.cpp:173-200).
+ * The world cube of edge `side`, centred on the origin, is cut into grid[0] x grid[1] x grid[2] cells; `tile` = x + y *
+ * grid[0] + z * grid[0] * grid[1]. Every ROOT transform goes to the cell its position falls in, every descendant follows
+ * its root (no parent chain is cut: a tile computes the world's matrices bit for bit), a mesh follows its entity's
+ * transform; free slots and meshes without a transform go to tile 0. Inside the tile slots keep their order, entity ids
+ * are renumbered from 1, parents remapped. The same rule as garden_amd/multi.py::partition_world (tests compare them).
+ * Each rank of a multi-GPU run parses the scene, keeps its own tile, binds it and culls; gv_scene_tile_maps gives the
+ * tile-local -> world slot tables (what a gathered visible index means). Destroy with gv_scene_destroy. */
+int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double side, uint32_t tile, GvScene** out_tile);
+int gv_scene_tile_maps(const GvScene* tile, uint32_t pool_id, const uint32_t** transform_global, uint32_t* transform_count,
+                       const uint32_t** mesh_global, uint32_t* mesh_count);
 
 /* ---- world matrices: TransformComponent::calcModel() with cameraPosition = 0 for every transform
  * slot (transform.hpp:197-214), cached on the device ---- */

@@ -16,6 +16,7 @@ extern "C" {
 int gv_transform_bind_columns(GvCtx*, const GvTransformColumns*, uint32_t, const uint32_t*, uint32_t) { return GV_E_STATE; }
 int gv_pool_bind_columns(GvCtx*, uint32_t, const GvMeshColumns*, uint32_t) { return GV_E_STATE; }
 int gv_mark_dirty(GvCtx*, uint32_t, uint32_t, uint32_t) { return GV_E_STATE; }
+int gv_pool_set_index_map(GvCtx*, uint32_t, const uint32_t*, uint32_t) { return GV_E_STATE; }
 }
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -47,6 +48,23 @@ int main(int argc, char** argv)
             if (rc == GV_OK) {
                 GvSceneInfo info;
                 gv_scene_info(sc, &info);
+                // every scene that parses is also cut into spatial tiles (gv_scene_extract_tile): whatever the mutation did
+                // to parents, ids and positions (NaN, inf, huge), a tile is a scene or an error, never a fault
+                const uint32_t grid[3] = {2, 1 + rnd() % 2, 1};
+                uint32_t transforms = 0;
+                for (uint32_t t = 0; t < grid[0] * grid[1] * grid[2]; t++) {
+                    GvScene* tile = nullptr;
+                    if (gv_scene_extract_tile(sc, grid, 1000.0, t, &tile) == GV_OK) {
+                        GvSceneInfo ti;
+                        gv_scene_info(tile, &ti);
+                        transforms += ti.transform_count;
+                        gv_scene_destroy(tile);
+                    }
+                }
+                if (transforms != info.transform_count) {
+                    printf("{\"ok\": false, \"why\": \"tiles hold %u of %u transforms\"}\n", transforms, info.transform_count);
+                    exit(1);
+                }
                 gv_scene_destroy(sc);
                 parsed++;
             } else {

@@ -169,6 +169,56 @@ def test_ingested_scene_culls_like_the_reference_pools(gpu, oracle, hier, add_ro
     sc.close()
 
 
+@pytest.mark.gpu
+def test_scene_file_to_spatial_tiles_to_cull_to_exchange(oracle):
+    """The native multi-GPU chain on one GPU: scene file -> gv_scene_parse_json -> gv_scene_extract_tile (each rank keeps
+    its tile) -> gv_scene_bind (installs the tile -> world slot tables) -> cull -> gv_exchange_shards (1-rank RCCL):
+    the union of the gathered ids over the tiles is the whole scene's oracle visible set, in world mesh slots."""
+    import torch
+
+    from garden_amd.lib import GpuVisibility
+    from garden_amd.multi import shard_capacity
+    text = scene_text(80_000, True)
+    whole = Scene(text, POOLS)
+    tr, meshes, e2t = columns_equal_aos(whole, text)
+    view = scene.main_camera_view()
+    side = 100.0 * 80_000 ** (1.0 / 3.0)
+    grid = (2, 2, 2)
+    expect = {pid: np.sort(oracle.prepare_meshes(meshes[pid].copy(), tr, e2t, view)["visible_idx"].astype(np.int64)) for pid in (0, 3)}
+    union = {0: [], 3: []}
+    with GpuVisibility(device=0) as vis:
+        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
+        for t in range(8):
+            tile = whole.extract_tile(grid, side, t)
+            tile.bind(vis)
+            for pid in (0, 3):
+                n = tile.info()["mesh_count"][pid]
+                vis.cull(pid, [view])
+                count = vis.result_count(0)
+                cap = shard_capacity(count)
+                gathered = torch.zeros(1 + cap, dtype=torch.int32, device="cuda:0")
+                vis.exchange_shards(0, cap, 0, gathered.data_ptr())
+                vis.wait()
+                row = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                assert row[0] == count
+                union[pid].append(row[1:1 + count])
+                _, mesh_global = tile.tile_maps(pid)
+                got = vis.fetch(0, write_back=False, occupancy=n)
+                assert np.array_equal(np.sort(row[1:1 + count]), np.sort(mesh_global[got["visible_idx"]].astype(np.int64)))
+            # un-bind before the tile's columns go away
+            flat = scene.flat_scene(64)
+            vis.bind_transforms(flat.transforms, flat.entity_to_transform)
+            for pid in (0, 3):
+                vis.bind_pool(pid, flat.meshes[:0])
+            vis.hierarchy_rebuild()
+            tile.close()
+        vis.exchange_shutdown()
+    for pid in (0, 3):
+        assert expect[pid].shape[0] > 500
+        assert np.array_equal(np.sort(np.concatenate(union[pid])), expect[pid])
+    whole.close()
+
+
 def test_committed_scene_fixture():
     """tests/golden/scene_golden.{json,npz} (made by tests/golden/make_scene_golden.py): the ingest and the Python
     restatement of the loader both still produce the committed pools."""
@@ -325,3 +375,65 @@ def test_scene_parsers_under_address_and_ub_sanitizers(tmp_path):
     (tmp_path / "seed.bson").write_bytes(to_bson(json.loads(text)))
     run = subprocess.run([exe, str(tmp_path / "seed.json"), str(tmp_path / "seed.bson")], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout[-500:] + run.stderr[-3000:]
+
+
+def _scene_as_aos(sc_handle, pool_id=0):
+    """The columns of a parsed scene as a garden_amd.scene.Scene (AoS pools), for the Python partitioner."""
+    from garden_amd.pools import MESH_DTYPE, TRANSFORM_DTYPE
+    c = sc_handle.transform_columns()
+    n = c["entity"].shape[0]
+    tr = np.zeros(n, TRANSFORM_DTYPE)
+    tr["entity"], tr["parent"], tr["uid"] = c["entity"], c["parent"], c["uid"]
+    tr["position"][:, :3], tr["scale"][:, :3], tr["rotation"] = c["position"], c["scale"], c["rotation"]
+    tr["selfActive"], tr["ancestorsActive"], tr["modelWithAncestors"] = c["self_active"], c["ancestors_active"], c["model_with_ancestors"]
+    m = sc_handle.mesh_columns(pool_id)
+    ms = np.zeros(m["entity"].shape[0], MESH_DTYPE)
+    ms["entity"], ms["isEnabled"] = m["entity"], m["is_enabled"]
+    ms["aabbMin"][:, :3], ms["aabbMax"][:, :3] = m["aabb_min"], m["aabb_max"]
+    return scene.Scene(ms, tr, c["entity_to_transform"])
+
+
+@pytest.mark.parametrize("grid", [(2, 2, 2), (3, 1, 2)])
+def test_native_tile_extraction_equals_partition_world(grid):
+    """gv_scene_extract_tile (the multi-GPU sharding rule of SURVEY.md §8e in the C-ABI: each rank parses the scene file
+    and keeps its tile) against garden_amd/multi.py::partition_world on the same scene: every column of every tile, the
+    renumbered ids, the remapped parents, entity_to_transform and the tile -> world slot tables."""
+    from garden_amd.multi import partition_world
+    src = scene.hierarchy_scene(5000, depth=4, fanout=5)
+    src = scene.shuffled_scene(src, fraction=0.4)  # mesh and transform pools in different orders
+    text = sj.write_scene(src.transforms, {"Model": src.meshes}, src.entity_to_transform)
+    whole = Scene(text, {"Model": 0})
+    aos = _scene_as_aos(whole)
+    side = 100.0 * 5000 ** (1.0 / 3.0)
+    part = partition_world(aos, grid, side=side)
+    seen_t, seen_m = 0, 0
+    for t in range(grid[0] * grid[1] * grid[2]):
+        tile = whole.extract_tile(grid, side, t)
+        exp = part.tiles[t]
+        c = tile.transform_columns()
+        tg, mg = tile.tile_maps(0)
+        assert np.array_equal(tg.astype(np.int64), part.transform_global[t]) and np.array_equal(mg.astype(np.int64), part.mesh_global[t])
+        assert np.array_equal(c["entity"], exp.transforms["entity"]), t
+        assert np.array_equal(c["parent"], exp.transforms["parent"]), t
+        assert np.array_equal(c["uid"], exp.transforms["uid"])
+        assert np.array_equal(c["position"].view(np.uint32), np.ascontiguousarray(exp.transforms["position"][:, :3]).view(np.uint32))
+        assert np.array_equal(c["rotation"].view(np.uint32), exp.transforms["rotation"].view(np.uint32))
+        assert np.array_equal(c["scale"].view(np.uint32), np.ascontiguousarray(exp.transforms["scale"][:, :3]).view(np.uint32))
+        for a, b in (("self_active", "selfActive"), ("ancestors_active", "ancestorsActive"), ("model_with_ancestors", "modelWithAncestors")):
+            assert np.array_equal(c[a], exp.transforms[b])
+        assert np.array_equal(c["entity_to_transform"], exp.entity_to_transform), t
+        m = tile.mesh_columns(0)
+        assert np.array_equal(m["entity"], exp.meshes["entity"]) and np.array_equal(m["is_enabled"], exp.meshes["isEnabled"])
+        assert np.array_equal(m["aabb_min"].view(np.uint32), np.ascontiguousarray(exp.meshes["aabbMin"][:, :3]).view(np.uint32))
+        assert np.array_equal(m["aabb_max"].view(np.uint32), np.ascontiguousarray(exp.meshes["aabbMax"][:, :3]).view(np.uint32))
+        i = tile.info()
+        assert i["transform_count"] == exp.transforms.shape[0] and i["mesh_count"][0] == exp.count
+        seen_t += exp.transforms.shape[0]
+        seen_m += exp.count
+        tile.close()
+    assert seen_t == aos.transforms.shape[0] and seen_m == aos.count
+    with pytest.raises(GvError):
+        whole.extract_tile(grid, side, grid[0] * grid[1] * grid[2])  # no such tile
+    with pytest.raises(GvError):
+        whole.tile_maps(0)  # the whole scene is not a tile
+    whole.close()
