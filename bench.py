@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--block-bounds", action="store_true",
                     help="GV_CONFIG_BLOCK_BOUNDS: conservative workgroup-level frustum rejection (same results); the "
                          "roofline numerator then counts the streams of examined workgroups only")
+    ap.add_argument("--hiz-rg16f", action="store_true",
+                    help="GV_CONFIG_HIZ_RG16F: the pyramid in the reference's RG16F image format, rounded outward (a variant: "
+                         "the headline keeps the fp32 pyramid; parity is then checked against the oracle's RG16F pyramid)")
     ap.add_argument("--exchange", default=os.environ.get("GV_BENCH_EXCHANGE_MODE", "allgather"),
                     choices=["allgather", "p2p", "broadcast"],
                     help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
@@ -301,7 +304,7 @@ def main():
     # hipEvents bracket only the dominant kernel inside the timed region (each event record costs ~2 us of
     # stream time); --profile-all brackets every kernel for the per-kernel breakdown in config.kernel_ms
     vis = GpuVisibility(device=local_rank, profile_events=args.profile_all, profile_cull_only=not args.profile_all,
-                        block_bounds=args.block_bounds)
+                        block_bounds=args.block_bounds, hiz_rg16f=args.hiz_rg16f)
     t_up = time.perf_counter()
     vis.bind_transforms(sc.transforms, sc.entity_to_transform)
     vis.bind_pool(0, sc.meshes)
@@ -504,7 +507,7 @@ def main():
         if not args.no_parity:
             m2 = sc.meshes.copy()
             exp = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view,
-                                           hiz=oracle_py.Hiz(depth, threads=threads) if wl["hiz"] else None, threads=threads)
+                                           hiz=oracle_py.Hiz(depth, threads=threads, rg16f=args.hiz_rg16f) if wl["hiz"] else None, threads=threads)
             order = np.argsort(exp["visible_idx"], kind="stable")
             same_set = bool(np.array_equal(got["visible_idx"], exp["visible_idx"][order]))
             same_vis = bool(np.array_equal(got["is_visible"], m2["isVisible"]))
@@ -542,7 +545,7 @@ def main():
                                   "kernel_source_sha_at_collection": tj.get("_kernel_source_sha"),
                                   "kernel_source_sha_now": now,
                                   "per_entity_scaled": False}
-                if tj.get("_kernel_source_sha") == now and not args.block_bounds and "cull_kernel_hbm_bytes_per_launch" in entry:
+                if tj.get("_kernel_source_sha") == now and not args.block_bounds and not args.hiz_rg16f and "cull_kernel_hbm_bytes_per_launch" in entry:
                     traffic = entry["cull_kernel_hbm_bytes_per_launch"]
                     measured_n = entry.get("entities", 10_000_000)
                     if measured_n != n:  # counters were taken at another pool size of the same streaming kernel
@@ -565,7 +568,7 @@ def main():
             "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None,
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
                        "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
-                       "visible_fraction": visible / n, "hiz": f"{HIZ_SIZE}x{HIZ_SIZE}" if wl["hiz"] else None,
+                       "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,
                        "exchange": (f"per frame: padded shards [count, uint32 indices...] (capacity {ex[0].capacity}) travel by "
                                     f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,

@@ -107,8 +107,17 @@ int world_current(GvCtx* ctx)
     return GV_OK;
 }
 
+// level k >= 1 of the pyramid: float2 texels, or packed binary16 pairs (4 bytes) under GV_CONFIG_HIZ_RG16F
+static float2* mip_ptr(GvCtx* ctx, uint32_t k)
+{
+    if (ctx->config.flags & GV_CONFIG_HIZ_RG16F)
+        return reinterpret_cast<float2*>(reinterpret_cast<uint32_t*>(ctx->d_mips.ptr) + ctx->mip_off[k]);
+    return ctx->d_mips.ptr + ctx->mip_off[k];
+}
+
 int hiz_reduce(GvCtx* ctx)
 {
+    const bool rg16f = (ctx->config.flags & GV_CONFIG_HIZ_RG16F) != 0;
     ctx->hiz_level1_stored = false;
     ZoneScope zone("HiZ Downsample");
     KernelTimer timer(ctx, GV_K_HIZ);
@@ -116,18 +125,18 @@ int hiz_reduce(GvCtx* ctx)
     while (k < ctx->hiz_mips) {
         const uint32_t sw = ctx->mip_w[k - 1], sh = ctx->mip_h[k - 1];
         const float* src_d = k == 1 ? ctx->depth_ptr : nullptr;
-        const float2* src_p = k == 1 ? nullptr : ctx->d_mips.ptr + ctx->mip_off[k - 1];
+        const float2* src_p = k == 1 ? nullptr : mip_ptr(ctx, k - 1);
         if (sw % 64 == 0 && sh % 64 == 0 && k + 5 < ctx->hiz_mips) {
             HizFusedDst dst;
             for (int l = 0; l < 6; l++)
-                dst.level[l] = ctx->d_mips.ptr + ctx->mip_off[k + l];
+                dst.level[l] = mip_ptr(ctx, k + l);
             if (k == 1 && ctx->hiz_level1_virtual)
                 dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
-            GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, ctx->stream));
+            GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, rg16f, ctx->stream));
             k += 6;
         } else {
-            GV_HIP(ctx, launch_hiz_level(src_d, src_p, ctx->d_mips.ptr + ctx->mip_off[k], sw, sh, ctx->mip_w[k],
-                                         ctx->mip_h[k], ctx->config.hiz_rule, ctx->stream));
+            GV_HIP(ctx, launch_hiz_level(src_d, src_p, mip_ptr(ctx, k), sw, sh, ctx->mip_w[k], ctx->mip_h[k], ctx->config.hiz_rule, rg16f,
+                                         ctx->stream));
             k += 1;
         }
     }
@@ -145,6 +154,7 @@ HizDevice hiz_device(const GvCtx* ctx)
         hz.height = ctx->hiz_h;
         hz.mip_count = ctx->hiz_mips;
         hz.nested = ctx->hiz_nested ? 1u : 0u;
+        hz.rg16f = (ctx->config.flags & GV_CONFIG_HIZ_RG16F) ? 1u : 0u;
         hz.level1_virtual = ctx->hiz_level1_virtual ? 1u : 0u;
     }
     return hz;
@@ -416,7 +426,7 @@ int flush_sorts(GvCtx* ctx)
             std::swap(vs.baked_model, vs.alt_model);
             std::swap(vs.distance_sq, vs.alt_dist);
             vs.sort_pending = 0;
-            vs.published = false;
+            vs.published = false, vs.records_fetched = false;
         }
     }
 }
@@ -520,6 +530,7 @@ void gv_destroy(GvCtx* ctx)
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
+        v.h_records.release(); v.d_records.release();
         v.tile_status.release(); v.tile_ticket.release();
     }
     ctx->d_world.release(); ctx->d_xdirty.release(); ctx->d_raw.release(); ctx->d_examined.release();
@@ -751,7 +762,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.main_pass = views[v].shadow_pass < 0;
         vs.emitted = emit;
         vs.valid = true;
-        vs.published = false;
+        vs.published = false, vs.records_fetched = false;
         vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
         build_view_params(views[v], &vps[v]);
         if (p.occupancy == 0)
@@ -895,7 +906,12 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
                     a.is_visible = w.is_visible.ptr;
                     GV_HIP(ctx, w.h_draw_count.reserve(4));
                     a.host_count = w.h_draw_count.ptr;
-                    if (w.emitted) {
+                    if (w.emitted && wp.record_layout.stride) {
+                        GV_HIP(ctx, w.h_records.reserve((size_t)w.occupancy * wp.record_layout.stride));
+                        a.host_records = w.h_records.ptr;
+                        a.layout = wp.record_layout;
+                        w.records_fetched = true;
+                    } else if (w.emitted) {
                         GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
                         GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
                         GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
@@ -930,7 +946,16 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         int rc = gv_pool_result_count(ctx, pool_id, view_index, &count);
         if (rc != GV_OK)
             return rc;
-        if (vs.emitted && count) {
+        if (vs.emitted && pool.record_layout.stride)
+            vs.records_fetched = true;
+        if (vs.emitted && count && pool.record_layout.stride) {  // packed on the device, one copy
+            const size_t bytes = (size_t)count * pool.record_layout.stride;
+            GV_HIP(ctx, vs.d_records.reserve((size_t)vs.occupancy * pool.record_layout.stride));
+            GV_HIP(ctx, vs.h_records.reserve((size_t)vs.occupancy * pool.record_layout.stride));
+            GV_HIP(ctx, launch_pack_records(vs.draw_count.ptr, vs.visible_idx.ptr, vs.baked_model.ptr, vs.distance_sq.ptr, pool.record_layout,
+                                            count, vs.d_records.ptr, ctx->stream));
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_records.ptr, vs.d_records.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (vs.emitted && count) {
             if ((rc = reserve_records()) != GV_OK)
                 return rc;
             GV_HIP(ctx, hipMemcpyAsync(vs.h_visible_idx.ptr, vs.visible_idx.ptr, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -951,7 +976,8 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
     memset(out, 0, sizeof(*out));
     out->draw_count = count;
     out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)
-    if (vs.emitted && count) {
+    const bool as_records = vs.emitted && vs.records_fetched;
+    if (vs.emitted && count && !as_records) {
         out->visible_idx = vs.h_visible_idx.ptr;
         out->baked_model = vs.h_baked_model.ptr;
         out->distance_sq = vs.h_distance_sq.ptr;
@@ -960,7 +986,20 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         // instanceCount += readyCount (mesh.cpp:174): the drawn meshes' own counts, summed over the fetched list (or, for
         // a count-only main pass, over the isVisible bytes); a count-only shadow view keeps draw_count
         std::atomic<uint64_t> total{0};
-        if (vs.emitted) {
+        if (as_records) {  // the slot is componentOffset / component size
+            const RecordLayout L = pool.record_layout;
+            const uint8_t* field = vs.h_records.ptr + L.component_offset;
+            parallel_ranges(0, count, [&](uint32_t a, uint32_t b) {
+                uint64_t sum = 0;
+                for (uint32_t k = a; k < b; k++) {
+                    uint64_t offset;
+                    memcpy(&offset, field + (size_t)k * L.stride, 8);
+                    sum += pool.ready_count((uint32_t)(offset / L.component_stride));
+                }
+                total += sum;
+            });
+            out->instance_count = (uint32_t)total.load();
+        } else if (vs.emitted) {
             const uint32_t* idx = vs.h_visible_idx.ptr;
             parallel_ranges(0, count, [&](uint32_t a, uint32_t b) {
                 uint64_t sum = 0;
@@ -1000,6 +1039,61 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             });
         out->is_visible = out_vis;
     }
+    return GV_OK;
+}
+
+int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout* layout)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS)
+        return ctx->fail(GV_E_ARG, "gv_pool_set_record_layout: pool %u out of range", pool_id);
+    RecordLayout L{};  // read when results are delivered, not when they are computed: queued culls are left alone
+    if (layout) {
+        const uint32_t stride = layout->stride;
+        auto inside = [&](uint32_t offset, uint32_t bytes) { return offset % 4 == 0 && offset <= stride && bytes <= stride - offset; };
+        struct Span { uint32_t at, bytes; } spans[4] = {{layout->component_offset, 8}, {layout->baked_model, 48}, {layout->distance_sq, 4},
+                                                       {layout->buffer_index, 4}};
+        const uint32_t fields = layout->buffer_index == GV_NONE ? 3 : 4;
+        bool ok = stride != 0 && stride % 16 == 0 && stride <= kMaxRecordStride && layout->component_stride != 0;
+        for (uint32_t i = 0; ok && i < fields; i++) {
+            ok = inside(spans[i].at, spans[i].bytes);
+            for (uint32_t j = 0; ok && j < i; j++)
+                ok = spans[i].at + spans[i].bytes <= spans[j].at || spans[j].at + spans[j].bytes <= spans[i].at;
+        }
+        if (!ok)
+            return ctx->fail(GV_E_ARG, "gv_pool_set_record_layout: stride %u (a multiple of 16, at most %u) with fields at %u/%u/%u/%u: "
+                             "fields must be 4-byte aligned, inside the record and disjoint", stride, kMaxRecordStride,
+                             layout->component_offset, layout->baked_model, layout->distance_sq, layout->buffer_index);
+        L = RecordLayout{stride, layout->component_offset, layout->baked_model, layout->distance_sq, layout->buffer_index,
+                         layout->component_stride, layout->buffer_index_value};
+    }
+    if (memcmp(&ctx->pools[pool_id].record_layout, &L, sizeof(L)) == 0)
+        return GV_OK;  // set every frame by callers that re-bind every frame
+    ctx->pools[pool_id].record_layout = L;
+    for (uint32_t v = 0; v < GV_MAX_VIEWS; v++)  // the next fetch delivers this pool's results again, in the new form
+        ctx->views[pool_id][v].published = false, ctx->views[pool_id][v].records_fetched = false;
+    return GV_OK;
+}
+
+int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!records || !count || !view_of(ctx, pool_id, view_index))
+        return ctx->fail(GV_E_ARG, "gv_pool_results_records: pool %u view %u has no results", pool_id, view_index);
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
+    if (!ctx->pools[pool_id].record_layout.stride)
+        return ctx->fail(GV_E_STATE, "gv_pool_results_records: pool %u has no record layout", pool_id);
+    if (!vs.emitted)
+        return ctx->fail(GV_E_STATE, "gv_pool_results_records: pool %u view %u was culled count-only (GV_CULL_NO_RECORDS)", pool_id, view_index);
+    if (!vs.records_fetched) {  // not fetched yet
+        GvResult unused;
+        if (int rc = gv_pool_results_fetch(ctx, pool_id, view_index, 0, &unused))
+            return rc;
+    }
+    *count = vs.h_draw_count.ptr[0];
+    *records = *count && vs.records_fetched ? vs.h_records.ptr : nullptr;
     return GV_OK;
 }
 
@@ -1093,7 +1187,7 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
         return GV_OK;
     if (vs.occupancy <= kSmallSortMaxSlots) {  // launched with the other views' sorts when the records are asked for
         vs.sort_pending = descending ? 2 : 1;
-        vs.published = false;
+        vs.published = false, vs.records_fetched = false;
         return GV_OK;
     }
     GV_HIP(ctx, hipSetDevice(ctx->device));
@@ -1135,7 +1229,7 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
         KernelTimer t(ctx, GV_K_SORT);
         GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending != 0, ctx->stream));
     }
-    vs.published = false;
+    vs.published = false, vs.records_fetched = false;
     // the sorted records now live in the alternate set: swap it in
     std::swap(vs.visible_idx, vs.alt_idx);
     std::swap(vs.baked_model, vs.alt_model);
@@ -1237,7 +1331,8 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
     }
     // level 1 stays virtual when the first six levels come from the fused kernel (sizes divisible by 64: plain 2x2 rule)
     ctx->hiz_level1_virtual = width % 64 == 0 && height % 64 == 0 && mips > 6 && getenv("GV_DEBUG_STORE_HIZ_LEVEL1") == nullptr;
-    GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>(off, 1)));
+    // (RG16F texels are half the size: the same buffer type, half the elements)
+    GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>((ctx->config.flags & GV_CONFIG_HIZ_RG16F) ? (off + 1) / 2 : off, 1)));
     GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_mip_offset.ptr, ctx->mip_off, sizeof(uint64_t) * GV_MAX_MIPS, hipMemcpyHostToDevice, ctx->stream));
     if (mem_kind == GV_MEM_DEVICE) {
@@ -1285,12 +1380,25 @@ int gv_hiz_read_level(GvCtx* ctx, uint32_t level, float* out_pairs, uint32_t* w,
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)ctx->mip_w[level] * ctx->mip_h[level];
     if (level == 1 && ctx->hiz_level1_virtual && !ctx->hiz_level1_stored) {  // on demand: one generic level pass
-        GV_HIP(ctx, launch_hiz_level(ctx->depth_ptr, nullptr, ctx->d_mips.ptr + ctx->mip_off[1], ctx->mip_w[0], ctx->mip_h[0],
-                                     ctx->mip_w[1], ctx->mip_h[1], ctx->config.hiz_rule, ctx->stream));
+        GV_HIP(ctx, launch_hiz_level(ctx->depth_ptr, nullptr, mip_ptr(ctx, 1), ctx->mip_w[0], ctx->mip_h[0], ctx->mip_w[1], ctx->mip_h[1],
+                                     ctx->config.hiz_rule, (ctx->config.flags & GV_CONFIG_HIZ_RG16F) != 0, ctx->stream));
         ctx->hiz_level1_stored = true;
     }
-    GV_HIP(ctx, hipMemcpyAsync(out_pairs, ctx->d_mips.ptr + ctx->mip_off[level], n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->config.flags & GV_CONFIG_HIZ_RG16F) {
+        // the texels arrive packed in the upper half of the caller's buffer and are widened in place, front to back
+        // (binary16 -> binary32 is exact): out_pairs holds the values the RG16F image holds
+        uint32_t* packed = reinterpret_cast<uint32_t*>(out_pairs) + n;
+        GV_HIP(ctx, hipMemcpyAsync(packed, mip_ptr(ctx, level), n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t t = packed[i];  // read before out_pairs[2i + 1] can reach it (2i + 1 <= n + i)
+            out_pairs[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(t & 0xFFFFu));
+            out_pairs[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(t >> 16));
+        }
+    } else {
+        GV_HIP(ctx, hipMemcpyAsync(out_pairs, ctx->d_mips.ptr + ctx->mip_off[level], n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     drain_events(ctx);
     if (w)
         *w = ctx->mip_w[level];

@@ -166,6 +166,7 @@ struct TransformBinding {
 
 struct PoolState {
     Column entity, is_enabled, aabb_min, aabb_max;
+    RecordLayout record_layout{};  // gv_pool_set_record_layout (stride 0: none)
     Column ready;              // gv_pool_bind_ready: per-slot ready count (ptr NULL: none, every slot counts 1)
     uint32_t ready_width = 0;  // 1 or 4 bytes
     uint32_t ready_count(size_t i) const { return !ready.ptr ? 1u : (ready_width == 4 ? ready.u32(i) : (uint32_t)ready.u8(i)); }
@@ -212,6 +213,9 @@ struct ViewState {
     PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
     PinnedBuf<float> h_baked_model, h_distance_sq;
     PinnedBuf<uint8_t> h_is_visible;
+    PinnedBuf<uint8_t> h_records;    // results in the pool's record layout (gv_pool_results_records)
+    DeviceBuf<uint8_t> d_records;    // ... packed on the device first for pools too large to publish directly
+    bool records_fetched = false;    // h_records holds this cull's records
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;
     // fused cull + emit (launch_cull_emit): look-back words, ticket counter and their running epoch / base

@@ -1143,14 +1143,70 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
 // launch (blockIdx.y = view) — the count, the records [0, count) and (main pass) the isVisible bytes — so gv_results_fetch is one launch and one
 // stream synchronisation instead of a count read-back, four copies and a second synchronisation. 16-byte stores:
 // consecutive lanes fill whole PCIe write bursts.
-__global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
+// Records [first, first + 64) of a view in the caller's struct layout (GvRecordLayout): built in LDS by the first 64 lanes,
+// written out by the whole workgroup as contiguous 16-byte pieces (whole PCIe bursts when dst is host memory).
+__device__ __forceinline__ void pack_records_chunk(uint4* stage, const uint32_t* __restrict__ idx, const float* __restrict__ model,
+                                                   const float* __restrict__ dist, const RecordLayout& L, uint32_t first, uint32_t n,
+                                                   uint8_t* __restrict__ dst)
 {
-    const PublishArgs& a = batch.view[blockIdx.y];
+    const uint32_t live = min(64u, n - first), quads = L.stride >> 4;
+    for (uint32_t q = threadIdx.x; q < live * quads; q += 256)
+        stage[q] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (threadIdx.x < live) {
+        const uint32_t j = first + threadIdx.x;
+        uint8_t* rec = reinterpret_cast<uint8_t*>(stage) + threadIdx.x * L.stride;
+        const unsigned long long offset = (unsigned long long)idx[j] * L.component_stride;  // componentOffset  mesh.cpp:170
+        uint32_t* w = reinterpret_cast<uint32_t*>(rec + L.component_offset);
+        w[0] = (uint32_t)offset;
+        w[1] = (uint32_t)(offset >> 32);
+        float* bm = reinterpret_cast<float*>(rec + L.baked_model);
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            bm[k] = model[(size_t)j * 12 + k];
+        *reinterpret_cast<float*>(rec + L.distance_sq) = dist[j];
+        if (L.buffer_index != 0xFFFFFFFFu)
+            *reinterpret_cast<uint32_t*>(rec + L.buffer_index) = L.buffer_index_value;
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(dst + (size_t)first * L.stride);
+    for (uint32_t q = threadIdx.x; q < live * quads; q += 256)
+        out[q] = stage[q];
+    __syncthreads();  // the stage is reused by the next chunk
+}
+
+__global__ __launch_bounds__(256) void pack_records_kernel(const uint32_t* __restrict__ count, const uint32_t* __restrict__ idx,
+                                                           const float* __restrict__ model, const float* __restrict__ dist,
+                                                           const RecordLayout L, uint32_t capacity, uint8_t* __restrict__ dst)
+{
+    __shared__ uint4 stage[64 * kMaxRecordStride / 16];
+    const uint32_t n = min(*count, capacity);
+    for (uint32_t first = blockIdx.x * 64; first < n; first += gridDim.x * 64)  // workgroup-uniform
+        pack_records_chunk(stage, idx, model, dist, L, first, n, dst);
+}
+
+hipError_t launch_pack_records(const uint32_t* count, const uint32_t* idx, const float* model, const float* dist, const RecordLayout& layout,
+                               uint32_t capacity, uint8_t* dst, hipStream_t stream)
+{
+    if (capacity == 0)
+        return hipSuccess;
+    const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 63u) / 64u));
+    hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, stream, count, idx, model, dist, layout, capacity, dst);
+    return hipGetLastError();
+}
+
+// One view's results into its pinned host buffers; `block` of `nblocks` workgroups share the copies.
+__device__ __forceinline__ void publish_block(const PublishArgs& a, const uint32_t block, const uint32_t nblocks)
+{
     const uint32_t n = *a.count;
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, threads = gridDim.x * 256;
+    const uint32_t tid = block * 256 + threadIdx.x, threads = nblocks * 256;
     if (tid == 0)
         *a.host_count = n;
-    if (a.host_idx) {
+    if (a.host_records) {  // the caller's own record structs instead of the three arrays
+        __shared__ uint4 stage[64 * kMaxRecordStride / 16];
+        for (uint32_t first = block * 64; first < n; first += nblocks * 64)  // workgroup-uniform
+            pack_records_chunk(stage, a.idx, a.model, a.dist, a.layout, first, n, a.host_records);
+    } else if (a.host_idx) {
         for (uint32_t j = tid; j < n; j += threads) {
             a.host_idx[j] = a.idx[j];
             a.host_dist[j] = a.dist[j];
@@ -1163,7 +1219,7 @@ __global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
     if (a.host_is_visible && a.orig) {
         // spatially ordered mirror: workgroup 0 puts the bytes back into pool-slot order in LDS (the pool is at most
         // kPublishMaxSlots bytes) and writes them out as whole words — no scattered single-byte stores over PCIe
-        if (blockIdx.x != 0)
+        if (block != 0)
             return;
         __shared__ uint8_t slots[(kPublishLdsSlots + 3u) & ~3u];
         for (uint32_t j = threadIdx.x; j < a.occupancy; j += 256)
@@ -1185,6 +1241,11 @@ __global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
         for (uint32_t j = (words << 2) + tid; j < a.occupancy; j += threads)
             a.host_is_visible[j] = a.is_visible[j];
     }
+}
+
+__global__ __launch_bounds__(256) void publish_kernel(const PublishBatch batch)
+{
+    publish_block(batch.view[blockIdx.y], blockIdx.x, gridDim.x);
 }
 // isVisible bytes of a spatially ordered mirror back into pool-slot order (dst[orig[j]] = src[j]) on the device, where a
 // random byte scatter is cheap; the host then only streams them into the components

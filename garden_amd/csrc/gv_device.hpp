@@ -106,9 +106,18 @@ __device__ __forceinline__ float hiz_min_texel(const HizDevice& hz, uint32_t lev
         m = a.y < m ? a.y : m;
         m = b.x < m ? b.x : m;
         m = b.y < m ? b.y : m;
-        return m;
+        return hz.rg16f ? half_to_float(half_directed(m, false)) : m;  // what the stored texel would hold
     }
-    return hz.mips[hz.mip_offset[level] + (uint64_t)y * lw + x].x;
+    const uint64_t at = hz.mip_offset[level] + (uint64_t)y * lw + x;
+    if (hz.rg16f)  // uniform
+        return half_to_float(reinterpret_cast<const uint32_t*>(hz.mips)[at] & 0xFFFFu);
+    return hz.mips[at].x;
+}
+__device__ __forceinline__ float2 hiz_pair(const HizDevice& hz, uint64_t at)
+{
+    if (hz.rg16f)  // uniform
+        return unpack_rg16f(reinterpret_cast<const uint32_t*>(hz.mips)[at]);
+    return hz.mips[at];
 }
 
 __device__ __forceinline__ float clamp01(float a)
@@ -181,20 +190,20 @@ __device__ __forceinline__ bool hiz_occluded(const HizDevice& hz, const float (&
         const int cw = max((int)(hz.width >> cl), 1), ch = max((int)(hz.height >> cl), 1);
         const int cx0 = min(ix0 >> cl, cw - 1), cx1 = min(ix1 >> cl, cw - 1);
         const int cy0 = min(iy0 >> cl, ch - 1), cy1 = min(iy1 >> cl, ch - 1);
-        const float2* coarse = hz.mips + hz.mip_offset[cl];
-        float2 t = coarse[(uint64_t)cy0 * cw + cx0];
+        const uint64_t coarse = hz.mip_offset[cl];
+        float2 t = hiz_pair(hz, coarse + (uint64_t)cy0 * cw + cx0);
         float cmin = t.x, cmax = t.y;
         if (cx1 != cx0) {
-            t = coarse[(uint64_t)cy0 * cw + cx1];
+            t = hiz_pair(hz, coarse + (uint64_t)cy0 * cw + cx1);
             cmin = fminf(cmin, t.x);
             cmax = fmaxf(cmax, t.y);
         }
         if (cy1 != cy0) {
-            t = coarse[(uint64_t)cy1 * cw + cx0];
+            t = hiz_pair(hz, coarse + (uint64_t)cy1 * cw + cx0);
             cmin = fminf(cmin, t.x);
             cmax = fmaxf(cmax, t.y);
             if (cx1 != cx0) {
-                t = coarse[(uint64_t)cy1 * cw + cx1];
+                t = hiz_pair(hz, coarse + (uint64_t)cy1 * cw + cx1);
                 cmin = fminf(cmin, t.x);
                 cmax = fmaxf(cmax, t.y);
             }

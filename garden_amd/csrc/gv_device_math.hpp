@@ -145,4 +145,38 @@ __device__ __forceinline__ bool all_behind_plane(const Corners& c, float nx, flo
     return m < 0.0f;
 }
 
+// RG16F pyramid texels (GV_CONFIG_HIZ_RG16F; HizRenderSystem::bufferFormat, render/hiz.hpp:41): binary16 with the min rounded
+// toward -inf and the max toward +inf, so a stored pair still bounds every depth it covers. Same function as the oracle's
+// gvo_half_directed (checked against every binary16 value; tests/test_gpu_cull.py compares the two on every half and its
+// float neighbours). NaN stays NaN (quiet), +-0 keep their sign, overflow goes to +-inf or +-65504 by direction.
+__device__ __forceinline__ uint32_t half_directed(float f, bool up)
+{
+    // nearest-even by the hardware conversion (v_cvt_f16_f32; subnormal halfs included), then one step in the wanted
+    // direction when nearest went the other way. A step is +-1 on the encoding: away from zero when the direction grows the
+    // magnitude (0x7BFF + 1 = inf), toward zero otherwise (inf - 1 = 65504; -0 steps to the smallest negative half).
+    const uint32_t sign = __float_as_uint(f) >> 31;
+    if (f != f)
+        return (sign << 15) | 0x7E00u;
+    uint32_t h = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);
+    const float back = (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+    const bool grow = up != (sign != 0u);
+    if (up ? back < f : back > f)
+        h = grow ? h + 1u : h - 1u;
+    return h;
+}
+// exact (binary16 is a subset of binary32; subnormals included: v_cvt_f32_f16 with the kernels' default denormal mode)
+__device__ __forceinline__ float half_to_float(uint32_t half_bits)
+{
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)half_bits);
+}
+// (min, max) -> one RG16F texel (min in the low half) and back
+__device__ __forceinline__ uint32_t pack_rg16f(float2 mm)
+{
+    return half_directed(mm.x, false) | (half_directed(mm.y, true) << 16);
+}
+__device__ __forceinline__ float2 unpack_rg16f(uint32_t texel)
+{
+    return make_float2(half_to_float(texel & 0xFFFFu), half_to_float(texel >> 16));
+}
+
 }  // namespace gv

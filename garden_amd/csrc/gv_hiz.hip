@@ -7,13 +7,26 @@ namespace gv {
 // ------------------------------------------------------------------------------------------------
 // Hi-Z pyramid
 // ------------------------------------------------------------------------------------------------
+// F16: the pyramid is an RG16F image (GV_CONFIG_HIZ_RG16F): pairs are packed binary16, written with the min rounded toward
+// -inf and the max toward +inf. Only a reduction of the fp32 depth image rounds; halfs reduce to halfs.
+template <bool F16>
 __device__ __forceinline__ float2 hiz_src(const float* d, const float2* p, uint32_t sw, uint32_t x, uint32_t y)
 {
     if (d) {  // HIZ_VARIANT_FIRST: (d, d)  hiz.frag:57-60
         const float v = d[(size_t)y * sw + x];
         return make_float2(v, v);
     }
+    if (F16)
+        return unpack_rg16f(reinterpret_cast<const uint32_t*>(p)[(size_t)y * sw + x]);
     return p[(size_t)y * sw + x];
+}
+template <bool F16>
+__device__ __forceinline__ void hiz_store(float2* level, size_t at, float2 mm)
+{
+    if (F16)
+        reinterpret_cast<uint32_t*>(level)[at] = pack_rg16f(mm);
+    else
+        level[at] = mm;
 }
 __device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
 {
@@ -22,6 +35,7 @@ __device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
 }
 
 // One destination texel per lane; any size (hiz.frag:27-56 with the odd-size branches).
+template <bool F16>
 __global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict__ src_depth,
                                                         const float2* __restrict__ src_pairs,
                                                         float2* __restrict__ dst, uint32_t sw, uint32_t sh, uint32_t dw,
@@ -35,36 +49,39 @@ __global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict_
     const uint32_t x0 = 2 * px, y0 = 2 * py;
     const uint32_t x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
     const uint32_t x2 = min(x0 + 2, sw - 1), y2 = min(y0 + 2, sh - 1);
-    float2 mm = hiz_src(src_depth, src_pairs, sw, x0, y0);
-    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y0));
-    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y1));
-    hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y1));
+    float2 mm = hiz_src<F16>(src_depth, src_pairs, sw, x0, y0);
+    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y0));
+    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x0, y1));
+    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y1));
     if (odd_x) {  // hiz.frag:36-41
-        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y1));
-        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y0));
+        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y1));
+        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y0));
         if (odd_y)  // hiz.frag:43-47
-            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x2, y2));
+            hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y2));
     }
     if (odd_y) {  // hiz.frag:49-55 reads gather components .y/.z = (2p.x+1, 2p.y+2), (2p.x+1, 2p.y+1)
-        hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x1, y2));
+        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y2));
         if (rule == 1u)  // GV_HIZ_RULE_CONSERVATIVE: the whole extra row
-            hiz_acc(mm, hiz_src(src_depth, src_pairs, sw, x0, y2));
+            hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x0, y2));
     }
-    dst[(size_t)py * dw + px] = mm;
+    hiz_store<F16>(dst, (size_t)py * dw + px, mm);
 }
 
 hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
-                            uint32_t dw, uint32_t dh, uint32_t rule, hipStream_t stream)
+                            uint32_t dw, uint32_t dh, uint32_t rule, bool rg16f, hipStream_t stream)
 {
-    hipLaunchKernelGGL(hiz_level_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, stream, src_depth, src_pairs,
-                       dst, sw, sh, dw, dh, rule);
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    if (rg16f)
+        hipLaunchKernelGGL(hiz_level_kernel<true>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh, dw, dh, rule);
+    else
+        hipLaunchKernelGGL(hiz_level_kernel<false>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh, dw, dh, rule);
     return hipGetLastError();
 }
 
 // Fused: one workgroup reduces a 64x64 source tile to 32^2, 16^2, 8^2, 4^2, 2^2 and 1 texel — six
 // levels in one pass, the source read once, intermediate levels staged in LDS instead of re-read
 // from HBM (the reference re-reads every mip in its own render pass, hiz.cpp:155-164).
-template <bool PAIRS>
+template <bool PAIRS, bool F16>
 __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict__ src_depth,
                                                         const float2* __restrict__ src_pairs, const HizFusedDst dst,
                                                         uint32_t sw, uint32_t sh)
@@ -79,7 +96,12 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
     float mn[4][4], mx[4][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (PAIRS) {
+        if (PAIRS && F16) {
+            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src_pairs) + (size_t)(py + r) * sw + px);
+            const float2 t0 = unpack_rg16f(t.x), t1 = unpack_rg16f(t.y), t2 = unpack_rg16f(t.z), t3 = unpack_rg16f(t.w);
+            mn[r][0] = t0.x; mx[r][0] = t0.y; mn[r][1] = t1.x; mx[r][1] = t1.y;
+            mn[r][2] = t2.x; mx[r][2] = t2.y; mn[r][3] = t3.x; mx[r][3] = t3.y;
+        } else if (PAIRS) {
             const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
             const float4 lo = row[0], hi = row[1];
             mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
@@ -100,14 +122,19 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
             hiz_acc(mm, make_float2(mn[2 * a][2 * b + 1], mx[2 * a][2 * b + 1]));
             hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b], mx[2 * a + 1][2 * b]));
             hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b + 1], mx[2 * a + 1][2 * b + 1]));
+            if (F16 && !PAIRS)  // the one place a value leaves fp32: from here on every level reduces representable halfs
+                mm = unpack_rg16f(pack_rg16f(mm));
             q[a][b] = mm;
         }
     const uint32_t w1 = sw >> 1;
     if (dst.level[0]) {  // null: the level stays virtual (queries reduce the source themselves)
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            float4* o = reinterpret_cast<float4*>(dst.level[0] + (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx);
-            *o = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
+            const size_t at = (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx;
+            if (F16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(dst.level[0]) + at) = make_uint2(pack_rg16f(q[a][0]), pack_rg16f(q[a][1]));
+            else
+                *reinterpret_cast<float4*>(dst.level[0] + at) = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
         }
     }
     // level +2: one texel per lane
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
     hiz_acc(m2, q[0][1]);
     hiz_acc(m2, q[1][0]);
     hiz_acc(m2, q[1][1]);
-    dst.level[1][(size_t)(oy / 4 + ty) * (sw >> 2) + ox / 4 + tx] = m2;
+    hiz_store<F16>(dst.level[1], (size_t)(oy / 4 + ty) * (sw >> 2) + ox / 4 + tx, m2);
     lds16[ty][tx] = m2;
     __syncthreads();
     if (threadIdx.x < 64) {  // level +3: 8x8
@@ -124,7 +151,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
         hiz_acc(mm, lds16[2 * y][2 * x + 1]);
         hiz_acc(mm, lds16[2 * y + 1][2 * x]);
         hiz_acc(mm, lds16[2 * y + 1][2 * x + 1]);
-        dst.level[2][(size_t)(oy / 8 + y) * (sw >> 3) + ox / 8 + x] = mm;
+        hiz_store<F16>(dst.level[2], (size_t)(oy / 8 + y) * (sw >> 3) + ox / 8 + x, mm);
         lds8[y][x] = mm;
     }
     __syncthreads();
@@ -134,7 +161,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
         hiz_acc(mm, lds8[2 * y][2 * x + 1]);
         hiz_acc(mm, lds8[2 * y + 1][2 * x]);
         hiz_acc(mm, lds8[2 * y + 1][2 * x + 1]);
-        dst.level[3][(size_t)(oy / 16 + y) * (sw >> 4) + ox / 16 + x] = mm;
+        hiz_store<F16>(dst.level[3], (size_t)(oy / 16 + y) * (sw >> 4) + ox / 16 + x, mm);
         lds4[y][x] = mm;
     }
     __syncthreads();
@@ -144,7 +171,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
         hiz_acc(mm, lds4[2 * y][2 * x + 1]);
         hiz_acc(mm, lds4[2 * y + 1][2 * x]);
         hiz_acc(mm, lds4[2 * y + 1][2 * x + 1]);
-        dst.level[4][(size_t)(oy / 32 + y) * (sw >> 5) + ox / 32 + x] = mm;
+        hiz_store<F16>(dst.level[4], (size_t)(oy / 32 + y) * (sw >> 5) + ox / 32 + x, mm);
         lds2[y][x] = mm;
     }
     __syncthreads();
@@ -153,19 +180,23 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
         hiz_acc(mm, lds2[0][1]);
         hiz_acc(mm, lds2[1][0]);
         hiz_acc(mm, lds2[1][1]);
-        dst.level[5][(size_t)(oy / 64) * (sw >> 6) + ox / 64] = mm;
+        hiz_store<F16>(dst.level[5], (size_t)(oy / 64) * (sw >> 6) + ox / 64, mm);
     }
     (void)sh;
 }
 
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
-                            uint32_t sh, hipStream_t stream)
+                            uint32_t sh, bool rg16f, hipStream_t stream)
 {
     const dim3 grid(sw / 64, sh / 64);
-    if (src_depth)
-        hipLaunchKernelGGL(hiz_fused_kernel<false>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    if (src_depth && rg16f)
+        hipLaunchKernelGGL((hiz_fused_kernel<false, true>), grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    else if (src_depth)
+        hipLaunchKernelGGL((hiz_fused_kernel<false, false>), grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+    else if (rg16f)
+        hipLaunchKernelGGL((hiz_fused_kernel<true, true>), grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
     else
-        hipLaunchKernelGGL(hiz_fused_kernel<true>, grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
+        hipLaunchKernelGGL((hiz_fused_kernel<true, false>), grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);
     return hipGetLastError();
 }
 

@@ -50,10 +50,11 @@ struct MeshMirror {
 
 struct HizDevice {
     const float* depth;          // mip 0
-    const float2* mips;          // levels >= 1, (min,max)
-    const uint64_t* mip_offset;  // device array [GV_MAX_MIPS], in float2 elements
+    const float2* mips;          // levels >= 1, (min,max); rg16f: the same texels as packed binary16 pairs (uint32_t each)
+    const uint64_t* mip_offset;  // device array [GV_MAX_MIPS], in texels
     uint32_t width, height, mip_count;
     uint32_t level1_virtual;  // level 1 is not stored (even sizes, fused build): a query derives its texels from the depth
+    uint32_t rg16f;   // GV_CONFIG_HIZ_RG16F: texels are RG16F, min rounded toward -inf / max toward +inf (level 0 stays the depth)
     uint32_t nested;  // every level's min bounds ALL texels it covers (even sizes all the way, or the conservative rule):
                       // a coarser level may then prove occlusion early (exact shortcut, see hiz_occluded)
 };
@@ -147,6 +148,11 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
 constexpr uint32_t kPublishMaxSlots = 262144;
 constexpr uint32_t kPublishLdsSlots = 16384;
+// the caller's record struct (GvRecordLayout); stride == 0: none
+struct RecordLayout {
+    uint32_t stride, component_offset, baked_model, distance_sq, buffer_index, component_stride, buffer_index_value;
+};
+constexpr uint32_t kMaxRecordStride = 128;
 struct PublishArgs {
     const uint32_t* count;  // device draw_count
     const uint32_t* idx;
@@ -160,12 +166,17 @@ struct PublishArgs {
     float* host_dist;
     uint8_t* host_is_visible;   // pool-slot order; NULL: not the main pass
     uint32_t occupancy;
+    uint8_t* host_records;      // records in the caller's struct layout instead of host_idx / host_model / host_dist (or NULL)
+    RecordLayout layout;
 };
 constexpr uint32_t kMaxPublishViews = 32;  // views of SEVERAL pools per launch (>= GV_MAX_VIEWS, checked in gv_context.cpp)
 struct PublishBatch {
     PublishArgs view[kMaxPublishViews];  // blockIdx.y
 };
 hipError_t launch_publish(const PublishBatch& batch, uint32_t views, uint32_t occupancy, hipStream_t stream);
+// records [0, *count) of a view as an array of the caller's structs (device or device-visible host memory)
+hipError_t launch_pack_records(const uint32_t* count, const uint32_t* idx, const float* model, const float* dist, const RecordLayout& layout,
+                               uint32_t capacity, uint8_t* dst, hipStream_t stream);
 hipError_t launch_unpermute_bytes(const uint8_t* src, const uint32_t* orig, uint32_t count, uint8_t* dst, hipStream_t stream);
 
 // sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
@@ -236,14 +247,15 @@ hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, 
 
 // Hi-Z pyramid. Level k >= 1 lives at mips + mip_offset[k]; level 0 is the depth image.
 // Generic one-level reduction (any size, shaders/hiz.frag:27-56 incl. the odd-size branches).
+// rg16f: src_pairs / dst (and HizFusedDst::level) point to packed binary16 pairs, 4 bytes per texel
 hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
-                            uint32_t dw, uint32_t dh, uint32_t rule, hipStream_t stream);
+                            uint32_t dw, uint32_t dh, uint32_t rule, bool rg16f, hipStream_t stream);
 // Fused 6-level reduction of 64x64 source tiles through LDS; needs sw % 64 == 0 && sh % 64 == 0.
 // dst[l] = level (src+1+l), l = 0..5.
 struct HizFusedDst {
     float2* level[6];
 };
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
-                            uint32_t sh, hipStream_t stream);
+                            uint32_t sh, bool rg16f, hipStream_t stream);
 
 }  // namespace gv

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <algorithm>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,8 @@ public:
     };
 
     bool isEnabled = true;
+    // true: records arrive as UnsortedMesh / SortedMesh structs (gv_pool_set_record_layout), combinedMeshes is one memcpy
+    bool recordStructs = true;
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
@@ -194,6 +197,40 @@ private:
         return v;
     }
 
+    // The engine's record structs as the library's GvRecordLayout: results then arrive as arrays of UnsortedMesh /
+    // SortedMesh and combinedMeshes is one memcpy. A struct the library cannot express (stride not a multiple of 16, or
+    // larger than 128 bytes) keeps the three-array fetch.
+    template <class Mesh>
+    static bool recordLayoutOf(GvRecordLayout& layout, size_t componentSize, uint32_t bufferIndexField, uint32_t bufferIndex)
+    {
+        static_assert(std::is_trivially_copyable<Mesh>::value, "records are copied bytewise");
+        static_assert(sizeof(((Mesh*)nullptr)->componentOffset) == 8 && sizeof(((Mesh*)nullptr)->bakedModel) == 48, "field sizes");
+        layout = GvRecordLayout{(uint32_t)sizeof(Mesh), (uint32_t)offsetof(Mesh, componentOffset), (uint32_t)offsetof(Mesh, bakedModel),
+                                (uint32_t)offsetof(Mesh, distanceSq), bufferIndexField, (uint32_t)componentSize, bufferIndex};
+        return sizeof(Mesh) % 16 == 0 && sizeof(Mesh) <= 128;
+    }
+
+    // the fetched records of (pool, view) into meshes[0, count): one copy when the pool has a record layout
+    template <class Mesh>
+    void copyRecords(Mesh* meshes, const GvResult& r, IMeshRenderSystem* meshSystem, uint32_t pool, uint32_t viewIndex, uint32_t bufferIndex)
+    {
+        if (r.draw_count && !r.visible_idx) {
+            const void* records = nullptr;
+            uint32_t count = 0;
+            check(gv_pool_results_records(ctx, pool, viewIndex, &records, &count), "gv_pool_results_records");
+            memcpy(static_cast<void*>(meshes), records, (size_t)count * sizeof(Mesh));
+            return;
+        }
+        const size_t componentSize = meshSystem->getMeshComponentSize();
+        for (uint32_t k = 0; k < r.draw_count; k++) {
+            meshes[k].componentOffset = (size_t)r.visible_idx[k] * componentSize;  // mesh.cpp:170 / :247
+            memcpy(meshes[k].bakedModel.m, r.baked_model + (size_t)k * 12, 48);     // mesh.cpp:171 / :248
+            meshes[k].distanceSq = r.distance_sq[k];                                // mesh.cpp:172 / :249-251
+            if constexpr (std::is_same<Mesh, SortedMesh>::value)
+                meshes[k].bufferIndex = bufferIndex;                                // mesh.cpp:252
+        }
+    }
+
     void fill(UnsortedBuffer* buffer, IMeshRenderSystem* meshSystem, uint32_t pool, uint32_t viewIndex, bool writeBack)
     {
         GvResult r{};
@@ -209,13 +246,7 @@ private:
             return;
         if (buffer->combinedMeshes.size() < r.draw_count)
             buffer->combinedMeshes.resize(r.draw_count);  // grown, never shrunk (mesh.cpp:377-395)
-        const size_t componentSize = meshSystem->getMeshComponentSize();
-        auto meshes = buffer->combinedMeshes.data();
-        for (uint32_t k = 0; k < r.draw_count; k++) {
-            meshes[k].componentOffset = (size_t)r.visible_idx[k] * componentSize;  // mesh.cpp:170
-            memcpy(meshes[k].bakedModel.m, r.baked_model + (size_t)k * 12, 48);     // mesh.cpp:171
-            meshes[k].distanceSq = r.distance_sq[k];                                // mesh.cpp:172
-        }
+        copyRecords(buffer->combinedMeshes.data(), r, meshSystem, pool, viewIndex, 0);
     }
 
     // prepareSortedMeshes' tail (mesh.cpp:246-261): this system's records go behind the ones already in the shared
@@ -238,14 +269,7 @@ private:
             return 0;
         if (combined.size() < (size_t)drawIndex + r.draw_count)
             combined.resize((size_t)drawIndex + r.draw_count);
-        const size_t componentSize = meshSystem->getMeshComponentSize();
-        auto meshes = combined.data() + drawIndex;
-        for (uint32_t k = 0; k < r.draw_count; k++) {
-            meshes[k].componentOffset = (size_t)r.visible_idx[k] * componentSize;  // mesh.cpp:247
-            memcpy(meshes[k].bakedModel.m, r.baked_model + (size_t)k * 12, 48);     // mesh.cpp:248
-            meshes[k].distanceSq = r.distance_sq[k];                                // mesh.cpp:249-251
-            meshes[k].bufferIndex = bufferIndex;                                    // mesh.cpp:252
-        }
+        copyRecords(combined.data() + drawIndex, r, meshSystem, pool, viewIndex, bufferIndex);
         drawIndex += r.draw_count;
         return r.draw_count;
     }
@@ -322,12 +346,23 @@ private:
         // per (pool, view), so the device works through the systems back to back while the host only enqueues; the
         // reference dispatches every system's tasks to its thread pool and waits once, too (mesh.cpp:408-546, :548).
         std::vector<uint32_t> viewCounts(meshSystems.size(), 0);
+        uint32_t sortedSeen = 0;
         check(gv_cull_batch_begin(ctx), "gv_cull_batch_begin");  // engine-sized pools: one cull / emit / sort / publish launch per tick
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
             check(gv_pool_bind(ctx, p, meshSystem->getMeshComponentData(), meshSystem->getMeshComponentSize(),
                                meshSystem->getMeshComponentOccupancy(), &meshLayout), "gv_pool_bind");
+            {
+                GvRecordLayout layout;
+                const bool sorted = isSortedType(renderType);
+                const bool expressible = sorted
+                    ? recordLayoutOf<SortedMesh>(layout, meshSystem->getMeshComponentSize(), (uint32_t)offsetof(SortedMesh, bufferIndex), sortedSeen)
+                    : recordLayoutOf<UnsortedMesh>(layout, meshSystem->getMeshComponentSize(), GV_NONE, 0);
+                sortedSeen += sorted ? 1 : 0;  // == the bufferIndex phase 2 gives this system
+                check(gv_pool_set_record_layout(ctx, p, emitRecords && recordStructs && expressible ? &layout : nullptr),
+                      "gv_pool_set_record_layout");
+            }
             if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem)) {
                 if (seenMesh[p] != versioned->meshVersion) {
                     check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");

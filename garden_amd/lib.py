@@ -22,6 +22,7 @@ GV_CONFIG_PROFILE_EVENTS = 1
 GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_CONFIG_KEEP_SLOT_ORDER = 4
 GV_CONFIG_BLOCK_BOUNDS = 8
+GV_CONFIG_HIZ_RG16F = 16
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU, GV_SWEEP_INCREMENTAL = 0, 1, 2, 3, 4
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
@@ -52,6 +53,11 @@ class GvResult(C.Structure):
     _fields_ = [("visible_idx", C.POINTER(C.c_uint32)), ("baked_model", C.POINTER(C.c_float)),
                 ("distance_sq", C.POINTER(C.c_float)), ("is_visible", C.POINTER(C.c_uint8)),
                 ("draw_count", C.c_uint32), ("instance_count", C.c_uint32)]
+
+
+class GvRecordLayout(C.Structure):
+    _fields_ = [("stride", C.c_uint32), ("component_offset", C.c_uint32), ("baked_model", C.c_uint32), ("distance_sq", C.c_uint32),
+                ("buffer_index", C.c_uint32), ("component_stride", C.c_uint32), ("buffer_index_value", C.c_uint32)]
 
 
 class GvDeviceResult(C.Structure):
@@ -107,7 +113,7 @@ EXPORTS = [
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
-    "gv_cull_batch_begin", "gv_cull_batch_end",
+    "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records",
 ]
 
 _lib = None
@@ -185,6 +191,8 @@ def load():
     lib.gv_pool_result_count.argtypes = [P, u32, u32, C.POINTER(u32)]
     lib.gv_pool_results_device.argtypes = [P, u32, u32, C.POINTER(GvDeviceResult)]
     lib.gv_pool_sort.argtypes = [P, u32, u32, C.c_int]
+    lib.gv_pool_set_record_layout.argtypes = [P, u32, C.POINTER(GvRecordLayout)]
+    lib.gv_pool_results_records.argtypes = [P, u32, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]
     lib.gv_cull_batch_begin.argtypes = [P]
     lib.gv_cull_batch_end.argtypes = [P]
     for name in EXPORTS:
@@ -211,7 +219,7 @@ class GpuVisibility:
     """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
 
     def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False,
-                 keep_slot_order=False, block_bounds=False):
+                 keep_slot_order=False, block_bounds=False, hiz_rg16f=False):
         self.lib = load()
         flags = GV_CONFIG_PROFILE_EVENTS if (profile_events or profile_cull_only) else 0
         if profile_cull_only:
@@ -220,6 +228,8 @@ class GpuVisibility:
             flags |= GV_CONFIG_KEEP_SLOT_ORDER
         if block_bounds:
             flags |= GV_CONFIG_BLOCK_BOUNDS
+        if hiz_rg16f:
+            flags |= GV_CONFIG_HIZ_RG16F
         cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, flags)
         self.ctx = C.c_void_p()
         rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))
@@ -359,6 +369,28 @@ class GpuVisibility:
         if r.is_visible and occupancy:
             out["is_visible"] = np.ctypeslib.as_array(r.is_visible, shape=(occupancy,)).copy()
         return out
+
+    def set_record_layout(self, pool_id, dtype=None, component_stride=1, buffer_index_value=0):
+        """Deliver pool `pool_id`'s records as an array of structs described by the numpy structured `dtype` with fields
+        componentOffset (u8), bakedModel (12 x f4), distanceSq (f4) and optionally bufferIndex (u4); None removes it."""
+        if dtype is None:
+            self._check(self.lib.gv_pool_set_record_layout(self.ctx, pool_id, None))
+            return
+        dtype = np.dtype(dtype)
+        at = {name: dtype.fields[name][1] for name in dtype.names}
+        layout = GvRecordLayout(dtype.itemsize, at["componentOffset"], at["bakedModel"], at["distanceSq"],
+                                at.get("bufferIndex", 0xFFFFFFFF), component_stride, buffer_index_value)
+        self._check(self.lib.gv_pool_set_record_layout(self.ctx, pool_id, C.byref(layout)))
+
+    def records(self, pool_id, view_index, dtype):
+        """The fetched records of (pool, view) as a copy of the library's struct array, viewed as `dtype`."""
+        ptr, n = C.c_void_p(), C.c_uint32()
+        self._check(self.lib.gv_pool_results_records(self.ctx, pool_id, view_index, C.byref(ptr), C.byref(n)))
+        dtype = np.dtype(dtype)
+        if n.value == 0:
+            return np.zeros(0, dtype)
+        raw = (C.c_uint8 * (n.value * dtype.itemsize)).from_address(ptr.value)
+        return np.frombuffer(raw, dtype=np.uint8).copy().view(dtype)  # bytewise: a structured copy would skip the padding
 
     def results_device(self, view_index=0):
         d = GvDeviceResult()

@@ -60,12 +60,19 @@ typedef enum GvConfigFlags {
                                              spatially (Morton code of the root ancestor's position) at every full
                                              rebuild so that neighbouring lanes touch neighbouring Hi-Z texels; all
                                              outputs are reported in pool slots either way */
-    GV_CONFIG_BLOCK_BOUNDS = 1u << 3      /* keep a world-space box per 256-entry cull workgroup (built on the device
+    GV_CONFIG_BLOCK_BOUNDS = 1u << 3,     /* keep a world-space box per 256-entry cull workgroup (built on the device
                                              while the pool's mirror is clean) and let a workgroup whose box lies behind
                                              a frustum plane by more than the rounding margin skip its streams. Same
                                              results bit for bit (the test is conservative w.r.t. the per-entity one);
                                              pools that change every frame are culled without boxes. Pays off with the
                                              default spatial mirror order. Batched views skip a workgroup when every view does */
+    GV_CONFIG_HIZ_RG16F = 1u << 4         /* keep the pyramid in the reference's image format (HizRenderSystem::bufferFormat =
+                                             SfloatR16G16, render/hiz.hpp:41): levels >= 1 are binary16 (min, max) pairs, half the
+                                             bytes. The reference lets the render target round to nearest, which can move a min
+                                             up or a max down; here min is rounded toward -inf and max toward +inf, so a texel
+                                             still bounds every depth it covers and the occlusion query stays conservative (it may
+                                             keep a few boxes an fp32 pyramid would cull, never the other way). Level 0 stays the
+                                             fp32 depth image. gv_hiz_read_level returns the stored halfs widened to float. */
 } GvConfigFlags;
 
 /* ---- pool binding: replaces LinearPool::getData/getOccupancy (docs/ECS/Components.md:137-170) as
@@ -227,6 +234,27 @@ int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_i
  * pools (up to 262144 slots) the first fetch publishes the results of every pool with ONE launch and ONE
  * synchronisation; the other fetches find theirs in the pinned host buffers. A (pool, view)'s results stay valid until
  * the next gv_cull of that pool. */
+/* Records in the ENGINE'S OWN struct layout. The reference appends `UnsortedMesh { psize componentOffset; float4x3
+ * bakedModel; float distanceSq; }` / `SortedMesh { ... uint32 bufferIndex; }` (render/mesh.hpp:191-205) to combinedMeshes;
+ * their padding depends on the math library's alignment of float4x3, so the layout is described, not assumed: once a
+ * pool has a record layout, the results of its views are ALSO delivered as an array of such structs in pinned host memory
+ * (gv_pool_results_records) — combinedMeshes is then filled with one memcpy instead of a loop over three arrays, and the
+ * SoA pointers of GvResult (visible_idx / baked_model / distance_sq) are NULL for that pool (draw_count, instance_count and
+ * is_visible are delivered as always). stride: bytes per record, a multiple of 16, at most 128; offsets inside the record:
+ * component_offset (uint64 = visible slot * component_stride, mesh.cpp:170), baked_model (12 floats, mesh.cpp:171),
+ * distance_sq (float, mesh.cpp:172 / :250-251), buffer_index (uint32 = buffer_index_value, mesh.cpp:252; GV_NONE: the struct
+ * has none); bytes not covered by a field are zero. layout == NULL removes it. */
+typedef struct GvRecordLayout {
+    uint32_t stride;
+    uint32_t component_offset, baked_model, distance_sq, buffer_index;
+    uint32_t component_stride;   /* getMeshComponentSize() */
+    uint32_t buffer_index_value; /* SortedMesh::bufferIndex of this pool's system */
+} GvRecordLayout;
+int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout* layout);
+/* After gv_pool_results_fetch of the same (pool, view): the records [0, *count) in the pool's record layout (library-owned
+ * pinned memory, valid until the next gv_cull of that pool). GV_E_STATE when the pool has no record layout. */
+int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count);
+
 /* A tick of engine-sized pools (the reference's everyday 10^3..10^4 entities per mesh system) is bound by launches,
  * not by bytes. Between gv_cull_batch_begin and the first call that reads results (gv_pool_results_* / gv_results_* /
  * gv_wait, or gv_cull_batch_end), gv_cull of a pool of up to 16384 slots whose views all emit records only RECORDS the

@@ -273,6 +273,71 @@ uint64_t gvo_hiz_layout(uint32_t w, uint32_t h, GvoHiz* out)
     return off;
 }
 
+/* RG16F pyramid (HizRenderSystem::bufferFormat = SfloatR16G16, include/garden/system/render/hiz.hpp:41). The reference lets
+ * the render target round float -> half (nearest, implementation-defined), which is not conservative; the build's variant
+ *  rounds min toward -inf and max toward +inf, so a stored pair still bounds every covered depth. These
+ * two functions ARE the format: binary16 with subnormals, NaN kept (quiet), overflow to +-inf / +-65504 by direction. */
+uint16_t gvo_half_directed(float f, int up)
+{
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    const uint32_t sign = bits >> 31, mag = bits & 0x7FFFFFFFu;
+    const uint32_t grow = (uint32_t)(up != 0) != sign; /* the direction increases the magnitude */
+    uint32_t h;
+    if (mag > 0x7F800000u)
+        h = 0x7E00u; /* NaN */
+    else if (mag == 0x7F800000u)
+        h = 0x7C00u;
+    else if (mag >= 0x47800000u) /* >= 2^16: beyond the largest half */
+        h = grow ? 0x7C00u : 0x7BFFu;
+    else {
+        const int e = (int)(mag >> 23) - 127;
+        if (e >= -14) { /* normal half; a carry out of the mantissa moves into the exponent (up to inf) */
+            const uint32_t mant = mag & 0x7FFFFFu;
+            h = ((uint32_t)(e + 15) << 10) | (mant >> 13);
+            if ((mant & 0x1FFFu) && grow)
+                h++;
+        } else { /* subnormal half (or zero): units of 2^-24 */
+            const uint32_t mant = (mag >> 23) ? ((mag & 0x7FFFFFu) | 0x800000u) : 0u; /* float subnormals: < 2^-126, all remainder */
+            const int shift = 13 + (-14 - e); /* >= 14 */
+            uint32_t rem;
+            if (shift > 31 || mant == 0) {
+                h = 0;
+                rem = mag;
+            } else {
+                h = mant >> shift;
+                rem = mant & ((1u << shift) - 1u);
+            }
+            if (rem && grow)
+                h++;
+        }
+    }
+    return (uint16_t)((sign << 15) | h);
+}
+
+float gvo_half_to_float(uint16_t hb)
+{
+    const uint32_t sign = (uint32_t)(hb >> 15) << 31, e = (hb >> 10) & 31u, m = hb & 0x3FFu;
+    uint32_t bits;
+    if (e == 31u)
+        bits = sign | 0x7F800000u | (m << 13);
+    else if (e != 0u)
+        bits = sign | ((e + 112u) << 23) | (m << 13);
+    else if (m == 0u)
+        bits = sign;
+    else { /* subnormal: m * 2^-24, normalised */
+        uint32_t mm = m, ee = 113u;
+        while (!(mm & 0x400u)) {
+            mm <<= 1;
+            ee--;
+        }
+        bits = sign | (ee << 23) | ((mm & 0x3FFu) << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
 static inline void src_texel(const GvoHiz* hz, const float* mips, uint32_t level, uint32_t x, uint32_t y, float* mn, float* mxv)
 {
     if (level == 0) { /* HIZ_VARIANT_FIRST: minMax = (d, d)  hiz.frag:57-60 */
@@ -287,8 +352,9 @@ static inline void src_texel(const GvoHiz* hz, const float* mips, uint32_t level
 }
 
 /* rows [py0, py1) of level k from level k - 1 (hiz.frag:23-63) */
-static void hiz_build_rows(const GvoHiz* hz, float* mips, int rule, uint32_t k, uint32_t py0, uint32_t py1)
+static void hiz_build_rows(const GvoHiz* hz, float* mips, int rule_and_format, uint32_t k, uint32_t py0, uint32_t py1)
 {
+    const int rule = rule_and_format & 0xFF, rg16f = (rule_and_format & GVO_HIZ_FORMAT_RG16F) != 0;
     const uint32_t sw = hz->mip_w[k - 1], sh = hz->mip_h[k - 1];
     const uint32_t dw = hz->mip_w[k];
     const int odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0; /* isPrevLevelOdd  hiz.frag:35 */
@@ -320,6 +386,10 @@ static void hiz_build_rows(const GvoHiz* hz, float* mips, int rule, uint32_t k, 
                     ACC(x0, y2); /* the full extra row, so that min/max bound every covered texel */
             }
 #undef ACC
+            if (rg16f) { /* what an RG16F texel holds (levels >= 2 reduce stored halfs: already exact) */
+                mn = gvo_half_to_float(gvo_half_directed(mn, 0));
+                mx = gvo_half_to_float(gvo_half_directed(mx, 1));
+            }
             float* d = mips + 2 * (hz->mip_offset[k] + (uint64_t)py * dw + px);
             d[0] = mn;
             d[1] = mx;

@@ -106,7 +106,10 @@ typedef struct GvoCullOut {
     uint32_t instance_count;
 } GvoCullOut;
 
-enum { GVO_HIZ_RULE_REFERENCE = 0, GVO_HIZ_RULE_CONSERVATIVE = 1 };
+enum { GVO_HIZ_RULE_REFERENCE = 0, GVO_HIZ_RULE_CONSERVATIVE = 1,
+       /* OR-ed into `rule`: levels >= 1 hold what an RG16F image (hiz.hpp:41) can hold, min rounded toward -inf and max
+        * toward +inf (level 0 is the depth image itself); the arrays stay float, every value is half-representable */
+       GVO_HIZ_FORMAT_RG16F = 0x100 };
 
 /* ---- math (build-defined canonical op order) ---- */
 void gvo_calc_model(const float pos[3], const float rot[4], const float scale[3], float out[16]);
@@ -121,6 +124,9 @@ void gvo_world_matrices(const GvoTransformPool* tp, uint32_t first, uint32_t cou
 void gvo_world_matrices_mt(const GvoTransformPool* tp, uint32_t first, uint32_t count, float* out12, uint32_t threads);
 
 /* ---- Hi-Z ---- */
+/* float -> binary16 bits rounded toward +inf (up != 0) or -inf, and the exact way back */
+uint16_t gvo_half_directed(float f, int up);
+float gvo_half_to_float(uint16_t half_bits);
 uint32_t gvo_calc_mip_count(uint32_t w, uint32_t h);
 /* Fills mip_w/h/offset; returns total (min,max) pairs needed for levels >= 1. */
 uint64_t gvo_hiz_layout(uint32_t w, uint32_t h, GvoHiz* out);

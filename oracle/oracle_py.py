@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "build", "libgv_oracle.so")
 GVO_NONE = 0xFFFFFFFF
 RULE_REFERENCE, RULE_CONSERVATIVE = 0, 1
+FORMAT_RG16F = 0x100  # OR-ed into the rule: levels >= 1 hold RG16F-representable values, rounded outward
 
 
 class GvoMeshPool(C.Structure):
@@ -73,6 +74,10 @@ def load():
     lib.gvo_world_matrices.argtypes = [C.POINTER(GvoTransformPool), C.c_uint32, C.c_uint32, C.c_void_p]
     lib.gvo_calc_mip_count.argtypes = [C.c_uint32, C.c_uint32]
     lib.gvo_calc_mip_count.restype = C.c_uint32
+    lib.gvo_half_directed.argtypes = [C.c_float, C.c_int]
+    lib.gvo_half_directed.restype = C.c_uint16
+    lib.gvo_half_to_float.argtypes = [C.c_uint16]
+    lib.gvo_half_to_float.restype = C.c_float
     lib.gvo_hiz_layout.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(GvoHiz)]
     lib.gvo_hiz_layout.restype = C.c_uint64
     lib.gvo_hiz_build.argtypes = [C.POINTER(GvoHiz), C.c_void_p, C.c_int]
@@ -156,7 +161,7 @@ def to_view(v):
 class Hiz:
     """Pyramid built by the oracle (hiz.frag:23-63)."""
 
-    def __init__(self, depth, rule=RULE_REFERENCE, threads=1):
+    def __init__(self, depth, rule=RULE_REFERENCE, threads=1, rg16f=False):
         lib = load()
         self.depth = _f32(depth)
         h, w = self.depth.shape
@@ -164,7 +169,7 @@ class Hiz:
         pairs = lib.gvo_hiz_layout(w, h, C.byref(self.c))
         self.mips = np.zeros((max(int(pairs), 1), 2), dtype=np.float32)
         self.c.depth = self.depth.ctypes.data
-        self.rule = rule
+        self.rule = rule | (FORMAT_RG16F if rg16f else 0)
         self.rebuild(threads)
         self.mip_count = self.c.mip_count
 

@@ -80,7 +80,10 @@ def test_hiz_occlusion_parity(gpu, oracle):
 
 @pytest.mark.parametrize("size", [(64, 64), (5, 3), (7, 7), (135, 77), (1920, 1080), (4096, 4096), (1024, 512)])
 @pytest.mark.parametrize("rule", [0, 1])
-def test_hiz_pyramid_parity(oracle, size, rule):
+@pytest.mark.parametrize("rg16f", [False, True])
+def test_hiz_pyramid_parity(oracle, size, rule, rg16f):
+    """rg16f: GV_CONFIG_HIZ_RG16F — the pyramid in the reference's image format (hiz.hpp:41), min rounded toward -inf and
+    max toward +inf; gv_hiz_read_level returns the stored halfs widened, equal to the oracle's values bit for bit."""
     from garden_amd.lib import GpuVisibility
     w, h = size
     depth = scene.synthetic_depth(w, h, rects=37)
@@ -91,11 +94,11 @@ def test_hiz_pyramid_parity(oracle, size, rule):
     # infinities — the reduction order of hiz.frag:29-60 is part of the contract, so these pin it
     k = max(1, (w * h) // 23)
     flat = depth.reshape(-1)
-    for value in (0.0, -0.0, np.nan, np.inf, -np.inf):
+    for value in (0.0, -0.0, np.nan, np.inf, -np.inf, 3e-6, -3e-6, 1e-9, 7e4, -7e4):  # incl. half subnormals, underflow, overflow
         flat[rng.choice(flat.size, k, replace=False)] = np.float32(value)
-    with GpuVisibility(device=0, hiz_rule=rule) as vis:
+    with GpuVisibility(device=0, hiz_rule=rule, hiz_rg16f=rg16f) as vis:
         vis.hiz_build(depth)
-        exp = oracle.Hiz(depth, rule=rule)
+        exp = oracle.Hiz(depth, rule=rule, rg16f=rg16f)
         assert vis.hiz_mip_count() == exp.mip_count
         for k in range(1, exp.mip_count):
             e = exp.level(k)
@@ -411,25 +414,30 @@ def test_non_finite_and_denormal_inputs_agree_with_the_oracle(gpu, oracle):
 
 
 @pytest.mark.parametrize("size,rule", [((301, 171), 1), ((640, 360), 1), ((1000, 1000), 1), ((301, 171), 0), ((1024, 512), 0)])
-def test_hiz_query_early_accept_is_exact(oracle, size, rule):
+@pytest.mark.parametrize("rg16f", [False, True])
+def test_hiz_query_early_accept_is_exact(oracle, size, rule, rg16f):
     """The coarse-level early-accept must never change a decision: NPOT pyramids under the conservative rule
     (nested, incl. the clamped last texels), NPOT under the reference rule (not nested: shortcut off), and an
-    all-even pyramid under the reference rule (nested)."""
+    all-even pyramid under the reference rule (nested). rg16f: the same queries against the RG16F pyramid (incl. the
+    virtual level 1 of the 1024x512 case: its texels are rounded like stored ones); outward rounding can only keep more."""
     from garden_amd.lib import GpuVisibility
     w, h = size
     sc = scene.flat_scene(120_000, seed=w + h + rule)
     depth = scene.synthetic_depth(w, h, rects=90)
     v = scene.main_camera_view(use_hiz=1)
-    with GpuVisibility(device=0, hiz_rule=rule) as vis:
+    with GpuVisibility(device=0, hiz_rule=rule, hiz_rg16f=rg16f) as vis:
         vis.bind_transforms(sc.transforms, sc.entity_to_transform)
         vis.bind_pool(0, sc.meshes)
         vis.hiz_build(depth)
         vis.cull(0, [v])
         got = vis.fetch(0, write_back=False, occupancy=sc.count)
-    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, hiz=oracle.Hiz(depth, rule=rule))
+    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, hiz=oracle.Hiz(depth, rule=rule, rg16f=rg16f))
     frustum_only = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, dict(v, use_hiz=0))
     assert 0 < exp["draw_count"] < frustum_only["draw_count"]
     assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+    if rg16f:  # conservative w.r.t. the fp32 pyramid: everything that one keeps is kept
+        fp32 = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, hiz=oracle.Hiz(depth, rule=rule))
+        assert np.isin(fp32["visible_idx"], exp["visible_idx"]).all() and exp["draw_count"] >= fp32["draw_count"]
 
 
 def test_device_side_result_accessors(gpu, oracle):
@@ -1158,3 +1166,141 @@ def test_a_tick_of_small_pools_is_culled_emitted_sorted_and_published_together(o
             # something moves between the ticks
             tr["position"][:3000, :3] += np.float32(3.0)
             vis.mark_dirty(0, 0, 3000)
+
+
+RECORD_DTYPES = {
+    # render/mesh.hpp:191-205 under an 8-byte-aligned float4x3 (64-byte structs; SortedMesh's bufferIndex fills the tail) ...
+    "packed": (np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                         "offsets": [0, 8, 56], "itemsize": 64}),
+               np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq", "bufferIndex"],
+                         "formats": ["<u8", ("<f4", 12), "<f4", "<u4"], "offsets": [0, 8, 56, 60], "itemsize": 64})),
+    # ... and under a 16-byte-aligned SIMD float4x3 (80-byte structs with padding after componentOffset and at the end)
+    "simd": (np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                       "offsets": [0, 16, 64], "itemsize": 80}),
+             np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq", "bufferIndex"],
+                       "formats": ["<u8", ("<f4", 12), "<f4", "<u4"], "offsets": [0, 16, 64, 68], "itemsize": 80})),
+}
+
+
+@pytest.mark.parametrize("n", [3_000, 20_000, 300_000])  # in-LDS publish / publish / device pack + one copy
+@pytest.mark.parametrize("kind", ["packed", "simd"])
+def test_records_in_the_engines_own_struct_layout(oracle, n, kind):
+    """gv_pool_set_record_layout: the results of a pool arrive as an array of the caller's UnsortedMesh / SortedMesh
+    structs (componentOffset = slot * component size, bakedModel, distanceSq, bufferIndex, padding zero) — the same
+    values, bit for bit, as the three-array fetch; sorted, batched, with ready counts, and removable again."""
+    from garden_amd.lib import GpuVisibility, GV_E_ARG, GV_E_STATE
+    unsorted_dt, sorted_dt = RECORD_DTYPES[kind]
+    sc = scene.flat_scene(n, seed=n + 5)
+    main = scene.main_camera_view()
+    shadow = scene.cascade_view(index=0)
+    component = int(sc.meshes.dtype.itemsize)
+    ready = np.random.default_rng(n).choice(np.array([0, 1, 1, 3], np.uint32), n)
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.bind_pool(1, sc.meshes)
+        vis.hierarchy_rebuild()
+        # reference: three arrays
+        vis.cull(0, [main, shadow])
+        vis.sort(0, descending=False, pool_id=0)
+        soa = [vis.fetch(v, write_back=False, occupancy=n, pool_id=0, order="raw") for v in range(2)]
+        assert soa[0]["draw_count"] > 0 and soa[1]["draw_count"] > 0
+
+        def check(rec, ref, dt, buffer_index, order=None):
+            assert rec.shape[0] == ref["draw_count"]
+            covered = np.zeros(dt.itemsize, bool)  # every byte no field owns is zero
+            for name in dt.names:
+                sub, at = dt.fields[name][:2]
+                covered[at:at + sub.itemsize] = True
+            raw = rec.view(np.uint8).reshape(-1, dt.itemsize)
+            assert not raw[:, ~covered].any()
+            if order is not None:
+                rec = rec[order]
+            assert np.array_equal(rec["componentOffset"], ref["visible_idx"].astype(np.uint64) * component)
+            assert np.array_equal(rec["bakedModel"].view(np.uint32), ref["baked_model"].view(np.uint32))
+            assert np.array_equal(rec["distanceSq"].view(np.uint32), ref["distance_sq"].view(np.uint32))
+            if buffer_index is not None:
+                assert np.all(rec["bufferIndex"] == buffer_index)
+
+        vis.set_record_layout(0, unsorted_dt, component_stride=component)
+        vis.set_record_layout(1, sorted_dt, component_stride=component, buffer_index_value=5)
+        for tick in range(2):  # the second tick runs inside a batch
+            if tick:
+                vis.cull_batch_begin()
+            vis.cull(0, [main, shadow])
+            vis.cull(1, [main])
+            vis.sort(0, descending=False, pool_id=0)
+            vis.sort(0, descending=True, pool_id=1)
+            got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0, order="raw")
+            assert got["draw_count"] == soa[0]["draw_count"] and got["visible_idx"] is None  # delivered as structs instead
+            assert np.array_equal(got["is_visible"], soa[0]["is_visible"])
+            check(vis.records(0, 0, unsorted_dt), soa[0], unsorted_dt, None)
+            check(vis.records(0, 1, unsorted_dt), soa[1], unsorted_dt, None)  # without a fetch of its own first
+            back = vis.records(1, 0, sorted_dt)
+            assert np.all(np.diff(back["distanceSq"]) <= 0)
+            order = np.argsort(back["componentOffset"], kind="stable")
+            ref = {k: (soa[0][k][np.argsort(soa[0]["visible_idx"], kind="stable")] if k in ("visible_idx", "baked_model", "distance_sq")
+                       else soa[0][k]) for k in soa[0]}
+            check(back, ref, sorted_dt, 5, order=order)
+        # instanceCount from the records (mesh.cpp:174) when ready counts are bound
+        vis.bind_ready(0, ready)
+        vis.cull(0, [main])
+        got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        rec = vis.records(0, 0, unsorted_dt)
+        slots = (rec["componentOffset"] // component).astype(np.int64)
+        assert np.all(ready[slots] > 0) and got["instance_count"] == int(ready[slots].sum()) and got["draw_count"] == rec.shape[0]
+        vis.bind_ready(0, None)
+        # a count-only view has no records; a pool without layout says so; a bad layout is refused
+        vis.cull(0, [dict(main, emit_records=0)])
+        with pytest.raises(RuntimeError) as e:
+            vis.records(0, 0, unsorted_dt)
+        assert "count-only" in str(e.value)
+        vis.set_record_layout(0, None)
+        vis.cull(0, [main, shadow])
+        vis.sort(0, descending=False, pool_id=0)
+        again = vis.fetch(0, write_back=False, occupancy=n, pool_id=0, order="raw")
+        assert np.array_equal(again["visible_idx"], soa[0]["visible_idx"])
+        with pytest.raises(RuntimeError) as e:
+            vis.records(0, 0, unsorted_dt)
+        assert "no record layout" in str(e.value)
+        for bad in (np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                              "offsets": [0, 8, 56], "itemsize": 72}),     # stride not a multiple of 16
+                    np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                              "offsets": [0, 4, 56], "itemsize": 64}),     # overlapping fields
+                    np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                              "offsets": [0, 8, 140], "itemsize": 144})):  # too large
+            with pytest.raises(RuntimeError):
+                vis.set_record_layout(0, bad, component_stride=component)
+
+
+def test_rg16f_conversion_on_every_half_and_its_float_neighbours(oracle):
+    """The device's directed float -> binary16 conversion (hardware nearest + one corrective step) against the oracle's
+    integer one (pinned on numpy's float16 table in the CPU tier): a depth image whose 2x2 blocks are constant makes
+    level 1 of the RG16F pyramid the pair (toward -inf, toward +inf) of each value — every finite half, the floats just
+    above and below each (incl. across 0, the subnormal range and both overflow edges), infinities, NaNs with payloads."""
+    from garden_amd.lib import GpuVisibility
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    h = h[np.isfinite(h)]
+    rng = np.random.default_rng(3)
+    extra = np.array([np.inf, -np.inf, 65519.99, 65520.0, 65536.0, 1e30, -1e30, 3e38, -3e38, 1e-45, -1e-45, 1e-40, 2.9e-8, 2.99e-8, -2.99e-8],
+                     dtype=np.float32)
+    nans = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFFBFFFFF, 0x7FC12345], dtype=np.uint32).view(np.float32)
+    rand = rng.integers(0, 2**32, 300_000, dtype=np.uint64).astype(np.uint32).view(np.float32)  # any bit pattern
+    vals = np.concatenate([h, np.nextafter(h, np.float32(np.inf)), np.nextafter(h, np.float32(-np.inf)), extra, nans, rand]).astype(np.float32)
+    width = 2048  # blocks per row = 1024
+    rows = -(-vals.size // (width // 2))
+    padded = np.zeros(rows * (width // 2), np.float32)
+    padded[:vals.size] = vals
+    depth = np.repeat(np.repeat(padded.reshape(rows, width // 2), 2, axis=0), 2, axis=1)
+    assert depth.shape == (2 * rows, width)
+    with GpuVisibility(device=0, hiz_rg16f=True) as vis:
+        vis.hiz_build(depth)
+        got = vis.hiz_read_level(1, width // 2, rows)
+    exp = oracle.Hiz(depth, rg16f=True).level(1)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    lib = oracle.load()
+    sample = np.concatenate([np.arange(0, vals.size, 97), np.arange(h.size * 3, h.size * 3 + extra.size + nans.size)])
+    flat = got.reshape(-1, 2)
+    for i in sample:  # and the level really is the per-value conversion
+        lo, hi = lib.gvo_half_to_float(lib.gvo_half_directed(float(vals[i]), 0)), lib.gvo_half_to_float(lib.gvo_half_directed(float(vals[i]), 1))
+        assert (flat[i, 0] == lo or (np.isnan(lo) and np.isnan(flat[i, 0]))) and (flat[i, 1] == hi or (np.isnan(hi) and np.isnan(flat[i, 1])))

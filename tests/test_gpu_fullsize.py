@@ -102,6 +102,30 @@ def test_cfg3_10m_hiz_properties_and_oracle(gpu, oracle, flat10m):
     assert same_records(hz1, exp) and np.array_equal(hz1["is_visible"], m2["isVisible"])
 
 
+def test_cfg3_10m_against_the_rg16f_pyramid(oracle, flat10m):
+    """GV_CONFIG_HIZ_RG16F at BASELINE's size: 10 M entities against the 4096^2 pyramid kept in the reference's image
+    format (min rounded toward -inf, max toward +inf; level 1 virtual): the oracle's set bit for bit, a superset of the
+    fp32 pyramid's set (never culls what that one keeps), and the rounding does let a few more through."""
+    from garden_amd.lib import GpuVisibility
+    sc = flat10m
+    depth = scene.synthetic_depth(HIZ, HIZ)
+    view = scene.main_camera_view(use_hiz=1)
+    with GpuVisibility(device=0, hiz_rg16f=True) as vis:
+        bind(vis, sc)
+        vis.hiz_build(depth)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(got, sc.count)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, hiz=oracle.Hiz(depth, rg16f=True, threads=THREADS), threads=THREADS)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    assert same_records(got, exp) and np.array_equal(got["is_visible"], m2["isVisible"])
+    fp32 = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, hiz=oracle.Hiz(depth, threads=THREADS), threads=THREADS)
+    assert np.isin(fp32["visible_idx"], got["visible_idx"]).all()
+    print(f"rg16f pyramid: {got['draw_count']} visible vs {fp32['draw_count']} with the fp32 pyramid")
+
+
 def test_cfg5_one_world_cut_into_spatial_tiles_through_the_exchange(oracle, hier10m):
     """cfg5 pattern on one GPU: ONE 10 M hierarchical world -> partition_world -> 8 spatial tiles (roots by position,
     descendants follow, ids remapped), each tile culled as its own pools, its list pushed through the native exchange

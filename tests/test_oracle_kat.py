@@ -264,3 +264,58 @@ def test_hiz_query_hand_cases(oracle):
     assert got is False or got is True  # value depends on the rounding of 0.1/9.5; must simply not crash
     crossing = oracle.calc_model((0, 0, 0.2), IDENT_Q, (1, 1, 1))  # box crosses the camera plane: never occluded
     assert not oracle.Hiz(wall_near, rule=1).occluded(vp, mn, mx, crossing)
+
+
+def _all_finite_halfs():
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    return np.sort(np.unique(h[np.isfinite(h)]))
+
+
+def test_half_directed_against_every_binary16_value(oracle):
+    """The RG16F variant's conversions, pinned on IEEE binary16 itself (numpy's float16 table, an independent
+    implementation): toward -inf gives the largest half <= x, toward +inf the smallest half >= x, for normals, subnormals,
+    both overflow sides, +-0, +-inf, NaN; and half -> float is exact for all 65536 encodings."""
+    lib = oracle.load()
+    halfs = _all_finite_halfs()
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([
+        rng.random(4000, dtype=np.float32), (rng.standard_normal(4000) * 1e-6).astype(np.float32),
+        (rng.standard_normal(2000) * 7e4).astype(np.float32), halfs[rng.integers(0, halfs.size, 2000)],
+        np.array([0.0, -0.0, 1.0, 65504.0, 65505.0, 65519.9, 65520.0, 65536.0, 1e9, -1e9, 5.96e-8, 5.9e-8, 6e-8, 1e-9, -1e-9,
+                  2.98e-8, 6.1e-5, 6.09e-5, 1e-45, -1e-45, 1.17e-38, -65504.0, -65505.0, -7e4], np.float32)])
+    for x in vals:
+        down = lib.gvo_half_to_float(lib.gvo_half_directed(float(x), 0))
+        up = lib.gvo_half_to_float(lib.gvo_half_directed(float(x), 1))
+        k = np.searchsorted(halfs, x, side="right") - 1
+        assert down == (halfs[k] if k >= 0 else -np.inf), (x, down)
+        k = np.searchsorted(halfs, x, side="left")
+        assert up == (halfs[k] if k < halfs.size else np.inf), (x, up)
+        assert down <= x <= up
+    assert lib.gvo_half_directed(-0.0, 0) == 0x8000 and lib.gvo_half_directed(-0.0, 1) == 0x8000 and lib.gvo_half_directed(0.0, 0) == 0
+    assert lib.gvo_half_directed(float("inf"), 0) == 0x7C00 and lib.gvo_half_directed(float("-inf"), 1) == 0xFC00
+    assert lib.gvo_half_directed(float("nan"), 0) & 0x7FFF == 0x7E00
+    table = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    for bits in range(65536):
+        got = np.float32(lib.gvo_half_to_float(bits))
+        assert got.view(np.uint32) == table[bits].view(np.uint32) or (np.isnan(got) and np.isnan(table[bits])), bits
+
+
+@pytest.mark.parametrize("size", [(8, 8), (7, 5), (64, 64), (33, 20)])
+@pytest.mark.parametrize("rule", [0, 1])
+def test_rg16f_pyramid_is_the_fp32_pyramid_rounded_outward(oracle, size, rule):
+    """FORMAT_RG16F (HizRenderSystem::bufferFormat, hiz.hpp:41, with the build's directed rounding): every level equals
+    the fp32 pyramid's min rounded toward -inf / max toward +inf (rounding is monotone, so it commutes with the reductions),
+    every stored value is a binary16 value, and each pair still bounds the fp32 pair it replaces."""
+    w, h = size
+    depth = np.random.default_rng(w * 7 + h).random((h, w)).astype(np.float32)
+    depth.reshape(-1)[::5] *= np.float32(1e-6)  # reach the subnormal halfs
+    exact = oracle.Hiz(depth, rule=rule)
+    half = oracle.Hiz(depth, rule=rule, rg16f=True)
+    halfs = _all_finite_halfs()
+    for k in range(1, exact.mip_count):
+        e, g = exact.level(k), half.level(k)
+        lo = halfs[np.searchsorted(halfs, e[..., 0], side="right") - 1]
+        hi = halfs[np.searchsorted(halfs, e[..., 1], side="left")]
+        assert np.array_equal(g[..., 0], lo) and np.array_equal(g[..., 1], hi), f"mip {k}"
+        assert np.all(g[..., 0] <= e[..., 0]) and np.all(g[..., 1] >= e[..., 1])
+        assert np.array_equal(g.astype(np.float16).astype(np.float32), g)
