@@ -40,7 +40,10 @@ __device__ unsigned long long gv_sort_trace[4][8192][8];
 #endif
 constexpr uint32_t kSortTile = 4096;               // keys per workgroup per pass
 constexpr uint32_t kSortRounds = kSortTile / 256;  // keys per lane
-constexpr uint32_t kLookWindow = 16;               // predecessors inspected per look-back step
+#ifndef GV_SORT_LOOK_WINDOW
+#define GV_SORT_LOOK_WINDOW 16
+#endif
+constexpr uint32_t kLookWindow = GV_SORT_LOOK_WINDOW;  // predecessors inspected per look-back step
 constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kFlagMask = 3u << 30, kCountMask = ~kFlagMask;
 
 __device__ __forceinline__ uint32_t order_key(float d, uint32_t descending)
