@@ -526,7 +526,7 @@ void gv_destroy(GvCtx* ctx)
       for (auto& v : per_pool) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
-        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release();
+        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
@@ -1200,14 +1200,19 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
         GV_HIP(ctx, vs.sort_keys[k].reserve(n));
         GV_HIP(ctx, vs.sort_vals[k].reserve(n));
     }
-    // sort_hist: [2 sets][4 * 256 global digit counters + 4 tile counters, padded to 1280] + look-back words
-    constexpr size_t kSet = 1280;
-    const size_t want = 2 * kSet + 4 * nblocks * 256;
+    // sort_hist: [2 sets of counters (global + per-group digit histograms)] + the tiles' digit counts
+    const size_t set_words = sort_set_words((uint32_t)n);
+    const size_t want = 2 * set_words + nblocks * 256;
     if (want > vs.sort_hist.cap) {
         GV_HIP(ctx, vs.sort_hist.reserve(want));
-        GV_HIP(ctx, hipMemsetAsync(vs.sort_hist.ptr, 0, 2 * kSet * sizeof(uint32_t), ctx->stream));  // both sets start at zero
+        vs.sort_set_words = 0;
+    }
+    if (vs.sort_set_words != set_words) {  // (a pool that changed size moves the sets: both start at zero again)
+        GV_HIP(ctx, hipMemsetAsync(vs.sort_hist.ptr, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
+        vs.sort_set_words = set_words;
         vs.sort_parity = 0;
     }
+    GV_HIP(ctx, vs.sort_ranks.reserve(n));
     SortBuffers b;
     b.count = vs.draw_count.ptr;
     b.idx_in = vs.visible_idx.ptr;
@@ -1216,13 +1221,13 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
     b.idx_out = vs.alt_idx.ptr;
     b.model_out = vs.alt_model.ptr;
     b.dist_out = vs.alt_dist.ptr;
+    b.ranks = vs.sort_ranks.ptr;
     for (int k = 0; k < 2; k++) {
         b.keys[k] = vs.sort_keys[k].ptr;
         b.vals[k] = vs.sort_vals[k].ptr;
-        b.ghist[k] = vs.sort_hist.ptr + k * kSet;
-        b.tile_counter[k] = vs.sort_hist.ptr + k * kSet + 1024;
+        b.counters[k] = vs.sort_hist.ptr + k * set_words;
     }
-    b.status = vs.sort_hist.ptr + 2 * kSet;
+    b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
     b.parity = vs.sort_parity;
     vs.sort_parity ^= 1u;  // this sort leaves the other set zeroed for the next one
     {

@@ -223,6 +223,8 @@ struct ViewState {
     DeviceBuf<uint32_t> tile_ticket;
     uint32_t tile_ticket_base = 0, tile_epoch = 0;
     uint32_t sort_parity = 0;  // which of the two counter sets in sort_hist the next large sort uses (gv_sort.hip)
+    size_t sort_set_words = 0; // size of one set as laid out in sort_hist (0: not initialised)
+    DeviceBuf<uint16_t> sort_ranks;
     uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };

@@ -188,14 +188,18 @@ struct SortBuffers {
     uint32_t* idx_out;
     float* model_out;
     float* dist_out;
-    // large pools (onesweep radix sort, gv_sort.hip):
-    uint32_t* keys[2];          // (key, record index) pairs, ping-pong
+    // large pools (radix sort, gv_sort.hip):
+    uint32_t* keys[2];       // (key, record index) pairs, ping-pong
     uint32_t* vals[2];
-    uint32_t* ghist[2];         // global digit histograms [4][256], two sets: a sort uses set `parity` (zero on entry)
-    uint32_t* tile_counter[2];  // dynamic tile counters [4] per set         and zeroes the other one for the next sort
-    uint32_t* status;           // decoupled look-back words [4][ceil(capacity / 4096)][256]
+    uint16_t* ranks;         // per key: rank among its tile's keys of the current digit
+    uint32_t* counters[2];   // two sets of sort_set_words(capacity) words — per-group digit counts [4][groups][256]: a sort
+                             // uses set `parity` (zero on entry) and zeroes the other
+    uint32_t* tile_hist;     // [ceil(capacity / 4096)][256] digit counts of every tile (rewritten by each pass)
     uint32_t parity;
 };
+constexpr uint32_t kSortGroupTiles = 32;
+inline uint32_t sort_group_count(uint32_t capacity) { return ((capacity + 4095u) / 4096u + kSortGroupTiles - 1u) / kSortGroupTiles; }
+inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count(capacity) * 256u; }
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 // pools of up to this many slots sort in one launch (rank sort, gv_sort.hip); gv_sort defers those so that the views of
 // one cull share a single launch (launch_sort_small_batch) when their results are first asked for

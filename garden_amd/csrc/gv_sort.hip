@@ -9,22 +9,23 @@ namespace gv {
 // Stable LSD radix sort on a 32-bit order-preserving key, 8 bits per pass; ties keep ascending slot order
 // (std::sort in the reference is unstable, so any tie order is within its contract).
 // ------------------------------------------------------------------------------------------------
-// Large pools: a single-pass-per-digit ("onesweep") LSD radix sort, 5 launches instead of 14:
-//   sort_prepare_kernel   one pass over distanceSq: the GLOBAL histograms of all four 8-bit digits at once (the digit
-//                         totals do not depend on the order of the keys, so they need not wait for the passes), and
-//                         the housekeeping of this sort's look-back state;
-//   onesweep_kernel x 4   per digit: a workgroup ranks its tile of 4096 keys (stable), publishes the tile's digit
-//                         counts and obtains the counts of all tiles before it by DECOUPLED LOOK-BACK (no histogram and
-//                         scan launches between the passes), reorders the tile by digit in LDS and writes each digit's
-//                         run to its final place. Pass 0 builds the keys from distanceSq itself; the LAST pass does not
-//                         write (key, index) pairs at all but gathers the 56-byte records straight to their sorted
-//                         positions (the separate key and gather launches of the 14-launch form are gone).
-// 2.1 M records move 8 + 16 + 16 + 16 + 8 B of pairs and 112 B of records each = 176 B; the working set (17 MB of pairs
-// at 2.1 M) stays in L2 / Infinity Cache, so the passes are latency- rather than HBM-bound: what matters is launches,
-// barriers and atomic conflicts (keys of one frame share their top bytes: every counter update is aggregated per wave
-// by digit matching first).
+// Large pools: two launches per digit, nothing between them but the kernel boundary.
+//   sort_rank_kernel     a workgroup ranks its tile of 4096 keys (stable; wave-private LDS counters), stores every key's
+//                        rank among the tile's keys of the same digit (16 bits), the tile's 256 digit counts, and adds
+//                        them into the counts of its GROUP of 32 tiles. Pass 0 builds the keys from distanceSq.
+//   sort_scatter_kernel  reloads the tile's keys and ranks, gets the number of same-digit keys in all tiles before it
+//                        as (group counts before its group) + (tile counts before it inside the group), and the digit's
+//                        total as the sum over all groups — a few dozen INDEPENDENT loads, one or two memory round trips,
+//                        no separate global histogram — reorders the tile by digit in LDS and writes
+//                        each digit's run to its final place. The LAST pass does not write (key, index) pairs but gathers
+//                        the 56-byte records straight to their sorted positions.
+// Why not one launch per digit with a decoupled look-back (the round-2 first form, 223 us at 2.1 M records): with every
+// tile resident at once the look-back is a serial chain through memory — 9-16 us of a 38 us pass were spent waiting for
+// predecessors (tools/onesweep_probe.hip), a wider window only made it worse (64 words per step: 15.6 us median) — while
+// a kernel boundary costs 1.6 us on this part and the keys, ranks and counts it has to carry (10 B per key) stay in L2 /
+// Infinity Cache. No workgroup ever waits for another: static tile ids, no tickets, no polling.
 #ifdef GV_SORT_TRACE  // dev tool only (tools/onesweep_probe.hip): wall-clock stamps per tile and phase
-__device__ unsigned long long gv_sort_trace[4][8192][8];
+__device__ unsigned long long gv_sort_trace[4][8192][12];
 #define GV_TRACE(k)                                                    \
     if (threadIdx.x == 0 && tile < 8192)                               \
         gv_sort_trace[a.pass][tile][k] = wall_clock64();
@@ -40,11 +41,7 @@ __device__ unsigned long long gv_sort_trace[4][8192][8];
 #endif
 constexpr uint32_t kSortTile = 4096;               // keys per workgroup per pass
 constexpr uint32_t kSortRounds = kSortTile / 256;  // keys per lane
-#ifndef GV_SORT_LOOK_WINDOW
-#define GV_SORT_LOOK_WINDOW 16
-#endif
-constexpr uint32_t kLookWindow = GV_SORT_LOOK_WINDOW;  // predecessors inspected per look-back step
-constexpr uint32_t kFlagAggregate = 1u << 30, kFlagPrefix = 2u << 30, kFlagMask = 3u << 30, kCountMask = ~kFlagMask;
+constexpr uint32_t kSortGroup = kSortGroupTiles;   // tiles whose digit counts are also summed per group
 
 __device__ __forceinline__ uint32_t order_key(float d, uint32_t descending)
 {
@@ -100,83 +97,20 @@ __device__ __forceinline__ void wave_lds_order()
 }
 
 struct SortState {
-    uint32_t* ghist;         // this sort's global digit histograms [4][256]   (zero on entry)
-    uint32_t* tile_counter;  // this sort's dynamic tile counters [4]          (zero on entry)
-    uint32_t* ghist_next;    // the other parity's set, zeroed here for the next sort
-    uint32_t* tile_counter_next;
-    uint32_t* status;        // look-back words [4][tile_stride][256]
-    uint32_t tile_stride;
+    uint32_t* group_hist;  // this sort's per-group digit counts [4][groups][256]   (zero on entry)
+    uint32_t* next_set;    // the other parity's set, zeroed here for the next sort
+    uint32_t set_words;
+    uint32_t* tile_hist;   // [tiles][256]: digit counts of every tile, rewritten by each pass
+    uint32_t groups;
 };
-
-// Global histograms of the four digits + housekeeping: one workgroup per tile of 4096 keys (surplus workgroups of the
-// capacity-sized grid leave at once), 16 keys per lane loaded up front, LDS counters, then one global atomic per
-// non-empty counter. Keys of one frame share their high bytes, so a wave whose 64 keys agree on a digit adds 64 with one
-// lane instead of queueing 64 same-address LDS atomics.
-__global__ __launch_bounds__(256) void sort_prepare_kernel(const float* __restrict__ dist, const uint32_t* __restrict__ count,
-                                                           uint32_t capacity, uint32_t descending, SortState st)
-{
-    __shared__ uint32_t bins[4][256];
-    const uint32_t n = min(*count, capacity);
-    const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    if (blockIdx.x == 0) {  // the other parity's counters, for the next sort (nobody reads them during this one)
-        for (uint32_t k = threadIdx.x; k < 4 * 256; k += 256)
-            st.ghist_next[k] = 0;
-        if (threadIdx.x < 4)
-            st.tile_counter_next[threadIdx.x] = 0;
-    }
-    if (blockIdx.x >= tiles)
-        return;
-#pragma unroll
-    for (uint32_t p = 0; p < 4; p++) {
-        bins[p][threadIdx.x] = 0;
-        st.status[((size_t)p * st.tile_stride + blockIdx.x) * 256 + threadIdx.x] = 0;  // this tile's look-back words
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base = blockIdx.x * kSortTile + (threadIdx.x >> 6) * (kSortTile / 4);
-    uint32_t key[kSortRounds];
-#pragma unroll
-    for (uint32_t r = 0; r < kSortRounds; r++) {
-        const uint32_t j = base + r * 64 + lane;
-        key[r] = j < n ? order_key(dist[j], descending) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t r = 0; r < kSortRounds; r++) {
-        const uint32_t j = base + r * 64 + lane;
-        const bool valid = j < n;
-        const unsigned long long live = __ballot(valid);
-        if (live == 0ull)
-            break;  // wave-uniform: the rest of this wave's keys lie beyond n
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)key[r]);  // lane 0 is valid whenever any lane is
-        const uint32_t diff = key[r] ^ first;
-#pragma unroll
-        for (uint32_t p = 0; p < 4; p++) {
-            const uint32_t d = (key[r] >> (8 * p)) & 255u;
-            const bool same = __ballot(valid && ((diff >> (8 * p)) & 255u) != 0u) == 0ull;  // every live key has lane 0's digit
-            if (same) {
-                if (lane == 0)
-                    atomicAdd(&bins[p][d], (uint32_t)__popcll(live));
-            } else if (valid) {
-                atomicAdd(&bins[p][d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t p = 0; p < 4; p++) {
-        const uint32_t c = bins[p][threadIdx.x];
-        if (c)
-            atomicAdd(&st.ghist[p * 256 + threadIdx.x], c);
-    }
-}
 
 struct SortPassArgs {
     const uint32_t* count;
     uint32_t capacity, descending, pass;
-    uint32_t static_tiles;      // GV_DEBUG_SORT_STATIC_TILES (measurement only)
     const float* dist_in;       // FIRST: keys are built from these
     const uint32_t* keys_in;    // !FIRST
     const uint32_t* vals_in;    // !FIRST
+    uint16_t* ranks;            // per key of the current order: rank among its tile's keys of the same digit
     uint32_t* keys_out;         // !LAST
     uint32_t* vals_out;         // !LAST
     const uint32_t* idx_in;     // LAST: the records, gathered to their sorted positions
@@ -187,46 +121,36 @@ struct SortPassArgs {
     SortState st;
 };
 
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void onesweep_kernel(const SortPassArgs a)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
 {
-    __shared__ uint32_t wcount[4][256];   // per-wave digit counts of the tile, then per-wave digit bases
-    __shared__ uint32_t tile_excl[256];   // exclusive scan of the tile's digit counts (tile-local sorted order)
-    __shared__ uint32_t dst_base[256];    // global position of the tile's first key of each digit
-    __shared__ uint32_t skey[kSortTile];  // the tile reordered by digit
-    __shared__ uint32_t sval[kSortTile];
-    __shared__ uint32_t wave_sum[4];
-    __shared__ uint32_t tile_id;
+    __shared__ uint32_t wcount[4][256];  // per-wave digit counts of the tile
     const uint32_t n = min(*a.count, a.capacity);
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
+    if (FIRST)  // the other parity's counters, for the next sort (nobody reads them during this one)
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.st.set_words; k += gridDim.x * 256)
+            a.st.next_set[k] = 0;
     if (blockIdx.x >= tiles)
         return;  // the grid is sized for the capacity, the count lives on the device: surplus workgroups leave at once
-    if (threadIdx.x == 0)
-        tile_id = a.static_tiles ? blockIdx.x                  // debug A/B only: relies on in-order workgroup dispatch
-                                 : atomicAdd(&a.st.tile_counter[a.pass], 1u);  // tiles are taken in order of arrival: a workgroup
-                                                              // only ever waits for tiles whose workgroups are already running
+    const uint32_t tile = blockIdx.x;
+    GV_TRACE(0)
 #pragma unroll
     for (uint32_t w = 0; w < 4; w++)
         wcount[w][threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t tile = tile_id;  // < tiles: exactly `tiles` workgroups take one each
-    GV_TRACE(0)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t shift = a.pass * 8;
-    // ---- A: each wave ranks its 1024 consecutive keys, 64 per round: wave-private counters, no workgroup barrier ----
+    // each wave ranks its 1024 consecutive keys, 64 per round: wave-private counters, no workgroup barrier
     const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / 4);
-    uint32_t key[kSortRounds], val[kSortRounds], local[kSortRounds];
+    uint32_t key[kSortRounds], local[kSortRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {  // all loads first
         const uint32_t j = wave_base + r * 64 + lane;
         const bool valid = j < n;
-        if (FIRST) {
+        if (FIRST)
             key[r] = valid ? order_key(a.dist_in[j], a.descending) : 0xFFFFFFFFu;
-            val[r] = j;
-        } else {
+        else
             key[r] = valid ? a.keys_in[j] : 0xFFFFFFFFu;
-            val[r] = valid ? a.vals_in[j] : 0u;
-        }
     }
     // Ranking: per round, the lanes sharing my digit (a wave whose live keys all agree — the high bytes of one frame's
     // distances — knows without asking; otherwise 8 ballots), my rank among them, and the wave's running count of that
@@ -234,7 +158,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const SortPassArgs a)
     // counts of rounds < r, so the ranking is stable). Two other forms were built and measured no faster on the box
     // (profiles/r02_sort_probe.txt): LDS lane-mask tables instead of the ballots (fewer instructions, more LDS round
     // trips), and all sixteen rounds' counts taken with returning LDS atomics in flight together (needs > 128 VGPRs).
-    GV_TRACE_AFTER_LOADS(6)
+    GV_TRACE_AFTER_LOADS(1)
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {
         const uint32_t j = wave_base + r * 64 + lane;
@@ -251,75 +175,97 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const SortPassArgs a)
         local[r] = prior + below;  // rank among this wave's keys of digit d
     }
     __syncthreads();
-    GV_TRACE(1)
-    // ---- B: one thread per digit: tile counts -> look-back -> this tile's global base per digit ----
-    const uint32_t d = threadIdx.x;
-    const uint32_t c0 = wcount[0][d], c1 = wcount[1][d], c2 = wcount[2][d], c3 = wcount[3][d];
-    const uint32_t tile_count = c0 + c1 + c2 + c3;
-    uint32_t* status = a.st.status + ((size_t)a.pass * a.st.tile_stride + tile) * 256;
-    // Decoupled look-back, a window at a time: all kLookWindow loads of a step are independent (one memory round trip
-    // for up to 16 predecessors instead of one per predecessor — with every tile resident at once a serial walk grows
-    // like sqrt(2 * tiles) round trips, which was most of a pass), consumed nearest first up to the first inclusive
-    // prefix; words not published yet are polled again.
-    uint32_t before = 0;  // keys of digit d in the tiles before this one
-    if (tile == 0) {
-        __hip_atomic_store(&status[d], kFlagPrefix | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(&status[d], kFlagAggregate | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t* first_tile = a.st.status + (size_t)a.pass * a.st.tile_stride * 256 + d;
-        int32_t p = (int32_t)tile - 1;  // nearest predecessor not consumed yet
-        bool done = false;
-        while (!done) {
-            uint32_t v[kLookWindow];
-#pragma unroll
-            for (int32_t i = 0; i < (int32_t)kLookWindow; i++)
-                v[i] = p - i >= 0 ? __hip_atomic_load(first_tile + (size_t)(p - i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                  : kFlagPrefix;  // in front of tile 0: nothing
-            bool open = true;
-            int32_t consumed = 0;
-#pragma unroll
-            for (int32_t i = 0; i < (int32_t)kLookWindow; i++) {
-                const uint32_t flag = v[i] & kFlagMask;
-                open = open && flag != 0;
-                if (open) {
-                    before += v[i] & kCountMask;
-                    consumed++;
-                    if (flag == kFlagPrefix) {
-                        done = true;
-                        open = false;
-                    }
-                }
-            }
-            p -= consumed;
-            if (consumed == 0)
-                __builtin_amdgcn_s_sleep(2);
-        }
-        __hip_atomic_store(&status[d], kFlagPrefix | (before + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     GV_TRACE(2)
+    {  // one thread per digit: the tile's counts, for the scatter kernel and for the tile's group
+        const uint32_t d = threadIdx.x;
+        const uint32_t tile_count = wcount[0][d] + wcount[1][d] + wcount[2][d] + wcount[3][d];
+        a.st.tile_hist[(size_t)tile * 256 + d] = tile_count;
+        if (tile_count)
+            atomicAdd(&a.st.group_hist[((size_t)a.pass * a.st.groups + tile / kSortGroup) * 256 + d], tile_count);
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kSortRounds; r++) {  // rank among the TILE's keys of the digit: the waves before mine come first
+        const uint32_t j = wave_base + r * 64 + lane;
+        if (j < n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            uint32_t rank = local[r];
+#pragma unroll
+            for (uint32_t w = 0; w < 3; w++)
+                rank += w < wave ? wcount[w][d] : 0u;
+            a.ranks[j] = (uint16_t)rank;
+        }
+    }
+    GV_TRACE(3)
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
+{
+    __shared__ uint32_t tile_excl[256];   // exclusive scan of the tile's digit counts (tile-local sorted order)
+    __shared__ uint32_t dst_base[256];    // global position of the tile's first key of each digit
+    __shared__ uint32_t skey[kSortTile];  // the tile reordered by digit
+    __shared__ uint32_t sval[kSortTile];
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t n = min(*a.count, a.capacity);
+    const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
+    if (blockIdx.x >= tiles)
+        return;
+    const uint32_t tile = blockIdx.x;
+    GV_TRACE(4)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t shift = a.pass * 8;
+    const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / 4);
+    uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kSortRounds; r++) {
+        const uint32_t j = wave_base + r * 64 + lane;
+        const bool valid = j < n;
+        if (FIRST) {
+            key[r] = valid ? order_key(a.dist_in[j], a.descending) : 0xFFFFFFFFu;
+            val[r] = j;
+        } else {
+            key[r] = valid ? a.keys_in[j] : 0xFFFFFFFFu;
+            val[r] = valid ? a.vals_in[j] : 0u;
+        }
+        rank[r] = valid ? (uint32_t)a.ranks[j] : 0u;
+    }
+    // one thread per digit: same-digit keys in the tiles before this one = whole groups + the tiles before it in its group
+    const uint32_t d = threadIdx.x;
+    const uint32_t tile_count = a.st.tile_hist[(size_t)tile * 256 + d];
+    const uint32_t group = tile / kSortGroup;
+    const uint32_t* __restrict__ gh = a.st.group_hist + (size_t)a.pass * a.st.groups * 256 + d;
+    const uint32_t* __restrict__ th = a.st.tile_hist + d;
+    const uint32_t live_groups = (tiles + kSortGroup - 1) / kSortGroup;
+    uint32_t before = 0, digit_total = 0;  // ... and the digit's count over ALL tiles (the global histogram, summed on the spot)
+#pragma unroll 8
+    for (uint32_t g = 0; g < live_groups; g++) {
+        const uint32_t c = gh[(size_t)g * 256];
+        digit_total += c;
+        before += g < group ? c : 0u;
+    }
+#pragma unroll 8
+    for (uint32_t u = group * kSortGroup; u < tile; u++)
+        before += th[(size_t)u * 256];
+    GV_TRACE_AFTER_LOADS(5)
     uint32_t total;
-    const uint32_t gbase = block_exclusive_scan(a.st.ghist[a.pass * 256 + d], wave_sum, &total);  // keys of lower digits, all tiles
+    const uint32_t gbase = block_exclusive_scan(digit_total, wave_sum, &total);  // keys of lower digits, all tiles
     const uint32_t texcl = block_exclusive_scan(tile_count, wave_sum, &total);                   // ... in this tile
     tile_excl[d] = texcl;
     dst_base[d] = gbase + before;
-    wcount[0][d] = texcl;  // per-wave bases in the tile-local sorted order
-    wcount[1][d] = texcl + c0;
-    wcount[2][d] = texcl + c0 + c1;
-    wcount[3][d] = texcl + c0 + c1 + c2;
     __syncthreads();
-    GV_TRACE(3)
-    // ---- C: reorder the tile by digit in LDS, then write every digit's run to its place ----
+    GV_TRACE(6)
+    // reorder the tile by digit in LDS, then write every digit's run to its place
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {
         const uint32_t j = wave_base + r * 64 + lane;
         if (j < n) {
-            const uint32_t lpos = wcount[wave][(key[r] >> shift) & 255u] + local[r];
+            const uint32_t lpos = tile_excl[(key[r] >> shift) & 255u] + rank[r];
             skey[lpos] = key[r];
             sval[lpos] = val[r];
         }
     }
     __syncthreads();
-    GV_TRACE(4)
+    GV_TRACE(7)
     const uint32_t live = min(kSortTile, n - tile * kSortTile);
     if (!LAST) {
 #pragma unroll 4
@@ -330,12 +276,14 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const SortPassArgs a)
             a.keys_out[pos] = k;
             a.vals_out[pos] = v;
         }
-        GV_TRACE(5)
+        GV_TRACE(8)
         return;
     }
     // LAST: the records go straight to their sorted positions. distanceSq is the key itself (order_key is a bijection:
-    // no gather), the pool slot is a 4-byte gather from an array that fits the caches, the 48-byte model is gathered by
-    // three lanes per record (one float4 each), so that the stores of a run of records are whole contiguous rows.
+    // no gather), the pool slot is a 4-byte gather from an array that fits the caches (carrying the slots through the passes
+    // instead was measured: the last pass 101 -> 75 us, the other three scatter kernels + 4-7 us each, no gain end to end),
+    // the 48-byte model is gathered by three lanes per record (one float4 each), so that the stores of a run of records are
+    // whole contiguous rows.
     for (uint32_t t = threadIdx.x; t < live; t += 256) {
         const uint32_t k = skey[t], v = sval[t];  // v = the record's index before the sort
         const uint32_t dd = (k >> shift) & 255u;
@@ -353,7 +301,7 @@ __global__ __launch_bounds__(256) void onesweep_kernel(const SortPassArgs a)
         const uint32_t t = q / 3u, part = q - t * 3u;
         dst[(size_t)skey[t] * 3 + part] = src[(size_t)sval[t] * 3 + part];
     }
-    GV_TRACE(5)
+    GV_TRACE(8)
 }
 
 // Small pools (up to kSmallSort records possible): ONE launch instead of fourteen — a tick of an engine-sized scene
@@ -454,28 +402,22 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         return hipGetLastError();
     }
     const uint32_t tiles = (capacity + kSortTile - 1) / kSortTile;  // at full capacity; the live count is on the device
-    SortState st;
-    st.ghist = b.ghist[b.parity];
-    st.tile_counter = b.tile_counter[b.parity];
-    st.ghist_next = b.ghist[b.parity ^ 1u];
-    st.tile_counter_next = b.tile_counter[b.parity ^ 1u];
-    st.status = b.status;
-    st.tile_stride = tiles;
-    hipLaunchKernelGGL(sort_prepare_kernel, dim3(tiles), dim3(256), 0, stream, b.dist_in, b.count, capacity,
-                       descending ? 1u : 0u, st);
     SortPassArgs a{};
+    a.st.groups = sort_group_count(capacity);
+    a.st.set_words = sort_set_words(capacity);
+    a.st.group_hist = b.counters[b.parity];
+    a.st.next_set = b.counters[b.parity ^ 1u];
+    a.st.tile_hist = b.tile_hist;
     a.count = b.count;
     a.capacity = capacity;
     a.descending = descending ? 1u : 0u;
-    static const uint32_t static_tiles = getenv("GV_DEBUG_SORT_STATIC_TILES") ? 1u : 0u;
-    a.static_tiles = static_tiles;
     a.dist_in = b.dist_in;
     a.idx_in = b.idx_in;
     a.model_in = b.model_in;
     a.idx_out = b.idx_out;
     a.model_out = b.model_out;
     a.dist_out = b.dist_out;
-    a.st = st;
+    a.ranks = b.ranks;
     for (uint32_t pass = 0; pass < 4; pass++) {
         const uint32_t src = (pass & 1u) ^ 1u, dst = pass & 1u;  // pass 0 writes set 0, pass 1 set 1, ...
         a.pass = pass;
@@ -483,12 +425,16 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         a.vals_in = b.vals[src];
         a.keys_out = b.keys[dst];
         a.vals_out = b.vals[dst];
-        if (pass == 0)
-            hipLaunchKernelGGL((onesweep_kernel<true, false>), dim3(tiles), dim3(256), 0, stream, a);
-        else if (pass == 3)
-            hipLaunchKernelGGL((onesweep_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, a);
-        else
-            hipLaunchKernelGGL((onesweep_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, a);
+        if (pass == 0) {
+            hipLaunchKernelGGL(sort_rank_kernel<true>, dim3(tiles), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL((sort_scatter_kernel<true, false>), dim3(tiles), dim3(256), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(sort_rank_kernel<false>, dim3(tiles), dim3(256), 0, stream, a);
+            if (pass == 3)
+                hipLaunchKernelGGL((sort_scatter_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((sort_scatter_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, a);
+        }
     }
     return hipGetLastError();
 }

@@ -5,19 +5,30 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/evidence
 rm -rf $out; mkdir -p $out
 {
-  echo "# tools/onesweep_probe (built with -DGV_SORT_TRACE): gv_sort, capacity 10 M slots; times in us"
+  echo "# tools/onesweep_probe: gv_sort (rank kernel + scatter kernel per digit), capacity 10 M slots; times in us"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Igarden_amd/csrc tools/onesweep_probe.hip -o /tmp/onesweep_plain 2>/dev/null
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DGV_SORT_TRACE -Igarden_amd/csrc tools/onesweep_probe.hip -o /tmp/onesweep_probe 2>/dev/null
+  timeout 120 /tmp/onesweep_plain 2124723 10000000
+  timeout 120 /tmp/onesweep_plain 308383 10000000
+  timeout 120 /tmp/onesweep_plain 9900000 10000000
+  echo "# the same with wall-clock stamps per tile and phase (-DGV_SORT_TRACE; a few us slower)"
   timeout 120 /tmp/onesweep_probe 2124723 10000000
-  timeout 120 /tmp/onesweep_probe 308383 10000000
   echo
   echo "# tools/sort_bench.py (through the C-ABI, cull + emit + gv_sort per frame, 50 frames; hipEvents)"
   timeout 200 python3 tools/sort_bench.py 2>&1 | grep records
   echo
-  echo "# ranking variants measured on the way (same probe, same sizes; kept: the first)"
-  echo "#   8-ballot match + wave-private LDS running counts (kept)            loads+rank 6.4-7.0 us/tile median, 112-118 VGPRs, gv_sort 223-231 us"
-  echo "#   LDS lane-mask table (atomicOr + read back) instead of the ballots  loads+rank 6.4-9.3 us, no gain: the dependent LDS round trips replace the ALU"
-  echo "#   4 rotating mask tables + returning LDS atomics for all 16 rounds   loads+rank 5.4-8.7 us but 9-12 VGPR spills at 128 VGPRs, reorder 0.9 -> 2.4-3.5 us, gv_sort 238-253 us"
-  echo "#   static tile ids (blockIdx.x) instead of tickets                    gv_sort 223 -> 211 us; correct only under in-order dispatch: not kept"
+  echo "# tools/permute_probe: the last pass's job in isolation — 48-byte records through a random permutation"
+  hipcc --offload-arch=gfx950 -O3 tools/permute_probe.hip -o /tmp/permute_probe 2>/dev/null
+  timeout 120 /tmp/permute_probe 2124723
+  echo
+  echo "# history of the large sort (2 124 723 records, same probe / same sizes):"
+  echo "#   round 1: 14 launches (4 x hist / scan / scatter, keys, gather)                                   349 us"
+  echo "#   round 2a: onesweep — one launch per digit with a decoupled look-back (+ a histogram launch)      223-231 us; a pass = 38-42 us of which 9-16 us"
+  echo "#             waiting for predecessor tiles (every tile is resident at once: the look-back is a serial chain through memory); a 64-word window: 269 us"
+  echo "#   round 2b (kept): rank kernel + scatter kernel per digit, no inter-workgroup waiting at all      203-207 us; a pass = 11 + 2 + 10 us, the last one + 90 us"
+  echo "#             of record gather (the isolated gather above: 70 us — sector-granular random reads, the floor of this pass)"
+  echo "#   ranking variants measured on the way (kept: 8-ballot match + wave-private LDS running counts): LDS lane-mask tables (no gain), 4 rotating mask tables"
+  echo "#             with returning LDS atomics (spills at 128 VGPRs), static tile ids under the look-back form (-12 us, unsafe there; the kept form needs no ids)"
 } > $out/r02_sort_probe.txt 2>&1
 {
   echo "# tests/cpp/headless_tick --mode gpu --ticks 2000 <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the drop-in's prepare phase)"
