@@ -1097,6 +1097,66 @@ int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, c
     return GV_OK;
 }
 
+int gv_pool_results_instance_bases(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const uint32_t** bases, uint32_t* count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!bases || !count || !view_of(ctx, pool_id, view_index))
+        return ctx->fail(GV_E_ARG, "gv_pool_results_instance_bases: pool %u view %u has no results", pool_id, view_index);
+    if (!view_of(ctx, pool_id, view_index)->emitted)
+        return ctx->fail(GV_E_STATE, "gv_pool_results_instance_bases: pool %u view %u was culled count-only (GV_CULL_NO_RECORDS)", pool_id,
+                         view_index);
+    GvResult r;
+    if (int rc = gv_pool_results_fetch(ctx, pool_id, view_index, 0, &r))  // (published results are only looked up)
+        return rc;
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
+    PoolState& pool = ctx->pools[pool_id];
+    const uint32_t n = r.draw_count;
+    vs.instance_bases.resize((size_t)n + 1);
+    uint32_t* out = vs.instance_bases.data();
+    const bool counted = pool.ready.ptr && pool.bound && pool.occupancy == vs.occupancy;
+    const bool as_records = vs.records_fetched;
+    const RecordLayout L = pool.record_layout;
+    auto slot_of = [&](uint32_t k) -> uint32_t {
+        if (!as_records)
+            return vs.h_visible_idx.ptr[k];
+        uint64_t offset;
+        memcpy(&offset, vs.h_records.ptr + (size_t)k * L.stride + L.component_offset, 8);
+        return (uint32_t)(offset / L.component_stride);
+    };
+    // exclusive prefix in two passes over fixed chunks: chunk sums in parallel, their prefix serially, the fill in parallel
+    constexpr uint32_t kChunk = 1u << 16;
+    const uint32_t chunks = (n + kChunk - 1) / kChunk;
+    std::vector<uint64_t> chunk_base((size_t)chunks + 1, 0);
+    if (counted)
+        parallel_ranges(0, chunks, [&](uint32_t ca, uint32_t cb) {
+            for (uint32_t c = ca; c < cb; c++) {
+                uint64_t sum = 0;
+                for (uint32_t k = c * kChunk, e = std::min(n, (c + 1) * kChunk); k < e; k++)
+                    sum += pool.ready_count(slot_of(k));
+                chunk_base[c + 1] = sum;
+            }
+        });
+    else
+        for (uint32_t c = 0; c < chunks; c++)
+            chunk_base[c + 1] = std::min(n, (c + 1) * kChunk) - c * kChunk;
+    for (uint32_t c = 0; c < chunks; c++)
+        chunk_base[c + 1] += chunk_base[c];
+    parallel_ranges(0, chunks, [&](uint32_t ca, uint32_t cb) {
+        for (uint32_t c = ca; c < cb; c++) {
+            uint32_t at = (uint32_t)chunk_base[c];
+            for (uint32_t k = c * kChunk, e = std::min(n, (c + 1) * kChunk); k < e; k++) {
+                out[k] = at;
+                at += counted ? pool.ready_count(slot_of(k)) : 1u;
+            }
+        }
+    });
+    out[n] = (uint32_t)chunk_base[chunks];
+    *bases = out;
+    *count = n;
+    return GV_OK;
+}
+
 int gv_results_device(GvCtx* ctx, uint32_t view_index, GvDeviceResult* out)
 {
     return ctx ? gv_pool_results_device(ctx, ctx->last_pool, view_index, out) : GV_E_ARG;

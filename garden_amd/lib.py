@@ -114,6 +114,7 @@ EXPORTS = [
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records",
+    "gv_pool_results_instance_bases",
 ]
 
 _lib = None
@@ -193,6 +194,7 @@ def load():
     lib.gv_pool_sort.argtypes = [P, u32, u32, C.c_int]
     lib.gv_pool_set_record_layout.argtypes = [P, u32, C.POINTER(GvRecordLayout)]
     lib.gv_pool_results_records.argtypes = [P, u32, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]
+    lib.gv_pool_results_instance_bases.argtypes = [P, u32, u32, C.POINTER(C.POINTER(u32)), C.POINTER(u32)]
     lib.gv_cull_batch_begin.argtypes = [P]
     lib.gv_cull_batch_end.argtypes = [P]
     for name in EXPORTS:
@@ -391,6 +393,12 @@ class GpuVisibility:
             return np.zeros(0, dtype)
         raw = (C.c_uint8 * (n.value * dtype.itemsize)).from_address(ptr.value)
         return np.frombuffer(raw, dtype=np.uint8).copy().view(dtype)  # bytewise: a structured copy would skip the padding
+
+    def instance_bases(self, pool_id=0, view_index=0):
+        """First instance index of every fetched record ([count + 1] words; the last one is instance_count)."""
+        ptr, n = C.POINTER(C.c_uint32)(), C.c_uint32()
+        self._check(self.lib.gv_pool_results_instance_bases(self.ctx, pool_id, view_index, C.byref(ptr), C.byref(n)))
+        return np.ctypeslib.as_array(ptr, shape=(n.value + 1,)).copy()
 
     def results_device(self, view_index=0):
         d = GvDeviceResult()

@@ -255,6 +255,14 @@ int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout
  * pinned memory, valid until the next gv_cull of that pool). GV_E_STATE when the pool has no record layout. */
 int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count);
 
+/* The first instance index of every fetched record: bases[k] = sum of the ready counts (gv_pool_bind_ready; 1 per record
+ * without) of records [0, k), bases[*count] = the view's instance_count. This is what `instanceCount.fetch_add(
+ * getInstancesAsync(view))` hands out draw by draw in the reference's render loops (mesh.cpp:596-599, :624-627, :709-712),
+ * available up front and in record order (after gv_sort: in sorted order), so a threaded draw loop needs no atomic and
+ * gives the same instance layout every frame. Library-owned host memory ([*count + 1] words), valid until the next gv_cull
+ * of the pool; fetches the results first if that has not happened yet. GV_E_STATE for a count-only view. */
+int gv_pool_results_instance_bases(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const uint32_t** bases, uint32_t* count);
+
 /* A tick of engine-sized pools (the reference's everyday 10^3..10^4 entities per mesh system) is bound by launches,
  * not by bytes. Between gv_cull_batch_begin and the first call that reads results (gv_pool_results_* / gv_results_* /
  * gv_wait, or gv_cull_batch_end), gv_cull of a pool of up to 16384 slots whose views all emit records only RECORDS the

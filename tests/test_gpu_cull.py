@@ -1304,3 +1304,47 @@ def test_rg16f_conversion_on_every_half_and_its_float_neighbours(oracle):
     for i in sample:  # and the level really is the per-value conversion
         lo, hi = lib.gvo_half_to_float(lib.gvo_half_directed(float(vals[i]), 0)), lib.gvo_half_to_float(lib.gvo_half_directed(float(vals[i]), 1))
         assert (flat[i, 0] == lo or (np.isnan(lo) and np.isnan(flat[i, 0]))) and (flat[i, 1] == hi or (np.isnan(hi) and np.isnan(flat[i, 1])))
+
+
+@pytest.mark.parametrize("n", [6_000, 200_000])  # published small pool / large pool (chunked prefix, radix sort)
+def test_instance_bases_are_the_reference_draw_loops_fetch_adds(oracle, n):
+    """gv_pool_results_instance_bases: bases[k] = what `instanceCount.fetch_add(getInstancesAsync(view))` returns for draw k
+    in the reference's single-threaded draw loop (mesh.cpp:617-631) — the running sum of the records' ready counts in record
+    order (sorted order after gv_sort), total = instance_count; identity without ready counts; same from the three arrays
+    and from the struct records; a count-only view has none."""
+    from garden_amd.lib import GpuVisibility
+    sc = scene.flat_scene(n, seed=n + 1)
+    main = scene.main_camera_view()
+    ready = np.random.default_rng(n).choice(np.array([0, 1, 1, 2, 5], np.uint32), n)
+    component = int(sc.meshes.dtype.itemsize)
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        vis.cull(0, [main])
+        got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0, order="raw")
+        bases = vis.instance_bases(0, 0)
+        assert bases.shape[0] == got["draw_count"] + 1 and np.array_equal(bases, np.arange(got["draw_count"] + 1, dtype=np.uint32))
+        vis.bind_ready(0, ready)
+        for layout in (None, RECORD_DTYPES["packed"][0]):
+            vis.set_record_layout(0, layout, component_stride=component)
+            vis.cull(0, [main])
+            vis.sort(0, descending=True, pool_id=0)
+            bases = vis.instance_bases(0, 0)  # before any fetch: it fetches
+            got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0, order="raw")
+            if layout is None:
+                slots, dist = got["visible_idx"].astype(np.int64), got["distance_sq"]
+            else:
+                rec = vis.records(0, 0, layout)
+                slots, dist = (rec["componentOffset"] // component).astype(np.int64), rec["distanceSq"]
+            assert slots.shape[0] == got["draw_count"] > 0 and np.all(np.diff(dist) <= 0)
+            counts = ready[slots]
+            assert np.all(counts > 0)
+            expect = np.concatenate([[0], np.cumsum(counts, dtype=np.uint64)]).astype(np.uint32)
+            assert np.array_equal(bases, expect) and int(bases[-1]) == got["instance_count"]
+            exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, main, ready=ready)
+            assert exp["instance_count"] == got["instance_count"] and exp["draw_count"] == got["draw_count"]
+        vis.cull(0, [dict(main, emit_records=0)])
+        with pytest.raises(RuntimeError) as e:
+            vis.instance_bases(0, 0)
+        assert "count-only" in str(e.value)
