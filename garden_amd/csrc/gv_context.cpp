@@ -1512,6 +1512,27 @@ int gv_stats_reset(GvCtx* ctx)
     memset(ctx->stats.device_ms, 0, sizeof(ctx->stats.device_ms));
     ctx->stats.upload_bytes = 0;
     ctx->bounds_blocks_total = 0;
+    memset(ctx->profile_seen, 0, sizeof(ctx->profile_seen));
+    memset(ctx->profile_timed, 0, sizeof(ctx->profile_timed));
+    return GV_OK;
+}
+
+int gv_profile_sampling(GvCtx* ctx, uint32_t every)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (every == 0)
+        return ctx->fail(GV_E_ARG, "gv_profile_sampling: every must be at least 1");
+    ctx->profile_every = every;
+    memset(ctx->profile_seen, 0, sizeof(ctx->profile_seen));
+    return GV_OK;
+}
+
+int gv_profile_samples(GvCtx* ctx, uint64_t samples[GV_K_COUNT])
+{
+    if (!ctx || !samples)
+        return GV_E_ARG;
+    memcpy(samples, ctx->profile_timed, sizeof(ctx->profile_timed));
     return GV_OK;
 }
 

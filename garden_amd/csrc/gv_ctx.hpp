@@ -335,6 +335,8 @@ struct Context {
     std::vector<PendingEvent> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     GvStats stats{};
+    uint32_t profile_every = 1;                      // gv_profile_sampling
+    uint64_t profile_seen[GV_K_COUNT] = {}, profile_timed[GV_K_COUNT] = {};
 
     int fail(int code, const char* fmt, ...)
     {
@@ -387,6 +389,8 @@ struct KernelTimer {
             return;
         if ((ctx->config.flags & GV_CONFIG_PROFILE_CULL_ONLY) && k != GV_K_CULL)
             return;
+        if (ctx->profile_seen[k]++ % ctx->profile_every != 0)  // gv_profile_sampling
+            return;
         if (!ctx->free_events.empty()) {
             start = ctx->free_events.back().first;
             stop = ctx->free_events.back().second;
@@ -395,6 +399,8 @@ struct KernelTimer {
             return;
         }
         on = hipEventRecord(start, ctx->stream) == hipSuccess;
+        if (on)
+            ctx->profile_timed[k]++;
     }
     ~KernelTimer()
     {

@@ -114,7 +114,7 @@ EXPORTS = [
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records",
-    "gv_pool_results_instance_bases",
+    "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples",
 ]
 
 _lib = None
@@ -194,6 +194,8 @@ def load():
     lib.gv_pool_sort.argtypes = [P, u32, u32, C.c_int]
     lib.gv_pool_set_record_layout.argtypes = [P, u32, C.POINTER(GvRecordLayout)]
     lib.gv_pool_results_records.argtypes = [P, u32, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]
+    lib.gv_profile_sampling.argtypes = [P, u32]
+    lib.gv_profile_samples.argtypes = [P, C.POINTER(C.c_uint64 * GV_K_COUNT)]
     lib.gv_pool_results_instance_bases.argtypes = [P, u32, u32, C.POINTER(C.POINTER(u32)), C.POINTER(u32)]
     lib.gv_cull_batch_begin.argtypes = [P]
     lib.gv_cull_batch_end.argtypes = [P]
@@ -499,6 +501,16 @@ class GpuVisibility:
 
     def stats_reset(self):
         self._check(self.lib.gv_stats_reset(self.ctx))
+
+    def profile_sampling(self, every):
+        """Bracket only every `every`-th launch of each kernel kind with events (each bracket costs ~5 us of stream time)."""
+        self._check(self.lib.gv_profile_sampling(self.ctx, every))
+
+    def profile_samples(self):
+        """Bracketed launches per kernel kind since stats_reset: the divisor for stats()['device_ms']."""
+        a = (C.c_uint64 * GV_K_COUNT)()
+        self._check(self.lib.gv_profile_samples(self.ctx, C.byref(a)))
+        return {k: int(a[i]) for i, k in enumerate(KERNEL_NAMES)}
 
 
 class Scene:

@@ -430,6 +430,14 @@ typedef struct GvStats {
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);
+/* Measurement aid: with GV_CONFIG_PROFILE_EVENTS, bracket only every `every`-th launch of each kernel kind (1 = all, the
+ * default; the first launch after gv_stats_reset is always one of them). A bracket is two event packets on the stream, ≈ 5 us
+ * of stream time per launch on MI355X (measured: frame 0.164 ms with, 0.159 ms without); bench.py samples so that the timed
+ * region is the frame rather than its instrumentation. GvStats.device_ms then sums the bracketed launches only;
+ * gv_profile_samples tells how many there were per kind since gv_stats_reset (divide by those, not by launches). */
+int gv_profile_sampling(GvCtx* ctx, uint32_t every);
+int gv_profile_samples(GvCtx* ctx, uint64_t samples[GV_K_COUNT]);
+
 /* Measurement aid (bench.py `roofline.measured_stream_peak`): `launches` read-only passes over the five input streams
  * the cull kernel reads from pool `pool_id` (mesh a/b, transform ab/c/flags = 65 bytes per entry), with the cull's own
  * loads and launch geometry, each timed with hipEvents on the context's stream. *gb_per_s = 65 * entries / median
