@@ -4,7 +4,8 @@ Not part of the test tiers (minutes of CPU oracle time); run after touching the 
 conservative pre-tests (sphere bound, block bounds):
     python tools/stress_parity.py [--entities 2000000] [--views 36] [--seed 1]
 Scenes: flat and 3-deep hierarchy; per scene: perspective cameras inside / outside the world in random directions,
-orthographic boxes of random size, Hi-Z on for half of the perspective views; plain and GV_CONFIG_BLOCK_BOUNDS contexts."""
+orthographic boxes of random size, Hi-Z on for half of the perspective views; plain and GV_CONFIG_BLOCK_BOUNDS contexts,
+and (Hi-Z views) a GV_CONFIG_HIZ_RG16F context against the oracle's RG16F pyramid."""
 import argparse
 import os
 import sys
@@ -28,14 +29,15 @@ def main():
     threads = os.cpu_count() or 1
     depth = scene.synthetic_depth(1024, 512)
     hz = oracle.Hiz(depth)
+    hz16 = oracle.Hiz(depth, rg16f=True)
     checked = failures = 0
     t0 = time.time()
     for name, sc in (("flat", scene.flat_scene(args.entities, seed=args.seed + 11)),
                      ("hierarchy", scene.hierarchy_scene(args.entities, depth=3, fanout=8, seed=args.seed + 12))):
         side = 100.0 * sc.count ** (1 / 3)
         ctxs = []
-        for bounds in (False, True):
-            g = GpuVisibility(device=0, block_bounds=bounds)
+        for bounds, rg16f in ((False, False), (True, False), (False, True)):
+            g = GpuVisibility(device=0, block_bounds=bounds, hiz_rg16f=rg16f)
             g.bind_transforms(sc.transforms, sc.entity_to_transform)
             g.bind_pool(0, sc.meshes)
             g.hierarchy_rebuild()
@@ -53,7 +55,14 @@ def main():
             exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v,
                                         hiz=hz if v["use_hiz"] else None, threads=threads)
             order = np.argsort(exp["visible_idx"], kind="stable")
-            for g, label in zip(ctxs, ("plain", "bounds")):
+            exp32, order32 = exp, order
+            for g, label in zip(ctxs, ("plain", "bounds", "rg16f")):
+                exp, order = exp32, order32
+                if label == "rg16f":
+                    if not v["use_hiz"]:
+                        continue
+                    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, hiz=hz16, threads=threads)
+                    order = np.argsort(exp["visible_idx"], kind="stable")
                 g.cull(0, [v])
                 got = g.fetch(0, write_back=False, occupancy=sc.count)
                 same = (got["draw_count"] == exp["draw_count"] and np.array_equal(got["visible_idx"], exp["visible_idx"][order])
