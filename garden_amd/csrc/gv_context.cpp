@@ -379,6 +379,61 @@ int flush_culls(GvCtx* ctx)
     return GV_OK;
 }
 
+// gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
+static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
+    const size_t nblocks = (n + 4095) / 4096;
+    GV_HIP(ctx, vs.alt_idx.reserve(n));
+    GV_HIP(ctx, vs.alt_model.reserve(n * 12));
+    GV_HIP(ctx, vs.alt_dist.reserve(n));
+    for (int k = 0; k < 2; k++) {
+        GV_HIP(ctx, vs.sort_keys[k].reserve(n));
+        GV_HIP(ctx, vs.sort_vals[k].reserve(n));
+    }
+    // sort_hist: [2 sets of counters (global + per-group digit histograms)] + the tiles' digit counts
+    const size_t set_words = sort_set_words((uint32_t)n);
+    const size_t want = 2 * set_words + nblocks * 256;
+    if (want > vs.sort_hist.cap) {
+        GV_HIP(ctx, vs.sort_hist.reserve(want));
+        vs.sort_set_words = 0;
+    }
+    if (vs.sort_set_words != set_words) {  // (a pool that changed size moves the sets: both start at zero again)
+        GV_HIP(ctx, hipMemsetAsync(vs.sort_hist.ptr, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
+        vs.sort_set_words = set_words;
+        vs.sort_parity = 0;
+    }
+    GV_HIP(ctx, vs.sort_ranks.reserve(n));
+    SortBuffers b;
+    b.count = vs.draw_count.ptr;
+    b.idx_in = vs.visible_idx.ptr;
+    b.model_in = vs.baked_model.ptr;
+    b.dist_in = vs.distance_sq.ptr;
+    b.idx_out = vs.alt_idx.ptr;
+    b.model_out = vs.alt_model.ptr;
+    b.dist_out = vs.alt_dist.ptr;
+    b.ranks = vs.sort_ranks.ptr;
+    for (int k = 0; k < 2; k++) {
+        b.keys[k] = vs.sort_keys[k].ptr;
+        b.vals[k] = vs.sort_vals[k].ptr;
+        b.counters[k] = vs.sort_hist.ptr + k * set_words;
+    }
+    b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
+    b.parity = vs.sort_parity;
+    vs.sort_parity ^= 1u;  // this sort leaves the other set zeroed for the next one
+    {
+        KernelTimer t(ctx, GV_K_SORT);
+        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream));
+    }
+    vs.published = false, vs.records_fetched = false;
+    // the sorted records now live in the alternate set: swap it in
+    std::swap(vs.visible_idx, vs.alt_idx);
+    std::swap(vs.baked_model, vs.alt_model);
+    std::swap(vs.distance_sq, vs.alt_dist);
+    return GV_OK;
+}
+
 // gv_sort on a small pool only records the request; the first call that needs the records (fetch, device accessors,
 // gv_wait) sorts every pending view of EVERY pool in ONE launch — five mesh systems with a main camera and three shadow
 // passes each cost one launch, not twenty.
@@ -395,6 +450,13 @@ int flush_sorts(GvCtx* ctx)
                 ViewState& vs = ctx->views[pool][v];
                 if (!vs.valid || !vs.sort_pending)
                     continue;
+                if (vs.occupancy > kBatchSortMaxSlots) {  // deferred (its cull may have been recorded), but not a batch member
+                    const bool descending = vs.sort_pending == 2;
+                    vs.sort_pending = 0;
+                    if (int rc = sort_large(ctx, vs, descending))
+                        return rc;
+                    continue;
+                }
                 const size_t n = vs.occupancy;
                 GV_HIP(ctx, vs.alt_idx.reserve(n));
                 GV_HIP(ctx, vs.alt_model.reserve(n * 12));
@@ -1250,56 +1312,7 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
         vs.published = false, vs.records_fetched = false;
         return GV_OK;
     }
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
-    const size_t nblocks = (n + 4095) / 4096;
-    GV_HIP(ctx, vs.alt_idx.reserve(n));
-    GV_HIP(ctx, vs.alt_model.reserve(n * 12));
-    GV_HIP(ctx, vs.alt_dist.reserve(n));
-    for (int k = 0; k < 2; k++) {
-        GV_HIP(ctx, vs.sort_keys[k].reserve(n));
-        GV_HIP(ctx, vs.sort_vals[k].reserve(n));
-    }
-    // sort_hist: [2 sets of counters (global + per-group digit histograms)] + the tiles' digit counts
-    const size_t set_words = sort_set_words((uint32_t)n);
-    const size_t want = 2 * set_words + nblocks * 256;
-    if (want > vs.sort_hist.cap) {
-        GV_HIP(ctx, vs.sort_hist.reserve(want));
-        vs.sort_set_words = 0;
-    }
-    if (vs.sort_set_words != set_words) {  // (a pool that changed size moves the sets: both start at zero again)
-        GV_HIP(ctx, hipMemsetAsync(vs.sort_hist.ptr, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
-        vs.sort_set_words = set_words;
-        vs.sort_parity = 0;
-    }
-    GV_HIP(ctx, vs.sort_ranks.reserve(n));
-    SortBuffers b;
-    b.count = vs.draw_count.ptr;
-    b.idx_in = vs.visible_idx.ptr;
-    b.model_in = vs.baked_model.ptr;
-    b.dist_in = vs.distance_sq.ptr;
-    b.idx_out = vs.alt_idx.ptr;
-    b.model_out = vs.alt_model.ptr;
-    b.dist_out = vs.alt_dist.ptr;
-    b.ranks = vs.sort_ranks.ptr;
-    for (int k = 0; k < 2; k++) {
-        b.keys[k] = vs.sort_keys[k].ptr;
-        b.vals[k] = vs.sort_vals[k].ptr;
-        b.counters[k] = vs.sort_hist.ptr + k * set_words;
-    }
-    b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
-    b.parity = vs.sort_parity;
-    vs.sort_parity ^= 1u;  // this sort leaves the other set zeroed for the next one
-    {
-        KernelTimer t(ctx, GV_K_SORT);
-        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending != 0, ctx->stream));
-    }
-    vs.published = false, vs.records_fetched = false;
-    // the sorted records now live in the alternate set: swap it in
-    std::swap(vs.visible_idx, vs.alt_idx);
-    std::swap(vs.baked_model, vs.alt_model);
-    std::swap(vs.distance_sq, vs.alt_dist);
-    return GV_OK;
+    return sort_large(ctx, vs, descending != 0);
 }
 
 int gv_sweep(GvCtx* ctx, uint32_t mode)

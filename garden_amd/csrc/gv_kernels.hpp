@@ -147,7 +147,7 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
 // gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
 constexpr uint32_t kPublishMaxSlots = 262144;
-constexpr uint32_t kPublishLdsSlots = 16384;
+constexpr uint32_t kPublishLdsSlots = 32768;
 // the caller's record struct (GvRecordLayout); stride == 0: none
 struct RecordLayout {
     uint32_t stride, component_offset, baked_model, distance_sq, buffer_index, component_stride, buffer_index_value;
@@ -201,9 +201,14 @@ constexpr uint32_t kSortGroupTiles = 32;
 inline uint32_t sort_group_count(uint32_t capacity) { return ((capacity + 4095u) / 4096u + kSortGroupTiles - 1u) / kSortGroupTiles; }
 inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count(capacity) * 256u; }
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
-// pools of up to this many slots sort in one launch (rank sort, gv_sort.hip); gv_sort defers those so that the views of
-// one cull share a single launch (launch_sort_small_batch) when their results are first asked for
-constexpr uint32_t kSmallSortMaxSlots = 16384;
+// Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
+// asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
+// launch for all views (rank sort, launch_sort_small_batch: O(n^2 / lanes), 11 us at 2 k records, 75 us at 16 k — where the
+// eight radix launches take 70 us whatever the count); larger deferred pools go through launch_sort, where the device's own
+// record count picks the rank sort (up to kRankSortMaxRecords) or the radix sort.
+constexpr uint32_t kSmallSortMaxSlots = 32768;
+constexpr uint32_t kBatchSortMaxSlots = 16384;
+constexpr uint32_t kRankSortMaxRecords = 12288;
 struct SmallSortEntry {  // one view of one small pool
     const uint32_t* count;  // device draw_count
     const uint32_t* idx_in;

@@ -107,6 +107,7 @@ struct SortState {
 struct SortPassArgs {
     const uint32_t* count;
     uint32_t capacity, descending, pass;
+    uint32_t min_records;       // the radix kernels leave at once when the live count is not above this (the rank sort took it)
     const float* dist_in;       // FIRST: keys are built from these
     const uint32_t* keys_in;    // !FIRST
     const uint32_t* vals_in;    // !FIRST
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
     if (FIRST)  // the other parity's counters, for the next sort (nobody reads them during this one)
         for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.st.set_words; k += gridDim.x * 256)
             a.st.next_set[k] = 0;
-    if (blockIdx.x >= tiles)
+    if (blockIdx.x >= tiles || n <= a.min_records)
         return;  // the grid is sized for the capacity, the count lives on the device: surplus workgroups leave at once
     const uint32_t tile = blockIdx.x;
     GV_TRACE(0)
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
     __shared__ uint32_t wave_sum[4];
     const uint32_t n = min(*a.count, a.capacity);
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    if (blockIdx.x >= tiles)
+    if (blockIdx.x >= tiles || n <= a.min_records)
         return;
     const uint32_t tile = blockIdx.x;
     GV_TRACE(4)
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
 // workgroup owns 64 records; its four waves each count over a quarter of the keys (staged in LDS, read as uniform
 // 16-byte broadcasts) and the partial counts meet in LDS. n^2 / 4 comparisons per wave, all CUs busy, no
 // inter-workgroup step: ~6 us at 2 k records where a one-workgroup bitonic network took 42 us.
-constexpr uint32_t kSmallSort = kSmallSortMaxSlots;
+constexpr uint32_t kSmallSort = kBatchSortMaxSlots;
+constexpr uint32_t kMidSortSlots = 1u << 20;  // pools up to this size also get the rank-sort launch (see launch_sort)
 
 // records of [jlo, jhi) (multiples of 4) that order before record i with key ki. WHERE: 0 = every j is below the
 // workgroup's records (ties count), 2 = every j is above them (ties do not), 1 = overlapping (compare the pair)
@@ -332,14 +334,16 @@ __device__ __forceinline__ uint32_t count_before(const uint32_t* key, uint32_t j
     return before;
 }
 
+// max_records: the key table's capacity (LDS); a live count above it leaves the records to the radix kernels behind
 template <class Entry>
-__device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capacity, uint32_t descending, uint32_t block)
+__device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capacity, uint32_t descending, uint32_t block,
+                                                 uint32_t max_records = 0xFFFFFFFFu)
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
     const uint32_t n = min(*b.count, capacity);
     const uint32_t i0 = block * 64;
-    if (i0 >= n)
+    if (i0 >= n || n > max_records)
         return;
     const uint32_t n4 = (n + 3u) & ~3u;
     for (uint32_t j = threadIdx.x; j < n4; j += 256) {
@@ -376,9 +380,9 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     dm[2] = m2;
 }
 
-__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending)
+__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending, uint32_t max_records)
 {
-    sort_small_block(b, capacity, descending, blockIdx.x);
+    sort_small_block(b, capacity, descending, blockIdx.x, max_records);
 }
 
 // several views of one small pool (main camera + shadow passes) in one launch: blockIdx.y picks the view
@@ -392,14 +396,22 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
 {
     if (capacity == 0)
         return hipSuccess;
-    if (capacity <= kSmallSort) {
-        const uint32_t lds = ((capacity + 3u) & ~3u) * 4;  // 64 KB of keys at the limit, beside the 1 KB of partial counts
+    // Short lists sort in one launch whatever the pool's size: a pool of up to kMidSortSlots slots (where only the device
+    // knows how short the visible list is) gets the rank-sort launch AND the radix launches, and the live count decides on
+    // the device which of the two does the work — the other leaves after one load, ~2 us per launch, against 70 us for
+    // the eight radix launches on a few thousand records. Measured crossover: ~12 k records (rank 11 us at 2 k, 75 us at
+    // 16 k, 160 us at 32 k).
+    const bool rank_sort = capacity <= kMidSortSlots;
+    if (rank_sort) {
+        const uint32_t records = capacity <= kSmallSort ? capacity : kRankSortMaxRecords;
+        const uint32_t lds = ((records + 3u) & ~3u) * 4;  // the key table, beside the 1 KB of partial counts
         static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
         if (raised != hipSuccess)
             return raised;
-        hipLaunchKernelGGL(sort_small_kernel, dim3((capacity + 63) / 64), dim3(256), lds, stream, b, capacity, descending ? 1u : 0u);
-        return hipGetLastError();
+        hipLaunchKernelGGL(sort_small_kernel, dim3((records + 63) / 64), dim3(256), lds, stream, b, capacity, descending ? 1u : 0u, records);
+        if (capacity <= kSmallSort)
+            return hipGetLastError();
     }
     const uint32_t tiles = (capacity + kSortTile - 1) / kSortTile;  // at full capacity; the live count is on the device
     SortPassArgs a{};
@@ -411,6 +423,7 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     a.count = b.count;
     a.capacity = capacity;
     a.descending = descending ? 1u : 0u;
+    a.min_records = rank_sort ? kRankSortMaxRecords : 0u;
     a.dist_in = b.dist_in;
     a.idx_in = b.idx_in;
     a.model_in = b.model_in;

@@ -265,9 +265,9 @@ int gv_pool_results_instance_bases(GvCtx* ctx, uint32_t pool_id, uint32_t view_i
 
 /* A tick of engine-sized pools (the reference's everyday 10^3..10^4 entities per mesh system) is bound by launches,
  * not by bytes. Between gv_cull_batch_begin and the first call that reads results (gv_pool_results_* / gv_results_* /
- * gv_wait, or gv_cull_batch_end), gv_cull of a pool of up to 16384 slots whose views all emit records only RECORDS the
+ * gv_wait, or gv_cull_batch_end), gv_cull of a pool of up to 32768 slots whose views all emit records only RECORDS the
  * cull; the first read then launches all recorded culls as ONE kernel, their emits as ONE kernel, the requested sorts
- * (gv_pool_sort) as ONE kernel and publishes every view's results to the host with ONE kernel and ONE synchronisation —
+ * (gv_pool_sort; pools of up to 16384 slots) as ONE kernel and publishes every view's results to the host with ONE kernel and ONE synchronisation —
  * four launches per frame however many mesh systems and shadow passes there are. Other culls (larger pools, count-only
  * views, GV_SWEEP_WITH_CULL, block bounds) run at once as usual. Same results. Do not re-bind or mark a pool dirty
  * between its gv_cull and the first read of the batch. */
@@ -306,9 +306,10 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode);
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
  * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: equal keys keep the order the records were
  * emitted in (std::sort in the reference leaves ties unspecified).
- * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. For pools of up to 16384 slots
+ * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. For pools of up to 32768 slots
  * the launch is deferred to the first call that reads the records (gv_results_*, gv_wait), where the pending sorts of
- * all views share one launch. */
+ * all views of up to 16384 slots share one launch. Pools of up to 2^20 slots get a one-launch rank sort AND the radix
+ * launches, and the record count on the device decides which of them works (short lists: one launch's worth of time). */
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
 
 /* ---- scene ingest: a Garden scene file straight into column pools, no component AoS ----
