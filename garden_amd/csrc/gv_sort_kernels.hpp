@@ -1,0 +1,59 @@
+// gv_sort_kernels.hpp — launch interface of gv_sort.hip (kept apart from gv_kernels.hpp: bench.py hashes that file to tell
+// whether the cull kernels changed since the PMC counters in profiles/traffic.json were collected; the sort does not
+// enter into that).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gv {
+
+constexpr uint32_t kMaxSortViews = 32;  // views of SEVERAL pools per batch launch (== kMaxPublishViews, checked in gv_kernels.hpp)
+
+// sortMeshes (mesh.cpp:265-328): stable LSD radix sort of the compact records by distanceSq.
+struct SortBuffers {
+    const uint32_t* count;  // device draw_count
+    const uint32_t* idx_in;
+    const float* model_in;
+    const float* dist_in;
+    uint32_t* idx_out;
+    float* model_out;
+    float* dist_out;
+    // large pools (radix sort, gv_sort.hip):
+    uint32_t* keys[2];       // (key, record index) pairs, ping-pong
+    uint32_t* vals[2];
+    uint16_t* ranks;         // per key: rank among its tile's keys of the current digit
+    uint32_t* counters[2];   // two sets of sort_set_words(capacity) words — per-group digit counts [4][groups][256]: a sort
+                             // uses set `parity` (zero on entry) and zeroes the other
+    uint32_t* tile_hist;     // [ceil(capacity / 4096)][256] digit counts of every tile (rewritten by each pass)
+    uint32_t parity;
+};
+constexpr uint32_t kSortGroupTiles = 32;
+inline uint32_t sort_group_count(uint32_t capacity) { return ((capacity + 4095u) / 4096u + kSortGroupTiles - 1u) / kSortGroupTiles; }
+inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count(capacity) * 256u; }
+hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
+// Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
+// asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
+// launch for all views (rank sort, launch_sort_small_batch: O(n^2 / lanes), 11 us at 2 k records, 75 us at 16 k — where the
+// eight radix launches take 70 us whatever the count); larger deferred pools go through launch_sort, where the device's own
+// record count picks the rank sort (up to kRankSortMaxRecords) or the radix sort.
+constexpr uint32_t kSmallSortMaxSlots = 32768;
+constexpr uint32_t kBatchSortMaxSlots = 16384;
+constexpr uint32_t kRankSortMaxRecords = 12288;
+struct SmallSortEntry {  // one view of one small pool
+    const uint32_t* count;  // device draw_count
+    const uint32_t* idx_in;
+    const float* model_in;
+    const float* dist_in;
+    uint32_t* idx_out;
+    float* model_out;
+    float* dist_out;
+    uint32_t capacity;      // the pool's slot count (upper bound of *count)
+    uint32_t descending;
+};
+struct SortBatch {
+    SmallSortEntry view[kMaxSortViews];  // views of SEVERAL pools per launch
+};
+// max_capacity: the largest entry capacity (sizes the grid and the LDS key table)
+hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t max_capacity, hipStream_t stream);
+
+}  // namespace gv
