@@ -1,0 +1,83 @@
+// Dev tool: what read bandwidth does this box deliver to (a) ONE contiguous stream, (b) five separate streams with the cull
+// kernel's element sizes (16 + 8 + 32 + 8 + 1 B per entry), (c) the same bytes laid out as tiles of 256 entries
+// ([16 B x 256][8 B x 256][32 B x 256][8 B x 256][1 B x 256] = 16 640 B per tile, one workgroup per tile)?
+//   hipcc --offload-arch=gfx950 -O3 tools/read_probe.hip -o /tmp/read_probe && /tmp/read_probe
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef float f32x2n __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 nt16(const float4* p)
+{
+    const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 nt8(const float2* p)
+{
+    const f32x2n v = __builtin_nontemporal_load(reinterpret_cast<const f32x2n*>(p));
+    return make_float2(v.x, v.y);
+}
+
+__global__ __launch_bounds__(256) void one_stream(const float4* __restrict__ a, size_t quads, float* sink)
+{
+    float acc = 0;
+    const size_t base = (size_t)blockIdx.x * 1040;  // 16 640 B per workgroup, as a tile
+    for (uint32_t q = threadIdx.x; q < 1040; q += 256)
+        if (base + q < quads) { const float4 v = nt16(a + base + q); acc += v.x + v.y + v.z + v.w; }
+    if (acc == 12345.678f) *sink = acc;
+}
+
+__global__ __launch_bounds__(256) void five_streams(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                    const float2* __restrict__ c, const unsigned char* __restrict__ f, uint32_t n, float* sink)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0;
+    if (i < n) {
+        const float4 va = nt16(a + i); const float2 vb = nt8(b + i);
+        const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1);
+        const float2 vc = nt8(c + i);
+        acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)f[i];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
+__global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ tiles, uint32_t ntiles, float* sink)
+{
+    const unsigned char* t = tiles + (size_t)blockIdx.x * 16640;
+    const uint32_t k = threadIdx.x;
+    float acc = 0;
+    if (blockIdx.x < ntiles) {
+        const float4 va = nt16(reinterpret_cast<const float4*>(t) + k);
+        const float2 vb = nt8(reinterpret_cast<const float2*>(t + 4096) + k);
+        const float4 x0 = nt16(reinterpret_cast<const float4*>(t + 6144) + 2 * k), x1 = nt16(reinterpret_cast<const float4*>(t + 6144) + 2 * k + 1);
+        const float2 vc = nt8(reinterpret_cast<const float2*>(t + 14336) + k);
+        acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)t[16384 + k];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
+int main()
+{
+    const uint32_t n = 10'000'000, ntiles = (n + 255) / 256;
+    const size_t bytes = (size_t)ntiles * 16640;
+    unsigned char* buf; float* sink;
+    hipMalloc(&buf, bytes + 4096); hipMalloc(&sink, 4); hipMemset(buf, 0, bytes);
+    // the five streams, each its own allocation like the mirror
+    float4 *a, *ab; float2 *b, *c; unsigned char* f;
+    hipMalloc(&a, (size_t)n * 16); hipMalloc(&b, (size_t)n * 8); hipMalloc(&ab, (size_t)n * 32); hipMalloc(&c, (size_t)n * 8); hipMalloc(&f, n);
+    hipMemset(a, 0, (size_t)n * 16); hipMemset(b, 0, (size_t)n * 8); hipMemset(ab, 0, (size_t)n * 32); hipMemset(c, 0, (size_t)n * 8); hipMemset(f, 0, n);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto time = [&](const char* name, auto launch, double gb) {
+        std::vector<float> ms;
+        for (int r = 0; r < 15; r++) { hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1); float t; hipEventElapsedTime(&t, e0, e1); ms.push_back(t); }
+        std::sort(ms.begin(), ms.end());
+        printf("%-44s %7.1f us  %.2f TB/s\n", name, ms[7] * 1000, gb / (ms[7] * 1e-3) / 1e3);
+    };
+    const double gb = 65.0 * n / 1e9;
+    time("one contiguous stream (650 MB)", [&] { hipLaunchKernelGGL(one_stream, dim3(ntiles), dim3(256), 0, 0, (const float4*)buf, bytes / 16, sink); }, bytes / 1e9);
+    time("five streams, one allocation each", [&] { hipLaunchKernelGGL(five_streams, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, f, n, sink); }, gb);
+    time("tiles of 256 entries (16 640 B each)", [&] { hipLaunchKernelGGL(tiled, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, sink); }, gb);
+    return 0;
+}
