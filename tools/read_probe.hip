@@ -43,6 +43,23 @@ __global__ __launch_bounds__(256) void five_streams(const float4* __restrict__ a
     if (acc == 12345.678f) *sink = acc;
 }
 
+// MASK: which of the five streams are read (bit 0 a, 1 b, 2 ab, 3 c, 4 flags)
+template <int MASK>
+__global__ __launch_bounds__(256) void some_streams(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                    const float2* __restrict__ c, const unsigned char* __restrict__ f, uint32_t n, float* sink)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0;
+    if (i < n) {
+        if (MASK & 1) { const float4 v = nt16(a + i); acc += v.x + v.w; }
+        if (MASK & 2) { const float2 v = nt8(b + i); acc += v.x + v.y; }
+        if (MASK & 4) { const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1); acc += x0.x + x0.w + x1.x + x1.w; }
+        if (MASK & 8) { const float2 v = nt8(c + i); acc += v.x + v.y; }
+        if (MASK & 16) acc += (float)f[i];
+    }
+    if (acc == 12345.678f) *sink = acc;
+}
+
 __global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ tiles, uint32_t ntiles, float* sink)
 {
     const unsigned char* t = tiles + (size_t)blockIdx.x * 16640;
@@ -78,6 +95,27 @@ int main()
     const double gb = 65.0 * n / 1e9;
     time("one contiguous stream (650 MB)", [&] { hipLaunchKernelGGL(one_stream, dim3(ntiles), dim3(256), 0, 0, (const float4*)buf, bytes / 16, sink); }, bytes / 1e9);
     time("five streams, one allocation each", [&] { hipLaunchKernelGGL(five_streams, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, f, n, sink); }, gb);
+#define SOME(MASK, BYTES, NAME) time(NAME, [&] { hipLaunchKernelGGL(some_streams<MASK>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, f, n, sink); }, BYTES * n / 1e9)
+    SOME(15, 64.0, "  without the flag bytes (64 B)");
+    SOME(29, 57.0, "  without b (57 B)");
+    SOME(23, 57.0, "  without c (57 B)");
+    SOME(27, 33.0, "  without ab (33 B)");
+    SOME(30, 49.0, "  without a (49 B)");
+    SOME(5, 48.0, "  a + ab only (48 B)");
+    SOME(4, 32.0, "  ab only (32 B)");
+    {  // the five streams back to back in ONE allocation, and the same with odd page offsets between them
+        unsigned char* one; hipMalloc(&one, (size_t)n * 65 + (1u << 24)); hipMemset(one, 0, (size_t)n * 65 + (1u << 24));
+        for (size_t pad : {(size_t)0, (size_t)4096 * 7, (size_t)4096 * 131 + 256}) {
+            unsigned char* p = one;
+            const float4* a2 = (const float4*)p; p += (size_t)n * 16 + pad;
+            const float2* b2 = (const float2*)p; p += (size_t)n * 8 + pad;
+            const float4* ab2 = (const float4*)p; p += (size_t)n * 32 + pad;
+            const float2* c2 = (const float2*)p; p += (size_t)n * 8 + pad;
+            const unsigned char* f2 = p;
+            char name[96]; snprintf(name, sizeof(name), "five streams in one allocation, gaps %zu B", pad);
+            time(name, [&] { hipLaunchKernelGGL(five_streams, dim3(ntiles), dim3(256), 0, 0, a2, b2, ab2, c2, f2, n, sink); }, gb);
+        }
+    }
     time("tiles of 256 entries (16 640 B each)", [&] { hipLaunchKernelGGL(tiled, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, sink); }, gb);
     return 0;
 }
