@@ -81,14 +81,16 @@ def algorithmic_bytes(wl, n, frustum_survivors, visible, depth, fused=False, exa
     """Minimal SoA stream bytes per launch for the cull kernel, and
     for the whole step (for information). `examined`: fraction of the 256-entry workgroups whose streams are read
     (1 without block bounds; with them the rest only write their outputs and read a 32-byte box)."""
-    cull = n * examined * 65.0 + n * (1.0 + 0.125)  # TRS 40 + AABB 24 + flags 1 read; isVisible 1 + ballot word 1/8 written
+    # TRS 40 + AABB 24 + flags 1 read; ballot word 1/8 written (the isVisible bytes are expanded from those words by the emit
+    # kernel: 1 B per entity there, not here)
+    cull = n * examined * 65.0 + n * 0.125
     if examined < 1.0:
         cull += (n / 256.0) * 32.0
     if wl["hier"]:
         cull += n * examined * 4.0  # parent index
     if wl["hiz"]:
         cull += frustum_survivors * 32.0  # 4 texels x (min,max) fp32 per frustum-surviving entity
-    emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125
+    emit = visible * (40.0 + 4.0 + 4.0 + 48.0 + 4.0) + n * 0.125 + n * 1.0
     # level 1 is not stored (DESIGN.md §5): depth read + levels 2..12 written
     hiz = (HIZ_SIZE * HIZ_SIZE * 4 + sum(max(HIZ_SIZE >> k, 1) ** 2 * 8 for k in range(2, 13))) if wl["hiz"] else 0.0
     sweep = n * (40.0 + 4.0 + 48.0) if wl["sweep"] else 0.0

@@ -171,8 +171,14 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     const HizDevice hz = hiz_device(ctx);
     const uint32_t chunks = (p.occupancy + kEmitChunk - 1) / kEmitChunk;
     ViewBuffers vbs[GV_MAX_VIEWS];
-    for (uint32_t v = 0; v < view_count; v++)
+    ViewParams cvps[GV_MAX_VIEWS];  // as the cull kernels see the views: isVisible bytes are left to the emit that follows
+    for (uint32_t v = 0; v < view_count; v++) {
         vbs[v] = view_buffers(ctx->views[pool_id][v]);
+        cvps[v] = vps[v];
+        static const bool cull_writes = getenv("GV_DEBUG_CULL_WRITES_IS_VISIBLE") != nullptr;  // debug A/B: both kernels store the bytes
+        if (ctx->views[pool_id][v].emitted && !cull_writes)
+            cvps[v].write_is_visible = 0;
+    }
     int rc = GV_OK;
     // GV_SWEEP_WITH_CULL: an exactly paired pool takes the fused MFMA sweep + cull for its first view; anything else
     // gets the same results from the plain MFMA sweep followed by the ordinary cull
@@ -229,7 +235,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         }
         if (batched) {
             KernelTimer t(ctx, GV_K_CULL);
-            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, vps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
+            GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, cvps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
         }
         static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
         // a batched cull whose views all want records: ONE self-prefixing emit launch for all of them
@@ -278,9 +284,9 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             if (!batched) {
                 KernelTimer t(ctx, GV_K_CULL);
                 if (fused && v == 0)
-                    GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, vps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
+                    GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
                 else {
-                    GV_HIP(ctx, launch_cull(mesh, xf, hz, vps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
+                    GV_HIP(ctx, launch_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
                 }
             }
             if (ctx->views[pool_id][v].emitted && chunks <= self_max) {
@@ -353,7 +359,12 @@ int flush_culls(GvCtx* ctx)
         ViewBuffers vbs[GV_MAX_VIEWS];
         for (uint32_t v = 0; v < j.view_count; v++)
             vbs[v] = view_buffers(ctx->views[j.pool_id][v]);
-        fill_cull_table_entry(host + cull_off + k * cull_bytes, mesh, xf, hz, j.vps, vbs, j.view_count);
+        ViewParams cvps[GV_MAX_VIEWS];  // (every view of a recorded job emits records: the emit expands isVisible)
+        for (uint32_t v = 0; v < j.view_count; v++) {
+            cvps[v] = j.vps[v];
+            cvps[v].write_is_visible = 0;
+        }
+        fill_cull_table_entry(host + cull_off + k * cull_bytes, mesh, xf, hz, cvps, vbs, j.view_count);
         for (uint32_t v = 0; v < j.view_count; v++) {
             ViewState& vs = ctx->views[j.pool_id][v];
             const uint32_t cur = vs.count_parity, other = cur ^ 1u;

@@ -784,6 +784,22 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             below[threadIdx.x >> 6] = sum;
     }
     __syncthreads();
+    if (args.view.write_is_visible) {
+        // isVisible of this workgroup's quarter of the chunk (mesh.cpp:144,152,161,166), expanded from the ballot words:
+        // lane t owns slots 4t .. 4t + 3 -> one 4-byte store, 1 KB of whole sectors per workgroup
+        const uint32_t local = (block % kEmitParts) * (kEmitChunk / kEmitParts) + 4u * threadIdx.x;  // slot inside the chunk
+        const uint32_t slot = chunk * kEmitChunk + local;
+        if (slot < args.mesh.count) {
+            const uint32_t nibble = (uint32_t)(words[local >> 6] >> (local & 63u)) & 15u;
+            const uint32_t bytes = (nibble & 1u) | ((nibble & 2u) << 7) | ((nibble & 4u) << 14) | ((nibble & 8u) << 21);
+            if (slot + 3u < args.mesh.count) {
+                *reinterpret_cast<uint32_t*>(args.out.is_visible + slot) = bytes;
+            } else {
+                for (uint32_t k = 0; slot + k < args.mesh.count; k++)
+                    args.out.is_visible[slot + k] = (uint8_t)((bytes >> (8u * k)) & 1u);
+            }
+        }
+    }
     uint32_t base;
     if (SELF) {
         base = below[1] + below[2] + below[3];

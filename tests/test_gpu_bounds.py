@@ -51,8 +51,11 @@ def test_bounded_cull_equals_the_per_entity_loop_over_many_views(gpu_bounds, ora
     if kind == "shuffled":
         sc = scene.shuffled_scene(sc, fraction=1.0)
     bind(gpu, sc)
-    gpu.stats_reset()
     side = 100.0 * n ** (1.0 / 3.0)
+    # the session's context may come from a test that changed its pools frame after frame (such pools are culled without
+    # boxes until a quiet frame): one cull settles it, whatever ran before
+    gpu.cull(0, [random_views(1, side, seed=99)[0]])
+    gpu.stats_reset()
     total = examined = 0
     for view in random_views(14, side):
         total += same_as_oracle(gpu, oracle, sc, view)

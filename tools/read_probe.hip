@@ -60,6 +60,52 @@ __global__ __launch_bounds__(256) void some_streams(const float4* __restrict__ a
     if (acc == 12345.678f) *sink = acc;
 }
 
+// the five streams + the cull kernel's outputs: one isVisible byte per entry, one ballot word per wave
+template <bool BYTES, bool WORDS>
+__global__ __launch_bounds__(256) void five_streams_out(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                        const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
+                                                        unsigned char* __restrict__ vis, unsigned long long* __restrict__ mask)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0;
+    if (i < n) {
+        const float4 va = nt16(a + i); const float2 vb = nt8(b + i);
+        const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1);
+        const float2 vc = nt8(c + i);
+        const unsigned long long w = bits[i >> 6];
+        acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)((w >> (i & 63)) & 1);
+    }
+    const bool visible = acc > 1.0f;
+    if (BYTES && i < n)
+        vis[i] = visible ? 1 : 0;
+    const unsigned long long word = __ballot(visible);
+    if (WORDS && (threadIdx.x & 63) == 0)
+        mask[i >> 6] = word;
+}
+
+// ballot words combined per workgroup: 4 lanes store the 4 words of the tile as one 32-byte piece
+__global__ __launch_bounds__(256) void five_streams_words4(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                           const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
+                                                           unsigned long long* __restrict__ mask)
+{
+    __shared__ unsigned long long w4[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0;
+    if (i < n) {
+        const float4 va = nt16(a + i); const float2 vb = nt8(b + i);
+        const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1);
+        const float2 vc = nt8(c + i);
+        const unsigned long long w = bits[i >> 6];
+        acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)((w >> (i & 63)) & 1);
+    }
+    const unsigned long long word = __ballot(acc > 1.0f);
+    if ((threadIdx.x & 63) == 0)
+        w4[threadIdx.x >> 6] = word;
+    __syncthreads();
+    if (threadIdx.x < 4)
+        mask[(size_t)blockIdx.x * 4 + threadIdx.x] = w4[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ tiles, uint32_t ntiles, float* sink)
 {
     const unsigned char* t = tiles + (size_t)blockIdx.x * 16640;
@@ -115,6 +161,15 @@ int main()
             char name[96]; snprintf(name, sizeof(name), "five streams in one allocation, gaps %zu B", pad);
             time(name, [&] { hipLaunchKernelGGL(five_streams, dim3(ntiles), dim3(256), 0, 0, a2, b2, ab2, c2, f2, n, sink); }, gb);
         }
+    }
+    {
+        unsigned char* vis; unsigned long long *mask, *bits;
+        hipMalloc(&vis, n); hipMalloc(&mask, (size_t)n / 8 + 64); hipMalloc(&bits, (size_t)n / 8 + 64); hipMemset(bits, 0xFF, (size_t)n / 8 + 64);
+        time("five streams (bits instead of flag bytes), no outputs", [&] { hipLaunchKernelGGL((five_streams_out<false, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 64.125 * n / 1e9);
+        time("  + a ballot word per wave", [&] { hipLaunchKernelGGL((five_streams_out<false, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 64.25 * n / 1e9);
+        time("  + the 4 ballot words of a workgroup as one 32-byte store", [&] { hipLaunchKernelGGL(five_streams_words4, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask); }, 64.25 * n / 1e9);
+        time("  + an isVisible byte per entry", [&] { hipLaunchKernelGGL((five_streams_out<true, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.125 * n / 1e9);
+        time("  + both (the cull kernel's outputs)", [&] { hipLaunchKernelGGL((five_streams_out<true, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.25 * n / 1e9);
     }
     time("tiles of 256 entries (16 640 B each)", [&] { hipLaunchKernelGGL(tiled, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, sink); }, gb);
     return 0;
