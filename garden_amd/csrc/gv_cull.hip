@@ -91,12 +91,17 @@ __device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, ui
         if (args.view.write_is_visible)
             args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
     }
+    __shared__ unsigned long long wave_word[kCullBlock / 64];
     const unsigned long long word = __ballot(visible);
     if (lane == 0) {
-        args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+        wave_word[wave] = word;
         wave_count[wave] = (uint32_t)__popcll(word);
     }
     __syncthreads();
+    // the tile's four ballot words leave as ONE 32-byte store (small stores are what a bandwidth-bound read kernel pays for:
+    // tools/read_probe.hip), the tile's count as one atomic
+    if (threadIdx.x < kCullBlock / 64)
+        args.out.mask[(size_t)lb * (kCullBlock / 64) + threadIdx.x] = wave_word[threadIdx.x];
     if (threadIdx.x == 0) {
         uint32_t total = 0;
 #pragma unroll
@@ -957,41 +962,6 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
         hipLaunchKernelGGL(emit_kernel<true>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(emit_kernel<false>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-
-// Read-stream probe (gv_debug_stream_peak): the cull kernel's five input streams of a flat, exactly paired pool —
-// mesh.a 16 B, mesh.b 8 B, xf.ab 32 B, xf.c 8 B, xf.flags 1 B = 65 B per entry — read with the same nontemporal
-// loads, workgroup size and tile mapping, nothing computed and nothing written: what this box's HBM delivers to
-// this access pattern (SURVEY.md §8d asks for the measured read-stream peak beside the vendor figure).
-__global__ __launch_bounds__(kCullBlock) void stream_probe_kernel(const MeshMirror mesh, const TransformMirror xf, uint32_t nblocks,
-                                                                 uint32_t xcd_run, float* __restrict__ sink)
-{
-    const uint32_t lb = tile_of_workgroup(blockIdx.x, xcd_run);
-    if (lb >= nblocks)
-        return;
-    const uint32_t i = lb * kCullBlock + threadIdx.x;
-    if (i >= mesh.count || i >= xf.count)
-        return;
-    const float4 ma = stream_load(&mesh.a[i]);
-    const float2 mb = stream_load(&mesh.b[i]);
-    const float4 xa = stream_load(&xf.ab[i].a);
-    const float4 xb = stream_load(&xf.ab[i].b);
-    const float2 xc = stream_load(&xf.c[i]);
-    const uint32_t f = stream_load(&xf.flags[i]);
-    const float s = ma.x + ma.y + ma.z + ma.w + mb.x + mb.y + xa.x + xa.y + xa.z + xa.w + xb.x + xb.y + xb.z + xb.w + xc.x + xc.y + (float)f;
-    if (s == 12345.678f)  // never true for real pools: keeps the loads alive
-        sink[0] = s;
-}
-
-hipError_t launch_stream_probe(const MeshMirror& mesh, const TransformMirror& xf, float* sink, hipStream_t stream)
-{
-    const uint32_t n = std::min(mesh.count, xf.count);
-    if (n == 0)
-        return hipSuccess;
-    const uint32_t nblocks = (n + kCullBlock - 1) / kCullBlock;
-    const uint32_t run = xcd_run_for_tiles(nblocks);
-    hipLaunchKernelGGL(stream_probe_kernel, dim3(grid_for_tiles(nblocks, run)), dim3(kCullBlock), 0, stream, mesh, xf, nblocks, run, sink);
     return hipGetLastError();
 }
 
