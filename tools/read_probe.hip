@@ -84,9 +84,10 @@ __global__ __launch_bounds__(256) void five_streams_out(const float4* __restrict
 }
 
 // ballot words combined per workgroup: 4 lanes store the 4 words of the tile as one 32-byte piece
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) void five_streams_words4(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
                                                            const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
-                                                           unsigned long long* __restrict__ mask)
+                                                           unsigned long long* __restrict__ mask, uint32_t* __restrict__ counts)
 {
     __shared__ unsigned long long w4[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(256) void five_streams_words4(const float4* __restr
     __syncthreads();
     if (threadIdx.x < 4)
         mask[(size_t)blockIdx.x * 4 + threadIdx.x] = w4[threadIdx.x];
+    if (ATOMIC && threadIdx.x == 0) {
+        const uint32_t total = (uint32_t)(__popcll(w4[0]) + __popcll(w4[1]) + __popcll(w4[2]) + __popcll(w4[3]));
+        if (total)
+            atomicAdd(&counts[blockIdx.x / 16], total);
+    }
 }
 
 __global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ tiles, uint32_t ntiles, float* sink)
@@ -167,7 +173,9 @@ int main()
         hipMalloc(&vis, n); hipMalloc(&mask, (size_t)n / 8 + 64); hipMalloc(&bits, (size_t)n / 8 + 64); hipMemset(bits, 0xFF, (size_t)n / 8 + 64);
         time("five streams (bits instead of flag bytes), no outputs", [&] { hipLaunchKernelGGL((five_streams_out<false, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 64.125 * n / 1e9);
         time("  + a ballot word per wave", [&] { hipLaunchKernelGGL((five_streams_out<false, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 64.25 * n / 1e9);
-        time("  + the 4 ballot words of a workgroup as one 32-byte store", [&] { hipLaunchKernelGGL(five_streams_words4, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask); }, 64.25 * n / 1e9);
+        uint32_t* counts; hipMalloc(&counts, (ntiles / 16 + 1) * 4); hipMemset(counts, 0, (ntiles / 16 + 1) * 4);
+        time("  + the 4 ballot words of a workgroup as one 32-byte store", [&] { hipLaunchKernelGGL(five_streams_words4<false>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
+        time("  + those words and one atomicAdd per workgroup (chunk counts)", [&] { hipLaunchKernelGGL(five_streams_words4<true>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
         time("  + an isVisible byte per entry", [&] { hipLaunchKernelGGL((five_streams_out<true, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.125 * n / 1e9);
         time("  + both (the cull kernel's outputs)", [&] { hipLaunchKernelGGL((five_streams_out<true, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.25 * n / 1e9);
     }
