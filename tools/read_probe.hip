@@ -112,6 +112,34 @@ __global__ __launch_bounds__(256) void five_streams_words4(const float4* __restr
     }
 }
 
+// the five streams with PER entries per lane (tiles of 256 * PER entries): more loads in flight per lane, fewer workgroups
+template <int PER>
+__global__ __launch_bounds__(256) void five_streams_ilp(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                        const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
+                                                        unsigned long long* __restrict__ mask)
+{
+    float acc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (blockIdx.x * PER + k) * 256 + threadIdx.x;
+        acc[k] = 0;
+        if (i < n) {
+            const float4 va = nt16(a + i); const float2 vb = nt8(b + i);
+            const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1);
+            const float2 vc = nt8(c + i);
+            const unsigned long long w = bits[i >> 6];
+            acc[k] = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)((w >> (i & 63)) & 1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (blockIdx.x * PER + k) * 256 + threadIdx.x;
+        const unsigned long long word = __ballot(acc[k] > 1.0f);
+        if ((threadIdx.x & 63) == 0 && i < n)
+            mask[i >> 6] = word;
+    }
+}
+
 __global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ tiles, uint32_t ntiles, float* sink)
 {
     const unsigned char* t = tiles + (size_t)blockIdx.x * 16640;
@@ -178,6 +206,20 @@ int main()
         time("  + those words and one atomicAdd per workgroup (chunk counts)", [&] { hipLaunchKernelGGL(five_streams_words4<true>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
         time("  + an isVisible byte per entry", [&] { hipLaunchKernelGGL((five_streams_out<true, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.125 * n / 1e9);
         time("  + both (the cull kernel's outputs)", [&] { hipLaunchKernelGGL((five_streams_out<true, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.25 * n / 1e9);
+    }
+    {
+        unsigned long long *mask2, *bits2;
+        hipMalloc(&mask2, (size_t)n / 8 + 64); hipMalloc(&bits2, (size_t)n / 8 + 64); hipMemset(bits2, 0xFF, (size_t)n / 8 + 64);
+        for (uint32_t m : {n, 1000000u}) {
+            const uint32_t t1 = (m + 255) / 256;
+            char name[96];
+            snprintf(name, sizeof(name), "%u entries, 1 per lane + ballot words", m);
+            time(name, [&] { hipLaunchKernelGGL(five_streams_ilp<1>, dim3(t1), dim3(256), 0, 0, a, b, ab, c, bits2, m, mask2); }, 64.25 * m / 1e9);
+            snprintf(name, sizeof(name), "%u entries, 2 per lane", m);
+            time(name, [&] { hipLaunchKernelGGL(five_streams_ilp<2>, dim3((t1 + 1) / 2), dim3(256), 0, 0, a, b, ab, c, bits2, m, mask2); }, 64.25 * m / 1e9);
+            snprintf(name, sizeof(name), "%u entries, 4 per lane", m);
+            time(name, [&] { hipLaunchKernelGGL(five_streams_ilp<4>, dim3((t1 + 3) / 4), dim3(256), 0, 0, a, b, ab, c, bits2, m, mask2); }, 64.25 * m / 1e9);
+        }
     }
     time("tiles of 256 entries (16 640 B each)", [&] { hipLaunchKernelGGL(tiled, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, sink); }, gb);
     return 0;
