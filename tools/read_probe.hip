@@ -155,6 +155,55 @@ __global__ __launch_bounds__(256) void tiled(const unsigned char* __restrict__ t
     if (acc == 12345.678f) *sink = acc;
 }
 
+// TILES consecutive 256-entry tiles per workgroup, one after the other (same registers), their ballot words stored together
+template <int TILES>
+__global__ __launch_bounds__(256) void five_streams_tiles(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
+                                                          const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
+                                                          unsigned long long* __restrict__ mask)
+{
+    __shared__ unsigned long long words[TILES * 4];
+    for (int k = 0; k < TILES; k++) {
+        const uint32_t i = (blockIdx.x * TILES + k) * 256 + threadIdx.x;
+        float acc = 0;
+        if (i < n) {
+            const float4 va = nt16(a + i); const float2 vb = nt8(b + i);
+            const float4 x0 = nt16(ab + 2 * (size_t)i), x1 = nt16(ab + 2 * (size_t)i + 1);
+            const float2 vc = nt8(c + i);
+            const unsigned long long w = bits[i >> 6];
+            acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)((w >> (i & 63)) & 1);
+        }
+        const unsigned long long word = __ballot(acc > 1.0f);
+        if ((threadIdx.x & 63) == 0)
+            words[k * 4 + (threadIdx.x >> 6)] = word;
+    }
+    __syncthreads();
+    if (threadIdx.x < TILES * 4)
+        mask[(size_t)blockIdx.x * TILES * 4 + threadIdx.x] = words[threadIdx.x];
+}
+
+// the tiled layout with the cull kernel's remaining output (ballot words, one 32-byte store per workgroup)
+__global__ __launch_bounds__(256) void tiled_words(const unsigned char* __restrict__ tiles, uint32_t ntiles, unsigned long long* __restrict__ mask)
+{
+    __shared__ unsigned long long w4[4];
+    const unsigned char* t = tiles + (size_t)blockIdx.x * 16640;
+    const uint32_t k = threadIdx.x;
+    float acc = 0;
+    if (blockIdx.x < ntiles) {
+        const float4 va = nt16(reinterpret_cast<const float4*>(t) + k);
+        const float2 vb = nt8(reinterpret_cast<const float2*>(t + 4096) + k);
+        const float4 x0 = nt16(reinterpret_cast<const float4*>(t + 6144) + 2 * k), x1 = nt16(reinterpret_cast<const float4*>(t + 6144) + 2 * k + 1);
+        const float2 vc = nt8(reinterpret_cast<const float2*>(t + 14336) + k);
+        const unsigned long long w = reinterpret_cast<const unsigned long long*>(t + 16384)[k >> 6];
+        acc = va.x + va.w + vb.x + vb.y + x0.x + x0.w + x1.x + x1.w + vc.x + vc.y + (float)((w >> (k & 63)) & 1);
+    }
+    const unsigned long long word = __ballot(acc > 1.0f);
+    if ((k & 63) == 0)
+        w4[k >> 6] = word;
+    __syncthreads();
+    if (k < 4)
+        mask[(size_t)blockIdx.x * 4 + k] = w4[k];
+}
+
 int main()
 {
     const uint32_t n = 10'000'000, ntiles = (n + 255) / 256;
@@ -220,6 +269,19 @@ int main()
             snprintf(name, sizeof(name), "%u entries, 4 per lane", m);
             time(name, [&] { hipLaunchKernelGGL(five_streams_ilp<4>, dim3((t1 + 3) / 4), dim3(256), 0, 0, a, b, ab, c, bits2, m, mask2); }, 64.25 * m / 1e9);
         }
+    }
+    {
+        unsigned long long *mask4, *bits4;
+        hipMalloc(&mask4, (size_t)n / 8 + 4096); hipMalloc(&bits4, (size_t)n / 8 + 4096); hipMemset(bits4, 0xFF, (size_t)n / 8 + 4096);
+        time("five streams, 1 tile per workgroup, 32-byte word store", [&] { hipLaunchKernelGGL(five_streams_tiles<1>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits4, n, mask4); }, 64.25 * n / 1e9);
+        time("five streams, 2 tiles per workgroup, 64-byte word store", [&] { hipLaunchKernelGGL(five_streams_tiles<2>, dim3((ntiles + 1) / 2), dim3(256), 0, 0, a, b, ab, c, bits4, n, mask4); }, 64.25 * n / 1e9);
+        time("five streams, 4 tiles per workgroup, 128-byte word store", [&] { hipLaunchKernelGGL(five_streams_tiles<4>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, a, b, ab, c, bits4, n, mask4); }, 64.25 * n / 1e9);
+        time("five streams, 16 tiles per workgroup, 512-byte word store", [&] { hipLaunchKernelGGL(five_streams_tiles<16>, dim3((ntiles + 15) / 16), dim3(256), 0, 0, a, b, ab, c, bits4, n, mask4); }, 64.25 * n / 1e9);
+    }
+    {
+        unsigned long long* mask3; hipMalloc(&mask3, (size_t)n / 8 + 64);
+        hipMemset(buf, 0xFF, 4096);
+        time("tiles of 256 entries + the ballot words", [&] { hipLaunchKernelGGL(tiled_words, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, mask3); }, 64.25 * n / 1e9);
     }
     time("tiles of 256 entries (16 640 B each)", [&] { hipLaunchKernelGGL(tiled, dim3(ntiles), dim3(256), 0, 0, buf, ntiles, sink); }, gb);
     return 0;
