@@ -7,23 +7,44 @@ namespace gv {
 // ------------------------------------------------------------------------------------------------
 // world-matrix sweep (camera = 0), VALU form: one lane per transform slot
 // ------------------------------------------------------------------------------------------------
+// The 256 world matrices of a tile leave as whole rows: every lane parks its 48 bytes in LDS and lane k then stores float4 k,
+// k + 256 and k + 512 of the tile's contiguous 12 KB — three 16-byte stores per lane at a 48-byte stride are un-coalesced per
+// instruction (the emit kernel gained 24 % from the same change, profiles/r02b_emit_ab.txt). `rows`: live slots of the tile
+// (256, less in the last one); every thread of the workgroup must call it (it synchronises).
+__device__ __forceinline__ void store_world_tile(float4* stage /* LDS [768] */, float4* __restrict__ world, uint32_t lb, uint32_t rows,
+                                                 float4 w0, float4 w1, float4 w2)
+{
+    float4* mine = stage + threadIdx.x * 3;
+    mine[0] = w0;
+    mine[1] = w1;
+    mine[2] = w2;
+    __syncthreads();
+    float4* __restrict__ dst = world + (size_t)lb * 768;
+    const uint32_t quads = rows * 3;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t q = threadIdx.x + 256 * k;
+        if (q < quads)
+            stream_store(dst + q, stage[q]);
+    }
+}
+
 __global__ __launch_bounds__(256) void sweep_valu_kernel(const TransformMirror xf, float4* __restrict__ world)
 {
+    __shared__ float4 stage[768];
     const uint32_t lb = blockIdx.x;
     const uint32_t s = lb * 256 + threadIdx.x;
-    if (s >= xf.count)
-        return;
-    const XfRecord r = stream_xf(xf, s);
     float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
-    if (r.flags & kXfLive) {
-        const Mat34 m = chain_model(xf, local_model(r), s, r.flags);
-        w0 = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
-        w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
-        w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+    if (s < xf.count) {
+        const XfRecord r = stream_xf(xf, s);
+        if (r.flags & kXfLive) {
+            const Mat34 m = chain_model(xf, local_model(r), s, r.flags);
+            w0 = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+            w1 = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+            w2 = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+        }
     }
-    stream_store(&world[(size_t)s * 3 + 0], w0);
-    stream_store(&world[(size_t)s * 3 + 1], w1);
-    stream_store(&world[(size_t)s * 3 + 2], w2);
+    store_world_tile(stage, world, lb, min(256u, xf.count - lb * 256u), w0, w1, w2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,6 +153,28 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// store_world_tile for ONE wave (no workgroup barrier, 3 KB of LDS that may be a region the wave no longer needs): lane k
+// stores float4 k, k + 64 and k + 128 of the wave's 64 contiguous matrices. `rows`: live slots among the wave's 64.
+__device__ __forceinline__ void store_world_wave(float4* wave_stage /* LDS [192] */, float4* __restrict__ world, uint32_t first_slot, uint32_t rows,
+                                                 float4 w0, float4 w1, float4 w2)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    wave_lds_sync();  // earlier reads of the region
+    float4* mine = wave_stage + lane * 3;
+    mine[0] = w0;
+    mine[1] = w1;
+    mine[2] = w2;
+    wave_lds_sync();
+    float4* __restrict__ dst = world + (size_t)first_slot * 3;
+    const uint32_t quads = rows * 3;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t q = lane + 64 * k;
+        if (q < quads)
+            stream_store(dst + q, wave_stage[q]);
+    }
+}
+
 // One ancestor step on the matrix side: x[r] = column q of the running product of slot 16r + e (w = bottom-row element),
 // the tile holds the parents' local models row-major. Four issues k = 0..3 into a zero accumulator = the canonical
 // fma chain. Slots whose chain has ended keep their product untouched (bit-exact, incl. -0). acc[3] (the bottom-row
@@ -200,16 +243,27 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
     wave_lds_sync();
     has_parent[wave][lane] = live ? 1u : 0u;
     wave_lds_sync();
+    // float4x3 order: column q's xyz at 12 floats per slot. The wave's 64 matrices are assembled in its (now free) tile and
+    // leave as whole rows — lane k stores float4 k, k + 64, k + 128 of 3 KB — instead of three 4-byte stores per lane and round
+    float* stage = reinterpret_cast<float*>(my_tile);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const uint32_t slot = lb * 256 + wave * 64 + 16 * r + e;
-        if (slot < xf.count) {
-            const bool ok = has_parent[wave][16 * r + e] != 0;
-            // float4x3 order: column q's xyz at 12 floats per slot -> 768 contiguous bytes per round
-            float* dst = world + (size_t)slot * 12 + q * 3;
-            stream_store(dst + 0, ok ? x[r].x : 0.0f);
-            stream_store(dst + 1, ok ? x[r].y : 0.0f);
-            stream_store(dst + 2, ok ? x[r].z : 0.0f);
+        const bool ok = has_parent[wave][16 * r + e] != 0;
+        float* dst = stage + (16 * r + e) * 12 + q * 3;
+        dst[0] = ok ? x[r].x : 0.0f;
+        dst[1] = ok ? x[r].y : 0.0f;
+        dst[2] = ok ? x[r].z : 0.0f;
+    }
+    wave_lds_sync();
+    const uint32_t wave_first = lb * 256 + wave * 64;
+    if (wave_first < xf.count) {
+        const uint32_t quads = min(64u, xf.count - wave_first) * 3;
+        float4* __restrict__ out = reinterpret_cast<float4*>(world) + (size_t)wave_first * 3;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t i4 = lane + 64 * k;
+            if (i4 < quads)
+                stream_store(out + i4, my_tile[i4]);
         }
     }
 }
@@ -293,16 +347,15 @@ __global__ __launch_bounds__(256) void sweep_cull_mfma_kernel(const SweepCullArg
         world.c2x = k2.x; world.c2y = k2.y; world.c2z = k2.z;
         world.c3x = k3.x; world.c3y = k3.y; world.c3z = k3.z;
     }
-    if (in_range) {
+    {
         float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
         if (live) {
             w0 = make_float4(world.c0x, world.c0y, world.c0z, world.c1x);
             w1 = make_float4(world.c1y, world.c1z, world.c2x, world.c2y);
             w2 = make_float4(world.c2z, world.c3x, world.c3y, world.c3z);
         }
-        stream_store(&args.world[(size_t)s * 3 + 0], w0);
-        stream_store(&args.world[(size_t)s * 3 + 1], w1);
-        stream_store(&args.world[(size_t)s * 3 + 2], w2);
+        const uint32_t wave_first = lb * 256u + wave * 64u;  // (the wave's tile is free again: its products sit in registers)
+        store_world_wave(my_tile, args.world, wave_first, wave_first < xf.count ? min(64u, xf.count - wave_first) : 0u, w0, w1, w2);
     }
     // ---- cull_kernel's tail on the model in registers (mesh.cpp:140-175) ----
     bool visible = false;
@@ -359,21 +412,23 @@ __global__ __launch_bounds__(256) void sweep_cull_valu_kernel(const SweepCullArg
         ma = stream_load(&mesh.a[s]);
         mb = stream_load(&mesh.b[s]);
     }
+    __shared__ float4 world_stage[768];
     uint32_t flags = 0;
     Mat34 world = {};
-    if (in_range) {
-        const XfRecord r = stream_xf(xf, s);
-        flags = r.flags;
+    {
         float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
-        if (flags & kXfLive) {
-            world = chain_model(xf, local_model(r), s, flags);
-            w0 = make_float4(world.c0x, world.c0y, world.c0z, world.c1x);
-            w1 = make_float4(world.c1y, world.c1z, world.c2x, world.c2y);
-            w2 = make_float4(world.c2z, world.c3x, world.c3y, world.c3z);
+        if (in_range) {
+            const XfRecord r = stream_xf(xf, s);
+            flags = r.flags;
+            if (flags & kXfLive) {
+                world = chain_model(xf, local_model(r), s, flags);
+                w0 = make_float4(world.c0x, world.c0y, world.c0z, world.c1x);
+                w1 = make_float4(world.c1y, world.c1z, world.c2x, world.c2y);
+                w2 = make_float4(world.c2z, world.c3x, world.c3y, world.c3z);
+            }
         }
-        stream_store(&args.world[(size_t)s * 3 + 0], w0);
-        stream_store(&args.world[(size_t)s * 3 + 1], w1);
-        stream_store(&args.world[(size_t)s * 3 + 2], w2);
+        const uint32_t wave_first = lb * 256u + wave * 64u;
+        store_world_wave(world_stage + wave * 192u, args.world, wave_first, wave_first < xf.count ? min(64u, xf.count - wave_first) : 0u, w0, w1, w2);
     }
     bool visible = false;
     if (has_mesh) {
