@@ -52,21 +52,26 @@ def main():
                 v = dict(v, camera_position=np.asarray([*pos, 0.0], np.float32))
             else:
                 v = scene.main_camera_view(seed=int(rng.integers(1 << 30)), camera_position=pos, use_hiz=int(k % 3 == 1))
-            exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v,
+            scratch = sc.meshes.copy()
+            exp = oracle.prepare_meshes(scratch, sc.transforms, sc.entity_to_transform, v,
                                         hiz=hz if v["use_hiz"] else None, threads=threads)
+            exp_vis32 = scratch["isVisible"].copy()
             order = np.argsort(exp["visible_idx"], kind="stable")
             exp32, order32 = exp, order
             for g, label in zip(ctxs, ("plain", "bounds", "rg16f")):
-                exp, order = exp32, order32
+                exp, order, exp_vis = exp32, order32, exp_vis32
                 if label == "rg16f":
                     if not v["use_hiz"]:
                         continue
-                    exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, v, hiz=hz16, threads=threads)
+                    scratch = sc.meshes.copy()
+                    exp = oracle.prepare_meshes(scratch, sc.transforms, sc.entity_to_transform, v, hiz=hz16, threads=threads)
                     order = np.argsort(exp["visible_idx"], kind="stable")
+                    exp_vis = scratch["isVisible"].copy()
                 g.cull(0, [v])
                 got = g.fetch(0, write_back=False, occupancy=sc.count)
                 same = (got["draw_count"] == exp["draw_count"] and np.array_equal(got["visible_idx"], exp["visible_idx"][order])
-                        and np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
+                        and np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32))
+                        and (got["is_visible"] is None or np.array_equal(got["is_visible"], exp_vis)))  # main pass: the bytes too
                 checked += 1
                 if not same:
                     failures += 1
