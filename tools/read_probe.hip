@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void five_streams_out(const float4* __restrict
 }
 
 // ballot words combined per workgroup: 4 lanes store the 4 words of the tile as one 32-byte piece
-template <bool ATOMIC>
+template <bool ATOMIC, bool NT = false>
 __global__ __launch_bounds__(256) void five_streams_words4(const float4* __restrict__ a, const float2* __restrict__ b, const float4* __restrict__ ab,
                                                            const float2* __restrict__ c, const unsigned long long* __restrict__ bits, uint32_t n,
                                                            unsigned long long* __restrict__ mask, uint32_t* __restrict__ counts)
@@ -103,8 +103,12 @@ __global__ __launch_bounds__(256) void five_streams_words4(const float4* __restr
     if ((threadIdx.x & 63) == 0)
         w4[threadIdx.x >> 6] = word;
     __syncthreads();
-    if (threadIdx.x < 4)
-        mask[(size_t)blockIdx.x * 4 + threadIdx.x] = w4[threadIdx.x];
+    if (threadIdx.x < 4) {
+        if (NT)
+            __builtin_nontemporal_store(w4[threadIdx.x], &mask[(size_t)blockIdx.x * 4 + threadIdx.x]);
+        else
+            mask[(size_t)blockIdx.x * 4 + threadIdx.x] = w4[threadIdx.x];
+    }
     if (ATOMIC && threadIdx.x == 0) {
         const uint32_t total = (uint32_t)(__popcll(w4[0]) + __popcll(w4[1]) + __popcll(w4[2]) + __popcll(w4[3]));
         if (total)
@@ -252,6 +256,7 @@ int main()
         time("  + a ballot word per wave", [&] { hipLaunchKernelGGL((five_streams_out<false, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 64.25 * n / 1e9);
         uint32_t* counts; hipMalloc(&counts, (ntiles / 16 + 1) * 4); hipMemset(counts, 0, (ntiles / 16 + 1) * 4);
         time("  + the 4 ballot words of a workgroup as one 32-byte store", [&] { hipLaunchKernelGGL(five_streams_words4<false>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
+        time("  + the 4 ballot words, nontemporal store", [&] { hipLaunchKernelGGL((five_streams_words4<false, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
         time("  + those words and one atomicAdd per workgroup (chunk counts)", [&] { hipLaunchKernelGGL(five_streams_words4<true>, dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, mask, counts); }, 64.25 * n / 1e9);
         time("  + an isVisible byte per entry", [&] { hipLaunchKernelGGL((five_streams_out<true, false>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.125 * n / 1e9);
         time("  + both (the cull kernel's outputs)", [&] { hipLaunchKernelGGL((five_streams_out<true, true>), dim3(ntiles), dim3(256), 0, 0, a, b, ab, c, bits, n, vis, mask); }, 65.25 * n / 1e9);
