@@ -223,6 +223,10 @@ def main():
                     choices=["allgather", "p2p", "broadcast"],
                     help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
                          "send/recv to every peer, or one broadcast per root (A/B for the fully connected xGMI node)")
+    ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "indices"), choices=["indices", "mask"],
+                    help="N > 1: what a shard carries — the compacted uint32 index list (default) or one bit per pool slot behind "
+                         "the count (1/32 word per slot whatever the view: ~7x fewer bytes at the bench's 21 %% visibility); an "
+                         "A/B for real hardware, the gathered sets are checked against the exact all-gatherv either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -295,7 +299,7 @@ def main():
 
     from garden_amd import scene
     from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
-    from garden_amd.multi import VisibleListExchange, allgatherv_indices, shard_capacity
+    from garden_amd.multi import VisibleListExchange, allgatherv_indices, shard_capacity, mask_words, expand_mask_rows
 
     wl = WORKLOADS[args.workload]
     n = args.entities or wl["entities"]
@@ -336,7 +340,10 @@ def main():
         compute()
         if ex[0] is not None:
             shard = ex[0].next_shard()
-            vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
+            if args.payload == "mask":
+                vis.copy_mask_device(0, shard.data_ptr(), ex[0].capacity)
+            else:
+                vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
             return ex[0].exchange()
         return None
 
@@ -367,6 +374,18 @@ def main():
     def check_padded(padded, exact, exact_counts):
         """The per-frame padded exchange delivered the same lists as the exact one (static scene)."""
         ex[0].drain()  # raises if any frame of the run overflowed its shard
+        if args.payload == "mask":  # bits per pool slot: the same SETS per rank (a mask has no order)
+            torch.cuda.synchronize()
+            d, counts = expand_mask_rows(padded, n)
+            if not np.array_equal(counts, exact_counts):
+                return "mask exchange: counts differ from the exact all-gatherv"
+            off = 0
+            for r in range(world):
+                c = int(exact_counts[r])
+                if not np.array_equal(d[off:off + c], np.sort(exact[off:off + c])):
+                    return f"mask exchange: rank {r}'s set differs from the exact all-gatherv"
+                off += c
+            return None
         dense, counts = ex[0].compact(padded)
         d = dense.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         if not np.array_equal(counts.numpy(), exact_counts):
@@ -405,8 +424,8 @@ def main():
             leave(1)
         gathered_total = int(exact_counts.sum())
         producer = lib_stream if backend == "nccl" else None
-        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", shard_capacity(int(exact_counts.max())), stream=producer,
-                                    mode=args.exchange)
+        capacity = mask_words(n) if args.payload == "mask" else shard_capacity(int(exact_counts.max()))
+        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=args.payload)
     for _ in range(args.warmup):
         step()
     fence()
@@ -576,10 +595,12 @@ def main():
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
                        "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,
-                       "exchange": (f"per frame: padded shards [count, uint32 indices...] (capacity {ex[0].capacity}) travel by "
+                       "exchange": (f"per frame: " + ("shards [count, one bit per pool slot] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
+                                    f"(capacity {ex[0].capacity} words) travel by "
                                     f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
                        "exchange_mode": args.exchange if exchange else None,
+                       "exchange_payload": args.payload if exchange else None,
                        "same_frames_without_exchange": no_exchange,
                        # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
                        "kernel_ms": {k: (st["device_ms"][k] * (st["launches"][k] / max(1, timed[k])) / max(1, args.steps))

@@ -1286,6 +1286,21 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
     return GV_OK;
 }
 
+int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t word_count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index) || !view_of(ctx, ctx->last_pool, view_index)->emitted)
+        return ctx->fail(GV_E_ARG, "gv_results_copy_mask_device: view %u has no emitted records", view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
+    ViewState& vs = *view_of(ctx, ctx->last_pool, view_index);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, launch_mask_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), word_count, vs.occupancy,
+                                  ctx->stream));
+    return GV_OK;
+}
+
 int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count)
 {
     if (!ctx)

@@ -56,4 +56,8 @@ struct SortBatch {
 // max_capacity: the largest entry capacity (sizes the grid and the LDS key table)
 hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t max_capacity, hipStream_t stream);
 
+// gv_shard.hip: the visible list of a view as [draw_count | one bit per pool slot] (words = ceil(slots / 32); capacity = the pool's
+// slot count, sizes the grid)
+hipError_t launch_mask_shard(const uint32_t* idx, const uint32_t* count, uint32_t* dst, uint32_t words, uint32_t capacity, hipStream_t stream);
+
 }  // namespace gv

@@ -215,6 +215,37 @@ def shard_capacity(max_count, slack=1.25, quantum=1024):
     return (int(max_count * slack) // quantum + 1) * quantum
 
 
+def mask_words(slots):
+    """uint32 words of a bit-per-slot shard for a pool of `slots` slots (gv_results_copy_mask_device)."""
+    return (int(slots) + 31) // 32
+
+
+def pack_mask_shard(visible_slots, slots):
+    """CPU restatement of gv_results_copy_mask_device: int32[1 + mask_words(slots)] = [count, bits...]."""
+    import numpy as np
+    v = np.asarray(visible_slots, dtype=np.int64)
+    words = np.zeros(mask_words(slots), dtype=np.uint32)
+    np.bitwise_or.at(words, v >> 5, (np.uint32(1) << (v & 31).astype(np.uint32)))
+    return torch.from_numpy(np.concatenate([[np.uint32(v.size)], words]).astype(np.uint32).view(np.int32))
+
+
+def expand_mask_rows(padded, slots_per_rank, index_bases=None):
+    """Global index lists from gathered mask shards: padded = [world, 1 + words] (int32 view of uint32), row r = rank r's
+    [count, bits]. Returns (indices in rank order and ascending slot order within a rank, counts). index_bases[r] is added to
+    rank r's slots (default r * slots_per_rank: contiguous tiles)."""
+    import numpy as np
+    rows = padded.cpu().numpy().view(np.uint32)
+    world = rows.shape[0]
+    out, counts = [], []
+    for r in range(world):
+        bits = np.unpackbits(rows[r, 1:].view(np.uint8), bitorder="little")[:slots_per_rank]
+        slots = np.flatnonzero(bits).astype(np.int64)
+        base = r * slots_per_rank if index_bases is None else int(index_bases[r])
+        out.append(slots + base)
+        counts.append(int(rows[r, 0]))
+    return np.concatenate(out) if out else np.zeros(0, np.int64), np.asarray(counts, dtype=np.int64)
+
+
 class VisibleListExchange:
     """Sync-free all-gather of the per-tile visible lists (one instance per process).
 
@@ -228,13 +259,17 @@ class VisibleListExchange:
 
     MODES = ("allgather", "p2p", "broadcast")
 
-    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2, mode="allgather"):
+    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2, mode="allgather", payload="indices"):
         """mode: how the shards travel. "allgather" = ONE equal-size all-gather; "p2p" = one group of send/recv pairs
         with every peer (batch_isend_irecv = ncclGroupStart ... ncclGroupEnd: each shard crosses exactly one xGMI link,
         all links at once); "broadcast" = one broadcast per root. Same rows in the same place either way — the node's
         fabric is point to point and fully connected, so ring vs direct is an A/B for real hardware."""
         assert mode in self.MODES, mode
+        assert payload in ("indices", "mask"), payload
         self.mode = mode
+        # "mask": shards are [count, one bit per pool slot] (gv_results_copy_mask_device; capacity = mask_words(slots)): a fixed
+        # size whatever the view, so a shard cannot overflow and the header is only the count
+        self.payload = payload
         self.dist, self.group, self.device = dist, group, torch.device(device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.backend = dist.get_backend(group)
@@ -294,7 +329,7 @@ class VisibleListExchange:
             self.header_events[s].synchronize()  # enqueued a whole frame ago
         self.in_flight[s] = False
         worst = int(self.headers[s].max())
-        if worst > self.capacity:
+        if self.payload == "indices" and worst > self.capacity:
             raise ShardOverflow(worst, self.capacity)
 
     def next_shard(self):

@@ -220,6 +220,14 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                  uint32_t index_base);
 
+/* The same shard as a bit per pool slot: dst[0] = draw_count, bit (s & 31) of dst[1 + (s >> 5)] = slot s of the pool is in the
+ * view's visible list; dst holds 1 + word_count uint32, word_count >= ceil(occupancy / 32) (slots beyond it are dropped). The
+ * size does not depend on the view: 1/32 of a word per slot where the index list costs a word per visible slot, i.e. smaller
+ * above ~3 % visibility and 1/7 of the list at the bench's 21 % — the encoding for dense views on the links of a multi-GPU node
+ * (an equal-size all-gather by construction). Bits are POOL slots of this rank (an index map is not applied: a consumer
+ * translates slot -> global id with the owner's table, or index_base + slot for contiguous tiles). No host synchronisation. */
+int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t word_count);
+
 /* A spatial tile's pool slots are not a contiguous range of the world's (roots -> tile, descendants
  * follow): `global_ids[slot]` is the id the exchange should carry for pool slot `slot` (e.g. the mesh slot in the
  * unpartitioned world, garden_amd/multi.py::partition_world's mesh_global). Uploaded once; from then on

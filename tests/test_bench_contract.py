@@ -54,3 +54,25 @@ def test_bench_gpus_2_starts_its_own_ranks(mode):
     assert d["config"]["exchange"] is not None and d["config"]["exchange_mode"] == mode
     assert d["parity"]["visible_set_bit_identical"] and d["parity"]["baked_model_bit_identical"]
     assert d["config"]["same_frames_without_exchange"]["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_mask_payload(ranks):
+    """`--payload mask`: shards carry one bit per pool slot; the gathered sets are checked against the exact all-gatherv
+    inside the bench. One rank over RCCL (GV_BENCH_EXCHANGE=1), two ranks sharing this box's GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if ranks == 1:
+        env.update(GV_BENCH_EXCHANGE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+        cmd = ["--workload", "cfg5", "--entities", "300000"]
+    else:
+        env["GV_BENCH_BACKEND"] = "gloo"
+        cmd = ["--gpus", "2", "--entities", "300000"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *cmd, "--steps", "4", "--warmup", "1", "--payload", "mask",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["exchange_payload"] == "mask" and "one bit per pool slot" in d["config"]["exchange"]
+    assert d["parity"]["visible_set_bit_identical"] and "error" not in d

@@ -1348,3 +1348,33 @@ def test_instance_bases_are_the_reference_draw_loops_fetch_adds(oracle, n):
         with pytest.raises(RuntimeError) as e:
             vis.instance_bases(0, 0)
         assert "count-only" in str(e.value)
+
+
+@pytest.mark.parametrize("n", [1000, 70_003, 400_000])
+def test_mask_shard_is_the_visible_list_as_bits(oracle, n):
+    """gv_results_copy_mask_device: [draw_count, one bit per POOL slot] — the same set as the index list (whatever the mirror
+    order), zero bits elsewhere, after a sort as well, and garden_amd.multi's CPU restatement of the encoding agrees."""
+    import torch
+    from garden_amd.lib import GpuVisibility
+    from garden_amd.multi import expand_mask_rows, mask_words, pack_mask_shard
+    sc = scene.flat_scene(n, seed=n)
+    view = scene.main_camera_view()
+    words = mask_words(n)
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        shard = torch.full((1 + words,), -1, dtype=torch.int32, device="cuda:0")  # poison: the call clears its words itself
+        for sort in (False, True):
+            vis.cull(0, [view])
+            if sort:
+                vis.sort(0, descending=False)
+            torch.cuda.synchronize()
+            vis.copy_mask_device(0, shard.data_ptr(), words)
+            vis.wait()
+            got = vis.fetch(0, write_back=False, occupancy=n)
+            exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
+            assert exp["draw_count"] > 0 and np.array_equal(np.sort(got["visible_idx"]), np.sort(exp["visible_idx"]))
+            slots, counts = expand_mask_rows(shard.view(1, -1), n, index_bases=[0])
+            assert counts.tolist() == [exp["draw_count"]] and np.array_equal(slots, np.sort(exp["visible_idx"]).astype(np.int64))
+            assert torch.equal(shard.cpu(), pack_mask_shard(exp["visible_idx"], n))

@@ -178,6 +178,43 @@ def test_padded_exchange_world_size_2_gloo():
         assert ok and overflow == cap + 5
 
 
+def _mask_exchange_worker(rank, world, port, ret, mode):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import VisibleListExchange, expand_mask_rows, mask_words, pack_mask_shard
+    slots = 5003  # not a multiple of 32: the last word is partly used
+    ex = VisibleListExchange(dist, "cpu", mask_words(slots), mode=mode, payload="mask")
+    rng = np.random.default_rng(7)  # the same on every rank: each one can rebuild every shard
+    ok = True
+    for frame in range(4):
+        sets = [np.sort(rng.choice(slots, size=(0 if (r == 1 and frame == 2) else 40 + 900 * r + 11 * frame), replace=False)) for r in range(world)]
+        shard = ex.next_shard()
+        shard.copy_(pack_mask_shard(sets[rank], slots))  # what gv_results_copy_mask_device writes
+        padded = ex.exchange()
+        got, counts = expand_mask_rows(padded, slots)
+        exp = np.concatenate([sets[r].astype(np.int64) + r * slots for r in range(world)])
+        ok = ok and np.array_equal(got, exp) and counts.tolist() == [s.size for s in sets]
+    ex.drain()  # a count above the word capacity is not an overflow for this payload
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (3, "p2p"), (2, "broadcast")])
+def test_mask_payload_exchange_gloo(world, mode):
+    """Shards as one bit per pool slot behind the count (the encoding for dense views: a fixed size whatever the view):
+    every rank ends with every rank's visible SET, through each transport pattern, incl. an empty shard and a pool whose
+    last word is partly used."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_mask_exchange_worker, args=(world, port, ret, mode), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
 def test_worker_pool_under_thread_sanitizer(tmp_path):
     """garden_amd/csrc/gv_workers.*: the persistent host worker pool behind the gathers and the isVisible write-back
     (the reference's ThreadPool::addItems split, thread-pool.cpp:180-194). Host-only: built here with
