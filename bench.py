@@ -323,6 +323,7 @@ def main():
 
     idx_buf = torch.empty(n, dtype=torch.int32, device=f"cuda:{local_rank}") if exchange else None
     ex = [None]  # VisibleListExchange, created once the shard capacity is known (first, exact exchange)
+    entry_tables = [None]  # --payload mask: every rank's mirror entry -> pool slot table
 
     view_array = vis.views_array([view])  # the GvView structs of the frame, built once (the timed loop is the library's, not ctypes')
 
@@ -374,9 +375,9 @@ def main():
     def check_padded(padded, exact, exact_counts):
         """The per-frame padded exchange delivered the same lists as the exact one (static scene)."""
         ex[0].drain()  # raises if any frame of the run overflowed its shard
-        if args.payload == "mask":  # bits per pool slot: the same SETS per rank (a mask has no order)
+        if args.payload == "mask":  # bits per mirror entry: the same SETS per rank (a mask has no order)
             torch.cuda.synchronize()
-            d, counts = expand_mask_rows(padded, n)
+            d, counts = expand_mask_rows(padded, n, entry_tables=entry_tables[0])
             if not np.array_equal(counts, exact_counts):
                 return "mask exchange: counts differ from the exact all-gatherv"
             off = 0
@@ -425,6 +426,18 @@ def main():
         gathered_total = int(exact_counts.sum())
         producer = lib_stream if backend == "nccl" else None
         capacity = mask_words(n) if args.payload == "mask" else shard_capacity(int(exact_counts.max()))
+        if args.payload == "mask":
+            # once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit shards
+            # needs to name the entities; the static scene never rebuilds its mirror)
+            mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
+            tables = [torch.empty_like(mine) for _ in range(world)]
+            if backend == "nccl":
+                dev_tables = [t.to(f"cuda:{local_rank}") for t in tables]
+                dist.all_gather(dev_tables, mine.to(f"cuda:{local_rank}"))
+                tables = [t.cpu() for t in dev_tables]
+            else:
+                dist.all_gather(tables, mine)
+            entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
         ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=args.payload)
     for _ in range(args.warmup):
         step()
@@ -595,7 +608,7 @@ def main():
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
                        "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
                        "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,
-                       "exchange": (f"per frame: " + ("shards [count, one bit per pool slot] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
+                       "exchange": (f"per frame: " + ("shards [count, one bit per mirror entry] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
                                     f"(capacity {ex[0].capacity} words) travel by "
                                     f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,

@@ -268,6 +268,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 vs.tile_ticket_base = 0;
                 vs.tile_epoch = 0;
             }
+            vs.ballots_current = false;
             vs.tile_epoch = vs.tile_epoch == UINT32_MAX ? 1u : vs.tile_epoch + 1u;
             {
                 KernelTimer t(ctx, GV_K_CULL);
@@ -837,6 +838,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.valid = true;
         vs.published = false, vs.records_fetched = false;
         vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
+        vs.ballots_current = true;  // every cull launch but the one-launch cull + emit of a small pool writes them
         build_view_params(views[v], &vps[v]);
         if (p.occupancy == 0)
             GV_HIP(ctx, hipMemsetAsync(vs.draw_count.ptr, 0, 4, ctx->stream));
@@ -1290,14 +1292,36 @@ int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_devic
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index) || !view_of(ctx, ctx->last_pool, view_index)->emitted)
-        return ctx->fail(GV_E_ARG, "gv_results_copy_mask_device: view %u has no emitted records", view_index);
-    if (int rc = flush_sorts(ctx))
+    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index))
+        return ctx->fail(GV_E_ARG, "gv_results_copy_mask_device: view %u has no results", view_index);
+    if (int rc = flush_culls(ctx))
         return rc;
     ViewState& vs = *view_of(ctx, ctx->last_pool, view_index);
+    if (word_count < (vs.occupancy + 31u) / 32u)
+        return ctx->fail(GV_E_ARG, "gv_results_copy_mask_device: %u words for a pool of %u slots", word_count, vs.occupancy);
+    if (!vs.ballots_current && !vs.main_pass)
+        return ctx->fail(GV_E_STATE, "gv_results_copy_mask_device: view %u has neither ballot words nor isVisible bytes", view_index);
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    GV_HIP(ctx, launch_mask_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), word_count, vs.occupancy,
-                                  ctx->stream));
+    GV_HIP(ctx, launch_mask_shard(vs.ballots_current ? vs.mask.ptr : nullptr, vs.is_visible.ptr, vs.draw_count.ptr, vs.occupancy,
+                                  static_cast<uint32_t*>(dst_device), word_count, ctx->stream));
+    return GV_OK;
+}
+
+int gv_pool_mirror_slots(GvCtx* ctx, uint32_t pool_id, uint32_t* entry_to_slot, uint32_t capacity)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !entry_to_slot)
+        return ctx->fail(GV_E_ARG, "gv_pool_mirror_slots: bad argument (pool %u)", pool_id);
+    PoolState& p = ctx->pools[pool_id];
+    if (!p.bound)
+        return ctx->fail(GV_E_STATE, "gv_pool_mirror_slots: pool %u is not bound", pool_id);
+    if (int rc = sync_mirror(ctx))
+        return rc;
+    const uint32_t n = std::min(p.occupancy, capacity);
+    const bool permuted = !p.perm.empty() && p.perm.size() == p.occupancy;
+    for (uint32_t e = 0; e < n; e++)
+        entry_to_slot[e] = permuted ? p.perm[e] : e;
     return GV_OK;
 }
 

@@ -216,6 +216,7 @@ struct ViewState {
     PinnedBuf<uint8_t> h_records;    // results in the pool's record layout (gv_pool_results_records)
     DeviceBuf<uint8_t> d_records;    // ... packed on the device first for pools too large to publish directly
     bool records_fetched = false;    // h_records holds this cull's records
+    bool ballots_current = false;    // `mask` holds this cull's ballot words (not after the one-launch cull + emit of a small pool)
     std::vector<uint32_t> instance_bases;  // gv_pool_results_instance_bases (built on request)
     uint32_t pool_id = 0, occupancy = 0;
     bool main_pass = false, emitted = false, valid = false;

@@ -4,30 +4,44 @@
 
 namespace gv {
 
-// The visible list of a view as a BIT per pool slot behind its count: dst[0] = draw_count, bit (s & 31) of dst[1 + (s >> 5)] =
-// slot s is visible. dst[1 .. 1 + words) must be zero on entry (the caller clears it in stream order). Same information as
-// the index list; 1/32 of a word per slot whatever the view, where the list costs a word per VISIBLE slot — the smaller
-// encoding above ~3 % visibility, and a fixed size, which is what an all-gather wants.
-__global__ __launch_bounds__(256) void mask_shard_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ count,
-                                                         uint32_t* __restrict__ dst, uint32_t words)
+// The visible list of a view as a BIT per mirror entry behind its count: dst[0] = draw_count, bit (e & 31) of dst[1 + (e >> 5)]
+// = mirror entry e is visible. That is the cull kernel's own output (one 64-bit ballot word per wave, little-endian = two of
+// these words), so the shard is a 1.6 MB copy per 12.5 M entries instead of a scatter: turning the bits into POOL-slot order
+// on the device was measured first — 2.6 M atomicOr into random words: +126 us per frame, the byte scatter of the fetch path
+// 176 us — and dropped; a consumer maps entry -> pool slot with the owner's table (gv_pool_mirror_slots), which only
+// changes when the mirror is rebuilt. `bytes` (mirror order) replaces `ballots` for the one-launch cull + emit of small
+// pools, which produces no ballot words.
+__global__ __launch_bounds__(256) void mask_shard_kernel(const uint32_t* __restrict__ ballots, const uint8_t* __restrict__ bytes,
+                                                         const uint32_t* __restrict__ count, uint32_t entries, uint32_t* __restrict__ dst,
+                                                         uint32_t words)
 {
-    const uint32_t n = *count;
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        dst[0] = n;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const uint32_t slot = idx[j], word = slot >> 5;
-        if (word < words)
-            atomicOr(&dst[1 + word], 1u << (slot & 31u));
+        dst[0] = *count;
+    const uint32_t live_words = (entries + 31u) / 32u;
+    if (ballots) {
+        for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x)
+            dst[1 + w] = w < live_words ? ballots[w] : 0u;
+        return;
+    }
+    // from the isVisible bytes: lane l of a wave owns entry 64 * k + l of the wave's k-th round
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t pair = wave; pair * 2u < words; pair += waves) {  // wave-uniform
+        const uint32_t e = pair * 64u + lane;
+        const unsigned long long word = __ballot(e < entries && bytes[e] != 0);
+        if (lane == 0) {
+            dst[1 + pair * 2u] = (uint32_t)word;
+            if (pair * 2u + 1u < words)
+                dst[2 + pair * 2u] = (uint32_t)(word >> 32);
+        }
     }
 }
 
-hipError_t launch_mask_shard(const uint32_t* idx, const uint32_t* count, uint32_t* dst, uint32_t words, uint32_t capacity, hipStream_t stream)
+hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* bytes, const uint32_t* count, uint32_t entries, uint32_t* dst,
+                             uint32_t words, hipStream_t stream)
 {
-    hipError_t rc = hipMemsetAsync(dst + 1, 0, (size_t)words * sizeof(uint32_t), stream);
-    if (rc != hipSuccess)
-        return rc;
-    const uint32_t blocks = std::max(1u, std::min(2048u, (capacity + 255u) / 256u));
-    hipLaunchKernelGGL(mask_shard_kernel, dim3(blocks), dim3(256), 0, stream, idx, count, dst, words);
+    const uint32_t blocks = std::max(1u, std::min(1024u, (words + 255u) / 256u));
+    hipLaunchKernelGGL(mask_shard_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(ballots), bytes, count, entries,
+                       dst, words);
     return hipGetLastError();
 }
 

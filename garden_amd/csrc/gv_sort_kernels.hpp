@@ -56,8 +56,9 @@ struct SortBatch {
 // max_capacity: the largest entry capacity (sizes the grid and the LDS key table)
 hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t max_capacity, hipStream_t stream);
 
-// gv_shard.hip: the visible list of a view as [draw_count | one bit per pool slot] (words = ceil(slots / 32); capacity = the pool's
-// slot count, sizes the grid)
-hipError_t launch_mask_shard(const uint32_t* idx, const uint32_t* count, uint32_t* dst, uint32_t words, uint32_t capacity, hipStream_t stream);
+// gv_shard.hip: the visible list of a view as [draw_count | one bit per MIRROR entry]: a copy of the cull kernel's ballot words
+// (or, when `ballots` is NULL, built from the isVisible bytes in mirror order); words >= ceil(entries / 32), the rest is zeroed
+hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* bytes, const uint32_t* count, uint32_t entries, uint32_t* dst,
+                             uint32_t words, hipStream_t stream);
 
 }  // namespace gv

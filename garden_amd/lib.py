@@ -106,7 +106,7 @@ EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
     "gv_transform_bind_columns", "gv_pool_bind_columns", "gv_pool_bind_ready",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
-    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_results_copy_mask_device", "gv_sort", "gv_sweep", "gv_get_world",
+    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_results_copy_mask_device", "gv_pool_mirror_slots", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
@@ -160,6 +160,7 @@ def load():
     lib.gv_results_copy_idx_device.argtypes = [P, u32, P, u32, u32]
     lib.gv_results_copy_shard_device.argtypes = [P, u32, P, u32, u32]
     lib.gv_results_copy_mask_device.argtypes = [P, u32, P, u32]
+    lib.gv_pool_mirror_slots.argtypes = [P, u32, P, u32]
     lib.gv_sort.argtypes = [P, u32, C.c_int]
     lib.gv_sweep.argtypes = [P, u32]
     lib.gv_get_world.argtypes = [P, u32, u32, P]
@@ -424,8 +425,15 @@ class GpuVisibility:
         self._check(self.lib.gv_results_copy_shard_device(self.ctx, view_index, dst_ptr, capacity, index_base))
 
     def copy_mask_device(self, view_index, dst_ptr, word_count):
-        """Exchange shard as a bit per pool slot: [draw_count, ceil(occupancy / 32) words] into device memory at dst_ptr."""
+        """Exchange shard as a bit per MIRROR entry: [draw_count, ceil(occupancy / 32) words] into device memory at dst_ptr
+        (entry e is pool slot mirror_slots()[e])."""
         self._check(self.lib.gv_results_copy_mask_device(self.ctx, view_index, dst_ptr, word_count))
+
+    def mirror_slots(self, pool_id, occupancy):
+        """entry -> pool slot table of the pool's device mirror (changes only when the mirror is rebuilt)."""
+        out = np.empty(occupancy, dtype=np.uint32)
+        self._check(self.lib.gv_pool_mirror_slots(self.ctx, pool_id, out.ctypes.data, occupancy))
+        return out
 
     # ---- native RCCL exchange (C++ engines; bench.py goes through torch.distributed instead) ----
     @staticmethod

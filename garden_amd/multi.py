@@ -220,28 +220,32 @@ def mask_words(slots):
     return (int(slots) + 31) // 32
 
 
-def pack_mask_shard(visible_slots, slots):
-    """CPU restatement of gv_results_copy_mask_device: int32[1 + mask_words(slots)] = [count, bits...]."""
+def pack_mask_shard(visible, entries):
+    """CPU restatement of gv_results_copy_mask_device: int32[1 + mask_words(entries)] = [count, bits...] over the ids in
+    `visible` (mirror entries on the device; any id space in the tests)."""
     import numpy as np
-    v = np.asarray(visible_slots, dtype=np.int64)
-    words = np.zeros(mask_words(slots), dtype=np.uint32)
+    v = np.asarray(visible, dtype=np.int64)
+    words = np.zeros(mask_words(entries), dtype=np.uint32)
     np.bitwise_or.at(words, v >> 5, (np.uint32(1) << (v & 31).astype(np.uint32)))
     return torch.from_numpy(np.concatenate([[np.uint32(v.size)], words]).astype(np.uint32).view(np.int32))
 
 
-def expand_mask_rows(padded, slots_per_rank, index_bases=None):
+def expand_mask_rows(padded, entries_per_rank, entry_tables=None, index_bases=None):
     """Global index lists from gathered mask shards: padded = [world, 1 + words] (int32 view of uint32), row r = rank r's
-    [count, bits]. Returns (indices in rank order and ascending slot order within a rank, counts). index_bases[r] is added to
-    rank r's slots (default r * slots_per_rank: contiguous tiles)."""
+    [count, bits over its mirror entries]. entry_tables[r] (gv_pool_mirror_slots of rank r, exchanged once per mirror
+    rebuild; None: identity) maps entries to pool slots, index_bases[r] (default r * entries_per_rank: contiguous tiles) is
+    added. Returns (indices in rank order, ascending within a rank; counts from the headers)."""
     import numpy as np
     rows = padded.cpu().numpy().view(np.uint32)
     world = rows.shape[0]
     out, counts = [], []
     for r in range(world):
-        bits = np.unpackbits(rows[r, 1:].view(np.uint8), bitorder="little")[:slots_per_rank]
-        slots = np.flatnonzero(bits).astype(np.int64)
-        base = r * slots_per_rank if index_bases is None else int(index_bases[r])
-        out.append(slots + base)
+        bits = np.unpackbits(rows[r, 1:].view(np.uint8), bitorder="little")[:entries_per_rank]
+        ids = np.flatnonzero(bits).astype(np.int64)
+        if entry_tables is not None and entry_tables[r] is not None:
+            ids = np.sort(np.asarray(entry_tables[r], dtype=np.int64)[ids])
+        base = r * entries_per_rank if index_bases is None else int(index_bases[r])
+        out.append(ids + base)
         counts.append(int(rows[r, 0]))
     return np.concatenate(out) if out else np.zeros(0, np.int64), np.asarray(counts, dtype=np.int64)
 

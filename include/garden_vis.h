@@ -220,13 +220,18 @@ int gv_results_copy_idx_device(GvCtx* ctx, uint32_t view_index, void* dst_device
 int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t capacity,
                                  uint32_t index_base);
 
-/* The same shard as a bit per pool slot: dst[0] = draw_count, bit (s & 31) of dst[1 + (s >> 5)] = slot s of the pool is in the
- * view's visible list; dst holds 1 + word_count uint32, word_count >= ceil(occupancy / 32) (slots beyond it are dropped). The
- * size does not depend on the view: 1/32 of a word per slot where the index list costs a word per visible slot, i.e. smaller
- * above ~3 % visibility and 1/7 of the list at the bench's 21 % — the encoding for dense views on the links of a multi-GPU node
- * (an equal-size all-gather by construction). Bits are POOL slots of this rank (an index map is not applied: a consumer
- * translates slot -> global id with the owner's table, or index_base + slot for contiguous tiles). No host synchronisation. */
+/* The same visible set as a BIT per entry of the pool's device mirror: dst[0] = draw_count, bit (e & 31) of dst[1 + (e >> 5)]
+ * = mirror entry e is in the view's visible list; dst holds 1 + word_count uint32, word_count >= ceil(occupancy / 32). The
+ * size does not depend on the view: 1/32 of a word per slot where the index list costs a word per visible slot — smaller above
+ * ~3 % visibility, 1/7 of the list at the bench's 21 % — and an equal-size all-gather by construction: the encoding for dense
+ * views on the links of a multi-GPU node. It is the cull kernel's own output, so producing it is a 1.6 MB copy per 12.5 M
+ * entries (bits in pool-slot order would cost a scatter per frame: measured, +126 us). Entry e is pool slot
+ * gv_pool_mirror_slots()[e]: that table only changes when the mirror is rebuilt (gv_hierarchy_rebuild, a pool bound with
+ * another occupancy), so consumers fetch it once per rebuild — with GV_CONFIG_KEEP_SLOT_ORDER it is the identity. Main-pass
+ * views of any pool, and every view that took the ordinary cull launch (GV_E_STATE otherwise). No host synchronisation. */
 int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t word_count);
+/* entry_to_slot[e] = pool slot of mirror entry e, e < min(occupancy, capacity); host memory. Synchronises the mirror first. */
+int gv_pool_mirror_slots(GvCtx* ctx, uint32_t pool_id, uint32_t* entry_to_slot, uint32_t capacity);
 
 /* A spatial tile's pool slots are not a contiguous range of the world's (roots -> tile, descendants
  * follow): `global_ids[slot]` is the id the exchange should carry for pool slot `slot` (e.g. the mesh slot in the

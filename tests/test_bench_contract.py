@@ -59,7 +59,7 @@ def test_bench_gpus_2_starts_its_own_ranks(mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_bench_mask_payload(ranks):
-    """`--payload mask`: shards carry one bit per pool slot; the gathered sets are checked against the exact all-gatherv
+    """`--payload mask`: shards carry one bit per mirror entry (the entry -> slot tables travel once); the gathered sets are checked against the exact all-gatherv
     inside the bench. One rank over RCCL (GV_BENCH_EXCHANGE=1), two ranks sharing this box's GPU over gloo."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     if ranks == 1:
@@ -74,5 +74,5 @@ def test_bench_mask_payload(ranks):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[:2000]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == ranks and d["config"]["exchange_payload"] == "mask" and "one bit per pool slot" in d["config"]["exchange"]
+    assert d["n_gpus"] == ranks and d["config"]["exchange_payload"] == "mask" and "one bit per mirror entry" in d["config"]["exchange"]
     assert d["parity"]["visible_set_bit_identical"] and "error" not in d

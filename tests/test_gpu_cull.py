@@ -1351,30 +1351,40 @@ def test_instance_bases_are_the_reference_draw_loops_fetch_adds(oracle, n):
 
 
 @pytest.mark.parametrize("n", [1000, 70_003, 400_000])
-def test_mask_shard_is_the_visible_list_as_bits(oracle, n):
-    """gv_results_copy_mask_device: [draw_count, one bit per POOL slot] — the same set as the index list (whatever the mirror
-    order), zero bits elsewhere, after a sort as well, and garden_amd.multi's CPU restatement of the encoding agrees."""
+@pytest.mark.parametrize("keep_slot_order", [False, True])
+def test_mask_shard_is_the_visible_list_as_bits(oracle, n, keep_slot_order):
+    """gv_results_copy_mask_device: [draw_count, one bit per MIRROR entry] — through gv_pool_mirror_slots the same set as the
+    index list (identity table with GV_CONFIG_KEEP_SLOT_ORDER), zero bits elsewhere, for the ordinary cull launch (ballot words
+    copied) and the one-launch cull + emit of a small pool (built from the isVisible bytes), main and shadow views; and
+    garden_amd.multi's CPU restatement of the encoding agrees."""
     import torch
     from garden_amd.lib import GpuVisibility
     from garden_amd.multi import expand_mask_rows, mask_words, pack_mask_shard
     sc = scene.flat_scene(n, seed=n)
-    view = scene.main_camera_view()
-    words = mask_words(n)
-    with GpuVisibility(device=0) as vis:
+    main, shadow = scene.main_camera_view(), scene.cascade_view(index=0, size=4000.0)
+    words = mask_words(n) + 3  # more words than needed: the rest must come back zero
+    with GpuVisibility(device=0, keep_slot_order=keep_slot_order) as vis:
         vis.bind_transforms(sc.transforms, sc.entity_to_transform)
         vis.bind_pool(0, sc.meshes)
         vis.hierarchy_rebuild()
-        shard = torch.full((1 + words,), -1, dtype=torch.int32, device="cuda:0")  # poison: the call clears its words itself
-        for sort in (False, True):
-            vis.cull(0, [view])
-            if sort:
-                vis.sort(0, descending=False)
+        table = vis.mirror_slots(0, n)
+        assert np.array_equal(np.sort(table), np.arange(n)) and (not keep_slot_order or np.array_equal(table, np.arange(n)))
+        shard = torch.full((1 + words,), -1, dtype=torch.int32, device="cuda:0")  # poison
+        for views, vi in (([main], 0), ([main, shadow], 1), ([main, shadow], 0)):
+            vis.cull(0, views)
             torch.cuda.synchronize()
-            vis.copy_mask_device(0, shard.data_ptr(), words)
+            vis.copy_mask_device(vi, shard.data_ptr(), words)
             vis.wait()
-            got = vis.fetch(0, write_back=False, occupancy=n)
-            exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
-            assert exp["draw_count"] > 0 and np.array_equal(np.sort(got["visible_idx"]), np.sort(exp["visible_idx"]))
-            slots, counts = expand_mask_rows(shard.view(1, -1), n, index_bases=[0])
+            exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, views[vi])
+            assert exp["draw_count"] > 0
+            slots, counts = expand_mask_rows(shard.view(1, -1), n, entry_tables=[table], index_bases=[0])
             assert counts.tolist() == [exp["draw_count"]] and np.array_equal(slots, np.sort(exp["visible_idx"]).astype(np.int64))
-            assert torch.equal(shard.cpu(), pack_mask_shard(exp["visible_idx"], n))
+            inverse = np.empty(n, np.int64)
+            inverse[table] = np.arange(n)
+            ref = pack_mask_shard(inverse[exp["visible_idx"]], (words - 0) * 32)[:1 + words]
+            assert torch.equal(shard.cpu(), ref)
+        if n <= 32768:  # a shadow view alone over a small pool takes the one-launch cull + emit: no ballot words, no bytes
+            vis.cull(0, [shadow])
+            with pytest.raises(RuntimeError) as e:
+                vis.copy_mask_device(0, shard.data_ptr(), words)
+            assert "neither" in str(e.value)
