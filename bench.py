@@ -438,7 +438,10 @@ def main():
             else:
                 dist.all_gather(tables, mine)
             entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
-        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=args.payload)
+        # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
+        per_rank = ([shard_capacity(int(c)) for c in exact_counts] if args.payload == "indices" and args.exchange != "allgather" else None)
+        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=args.payload,
+                                    capacities=per_rank)
     for _ in range(args.warmup):
         step()
     fence()

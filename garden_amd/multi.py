@@ -263,7 +263,8 @@ class VisibleListExchange:
 
     MODES = ("allgather", "p2p", "broadcast")
 
-    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2, mode="allgather", payload="indices"):
+    def __init__(self, dist, device, capacity, stream=None, group=None, slots=2, mode="allgather", payload="indices",
+                 capacities=None):
         """mode: how the shards travel. "allgather" = ONE equal-size all-gather; "p2p" = one group of send/recv pairs
         with every peer (batch_isend_irecv = ncclGroupStart ... ncclGroupEnd: each shard crosses exactly one xGMI link,
         all links at once); "broadcast" = one broadcast per root. Same rows in the same place either way — the node's
@@ -274,10 +275,18 @@ class VisibleListExchange:
         # "mask": shards are [count, one bit per pool slot] (gv_results_copy_mask_device; capacity = mask_words(slots)): a fixed
         # size whatever the view, so a shard cannot overflow and the header is only the count
         self.payload = payload
+        # capacities[r] <= capacity: how much of rank r's shard actually travels in the "p2p" and "broadcast" patterns (every
+        # rank passes the same list, e.g. shard_capacity of each rank's count in an earlier frame: all ranks know all counts
+        # from the headers). The equal-size all-gather always moves `capacity` per rank; a tile behind the camera then costs
+        # as much as the fullest one. Rows keep their fixed place in the result.
+        self.capacities = None
         self.dist, self.group, self.device = dist, group, torch.device(device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.backend = dist.get_backend(group)
         self.capacity, self.slots, self.frame = int(capacity), slots, 0
+        if capacities is not None:
+            assert len(capacities) == self.world and all(0 <= int(c) <= self.capacity for c in capacities), capacities
+            self.capacities = [int(c) for c in capacities]
         self.native = self.backend == "nccl" and self.device.type == "cuda"
         self.stream = stream if self.native else None  # producer stream (torch.cuda.Stream / ExternalStream)
         self.side = torch.cuda.Stream(device=self.device) if self.native else None
@@ -303,17 +312,18 @@ class VisibleListExchange:
         if self.mode == "allgather":
             return self.dist.all_gather_into_tensor(out, shard, group=self.group, async_op=async_op)
         rows[self.rank].copy_(shard)  # own row: a local copy in stream order
+        live = (lambda r: 1 + self.capacities[r]) if self.capacities is not None else (lambda r: n)  # header + what travels
         works = []
         if self.mode == "p2p":
             ops = []
             for d in range(1, self.world):
                 to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
-                ops.append(self.dist.P2POp(self.dist.isend, shard, self._global(to), self.group))
-                ops.append(self.dist.P2POp(self.dist.irecv, rows[frm], self._global(frm), self.group))
+                ops.append(self.dist.P2POp(self.dist.isend, shard[:live(self.rank)], self._global(to), self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, rows[frm][:live(frm)], self._global(frm), self.group))
             works = self.dist.batch_isend_irecv(ops) if ops else []
         else:
             for r in range(self.world):
-                works.append(self.dist.broadcast(rows[r], src=self._global(r), group=self.group, async_op=True))
+                works.append(self.dist.broadcast(rows[r][:live(r)], src=self._global(r), group=self.group, async_op=True))
         ws = _WorkSet(works)
         if not async_op:
             ws.wait()
@@ -333,8 +343,13 @@ class VisibleListExchange:
             self.header_events[s].synchronize()  # enqueued a whole frame ago
         self.in_flight[s] = False
         worst = int(self.headers[s].max())
-        if self.payload == "indices" and worst > self.capacity:
-            raise ShardOverflow(worst, self.capacity)
+        if self.payload == "indices":
+            if worst > self.capacity:
+                raise ShardOverflow(worst, self.capacity)
+            if self.capacities is not None and self.mode != "allgather":
+                for r in range(self.world):  # a rank whose list outgrew the part of its shard that travels
+                    if int(self.headers[s][r]) > self.capacities[r]:
+                        raise ShardOverflow(int(self.headers[s][r]), self.capacities[r])
 
     def next_shard(self):
         s = self.frame % self.slots

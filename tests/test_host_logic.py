@@ -178,6 +178,54 @@ def test_padded_exchange_world_size_2_gloo():
         assert ok and overflow == cap + 5
 
 
+def _uneven_exchange_worker(rank, world, port, ret, mode):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garden_amd.multi import ShardOverflow, VisibleListExchange
+    counts = [0, 700, 33][:world]          # a tile behind the camera, a full one, a sparse one
+    caps = [16, 704, 48][:world]           # what travels per rank (the direct patterns); the rows stay 1 + 704 wide
+    ex = VisibleListExchange(dist, "cpu", 704, mode=mode, capacities=caps)
+    ok = True
+    for frame in range(3):
+        shard = ex.next_shard()
+        shard.zero_()
+        shard[0] = counts[rank]
+        shard[1:1 + counts[rank]] = torch.arange(counts[rank], dtype=torch.int32) + 10_000 * rank + frame
+        padded = ex.exchange()
+        dense, got_counts = ex.compact(padded)
+        exp = torch.cat([torch.arange(counts[r], dtype=torch.int32) + 10_000 * r + frame for r in range(world)])
+        ok = ok and torch.equal(dense, exp) and got_counts.tolist() == counts
+    ex.drain()
+    shard = ex.next_shard()  # the sparse rank's list outgrows the part of its shard that travels (but not the row)
+    shard[0] = 60 if rank == world - 1 else counts[rank]
+    ex.exchange()
+    try:
+        ex.drain()
+        overflow = None
+    except ShardOverflow as e:
+        overflow = e.needed
+    ret[rank] = (ok, overflow)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["p2p", "broadcast"])
+def test_direct_patterns_move_only_what_each_rank_needs_gloo(mode):
+    """capacities=[...]: in the p2p and broadcast patterns rank r's shard travels as 1 + capacities[r] words (every rank
+    knows every count, so every rank sizes every transfer the same way); results as with full rows, and a list that
+    outgrows its rank's travelling part is reported on every rank."""
+    import torch.multiprocessing as mp
+    world, port = 3, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_uneven_exchange_worker, args=(world, port, ret, mode), nprocs=world, join=True)
+    for rank in range(world):
+        ok, overflow = ret[rank]
+        assert ok and overflow == 60, (rank, ok, overflow)
+
+
 def _mask_exchange_worker(rank, world, port, ret, mode):
     import torch
     import torch.distributed as dist
