@@ -223,10 +223,12 @@ def main():
                     choices=["allgather", "p2p", "broadcast"],
                     help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
                          "send/recv to every peer, or one broadcast per root (A/B for the fully connected xGMI node)")
-    ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "indices"), choices=["indices", "mask"],
-                    help="N > 1: what a shard carries — the compacted uint32 index list (default) or one bit per pool slot behind "
-                         "the count (1/32 word per slot whatever the view: ~7x fewer bytes at the bench's 21 %% visibility); an "
-                         "A/B for real hardware, the gathered sets are checked against the exact all-gatherv either way")
+    ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "auto"), choices=["auto", "indices", "mask"],
+                    help="N > 1: what a shard carries — the compacted uint32 index list, or one bit per mirror entry behind the "
+                         "count (1/32 word per entry whatever the view: ~7x fewer bytes at the bench's 21 %% visibility). auto "
+                         "(default): the smaller of the two for the view at hand (bits above 1/32 visible), after one trial frame of "
+                         "the bit form has been checked against the exact all-gatherv on every rank — the lists otherwise. The gathered "
+                         "sets of the timed frames are checked against the exact all-gatherv either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -425,23 +427,51 @@ def main():
             leave(1)
         gathered_total = int(exact_counts.sum())
         producer = lib_stream if backend == "nccl" else None
-        capacity = mask_words(n) if args.payload == "mask" else shard_capacity(int(exact_counts.max()))
-        if args.payload == "mask":
-            # once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit shards
-            # needs to name the entities; the static scene never rebuilds its mirror)
-            mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
-            tables = [torch.empty_like(mine) for _ in range(world)]
-            if backend == "nccl":
-                dev_tables = [t.to(f"cuda:{local_rank}") for t in tables]
-                dist.all_gather(dev_tables, mine.to(f"cuda:{local_rank}"))
-                tables = [t.cpu() for t in dev_tables]
+
+        def make_exchange(payload):
+            """The frame loop's exchange object for `payload` (and, for bit shards, every rank's entry -> slot table)."""
+            args.payload = payload
+            if payload == "mask":
+                # once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit
+                # shards needs to name the entities; the static scene never rebuilds its mirror)
+                mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
+                tables = [torch.empty_like(mine) for _ in range(world)]
+                if backend == "nccl":
+                    dev_tables = [t.to(f"cuda:{local_rank}") for t in tables]
+                    dist.all_gather(dev_tables, mine.to(f"cuda:{local_rank}"))
+                    tables = [t.cpu() for t in dev_tables]
+                else:
+                    dist.all_gather(tables, mine)
+                entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
+            capacity = mask_words(n) if payload == "mask" else shard_capacity(int(exact_counts.max()))
+            # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
+            per_rank = ([shard_capacity(int(c)) for c in exact_counts] if payload == "indices" and args.exchange != "allgather" else None)
+            return VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=payload,
+                                       capacities=per_rank)
+
+        payload_note = None
+        if args.payload == "auto":
+            # the smaller encoding for this view: bits beat a word per visible entry above 1/32 visible (all ranks see all counts)
+            dense_view = int(exact_counts.sum()) * 32 > n * world
+            payload_note = f"auto: {exact_counts.sum() / (n * world):.1%} of the entities visible"
+            if dense_view:
+                trial_problem = "trial not run"
+                try:  # one frame of the bit form against the exact lists before it is trusted with the timed frames
+                    ex[0] = make_exchange("mask")
+                    trial_problem = check_padded(step(), exact, exact_counts)
+                except Exception as e:  # noqa: BLE001 — anything at all: fall back to the lists
+                    trial_problem = f"{type(e).__name__}: {e}"
+                if all_agree(trial_problem is None):
+                    payload_note += ", bit shards (checked on a trial frame)"
+                else:
+                    print(f"bench.py: bit-shard trial failed on some rank ({trial_problem}); using index lists", file=sys.stderr)
+                    payload_note += ", index lists (the bit-shard trial failed)"
+                    ex[0] = make_exchange("indices")
             else:
-                dist.all_gather(tables, mine)
-            entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
-        # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
-        per_rank = ([shard_capacity(int(c)) for c in exact_counts] if args.payload == "indices" and args.exchange != "allgather" else None)
-        ex[0] = VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=args.payload,
-                                    capacities=per_rank)
+                payload_note += ", index lists"
+                ex[0] = make_exchange("indices")
+        else:
+            ex[0] = make_exchange(args.payload)
     for _ in range(args.warmup):
         step()
     fence()
@@ -616,7 +646,7 @@ def main():
                                     f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
                                     f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
                        "exchange_mode": args.exchange if exchange else None,
-                       "exchange_payload": args.payload if exchange else None,
+                       "exchange_payload": (args.payload + (f" ({payload_note})" if payload_note else "")) if exchange else None,
                        "same_frames_without_exchange": no_exchange,
                        # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
                        "kernel_ms": {k: (st["device_ms"][k] * (st["launches"][k] / max(1, timed[k])) / max(1, args.steps))
