@@ -153,30 +153,16 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
     return GV_OK;
 }
 
-int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device)
+// ctx->d_shard[0 .. words) of every rank into rows [rank * words ...) of gathered_device, by the configured pattern
+static int exchange_rows(GvCtx* ctx, size_t words, void* gathered_device, const char* what)
 {
-    if (!ctx)
-        return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_shards: gv_exchange_init has not run");
-    if (!gathered_device || capacity == 0)
-        return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t* before = ctx->d_shard.ptr;
-    GV_HIP(ctx, ctx->d_shard.reserve((size_t)capacity + 1));
-    if (ctx->d_shard.ptr != before)  // the collective reads the whole shard: no byte of it is left uninitialised
-        GV_HIP(ctx, hipMemsetAsync(ctx->d_shard.ptr, 0, ctx->d_shard.cap * sizeof(uint32_t), ctx->stream));
-    const int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, capacity, index_base);
-    if (rc != GV_OK)
-        return rc;
     Rccl& r = rccl();
-    const size_t words = (size_t)capacity + 1;
     uint32_t* rows = static_cast<uint32_t*>(gathered_device);
     const int me = ctx->exchange_rank, world = ctx->exchange_world;
     if (ctx->exchange_mode == GV_EXCHANGE_ALLGATHER) {
         const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, words, kNcclUint32, ctx->exchange_comm, ctx->stream);
         if (nrc != 0)
-            return ctx->fail(GV_E_RCCL, "ncclAllGather: %s", r.GetErrorString(nrc));
+            return ctx->fail(GV_E_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(nrc));
         return GV_OK;
     }
     // the direct forms place this rank's own row with a device copy; the peers' rows arrive over the links
@@ -199,9 +185,51 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint3
     if (nrc == 0)
         nrc = erc;
     if (nrc != 0)
-        return ctx->fail(GV_E_RCCL, "%s exchange: %s", ctx->exchange_mode == GV_EXCHANGE_P2P ? "ncclSend/ncclRecv" : "ncclBroadcast",
+        return ctx->fail(GV_E_RCCL, "%s: %s exchange: %s", what, ctx->exchange_mode == GV_EXCHANGE_P2P ? "ncclSend/ncclRecv" : "ncclBroadcast",
                          r.GetErrorString(nrc));
     return GV_OK;
+}
+
+// the rank's staging shard, every byte defined (the collective reads all of it)
+static int reserve_shard(GvCtx* ctx, size_t words)
+{
+    const uint32_t* before = ctx->d_shard.ptr;
+    GV_HIP(ctx, ctx->d_shard.reserve(words));
+    if (ctx->d_shard.ptr != before)
+        GV_HIP(ctx, hipMemsetAsync(ctx->d_shard.ptr, 0, ctx->d_shard.cap * sizeof(uint32_t), ctx->stream));
+    return GV_OK;
+}
+
+int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_shards: gv_exchange_init has not run");
+    if (!gathered_device || capacity == 0)
+        return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = reserve_shard(ctx, (size_t)capacity + 1))
+        return rc;
+    if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, capacity, index_base))
+        return rc;
+    return exchange_rows(ctx, (size_t)capacity + 1, gathered_device, "gv_exchange_shards");
+}
+
+int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_masks: gv_exchange_init has not run");
+    if (!gathered_device || word_count == 0)
+        return ctx->fail(GV_E_ARG, "gv_exchange_masks: NULL buffer or zero word count");
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = reserve_shard(ctx, (size_t)word_count + 1))
+        return rc;
+    if (int rc = gv_results_copy_mask_device(ctx, view_index, ctx->d_shard.ptr, word_count))
+        return rc;
+    return exchange_rows(ctx, (size_t)word_count + 1, gathered_device, "gv_exchange_masks");
 }
 
 int gv_exchange_shutdown(GvCtx* ctx)

@@ -111,7 +111,7 @@ EXPORTS = [
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples",
@@ -187,6 +187,7 @@ def load():
     lib.gv_exchange_unique_id.argtypes = [P]
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
     lib.gv_exchange_shards.argtypes = [P, u32, u32, u32, P]
+    lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]
     lib.gv_exchange_set_mode.argtypes = [P, u32]
     lib.gv_pool_set_index_map.argtypes = [P, u32, P, u32]
@@ -449,6 +450,10 @@ class GpuVisibility:
 
     def exchange_shards(self, view_index, capacity, index_base, gathered_ptr):
         self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, index_base, gathered_ptr))
+
+    def exchange_masks(self, view_index, word_count, gathered_ptr):
+        """All ranks' [draw_count, one bit per mirror entry] shards into gathered_ptr ([world, 1 + word_count] uint32, device)."""
+        self._check(self.lib.gv_exchange_masks(self.ctx, view_index, word_count, gathered_ptr))
 
     def exchange_set_mode(self, mode):
         """0 all-gather, 1 grouped send/recv with every peer, 2 one broadcast per root (GvExchangeMode)."""

@@ -303,6 +303,10 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
 int gv_exchange_unique_id(void* out_id_128_bytes);
 int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int world_size);
 int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device);
+/* The same exchange with bit shards (gv_results_copy_mask_device): row r of gathered_device = rank r's [draw_count, one bit per
+ * mirror entry] (word_count + 1 uint32 per row; word_count the same on every rank, >= ceil(occupancy / 32) of the largest
+ * pool). A fixed size whatever the view — the encoding for dense views (1/32 word per entry). */
+int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device);
 int gv_exchange_shutdown(GvCtx* ctx);
 /* How gv_exchange_shards moves the shards (same result rows either way). The node's xGMI fabric is point to point and
  * fully connected: a ring all-gather serialises world-1 hops, the direct forms use every link at

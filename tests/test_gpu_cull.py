@@ -800,9 +800,24 @@ def test_native_rccl_exchange_single_rank(oracle):
         k = raw["draw_count"]
         assert g[0] == k and 0 < k <= cap
         assert np.array_equal(g[1:1 + k].astype(np.int64), raw["visible_idx"].astype(np.int64) + 5_000_000)
+        # the same frame as bit shards (gv_exchange_masks), through every transport pattern
+        from garden_amd.multi import expand_mask_rows, mask_words
+        words = mask_words(sc.count)
+        table = vis.mirror_slots(0, sc.count)
+        for mode in (0, 1, 2):
+            vis.exchange_set_mode(mode)
+            rows = torch.full((1, 1 + words), -1, dtype=torch.int32, device="cuda:0")
+            vis.cull(0, [view])
+            vis.exchange_masks(0, words, rows.data_ptr())
+            vis.wait()
+            slots, counts = expand_mask_rows(rows, sc.count, entry_tables=[table], index_bases=[0])
+            assert counts.tolist() == [k] and np.array_equal(slots, np.sort(raw["visible_idx"]).astype(np.int64)), mode
+        vis.exchange_set_mode(0)
         vis.exchange_shutdown()
         with pytest.raises(Exception):
             vis.exchange_shards(0, cap, 0, gathered.data_ptr())  # GV_E_STATE after shutdown
+        with pytest.raises(Exception):
+            vis.exchange_masks(0, words, gathered.data_ptr())
 
 
 @pytest.mark.gpu
