@@ -134,6 +134,22 @@ int hiz_reduce(GvCtx* ctx)
                 dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
             GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, rg16f, ctx->stream));
             k += 6;
+        } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels && getenv("GV_DEBUG_HIZ_NO_TAIL") == nullptr) {
+            // the rest of the pyramid is small: one workgroup, one launch (frame sizes are rarely divisible by 64)
+            static_assert(GV_MAX_MIPS <= 16, "HizTailArgs holds 16 levels");
+            HizTailArgs tail{};
+            tail.depth = ctx->depth_ptr;
+            tail.mips = ctx->d_mips.ptr;
+            for (uint32_t m = 0; m < ctx->hiz_mips; m++) {
+                tail.offset[m] = ctx->mip_off[m];
+                tail.w[m] = ctx->mip_w[m];
+                tail.h[m] = ctx->mip_h[m];
+            }
+            tail.first = k;
+            tail.count = ctx->hiz_mips - k;
+            tail.rule = ctx->config.hiz_rule;
+            GV_HIP(ctx, launch_hiz_tail(tail, rg16f, ctx->stream));
+            k = ctx->hiz_mips;
         } else {
             GV_HIP(ctx, launch_hiz_level(src_d, src_p, mip_ptr(ctx, k), sw, sh, ctx->mip_w[k], ctx->mip_h[k], ctx->config.hiz_rule, rg16f,
                                          ctx->stream));

@@ -34,7 +34,40 @@ __device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
     mm.y = t.y > mm.y ? t.y : mm.y;  // MAX_DEPTH  depth.gsl:32-33
 }
 
-// One destination texel per lane; any size (hiz.frag:27-56 with the odd-size branches).
+// One destination texel of a level from the level before it; any size (hiz.frag:27-56 with the odd-size branches).
+// SRC(x, y) -> (min, max) of the source level's texel.
+template <class SRC>
+__device__ __forceinline__ float2 hiz_level_texel_from(SRC src, uint32_t sw, uint32_t sh, uint32_t px, uint32_t py, uint32_t rule)
+{
+    const bool odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0;
+    const uint32_t x0 = 2 * px, y0 = 2 * py;
+    const uint32_t x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const uint32_t x2 = min(x0 + 2, sw - 1), y2 = min(y0 + 2, sh - 1);
+    float2 mm = src(x0, y0);
+    hiz_acc(mm, src(x1, y0));
+    hiz_acc(mm, src(x0, y1));
+    hiz_acc(mm, src(x1, y1));
+    if (odd_x) {  // hiz.frag:36-41
+        hiz_acc(mm, src(x2, y1));
+        hiz_acc(mm, src(x2, y0));
+        if (odd_y)  // hiz.frag:43-47
+            hiz_acc(mm, src(x2, y2));
+    }
+    if (odd_y) {  // hiz.frag:49-55 reads gather components .y/.z = (2p.x+1, 2p.y+2), (2p.x+1, 2p.y+1)
+        hiz_acc(mm, src(x1, y2));
+        if (rule == 1u)  // GV_HIZ_RULE_CONSERVATIVE: the whole extra row
+            hiz_acc(mm, src(x0, y2));
+    }
+    return mm;
+}
+template <bool F16>
+__device__ __forceinline__ float2 hiz_level_texel(const float* __restrict__ src_depth, const float2* __restrict__ src_pairs, uint32_t sw,
+                                                  uint32_t sh, uint32_t px, uint32_t py, uint32_t rule)
+{
+    return hiz_level_texel_from([&](uint32_t x, uint32_t y) { return hiz_src<F16>(src_depth, src_pairs, sw, x, y); }, sw, sh, px, py, rule);
+}
+
+// One destination texel per lane.
 template <bool F16>
 __global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict__ src_depth,
                                                         const float2* __restrict__ src_pairs,
@@ -45,26 +78,53 @@ __global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict_
     const uint32_t py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= dw || py >= dh)
         return;
-    const bool odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0;
-    const uint32_t x0 = 2 * px, y0 = 2 * py;
-    const uint32_t x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
-    const uint32_t x2 = min(x0 + 2, sw - 1), y2 = min(y0 + 2, sh - 1);
-    float2 mm = hiz_src<F16>(src_depth, src_pairs, sw, x0, y0);
-    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y0));
-    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x0, y1));
-    hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y1));
-    if (odd_x) {  // hiz.frag:36-41
-        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y1));
-        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y0));
-        if (odd_y)  // hiz.frag:43-47
-            hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x2, y2));
+    hiz_store<F16>(dst, (size_t)py * dw + px, hiz_level_texel<F16>(src_depth, src_pairs, sw, sh, px, py, rule));
+}
+
+// The small levels of a pyramid of ANY size in one launch: one workgroup walks levels [first, first + count) in turn. Every
+// level is written to the pyramid AND kept in LDS, where the next one reads it (two 64 KB halves in turn): a level costs a
+// barrier instead of a launch or a round trip through L2. Frame sizes are rarely divisible by 64 (1920 x 1080, 2560 x 1440,
+// 3840 x 2160: none is), so without this a build is one launch per level, most of them a few hundred texels.
+template <bool F16>
+__global__ __launch_bounds__(1024) void hiz_tail_kernel(const HizTailArgs a)
+{
+    __shared__ float2 level[2][kHizTailTexels];
+    for (uint32_t l = 0; l < a.count; l++) {
+        const uint32_t k = a.first + l;
+        const uint32_t sw = a.w[k - 1], sh = a.h[k - 1], dw = a.w[k], dh = a.h[k];
+        float2* dst = F16 ? reinterpret_cast<float2*>(reinterpret_cast<uint32_t*>(a.mips) + a.offset[k]) : a.mips + a.offset[k];
+        float2* keep = level[l & 1u];
+        const float2* prev = level[(l & 1u) ^ 1u];
+        for (uint32_t t = threadIdx.x; t < dw * dh; t += 1024) {
+            const uint32_t px = t % dw, py = t / dw;
+            float2 mm;
+            if (l != 0) {
+                mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return prev[y * sw + x]; }, sw, sh, px, py, a.rule);
+            } else {
+                const float* src_depth = k == 1 ? a.depth : nullptr;
+                const float2* src_pairs = k == 1 ? nullptr
+                                                 : (F16 ? reinterpret_cast<const float2*>(reinterpret_cast<const uint32_t*>(a.mips) + a.offset[k - 1])
+                                                        : a.mips + a.offset[k - 1]);
+                mm = hiz_level_texel<F16>(src_depth, src_pairs, sw, sh, px, py, a.rule);
+                if (F16 && k == 1)  // the one place a value leaves fp32: what the texel holds is what the next level reduces
+                    mm = unpack_rg16f(pack_rg16f(mm));
+            }
+            hiz_store<F16>(dst, t, mm);
+            keep[t] = mm;
+        }
+        __syncthreads();
     }
-    if (odd_y) {  // hiz.frag:49-55 reads gather components .y/.z = (2p.x+1, 2p.y+2), (2p.x+1, 2p.y+1)
-        hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x1, y2));
-        if (rule == 1u)  // GV_HIZ_RULE_CONSERVATIVE: the whole extra row
-            hiz_acc(mm, hiz_src<F16>(src_depth, src_pairs, sw, x0, y2));
-    }
-    hiz_store<F16>(dst, (size_t)py * dw + px, mm);
+}
+
+hipError_t launch_hiz_tail(const HizTailArgs& args, bool rg16f, hipStream_t stream)
+{
+    if (args.count == 0)
+        return hipSuccess;
+    if (rg16f)
+        hipLaunchKernelGGL(hiz_tail_kernel<true>, dim3(1), dim3(1024), 0, stream, args);
+    else
+        hipLaunchKernelGGL(hiz_tail_kernel<false>, dim3(1), dim3(1024), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,

@@ -222,6 +222,17 @@ hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, 
 // rg16f: src_pairs / dst (and HizFusedDst::level) point to packed binary16 pairs, 4 bytes per texel
 hipError_t launch_hiz_level(const float* src_depth, const float2* src_pairs, float2* dst, uint32_t sw, uint32_t sh,
                             uint32_t dw, uint32_t dh, uint32_t rule, bool rg16f, hipStream_t stream);
+// Levels [first, first + count) by ONE workgroup, one after the other (any sizes; a level's source is the level before it, the
+// depth image for level 1). For the small levels of a pyramid: at most kHizTailTexels texels in the first of them.
+constexpr uint32_t kHizTailTexels = 8192;  // two levels of this size fit the LDS
+struct HizTailArgs {
+    const float* depth;
+    float2* mips;          // level k >= 1 at mips + offset[k] (texels; packed binary16 pairs when rg16f)
+    uint64_t offset[16];
+    uint32_t w[16], h[16];
+    uint32_t first, count, rule;
+};
+hipError_t launch_hiz_tail(const HizTailArgs& args, bool rg16f, hipStream_t stream);
 // Fused 6-level reduction of 64x64 source tiles through LDS; needs sw % 64 == 0 && sh % 64 == 0.
 // dst[l] = level (src+1+l), l = 0..5.
 struct HizFusedDst {
