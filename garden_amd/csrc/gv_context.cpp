@@ -594,6 +594,13 @@ int gv_create(const GvConfig* config, GvCtx** out_ctx)
     return GV_OK;
 }
 
+static void release_record_target(PoolState::RecordTarget& target)
+{
+    if (target.dev)
+        (void)hipHostUnregister(target.host);
+    target = PoolState::RecordTarget{};
+}
+
 void gv_destroy(GvCtx* ctx)
 {
     if (!ctx)
@@ -610,6 +617,8 @@ void gv_destroy(GvCtx* ctx)
     ctx->d_xab.release(); ctx->d_xc.release(); ctx->d_xflags.release(); ctx->d_xactive.release(); ctx->d_xparent.release();
     ctx->h_xab.release(); ctx->h_xc.release(); ctx->h_xflags.release(); ctx->h_xparent.release();
     for (auto& p : ctx->pools) {
+        for (auto& target : p.record_target)
+            release_record_target(target);
         p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
     }
     for (auto& per_pool : ctx->views)
@@ -981,6 +990,7 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             PublishBatch batch{};
             uint32_t views = 0, widest = 0;
             ViewState* sent[kMaxPublishViews];
+            bool staged[kMaxPublishViews] = {};  // record targets that could not be page-locked: filled from h_records below
             for (uint32_t q = 0; q < GV_MAX_POOLS && views < kMaxPublishViews; q++) {
                 const uint32_t pid = (pool_id + q) % GV_MAX_POOLS;  // the pool asked for first: it always fits
                 PoolState& wp = ctx->pools[pid];
@@ -998,8 +1008,19 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
                     GV_HIP(ctx, w.h_draw_count.reserve(4));
                     a.host_count = w.h_draw_count.ptr;
                     if (w.emitted && wp.record_layout.stride) {
-                        GV_HIP(ctx, w.h_records.reserve((size_t)w.occupancy * wp.record_layout.stride));
-                        a.host_records = w.h_records.ptr;
+                        const PoolState::RecordTarget& target = wp.record_target[v];
+                        const size_t need = (size_t)w.occupancy * wp.record_layout.stride;
+                        if (target.host && target.bytes < need)
+                            return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu",
+                                             pid, v, target.bytes, need);
+                        if (target.dev) {  // the device writes the caller's array
+                            a.host_records = target.dev;
+                        } else {
+                            GV_HIP(ctx, w.h_records.reserve(need));
+                            a.host_records = w.h_records.ptr;
+                        }
+                        w.records_at = target.host ? target.host : w.h_records.ptr;
+                        staged[views] = target.host && !target.dev;
                         a.layout = wp.record_layout;
                         w.records_fetched = true;
                     } else if (w.emitted) {
@@ -1029,8 +1050,12 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             GV_HIP(ctx, launch_publish(batch, views, widest, ctx->stream));
             GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             drain_events(ctx);
-            for (uint32_t k = 0; k < views; k++)
-                sent[k]->published = true;
+            for (uint32_t k = 0; k < views; k++) {
+                ViewState& w = *sent[k];
+                w.published = true;
+                if (staged[k])
+                    memcpy(w.records_at, w.h_records.ptr, (size_t)w.h_draw_count.ptr[0] * batch.view[k].layout.stride);
+            }
         }
         count = vs.h_draw_count.ptr[0];
     } else {
@@ -1039,13 +1064,25 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             return rc;
         if (vs.emitted && pool.record_layout.stride)
             vs.records_fetched = true;
+        const PoolState::RecordTarget& target = pool.record_target[view_index];
+        uint8_t* staged_for = nullptr;  // a target that could not be page-locked: filled from h_records after the copies
+        if (vs.emitted && pool.record_layout.stride) {
+            const size_t need = (size_t)vs.occupancy * pool.record_layout.stride;
+            if (target.host && target.bytes < need)
+                return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu",
+                                 pool_id, view_index, target.bytes, need);
+            if (!target.dev)
+                GV_HIP(ctx, vs.h_records.reserve(need));
+            vs.records_at = target.host ? target.host : vs.h_records.ptr;
+        }
         if (vs.emitted && count && pool.record_layout.stride) {  // packed on the device, one copy
             const size_t bytes = (size_t)count * pool.record_layout.stride;
             GV_HIP(ctx, vs.d_records.reserve((size_t)vs.occupancy * pool.record_layout.stride));
-            GV_HIP(ctx, vs.h_records.reserve((size_t)vs.occupancy * pool.record_layout.stride));
             GV_HIP(ctx, launch_pack_records(vs.draw_count.ptr, vs.visible_idx.ptr, vs.baked_model.ptr, vs.distance_sq.ptr, pool.record_layout,
                                             count, vs.d_records.ptr, ctx->stream));
-            GV_HIP(ctx, hipMemcpyAsync(vs.h_records.ptr, vs.d_records.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            uint8_t* dst = target.dev ? target.host : vs.h_records.ptr;
+            staged_for = target.host && !target.dev ? target.host : nullptr;
+            GV_HIP(ctx, hipMemcpyAsync(dst, vs.d_records.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
         } else if (vs.emitted && count) {
             if ((rc = reserve_records()) != GV_OK)
                 return rc;
@@ -1063,6 +1100,8 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             GV_HIP(ctx, hipMemcpyAsync(vs.h_is_visible.ptr, src, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
         }
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (staged_for)
+            memcpy(staged_for, vs.h_records.ptr, (size_t)count * pool.record_layout.stride);
     }
     memset(out, 0, sizeof(*out));
     out->draw_count = count;
@@ -1079,7 +1118,7 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         std::atomic<uint64_t> total{0};
         if (as_records) {  // the slot is componentOffset / component size
             const RecordLayout L = pool.record_layout;
-            const uint8_t* field = vs.h_records.ptr + L.component_offset;
+            const uint8_t* field = vs.records_at + L.component_offset;
             parallel_ranges(0, count, [&](uint32_t a, uint32_t b) {
                 uint64_t sum = 0;
                 for (uint32_t k = a; k < b; k++) {
@@ -1167,6 +1206,40 @@ int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout
     return GV_OK;
 }
 
+int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* records, size_t bytes)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || view_index >= GV_MAX_VIEWS)
+        return ctx->fail(GV_E_ARG, "gv_pool_set_record_target: pool %u view %u out of range", pool_id, view_index);
+    if (records && ((uintptr_t)records % 16 != 0 || bytes == 0))
+        return ctx->fail(GV_E_ARG, "gv_pool_set_record_target: records must be 16-byte aligned and bytes non-zero");
+    PoolState::RecordTarget& target = ctx->pools[pool_id].record_target[view_index];
+    if (target.host == records && (target.bytes == bytes || !records))
+        return GV_OK;  // set every frame by callers that re-bind every frame
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (target.dev)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still write the range that is let go
+    release_record_target(target);
+    ViewState& vs = ctx->views[pool_id][view_index];
+    vs.published = false, vs.records_fetched = false;  // the next fetch delivers this view's records again, to the new place
+    if (!records)
+        return GV_OK;
+    target.host = static_cast<uint8_t*>(records);
+    target.bytes = bytes;
+    void* dev = nullptr;
+    // page-locked once per (address, size): combinedMeshes is grown, never shrunk (mesh.cpp:377-395). A range that cannot be
+    // locked (it shares pages with another locked range, RLIMIT_MEMLOCK ...) is filled by a host copy at the fetch instead.
+    if (hipHostRegister(records, bytes, hipHostRegisterDefault) == hipSuccess) {
+        if (hipHostGetDevicePointer(&dev, records, 0) == hipSuccess && dev)
+            target.dev = static_cast<uint8_t*>(dev);
+        else
+            (void)hipHostUnregister(records);
+    }
+    (void)hipGetLastError();
+    return GV_OK;
+}
+
 int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count)
 {
     if (!ctx)
@@ -1184,7 +1257,7 @@ int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, c
             return rc;
     }
     *count = vs.h_draw_count.ptr[0];
-    *records = *count && vs.records_fetched ? vs.h_records.ptr : nullptr;
+    *records = *count && vs.records_fetched ? vs.records_at : nullptr;
     return GV_OK;
 }
 
@@ -1212,7 +1285,7 @@ int gv_pool_results_instance_bases(GvCtx* ctx, uint32_t pool_id, uint32_t view_i
         if (!as_records)
             return vs.h_visible_idx.ptr[k];
         uint64_t offset;
-        memcpy(&offset, vs.h_records.ptr + (size_t)k * L.stride + L.component_offset, 8);
+        memcpy(&offset, vs.records_at + (size_t)k * L.stride + L.component_offset, 8);
         return (uint32_t)(offset / L.component_stride);
     };
     // exclusive prefix in two passes over fixed chunks: chunk sums in parallel, their prefix serially, the fill in parallel

@@ -167,6 +167,12 @@ struct TransformBinding {
 struct PoolState {
     Column entity, is_enabled, aabb_min, aabb_max;
     RecordLayout record_layout{};  // gv_pool_set_record_layout (stride 0: none)
+    struct RecordTarget {        // gv_pool_set_record_target: the caller's own array for a view's records
+        uint8_t* host = nullptr;
+        size_t bytes = 0;
+        uint8_t* dev = nullptr;  // the page-locked range as the device addresses it (NULL: not lockable -> host copy at the fetch)
+    };
+    RecordTarget record_target[GV_MAX_VIEWS];
     Column ready;              // gv_pool_bind_ready: per-slot ready count (ptr NULL: none, every slot counts 1)
     uint32_t ready_width = 0;  // 1 or 4 bytes
     uint32_t ready_count(size_t i) const { return !ready.ptr ? 1u : (ready_width == 4 ? ready.u32(i) : (uint32_t)ready.u8(i)); }
@@ -215,7 +221,8 @@ struct ViewState {
     PinnedBuf<uint8_t> h_is_visible;
     PinnedBuf<uint8_t> h_records;    // results in the pool's record layout (gv_pool_results_records)
     DeviceBuf<uint8_t> d_records;    // ... packed on the device first for pools too large to publish directly
-    bool records_fetched = false;    // h_records holds this cull's records
+    bool records_fetched = false;    // records_at holds this cull's records
+    uint8_t* records_at = nullptr;   // h_records, or the caller's array (gv_pool_set_record_target)
     bool ballots_current = false;    // `mask` holds this cull's ballot words (not after the one-launch cull + emit of a small pool)
     std::vector<uint32_t> instance_bases;  // gv_pool_results_instance_bases (built on request)
     uint32_t pool_id = 0, occupancy = 0;

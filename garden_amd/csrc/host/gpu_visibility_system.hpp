@@ -76,6 +76,9 @@ public:
     bool isEnabled = true;
     // true: records arrive as UnsortedMesh / SortedMesh structs (gv_pool_set_record_layout), combinedMeshes is one memcpy
     bool recordStructs = true;
+    // true (with recordStructs): the device writes an unsorted buffer's records straight into its combinedMeshes
+    // (gv_pool_set_record_target; the vector is grown, never shrunk, so it is page-locked once) — no copy after the fetch
+    bool recordTargets = true;
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
@@ -244,6 +247,13 @@ private:
         buffer->instanceCount = r.instance_count;
         if (!emitRecords)
             return;
+        if (r.draw_count && !r.visible_idx) {
+            const void* records = nullptr;
+            uint32_t count = 0;
+            check(gv_pool_results_records(ctx, pool, viewIndex, &records, &count), "gv_pool_results_records");
+            if (records == static_cast<const void*>(buffer->combinedMeshes.data()))
+                return;  // written in place by the device (recordTargets)
+        }
         if (buffer->combinedMeshes.size() < r.draw_count)
             buffer->combinedMeshes.resize(r.draw_count);  // grown, never shrunk (mesh.cpp:377-395)
         copyRecords(buffer->combinedMeshes.data(), r, meshSystem, pool, viewIndex, 0);
@@ -346,13 +356,14 @@ private:
         // per (pool, view), so the device works through the systems back to back while the host only enqueues; the
         // reference dispatches every system's tasks to its thread pool and waits once, too (mesh.cpp:408-546, :548).
         std::vector<uint32_t> viewCounts(meshSystems.size(), 0);
-        uint32_t sortedSeen = 0;
+        uint32_t sortedSeen = 0, unsortedSeen = 0;
         check(gv_cull_batch_begin(ctx), "gv_cull_batch_begin");  // engine-sized pools: one cull / emit / sort / publish launch per tick
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
             check(gv_pool_bind(ctx, p, meshSystem->getMeshComponentData(), meshSystem->getMeshComponentSize(),
                                meshSystem->getMeshComponentOccupancy(), &meshLayout), "gv_pool_bind");
+            bool inPlace = false;
             {
                 GvRecordLayout layout;
                 const bool sorted = isSortedType(renderType);
@@ -362,6 +373,7 @@ private:
                 sortedSeen += sorted ? 1 : 0;  // == the bufferIndex phase 2 gives this system
                 check(gv_pool_set_record_layout(ctx, p, emitRecords && recordStructs && expressible ? &layout : nullptr),
                       "gv_pool_set_record_layout");
+                inPlace = !sorted && emitRecords && recordStructs && expressible && recordTargets;
             }
             if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem)) {
                 if (seenMesh[p] != versioned->meshVersion) {
@@ -388,6 +400,27 @@ private:
                                              (int8_t)s, false, emitRecords));
             }
             viewCounts[p] = (uint32_t)views.size();
+            if (!isSortedType(renderType)) {
+                // An unsorted system's buffers are its own (mesh.hpp:213-217), sized before its tasks run like the
+                // reference's scratch (mesh.cpp:377-395; here to the occupancy, which bounds any draw count): the device
+                // writes the records where renderUnsorted reads them. Shared sorted arrays keep the append + merge.
+                const uint32_t bufferIndex = unsortedSeen++;  // == the bufferIndex phase 2 gives this system
+                auto& sb = shadowBuffers[bufferIndex];
+                while (sb.size() + 1 < views.size())
+                    sb.push_back(new UnsortedBuffer());
+                const size_t occupancy = meshSystem->getMeshComponentOccupancy();
+                for (uint32_t v = 0; v < views.size(); v++) {
+                    UnsortedBuffer* buffer = v == 0 ? unsortedBuffers[bufferIndex] : sb[v - 1];
+                    if (inPlace && occupancy && buffer->combinedMeshes.size() < occupancy)
+                        buffer->combinedMeshes.resize(occupancy);
+                    if (inPlace && occupancy && reinterpret_cast<uintptr_t>(buffer->combinedMeshes.data()) % 16 == 0) {
+                        check(gv_pool_set_record_target(ctx, p, v, buffer->combinedMeshes.data(),
+                                                        buffer->combinedMeshes.size() * sizeof(UnsortedMesh)), "gv_pool_set_record_target");
+                    } else {
+                        check(gv_pool_set_record_target(ctx, p, v, nullptr, 0), "gv_pool_set_record_target");
+                    }
+                }
+            }
             if (sweepWorldMatrices && p == 0)
                 check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_WITH_CULL), "gv_sweep");
             {

@@ -113,7 +113,7 @@ EXPORTS = [
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
-    "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records",
+    "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples",
 ]
 
@@ -197,6 +197,7 @@ def load():
     lib.gv_pool_sort.argtypes = [P, u32, u32, C.c_int]
     lib.gv_pool_set_record_layout.argtypes = [P, u32, C.POINTER(GvRecordLayout)]
     lib.gv_pool_results_records.argtypes = [P, u32, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]
+    lib.gv_pool_set_record_target.argtypes = [P, u32, u32, C.c_void_p, C.c_size_t]
     lib.gv_profile_sampling.argtypes = [P, u32]
     lib.gv_profile_samples.argtypes = [P, C.POINTER(C.c_uint64 * GV_K_COUNT)]
     lib.gv_pool_results_instance_bases.argtypes = [P, u32, u32, C.POINTER(C.POINTER(u32)), C.POINTER(u32)]
@@ -398,6 +399,15 @@ class GpuVisibility:
             return np.zeros(0, dtype)
         raw = (C.c_uint8 * (n.value * dtype.itemsize)).from_address(ptr.value)
         return np.frombuffer(raw, dtype=np.uint8).copy().view(dtype)  # bytewise: a structured copy would skip the padding
+
+    def set_record_target(self, pool_id, view_index, array):
+        """The records of (pool, view) are written straight into `array` (a C-contiguous numpy array the caller keeps alive
+        and in place; None removes the target): the engine's own combinedMeshes instead of the library's buffer."""
+        if array is None:
+            self._check(self.lib.gv_pool_set_record_target(self.ctx, pool_id, view_index, None, 0))
+            return
+        assert array.flags["C_CONTIGUOUS"] and array.flags["WRITEABLE"]
+        self._check(self.lib.gv_pool_set_record_target(self.ctx, pool_id, view_index, array.ctypes.data, array.nbytes))
 
     def instance_bases(self, pool_id=0, view_index=0):
         """First instance index of every fetched record ([count + 1] words; the last one is instance_count)."""

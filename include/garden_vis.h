@@ -267,6 +267,16 @@ int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout
 /* After gv_pool_results_fetch of the same (pool, view): the records [0, *count) in the pool's record layout (library-owned
  * pinned memory, valid until the next gv_cull of that pool). GV_E_STATE when the pool has no record layout. */
 int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count);
+/* The records of (pool, view) straight into the CALLER'S array — `UnsortedBuffer::combinedMeshes.data()`, which the reference
+ * grows and never shrinks (mesh.cpp:377-395), so the address is stable across frames: the library page-locks the range
+ * once (when the address or size changes) and from then on the device writes each frame's records [0, draw_count) into
+ * it over PCIe; the fetch's memcpy into combinedMeshes (1.4 MB per frame for a 100 k-entity pool) disappears, and
+ * gv_pool_results_records returns `records` itself. The pool needs a record layout; `bytes` >= occupancy * stride of every
+ * pool culled while the target is set (GV_E_ARG at the fetch otherwise — draw_count <= occupancy, so the device can never
+ * write past it); `records` 16-byte aligned. A range that cannot be page-locked is still filled (by a host copy inside the
+ * fetch). The range must stay allocated until it is replaced (another call for the same pool and view), removed
+ * (records == NULL) or the context is destroyed. */
+int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* records, size_t bytes);
 
 /* The first instance index of every fetched record: bases[k] = sum of the ready counts (gv_pool_bind_ready; 1 per record
  * without) of records [0, k), bases[*count] = the view's instance_count. This is what `instanceCount.fetch_add(

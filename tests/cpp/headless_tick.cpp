@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -167,6 +167,7 @@ int main(int argc, char** argv)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
                             // checks gv_get_world of every transform slot against the oracle's chain walk, bit for bit
     bool itemised = false;  // --itemised: --animate reports the moved entities one by one (TransformSystem::markMoved)
+    bool copyRecords = false;  // --copy-records: records arrive in the library's buffer and are copied into combinedMeshes (no record target)
     bool soaRecords = false;  // --soa-records: the GPU system fetches three arrays and fills combinedMeshes itself (no record layout)
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
@@ -184,6 +185,7 @@ int main(int argc, char** argv)
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
         else if (a == "--soa-records") soaRecords = true;
+        else if (a == "--copy-records") copyRecords = true;
         else if (a == "--avx2") avx2 = true;  // CPU system: AVX2+FMA SoA path (bit-identical to the scalar loop)
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
@@ -219,8 +221,10 @@ int main(int argc, char** argv)
         }
         if (mode == "gpu" || mode == "both")
             gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
-        if (gpu)
+        if (gpu) {
             gpu->recordStructs = !soaRecords;
+            gpu->recordTargets = !copyRecords;
+        }
         if (gpu && world)
             gpu->sweepWorldMatrices = gpu->sweepIncremental = true;
         manager.initialize();

@@ -1288,6 +1288,85 @@ def test_records_in_the_engines_own_struct_layout(oracle, n, kind):
                 vis.set_record_layout(0, bad, component_stride=component)
 
 
+@pytest.mark.parametrize("n", [3_000, 20_000, 300_000])  # in-LDS publish / publish / device pack + one copy
+def test_record_target_receives_the_records_in_place(oracle, n):
+    """gv_pool_set_record_target: the device writes a view's records straight into the caller's own array (the
+    engine's combinedMeshes) — the same bytes as the library-buffer delivery, gv_pool_results_records hands back the
+    caller's address, slots past draw_count are left alone, an array smaller than occupancy * stride is refused at the
+    fetch, the target can be moved and removed."""
+    from garden_amd.lib import GpuVisibility
+    import ctypes as C
+    unsorted_dt, _ = RECORD_DTYPES["packed"]
+    sc = scene.flat_scene(n, seed=n + 11)
+    main = scene.main_camera_view()
+    shadow = scene.cascade_view(index=0)
+    component = int(sc.meshes.dtype.itemsize)
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        vis.set_record_layout(0, unsorted_dt, component_stride=component)
+        vis.cull(0, [main, shadow])
+        vis.sort(0, descending=False, pool_id=0)
+        vis.sort(1, descending=False, pool_id=0)
+        vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        ref = [vis.records(0, v, unsorted_dt) for v in range(2)]
+        assert ref[0].shape[0] > 0 and ref[1].shape[0] > 0
+
+        def address(pool_id, view):
+            ptr, count = C.c_void_p(), C.c_uint32()
+            vis._check(vis.lib.gv_pool_results_records(vis.ctx, pool_id, view, C.byref(ptr), C.byref(count)))
+            return ptr.value, count.value
+
+        targets = [np.full(n, 0xAB, np.uint8).repeat(unsorted_dt.itemsize).view(unsorted_dt) for _ in range(2)]
+        for tick in range(3):  # the same arrays every frame, as the engine's vectors are
+            for v in range(2):
+                vis.set_record_target(0, v, targets[v])
+            vis.cull(0, [main, shadow])
+            vis.sort(0, descending=False, pool_id=0)
+            vis.sort(1, descending=False, pool_id=0)
+            got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+            assert got["draw_count"] == ref[0].shape[0]
+            for v in range(2):
+                at, count = address(0, v)
+                assert at == targets[v].ctypes.data and count == ref[v].shape[0]
+                assert np.array_equal(targets[v][:count].view(np.uint8), ref[v].view(np.uint8))
+                assert np.all(targets[v][count:].view(np.uint8) == 0xAB)  # nothing past the records is touched
+                targets[v][:count].view(np.uint8)[:] = 0xAB
+        # instance-count prefix sums read the records where they were delivered
+        bases = vis.instance_bases(0, 0)
+        assert bases.shape[0] == ref[0].shape[0] + 1 and bases[-1] == ref[0].shape[0]
+        # moved to another (larger) array; view 1 back to the library's buffer
+        moved = np.zeros(n + 100, unsorted_dt)
+        vis.set_record_target(0, 0, moved)
+        vis.set_record_target(0, 1, None)
+        vis.cull(0, [main, shadow])
+        vis.sort(0, descending=False, pool_id=0)
+        vis.sort(1, descending=False, pool_id=0)
+        vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        at, count = address(0, 0)
+        assert at == moved.ctypes.data and np.array_equal(moved[:count].view(np.uint8), ref[0].view(np.uint8))
+        at1, count1 = address(0, 1)
+        assert at1 != targets[1].ctypes.data and np.array_equal(vis.records(0, 1, unsorted_dt).view(np.uint8), ref[1].view(np.uint8))
+        assert np.all(targets[1].view(np.uint8) == 0xAB)
+        # too small for the pool: refused at the fetch, nothing written
+        small = np.full((n - 1) * unsorted_dt.itemsize, 0xCD, np.uint8).view(unsorted_dt)
+        vis.set_record_target(0, 0, small)
+        vis.cull(0, [main])
+        with pytest.raises(RuntimeError) as e:
+            vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        assert "record target" in str(e.value)
+        assert np.all(small.view(np.uint8) == 0xCD)
+        vis.set_record_target(0, 0, None)
+        vis.cull(0, [main])
+        vis.sort(0, descending=False, pool_id=0)
+        vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        assert np.array_equal(vis.records(0, 0, unsorted_dt).view(np.uint8), ref[0].view(np.uint8))
+        # misaligned arrays are refused when they are set
+        with pytest.raises(RuntimeError):
+            vis._check(vis.lib.gv_pool_set_record_target(vis.ctx, 0, 0, moved.ctypes.data + 8, 4096))
+
+
 def test_rg16f_conversion_on_every_half_and_its_float_neighbours(oracle):
     """The device's directed float -> binary16 conversion (hardware nearest + one corrective step) against the oracle's
     integer one (pinned on numpy's float16 table in the CPU tier): a depth image whose 2x2 blocks are constant makes
