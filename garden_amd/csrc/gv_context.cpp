@@ -412,7 +412,7 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 {
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
-    const size_t nblocks = (n + 4095) / 4096;
+    const size_t nblocks = sort_tile_count((uint32_t)n);
     GV_HIP(ctx, vs.alt_idx.reserve(n));
     GV_HIP(ctx, vs.alt_model.reserve(n * 12));
     GV_HIP(ctx, vs.alt_dist.reserve(n));

@@ -39,8 +39,15 @@ __device__ unsigned long long gv_sort_trace[4][8192][12];
 #define GV_TRACE(k)
 #define GV_TRACE_AFTER_LOADS(slot)
 #endif
-constexpr uint32_t kSortTile = 4096;               // keys per workgroup per pass
-constexpr uint32_t kSortRounds = kSortTile / 256;  // keys per lane
+constexpr uint32_t kSortTile = kSortTileKeys;      // keys per workgroup per pass ...
+constexpr uint32_t kShortTile = kSortShortTileKeys;  // ... and for lists of up to kSortShortRecords records: the kernels are
+                                                     // latency chains per tile whatever the count (rank 8 us, the record
+                                                     // gather 26 us with six 4096-key tiles at 21 k records), so a short list
+                                                     // is spread over four times as many workgroups with a quarter of the
+                                                     // rounds each; long lists keep the long runs per digit (64-byte stores).
+                                                     // Measured (tools/onesweep_probe.hip, short / long tiles): 21.7 k records
+                                                     // 42 / 71 us, 65 k 46 / 78, 131 k 53 / 94, 308 k 64 / 100, 1 M 114 / 114,
+                                                     // 2.1 M 234 / 204
 constexpr uint32_t kSortGroup = kSortGroupTiles;   // tiles whose digit counts are also summed per group
 
 __device__ __forceinline__ uint32_t order_key(float d, uint32_t descending)
@@ -122,16 +129,12 @@ struct SortPassArgs {
     SortState st;
 };
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
+template <bool FIRST, uint32_t TILE>
+__device__ __forceinline__ void sort_rank_tile(const SortPassArgs& a, const uint32_t n, uint32_t (*wcount)[256])
 {
-    __shared__ uint32_t wcount[4][256];  // per-wave digit counts of the tile
-    const uint32_t n = min(*a.count, a.capacity);
+    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / 256;  // keys per workgroup, per lane
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    if (FIRST)  // the other parity's counters, for the next sort (nobody reads them during this one)
-        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.st.set_words; k += gridDim.x * 256)
-            a.st.next_set[k] = 0;
-    if (blockIdx.x >= tiles || n <= a.min_records)
+    if (blockIdx.x >= tiles)
         return;  // the grid is sized for the capacity, the count lives on the device: surplus workgroups leave at once
     const uint32_t tile = blockIdx.x;
     GV_TRACE(0)
@@ -199,17 +202,41 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
     GV_TRACE(3)
 }
 
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
 {
-    __shared__ uint32_t tile_excl[256];   // exclusive scan of the tile's digit counts (tile-local sorted order)
-    __shared__ uint32_t dst_base[256];    // global position of the tile's first key of each digit
-    __shared__ uint32_t skey[kSortTile];  // the tile reordered by digit
-    __shared__ uint32_t sval[kSortTile];
-    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t wcount[4][256];  // per-wave digit counts of the tile
     const uint32_t n = min(*a.count, a.capacity);
+    if (FIRST)  // the other parity's counters, for the next sort (nobody reads them during this one)
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.st.set_words; k += gridDim.x * 256)
+            a.st.next_set[k] = 0;
+    if (n <= a.min_records)
+        return;
+    if (n <= kSortShortRecords)
+        sort_rank_tile<FIRST, kShortTile>(a, n, wcount);
+    else
+        sort_rank_tile<FIRST, kSortTile>(a, n, wcount);
+}
+
+struct SortScatterLds {
+    uint32_t tile_excl[256];   // exclusive scan of the tile's digit counts (tile-local sorted order)
+    uint32_t dst_base[256];    // global position of the tile's first key of each digit
+    uint32_t skey[kSortTile];  // the tile reordered by digit
+    uint32_t sval[kSortTile];
+    uint32_t wave_sum[4];
+};
+
+template <bool FIRST, bool LAST, uint32_t TILE>
+__device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const uint32_t n, SortScatterLds& lds)
+{
+    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / 256;
+    uint32_t* const tile_excl = lds.tile_excl;
+    uint32_t* const dst_base = lds.dst_base;
+    uint32_t* const skey = lds.skey;
+    uint32_t* const sval = lds.sval;
+    uint32_t* const wave_sum = lds.wave_sum;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    if (blockIdx.x >= tiles || n <= a.min_records)
+    if (blockIdx.x >= tiles)
         return;
     const uint32_t tile = blockIdx.x;
     GV_TRACE(4)
@@ -303,6 +330,19 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
         dst[(size_t)skey[t] * 3 + part] = src[(size_t)sval[t] * 3 + part];
     }
     GV_TRACE(8)
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
+{
+    __shared__ SortScatterLds lds;
+    const uint32_t n = min(*a.count, a.capacity);
+    if (n <= a.min_records)
+        return;
+    if (n <= kSortShortRecords)
+        sort_scatter_tile<FIRST, LAST, kShortTile>(a, n, lds);
+    else
+        sort_scatter_tile<FIRST, LAST, kSortTile>(a, n, lds);
 }
 
 // Small pools (up to kSmallSort records possible): ONE launch instead of fourteen — a tick of an engine-sized scene
@@ -413,7 +453,7 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         if (capacity <= kSmallSort)
             return hipGetLastError();
     }
-    const uint32_t tiles = (capacity + kSortTile - 1) / kSortTile;  // at full capacity; the live count is on the device
+    const uint32_t tiles = sort_tile_count(capacity);  // at full capacity (long or short tiles); the live count is on the device
     SortPassArgs a{};
     a.st.groups = sort_group_count(capacity);
     a.st.set_words = sort_set_words(capacity);

@@ -24,11 +24,24 @@ struct SortBuffers {
     uint16_t* ranks;         // per key: rank among its tile's keys of the current digit
     uint32_t* counters[2];   // two sets of sort_set_words(capacity) words — per-group digit counts [4][groups][256]: a sort
                              // uses set `parity` (zero on entry) and zeroes the other
-    uint32_t* tile_hist;     // [ceil(capacity / 4096)][256] digit counts of every tile (rewritten by each pass)
+    uint32_t* tile_hist;     // [sort_tile_count(capacity)][256] digit counts of every tile (rewritten by each pass)
     uint32_t parity;
 };
 constexpr uint32_t kSortGroupTiles = 32;
-inline uint32_t sort_group_count(uint32_t capacity) { return ((capacity + 4095u) / 4096u + kSortGroupTiles - 1u) / kSortGroupTiles; }
+constexpr uint32_t kSortTileKeys = 4096;        // keys per workgroup and pass ...
+constexpr uint32_t kSortShortTileKeys = 1024;   // ... for lists of up to kSortShortRecords records (chosen on the device)
+#ifndef GV_SORT_SHORT_RECORDS  // (tools/onesweep_probe.hip measures other thresholds)
+#define GV_SORT_SHORT_RECORDS 524288
+#endif
+constexpr uint32_t kSortShortRecords = GV_SORT_SHORT_RECORDS;
+// workgroups / rows of tile_hist a sort of up to `capacity` records can need, whichever tile size its live count picks
+inline uint32_t sort_tile_count(uint32_t capacity)
+{
+    const uint32_t longs = (capacity + kSortTileKeys - 1u) / kSortTileKeys;
+    const uint32_t shorts = ((capacity < kSortShortRecords ? capacity : kSortShortRecords) + kSortShortTileKeys - 1u) / kSortShortTileKeys;
+    return longs > shorts ? longs : shorts;
+}
+inline uint32_t sort_group_count(uint32_t capacity) { return (sort_tile_count(capacity) + kSortGroupTiles - 1u) / kSortGroupTiles; }
 inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count(capacity) * 256u; }
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
 // Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first

@@ -215,12 +215,15 @@ def test_batched_views_equal_separate_passes(gpu, oracle):
 @pytest.mark.parametrize("n,descending,d2", [(100_000, False, 0), (100_000, True, 0), (300_000, False, 0), (5_000, True, 1), (70, False, 0),
                                             (4096, False, 0), (4000, True, 0), (513, False, 1), (3, True, 0), (40, False, 0),
                                             # occupancy <= 16384: one-launch LDS sort, network sized by the count on the device
-                                            (16_384, False, 0), (16_384, True, 1), (12_000, True, 0), (16_385, False, 0), (9_000, False, 0)])
+                                            (16_384, False, 0), (16_384, True, 1), (12_000, True, 0), (16_385, False, 0), (9_000, False, 0),
+                                            # radix sort with the short tiles (up to 524288 records, chosen on the device) and just beyond
+                                            (13_500, False, 0), (21_000, True, 0), (50_000, False, 1), (68_000, True, 0), (540_000, False, 0),
+                                            (560_000, True, 0)])
 def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     """gv_sort == sortMeshes (mesh.cpp:265-328): ascending distanceSq for unsorted buffers, descending for the
     sorted ones; the oracle breaks ties by slot, and so does the stable radix sort."""
     sc = scene.flat_scene(n, seed=3 + n)
-    wide = n >= 100_000 or n in (12_000, 16_384, 16_385)  # nearly everything visible: large record counts
+    wide = n >= 13_500 or n == 12_000  # nearly everything visible: large record counts
     v = scene.cascade_view(size=30000.0, depth=60000.0) if wide else scene.main_camera_view()
     v = dict(v, distance_2d=d2)
     gpu.bind_transforms(sc.transforms, sc.entity_to_transform)

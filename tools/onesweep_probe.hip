@@ -20,7 +20,7 @@ int main(int argc, char** argv)
     std::vector<float> dist(n);
     srand(7);
     for (auto& d : dist) { const float r = 100.0f + 20000.0f * (float)rand() / RAND_MAX; d = r * r; }
-    const uint32_t tiles = (capacity + 4095) / 4096;
+    const uint32_t tiles = gv::sort_tile_count(capacity);
     gv::SortBuffers b{};
     uint32_t *count, *idx_in, *idx_out, *hist;
     uint16_t* ranks;
