@@ -49,6 +49,14 @@ constexpr uint32_t kShortTile = kSortShortTileKeys;  // ... and for lists of up 
                                                      // 42 / 71 us, 65 k 46 / 78, 131 k 53 / 94, 308 k 64 / 100, 1 M 114 / 114,
                                                      // 2.1 M 234 / 204
 constexpr uint32_t kSortGroup = kSortGroupTiles;   // tiles whose digit counts are also summed per group
+#ifndef GV_SORT_THREADS  // (tools/onesweep_probe.hip measures other workgroup sizes)
+#define GV_SORT_THREADS 512
+#endif
+constexpr uint32_t kSortThreads = GV_SORT_THREADS;  // per workgroup of the rank / scatter kernels: the same tiles (run lengths) with
+                                                    // half the rounds per lane and twice the waves per tile of the 256-thread form.
+                                                    // Measured, 256 / 512 / 1024 threads: 1 M records 111 / 98 / 101 us, 2.1 M
+                                                    // 198 / 190 / 207, 9.9 M 851 / 816 / 910
+constexpr uint32_t kSortWaves = kSortThreads / 64;
 
 __device__ __forceinline__ uint32_t order_key(float d, uint32_t descending)
 {
@@ -70,8 +78,8 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool v
     return peer;
 }
 
-// exclusive scan of one value per thread over a 256-thread workgroup; every thread also gets the grand total
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sum /* LDS [4] */, uint32_t* total)
+// exclusive scan of one value per thread over the workgroup; every thread also gets the grand total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sum /* LDS [kSortWaves] */, uint32_t* total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -87,7 +95,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     __syncthreads();
     uint32_t wave_prefix = 0, all = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 4; w++) {
+    for (uint32_t w = 0; w < kSortWaves; w++) {
         wave_prefix += w < wave ? wave_sum[w] : 0u;
         all += wave_sum[w];
     }
@@ -132,20 +140,19 @@ struct SortPassArgs {
 template <bool FIRST, uint32_t TILE>
 __device__ __forceinline__ void sort_rank_tile(const SortPassArgs& a, const uint32_t n, uint32_t (*wcount)[256])
 {
-    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / 256;  // keys per workgroup, per lane
+    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / kSortThreads;  // keys per workgroup, per lane
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
     if (blockIdx.x >= tiles)
         return;  // the grid is sized for the capacity, the count lives on the device: surplus workgroups leave at once
     const uint32_t tile = blockIdx.x;
     GV_TRACE(0)
-#pragma unroll
-    for (uint32_t w = 0; w < 4; w++)
-        wcount[w][threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < kSortWaves * 256u; k += kSortThreads)
+        (&wcount[0][0])[k] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t shift = a.pass * 8;
-    // each wave ranks its 1024 consecutive keys, 64 per round: wave-private counters, no workgroup barrier
-    const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / 4);
+    // each wave ranks its own run of consecutive keys, 64 per round: wave-private counters, no workgroup barrier
+    const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / kSortWaves);
     uint32_t key[kSortRounds], local[kSortRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {  // all loads first
@@ -180,35 +187,38 @@ __device__ __forceinline__ void sort_rank_tile(const SortPassArgs& a, const uint
     }
     __syncthreads();
     GV_TRACE(2)
-    {  // one thread per digit: the tile's counts, for the scatter kernel and for the tile's group
-        const uint32_t d = threadIdx.x;
-        const uint32_t tile_count = wcount[0][d] + wcount[1][d] + wcount[2][d] + wcount[3][d];
+    if (threadIdx.x < 256) {  // one thread per digit: the waves' counts become the counts of the waves before them, and
+        const uint32_t d = threadIdx.x;  // their sum the tile's count, for the scatter kernel and for the tile's group
+        uint32_t tile_count = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kSortWaves; w++) {
+            const uint32_t c = wcount[w][d];
+            wcount[w][d] = tile_count;
+            tile_count += c;
+        }
         a.st.tile_hist[(size_t)tile * 256 + d] = tile_count;
         if (tile_count)
             atomicAdd(&a.st.group_hist[((size_t)a.pass * a.st.groups + tile / kSortGroup) * 256 + d], tile_count);
     }
+    __syncthreads();
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {  // rank among the TILE's keys of the digit: the waves before mine come first
         const uint32_t j = wave_base + r * 64 + lane;
         if (j < n) {
             const uint32_t d = (key[r] >> shift) & 255u;
-            uint32_t rank = local[r];
-#pragma unroll
-            for (uint32_t w = 0; w < 3; w++)
-                rank += w < wave ? wcount[w][d] : 0u;
-            a.ranks[j] = (uint16_t)rank;
+            a.ranks[j] = (uint16_t)(local[r] + wcount[wave][d]);
         }
     }
     GV_TRACE(3)
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(256) void sort_rank_kernel(const SortPassArgs a)
+__global__ __launch_bounds__(kSortThreads) void sort_rank_kernel(const SortPassArgs a)
 {
-    __shared__ uint32_t wcount[4][256];  // per-wave digit counts of the tile
+    __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counts of the tile
     const uint32_t n = min(*a.count, a.capacity);
     if (FIRST)  // the other parity's counters, for the next sort (nobody reads them during this one)
-        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < a.st.set_words; k += gridDim.x * 256)
+        for (uint32_t k = blockIdx.x * kSortThreads + threadIdx.x; k < a.st.set_words; k += gridDim.x * kSortThreads)
             a.st.next_set[k] = 0;
     if (n <= a.min_records)
         return;
@@ -223,13 +233,13 @@ struct SortScatterLds {
     uint32_t dst_base[256];    // global position of the tile's first key of each digit
     uint32_t skey[kSortTile];  // the tile reordered by digit
     uint32_t sval[kSortTile];
-    uint32_t wave_sum[4];
+    uint32_t wave_sum[kSortWaves];
 };
 
 template <bool FIRST, bool LAST, uint32_t TILE>
 __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const uint32_t n, SortScatterLds& lds)
 {
-    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / 256;
+    constexpr uint32_t kSortTile = TILE, kSortRounds = TILE / kSortThreads;
     uint32_t* const tile_excl = lds.tile_excl;
     uint32_t* const dst_base = lds.dst_base;
     uint32_t* const skey = lds.skey;
@@ -242,7 +252,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     GV_TRACE(4)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t shift = a.pass * 8;
-    const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / 4);
+    const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / kSortWaves);
     uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {
@@ -258,28 +268,33 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
         rank[r] = valid ? (uint32_t)a.ranks[j] : 0u;
     }
     // one thread per digit: same-digit keys in the tiles before this one = whole groups + the tiles before it in its group
-    const uint32_t d = threadIdx.x;
-    const uint32_t tile_count = a.st.tile_hist[(size_t)tile * 256 + d];
-    const uint32_t group = tile / kSortGroup;
-    const uint32_t* __restrict__ gh = a.st.group_hist + (size_t)a.pass * a.st.groups * 256 + d;
-    const uint32_t* __restrict__ th = a.st.tile_hist + d;
-    const uint32_t live_groups = (tiles + kSortGroup - 1) / kSortGroup;
-    uint32_t before = 0, digit_total = 0;  // ... and the digit's count over ALL tiles (the global histogram, summed on the spot)
+    const uint32_t d = threadIdx.x & 255u;
+    const bool digit_thread = threadIdx.x < 256u;  // (workgroup-wave-uniform: whole waves)
+    uint32_t tile_count = 0, before = 0, digit_total = 0;  // ... and the digit's count over ALL tiles (the global histogram, summed on the spot)
+    if (digit_thread) {
+        tile_count = a.st.tile_hist[(size_t)tile * 256 + d];
+        const uint32_t group = tile / kSortGroup;
+        const uint32_t* __restrict__ gh = a.st.group_hist + (size_t)a.pass * a.st.groups * 256 + d;
+        const uint32_t* __restrict__ th = a.st.tile_hist + d;
+        const uint32_t live_groups = (tiles + kSortGroup - 1) / kSortGroup;
 #pragma unroll 8
-    for (uint32_t g = 0; g < live_groups; g++) {
-        const uint32_t c = gh[(size_t)g * 256];
-        digit_total += c;
-        before += g < group ? c : 0u;
+        for (uint32_t g = 0; g < live_groups; g++) {
+            const uint32_t c = gh[(size_t)g * 256];
+            digit_total += c;
+            before += g < group ? c : 0u;
+        }
+#pragma unroll 8
+        for (uint32_t u = group * kSortGroup; u < tile; u++)
+            before += th[(size_t)u * 256];
     }
-#pragma unroll 8
-    for (uint32_t u = group * kSortGroup; u < tile; u++)
-        before += th[(size_t)u * 256];
     GV_TRACE_AFTER_LOADS(5)
     uint32_t total;
     const uint32_t gbase = block_exclusive_scan(digit_total, wave_sum, &total);  // keys of lower digits, all tiles
     const uint32_t texcl = block_exclusive_scan(tile_count, wave_sum, &total);                   // ... in this tile
-    tile_excl[d] = texcl;
-    dst_base[d] = gbase + before;
+    if (digit_thread) {
+        tile_excl[d] = texcl;
+        dst_base[d] = gbase + before;
+    }
     __syncthreads();
     GV_TRACE(6)
     // reorder the tile by digit in LDS, then write every digit's run to its place
@@ -297,7 +312,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     const uint32_t live = min(kSortTile, n - tile * kSortTile);
     if (!LAST) {
 #pragma unroll 4
-        for (uint32_t t = threadIdx.x; t < live; t += 256) {
+        for (uint32_t t = threadIdx.x; t < live; t += kSortThreads) {
             const uint32_t k = skey[t], v = sval[t];
             const uint32_t dd = (k >> shift) & 255u;
             const uint32_t pos = dst_base[dd] + (t - tile_excl[dd]);
@@ -312,7 +327,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     // instead was measured: the last pass 101 -> 75 us, the other three scatter kernels + 4-7 us each, no gain end to end),
     // the 48-byte model is gathered by three lanes per record (one float4 each), so that the stores of a run of records are
     // whole contiguous rows.
-    for (uint32_t t = threadIdx.x; t < live; t += 256) {
+    for (uint32_t t = threadIdx.x; t < live; t += kSortThreads) {
         const uint32_t k = skey[t], v = sval[t];  // v = the record's index before the sort
         const uint32_t dd = (k >> shift) & 255u;
         const uint32_t pos = dst_base[dd] + (t - tile_excl[dd]);
@@ -325,7 +340,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     const float4* __restrict__ src = reinterpret_cast<const float4*>(a.model_in);
     float4* __restrict__ dst = reinterpret_cast<float4*>(a.model_out);
 #pragma unroll 4
-    for (uint32_t q = threadIdx.x; q < live * 3u; q += 256) {
+    for (uint32_t q = threadIdx.x; q < live * 3u; q += kSortThreads) {
         const uint32_t t = q / 3u, part = q - t * 3u;
         dst[(size_t)skey[t] * 3 + part] = src[(size_t)sval[t] * 3 + part];
     }
@@ -333,7 +348,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
 }
 
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const SortPassArgs a)
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPassArgs a)
 {
     __shared__ SortScatterLds lds;
     const uint32_t n = min(*a.count, a.capacity);
@@ -479,14 +494,14 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         a.keys_out = b.keys[dst];
         a.vals_out = b.vals[dst];
         if (pass == 0) {
-            hipLaunchKernelGGL(sort_rank_kernel<true>, dim3(tiles), dim3(256), 0, stream, a);
-            hipLaunchKernelGGL((sort_scatter_kernel<true, false>), dim3(tiles), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(sort_rank_kernel<true>, dim3(tiles), dim3(kSortThreads), 0, stream, a);
+            hipLaunchKernelGGL((sort_scatter_kernel<true, false>), dim3(tiles), dim3(kSortThreads), 0, stream, a);
         } else {
-            hipLaunchKernelGGL(sort_rank_kernel<false>, dim3(tiles), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(sort_rank_kernel<false>, dim3(tiles), dim3(kSortThreads), 0, stream, a);
             if (pass == 3)
-                hipLaunchKernelGGL((sort_scatter_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((sort_scatter_kernel<false, true>), dim3(tiles), dim3(kSortThreads), 0, stream, a);
             else
-                hipLaunchKernelGGL((sort_scatter_kernel<false, false>), dim3(tiles), dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((sort_scatter_kernel<false, false>), dim3(tiles), dim3(kSortThreads), 0, stream, a);
         }
     }
     return hipGetLastError();
