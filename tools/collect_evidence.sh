@@ -27,12 +27,13 @@ rm -rf $out; mkdir -p $out
   echo "#             waiting for predecessor tiles (every tile is resident at once: the look-back is a serial chain through memory); a 64-word window: 269 us"
   echo "#   round 2b (kept): rank kernel + scatter kernel per digit, no inter-workgroup waiting at all      203-207 us; a pass = 11 + 2 + 10 us, the last one + 90 us"
   echo "#             of record gather (the isolated gather above: 70 us — sector-granular random reads, the floor of this pass)"
+  echo "#   round 2c (kept): the same two kernels with 512-lane workgroups, and 1024-key tiles for lists of up to 512 k records (chosen on the device)   190-195 us; 308 k records 100 -> 62 us, 21.7 k 71 -> 42 us"
   echo "#   ranking variants measured on the way (kept: 8-ballot match + wave-private LDS running counts): LDS lane-mask tables (no gain), 4 rotating mask tables"
   echo "#             with returning LDS atomics (spills at 128 VGPRs), static tile ids under the look-back form (-12 us, unsafe there; the kept form needs no ids)"
 } > $out/r02_sort_probe.txt 2>&1
 {
   echo "# tests/cpp/headless_tick --mode gpu --ticks 2000 <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the drop-in's prepare phase)"
-  for a in "--entities 2000" "--entities 10000" "--entities 100000" "--entities 10000 --mixed" "--entities 10000 --mixed --csm" "--entities 10000 --hier --world --animate 50 --itemised"; do
+  for a in "--entities 2000" "--entities 10000" "--entities 10000 --copy-records" "--entities 100000" "--entities 100000 --copy-records" "--entities 10000 --mixed" "--entities 10000 --mixed --csm" "--entities 10000 --hier --world --animate 50 --itemised"; do
     echo "## $a"
     GV_TICK_BREAKDOWN=1 ./tests/cpp/build/headless_tick --mode gpu --ticks 2000 $a 2>&1 | grep -E "prepare us"
   done

@@ -28,6 +28,35 @@ __global__ __launch_bounds__(256) void permute(const float4* __restrict__ src, f
     }
 }
 
+// the same with the 4-byte pool slot beside the model (the sort's last pass moves both): gather = idx_out[t] = idx_in[perm[t]]
+// (a random 4-byte read: a whole sector fetched), scatter = idx_out[perm[t]] = idx_in[t] (a random 4-byte write: nothing fetched)
+template <bool SCATTER, int UNROLL>
+__global__ __launch_bounds__(256) void permute_idx(const float4* __restrict__ src, float4* __restrict__ dst, const uint32_t* __restrict__ perm,
+                                                   const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ idx_out, uint32_t n)
+{
+    const uint32_t per_block = 4096 * 3;
+    const size_t base = (size_t)blockIdx.x * per_block;
+    for (uint32_t t = blockIdx.x * 4096 + threadIdx.x; t < min(n, (blockIdx.x + 1) * 4096u); t += 256) {
+        const uint32_t p = perm[t];
+        if (SCATTER)
+            idx_out[p] = idx_in[t];
+        else
+            idx_out[t] = idx_in[p];
+    }
+#pragma unroll UNROLL
+    for (uint32_t q = threadIdx.x; q < per_block; q += 256) {
+        const size_t g = base + q;
+        const uint32_t t = (uint32_t)(g / 3), part = (uint32_t)(g - (size_t)t * 3);
+        if (t < n) {
+            const uint32_t p = perm[t];
+            if (SCATTER)
+                dst[(size_t)p * 3 + part] = src[g];
+            else
+                dst[g] = src[(size_t)p * 3 + part];
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 2124723u;
@@ -58,5 +87,21 @@ int main(int argc, char** argv)
     run("gather, 48 loads in flight", permute<false, 48>);
     run("scatter, unroll 4", permute<true, 4>);
     run("scatter, unroll 16", permute<true, 16>);
+    uint32_t *idx_in, *idx_out;
+    hipMalloc(&idx_in, (size_t)n * 4); hipMalloc(&idx_out, (size_t)n * 4);
+    hipMemset(idx_in, 1, (size_t)n * 4);
+    auto run_idx = [&](const char* name, auto kernel) {
+        std::vector<float> ms;
+        for (int rep = 0; rep < 9; rep++) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, src, dst, dperm, idx_in, idx_out, n);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float t; hipEventElapsedTime(&t, a, b); ms.push_back(t);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("%-34s %7.1f us\n", name, ms[4] * 1000);
+    };
+    run_idx("gather + 4-byte slot gather", permute_idx<false, 4>);
+    run_idx("scatter + 4-byte slot scatter", permute_idx<true, 4>);
     return 0;
 }
