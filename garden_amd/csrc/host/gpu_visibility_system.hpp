@@ -79,6 +79,7 @@ public:
     // true (with recordStructs): the device writes an unsorted buffer's records straight into its combinedMeshes
     // (gv_pool_set_record_target; the vector is grown, never shrunk, so it is page-locked once) — no copy after the fetch
     bool recordTargets = true;
+    size_t recordTargetMaxBytes = size_t(256) << 20;  // larger arrays are not page-locked: their records are copied after the fetch
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
@@ -411,9 +412,10 @@ private:
                 const size_t occupancy = meshSystem->getMeshComponentOccupancy();
                 for (uint32_t v = 0; v < views.size(); v++) {
                     UnsortedBuffer* buffer = v == 0 ? unsortedBuffers[bufferIndex] : sb[v - 1];
-                    if (inPlace && occupancy && buffer->combinedMeshes.size() < occupancy)
+                    const bool target = inPlace && occupancy && occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
+                    if (target && buffer->combinedMeshes.size() < occupancy)
                         buffer->combinedMeshes.resize(occupancy);
-                    if (inPlace && occupancy && reinterpret_cast<uintptr_t>(buffer->combinedMeshes.data()) % 16 == 0) {
+                    if (target && reinterpret_cast<uintptr_t>(buffer->combinedMeshes.data()) % 16 == 0) {
                         check(gv_pool_set_record_target(ctx, p, v, buffer->combinedMeshes.data(),
                                                         buffer->combinedMeshes.size() * sizeof(UnsortedMesh)), "gv_pool_set_record_target");
                     } else {
