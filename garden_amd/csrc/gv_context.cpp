@@ -8,6 +8,7 @@
 //
 // There is NO CPU fallback: without a gfx950 device gv_create fails with GV_E_NODEVICE.
 #include "gv_ctx.hpp"
+#include "gv_hiz_kernels.hpp"
 
 using namespace gv;
 
@@ -150,6 +151,20 @@ int hiz_reduce(GvCtx* ctx)
             tail.rule = ctx->config.hiz_rule;
             GV_HIP(ctx, launch_hiz_tail(tail, rg16f, ctx->stream));
             k = ctx->hiz_mips;
+        } else if (k + 2 < ctx->hiz_mips && sw >= 2 && sh >= 2 && getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr) {
+            // any size: three levels per launch, a rim of the two intermediate levels recomputed per workgroup (gv_hiz.hip)
+            HizFused3Args f{};
+            f.depth = src_d;
+            f.src_pairs = src_p;
+            for (uint32_t l = 0; l < 4; l++) {
+                f.w[l] = ctx->mip_w[k - 1 + l];
+                f.h[l] = ctx->mip_h[k - 1 + l];
+            }
+            for (uint32_t l = 0; l < 3; l++)
+                f.dst[l] = mip_ptr(ctx, k + l);
+            f.rule = ctx->config.hiz_rule;
+            GV_HIP(ctx, launch_hiz_fused3(f, rg16f, ctx->stream));
+            k += 3;
         } else {
             GV_HIP(ctx, launch_hiz_level(src_d, src_p, mip_ptr(ctx, k), sw, sh, ctx->mip_w[k], ctx->mip_h[k], ctx->config.hiz_rule, rg16f,
                                          ctx->stream));

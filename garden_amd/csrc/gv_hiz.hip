@@ -1,6 +1,7 @@
 // gv_hiz.hip — Hi-Z pyramid: HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167) with the reduction
 // rule of shaders/hiz.frag:23-63.
 #include "gv_device.hpp"
+#include "gv_hiz_kernels.hpp"
 
 namespace gv {
 
@@ -67,6 +68,68 @@ __device__ __forceinline__ float2 hiz_level_texel(const float* __restrict__ src_
     return hiz_level_texel_from([&](uint32_t x, uint32_t y) { return hiz_src<F16>(src_depth, src_pairs, sw, x, y); }, sw, sh, px, py, rule);
 }
 
+// The same texel with the source read two columns at a time (one 8- or 16-byte load per row instead of two scalar ones: the
+// scalar form touches every other word per instruction and is bound by the texture addresser, not by memory). Needs
+// sw >= 2 && sh >= 2: then no coordinate of hiz.frag's footprint is clamped. Same accumulation order as above (the order
+// decides which of +0 / -0 and whether a NaN survives).
+struct __attribute__((aligned(4))) HizDepth2 { float a, b; };
+struct __attribute__((aligned(4))) HizHalf2 { uint32_t a, b; };
+struct __attribute__((aligned(8))) HizPair2 { float2 a, b; };
+template <bool F16>
+__device__ __forceinline__ void hiz_src2(const float* d, const float2* p, uint32_t sw, uint32_t x, uint32_t y, float2& a, float2& b)
+{
+    const size_t at = (size_t)y * sw + x;
+    if (d) {
+        const HizDepth2 v = *reinterpret_cast<const HizDepth2*>(d + at);
+        a = make_float2(v.a, v.a);
+        b = make_float2(v.b, v.b);
+    } else if (F16) {
+        const HizHalf2 v = *reinterpret_cast<const HizHalf2*>(reinterpret_cast<const uint32_t*>(p) + at);
+        a = unpack_rg16f(v.a);
+        b = unpack_rg16f(v.b);
+    } else {
+        const HizPair2 v = *reinterpret_cast<const HizPair2*>(p + at);
+        a = v.a;
+        b = v.b;
+    }
+}
+template <bool F16>
+__device__ __forceinline__ float2 hiz_level_texel_rows(const float* __restrict__ src_depth, const float2* __restrict__ src_pairs, uint32_t sw,
+                                                       uint32_t sh, uint32_t px, uint32_t py, uint32_t rule)
+{
+    const bool odd_x = (sw & 1u) != 0, odd_y = (sh & 1u) != 0;
+    const uint32_t x0 = 2 * px, y0 = 2 * py;
+    float2 v00, v10, v01, v11, v20 = {}, v21 = {}, v02 = {}, v12 = {}, v22 = {};
+    hiz_src2<F16>(src_depth, src_pairs, sw, x0, y0, v00, v10);
+    hiz_src2<F16>(src_depth, src_pairs, sw, x0, y0 + 1, v01, v11);
+    if (odd_x) {
+        v20 = hiz_src<F16>(src_depth, src_pairs, sw, x0 + 2, y0);
+        v21 = hiz_src<F16>(src_depth, src_pairs, sw, x0 + 2, y0 + 1);
+    }
+    if (odd_y) {
+        hiz_src2<F16>(src_depth, src_pairs, sw, x0, y0 + 2, v02, v12);
+        if (odd_x)
+            v22 = hiz_src<F16>(src_depth, src_pairs, sw, x0 + 2, y0 + 2);
+    }
+    float2 mm = v00;
+    hiz_acc(mm, v10);
+    hiz_acc(mm, v01);
+    hiz_acc(mm, v11);
+    if (odd_x) {  // hiz.frag:36-41
+        hiz_acc(mm, v21);
+        hiz_acc(mm, v20);
+        if (odd_y)  // hiz.frag:43-47
+            hiz_acc(mm, v22);
+    }
+    if (odd_y) {  // hiz.frag:49-55
+        hiz_acc(mm, v12);
+        if (rule == 1u)
+            hiz_acc(mm, v02);
+    }
+    (void)sh;
+    return mm;
+}
+
 // One destination texel per lane.
 template <bool F16>
 __global__ __launch_bounds__(256) void hiz_level_kernel(const float* __restrict__ src_depth,
@@ -95,25 +158,112 @@ __global__ __launch_bounds__(1024) void hiz_tail_kernel(const HizTailArgs a)
         float2* dst = F16 ? reinterpret_cast<float2*>(reinterpret_cast<uint32_t*>(a.mips) + a.offset[k]) : a.mips + a.offset[k];
         float2* keep = level[l & 1u];
         const float2* prev = level[(l & 1u) ^ 1u];
-        for (uint32_t t = threadIdx.x; t < dw * dh; t += 1024) {
-            const uint32_t px = t % dw, py = t / dw;
-            float2 mm;
-            if (l != 0) {
-                mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return prev[y * sw + x]; }, sw, sh, px, py, a.rule);
-            } else {
-                const float* src_depth = k == 1 ? a.depth : nullptr;
-                const float2* src_pairs = k == 1 ? nullptr
-                                                 : (F16 ? reinterpret_cast<const float2*>(reinterpret_cast<const uint32_t*>(a.mips) + a.offset[k - 1])
-                                                        : a.mips + a.offset[k - 1]);
-                mm = hiz_level_texel<F16>(src_depth, src_pairs, sw, sh, px, py, a.rule);
-                if (F16 && k == 1)  // the one place a value leaves fp32: what the texel holds is what the next level reduces
-                    mm = unpack_rg16f(pack_rg16f(mm));
+        if (l == 0) {  // from memory: all of a lane's loads first, then its stores (the stores would fence the next texel's loads)
+            const float* src_depth = k == 1 ? a.depth : nullptr;
+            const float2* src_pairs = k == 1 ? nullptr
+                                             : (F16 ? reinterpret_cast<const float2*>(reinterpret_cast<const uint32_t*>(a.mips) + a.offset[k - 1])
+                                                    : a.mips + a.offset[k - 1]);
+            float2 mine[kHizTailTexels / 1024];
+#pragma unroll
+            for (uint32_t u = 0; u < kHizTailTexels / 1024; u++) {
+                const uint32_t t = threadIdx.x + u * 1024;
+                if (t < dw * dh) {
+                    mine[u] = sw >= 2 && sh >= 2 ? hiz_level_texel_rows<F16>(src_depth, src_pairs, sw, sh, t % dw, t / dw, a.rule)
+                                                 : hiz_level_texel<F16>(src_depth, src_pairs, sw, sh, t % dw, t / dw, a.rule);
+                    if (F16 && k == 1)  // the one place a value leaves fp32: what the texel holds is what the next level reduces
+                        mine[u] = unpack_rg16f(pack_rg16f(mine[u]));
+                }
             }
-            hiz_store<F16>(dst, t, mm);
-            keep[t] = mm;
+#pragma unroll
+            for (uint32_t u = 0; u < kHizTailTexels / 1024; u++) {
+                const uint32_t t = threadIdx.x + u * 1024;
+                if (t < dw * dh) {
+                    hiz_store<F16>(dst, t, mine[u]);
+                    keep[t] = mine[u];
+                }
+            }
+        } else {
+            for (uint32_t t = threadIdx.x; t < dw * dh; t += 1024) {
+                const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return prev[y * sw + x]; }, sw, sh, t % dw, t / dw, a.rule);
+                hiz_store<F16>(dst, t, mm);
+                keep[t] = mm;
+            }
         }
         __syncthreads();
     }
+}
+
+// Three levels of ANY size in one launch: a workgroup owns 32 x 32 texels of level k+1, 16 x 16 of level k+2 and 8 x 8 of
+// level k+3. The odd-size rule (hiz.frag:36-55) makes a texel reach one source column / row further, so the workgroup
+// computes a rim beside what it owns — 37 x 37 of level k+1 and 18 x 18 of level k+2, kept in LDS, never stored — instead
+// of waiting for its neighbours: 1.34x the level-k+1 arithmetic, no second and third launch, no round trip of the two
+// intermediate levels through L2. Frame sizes are rarely divisible by 64 (1920 x 1080, 2560 x 1440, 3840 x 2160: none is),
+// so this, not hiz_fused_kernel, is what an engine's pyramid build runs.
+constexpr uint32_t kF3Own1 = 32, kF3Rim1 = 37, kF3Own2 = 16, kF3Rim2 = 18, kF3Own3 = 8;
+template <bool F16>
+__global__ __launch_bounds__(256) void hiz_fused3_kernel(const HizFused3Args a)
+{
+    __shared__ float2 l1[kF3Rim1][kF3Rim1 + 1];
+    __shared__ float2 l2[kF3Rim2][kF3Rim2 + 1];
+    const uint32_t sw = a.w[0], sh = a.h[0], w1 = a.w[1], h1 = a.h[1], w2 = a.w[2], h2 = a.h[2], w3 = a.w[3], h3 = a.h[3];
+    // level k+1: [x1, x1 + cw1) x [y1, y1 + ch1), all loads of a lane's texels first
+    const uint32_t x1 = blockIdx.x * kF3Own1, y1 = blockIdx.y * kF3Own1;
+    const uint32_t cw1 = min(kF3Rim1, w1 - x1), ch1 = min(kF3Rim1, h1 - y1);
+    constexpr uint32_t kPerLane = (kF3Rim1 * kF3Rim1 + 255u) / 256u;
+    float2 mine[kPerLane];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        const uint32_t lx = t % kF3Rim1, ly = t / kF3Rim1;
+        if (lx < cw1 && ly < ch1) {
+            float2 mm = hiz_level_texel_rows<F16>(a.depth, a.src_pairs, sw, sh, x1 + lx, y1 + ly, a.rule);
+            if (F16 && a.depth)  // the one place a value leaves fp32: what the texel holds is what the next level reduces
+                mm = unpack_rg16f(pack_rg16f(mm));
+            mine[u] = mm;
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerLane; u++) {
+        const uint32_t t = threadIdx.x + u * 256u;
+        const uint32_t lx = t % kF3Rim1, ly = t / kF3Rim1;
+        if (lx < cw1 && ly < ch1) {
+            l1[ly][lx] = mine[u];
+            if (lx < kF3Own1 && ly < kF3Own1)
+                hiz_store<F16>(a.dst[0], (size_t)(y1 + ly) * w1 + x1 + lx, mine[u]);
+        }
+    }
+    __syncthreads();
+    // level k+2 from LDS: [x2, x2 + cw2) x [y2, y2 + ch2)
+    const uint32_t x2 = blockIdx.x * kF3Own2, y2 = blockIdx.y * kF3Own2;
+    const uint32_t cw2 = x2 < w2 ? min(kF3Rim2, w2 - x2) : 0u, ch2 = y2 < h2 ? min(kF3Rim2, h2 - y2) : 0u;
+    for (uint32_t t = threadIdx.x; t < kF3Rim2 * kF3Rim2; t += 256u) {
+        const uint32_t lx = t % kF3Rim2, ly = t / kF3Rim2;
+        if (lx >= cw2 || ly >= ch2)
+            continue;
+        const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return l1[y - y1][x - x1]; }, w1, h1, x2 + lx, y2 + ly, a.rule);
+        l2[ly][lx] = mm;
+        if (lx < kF3Own2 && ly < kF3Own2)
+            hiz_store<F16>(a.dst[1], (size_t)(y2 + ly) * w2 + x2 + lx, mm);
+    }
+    __syncthreads();
+    // level k+3 from LDS
+    const uint32_t x3 = blockIdx.x * kF3Own3, y3 = blockIdx.y * kF3Own3;
+    const uint32_t cw3 = x3 < w3 ? min(kF3Own3, w3 - x3) : 0u, ch3 = y3 < h3 ? min(kF3Own3, h3 - y3) : 0u;
+    const uint32_t lx = threadIdx.x % kF3Own3, ly = threadIdx.x / kF3Own3;
+    if (lx < cw3 && ly < ch3) {
+        const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return l2[y - y2][x - x2]; }, w2, h2, x3 + lx, y3 + ly, a.rule);
+        hiz_store<F16>(a.dst[2], (size_t)(y3 + ly) * w3 + x3 + lx, mm);
+    }
+}
+
+hipError_t launch_hiz_fused3(const HizFused3Args& args, bool rg16f, hipStream_t stream)
+{
+    const dim3 grid((args.w[1] + kF3Own1 - 1) / kF3Own1, (args.h[1] + kF3Own1 - 1) / kF3Own1);
+    if (rg16f)
+        hipLaunchKernelGGL(hiz_fused3_kernel<true>, grid, dim3(256), 0, stream, args);
+    else
+        hipLaunchKernelGGL(hiz_fused3_kernel<false>, grid, dim3(256), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t launch_hiz_tail(const HizTailArgs& args, bool rg16f, hipStream_t stream)
