@@ -39,5 +39,13 @@ rm -rf $out; mkdir -p $out
   done
   echo "# round 1 (profiles/r01k_tick_*, DESIGN.md): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203"
 } > $out/r02_tick.txt 2>&1
+{
+  echo "# tools/hiz_sizes.py: pyramid rebuild by frame size, wall clock over 300 back-to-back rebuilds (us)"
+  timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
+  echo "# the same without the any-size fused kernel (GV_DEBUG_HIZ_NO_FUSED3=1: one launch per level down to the tail)"
+  GV_DEBUG_HIZ_NO_FUSED3=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
+  echo "# ... and without the tail kernel either (GV_DEBUG_HIZ_NO_TAIL=1: one launch per level all the way, the round-1 form for such sizes)"
+  GV_DEBUG_HIZ_NO_FUSED3=1 GV_DEBUG_HIZ_NO_TAIL=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
+} > $out/r02_hiz_sizes.txt 2>&1
 python3 bench.py > $out/r02k_default_bench_line.json 2> $out/default.err
 tail -c 600 $out/default.err
