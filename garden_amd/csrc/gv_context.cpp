@@ -434,6 +434,7 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     for (int k = 0; k < 2; k++) {
         GV_HIP(ctx, vs.sort_keys[k].reserve(n));
         GV_HIP(ctx, vs.sort_vals[k].reserve(n));
+        GV_HIP(ctx, vs.sort_slots[k].reserve(n));
     }
     // sort_hist: [2 sets of counters (global + per-group digit histograms)] + the tiles' digit counts
     const size_t set_words = sort_set_words((uint32_t)n);
@@ -460,6 +461,7 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     for (int k = 0; k < 2; k++) {
         b.keys[k] = vs.sort_keys[k].ptr;
         b.vals[k] = vs.sort_vals[k].ptr;
+        b.slots[k] = vs.sort_slots[k].ptr;
         b.counters[k] = vs.sort_hist.ptr + k * set_words;
     }
     b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
@@ -641,7 +643,7 @@ void gv_destroy(GvCtx* ctx)
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
         v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release();
-        for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); }
+        for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); v.sort_slots[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
         v.h_records.release(); v.d_records.release();

@@ -214,7 +214,7 @@ struct ViewState {
     DeviceBuf<uint32_t> visible_idx;
     DeviceBuf<float> baked_model, distance_sq;
     // gv_sort: alternate record set + radix-sort scratch (allocated on first use)
-    DeviceBuf<uint32_t> alt_idx, sort_keys[2], sort_vals[2], sort_hist;
+    DeviceBuf<uint32_t> alt_idx, sort_keys[2], sort_vals[2], sort_slots[2], sort_hist;
     DeviceBuf<float> alt_model, alt_dist;
     PinnedBuf<uint32_t> h_visible_idx, h_draw_count;
     PinnedBuf<float> h_baked_model, h_distance_sq;

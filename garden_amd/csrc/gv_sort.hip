@@ -49,6 +49,9 @@ constexpr uint32_t kShortTile = kSortShortTileKeys;  // ... and for lists of up 
                                                      // 42 / 71 us, 65 k 46 / 78, 131 k 53 / 94, 308 k 64 / 100, 1 M 114 / 114,
                                                      // 2.1 M 234 / 204
 constexpr uint32_t kSortGroup = kSortGroupTiles;   // tiles whose digit counts are also summed per group
+#ifndef GV_SORT_CARRY_SLOTS  // 1: the pool slots travel with the (key, index) pairs
+#define GV_SORT_CARRY_SLOTS 1
+#endif
 #ifndef GV_SORT_THREADS  // (tools/onesweep_probe.hip measures other workgroup sizes)
 #define GV_SORT_THREADS 512
 #endif
@@ -129,6 +132,8 @@ struct SortPassArgs {
     uint16_t* ranks;            // per key of the current order: rank among its tile's keys of the same digit
     uint32_t* keys_out;         // !LAST
     uint32_t* vals_out;         // !LAST
+    const uint32_t* slots_in;   // !FIRST: the records' pool slots, in the current order (FIRST reads idx_in)
+    uint32_t* slots_out;        // !LAST
     const uint32_t* idx_in;     // LAST: the records, gathered to their sorted positions
     const float* model_in;
     uint32_t* idx_out;
@@ -233,6 +238,9 @@ struct SortScatterLds {
     uint32_t dst_base[256];    // global position of the tile's first key of each digit
     uint32_t skey[kSortTile];  // the tile reordered by digit
     uint32_t sval[kSortTile];
+#if GV_SORT_CARRY_SLOTS
+    uint32_t sslot[kSortTile];
+#endif
     uint32_t wave_sum[kSortWaves];
 };
 
@@ -244,6 +252,9 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     uint32_t* const dst_base = lds.dst_base;
     uint32_t* const skey = lds.skey;
     uint32_t* const sval = lds.sval;
+#if GV_SORT_CARRY_SLOTS
+    uint32_t* const sslot = lds.sslot;
+#endif
     uint32_t* const wave_sum = lds.wave_sum;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
     if (blockIdx.x >= tiles)
@@ -254,6 +265,9 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
     const uint32_t shift = a.pass * 8;
     const uint32_t wave_base = tile * kSortTile + wave * (kSortTile / kSortWaves);
     uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
+#if GV_SORT_CARRY_SLOTS
+    uint32_t slot[kSortRounds];
+#endif
 #pragma unroll
     for (uint32_t r = 0; r < kSortRounds; r++) {
         const uint32_t j = wave_base + r * 64 + lane;
@@ -265,6 +279,9 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
             key[r] = valid ? a.keys_in[j] : 0xFFFFFFFFu;
             val[r] = valid ? a.vals_in[j] : 0u;
         }
+#if GV_SORT_CARRY_SLOTS
+        slot[r] = valid ? (FIRST ? a.idx_in[j] : a.slots_in[j]) : 0u;  // pass 0: a sequential read, where the last pass had a random one
+#endif
         rank[r] = valid ? (uint32_t)a.ranks[j] : 0u;
     }
     // one thread per digit: same-digit keys in the tiles before this one = whole groups + the tiles before it in its group
@@ -305,6 +322,9 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
             const uint32_t lpos = tile_excl[(key[r] >> shift) & 255u] + rank[r];
             skey[lpos] = key[r];
             sval[lpos] = val[r];
+#if GV_SORT_CARRY_SLOTS
+            sslot[lpos] = slot[r];
+#endif
         }
     }
     __syncthreads();
@@ -318,22 +338,29 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
             const uint32_t pos = dst_base[dd] + (t - tile_excl[dd]);
             a.keys_out[pos] = k;
             a.vals_out[pos] = v;
+#if GV_SORT_CARRY_SLOTS
+            a.slots_out[pos] = sslot[t];
+#endif
         }
         GV_TRACE(8)
         return;
     }
     // LAST: the records go straight to their sorted positions. distanceSq is the key itself (order_key is a bijection:
-    // no gather), the pool slot is a 4-byte gather from an array that fits the caches (carrying the slots through the passes
-    // instead was measured: the last pass 101 -> 75 us, the other three scatter kernels + 4-7 us each, no gain end to end),
-    // the 48-byte model is gathered by three lanes per record (one float4 each), so that the stores of a run of records are
-    // whole contiguous rows.
+    // no gather), the pool slot has travelled with the pair (as a 4-byte gather from idx_in it cost 27 us of a 97 us pass at
+    // 2.1 M records: a whole sector fetched per slot; carried, it costs the other passes ~1.5 us each with 512-lane
+    // workgroups — with 256-lane ones it cost them 4-7 us each and was not worth it), the 48-byte model is gathered by three
+    // lanes per record (one float4 each), so that the stores of a run of records are whole contiguous rows.
     for (uint32_t t = threadIdx.x; t < live; t += kSortThreads) {
-        const uint32_t k = skey[t], v = sval[t];  // v = the record's index before the sort
+        const uint32_t k = skey[t];
         const uint32_t dd = (k >> shift) & 255u;
         const uint32_t pos = dst_base[dd] + (t - tile_excl[dd]);
         const uint32_t u = a.descending ? ~k : k;
         a.dist_out[pos] = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-        a.idx_out[pos] = a.idx_in[v];
+#if GV_SORT_CARRY_SLOTS
+        a.idx_out[pos] = sslot[t];
+#else
+        a.idx_out[pos] = a.idx_in[sval[t]];  // sval[t] = the record's index before the sort
+#endif
         skey[t] = pos;  // only this thread reads skey[t] in this loop
     }
     __syncthreads();
@@ -493,6 +520,8 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         a.vals_in = b.vals[src];
         a.keys_out = b.keys[dst];
         a.vals_out = b.vals[dst];
+        a.slots_in = b.slots[src];
+        a.slots_out = b.slots[dst];
         if (pass == 0) {
             hipLaunchKernelGGL(sort_rank_kernel<true>, dim3(tiles), dim3(kSortThreads), 0, stream, a);
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), dim3(tiles), dim3(kSortThreads), 0, stream, a);

@@ -21,6 +21,7 @@ struct SortBuffers {
     // large pools (radix sort, gv_sort.hip):
     uint32_t* keys[2];       // (key, record index) pairs, ping-pong
     uint32_t* vals[2];
+    uint32_t* slots[2];      // the records' pool slots, carried beside the pairs (the last pass then gathers only the models)
     uint16_t* ranks;         // per key: rank among its tile's keys of the current digit
     uint32_t* counters[2];   // two sets of sort_set_words(capacity) words — per-group digit counts [4][groups][256]: a sort
                              // uses set `parity` (zero on entry) and zeroes the other

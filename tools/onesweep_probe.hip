@@ -32,7 +32,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&ranks, (size_t)capacity * 2));
     CK(hipMemcpy(dist_in, dist.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     CK(hipMemset(idx_in, 0, (size_t)capacity * 4)); CK(hipMemset(model_in, 0, (size_t)capacity * 48));
-    for (int k = 0; k < 2; k++) { CK(hipMalloc(&b.keys[k], (size_t)capacity * 4)); CK(hipMalloc(&b.vals[k], (size_t)capacity * 4)); }
+    for (int k = 0; k < 2; k++) { CK(hipMalloc(&b.keys[k], (size_t)capacity * 4)); CK(hipMalloc(&b.vals[k], (size_t)capacity * 4)); CK(hipMalloc(&b.slots[k], (size_t)capacity * 4)); }
     const size_t set_words = gv::sort_set_words(capacity);
     const size_t words = 2 * set_words + (size_t)tiles * 256;
     CK(hipMalloc(&hist, words * 4)); CK(hipMemset(hist, 0, words * 4));
