@@ -2,7 +2,7 @@
 """Stress run (GPU box): many random cameras over large scenes, GPU visible sets against the oracle's, bit for bit.
 Not part of the test tiers (minutes of CPU oracle time); run after touching the cull kernels' arithmetic or the
 conservative pre-tests (sphere bound, block bounds):
-    python tools/stress_parity.py [--entities 2000000] [--views 36] [--seed 1]
+    python tools/stress_parity.py [--entities 2000000] [--views 36] [--seed 1] [--depth 1920x1080]
 Scenes: flat and 3-deep hierarchy; per scene: perspective cameras inside / outside the world in random directions,
 orthographic boxes of random size, Hi-Z on for half of the perspective views; plain and GV_CONFIG_BLOCK_BOUNDS contexts,
 and (Hi-Z views) a GV_CONFIG_HIZ_RG16F context against the oracle's RG16F pyramid."""
@@ -24,10 +24,12 @@ def main():
     ap.add_argument("--entities", type=int, default=2_000_000)
     ap.add_argument("--views", type=int, default=36)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--depth", default="1024x512", help="frame size of the depth image, WxH (sizes not divisible by 64 take the any-size pyramid kernels)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     threads = os.cpu_count() or 1
-    depth = scene.synthetic_depth(1024, 512)
+    dw, dh = (int(v) for v in args.depth.lower().split("x"))
+    depth = scene.synthetic_depth(dw, dh)
     hz = oracle.Hiz(depth)
     hz16 = oracle.Hiz(depth, rg16f=True)
     checked = failures = 0
