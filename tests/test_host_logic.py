@@ -238,7 +238,7 @@ def _mask_exchange_worker(rank, world, port, ret, mode):
     rng = np.random.default_rng(7)  # the same on every rank: each one can rebuild every shard
     ok = True
     for frame in range(4):
-        sets = [np.sort(rng.choice(slots, size=(0 if (r == 1 and frame == 2) else 40 + 900 * r + 11 * frame), replace=False)) for r in range(world)]
+        sets = [np.sort(rng.choice(slots, size=(0 if (r == 1 and frame == 2) else 40 + (4500 // world) * r + 11 * frame), replace=False)) for r in range(world)]
         shard = ex.next_shard()
         shard.copy_(pack_mask_shard(sets[rank], slots))  # what gv_results_copy_mask_device writes
         padded = ex.exchange()
@@ -251,7 +251,7 @@ def _mask_exchange_worker(rank, world, port, ret, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allgather"), (3, "p2p"), (2, "broadcast")])
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (3, "p2p"), (2, "broadcast"), (8, "p2p"), (8, "broadcast")])  # 8: the node's rank count
 def test_mask_payload_exchange_gloo(world, mode):
     """Shards as one bit per pool slot behind the count (the encoding for dense views: a fixed size whatever the view):
     every rank ends with every rank's visible SET, through each transport pattern, incl. an empty shard and a pool whose
@@ -374,7 +374,8 @@ def _tile_exchange_worker(rank, world, port, mode, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "p2p"), (2, "broadcast"), (3, "p2p")])
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "p2p"), (2, "broadcast"), (3, "p2p"),
+                                        (8, "allgather"), (8, "p2p"), (8, "broadcast")])  # 8 ranks = the node: cfg5's 2 x 2 x 2 octants
 def test_partitioned_world_through_the_exchange_gloo(oracle, world, mode):
     """ONE world -> spatial tiles -> per-tile cull -> exchange (each transport pattern) -> every rank holds the
     whole-world visible set."""
