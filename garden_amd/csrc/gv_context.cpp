@@ -482,6 +482,63 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 // gv_sort on a small pool only records the request; the first call that needs the records (fetch, device accessors,
 // gv_wait) sorts every pending view of EVERY pool in ONE launch — five mesh systems with a main camera and three shadow
 // passes each cost one launch, not twenty.
+// What delivers the results of (pool pid, view v) to the host: the count, the records [0, count) (three arrays, or the
+// pool's record structs — in the library's pinned buffer or the caller's own page-locked array) and, for a main pass, the
+// isVisible bytes in pool-slot order. Buffers are reserved here; used by the publish launch of gv_pool_results_fetch and by the
+// small-pool sort, which publishes what it has just sorted.
+int publish_args_of(GvCtx* ctx, uint32_t pid, uint32_t v, PublishArgs& a)
+{
+    PoolState& wp = ctx->pools[pid];
+    ViewState& w = ctx->views[pid][v];
+    const bool wperm = !wp.perm.empty() && wp.perm.size() == w.occupancy;
+    a = PublishArgs{};
+    a.count = w.draw_count.ptr;
+    a.idx = w.visible_idx.ptr;
+    a.model = w.baked_model.ptr;
+    a.dist = w.distance_sq.ptr;
+    a.is_visible = w.is_visible.ptr;
+    GV_HIP(ctx, w.h_draw_count.reserve(4));
+    a.host_count = w.h_draw_count.ptr;
+    w.records_staged = false;
+    if (w.emitted && wp.record_layout.stride) {
+        const PoolState::RecordTarget& target = wp.record_target[v];
+        const size_t need = (size_t)w.occupancy * wp.record_layout.stride;
+        if (target.host && target.bytes < need)
+            return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu", pid, v,
+                             target.bytes, need);
+        if (target.dev) {  // the device writes the caller's array
+            a.host_records = target.dev;
+        } else {
+            GV_HIP(ctx, w.h_records.reserve(need));
+            a.host_records = w.h_records.ptr;
+        }
+        w.records_at = target.host ? target.host : w.h_records.ptr;
+        w.records_staged = target.host && !target.dev;  // not page-locked: filled from h_records after the synchronisation
+        a.layout = wp.record_layout;
+        w.records_fetched = true;
+    } else if (w.emitted) {
+        GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
+        GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
+        GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
+        a.host_idx = w.h_visible_idx.ptr;
+        a.host_model = w.h_baked_model.ptr;
+        a.host_dist = w.h_distance_sq.ptr;
+    }
+    a.orig = wperm ? wp.d_orig.ptr : nullptr;
+    if (w.main_pass) {
+        GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
+        a.host_is_visible = w.h_is_visible.ptr;
+        if (wperm && w.occupancy > kPublishLdsSlots) {  // too large for the in-LDS un-permutation
+            GV_HIP(ctx, w.is_visible_slots.reserve(w.occupancy));
+            GV_HIP(ctx, launch_unpermute_bytes(w.is_visible.ptr, wp.d_orig.ptr, w.occupancy, w.is_visible_slots.ptr, ctx->stream));
+            a.is_visible = w.is_visible_slots.ptr;
+            a.orig = nullptr;
+        }
+    }
+    a.occupancy = w.occupancy;
+    return GV_OK;
+}
+
 int flush_sorts(GvCtx* ctx)
 {
     if (int rc = flush_culls(ctx))  // the records about to be sorted / read may still be waiting to be culled
@@ -490,6 +547,22 @@ int flush_sorts(GvCtx* ctx)
         uint32_t widest = 0, views = 0;
         ViewState* taken[kMaxPublishViews];
         SortBatch batch{};
+        // The sort publishes what it has sorted (count, records at their sorted places, isVisible: one kernel boundary and the
+        // publish kernel's own dependent loads less per tick) — unless other small views wait for a publish launch anyway
+        // (a tick with unsorted OIT buffers): then that launch takes these views along and the sort stays lean.
+        static const bool fuse_allowed = getenv("GV_DEBUG_SORT_NO_PUBLISH") == nullptr;
+        bool fuse_publish = fuse_allowed;
+        for (uint32_t pool = 0; pool < GV_MAX_POOLS && fuse_publish; pool++)
+            for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
+                const ViewState& w = ctx->views[pool][v];
+                if (w.valid && !w.published && !w.sort_pending && w.occupancy != 0 && w.occupancy <= kPublishMaxSlots)
+                    fuse_publish = false;
+                // ... and only records that leave as whole structs: a record written at its sorted place is one aligned 64- /
+                // 80-byte piece; the three arrays would leave as scattered 4- and 48-byte pieces, which measured slower
+                // (10 k entities: 50.8 vs 46.3 us per tick) than the publish kernel's contiguous rows
+                if (w.valid && w.sort_pending && w.occupancy <= kBatchSortMaxSlots && !ctx->pools[pool].record_layout.stride)
+                    fuse_publish = false;
+            }
         for (uint32_t pool = 0; pool < GV_MAX_POOLS && views < kMaxPublishViews; pool++)
             for (uint32_t v = 0; v < GV_MAX_VIEWS && views < kMaxPublishViews; v++) {
                 ViewState& vs = ctx->views[pool][v];
@@ -516,6 +589,10 @@ int flush_sorts(GvCtx* ctx)
                 b.dist_out = vs.alt_dist.ptr;
                 b.capacity = vs.occupancy;
                 b.descending = vs.sort_pending == 2 ? 1u : 0u;
+                b.fused_publish = fuse_publish ? 1u : 0u;
+                if (fuse_publish)
+                    if (int rc = publish_args_of(ctx, pool, v, b.publish))
+                        return rc;
                 widest = std::max(widest, vs.occupancy);
                 taken[views++] = &vs;
             }
@@ -533,7 +610,12 @@ int flush_sorts(GvCtx* ctx)
             std::swap(vs.baked_model, vs.alt_model);
             std::swap(vs.distance_sq, vs.alt_dist);
             vs.sort_pending = 0;
-            vs.published = false, vs.records_fetched = false;
+            if (batch.view[k].fused_publish) {
+                vs.published = true;  // ... once the stream has been synchronised
+                ctx->publish_sync_pending = true;
+            } else {
+                vs.published = false, vs.records_fetched = false;
+            }
         }
     }
 }
@@ -999,80 +1081,40 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         // view of this cull (the main camera and its shadow passes are fetched one after the other, mesh.cpp:809-843)
         // straight into the pinned host buffers, one synchronisation ends the frame; the sibling views' fetches find
         // their results already there
-        if (!vs.published) {
+        if (!vs.published || ctx->publish_sync_pending) {
             GV_HIP(ctx, hipSetDevice(ctx->device));
             static_assert(kMaxPublishViews >= GV_MAX_VIEWS, "PublishBatch holds at least one pool's views");
             // ... of EVERY pool culled since the last fetch: a frame that culls all its mesh systems first and reads
-            // afterwards (gv_pool_results_fetch) ends with this one launch and one synchronisation
+            // afterwards (gv_pool_results_fetch) ends with this one launch and one synchronisation. Views whose small-pool
+            // sort has published them already (flush_sorts) only wait for that synchronisation.
             PublishBatch batch{};
             uint32_t views = 0, widest = 0;
             ViewState* sent[kMaxPublishViews];
-            bool staged[kMaxPublishViews] = {};  // record targets that could not be page-locked: filled from h_records below
             for (uint32_t q = 0; q < GV_MAX_POOLS && views < kMaxPublishViews; q++) {
                 const uint32_t pid = (pool_id + q) % GV_MAX_POOLS;  // the pool asked for first: it always fits
-                PoolState& wp = ctx->pools[pid];
                 for (uint32_t v = 0; v < GV_MAX_VIEWS && views < kMaxPublishViews; v++) {
                     ViewState& w = ctx->views[pid][v];
                     if (!w.valid || w.published || w.occupancy == 0 || w.occupancy > kPublishMaxSlots)
                         continue;
-                    const bool wperm = !wp.perm.empty() && wp.perm.size() == w.occupancy;
-                    PublishArgs& a = batch.view[views];
-                    a.count = w.draw_count.ptr;
-                    a.idx = w.visible_idx.ptr;
-                    a.model = w.baked_model.ptr;
-                    a.dist = w.distance_sq.ptr;
-                    a.is_visible = w.is_visible.ptr;
-                    GV_HIP(ctx, w.h_draw_count.reserve(4));
-                    a.host_count = w.h_draw_count.ptr;
-                    if (w.emitted && wp.record_layout.stride) {
-                        const PoolState::RecordTarget& target = wp.record_target[v];
-                        const size_t need = (size_t)w.occupancy * wp.record_layout.stride;
-                        if (target.host && target.bytes < need)
-                            return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu",
-                                             pid, v, target.bytes, need);
-                        if (target.dev) {  // the device writes the caller's array
-                            a.host_records = target.dev;
-                        } else {
-                            GV_HIP(ctx, w.h_records.reserve(need));
-                            a.host_records = w.h_records.ptr;
-                        }
-                        w.records_at = target.host ? target.host : w.h_records.ptr;
-                        staged[views] = target.host && !target.dev;
-                        a.layout = wp.record_layout;
-                        w.records_fetched = true;
-                    } else if (w.emitted) {
-                        GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
-                        GV_HIP(ctx, w.h_baked_model.reserve((size_t)w.occupancy * 12));
-                        GV_HIP(ctx, w.h_distance_sq.reserve(w.occupancy));
-                        a.host_idx = w.h_visible_idx.ptr;
-                        a.host_model = w.h_baked_model.ptr;
-                        a.host_dist = w.h_distance_sq.ptr;
-                    }
-                    a.orig = wperm ? wp.d_orig.ptr : nullptr;
-                    if (w.main_pass) {
-                        GV_HIP(ctx, w.h_is_visible.reserve(w.occupancy));
-                        a.host_is_visible = w.h_is_visible.ptr;
-                        if (wperm && w.occupancy > kPublishLdsSlots) {  // too large for the in-LDS un-permutation
-                            GV_HIP(ctx, w.is_visible_slots.reserve(w.occupancy));
-                            GV_HIP(ctx, launch_unpermute_bytes(w.is_visible.ptr, wp.d_orig.ptr, w.occupancy, w.is_visible_slots.ptr, ctx->stream));
-                            a.is_visible = w.is_visible_slots.ptr;
-                            a.orig = nullptr;
-                        }
-                    }
-                    a.occupancy = w.occupancy;
+                    if (int rc = publish_args_of(ctx, pid, v, batch.view[views]))
+                        return rc;
                     widest = std::max(widest, w.occupancy);
                     sent[views++] = &w;
                 }
             }
-            GV_HIP(ctx, launch_publish(batch, views, widest, ctx->stream));
+            if (views)
+                GV_HIP(ctx, launch_publish(batch, views, widest, ctx->stream));
             GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             drain_events(ctx);
-            for (uint32_t k = 0; k < views; k++) {
-                ViewState& w = *sent[k];
-                w.published = true;
-                if (staged[k])
-                    memcpy(w.records_at, w.h_records.ptr, (size_t)w.h_draw_count.ptr[0] * batch.view[k].layout.stride);
-            }
+            ctx->publish_sync_pending = false;
+            for (uint32_t k = 0; k < views; k++)
+                sent[k]->published = true;
+            for (auto& per_pool : ctx->views)  // record targets that could not be page-locked
+                for (ViewState& w : per_pool)
+                    if (w.valid && w.published && w.records_staged) {
+                        memcpy(w.records_at, w.h_records.ptr, (size_t)w.h_draw_count.ptr[0] * ctx->pools[w.pool_id].record_layout.stride);
+                        w.records_staged = false;
+                    }
         }
         count = vs.h_draw_count.ptr[0];
     } else {
@@ -1268,7 +1310,7 @@ int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, c
         return ctx->fail(GV_E_STATE, "gv_pool_results_records: pool %u has no record layout", pool_id);
     if (!vs.emitted)
         return ctx->fail(GV_E_STATE, "gv_pool_results_records: pool %u view %u was culled count-only (GV_CULL_NO_RECORDS)", pool_id, view_index);
-    if (!vs.records_fetched) {  // not fetched yet
+    if (!vs.records_fetched || ctx->publish_sync_pending) {  // not fetched yet (or published by a sort that nobody has waited for)
         GvResult unused;
         if (int rc = gv_pool_results_fetch(ctx, pool_id, view_index, 0, &unused))
             return rc;

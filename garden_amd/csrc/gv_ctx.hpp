@@ -223,6 +223,7 @@ struct ViewState {
     DeviceBuf<uint8_t> d_records;    // ... packed on the device first for pools too large to publish directly
     bool records_fetched = false;    // records_at holds this cull's records
     uint8_t* records_at = nullptr;   // h_records, or the caller's array (gv_pool_set_record_target)
+    bool records_staged = false;     // the caller's array could not be page-locked: h_records is copied into it after the synchronisation
     bool ballots_current = false;    // `mask` holds this cull's ballot words (not after the one-launch cull + emit of a small pool)
     std::vector<uint32_t> instance_bases;  // gv_pool_results_instance_bases (built on request)
     uint32_t pool_id = 0, occupancy = 0;
@@ -330,6 +331,7 @@ struct Context {
     uint64_t mip_off[GV_MAX_MIPS]{};
     bool hiz_valid = false;
     bool hiz_nested = false;           // every level bounds all the texels it covers (see HizDevice::nested)
+    bool publish_sync_pending = false;  // a small-pool sort has published its views; nobody has synchronised the stream since
     bool hiz_level1_virtual = false;   // decided in gv_hiz_build: sizes whose first six levels take the fused kernel
     bool hiz_level1_stored = false;    // ... and whether gv_hiz_read_level has materialised it since the last build
 

@@ -416,14 +416,86 @@ __device__ __forceinline__ uint32_t count_before(const uint32_t* key, uint32_t j
     return before;
 }
 
+// What publish_kernel (gv_cull.hip) would do for this view after the sort, done by the sort's own launch: the count and (main
+// pass) the isVisible bytes in pool-slot order go to the host here, shared by all workgroups of the view's row of the grid
+// — the records follow from sort_small_block, each at its sorted place. One kernel boundary and the publish kernel's
+// dependent loads (count, records) less per tick.
+__device__ __forceinline__ void publish_visibility(const PublishArgs& a, uint32_t n, uint32_t block, uint32_t nblocks)
+{
+    if (block == 0 && threadIdx.x == 0)
+        *a.host_count = n;
+    if (!a.host_is_visible)
+        return;
+    if (a.orig) {  // spatially ordered mirror: back into pool-slot order in LDS, out as whole words (workgroup 0)
+        if (block != 0)
+            return;
+        __shared__ uint8_t slots[(kBatchSortMaxSlots + 3u) & ~3u];
+        for (uint32_t j = threadIdx.x; j < a.occupancy; j += 256)
+            slots[a.orig[j]] = a.is_visible[j];
+        __syncthreads();
+        const uint32_t words = a.occupancy >> 2;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(slots);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.host_is_visible);
+        for (uint32_t w = threadIdx.x; w < words; w += 256)
+            dst[w] = src[w];
+        for (uint32_t j = (words << 2) + threadIdx.x; j < a.occupancy; j += 256)
+            a.host_is_visible[j] = slots[j];
+        __syncthreads();
+    } else {
+        const uint32_t tid = block * 256 + threadIdx.x, threads = nblocks * 256;
+        const uint32_t words = a.occupancy >> 2;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(a.is_visible);
+        uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(a.host_is_visible);
+        for (uint32_t w = tid; w < words; w += threads)
+            dst[w] = src[w];
+        for (uint32_t j = (words << 2) + tid; j < a.occupancy; j += threads)
+            a.host_is_visible[j] = a.is_visible[j];
+    }
+}
+
+// One sorted record to the host, at its sorted place: the three arrays, or the caller's record struct (GvRecordLayout; built in
+// the lane's own row of `stage` so that the bytes no field owns leave as zeros, written out as whole 16-byte pieces).
+__device__ __forceinline__ void publish_record(const PublishArgs& a, uint32_t rank, uint32_t idx, float dist, float4 m0, float4 m1, float4 m2,
+                                               uint32_t* stage /* LDS: kMaxRecordStride / 4 words of this lane */)
+{
+    if (a.host_records) {
+        const RecordLayout& L = a.layout;
+        const uint32_t words = L.stride >> 2;
+        for (uint32_t k = 0; k < words; k++)
+            stage[k] = 0;
+        const unsigned long long offset = (unsigned long long)idx * L.component_stride;  // componentOffset  mesh.cpp:170
+        stage[L.component_offset >> 2] = (uint32_t)offset;
+        stage[(L.component_offset >> 2) + 1] = (uint32_t)(offset >> 32);
+        uint32_t* bm = stage + (L.baked_model >> 2);
+        bm[0] = __float_as_uint(m0.x); bm[1] = __float_as_uint(m0.y); bm[2] = __float_as_uint(m0.z); bm[3] = __float_as_uint(m0.w);
+        bm[4] = __float_as_uint(m1.x); bm[5] = __float_as_uint(m1.y); bm[6] = __float_as_uint(m1.z); bm[7] = __float_as_uint(m1.w);
+        bm[8] = __float_as_uint(m2.x); bm[9] = __float_as_uint(m2.y); bm[10] = __float_as_uint(m2.z); bm[11] = __float_as_uint(m2.w);
+        stage[L.distance_sq >> 2] = __float_as_uint(dist);
+        if (L.buffer_index != 0xFFFFFFFFu)
+            stage[L.buffer_index >> 2] = L.buffer_index_value;
+        uint4* out = reinterpret_cast<uint4*>(a.host_records + (size_t)rank * L.stride);
+        for (uint32_t q = 0; q < (L.stride >> 4); q++)
+            out[q] = make_uint4(stage[4 * q], stage[4 * q + 1], stage[4 * q + 2], stage[4 * q + 3]);
+    } else if (a.host_idx) {
+        a.host_idx[rank] = idx;
+        a.host_dist[rank] = dist;
+        float4* hm = reinterpret_cast<float4*>(a.host_model) + (size_t)rank * 3;
+        hm[0] = m0;
+        hm[1] = m1;
+        hm[2] = m2;
+    }
+}
+
 // max_records: the key table's capacity (LDS); a live count above it leaves the records to the radix kernels behind
 template <class Entry>
 __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capacity, uint32_t descending, uint32_t block,
-                                                 uint32_t max_records = 0xFFFFFFFFu)
+                                                 uint32_t max_records = 0xFFFFFFFFu, const PublishArgs* pub = nullptr)
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
     const uint32_t n = min(*b.count, capacity);
+    if (pub)  // (uniform)
+        publish_visibility(*pub, n, block, gridDim.x);
     const uint32_t i0 = block * 64;
     if (i0 >= n || n > max_records)
         return;
@@ -452,14 +524,20 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     if (part != 0 || i >= n)
         return;
     const uint32_t rank = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
-    b.idx_out[rank] = b.idx_in[i];
-    b.dist_out[rank] = b.dist_in[i];
+    const uint32_t idx = b.idx_in[i];
+    const float dist = b.dist_in[i];
+    b.idx_out[rank] = idx;
+    b.dist_out[rank] = dist;
     const float4* sm = reinterpret_cast<const float4*>(b.model_in + (size_t)i * 12);
     float4* dm = reinterpret_cast<float4*>(b.model_out + (size_t)rank * 12);
     const float4 m0 = sm[0], m1 = sm[1], m2 = sm[2];
     dm[0] = m0;
     dm[1] = m1;
     dm[2] = m2;
+    if (pub) {
+        __shared__ uint32_t record_stage[64][kMaxRecordStride / 4 + 1];  // (+1: rows on different banks)
+        publish_record(*pub, rank, idx, dist, m0, m1, m2, record_stage[lane]);
+    }
 }
 
 __global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending, uint32_t max_records)
@@ -471,7 +549,7 @@ __global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, ui
 __global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatch batch)
 {
     const SmallSortEntry& e = batch.view[blockIdx.y];
-    sort_small_block(e, e.capacity, e.descending, blockIdx.x);
+    sort_small_block(e, e.capacity, e.descending, blockIdx.x, 0xFFFFFFFFu, e.fused_publish ? &e.publish : nullptr);
 }
 
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream)

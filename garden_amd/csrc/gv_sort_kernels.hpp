@@ -63,6 +63,8 @@ struct SmallSortEntry {  // one view of one small pool
     float* dist_out;
     uint32_t capacity;      // the pool's slot count (upper bound of *count)
     uint32_t descending;
+    uint32_t fused_publish; // the launch also delivers the view to the host (what publish_kernel would do afterwards):
+    PublishArgs publish;    // count, records at their sorted places (host_idx / host_model / host_dist or host_records), isVisible
 };
 struct SortBatch {
     SmallSortEntry view[kMaxSortViews];  // views of SEVERAL pools per launch
