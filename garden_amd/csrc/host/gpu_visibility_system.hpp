@@ -413,8 +413,11 @@ private:
                 for (uint32_t v = 0; v < views.size(); v++) {
                     UnsortedBuffer* buffer = v == 0 ? unsortedBuffers[bufferIndex] : sb[v - 1];
                     const bool target = inPlace && occupancy && occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
-                    if (target && buffer->combinedMeshes.size() < occupancy)
+                    if (target && buffer->combinedMeshes.size() < occupancy) {
+                        // growing re-allocates: let the old range go while it is still allocated
+                        check(gv_pool_set_record_target(ctx, p, v, nullptr, 0), "gv_pool_set_record_target");
                         buffer->combinedMeshes.resize(occupancy);
+                    }
                     if (target && reinterpret_cast<uintptr_t>(buffer->combinedMeshes.data()) % 16 == 0) {
                         check(gv_pool_set_record_target(ctx, p, v, buffer->combinedMeshes.data(),
                                                         buffer->combinedMeshes.size() * sizeof(UnsortedMesh)), "gv_pool_set_record_target");
