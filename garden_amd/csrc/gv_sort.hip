@@ -426,9 +426,9 @@ __device__ __forceinline__ void publish_visibility(const PublishArgs& a, uint32_
         *a.host_count = n;
     if (!a.host_is_visible)
         return;
-    if (a.orig) {  // spatially ordered mirror: back into pool-slot order in LDS, out as whole words (workgroup 0)
-        if (block != 0)
-            return;
+    if (a.orig) {  // spatially ordered mirror: back into pool-slot order in LDS, out as whole words — by the row's LAST
+        if (block != nblocks - 1)  // workgroup: it has no records to sort unless nearly every slot is visible, so the
+            return;                // un-permutation runs beside the sort instead of in front of workgroup 0's share of it
         __shared__ uint8_t slots[(kBatchSortMaxSlots + 3u) & ~3u];
         for (uint32_t j = threadIdx.x; j < a.occupancy; j += 256)
             slots[a.orig[j]] = a.is_visible[j];
