@@ -482,6 +482,35 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 // gv_sort on a small pool only records the request; the first call that needs the records (fetch, device accessors,
 // gv_wait) sorts every pending view of EVERY pool in ONE launch — five mesh systems with a main camera and three shadow
 // passes each cost one launch, not twenty.
+// Everything queued on the context's stream has finished — where hipStreamSynchronize would do, for the end of an engine-sized
+// tick: a one-lane kernel behind the queue writes a sequence number into pinned memory and the host polls it
+// (launch_done_flag). Falls back to the synchronisation when profiling events wait to be read, when the word does not arrive
+// within 2 ms (a long queue: let the runtime sleep) or with GV_DEBUG_NO_DONE_FLAG.
+int wait_for_stream(GvCtx* ctx)
+{
+    static const bool use_flag = getenv("GV_DEBUG_NO_DONE_FLAG") == nullptr;
+    if (!use_flag || !ctx->pending.empty()) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GV_OK;
+    }
+    if (!ctx->h_done.ptr) {
+        GV_HIP(ctx, ctx->h_done.reserve(16));
+        ctx->h_done.ptr[0] = 0;
+    }
+    const uint32_t seq = ++ctx->done_seq;
+    GV_HIP(ctx, launch_done_flag(ctx->h_done.ptr, seq, ctx->stream));
+    volatile uint32_t* word = ctx->h_done.ptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *word != seq; spins++) {
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GV_OK;
+}
+
 // What delivers the results of (pool pid, view v) to the host: the count, the records [0, count) (three arrays, or the
 // pool's record structs — in the library's pinned buffer or the caller's own page-locked array) and, for a main pass, the
 // isVisible bytes in pool-slot order. Buffers are reserved here; used by the publish launch of gv_pool_results_fetch and by the
@@ -739,7 +768,7 @@ void gv_destroy(GvCtx* ctx)
     }
     ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
     ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
-    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release();
+    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release(); ctx->h_done.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_tick[k].release();
         if (ctx->tick_done[k])
@@ -1104,7 +1133,8 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             }
             if (views)
                 GV_HIP(ctx, launch_publish(batch, views, widest, ctx->stream));
-            GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int rc = wait_for_stream(ctx))
+                return rc;
             drain_events(ctx);
             ctx->publish_sync_pending = false;
             for (uint32_t k = 0; k < views; k++)

@@ -331,6 +331,8 @@ struct Context {
     uint64_t mip_off[GV_MAX_MIPS]{};
     bool hiz_valid = false;
     bool hiz_nested = false;           // every level bounds all the texels it covers (see HizDevice::nested)
+    PinnedBuf<uint32_t> h_done;  // the word the done-flag kernel writes (wait_for_stream)
+    uint32_t done_seq = 0;
     bool publish_sync_pending = false;  // a small-pool sort has published its views; nobody has synchronised the stream since
     bool hiz_level1_virtual = false;   // decided in gv_hiz_build: sizes whose first six levels take the fused kernel
     bool hiz_level1_stored = false;    // ... and whether gv_hiz_read_level has materialised it since the last build

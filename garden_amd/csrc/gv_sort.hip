@@ -614,6 +614,17 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     return hipGetLastError();
 }
 
+__global__ void done_flag_kernel(uint32_t* host_flag, uint32_t value)
+{
+    __hip_atomic_store(host_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t stream)
+{
+    hipLaunchKernelGGL(done_flag_kernel, dim3(1), dim3(1), 0, stream, host_flag, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t capacity, hipStream_t stream)
 {
     if (capacity == 0 || views == 0)

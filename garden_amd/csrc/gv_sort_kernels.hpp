@@ -72,6 +72,12 @@ struct SortBatch {
 // max_capacity: the largest entry capacity (sizes the grid and the LDS key table)
 hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t max_capacity, hipStream_t stream);
 
+// The end of a tick's device chain without a stream synchronisation: a one-lane kernel behind everything queued so far
+// writes `value` into pinned host memory (kernels of one stream run in order, and a kernel's stores have landed when the
+// next one starts), the host polls that word. hipStreamSynchronize returns 6-11 us after the last store is visible on this
+// stack (tools/sync_probe.hip); the polled word is there after one more kernel boundary.
+hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t stream);
+
 // gv_shard.hip: the visible list of a view as [draw_count | one bit per MIRROR entry]: a copy of the cull kernel's ballot words
 // (or, when `ballots` is NULL, built from the isVisible bytes in mirror order); words >= ceil(entries / 32), the rest is zeroed
 hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* bytes, const uint32_t* count, uint32_t entries, uint32_t* dst,

@@ -19,8 +19,16 @@ static double now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    // sync_probe [spin|yield|block]: hipSetDeviceFlags(hipDeviceSchedule...) before anything else touches the device;
+    // sync_probe query: hipStreamQuery polled instead of hipStreamSynchronize
+    const char* mode = argc > 1 ? argv[1] : "auto";
+    if (mode[0] == 's') hipSetDeviceFlags(hipDeviceScheduleSpin);
+    if (mode[0] == 'y') hipSetDeviceFlags(hipDeviceScheduleYield);
+    if (mode[0] == 'b') hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    const bool query = mode[0] == 'q';
+    printf("mode %s\n", mode);
     unsigned* flag;
     hipHostMalloc(&flag, 4, hipHostMallocDefault);
     *flag = 0;
@@ -34,14 +42,14 @@ int main()
             hipLaunchKernelGGL(work_then_flag, dim3(1), dim3(64), 0, s, flag, v, spin);
             while (*(volatile unsigned*)flag != v) {}
             const double t1 = now_us();
-            hipStreamSynchronize(s);
+            if (query) { while (hipStreamQuery(s) == hipErrorNotReady) {} } else hipStreamSynchronize(s);
             const double t2 = now_us();
             launch_to_flag.push_back(t1 - t0);
             flag_to_sync.push_back(t2 - t1);
             // the same without the spin: launch + synchronize
             const double t3 = now_us();
             hipLaunchKernelGGL(work_then_flag, dim3(1), dim3(64), 0, s, flag, v, spin);
-            hipStreamSynchronize(s);
+            if (query) { while (hipStreamQuery(s) == hipErrorNotReady) {} } else hipStreamSynchronize(s);
             sync_only.push_back(now_us() - t3);
         }
         auto med = [](std::vector<double>& a) { std::sort(a.begin(), a.end()); return a[a.size() / 2]; };
