@@ -71,14 +71,19 @@ __device__ __forceinline__ uint32_t order_key(float d, uint32_t descending)
 // lanes of the wave whose `digit` equals this lane's (among `valid` lanes): 8 ballots
 __device__ __forceinline__ unsigned long long match_digit(uint32_t digit, bool valid)
 {
-    unsigned long long peer = __ballot(valid);
+    // per bit: t = 0 / ~0 from the lane's bit, m = the lanes whose bit is set; the lanes that agree with this one are
+    // ~(m ^ t) — six VALU operations per bit (sign-extending bit extract, compare, two xnor, two and) where the select form
+    // of the same thing compiled to nine
+    const unsigned long long all = __ballot(valid);
+    uint32_t lo = (uint32_t)all, hi = (uint32_t)(all >> 32);
 #pragma unroll
     for (uint32_t b = 0; b < 8; b++) {
-        const bool bit = (digit >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peer &= bit ? m : ~m;
+        const uint32_t t = (uint32_t)((int32_t)(digit << (31u - b)) >> 31);
+        const unsigned long long m = __ballot(t != 0u);
+        lo &= ~((uint32_t)m ^ t);
+        hi &= ~((uint32_t)(m >> 32) ^ t);
     }
-    return peer;
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // exclusive scan of one value per thread over the workgroup; every thread also gets the grand total
