@@ -28,6 +28,7 @@ rm -rf $out; mkdir -p $out
   echo "#   round 2b (kept): rank kernel + scatter kernel per digit, no inter-workgroup waiting at all      203-207 us; a pass = 11 + 2 + 10 us, the last one + 90 us"
   echo "#             of record gather (the isolated gather above: 70 us — sector-granular random reads, the floor of this pass)"
   echo "#   round 2c (kept): the same two kernels with 512-lane workgroups, and 1024-key tiles for lists of up to 512 k records (chosen on the device)   190-195 us; 308 k records 100 -> 62 us, 21.7 k 71 -> 42 us"
+  echo "#   round 2d (kept): pool slots carried beside the pairs (the last pass gathers only the models) and a leaner digit match in the rank kernel      175-182 us"
   echo "#   ranking variants measured on the way (kept: 8-ballot match + wave-private LDS running counts): LDS lane-mask tables (no gain), 4 rotating mask tables"
   echo "#             with returning LDS atomics (spills at 128 VGPRs), static tile ids under the look-back form (-12 us, unsafe there; the kept form needs no ids)"
 } > $out/r02_sort_probe.txt 2>&1
