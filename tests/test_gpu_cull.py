@@ -1295,8 +1295,9 @@ def test_records_in_the_engines_own_struct_layout(oracle, n, kind):
                 vis.set_record_layout(0, bad, component_stride=component)
 
 
-@pytest.mark.parametrize("n", [3_000, 20_000, 300_000])  # in-LDS publish / publish / device pack + one copy
-def test_record_target_receives_the_records_in_place(oracle, n):
+@pytest.mark.parametrize("keep_slot_order", [False, True])  # isVisible un-permuted in LDS / copied as it is
+@pytest.mark.parametrize("n", [3_000, 20_000, 300_000])  # the sort publishes / publish launch / device pack + one copy
+def test_record_target_receives_the_records_in_place(oracle, n, keep_slot_order):
     """gv_pool_set_record_target: the device writes a view's records straight into the caller's own array (the
     engine's combinedMeshes) — the same bytes as the library-buffer delivery, gv_pool_results_records hands back the
     caller's address, slots past draw_count are left alone, an array smaller than occupancy * stride is refused at the
@@ -1308,7 +1309,7 @@ def test_record_target_receives_the_records_in_place(oracle, n):
     main = scene.main_camera_view()
     shadow = scene.cascade_view(index=0)
     component = int(sc.meshes.dtype.itemsize)
-    with GpuVisibility(device=0) as vis:
+    with GpuVisibility(device=0, keep_slot_order=keep_slot_order) as vis:
         vis.bind_transforms(sc.transforms, sc.entity_to_transform)
         vis.bind_pool(0, sc.meshes)
         vis.hierarchy_rebuild()
@@ -1316,9 +1317,14 @@ def test_record_target_receives_the_records_in_place(oracle, n):
         vis.cull(0, [main, shadow])
         vis.sort(0, descending=False, pool_id=0)
         vis.sort(1, descending=False, pool_id=0)
-        vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        first = vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
         ref = [vis.records(0, v, unsorted_dt) for v in range(2)]
         assert ref[0].shape[0] > 0 and ref[1].shape[0] > 0
+        # the main pass's isVisible bytes (pool-slot order) say what the records say
+        seen = np.zeros(n, np.uint8)
+        seen[(ref[0]["componentOffset"] // component).astype(np.int64)] = 1
+        assert np.array_equal(first["is_visible"], seen)
+        assert np.all(np.diff(ref[0]["distanceSq"]) >= 0)
 
         def address(pool_id, view):
             ptr, count = C.c_void_p(), C.c_uint32()
@@ -1333,7 +1339,7 @@ def test_record_target_receives_the_records_in_place(oracle, n):
             vis.sort(0, descending=False, pool_id=0)
             vis.sort(1, descending=False, pool_id=0)
             got = vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
-            assert got["draw_count"] == ref[0].shape[0]
+            assert got["draw_count"] == ref[0].shape[0] and np.array_equal(got["is_visible"], seen)
             for v in range(2):
                 at, count = address(0, v)
                 assert at == targets[v].ctypes.data and count == ref[v].shape[0]
