@@ -466,10 +466,14 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     }
     b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
     b.parity = vs.sort_parity;
-    vs.sort_parity ^= 1u;  // this sort leaves the other set zeroed for the next one
+    // the previous frame's count says what to enqueue for a mid-sized pool: a short list gets the rank sort alone
+    static const bool hints = getenv("GV_DEBUG_SORT_NO_HINT") == nullptr;
+    const SortMode mode = hints && vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly : kSortBoth;
+    if (!sort_is_rank_only((uint32_t)n, mode))
+        vs.sort_parity ^= 1u;  // the radix passes leave the other set of counters zeroed for the next sort
     {
         KernelTimer t(ctx, GV_K_SORT);
-        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream));
+        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream, mode));
     }
     vs.published = false, vs.records_fetched = false;
     // the sorted records now live in the alternate set: swap it in
@@ -1192,6 +1196,7 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         if (staged_for)
             memcpy(staged_for, vs.h_records.ptr, (size_t)count * pool.record_layout.stride);
     }
+    vs.count_hint = count;  // (what the next frame's sort of this view expects)
     memset(out, 0, sizeof(*out));
     out->draw_count = count;
     out->instance_count = count;  // default getReadyMeshesAsync returns 0/1 (render/mesh.hpp:142-146)

@@ -223,6 +223,7 @@ struct ViewState {
     DeviceBuf<uint8_t> d_records;    // ... packed on the device first for pools too large to publish directly
     bool records_fetched = false;    // records_at holds this cull's records
     uint8_t* records_at = nullptr;   // h_records, or the caller's array (gv_pool_set_record_target)
+    uint32_t count_hint = 0xFFFFFFFFu;  // draw count of this view's previous fetch (unknown: none)
     bool records_staged = false;     // the caller's array could not be page-locked: h_records is copied into it after the synchronisation
     bool ballots_current = false;    // `mask` holds this cull's ballot words (not after the one-launch cull + emit of a small pool)
     std::vector<uint32_t> instance_bases;  // gv_pool_results_instance_bases (built on request)

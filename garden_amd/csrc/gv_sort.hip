@@ -491,10 +491,42 @@ __device__ __forceinline__ void publish_record(const PublishArgs& a, uint32_t ra
     }
 }
 
-// max_records: the key table's capacity (LDS); a live count above it leaves the records to the radix kernels behind
+// The same count with the keys read from memory (built from distanceSq on the fly; uniform 16-byte loads): for a list that
+// outgrew the LDS key table in a launch that has no radix passes behind it (kSortRankOnly) — correct at any count, several
+// times slower than the table form, and rare: the count has to jump past the table within one frame.
+template <int WHERE>
+__device__ __forceinline__ uint32_t count_before_global(const float* __restrict__ dist, uint32_t descending, uint32_t n, uint32_t jlo, uint32_t jhi,
+                                                        uint32_t ki, uint32_t i)
+{
+    uint32_t before = 0;
+#pragma unroll 2
+    for (uint32_t j = jlo; j < jhi; j += 4) {
+        uint4 k;
+        if (j + 3u < n) {
+            const float4 d = *reinterpret_cast<const float4*>(dist + j);
+            k = make_uint4(order_key(d.x, descending), order_key(d.y, descending), order_key(d.z, descending), order_key(d.w, descending));
+        } else {  // the last, partly filled group: padding keys are never counted
+            k.x = j < n ? order_key(dist[j], descending) : 0xFFFFFFFFu;
+            k.y = j + 1u < n ? order_key(dist[j + 1u], descending) : 0xFFFFFFFFu;
+            k.z = j + 2u < n ? order_key(dist[j + 2u], descending) : 0xFFFFFFFFu;
+            k.w = 0xFFFFFFFFu;
+        }
+        if (WHERE == 0)
+            before += (k.x <= ki) + (k.y <= ki) + (k.z <= ki) + (k.w <= ki);
+        else if (WHERE == 2)
+            before += (k.x < ki) + (k.y < ki) + (k.z < ki) + (k.w < ki);
+        else
+            before += ((k.x < ki) | ((k.x == ki) & (j < i))) + ((k.y < ki) | ((k.y == ki) & (j + 1 < i))) +
+                      ((k.z < ki) | ((k.z == ki) & (j + 2 < i))) + ((k.w < ki) | ((k.w == ki) & (j + 3 < i)));
+    }
+    return before;
+}
+
+// max_records: a live count above it leaves the records to the radix kernels behind; table: the key table's capacity (LDS) —
+// counts between the two take the from-memory form above
 template <class Entry>
 __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capacity, uint32_t descending, uint32_t block,
-                                                 uint32_t max_records = 0xFFFFFFFFu, const PublishArgs* pub = nullptr)
+                                                 uint32_t max_records = 0xFFFFFFFFu, const PublishArgs* pub = nullptr, uint32_t table = 0xFFFFFFFFu)
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
@@ -505,25 +537,35 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     if (i0 >= n || n > max_records)
         return;
     const uint32_t n4 = (n + 3u) & ~3u;
-    for (uint32_t j = threadIdx.x; j < n4; j += 256) {
-        uint32_t k = 0xFFFFFFFFu;  // padding: never counted (its index is beyond every record's)
-        if (j < n) {
-            const uint32_t u = __float_as_uint(b.dist_in[j]);
-            k = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-            if (descending)
-                k = ~k;
+    const bool in_lds = n <= table;  // (uniform)
+    if (in_lds) {
+        for (uint32_t j = threadIdx.x; j < n4; j += 256) {
+            uint32_t k = 0xFFFFFFFFu;  // padding: never counted (its index is beyond every record's)
+            if (j < n) {
+                const uint32_t u = __float_as_uint(b.dist_in[j]);
+                k = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+                if (descending)
+                    k = ~k;
+            }
+            key[j] = k;
         }
-        key[j] = k;
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
     const uint32_t i = i0 + lane;
-    const uint32_t ki = key[min(i, n4 - 1)];
     const uint32_t per = ((n4 >> 2) + 3u) & ~3u;  // keys per wave, a multiple of 4
     const uint32_t jlo = min(part * per, n4), jhi = min(jlo + per, n4);
     const uint32_t own_lo = min(max(i0 & ~3u, jlo), jhi), own_hi = min(max((i0 + 64u + 3u) & ~3u, jlo), jhi);
-    const uint32_t before = count_before<0>(key, jlo, own_lo, ki, i) + count_before<1>(key, own_lo, own_hi, ki, i) +
-                            count_before<2>(key, own_hi, jhi, ki, i);
+    uint32_t before;
+    if (in_lds) {
+        const uint32_t ki = key[min(i, n4 - 1)];
+        before = count_before<0>(key, jlo, own_lo, ki, i) + count_before<1>(key, own_lo, own_hi, ki, i) + count_before<2>(key, own_hi, jhi, ki, i);
+    } else {
+        const uint32_t ki = order_key(b.dist_in[min(i, n - 1u)], descending);
+        before = count_before_global<0>(b.dist_in, descending, n, jlo, own_lo, ki, i) +
+                 count_before_global<1>(b.dist_in, descending, n, own_lo, own_hi, ki, i) +
+                 count_before_global<2>(b.dist_in, descending, n, own_hi, jhi, ki, i);
+    }
     partial[part][lane] = before;
     __syncthreads();
     if (part != 0 || i >= n)
@@ -545,9 +587,10 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     }
 }
 
-__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending, uint32_t max_records)
+__global__ __launch_bounds__(256) void sort_small_kernel(const SortBuffers b, uint32_t capacity, uint32_t descending, uint32_t max_records,
+                                                         uint32_t table)
 {
-    sort_small_block(b, capacity, descending, blockIdx.x, max_records);
+    sort_small_block(b, capacity, descending, blockIdx.x, max_records, nullptr, table);
 }
 
 // several views of one small pool (main camera + shadow passes) in one launch: blockIdx.y picks the view. N: entries in the
@@ -564,10 +607,14 @@ __global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatchN<
     sort_small_block(e, e.capacity, e.descending, blockIdx.x, 0xFFFFFFFFu, e.fused_publish ? &e.publish : nullptr);
 }
 
-hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream)
+hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode)
 {
     if (capacity == 0)
         return hipSuccess;
+    // kSortRankOnly (the caller expects a short list: the previous frame's count): a mid-sized pool gets the rank-sort launch
+    // alone — the eight radix launches that would leave after one load each are ~16 us of an engine-sized tick — and a
+    // list that outgrew the key table after all is still sorted by it, from memory (count_before_global)
+    const bool rank_only = sort_is_rank_only(capacity, mode);
     // Short lists sort in one launch whatever the pool's size: a pool of up to kMidSortSlots slots (where only the device
     // knows how short the visible list is) gets the rank-sort launch AND the radix launches, and the live count decides on
     // the device which of the two does the work — the other leaves after one load, ~2 us per launch, against 70 us for
@@ -581,8 +628,9 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
         if (raised != hipSuccess)
             return raised;
-        hipLaunchKernelGGL(sort_small_kernel, dim3((records + 63) / 64), dim3(256), lds, stream, b, capacity, descending ? 1u : 0u, records);
-        if (capacity <= kSmallSort)
+        hipLaunchKernelGGL(sort_small_kernel, dim3(((rank_only ? capacity : records) + 63) / 64), dim3(256), lds, stream, b, capacity,
+                           descending ? 1u : 0u, rank_only ? 0xFFFFFFFFu : records, records);
+        if (capacity <= kSmallSort || rank_only)
             return hipGetLastError();
     }
     const uint32_t tiles = sort_tile_count(capacity);  // at full capacity (long or short tiles); the live count is on the device

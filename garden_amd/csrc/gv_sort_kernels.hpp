@@ -44,7 +44,14 @@ inline uint32_t sort_tile_count(uint32_t capacity)
 }
 inline uint32_t sort_group_count(uint32_t capacity) { return (sort_tile_count(capacity) + kSortGroupTiles - 1u) / kSortGroupTiles; }
 inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count(capacity) * 256u; }
-hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream);
+// kSortBoth: pools of up to 2^20 slots get the rank-sort launch and the radix launches, the device's count picks (below).
+// kSortRankOnly: the caller expects a short list (the previous frame's count was at most kRankOnlyHintRecords): pools of
+// kBatchSortMaxSlots < slots <= kRankOnlyMaxSlots get the rank-sort launch alone (it sorts any count, slowly beyond its
+// key table: 0.74 ms for 38 k records where the radix passes take 0.17 ms — once, the next frame's hint is the new count); the counters of the radix passes are not touched (sort_is_rank_only: the caller keeps its parity).
+enum SortMode : uint32_t { kSortBoth = 0, kSortRankOnly = 1 };
+constexpr uint32_t kRankOnlyMaxSlots = 65536;  // bounds the one slow frame after a count that jumps (~2 ms at 64 k records)
+constexpr uint32_t kRankOnlyHintRecords = 8192;
+hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode = kSortBoth);
 // Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
 // asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
 // launch for all views (rank sort, launch_sort_small_batch: O(n^2 / lanes), 11 us at 2 k records, 75 us at 16 k — where the
@@ -53,6 +60,7 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
 constexpr uint32_t kSmallSortMaxSlots = 32768;
 constexpr uint32_t kBatchSortMaxSlots = 16384;
 constexpr uint32_t kRankSortMaxRecords = 12288;
+inline bool sort_is_rank_only(uint32_t capacity, uint32_t mode) { return mode == 1u && capacity > kBatchSortMaxSlots && capacity <= 65536u; }
 struct SmallSortEntry {  // one view of one small pool
     const uint32_t* count;  // device draw_count
     const uint32_t* idx_in;

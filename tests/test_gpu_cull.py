@@ -249,6 +249,34 @@ def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [40_000, 65_000, 150_000])  # (150 000: beyond the pools the hint applies to)
+def test_sort_of_a_mid_sized_pool_follows_the_previous_count(gpu, oracle, n):
+    """A pool between the one-launch batch and 65 536 slots is sorted by the rank sort ALONE when the view's previous fetch
+    saw a short list (no idle radix launches); a list that outgrows the rank sort's key table within one frame is still
+    sorted by that launch (keys from memory), and the frame after it takes the radix passes again."""
+    sc = scene.flat_scene(n, seed=5 + n)
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    small = scene.cascade_view(size=700.0 if n == 40_000 else (800.0 if n == 65_000 else 1100.0), depth=60000.0)   # a few thousand records
+    wide = scene.cascade_view(size=30000.0, depth=60000.0)                             # nearly everything
+    counts = []
+    for v, descending in [(small, False), (small, True), (wide, False), (wide, True), (small, False), (scene.main_camera_view(), True)]:
+        gpu.cull(0, [v])
+        gpu.sort(0, descending=descending)
+        got = gpu.fetch(0, write_back=False, occupancy=sc.count, order="raw")
+        exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, v, sort="descending" if descending else "ascending")
+        assert got["draw_count"] == exp["draw_count"] > 0
+        d = got["distance_sq"]
+        assert np.all(d[:-1] >= d[1:]) if descending else np.all(d[:-1] <= d[1:])
+        o = np.lexsort((got["visible_idx"], -d if descending else d))  # ties: canonical by slot (see test_gpu_sort_matches_sort_meshes)
+        assert np.array_equal(got["visible_idx"][o], exp["visible_idx"])
+        assert np.array_equal(got["baked_model"][o].view(np.uint32), exp["baked_model"].view(np.uint32))
+        assert np.array_equal(got["distance_sq"][o].view(np.uint32), exp["distance_sq"].view(np.uint32))
+        counts.append(int(got["draw_count"]))
+    assert counts[0] <= 8192 < 12288 < counts[2], counts  # short list -> rank sort alone; then a list beyond its key table
+
+
 @pytest.mark.parametrize("fraction,hier", [(1.0, False), (1.0, True), (0.05, False), (0.3, True)])
 def test_mesh_and_transform_pools_in_different_order(gpu, oracle, fraction, hier):
     """ECS pools are independent: mesh slot i need not map to transform slot i. fraction = 1 exercises the
