@@ -468,7 +468,9 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     b.parity = vs.sort_parity;
     // the previous frame's count says what to enqueue for a mid-sized pool: a short list gets the rank sort alone
     static const bool hints = getenv("GV_DEBUG_SORT_NO_HINT") == nullptr;
-    const SortMode mode = hints && vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly : kSortBoth;
+    const SortMode mode = !hints || vs.count_hint == 0xFFFFFFFFu ? kSortBoth
+                          : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
+                          : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
     if (!sort_is_rank_only((uint32_t)n, mode))
         vs.sort_parity ^= 1u;  // the radix passes leave the other set of counters zeroed for the next sort
     {

@@ -620,7 +620,7 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     // the device which of the two does the work — the other leaves after one load, ~2 us per launch, against 70 us for
     // the eight radix launches on a few thousand records. Measured crossover: ~12 k records (rank 11 us at 2 k, 75 us at
     // 16 k, 160 us at 32 k).
-    const bool rank_sort = capacity <= kMidSortSlots;
+    const bool rank_sort = capacity <= kMidSortSlots && (mode != kSortRadixOnly || capacity <= kSmallSort);
     if (rank_sort) {
         const uint32_t records = capacity <= kSmallSort ? capacity : kRankSortMaxRecords;
         const uint32_t lds = ((records + 3u) & ~3u) * 4;  // the key table, beside the 1 KB of partial counts
