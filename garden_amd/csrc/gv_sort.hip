@@ -622,7 +622,7 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     // 16 k, 160 us at 32 k).
     const bool rank_sort = capacity <= kMidSortSlots && (mode != kSortRadixOnly || capacity <= kSmallSort);
     if (rank_sort) {
-        const uint32_t records = capacity <= kSmallSort ? capacity : kRankSortMaxRecords;
+        const uint32_t records = capacity <= kSmallSort ? capacity : (rank_only ? kRankOnlyTableRecords : kRankSortMaxRecords);
         const uint32_t lds = ((records + 3u) & ~3u) * 4;  // the key table, beside the 1 KB of partial counts
         static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);

@@ -50,7 +50,8 @@ inline uint32_t sort_set_words(uint32_t capacity) { return 4u * sort_group_count
 // key table: 0.74 ms for 38 k records where the radix passes take 0.17 ms — once, the next frame's hint is the new count); the counters of the radix passes are not touched (sort_is_rank_only: the caller keeps its parity).
 enum SortMode : uint32_t { kSortBoth = 0, kSortRankOnly = 1, kSortRadixOnly = 2 };  // kSortRadixOnly: a long list is expected, the rank-sort launch is left out
 constexpr uint32_t kRankOnlyMaxSlots = 65536;  // bounds the one slow frame after a count that jumps (~2 ms at 64 k records)
-constexpr uint32_t kRankOnlyHintRecords = 8192;
+constexpr uint32_t kRankOnlyHintRecords = 10240;  // (the rank-only launch's key table holds 16384: 60 % headroom before the slow form)
+constexpr uint32_t kRankOnlyTableRecords = 16384;
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode = kSortBoth);
 // Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
 // asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
