@@ -266,6 +266,89 @@ hipError_t launch_hiz_fused3(const HizFused3Args& args, bool rg16f, hipStream_t 
     return hipGetLastError();
 }
 
+// Four levels per launch (HizFused4Args): level k+1 in LDS with a rim of 11 (75 x 75 for the 64 x 64 the workgroup owns), then
+// 37 x 37, 18 x 18 and the 8 x 8 of level k+4. 512 lanes: twelve level-k+1 texels each.
+constexpr uint32_t kF4Threads = 512;
+constexpr uint32_t kF4Own1 = 64, kF4Rim1 = 75, kF4Own2 = 32, kF4Rim2 = 37, kF4Own3 = 16, kF4Rim3 = 18, kF4Own4 = 8;
+template <bool F16>
+__global__ __launch_bounds__(kF4Threads) void hiz_fused4_kernel(const HizFused4Args a)
+{
+    __shared__ float2 l1[kF4Rim1][kF4Rim1 + 1];
+    __shared__ float2 l2[kF4Rim2][kF4Rim2 + 1];
+    __shared__ float2 l3[kF4Rim3][kF4Rim3 + 1];
+    const uint32_t sw = a.w[0], sh = a.h[0], w1 = a.w[1], h1 = a.h[1], w2 = a.w[2], h2 = a.h[2], w3 = a.w[3], h3 = a.h[3], w4 = a.w[4], h4 = a.h[4];
+    const uint32_t x1 = blockIdx.x * kF4Own1, y1 = blockIdx.y * kF4Own1;
+    const uint32_t cw1 = min(kF4Rim1, w1 - x1), ch1 = min(kF4Rim1, h1 - y1);
+    constexpr uint32_t kPerLane = (kF4Rim1 * kF4Rim1 + kF4Threads - 1u) / kF4Threads;
+    constexpr uint32_t kBatch = 4;  // texels whose loads are in flight together
+    for (uint32_t u0 = 0; u0 < kPerLane; u0 += kBatch) {
+        float2 mine[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; u++) {
+            const uint32_t t = threadIdx.x + (u0 + u) * kF4Threads;
+            const uint32_t lx = t % kF4Rim1, ly = t / kF4Rim1;
+            if (lx < cw1 && ly < ch1) {
+                float2 mm = hiz_level_texel_rows<F16>(a.depth, a.src_pairs, sw, sh, x1 + lx, y1 + ly, a.rule);
+                if (F16 && a.depth)  // the one place a value leaves fp32: what the texel holds is what the next level reduces
+                    mm = unpack_rg16f(pack_rg16f(mm));
+                mine[u] = mm;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; u++) {
+            const uint32_t t = threadIdx.x + (u0 + u) * kF4Threads;
+            const uint32_t lx = t % kF4Rim1, ly = t / kF4Rim1;
+            if (lx < cw1 && ly < ch1) {
+                l1[ly][lx] = mine[u];
+                if (lx < kF4Own1 && ly < kF4Own1)
+                    hiz_store<F16>(a.dst[0], (size_t)(y1 + ly) * w1 + x1 + lx, mine[u]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t x2 = blockIdx.x * kF4Own2, y2 = blockIdx.y * kF4Own2;
+    const uint32_t cw2 = x2 < w2 ? min(kF4Rim2, w2 - x2) : 0u, ch2 = y2 < h2 ? min(kF4Rim2, h2 - y2) : 0u;
+    for (uint32_t t = threadIdx.x; t < kF4Rim2 * kF4Rim2; t += kF4Threads) {
+        const uint32_t lx = t % kF4Rim2, ly = t / kF4Rim2;
+        if (lx >= cw2 || ly >= ch2)
+            continue;
+        const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return l1[y - y1][x - x1]; }, w1, h1, x2 + lx, y2 + ly, a.rule);
+        l2[ly][lx] = mm;
+        if (lx < kF4Own2 && ly < kF4Own2)
+            hiz_store<F16>(a.dst[1], (size_t)(y2 + ly) * w2 + x2 + lx, mm);
+    }
+    __syncthreads();
+    const uint32_t x3 = blockIdx.x * kF4Own3, y3 = blockIdx.y * kF4Own3;
+    const uint32_t cw3 = x3 < w3 ? min(kF4Rim3, w3 - x3) : 0u, ch3 = y3 < h3 ? min(kF4Rim3, h3 - y3) : 0u;
+    if (threadIdx.x < kF4Rim3 * kF4Rim3) {
+        const uint32_t lx = threadIdx.x % kF4Rim3, ly = threadIdx.x / kF4Rim3;
+        if (lx < cw3 && ly < ch3) {
+            const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return l2[y - y2][x - x2]; }, w2, h2, x3 + lx, y3 + ly, a.rule);
+            l3[ly][lx] = mm;
+            if (lx < kF4Own3 && ly < kF4Own3)
+                hiz_store<F16>(a.dst[2], (size_t)(y3 + ly) * w3 + x3 + lx, mm);
+        }
+    }
+    __syncthreads();
+    const uint32_t x4 = blockIdx.x * kF4Own4, y4 = blockIdx.y * kF4Own4;
+    const uint32_t cw4 = x4 < w4 ? min(kF4Own4, w4 - x4) : 0u, ch4 = y4 < h4 ? min(kF4Own4, h4 - y4) : 0u;
+    const uint32_t lx = threadIdx.x % kF4Own4, ly = threadIdx.x / kF4Own4;
+    if (lx < cw4 && ly < ch4) {
+        const float2 mm = hiz_level_texel_from([&](uint32_t x, uint32_t y) { return l3[y - y3][x - x3]; }, w3, h3, x4 + lx, y4 + ly, a.rule);
+        hiz_store<F16>(a.dst[3], (size_t)(y4 + ly) * w4 + x4 + lx, mm);
+    }
+}
+
+hipError_t launch_hiz_fused4(const HizFused4Args& args, bool rg16f, hipStream_t stream)
+{
+    const dim3 grid((args.w[1] + kF4Own1 - 1) / kF4Own1, (args.h[1] + kF4Own1 - 1) / kF4Own1);
+    if (rg16f)
+        hipLaunchKernelGGL(hiz_fused4_kernel<true>, grid, dim3(kF4Threads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(hiz_fused4_kernel<false>, grid, dim3(kF4Threads), 0, stream, args);
+    return hipGetLastError();
+}
+
 hipError_t launch_hiz_tail(const HizTailArgs& args, bool rg16f, hipStream_t stream)
 {
     if (args.count == 0)

@@ -19,4 +19,16 @@ struct HizFused3Args {
 };
 hipError_t launch_hiz_fused3(const HizFused3Args& args, bool rg16f, hipStream_t stream);
 
+// The same with FOUR levels per launch: a workgroup owns 64 x 64 texels of level k+1 ... 8 x 8 of level k+4 (rims 75 / 37 / 18:
+// 1.37x the level-k+1 arithmetic). For frames large enough to fill the GPU with such workgroups (1920 x 1080 and up): the
+// one-workgroup tail kernel then starts a level later, where it has a quarter of the texels to read from memory.
+struct HizFused4Args {
+    const float* depth;
+    const float2* src_pairs;
+    float2* dst[4];
+    uint32_t w[5], h[5];
+    uint32_t rule;
+};
+hipError_t launch_hiz_fused4(const HizFused4Args& args, bool rg16f, hipStream_t stream);
+
 }  // namespace gv
