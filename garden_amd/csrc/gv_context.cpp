@@ -152,13 +152,14 @@ int hiz_reduce(GvCtx* ctx)
             GV_HIP(ctx, launch_hiz_tail(tail, rg16f, ctx->stream));
             k = ctx->hiz_mips;
         } else if (k + 3 < ctx->hiz_mips && sw >= 2 && sh >= 2 && getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr &&
-                   getenv("GV_DEBUG_HIZ_NO_FUSED4") == nullptr && ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) >= 128 &&
+                   getenv("GV_DEBUG_HIZ_NO_FUSED4") == nullptr &&
+                   ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) >= 96 &&
                    ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) <= 200 &&
                    (uint64_t)ctx->mip_w[k + 2] * ctx->mip_h[k + 2] > kHizTailTexels && (uint64_t)ctx->mip_w[k + 3] * ctx->mip_h[k + 3] > kHizTailTexels / 2) {
             // Four levels per launch where that is what makes the one-workgroup tail start small: three levels would leave it a
             // first level of more than 4096 texels to read from memory (1920 x 1080: 8040), and the frame is large enough for
             // 64 x 64 workgroups to fill the GPU but not so large that the heavier workgroups cost more than the tail saves
-            // (measured: 1920 x 1080 22.8 -> 17.1 us; 2560 x 1440 21.0 -> 22.4 and 3840 x 2160 27.2 -> 32.6 keep three levels)
+            // (measured: 1920 x 1080 22.8 -> 17.1 us, 1600 x 900 17.7 -> 16.3; 2560 x 1440 21.0 -> 22.4 and 3840 x 2160 27.2 -> 32.6 keep three levels)
             HizFused4Args f{};
             f.depth = src_d;
             f.src_pairs = src_p;

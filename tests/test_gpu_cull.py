@@ -82,7 +82,7 @@ def test_hiz_occlusion_parity(gpu, oracle):
                                   # sizes not divisible by 64 take the any-size fused kernel (three levels per launch, rims recomputed):
                                   # odd at every level / thin / two such launches in a row (the second reads pairs) / partial edge tiles
                                   (257, 131), (515, 389), (1283, 719), (1000, 37), (2560, 1440), (3840, 2160), (2049, 1025),
-                                  (20000, 3), (3, 20000), (16400, 2)])  # one-texel-high / -wide levels inside the fused kernel
+                                  (20000, 3), (3, 20000), (16400, 2), (1600, 900)])  # one-texel-high / -wide levels inside the fused kernel
 @pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("rg16f", [False, True])
 def test_hiz_pyramid_parity(oracle, size, rule, rg16f):

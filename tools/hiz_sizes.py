@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, '.')
 from garden_amd import scene
 from garden_amd.lib import GpuVisibility
-for (w, h) in [(4096, 4096), (3840, 2160), (2560, 1440), (1920, 1080), (2048, 1024), (1280, 720)]:
+for (w, h) in [(4096, 4096), (3840, 2160), (2560, 1440), (1920, 1080), (2048, 1024), (1600, 900), (1366, 768), (1280, 720)]:
     depth = scene.synthetic_depth(w, h)
     with GpuVisibility(device=0) as vis:
         vis.hiz_build(depth)
