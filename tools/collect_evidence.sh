@@ -43,7 +43,7 @@ rm -rf $out; mkdir -p $out
 {
   echo "# tools/hiz_sizes.py: pyramid rebuild by frame size, wall clock over 300 back-to-back rebuilds (us)"
   timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-  echo "# the same with three levels per launch only (GV_DEBUG_HIZ_NO_FUSED4=1: 1920x1080 is the size that takes four)"
+  echo "# the same with three levels per launch only (GV_DEBUG_HIZ_NO_FUSED4=1: 1920x1080 and 1600x900 are the sizes that take four)"
   GV_DEBUG_HIZ_NO_FUSED4=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
   echo "# the same without the any-size fused kernel (GV_DEBUG_HIZ_NO_FUSED3=1: one launch per level down to the tail)"
   GV_DEBUG_HIZ_NO_FUSED3=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
