@@ -122,6 +122,8 @@ int hiz_reduce(GvCtx* ctx)
     ctx->hiz_level1_stored = false;
     ZoneScope zone("HiZ Downsample");
     KernelTimer timer(ctx, GV_K_HIZ);
+    static const bool use_tail = getenv("GV_DEBUG_HIZ_NO_TAIL") == nullptr, use_fused3 = getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr,
+                      use_fused4 = use_fused3 && getenv("GV_DEBUG_HIZ_NO_FUSED4") == nullptr;
     uint32_t k = 1;
     while (k < ctx->hiz_mips) {
         const uint32_t sw = ctx->mip_w[k - 1], sh = ctx->mip_h[k - 1];
@@ -135,7 +137,7 @@ int hiz_reduce(GvCtx* ctx)
                 dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
             GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, rg16f, ctx->stream));
             k += 6;
-        } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels && getenv("GV_DEBUG_HIZ_NO_TAIL") == nullptr) {
+        } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels && use_tail) {
             // the rest of the pyramid is small: one workgroup, one launch (frame sizes are rarely divisible by 64)
             static_assert(GV_MAX_MIPS <= 16, "HizTailArgs holds 16 levels");
             HizTailArgs tail{};
@@ -151,8 +153,7 @@ int hiz_reduce(GvCtx* ctx)
             tail.rule = ctx->config.hiz_rule;
             GV_HIP(ctx, launch_hiz_tail(tail, rg16f, ctx->stream));
             k = ctx->hiz_mips;
-        } else if (k + 3 < ctx->hiz_mips && sw >= 2 && sh >= 2 && getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr &&
-                   getenv("GV_DEBUG_HIZ_NO_FUSED4") == nullptr &&
+        } else if (k + 3 < ctx->hiz_mips && sw >= 2 && sh >= 2 && use_fused4 &&
                    ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) >= 96 &&
                    ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) <= 200 &&
                    (uint64_t)ctx->mip_w[k + 2] * ctx->mip_h[k + 2] > kHizTailTexels && (uint64_t)ctx->mip_w[k + 3] * ctx->mip_h[k + 3] > kHizTailTexels / 2) {
@@ -172,7 +173,7 @@ int hiz_reduce(GvCtx* ctx)
             f.rule = ctx->config.hiz_rule;
             GV_HIP(ctx, launch_hiz_fused4(f, rg16f, ctx->stream));
             k += 4;
-        } else if (k + 2 < ctx->hiz_mips && sw >= 2 && sh >= 2 && getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr) {
+        } else if (k + 2 < ctx->hiz_mips && sw >= 2 && sh >= 2 && use_fused3) {
             // any size: three levels per launch, a rim of the two intermediate levels recomputed per workgroup (gv_hiz.hip)
             HizFused3Args f{};
             f.depth = src_d;
