@@ -530,6 +530,13 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
 {
     extern __shared__ uint32_t key[];  // order-preserving keys of all n records, padded to a multiple of 4
     __shared__ uint32_t partial[4][64];
+    // the first 2048 distances are asked for together with the count they depend on (the buffers are sized for the pool): a
+    // short list's keys cost one round trip to memory instead of two
+    constexpr uint32_t kSpeculated = 8;
+    float early[kSpeculated];
+#pragma unroll
+    for (uint32_t k = 0; k < kSpeculated; k++)
+        early[k] = b.dist_in[min(threadIdx.x + 256u * k, capacity - 1u)];
     const uint32_t n = min(*b.count, capacity);
     if (pub)  // (uniform)
         publish_visibility(*pub, n, block, gridDim.x);
@@ -539,16 +546,14 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     const uint32_t n4 = (n + 3u) & ~3u;
     const bool in_lds = n <= table;  // (uniform)
     if (in_lds) {
-        for (uint32_t j = threadIdx.x; j < n4; j += 256) {
-            uint32_t k = 0xFFFFFFFFu;  // padding: never counted (its index is beyond every record's)
-            if (j < n) {
-                const uint32_t u = __float_as_uint(b.dist_in[j]);
-                k = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-                if (descending)
-                    k = ~k;
-            }
-            key[j] = k;
+#pragma unroll
+        for (uint32_t r = 0; r < kSpeculated; r++) {
+            const uint32_t j = threadIdx.x + 256u * r;
+            if (j < n4)
+                key[j] = j < n ? order_key(early[r], descending) : 0xFFFFFFFFu;  // padding: never counted (its index is beyond every record's)
         }
+        for (uint32_t j = threadIdx.x + 256u * kSpeculated; j < n4; j += 256)
+            key[j] = j < n ? order_key(b.dist_in[j], descending) : 0xFFFFFFFFu;
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
