@@ -7,9 +7,13 @@ A "step" is one frame of the hot path over one batch of resident component pools
   cfg5: 12.5M entities per GPU (100M over 8 GPUs), flat, frustum-only + the exchange (run with --gpus 8)
   cfg4: 10M entities, 4-deep hierarchy: MFMA world-matrix sweep fused with the frustum cull (one pass) + compaction
         (--sweep mfma|valu: separate sweep and cull launches; fused-valu: the fused pass with the v_fma chain)
-For N > 1 each rank owns one spatial tile (same per-GPU entity count: weak scaling), culls it against the
-same view and the ranks all-gatherv the compacted global visible-index lists over RCCL (cfg5 pattern); the default
-workload is then cfg5 (12.5M per GPU, frustum-only + the exchange), for N = 1 it is cfg3.
+For N > 1 each rank owns one spatial tile, culls it against the same view and the ranks all-gatherv the COMPACTED
+global visible-index lists over RCCL (cfg5 pattern, --payload indices: what BASELINE.json's north_star names); the
+default workload is then cfg5 (12.5M per GPU, frustum-only + the exchange), for N = 1 it is cfg3. The N > 1 line also
+carries: the same ranks' frames WITHOUT the exchange (`n1_same_workload`, what one GPU does with one tile) and
+`scaling_efficiency` = value / (N * that); `exchange_ms` (one isolated exchange) and the bytes each rank's shard puts on
+the links; the bit-shard encoding timed in the same run (`mask_variant`); parity of EVERY rank's tile against the oracle.
+--scaling strong --entities-total T: one world of T entities cut into N tiles (T / N per GPU; N = 1: all of it).
 
 `python bench.py --gpus N` without a torch.distributed environment (WORLD_SIZE unset) starts the N ranks itself, as
 fresh child processes (python -m torch.distributed.run ... bench.py <same arguments>) BEFORE anything here touches the
@@ -223,12 +227,17 @@ def main():
                     choices=["allgather", "p2p", "broadcast"],
                     help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
                          "send/recv to every peer, or one broadcast per root (A/B for the fully connected xGMI node)")
-    ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "auto"), choices=["auto", "indices", "mask"],
-                    help="N > 1: what a shard carries — the compacted uint32 index list, or one bit per mirror entry behind the "
-                         "count (1/32 word per entry whatever the view: ~7x fewer bytes at the bench's 21 %% visibility). auto "
-                         "(default): the smaller of the two for the view at hand (bits above 1/32 visible), after one trial frame of "
-                         "the bit form has been checked against the exact all-gatherv on every rank — the lists otherwise. The gathered "
-                         "sets of the timed frames are checked against the exact all-gatherv either way")
+    ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "indices"), choices=["auto", "indices", "mask"],
+                    help="N > 1: what a shard carries — the compacted uint32 index list (default: the all-gatherv of the visible list "
+                         "BASELINE.json names), or one bit per mirror entry behind the count (1/32 word per entry whatever the view: ~7x "
+                         "fewer bytes at the bench's 21 %% visibility; timed in the same run as `mask_variant` unless --no-mask-variant). "
+                         "auto: the smaller of the two for the view at hand (bits above 1/32 visible), after one trial frame of the bit "
+                         "form has been checked against the exact all-gatherv on every rank. The gathered sets of the timed frames are "
+                         "checked against the exact all-gatherv either way")
+    ap.add_argument("--no-mask-variant", action="store_true", help="N > 1: skip the bit-shard frames timed beside the index lists")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): the workload's entity count PER GPU; strong: --entities-total cut into N spatial tiles")
+    ap.add_argument("--entities-total", type=int, default=100_000_000, help="--scaling strong: entities of the whole world")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -244,8 +253,8 @@ def main():
                                    f"torch.distributed.run --nproc-per-node {args.gpus}, or run plain "
                                    f"`python bench.py --gpus {args.gpus}` (it starts the ranks itself)"}), flush=True)
         sys.exit(2)
-    if args.workload is None:
-        args.workload = "cfg5" if args.gpus > 1 else "cfg3"
+    if args.workload is None:  # (strong scaling: the same workload at every N, N = 1 included)
+        args.workload = "cfg5" if args.gpus > 1 or args.scaling == "strong" else "cfg3"
 
     # The contract is ONE JSON line on stdout. Libraries underneath (RCCL prints a version banner when a communicator
     # is created) write to file descriptor 1 too, so everything but the result lines is sent to stderr.
@@ -305,6 +314,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     n = args.entities or wl["entities"]
+    if args.scaling == "strong":  # one world of --entities-total cut into `world` spatial tiles (the same world at every N)
+        n = args.entities_total // world
     sc = make_tile_scene(wl, n, rank, world)
     view = scene.main_camera_view(use_hiz=1 if wl["hiz"] else 0)
     depth = scene.synthetic_depth(HIZ_SIZE, HIZ_SIZE) if wl["hiz"] else None
@@ -419,6 +430,7 @@ def main():
         return elapsed, per, last
 
     gathered_total = None
+    tables_ready = [False]
     if exchange:
         exact, exact_counts, problem = check_exchange()
         if not all_agree(problem is None):
@@ -431,7 +443,7 @@ def main():
         def make_exchange(payload):
             """The frame loop's exchange object for `payload` (and, for bit shards, every rank's entry -> slot table)."""
             args.payload = payload
-            if payload == "mask":
+            if payload == "mask" and not tables_ready[0]:
                 # once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit
                 # shards needs to name the entities; the static scene never rebuilds its mirror)
                 mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
@@ -443,11 +455,18 @@ def main():
                 else:
                     dist.all_gather(tables, mine)
                 entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
+                tables_ready[0] = True
             capacity = mask_words(n) if payload == "mask" else shard_capacity(int(exact_counts.max()))
             # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
             per_rank = ([shard_capacity(int(c)) for c in exact_counts] if payload == "indices" and args.exchange != "allgather" else None)
             return VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=payload,
                                        capacities=per_rank)
+
+        def shard_words_per_rank(x):
+            """uint32 words rank r's shard puts on each link per frame (header included) under the exchange's pattern."""
+            if x.capacities is not None and x.mode != "allgather":
+                return [1 + c for c in x.capacities]
+            return [1 + x.capacity] * world
 
         payload_note = None
         if args.payload == "auto":
@@ -495,16 +514,80 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # N > 1: the same frames without the exchange step (same ranks, same run): what the collective costs
-    no_exchange = None
-    if world > 1:
+    timed_payload = args.payload if exchange else None
+    timed_exchange = ex[0]
+
+    def max_over_ranks(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def every_rank(x):
+        """[x of rank 0, x of rank 1, ...] on every rank."""
+        if world == 1:
+            return [float(x)]
+        dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        out = torch.empty(world, dtype=torch.float64, device=dev)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out, t)
+        else:
+            pieces = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(pieces, t)
+            out = torch.cat(pieces)
+        return [float(v) for v in out.cpu()]
+
+    # With an exchange: the same frames WITHOUT it (same ranks, same run) = what one GPU does with one tile of this workload
+    # (`n1_same_workload`), and so what the collective costs and what the scaling efficiency is; one ISOLATED exchange (nothing
+    # overlapped: shard copy + collective + completion, host clock); and the other shard encoding timed the same way.
+    no_exchange = exchange_ms = mask_variant = None
+    if exchange:
         for _ in range(3):
             compute()
         e2, per2, _ = timed_steps(compute, args.steps)
-        t = torch.tensor([e2], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        no_exchange = dict(ms_per_step=float(t.item()) / args.steps * 1e3, value=n * world * args.steps / float(t.item()),
+        per_rank_ms = every_rank(e2 / args.steps * 1e3)
+        e2 = max_over_ranks(e2)
+        no_exchange = dict(ms_per_step=e2 / args.steps * 1e3, value=n * world * args.steps / e2,
+                           value_per_gpu=n * args.steps / e2, ms_per_step_by_rank=per_rank_ms,
                            ms_per_step_median_rank0=float(np.median(per2)))
+        lat = []
+        for _ in range(5):
+            compute()
+            fence()
+            t0 = time.perf_counter()
+            shard = ex[0].next_shard()
+            if args.payload == "mask":
+                vis.copy_mask_device(0, shard.data_ptr(), ex[0].capacity)
+            else:
+                vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
+            ex[0].exchange()
+            ex[0].drain()
+            vis.wait()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        exchange_ms = max_over_ranks(float(np.median(lat)) * 1e3)
+        if timed_payload == "indices" and not args.no_mask_variant:
+            mv_problem = None
+            try:
+                ex[0] = make_exchange("mask")
+                for _ in range(3):
+                    step()
+                e3, per3, last3 = timed_steps(step, args.steps)
+                mv_problem = check_padded(last3, exact, exact_counts)
+                e3 = max_over_ranks(e3)
+                mask_variant = dict(ms_per_step=e3 / args.steps * 1e3, value=n * world * args.steps / e3,
+                                    shard_bytes_per_rank=[4 * w for w in shard_words_per_rank(ex[0])],
+                                    delivers="every rank holds every rank's [count, one bit per mirror entry]; the entry -> pool slot "
+                                             "tables travelled once at set-up (a consumer that wants the index list expands the rows)",
+                                    checked_against_exact_allgatherv=mv_problem is None)
+            except Exception as e:  # noqa: BLE001 — a failing variant is reported, it does not take the headline with it
+                mv_problem = f"{type(e).__name__}: {e}"
+            ok = all_agree(mv_problem is None)
+            if not ok:
+                mask_variant = dict(error=mv_problem or "failed on another rank")
+            args.payload, ex[0] = timed_payload, timed_exchange
 
     # SURVEY.md §8d: also report the rate when every TRS is re-uploaded each frame (host AoS -> mirror gather + PCIe
     # + cull). Outside the timed region; never `value`.
@@ -521,6 +604,21 @@ def main():
     if rank == 0:
         # this box's read-stream peak on the cull kernel's own access pattern (five streams, 65 B per entity)
         stream_peak = vis.stream_peak(0, 20)
+
+    # per-kernel breakdown of a frame (pyramid / sweep / cull / emit), from a few frames OUTSIDE the timed region with every
+    # kernel bracketed (the timed region brackets only the dominant kernel, on every fourth frame)
+    frame_kernel_ms = None
+    if not args.profile_all:
+        from garden_amd.lib import KERNEL_NAMES
+        vis.wait()
+        vis.profile_kernels(KERNEL_NAMES)
+        vis.stats_reset()
+        breakdown_frames = 10
+        for _ in range(breakdown_frames):
+            compute()
+        s2 = vis.stats()
+        frame_kernel_ms = {k: s2["device_ms"][k] / breakdown_frames for k in s2["device_ms"] if s2["device_ms"][k] > 0}
+        vis.profile_kernels(["cull"])
 
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
@@ -565,33 +663,61 @@ def main():
             emit({"error": "block-bounds variant differs from the linear scan", "variant": bounds_variant})
             leave(1)
 
+    # cfg4: the bench default is the MFMA chain BASELINE.json names; the bit-identical v_fma chain is timed beside it
+    valu_variant = None
+    if world == 1 and wl["sweep"] and args.sweep == "fused":
+        def valu_step():
+            vis.sweep(GV_SWEEP_WITH_CULL_VALU)
+            vis.cull(0, view_array)
+
+        for _ in range(5):
+            valu_step()
+        vis.wait()
+        vis.stats_reset()
+        frames, t3 = 30, time.perf_counter()
+        for _ in range(frames):
+            valu_step()
+        vis.wait()
+        dt = time.perf_counter() - t3
+        sv, tv = vis.stats(), vis.profile_samples()
+        gvv = vis.fetch(0, write_back=False, occupancy=n)
+        same = bool(np.array_equal(gvv["visible_idx"], got["visible_idx"]) and np.array_equal(gvv["is_visible"], got["is_visible"])
+                    and np.array_equal(gvv["baked_model"].view(np.uint32), got["baked_model"].view(np.uint32)))
+        valu_variant = dict(kernel="gv::sweep_cull_valu_kernel", ms_per_step=dt / frames * 1e3, value=n * frames / dt,
+                            avg_launch_ms=sv["device_ms"]["cull"] / max(1, tv["cull"]), outputs_identical=same)
+        if not same:
+            emit({"error": "cfg4: the VALU chain's outputs differ from the MFMA chain's", "variant": valu_variant})
+            leave(1)
+
     visible = got["draw_count"]
     parity = None
     survivors = visible
     parity_ok = True
-    if rank == 0:
-        from oracle import oracle_py
-        cores = os.cpu_count() or 1
-        threads = max(1, cores // world)
-        frustum_only = dict(view, use_hiz=0)
-        if wl["hiz"]:
-            m2 = sc.meshes.copy()
-            survivors = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, frustum_only, threads=threads)["draw_count"]
-        if not args.no_parity:
-            m2 = sc.meshes.copy()
-            exp = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view,
-                                           hiz=oracle_py.Hiz(depth, threads=threads, rg16f=args.hiz_rg16f) if wl["hiz"] else None, threads=threads)
-            order = np.argsort(exp["visible_idx"], kind="stable")
-            same_set = bool(np.array_equal(got["visible_idx"], exp["visible_idx"][order]))
-            same_vis = bool(np.array_equal(got["is_visible"], m2["isVisible"]))
-            same_mat = same_set and bool(np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
-            parity = dict(visible_set_bit_identical=same_set, is_visible_identical=same_vis,
-                          baked_model_bit_identical=same_mat, visible=int(visible), checked_entities=int(n),
-                          checked_rank=0)
-            parity_ok = same_set and same_vis and same_mat
+    # EVERY rank checks its own tile against the oracle (the host's cores shared between the ranks); the verdict is all-reduced
+    from oracle import oracle_py
+    cores = os.cpu_count() or 1
+    threads = max(1, cores // world)
+    if rank == 0 and wl["hiz"]:  # frustum survivors of rank 0's tile: the Hi-Z texel term of the roofline numerator
+        m2 = sc.meshes.copy()
+        survivors = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, dict(view, use_hiz=0), threads=threads)["draw_count"]
+    if not args.no_parity:
+        m2 = sc.meshes.copy()
+        exp = oracle_py.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view,
+                                       hiz=oracle_py.Hiz(depth, threads=threads, rg16f=args.hiz_rg16f) if wl["hiz"] else None, threads=threads)
+        order = np.argsort(exp["visible_idx"], kind="stable")
+        same_set = bool(np.array_equal(got["visible_idx"], exp["visible_idx"][order]))
+        same_vis = bool(np.array_equal(got["is_visible"], m2["isVisible"]))
+        same_mat = same_set and bool(np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][order].view(np.uint32)))
+        parity_ok = same_set and same_vis and same_mat
+        verdicts = every_rank((1 if same_set else 0) + (2 if same_vis else 0) + (4 if same_mat else 0))
+        counts_by_rank = every_rank(visible)
+        parity = dict(visible_set_bit_identical=all(int(v) & 1 for v in verdicts), is_visible_identical=all(int(v) & 2 for v in verdicts),
+                      baked_model_bit_identical=all(int(v) & 4 for v in verdicts), visible=int(sum(counts_by_rank)),
+                      visible_by_rank=[int(c) for c in counts_by_rank], checked_entities=int(n) * world, checked_ranks=world,
+                      oracle_threads_per_rank=threads)
     if not all_agree(parity_ok):
         if rank == 0:
-            emit({"error": "results differ from the CPU oracle", "parity": parity})
+            emit({"error": "results differ from the CPU oracle on some rank", "parity": parity})
         vis.close()
         leave(1)
 
@@ -603,6 +729,8 @@ def main():
         ab = algorithmic_bytes(wl, n, survivors, visible, depth, fused=fused, examined=examined)
         cull_ms = st["device_ms"]["cull"] / max(1, timed["cull"])
         achieved = ab["cull"] / (cull_ms * 1e-3) / 1e9 if cull_ms > 0 else 0.0
+        if valu_variant and valu_variant["avg_launch_ms"] > 0:  # same algorithmic bytes, the other chain
+            valu_variant["frac"] = ab["cull"] / (valu_variant["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         # roofline.traffic: PMC bytes of this kernel from profiles/traffic.json — only while the kernel sources still
         # hash to what they were when the counters were collected
         traffic, traffic_source = None, None
@@ -632,14 +760,27 @@ def main():
             "unit": "entity culls/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             # per-frame durations from one hipEvent per frame boundary on the library's stream (rank 0)
             "ms_per_step_median": median_ms, "ms_per_step_min": float(per_step_ms.min()), "ms_per_step_max": float(per_step_ms.max()),
             "value_at_median_step": n * world / (median_ms * 1e-3),
-            "config": {"workload": wl["name"], "sweep": args.sweep if wl["sweep"] else None,
+            # N > 1: ONE GPU on ONE tile of this same workload (these ranks' frames without the exchange step, slowest rank) and
+            # value / (N * that). Weak scaling: the efficiency of the job; strong: of the exchange only (the N = 1 run of the same
+            # --entities-total is the other half: tools/scale_sweep.sh puts the runs side by side)
+            "n1_same_workload": ({"value": no_exchange["value_per_gpu"], "unit": "entity culls/s", "ms_per_step": no_exchange["ms_per_step"],
+                                  "entities": n, "what": "the same ranks' frames without the exchange step, same run (slowest rank)"}
+                                 if no_exchange and world > 1 else None),
+            "scaling_efficiency": ((n * world * args.steps / elapsed) / (world * no_exchange["value_per_gpu"])) if no_exchange and world > 1 else None,
+            # the same frame through GV_CONFIG_BLOCK_BOUNDS (same outputs, checked): reported beside `value`, never as it
+            "value_with_block_bounds": bounds_variant["value"] if bounds_variant else None,
+            "config": {"workload": (wl["name"] if args.scaling == "weak" else
+                                    f"{args.workload}-strong: ONE world of {n * world} entities cut into {world} spatial tile(s), "
+                                    f"{n} per GPU; per tile as {wl['name']}"), "sweep": args.sweep if wl["sweep"] else None,
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
-                       "block_bounds_variant": bounds_variant, "entities_per_gpu": n, "entities_total": n * world,
+                       "block_bounds_variant": bounds_variant, "valu_variant": valu_variant, "entities_per_gpu": n, "entities_total": n * world,
+                       "scaling_mode": (f"strong: one world of {n * world} entities cut into {world} spatial tile(s)" if args.scaling == "strong"
+                                        else f"weak: {n} entities per GPU"),
                        "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,
                        "exchange": (f"per frame: " + ("shards [count, one bit per mirror entry] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
                                     f"(capacity {ex[0].capacity} words) travel by "
@@ -648,9 +789,20 @@ def main():
                        "exchange_mode": args.exchange if exchange else None,
                        "exchange_payload": (args.payload + (f" ({payload_note})" if payload_note else "")) if exchange else None,
                        "same_frames_without_exchange": no_exchange,
-                       # per frame; only the bracketed kernels appear (default: the dominant one; --profile-all: every kernel)
+                       # one isolated exchange (shard copy + collective + completion; nothing overlapped; host clock, slowest rank)
+                       "exchange_ms": exchange_ms,
+                       # what the exchange adds to a frame when it runs behind the next frame's cull (two slots in flight)
+                       "exchange_overhead_ms_per_step": (elapsed / args.steps * 1e3 - no_exchange["ms_per_step"]) if no_exchange else None,
+                       # bytes rank r's shard puts on each link per frame as it travels (padding included) / of those, list entries
+                       "shard_bytes_per_rank": [4 * w for w in shard_words_per_rank(ex[0])] if exchange else None,
+                       "list_bytes_per_rank": ([4 * (1 + int(c)) for c in exact_counts] if exchange else None),
+                       "gathered_bytes_per_rank": (4 * sum(shard_words_per_rank(ex[0]))) if exchange else None,
+                       "mask_variant": mask_variant,
+                       # per frame, in the TIMED region: only the bracketed kernels appear (default: the dominant one; --profile-all: all)
                        "kernel_ms": {k: (st["device_ms"][k] * (st["launches"][k] / max(1, timed[k])) / max(1, args.steps))
                                      for k in st["device_ms"] if st["device_ms"][k] > 0},
+                       # per frame, every kernel, from 10 extra frames outside the timed region (hipEvents around each launch)
+                       "frame_kernel_ms": frame_kernel_ms,
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes,
                        "culls_per_s_with_full_trs_upload_each_frame": dirty_rate},
             "roofline": {"bound": "hbm", "kernel": ("gv::sweep_cull_mfma_kernel" if args.sweep == "fused" else "gv::sweep_cull_valu_kernel") if fused else "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -72,7 +72,11 @@ int reserve_view(GvCtx* ctx, ViewState& vs, uint32_t occupancy, bool emit)
     }
     GV_HIP(ctx, vs.chunk_offset.reserve(chunks));
     GV_HIP(ctx, vs.draw_count.reserve(4));
-    GV_HIP(ctx, vs.is_visible.reserve(n));
+    if (n > vs.is_visible.cap || chunks * kEmitParts > vs.vis_flags.cap) {
+        GV_HIP(ctx, vs.is_visible.reserve(n));
+        GV_HIP(ctx, vs.vis_flags.reserve(chunks * kEmitParts));
+        vs.vis_flags_current = false;  // new bytes: unknown contents
+    }
     GV_HIP(ctx, vs.h_draw_count.reserve(4));
     if (emit) {
         GV_HIP(ctx, vs.visible_idx.reserve(n));
@@ -91,10 +95,23 @@ ViewBuffers view_buffers(ViewState& vs)
     b.chunk_offset = vs.chunk_offset.ptr;
     b.draw_count = vs.draw_count.ptr;
     b.is_visible = vs.is_visible.ptr;
+    b.vis_flags = vs.vis_flags.ptr;
     b.visible_idx = vs.visible_idx.ptr;
     b.baked_model = vs.baked_model.ptr;
     b.distance_sq = vs.distance_sq.ptr;
     return b;
+}
+
+// In front of a self-prefixing emit of this view: its quarter-chunk flags must describe the isVisible bytes. They do when the
+// previous writer of those bytes was such an emit too; otherwise (a cull that stored the bytes itself, the one-launch cull + emit,
+// the scan-path emit, new buffers) every quarter is marked "may hold a non-zero" and the emit rewrites it once.
+int emit_flags_ready(GvCtx* ctx, ViewState& vs)
+{
+    static const bool sparse = getenv("GV_DEBUG_EMIT_NO_SPARSE") == nullptr;  // debug A/B: every workgroup always writes its bytes
+    if ((!vs.vis_flags_current || !sparse) && vs.vis_flags.ptr)
+        GV_HIP(ctx, hipMemsetAsync(vs.vis_flags.ptr, 1, vs.vis_flags.cap, ctx->stream));
+    vs.vis_flags_current = true;
+    return GV_OK;
 }
 
 // The world-matrix cache has just been brought up to date (any sweep): the re-mirror flags start over.
@@ -231,6 +248,8 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         static const bool cull_writes = getenv("GV_DEBUG_CULL_WRITES_IS_VISIBLE") != nullptr;  // debug A/B: both kernels store the bytes
         if (ctx->views[pool_id][v].emitted && !cull_writes)
             cvps[v].write_is_visible = 0;
+        if (cvps[v].write_is_visible)
+            ctx->views[pool_id][v].vis_flags_current = false;  // the cull stores the bytes itself
     }
     int rc = GV_OK;
     // GV_SWEEP_WITH_CULL: an exactly paired pool takes the fused MFMA sweep + cull for its first view; anything else
@@ -304,6 +323,8 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 vs.stale_chunks[other] = 0;
                 vs.stale_chunks[cur] = chunks;
                 vs.count_parity = other;
+                if ((rc = emit_flags_ready(ctx, vs)) != GV_OK)
+                    return rc;
             }
             KernelTimer t(ctx, GV_K_EMIT);
             GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream, emit_world));
@@ -322,6 +343,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 vs.tile_epoch = 0;
             }
             vs.ballots_current = false;
+            vs.vis_flags_current = false;  // cull_emit_kernel stores the bytes
             vs.tile_epoch = vs.tile_epoch == UINT32_MAX ? 1u : vs.tile_epoch + 1u;
             {
                 KernelTimer t(ctx, GV_K_CULL);
@@ -348,6 +370,8 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 // next cull of this view adds into the other one, which this emit has cleared
                 ViewState& vs = ctx->views[pool_id][v];
                 const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+                if ((rc = emit_flags_ready(ctx, vs)) != GV_OK)
+                    return rc;
                 KernelTimer t(ctx, GV_K_EMIT);
                 GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world));
                 vs.stale_chunks[other] = 0;
@@ -360,6 +384,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 GV_HIP(ctx, launch_scan(vbs[v], chunks, ctx->stream));
             }
             if (ctx->views[pool_id][v].emitted) {
+                ctx->views[pool_id][v].vis_flags_current = false;  // (the scan-path emit writes every byte and keeps no flags)
                 KernelTimer t(ctx, GV_K_EMIT);
                 GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world));
             }
@@ -422,6 +447,8 @@ int flush_culls(GvCtx* ctx)
         for (uint32_t v = 0; v < j.view_count; v++) {
             ViewState& vs = ctx->views[j.pool_id][v];
             const uint32_t cur = vs.count_parity, other = cur ^ 1u;
+            if (int rc = emit_flags_ready(ctx, vs))
+                return rc;
             fill_emit_table_entry(host + emit_off + (size_t)(e++) * emit_bytes, mesh, xf, j.vps[v], vbs[v],
                                   std::max(chunks, vs.stale_chunks[other]), nullptr);
             vs.stale_chunks[other] = 0;
@@ -740,6 +767,7 @@ int gv_create(const GvConfig* config, GvCtx** out_ctx)
     }
     ctx->config = cfg;
     ctx->device = cfg.device;
+    ctx->profile_mask = !(cfg.flags & GV_CONFIG_PROFILE_EVENTS) ? 0u : (cfg.flags & GV_CONFIG_PROFILE_CULL_ONLY) ? 1u << GV_K_CULL : (1u << GV_K_COUNT) - 1u;
     if ((e = hipSetDevice(cfg.device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("gv_create: ") + hipGetErrorString(e);
@@ -780,7 +808,7 @@ void gv_destroy(GvCtx* ctx)
     for (auto& per_pool : ctx->views)
       for (auto& v : per_pool) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
-        v.is_visible.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
+        v.is_visible.release(); v.vis_flags.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
         v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); v.sort_slots[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
@@ -1794,6 +1822,17 @@ int gv_profile_sampling(GvCtx* ctx, uint32_t every)
     if (every == 0)
         return ctx->fail(GV_E_ARG, "gv_profile_sampling: every must be at least 1");
     ctx->profile_every = every;
+    memset(ctx->profile_seen, 0, sizeof(ctx->profile_seen));
+    return GV_OK;
+}
+
+int gv_profile_kernels(GvCtx* ctx, uint32_t kernel_mask)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (kernel_mask >> GV_K_COUNT)
+        return ctx->fail(GV_E_ARG, "gv_profile_kernels: mask 0x%x names kernels beyond GV_K_COUNT", kernel_mask);
+    ctx->profile_mask = kernel_mask;
     memset(ctx->profile_seen, 0, sizeof(ctx->profile_seen));
     return GV_OK;
 }

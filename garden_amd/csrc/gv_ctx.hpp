@@ -210,6 +210,9 @@ struct ViewState {
     uint32_t stale_chunks[2] = {0, 0};  // entries of each totals buffer that may be non-zero right now
 
     DeviceBuf<uint8_t> is_visible;        // mirror order, written by the cull
+    DeviceBuf<uint8_t> vis_flags;         // ViewBuffers::vis_flags: which quarter-chunks of is_visible may hold a non-zero
+    bool vis_flags_current = false;       // false: something other than the self-prefixing emit wrote is_visible since (or the
+                                          // buffers are new): the flags are set to "may be non-zero" before the next emit
     DeviceBuf<uint8_t> is_visible_slots;  // pool-slot order, filled by gv_results_fetch of a large, spatially ordered pool
     DeviceBuf<uint32_t> visible_idx;
     DeviceBuf<float> baked_model, distance_sq;
@@ -349,6 +352,7 @@ struct Context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     GvStats stats{};
     uint32_t profile_every = 1;                      // gv_profile_sampling
+    uint32_t profile_mask = 0;                       // bit k: launches of GvKernelId k are bracketed (gv_create from the config flags; gv_profile_kernels)
     uint64_t profile_seen[GV_K_COUNT] = {}, profile_timed[GV_K_COUNT] = {};
 
     int fail(int code, const char* fmt, ...)
@@ -398,9 +402,7 @@ struct KernelTimer {
     KernelTimer(GvCtx* c, int k) : ctx(c), kernel(k)
     {
         ctx->stats.launches[k]++;
-        if (!(ctx->config.flags & GV_CONFIG_PROFILE_EVENTS))
-            return;
-        if ((ctx->config.flags & GV_CONFIG_PROFILE_CULL_ONLY) && k != GV_K_CULL)
+        if (!((ctx->profile_mask >> k) & 1u))
             return;
         if (ctx->profile_seen[k]++ % ctx->profile_every != 0)  // gv_profile_sampling
             return;

@@ -732,7 +732,6 @@ __device__ __forceinline__ uint32_t select_bit(unsigned long long word, uint32_t
 }
 
 constexpr uint32_t kSelfPrefixLoads = (kSelfPrefixMaxChunks / 4 + 191) / 192;  // uint4 loads per lane of waves 1-3
-constexpr uint32_t kEmitParts = 4;  // workgroups per 4096-slot chunk: 1024 slots = 16 ballot words each
 
 // Four workgroups per 4096-slot chunk, each owning 16 of its 64 ballot words. Every workgroup prefix-sums the
 // chunk's 64 words (512 B, L2), then lane r takes the r-th visible slot of its quarter (binary search over the
@@ -752,6 +751,24 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     const uint32_t chunk = block / kEmitParts, part = block % kEmitParts;
     const uint32_t first_word = chunk * 64;
     const uint32_t total_words = ((args.mesh.count + kCullBlock - 1) / kCullBlock) * (kCullBlock / 64);
+    // An EMPTY chunk (behind an occlusion pass most are: cfg3 keeps 3 % of the entities, in a fifth of the chunks) has no record
+    // to emit; its isVisible bytes are zeros, which they already are unless the quarter's flag says otherwise. Such a workgroup
+    // leaves after one load instead of walking the whole chain of dependent loads (ballot words -> prefix -> barrier -> ...):
+    // the launch was bound by 9 768 workgroups taking turns at that chain, not by bytes. Workgroup 0 keeps its global duties.
+    if (SELF && args.out.vis_flags && block != 0 && args.out.chunk_count[chunk] == 0) {  // workgroup-uniform
+        if (!args.view.write_is_visible || !args.out.vis_flags[block])
+            return;
+        const uint32_t slot = chunk * kEmitChunk + part * (kEmitChunk / kEmitParts) + 4u * threadIdx.x;
+        if (slot + 3u < args.mesh.count) {
+            *reinterpret_cast<uint32_t*>(args.out.is_visible + slot) = 0u;
+        } else {
+            for (uint32_t k = 0; slot + k < args.mesh.count; k++)
+                args.out.is_visible[slot + k] = 0;
+        }
+        if (threadIdx.x == 0)
+            args.out.vis_flags[block] = 0;
+        return;
+    }
     if (threadIdx.x < 64) {
         const uint32_t w = first_word + threadIdx.x;
         const unsigned long long word = w < total_words ? args.out.mask[w] : 0ull;
@@ -804,6 +821,8 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
                     args.out.is_visible[slot + k] = (uint8_t)((bytes >> (8u * k)) & 1u);
             }
         }
+        if (SELF && args.out.vis_flags && threadIdx.x == 0)  // does this quarter now hold a non-zero byte?
+            args.out.vis_flags[block] = prefix[(part + 1) * (64 / kEmitParts)] != prefix[part * (64 / kEmitParts)] ? 1 : 0;
     }
     uint32_t base;
     if (SELF) {

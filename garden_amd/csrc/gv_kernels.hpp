@@ -64,6 +64,7 @@ constexpr uint32_t kFusedEmitMaxSlots = 32768;  // pools up to this size cull + 
                                                 // ~16 ns per tile, so it only pays while a launch costs more (6.9 vs 9.8 us at 10 k
                                                 // slots, equal at 100 k, 64 vs 24 us at 1 M; profiles/r02i_fused_emit.txt)
 constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
+constexpr uint32_t kEmitParts = 4;     // emit workgroups per chunk: 1024 slots = 16 ballot words each
 
 struct ViewParams {
     float planes[6][4];
@@ -86,6 +87,9 @@ struct ViewBuffers {
     uint32_t* chunk_offset;    // exclusive scan of chunk_count (scan path only)
     uint32_t* draw_count;      // total
     uint8_t* is_visible;       // per slot (main pass)
+    uint8_t* vis_flags;        // per emit workgroup (kEmitParts per chunk): 1 = its quarter of the chunk's isVisible bytes may hold
+                               // a non-zero, 0 = known to be all zero. Lets the self-prefixing emit leave an EMPTY chunk after one
+                               // load (behind an occlusion pass most chunks are empty). NULL: every workgroup writes its bytes
     uint32_t* visible_idx;     // compact records [0, draw_count), ascending slot order
     float* baked_model;        // 12 floats per record
     float* distance_sq;

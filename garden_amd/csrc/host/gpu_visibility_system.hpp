@@ -107,6 +107,10 @@ public:
     }
     ~GpuVisibilitySystem() override
     {
+        // the context first: gv_destroy synchronises the stream and un-registers every record target, so no queued publish /
+        // sort can still write into a combinedMeshes array and no page-locked range is freed while it is registered
+        gv_destroy(ctx);
+        ctx = nullptr;
         for (auto b : unsortedBuffers)
             delete b;
         for (auto b : sortedBuffers)
@@ -114,7 +118,6 @@ public:
         for (auto& v : shadowBuffers)
             for (auto b : v)
                 delete b;
-        gv_destroy(ctx);
     }
 
     GvCtx* getContext() const noexcept { return ctx; }

@@ -114,7 +114,7 @@ EXPORTS = [
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
-    "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples",
+    "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
 ]
 
 _lib = None
@@ -200,6 +200,7 @@ def load():
     lib.gv_pool_set_record_target.argtypes = [P, u32, u32, C.c_void_p, C.c_size_t]
     lib.gv_profile_sampling.argtypes = [P, u32]
     lib.gv_profile_samples.argtypes = [P, C.POINTER(C.c_uint64 * GV_K_COUNT)]
+    lib.gv_profile_kernels.argtypes = [P, u32]
     lib.gv_pool_results_instance_bases.argtypes = [P, u32, u32, C.POINTER(C.POINTER(u32)), C.POINTER(u32)]
     lib.gv_cull_batch_begin.argtypes = [P]
     lib.gv_cull_batch_end.argtypes = [P]
@@ -250,6 +251,7 @@ class GpuVisibility:
         if getattr(self, "ctx", None) and self.ctx.value:
             self.lib.gv_destroy(self.ctx)
             self.ctx = C.c_void_p()
+            self._keep = {}  # bound pools and record targets are let go only after the context (and its page locks) is gone
 
     __del__ = close
 
@@ -405,9 +407,11 @@ class GpuVisibility:
         and in place; None removes the target): the engine's own combinedMeshes instead of the library's buffer."""
         if array is None:
             self._check(self.lib.gv_pool_set_record_target(self.ctx, pool_id, view_index, None, 0))
+            self._keep.pop(("target", pool_id, view_index), None)  # (only now: the call above synchronises and un-registers)
             return
         assert array.flags["C_CONTIGUOUS"] and array.flags["WRITEABLE"]
         self._check(self.lib.gv_pool_set_record_target(self.ctx, pool_id, view_index, array.ctypes.data, array.nbytes))
+        self._keep[("target", pool_id, view_index)] = array  # page-locked and written by the device until replaced / removed / close()
 
     def instance_bases(self, pool_id=0, view_index=0):
         """First instance index of every fetched record ([count + 1] words; the last one is instance_count)."""
@@ -533,6 +537,10 @@ class GpuVisibility:
     def profile_sampling(self, every):
         """Bracket only every `every`-th launch of each kernel kind with events (each bracket costs ~5 us of stream time)."""
         self._check(self.lib.gv_profile_sampling(self.ctx, every))
+
+    def profile_kernels(self, names):
+        """Bracket the launches of these kernel kinds (KERNEL_NAMES) from now on; [] = none."""
+        self._check(self.lib.gv_profile_kernels(self.ctx, sum(1 << KERNEL_NAMES.index(n) for n in names)))
 
     def profile_samples(self):
         """Bracketed launches per kernel kind since stats_reset: the divisor for stats()['device_ms']."""

@@ -464,6 +464,10 @@ int gv_stats_reset(GvCtx* ctx);
  * region is the frame rather than its instrumentation. GvStats.device_ms then sums the bracketed launches only;
  * gv_profile_samples tells how many there were per kind since gv_stats_reset (divide by those, not by launches). */
 int gv_profile_sampling(GvCtx* ctx, uint32_t every);
+/* Which kernel kinds are bracketed from now on: bit k = GvKernelId k (0: none). gv_create derives the initial mask from the
+ * config flags (PROFILE_EVENTS: all, + PROFILE_CULL_ONLY: GV_K_CULL); bench.py keeps the timed region on the dominant
+ * kernel and takes the per-kernel breakdown of a frame from a few extra frames outside it. */
+int gv_profile_kernels(GvCtx* ctx, uint32_t kernel_mask);
 int gv_profile_samples(GvCtx* ctx, uint64_t samples[GV_K_COUNT]);
 
 /* Measurement aid (bench.py `roofline.measured_stream_peak`): `launches` read-only passes over the five input streams

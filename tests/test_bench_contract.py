@@ -34,6 +34,9 @@ def test_bench_prints_one_json_line(exchange):
         assert set(("value", "unit", "cores", "kind", "sample", "pyramid_ms", "cull_ms", "cull_culls_per_s")) <= set(d["cpu_baseline"])
     assert d["parity"]["visible_set_bit_identical"] and d["config"]["workload"].startswith("cfg3")
     assert (d["config"]["exchange"] is not None) == exchange
+    # every kernel of a frame, measured outside the timed region; the timed region brackets the dominant kernel only
+    assert set(("cull", "emit", "hiz")) <= set(d["config"]["frame_kernel_ms"]) and set(d["config"]["kernel_ms"]) == {"cull"}
+    assert d["value_with_block_bounds"] == d["config"]["block_bounds_variant"]["value"]
 
 
 @pytest.mark.gpu
@@ -54,6 +57,56 @@ def test_bench_gpus_2_starts_its_own_ranks(mode):
     assert d["config"]["exchange"] is not None and d["config"]["exchange_mode"] == mode
     assert d["parity"]["visible_set_bit_identical"] and d["parity"]["baked_model_bit_identical"]
     assert d["config"]["same_frames_without_exchange"]["value"] > 0
+    # the compacted index list is what travels by default (BASELINE.json's north_star); the bit shards are a timed variant
+    assert d["config"]["exchange_payload"] == "indices" and "uint32 indices" in d["config"]["exchange"]
+    assert d["config"]["mask_variant"]["checked_against_exact_allgatherv"] and d["config"]["mask_variant"]["ms_per_step"] > 0
+    assert d["parity"]["checked_ranks"] == 2 and len(d["parity"]["visible_by_rank"]) == 2
+
+
+def _run_bench(argv, env_extra, timeout=1500):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[:2000]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_every_field_of_the_scaling_line():
+    """The line the first 8-GPU run will print, with 8 ranks sharing this box's one GPU over gloo (functional, never a
+    measurement): the default workload is cfg5's shape, the compacted index lists travel, every rank's tile is checked against
+    the oracle, and the line carries n1_same_workload / scaling_efficiency / exchange_ms / shard bytes / the bit-shard variant."""
+    d = _run_bench(["--gpus", "8", "--entities", "200000", "--steps", "4", "--warmup", "1"], {"GV_BENCH_BACKEND": "gloo"})
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and c["workload"].startswith("cfg5") and c["entities_total"] == 1_600_000
+    assert c["exchange_payload"] == "indices" and c["exchange_mode"] == "allgather"
+    assert d["n1_same_workload"]["value"] > 0 and d["n1_same_workload"]["entities"] == 200000
+    assert 0 < d["scaling_efficiency"] < 1.5
+    assert abs(d["scaling_efficiency"] - d["value"] / (8 * d["n1_same_workload"]["value"])) < 1e-9
+    assert c["exchange_ms"] > 0 and c["exchange_overhead_ms_per_step"] is not None
+    assert len(c["shard_bytes_per_rank"]) == 8 and len(c["list_bytes_per_rank"]) == 8 and c["gathered_bytes_per_rank"] == sum(c["shard_bytes_per_rank"])
+    assert all(s >= l for s, l in zip(c["shard_bytes_per_rank"], c["list_bytes_per_rank"]))  # padded shards hold the lists
+    assert len(c["same_frames_without_exchange"]["ms_per_step_by_rank"]) == 8
+    assert c["mask_variant"]["checked_against_exact_allgatherv"] and len(c["mask_variant"]["shard_bytes_per_rank"]) == 8
+    par = d["parity"]
+    assert par["checked_ranks"] == 8 and par["checked_entities"] == 1_600_000 and len(par["visible_by_rank"]) == 8
+    assert par["visible_set_bit_identical"] and par["is_visible_identical"] and par["baked_model_bit_identical"]
+    assert sum(par["visible_by_rank"]) == par["visible"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_strong_scaling_cuts_one_world(ranks):
+    """--scaling strong: --entities-total is the WORLD; N ranks take total / N each (N = 1: all of it, same workload name)."""
+    argv = ["--gpus", str(ranks), "--scaling", "strong", "--entities-total", "600000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    d = _run_bench(argv, {"GV_BENCH_BACKEND": "gloo"} if ranks > 1 else {})
+    assert d["scaling"] == "strong" and d["n_gpus"] == ranks
+    assert d["config"]["entities_total"] == 600000 and d["config"]["entities_per_gpu"] == 600000 // ranks
+    assert d["config"]["workload"].startswith("cfg5-strong") and d["parity"]["visible_set_bit_identical"]
+    assert (d["n1_same_workload"] is not None) == (ranks > 1)
 
 
 @pytest.mark.gpu
@@ -75,4 +128,5 @@ def test_bench_mask_payload(ranks):
     assert len(lines) == 1, p.stdout[:2000]
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["config"]["exchange_payload"] == "mask" and "one bit per mirror entry" in d["config"]["exchange"]
+    assert d["config"]["mask_variant"] is None  # the variant is only timed beside the index lists
     assert d["parity"]["visible_set_bit_identical"] and "error" not in d
