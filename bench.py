@@ -323,7 +323,8 @@ def main():
     # hipEvents bracket only the dominant kernel inside the timed region (each event record costs ~2 us of
     # stream time); --profile-all brackets every kernel for the per-kernel breakdown in config.kernel_ms
     vis = GpuVisibility(device=local_rank, profile_events=args.profile_all, profile_cull_only=not args.profile_all,
-                        block_bounds=args.block_bounds, hiz_rg16f=args.hiz_rg16f)
+                        block_bounds=args.block_bounds, hiz_rg16f=args.hiz_rg16f,
+                        linear_scan=not args.block_bounds)  # the headline is the flat loop SURVEY.md §8d prices (mesh.cpp:137-175)
     t_up = time.perf_counter()
     vis.bind_transforms(sc.transforms, sc.entity_to_transform)
     vis.bind_pool(0, sc.meshes)
@@ -413,20 +414,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_steps(run, steps):
-        """Wall clock over `steps` frames between two fences (the contract's number) + one event per frame boundary on
-        the library's stream (K + 1 records: the per-frame durations behind the median)."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    def timed_steps(run, steps, group=1):
+        """Wall clock over `steps` frames between two fences (the contract's number) + one event per `group` frames on the
+        library's stream (the durations behind the median). An event record is not free: the stream drains in front of it,
+        ~6 us per record on MI355X (rocprofv3 shows the gap in front of the next kernel) — one per FRAME was 4 % of the cfg3
+        frame, so the timed region marks every `group`-th frame boundary only."""
+        bounds = list(range(0, steps, max(1, group))) + [steps]
+        marks = {k: torch.cuda.Event(enable_timing=True) for k in bounds}
         fence()
         t0 = time.perf_counter()
         last = None
         marks[0].record(lib_stream)
         for k in range(steps):
             last = run()
-            marks[k + 1].record(lib_stream)
+            if k + 1 in marks:
+                marks[k + 1].record(lib_stream)
         fence()
         elapsed = time.perf_counter() - t0
-        per = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(steps)], dtype=np.float64)  # ms
+        per = np.array([marks[a].elapsed_time(marks[b]) / (b - a) for a, b in zip(bounds[:-1], bounds[1:])], dtype=np.float64)  # ms per frame
         return elapsed, per, last
 
     gathered_total = None
@@ -496,11 +501,12 @@ def main():
     fence()
     upload_bytes = vis.stats()["upload_bytes"]
     vis.stats_reset()
-    # A bracket is two event packets = ~5 us of stream time per launch (0.164 vs 0.159 ms per frame): the dominant kernel is
-    # timed on every fourth frame of the timed region (>= 5 launches), so that the region is the frame, not its instrumentation
-    sample_every = 1 if args.profile_all else max(1, min(4, args.steps // 5))
+    # A bracket around a kernel is two event records = ~12 us of stream time (the stream drains in front of each): the dominant
+    # kernel is bracketed on 4-5 frames of the timed region, so that the region is the frame, not its instrumentation
+    sample_every = 1 if args.profile_all else max(1, args.steps // 4)
     vis.profile_sampling(sample_every)
-    elapsed, per_step_ms, last = timed_steps(step, args.steps)
+    mark_group = max(1, args.steps // 5)
+    elapsed, per_step_ms, last = timed_steps(step, args.steps, mark_group)
     st = vis.stats()
     timed = vis.profile_samples()
     vis.profile_sampling(1)
@@ -546,7 +552,7 @@ def main():
     if exchange:
         for _ in range(3):
             compute()
-        e2, per2, _ = timed_steps(compute, args.steps)
+        e2, per2, _ = timed_steps(compute, args.steps, mark_group)
         per_rank_ms = every_rank(e2 / args.steps * 1e3)
         e2 = max_over_ranks(e2)
         no_exchange = dict(ms_per_step=e2 / args.steps * 1e3, value=n * world * args.steps / e2,
@@ -574,7 +580,7 @@ def main():
                 ex[0] = make_exchange("mask")
                 for _ in range(3):
                     step()
-                e3, per3, last3 = timed_steps(step, args.steps)
+                e3, per3, last3 = timed_steps(step, args.steps, mark_group)
                 mv_problem = check_padded(last3, exact, exact_counts)
                 e3 = max_over_ranks(e3)
                 mask_variant = dict(ms_per_step=e3 / args.steps * 1e3, value=n * world * args.steps / e3,
@@ -623,11 +629,12 @@ def main():
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
 
-    # Same workload through GV_CONFIG_BLOCK_BOUNDS (opt-in: conservative workgroup-level frustum rejection, same
-    # results). Reported beside the headline, never as `value`: the headline stays the linear scan SURVEY.md §8d prices.
+    # Same workload as the library runs it BY DEFAULT (round 3): block bounds — conservative workgroup-level frustum and Hi-Z
+    # rejection, same results — for pools above 262144 slots. Reported beside the headline (`value_with_block_bounds`), never as
+    # `value`: the headline stays the linear scan SURVEY.md §8d prices (GV_CONFIG_LINEAR_SCAN).
     bounds_variant = None
     if world == 1 and not args.block_bounds and not (wl["sweep"] and args.sweep.startswith("fused")):
-        vb = GpuVisibility(device=local_rank, profile_cull_only=True, block_bounds=True)
+        vb = GpuVisibility(device=local_rank, profile_cull_only=True, block_bounds=n <= 262144)
         vb.bind_transforms(sc.transforms, sc.entity_to_transform)
         vb.bind_pool(0, sc.meshes)
         vb.hierarchy_rebuild()
@@ -645,17 +652,18 @@ def main():
             bounded_step()
         vb.wait()
         vb.stats_reset()
+        vb.profile_sampling(8)  # (a bracket costs ~12 us of stream time: a few of the 30 frames)
         frames, t2 = 30, time.perf_counter()
         for _ in range(frames):
             bounded_step()
         vb.wait()
         dt = time.perf_counter() - t2
-        sb = vb.stats()
+        sb, tb = vb.stats(), vb.profile_samples()
         gb = vb.fetch(0, write_back=False, occupancy=n)
         same = bool(np.array_equal(gb["visible_idx"], got["visible_idx"]) and np.array_equal(gb["is_visible"], got["is_visible"])
                     and np.array_equal(gb["baked_model"].view(np.uint32), got["baked_model"].view(np.uint32)))
         bounds_variant = dict(ms_per_step=dt / frames * 1e3, value=n * frames / dt,
-                              cull_kernel_ms=sb["device_ms"]["cull"] / max(1, sb["launches"]["cull"]),
+                              cull_kernel_ms=sb["device_ms"]["cull"] / max(1, tb["cull"]),
                               examined_workgroup_fraction=sb["bounds_blocks_examined"] / max(1, sb["bounds_blocks_total"]),
                               outputs_identical_to_headline=same)
         vb.close()
@@ -762,7 +770,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            # per-frame durations from one hipEvent per frame boundary on the library's stream (rank 0)
+            # from one hipEvent per `frames_per_mark` frame boundaries on the library's stream (rank 0): median / min / max of the
+            # groups' per-frame means (an event per frame costs ~6 us of stream time per frame: not in the timed region)
+            "frames_per_mark": mark_group,
             "ms_per_step_median": median_ms, "ms_per_step_min": float(per_step_ms.min()), "ms_per_step_max": float(per_step_ms.max()),
             "value_at_median_step": n * world / (median_ms * 1e-3),
             # N > 1: ONE GPU on ONE tile of this same workload (these ranks' frames without the exchange step, slowest rank) and

@@ -273,7 +273,9 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
     BlockBounds bounds;
     bool use_bounds = false;
-    if ((ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) && p.occupancy != 0 && !fused) {
+    const bool bounds_wanted = (ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) ||
+                               (!(ctx->config.flags & GV_CONFIG_LINEAR_SCAN) && p.occupancy > kAutoBoundsMinSlots);
+    if (bounds_wanted && p.occupancy != 0 && !fused) {
         const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
         if (!current && !(changed && p.changed_prev)) {
@@ -290,7 +292,15 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         p.seen_epoch = p.epoch;
         p.seen_xf_epoch = ctx->xf_epoch;
         if (current) {
-            GV_HIP(ctx, ctx->d_examined.reserve((p.occupancy + kCullBlock - 1) / kCullBlock));
+            const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
+            GV_HIP(ctx, ctx->d_examined.reserve(nb));
+            const size_t list_words = 4 + nb * (cull_list_entry_bytes() / sizeof(uint32_t));
+            GV_HIP(ctx, p.d_kept_flag.reserve(nb));
+            if (list_words > p.d_kept.cap) {
+                GV_HIP(ctx, p.d_kept.reserve(list_words));
+                GV_HIP(ctx, hipMemsetAsync(p.d_kept.ptr, 0, 2 * sizeof(uint32_t), ctx->stream));
+                p.kept_parity = 0;
+            }
             use_bounds = true;
         }
     }
@@ -359,9 +369,17 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
             if (!batched) {
                 KernelTimer t(ctx, GV_K_CULL);
+                // bounds: classify the workgroups first and cull the kept ones from a list (GV_DEBUG_BOUNDS_IN_KERNEL: the
+                // round-2 form, every workgroup tests its own box inside the cull kernel)
+                static const bool listed = getenv("GV_DEBUG_BOUNDS_IN_KERNEL") == nullptr;
                 if (fused && v == 0)
                     GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
-                else {
+                else if (use_bounds && listed) {
+                    uint32_t* counters = p.d_kept.ptr;
+                    GV_HIP(ctx, launch_cull_listed(mesh, xf, hz, cvps[v], vbs[v], bounds, counters + p.kept_parity, counters + (p.kept_parity ^ 1u),
+                                                   counters + 4, p.d_kept_flag.ptr, ctx->stream));
+                    p.kept_parity ^= 1u;
+                } else {
                     GV_HIP(ctx, launch_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
                 }
             }
@@ -803,7 +821,7 @@ void gv_destroy(GvCtx* ctx)
     for (auto& p : ctx->pools) {
         for (auto& target : p.record_target)
             release_record_target(target);
-        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release(); p.d_kept.release(); p.d_kept_flag.release();
     }
     for (auto& per_pool : ctx->views)
       for (auto& v : per_pool) {

@@ -39,8 +39,17 @@ struct DeviceBuf {  // grow-only device allocation (scratch vectors grow, never 
         ptr = nullptr;
         cap = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
-        if (e == hipSuccess)
+        if (e == hipSuccess) {
             cap = n;
+            // GV_DEBUG_POISON: fresh device memory is filled with a pattern instead of whatever (often zeros) the allocator hands
+            // out, so that a kernel that reads what nobody wrote fails every time, not once in a long session
+            static const bool poison = getenv("GV_DEBUG_POISON") != nullptr;
+            if (poison) {  // (the fill must have landed before any stream touches the buffer: hipMemset alone may still be in flight)
+                e = hipMemset(ptr, 0xCD, n * sizeof(T));
+                if (e == hipSuccess)
+                    e = hipDeviceSynchronize();
+            }
+        }
         return e;
     }
     // like reserve, but the first `keep` elements survive (pool growth: the mirror is appended to, not rebuilt);
@@ -190,6 +199,9 @@ struct PoolState {
     uint32_t index_map_count = 0;     // 0: none
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    DeviceBuf<uint32_t> d_kept;    // [2 alternating counters, 2 words of padding | list entries] of launch_cull_listed
+    DeviceBuf<uint8_t> d_kept_flag;  // per list entry (Hi-Z views)
+    uint32_t kept_parity = 0;      // which counter the next classify launch adds into
     uint32_t mirrored = 0, appended = 0;  // entries the mirror holds / of those, appended (unsorted) since the last full build
     uint64_t epoch = 1, bounds_epoch = 0, bounds_xf_epoch = 0;  // epoch: bumped whenever this pool's mirror changes
     uint64_t seen_epoch = 0, seen_xf_epoch = 0;                 // state at this pool's previous gv_cull

@@ -61,6 +61,99 @@ __device__ __forceinline__ bool block_behind_frustum(const float4 lo, const floa
     return block_behind_planes(lo, hi, view.planes, view.plane_count, view.cam, max_depth);
 }
 
+// Block-level Hi-Z: true when EVERY candidate of the workgroup would be found occluded by its own query (hiz_occluded), so the
+// workgroup can skip its streams like one behind a frustum plane. Called by all 256 lanes (workgroup-uniform arguments).
+//
+// An entity e is occluded iff zNear_e < zFar_e, zNear_e = max z/w over its 8 corners, zFar_e = min over the <= 2x2 texels
+// that cover its pixel rect R_e at its level L_e. For the block:
+//   * the box [lo, hi] holds every corner of every candidate (world space); inflated by the rounding margin of
+//     block_behind_planes it also holds them as the per-frame arithmetic computes them (camera-relative products, fma order), and
+//     the margin's effect on every projected quantity (>= 1e-7 relative: margin >= 0.01, w <= 1e5) dominates the fp32 rounding
+//     of both evaluations. x/w, y/w, z/w are monotone along any segment with w > 0, so their extrema over the box are at its
+//     corners: zNear_b = max z/w >= zNear_e, and the block's pixel rect R_b (one more pixel each way) contains every R_e;
+//     a box that reaches w <= 0 is never tested (its entities may take the "cannot bound: visible" exit).
+//   * lo.w = the largest sphere reach r of the block's candidates (block_bounds_kernel): two corners of one entity differ by
+//     <= 2 r in L1, so its rect spans at most n_max pixels (below) and its level is at most L_max = floor(log2 n_max) + 1.
+//   * at any level L_b >= L_max of a NESTED pyramid every texel of level L_e <= L_b that touches R_e lies inside a level-L_b texel
+//     that touches R_b, and a texel's min bounds everything under it: zFar_b = min over ALL level-L_b texels touching R_b <= zFar_e.
+//   So zNear_b < zFar_b  =>  zNear_e <= zNear_b < zFar_b <= zFar_e for every candidate: all occluded. L_b is also raised until R_b
+//   spans <= 16 x 16 texels: one texel per lane, one reduction. A NaN texel (an entity's own compare would fail on it) or any
+//   non-finite intermediate declines the shortcut.
+__device__ __forceinline__ bool block_occluded(const HizDevice& hz, const ViewParams& view, const float4 lo, const float4 hi,
+                                               uint32_t max_depth, float* wave_min /* LDS [kCullBlock / 64] */)
+{
+    if (!hz.nested)
+        return false;
+    const float (&vp)[16] = view.vp;
+    const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
+                      fabsf(view.cam[0]) + fabsf(view.cam[1]) + fabsf(view.cam[2]);
+    const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
+    const float bx[2] = {lo.x - view.cam[0] - margin, hi.x - view.cam[0] + margin};
+    const float by[2] = {lo.y - view.cam[1] - margin, hi.y - view.cam[1] + margin};
+    const float bz[2] = {lo.z - view.cam[2] - margin, hi.z - view.cam[2] + margin};
+    const float inf = __builtin_huge_valf();
+    float nx0 = inf, nx1 = -inf, ny0 = inf, ny1 = -inf, znear = -inf, wmin = inf;
+    bool bounded = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x = bx[k & 1], y = by[(k >> 1) & 1], z = bz[k >> 2];
+        const float clx = fmaf(vp[0], x, fmaf(vp[4], y, fmaf(vp[8], z, vp[12])));
+        const float cly = fmaf(vp[1], x, fmaf(vp[5], y, fmaf(vp[9], z, vp[13])));
+        const float clz = fmaf(vp[2], x, fmaf(vp[6], y, fmaf(vp[10], z, vp[14])));
+        const float clw = fmaf(vp[3], x, fmaf(vp[7], y, fmaf(vp[11], z, vp[15])));
+        bounded = bounded && (clw > 0.0f);
+        const float rcp = 1.0f / clw;
+        const float ndx = clx * rcp, ndy = cly * rcp, ndz = clz * rcp;
+        nx0 = fminf(nx0, ndx); nx1 = fmaxf(nx1, ndx);
+        ny0 = fminf(ny0, ndy); ny1 = fmaxf(ny1, ndy);
+        znear = fmaxf(znear, ndz);
+        wmin = fminf(wmin, clw);
+    }
+    if (!bounded)
+        return false;
+    // the largest pixel extent one candidate's rect can have, from its reach r: |x1/w1 - x2/w2| <= (|x1 - x2| + |x2/w2| |w2 - w1|) / w1
+    const float r = lo.w;
+    const float r0 = fmaxf(fmaxf(fabsf(vp[0]), fabsf(vp[4])), fabsf(vp[8])), r1 = fmaxf(fmaxf(fabsf(vp[1]), fabsf(vp[5])), fabsf(vp[9]));
+    const float r3 = fmaxf(fmaxf(fabsf(vp[3]), fabsf(vp[7])), fabsf(vp[11]));
+    const float span = 2.0f * r / wmin;
+    const float ext_x = 0.5f * (float)hz.width * span * fmaf(fmaxf(fabsf(nx0), fabsf(nx1)), r3, r0) + 3.0f;
+    const float ext_y = 0.5f * (float)hz.height * span * fmaf(fmaxf(fabsf(ny0), fabsf(ny1)), r3, r1) + 3.0f;
+    const float n_max = fmaxf(ext_x, ext_y);
+    if (!(n_max < 32768.0f))  // also NaN / inf (a box or reach that is not finite)
+        return false;
+    const uint32_t l_max = (31u - (uint32_t)__clz((int)n_max)) + 1u;  // n_max >= 3
+    const int W = (int)hz.width, H = (int)hz.height;
+    const float umin = clamp01(fmaf(nx0, 0.5f, 0.5f)), umax = clamp01(fmaf(nx1, 0.5f, 0.5f));
+    const float vmin = clamp01(fmaf(ny0, 0.5f, 0.5f)), vmax = clamp01(fmaf(ny1, 0.5f, 0.5f));
+    const int ix0 = max((int)(umin * (float)W) - 1, 0), ix1 = min((int)(umax * (float)W) + 1, W - 1);
+    const int iy0 = max((int)(vmin * (float)H) - 1, 0), iy1 = min((int)(vmax * (float)H) + 1, H - 1);
+    uint32_t level = min(l_max, hz.mip_count - 1u);
+    while (level + 1u < hz.mip_count && (((ix1 >> level) - (ix0 >> level)) > 15 || ((iy1 >> level) - (iy0 >> level)) > 15))
+        level++;
+    const int lw = max(W >> level, 1), lh = max(H >> level, 1);
+    const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
+    const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
+    if (tx1 - tx0 > 15 || ty1 - ty0 > 15)  // (only when the top level is wider than 16 texels: cannot happen for a full pyramid)
+        return false;
+    const int tx = tx0 + (int)(threadIdx.x & 15u), ty = ty0 + (int)(threadIdx.x >> 4);
+    float t = inf;
+    if (tx <= tx1 && ty <= ty1)
+        t = hiz_min_texel(hz, level, (uint32_t)lw, (uint32_t)tx, (uint32_t)ty);
+    const bool nan = t != t;
+    float m = nan ? inf : t;
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1)
+        m = fminf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63u) == 0)
+        wave_min[threadIdx.x >> 6] = m;
+    const int any_nan = __syncthreads_or(nan ? 1 : 0);
+    float zfar = wave_min[0];
+#pragma unroll
+    for (uint32_t w = 1; w < kCullBlock / 64; w++)
+        zfar = fminf(zfar, wave_min[w]);
+    return !any_nan && fmaf(fabsf(znear), 2e-6f, znear) < zfar;
+}
+
 // The per-entity work of one 256-entry workgroup `lb`.
 template <bool HIZ, uint32_t MAP>
 __device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, uint32_t* wave_count)
@@ -126,7 +219,11 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
         const bool empty = lo.x > hi.x;  // no candidate at all (+inf / -inf)
-        const bool skip = empty || block_behind_frustum(lo, hi, args.view, args.xf.max_depth);
+        bool skip = empty || block_behind_frustum(lo, hi, args.view, args.xf.max_depth);
+        if (HIZ && !skip) {  // inside the frustum: is the whole box behind what the pyramid holds over its footprint?
+            __shared__ float wave_min[kCullBlock / 64];
+            skip = block_occluded(args.hiz, args.view, lo, hi, args.xf.max_depth, wave_min);
+        }
         if (threadIdx.x == 0)  // statistics: a plain store per workgroup (a shared counter would serialise ~10^4 atomics)
             args.bounds.examined[lb] = skip ? 0 : 1;
         if (skip) {
@@ -139,6 +236,269 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
     }
     cull_block<HIZ, MAP>(args, lb, wave_count);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Block bounds as two launches (round 3): classify, then cull the kept workgroups only.
+// Inside the cull kernel the block tests are a latency chain in front of every workgroup (box load -> 8 projections ->
+// texel loads -> reduction) and 30 k skipped workgroups are still 30 k dispatches: with every frustum-surviving workgroup
+// found occluded the bounded kernel still took 60 us (tools/block_hiz_probe.py). block_classify_kernel runs the same two
+// frustum test with ONE LANE per 256-entry block (block_classify_kernel: 5 us at 39 k blocks), lists the survivors (one atomic per
+// wave of 64 blocks) and, for a Hi-Z view, the texel window of each; block_window_kernel then reads every listed window with one
+// WAVE per block (a lane walking its own window measured 66 us, a wave per block for the whole test 25 us: the launch-to-decision
+// chain was paid 39 k times); cull_list_kernel runs the per-entity path of the listed blocks that were not proven occluded.
+// Skipped blocks get their outputs (zero ballot words; zero isVisible bytes when the cull owns them) from whichever launch
+// decides them. Same tests, same outputs.
+// ------------------------------------------------------------------------------------------------
+// What block_occluded needs from the block's box for one view, worked out by ONE LANE (block_classify_kernel runs a lane per
+// block): the texel window (level, first texel, extent <= 16 x 16) and the box's nearest depth. level 0xFF: the block cannot
+// be tested (pyramid not nested, box reaches w <= 0, non-finite, window too large) and is kept.
+struct BlockWindow {
+    uint32_t block;   // the 256-entry block
+    uint32_t level;   // | (tx1 - tx0) << 8 | (ty1 - ty0) << 12
+    uint32_t origin;  // tx0 | ty0 << 16
+    float znear;      // already widened by its rounding allowance
+};
+__device__ __forceinline__ BlockWindow block_window(const HizDevice& hz, const ViewParams& view, const float4 lo, const float4 hi,
+                                                    uint32_t max_depth, uint32_t lb)
+{
+    BlockWindow out{lb, 0xFFu, 0u, 0.0f};
+    if (!hz.nested)
+        return out;
+    const float (&vp)[16] = view.vp;
+    const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
+                      fabsf(view.cam[0]) + fabsf(view.cam[1]) + fabsf(view.cam[2]);
+    const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
+    const float bx[2] = {lo.x - view.cam[0] - margin, hi.x - view.cam[0] + margin};
+    const float by[2] = {lo.y - view.cam[1] - margin, hi.y - view.cam[1] + margin};
+    const float bz[2] = {lo.z - view.cam[2] - margin, hi.z - view.cam[2] + margin};
+    const float inf = __builtin_huge_valf();
+    float nx0 = inf, nx1 = -inf, ny0 = inf, ny1 = -inf, znear = -inf, wmin = inf;
+    bool bounded = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x = bx[k & 1], y = by[(k >> 1) & 1], z = bz[k >> 2];
+        const float clx = fmaf(vp[0], x, fmaf(vp[4], y, fmaf(vp[8], z, vp[12])));
+        const float cly = fmaf(vp[1], x, fmaf(vp[5], y, fmaf(vp[9], z, vp[13])));
+        const float clz = fmaf(vp[2], x, fmaf(vp[6], y, fmaf(vp[10], z, vp[14])));
+        const float clw = fmaf(vp[3], x, fmaf(vp[7], y, fmaf(vp[11], z, vp[15])));
+        bounded = bounded && (clw > 0.0f);
+        const float rcp = 1.0f / clw;
+        const float ndx = clx * rcp, ndy = cly * rcp, ndz = clz * rcp;
+        nx0 = fminf(nx0, ndx); nx1 = fmaxf(nx1, ndx);
+        ny0 = fminf(ny0, ndy); ny1 = fmaxf(ny1, ndy);
+        znear = fmaxf(znear, ndz);
+        wmin = fminf(wmin, clw);
+    }
+    if (!bounded)
+        return out;
+    const float r = lo.w;
+    const float r0 = fmaxf(fmaxf(fabsf(vp[0]), fabsf(vp[4])), fabsf(vp[8])), r1 = fmaxf(fmaxf(fabsf(vp[1]), fabsf(vp[5])), fabsf(vp[9]));
+    const float r3 = fmaxf(fmaxf(fabsf(vp[3]), fabsf(vp[7])), fabsf(vp[11]));
+    const float span = 2.0f * r / wmin;
+    const float ext_x = 0.5f * (float)hz.width * span * fmaf(fmaxf(fabsf(nx0), fabsf(nx1)), r3, r0) + 3.0f;
+    const float ext_y = 0.5f * (float)hz.height * span * fmaf(fmaxf(fabsf(ny0), fabsf(ny1)), r3, r1) + 3.0f;
+    const float n_max = fmaxf(ext_x, ext_y);
+    if (!(n_max < 32768.0f))
+        return out;
+    const uint32_t l_max = (31u - (uint32_t)__clz((int)n_max)) + 1u;
+    const int W = (int)hz.width, H = (int)hz.height;
+    const float umin = clamp01(fmaf(nx0, 0.5f, 0.5f)), umax = clamp01(fmaf(nx1, 0.5f, 0.5f));
+    const float vmin = clamp01(fmaf(ny0, 0.5f, 0.5f)), vmax = clamp01(fmaf(ny1, 0.5f, 0.5f));
+    const int ix0 = max((int)(umin * (float)W) - 1, 0), ix1 = min((int)(umax * (float)W) + 1, W - 1);
+    const int iy0 = max((int)(vmin * (float)H) - 1, 0), iy1 = min((int)(vmax * (float)H) + 1, H - 1);
+    uint32_t level = min(l_max, hz.mip_count - 1u);
+    while (level + 1u < hz.mip_count && (((ix1 >> level) - (ix0 >> level)) > 15 || ((iy1 >> level) - (iy0 >> level)) > 15))
+        level++;
+    const int lw = max(W >> level, 1), lh = max(H >> level, 1);
+    const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
+    const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
+    if (tx1 - tx0 > 15 || ty1 - ty0 > 15)
+        return out;
+    out.level = level | ((uint32_t)(tx1 - tx0) << 8) | ((uint32_t)(ty1 - ty0) << 12);
+    out.origin = (uint32_t)tx0 | ((uint32_t)ty0 << 16);
+    out.znear = fmaf(fabsf(znear), 2e-6f, znear);
+    return out;
+}
+
+struct ClassifyArgs {
+    BlockBounds bounds;
+    HizDevice hiz;
+    ViewParams view;
+    unsigned long long* mask;   // the view's ballot words: zeroed for the skipped blocks
+    uint8_t* is_visible;        // the view's bytes: zeroed for the skipped blocks when view.write_is_visible
+    uint32_t* kept_count;       // this launch's counter (zero on entry)
+    BlockWindow* kept;          // the frustum-surviving blocks, ascending within a wave's 64 blocks, waves in order of arrival
+    uint8_t* kept_flag;         // HIZ: per list entry, 1 = not proven occluded (written by block_window_kernel)
+    uint32_t nblocks, count, max_depth;
+};
+
+__device__ __forceinline__ void write_skipped_block(const ClassifyArgs& a, uint32_t lb)
+{
+    uint4* words = reinterpret_cast<uint4*>(a.mask + (size_t)lb * (kCullBlock / 64));  // 4 ballot words = 32 bytes
+    words[0] = make_uint4(0, 0, 0, 0);
+    words[1] = make_uint4(0, 0, 0, 0);
+    if (a.view.write_is_visible) {  // (only when no emit follows the cull: count-only main views)
+        const uint32_t first = lb * kCullBlock, end = min(first + kCullBlock, a.count);
+        for (uint32_t s = first; s < end; s++)
+            a.is_visible[s] = 0;
+    }
+}
+
+// launch 1: one LANE per 256-entry block, one wave per workgroup. Frustum test; the survivors go to the list (HIZ: with their
+// texel windows).
+template <bool HIZ>
+__global__ __launch_bounds__(64) void block_classify_kernel(const ClassifyArgs a)
+{
+    const uint32_t lb = blockIdx.x * 64u + threadIdx.x;
+    bool kept = false;
+    BlockWindow win{lb, 0xFFu, 0u, 0.0f};
+    if (lb < a.nblocks) {
+        const float4 lo = a.bounds.lo[lb], hi = a.bounds.hi[lb];
+        kept = !(lo.x > hi.x || block_behind_frustum(lo, hi, a.view, a.max_depth));
+        if (HIZ && kept)
+            win = block_window(a.hiz, a.view, lo, hi, a.max_depth, lb);
+        if (!HIZ || !kept)  // (HIZ survivors: decided by block_window_kernel)
+            a.bounds.examined[lb] = kept ? 1 : 0;
+        if (!kept)
+            write_skipped_block(a, lb);
+    }
+    const unsigned long long keep = __ballot(kept);
+    if (keep == 0ull)
+        return;
+    uint32_t base = 0;
+    if (threadIdx.x == 0)
+        base = atomicAdd(a.kept_count, (uint32_t)__popcll(keep));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (kept)
+        a.kept[base + (uint32_t)__popcll(keep & ((1ull << threadIdx.x) - 1ull))] = win;
+}
+
+// launch 2 (Hi-Z views): one WAVE per listed block reads its window, four texels per lane, and decides (block_occluded's test).
+__global__ __launch_bounds__(256) void block_window_kernel(const ClassifyArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t listed = *a.kept_count;
+    const float inf = __builtin_huge_valf();
+    for (uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6))); j < listed; j += waves) {
+        const BlockWindow w = a.kept[j];  // wave-uniform
+        bool occluded = false;
+        const uint32_t level = w.level & 0xFFu;
+        if (level != 0xFFu) {
+            const uint32_t dx = (w.level >> 8) & 15u, dy = (w.level >> 12) & 15u, tx0 = w.origin & 0xFFFFu, ty0 = w.origin >> 16;
+            const uint32_t lw = max(a.hiz.width >> level, 1u);
+            const uint32_t lx = lane & 15u;
+            float m = inf;
+            bool nan = false;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {  // all four loads in flight together
+                const uint32_t ly = (lane >> 4) + 4u * q;
+                float t = inf;
+                if (lx <= dx && ly <= dy)
+                    t = hiz_min_texel(a.hiz, level, lw, tx0 + lx, ty0 + ly);
+                nan = nan || t != t;
+                m = fminf(m, t);  // (a NaN is dropped here and reported through `nan`)
+            }
+#pragma unroll
+            for (uint32_t d = 32; d >= 1; d >>= 1)
+                m = fminf(m, __shfl_xor(m, d, 64));
+            occluded = __ballot(nan) == 0ull && w.znear < m;
+        }
+        if (lane == 0) {
+            a.kept_flag[j] = occluded ? 0 : 1;
+            a.bounds.examined[w.block] = occluded ? 0 : 1;
+        }
+        if (occluded) {
+            if (lane < kCullBlock / 64)
+                a.mask[(size_t)w.block * (kCullBlock / 64) + lane] = 0ull;
+            if (a.view.write_is_visible) {
+                const uint32_t slot = w.block * kCullBlock + 4u * lane;
+                if (slot + 3u < a.count)
+                    *reinterpret_cast<uint32_t*>(a.is_visible + slot) = 0u;
+                else
+                    for (uint32_t s = 0; slot + s < a.count && s < 4u; s++)
+                        a.is_visible[slot + s] = 0;
+            }
+        }
+    }
+}
+
+struct CullListArgs {
+    const uint32_t* kept_count;
+    const BlockWindow* kept;
+    const uint8_t* kept_flag;  // NULL: every listed block is culled (no Hi-Z block test)
+    uint32_t* next_count;      // the counter of the NEXT classify launch (the two alternate): cleared here
+};
+
+// last launch: the per-entity path of the listed blocks
+template <bool HIZ, uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void cull_list_kernel(const CullArgs args, const CullListArgs la)
+{
+    __shared__ uint32_t wave_count[kCullBlock / 64];
+    const uint32_t listed = *la.kept_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *la.next_count = 0;
+    for (uint32_t j = blockIdx.x; j < listed; j += gridDim.x) {  // workgroup-uniform trip count
+        if (la.kept_flag && !la.kept_flag[j])
+            continue;
+        cull_block<HIZ, MAP>(args, la.kept[j].block, wave_count);
+        __syncthreads();  // the LDS words are reused by the next block
+    }
+}
+
+hipError_t launch_cull_listed(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                              const ViewBuffers& out, const BlockBounds& bounds, uint32_t* kept_count, uint32_t* next_count,
+                              void* kept_list, uint8_t* kept_flag, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    const uint32_t nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    const bool window_test = vp.use_hiz && hiz.nested;
+    ClassifyArgs c{};
+    c.bounds = bounds;
+    c.hiz = hiz;
+    c.view = vp;
+    c.mask = out.mask;
+    c.is_visible = out.is_visible;
+    c.kept_count = kept_count;
+    c.kept = static_cast<BlockWindow*>(kept_list);
+    c.kept_flag = kept_flag;
+    c.nblocks = nblocks;
+    c.count = mesh.count;
+    c.max_depth = xf.max_depth;
+    // a quarter of the workgroups a flat launch has (behind a frustum test a quarter of the blocks is kept: one each; a view that
+    // keeps everything walks four per workgroup) — a launch of 39 k workgroups that mostly return at once costs 9 us of dispatch
+    const uint32_t list_grid = (nblocks + 3u) / 4u;
+    if (window_test) {
+        hipLaunchKernelGGL(block_classify_kernel<true>, dim3((nblocks + 63) / 64), dim3(64), 0, stream, c);
+        hipLaunchKernelGGL(block_window_kernel, dim3((list_grid + 3u) / 4u), dim3(256), 0, stream, c);
+    } else {
+        hipLaunchKernelGGL(block_classify_kernel<false>, dim3((nblocks + 63) / 64), dim3(64), 0, stream, c);
+    }
+    CullArgs a{};
+    a.mesh = mesh;
+    a.xf = xf;
+    a.hiz = hiz;
+    a.view = vp;
+    a.out = out;
+    a.nblocks = nblocks;
+    const CullListArgs la{kept_count, static_cast<const BlockWindow*>(kept_list), window_test ? kept_flag : nullptr, next_count};
+    const dim3 grid(list_grid), block(kCullBlock);
+#define GV_LAUNCH_LIST(HIZ)                                                                                              \
+    switch (mesh.mapping) {                                                                                             \
+    case kMapExact: hipLaunchKernelGGL((cull_list_kernel<HIZ, kMapExact>), grid, block, 0, stream, a, la); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_list_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a, la); break; \
+    default: hipLaunchKernelGGL((cull_list_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a, la); break;              \
+    }
+    if (vp.use_hiz) {
+        GV_LAUNCH_LIST(true)
+    } else {
+        GV_LAUNCH_LIST(false)
+    }
+#undef GV_LAUNCH_LIST
+    return hipGetLastError();
+}
+size_t cull_list_entry_bytes() { return sizeof(BlockWindow); }
 
 // ------------------------------------------------------------------------------------------------
 // K1 + K3 in one launch: cull, order-stable compaction and record emission of one view.
@@ -330,18 +690,23 @@ template <uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirror mesh, const TransformMirror xf,
                                                                   float4* __restrict__ out_lo, float4* __restrict__ out_hi)
 {
-    __shared__ float red[kCullBlock / 64][6];
+    __shared__ float red[kCullBlock / 64][7];
     const uint32_t lb = blockIdx.x;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float inf = __builtin_huge_valf();
     float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    float reach = 0.0f;  // the largest sphere reach of the workgroup's candidates (block_occluded: bounds an entity's pixel extent)
     if (i < mesh.count) {
         Mat34 m;
         Corners c;
+        float4 box_a;
+        float2 box_b;
         const float cam[3] = {0.0f, 0.0f, 0.0f};
-        if (prepare_slot<MAP>(mesh, xf, cam, i, m, c)) {
-            bool finite = true;
+        if (prepare_model<MAP>(mesh, xf, cam, i, m, box_a, box_b)) {
+            aabb_corners(m, box_a, box_b, c);
+            reach = sphere_reach(m, box_a, box_b);
+            bool finite = reach == reach;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float xs[2] = {c.x[k].x, c.x[k].y}, ys[2] = {c.y[k].x, c.y[k].y}, zs[2] = {c.z[k].x, c.z[k].y};
@@ -353,11 +718,13 @@ __global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirr
                     lo[2] = fminf(lo[2], zs[h]); hi[2] = fmaxf(hi[2], zs[h]);
                 }
             }
-            if (!finite)  // a member the box cannot bound: the workgroup is always examined
+            if (!finite) {  // a member the box cannot bound: the workgroup is always examined
                 for (int k = 0; k < 3; k++) {
                     lo[k] = -inf;
                     hi[k] = inf;
                 }
+                reach = inf;
+            }
         }
     }
 #pragma unroll
@@ -367,19 +734,26 @@ __global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirr
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], d, 64));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d, 64));
         }
-    if (lane == 0)
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1)
+        reach = fmaxf(reach, __shfl_xor(reach, d, 64));
+    if (lane == 0) {
         for (int k = 0; k < 3; k++) {
             red[wave][k] = lo[k];
             red[wave][3 + k] = hi[k];
         }
+        red[wave][6] = reach;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (uint32_t w = 1; w < kCullBlock / 64; w++)
+        for (uint32_t w = 1; w < kCullBlock / 64; w++) {
             for (int k = 0; k < 3; k++) {
                 red[0][k] = fminf(red[0][k], red[w][k]);
                 red[0][3 + k] = fmaxf(red[0][3 + k], red[w][3 + k]);
             }
-        out_lo[lb] = make_float4(red[0][0], red[0][1], red[0][2], 0.0f);
+            red[0][6] = fmaxf(red[0][6], red[w][6]);
+        }
+        out_lo[lb] = make_float4(red[0][0], red[0][1], red[0][2], red[0][6]);
         out_hi[lb] = make_float4(red[0][3], red[0][4], red[0][5], 0.0f);
     }
 }
@@ -756,7 +1130,9 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     // leaves after one load instead of walking the whole chain of dependent loads (ballot words -> prefix -> barrier -> ...):
     // the launch was bound by 9 768 workgroups taking turns at that chain, not by bytes. Workgroup 0 keeps its global duties.
     if (SELF && args.out.vis_flags && block != 0 && args.out.chunk_count[chunk] == 0) {  // workgroup-uniform
-        if (!args.view.write_is_visible || !args.out.vis_flags[block])
+        const bool dirty = args.view.write_is_visible && args.out.vis_flags[block];
+        __syncthreads();  // every wave has read the flag before thread 0 may clear it (a late wave would otherwise see "clean" and skip its stores)
+        if (!dirty)
             return;
         const uint32_t slot = chunk * kEmitChunk + part * (kEmitChunk / kEmitParts) + 4u * threadIdx.x;
         if (slot + 3u < args.mesh.count) {
@@ -765,7 +1141,8 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             for (uint32_t k = 0; slot + k < args.mesh.count; k++)
                 args.out.is_visible[slot + k] = 0;
         }
-        if (threadIdx.x == 0)
+        // (a quarter that reaches past the pool's end is never marked clean: the bytes behind the end may be a larger pool's)
+        if (threadIdx.x == 0 && chunk * kEmitChunk + (part + 1u) * (kEmitChunk / kEmitParts) <= args.mesh.count)
             args.out.vis_flags[block] = 0;
         return;
     }
@@ -821,8 +1198,10 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
                     args.out.is_visible[slot + k] = (uint8_t)((bytes >> (8u * k)) & 1u);
             }
         }
-        if (SELF && args.out.vis_flags && threadIdx.x == 0)  // does this quarter now hold a non-zero byte?
-            args.out.vis_flags[block] = prefix[(part + 1) * (64 / kEmitParts)] != prefix[part * (64 / kEmitParts)] ? 1 : 0;
+        if (SELF && args.out.vis_flags && threadIdx.x == 0)  // does this quarter now hold a non-zero byte (or bytes this pool does not reach)?
+            args.out.vis_flags[block] = prefix[(part + 1) * (64 / kEmitParts)] != prefix[part * (64 / kEmitParts)] ||
+                                                chunk * kEmitChunk + (part + 1u) * (kEmitChunk / kEmitParts) > args.mesh.count
+                                            ? 1 : 0;
     }
     uint32_t base;
     if (SELF) {

@@ -63,6 +63,8 @@ constexpr uint32_t kCullBlock = 256;   // slots per cull workgroup (4 waves)
 constexpr uint32_t kFusedEmitMaxSlots = 32768;  // pools up to this size cull + emit in one launch: the look-back chain costs
                                                 // ~16 ns per tile, so it only pays while a launch costs more (6.9 vs 9.8 us at 10 k
                                                 // slots, equal at 100 k, 64 vs 24 us at 1 M; profiles/r02i_fused_emit.txt)
+constexpr uint32_t kAutoBoundsMinSlots = 262144;  // pools above this size get block bounds unless GV_CONFIG_LINEAR_SCAN (smaller
+                                                  // ones are launch-bound and keep the one-launch / batched paths)
 constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
 constexpr uint32_t kEmitParts = 4;     // emit workgroups per chunk: 1024 slots = 16 ballot words each
 
@@ -99,13 +101,21 @@ struct ViewBuffers {
 // cull workgroup, built while the mirror is clean. A workgroup whose box lies behind one frustum plane by more than
 // the rounding margin skips its streams: every entity in it would have failed that plane in the per-entity test.
 struct BlockBounds {
-    const float4* lo = nullptr;   // xyz = min corner (+inf when the block has no candidate; -inf when a member is non-finite)
+    const float4* lo = nullptr;   // xyz = min corner (+inf when the block has no candidate; -inf when a member is non-finite);
+                                  // w = the largest sphere reach of its candidates (block_occluded; +inf likewise)
     const float4* hi = nullptr;   // xyz = max corner (-inf / +inf likewise)
     uint8_t* examined = nullptr;  // per workgroup: 1 = ran the per-entity path, 0 = skipped (statistics)
 };
 hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
+// Block bounds as classify (+ window test for Hi-Z views) + cull over the listed workgroups (two or three launches; same outputs
+// as launch_cull with bounds). kept_count / next_count: two alternating device counters (both zero before the first use; each
+// launch clears the other one for the next); kept_list: cull_list_entry_bytes() per workgroup; kept_flag: a byte per workgroup.
+size_t cull_list_entry_bytes();
+hipError_t launch_cull_listed(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
+                              const ViewBuffers& out, const BlockBounds& bounds, uint32_t* kept_count, uint32_t* next_count,
+                              void* kept_list, uint8_t* kept_flag, hipStream_t stream);
 // Cull + order-stable compaction + record emission of one view in ONE launch (decoupled look-back over the 256-entry
 // tiles; gv_cull.hip): same outputs as launch_cull + launch_emit except mask / chunk counts, which it does not produce.
 // status: one 64-bit word per tile (zero-initialised once, never cleared: words carry `epoch`); ticket: a running

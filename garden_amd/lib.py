@@ -23,6 +23,7 @@ GV_CONFIG_PROFILE_CULL_ONLY = 2
 GV_CONFIG_KEEP_SLOT_ORDER = 4
 GV_CONFIG_BLOCK_BOUNDS = 8
 GV_CONFIG_HIZ_RG16F = 16
+GV_CONFIG_LINEAR_SCAN = 32
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU, GV_SWEEP_INCREMENTAL = 0, 1, 2, 3, 4
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
@@ -228,7 +229,7 @@ class GpuVisibility:
     """One libgarden_vis context (one per process per GPU). Thin: every method is one C-ABI call."""
 
     def __init__(self, device=0, hiz_rule=GV_HIZ_RULE_REFERENCE, profile_events=False, profile_cull_only=False,
-                 keep_slot_order=False, block_bounds=False, hiz_rg16f=False):
+                 keep_slot_order=False, block_bounds=False, hiz_rg16f=False, linear_scan=False):
         self.lib = load()
         flags = GV_CONFIG_PROFILE_EVENTS if (profile_events or profile_cull_only) else 0
         if profile_cull_only:
@@ -239,6 +240,8 @@ class GpuVisibility:
             flags |= GV_CONFIG_BLOCK_BOUNDS
         if hiz_rg16f:
             flags |= GV_CONFIG_HIZ_RG16F
+        if linear_scan:
+            flags |= GV_CONFIG_LINEAR_SCAN
         cfg = GvConfig(C.sizeof(GvConfig), device, hiz_rule, flags)
         self.ctx = C.c_void_p()
         rc = self.lib.gv_create(C.byref(cfg), C.byref(self.ctx))

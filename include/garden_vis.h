@@ -62,10 +62,16 @@ typedef enum GvConfigFlags {
                                              outputs are reported in pool slots either way */
     GV_CONFIG_BLOCK_BOUNDS = 1u << 3,     /* keep a world-space box per 256-entry cull workgroup (built on the device
                                              while the pool's mirror is clean) and let a workgroup whose box lies behind
-                                             a frustum plane by more than the rounding margin skip its streams. Same
-                                             results bit for bit (the test is conservative w.r.t. the per-entity one);
-                                             pools that change every frame are culled without boxes. Pays off with the
-                                             default spatial mirror order. Batched views skip a workgroup when every view does */
+                                             a frustum plane by more than the rounding margin — or, for a Hi-Z view over a
+                                             nested pyramid, wholly behind what the pyramid holds over the box's footprint —
+                                             skip its streams. Same results bit for bit (both tests are conservative w.r.t. the
+                                             per-entity ones); pools that change every frame are culled without boxes. Pays
+                                             off with the default spatial mirror order. Batched views skip a workgroup when
+                                             every view does. DEFAULT for pools of more than 262144 slots (round 3); this flag
+                                             forces it for pools of every size (they then take neither the one-launch cull + emit
+                                             nor the batched tick) */
+    GV_CONFIG_LINEAR_SCAN = 1u << 5,      /* never use block bounds: every workgroup reads its streams (the flat loop of
+                                             mesh.cpp:137-175, which SURVEY.md §8d prices; bench.py's headline and roofline kernel) */
     GV_CONFIG_HIZ_RG16F = 1u << 4         /* keep the pyramid in the reference's image format (HizRenderSystem::bufferFormat =
                                              SfloatR16G16, render/hiz.hpp:41): levels >= 1 are binary16 (min, max) pairs, half the
                                              bytes. The reference lets the render target round to nearest, which can move a min

@@ -59,3 +59,12 @@ def gpu_bounds():
     vis = GpuVisibility(device=0, block_bounds=True)
     yield vis
     vis.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_linear():
+    """Context with GV_CONFIG_LINEAR_SCAN: every workgroup reads its streams whatever the pool's size (no block bounds)."""
+    from garden_amd.lib import GpuVisibility
+    vis = GpuVisibility(device=0, linear_scan=True)
+    yield vis
+    vis.close()

@@ -1523,3 +1523,22 @@ def test_mask_shard_is_the_visible_list_as_bits(oracle, n, keep_slot_order):
             with pytest.raises(RuntimeError) as e:
                 vis.copy_mask_device(0, shard.data_ptr(), words)
             assert "neither" in str(e.value)
+
+
+@pytest.mark.parametrize("bounds", [False, True])
+def test_is_visible_bytes_when_pools_of_different_sizes_share_a_context(oracle, bounds):
+    """Round 3: the emit kernel leaves an empty chunk alone when its isVisible bytes are known to be zeros (a flag per quarter
+    chunk). One context, pools of different sizes and contents bound in turn (what the tiles of a partitioned world do), sparse
+    and dense and empty views, count-only frames in between (there the cull writes the bytes itself): every byte is right."""
+    from garden_amd.lib import GpuVisibility
+    away = scene.main_camera_view(camera_position=(1e7, 1e7, 1e7))  # nothing visible
+    with GpuVisibility(device=0, block_bounds=bounds) as vis:
+        for n, seed in [(300_000, 1), (70_000, 2), (299_000, 3), (150_001, 4), (4097, 5), (300_000, 6), (40_000, 7)]:
+            sc = scene.flat_scene(n, seed=seed)
+            for view in (scene.main_camera_view(seed=seed), away, scene.main_camera_view(seed=seed + 100), dict(scene.main_camera_view(seed=seed), emit_records=0),
+                         scene.cascade_view(size=900.0, depth=4000.0, index=-1), away):
+                view = dict(view, shadow_pass=-1)
+                for got, got_vis, exp, exp_vis in run_both(vis, oracle, sc, [view]):
+                    assert got["draw_count"] == exp["draw_count"]
+                    assert np.array_equal(got_vis, exp_vis), (n, seed)
+                    assert np.array_equal(got["is_visible"], exp_vis)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--entities", type=int, default=2_000_000)
     ap.add_argument("--views", type=int, default=36)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--hiz-share", type=int, default=3, help="every N-th view is a perspective view with Hi-Z on (3: a third of the views; 1: all of them)")
     ap.add_argument("--depth", default="1024x512", help="frame size of the depth image, WxH (sizes not divisible by 64 take the any-size pyramid kernels)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -39,7 +40,7 @@ def main():
         side = 100.0 * sc.count ** (1 / 3)
         ctxs = []
         for bounds, rg16f in ((False, False), (True, False), (False, True)):
-            g = GpuVisibility(device=0, block_bounds=bounds, hiz_rg16f=rg16f)
+            g = GpuVisibility(device=0, block_bounds=bounds, hiz_rg16f=rg16f, linear_scan=not bounds)
             g.bind_transforms(sc.transforms, sc.entity_to_transform)
             g.bind_pool(0, sc.meshes)
             g.hierarchy_rebuild()
@@ -48,12 +49,12 @@ def main():
         for k in range(args.views):
             where = rng.normal(0, side * (0.05 if k % 2 else 0.6), 3)
             pos = tuple(float(x) for x in where.astype(np.float32))
-            if k % 3 == 2:
+            if k % 3 == 2 and args.hiz_share != 1:
                 v = scene.cascade_view(seed=int(rng.integers(1 << 30)), size=float(rng.uniform(0.02, 1.5) * side),
                                        depth=float(rng.uniform(0.5, 4) * side), index=k % 4)
                 v = dict(v, camera_position=np.asarray([*pos, 0.0], np.float32))
             else:
-                v = scene.main_camera_view(seed=int(rng.integers(1 << 30)), camera_position=pos, use_hiz=int(k % 3 == 1))
+                v = scene.main_camera_view(seed=int(rng.integers(1 << 30)), camera_position=pos, use_hiz=int(k % 3 == 1 or args.hiz_share == 1))
             scratch = sc.meshes.copy()
             exp = oracle.prepare_meshes(scratch, sc.transforms, sc.entity_to_transform, v,
                                         hiz=hz if v["use_hiz"] else None, threads=threads)
