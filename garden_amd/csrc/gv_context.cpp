@@ -489,6 +489,24 @@ int flush_culls(GvCtx* ctx)
     return GV_OK;
 }
 
+// A recorded cull (gv_cull_batch_begin) is launched with the pools' mirrors as they are at the FLUSH: a bind or a dirty mark
+// of a pool it reads, in between, would let it run on another occupancy than its view buffers were sized for. Such a call
+// therefore launches what has been recorded so far first; recording then goes on. pool: the mesh pool about to change, or
+// GV_MAX_POOLS for the transform pool (every recorded cull reads it). A frame that binds and culls its mesh systems one after
+// the other (the shim does) keeps its one batch: a system's bind does not touch the pools recorded before it.
+int flush_recorded_culls(GvCtx* ctx, uint32_t pool)
+{
+    bool reads_it = false;
+    for (const auto& j : ctx->cull_jobs)
+        reads_it = reads_it || pool == GV_MAX_POOLS || j.pool_id == pool;
+    if (!reads_it)
+        return GV_OK;
+    const bool batching = ctx->cull_batching;
+    const int rc = flush_culls(ctx);
+    ctx->cull_batching = batching;
+    return rc;
+}
+
 // gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
 static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 {
@@ -889,6 +907,8 @@ int gv_transform_bind_columns(GvCtx* ctx, const GvTransformColumns* columns, uin
         return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: NULL argument");
     if (occupancy >= kSlotNone)
         return ctx->fail(GV_E_ARG, "gv_transform_bind_columns: occupancy %u exceeds the 28-bit slot range", occupancy);
+    if (int rc = flush_recorded_culls(ctx, GV_MAX_POOLS))
+        return rc;
     const GvColumn* all[8] = {&columns->entity, &columns->parent, &columns->position, &columns->scale, &columns->rotation,
                               &columns->self_active, &columns->ancestors_active, &columns->model_with_ancestors};
     const uint32_t width[8] = {4, 4, 12, 12, 16, 1, 1, 1};
@@ -947,6 +967,8 @@ int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* colu
         return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: bad argument (pool_id %u)", pool_id);
     if (occupancy >= kSlotNone)
         return ctx->fail(GV_E_ARG, "gv_pool_bind_columns: occupancy %u exceeds the 28-bit slot range", occupancy);
+    if (int rc = flush_recorded_culls(ctx, pool_id))
+        return rc;
     const GvColumn* all[4] = {&columns->entity, &columns->is_enabled, &columns->aabb_min, &columns->aabb_max};
     const uint32_t width[4] = {4, 1, 12, 12};
     for (int k = 0; k < 4; k++)
@@ -976,6 +998,8 @@ int gv_pool_bind_ready(GvCtx* ctx, uint32_t pool_id, const void* data, uint32_t 
         return GV_E_ARG;
     if (pool_id >= GV_MAX_POOLS || (data && ((width != 1 && width != 4) || stride < width)))
         return ctx->fail(GV_E_ARG, "gv_pool_bind_ready: bad argument (pool %u, width %u, stride %u)", pool_id, width, stride);
+    if (int rc = flush_recorded_culls(ctx, pool_id))
+        return rc;
     PoolState& p = ctx->pools[pool_id];
     const bool had = p.ready.ptr != nullptr;
     p.ready = Column{static_cast<const uint8_t*>(data), data ? stride : 0};
@@ -989,6 +1013,8 @@ int gv_mark_dirty(GvCtx* ctx, uint32_t kind, uint32_t first, uint32_t count)
 {
     if (!ctx)
         return GV_E_ARG;
+    if (int rc = flush_recorded_culls(ctx, kind == GV_DIRTY_MESH ? std::min(first >> 28, GV_MAX_POOLS - 1u) : GV_MAX_POOLS))
+        return rc;
     switch (kind) {
     case GV_DIRTY_TRANSFORM:
         ctx->xf_dirty.add(first, count);
@@ -1017,6 +1043,8 @@ int gv_hierarchy_rebuild(GvCtx* ctx)
 {
     if (!ctx)
         return GV_E_ARG;
+    if (int rc = flush_recorded_culls(ctx, GV_MAX_POOLS))
+        return rc;
     ctx->xf_need_full = true;
     return sync_mirror(ctx);
 }
@@ -1025,6 +1053,8 @@ int gv_sync(GvCtx* ctx)
 {
     if (!ctx)
         return GV_E_ARG;
+    if (int rc = flush_recorded_culls(ctx, GV_MAX_POOLS))
+        return rc;
     return sync_mirror(ctx);
 }
 

@@ -504,6 +504,8 @@ int scatter_stream(GvCtx* ctx, const T* host_packet, T* device_packet, T* dst, u
 
 // Dirty pool slots of a permuted mirror land on scattered entries: ship ALL the dirty ranges of a sync as one compact
 // packet {entry, record} and scatter on the device (one packet, one synchronisation, however many ranges).
+constexpr size_t kRangedCopyMaxRanges = 32;  // dirty ranges of a slot-order mirror sent as plain copies; more go as one scattered packet
+
 int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& ranges)
 {
     std::vector<uint32_t> start(ranges.size() + 1, 0);
@@ -519,7 +521,7 @@ int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& r
         const uint32_t lo = ranges[q].lo, base = start[q];
         parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
             for (uint32_t k = a; k < b; k++) {
-                const uint32_t j = ctx->xinv[lo + k];
+                const uint32_t j = ctx->xinv.empty() ? lo + k : ctx->xinv[lo + k];  // (a mirror in slot order: the identity)
                 ctx->sc_idx.ptr[base + k] = j;
                 ctx->sc_ab.ptr[base + k] = ctx->h_xab.ptr[j];
                 ctx->sc_c.ptr[base + k] = ctx->h_xc.ptr[j];
@@ -556,7 +558,7 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRan
         const uint32_t lo = ranges[q].lo, base = start[q];
         parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {
             for (uint32_t k = a; k < b; k++) {
-                const uint32_t j = p.inv[lo + k];
+                const uint32_t j = p.inv.empty() ? lo + k : p.inv[lo + k];
                 ctx->sc_idx.ptr[base + k] = j;
                 ctx->sc_a.ptr[base + k] = p.h_a.ptr[j];
                 ctx->sc_c.ptr[base + k] = p.h_b.ptr[j];
@@ -778,7 +780,10 @@ int sync_mirror(GvCtx* ctx)
                 }
                 for (const auto& r : host)
                     gather_transforms(ctx, r.lo, r.hi);
-                if (ctx->xinv.empty()) {
+                // a mirror in slot order takes plain ranged copies — five small copies and a memset per range — while the ranges
+                // are few; a frame that moved thousands of scattered entities (up to 16 384 ranges) would queue ~10^5 tiny copies
+                // that way: it travels as the one scattered packet too
+                if (ctx->xinv.empty() && host.size() <= kRangedCopyMaxRanges) {
                     for (const auto& r : host) {
                         if ((rc = upload_transforms(ctx, r.lo, r.hi)) != GV_OK)
                             break;
@@ -887,7 +892,7 @@ int sync_mirror(GvCtx* ctx)
                 } else {
                     for (const auto& r : ranges)
                         gather_meshes(ctx, p, r.lo, r.hi);
-                    if (p.inv.empty()) {
+                    if (p.inv.empty() && ranges.size() <= kRangedCopyMaxRanges) {
                         for (const auto& r : ranges)
                             if ((rc = upload_meshes(ctx, p, r.lo, r.hi)) != GV_OK)
                                 break;

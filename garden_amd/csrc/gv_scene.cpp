@@ -971,6 +971,8 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
         (uint64_t)grid[0] * grid[1] * grid[2] > 4096u || tile >= grid[0] * grid[1] * grid[2])
         return GV_E_ARG;
     *out_tile = nullptr;
+    GvScene* out = nullptr;
+    try {  // (the vectors and the map below allocate: nothing may escape into C / ctypes callers)
     const uint32_t nt = (uint32_t)scene->entity.size();
     const auto& e2t = scene->entity_to_transform;
     auto slot_of = [&](uint32_t entity) -> uint32_t {
@@ -991,14 +993,16 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
         uint32_t t = 0, mul = 1;
         for (int a = 0; a < 3; a++) {
             const double cell = ((double)scene->position[(size_t)root * 3 + a] / side + 0.5) * (double)grid[a];
-            long long c = (long long)cell;  // truncation, as numpy's astype(int64)
+            // truncation, as numpy's astype(int64) — whose result for NaN and for values outside the int64 range is INT64_MIN
+            // (x86 cvttsd2si), i.e. cell 0 after the clamp; decided in double here: the cast itself would be undefined behaviour
+            long long c = (cell > -9.2e18 && cell < 9.2e18) ? (long long)cell : 0;
             c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
             t += (uint32_t)c * mul;
             mul *= grid[a];
         }
         xf_tile[s] = t;
     }
-    GvScene* out = new (std::nothrow) GvScene();
+    out = new (std::nothrow) GvScene();
     if (!out)
         return GV_E_OOM;
     out->is_tile = true;
@@ -1089,6 +1093,10 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
     out->info.transform_count = (uint32_t)out->entity.size();
     *out_tile = out;
     return GV_OK;
+    } catch (...) {  // std::bad_alloc
+        delete out;
+        return GV_E_OOM;
+    }
 }
 
 int gv_scene_tile_maps(const GvScene* tile, uint32_t pool_id, const uint32_t** transform_global, uint32_t* transform_count,

@@ -298,8 +298,9 @@ int gv_pool_results_instance_bases(GvCtx* ctx, uint32_t pool_id, uint32_t view_i
  * cull; the first read then launches all recorded culls as ONE kernel, their emits as ONE kernel, the requested sorts
  * (gv_pool_sort; pools of up to 16384 slots) as ONE kernel and publishes every view's results to the host with ONE kernel and ONE synchronisation —
  * four launches per frame however many mesh systems and shadow passes there are. Other culls (larger pools, count-only
- * views, GV_SWEEP_WITH_CULL, block bounds) run at once as usual. Same results. Do not re-bind or mark a pool dirty
- * between its gv_cull and the first read of the batch. */
+ * views, GV_SWEEP_WITH_CULL, block bounds) run at once as usual. Same results. A bind or gv_mark_dirty of a pool a recorded cull
+ * reads (its mesh pool; the transform pool, gv_sync and gv_hierarchy_rebuild concern every recorded cull) first launches what
+ * has been recorded so far — the recorded culls see the pools as they were when gv_cull was called — and recording goes on. */
 int gv_cull_batch_begin(GvCtx* ctx);
 int gv_cull_batch_end(GvCtx* ctx);
 int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int write_back, GvResult* out);

@@ -153,6 +153,8 @@ void gvo_prepare_meshes(const GvoMeshPool* mp, const GvoTransformPool* tp, const
  * scalar routines above; the timed cpu_baseline of bench.py ---- */
 typedef struct GvoSoa GvoSoa;
 GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp);
+/* the same, filled by `threads` workers over the ranges gvo_prepare_meshes_avx2 will hand them (first touch = the culling thread) */
+GvoSoa* gvo_soa_build_threads(const GvoMeshPool* mp, const GvoTransformPool* tp, uint32_t threads);
 void gvo_soa_free(GvoSoa* soa);
 void gvo_prepare_meshes_avx2(const GvoSoa* soa, const GvoMeshPool* mp, const GvoView* view, const GvoHiz* hiz,
                              uint32_t threads, GvoCullOut* out);

@@ -6,7 +6,8 @@
  *
  * Same control flow as prepareUnsortedMeshes (source/system/render/mesh.cpp:137-175), same canonical arithmetic
  * (explicit fused multiply-adds in the written order), same ThreadPool::addItems range split
- * (source/thread-pool.cpp:173-200). The Hi-Z query of frustum survivors runs through the scalar routine.
+ * (source/thread-pool.cpp:173-200). The Hi-Z query of the frustum survivors runs 8-wide too (hiz_occluded8: the scalar routine's
+ * operations lane by lane, texels by gather).
  * Build flags: -O2 -march=haswell -ffp-contract=off (cmake/compile-options.cmake:34-36 uses -march=haswell too).
  */
 #include <immintrin.h>
@@ -34,20 +35,19 @@ typedef struct GvoSoa {
 
 static void* xmalloc(size_t n) { void* p = NULL; if (posix_memalign(&p, 64, n ? n : 64)) abort(); return p; }
 
-GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp)
+/* One contiguous range of transform slots / mesh slots copied into the SoA arrays. Run by the thread that will later cull
+ * the same range (gvo_soa_build_threads), so that the pages it touches first live on its own NUMA node. */
+typedef struct SoaFill {
+    GvoSoa* s; const GvoMeshPool* mp; const GvoTransformPool* tp;
+    uint32_t xlo, xhi, mlo, mhi;
+} SoaFill;
+
+static void* soa_fill_main(void* arg)
 {
-    GvoSoa* s = (GvoSoa*)calloc(1, sizeof(GvoSoa));
-    const uint32_t nm = mp->occupancy, nx = tp->occupancy;
-    const size_t pm = ((size_t)nm + 8) * 4, px = ((size_t)nx + 8) * 4;
-    s->mesh_count = nm; s->xf_count = nx;
-    float** xf_f[] = {&s->px, &s->py, &s->pz, &s->qx, &s->qy, &s->qz, &s->qw, &s->sx, &s->sy, &s->sz};
-    for (int k = 0; k < 10; k++) { *xf_f[k] = (float*)xmalloc(px); memset(*xf_f[k], 0, px); }
-    s->parent = (int32_t*)xmalloc(px); s->xf_flags = (uint8_t*)xmalloc(nx + 8);
-    float** m_f[] = {&s->mnx, &s->mny, &s->mnz, &s->mxx, &s->mxy, &s->mxz};
-    for (int k = 0; k < 6; k++) { *m_f[k] = (float*)xmalloc(pm); memset(*m_f[k], 0, pm); }
-    s->slot = (int32_t*)xmalloc(pm); s->candidate = (uint8_t*)xmalloc(nm + 8);
-    memset(s->candidate, 0, nm + 8);
-    for (uint32_t t = 0; t < nx; t++) {
+    const SoaFill* f = (const SoaFill*)arg;
+    GvoSoa* s = f->s; const GvoMeshPool* mp = f->mp; const GvoTransformPool* tp = f->tp;
+    const uint32_t nx = tp->occupancy;
+    for (uint32_t t = f->xlo; t < f->xhi; t++) {
         const uint8_t* c = tp->base + (size_t)t * tp->stride;
         const float* p = (const float*)(c + tp->off_position);
         const float* q = (const float*)(c + tp->off_rotation);
@@ -61,7 +61,7 @@ GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp)
         s->xf_flags[t] = (uint8_t)(((c[tp->off_self_active] && c[tp->off_ancestors_active]) ? 1 : 0) |
                                    (c[tp->off_model_with_ancestors] ? 2 : 0));
     }
-    for (uint32_t i = 0; i < nm; i++) {
+    for (uint32_t i = f->mlo; i < f->mhi; i++) {
         const uint8_t* c = mp->base + (size_t)i * mp->stride;
         const float* a = (const float*)(c + mp->off_aabb_min);
         const float* b = (const float*)(c + mp->off_aabb_max);
@@ -72,8 +72,47 @@ GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp)
         s->slot[i] = (ts == GVO_NONE || ts >= nx) ? -1 : (int32_t)ts;
         s->candidate[i] = (uint8_t)((e != 0 && c[mp->off_is_enabled]) ? 1 : 0);
     }
+    return NULL;
+}
+
+/* threads > 1: the arrays are filled (first touched) by `threads` workers over the SAME contiguous ranges
+ * gvo_prepare_meshes_avx2 hands them (ThreadPool::addItems' split, thread-pool.cpp:179-194). */
+GvoSoa* gvo_soa_build_threads(const GvoMeshPool* mp, const GvoTransformPool* tp, uint32_t threads)
+{
+    GvoSoa* s = (GvoSoa*)calloc(1, sizeof(GvoSoa));
+    const uint32_t nm = mp->occupancy, nx = tp->occupancy;
+    const size_t pm = ((size_t)nm + 8) * 4, px = ((size_t)nx + 8) * 4;
+    s->mesh_count = nm; s->xf_count = nx;
+    float** xf_f[] = {&s->px, &s->py, &s->pz, &s->qx, &s->qy, &s->qz, &s->qw, &s->sx, &s->sy, &s->sz};
+    for (int k = 0; k < 10; k++) { *xf_f[k] = (float*)xmalloc(px); memset(*xf_f[k] + nx, 0, 32); }  /* the 8-lane tail only */
+    s->parent = (int32_t*)xmalloc(px); s->xf_flags = (uint8_t*)xmalloc(nx + 8);
+    float** m_f[] = {&s->mnx, &s->mny, &s->mnz, &s->mxx, &s->mxy, &s->mxz};
+    for (int k = 0; k < 6; k++) { *m_f[k] = (float*)xmalloc(pm); memset(*m_f[k] + nm, 0, 32); }
+    s->slot = (int32_t*)xmalloc(pm); s->candidate = (uint8_t*)xmalloc(nm + 8);
+    memset(s->parent + nx, 0xFF, 32); memset(s->xf_flags + nx, 0, 8);
+    memset(s->slot + nm, 0xFF, 32); memset(s->candidate + nm, 0, 8);
+    const uint32_t most = nm > nx ? nm : nx;
+    uint32_t tasks = threads < 1 ? 1 : threads;
+    if (tasks > most) tasks = most ? most : 1;
+    SoaFill* fills = (SoaFill*)calloc(tasks, sizeof(SoaFill));
+    void** argv = (void**)malloc(sizeof(void*) * tasks);
+    const uint32_t mper = (uint32_t)ceilf((float)nm / (float)tasks), xper = (uint32_t)ceilf((float)nx / (float)tasks);
+    for (uint32_t k = 0; k < tasks; k++) {
+        SoaFill* f = &fills[k];
+        f->s = s; f->mp = mp; f->tp = tp;
+        f->mlo = mper * k < nm ? mper * k : nm; f->mhi = f->mlo + mper < nm ? f->mlo + mper : nm;
+        f->xlo = xper * k < nx ? xper * k : nx; f->xhi = f->xlo + xper < nx ? f->xlo + xper : nx;
+        argv[k] = f;
+    }
+    if (tasks == 1)
+        soa_fill_main(argv[0]);
+    else
+        gvo_pool_run(soa_fill_main, argv, (int)tasks, (int)tasks);
+    free(argv); free(fills);
     return s;
 }
+
+GvoSoa* gvo_soa_build(const GvoMeshPool* mp, const GvoTransformPool* tp) { return gvo_soa_build_threads(mp, tp, 1); }
 
 void gvo_soa_free(GvoSoa* s)
 {
@@ -154,6 +193,97 @@ static inline M34 gather_model8(const GvoSoa* s, __m256i idx, __m256 mask)
 #undef G
 }
 
+/* gvo_hiz_occluded for 8 boxes at once (their 8 corners each are already in registers): the same operations in the same
+ * order per lane — IEEE divisions, fminf / fmaxf as glibc defines them (a NaN operand is ignored), the integer level search,
+ * the four texel reads as gathers — so that the result equals the scalar routine's bit for bit (tests/test_oracle_avx2.py).
+ * `lanes`: bit l = box l is to be tested; returns the mask of occluded boxes. Needs every texel index to fit 31 bits. */
+static inline __m256 fmin8(__m256 acc, __m256 u)
+{   /* fminf(acc, u): acc < u ? acc : (u is NaN ? acc : u); MINPS returns its second operand when either is NaN */
+    return _mm256_blendv_ps(_mm256_min_ps(acc, u), acc, _mm256_cmp_ps(u, u, _CMP_UNORD_Q));
+}
+static inline __m256 fmax8(__m256 acc, __m256 u)
+{
+    return _mm256_blendv_ps(_mm256_max_ps(acc, u), acc, _mm256_cmp_ps(u, u, _CMP_UNORD_Q));
+}
+static inline __m256 clamp01_8(__m256 a)
+{   /* a > 0 ? (a < 1 ? a : 1) : 0 */
+    const __m256 one = _mm256_set1_ps(1.0f);
+    const __m256 t = _mm256_blendv_ps(one, a, _mm256_cmp_ps(a, one, _CMP_LT_OQ));
+    return _mm256_and_ps(t, _mm256_cmp_ps(a, _mm256_setzero_ps(), _CMP_GT_OQ));
+}
+static int hiz_fits_int32(const GvoHiz* hz)
+{
+    const uint64_t last = hz->mip_count ? hz->mip_offset[hz->mip_count - 1] + (uint64_t)hz->mip_w[hz->mip_count - 1] * hz->mip_h[hz->mip_count - 1] : 0;
+    return (uint64_t)hz->width * hz->height < (1ull << 31) && 2 * last < (1ull << 31);
+}
+static inline uint32_t hiz_occluded8(const GvoHiz* hz, const float vp[16], const __m256* cx, const __m256* cy, const __m256* cz, uint32_t lanes)
+{
+    const __m256 zero = _mm256_setzero_ps(), half = _mm256_set1_ps(0.5f), one = _mm256_set1_ps(1.0f);
+    __m256 umin = zero, umax = zero, vmin = zero, vmax = zero, znear = zero;
+    __m256 bounded = _mm256_castsi256_ps(_mm256_set1_epi32(-1));
+    for (int k = 0; k < 8; k++) {
+        const __m256 clx = FMA(_mm256_set1_ps(vp[0]), cx[k], FMA(_mm256_set1_ps(vp[4]), cy[k], FMA(_mm256_set1_ps(vp[8]), cz[k], _mm256_set1_ps(vp[12]))));
+        const __m256 cly = FMA(_mm256_set1_ps(vp[1]), cx[k], FMA(_mm256_set1_ps(vp[5]), cy[k], FMA(_mm256_set1_ps(vp[9]), cz[k], _mm256_set1_ps(vp[13]))));
+        const __m256 clz = FMA(_mm256_set1_ps(vp[2]), cx[k], FMA(_mm256_set1_ps(vp[6]), cy[k], FMA(_mm256_set1_ps(vp[10]), cz[k], _mm256_set1_ps(vp[14]))));
+        const __m256 clw = FMA(_mm256_set1_ps(vp[3]), cx[k], FMA(_mm256_set1_ps(vp[7]), cy[k], FMA(_mm256_set1_ps(vp[11]), cz[k], _mm256_set1_ps(vp[15]))));
+        bounded = _mm256_and_ps(bounded, _mm256_cmp_ps(clw, zero, _CMP_GT_OQ)); /* !(clw > 0): cannot bound -> visible */
+        const __m256 rcp = _mm256_div_ps(one, clw);
+        const __m256 u = FMA(MUL(clx, rcp), half, half), v = FMA(MUL(cly, rcp), half, half), zc = MUL(clz, rcp);
+        if (k == 0) {
+            umin = umax = u; vmin = vmax = v; znear = zc;
+        } else {
+            umin = fmin8(umin, u); umax = fmax8(umax, u);
+            vmin = fmin8(vmin, v); vmax = fmax8(vmax, v);
+            znear = fmax8(znear, zc);
+        }
+    }
+    lanes &= (uint32_t)_mm256_movemask_ps(bounded);
+    if (!lanes)
+        return 0;
+    umin = clamp01_8(umin); umax = clamp01_8(umax); vmin = clamp01_8(vmin); vmax = clamp01_8(vmax);
+    const __m256 Wf = _mm256_set1_ps((float)(int)hz->width), Hf = _mm256_set1_ps((float)(int)hz->height);
+    const __m256i wm1 = _mm256_set1_epi32((int)hz->width - 1), hm1 = _mm256_set1_epi32((int)hz->height - 1);
+    /* lanes that are not tested may hold anything (NaN, huge): keep their integers harmless */
+    const __m256 live = _mm256_castsi256_ps(_mm256_cmpgt_epi32(_mm256_and_si256(_mm256_set1_epi32((int)lanes), _mm256_setr_epi32(1, 2, 4, 8, 16, 32, 64, 128)),
+                                                              _mm256_setzero_si256()));
+    const __m256i ix0 = _mm256_min_epi32(_mm256_cvttps_epi32(_mm256_and_ps(MUL(umin, Wf), live)), wm1);
+    const __m256i ix1 = _mm256_min_epi32(_mm256_cvttps_epi32(_mm256_and_ps(MUL(umax, Wf), live)), wm1);
+    const __m256i iy0 = _mm256_min_epi32(_mm256_cvttps_epi32(_mm256_and_ps(MUL(vmin, Hf), live)), hm1);
+    const __m256i iy1 = _mm256_min_epi32(_mm256_cvttps_epi32(_mm256_and_ps(MUL(vmax, Hf), live)), hm1);
+    /* smallest level at which the pixel rect touches <= 2x2 texels */
+    __m256i level = _mm256_setzero_si256(), still = _mm256_castps_si256(live);
+    const __m256i one_i = _mm256_set1_epi32(1);
+    for (uint32_t L = 0; L + 1 < hz->mip_count; L++) {
+        const __m128i sh = _mm_cvtsi32_si128((int)L);
+        const __m256i dx = _mm256_sub_epi32(_mm256_srl_epi32(ix1, sh), _mm256_srl_epi32(ix0, sh));
+        const __m256i dy = _mm256_sub_epi32(_mm256_srl_epi32(iy1, sh), _mm256_srl_epi32(iy0, sh));
+        still = _mm256_and_si256(still, _mm256_or_si256(_mm256_cmpgt_epi32(dx, one_i), _mm256_cmpgt_epi32(dy, one_i)));
+        if (!_mm256_movemask_ps(_mm256_castsi256_ps(still)))
+            break;
+        level = _mm256_sub_epi32(level, still); /* still = -1 where the rect is still too wide at L: level = L + 1 */
+    }
+    int off32[16];
+    for (int k = 0; k < 16; k++) off32[k] = (int)hz->mip_offset[k];
+    const __m256i lw = _mm256_i32gather_epi32((const int*)hz->mip_w, level, 4), lh = _mm256_i32gather_epi32((const int*)hz->mip_h, level, 4);
+    const __m256i lwm1 = _mm256_sub_epi32(lw, one_i), lhm1 = _mm256_sub_epi32(lh, one_i);
+    const __m256i tx0 = _mm256_min_epi32(_mm256_srlv_epi32(ix0, level), lwm1), tx1 = _mm256_min_epi32(_mm256_srlv_epi32(ix1, level), lwm1);
+    const __m256i ty0 = _mm256_min_epi32(_mm256_srlv_epi32(iy0, level), lhm1), ty1 = _mm256_min_epi32(_mm256_srlv_epi32(iy1, level), lhm1);
+    const __m256i is0 = _mm256_cmpeq_epi32(level, _mm256_setzero_si256());
+    const __m256 is0f = _mm256_and_ps(_mm256_castsi256_ps(is0), live), isnf = _mm256_andnot_ps(_mm256_castsi256_ps(is0), live);
+    const __m256i base = _mm256_i32gather_epi32(off32, level, 4);
+#define TEXEL(TX, TY) ({                                                                                                        \
+        const __m256i at = _mm256_add_epi32(_mm256_mullo_epi32((TY), lw), (TX));                                                    \
+        const __m256 d = _mm256_mask_i32gather_ps(zero, hz->depth, at, is0f, 4);                                                    \
+        const __m256 m = _mm256_mask_i32gather_ps(zero, hz->mips, _mm256_slli_epi32(_mm256_add_epi32(base, at), 1), isnf, 4);       \
+        _mm256_blendv_ps(m, d, is0f); })
+    __m256 zfar = TEXEL(tx0, ty0), a;
+    a = TEXEL(tx1, ty0); zfar = _mm256_blendv_ps(zfar, a, _mm256_cmp_ps(a, zfar, _CMP_LT_OQ));
+    a = TEXEL(tx0, ty1); zfar = _mm256_blendv_ps(zfar, a, _mm256_cmp_ps(a, zfar, _CMP_LT_OQ));
+    a = TEXEL(tx1, ty1); zfar = _mm256_blendv_ps(zfar, a, _mm256_cmp_ps(a, zfar, _CMP_LT_OQ));
+#undef TEXEL
+    return lanes & (uint32_t)_mm256_movemask_ps(_mm256_cmp_ps(znear, zfar, _CMP_LT_OQ));
+}
+
 void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const GvoView* view, const GvoFrustum* fr,
                                    const GvoHiz* hiz, uint32_t item_offset, uint32_t item_end, GvoCullOut* out)
 {
@@ -163,6 +293,7 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
     const __m256 camx = _mm256_set1_ps(view->camera_position[0]), camy = _mm256_set1_ps(view->camera_position[1]),
                  camz = _mm256_set1_ps(view->camera_position[2]);
     const __m256i lanes = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const int hiz_8wide = view->use_hiz && hiz && hiz_fits_int32(hiz);
     for (uint32_t i = item_offset; i < item_end; i += 8) {
         const uint32_t left = item_end - i;
         const __m256i in_range = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)(left < 8 ? left : 8)), lanes);
@@ -228,6 +359,8 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
                 behind = _mm256_or_ps(behind, all_neg);
             }
             vis_mask = (uint32_t)_mm256_movemask_ps(_mm256_andnot_ps(behind, okf));
+            if (vis_mask && hiz_8wide) /* the occlusion query of the frustum survivors, 8 at a time */
+                vis_mask &= ~hiz_occluded8(hiz, view->view_proj, cx, cy, cz, vis_mask);
         }
         /* scalar epilogue per lane: optional Hi-Z query, isVisible write-back, record append (mesh.cpp:158-174) */
         float mm[12][8];
@@ -239,7 +372,7 @@ void gvo_prepare_meshes_range_avx2(const GvoSoa* s, const GvoMeshPool* mp, const
         for (uint32_t l = 0; l < lanes_here; l++) {
             uint8_t* mesh = mp->base + (size_t)(i + l) * mp->stride;
             int visible = (vis_mask >> l) & 1;
-            if (visible && view->use_hiz && hiz) {
+            if (visible && view->use_hiz && hiz && !hiz_8wide) { /* (a pyramid too large for 32-bit gather indices: the scalar routine) */
                 float model[16] = {mm[0][l], mm[1][l], mm[2][l], 0, mm[3][l], mm[4][l], mm[5][l], 0,
                                    mm[6][l], mm[7][l], mm[8][l], 0, mm[9][l], mm[10][l], mm[11][l], 1};
                 const float amin[3] = {s->mnx[i + l], s->mny[i + l], s->mnz[i + l]};

@@ -90,6 +90,8 @@ def load():
     lib.gvo_sort_records.argtypes = [C.POINTER(GvoCullOut), C.c_int]
     lib.gvo_soa_build.argtypes = [C.POINTER(GvoMeshPool), C.POINTER(GvoTransformPool)]
     lib.gvo_soa_build.restype = C.c_void_p
+    lib.gvo_soa_build_threads.argtypes = [C.POINTER(GvoMeshPool), C.POINTER(GvoTransformPool), C.c_uint32]
+    lib.gvo_soa_build_threads.restype = C.c_void_p
     lib.gvo_soa_free.argtypes = [C.c_void_p]
     lib.gvo_prepare_meshes_avx2.argtypes = [C.c_void_p, C.POINTER(GvoMeshPool), C.POINTER(GvoView), C.POINTER(GvoHiz),
                                             C.c_uint32, C.POINTER(GvoCullOut)]
@@ -238,12 +240,14 @@ def prepare_meshes(meshes, transforms, e2t, view, hiz=None, threads=1, sort=None
 class Avx2Scene:
     """SoA copy of the pools for the AVX2 path (built once, like the GPU mirror)."""
 
-    def __init__(self, meshes, transforms, e2t, ready=None):
+    def __init__(self, meshes, transforms, e2t, ready=None, threads=1):
+        """threads > 1: the arrays are filled by that many workers over the ranges prepare_meshes(threads=...) will hand them
+        (first touch by the thread that culls the range: the pages land on its NUMA node)."""
         self.lib = load()
         self.meshes, self.transforms, self.ready = meshes, transforms, ready
         self.e2t = np.ascontiguousarray(e2t, dtype=np.uint32)
         self.mp, self.tp = mesh_pool(meshes, ready), transform_pool(transforms, self.e2t)
-        self.soa = self.lib.gvo_soa_build(C.byref(self.mp), C.byref(self.tp))
+        self.soa = self.lib.gvo_soa_build_threads(C.byref(self.mp), C.byref(self.tp), max(1, int(threads)))
         n = max(meshes.shape[0], 1)
         self.idx = np.empty(n, np.uint32)
         self.bm = np.empty((n, 12), np.float32)

@@ -1542,3 +1542,73 @@ def test_is_visible_bytes_when_pools_of_different_sizes_share_a_context(oracle, 
                     assert got["draw_count"] == exp["draw_count"]
                     assert np.array_equal(got_vis, exp_vis), (n, seed)
                     assert np.array_equal(got["is_visible"], exp_vis)
+
+
+def test_changes_inside_a_batch_do_not_reach_the_culls_recorded_before_them(oracle):
+    """gv_cull_batch_begin only RECORDS the culls of engine-sized pools; they are launched at the first read. A dirty mark of
+    the transform pool (or a re-bind of a recorded pool) in between must not change what a recorded cull sees, nor let it run on
+    an occupancy its buffers were not sized for: such a call launches the recorded culls first."""
+    from garden_amd.lib import GpuVisibility, GV_DIRTY_TRANSFORM
+    n = 12_000
+    sc = scene.flat_scene(n, seed=5)
+    twin = sc.meshes.copy()  # a second mesh system over the same entities
+    view = scene.main_camera_view()
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.bind_pool(1, twin)
+        vis.hierarchy_rebuild()
+        before = sc.transforms.copy()
+        m0 = sc.meshes.copy()
+        exp0 = oracle.prepare_meshes(m0, before, sc.entity_to_transform, view)
+        vis.cull_batch_begin()
+        vis.cull(0, [view])                                   # recorded
+        sc.transforms["position"][:, 0] += np.float32(900.0)  # the world moves ...
+        vis.mark_dirty(GV_DIRTY_TRANSFORM, 0, n)              # ... and says so: pool 0's cull runs now, on the old world
+        vis.cull(1, [view])                                   # recorded, sees the new world
+        got1 = vis.fetch(0, write_back=False, occupancy=n, pool_id=1)
+        got0 = vis.fetch(0, write_back=False, occupancy=n, pool_id=0)
+        m1 = twin.copy()
+        exp1 = oracle.prepare_meshes(m1, sc.transforms, sc.entity_to_transform, view)
+        assert exp0["draw_count"] != exp1["draw_count"]
+        for got, exp, m in ((got0, exp0, m0), (got1, exp1, m1)):
+            assert got["draw_count"] == exp["draw_count"]
+            assert np.array_equal(got["visible_idx"], exp["visible_idx"])
+            assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+            assert np.array_equal(got["is_visible"], m["isVisible"])
+        # a recorded pool re-bound smaller inside the batch: its recorded cull runs on the pool it was recorded for
+        small = scene.flat_scene(3_000, seed=6)
+        vis.cull_batch_begin()
+        vis.cull(0, [view])
+        vis.bind_transforms(small.transforms, small.entity_to_transform)
+        vis.bind_pool(0, small.meshes)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=small.count, pool_id=0)
+        ms = small.meshes.copy()
+        exps = oracle.prepare_meshes(ms, small.transforms, small.entity_to_transform, view)
+        assert got["draw_count"] == exps["draw_count"] and np.array_equal(got["visible_idx"], exps["visible_idx"])
+        assert np.array_equal(got["is_visible"], ms["isVisible"])
+
+
+def test_thousands_of_scattered_dirty_marks_on_a_slot_order_mirror(gpu_slot_order, oracle):
+    """A frame that moves thousands of scattered entities marks thousands of ranges; a mirror in slot order sends them as ONE
+    scattered packet (ranged copies would be five small copies per range), a few ranges still as plain copies."""
+    gpu = gpu_slot_order
+    n = 200_000
+    sc = scene.flat_scene(n, seed=9)
+    view = scene.main_camera_view()
+    run_both(gpu, oracle, sc, [view])
+    rng = np.random.default_rng(3)
+    for count in (5, 3000):
+        moved = np.sort(rng.choice(n // 3, count, replace=False)) * 3  # isolated slots: `count` ranges
+        sc.transforms["position"][moved, :3] += rng.uniform(-300, 300, (count, 3)).astype(np.float32)
+        sc.meshes["aabbMax"][moved, :3] *= np.float32(1.5)
+        for s in moved:
+            gpu.mark_dirty(0, int(s), 1)
+            gpu.mark_dirty(2, int(s), 1, pool_id=0)
+        gpu.cull(0, [view])
+        sc.meshes["isVisible"] = 7
+        got = gpu.fetch(0, write_back=True, occupancy=n)
+        got_vis = sc.meshes["isVisible"].copy()
+        exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, view)
+        assert_same(got, got_vis, exp, sc.meshes["isVisible"].copy())

@@ -437,3 +437,34 @@ def test_native_tile_extraction_equals_partition_world(grid):
     with pytest.raises(GvError):
         whole.tile_maps(0)  # the whole scene is not a tile
     whole.close()
+
+
+def test_tile_extraction_of_positions_no_cell_can_hold():
+    """Root positions that are +-inf (1e300 in the file), huge but finite, or far outside the world cube: the native extraction
+    puts them where partition_world's numpy arithmetic puts them (astype(int64) of a value outside the int64 range is INT64_MIN
+    -> cell 0 after the clamp), decided in double — the cast itself would be undefined behaviour."""
+    from garden_amd.multi import partition_world
+    src = scene.flat_scene(600, defects=False)
+    marks = {900001.25: "1e300", 900002.25: "-1e300", 900003.25: "1e30", 900004.25: "-1e30", 900005.25: "7e18", 900006.25: "-7e18",
+             900007.25: "123456.0"}
+    for k, (m, _) in enumerate(marks.items()):
+        src.transforms["position"][10 + k, k % 3] = np.float32(m)
+    text = sj.write_scene(src.transforms, {"Model": src.meshes}, src.entity_to_transform)
+    for m, lit in marks.items():
+        assert text.count(repr(m)) == 1
+        text = text.replace(repr(m), lit)
+    whole = Scene(text, {"Model": 0})
+    aos = _scene_as_aos(whole)
+    assert np.isinf(aos.transforms["position"][10, 0]) and np.isinf(aos.transforms["position"][11, 1])
+    grid, side = (2, 2, 2), 100.0 * 600 ** (1.0 / 3.0)
+    with np.errstate(invalid="ignore", over="ignore"):
+        part = partition_world(aos, grid, side=side)
+    total = 0
+    for t in range(8):
+        tile = whole.extract_tile(grid, side, t)
+        tg, mg = tile.tile_maps(0)
+        assert np.array_equal(tg.astype(np.int64), part.transform_global[t]), t
+        assert np.array_equal(mg.astype(np.int64), part.mesh_global[t]), t
+        total += tg.shape[0]
+        tile.close()
+    assert total == 600

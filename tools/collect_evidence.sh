@@ -4,22 +4,35 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/evidence
 rm -rf $out; mkdir -p $out
+# a probe is (re)built from the sources of THIS snapshot or not run at all: no binary left in /tmp by an earlier call is ever
+# measured in its place, and the compiler's output is kept beside the evidence
+build_probe() {  # build_probe <binary> <hipcc arguments...>
+    local bin=$1; shift
+    rm -f "$bin"
+    if ! hipcc "$@" -o "$bin" 2>>"$out/hipcc_stderr.txt"; then
+        echo "FAILED: hipcc $* (see hipcc_stderr.txt): $bin was not built, its measurements are missing below"
+        return 1
+    fi
+}
+run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe has just made
+    [ -x "$1" ] && timeout 120 "$@" || echo "SKIPPED: $* (not built)"
+}
 {
   echo "# tools/onesweep_probe: gv_sort (rank kernel + scatter kernel per digit), capacity 10 M slots; times in us"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Igarden_amd/csrc tools/onesweep_probe.hip -o /tmp/onesweep_plain 2>/dev/null
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DGV_SORT_TRACE -Igarden_amd/csrc tools/onesweep_probe.hip -o /tmp/onesweep_probe 2>/dev/null
-  timeout 120 /tmp/onesweep_plain 2124723 10000000
-  timeout 120 /tmp/onesweep_plain 308383 10000000
-  timeout 120 /tmp/onesweep_plain 9900000 10000000
+  build_probe /tmp/onesweep_plain --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Igarden_amd/csrc tools/onesweep_probe.hip
+  build_probe /tmp/onesweep_probe --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DGV_SORT_TRACE -Igarden_amd/csrc tools/onesweep_probe.hip
+  run_probe /tmp/onesweep_plain 2124723 10000000
+  run_probe /tmp/onesweep_plain 308383 10000000
+  run_probe /tmp/onesweep_plain 9900000 10000000
   echo "# the same with wall-clock stamps per tile and phase (-DGV_SORT_TRACE; a few us slower)"
-  timeout 120 /tmp/onesweep_probe 2124723 10000000
+  run_probe /tmp/onesweep_probe 2124723 10000000
   echo
   echo "# tools/sort_bench.py (through the C-ABI, cull + emit + gv_sort per frame, 50 frames; hipEvents)"
   timeout 200 python3 tools/sort_bench.py 2>&1 | grep records
   echo
   echo "# tools/permute_probe: the last pass's job in isolation — 48-byte records through a random permutation"
-  hipcc --offload-arch=gfx950 -O3 tools/permute_probe.hip -o /tmp/permute_probe 2>/dev/null
-  timeout 120 /tmp/permute_probe 2124723
+  build_probe /tmp/permute_probe --offload-arch=gfx950 -O3 tools/permute_probe.hip
+  run_probe /tmp/permute_probe 2124723
   echo
   echo "# history of the large sort (2 124 723 records, same probe / same sizes):"
   echo "#   round 1: 14 launches (4 x hist / scan / scatter, keys, gather)                                   349 us"
@@ -31,7 +44,7 @@ rm -rf $out; mkdir -p $out
   echo "#   round 2d (kept): pool slots carried beside the pairs (the last pass gathers only the models) and a leaner digit match in the rank kernel      175-182 us"
   echo "#   ranking variants measured on the way (kept: 8-ballot match + wave-private LDS running counts): LDS lane-mask tables (no gain), 4 rotating mask tables"
   echo "#             with returning LDS atomics (spills at 128 VGPRs), static tile ids under the look-back form (-12 us, unsafe there; the kept form needs no ids)"
-} > $out/r02_sort_probe.txt 2>&1
+} > $out/sort_probe.txt 2>&1
 {
   echo "# tests/cpp/headless_tick --mode gpu --ticks 2000 <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the drop-in's prepare phase)"
   for a in "--entities 2000" "--entities 10000" "--entities 10000 --copy-records" "--entities 100000" "--entities 100000 --copy-records" "--entities 10000 --mixed" "--entities 10000 --mixed --csm" "--entities 10000 --hier --world --animate 50 --itemised"; do
