@@ -10,6 +10,9 @@
 #include "gv_ctx.hpp"
 #include "gv_hiz_kernels.hpp"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 using namespace gv;
 
 namespace {
@@ -814,11 +817,24 @@ int gv_create(const GvConfig* config, GvCtx** out_ctx)
     return GV_OK;
 }
 
-static void release_record_target(PoolState::RecordTarget& target)
+// false: the range was page-locked and the runtime no longer knows it — the caller let go of the memory (freed it, or a vector
+// reallocated) while it was still the record target; gv_pool_set_record_target reports that (include/garden_vis.h: the range must
+// stay allocated until it is replaced, removed or the context destroyed)
+static bool release_record_target(PoolState::RecordTarget& target)
 {
-    if (target.dev)
-        (void)hipHostUnregister(target.host);
+    bool intact = true;
+    if (target.dev) {
+        // the runtime un-registers by address and does not notice that the pages are gone (measured: hipHostUnregister of an
+        // unmapped range succeeds), so the mapping is asked directly: msync fails with ENOMEM when any page of the range is not
+        // mapped any more — which is what a freed (munmap'ed) std::vector of this size looks like
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = (uintptr_t)target.host & ~(page - 1), hi = ((uintptr_t)target.host + target.bytes + page - 1) & ~(page - 1);
+        intact = msync(reinterpret_cast<void*>(lo), hi - lo, MS_ASYNC) == 0;
+        intact = (hipHostUnregister(target.host) == hipSuccess) && intact;
+        (void)hipGetLastError();
+    }
     target = PoolState::RecordTarget{};
+    return intact;
 }
 
 void gv_destroy(GvCtx* ctx)
@@ -1414,11 +1430,16 @@ int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index,
     GV_HIP(ctx, hipSetDevice(ctx->device));
     if (target.dev)
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still write the range that is let go
-    release_record_target(target);
+    const bool intact = release_record_target(target);
     ViewState& vs = ctx->views[pool_id][view_index];
     vs.published = false, vs.records_fetched = false;  // the next fetch delivers this view's records again, to the new place
+    // (the new target is installed either way; a lost registration is reported once it is)
+    const int verdict = intact ? GV_OK
+                               : ctx->fail(GV_E_STATE, "gv_pool_set_record_target: the previous record target of pool %u view %u was no longer "
+                                                       "page-locked when it was let go: the range must stay allocated until it is replaced or removed "
+                                                       "(the new target is in place)", pool_id, view_index);
     if (!records)
-        return GV_OK;
+        return verdict;
     target.host = static_cast<uint8_t*>(records);
     target.bytes = bytes;
     void* dev = nullptr;
@@ -1431,7 +1452,7 @@ int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index,
             (void)hipHostUnregister(records);
     }
     (void)hipGetLastError();
-    return GV_OK;
+    return verdict;
 }
 
 int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count)

@@ -1,0 +1,491 @@
+// Host orchestration of libgarden_vis under AddressSanitizer + UndefinedBehaviorSanitizer (CPU tier, no GPU).
+//
+// gv_context.cpp, gv_mirror.cpp and gv_exchange.cpp are normally only ever compiled as HIP; here they are built as plain C++
+// against tests/cpp/hip_stub (device memory = zeroed host memory, copies = memcpy, kernels = no-ops) and driven through the
+// C-ABI of include/garden_vis.h: binds, mirror builds in both orders, every dirty-range path (ranged copies, the one scattered
+// packet, the device-side gather through the pinned chunks and the worker threads, link changes), pools that grow / shrink /
+// move, column binds, ready columns, record layouts and targets, batched ticks, sorts, Hi-Z builds of odd sizes, sweeps,
+// scene ingest and tile extraction, error paths. Kernels do nothing, so RESULTS are not checked here (the GPU tier does
+// that against the oracle) — what is checked is that every staging buffer, index table and copy the host side makes stays
+// inside what it allocated, and that the status codes are the documented ones. TEST-ONLY: the product library still
+// returns GV_E_NODEVICE without a gfx950 device.
+#include <cassert>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/garden_vis.h"
+
+struct Transform {  // include/garden/system/transform.hpp:31-61 (80 bytes in a release build)
+    uint32_t entity, parent;
+    uint64_t uid;
+    float position[4], scale[4], rotation[4];
+    void* childs;
+    uint8_t selfActive, ancestorsActive, modelWithAncestors, pad[5];
+};
+static_assert(sizeof(Transform) == 80, "TransformComponent layout");
+struct Mesh {  // include/garden/system/render/mesh.hpp:45-55
+    uint32_t entity;
+    uint8_t reserved[3], isEnabled, isVisible, pad[7];
+    float aabbMin[4], aabbMax[4];
+};
+static_assert(sizeof(Mesh) == 48, "MeshRenderComponent layout");
+struct BigMesh : Mesh {  // a derived component: larger stride
+    float extra[12];
+};
+
+#define CHECK(call)                                                                                     \
+    do {                                                                                                \
+        const int rc__ = (call);                                                                        \
+        if (rc__ != GV_OK) {                                                                            \
+            std::fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #call, rc__, gv_last_error(ctx)); \
+            std::exit(1);                                                                               \
+        }                                                                                               \
+    } while (0)
+#define EXPECT(call, code)                                                                              \
+    do {                                                                                                \
+        const int rc__ = (call);                                                                        \
+        if (rc__ != (code)) {                                                                           \
+            std::fprintf(stderr, "%s:%d: %s -> %d, expected %d\n", __FILE__, __LINE__, #call, rc__, (int)(code)); \
+            std::exit(1);                                                                               \
+        }                                                                                               \
+    } while (0)
+
+struct World {
+    std::vector<Transform> xf;
+    std::vector<Mesh> meshes;
+    std::vector<BigMesh> big;
+    std::vector<uint32_t> e2t;  // entity id -> transform slot
+    std::mt19937 rng{12345};
+
+    void build(uint32_t n, uint32_t depth)
+    {
+        std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+        xf.assign(n, Transform{});
+        meshes.assign(n, Mesh{});
+        e2t.assign(n + 1, GV_NONE);
+        for (uint32_t i = 0; i < n; i++) {
+            Transform& t = xf[i];
+            if (i % 97 == 5)
+                continue;  // a free slot
+            t.entity = i + 1;
+            e2t[t.entity] = i;
+            // a forest: slot i hangs under an earlier slot of the previous "level" band
+            const uint32_t level = depth ? (i * (depth + 1)) / n : 0;
+            if (level > 0) {
+                const uint32_t band = n / (depth + 1);
+                uint32_t p = (level - 1) * band + rng() % band;
+                if (xf[p].entity != 0)
+                    t.parent = xf[p].entity;
+            }
+            t.uid = 1000u + i;
+            for (int k = 0; k < 3; k++) {
+                t.position[k] = 3000.0f * u(rng);
+                t.scale[k] = 1.0f + 0.5f * u(rng);
+            }
+            float q[4] = {u(rng), u(rng), u(rng), u(rng)}, len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) + 1e-6f;
+            for (int k = 0; k < 4; k++)
+                t.rotation[k] = q[k] / len;
+            t.selfActive = i % 101 != 3;
+            t.ancestorsActive = 1;
+            t.modelWithAncestors = i % 13 != 0;
+            Mesh& m = meshes[i];
+            m.entity = t.entity;
+            m.isEnabled = i % 89 != 1;
+            for (int k = 0; k < 3; k++) {
+                m.aabbMin[k] = -0.5f - 0.5f * std::fabs(u(rng));
+                m.aabbMax[k] = 0.5f + 0.5f * std::fabs(u(rng));
+            }
+        }
+        big.assign(n / 3 + 7, BigMesh{});
+        for (uint32_t j = 0; j + 7 < big.size(); j++) {  // every third entity, in another order; the tail stays free
+            const uint32_t i = ((j * 7919u) % (n / 3)) * 3;
+            static_cast<Mesh&>(big[j]) = meshes[i];
+        }
+    }
+};
+
+static GvTransformLayout transform_layout()
+{
+    return GvTransformLayout{(uint32_t)offsetof(Transform, entity), (uint32_t)offsetof(Transform, parent), (uint32_t)offsetof(Transform, position),
+                             (uint32_t)offsetof(Transform, scale), (uint32_t)offsetof(Transform, rotation), (uint32_t)offsetof(Transform, selfActive),
+                             (uint32_t)offsetof(Transform, ancestorsActive), (uint32_t)offsetof(Transform, modelWithAncestors)};
+}
+static GvMeshLayout mesh_layout()
+{
+    return GvMeshLayout{(uint32_t)offsetof(Mesh, entity), (uint32_t)offsetof(Mesh, isEnabled), (uint32_t)offsetof(Mesh, isVisible),
+                        (uint32_t)offsetof(Mesh, aabbMin), (uint32_t)offsetof(Mesh, aabbMax)};
+}
+
+static GvView make_view(int8_t shadow_pass, uint8_t hiz, uint8_t emit, float cx = 0.0f)
+{
+    GvView v{};
+    const float f = 1.0f, aspect = 16.0f / 9.0f, zn = 0.01f;  // infinite reversed-Z perspective, camera looking down -z
+    v.view_proj[0] = f / aspect;
+    v.view_proj[5] = f;
+    v.view_proj[11] = -1.0f;
+    v.view_proj[14] = zn;
+    v.camera_position[0] = cx;
+    v.shadow_pass = shadow_pass;
+    v.use_hiz = hiz;
+    v.emit_records = emit;
+    return v;
+}
+
+static void bind_all(GvCtx* ctx, World& w)
+{
+    const GvTransformLayout tl = transform_layout();
+    const GvMeshLayout ml = mesh_layout();
+    CHECK(gv_transform_bind(ctx, w.xf.data(), sizeof(Transform), (uint32_t)w.xf.size(), &tl, w.e2t.data(), (uint32_t)w.e2t.size()));
+    CHECK(gv_pool_bind(ctx, 0, w.meshes.data(), sizeof(Mesh), (uint32_t)w.meshes.size(), &ml));
+    CHECK(gv_pool_bind(ctx, 1, w.big.data(), sizeof(BigMesh), (uint32_t)w.big.size(), &ml));
+}
+
+static void check_permutation(GvCtx* ctx, uint32_t pool, uint32_t n)
+{
+    std::vector<uint32_t> slots(n, GV_NONE);
+    CHECK(gv_pool_mirror_slots(ctx, pool, slots.data(), n));
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t s : slots) {
+        if (s >= n || seen[s]) {
+            std::fprintf(stderr, "pool %u: the mirror order is not a permutation of its %u slots\n", pool, n);
+            std::exit(1);
+        }
+        seen[s] = 1;
+    }
+}
+
+static void frame(GvCtx* ctx, uint32_t pools, bool hiz, bool sort)
+{
+    GvView views[3] = {make_view(-1, hiz ? 1 : 0, 1), make_view(0, 0, 1), make_view(1, 0, 1)};
+    for (uint32_t p = 0; p < pools; p++) {
+        CHECK(gv_cull(ctx, p, views, p == 0 ? 3u : 1u));
+        if (sort)
+            CHECK(gv_pool_sort(ctx, p, 0, p & 1));
+    }
+    for (uint32_t p = 0; p < pools; p++) {
+        GvResult r{};
+        CHECK(gv_pool_results_fetch(ctx, p, 0, 1, &r));
+        if (r.draw_count != 0) {  // kernels are no-ops and device memory is zeroed
+            std::fprintf(stderr, "draw_count %u from no-op kernels\n", r.draw_count);
+            std::exit(1);
+        }
+        uint32_t count = 7;
+        CHECK(gv_pool_result_count(ctx, p, 0, &count));
+        GvDeviceResult d{};
+        CHECK(gv_pool_results_device(ctx, p, 0, &d));
+    }
+}
+
+static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
+{
+    GvConfig cfg{(uint32_t)sizeof(GvConfig), 0, GV_HIZ_RULE_REFERENCE, config_flags};
+    GvCtx* ctx = nullptr;
+    if (gv_create(&cfg, &ctx) != GV_OK) {
+        std::fprintf(stderr, "gv_create: %s\n", gv_last_error(nullptr));
+        std::exit(1);
+    }
+    World w;
+    w.build(n, depth);
+    const GvView one = make_view(-1, 0, 1);
+    // ---- calls out of order / bad arguments ----
+    EXPECT(gv_cull(ctx, 0, &one, 1), GV_E_STATE);
+    EXPECT(gv_cull(ctx, GV_MAX_POOLS, &one, 1), GV_E_ARG);
+    EXPECT(gv_hiz_rebuild(ctx), GV_E_STATE);
+    {
+        GvTransformLayout tl = transform_layout();
+        EXPECT(gv_transform_bind(ctx, w.xf.data(), 8, (uint32_t)w.xf.size(), &tl, w.e2t.data(), (uint32_t)w.e2t.size()), GV_E_ARG);
+        GvMeshLayout ml = mesh_layout();
+        EXPECT(gv_pool_bind(ctx, 0, w.meshes.data(), 16, (uint32_t)w.meshes.size(), &ml), GV_E_ARG);
+        EXPECT(gv_mark_dirty(ctx, 9, 0, 1), GV_E_ARG);
+    }
+    // ---- first build, both pools ----
+    bind_all(ctx, w);
+    CHECK(gv_hierarchy_rebuild(ctx));
+    check_permutation(ctx, 0, (uint32_t)w.meshes.size());
+    check_permutation(ctx, 1, (uint32_t)w.big.size());
+    frame(ctx, 2, false, false);
+    // ---- Hi-Z builds: sizes that take every kernel path's host logic, host and "device" memory ----
+    for (const auto& size : {std::pair<uint32_t, uint32_t>{256, 128}, {135, 77}, {1, 1}, {1920, 1080}, {64, 4096}}) {
+        std::vector<float> depth_image((size_t)size.first * size.second, 0.25f);
+        CHECK(gv_hiz_build(ctx, depth_image.data(), size.first, size.second, GV_MEM_HOST));
+        uint32_t mips = 0;
+        CHECK(gv_hiz_mip_count(ctx, &mips));
+        for (uint32_t level = 1; level < mips; level++) {
+            uint32_t lw = 0, lh = 0;
+            std::vector<float> pairs((size_t)std::max(size.first >> level, 1u) * std::max(size.second >> level, 1u) * 2);
+            CHECK(gv_hiz_read_level(ctx, level, pairs.data(), &lw, &lh));
+        }
+        CHECK(gv_hiz_rebuild(ctx));
+        frame(ctx, 1, true, true);
+    }
+    EXPECT(gv_hiz_build(ctx, nullptr, 4, 4, GV_MEM_HOST), GV_E_ARG);
+    // ---- sweeps and the world-matrix cache ----
+    for (uint32_t mode : {GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_INCREMENTAL, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU}) {
+        CHECK(gv_sweep(ctx, mode));
+        frame(ctx, 2, false, false);
+    }
+    CHECK(gv_sweep(ctx, GV_SWEEP_VALU));
+    {
+        std::vector<float> world((size_t)1000 * 12);
+        CHECK(gv_get_world(ctx, n / 2, 1000, world.data()));
+        EXPECT(gv_get_world(ctx, n - 10, 1000, world.data()), GV_E_ARG);
+    }
+    // ---- dirty ranges: few, thousands of scattered ones, large (device-side gather), everything; meshes too ----
+    std::mt19937 rng(99);
+    for (uint32_t count : {3u, 40u, 3000u}) {
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t s = rng() % n;
+            w.xf[s].position[0] += 1.0f;
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, s, 1 + k % 3 < n - s ? 1 + k % 3 : 1));
+            const uint32_t ms = rng() % n;
+            w.meshes[ms].aabbMax[1] += 0.1f;
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, ms, 1));
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, (1u << 28) | (rng() % (uint32_t)w.big.size()), 1));
+        }
+        CHECK(gv_sweep(ctx, GV_SWEEP_INCREMENTAL));
+        frame(ctx, 2, false, false);
+    }
+    CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, n / 4, n / 3));       // one large range: raw AoS span + device gather
+    CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, n - 5, 100));          // reaches past the pool: clamped
+    CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0xFFFFFFF0u, 0x40u));  // wraps: saturated, then clamped
+    CHECK(gv_sync(ctx));
+    CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 0, n));                // most of the pool: the dense forms
+    CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, 0, n));
+    frame(ctx, 2, false, true);
+    // ---- re-parenting (ranged GV_DIRTY_HIERARCHY), a cycle (rejected), its repair ----
+    for (uint32_t k = 0; k < 50; k++) {
+        const uint32_t s = n / 2 + rng() % (n / 2), p = rng() % (n / 2);
+        if (w.xf[s].entity && w.xf[p].entity) {
+            w.xf[s].parent = w.xf[p].entity;
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, s, 1));
+        }
+    }
+    CHECK(gv_sync(ctx));
+    {
+        uint32_t a = 10, b = 11;
+        while (!w.xf[a].entity || !w.xf[b].entity)
+            a += 2, b += 2;
+        const uint32_t pa = w.xf[a].parent, pb = w.xf[b].parent;
+        w.xf[a].parent = w.xf[b].entity;
+        w.xf[b].parent = w.xf[a].entity;
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, a, 2));
+        EXPECT(gv_sync(ctx), GV_E_ARG);  // a cycle
+        w.xf[a].parent = pa;
+        w.xf[b].parent = pb;
+        CHECK(gv_hierarchy_rebuild(ctx));
+    }
+    // ---- pools that grow (appended to the mirror), move, and shrink (rebuilt) ----
+    for (int round = 0; round < 6; round++) {
+        const uint32_t old = (uint32_t)w.xf.size(), grown = old + old / 20 + 3;
+        World bigger;
+        bigger.rng.seed(round);
+        bigger.build(grown, depth);
+        for (uint32_t i = 0; i < old; i++) {  // the old slots keep their contents (at new addresses)
+            bigger.xf[i] = w.xf[i];
+            bigger.meshes[i] = w.meshes[i];
+        }
+        bigger.e2t.assign(grown + 1, GV_NONE);
+        for (uint32_t i = 0; i < grown; i++)
+            if (bigger.xf[i].entity) {
+                bigger.xf[i].entity = i + 1;
+                bigger.meshes[i].entity = i + 1;
+                if (i >= old)
+                    bigger.xf[i].parent = 0;
+                bigger.e2t[i + 1] = i;
+            }
+        w.xf.swap(bigger.xf);
+        w.meshes.swap(bigger.meshes);
+        w.e2t.swap(bigger.e2t);
+        bind_all(ctx, w);
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, old, grown - old));
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, old, grown - old));
+        frame(ctx, 2, false, round & 1);
+        check_permutation(ctx, 0, (uint32_t)w.meshes.size());
+    }
+    w.build(n / 2, depth);  // shrinks: rebuilt
+    bind_all(ctx, w);
+    frame(ctx, 2, false, false);
+    check_permutation(ctx, 0, (uint32_t)w.meshes.size());
+    // ---- ready columns ----
+    {
+        std::vector<uint8_t> ready8(w.meshes.size(), 1);
+        std::vector<uint32_t> ready32(w.meshes.size(), 2);
+        ready8[5] = 0;
+        CHECK(gv_pool_bind_ready(ctx, 0, ready8.data(), 1, 1));
+        frame(ctx, 1, false, false);
+        CHECK(gv_pool_bind_ready(ctx, 0, ready32.data(), 4, 4));
+        frame(ctx, 1, false, false);
+        EXPECT(gv_pool_bind_ready(ctx, 0, ready32.data(), 4, 2), GV_E_ARG);
+        CHECK(gv_pool_bind_ready(ctx, 0, nullptr, 0, 0));
+    }
+    // ---- records in the engine's struct; the engine's own array as the target: set, grow + replace, too small, removed ----
+    {
+        const GvRecordLayout layout{64, 0, 8, 56, GV_NONE, (uint32_t)sizeof(Mesh), 0};
+        CHECK(gv_pool_set_record_layout(ctx, 0, &layout));
+        const GvRecordLayout bad{60, 0, 8, 56, GV_NONE, (uint32_t)sizeof(Mesh), 0};
+        EXPECT(gv_pool_set_record_layout(ctx, 0, &bad), GV_E_ARG);
+        std::vector<uint8_t> a(w.meshes.size() * 64 + 16), b(w.meshes.size() * 64 * 2 + 16), small(w.meshes.size() * 64 - 64 + 16);
+        auto aligned = [](std::vector<uint8_t>& v) { return reinterpret_cast<void*>(((uintptr_t)v.data() + 15) & ~(uintptr_t)15); };
+        CHECK(gv_pool_set_record_target(ctx, 0, 0, aligned(a), a.size() - 16));
+        frame(ctx, 1, false, true);
+        const void* records = nullptr;
+        uint32_t count = 1;
+        CHECK(gv_pool_results_records(ctx, 0, 0, &records, &count));
+        const uint32_t* bases = nullptr;
+        CHECK(gv_pool_results_instance_bases(ctx, 0, 0, &bases, &count));
+        CHECK(gv_pool_set_record_target(ctx, 0, 0, aligned(b), b.size() - 16));  // replaced while the old one is still allocated
+        frame(ctx, 1, false, false);
+        CHECK(gv_pool_set_record_target(ctx, 0, 0, aligned(small), small.size() - 16));
+        GvView v = make_view(-1, 0, 1);
+        CHECK(gv_cull(ctx, 0, &v, 1));
+        GvResult r{};
+        EXPECT(gv_pool_results_fetch(ctx, 0, 0, 0, &r), GV_E_ARG);  // smaller than occupancy * stride
+        EXPECT(gv_pool_set_record_target(ctx, 0, 0, reinterpret_cast<uint8_t*>(aligned(a)) + 4, 64), GV_E_ARG);  // misaligned
+        CHECK(gv_pool_set_record_target(ctx, 0, 0, nullptr, 0));
+        CHECK(gv_pool_set_record_layout(ctx, 0, nullptr));
+        frame(ctx, 1, false, true);
+    }
+    // ---- exchange helpers: index map, device copies into caller memory ----
+    {
+        std::vector<uint32_t> global_ids(w.meshes.size());
+        for (size_t i = 0; i < global_ids.size(); i++)
+            global_ids[i] = (uint32_t)(i * 3);
+        CHECK(gv_pool_set_index_map(ctx, 0, global_ids.data(), (uint32_t)global_ids.size()));
+        GvView v = make_view(-1, 0, 1);
+        CHECK(gv_cull(ctx, 0, &v, 1));
+        std::vector<uint32_t> dst(w.meshes.size() + 1), words((w.meshes.size() + 31) / 32 + 1);
+        CHECK(gv_results_copy_idx_device(ctx, 0, dst.data(), (uint32_t)w.meshes.size(), 100));
+        CHECK(gv_results_copy_shard_device(ctx, 0, dst.data(), (uint32_t)w.meshes.size(), 100));
+        CHECK(gv_results_copy_mask_device(ctx, 0, words.data(), (uint32_t)words.size() - 1));
+        EXPECT(gv_results_copy_mask_device(ctx, 0, words.data(), 1), GV_E_ARG);
+        CHECK(gv_pool_set_index_map(ctx, 0, nullptr, 0));
+        CHECK(gv_wait(ctx));
+    }
+    // ---- column (SoA) binds: every field its own array, padded strides ----
+    {
+        const uint32_t m = (uint32_t)w.xf.size();
+        std::vector<uint32_t> entity(m), parent(m);
+        std::vector<float> pos((size_t)m * 4), scl((size_t)m * 3), rot((size_t)m * 4), mn((size_t)m * 3), mx((size_t)m * 5);
+        std::vector<uint8_t> sa(m), aa(m), wa(m), en(m), vis(m);
+        for (uint32_t i = 0; i < m; i++) {
+            entity[i] = w.xf[i].entity;
+            parent[i] = w.xf[i].parent;
+            for (int k = 0; k < 3; k++) {
+                pos[(size_t)i * 4 + k] = w.xf[i].position[k];
+                scl[(size_t)i * 3 + k] = w.xf[i].scale[k];
+                mn[(size_t)i * 3 + k] = w.meshes[i].aabbMin[k];
+                mx[(size_t)i * 5 + k] = w.meshes[i].aabbMax[k];
+            }
+            for (int k = 0; k < 4; k++)
+                rot[(size_t)i * 4 + k] = w.xf[i].rotation[k];
+            sa[i] = w.xf[i].selfActive, aa[i] = w.xf[i].ancestorsActive, wa[i] = w.xf[i].modelWithAncestors, en[i] = w.meshes[i].isEnabled;
+        }
+        GvTransformColumns tc{{entity.data(), 4}, {parent.data(), 4}, {pos.data(), 16}, {scl.data(), 12}, {rot.data(), 16}, {sa.data(), 1}, {aa.data(), 1}, {wa.data(), 1}};
+        GvMeshColumns mc{{entity.data(), 4}, {en.data(), 1}, {mn.data(), 12}, {mx.data(), 20}, vis.data(), 1};
+        CHECK(gv_transform_bind_columns(ctx, &tc, m, w.e2t.data(), (uint32_t)w.e2t.size()));
+        CHECK(gv_pool_bind_columns(ctx, 0, &mc, m));
+        CHECK(gv_hierarchy_rebuild(ctx));
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, m / 3, m / 2));  // columns: the host gather, whatever the size
+        frame(ctx, 1, false, false);
+        GvTransformColumns broken = tc;
+        broken.rotation.stride = 8;
+        EXPECT(gv_transform_bind_columns(ctx, &broken, m, w.e2t.data(), (uint32_t)w.e2t.size()), GV_E_ARG);
+        bind_all(ctx, w);
+        CHECK(gv_hierarchy_rebuild(ctx));
+    }
+    // ---- a tick of engine-sized pools: recorded culls, changes inside the batch, deferred sorts ----
+    {
+        World small;
+        small.build(9000, depth);
+        const GvTransformLayout tl = transform_layout();
+        const GvMeshLayout ml = mesh_layout();
+        CHECK(gv_transform_bind(ctx, small.xf.data(), sizeof(Transform), (uint32_t)small.xf.size(), &tl, small.e2t.data(), (uint32_t)small.e2t.size()));
+        for (uint32_t p = 0; p < 5; p++)
+            CHECK(gv_pool_bind(ctx, p, small.meshes.data(), sizeof(Mesh), (uint32_t)small.meshes.size() - p * 1000, &ml));
+        for (int tick = 0; tick < 4; tick++) {
+            CHECK(gv_cull_batch_begin(ctx));
+            GvView views[4] = {make_view(-1, 0, 1), make_view(0, 0, 1), make_view(1, 0, 1), make_view(2, 0, 1)};
+            for (uint32_t p = 0; p < 5; p++) {
+                CHECK(gv_cull(ctx, p, views, 1 + p % 4));
+                for (uint32_t v = 0; v < 1 + p % 4; v++)
+                    CHECK(gv_pool_sort(ctx, p, v, v & 1));
+                if (tick == 2 && p == 2) {  // a change in the middle of the batch
+                    CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 100, 50));
+                    CHECK(gv_pool_bind(ctx, 1, small.meshes.data(), sizeof(Mesh), 4000, &ml));
+                }
+            }
+            for (uint32_t p = 0; p < 5; p++)
+                for (uint32_t v = 0; v < 1 + p % 4; v++) {
+                    GvResult r{};
+                    if (tick == 2 && p == 1 && v == 0)  // its pool was re-bound (smaller) after the cull: no write-back into it
+                        EXPECT(gv_pool_results_fetch(ctx, p, v, 1, &r), GV_E_STATE);
+                    CHECK(gv_pool_results_fetch(ctx, p, v, (tick != 2 || p != 1) && v == 0, &r));
+                }
+            CHECK(gv_cull_batch_end(ctx));
+        }
+        for (uint32_t p = 2; p < 5; p++)  // (these systems go away with `small`: an empty pool needs no memory)
+            CHECK(gv_pool_bind(ctx, p, nullptr, sizeof(Mesh), 0, &ml));
+        bind_all(ctx, w);
+        CHECK(gv_hierarchy_rebuild(ctx));
+    }
+    // ---- scene ingest -> columns -> bind; tiles ----
+    {
+        std::string text = "{\"version\":\"0.0.1\",\"entities\":[";
+        for (int e = 0; e < 300; e++) {
+            char buf[512];
+            std::snprintf(buf, sizeof(buf),
+                          "%s{\"components\":[{\".type\":\"Transform\",\"uid\":\"AAAAAAAAA%02d\",\"position\":{\"x\":%d.5,\"y\":%d.25,\"z\":-%d.0}%s},"
+                          "{\".type\":\"Model\",\"aabb\":{\"min\":{\"x\":-1.0,\"y\":-1.0,\"z\":-1.0},\"max\":{\"x\":1.0,\"y\":2.0,\"z\":1.0}}}]}",
+                          e ? "," : "", e % 64, e * 7 % 900 - 450, e * 3 % 700 - 350, e * 11 % 800,
+                          e % 5 == 4 ? ",\"parent\":\"AAAAAAAAA00\"" : "");
+            text += buf;
+        }
+        text += "]}";
+        const GvScenePool pools[1] = {{"Model", 0}};
+        GvScene* scene = nullptr;
+        char error[256];
+        const int rc = gv_scene_parse_json(text.c_str(), text.size(), pools, 1, GV_SCENE_ADD_ROOT_ENTITY, &scene, error, sizeof(error));
+        if (rc != GV_OK) {
+            std::fprintf(stderr, "scene: %s\n", error);
+            std::exit(1);
+        }
+        CHECK(gv_scene_bind(ctx, scene));
+        frame(ctx, 1, false, true);
+        const uint32_t grid[3] = {2, 2, 1};
+        for (uint32_t t = 0; t < 4; t++) {
+            GvScene* tile = nullptr;
+            CHECK(gv_scene_extract_tile(scene, grid, 1000.0, t, &tile));
+            CHECK(gv_scene_bind(ctx, tile));
+            frame(ctx, 1, false, false);
+            gv_scene_destroy(tile);
+            CHECK(gv_scene_bind(ctx, scene));
+        }
+        GvScene* none = nullptr;
+        EXPECT(gv_scene_parse_json(text.c_str(), text.size() / 2, pools, 1, 0, &none, error, sizeof(error)), GV_E_ARG);
+        bind_all(ctx, w);
+        CHECK(gv_hierarchy_rebuild(ctx));
+        gv_scene_destroy(scene);
+    }
+    GvStats stats{};
+    CHECK(gv_stats(ctx, &stats));
+    CHECK(gv_stats_reset(ctx));
+    gv_destroy(ctx);
+}
+
+int main()
+{
+    // spatially ordered mirror (default), pool-slot order, forced block bounds, linear scan; flat and 4-deep
+    exercise(0, 40000, 3);
+    exercise(GV_CONFIG_KEEP_SLOT_ORDER, 30000, 0);
+    exercise(GV_CONFIG_BLOCK_BOUNDS | GV_CONFIG_PROFILE_EVENTS, 30000, 2);
+    exercise(GV_CONFIG_LINEAR_SCAN | GV_CONFIG_HIZ_RG16F | GV_CONFIG_KEEP_SLOT_ORDER, 300000, 3);  // (above the device-gather and auto-bounds sizes)
+    std::printf("host orchestration: ok\n");
+    return 0;
+}

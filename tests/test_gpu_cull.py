@@ -1612,3 +1612,21 @@ def test_thousands_of_scattered_dirty_marks_on_a_slot_order_mirror(gpu_slot_orde
         got_vis = sc.meshes["isVisible"].copy()
         exp = oracle.prepare_meshes(sc.meshes, sc.transforms, sc.entity_to_transform, view)
         assert_same(got, got_vis, exp, sc.meshes["isVisible"].copy())
+
+
+@pytest.mark.parametrize("case", ["grow", "replace", "early_free"])
+def test_record_target_lifetime_through_the_bare_c_abi(case):
+    """gv_pool_set_record_target without the shim (tools/record_target_probe.py, its own process: the array is an anonymous
+    mapping the script unmaps itself): `grow` — clear the target, free the array, set a larger one, every frame; `replace` — set
+    the new array while the old one is still mapped, free it afterwards; `early_free` — the array is unmapped while it is still
+    the target: the next gv_pool_set_record_target reports GV_E_STATE every time (the new target is in place, the frames go on)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "record_target_probe.py"), case, "8"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert f"{case}: 8 frames ok" in p.stdout
+    if case == "early_free":
+        assert "lost registration reported 8 times" in p.stdout
