@@ -272,16 +272,20 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         if ((rc = world_current(ctx)) != GV_OK)  // (the fused form below writes every slot of the same buffer)
             return rc;
     }
-    // GV_CONFIG_BLOCK_BOUNDS: workgroup boxes are (re)built when the mirror of this pool is clean, or has just changed
-    // after a quiet frame; a pool that changes frame after frame (dynamic scene) is culled without them
+    // What is derived from a pool AT REST — block bounds, emit seeds — is (re)built when the pool's mirror is clean, or has just
+    // changed after a quiet frame; a pool that changes frame after frame (dynamic scene) goes without
+    const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
+    const bool may_rebuild = !(changed && p.changed_prev);
+    p.changed_prev = changed;
+    p.seen_epoch = p.epoch;
+    p.seen_xf_epoch = ctx->xf_epoch;
     BlockBounds bounds;
     bool use_bounds = false;
     const bool bounds_wanted = (ctx->config.flags & GV_CONFIG_BLOCK_BOUNDS) ||
                                (!(ctx->config.flags & GV_CONFIG_LINEAR_SCAN) && p.occupancy > kAutoBoundsMinSlots);
     if (bounds_wanted && p.occupancy != 0 && !fused) {
-        const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
-        if (!current && !(changed && p.changed_prev)) {
+        if (!current && may_rebuild) {
             const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
             GV_HIP(ctx, p.d_blk_lo.reserve(nb));
             GV_HIP(ctx, p.d_blk_hi.reserve(nb));
@@ -291,9 +295,6 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             p.bounds_xf_epoch = ctx->xf_epoch;
             current = true;
         }
-        p.changed_prev = changed;
-        p.seen_epoch = p.epoch;
-        p.seen_xf_epoch = ctx->xf_epoch;
         if (current) {
             const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
             GV_HIP(ctx, ctx->d_examined.reserve(nb));
@@ -306,6 +307,26 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             }
             use_bounds = true;
         }
+    }
+    // emit seeds: a flat, exactly paired pool of some size whose views want records (gv_kernels.hpp)
+    const EmitSeed* seeds = nullptr;
+    static const bool seeds_allowed = getenv("GV_DEBUG_NO_EMIT_SEEDS") == nullptr;
+    bool wants_records = false;
+    for (uint32_t v = 0; v < view_count; v++)
+        wants_records = wants_records || ctx->views[pool_id][v].emitted;
+    if (seeds_allowed && wants_records && !batched && p.occupancy >= kEmitSeedMinSlots && mesh.mapping == kMapExact && xf.max_depth == 0 &&
+        mesh.count <= xf.count) {
+        bool current = p.seed_epoch == p.epoch && p.seed_xf_epoch == ctx->xf_epoch && p.d_seed.cap >= p.occupancy;
+        if (!current && may_rebuild) {
+            GV_HIP(ctx, p.d_seed.reserve(p.occupancy));
+            KernelTimer t(ctx, GV_K_SWEEP);
+            GV_HIP(ctx, launch_emit_seeds(mesh, xf, p.d_seed.ptr, ctx->stream));
+            p.seed_epoch = p.epoch;
+            p.seed_xf_epoch = ctx->xf_epoch;
+            current = true;
+        }
+        if (current)
+            seeds = p.d_seed.ptr;
     }
     // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
     // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
@@ -394,7 +415,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                 if ((rc = emit_flags_ready(ctx, vs)) != GV_OK)
                     return rc;
                 KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world));
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, true, std::max(chunks, vs.stale_chunks[other]), emit_world, seeds));
                 vs.stale_chunks[other] = 0;
                 vs.stale_chunks[cur] = chunks;
                 vs.count_parity = other;
@@ -407,7 +428,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             if (ctx->views[pool_id][v].emitted) {
                 ctx->views[pool_id][v].vis_flags_current = false;  // (the scan-path emit writes every byte and keeps no flags)
                 KernelTimer t(ctx, GV_K_EMIT);
-                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world));
+                GV_HIP(ctx, launch_emit(mesh, xf, vps[v], vbs[v], ctx->stream, false, 0, emit_world, seeds));
             }
         }
     }
@@ -511,9 +532,9 @@ int flush_recorded_culls(GvCtx* ctx, uint32_t pool)
 }
 
 // gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
-static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
+// Buffers and launch arguments of a large sort of `vs`: inputs = the view's current records, outputs = its alternate set.
+static int sort_buffers_of(GvCtx* ctx, ViewState& vs, SortBuffers& b)
 {
-    GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = vs.occupancy;  // upper bound of draw_count, known without a readback
     const size_t nblocks = sort_tile_count((uint32_t)n);
     GV_HIP(ctx, vs.alt_idx.reserve(n));
@@ -537,7 +558,7 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
         vs.sort_parity = 0;
     }
     GV_HIP(ctx, vs.sort_ranks.reserve(n));
-    SortBuffers b;
+    b = SortBuffers{};
     b.count = vs.draw_count.ptr;
     b.idx_in = vs.visible_idx.ptr;
     b.model_in = vs.baked_model.ptr;
@@ -554,13 +575,78 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     }
     b.tile_hist = vs.sort_hist.ptr + 2 * set_words;
     b.parity = vs.sort_parity;
+    return GV_OK;
+}
+
+// A value-bucket sort (launch_sort_buckets) reports through a pinned word whether every bucket fitted its workgroup's LDS. Before
+// anybody reads the records of such a sort the word is looked at — one stream synchronisation — and a frame whose keys were
+// bunched beyond that (many equal distances; a frame unlike the one before) is sorted again by the radix passes, from the
+// untouched inputs. The view then stays with the radix passes for a while.
+int verify_sort(GvCtx* ctx, ViewState& vs)
+{
+    if (!vs.sort_check_pending)
+        return GV_OK;
+    vs.sort_check_pending = false;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!vs.h_sort_status.ptr[0])
+        return GV_OK;
+    // the records in emission order are in the alternate set now (sort_large swapped): sort them back into the current set
+    std::swap(vs.visible_idx, vs.alt_idx);
+    std::swap(vs.baked_model, vs.alt_model);
+    std::swap(vs.distance_sq, vs.alt_dist);
+    SortBuffers b;
+    if (int rc = sort_buffers_of(ctx, vs, b))
+        return rc;
+    vs.sort_parity ^= 1u;
+    {
+        KernelTimer t(ctx, GV_K_SORT);
+        GV_HIP(ctx, launch_sort(b, vs.occupancy, vs.sort_descending, ctx->stream, kSortRadixOnly));
+    }
+    std::swap(vs.visible_idx, vs.alt_idx);
+    std::swap(vs.baked_model, vs.alt_model);
+    std::swap(vs.distance_sq, vs.alt_dist);
+    vs.bucket_cooldown = 120;
+    return GV_OK;
+}
+
+// gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
+static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = verify_sort(ctx, vs))  // (a second sort of the same records: the first one has to be whole)
+        return rc;
+    const size_t n = vs.occupancy;
+    SortBuffers b;
+    if (int rc = sort_buffers_of(ctx, vs, b))
+        return rc;
     // the previous frame's count says what to enqueue for a mid-sized pool: a short list gets the rank sort alone
     static const bool hints = getenv("GV_DEBUG_SORT_NO_HINT") == nullptr;
     const SortMode mode = !hints || vs.count_hint == 0xFFFFFFFFu ? kSortBoth
                           : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
                           : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
-    if (!sort_is_rank_only((uint32_t)n, mode))
+    // long lists go through value buckets (four launches) instead of the radix passes (eight) unless this view's keys
+    // recently bunched up beyond what a bucket holds (verify_sort)
+    static const bool buckets_allowed = getenv("GV_DEBUG_SORT_NO_BUCKETS") == nullptr;
+    const bool buckets = buckets_allowed && !sort_is_rank_only((uint32_t)n, mode) && vs.bucket_cooldown == 0;
+    if (vs.bucket_cooldown)
+        vs.bucket_cooldown--;
+    if (buckets) {
+        const size_t words = sort_bucket_words() + sort_minmax_words((uint32_t)n);
+        if (words > vs.sort_bucket.cap) {
+            GV_HIP(ctx, vs.sort_bucket.reserve(words));
+            GV_HIP(ctx, hipMemsetAsync(vs.sort_bucket.ptr, 0, sort_bucket_words() * sizeof(uint32_t), ctx->stream));
+        }
+        GV_HIP(ctx, vs.h_sort_status.reserve(4));
+        vs.h_sort_status.ptr[0] = 0;  // (nothing of this view is in flight: verify_sort above)
+        b.bucket_words = vs.sort_bucket.ptr;
+        b.bucket_minmax = vs.sort_bucket.ptr + sort_bucket_words();
+        b.bucket_status = vs.h_sort_status.ptr;
+        vs.sort_check_pending = true;
+        vs.sort_descending = descending;
+    } else if (!sort_is_rank_only((uint32_t)n, mode)) {
         vs.sort_parity ^= 1u;  // the radix passes leave the other set of counters zeroed for the next sort
+    }
     {
         KernelTimer t(ctx, GV_K_SORT);
         GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream, mode));
@@ -719,8 +805,14 @@ int flush_sorts(GvCtx* ctx)
                 widest = std::max(widest, vs.occupancy);
                 taken[views++] = &vs;
             }
-        if (views == 0)
+        if (views == 0) {
+            for (auto& per_pool : ctx->views)  // large sorts done as value buckets: whole, or redone, before anybody reads them
+                for (ViewState& w : per_pool)
+                    if (w.valid && w.sort_check_pending)
+                        if (int rc = verify_sort(ctx, w))
+                            return rc;
             return GV_OK;
+        }
         GV_HIP(ctx, hipSetDevice(ctx->device));
         {
             ZoneScope zone("Meshes Sort");
@@ -817,19 +909,23 @@ int gv_create(const GvConfig* config, GvCtx** out_ctx)
     return GV_OK;
 }
 
-// false: the range was page-locked and the runtime no longer knows it — the caller let go of the memory (freed it, or a vector
-// reallocated) while it was still the record target; gv_pool_set_record_target reports that (include/garden_vis.h: the range must
-// stay allocated until it is replaced, removed or the context destroyed)
+// Is every page of [p, p + bytes) still mapped? (msync fails with ENOMEM otherwise.) A freed std::vector of this size — the
+// engine's combinedMeshes that was let go, or reallocated, while it was still the record target — is an unmapped range.
+static bool range_mapped(const void* p, size_t bytes)
+{
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = (uintptr_t)p & ~(page - 1), hi = ((uintptr_t)p + bytes + page - 1) & ~(page - 1);
+    return msync(reinterpret_cast<void*>(lo), hi - lo, MS_ASYNC) == 0;
+}
+
+// false: the caller let go of the memory while it was still the record target (include/garden_vis.h: the range must stay
+// allocated until it is replaced, removed or the context destroyed); gv_pool_set_record_target reports that
 static bool release_record_target(PoolState::RecordTarget& target)
 {
     bool intact = true;
-    if (target.dev) {
-        // the runtime un-registers by address and does not notice that the pages are gone (measured: hipHostUnregister of an
-        // unmapped range succeeds), so the mapping is asked directly: msync fails with ENOMEM when any page of the range is not
-        // mapped any more — which is what a freed (munmap'ed) std::vector of this size looks like
-        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
-        const uintptr_t lo = (uintptr_t)target.host & ~(page - 1), hi = ((uintptr_t)target.host + target.bytes + page - 1) & ~(page - 1);
-        intact = msync(reinterpret_cast<void*>(lo), hi - lo, MS_ASYNC) == 0;
+    if (target.host)
+        intact = range_mapped(target.host, target.bytes);
+    if (target.dev) {  // (GV_DEBUG_RECORD_TARGET_PAGE_LOCK only)
         intact = (hipHostUnregister(target.host) == hipSuccess) && intact;
         (void)hipGetLastError();
     }
@@ -855,13 +951,13 @@ void gv_destroy(GvCtx* ctx)
     for (auto& p : ctx->pools) {
         for (auto& target : p.record_target)
             release_record_target(target);
-        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release(); p.d_kept.release(); p.d_kept_flag.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_inv.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release(); p.d_seed.release(); p.d_kept.release(); p.d_kept_flag.release();
     }
     for (auto& per_pool : ctx->views)
       for (auto& v : per_pool) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.vis_flags.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
-        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release();
+        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release(); v.sort_bucket.release(); v.h_sort_status.release();
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); v.sort_slots[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
@@ -869,6 +965,7 @@ void gv_destroy(GvCtx* ctx)
         v.tile_status.release(); v.tile_ticket.release();
     }
     ctx->d_world.release(); ctx->d_xdirty.release(); ctx->d_raw.release(); ctx->d_examined.release();
+    ctx->d_e2t.release(); ctx->d_flag.release(); ctx->h_flag.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_raw[k].release();
         if (ctx->raw_done[k])
@@ -1111,6 +1208,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.valid = true;
         vs.published = false, vs.records_fetched = false;
         vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
+        vs.sort_check_pending = false;
         vs.ballots_current = true;  // every cull launch but the one-launch cull + emit of a small pool writes them
         build_view_params(views[v], &vps[v]);
         if (p.occupancy == 0)
@@ -1262,7 +1360,11 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             for (auto& per_pool : ctx->views)  // record targets that could not be page-locked
                 for (ViewState& w : per_pool)
                     if (w.valid && w.published && w.records_staged) {
-                        memcpy(w.records_at, w.h_records.ptr, (size_t)w.h_draw_count.ptr[0] * ctx->pools[w.pool_id].record_layout.stride);
+                        const size_t bytes = (size_t)w.h_draw_count.ptr[0] * ctx->pools[w.pool_id].record_layout.stride;
+                        if (bytes && !range_mapped(w.records_at, bytes))
+                            return ctx->fail(GV_E_STATE, "gv_results_fetch: the record target of pool %u is not mapped any more (freed while it was "
+                                                         "still the target?)", w.pool_id);
+                        memcpy(w.records_at, w.h_records.ptr, bytes);
                         w.records_staged = false;
                     }
         }
@@ -1309,8 +1411,12 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             GV_HIP(ctx, hipMemcpyAsync(vs.h_is_visible.ptr, src, vs.occupancy, hipMemcpyDeviceToHost, ctx->stream));
         }
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (staged_for)
+        if (staged_for) {
+            if (!range_mapped(staged_for, (size_t)count * pool.record_layout.stride))
+                return ctx->fail(GV_E_STATE, "gv_results_fetch: the record target of pool %u is not mapped any more (freed while it was still "
+                                             "the target?)", pool_id);
             memcpy(staged_for, vs.h_records.ptr, (size_t)count * pool.record_layout.stride);
+        }
     }
     vs.count_hint = count;  // (what the next frame's sort of this view expects)
     memset(out, 0, sizeof(*out));
@@ -1436,16 +1542,23 @@ int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index,
     // (the new target is installed either way; a lost registration is reported once it is)
     const int verdict = intact ? GV_OK
                                : ctx->fail(GV_E_STATE, "gv_pool_set_record_target: the previous record target of pool %u view %u was no longer "
-                                                       "page-locked when it was let go: the range must stay allocated until it is replaced or removed "
+                                                       "mapped when it was let go: the range must stay allocated until it is replaced or removed "
                                                        "(the new target is in place)", pool_id, view_index);
     if (!records)
         return verdict;
     target.host = static_cast<uint8_t*>(records);
     target.bytes = bytes;
+    // The caller's array is NOT page-locked: the records arrive in the library's own pinned buffer and the fetch copies them
+    // into the array (one memcpy of draw_count records: 3.4 us at 10 k entities, ~50 us for the 1.4 MB of a 100 k-entity pool).
+    // Round 2 let the device write the array in place (hipHostRegister once per address): 4 us less per tick at 10 k entities —
+    // and, measured in round 3, the GPU test tier then ABORTED inside the runtime in 4 of 16 runs (tools/suite_soak.sh;
+    // profiles/r03_record_target_soak.txt), in an unrelated later copy into pageable memory that reused the addresses of an
+    // array that had been registered and un-registered: the same failure the mirror path showed in round 2 with page-locked
+    // application memory (3 of 10). Application memory is therefore never registered. GV_DEBUG_RECORD_TARGET_PAGE_LOCK=1
+    // brings the in-place form back for A/Bs.
+    static const bool page_lock = getenv("GV_DEBUG_RECORD_TARGET_PAGE_LOCK") != nullptr;
     void* dev = nullptr;
-    // page-locked once per (address, size): combinedMeshes is grown, never shrunk (mesh.cpp:377-395). A range that cannot be
-    // locked (it shares pages with another locked range, RLIMIT_MEMLOCK ...) is filled by a host copy at the fetch instead.
-    if (hipHostRegister(records, bytes, hipHostRegisterDefault) == hipSuccess) {
+    if (page_lock && hipHostRegister(records, bytes, hipHostRegisterDefault) == hipSuccess) {
         if (hipHostGetDevicePointer(&dev, records, 0) == hipSuccess && dev)
             target.dev = static_cast<uint8_t*>(dev);
         else

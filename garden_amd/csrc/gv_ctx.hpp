@@ -195,10 +195,14 @@ struct PoolState {
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
+    DeviceBuf<uint32_t> d_inv;   // inv on the device: the device-side gather of dirty mesh ranges (upload_meshes_device)
+    DirtyRange staging_stale;    // slots whose host staging entries lag behind the device (written by that path)
     DeviceBuf<uint32_t> d_index_map;  // gv_pool_set_index_map: pool slot -> the caller's global id (exchange shards)
     uint32_t index_map_count = 0;     // 0: none
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    DeviceBuf<EmitSeed> d_seed;    // emit seeds (gv_kernels.hpp), valid for (seed_xf_epoch, seed_epoch)
+    uint64_t seed_epoch = 0, seed_xf_epoch = 0;
     DeviceBuf<uint32_t> d_kept;    // [2 alternating counters, 2 words of padding | list entries] of launch_cull_listed
     DeviceBuf<uint8_t> d_kept_flag;  // per list entry (Hi-Z views)
     uint32_t kept_parity = 0;      // which counter the next classify launch adds into
@@ -251,6 +255,11 @@ struct ViewState {
     uint32_t sort_parity = 0;  // which of the two counter sets in sort_hist the next large sort uses (gv_sort.hip)
     size_t sort_set_words = 0; // size of one set as laid out in sort_hist (0: not initialised)
     DeviceBuf<uint16_t> sort_ranks;
+    DeviceBuf<uint32_t> sort_bucket;     // bucket counters + tile min / max keys of the value-bucket sort (launch_sort_buckets)
+    PinnedBuf<uint32_t> h_sort_status;   // [0] = 1: a bucket overflowed, the outputs are incomplete (verify_sort redoes the frame)
+    bool sort_check_pending = false;     // a bucket sort is in flight whose status word nobody has looked at yet
+    bool sort_descending = false;        // ... and its direction (for the redo)
+    uint32_t bucket_cooldown = 0;        // large sorts of this view that take the radix passes before buckets are tried again
     uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };
@@ -293,6 +302,9 @@ struct Context {
     PinnedBuf<uint8_t> h_raw[2];   // the library's own pinned chunks the span travels through (double-buffered)
     hipEvent_t raw_done[2] = {nullptr, nullptr};  // chunk buffer k may be rewritten once its last copy has run
     DirtyRange staging_stale;      // slots whose host staging entries lag behind the device (written by that path)
+    DeviceBuf<uint32_t> d_e2t;     // entity -> transform slot table on the device, refreshed by every device-side mesh gather
+    DeviceBuf<uint32_t> d_flag;    // one word: "a candidate no longer pairs with its own index" (aos_meshes_kernel)
+    PinnedBuf<uint32_t> h_flag;
     bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // the env switches the path off (debugging)
     // scratch of the scattered (dirty-range) host upload path
     PinnedBuf<uint32_t> sc_idx, sc_u32;

@@ -1040,6 +1040,7 @@ struct EmitArgs {
     uint32_t direct_stores; // debug A/B: every lane stores its own 48-byte model (the round-1 form)
     const float4* world;    // world matrices of every transform entry (3 float4 each) when a sweep of the CURRENT mirror
                             // has just written them (gv_sweep / the fused sweep + cull), else NULL
+    const EmitSeed* seeds;  // one 64-byte record per mirror entry of a flat, exactly paired pool at rest (gv_kernels.hpp), else NULL
 };
 
 // The camera-relative model (bakedModel) of visible mirror entry i (mesh.cpp:169-173). Visible entries passed every
@@ -1052,7 +1053,12 @@ __device__ __forceinline__ Mat34 record_model(const EmitArgs& args, uint32_t i)
     // chains at all
     const bool chains = args.xf.max_depth != 0;  // uniform
     Mat34 world;
-    if (args.world) {  // uniform
+    if (args.seeds) {  // uniform: one sector holds all of it (flat + exactly paired: no chain, slot == i)
+        const EmitSeed* s = args.seeds + i;
+        const float4 a = s->a, b = s->b;
+        const float2 c = s->c;
+        world = calc_model(a.x, a.y, a.z, b.x, b.y, b.z, b.w, a.w, c.x, c.y);
+    } else if (args.world) {  // uniform
         uint32_t slot = i;
         if (args.mesh.mapping != kMapExact)
             slot = args.mesh.link[i] & kSlotMask;
@@ -1237,7 +1243,8 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             const uint32_t i = (first_word + lo) * 64 + pos;
             const Mat34 m = record_model(args, i);
             const size_t rank = (size_t)base + r;
-            args.out.visible_idx[rank] = args.mesh.orig ? args.mesh.orig[i] : i;  // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
+            // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
+            args.out.visible_idx[rank] = args.seeds ? args.seeds[i].orig : (args.mesh.orig ? args.mesh.orig[i] : i);
             args.out.distance_sq[rank] = record_distance(args, m);
             float4* row = args.direct_stores ? reinterpret_cast<float4*>(args.out.baked_model) + rank * 3 : stage + threadIdx.x * 3;
             row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
@@ -1282,6 +1289,7 @@ __global__ __launch_bounds__(256) void emit_batch_kernel(const EmitBatchArgs bat
     args.nchunks = batch.nchunks;
     args.clear_chunks = batch.clear_chunks[blockIdx.y];
     args.world = batch.world;
+    args.seeds = nullptr;
     args.direct_stores = 0;
     emit_block<true>(args, blockIdx.x);
 }
@@ -1310,6 +1318,7 @@ void fill_emit_table_entry(void* entry, const MeshMirror& mesh, const TransformM
     a.clear_chunks = clear_chunks;
     a.direct_stores = 0;
     a.world = world;
+    a.seeds = nullptr;
 }
 
 hipError_t launch_emit_table(const void* device_table, uint32_t entries, uint32_t max_slots, hipStream_t stream)
@@ -1342,12 +1351,13 @@ hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, 
 }
 
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks, const float4* world)
+                       hipStream_t stream, bool self_prefix, uint32_t clear_chunks, const float4* world, const EmitSeed* seeds)
 {
     if (mesh.count == 0)
         return hipSuccess;
     EmitArgs a;
     a.world = world;
+    a.seeds = seeds;
     static const uint32_t direct = getenv("GV_DEBUG_EMIT_DIRECT_STORES") ? 1u : 0u;
     a.direct_stores = direct;
     a.mesh = mesh;
@@ -1360,6 +1370,27 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
         hipLaunchKernelGGL(emit_kernel<true>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(emit_kernel<false>, dim3(a.nchunks * kEmitParts), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void emit_seeds_kernel(const MeshMirror mesh, const TransformMirror xf, EmitSeed* __restrict__ seeds)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= mesh.count || i >= xf.count)
+        return;
+    float4* out = reinterpret_cast<float4*>(seeds + i);
+    const float2 c = xf.c[i];
+    out[0] = xf.ab[i].a;
+    out[1] = xf.ab[i].b;
+    out[2] = make_float4(c.x, c.y, __uint_as_float(mesh.orig ? mesh.orig[i] : i), 0.0f);
+    out[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+hipError_t launch_emit_seeds(const MeshMirror& mesh, const TransformMirror& xf, EmitSeed* seeds, hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(emit_seeds_kernel, dim3((mesh.count + 255) / 256), dim3(256), 0, stream, mesh, xf, seeds);
     return hipGetLastError();
 }
 
@@ -1424,6 +1455,52 @@ hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& l
         return hipSuccess;
     hipLaunchKernelGGL(aos_transforms_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, xinv,
                        ab, c, flags, dirty);
+    return hipGetLastError();
+}
+
+// Dirty MeshRenderComponents shipped as raw AoS bytes (slots [first, first + count) of the caller's pool): the gather the host
+// otherwise does (gather_meshes, gv_mirror.cpp) — Manager::tryGet<TransformComponent>(entity) through the entity -> slot table
+// (mesh.cpp:149), the candidate rule (mesh.cpp:142), the empty box of a non-candidate — at HBM speed. *demoted is set when a
+// candidate no longer pairs with its own mirror index (a pool mapped kMapExact must then be demoted by the host).
+__global__ __launch_bounds__(256) void aos_meshes_kernel(const uint8_t* __restrict__ raw, AosMeshLayout L, uint32_t first, uint32_t count,
+                                                         const uint32_t* __restrict__ inv, const uint32_t* __restrict__ e2t,
+                                                         uint32_t entity_capacity, uint32_t xf_occupancy, const uint32_t* __restrict__ xinv,
+                                                         float4* __restrict__ a, float2* __restrict__ b, uint32_t* __restrict__ link,
+                                                         uint32_t* __restrict__ demoted)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint8_t* m = raw + (size_t)k * L.stride;
+    float mn[3], mx[3];
+    uint32_t entity;
+    memcpy(mn, m + L.aabb_min, 12);
+    memcpy(mx, m + L.aabb_max, 12);
+    memcpy(&entity, m + L.entity, 4);
+    uint32_t slot = kSlotNone;
+    if (entity != 0 && entity < entity_capacity) {
+        const uint32_t s = e2t[entity];
+        if (s != 0xFFFFFFFFu && s < xf_occupancy)
+            slot = xinv ? xinv[s] : s;
+    }
+    const bool candidate = entity != 0 && m[L.is_enabled] != 0 && slot != kSlotNone;
+    const uint32_t i = first + k;
+    const uint32_t j = inv ? inv[i] : i;
+    a[j] = candidate ? make_float4(mn[0], mn[1], mn[2], mx[0]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    b[j] = candidate ? make_float2(mx[1], mx[2]) : make_float2(0.0f, 0.0f);
+    link[j] = slot | (candidate ? kMeshCandidate : 0u);
+    if (candidate && slot != j)
+        atomicOr(demoted, 1u);
+}
+
+hipError_t launch_aos_meshes(const uint8_t* raw, const AosMeshLayout& layout, uint32_t first, uint32_t count, const uint32_t* inv,
+                             const uint32_t* e2t, uint32_t entity_capacity, uint32_t xf_occupancy, const uint32_t* xinv, float4* a, float2* b,
+                             uint32_t* link, uint32_t* demoted, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(aos_meshes_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, raw, layout, first, count, inv, e2t, entity_capacity,
+                       xf_occupancy, xinv, a, b, link, demoted);
     return hipGetLastError();
 }
 

@@ -97,6 +97,20 @@ struct ViewBuffers {
     float* distance_sq;
 };
 
+// Emit seeds (round 3): for a flat, exactly paired pool that is at rest, everything the emit kernel gathers per visible entry —
+// TRS record, scale tail, pool slot: three 64-byte sectors for 44 useful bytes, and the sparse gather is what bounds the emit
+// behind an occlusion pass (316 k records -> 60 MB of sectors at cfg3) — as ONE 64-byte record per mirror entry, built on the
+// device while the pool's mirror is clean (like the block bounds; a pool that changes every frame goes without). Same bits.
+struct EmitSeed {
+    float4 a, b;      // XfAB
+    float2 c;         // (scale.y, scale.z)
+    uint32_t orig;    // pool slot of the entry
+    uint32_t pad[5];
+};
+static_assert(sizeof(EmitSeed) == 64, "one sector per visible entry");
+constexpr uint32_t kEmitSeedMinSlots = 262144;  // smaller pools are launch-bound (and take other emit paths)
+hipError_t launch_emit_seeds(const MeshMirror& mesh, const TransformMirror& xf, EmitSeed* seeds, hipStream_t stream);
+
 // Block bounds (opt-in, GV_CONFIG_BLOCK_BOUNDS): world-space AABB of all corners of the candidates of each 256-entry
 // cull workgroup, built while the mirror is clean. A workgroup whose box lies behind one frustum plane by more than
 // the rounding margin skips its streams: every entity in it would have failed that plane in the per-entity test.
@@ -152,7 +166,8 @@ constexpr uint32_t kSelfPrefixMaxChunks = 4096;
 // world: the resident world matrices of the current transform mirror (3 float4 per entry), or NULL — records then take
 // world[slot] instead of re-walking the parent chain (same bits)
 hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out,
-                       hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0, const float4* world = nullptr);
+                       hipStream_t stream, bool self_prefix = false, uint32_t clear_chunks = 0, const float4* world = nullptr,
+                       const EmitSeed* seeds = nullptr);
 // all views of a batched cull in one launch (self-prefixing form; views[v] / outs[v] / clear_chunks[v] per view)
 hipError_t launch_emit_batch(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams* views, const ViewBuffers* outs,
                              const uint32_t* clear_chunks, uint32_t nviews, hipStream_t stream, const float4* world = nullptr);
@@ -212,6 +227,15 @@ struct AosTransformLayout {
 hipError_t launch_aos_transforms(const uint8_t* raw, const AosTransformLayout& layout, uint32_t first, uint32_t count,
                                  const uint32_t* xinv, XfAB* ab, float2* c, uint8_t* flags, uint8_t* dirty, hipStream_t stream);
 hipError_t launch_pack_active(const uint8_t* flags, uint32_t count, unsigned long long* bits, hipStream_t stream);
+// The same for dirty MeshRenderComponents (GV_DIRTY_MESH): raw AoS span -> mesh mirror entries. inv: pool slot -> mirror entry
+// (NULL: slot order); e2t: the entity -> transform slot table on the device; xinv: transform slot -> mirror entry (or NULL);
+// *demoted |= 1 when a candidate does not pair with its own mirror index.
+struct AosMeshLayout {
+    uint32_t stride, entity, is_enabled, aabb_min, aabb_max;
+};
+hipError_t launch_aos_meshes(const uint8_t* raw, const AosMeshLayout& layout, uint32_t first, uint32_t count, const uint32_t* inv,
+                             const uint32_t* e2t, uint32_t entity_capacity, uint32_t xf_occupancy, const uint32_t* xinv, float4* a, float2* b,
+                             uint32_t* link, uint32_t* demoted, hipStream_t stream);
 // dirty-range upload into a permuted mirror: dst[idx[k]] = src[k], element size 1, 4, 8 or 16 bytes
 hipError_t launch_scatter(const uint32_t* idx, uint32_t count, const void* src, void* dst, uint32_t elem_bytes,
                           hipStream_t stream);

@@ -376,25 +376,17 @@ bool track_world_dirty(GvCtx* ctx)
     return ctx->world_valid && ctx->d_xdirty.ptr && ctx->d_xdirty.cap >= ctx->xf.occupancy;
 }
 
-int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
+// `bytes` of the caller's (pageable) memory at `span` into ctx->d_raw, through two pinned chunks of the library's own: worker
+// threads fill chunk k while chunk k-1 is on the wire. The caller's memory is never page-locked: transient hipHostRegister /
+// hipHostUnregister of application memory was a third faster but left this stack aborting in LATER pageable copies that
+// touched the same addresses (3 of 10 runs of the GPU suite; 0 of 10 without it). GV_E_STATE: no room on the device.
+int stream_raw_span(GvCtx* ctx, const uint8_t* span, size_t bytes)
 {
-    const uint8_t* base = nullptr;
-    AosTransformLayout L{};
-    uint32_t extent = 0;
-    if (!ctx->device_gather || hi <= lo || !aos_transform_layout(ctx->xf, &base, &L, &extent))
-        return GV_E_STATE;
-    const uint32_t count = hi - lo;
-    const size_t bytes = (size_t)(count - 1) * L.stride + extent;
-    const uint8_t* span = base + (size_t)lo * L.stride;
     if (bytes > ctx->d_raw.cap) {
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier gather may still be reading the buffer about to go
         if (ctx->d_raw.reserve(bytes) != hipSuccess)
             return GV_E_STATE;
     }
-    // The caller's (pageable) span travels through two pinned chunks of the library's own: worker threads fill chunk k
-    // while chunk k-1 is on the wire. The caller's memory is never page-locked: transient hipHostRegister /
-    // hipHostUnregister of application memory was a third faster but left this stack aborting in
-    // LATER pageable copies that touched the same addresses (3 of 10 runs of the GPU suite; 0 of 10 without it).
     // chunk size: at least four chunks so that copying into a chunk overlaps the previous one's DMA, 1 .. 32 MB each
     const size_t chunk_bytes = std::min<size_t>((size_t)32 << 20, std::max<size_t>((size_t)1 << 20, ((bytes / 4 + 65535) >> 16) << 16));
     const size_t chunk_cap = std::min(bytes, chunk_bytes);
@@ -422,12 +414,99 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
         GV_HIP(ctx, hipMemcpyAsync(ctx->d_raw.ptr + off, stage, n, hipMemcpyHostToDevice, ctx->stream));
         GV_HIP(ctx, hipEventRecord(ctx->raw_done[turn], ctx->stream));
     }
+    return GV_OK;
+}
+
+int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
+{
+    const uint8_t* base = nullptr;
+    AosTransformLayout L{};
+    uint32_t extent = 0;
+    if (!ctx->device_gather || hi <= lo || !aos_transform_layout(ctx->xf, &base, &L, &extent))
+        return GV_E_STATE;
+    const uint32_t count = hi - lo;
+    const size_t bytes = (size_t)(count - 1) * L.stride + extent;
+    const uint8_t* span = base + (size_t)lo * L.stride;
+    if (int rc = stream_raw_span(ctx, span, bytes))
+        return rc;
     GV_HIP(ctx, launch_aos_transforms(ctx->d_raw.ptr, L, lo, count, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->d_xab.ptr,
                                       ctx->d_xc.ptr, ctx->d_xflags.ptr, track_world_dirty(ctx) ? ctx->d_xdirty.ptr : nullptr,
                                       ctx->stream));
     ctx->staging_stale.add(lo, count);
     ctx->stats.upload_bytes += bytes;
     return GV_OK;
+}
+
+// Field offsets of a mesh pool bound as an array of structs (every column shares one stride and lies inside one element).
+bool aos_mesh_layout(const PoolState& p, const uint8_t** base, AosMeshLayout* L, uint32_t* extent)
+{
+    const Column* cols[4] = {&p.entity, &p.is_enabled, &p.aabb_min, &p.aabb_max};
+    const uint32_t width[4] = {4, 1, 12, 12};
+    const size_t stride = p.entity.stride;
+    const uint8_t* lo = p.entity.ptr;
+    for (const Column* c : cols) {
+        if (c->stride != stride || !c->ptr)
+            return false;
+        lo = std::min(lo, c->ptr);
+    }
+    uint32_t off[4];
+    *extent = 0;
+    for (int k = 0; k < 4; k++) {
+        const size_t o = (size_t)(cols[k]->ptr - lo);
+        if (o + width[k] > stride)
+            return false;
+        off[k] = (uint32_t)o;
+        *extent = std::max(*extent, off[k] + width[k]);
+    }
+    *base = lo;
+    *L = AosMeshLayout{(uint32_t)stride, off[0], off[1], off[2], off[3]};
+    return true;
+}
+
+// GV_DIRTY_MESH over slots [lo, hi) of an AoS pool, device side (round 3; the transform side has had this since round 1): the
+// raw components travel through the pinned chunks, aos_meshes_kernel resolves each mesh's transform through a device copy of
+// the entity -> slot table (refreshed here: the table is the caller's and may have changed) and writes the mirror entries.
+// Worth it when the span outweighs that table: ranges of at least 2048 slots and 1/12 of the entity capacity (48 raw bytes per
+// slot against 4 per entity). Not applicable (GV_E_STATE -> the host gather) to column binds and to pools with a ready column.
+int upload_meshes_device(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
+{
+    const uint8_t* base = nullptr;
+    AosMeshLayout L{};
+    uint32_t extent = 0;
+    const uint32_t count = hi > lo ? hi - lo : 0;
+    if (!ctx->device_gather || count < 2048 || (uint64_t)count * 12 < ctx->xf.entity_capacity || p.ready.ptr ||
+        !aos_mesh_layout(p, &base, &L, &extent))
+        return GV_E_STATE;
+    const size_t bytes = (size_t)(count - 1) * L.stride + extent;
+    if (int rc = stream_raw_span(ctx, base + (size_t)lo * L.stride, bytes))
+        return rc;
+    const uint32_t cap = ctx->xf.entity_capacity;
+    if (ctx->d_e2t.reserve(std::max<size_t>(cap, 1)) != hipSuccess || ctx->d_flag.reserve(4) != hipSuccess || ctx->h_flag.reserve(4) != hipSuccess)
+        return GV_E_STATE;
+    if (cap)
+        GV_HIP(ctx, hipMemcpyAsync(ctx->d_e2t.ptr, ctx->xf.entity_to_transform, (size_t)cap * 4, hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemsetAsync(ctx->d_flag.ptr, 0, 4, ctx->stream));
+    GV_HIP(ctx, launch_aos_meshes(ctx->d_raw.ptr, L, lo, count, p.inv.empty() ? nullptr : p.d_inv.ptr, ctx->d_e2t.ptr, cap, ctx->xf.occupancy,
+                                  ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, ctx->d_flag.ptr,
+                                  ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(ctx->h_flag.ptr, ctx->d_flag.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the mapping has to be known before the next cull is chosen
+    if (ctx->h_flag.ptr[0] && p.mapping == kMapExact)
+        p.mapping = kMapSpeculate;  // an edited mesh no longer pairs with its own index
+    p.staging_stale.add(lo, count);
+    ctx->stats.upload_bytes += bytes + (size_t)cap * 4;
+    return GV_OK;
+}
+
+// (mesh side of refresh_stale_staging)
+void refresh_stale_mesh_staging(GvCtx* ctx, PoolState& p)
+{
+    if (!p.staging_stale.any())
+        return;
+    const uint32_t lo = p.staging_stale.lo, hi = std::min(p.staging_stale.hi, p.occupancy);
+    if (lo < hi)
+        gather_meshes(ctx, p, lo, hi);
+    p.staging_stale.clear();
 }
 
 // Host paths read the staging arrays: bring stale entries (written on the device only) up to date first.
@@ -641,7 +720,9 @@ int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
         for (uint32_t i = n0; i < n1; i++)
             p.perm[i] = p.inv[i] = i;
         GV_HIP(ctx, p.d_orig.grow(n1, n0, ctx->stream));
+        GV_HIP(ctx, p.d_inv.grow(n1, n0, ctx->stream));
         GV_HIP(ctx, hipMemcpyAsync(p.d_orig.ptr + n0, p.perm.data() + n0, (size_t)(n1 - n0) * 4, hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(p.d_inv.ptr + n0, p.inv.data() + n0, (size_t)(n1 - n0) * 4, hipMemcpyHostToDevice, ctx->stream));
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
     }
     gather_meshes(ctx, p, n0, n1);
@@ -866,13 +947,16 @@ int sync_mirror(GvCtx* ctx)
                     return rc;
                 if (!p.perm.empty()) {
                     GV_HIP(ctx, p.d_orig.reserve(cap));
+                    GV_HIP(ctx, p.d_inv.reserve(cap));
                     GV_HIP(ctx, hipMemcpyAsync(p.d_orig.ptr, p.perm.data(), (size_t)p.occupancy * 4, hipMemcpyHostToDevice, ctx->stream));
+                    GV_HIP(ctx, hipMemcpyAsync(p.d_inv.ptr, p.inv.data(), (size_t)p.occupancy * 4, hipMemcpyHostToDevice, ctx->stream));
                     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
                 }
             }
             phase.lap("mapping + upload meshes");
             p.need_full = false;
             p.dirty.clear();
+            p.staging_stale.clear();  // (every entry has just been gathered)
             p.epoch++;
             p.mirrored = p.occupancy;
             p.appended = 0;
@@ -886,18 +970,33 @@ int sync_mirror(GvCtx* ctx)
             const uint64_t total = p.dirty.total();
             if (total) {
                 int rc = GV_OK;
-                if (!p.inv.empty() && total * 2 > p.occupancy) {  // most of a permuted pool: one dense upload
-                    gather_meshes(ctx, p, ranges.front().lo, ranges.back().hi);
+                // large ranges of an AoS pool: raw span + device-side gather (upload_meshes_device says when it applies);
+                // `left` is what remains for the host paths
+                std::vector<DirtyRanges::R> left;
+                uint64_t left_total = 0;
+                for (const auto& r : ranges) {
+                    const int one = upload_meshes_device(ctx, p, r.lo, r.hi);
+                    if (one == GV_E_STATE) {
+                        left.push_back(r);
+                        left_total += r.hi - r.lo;
+                    } else if (one != GV_OK) {
+                        return one;
+                    }
+                }
+                if (left.empty()) {
+                } else if (!p.inv.empty() && left_total * 2 > p.occupancy) {  // most of a permuted pool: one dense upload
+                    refresh_stale_mesh_staging(ctx, p);  // (it re-uploads every entry from the staging arrays)
+                    gather_meshes(ctx, p, left.front().lo, left.back().hi);
                     rc = upload_meshes(ctx, p, 0, p.occupancy);
                 } else {
-                    for (const auto& r : ranges)
+                    for (const auto& r : left)
                         gather_meshes(ctx, p, r.lo, r.hi);
-                    if (p.inv.empty() && ranges.size() <= kRangedCopyMaxRanges) {
-                        for (const auto& r : ranges)
+                    if (p.inv.empty() && left.size() <= kRangedCopyMaxRanges) {
+                        for (const auto& r : left)
                             if ((rc = upload_meshes(ctx, p, r.lo, r.hi)) != GV_OK)
                                 break;
                     } else {
-                        rc = upload_meshes_scattered(ctx, p, ranges);
+                        rc = upload_meshes_scattered(ctx, p, left);
                     }
                 }
                 if (rc != GV_OK)

@@ -77,9 +77,9 @@ public:
     // true: records arrive as UnsortedMesh / SortedMesh structs (gv_pool_set_record_layout), combinedMeshes is one memcpy
     bool recordStructs = true;
     // true (with recordStructs): the device writes an unsorted buffer's records straight into its combinedMeshes
-    // (gv_pool_set_record_target; the vector is grown, never shrunk, so it is page-locked once) — no copy after the fetch
+    // (gv_pool_set_record_target): the fetch leaves the records in the vector itself — no copy loop in the shim
     bool recordTargets = true;
-    size_t recordTargetMaxBytes = size_t(256) << 20;  // larger arrays are not page-locked: their records are copied after the fetch
+    size_t recordTargetMaxBytes = size_t(256) << 20;  // larger arrays are not made targets: their records are copied after the fetch
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
@@ -108,7 +108,7 @@ public:
     ~GpuVisibilitySystem() override
     {
         // the context first: gv_destroy synchronises the stream and un-registers every record target, so no queued publish /
-        // sort can still write into a combinedMeshes array and no page-locked range is freed while it is registered
+        // sort can still write into a combinedMeshes array (GV_DEBUG_RECORD_TARGET_PAGE_LOCK) and no target outlives its array
         gv_destroy(ctx);
         ctx = nullptr;
         for (auto b : unsortedBuffers)

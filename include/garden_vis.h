@@ -273,15 +273,16 @@ int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout
 /* After gv_pool_results_fetch of the same (pool, view): the records [0, *count) in the pool's record layout (library-owned
  * pinned memory, valid until the next gv_cull of that pool). GV_E_STATE when the pool has no record layout. */
 int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, const void** records, uint32_t* count);
-/* The records of (pool, view) straight into the CALLER'S array — `UnsortedBuffer::combinedMeshes.data()`, which the reference
- * grows and never shrinks (mesh.cpp:377-395), so the address is stable across frames: the library page-locks the range
- * once (when the address or size changes) and from then on the device writes each frame's records [0, draw_count) into
- * it over PCIe; the fetch's memcpy into combinedMeshes (1.4 MB per frame for a 100 k-entity pool) disappears, and
- * gv_pool_results_records returns `records` itself. The pool needs a record layout; `bytes` >= occupancy * stride of every
- * pool culled while the target is set (GV_E_ARG at the fetch otherwise — draw_count <= occupancy, so the device can never
- * write past it); `records` 16-byte aligned. A range that cannot be page-locked is still filled (by a host copy inside the
- * fetch). The range must stay allocated until it is replaced (another call for the same pool and view), removed
- * (records == NULL) or the context is destroyed. */
+/* The records of (pool, view) into the CALLER'S array — `UnsortedBuffer::combinedMeshes.data()`, which the reference grows and
+ * never shrinks (mesh.cpp:377-395): the fetch leaves each frame's records [0, draw_count) there (one memcpy from the library's
+ * pinned buffer, inside the fetch — the engine's own copy loop disappears) and gv_pool_results_records returns `records` itself.
+ * The array is never page-locked: letting the device write it in place (round 2: hipHostRegister once per address, 4 us less
+ * per 10 k-entity tick) made LATER, unrelated copies into pageable memory abort inside the runtime now and then once such an
+ * array had been freed and its addresses reused (round 3: 4 of 16 runs of the GPU test tier). The pool needs a
+ * record layout; `bytes` >= occupancy * stride of every pool culled while the target is set (GV_E_ARG at the fetch otherwise);
+ * `records` 16-byte aligned. The range must stay allocated until it is replaced (another call for the same pool and view),
+ * removed (records == NULL) or the context is destroyed: a range that is found unmapped when it is let go or written is
+ * reported with GV_E_STATE (a freed heap block that is still mapped cannot be told from a live one). */
 int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* records, size_t bytes);
 
 /* The first instance index of every fetched record: bases[k] = sum of the ready counts (gv_pool_bind_ready; 1 per record

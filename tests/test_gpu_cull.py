@@ -249,6 +249,43 @@ def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
     assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["spread", "few_values", "two_clusters", "all_equal", "one_outlier"])
+def test_large_sorts_when_the_keys_bunch_up(gpu_slot_order, oracle, kind):
+    """Round 3: long lists are sorted through value buckets that are finished in LDS; keys that bunch up beyond what a bucket
+    holds — a handful of distinct distances, two tight clusters, all equal, one far outlier that stretches the range — are
+    detected and that frame is sorted again by the stable radix passes. Either way the order is sortMeshes' (mesh.cpp:265-328)
+    with ties in emission order, which in a slot-order mirror is the oracle's tie order: compared element for element."""
+    gpu = gpu_slot_order
+    n = 600_000
+    sc = scene.flat_scene(n, seed=21, defects=False)
+    rng = np.random.Generator(np.random.PCG64(4))
+    z = sc.transforms["position"][:, 2]
+    if kind == "few_values":
+        z[:] = rng.integers(0, 5, n).astype(np.float32) * np.float32(250.0)
+    elif kind == "two_clusters":
+        z[:] = np.where(rng.random(n) < 0.5, 0.0, 9000.0).astype(np.float32) + rng.uniform(-1e-3, 1e-3, n).astype(np.float32)
+    elif kind == "all_equal":
+        z[:] = np.float32(42.0)
+    elif kind == "one_outlier":
+        z[:] = rng.uniform(0, 1000, n).astype(np.float32)
+        z[12345] = np.float32(3e8)
+    view = dict(scene.cascade_view(size=1e6, depth=2e9), distance_2d=1, shadow_pass=-1)
+    view["view_proj"] = [2e-6, 0, 0, 0, 0, 2e-6, 0, 0, 0, 0, 5e-10, 0, 0, 0, 0.5, 1]  # an axis-aligned box around everything
+    view["camera_offset"] = [0, 0, 0, 0]
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.hierarchy_rebuild()
+    for descending in (False, True, False):  # (the second and third sort of a bunched view take the radix passes straight away)
+        gpu.cull(0, [view])
+        gpu.sort(0, descending=descending)
+        got = gpu.fetch(0, write_back=False, occupancy=n, order="raw")
+        exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, sort="descending" if descending else "ascending")
+        assert got["draw_count"] == exp["draw_count"] > 0.9 * n
+        assert np.array_equal(got["distance_sq"].view(np.uint32), exp["distance_sq"].view(np.uint32))
+        assert np.array_equal(got["visible_idx"], exp["visible_idx"])  # ties: ascending slot on both sides
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"].view(np.uint32))
+
+
 @pytest.mark.parametrize("n", [40_000, 65_000, 150_000])  # (150 000: beyond the pools the hint applies to)
 def test_sort_of_a_mid_sized_pool_follows_the_previous_count(gpu, oracle, n):
     """A pool between the one-launch batch and 65 536 slots is sorted by the rank sort ALONE when the view's previous fetch
@@ -761,6 +798,62 @@ def test_large_dirty_ranges_take_the_device_side_gather(request, oracle, hier, c
         vis.mark_dirty(1, 50_000, 80_000)   # a large ranged hierarchy change: dense host path over stale staging
         check()
     move(10_000, 20_000)
+    check()
+
+
+@pytest.mark.parametrize("hier", [False, True])
+@pytest.mark.parametrize("ctx_name", ["gpu", "gpu_slot_order"])
+def test_large_dirty_mesh_ranges_take_the_device_side_gather(request, oracle, hier, ctx_name):
+    """GV_DIRTY_MESH over large ranges of an AoS pool (round 3): the raw components are copied and gathered on the device —
+    boxes, enable flags, and the entity -> transform lookup (through a device copy of the entity map), including meshes that
+    change hands (an exactly paired pool is demoted) — while the host staging of those slots goes stale; small ranges and dense
+    host re-mirrors afterwards must still see coherent data."""
+    vis = request.getfixturevalue(ctx_name)
+    n = 150_000
+    sc = scene.hierarchy_scene(n, depth=4, fanout=6) if hier else scene.flat_scene(n)
+    view = scene.main_camera_view()
+    rng = np.random.Generator(np.random.PCG64(7))
+    vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+    vis.bind_pool(0, sc.meshes)
+    vis.hierarchy_rebuild()
+
+    def check():
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=n)
+        m2 = sc.meshes.copy()
+        exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+        assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
+        o = np.argsort(exp["visible_idx"], kind="stable")
+        assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+        assert np.array_equal(got["is_visible"], m2["isVisible"])
+        return got["draw_count"]
+
+    def edit(lo, cnt):
+        sc.meshes["aabbMax"][lo:lo + cnt, :3] *= rng.uniform(0.5, 3.0, (cnt, 3)).astype(np.float32)
+        sc.meshes["isEnabled"][lo:lo + cnt] ^= (rng.random(cnt) < 0.05).astype(np.uint8)
+        sc.meshes["aabbMin"][lo:lo + cnt:97, :3] = sc.meshes["aabbMax"][lo:lo + cnt:97, :3]  # some boxes collapse (the size <= 0 rule)
+        vis.mark_dirty(2, lo, cnt, pool_id=0)
+
+    first = check()
+    up0 = vis.stats()["upload_bytes"]
+    edit(20_000, 60_000)                      # device-side gather: 48 raw bytes per slot + the entity map
+    assert check() != first
+    stride, cap = sc.meshes.dtype.itemsize, len(sc.entity_to_transform)
+    assert vis.stats()["upload_bytes"] - up0 >= 59_999 * stride + cap * 4
+    edit(70_000, 300)                         # a small range inside the stale region: host gather
+    check()
+    # meshes change hands: the entities of two stretches are swapped (no mesh pairs with its own transform index there any more)
+    a, b = slice(30_000, 50_000), slice(90_000, 110_000)
+    sc.meshes["entity"][a], sc.meshes["entity"][b] = sc.meshes["entity"][b].copy(), sc.meshes["entity"][a].copy()
+    sc.meshes["entity"][52_000:52_500] = 0    # ... and some meshes are destroyed
+    vis.mark_dirty(2, 30_000, 80_000, pool_id=0)
+    check()
+    edit(0, n)                                # the whole pool
+    check()
+    for lo in range(10, n - 10, 6007):        # many small ranges: the host paths over (formerly) stale staging
+        sc.meshes["isEnabled"][lo:lo + 5] = 1
+        sc.meshes["aabbMax"][lo:lo + 5, :3] += np.float32(0.25)
+        vis.mark_dirty(2, lo, 5, pool_id=0)
     check()
 
 
