@@ -578,44 +578,10 @@ static int sort_buffers_of(GvCtx* ctx, ViewState& vs, SortBuffers& b)
     return GV_OK;
 }
 
-// A value-bucket sort (launch_sort_buckets) reports through a pinned word whether every bucket fitted its workgroup's LDS. Before
-// anybody reads the records of such a sort the word is looked at — one stream synchronisation — and a frame whose keys were
-// bunched beyond that (many equal distances; a frame unlike the one before) is sorted again by the radix passes, from the
-// untouched inputs. The view then stays with the radix passes for a while.
-int verify_sort(GvCtx* ctx, ViewState& vs)
-{
-    if (!vs.sort_check_pending)
-        return GV_OK;
-    vs.sort_check_pending = false;
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (!vs.h_sort_status.ptr[0])
-        return GV_OK;
-    // the records in emission order are in the alternate set now (sort_large swapped): sort them back into the current set
-    std::swap(vs.visible_idx, vs.alt_idx);
-    std::swap(vs.baked_model, vs.alt_model);
-    std::swap(vs.distance_sq, vs.alt_dist);
-    SortBuffers b;
-    if (int rc = sort_buffers_of(ctx, vs, b))
-        return rc;
-    vs.sort_parity ^= 1u;
-    {
-        KernelTimer t(ctx, GV_K_SORT);
-        GV_HIP(ctx, launch_sort(b, vs.occupancy, vs.sort_descending, ctx->stream, kSortRadixOnly));
-    }
-    std::swap(vs.visible_idx, vs.alt_idx);
-    std::swap(vs.baked_model, vs.alt_model);
-    std::swap(vs.distance_sq, vs.alt_dist);
-    vs.bucket_cooldown = 120;
-    return GV_OK;
-}
-
 // gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
 static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 {
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc = verify_sort(ctx, vs))  // (a second sort of the same records: the first one has to be whole)
-        return rc;
     const size_t n = vs.occupancy;
     SortBuffers b;
     if (int rc = sort_buffers_of(ctx, vs, b))
@@ -625,28 +591,8 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     const SortMode mode = !hints || vs.count_hint == 0xFFFFFFFFu ? kSortBoth
                           : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
                           : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
-    // long lists go through value buckets (four launches) instead of the radix passes (eight) unless this view's keys
-    // recently bunched up beyond what a bucket holds (verify_sort)
-    static const bool buckets_allowed = getenv("GV_DEBUG_SORT_NO_BUCKETS") == nullptr;
-    const bool buckets = buckets_allowed && !sort_is_rank_only((uint32_t)n, mode) && vs.bucket_cooldown == 0;
-    if (vs.bucket_cooldown)
-        vs.bucket_cooldown--;
-    if (buckets) {
-        const size_t words = sort_bucket_words() + sort_minmax_words((uint32_t)n);
-        if (words > vs.sort_bucket.cap) {
-            GV_HIP(ctx, vs.sort_bucket.reserve(words));
-            GV_HIP(ctx, hipMemsetAsync(vs.sort_bucket.ptr, 0, sort_bucket_words() * sizeof(uint32_t), ctx->stream));
-        }
-        GV_HIP(ctx, vs.h_sort_status.reserve(4));
-        vs.h_sort_status.ptr[0] = 0;  // (nothing of this view is in flight: verify_sort above)
-        b.bucket_words = vs.sort_bucket.ptr;
-        b.bucket_minmax = vs.sort_bucket.ptr + sort_bucket_words();
-        b.bucket_status = vs.h_sort_status.ptr;
-        vs.sort_check_pending = true;
-        vs.sort_descending = descending;
-    } else if (!sort_is_rank_only((uint32_t)n, mode)) {
+    if (!sort_is_rank_only((uint32_t)n, mode))
         vs.sort_parity ^= 1u;  // the radix passes leave the other set of counters zeroed for the next sort
-    }
     {
         KernelTimer t(ctx, GV_K_SORT);
         GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream, mode));
@@ -805,14 +751,8 @@ int flush_sorts(GvCtx* ctx)
                 widest = std::max(widest, vs.occupancy);
                 taken[views++] = &vs;
             }
-        if (views == 0) {
-            for (auto& per_pool : ctx->views)  // large sorts done as value buckets: whole, or redone, before anybody reads them
-                for (ViewState& w : per_pool)
-                    if (w.valid && w.sort_check_pending)
-                        if (int rc = verify_sort(ctx, w))
-                            return rc;
+        if (views == 0)
             return GV_OK;
-        }
         GV_HIP(ctx, hipSetDevice(ctx->device));
         {
             ZoneScope zone("Meshes Sort");
@@ -957,7 +897,7 @@ void gv_destroy(GvCtx* ctx)
       for (auto& v : per_pool) {
         v.mask.release(); v.chunk_count.release(); v.chunk_count2.release(); v.chunk_offset.release(); v.draw_count.release();
         v.is_visible.release(); v.vis_flags.release(); v.visible_idx.release(); v.baked_model.release(); v.distance_sq.release();
-        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release(); v.sort_bucket.release(); v.h_sort_status.release();
+        v.alt_idx.release(); v.alt_model.release(); v.alt_dist.release(); v.sort_hist.release(); v.sort_ranks.release(); 
         for (int k = 0; k < 2; k++) { v.sort_keys[k].release(); v.sort_vals[k].release(); v.sort_slots[k].release(); }
         v.h_visible_idx.release(); v.h_draw_count.release(); v.h_baked_model.release();
         v.h_distance_sq.release(); v.h_is_visible.release(); v.is_visible_slots.release();
@@ -1208,7 +1148,6 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
         vs.valid = true;
         vs.published = false, vs.records_fetched = false;
         vs.sort_pending = 0;  // a sort of the previous results that nobody asked for any more
-        vs.sort_check_pending = false;
         vs.ballots_current = true;  // every cull launch but the one-launch cull + emit of a small pool writes them
         build_view_params(views[v], &vps[v]);
         if (p.occupancy == 0)

@@ -255,11 +255,6 @@ struct ViewState {
     uint32_t sort_parity = 0;  // which of the two counter sets in sort_hist the next large sort uses (gv_sort.hip)
     size_t sort_set_words = 0; // size of one set as laid out in sort_hist (0: not initialised)
     DeviceBuf<uint16_t> sort_ranks;
-    DeviceBuf<uint32_t> sort_bucket;     // bucket counters + tile min / max keys of the value-bucket sort (launch_sort_buckets)
-    PinnedBuf<uint32_t> h_sort_status;   // [0] = 1: a bucket overflowed, the outputs are incomplete (verify_sort redoes the frame)
-    bool sort_check_pending = false;     // a bucket sort is in flight whose status word nobody has looked at yet
-    bool sort_descending = false;        // ... and its direction (for the redo)
-    uint32_t bucket_cooldown = 0;        // large sorts of this view that take the radix passes before buckets are tried again
     uint8_t sort_pending = 0;  // small pool: gv_sort asked for (1 ascending, 2 descending), not launched yet (flush_sorts)
     bool published = false;  // small pool: the host buffers already hold this view's results (gv_results_fetch of a sibling view)
 };

@@ -1047,13 +1047,13 @@ struct EmitArgs {
 // filter in K1: only the transform entry and its model are needed here. When the world matrices of this mirror are
 // resident (args.world) the record takes world[slot] — the very product chain_model would rebuild, already in HBM as
 // 48 contiguous bytes — instead of re-walking the parent chain (4 x (32 + 8 + 4) bytes of dependent gathers at depth 3).
-__device__ __forceinline__ Mat34 record_model(const EmitArgs& args, uint32_t i)
+__device__ __forceinline__ Mat34 record_model(const EmitArgs& args, uint32_t i, bool use_seed)
 {
     // every gather here is a sparse 64-byte fetch for a few useful bytes: the flag byte is only read when the pool has
     // chains at all
     const bool chains = args.xf.max_depth != 0;  // uniform
     Mat34 world;
-    if (args.seeds) {  // uniform: one sector holds all of it (flat + exactly paired: no chain, slot == i)
+    if (use_seed) {  // workgroup-uniform: one sector holds all of it (flat + exactly paired: no chain, slot == i)
         const EmitSeed* s = args.seeds + i;
         const float4 a = s->a, b = s->b;
         const float2 c = s->c;
@@ -1224,6 +1224,10 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     }
     const uint32_t wlo = part * (64 / kEmitParts), whi = wlo + 64 / kEmitParts;
     const uint32_t total = prefix[whi];
+    // Seeds pay where the visible entries are SPARSE (behind an occlusion pass: one sector instead of three per record); in a
+    // dense chunk neighbouring records share the sectors of the streams and the 64-byte seeds move more, measured: at 21 %
+    // visible the emit took 59.9 us with seeds against 45.8 us without, at 12 % (cfg3's in-frustum chunks) 18.4 against 21.4.
+    const bool use_seed = args.seeds != nullptr && prefix[64] <= kEmitChunk * 5 / 32;
     // 256 consecutive output records per round (uniform trip count). Each lane builds one record; the 48-byte models go
     // through LDS so that they leave as whole rows — lane k stores float4 k, k + 256, k + 512 of the round's contiguous
     // 12 KB — instead of three 16-byte pieces per lane at a 48-byte stride.
@@ -1241,10 +1245,10 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             }
             const uint32_t pos = select_bit(words[lo], r - prefix[lo]);
             const uint32_t i = (first_word + lo) * 64 + pos;
-            const Mat34 m = record_model(args, i);
+            const Mat34 m = record_model(args, i, use_seed);
             const size_t rank = (size_t)base + r;
             // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
-            args.out.visible_idx[rank] = args.seeds ? args.seeds[i].orig : (args.mesh.orig ? args.mesh.orig[i] : i);
+            args.out.visible_idx[rank] = use_seed ? args.seeds[i].orig : (args.mesh.orig ? args.mesh.orig[i] : i);
             args.out.distance_sq[rank] = record_distance(args, m);
             float4* row = args.direct_stores ? reinterpret_cast<float4*>(args.out.baked_model) + rank * 3 : stage + threadIdx.x * 3;
             row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);

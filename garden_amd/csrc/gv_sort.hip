@@ -638,9 +638,6 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
         if (capacity <= kSmallSort || rank_only)
             return hipGetLastError();
     }
-    if (b.bucket_words)  // long lists: four launches over value buckets instead of the eight radix launches
-        return launch_sort_buckets(b, capacity, descending, rank_sort ? kRankSortMaxRecords : 0u, b.bucket_words, b.bucket_minmax,
-                                   b.bucket_status, stream);
     const uint32_t tiles = sort_tile_count(capacity);  // at full capacity (long or short tiles); the live count is on the device
     SortPassArgs a{};
     a.st.groups = sort_group_count(capacity);
@@ -679,281 +676,6 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
                 hipLaunchKernelGGL((sort_scatter_kernel<false, false>), dim3(tiles), dim3(kSortThreads), 0, stream, a);
         }
     }
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Long lists (round 3): a value-bucket sort — four launches, two of them over 8-byte pairs — instead of the eight radix launches.
-// The radix passes are latency chains over ~500 tiles each; what they move is small (12 B per key and pass), what they cost is
-// their number. Here the keys are cut into kBuckets equal ranges of [min key, max key] (a frame's distances fill that range
-// without gaps: the fullest bucket of the bench scene holds a few thousand of 2.1 M records), every bucket is finished inside
-// ONE workgroup's LDS, and the records are gathered to their final places by the same workgroup:
-//   sort_minmax_kernel          per tile of 4096 keys: min and max key
-//   sort_bucket_count_kernel    per tile: LDS histogram over the buckets, one global add per non-empty (tile, bucket)
-//   sort_bucket_scatter_kernel  per tile: the same histogram with ranks, one returning add per non-empty (tile, bucket) places
-//                               the tile's keys of a bucket; (key, emission index) pairs go to their bucket's range
-//   sort_bucket_finish_kernel   per bucket: bitonic sort of the pairs in LDS — (key, emission index) is unique, so the order is
-//                               the stable order of the radix passes whatever the network does with equal keys —, then
-//                               distanceSq from the key, the pool slot and the 48-byte model gathered to the sorted place
-// A bucket that holds more than kBucketCap pairs (keys bunched together: many equal distances, a frame unlike the one before)
-// is reported through `status` and left undone; the host then sorts that frame again with the radix passes (gv_context.cpp).
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kBuckets = kSortBuckets, kBucketCap = kSortBucketCap;
-constexpr uint32_t kBucketThreads = 512, kBucketTile = 4096;
-
-struct BucketSortArgs {
-    const uint32_t* count;
-    uint32_t capacity, descending, min_records;
-    const float* dist_in;
-    const uint32_t* idx_in;
-    const float* model_in;
-    uint32_t* idx_out;
-    float* model_out;
-    float* dist_out;
-    uint32_t* minmax;         // [tiles][2]
-    uint32_t* bucket_count;   // [kBuckets], zero on entry (the finish kernel clears it again)
-    uint32_t* bucket_cursor;  // [kBuckets], zero on entry (likewise)
-    uint32_t* bucket_start;   // [kBuckets + 1]: exclusive prefix of bucket_count, written by the scatter kernel's workgroup 0
-    uint32_t* pair_key;       // [capacity] pairs grouped by bucket
-    uint32_t* pair_val;
-    uint32_t* status;         // pinned host memory: [0] = 1 when a bucket overflowed (the sort is then incomplete)
-};
-
-__global__ __launch_bounds__(kBucketThreads) void sort_minmax_kernel(const BucketSortArgs a)
-{
-    __shared__ uint32_t wmin[kBucketThreads / 64], wmax[kBucketThreads / 64];
-    const uint32_t n = min(*a.count, a.capacity);
-    if (n <= a.min_records || blockIdx.x * kBucketTile >= n)
-        return;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-#pragma unroll
-    for (uint32_t r = 0; r < kBucketTile / kBucketThreads; r++) {
-        const uint32_t j = blockIdx.x * kBucketTile + r * kBucketThreads + threadIdx.x;
-        if (j < n) {
-            const uint32_t k = order_key(a.dist_in[j], a.descending);
-            lo = min(lo, k);
-            hi = max(hi, k);
-        }
-    }
-#pragma unroll
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        wmin[threadIdx.x >> 6] = lo;
-        wmax[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (uint32_t w = 1; w < kBucketThreads / 64; w++) {
-            lo = min(lo, wmin[w]);
-            hi = max(hi, wmax[w]);
-        }
-        a.minmax[blockIdx.x * 2] = lo;
-        a.minmax[blockIdx.x * 2 + 1] = hi;
-    }
-}
-
-// min key and the shift that maps (key - min) onto [0, kBuckets): every workgroup reduces the tiles' partials itself
-__device__ __forceinline__ void bucket_range(const BucketSortArgs& a, uint32_t n, uint32_t* scratch /* LDS [2 * waves] */, uint32_t& kmin, uint32_t& shift)
-{
-    const uint32_t tiles = (n + kBucketTile - 1) / kBucketTile;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (uint32_t t = threadIdx.x; t < tiles; t += kBucketThreads) {
-        lo = min(lo, a.minmax[t * 2]);
-        hi = max(hi, a.minmax[t * 2 + 1]);
-    }
-#pragma unroll
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64));
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        scratch[threadIdx.x >> 6] = lo;
-        scratch[kBucketThreads / 64 + (threadIdx.x >> 6)] = hi;
-    }
-    __syncthreads();
-    lo = scratch[0];
-    hi = scratch[kBucketThreads / 64];
-    for (uint32_t w = 1; w < kBucketThreads / 64; w++) {
-        lo = min(lo, scratch[w]);
-        hi = max(hi, scratch[kBucketThreads / 64 + w]);
-    }
-    __syncthreads();
-    kmin = lo;
-    const uint32_t span = hi - lo;  // bucket = (key - kmin) >> shift < kBuckets
-    uint32_t s = 0;
-    while ((span >> s) >= kBuckets)
-        s++;
-    shift = s;
-}
-
-template <bool SCATTER>
-__global__ __launch_bounds__(kBucketThreads) void sort_bucket_tile_kernel(const BucketSortArgs a)
-{
-    __shared__ uint32_t hist[kBuckets];   // count of the tile's keys per bucket; SCATTER: then the tile's base inside the bucket
-    __shared__ uint32_t scratch[2 * kBucketThreads / 64 + 2];
-    const uint32_t n = min(*a.count, a.capacity);
-    if (n <= a.min_records || blockIdx.x * kBucketTile >= n)
-        return;
-    uint32_t kmin, shift;
-    bucket_range(a, n, scratch, kmin, shift);
-    for (uint32_t b = threadIdx.x; b < kBuckets; b += kBucketThreads)
-        hist[b] = 0;
-    __syncthreads();
-    constexpr uint32_t kRounds = kBucketTile / kBucketThreads;
-    uint32_t key[kRounds], local[kRounds];
-#pragma unroll
-    for (uint32_t r = 0; r < kRounds; r++) {
-        const uint32_t j = blockIdx.x * kBucketTile + r * kBucketThreads + threadIdx.x;
-        key[r] = j < n ? order_key(a.dist_in[j], a.descending) : 0xFFFFFFFFu;
-        local[r] = j < n ? atomicAdd(&hist[(key[r] - kmin) >> shift], 1u) : 0u;  // rank among the tile's keys of the bucket (any order)
-    }
-    __syncthreads();
-    if (!SCATTER) {
-        for (uint32_t b = threadIdx.x; b < kBuckets; b += kBucketThreads)
-            if (hist[b])
-                atomicAdd(&a.bucket_count[b], hist[b]);
-        return;
-    }
-    // where the tile's keys of bucket b go inside the bucket: one returning add per non-empty (tile, bucket)
-    for (uint32_t b = threadIdx.x; b < kBuckets; b += kBucketThreads)
-        if (hist[b])
-            hist[b] = atomicAdd(&a.bucket_cursor[b], hist[b]);
-    // ... and where the bucket starts: the exclusive prefix of the bucket counts, by every workgroup for itself (32 KB of L2 reads)
-    __shared__ uint32_t start[kBuckets];
-    constexpr uint32_t kPer = kBuckets / kBucketThreads;
-    uint32_t mine[kPer], sum = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; q++) {
-        mine[q] = a.bucket_count[threadIdx.x * kPer + q];
-        sum += mine[q];
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((threadIdx.x & 63u) >= d)
-            incl += up;
-    }
-    if ((threadIdx.x & 63u) == 63u)
-        scratch[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t before = incl - sum;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-        before += scratch[w];
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; q++) {
-        start[threadIdx.x * kPer + q] = before;
-        before += mine[q];
-    }
-    __syncthreads();
-    if (blockIdx.x == 0)  // for the finish kernel
-        for (uint32_t b = threadIdx.x; b < kBuckets; b += kBucketThreads)
-            a.bucket_start[b] = start[b];
-#pragma unroll
-    for (uint32_t r = 0; r < kRounds; r++) {
-        const uint32_t j = blockIdx.x * kBucketTile + r * kBucketThreads + threadIdx.x;
-        if (j < n) {
-            const uint32_t b = (key[r] - kmin) >> shift;
-            const uint32_t pos = start[b] + hist[b] + local[r];
-            a.pair_key[pos] = key[r];
-            a.pair_val[pos] = j;
-        }
-    }
-}
-
-// one 64-bit word per pair: the key above the emission index — unique, and its order is the stable order
-__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* v, uint32_t padded)
-{
-    for (uint32_t k = 2; k <= padded; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < padded / 2; t += kBucketThreads) {
-                const uint32_t i = 2 * t - (t & (j - 1));  // the lower index of the t-th compare-exchange pair at distance j
-                const uint32_t p = i + j;
-                const bool up = (i & k) == 0;
-                const unsigned long long x = v[i], y = v[p];
-                if ((x > y) == up) {
-                    v[i] = y;
-                    v[p] = x;
-                }
-            }
-            __syncthreads();
-        }
-}
-
-__global__ __launch_bounds__(kBucketThreads) void sort_bucket_finish_kernel(const BucketSortArgs a)
-{
-    __shared__ unsigned long long v[kBucketCap];
-    const uint32_t n = min(*a.count, a.capacity);
-    if (n <= a.min_records)
-        return;
-    const uint32_t b = blockIdx.x;
-    const uint32_t nb = a.bucket_count[b];
-    if (nb == 0)
-        return;
-    const uint32_t first = a.bucket_start[b];
-    __syncthreads();  // (every thread has read the count before thread 0 clears it)
-    if (threadIdx.x == 0) {
-        a.bucket_count[b] = 0;   // ready for the next sort
-        a.bucket_cursor[b] = 0;
-    }
-    if (nb > kBucketCap) {  // cannot be finished here: the host sorts this frame again with the radix passes
-        if (threadIdx.x == 0)
-            a.status[0] = 1;
-        return;
-    }
-    uint32_t padded = 2;
-    while (padded < nb)
-        padded <<= 1;
-    for (uint32_t t = threadIdx.x; t < padded; t += kBucketThreads)
-        v[t] = t < nb ? ((unsigned long long)a.pair_key[first + t] << 32) | a.pair_val[first + t] : ~0ull;
-    __syncthreads();
-    if (nb > 1)
-        bitonic_sort_lds(v, padded);
-    for (uint32_t t = threadIdx.x; t < nb; t += kBucketThreads) {
-        const uint32_t k = (uint32_t)(v[t] >> 32), j = (uint32_t)v[t];
-        const uint32_t u = a.descending ? ~k : k;
-        a.dist_out[first + t] = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));  // distanceSq is the key: no gather
-        a.idx_out[first + t] = a.idx_in[j];
-    }
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.model_in);
-    float4* __restrict__ dst = reinterpret_cast<float4*>(a.model_out);
-    for (uint32_t q = threadIdx.x; q < nb * 3u; q += kBucketThreads) {  // three lanes per 48-byte model: whole rows leave
-        const uint32_t t = q / 3u, part = q - t * 3u;
-        dst[(size_t)(first + t) * 3 + part] = src[(size_t)(uint32_t)v[t] * 3 + part];
-    }
-}
-
-hipError_t launch_sort_buckets(const SortBuffers& b, uint32_t capacity, bool descending, uint32_t min_records, uint32_t* bucket_words,
-                               uint32_t* minmax, uint32_t* status, hipStream_t stream)
-{
-    if (capacity == 0)
-        return hipSuccess;
-    BucketSortArgs a{};
-    a.count = b.count;
-    a.capacity = capacity;
-    a.descending = descending ? 1u : 0u;
-    a.min_records = min_records;
-    a.dist_in = b.dist_in;
-    a.idx_in = b.idx_in;
-    a.model_in = b.model_in;
-    a.idx_out = b.idx_out;
-    a.model_out = b.model_out;
-    a.dist_out = b.dist_out;
-    a.minmax = minmax;
-    a.bucket_count = bucket_words;
-    a.bucket_cursor = bucket_words + kBuckets;
-    a.bucket_start = bucket_words + 2 * kBuckets;
-    a.pair_key = b.keys[0];
-    a.pair_val = b.vals[0];
-    a.status = status;
-    const uint32_t tiles = (capacity + kBucketTile - 1) / kBucketTile;
-    hipLaunchKernelGGL(sort_minmax_kernel, dim3(tiles), dim3(kBucketThreads), 0, stream, a);
-    hipLaunchKernelGGL(sort_bucket_tile_kernel<false>, dim3(tiles), dim3(kBucketThreads), 0, stream, a);
-    hipLaunchKernelGGL(sort_bucket_tile_kernel<true>, dim3(tiles), dim3(kBucketThreads), 0, stream, a);
-    hipLaunchKernelGGL(sort_bucket_finish_kernel, dim3(kBuckets), dim3(kBucketThreads), 0, stream, a);
     return hipGetLastError();
 }
 

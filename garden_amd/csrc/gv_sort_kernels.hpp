@@ -27,10 +27,6 @@ struct SortBuffers {
                              // uses set `parity` (zero on entry) and zeroes the other
     uint32_t* tile_hist;     // [sort_tile_count(capacity)][256] digit counts of every tile (rewritten by each pass)
     uint32_t parity;
-    // long lists as value buckets instead of radix passes (launch_sort_buckets below); bucket_words == NULL: radix passes
-    uint32_t* bucket_words = nullptr;
-    uint32_t* bucket_minmax = nullptr;
-    uint32_t* bucket_status = nullptr;
 };
 constexpr uint32_t kSortGroupTiles = 32;
 constexpr uint32_t kSortTileKeys = 4096;        // keys per workgroup and pass ...
@@ -57,17 +53,6 @@ constexpr uint32_t kRankOnlyMaxSlots = 65536;  // bounds the one slow frame afte
 constexpr uint32_t kRankOnlyHintRecords = 10240;  // (the rank-only launch's key table holds 16384: 60 % headroom before the slow form)
 constexpr uint32_t kRankOnlyTableRecords = 16384;
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode = kSortBoth);
-// Long lists (round 3): value buckets finished in LDS — four launches instead of the eight radix launches (gv_sort.hip). Uses
-// b.keys[0] / b.vals[0] for the (key, emission index) pairs; bucket_words: sort_bucket_words() words, zero before the first
-// use (the sort leaves them zero); minmax: two words per 4096-key tile of `capacity`; status: a word of pinned host
-// memory, cleared by the caller, that becomes 1 when a bucket held more than kSortBucketCap pairs — the outputs are then
-// INCOMPLETE and the caller sorts again with launch_sort(kSortRadixOnly). Lists of up to min_records
-// records are left alone (the rank-sort launch in front took them).
-constexpr uint32_t kSortBuckets = 8192, kSortBucketCap = 4096;
-inline size_t sort_bucket_words() { return 3 * (size_t)kSortBuckets + 1; }
-inline size_t sort_minmax_words(uint32_t capacity) { return 2 * (((size_t)capacity + 4095) / 4096); }
-hipError_t launch_sort_buckets(const SortBuffers& b, uint32_t capacity, bool descending, uint32_t min_records, uint32_t* bucket_words,
-                               uint32_t* minmax, uint32_t* status, hipStream_t stream);
 // Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
 // asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
 // launch for all views (rank sort, launch_sort_small_batch: O(n^2 / lanes), 11 us at 2 k records, 75 us at 16 k — where the

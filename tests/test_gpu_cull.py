@@ -251,10 +251,10 @@ def test_gpu_sort_matches_sort_meshes(gpu, oracle, n, descending, d2):
 
 @pytest.mark.parametrize("kind", ["spread", "few_values", "two_clusters", "all_equal", "one_outlier"])
 def test_large_sorts_when_the_keys_bunch_up(gpu_slot_order, oracle, kind):
-    """Round 3: long lists are sorted through value buckets that are finished in LDS; keys that bunch up beyond what a bucket
-    holds — a handful of distinct distances, two tight clusters, all equal, one far outlier that stretches the range — are
-    detected and that frame is sorted again by the stable radix passes. Either way the order is sortMeshes' (mesh.cpp:265-328)
-    with ties in emission order, which in a slot-order mirror is the oracle's tie order: compared element for element."""
+    """Long lists whose keys bunch up — a handful of distinct distances, two tight clusters, all equal, one far outlier that
+    stretches the range (round 3; written for a value-bucket sort that was measured and withdrawn, kept for the radix passes) —
+    come out in sortMeshes' order (mesh.cpp:265-328) with ties in emission order, which in a slot-order mirror is the oracle's
+    tie order: compared element for element."""
     gpu = gpu_slot_order
     n = 600_000
     sc = scene.flat_scene(n, seed=21, defects=False)
@@ -275,7 +275,7 @@ def test_large_sorts_when_the_keys_bunch_up(gpu_slot_order, oracle, kind):
     gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
     gpu.bind_pool(0, sc.meshes)
     gpu.hierarchy_rebuild()
-    for descending in (False, True, False):  # (the second and third sort of a bunched view take the radix passes straight away)
+    for descending in (False, True):
         gpu.cull(0, [view])
         gpu.sort(0, descending=descending)
         got = gpu.fetch(0, write_back=False, occupancy=n, order="raw")
