@@ -28,6 +28,22 @@ __global__ __launch_bounds__(256) void permute(const float4* __restrict__ src, f
     }
 }
 
+// gather whose SOURCE rows sit at a 64-byte stride (48 used): every record is one aligned 64-byte piece of one 128-byte line, where a
+// 48-byte stride has 3 of 8 records straddle two lines. The destination stays a packed 48-byte row.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_padded(const float4* __restrict__ src, float4* __restrict__ dst, const uint32_t* __restrict__ perm, uint32_t n)
+{
+    const uint32_t per_block = 4096 * 3;
+    const size_t base = (size_t)blockIdx.x * per_block;
+#pragma unroll UNROLL
+    for (uint32_t q = threadIdx.x; q < per_block; q += 256) {
+        const size_t g = base + q;
+        const uint32_t t = (uint32_t)(g / 3), part = (uint32_t)(g - (size_t)t * 3);
+        if (t < n)
+            dst[g] = src[(size_t)perm[t] * 4 + part];
+    }
+}
+
 // the same with the 4-byte pool slot beside the model (the sort's last pass moves both): gather = idx_out[t] = idx_in[perm[t]]
 // (a random 4-byte read: a whole sector fetched), scatter = idx_out[perm[t]] = idx_in[t] (a random 4-byte write: nothing fetched)
 template <bool SCATTER, int UNROLL>
@@ -87,6 +103,23 @@ int main(int argc, char** argv)
     run("gather, 48 loads in flight", permute<false, 48>);
     run("scatter, unroll 4", permute<true, 4>);
     run("scatter, unroll 16", permute<true, 16>);
+    {   // padded source rows (64-byte stride)
+        float4* wide;
+        hipMalloc(&wide, (size_t)n * 64); hipMemset(wide, 1, (size_t)n * 64);
+        float4* keep = src; src = wide;
+        run("gather, source rows 64-B stride", gather_padded<4>);
+        src = keep; hipFree(wide);
+    }
+    for (uint32_t window : {4096u, 16384u, 65536u, 262144u}) {  // a permutation that stays inside windows of that many records
+        std::vector<uint32_t> local(n);
+        std::iota(local.begin(), local.end(), 0u);
+        for (uint32_t lo = 0; lo < n; lo += window)
+            std::shuffle(local.begin() + lo, local.begin() + std::min(n, lo + window), rng);
+        hipMemcpy(dperm, local.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        char name[64]; snprintf(name, sizeof name, "gather inside windows of %u", window);
+        run(name, permute<false, 4>);
+    }
+    hipMemcpy(dperm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
     uint32_t *idx_in, *idx_out;
     hipMalloc(&idx_in, (size_t)n * 4); hipMalloc(&idx_out, (size_t)n * 4);
     hipMemset(idx_in, 1, (size_t)n * 4);

@@ -41,7 +41,7 @@ out = {"_kernel_source_sha": kernel_source_sha(), "_collected": datetime.datetim
        "word per wave) -> factor = known bytes / (FETCH_SIZE KB * 1024); WRITE_SIZE taken as reported (KB * 1024). Per "
        "launch of gv::cull_kernel. The factor is applied to all reads of cfg3 too, which over-counts its 8-byte Hi-Z "
        "texel gathers (narrow reads are reported closer to 1:1): cfg3's figure is an upper bound."}
-PLAIN, BOUNDED = "false>(gv::CullArgs)", "true>(gv::CullArgs)"  # cull_kernel<HIZ, MAP, BOUNDS>
+PLAIN, BOUNDED = "false>(gv::CullArgs)", "gv::cull_list_kernel"  # cull_kernel<HIZ, MAP, BOUNDS = false>; the bounded path's per-entity kernel (round 3: the kept-block list form)
 f2, n2 = counter_mean("cfg2", "FETCH_SIZE", PLAIN)
 w2, _ = counter_mean("cfg2", "WRITE_SIZE", PLAIN)
 known = N * 65 + N / 64 * 8
@@ -58,6 +58,7 @@ if newest("cfg3bb_FETCH_SIZE/*/*counter_collection.csv"):
     fb, nb = counter_mean("cfg3bb", "FETCH_SIZE", BOUNDED)
     wb, _ = counter_mean("cfg3bb", "WRITE_SIZE", BOUNDED)
     out["cfg3_block_bounds"] = {"FETCH_SIZE_KB": fb, "WRITE_SIZE_KB": wb, "launches": nb,
+                                "kernel": "gv::cull_list_kernel (+ block_classify_kernel, block_window_kernel: a few hundred KB each)",
                                 "cull_kernel_hbm_bytes_per_launch": fb * 1024 * factor + wb * 1024}
 if newest("cfg4_FETCH_SIZE/*/*counter_collection.csv"):
     f4, n4 = counter_mean("cfg4", "FETCH_SIZE", "sweep_cull_mfma_kernel")
