@@ -735,6 +735,198 @@ int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
     return GV_OK;
 }
 
+// ---- the spatial re-order on the device (gv_reorder.hip) ---------------------------------------------
+// What a full rebuild does on the host and ships over PCIe (order, gather of every component, 73 B per entity of upload:
+// 0.13-0.22 s at 10 M entities) the device does from what it already holds: Morton codes of the roots, gv_sort's radix
+// kernels on the bare codes (stable: trees stay contiguous, ancestors stay in front of their descendants), one permuting
+// pass per stream. The host downloads the new slot <-> entry tables; its staging arrays go stale as a whole and are
+// re-gathered only if a dense host path ever needs them (refresh_stale_*).
+struct KeySorter {  // scratch of launch_sort on bare keys (~30 B per key; lives for one re-order)
+    DeviceBuf<uint32_t> keys[2], vals[2], slots[2], hist, count;
+    DeviceBuf<uint16_t> ranks;
+    int sort(GvCtx* ctx, const float* key_bits, uint32_t n, uint32_t* order_out)
+    {
+        for (int k = 0; k < 2; k++) {
+            GV_HIP(ctx, keys[k].reserve(n));
+            GV_HIP(ctx, vals[k].reserve(n));
+            GV_HIP(ctx, slots[k].reserve(n));
+        }
+        GV_HIP(ctx, ranks.reserve(n));
+        GV_HIP(ctx, count.reserve(4));
+        const size_t set_words = sort_set_words(n), tiles = sort_tile_count(n);
+        GV_HIP(ctx, hist.reserve(2 * set_words + tiles * 256));
+        GV_HIP(ctx, hipMemsetAsync(hist.ptr, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
+        GV_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(count.ptr), (int)n, 1, ctx->stream));
+        SortBuffers b{};
+        b.count = count.ptr;
+        b.dist_in = key_bits;
+        b.idx_out = order_out;
+        b.ranks = ranks.ptr;
+        for (int k = 0; k < 2; k++) {
+            b.keys[k] = keys[k].ptr;
+            b.vals[k] = vals[k].ptr;
+            b.slots[k] = slots[k].ptr;
+            b.counters[k] = hist.ptr + k * set_words;
+        }
+        b.tile_hist = hist.ptr + 2 * set_words;
+        GV_HIP(ctx, launch_sort(b, n, false, ctx->stream, kSortRadixOnly));
+        return GV_OK;
+    }
+    void release()
+    {
+        for (int k = 0; k < 2; k++)
+            keys[k].release(), vals[k].release(), slots[k].release();
+        hist.release(), count.release(), ranks.release();
+    }
+};
+
+// `words` 32-bit words from the device into a std::vector through a pinned bounce buffer (enqueue only)
+inline int download_words(GvCtx* ctx, const uint32_t* dev, uint32_t* bounce, size_t words)
+{
+    GV_HIP(ctx, hipMemcpyAsync(bounce, dev, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return GV_OK;
+}
+inline void copy_words(std::vector<uint32_t>& dst, const uint32_t* src, size_t words)
+{
+    dst.resize(words);
+    parallel_ranges(0, (uint32_t)words, [&](uint32_t a, uint32_t b) { memcpy(dst.data() + a, src + a, (size_t)(b - a) * 4); });
+}
+// a slot <-> entry pair as downloaded: both tables in range and inverse of each other where it is cheap to see (every
+// 257th entry) — a table that is not would send later host gathers out of bounds
+inline bool tables_agree(const std::vector<uint32_t>& perm, const std::vector<uint32_t>& inv)
+{
+    const size_t n = perm.size();
+    std::atomic<bool> ok{inv.size() == n};
+    parallel_ranges(0, (uint32_t)n, [&](uint32_t a, uint32_t b) {
+        bool good = true;
+        for (uint32_t j = a; j < b; j++)
+            good &= perm[j] < n && inv[j] < n;
+        for (uint32_t j = a; j < b && good; j += 257)
+            good &= inv[perm[j]] == j;
+        if (!good)
+            ok.store(false, std::memory_order_relaxed);
+    });
+    return ok;
+}
+
+// xnewpos (out): old transform entry -> new entry, for the mesh pools' links
+int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xnewpos)
+{
+    const uint32_t n = ctx->xf_mirrored;
+    DeviceBuf<uint32_t> root, order, box, perm;
+    DeviceBuf<float> code;
+    DeviceBuf<XfAB> ab;
+    DeviceBuf<float2> c;
+    DeviceBuf<uint8_t> flags;
+    DeviceBuf<uint32_t> parent;
+    auto drop = [&] { root.release(), order.release(), box.release(), perm.release(), code.release(), ab.release(), c.release(), flags.release(), parent.release(); };
+    struct Guard { decltype(drop)& f; ~Guard() { f(); } } guard{drop};
+    GV_HIP(ctx, root.reserve(n));
+    GV_HIP(ctx, order.reserve(n));
+    GV_HIP(ctx, perm.reserve(n));
+    GV_HIP(ctx, box.reserve(8));
+    GV_HIP(ctx, code.reserve(n));
+    GV_HIP(ctx, xnewpos.reserve(n));
+    // the fresh streams keep the old capacities (head-room of a growing pool)
+    GV_HIP(ctx, ab.reserve(ctx->d_xab.cap));
+    GV_HIP(ctx, c.reserve(ctx->d_xc.cap));
+    GV_HIP(ctx, flags.reserve(ctx->d_xflags.cap));
+    GV_HIP(ctx, parent.reserve(ctx->d_xparent.cap));
+    GV_HIP(ctx, launch_reorder_codes(xf_mirror(ctx), root.ptr, box.ptr, code.ptr, ctx->stream));
+    if (int rc = ks.sort(ctx, code.ptr, n, order.ptr))
+        return rc;
+    GV_HIP(ctx, launch_reorder_invert(order.ptr, n, xnewpos.ptr, ctx->stream));
+    GV_HIP(ctx, launch_reorder_transforms(order.ptr, xnewpos.ptr, n, ctx->d_xab.ptr, ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->d_xparent.ptr, ab.ptr, c.ptr,
+                                          flags.ptr, parent.ptr, ctx->stream));
+    GV_HIP(ctx, launch_reorder_remap(ctx->d_xinv.ptr, n, xnewpos.ptr, perm.ptr, ctx->stream));
+    // the new tables and parent links come home; the staging records double as the pinned bounce buffer (stale from here on)
+    uint32_t* bounce = reinterpret_cast<uint32_t*>(ctx->h_xab.ptr);  // 8 words per entry
+    if (int rc = download_words(ctx, ctx->d_xinv.ptr, bounce, n)) return rc;
+    if (int rc = download_words(ctx, perm.ptr, bounce + n, n)) return rc;
+    if (int rc = download_words(ctx, parent.ptr, ctx->h_xparent.ptr, n)) return rc;
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> xinv, xperm;
+    copy_words(xinv, bounce, n);
+    copy_words(xperm, bounce + n, n);
+    if (!tables_agree(xperm, xinv))
+        return ctx->fail(GV_E_HIP, "device re-order of the transform mirror returned tables that are not a permutation");
+    ctx->xinv.swap(xinv);
+    ctx->xperm.swap(xperm);
+    std::swap(ctx->d_xab, ab);
+    std::swap(ctx->d_xc, c);
+    std::swap(ctx->d_xflags, flags);
+    std::swap(ctx->d_xparent, parent);
+    GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
+    ctx->staging_stale.add(0, n);
+    ctx->world_valid = false;  // (the cache is in the old order; the next sweep rebuilds it)
+    ctx->world_partial = false;
+    if (ctx->d_xdirty.ptr)
+        GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr, 0, ctx->d_xdirty.cap, ctx->stream));
+    ctx->xdirty_set = false;
+    ctx->xf_epoch++;
+    ctx->xf_appended = 0;
+    ctx->stats.mirror_reorders++;
+    return GV_OK;
+}
+
+// one mesh pool follows its transforms (xnewpos: they have just moved; NULL: only this pool's tail is out of order).
+// GV_E_STATE: not applicable (the pool has no order table) -> the caller schedules a host rebuild of the pool
+int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_t* xnewpos)
+{
+    const uint32_t n = p.mirrored;
+    if (p.perm.empty() || n < 2 || !p.d_orig.ptr || !p.d_inv.ptr)
+        return GV_E_STATE;
+    DeviceBuf<uint32_t> order, link, orig, inv;
+    DeviceBuf<float> key;
+    DeviceBuf<float4> a;
+    DeviceBuf<float2> b;
+    auto drop = [&] { order.release(), link.release(), orig.release(), inv.release(), key.release(), a.release(), b.release(); };
+    struct Guard { decltype(drop)& f; ~Guard() { f(); } } guard{drop};
+    GV_HIP(ctx, order.reserve(n));
+    GV_HIP(ctx, key.reserve(n));
+    GV_HIP(ctx, a.reserve(p.d_a.cap));
+    GV_HIP(ctx, b.reserve(p.d_b.cap));
+    GV_HIP(ctx, link.reserve(p.d_link.cap));
+    GV_HIP(ctx, orig.reserve(p.d_orig.cap));
+    GV_HIP(ctx, inv.reserve(p.d_inv.cap));
+    GV_HIP(ctx, ctx->d_flag.reserve(4));
+    GV_HIP(ctx, ctx->h_flag.reserve(4));
+    GV_HIP(ctx, hipMemsetAsync(ctx->d_flag.ptr, 0, 4, ctx->stream));
+    GV_HIP(ctx, launch_reorder_mesh_keys(p.d_link.ptr, n, xnewpos, ctx->xf_mirrored, key.ptr, ctx->stream));
+    if (int rc = ks.sort(ctx, key.ptr, n, order.ptr))
+        return rc;
+    GV_HIP(ctx, launch_reorder_meshes(order.ptr, n, xnewpos, ctx->xf_mirrored, p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.d_orig.ptr, a.ptr, b.ptr, link.ptr,
+                                      orig.ptr, inv.ptr, ctx->d_flag.ptr, ctx->stream));
+    uint32_t* bounce = reinterpret_cast<uint32_t*>(p.h_a.ptr);  // 4 words per entry
+    if (int rc = download_words(ctx, orig.ptr, bounce, n)) return rc;
+    if (int rc = download_words(ctx, inv.ptr, bounce + n, n)) return rc;
+    GV_HIP(ctx, hipMemcpyAsync(ctx->h_flag.ptr, ctx->d_flag.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> perm, pinv;
+    copy_words(perm, bounce, n);
+    copy_words(pinv, bounce + n, n);
+    if (!tables_agree(perm, pinv))
+        return ctx->fail(GV_E_HIP, "device re-order of a mesh mirror returned tables that are not a permutation");
+    p.perm.swap(perm);
+    p.inv.swap(pinv);
+    std::swap(p.d_a, a);
+    std::swap(p.d_b, b);
+    std::swap(p.d_link, link);
+    std::swap(p.d_orig, orig);
+    std::swap(p.d_inv, inv);
+    if (ctx->h_flag.ptr[0] && p.mapping == kMapExact)
+        p.mapping = kMapSpeculate;
+    p.staging_stale.add(0, n);
+    p.epoch++;
+    p.appended = 0;
+    const uint32_t pool_id = (uint32_t)(&p - ctx->pools);
+    for (auto& vs : ctx->views[pool_id]) {  // per-entry outputs of earlier culls are in the old order
+        vs.vis_flags_current = false;
+        vs.ballots_current = false;
+    }
+    return GV_OK;
+}
+
 struct PhaseTimer {  // GV_DEBUG_TIMING=1: prints the host phases of a mirror build
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     bool on = getenv("GV_DEBUG_TIMING") != nullptr;
@@ -759,9 +951,17 @@ int sync_mirror(GvCtx* ctx)
     const uint32_t n = ctx->xf.occupancy;
     bool staged = false;
     const bool spatial = !(ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER);
+    // Too much of a pool sits in the unsorted tail: back into spatial order — on the device (the new slots are appended first, like
+    // any growth, then the mirror is permuted where it lies: reorder_*_device), or as a full host rebuild with GV_DEBUG_HOST_REORDER
+    static const bool device_reorder = getenv("GV_DEBUG_HOST_REORDER") == nullptr;
+    bool reorder_xf = false;
     if (!ctx->xf_need_full && n > ctx->xf_mirrored && spatial &&
-        ((uint64_t)ctx->xf_appended + (n - ctx->xf_mirrored)) * 8 > n && n >= 1024)
-        ctx->xf_need_full = true;  // too much of the pool sits in the unsorted tail: re-order everything
+        ((uint64_t)ctx->xf_appended + (n - ctx->xf_mirrored)) * 8 > n && n >= 1024) {
+        if (device_reorder && !ctx->xperm.empty())
+            reorder_xf = true;
+        else
+            ctx->xf_need_full = true;
+    }
     if (ctx->xf_need_full) {
         // staging is about to be rewritten: make sure earlier async uploads have drained
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -901,12 +1101,17 @@ int sync_mirror(GvCtx* ctx)
         ctx->xf_dirty.clear();
       }
     }
+    bool reorder_pool[GV_MAX_POOLS] = {};
     for (auto& p : ctx->pools) {
         if (!p.bound)
             continue;
         if (!p.need_full && p.occupancy > p.mirrored && spatial &&
-            ((uint64_t)p.appended + (p.occupancy - p.mirrored)) * 8 > p.occupancy && p.occupancy >= 1024)
-            p.need_full = true;
+            ((uint64_t)p.appended + (p.occupancy - p.mirrored)) * 8 > p.occupancy && p.occupancy >= 1024) {
+            if (device_reorder && !p.perm.empty())
+                reorder_pool[&p - ctx->pools] = true;
+            else
+                p.need_full = true;
+        }
         if (!p.need_full && p.occupancy > p.mirrored) {
             staged = true;
             const int rc = grow_meshes(ctx, p, p.mirrored, p.occupancy);
@@ -1005,6 +1210,36 @@ int sync_mirror(GvCtx* ctx)
             p.dirty.clear();
             p.epoch++;
         }
+    }
+    // the re-order itself, behind everything that brought the mirror up to date in its old order
+    bool any_reorder = reorder_xf;
+    for (bool b : reorder_pool)
+        any_reorder = any_reorder || b;
+    if (any_reorder) {
+        KeySorter ks;
+        DeviceBuf<uint32_t> xnewpos;
+        struct Scratch { KeySorter& ks; DeviceBuf<uint32_t>& x; ~Scratch() { ks.release(); x.release(); } } scratch{ks, xnewpos};
+        bool again = false;
+        if (reorder_xf) {
+            if (int rc = reorder_transforms_device(ctx, ks, xnewpos))
+                return rc;
+            phase.lap("device re-order: transforms");
+        }
+        for (auto& p : ctx->pools) {
+            if (!p.bound || p.need_full || !(reorder_xf || reorder_pool[&p - ctx->pools]))
+                continue;  // (a pool whose transforms moved follows them: its links name transform entries)
+            const int rc = p.occupancy ? reorder_meshes_device(ctx, p, ks, reorder_xf ? xnewpos.ptr : nullptr) : GV_OK;
+            if (rc == GV_E_STATE) {
+                p.need_full = true;
+                again = true;
+            } else if (rc != GV_OK) {
+                return rc;
+            }
+        }
+        phase.lap("device re-order: mesh pools");
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the old streams are freed with the scratch
+        if (again)
+            return sync_mirror(ctx);  // (pools without an order table: rebuilt on the host from the new transform tables)
     }
     return GV_OK;
 }

@@ -285,7 +285,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
             val[r] = valid ? a.vals_in[j] : 0u;
         }
 #if GV_SORT_CARRY_SLOTS
-        slot[r] = valid ? (FIRST ? a.idx_in[j] : a.slots_in[j]) : 0u;  // pass 0: a sequential read, where the last pass had a random one
+        slot[r] = valid ? (FIRST ? (a.idx_in ? a.idx_in[j] : j) : a.slots_in[j]) : 0u;  // pass 0: a sequential read, where the last pass had a random one (no idx_in: the identity)
 #endif
         rank[r] = valid ? (uint32_t)a.ranks[j] : 0u;
     }
@@ -360,14 +360,17 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
         const uint32_t dd = (k >> shift) & 255u;
         const uint32_t pos = dst_base[dd] + (t - tile_excl[dd]);
         const uint32_t u = a.descending ? ~k : k;
-        a.dist_out[pos] = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        if (a.dist_out)
+            a.dist_out[pos] = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 #if GV_SORT_CARRY_SLOTS
         a.idx_out[pos] = sslot[t];
 #else
-        a.idx_out[pos] = a.idx_in[sval[t]];  // sval[t] = the record's index before the sort
+        a.idx_out[pos] = a.idx_in ? a.idx_in[sval[t]] : sval[t];  // sval[t] = the record's index before the sort
 #endif
         skey[t] = pos;  // only this thread reads skey[t] in this loop
     }
+    if (!a.model_in)  // (uniform) a sort of bare keys: the order is the result (launch_sort_keys)
+        return;
     __syncthreads();
     const float4* __restrict__ src = reinterpret_cast<const float4*>(a.model_in);
     float4* __restrict__ dst = reinterpret_cast<float4*>(a.model_out);
@@ -576,10 +579,13 @@ __device__ __forceinline__ void sort_small_block(const Entry& b, uint32_t capaci
     if (part != 0 || i >= n)
         return;
     const uint32_t rank = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
-    const uint32_t idx = b.idx_in[i];
+    const uint32_t idx = b.idx_in ? b.idx_in[i] : i;
     const float dist = b.dist_in[i];
     b.idx_out[rank] = idx;
-    b.dist_out[rank] = dist;
+    if (b.dist_out)
+        b.dist_out[rank] = dist;
+    if (!b.model_in)  // (uniform) bare keys
+        return;
     const float4* sm = reinterpret_cast<const float4*>(b.model_in + (size_t)i * 12);
     float4* dm = reinterpret_cast<float4*>(b.model_out + (size_t)rank * 12);
     const float4 m0 = sm[0], m1 = sm[1], m2 = sm[2];

@@ -53,6 +53,27 @@ constexpr uint32_t kRankOnlyMaxSlots = 65536;  // bounds the one slow frame afte
 constexpr uint32_t kRankOnlyHintRecords = 10240;  // (the rank-only launch's key table holds 16384: 60 % headroom before the slow form)
 constexpr uint32_t kRankOnlyTableRecords = 16384;
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode = kSortBoth);
+// The same kernels as a sort of BARE KEYS: model_in / model_out NULL -> no record moves, idx_out receives the stable order
+// (idx_in NULL: of the identity, i.e. idx_out[k] = index of the k-th smallest key), dist_out may be NULL. Keys are the bit patterns
+// of NON-NEGATIVE floats (any uint32 below 2^31 read as a float: the kernels only ever look at the bits).
+
+// gv_reorder.hip — the device-side spatial re-order of the mirror (gv_mirror.cpp reorder_*_device). Included from gv_kernels.hpp
+// behind the mirror types.
+// root[j], and code[j] = Morton code of the root's position within the live roots' box (box: 6 words of scratch) as key bits
+hipError_t launch_reorder_codes(const TransformMirror& xf, uint32_t* root, uint32_t* box, float* code, hipStream_t stream);
+hipError_t launch_reorder_invert(const uint32_t* order, uint32_t n, uint32_t* newpos, hipStream_t stream);  // newpos[order[k]] = k
+// entry k of the new mirror = entry order[k] of the old one; parent links follow newpos
+hipError_t launch_reorder_transforms(const uint32_t* order, const uint32_t* newpos, uint32_t n, const XfAB* ab_in, const float2* c_in,
+                                     const uint8_t* flags_in, const uint32_t* parent_in, XfAB* ab_out, float2* c_out, uint8_t* flags_out,
+                                     uint32_t* parent_out, hipStream_t stream);
+// table[s] = newpos[table[s]]; inverse (may be NULL): inverse[table[s]] = s
+hipError_t launch_reorder_remap(uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* inverse, hipStream_t stream);
+// key[i] = the (new: xnewpos, or NULL = unchanged) mirror entry of mesh entry i's transform; none: last
+hipError_t launch_reorder_mesh_keys(const uint32_t* link, uint32_t n, const uint32_t* xnewpos, uint32_t xn, float* key, hipStream_t stream);
+// *unpaired = 1 when a candidate does not sit at its transform's index afterwards (kMapExact no longer holds)
+hipError_t launch_reorder_meshes(const uint32_t* order, uint32_t n, const uint32_t* xnewpos, uint32_t xn, const float4* a_in, const float2* b_in,
+                                 const uint32_t* link_in, const uint32_t* orig_in, float4* a_out, float2* b_out, uint32_t* link_out,
+                                 uint32_t* orig_out, uint32_t* inv_out, uint32_t* unpaired, hipStream_t stream);
 // Small pools: gv_sort only records the request, so that the views of one tick share launches when their results are first
 // asked for (and a cull recorded by gv_cull_batch_begin has run by then). Up to kBatchSortMaxSlots slots they sort in ONE
 // launch for all views (rank sort, launch_sort_small_batch: O(n^2 / lanes), 11 us at 2 k records, 75 us at 16 k — where the

@@ -463,6 +463,8 @@ typedef struct GvStats {
     uint64_t bounds_blocks_total;    /* GV_CONFIG_BLOCK_BOUNDS: workgroups of the last cull that ran with boxes (0: none
                                         since gv_stats_reset) ... */
     uint64_t bounds_blocks_examined; /* ... and how many of them had to run the per-entity path */
+    uint64_t mirror_reorders;        /* spatial re-orders of the transform mirror done ON the device since gv_create (an unsorted
+                                        tail of created entities past 1/8 of the pool; no PCIe re-upload) */
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);

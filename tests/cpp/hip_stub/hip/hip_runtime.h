@@ -48,6 +48,13 @@ static inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigne
 static inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memmove(dst, src, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { if (n) std::memset(dst, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* dst, int v, size_t n) { if (n) std::memset(dst, v, n); return hipSuccess; }
+typedef void* hipDeviceptr_t;
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t words, hipStream_t)
+{
+    for (size_t k = 0; k < words; k++)
+        std::memcpy(static_cast<char*>(dst) + 4 * k, &v, 4);
+    return hipSuccess;
+}
 
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(std::malloc(1)); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }

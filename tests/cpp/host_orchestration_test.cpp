@@ -309,6 +309,22 @@ static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
         frame(ctx, 2, false, round & 1);
         check_permutation(ctx, 0, (uint32_t)w.meshes.size());
     }
+    {   // six rounds of +5 %: the unsorted tail has passed 1/8 of the pools on the way — a spatially ordered mirror was re-ordered
+        // where it lies (gv_mirror.cpp reorder_*_device; the stub build runs tests/cpp/hip_stub/reorder_cpu.cpp for its kernels)
+        GvStats st{};
+        CHECK(gv_stats(ctx, &st));
+        if ((st.mirror_reorders != 0) == ((config_flags & GV_CONFIG_KEEP_SLOT_ORDER) != 0)) {
+            std::fprintf(stderr, "mirror_reorders = %llu with config flags %#x\n", (unsigned long long)st.mirror_reorders, config_flags);
+            std::exit(1);
+        }
+        // dirty marks after the re-order land on the new entries; a hierarchy mark re-validates the downloaded links
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 7, 3000));
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 3, 2));
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, 11, 2500));
+        CHECK(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, 40, 10));
+        frame(ctx, 2, false, false);
+        check_permutation(ctx, 0, (uint32_t)w.meshes.size());
+    }
     w.build(n / 2, depth);  // shrinks: rebuilt
     bind_all(ctx, w);
     frame(ctx, 2, false, false);

@@ -740,10 +740,88 @@ def test_pools_that_grow_are_appended_to_the_mirror(request, oracle, hier, ctx_n
     check(cut(31_700, 32_000))     # meshes of entities whose transforms do not exist yet (no transform: filtered out)
     # ... which arrive now: those meshes gained a TransformComponent, which the caller reports like any other change
     check(cut(32_000, 32_000), dirty_meshes=(31_700, 300))
-    check(cut(36_000, 36_000))     # the tail passes 1/8 of the pool: the library re-orders
+    assert vis.stats()["mirror_reorders"] == 0
+    check(cut(36_000, 36_000))     # the tail passes 1/8 of the pool: the library re-orders (on the device: gv_reorder.hip)
+    assert vis.stats()["mirror_reorders"] == (0 if ctx_name == "gpu_slot_order" else 1)
     check(cut(40_000, 40_000))
     check(cut(25_000, 25_000))     # shrink: rebuild
     check(cut(25_100, 25_100))
+
+
+@pytest.mark.parametrize("kind", ["flat", "hier", "shuffled"])
+def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, kind, monkeypatch):
+    """entities created in batches until the unsorted tail of the mirror passes 1/8 of the pools, twice over.
+    The library then puts the mirror back into spatial order on the device (Morton codes of the roots, the radix kernels on
+    bare keys, one permuting pass per stream; gv_mirror.cpp reorder_*_device) instead of rebuilding it on the host. After every
+    step: visible set, records, isVisible and every world matrix against the oracle; then dirty marks of every kind (scattered
+    slots, a large range through the device-side gather, re-parenting) must land on the re-ordered entries, and a second mesh
+    pool bound to the same transforms must have followed them. 'shuffled': mesh slots do not pair with transform slots."""
+    n = 260_000
+    full = scene.hierarchy_scene(n, depth=4, fanout=5) if kind == "hier" else scene.flat_scene(n)
+    rng = np.random.Generator(np.random.PCG64(4))
+    if kind == "shuffled":
+        full = scene.Scene(full.meshes[rng.permutation(n)].copy(), full.transforms, full.entity_to_transform)
+    view = scene.main_camera_view()
+    second = full.meshes[::3].copy()  # another mesh system over the same entities
+
+    def cut(k):
+        e2t = full.entity_to_transform.copy()
+        e2t[e2t >= k] = 0xFFFFFFFF
+        return scene.Scene(full.meshes[:k].copy(), full.transforms[:k].copy(), e2t)
+
+    def check(sc, rebind=True):
+        if rebind:
+            gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+            gpu.bind_pool(0, sc.meshes)
+            gpu.bind_pool(1, second)
+            # meshes whose entity has only now received its transform: reported like any other change of a mesh
+            gpu.mark_dirty(2, 0, second.shape[0], pool_id=1)
+            if kind == "shuffled":
+                gpu.mark_dirty(2, 0, sc.meshes.shape[0], pool_id=0)
+        for pool, meshes in ((0, sc.meshes), (1, second)):
+            gpu.cull(pool, [view])
+            got = gpu.fetch(0, write_back=False, occupancy=meshes.shape[0])
+            m2 = meshes.copy()
+            exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view)
+            assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
+            o = np.argsort(exp["visible_idx"], kind="stable")
+            assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+            assert np.array_equal(got["is_visible"], m2["isVisible"])
+        gpu.sweep(1)
+        assert np.array_equal(gpu.get_world(0, sc.transforms.shape[0]).view(np.uint32),
+                              oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
+
+    sizes = [150_000, 160_000, 172_000, 200_000, 215_000, 236_000, 260_000]
+    sc = cut(sizes[0])
+    gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
+    gpu.bind_pool(0, sc.meshes)
+    gpu.bind_pool(1, second)
+    gpu.hierarchy_rebuild()
+    check(sc, rebind=False)
+    for k in sizes[1:]:
+        sc = cut(k)
+        check(sc)
+    assert gpu.stats()["mirror_reorders"] >= 2
+    # changes after the re-order land where the entries now are
+    lo = 3_000
+    sc.transforms["position"][lo:lo + 5_000, :3] += rng.normal(0, 25, (5_000, 3)).astype(np.float32)
+    gpu.mark_dirty(0, lo, 5_000)  # GV_DIRTY_TRANSFORM, a large range: device-side gather
+    for s in rng.integers(0, n, 40):
+        sc.transforms["position"][s, :3] += np.float32(11)
+        sc.transforms["selfActive"][s] ^= 1
+        gpu.mark_dirty(0, int(s), 1)
+    sc.meshes["isEnabled"][100:3_000] ^= 1
+    gpu.mark_dirty(2, 100, 2_900, pool_id=0)  # GV_DIRTY_MESH
+    check(sc, rebind=False)
+    if kind == "hier":
+        kids = np.flatnonzero(sc.transforms["parent"] != 0)[:50]
+        sc.transforms["parent"][kids] = 0  # re-parented to the root: links changed
+        for s in kids:
+            gpu.mark_dirty(1, int(s), 1)  # GV_DIRTY_HIERARCHY
+        check(sc, rebind=False)
+    sc.transforms["rotation"][:] = sc.transforms["rotation"][::-1].copy()
+    gpu.mark_dirty(0, 0, n)  # the whole pool: dense path
+    check(sc, rebind=False)
 
 
 @pytest.mark.parametrize("hier", [False, True])

@@ -426,7 +426,8 @@ def test_dirty_ranges_under_address_and_ub_sanitizers(tmp_path):
 def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     """The 2.8 k lines of host orchestration behind the C-ABI (garden_amd/csrc/gv_context.cpp, gv_mirror.cpp, gv_exchange.cpp,
     + gv_scene.cpp, gv_workers.cpp) are otherwise only ever compiled as HIP. Here they are built as plain C++ against
-    tests/cpp/hip_stub (device memory = zeroed host memory, copies = memcpy, kernels = generated no-ops) with
+    tests/cpp/hip_stub (device memory = zeroed host memory, copies = memcpy, kernels = generated no-ops; the mirror re-order's
+    kernels as plain loops, reorder_cpu.cpp, so that its host half sees real tables) with
     -fsanitize=address,undefined and driven through include/garden_vis.h by tests/cpp/host_orchestration_test.cpp: binds, mirror
     builds, every dirty-range path, growth / shrink / moved pools, columns, ready counts, record targets, batched ticks, sorts,
     Hi-Z builds, sweeps, scene ingest, tiles, error codes — in four context configurations. TEST-ONLY stub: the product library
@@ -440,7 +441,7 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     assert gen.returncode == 0 and gen.stdout.count("hipError_t launch_") > 30, gen.stderr
     stubs.write_text(gen.stdout)
     flags = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + stub, "-I" + csrc]
-    sources = [str(stubs), os.path.join(root, "tests", "cpp", "host_orchestration_test.cpp")] + \
+    sources = [str(stubs), os.path.join(stub, "reorder_cpu.cpp"), os.path.join(root, "tests", "cpp", "host_orchestration_test.cpp")] + \
               [os.path.join(csrc, f) for f in ("gv_context.cpp", "gv_mirror.cpp", "gv_exchange.cpp", "gv_scene.cpp", "gv_workers.cpp")]
     objects = []
     builds = []
