@@ -19,6 +19,19 @@ void drain_events(GvCtx* ctx)
 
 namespace {
 
+struct PhaseTimer {  // GV_DEBUG_TIMING=1: prints the host phases of a mirror build
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("GV_DEBUG_TIMING") != nullptr;
+    void lap(const char* what)
+    {
+        if (!on)
+            return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gv] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 inline uint32_t entity_slot(const TransformBinding& xf, uint32_t entity)
 {
     if (entity == 0 || entity >= xf.entity_capacity)
@@ -47,7 +60,9 @@ void radix_order(const std::vector<uint32_t>& keys, std::vector<uint32_t>& order
     const size_t n = order.size();
     const uint32_t threads = worker_parts(n);
     const size_t per = (n + threads - 1) / threads;
-    std::vector<uint32_t> tmp(n);
+    std::vector<uint32_t> tmp;
+    tmp.reserve(order.capacity());  // (the buffers swap roles: the caller's head-room survives)
+    tmp.resize(n);
     std::vector<size_t> hist((size_t)threads * 1024);
     auto run = [&](auto&& fn) { run_parts(threads, fn); };
     for (int pass = 0; pass < 3; pass++) {
@@ -178,6 +193,8 @@ int build_transform_order(GvCtx* ctx)
             code[s] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
         }
     });
+    ctx->xperm.reserve((size_t)n + n / 4);  // (head-room for appended slots, like the staging arrays)
+    ctx->xinv.reserve((size_t)n + n / 4);
     ctx->xperm.resize(n);
     for (uint32_t s = 0; s < n; s++)
         ctx->xperm[s] = s;
@@ -210,6 +227,8 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
             }
         });
         if (paired) {
+            p.perm.reserve((size_t)n + n / 4);
+            p.inv.reserve((size_t)n + n / 4);
             p.perm = ctx->xperm;
             p.inv = ctx->xinv;
             return;
@@ -222,6 +241,8 @@ void build_mesh_order(GvCtx* ctx, PoolState& p)
             key[i] = slot == kSlotNone ? 0x3FFFFFFFu : ctx->xinv[slot];  // < 2^28: fits the 30-bit sort key
         }
     });
+    p.perm.reserve((size_t)n + n / 4);
+    p.inv.reserve((size_t)n + n / 4);
     p.perm.resize(n);
     for (uint32_t i = 0; i < n; i++)
         p.perm[i] = i;
@@ -657,7 +678,7 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRan
 // Pool growth (entities created since the last sync): the new slots [n0, n1) are appended to the mirror as entries
 // [n0, n1) — identity on the tail of the permutation — instead of rebuilding it; they stay outside the spatial order
 // until the next full build, which sync_mirror schedules once the unsorted tail passes 1/8 of the pool.
-int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
+int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1, PhaseTimer& phase)
 {
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GV_HIP(ctx, ctx->d_xab.grow(n1, n0, ctx->stream));
@@ -665,10 +686,12 @@ int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
     GV_HIP(ctx, ctx->d_xflags.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xparent.grow(n1, n0, ctx->stream));
     GV_HIP(ctx, ctx->d_xactive.grow((size_t)n1 / 64 + 1, 0, ctx->stream));  // re-derived below
+    phase.lap("  append transforms: device streams");
     GV_HIP(ctx, ctx->h_xab.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xc.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xflags.grow(n1, n0));
     GV_HIP(ctx, ctx->h_xparent.grow(n1, n0));
+    phase.lap("  append transforms: pinned staging");
     if (!ctx->xperm.empty()) {
         ctx->xperm.resize(n1);
         ctx->xinv.resize(n1);
@@ -678,19 +701,47 @@ int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1)
         GV_HIP(ctx, hipMemcpyAsync(ctx->d_xinv.ptr + n0, ctx->xinv.data() + n0, (size_t)(n1 - n0) * 4, hipMemcpyHostToDevice, ctx->stream));
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pageable source
     }
+    phase.lap("  append transforms: tables");
     gather_transforms(ctx, n0, n1);
+    phase.lap("  append transforms: gather");
     bool chained = ctx->max_depth != 0;
     for (uint32_t j = n0; j < n1 && !chained; j++)
         chained = ctx->h_xparent.ptr[j] != kSlotNone;
     if (chained) {  // new slots with parents (or a pool that already has chains): depth / cycle check over the links
-        uint32_t depth = 0;
-        const int rc = compute_max_depth(ctx, &depth);
+        // Only the appended entries can have changed the longest chain: the links of the entries already mirrored are what they
+        // were (a re-parented old slot is a GV_DIRTY_HIERARCHY mark, which re-validates everything). Every new entry walks to its
+        // root — on the gather threads, 1.25 M entries appended to 8.75 M: 25 ms for the serial pass over the whole pool -> < 1 ms;
+        // a walk longer than any chain can be (the old maximum + every new entry) is a cycle among the new links: the full pass
+        // then names it.
+        uint32_t depth = ctx->max_depth;
+        const uint64_t bound = (uint64_t)ctx->max_depth + (n1 - n0) + 1;
+        std::atomic<uint32_t> deepest{depth};
+        std::atomic<bool> cyclic{false};
+        parallel_ranges(n0, n1 - n0, [&](uint32_t a, uint32_t b) {
+            uint32_t local = 0;
+            for (uint32_t j = a; j < b && !cyclic.load(std::memory_order_relaxed); j++) {
+                uint32_t cur = j;
+                uint64_t steps = 0;
+                while ((cur = ctx->h_xparent.ptr[cur]) != kSlotNone)
+                    if (++steps > bound) {
+                        cyclic.store(true, std::memory_order_relaxed);
+                        break;
+                    }
+                local = std::max<uint32_t>(local, (uint32_t)std::min<uint64_t>(steps, UINT32_MAX));
+            }
+            uint32_t seen = deepest.load(std::memory_order_relaxed);
+            while (local > seen && !deepest.compare_exchange_weak(seen, local, std::memory_order_relaxed)) {
+            }
+        });
+        depth = deepest.load();
+        const int rc = cyclic ? compute_max_depth(ctx, &depth) : GV_OK;
         if (rc != GV_OK) {
             ctx->xf_need_full = true;
             return rc;
         }
         ctx->max_depth = depth;
     }
+    phase.lap("  append transforms: depth check");
     const int rc = upload_transforms(ctx, n0, n1);
     if (rc != GV_OK)
         return rc;
@@ -734,6 +785,7 @@ int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
     p.epoch++;
     return GV_OK;
 }
+
 
 // ---- the spatial re-order on the device (gv_reorder.hip) ---------------------------------------------
 // What a full rebuild does on the host and ships over PCIe (order, gather of every component, 73 B per entity of upload:
@@ -793,10 +845,9 @@ inline void copy_words(std::vector<uint32_t>& dst, const uint32_t* src, size_t w
 }
 // a slot <-> entry pair as downloaded: both tables in range and inverse of each other where it is cheap to see (every
 // 257th entry) — a table that is not would send later host gathers out of bounds
-inline bool tables_agree(const std::vector<uint32_t>& perm, const std::vector<uint32_t>& inv)
+inline bool tables_agree(const uint32_t* perm, const uint32_t* inv, size_t n)
 {
-    const size_t n = perm.size();
-    std::atomic<bool> ok{inv.size() == n};
+    std::atomic<bool> ok{true};
     parallel_ranges(0, (uint32_t)n, [&](uint32_t a, uint32_t b) {
         bool good = true;
         for (uint32_t j = a; j < b; j++)
@@ -810,7 +861,7 @@ inline bool tables_agree(const std::vector<uint32_t>& perm, const std::vector<ui
 }
 
 // xnewpos (out): old transform entry -> new entry, for the mesh pools' links
-int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xnewpos)
+int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xnewpos, PhaseTimer& phase)
 {
     const uint32_t n = ctx->xf_mirrored;
     DeviceBuf<uint32_t> root, order, box, perm;
@@ -832,6 +883,7 @@ int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xn
     GV_HIP(ctx, c.reserve(ctx->d_xc.cap));
     GV_HIP(ctx, flags.reserve(ctx->d_xflags.cap));
     GV_HIP(ctx, parent.reserve(ctx->d_xparent.cap));
+    phase.lap("  re-order: scratch");
     GV_HIP(ctx, launch_reorder_codes(xf_mirror(ctx), root.ptr, box.ptr, code.ptr, ctx->stream));
     if (int rc = ks.sort(ctx, code.ptr, n, order.ptr))
         return rc;
@@ -845,13 +897,12 @@ int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xn
     if (int rc = download_words(ctx, perm.ptr, bounce + n, n)) return rc;
     if (int rc = download_words(ctx, parent.ptr, ctx->h_xparent.ptr, n)) return rc;
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> xinv, xperm;
-    copy_words(xinv, bounce, n);
-    copy_words(xperm, bounce + n, n);
-    if (!tables_agree(xperm, xinv))
+    phase.lap("  re-order: device + downloads");
+    if (!tables_agree(bounce + n, bounce, n))
         return ctx->fail(GV_E_HIP, "device re-order of the transform mirror returned tables that are not a permutation");
-    ctx->xinv.swap(xinv);
-    ctx->xperm.swap(xperm);
+    copy_words(ctx->xinv, bounce, n);  // (in place: the vectors already have this size)
+    copy_words(ctx->xperm, bounce + n, n);
+    phase.lap("  re-order: host tables");
     std::swap(ctx->d_xab, ab);
     std::swap(ctx->d_xc, c);
     std::swap(ctx->d_xflags, flags);
@@ -871,7 +922,7 @@ int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xn
 
 // one mesh pool follows its transforms (xnewpos: they have just moved; NULL: only this pool's tail is out of order).
 // GV_E_STATE: not applicable (the pool has no order table) -> the caller schedules a host rebuild of the pool
-int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_t* xnewpos)
+int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_t* xnewpos, PhaseTimer& phase)
 {
     const uint32_t n = p.mirrored;
     if (p.perm.empty() || n < 2 || !p.d_orig.ptr || !p.d_inv.ptr)
@@ -892,6 +943,7 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     GV_HIP(ctx, ctx->d_flag.reserve(4));
     GV_HIP(ctx, ctx->h_flag.reserve(4));
     GV_HIP(ctx, hipMemsetAsync(ctx->d_flag.ptr, 0, 4, ctx->stream));
+    phase.lap("  re-order: scratch");
     GV_HIP(ctx, launch_reorder_mesh_keys(p.d_link.ptr, n, xnewpos, ctx->xf_mirrored, key.ptr, ctx->stream));
     if (int rc = ks.sort(ctx, key.ptr, n, order.ptr))
         return rc;
@@ -902,13 +954,12 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     if (int rc = download_words(ctx, inv.ptr, bounce + n, n)) return rc;
     GV_HIP(ctx, hipMemcpyAsync(ctx->h_flag.ptr, ctx->d_flag.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> perm, pinv;
-    copy_words(perm, bounce, n);
-    copy_words(pinv, bounce + n, n);
-    if (!tables_agree(perm, pinv))
+    phase.lap("  re-order: device + downloads");
+    if (!tables_agree(bounce, bounce + n, n))
         return ctx->fail(GV_E_HIP, "device re-order of a mesh mirror returned tables that are not a permutation");
-    p.perm.swap(perm);
-    p.inv.swap(pinv);
+    copy_words(p.perm, bounce, n);
+    copy_words(p.inv, bounce + n, n);
+    phase.lap("  re-order: host tables");
     std::swap(p.d_a, a);
     std::swap(p.d_b, b);
     std::swap(p.d_link, link);
@@ -927,18 +978,6 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     return GV_OK;
 }
 
-struct PhaseTimer {  // GV_DEBUG_TIMING=1: prints the host phases of a mirror build
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    bool on = getenv("GV_DEBUG_TIMING") != nullptr;
-    void lap(const char* what)
-    {
-        if (!on)
-            return;
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[gv] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 
 }  // namespace
 
@@ -972,10 +1011,14 @@ int sync_mirror(GvCtx* ctx)
         GV_HIP(ctx, ctx->d_xflags.reserve(cap));
         GV_HIP(ctx, ctx->d_xactive.reserve(cap / 64 + 1));
         GV_HIP(ctx, ctx->d_xparent.reserve(cap));
-        GV_HIP(ctx, ctx->h_xab.reserve(cap));
-        GV_HIP(ctx, ctx->h_xc.reserve(cap));
-        GV_HIP(ctx, ctx->h_xflags.reserve(cap));
-        GV_HIP(ctx, ctx->h_xparent.reserve(cap));
+        // pinned staging and the host tables get a quarter of head-room: page-locking is what an append of created entities
+        // would otherwise wait for (76 of 188 ms when 1.25 M slots were appended to 8.75 M, tools/reorder_bench.py), and the
+        // mirror is re-ordered in place (no new allocation) by the time the tail reaches an eighth of the pool
+        const size_t hcap = cap + cap / 4;
+        GV_HIP(ctx, ctx->h_xab.reserve(hcap));
+        GV_HIP(ctx, ctx->h_xc.reserve(hcap));
+        GV_HIP(ctx, ctx->h_xflags.reserve(hcap));
+        GV_HIP(ctx, ctx->h_xparent.reserve(hcap));
         phase.lap("reserve transforms");
         int rc = build_transform_order(ctx);
         if (rc != GV_OK)
@@ -1022,7 +1065,7 @@ int sync_mirror(GvCtx* ctx)
     } else {
       if (n > ctx->xf_mirrored) {
         staged = true;
-        const int rc = grow_transforms(ctx, ctx->xf_mirrored, n);
+        const int rc = grow_transforms(ctx, ctx->xf_mirrored, n, phase);
         if (rc != GV_OK)
             return rc;
       }
@@ -1114,9 +1157,11 @@ int sync_mirror(GvCtx* ctx)
         }
         if (!p.need_full && p.occupancy > p.mirrored) {
             staged = true;
+            phase.lap("transforms up to date");
             const int rc = grow_meshes(ctx, p, p.mirrored, p.occupancy);
             if (rc != GV_OK)
                 return rc;
+            phase.lap("append meshes");
         }
         if (p.need_full) {
             if (!staged) {
@@ -1127,9 +1172,9 @@ int sync_mirror(GvCtx* ctx)
             GV_HIP(ctx, p.d_a.reserve(cap));
             GV_HIP(ctx, p.d_b.reserve(cap));
             GV_HIP(ctx, p.d_link.reserve(cap));
-            GV_HIP(ctx, p.h_a.reserve(cap));
-            GV_HIP(ctx, p.h_b.reserve(cap));
-            GV_HIP(ctx, p.h_link.reserve(cap));
+            GV_HIP(ctx, p.h_a.reserve(cap + cap / 4));  // (head-room: see the transform staging above)
+            GV_HIP(ctx, p.h_b.reserve(cap + cap / 4));
+            GV_HIP(ctx, p.h_link.reserve(cap + cap / 4));
             phase.lap("upload transforms + reserve");
             build_mesh_order(ctx, p);
             phase.lap("mesh order");
@@ -1216,19 +1261,20 @@ int sync_mirror(GvCtx* ctx)
     for (bool b : reorder_pool)
         any_reorder = any_reorder || b;
     if (any_reorder) {
+        phase.lap("appended slots + dirty ranges");
         KeySorter ks;
         DeviceBuf<uint32_t> xnewpos;
         struct Scratch { KeySorter& ks; DeviceBuf<uint32_t>& x; ~Scratch() { ks.release(); x.release(); } } scratch{ks, xnewpos};
         bool again = false;
         if (reorder_xf) {
-            if (int rc = reorder_transforms_device(ctx, ks, xnewpos))
+            if (int rc = reorder_transforms_device(ctx, ks, xnewpos, phase))
                 return rc;
             phase.lap("device re-order: transforms");
         }
         for (auto& p : ctx->pools) {
             if (!p.bound || p.need_full || !(reorder_xf || reorder_pool[&p - ctx->pools]))
                 continue;  // (a pool whose transforms moved follows them: its links name transform entries)
-            const int rc = p.occupancy ? reorder_meshes_device(ctx, p, ks, reorder_xf ? xnewpos.ptr : nullptr) : GV_OK;
+            const int rc = p.occupancy ? reorder_meshes_device(ctx, p, ks, reorder_xf ? xnewpos.ptr : nullptr, phase) : GV_OK;
             if (rc == GV_E_STATE) {
                 p.need_full = true;
                 again = true;
@@ -1238,6 +1284,9 @@ int sync_mirror(GvCtx* ctx)
         }
         phase.lap("device re-order: mesh pools");
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the old streams are freed with the scratch
+        ks.release();
+        xnewpos.release();
+        phase.lap("device re-order: scratch freed");
         if (again)
             return sync_mirror(ctx);  // (pools without an order table: rebuilt on the host from the new transform tables)
     }

@@ -740,9 +740,9 @@ def test_pools_that_grow_are_appended_to_the_mirror(request, oracle, hier, ctx_n
     check(cut(31_700, 32_000))     # meshes of entities whose transforms do not exist yet (no transform: filtered out)
     # ... which arrive now: those meshes gained a TransformComponent, which the caller reports like any other change
     check(cut(32_000, 32_000), dirty_meshes=(31_700, 300))
-    assert vis.stats()["mirror_reorders"] == 0
+    before = vis.stats()["mirror_reorders"]  # (counted since gv_create; the context is shared by the module's tests)
     check(cut(36_000, 36_000))     # the tail passes 1/8 of the pool: the library re-orders (on the device: gv_reorder.hip)
-    assert vis.stats()["mirror_reorders"] == (0 if ctx_name == "gpu_slot_order" else 1)
+    assert vis.stats()["mirror_reorders"] - before == (0 if ctx_name == "gpu_slot_order" else 1)
     check(cut(40_000, 40_000))
     check(cut(25_000, 25_000))     # shrink: rebuild
     check(cut(25_100, 25_100))
@@ -792,6 +792,7 @@ def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, k
                               oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
 
     sizes = [150_000, 160_000, 172_000, 200_000, 215_000, 236_000, 260_000]
+    before = gpu.stats()["mirror_reorders"]
     sc = cut(sizes[0])
     gpu.bind_transforms(sc.transforms, sc.entity_to_transform)
     gpu.bind_pool(0, sc.meshes)
@@ -801,7 +802,7 @@ def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, k
     for k in sizes[1:]:
         sc = cut(k)
         check(sc)
-    assert gpu.stats()["mirror_reorders"] >= 2
+    assert gpu.stats()["mirror_reorders"] - before >= 2
     # changes after the re-order land where the entries now are
     lo = 3_000
     sc.transforms["position"][lo:lo + 5_000, :3] += rng.normal(0, 25, (5_000, 3)).astype(np.float32)

@@ -17,7 +17,7 @@ def one(n_total, kind):
     from garden_amd.lib import GpuVisibility
     from oracle import oracle_py
     full = scene.hierarchy_scene(n_total) if kind == "hier" else scene.flat_scene(n_total)
-    n0 = n_total - n_total // 9  # the tail is then just over 1/8 of the grown pool
+    n0 = n_total - (n_total // 8 + 1)  # the tail is then just over 1/8 of the grown pool
     view = scene.main_camera_view()
 
     def cut(n):
