@@ -1141,8 +1141,7 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
         if (!dirty)
             return;
         const uint32_t slot = chunk * kEmitChunk + part * (kEmitChunk / kEmitParts) + 4u * threadIdx.x;
-        if (4u * threadIdx.x >= kEmitChunk / kEmitParts) {
-        } else if (slot + 3u < args.mesh.count) {
+        if (slot + 3u < args.mesh.count) {
             *reinterpret_cast<uint32_t*>(args.out.is_visible + slot) = 0u;
         } else {
             for (uint32_t k = 0; slot + k < args.mesh.count; k++)
@@ -1195,7 +1194,7 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
         // lane t owns slots 4t .. 4t + 3 -> one 4-byte store, 1 KB of whole sectors per workgroup
         const uint32_t local = (block % kEmitParts) * (kEmitChunk / kEmitParts) + 4u * threadIdx.x;  // slot inside the chunk
         const uint32_t slot = chunk * kEmitChunk + local;
-        if (slot < args.mesh.count && 4u * threadIdx.x < kEmitChunk / kEmitParts) {
+        if (slot < args.mesh.count) {
             const uint32_t nibble = (uint32_t)(words[local >> 6] >> (local & 63u)) & 15u;
             const uint32_t bytes = (nibble & 1u) | ((nibble & 2u) << 7) | ((nibble & 4u) << 14) | ((nibble & 8u) << 21);
             if (slot + 3u < args.mesh.count) {

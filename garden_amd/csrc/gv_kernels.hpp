@@ -66,10 +66,7 @@ constexpr uint32_t kFusedEmitMaxSlots = 32768;  // pools up to this size cull + 
 constexpr uint32_t kAutoBoundsMinSlots = 262144;  // pools above this size get block bounds unless GV_CONFIG_LINEAR_SCAN (smaller
                                                   // ones are launch-bound and keep the one-launch / batched paths)
 constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
-#ifndef GV_EMIT_PARTS  // (A/B builds: tools/ab_lib.sh)
-#define GV_EMIT_PARTS 4
-#endif
-constexpr uint32_t kEmitParts = GV_EMIT_PARTS;     // emit workgroups per chunk: 1024 slots = 16 ballot words each
+constexpr uint32_t kEmitParts = 4;     // emit workgroups per chunk: 1024 slots = 16 ballot words each
 
 struct ViewParams {
     float planes[6][4];
