@@ -378,10 +378,14 @@ __global__ __launch_bounds__(256) void block_window_kernel(const ClassifyArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves = gridDim.x * 4u;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    BlockWindow next = a.kept[min(first, a.nblocks - 1u)];  // (asked for together with the count: the list is sized for every block of the pool)
     const uint32_t listed = *a.kept_count;
     const float inf = __builtin_huge_valf();
-    for (uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6))); j < listed; j += waves) {
-        const BlockWindow w = a.kept[j];  // wave-uniform
+    for (uint32_t j = first; j < listed; j += waves) {
+        const BlockWindow w = next;  // wave-uniform
+        if (j + waves < listed)
+            next = a.kept[j + waves];
         bool occluded = false;
         const uint32_t level = w.level & 0xFFu;
         if (level != 0xFFu) {
@@ -430,19 +434,43 @@ struct CullListArgs {
     uint32_t* next_count;      // the counter of the NEXT classify launch (the two alternate): cleared here
 };
 
+// the kernel's first argument (a CullArgs at the start of the kernarg segment), read again through a pointer the compiler cannot
+// see through
+typedef const CullArgs __attribute__((address_space(4))) * ConstCullArgs;
+__device__ __forceinline__ void reload_cull_args(CullArgs& out)
+{
+    ConstCullArgs kernarg = (ConstCullArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kernarg));
+    __builtin_memcpy(&out, kernarg, sizeof(out));
+}
+
 // last launch: the per-entity path of the listed blocks
 template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_list_kernel(const CullArgs args, const CullListArgs la)
 {
     __shared__ uint32_t wave_count[kCullBlock / 64];
+    // the workgroup's first list entry is asked for together with the count that says whether it exists (the list and the flags are
+    // sized for every block of the pool): one round trip in front of the block's own loads instead of three
+    uint32_t flag = la.kept_flag ? la.kept_flag[blockIdx.x] : 1u;
+    uint32_t block = la.kept[blockIdx.x].block;
     const uint32_t listed = *la.kept_count;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         *la.next_count = 0;
-    for (uint32_t j = blockIdx.x; j < listed; j += gridDim.x) {  // workgroup-uniform trip count
-        if (la.kept_flag && !la.kept_flag[j])
-            continue;
-        cull_block<HIZ, MAP>(args, la.kept[j].block, wave_count);
-        __syncthreads();  // the LDS words are reused by the next block
+    for (uint32_t j = blockIdx.x; j < listed;) {  // workgroup-uniform trip count
+        if (__builtin_amdgcn_readfirstlane((int)flag)) {  // (loaded values: told to the compiler to be wave-uniform, so that the block's
+            // The kernel arguments are read afresh for every block, through a pointer the compiler cannot see through: read once
+            // in front of the loop, the ~70 SGPRs of planes, matrices and pointers stay live across it — 106 SGPRs, the overflow
+            // spilled into 20 VGPRs, six waves per SIMD where cull_kernel (56 VGPRs) runs eight.
+            CullArgs fresh;
+            reload_cull_args(fresh);
+            cull_block<HIZ, MAP>(fresh, (uint32_t)__builtin_amdgcn_readfirstlane((int)block), wave_count);  // addresses are scalar as in cull_kernel)
+            __syncthreads();  // the LDS words are reused by the next block
+        }
+        j += gridDim.x;
+        if (j < listed) {
+            flag = la.kept_flag ? la.kept_flag[j] : 1u;
+            block = la.kept[j].block;
+        }
     }
 }
 
