@@ -154,12 +154,32 @@ __device__ __forceinline__ bool block_occluded(const HizDevice& hz, const ViewPa
     return !any_nan && fmaf(fabsf(znear), 2e-6f, znear) < zfar;
 }
 
-// The per-entity work of one 256-entry workgroup `lb`.
-template <bool HIZ, uint32_t MAP>
-__device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, uint32_t* wave_count)
+// the kernel's first argument (a CullArgs at the start of the kernarg segment), read again through a pointer the compiler cannot
+// see through
+typedef const CullArgs __attribute__((address_space(4))) * ConstCullArgs;
+__device__ __forceinline__ void reload_cull_args(CullArgs& out)
 {
-    const uint32_t i = lb * kCullBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    ConstCullArgs kernarg = (ConstCullArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kernarg));
+    __builtin_memcpy(&out, kernarg, sizeof(out));
+}
+
+// The per-entity work of one 256-entry workgroup `lb`. RELOAD (cull_list_kernel, which calls this in a loop): the kernel arguments
+// are read afresh at each stage — inlined into a loop, the ~70 SGPRs of planes, matrices and pointers would otherwise be read once
+// in front of it and stay live across it (106 SGPRs, the overflow spilled into VGPRs: six waves per SIMD where cull_kernel runs
+// eight); per stage each field lives only where it is used.
+template <bool HIZ, uint32_t MAP, bool RELOAD = false>
+__device__ __forceinline__ void cull_block(const CullArgs& args0, uint32_t lb, uint32_t* wave_count)
+{
+    CullArgs stage1;
+    if (RELOAD)
+        reload_cull_args(stage1);
+    const CullArgs& args = RELOAD ? stage1 : args0;
+    uint32_t tid = threadIdx.x;
+    if (RELOAD)  // (... and so is everything that only depends on the lane: hoisted out of the loop it would sit in VGPRs across it)
+        asm volatile("" : "+v"(tid));
+    const uint32_t i = lb * kCullBlock + tid;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     bool visible = false;
     if (i < args.mesh.count) {
         Mat34 m;
@@ -179,11 +199,20 @@ __device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, ui
         // Hi-Z occlusion query on the survivors. Measured (profiles/r01b_hiz_ablation.txt): compacting the
         // survivors across the workgroup through LDS first buys nothing — the stage is bound by the texel
         // gathers (~4.5 M random 64-B sectors per frame), not by divergent VALU work.
-        if (HIZ && visible)
-            visible = !hiz_occluded(args.hiz, args.view.vp, c);
-        if (args.view.write_is_visible)
-            args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
+        if (HIZ && visible) {
+            CullArgs stage2;
+            if (RELOAD)
+                reload_cull_args(stage2);
+            const CullArgs& a2 = RELOAD ? stage2 : args0;
+            visible = !hiz_occluded(a2.hiz, a2.view.vp, c);
+        }
     }
+    CullArgs stage3;
+    if (RELOAD)
+        reload_cull_args(stage3);
+    const CullArgs& out_args = RELOAD ? stage3 : args0;
+    if (i < out_args.mesh.count && out_args.view.write_is_visible)
+        out_args.out.is_visible[i] = visible ? 1 : 0;  // mesh.cpp:144,152,161,166
     __shared__ unsigned long long wave_word[kCullBlock / 64];
     const unsigned long long word = __ballot(visible);
     if (lane == 0) {
@@ -193,15 +222,15 @@ __device__ __forceinline__ void cull_block(const CullArgs& args, uint32_t lb, ui
     __syncthreads();
     // the tile's four ballot words leave as ONE 32-byte store (small stores are what a bandwidth-bound read kernel pays for:
     // tools/read_probe.hip), the tile's count as one atomic
-    if (threadIdx.x < kCullBlock / 64)
-        args.out.mask[(size_t)lb * (kCullBlock / 64) + threadIdx.x] = wave_word[threadIdx.x];
-    if (threadIdx.x == 0) {
+    if (tid < kCullBlock / 64)
+        out_args.out.mask[(size_t)lb * (kCullBlock / 64) + tid] = wave_word[tid];
+    if (tid == 0) {
         uint32_t total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kCullBlock / 64; w++)
             total += wave_count[w];
         if (total)  // integer adds commute: the sum is deterministic whatever the arrival order
-            atomicAdd(&args.out.chunk_count[lb / (kEmitChunk / kCullBlock)], total);
+            atomicAdd(&out_args.out.chunk_count[lb / (kEmitChunk / kCullBlock)], total);
     }
 }
 
@@ -434,16 +463,6 @@ struct CullListArgs {
     uint32_t* next_count;      // the counter of the NEXT classify launch (the two alternate): cleared here
 };
 
-// the kernel's first argument (a CullArgs at the start of the kernarg segment), read again through a pointer the compiler cannot
-// see through
-typedef const CullArgs __attribute__((address_space(4))) * ConstCullArgs;
-__device__ __forceinline__ void reload_cull_args(CullArgs& out)
-{
-    ConstCullArgs kernarg = (ConstCullArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kernarg));
-    __builtin_memcpy(&out, kernarg, sizeof(out));
-}
-
 // last launch: the per-entity path of the listed blocks
 template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_list_kernel(const CullArgs args, const CullListArgs la)
@@ -458,12 +477,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_list_kernel(const CullArgs ar
         *la.next_count = 0;
     for (uint32_t j = blockIdx.x; j < listed;) {  // workgroup-uniform trip count
         if (__builtin_amdgcn_readfirstlane((int)flag)) {  // (loaded values: told to the compiler to be wave-uniform, so that the block's
-            // The kernel arguments are read afresh for every block, through a pointer the compiler cannot see through: read once
-            // in front of the loop, the ~70 SGPRs of planes, matrices and pointers stay live across it — 106 SGPRs, the overflow
-            // spilled into 20 VGPRs, six waves per SIMD where cull_kernel (56 VGPRs) runs eight.
-            CullArgs fresh;
-            reload_cull_args(fresh);
-            cull_block<HIZ, MAP>(fresh, (uint32_t)__builtin_amdgcn_readfirstlane((int)block), wave_count);  // addresses are scalar as in cull_kernel)
+            cull_block<HIZ, MAP, true>(args, (uint32_t)__builtin_amdgcn_readfirstlane((int)block), wave_count);  // addresses are scalar as in cull_kernel)
             __syncthreads();  // the LDS words are reused by the next block
         }
         j += gridDim.x;
