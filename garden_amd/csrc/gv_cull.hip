@@ -465,7 +465,7 @@ struct CullListArgs {
 
 // last launch: the per-entity path of the listed blocks
 template <bool HIZ, uint32_t MAP>
-__global__ __launch_bounds__(kCullBlock) void cull_list_kernel(const CullArgs args, const CullListArgs la)
+__global__ __launch_bounds__(kCullBlock, 8) void cull_list_kernel(const CullArgs args, const CullListArgs la)
 {
     __shared__ uint32_t wave_count[kCullBlock / 64];
     // the workgroup's first list entry is asked for together with the count that says whether it exists (the list and the flags are
