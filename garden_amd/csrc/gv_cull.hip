@@ -829,34 +829,54 @@ struct MultiCullArgs {
     BlockBounds bounds;  // BOUNDS variants only
 };
 
+// One view's part of the batch arguments, read where the view is processed: the view loops below are NOT unrolled and fetch
+// planes[v] / outs[v] with scalar loads at a runtime offset from `base` (the argument block in the constant address space: the
+// kernarg segment, or the job's table entry). Unrolled over eight views the ~45 dwords per view were all live at once — 106 SGPRs
+// and 200-290 more spilled into VGPR lanes, a v_readlane per use.
+typedef const MultiCullArgs __attribute__((address_space(4))) * ConstMultiArgs;
+__device__ __forceinline__ MultiViewPlanes view_planes(ConstMultiArgs base, uint32_t v)
+{
+    MultiViewPlanes out;
+    __builtin_memcpy(&out, &base->planes[v], sizeof(out));
+    return out;
+}
+__device__ __forceinline__ ViewBuffers view_outputs(ConstMultiArgs base, uint32_t v)
+{
+    ViewBuffers out;
+    __builtin_memcpy(&out, &base->outs[v], sizeof(out));
+    return out;
+}
+
 template <bool HIZ, uint32_t MAP, bool BOUNDS>
-__device__ __forceinline__ void cull_multi_block(const MultiCullArgs& args, const uint32_t lb,
+__device__ __forceinline__ void cull_multi_block(const MultiCullArgs& args, ConstMultiArgs base, const uint32_t lb,
                                                  uint32_t (&wave_count)[kMaxBatchViews][kCullBlock / 64])
 {
+    asm volatile("" : "+s"(base));  // (opaque: nothing read through it is moved out of the loops)
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool in_range = i < args.mesh.count;
+    const uint32_t nviews = min(args.nviews, kMaxBatchViews);
     if (BOUNDS) {  // the workgroup is skipped when its box is outside EVERY view of the batch
         const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
         bool skip = true;
         if (!(lo.x > hi.x)) {
-#pragma unroll
-            for (uint32_t v = 0; v < kMaxBatchViews; v++)
-                if (v < args.nviews)
-                    skip = skip && block_behind_planes(lo, hi, args.planes[v].planes, args.planes[v].plane_count, args.cam,
-                                                       args.xf.max_depth);
+#pragma unroll 1
+            for (uint32_t v = 0; v < nviews && skip; v++) {
+                const MultiViewPlanes pl = view_planes(base, v);
+                skip = block_behind_planes(lo, hi, pl.planes, pl.plane_count, args.cam, args.xf.max_depth);
+            }
         }
         if (threadIdx.x == 0)
             args.bounds.examined[lb] = skip ? 0 : 1;
         if (skip) {
-#pragma unroll
-            for (uint32_t v = 0; v < kMaxBatchViews; v++)
-                if (v < args.nviews) {
-                    if (args.planes[v].write_is_visible && in_range)
-                        args.outs[v].is_visible[i] = 0;
-                    if (lane == 0)
-                        args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
-                }
+#pragma unroll 1
+            for (uint32_t v = 0; v < nviews; v++) {
+                const ViewBuffers out = view_outputs(base, v);
+                if (base->planes[v].write_is_visible && in_range)
+                    out.is_visible[i] = 0;
+                if (lane == 0)
+                    out.mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
+            }
             return;
         }
     }
@@ -867,43 +887,38 @@ __device__ __forceinline__ void cull_multi_block(const MultiCullArgs& args, cons
     const bool candidate = in_range && prepare_model<MAP>(args.mesh, args.xf, args.cam, i, m, box_a, box_b);
     const float reach = candidate ? sphere_reach(m, box_a, box_b) : 0.0f;  // one sphere for every view of the batch
     bool have_corners = false;  // generated once, by the first view that needs them
-#pragma unroll
-    for (uint32_t v = 0; v < kMaxBatchViews; v++) {
-        if (v < args.nviews) {  // uniform
-            const uint32_t where = candidate ? classify_sphere(m, reach, args.planes[v].planes, args.planes[v].plane_count) : kSphereOutside;
-            bool visible = where == kSphereInside;
-            if (where == kSphereUndecided || (HIZ && v == 0 && visible)) {
-                if (!have_corners) {
-                    aabb_corners(m, box_a, box_b, c);
-                    have_corners = true;
-                }
-                if (where == kSphereUndecided)
-                    visible = !behind_frustum(c, args.planes[v].planes, args.planes[v].plane_count);
+#pragma unroll 1
+    for (uint32_t v = 0; v < nviews; v++) {
+        const MultiViewPlanes pl = view_planes(base, v);
+        const uint32_t where = candidate ? classify_sphere(m, reach, pl.planes, pl.plane_count) : kSphereOutside;
+        bool visible = where == kSphereInside;
+        if (where == kSphereUndecided || (HIZ && v == 0 && visible)) {
+            if (!have_corners) {
+                aabb_corners(m, box_a, box_b, c);
+                have_corners = true;
             }
-            if (HIZ && v == 0 && visible)
-                visible = !hiz_occluded(args.hiz, args.vp0, c);
-            if (args.planes[v].write_is_visible && in_range)
-                args.outs[v].is_visible[i] = visible ? 1 : 0;
-            const unsigned long long word = __ballot(visible);
-            if (lane == 0) {
-                args.outs[v].mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
-                wave_count[v][wave] = (uint32_t)__popcll(word);
-            }
+            if (where == kSphereUndecided)
+                visible = !behind_frustum(c, pl.planes, pl.plane_count);
+        }
+        if (HIZ && v == 0 && visible)
+            visible = !hiz_occluded(args.hiz, args.vp0, c);
+        const ViewBuffers out = view_outputs(base, v);
+        if (pl.write_is_visible && in_range)
+            out.is_visible[i] = visible ? 1 : 0;
+        const unsigned long long word = __ballot(visible);
+        if (lane == 0) {
+            out.mask[(size_t)lb * (kCullBlock / 64) + wave] = word;
+            wave_count[v][wave] = (uint32_t)__popcll(word);
         }
     }
     __syncthreads();
-    if (threadIdx.x < args.nviews) {
+    if (threadIdx.x < nviews) {
         uint32_t total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < kCullBlock / 64; w++)
             total += wave_count[threadIdx.x][w];
         if (total) {
-            // outs[] indexed by a lane-varying view: pick the pointer with uniform compares (kernarg stays in SGPRs)
-            uint32_t* counts = nullptr;
-#pragma unroll
-            for (uint32_t v = 0; v < kMaxBatchViews; v++)
-                if (threadIdx.x == v)
-                    counts = args.outs[v].chunk_count;
+            uint32_t* counts = base->outs[threadIdx.x].chunk_count;  // (a lane-varying view: an ordinary load from the argument block)
             atomicAdd(&counts[lb / (kEmitChunk / kCullBlock)], total);
         }
     }
@@ -913,7 +928,7 @@ template <bool HIZ, uint32_t MAP, bool BOUNDS>
 __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullArgs args)
 {
     __shared__ uint32_t wave_count[kMaxBatchViews][kCullBlock / 64];
-    cull_multi_block<HIZ, MAP, BOUNDS>(args, blockIdx.x, wave_count);
+    cull_multi_block<HIZ, MAP, BOUNDS>(args, (ConstMultiArgs)__builtin_amdgcn_kernarg_segment_ptr(), blockIdx.x, wave_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_multi_kernel(const MultiCullA
 // (blockIdx.y = (job, view)). The job descriptors live in a device table; the kernels read it through the constant
 // address space (uniform index -> scalar loads, exactly what a by-value kernel argument compiles to).
 // ------------------------------------------------------------------------------------------------
-typedef const MultiCullArgs __attribute__((address_space(4))) * ConstCullTable;
+typedef ConstMultiArgs ConstCullTable;
 
 __global__ __launch_bounds__(kCullBlock) void cull_table_kernel(const MultiCullArgs* __restrict__ table)
 {
@@ -933,9 +948,9 @@ __global__ __launch_bounds__(kCullBlock) void cull_table_kernel(const MultiCullA
         return;  // the grid is as wide as the largest pool of the tick
 #define GV_TABLE_CULL(HIZ)                                                                              \
     switch (args.mesh.mapping) {                                                                        \
-    case kMapExact: cull_multi_block<HIZ, kMapExact, false>(args, blockIdx.x, wave_count); break;       \
-    case kMapSpeculate: cull_multi_block<HIZ, kMapSpeculate, false>(args, blockIdx.x, wave_count); break; \
-    default: cull_multi_block<HIZ, kMapGeneral, false>(args, blockIdx.x, wave_count); break;            \
+    case kMapExact: cull_multi_block<HIZ, kMapExact, false>(args, (ConstCullTable)table + blockIdx.y, blockIdx.x, wave_count); break;       \
+    case kMapSpeculate: cull_multi_block<HIZ, kMapSpeculate, false>(args, (ConstCullTable)table + blockIdx.y, blockIdx.x, wave_count); break; \
+    default: cull_multi_block<HIZ, kMapGeneral, false>(args, (ConstCullTable)table + blockIdx.y, blockIdx.x, wave_count); break;            \
     }
     if (args.use_hiz0) {
         GV_TABLE_CULL(true)
