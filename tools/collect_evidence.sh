@@ -51,8 +51,8 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
     echo "## $a"
     GV_TICK_BREAKDOWN=1 ./tests/cpp/build/headless_tick --mode gpu --ticks 2000 $a 2>&1 | grep -E "prepare us"
   done
-  echo "# round 1 (profiles/r01k_tick_*, DESIGN.md): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203"
-} > $out/r02_tick.txt 2>&1
+  echo "# round 1 (profiles/r01k_tick_*): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203; round 2 (profiles/r02_tick.txt, records into page-locked engine vectors): 2 k 21-22, 10 k 33.8-36, 100 k 161-173, --mixed --csm 76-86"
+} > $out/r03_tick.txt 2>&1
 {
   echo "# tools/hiz_sizes.py: pyramid rebuild by frame size, wall clock over 300 back-to-back rebuilds (us)"
   timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
@@ -62,6 +62,10 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
   GV_DEBUG_HIZ_NO_FUSED3=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
   echo "# ... and without the tail kernel either (GV_DEBUG_HIZ_NO_TAIL=1: one launch per level all the way, the round-1 form for such sizes)"
   GV_DEBUG_HIZ_NO_FUSED3=1 GV_DEBUG_HIZ_NO_TAIL=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-} > $out/r02_hiz_sizes.txt 2>&1
-python3 bench.py > $out/r02k_default_bench_line.json 2> $out/default.err
+} > $out/r03_hiz_sizes.txt 2>&1
+{
+  echo "# tools/multiview_bench.py: main camera + 3 cascades over 10 M entities, one batched pass vs one pass per view (ms per frame; kernel us per frame)"
+  timeout 300 python3 tools/multiview_bench.py 2>&1 | grep -E "batched|separate"
+} > $out/r03_multiview.txt 2>&1
+python3 bench.py > $out/default_bench_line.json 2> $out/default.err
 tail -c 600 $out/default.err
