@@ -15,7 +15,7 @@ for block in re.findall(r"- \.agpr_count:.*?\.wavefront_size:", text, re.S):
     g = lambda k: re.search(r"\." + k + r":\s+(\S+)", block)
     name = g("name").group(1)
     try:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+        name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     except Exception:
         pass
     name = re.sub(r"\(.*", "", name).replace("void ", "")
