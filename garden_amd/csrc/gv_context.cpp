@@ -1681,6 +1681,20 @@ int gv_pool_mirror_slots(GvCtx* ctx, uint32_t pool_id, uint32_t* entry_to_slot, 
     return GV_OK;
 }
 
+int gv_pool_mirror_epoch(GvCtx* ctx, uint32_t pool_id, uint64_t* epoch)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || !epoch)
+        return ctx->fail(GV_E_ARG, "gv_pool_mirror_epoch: bad argument (pool %u)", pool_id);
+    if (!ctx->pools[pool_id].bound)
+        return ctx->fail(GV_E_STATE, "gv_pool_mirror_epoch: pool %u is not bound", pool_id);
+    if (int rc = sync_mirror(ctx))
+        return rc;
+    *epoch = ctx->pools[pool_id].order_epoch;
+    return GV_OK;
+}
+
 int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count)
 {
     if (!ctx)

@@ -194,6 +194,7 @@ struct PoolState {
     DirtyRanges dirty;               // itemised (scattered enable / ready / AABB edits re-mirror what they touched)
     // spatial mirror order (empty = slot order): perm[j] = pool slot held by mirror entry j, inv = its inverse
     std::vector<uint32_t> perm, inv;
+    uint64_t order_epoch = 0;    // bumped whenever the entry -> slot table changes (full build, appended slots, re-order): gv_pool_mirror_epoch
     DeviceBuf<uint32_t> d_orig;  // perm on the device: emit reports original pool slots
     DeviceBuf<uint32_t> d_inv;   // inv on the device: the device-side gather of dirty mesh ranges (upload_meshes_device)
     DirtyRange staging_stale;    // slots whose host staging entries lag behind the device (written by that path)

@@ -783,6 +783,7 @@ int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
     p.mirrored = n1;
     p.appended += n1 - n0;
     p.epoch++;
+    p.order_epoch++;
     return GV_OK;
 }
 
@@ -864,17 +865,18 @@ inline bool tables_agree(const uint32_t* perm, const uint32_t* inv, size_t n)
 int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xnewpos, PhaseTimer& phase)
 {
     const uint32_t n = ctx->xf_mirrored;
-    DeviceBuf<uint32_t> root, order, box, perm;
+    DeviceBuf<uint32_t> root, order, box, perm, xinv_new;
     DeviceBuf<float> code;
     DeviceBuf<XfAB> ab;
     DeviceBuf<float2> c;
     DeviceBuf<uint8_t> flags;
     DeviceBuf<uint32_t> parent;
-    auto drop = [&] { root.release(), order.release(), box.release(), perm.release(), code.release(), ab.release(), c.release(), flags.release(), parent.release(); };
+    auto drop = [&] { root.release(), order.release(), box.release(), perm.release(), xinv_new.release(), code.release(), ab.release(), c.release(), flags.release(), parent.release(); };
     struct Guard { decltype(drop)& f; ~Guard() { f(); } } guard{drop};
     GV_HIP(ctx, root.reserve(n));
     GV_HIP(ctx, order.reserve(n));
     GV_HIP(ctx, perm.reserve(n));
+    GV_HIP(ctx, xinv_new.reserve(ctx->d_xinv.cap));
     GV_HIP(ctx, box.reserve(8));
     GV_HIP(ctx, code.reserve(n));
     GV_HIP(ctx, xnewpos.reserve(n));
@@ -890,23 +892,25 @@ int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xn
     GV_HIP(ctx, launch_reorder_invert(order.ptr, n, xnewpos.ptr, ctx->stream));
     GV_HIP(ctx, launch_reorder_transforms(order.ptr, xnewpos.ptr, n, ctx->d_xab.ptr, ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->d_xparent.ptr, ab.ptr, c.ptr,
                                           flags.ptr, parent.ptr, ctx->stream));
-    GV_HIP(ctx, launch_reorder_remap(ctx->d_xinv.ptr, n, xnewpos.ptr, perm.ptr, ctx->stream));
+    GV_HIP(ctx, launch_reorder_remap(ctx->d_xinv.ptr, n, xnewpos.ptr, xinv_new.ptr, perm.ptr, ctx->stream));  // (nothing of the old mirror is written: a failure below leaves it whole)
     // the new tables and parent links come home; the staging records double as the pinned bounce buffer (stale from here on)
     uint32_t* bounce = reinterpret_cast<uint32_t*>(ctx->h_xab.ptr);  // 8 words per entry
-    if (int rc = download_words(ctx, ctx->d_xinv.ptr, bounce, n)) return rc;
+    if (int rc = download_words(ctx, xinv_new.ptr, bounce, n)) return rc;
     if (int rc = download_words(ctx, perm.ptr, bounce + n, n)) return rc;
-    if (int rc = download_words(ctx, parent.ptr, ctx->h_xparent.ptr, n)) return rc;
+    if (int rc = download_words(ctx, parent.ptr, bounce + 2 * (size_t)n, n)) return rc;
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     phase.lap("  re-order: device + downloads");
     if (!tables_agree(bounce + n, bounce, n))
         return ctx->fail(GV_E_HIP, "device re-order of the transform mirror returned tables that are not a permutation");
     copy_words(ctx->xinv, bounce, n);  // (in place: the vectors already have this size)
     copy_words(ctx->xperm, bounce + n, n);
+    parallel_ranges(0, n, [&](uint32_t a, uint32_t b) { memcpy(ctx->h_xparent.ptr + a, bounce + 2 * (size_t)n + a, (size_t)(b - a) * 4); });
     phase.lap("  re-order: host tables");
     std::swap(ctx->d_xab, ab);
     std::swap(ctx->d_xc, c);
     std::swap(ctx->d_xflags, flags);
     std::swap(ctx->d_xparent, parent);
+    std::swap(ctx->d_xinv, xinv_new);
     GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
     ctx->staging_stale.add(0, n);
     ctx->world_valid = false;  // (the cache is in the old order; the next sweep rebuilds it)
@@ -969,6 +973,7 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
         p.mapping = kMapSpeculate;
     p.staging_stale.add(0, n);
     p.epoch++;
+    p.order_epoch++;
     p.appended = 0;
     const uint32_t pool_id = (uint32_t)(&p - ctx->pools);
     for (auto& vs : ctx->views[pool_id]) {  // per-entry outputs of earlier culls are in the old order
@@ -1208,6 +1213,7 @@ int sync_mirror(GvCtx* ctx)
             p.dirty.clear();
             p.staging_stale.clear();  // (every entry has just been gathered)
             p.epoch++;
+            p.order_epoch++;
             p.mirrored = p.occupancy;
             p.appended = 0;
         } else if (p.dirty.any()) {

@@ -136,15 +136,15 @@ __global__ __launch_bounds__(kThreads) void reorder_transforms_kernel(const uint
     parent_out[k] = (p == kSlotNone || p >= n) ? kSlotNone : newpos[p];
 }
 
-// table[s] = newpos[table[s]] (slot -> entry tables), and its inverse entry -> slot when asked for
-__global__ __launch_bounds__(kThreads) void reorder_remap_kernel(uint32_t* __restrict__ table, uint32_t n, const uint32_t* __restrict__ newpos,
-                                                                 uint32_t* __restrict__ inverse)
+// out[s] = newpos[table[s]] (slot -> entry tables), and its inverse entry -> slot when asked for
+__global__ __launch_bounds__(kThreads) void reorder_remap_kernel(const uint32_t* __restrict__ table, uint32_t n, const uint32_t* __restrict__ newpos,
+                                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ inverse)
 {
     const uint32_t s = blockIdx.x * kThreads + threadIdx.x;
     if (s >= n)
         return;
     const uint32_t j = newpos[table[s]];
-    table[s] = j;
+    out[s] = j;
     if (inverse)
         inverse[j] = s;
 }
@@ -225,10 +225,10 @@ hipError_t launch_reorder_transforms(const uint32_t* order, const uint32_t* newp
     return hipGetLastError();
 }
 
-hipError_t launch_reorder_remap(uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* inverse, hipStream_t stream)
+hipError_t launch_reorder_remap(const uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* out, uint32_t* inverse, hipStream_t stream)
 {
     if (n)
-        hipLaunchKernelGGL(reorder_remap_kernel, grid_for(n), dim3(kThreads), 0, stream, table, n, newpos, inverse);
+        hipLaunchKernelGGL(reorder_remap_kernel, grid_for(n), dim3(kThreads), 0, stream, table, n, newpos, out, inverse);
     return hipGetLastError();
 }
 

@@ -66,8 +66,8 @@ hipError_t launch_reorder_invert(const uint32_t* order, uint32_t n, uint32_t* ne
 hipError_t launch_reorder_transforms(const uint32_t* order, const uint32_t* newpos, uint32_t n, const XfAB* ab_in, const float2* c_in,
                                      const uint8_t* flags_in, const uint32_t* parent_in, XfAB* ab_out, float2* c_out, uint8_t* flags_out,
                                      uint32_t* parent_out, hipStream_t stream);
-// table[s] = newpos[table[s]]; inverse (may be NULL): inverse[table[s]] = s
-hipError_t launch_reorder_remap(uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* inverse, hipStream_t stream);
+// out[s] = newpos[table[s]]; inverse (may be NULL): inverse[out[s]] = s
+hipError_t launch_reorder_remap(const uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* out, uint32_t* inverse, hipStream_t stream);
 // key[i] = the (new: xnewpos, or NULL = unchanged) mirror entry of mesh entry i's transform; none: last
 hipError_t launch_reorder_mesh_keys(const uint32_t* link, uint32_t n, const uint32_t* xnewpos, uint32_t xn, float* key, hipStream_t stream);
 // *unpaired = 1 when a candidate does not sit at its transform's index afterwards (kMapExact no longer holds)

@@ -107,7 +107,7 @@ EXPORTS = [
     "gv_abi_version", "gv_create", "gv_destroy", "gv_last_error", "gv_transform_bind", "gv_pool_bind",
     "gv_transform_bind_columns", "gv_pool_bind_columns", "gv_pool_bind_ready",
     "gv_mark_dirty", "gv_hierarchy_rebuild", "gv_sync", "gv_cull", "gv_wait", "gv_results_fetch",
-    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_results_copy_mask_device", "gv_pool_mirror_slots", "gv_sort", "gv_sweep", "gv_get_world",
+    "gv_result_count", "gv_results_device", "gv_results_copy_idx_device", "gv_results_copy_shard_device", "gv_results_copy_mask_device", "gv_pool_mirror_slots", "gv_pool_mirror_epoch", "gv_sort", "gv_sweep", "gv_get_world",
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
@@ -162,6 +162,7 @@ def load():
     lib.gv_results_copy_shard_device.argtypes = [P, u32, P, u32, u32]
     lib.gv_results_copy_mask_device.argtypes = [P, u32, P, u32]
     lib.gv_pool_mirror_slots.argtypes = [P, u32, P, u32]
+    lib.gv_pool_mirror_epoch.argtypes = [P, u32, P]
     lib.gv_sort.argtypes = [P, u32, C.c_int]
     lib.gv_sweep.argtypes = [P, u32]
     lib.gv_get_world.argtypes = [P, u32, u32, P]
@@ -446,6 +447,12 @@ class GpuVisibility:
         """Exchange shard as a bit per MIRROR entry: [draw_count, ceil(occupancy / 32) words] into device memory at dst_ptr
         (entry e is pool slot mirror_slots()[e])."""
         self._check(self.lib.gv_results_copy_mask_device(self.ctx, view_index, dst_ptr, word_count))
+
+    def mirror_epoch(self, pool_id=0):
+        """Changes whenever mirror_slots() does (rebuild, appended slots, re-order after entity churn)."""
+        e = C.c_uint64()
+        self._check(self.lib.gv_pool_mirror_epoch(self.ctx, pool_id, C.byref(e)))
+        return int(e.value)
 
     def mirror_slots(self, pool_id, occupancy):
         """entry -> pool slot table of the pool's device mirror (changes only when the mirror is rebuilt)."""

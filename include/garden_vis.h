@@ -232,12 +232,16 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
  * ~3 % visibility, 1/7 of the list at the bench's 21 % — and an equal-size all-gather by construction: the encoding for dense
  * views on the links of a multi-GPU node. It is the cull kernel's own output, so producing it is a 1.6 MB copy per 12.5 M
  * entries (bits in pool-slot order would cost a scatter per frame: measured, +126 us). Entry e is pool slot
- * gv_pool_mirror_slots()[e]: that table only changes when the mirror is rebuilt (gv_hierarchy_rebuild, a pool bound with
- * another occupancy), so consumers fetch it once per rebuild — with GV_CONFIG_KEEP_SLOT_ORDER it is the identity. Main-pass
+ * gv_pool_mirror_slots()[e]: that table only changes when the mirror is rebuilt, grown or re-ordered (gv_hierarchy_rebuild, a pool
+ * bound with another occupancy; gv_pool_mirror_epoch says when), so consumers fetch it once per change — with GV_CONFIG_KEEP_SLOT_ORDER it is the identity. Main-pass
  * views of any pool, and every view that took the ordinary cull launch (GV_E_STATE otherwise). No host synchronisation. */
 int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t word_count);
 /* entry_to_slot[e] = pool slot of mirror entry e, e < min(occupancy, capacity); host memory. Synchronises the mirror first. */
 int gv_pool_mirror_slots(GvCtx* ctx, uint32_t pool_id, uint32_t* entry_to_slot, uint32_t capacity);
+/* A counter that changes whenever that table does — a (re)build, slots appended after a bind with a larger occupancy, the
+ * re-order of the mirror after entity churn: a consumer of the bit shards compares it with the value it fetched the table at.
+ * Synchronises the mirror first (like gv_pool_mirror_slots: the two are consistent with each other). */
+int gv_pool_mirror_epoch(GvCtx* ctx, uint32_t pool_id, uint64_t* epoch);
 
 /* A spatial tile's pool slots are not a contiguous range of the world's (roots -> tile, descendants
  * follow): `global_ids[slot]` is the id the exchange should carry for pool slot `slot` (e.g. the mesh slot in the

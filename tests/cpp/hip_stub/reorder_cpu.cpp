@@ -80,12 +80,12 @@ hipError_t launch_reorder_transforms(const uint32_t* order, const uint32_t* newp
     return hipSuccess;
 }
 
-hipError_t launch_reorder_remap(uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* inverse, hipStream_t)
+hipError_t launch_reorder_remap(const uint32_t* table, uint32_t n, const uint32_t* newpos, uint32_t* out, uint32_t* inverse, hipStream_t)
 {
     for (uint32_t s = 0; s < n; s++) {
-        table[s] = newpos[table[s]];
+        out[s] = newpos[table[s]];
         if (inverse)
-            inverse[table[s]] = s;
+            inverse[out[s]] = s;
     }
     return hipSuccess;
 }

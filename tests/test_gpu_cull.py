@@ -791,6 +791,22 @@ def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, k
         assert np.array_equal(gpu.get_world(0, sc.transforms.shape[0]).view(np.uint32),
                               oracle.world_matrices(sc.transforms, sc.entity_to_transform).view(np.uint32))
 
+    import torch
+    from garden_amd.multi import expand_mask_rows, mask_words
+
+    def check_bits(sc):
+        """The visible list as one bit per MIRROR entry decodes to the same set through the entry -> slot table as it is now."""
+        k = sc.meshes.shape[0]
+        table = gpu.mirror_slots(0, k)
+        assert np.array_equal(np.sort(table), np.arange(k))
+        gpu.cull(0, [view])
+        shard = torch.full((1 + mask_words(k),), -1, dtype=torch.int32, device="cuda:0")
+        gpu.copy_mask_device(0, shard.data_ptr(), mask_words(k))
+        gpu.wait()
+        exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
+        slots, counts = expand_mask_rows(shard.view(1, -1), k, entry_tables=[table], index_bases=[0])
+        assert counts.tolist() == [exp["draw_count"]] and np.array_equal(slots, np.sort(exp["visible_idx"]).astype(np.int64))
+
     sizes = [150_000, 160_000, 172_000, 200_000, 215_000, 236_000, 260_000]
     before = gpu.stats()["mirror_reorders"]
     sc = cut(sizes[0])
@@ -799,10 +815,15 @@ def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, k
     gpu.bind_pool(1, second)
     gpu.hierarchy_rebuild()
     check(sc, rebind=False)
+    epochs = [gpu.mirror_epoch(0)]
     for k in sizes[1:]:
         sc = cut(k)
         check(sc)
+        epochs.append(gpu.mirror_epoch(0))  # the table changed (appended slots, and twice a re-order): consumers can tell
+        assert epochs[-1] > epochs[-2]
+        check_bits(sc)
     assert gpu.stats()["mirror_reorders"] - before >= 2
+    assert gpu.mirror_epoch(0) == epochs[-1] and gpu.mirror_epoch(1) > 0  # ... and stays put while it does not
     # changes after the re-order land where the entries now are
     lo = 3_000
     sc.transforms["position"][lo:lo + 5_000, :3] += rng.normal(0, 25, (5_000, 3)).astype(np.float32)
