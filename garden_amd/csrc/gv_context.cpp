@@ -285,14 +285,34 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                                (!(ctx->config.flags & GV_CONFIG_LINEAR_SCAN) && p.occupancy > kAutoBoundsMinSlots);
     if (bounds_wanted && p.occupancy != 0 && !fused) {
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
+        const bool patchable = mesh.mapping == kMapExact && xf.max_depth == 0 && mesh.count <= xf.count;  // entry i <-> transform entry i, no chains
+        static const bool patching = getenv("GV_DEBUG_NO_BOUNDS_PATCH") == nullptr;
+        if (!current && patching && p.patch_valid && patchable && p.d_blk_lo.ptr && p.d_blk_dirty.ptr) {
+            // every change since the boxes were current is on record (sync_mirror flagged the blocks): re-derive those blocks — and
+            // their entries' emit seeds when the seeds were in step with the boxes — instead of culling without boxes until the
+            // pool comes to rest (a scene in which a few entities move every frame never does)
+            const bool seeds_in_step = p.d_seed.ptr && p.d_seed.cap >= p.occupancy && p.seed_epoch == p.bounds_epoch && p.seed_xf_epoch == p.bounds_xf_epoch;
+            KernelTimer t(ctx, GV_K_SWEEP);
+            GV_HIP(ctx, launch_block_patch(mesh, xf, p.d_blk_lo.ptr, p.d_blk_hi.ptr, seeds_in_step ? p.d_seed.ptr : nullptr, p.d_blk_dirty.ptr, ctx->stream));
+            if (seeds_in_step) {
+                p.seed_epoch = p.epoch;
+                p.seed_xf_epoch = ctx->xf_epoch;
+            }
+            p.bounds_epoch = p.epoch;
+            p.bounds_xf_epoch = ctx->xf_epoch;
+            current = true;
+        }
         if (!current && may_rebuild) {
             const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
             GV_HIP(ctx, p.d_blk_lo.reserve(nb));
             GV_HIP(ctx, p.d_blk_hi.reserve(nb));
+            GV_HIP(ctx, p.d_blk_dirty.reserve((nb + 15) & ~(size_t)15));
+            GV_HIP(ctx, hipMemsetAsync(p.d_blk_dirty.ptr, 0, p.d_blk_dirty.cap, ctx->stream));
             KernelTimer t(ctx, GV_K_SWEEP);  // accounted with the other per-change passes
             GV_HIP(ctx, launch_block_bounds(mesh, xf, p.d_blk_lo.ptr, p.d_blk_hi.ptr, ctx->stream));
             p.bounds_epoch = p.epoch;
             p.bounds_xf_epoch = ctx->xf_epoch;
+            p.patch_valid = patchable;  // from here on every sync records what it re-mirrors (gv_mirror.cpp mark_dirty_blocks)
             current = true;
         }
         if (current) {

@@ -202,6 +202,9 @@ struct PoolState {
     uint32_t index_map_count = 0;     // 0: none
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
+    DeviceBuf<uint8_t> d_blk_dirty;  // one byte per block: holds an entry re-mirrored since the boxes (and seeds) were last current
+    bool patch_valid = false;        // every change of the mirror since then is recorded in d_blk_dirty (flat, exactly paired pools):
+                                     // the next cull re-derives the flagged blocks instead of going without boxes
     DeviceBuf<EmitSeed> d_seed;    // emit seeds (gv_kernels.hpp), valid for (seed_xf_epoch, seed_epoch)
     uint64_t seed_epoch = 0, seed_xf_epoch = 0;
     DeviceBuf<uint32_t> d_kept;    // [2 alternating counters, 2 words of padding | list entries] of launch_cull_listed
@@ -298,6 +301,8 @@ struct Context {
     PinnedBuf<uint8_t> h_raw[2];   // the library's own pinned chunks the span travels through (double-buffered)
     hipEvent_t raw_done[2] = {nullptr, nullptr};  // chunk buffer k may be rewritten once its last copy has run
     DirtyRange staging_stale;      // slots whose host staging entries lag behind the device (written by that path)
+    PinnedBuf<uint32_t> h_ranges;  // a sync's dirty ranges on their way to mark_dirty_blocks_kernel
+    DeviceBuf<uint32_t> d_ranges;
     DeviceBuf<uint32_t> d_e2t;     // entity -> transform slot table on the device, refreshed by every device-side mesh gather
     DeviceBuf<uint32_t> d_flag;    // one word: "a candidate no longer pairs with its own index" (aos_meshes_kernel)
     PinnedBuf<uint32_t> h_flag;

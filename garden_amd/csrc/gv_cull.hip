@@ -729,11 +729,9 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
 
 // World-space box of each cull workgroup's candidates (camera at the origin: translate(-0) leaves c3 as it is).
 template <uint32_t MAP>
-__global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirror mesh, const TransformMirror xf,
-                                                                  float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+__device__ __forceinline__ void block_bounds_of(const MeshMirror& mesh, const TransformMirror& xf, const uint32_t lb, float (*red)[7],
+                                                float4* __restrict__ out_lo, float4* __restrict__ out_hi)
 {
-    __shared__ float red[kCullBlock / 64][7];
-    const uint32_t lb = blockIdx.x;
     const uint32_t i = lb * kCullBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float inf = __builtin_huge_valf();
@@ -798,6 +796,106 @@ __global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirr
         out_lo[lb] = make_float4(red[0][0], red[0][1], red[0][2], red[0][6]);
         out_hi[lb] = make_float4(red[0][3], red[0][4], red[0][5], 0.0f);
     }
+}
+
+template <uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void block_bounds_kernel(const MeshMirror mesh, const TransformMirror xf,
+                                                                  float4* __restrict__ out_lo, float4* __restrict__ out_hi)
+{
+    __shared__ float red[kCullBlock / 64][7];
+    block_bounds_of<MAP>(mesh, xf, blockIdx.x, red, out_lo, out_hi);
+}
+
+// one emit seed per entry of a flat, exactly paired pool (gv_kernels.hpp EmitSeed)
+__device__ __forceinline__ void emit_seed_of(const MeshMirror& mesh, const TransformMirror& xf, EmitSeed* __restrict__ seeds, uint32_t i)
+{
+    if (i >= mesh.count || i >= xf.count)
+        return;
+    float4* out = reinterpret_cast<float4*>(seeds + i);
+    const float2 c = xf.c[i];
+    out[0] = xf.ab[i].a;
+    out[1] = xf.ab[i].b;
+    out[2] = make_float4(c.x, c.y, __uint_as_float(mesh.orig ? mesh.orig[i] : i), 0.0f);
+    out[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// What a pool AT REST has derived from its mirror — block bounds, emit seeds — kept current while a few entries change per frame
+// (round 3; flat, exactly paired pools): every sync flags the 256-entry blocks that hold a re-mirrored entry
+// (mark_dirty_blocks_kernel); the next cull re-derives just those. A workgroup reads the flags of 16 consecutive blocks with one
+// load and walks the flagged ones: a tenth of the workgroups of one per block (a launch whose workgroups mostly leave at once is
+// still paid per workgroup: 9 us for 39 k).
+constexpr uint32_t kPatchSpan = 16;
+template <uint32_t MAP>
+__global__ __launch_bounds__(kCullBlock) void block_patch_kernel(const MeshMirror mesh, const TransformMirror xf, float4* __restrict__ out_lo,
+                                                                 float4* __restrict__ out_hi, EmitSeed* __restrict__ seeds /* or NULL */,
+                                                                 uint8_t* __restrict__ flags /* padded to a multiple of kPatchSpan */,
+                                                                 uint32_t nblocks)
+{
+    __shared__ float red[kCullBlock / 64][7];
+    const uint4 word = *reinterpret_cast<const uint4*>(flags + (size_t)blockIdx.x * kPatchSpan);  // workgroup-uniform
+    if ((word.x | word.y | word.z | word.w) == 0u)
+        return;
+    const uint32_t w[4] = {word.x, word.y, word.z, word.w};
+#pragma unroll 1
+    for (uint32_t k = 0; k < kPatchSpan; k++) {
+        const uint32_t lb = blockIdx.x * kPatchSpan + k;
+        if (!((w[k >> 2] >> (8u * (k & 3u))) & 0xFFu) || lb >= nblocks)
+            continue;
+        block_bounds_of<MAP>(mesh, xf, lb, red, out_lo, out_hi);
+        if (seeds)
+            emit_seed_of(mesh, xf, seeds, lb * kCullBlock + threadIdx.x);
+        __syncthreads();  // `red` is reused by the next block
+    }
+    if (threadIdx.x == 0)  // (every lane has read the flags into `word` before anyone gets here: the load precedes the first barrier)
+        *reinterpret_cast<uint4*>(flags + (size_t)blockIdx.x * kPatchSpan) = make_uint4(0, 0, 0, 0);
+}
+
+hipError_t launch_block_patch(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, EmitSeed* seeds, uint8_t* flags,
+                              hipStream_t stream)
+{
+    if (mesh.count == 0)
+        return hipSuccess;
+    const uint32_t nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
+    const dim3 grid((nblocks + kPatchSpan - 1) / kPatchSpan), block(kCullBlock);
+    switch (mesh.mapping) {
+    case kMapExact: hipLaunchKernelGGL((block_patch_kernel<kMapExact>), grid, block, 0, stream, mesh, xf, lo, hi, seeds, flags, nblocks); break;
+    case kMapSpeculate: hipLaunchKernelGGL((block_patch_kernel<kMapSpeculate>), grid, block, 0, stream, mesh, xf, lo, hi, seeds, flags, nblocks); break;
+    default: hipLaunchKernelGGL((block_patch_kernel<kMapGeneral>), grid, block, 0, stream, mesh, xf, lo, hi, seeds, flags, nblocks); break;
+    }
+    return hipGetLastError();
+}
+
+// flags[entry >> 8] = 1 for every entry re-mirrored by a sync: thread t is the t-th dirty slot of the sync's ranges (start[k] = slots
+// in the ranges before range k, first[k] = its first slot); inv: pool slot -> mirror entry (NULL: the mirror is in slot order)
+__global__ __launch_bounds__(256) void mark_dirty_blocks_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ first, uint32_t nranges,
+                                                                const uint32_t* __restrict__ inv, uint32_t entries, uint8_t* __restrict__ flags)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= start[nranges])
+        return;
+    uint32_t lo = 0, hi = nranges;  // the range k with start[k] <= t < start[k + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (start[mid] <= t)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t slot = first[lo] + (t - start[lo]);
+    if (slot >= entries)
+        return;
+    const uint32_t entry = inv ? inv[slot] : slot;
+    if (entry < entries)
+        flags[entry / kCullBlock] = 1;
+}
+
+hipError_t launch_mark_dirty_blocks(const uint32_t* start, const uint32_t* first, uint32_t nranges, uint32_t total, const uint32_t* inv,
+                                    uint32_t entries, uint8_t* flags, hipStream_t stream)
+{
+    if (total == 0 || nranges == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(mark_dirty_blocks_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, start, first, nranges, inv, entries, flags);
+    return hipGetLastError();
 }
 
 hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream)
@@ -1436,15 +1534,7 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
 
 __global__ __launch_bounds__(256) void emit_seeds_kernel(const MeshMirror mesh, const TransformMirror xf, EmitSeed* __restrict__ seeds)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= mesh.count || i >= xf.count)
-        return;
-    float4* out = reinterpret_cast<float4*>(seeds + i);
-    const float2 c = xf.c[i];
-    out[0] = xf.ab[i].a;
-    out[1] = xf.ab[i].b;
-    out[2] = make_float4(c.x, c.y, __uint_as_float(mesh.orig ? mesh.orig[i] : i), 0.0f);
-    out[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    emit_seed_of(mesh, xf, seeds, blockIdx.x * 256 + threadIdx.x);
 }
 
 hipError_t launch_emit_seeds(const MeshMirror& mesh, const TransformMirror& xf, EmitSeed* seeds, hipStream_t stream)

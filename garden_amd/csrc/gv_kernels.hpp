@@ -121,6 +121,14 @@ struct BlockBounds {
     uint8_t* examined = nullptr;  // per workgroup: 1 = ran the per-entity path, 0 = skipped (statistics)
 };
 hipError_t launch_block_bounds(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, hipStream_t stream);
+// ... kept current while a few entries change per frame: flags (one byte per 256-entry block, padded to a multiple of 16, set by
+// launch_mark_dirty_blocks for every block that holds a re-mirrored entry) name the blocks whose box — and whose entries' emit
+// seeds, when `seeds` is given — are re-derived; the flags are cleared.
+hipError_t launch_block_patch(const MeshMirror& mesh, const TransformMirror& xf, float4* lo, float4* hi, EmitSeed* seeds, uint8_t* flags,
+                              hipStream_t stream);
+// the dirty slot ranges of a sync (start[nranges + 1]: running slot counts, first[nranges]: first slots; device memory) -> flags
+hipError_t launch_mark_dirty_blocks(const uint32_t* start, const uint32_t* first, uint32_t nranges, uint32_t total, const uint32_t* inv,
+                                    uint32_t entries, uint8_t* flags, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
 // Block bounds as classify (+ window test for Hi-Z views) + cull over the listed workgroups (two or three launches; same outputs

@@ -747,6 +747,8 @@ int grow_transforms(GvCtx* ctx, uint32_t n0, uint32_t n1, PhaseTimer& phase)
         return rc;
     GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n1, ctx->d_xactive.ptr, ctx->stream));
     ctx->xf_mirrored = n1;
+    for (auto& q : ctx->pools)
+        q.patch_valid = false;  // (appended entries: the blocks change; rebuilt once the pools are at rest)
     ctx->xf_appended += n1 - n0;
     ctx->world_valid = false;  // (d_world is sized at the next sweep; appended entries have no matrix yet)
     ctx->world_partial = false;
@@ -784,6 +786,7 @@ int grow_meshes(GvCtx* ctx, PoolState& p, uint32_t n0, uint32_t n1)
     p.appended += n1 - n0;
     p.epoch++;
     p.order_epoch++;
+    p.patch_valid = false;
     return GV_OK;
 }
 
@@ -974,6 +977,7 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     p.staging_stale.add(0, n);
     p.epoch++;
     p.order_epoch++;
+    p.patch_valid = false;
     p.appended = 0;
     const uint32_t pool_id = (uint32_t)(&p - ctx->pools);
     for (auto& vs : ctx->views[pool_id]) {  // per-entry outputs of earlier culls are in the old order
@@ -983,6 +987,30 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     return GV_OK;
 }
 
+
+// The blocks of pool `p` that hold an entry of the slot ranges `ranges` get their flag set (PoolState::d_blk_dirty): what the
+// next cull has to re-derive of the pool's block bounds and emit seeds. inv: slot -> mirror entry of those slots on the device.
+int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges, const uint32_t* inv)
+{
+    const uint32_t nr = (uint32_t)ranges.size();
+    if (nr == 0 || !p.d_blk_dirty.ptr)
+        return GV_OK;
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (an earlier call's copy may still be reading the pinned words)
+    GV_HIP(ctx, ctx->h_ranges.reserve(2 * (size_t)nr + 1));
+    GV_HIP(ctx, ctx->d_ranges.reserve(2 * (size_t)nr + 1));
+    uint32_t* start = ctx->h_ranges.ptr;
+    uint32_t* first = start + nr + 1;
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < nr; k++) {
+        start[k] = total;
+        first[k] = ranges[k].lo;
+        total += ranges[k].hi - ranges[k].lo;
+    }
+    start[nr] = total;
+    GV_HIP(ctx, hipMemcpyAsync(ctx->d_ranges.ptr, ctx->h_ranges.ptr, (2 * (size_t)nr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, launch_mark_dirty_blocks(ctx->d_ranges.ptr, ctx->d_ranges.ptr + nr + 1, nr, total, inv, p.occupancy, p.d_blk_dirty.ptr, ctx->stream));
+    return GV_OK;
+}
 
 }  // namespace
 
@@ -1126,6 +1154,17 @@ int sync_mirror(GvCtx* ctx)
             if (rc != GV_OK)
                 return rc;
             GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
+            // pools that keep block bounds / emit seeds current across changes: flag the blocks these transforms sit in (entry i of
+            // an exactly paired, flat pool is transform entry i); anything else falls back to "rebuilt once the pool is at rest"
+            for (auto& q : ctx->pools) {
+                if (!q.bound || !q.patch_valid)
+                    continue;
+                if (dense || ctx->xf_links_dirty || ctx->max_depth != 0 || q.mapping != kMapExact) {
+                    q.patch_valid = false;
+                } else if (int mrc = mark_dirty_blocks(ctx, q, ranges, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr)) {
+                    return mrc;
+                }
+            }
             if (ctx->xf_links_dirty) {  // setParent (transform.cpp:130-195): chains changed length, maybe closed a cycle
                 uint32_t depth = 0;
                 rc = compute_max_depth(ctx, &depth);
@@ -1210,6 +1249,7 @@ int sync_mirror(GvCtx* ctx)
             }
             phase.lap("mapping + upload meshes");
             p.need_full = false;
+            p.patch_valid = false;
             p.dirty.clear();
             p.staging_stale.clear();  // (every entry has just been gathered)
             p.epoch++;
@@ -1257,6 +1297,13 @@ int sync_mirror(GvCtx* ctx)
                 }
                 if (rc != GV_OK)
                     return rc;
+                if (p.patch_valid) {  // (see the transform side)
+                    const bool most = !left.empty() && !p.inv.empty() && left_total * 2 > p.occupancy;
+                    if (most || p.mapping != kMapExact)
+                        p.patch_valid = false;
+                    else if (int mrc = mark_dirty_blocks(ctx, p, ranges, p.inv.empty() ? nullptr : p.d_inv.ptr))
+                        return mrc;
+                }
             }
             p.dirty.clear();
             p.epoch++;
