@@ -275,7 +275,11 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     // What is derived from a pool AT REST — block bounds, emit seeds — is (re)built when the pool's mirror is clean, or has just
     // changed after a quiet frame; a pool that changes frame after frame (dynamic scene) goes without
     const bool changed = p.seen_epoch != p.epoch || p.seen_xf_epoch != ctx->xf_epoch;
-    const bool may_rebuild = !(changed && p.changed_prev);
+    // ... or keeps changing only a little (kMinSmallStreak syncs in a row that re-mirrored a few entries each): then it gets them
+    // once more and they are patched from there on (below)
+    constexpr uint32_t kMinSmallStreak = 4;
+    static const bool patching = getenv("GV_DEBUG_NO_BOUNDS_PATCH") == nullptr;
+    const bool may_rebuild = !(changed && p.changed_prev) || (patching && changed && p.small_streak >= kMinSmallStreak);
     p.changed_prev = changed;
     p.seen_epoch = p.epoch;
     p.seen_xf_epoch = ctx->xf_epoch;
@@ -286,7 +290,6 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     if (bounds_wanted && p.occupancy != 0 && !fused) {
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
         const bool patchable = mesh.mapping == kMapExact && xf.max_depth == 0 && mesh.count <= xf.count;  // entry i <-> transform entry i, no chains
-        static const bool patching = getenv("GV_DEBUG_NO_BOUNDS_PATCH") == nullptr;
         if (!current && patching && p.patch_valid && patchable && p.d_blk_lo.ptr && p.d_blk_dirty.ptr) {
             // every change since the boxes were current is on record (sync_mirror flagged the blocks): re-derive those blocks — and
             // their entries' emit seeds when the seeds were in step with the boxes — instead of culling without boxes until the
@@ -911,7 +914,7 @@ void gv_destroy(GvCtx* ctx)
     for (auto& p : ctx->pools) {
         for (auto& target : p.record_target)
             release_record_target(target);
-        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_inv.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release(); p.d_seed.release(); p.d_kept.release(); p.d_kept_flag.release();
+        p.d_a.release(); p.d_b.release(); p.d_link.release(); p.h_a.release(); p.h_b.release(); p.h_link.release(); p.d_orig.release(); p.d_inv.release(); p.d_index_map.release(); p.d_blk_lo.release(); p.d_blk_hi.release(); p.d_seed.release(); p.d_kept.release(); p.d_kept_flag.release(); p.d_blk_dirty.release();
     }
     for (auto& per_pool : ctx->views)
       for (auto& v : per_pool) {
@@ -925,7 +928,7 @@ void gv_destroy(GvCtx* ctx)
         v.tile_status.release(); v.tile_ticket.release();
     }
     ctx->d_world.release(); ctx->d_xdirty.release(); ctx->d_raw.release(); ctx->d_examined.release();
-    ctx->d_e2t.release(); ctx->d_flag.release(); ctx->h_flag.release();
+    ctx->d_e2t.release(); ctx->d_flag.release(); ctx->h_flag.release(); ctx->h_ranges.release(); ctx->d_ranges.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_raw[k].release();
         if (ctx->raw_done[k])

@@ -203,6 +203,8 @@ struct PoolState {
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
     DeviceBuf<uint8_t> d_blk_dirty;  // one byte per block: holds an entry re-mirrored since the boxes (and seeds) were last current
+    uint32_t small_streak = 0;       // syncs in a row that re-mirrored only a few entries of this pool (a pool that keeps changing a
+                                     // little gets its boxes rebuilt once, then patched; one that keeps changing a lot goes without)
     bool patch_valid = false;        // every change of the mirror since then is recorded in d_blk_dirty (flat, exactly paired pools):
                                      // the next cull re-derives the flagged blocks instead of going without boxes
     DeviceBuf<EmitSeed> d_seed;    // emit seeds (gv_kernels.hpp), valid for (seed_xf_epoch, seed_epoch)

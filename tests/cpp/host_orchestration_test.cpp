@@ -501,6 +501,7 @@ int main()
     exercise(0, 40000, 3);
     exercise(GV_CONFIG_KEEP_SLOT_ORDER, 30000, 0);
     exercise(GV_CONFIG_BLOCK_BOUNDS | GV_CONFIG_PROFILE_EVENTS, 30000, 2);
+    exercise(GV_CONFIG_BLOCK_BOUNDS, 20000, 0);  // flat + exactly paired: block bounds / emit seeds patched per dirty block (mark_dirty_blocks)
     exercise(GV_CONFIG_LINEAR_SCAN | GV_CONFIG_HIZ_RG16F | GV_CONFIG_KEEP_SLOT_ORDER, 300000, 3);  // (above the device-gather and auto-bounds sizes)
     std::printf("host orchestration: ok\n");
     return 0;
