@@ -1276,6 +1276,9 @@ constexpr uint32_t kSelfPrefixLoads = (kSelfPrefixMaxChunks / 4 + 191) / 192;  /
 // SELF: no scan launch in front — while wave 0 prefixes the ballot words, waves 1-3 sum the chunk totals below this
 // chunk (a few KB of L2 reads) to get its base; workgroup 0 also writes the grand total and clears the OTHER totals
 // buffer for the next frame's cull (the two buffers alternate, so nobody is still reading the one being cleared).
+#ifndef GV_EMIT_PIPELINED  // (A/B builds: tools/ab_lib.sh)
+#define GV_EMIT_PIPELINED 1
+#endif
 template <bool SELF>
 __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t block)
 {
@@ -1383,6 +1386,70 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     // dense chunk neighbouring records share the sectors of the streams and the 64-byte seeds move more, measured: at 21 %
     // visible the emit took 59.9 us with seeds against 45.8 us without, at 12 % (cfg3's in-frustum chunks) 18.4 against 21.4.
     const bool use_seed = args.seeds != nullptr && prefix[64] <= kEmitChunk * 5 / 32;
+    // the record r of this workgroup's quarter -> its mirror entry (binary search over the quarter's words + k-th set bit)
+    auto entry_of = [&](uint32_t r) {
+        uint32_t lo = wlo, hi = whi;  // word w in [wlo, whi) with prefix[w] <= r < prefix[w + 1]
+#pragma unroll
+        for (uint32_t span = 64 / kEmitParts; span > 1; span >>= 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= r)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return (first_word + lo) * 64 + select_bit(words[lo], r - prefix[lo]);
+    };
+    // DENSE chunks of a flat, exactly paired pool (no seeds, no world matrices, no chains: the record is the local model of entry
+    // i): the gathers of round k + 1 are issued before round k's records go through LDS and out, so that a round waits for its
+    // stores and the next round's loads together instead of one after the other (a quarter of a full chunk is four rounds). Same-box A/B: emit 53.5 -> 51.2 us at 2.6 M records, 45.3 -> 43.8 us at 2.06 M (a barrier that
+    // orders LDS only, so that the gathers fly across it, measured the same).
+    const bool pipelined = GV_EMIT_PIPELINED && !use_seed && !args.world && !args.direct_stores && args.xf.max_depth == 0 &&
+                           args.mesh.mapping == kMapExact;  // uniform
+    if (pipelined) {
+        uint32_t r0 = prefix[wlo];
+        uint32_t i_cur = 0xFFFFFFFFu, orig_cur = 0;
+        float4 a_cur = {}, b_cur = {};
+        float2 c_cur = {};
+        if (r0 + threadIdx.x < total) {
+            i_cur = entry_of(r0 + threadIdx.x);
+            a_cur = args.xf.ab[i_cur].a;
+            b_cur = args.xf.ab[i_cur].b;
+            c_cur = args.xf.c[i_cur];
+            orig_cur = args.mesh.orig ? args.mesh.orig[i_cur] : i_cur;
+        }
+        for (; r0 < total; r0 += 256) {
+            uint32_t i_nxt = 0xFFFFFFFFu, orig_nxt = 0;
+            float4 a_nxt = {}, b_nxt = {};
+            float2 c_nxt = {};
+            if (r0 + 256u + threadIdx.x < total) {
+                i_nxt = entry_of(r0 + 256u + threadIdx.x);
+                a_nxt = args.xf.ab[i_nxt].a;
+                b_nxt = args.xf.ab[i_nxt].b;
+                c_nxt = args.xf.c[i_nxt];
+                orig_nxt = args.mesh.orig ? args.mesh.orig[i_nxt] : i_nxt;
+            }
+            if (i_cur != 0xFFFFFFFFu) {
+                XfRecord rec;
+                rec.a = a_cur, rec.b = b_cur, rec.c = c_cur, rec.flags = 0u;
+                const Mat34 m = translated(local_model(rec), args.view.cam[0], args.view.cam[1], args.view.cam[2]);
+                const size_t rank = (size_t)base + r0 + threadIdx.x;
+                args.out.visible_idx[rank] = orig_cur;
+                args.out.distance_sq[rank] = record_distance(args, m);
+                float4* row = stage + threadIdx.x * 3;
+                row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
+                row[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
+                row[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
+            }
+            __syncthreads();
+            const uint32_t quads = min(256u, total - r0) * 3u;
+            float4* dst = reinterpret_cast<float4*>(args.out.baked_model) + ((size_t)base + r0) * 3;
+            for (uint32_t q = threadIdx.x; q < quads; q += 256)
+                dst[q] = stage[q];
+            __syncthreads();  // the stage is rewritten by the next round
+            i_cur = i_nxt, orig_cur = orig_nxt, a_cur = a_nxt, b_cur = b_nxt, c_cur = c_nxt;
+        }
+        return;
+    }
     // 256 consecutive output records per round (uniform trip count). Each lane builds one record; the 48-byte models go
     // through LDS so that they leave as whole rows — lane k stores float4 k, k + 256, k + 512 of the round's contiguous
     // 12 KB — instead of three 16-byte pieces per lane at a 48-byte stride.
