@@ -279,7 +279,9 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     // once more and they are patched from there on (below)
     constexpr uint32_t kMinSmallStreak = 4;
     static const bool patching = getenv("GV_DEBUG_NO_BOUNDS_PATCH") == nullptr;
-    const bool may_rebuild = !(changed && p.changed_prev) || (patching && changed && p.small_streak >= kMinSmallStreak);
+    // (only pools whose boxes can then be patched — entry i <-> transform entry i, no chains —: any other would be rebuilt every frame)
+    const bool patchable = mesh.mapping == kMapExact && xf.max_depth == 0 && mesh.count <= xf.count;
+    const bool may_rebuild = !(changed && p.changed_prev) || (patching && patchable && changed && p.small_streak >= kMinSmallStreak);
     p.changed_prev = changed;
     p.seen_epoch = p.epoch;
     p.seen_xf_epoch = ctx->xf_epoch;
@@ -289,7 +291,6 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                                (!(ctx->config.flags & GV_CONFIG_LINEAR_SCAN) && p.occupancy > kAutoBoundsMinSlots);
     if (bounds_wanted && p.occupancy != 0 && !fused) {
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
-        const bool patchable = mesh.mapping == kMapExact && xf.max_depth == 0 && mesh.count <= xf.count;  // entry i <-> transform entry i, no chains
         if (!current && patching && p.patch_valid && patchable && p.d_blk_lo.ptr && p.d_blk_dirty.ptr) {
             // every change since the boxes were current is on record (sync_mirror flagged the blocks): re-derive those blocks — and
             // their entries' emit seeds when the seeds were in step with the boxes — instead of culling without boxes until the

@@ -266,9 +266,16 @@ def test_boxes_stay_current_while_a_few_entities_move_every_frame(request, oracl
     sc.transforms["parent"][77] = sc.transforms["entity"][78]
     gpu.mark_dirty(1, 77, 1)
     same_as_oracle(gpu, oracle, sc, view)
-    sc.transforms["position"][5, :3] += np.float32(3)
-    gpu.mark_dirty(0, 5, 1)
+    for frame in range(7):  # ... and it is not rebuilt frame after frame either: a moving hierarchy goes without boxes until it rests
+        sc.transforms["position"][5 + frame, :3] += np.float32(3)
+        gpu.mark_dirty(0, 5 + frame, 1)
+        gpu.stats_reset()
+        same_as_oracle(gpu, oracle, sc, view)
+        assert frame == 0 or gpu.stats()["bounds_blocks_total"] == 0, frame
+    same_as_oracle(gpu, oracle, sc, view)  # at rest: the boxes come back
+    gpu.stats_reset()
     same_as_oracle(gpu, oracle, sc, view)
+    assert gpu.stats()["bounds_blocks_total"] == nblocks
 
 
 def test_empty_and_tiny_pools_with_boxes(gpu_bounds, oracle):
