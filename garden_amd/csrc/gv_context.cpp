@@ -935,6 +935,10 @@ void gv_destroy(GvCtx* ctx)
         if (ctx->raw_done[k])
             (void)hipEventDestroy(ctx->raw_done[k]);
     }
+    if (ctx->upload_done) {
+        (void)hipEventDestroy(ctx->upload_done);
+        ctx->upload_done = nullptr;
+    }
     ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
     ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
     ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release(); ctx->h_done.release();

@@ -303,6 +303,8 @@ struct Context {
     PinnedBuf<uint8_t> h_raw[2];   // the library's own pinned chunks the span travels through (double-buffered)
     hipEvent_t raw_done[2] = {nullptr, nullptr};  // chunk buffer k may be rewritten once its last copy has run
     DirtyRange staging_stale;      // slots whose host staging entries lag behind the device (written by that path)
+    hipEvent_t upload_done = nullptr;  // behind the last copies that read the pinned staging / packet buffers: the next sync waits for THIS before
+    bool upload_pending = false;       // it rewrites them, not for the whole stream (the previous frame's cull may still be running)
     PinnedBuf<uint32_t> h_ranges;  // a sync's dirty ranges on their way to mark_dirty_blocks_kernel
     DeviceBuf<uint32_t> d_ranges;
     DeviceBuf<uint32_t> d_e2t;     // entity -> transform slot table on the device, refreshed by every device-side mesh gather

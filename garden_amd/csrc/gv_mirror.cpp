@@ -574,8 +574,31 @@ int upload_meshes(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
     return GV_OK;
 }
 
+// The pinned staging arrays and packet buffers are read by asynchronous copies: before the host rewrites them it waits for the
+// copies of the previous sync — an event recorded behind them — not for the whole stream: the previous frame's cull and emit, queued
+// behind those copies, may still be running (a scene in which something moves every frame would otherwise run host and device one
+// after the other: 0.20 instead of 0.12 ms per frame at 10 M entities with ten movers, tools/moving_bench.py).
+int wait_uploads(GvCtx* ctx)
+{
+    if (ctx->upload_pending) {
+        GV_HIP(ctx, hipEventSynchronize(ctx->upload_done));
+        ctx->upload_pending = false;
+    }
+    return GV_OK;
+}
+int record_uploads(GvCtx* ctx)
+{
+    if (!ctx->upload_done)
+        GV_HIP(ctx, hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming));
+    GV_HIP(ctx, hipEventRecord(ctx->upload_done, ctx->stream));
+    ctx->upload_pending = true;
+    return GV_OK;
+}
+
 int reserve_scatter(GvCtx* ctx, size_t n)
 {
+    if (n > ctx->sc_idx.cap || n > ctx->dsc_idx.cap)  // (buffers about to be replaced: nothing queued may still use the old ones)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GV_HIP(ctx, ctx->sc_idx.reserve(n));
     GV_HIP(ctx, ctx->sc_u32.reserve(n));
     GV_HIP(ctx, ctx->sc_a.reserve(n));
@@ -617,6 +640,8 @@ int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& r
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
         return rc;
+    if ((rc = wait_uploads(ctx)) != GV_OK)
+        return rc;
     for (size_t q = 0; q < ranges.size(); q++) {
         const uint32_t lo = ranges[q].lo, base = start[q];
         parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
@@ -637,7 +662,8 @@ int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& r
     if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, ctx->d_xparent.ptr, n)) != GV_OK) return rc;
     if (track_world_dirty(ctx))
         GV_HIP(ctx, launch_mark_bytes(ctx->dsc_idx.ptr, n, ctx->d_xdirty.ptr, ctx->stream));
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the packet buffers are reused by the next sync
+    if ((rc = record_uploads(ctx)) != GV_OK)  // the packet buffers are reused by the next sync: it waits for this
+        return rc;
     ctx->stats.upload_bytes += (size_t)n * (4 + 45);
     return GV_OK;
 }
@@ -653,6 +679,8 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRan
         return GV_OK;
     int rc = reserve_scatter(ctx, n);
     if (rc != GV_OK)
+        return rc;
+    if ((rc = wait_uploads(ctx)) != GV_OK)
         return rc;
     for (size_t q = 0; q < ranges.size(); q++) {
         const uint32_t lo = ranges[q].lo, base = start[q];
@@ -670,7 +698,8 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRan
     if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, p.d_a.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, p.d_b.ptr, n)) != GV_OK) return rc;
     if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, p.d_link.ptr, n)) != GV_OK) return rc;
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = record_uploads(ctx)) != GV_OK)
+        return rc;
     ctx->stats.upload_bytes += (size_t)n * (4 + 28);
     return GV_OK;
 }
@@ -997,9 +1026,13 @@ int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R
     const uint32_t nr = (uint32_t)ranges.size();
     if (nr == 0 || !p.d_blk_dirty.ptr)
         return GV_OK;
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (an earlier call's copy may still be reading the pinned words)
-    GV_HIP(ctx, ctx->h_ranges.reserve(2 * (size_t)nr + 1));
-    GV_HIP(ctx, ctx->d_ranges.reserve(2 * (size_t)nr + 1));
+    if (2 * (size_t)nr + 1 > ctx->h_ranges.cap || 2 * (size_t)nr + 1 > ctx->d_ranges.cap) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (buffers about to be replaced)
+        GV_HIP(ctx, ctx->h_ranges.reserve(std::max<size_t>(2 * (size_t)nr + 1, 1024)));
+        GV_HIP(ctx, ctx->d_ranges.reserve(std::max<size_t>(2 * (size_t)nr + 1, 1024)));
+    }
+    if (int rc = wait_uploads(ctx))  // (an earlier call's copy may still be reading the pinned words)
+        return rc;
     uint32_t* start = ctx->h_ranges.ptr;
     uint32_t* first = start + nr + 1;
     uint32_t total = 0;
@@ -1011,7 +1044,7 @@ int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R
     start[nr] = total;
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_ranges.ptr, ctx->h_ranges.ptr, (2 * (size_t)nr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     GV_HIP(ctx, launch_mark_dirty_blocks(ctx->d_ranges.ptr, ctx->d_ranges.ptr + nr + 1, nr, total, inv, p.occupancy, p.d_blk_dirty.ptr, ctx->stream));
-    return GV_OK;
+    return record_uploads(ctx);
 }
 
 }  // namespace
@@ -1105,7 +1138,8 @@ int sync_mirror(GvCtx* ctx)
             return rc;
       }
       if (ctx->xf_dirty.any()) {
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (int wrc = wait_uploads(ctx))  // (staging is about to be rewritten: the copies that read it have to be through)
+            return wrc;
         staged = true;
         ctx->xf_dirty.normalise(n, 0);  // exact: a re-mirrored slot is a flagged slot (its whole subtree is re-swept)
         const std::vector<DirtyRanges::R> ranges = ctx->xf_dirty.items;
@@ -1270,10 +1304,9 @@ int sync_mirror(GvCtx* ctx)
             p.mirrored = p.occupancy;
             p.appended = 0;
         } else if (p.dirty.any()) {
-            if (!staged) {
-                GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                staged = true;
-            }
+            if (int wrc = wait_uploads(ctx))
+                return wrc;
+            staged = true;
             p.dirty.normalise(p.occupancy, 0);
             const std::vector<DirtyRanges::R> ranges = p.dirty.items;
             const uint64_t total = p.dirty.total();
@@ -1325,6 +1358,9 @@ int sync_mirror(GvCtx* ctx)
             p.epoch++;
         }
     }
+    if (staged)  // whatever copies this sync queued from the pinned staging arrays: the next sync waits for them before it rewrites those
+        if (int rrc = record_uploads(ctx))
+            return rrc;
     // the re-order itself, behind everything that brought the mirror up to date in its old order
     bool any_reorder = reorder_xf;
     for (bool b : reorder_pool)
