@@ -939,8 +939,7 @@ void gv_destroy(GvCtx* ctx)
         (void)hipEventDestroy(ctx->upload_done);
         ctx->upload_done = nullptr;
     }
-    ctx->d_xinv.release(); ctx->sc_idx.release(); ctx->sc_u32.release(); ctx->sc_a.release(); ctx->sc_ab.release(); ctx->sc_c.release(); ctx->sc_u8.release();
-    ctx->dsc_idx.release(); ctx->dsc_u32.release(); ctx->dsc_a.release(); ctx->dsc_ab.release(); ctx->dsc_c.release(); ctx->dsc_u8.release();
+    ctx->d_xinv.release(); ctx->sc_xf.release(); ctx->dsc_xf.release(); ctx->sc_mesh.release(); ctx->dsc_mesh.release(); ctx->dsc_a.release(); ctx->dsc_c.release();
     ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release(); ctx->h_done.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_tick[k].release();

@@ -312,16 +312,12 @@ struct Context {
     PinnedBuf<uint32_t> h_flag;
     bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // the env switches the path off (debugging)
     // scratch of the scattered (dirty-range) host upload path
-    PinnedBuf<uint32_t> sc_idx, sc_u32;
-    PinnedBuf<float4> sc_a;
-    PinnedBuf<XfAB> sc_ab;
-    PinnedBuf<float2> sc_c;
-    PinnedBuf<uint8_t> sc_u8;
-    DeviceBuf<uint32_t> dsc_idx, dsc_u32;
-    DeviceBuf<float4> dsc_a;
-    DeviceBuf<XfAB> dsc_ab;
-    DeviceBuf<float2> dsc_c;
-    DeviceBuf<uint8_t> dsc_u8;
+    PinnedBuf<XfPacket> sc_xf;       // one packet of {entry, record} per sync and side (gv_sort_kernels.hpp)
+    DeviceBuf<XfPacket> dsc_xf;
+    PinnedBuf<MeshPacket> sc_mesh;
+    DeviceBuf<MeshPacket> dsc_mesh;
+    DeviceBuf<float4> dsc_a;         // device scratch of gv_get_world (the gathered matrices of a permuted mirror) ...
+    DeviceBuf<float2> dsc_c;         // ... and of gv_debug_stream_peak (its sink)
 
     PoolState pools[GV_MAX_POOLS];
     // results are kept per (pool, view): every mesh system's cull can be issued before the first result is read

@@ -595,41 +595,26 @@ int record_uploads(GvCtx* ctx)
     return GV_OK;
 }
 
-int reserve_scatter(GvCtx* ctx, size_t n)
-{
-    if (n > ctx->sc_idx.cap || n > ctx->dsc_idx.cap)  // (buffers about to be replaced: nothing queued may still use the old ones)
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    GV_HIP(ctx, ctx->sc_idx.reserve(n));
-    GV_HIP(ctx, ctx->sc_u32.reserve(n));
-    GV_HIP(ctx, ctx->sc_a.reserve(n));
-    GV_HIP(ctx, ctx->sc_ab.reserve(n));
-    GV_HIP(ctx, ctx->sc_c.reserve(n));
-    GV_HIP(ctx, ctx->sc_u8.reserve(n));
-    GV_HIP(ctx, ctx->dsc_idx.reserve(n));
-    GV_HIP(ctx, ctx->dsc_u32.reserve(n));
-    GV_HIP(ctx, ctx->dsc_a.reserve(n));
-    GV_HIP(ctx, ctx->dsc_ab.reserve(n));
-    GV_HIP(ctx, ctx->dsc_c.reserve(n));
-    GV_HIP(ctx, ctx->dsc_u8.reserve(n));
-    return GV_OK;
-}
-
 bool track_world_dirty(GvCtx* ctx);
 
-// one stream of a scattered packet: host packet -> device packet -> dst[idx[k]] = packet[k]
-template <typename T>
-int scatter_stream(GvCtx* ctx, const T* host_packet, T* device_packet, T* dst, uint32_t n)
+// Dirty pool slots of a permuted mirror land on scattered entries: ALL the dirty ranges of a sync travel as one packet — one
+// copy, one launch (scatter_xf_packets_kernel: records, world-cache dirty bytes, active bits, block flags), one event.
+constexpr size_t kRangedCopyMaxRanges = 32;  // dirty ranges of a slot-order mirror sent as plain copies; more go as one scattered packet
+static_assert(kMaxFlaggedPools == GV_MAX_POOLS, "BlockFlagTargets has a slot per pool");
+
+template <typename Packet>
+int reserve_packets(GvCtx* ctx, PinnedBuf<Packet>& host, DeviceBuf<Packet>& dev, size_t n)
 {
-    GV_HIP(ctx, hipMemcpyAsync(device_packet, host_packet, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, launch_scatter(ctx->dsc_idx.ptr, n, device_packet, dst, (uint32_t)sizeof(T), ctx->stream));
-    return GV_OK;
+    if (n > host.cap || n > dev.cap) {  // (buffers about to be replaced: nothing queued may still use the old ones)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t want = std::max<size_t>(n + n / 2, 1024);
+        GV_HIP(ctx, host.reserve(want));
+        GV_HIP(ctx, dev.reserve(want));
+    }
+    return wait_uploads(ctx);  // the previous packet's copy has read the pinned buffer
 }
 
-// Dirty pool slots of a permuted mirror land on scattered entries: ship ALL the dirty ranges of a sync as one compact
-// packet {entry, record} and scatter on the device (one packet, one synchronisation, however many ranges).
-constexpr size_t kRangedCopyMaxRanges = 32;  // dirty ranges of a slot-order mirror sent as plain copies; more go as one scattered packet
-
-int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& ranges)
+int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& ranges, const BlockFlagTargets& blocks)
 {
     std::vector<uint32_t> start(ranges.size() + 1, 0);
     for (size_t k = 0; k < ranges.size(); k++)
@@ -637,39 +622,35 @@ int upload_transforms_scattered(GvCtx* ctx, const std::vector<DirtyRanges::R>& r
     const uint32_t n = start.back();
     if (n == 0)
         return GV_OK;
-    int rc = reserve_scatter(ctx, n);
-    if (rc != GV_OK)
-        return rc;
-    if ((rc = wait_uploads(ctx)) != GV_OK)
+    if (int rc = reserve_packets(ctx, ctx->sc_xf, ctx->dsc_xf, n))
         return rc;
     for (size_t q = 0; q < ranges.size(); q++) {
         const uint32_t lo = ranges[q].lo, base = start[q];
         parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {  // random reads of the staging arrays: spread over the cores
             for (uint32_t k = a; k < b; k++) {
                 const uint32_t j = ctx->xinv.empty() ? lo + k : ctx->xinv[lo + k];  // (a mirror in slot order: the identity)
-                ctx->sc_idx.ptr[base + k] = j;
-                ctx->sc_ab.ptr[base + k] = ctx->h_xab.ptr[j];
-                ctx->sc_c.ptr[base + k] = ctx->h_xc.ptr[j];
-                ctx->sc_u8.ptr[base + k] = ctx->h_xflags.ptr[j];
-                ctx->sc_u32.ptr[base + k] = ctx->h_xparent.ptr[j];
+                XfPacket& pk = ctx->sc_xf.ptr[base + k];
+                pk.a = ctx->h_xab.ptr[j].a;
+                pk.b = ctx->h_xab.ptr[j].b;
+                pk.c = ctx->h_xc.ptr[j];
+                pk.entry = j;
+                pk.flags = ctx->h_xflags.ptr[j];
+                pk.parent = ctx->h_xparent.ptr[j];
+                pk.pad[0] = pk.pad[1] = pk.pad[2] = 0;
             }
         });
     }
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = scatter_stream(ctx, ctx->sc_ab.ptr, ctx->dsc_ab.ptr, ctx->d_xab.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, ctx->d_xc.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_u8.ptr, ctx->dsc_u8.ptr, ctx->d_xflags.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, ctx->d_xparent.ptr, n)) != GV_OK) return rc;
-    if (track_world_dirty(ctx))
-        GV_HIP(ctx, launch_mark_bytes(ctx->dsc_idx.ptr, n, ctx->d_xdirty.ptr, ctx->stream));
-    if ((rc = record_uploads(ctx)) != GV_OK)  // the packet buffers are reused by the next sync: it waits for this
+    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_xf.ptr, ctx->sc_xf.ptr, (size_t)n * sizeof(XfPacket), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, launch_scatter_xf_packets(ctx->dsc_xf.ptr, n, ctx->d_xab.ptr, ctx->d_xc.ptr, ctx->d_xflags.ptr, ctx->d_xparent.ptr, ctx->d_xactive.ptr,
+                                          track_world_dirty(ctx) ? ctx->d_xdirty.ptr : nullptr, blocks, ctx->stream));
+    if (int rc = record_uploads(ctx))  // the packet buffer is reused by the next sync: it waits for this
         return rc;
-    ctx->stats.upload_bytes += (size_t)n * (4 + 45);
+    ctx->stats.upload_bytes += (size_t)n * sizeof(XfPacket);
     return GV_OK;
 }
 
 // all dirty ranges of a pool as ONE packet (see upload_transforms_scattered)
-int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges)
+int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges, uint8_t* block_flags)
 {
     std::vector<uint32_t> start(ranges.size() + 1, 0);
     for (size_t k = 0; k < ranges.size(); k++)
@@ -677,30 +658,26 @@ int upload_meshes_scattered(GvCtx* ctx, PoolState& p, const std::vector<DirtyRan
     const uint32_t n = start.back();
     if (n == 0)
         return GV_OK;
-    int rc = reserve_scatter(ctx, n);
-    if (rc != GV_OK)
-        return rc;
-    if ((rc = wait_uploads(ctx)) != GV_OK)
+    if (int rc = reserve_packets(ctx, ctx->sc_mesh, ctx->dsc_mesh, n))
         return rc;
     for (size_t q = 0; q < ranges.size(); q++) {
         const uint32_t lo = ranges[q].lo, base = start[q];
         parallel_ranges(0, ranges[q].hi - lo, [&](uint32_t a, uint32_t b) {
             for (uint32_t k = a; k < b; k++) {
                 const uint32_t j = p.inv.empty() ? lo + k : p.inv[lo + k];
-                ctx->sc_idx.ptr[base + k] = j;
-                ctx->sc_a.ptr[base + k] = p.h_a.ptr[j];
-                ctx->sc_c.ptr[base + k] = p.h_b.ptr[j];
-                ctx->sc_u32.ptr[base + k] = p.h_link.ptr[j];
+                MeshPacket& pk = ctx->sc_mesh.ptr[base + k];
+                pk.a = p.h_a.ptr[j];
+                pk.b = p.h_b.ptr[j];
+                pk.entry = j;
+                pk.link = p.h_link.ptr[j];
             }
         });
     }
-    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_idx.ptr, ctx->sc_idx.ptr, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = scatter_stream(ctx, ctx->sc_a.ptr, ctx->dsc_a.ptr, p.d_a.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_c.ptr, ctx->dsc_c.ptr, p.d_b.ptr, n)) != GV_OK) return rc;
-    if ((rc = scatter_stream(ctx, ctx->sc_u32.ptr, ctx->dsc_u32.ptr, p.d_link.ptr, n)) != GV_OK) return rc;
-    if ((rc = record_uploads(ctx)) != GV_OK)
+    GV_HIP(ctx, hipMemcpyAsync(ctx->dsc_mesh.ptr, ctx->sc_mesh.ptr, (size_t)n * sizeof(MeshPacket), hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, launch_scatter_mesh_packets(ctx->dsc_mesh.ptr, n, p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, block_flags, ctx->stream));
+    if (int rc = record_uploads(ctx))
         return rc;
-    ctx->stats.upload_bytes += (size_t)n * (4 + 28);
+    ctx->stats.upload_bytes += (size_t)n * sizeof(MeshPacket);
     return GV_OK;
 }
 
@@ -1147,8 +1124,34 @@ int sync_mirror(GvCtx* ctx)
         if (total) {
             const uint32_t lo = ranges.front().lo, hi = ranges.back().hi;  // the covering range
             int rc = GV_OK;
-            bool dense = false;
-            if (total * 2 > n) {
+            const bool dense = total * 2 > n;
+            // Pools that keep block bounds / emit seeds current across changes (flat, exactly paired: entry i of the pool is
+            // transform entry i) get the blocks these transforms sit in flagged; anything else falls back to "rebuilt once the pool
+            // is at rest". ... while the re-mirrored entries are few: slots that are neighbours in the pool are scattered over the
+            // spatially ordered mirror, so 10^5 of them touch nearly every block of a 10 M pool and the patch becomes a full rebuild
+            // (measured: 426 us against 145 us for culling that frame without boxes; 1000 scattered movers: 37 us).
+            BlockFlagTargets targets{};
+            bool flagging = false;
+            for (uint32_t k = 0; k < GV_MAX_POOLS; k++) {
+                PoolState& q = ctx->pools[k];
+                if (!q.bound)
+                    continue;
+                const uint64_t nblocks = (q.occupancy + kCullBlock - 1) / kCullBlock;
+                const bool few = !dense && !ctx->xf_links_dirty && total * 16 <= nblocks + 16 * 64;
+                q.small_streak = few ? std::min(q.small_streak + 1u, 1000u) : 0u;
+                if (!q.patch_valid)
+                    continue;
+                if (!few || ctx->max_depth != 0 || q.mapping != kMapExact || !q.d_blk_dirty.ptr) {
+                    q.patch_valid = false;
+                } else {
+                    targets.flags[k] = q.d_blk_dirty.ptr;
+                    targets.occupancy[k] = q.occupancy;
+                    flagging = true;
+                }
+            }
+            std::vector<DirtyRanges::R> unflagged;  // ranges whose upload path does not flag blocks itself
+            bool bits_current = false;              // the active bit-plane was kept up to date entry by entry (the packet path)
+            if (dense) {
                 // most of the pool: one pass over the covering range (re-mirroring a clean slot is harmless)
                 rc = GV_E_STATE;
                 if (!ctx->xf_links_dirty)
@@ -1157,7 +1160,6 @@ int sync_mirror(GvCtx* ctx)
                     refresh_stale_staging(ctx);  // this path re-uploads every entry from the staging arrays
                     rc = regather_transforms_pipelined(ctx, lo, hi);  // dense, chunked, DMA under gather
                 }
-                dense = true;
             } else {
                 // itemised: large ranges take the device-side gather, everything else travels as ONE scattered packet
                 // (or as plain ranged copies when the mirror is in slot order)
@@ -1170,6 +1172,8 @@ int sync_mirror(GvCtx* ctx)
                         host.push_back(r);
                     else if (one != GV_OK)
                         return one;
+                    else
+                        unflagged.push_back(r);
                 }
                 for (const auto& r : host)
                     gather_transforms(ctx, r.lo, r.hi);
@@ -1182,36 +1186,22 @@ int sync_mirror(GvCtx* ctx)
                             break;
                         if (track_world_dirty(ctx))
                             GV_HIP(ctx, hipMemsetAsync(ctx->d_xdirty.ptr + r.lo, 1, r.hi - r.lo, ctx->stream));
+                        unflagged.push_back(r);
                     }
                 } else {
-                    rc = upload_transforms_scattered(ctx, host);
+                    rc = upload_transforms_scattered(ctx, host, targets);
+                    bits_current = unflagged.empty();
                 }
             }
             if (rc != GV_OK)
                 return rc;
-            GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
-            // pools that keep block bounds / emit seeds current across changes: flag the blocks these transforms sit in (entry i of
-            // an exactly paired, flat pool is transform entry i); anything else falls back to "rebuilt once the pool is at rest"
-            for (auto& q : ctx->pools) {
-                if (!q.bound)
-                    continue;
-                {
-                    const uint64_t nb = (q.occupancy + kCullBlock - 1) / kCullBlock;
-                    const bool few = !dense && !ctx->xf_links_dirty && total * 16 <= nb + 16 * 64;
-                    q.small_streak = few ? std::min(q.small_streak + 1u, 1000u) : 0u;
-                }
-                if (!q.patch_valid)
-                    continue;
-                // ... while the re-mirrored entries are few: slots that are neighbours in the pool are scattered over the spatially
-                // ordered mirror, so 10^5 of them touch nearly every block of a 10 M pool and the patch becomes a full rebuild
-                // (measured: 426 us against 145 us for culling that frame without boxes; 1000 scattered movers: 37 us)
-                const uint64_t nblocks = (q.occupancy + kCullBlock - 1) / kCullBlock;
-                if (dense || ctx->xf_links_dirty || ctx->max_depth != 0 || q.mapping != kMapExact || total * 16 > nblocks + 16 * 64) {
-                    q.patch_valid = false;
-                } else if (int mrc = mark_dirty_blocks(ctx, q, ranges, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr)) {
-                    return mrc;
-                }
-            }
+            if (!bits_current)
+                GV_HIP(ctx, launch_pack_active(ctx->d_xflags.ptr, n, ctx->d_xactive.ptr, ctx->stream));
+            if (flagging && !unflagged.empty())
+                for (uint32_t k = 0; k < GV_MAX_POOLS; k++)
+                    if (targets.flags[k])
+                        if (int mrc = mark_dirty_blocks(ctx, ctx->pools[k], unflagged, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr))
+                            return mrc;
             if (ctx->xf_links_dirty) {  // setParent (transform.cpp:130-195): chains changed length, maybe closed a cycle
                 uint32_t depth = 0;
                 rc = compute_max_depth(ctx, &depth);
@@ -1316,6 +1306,7 @@ int sync_mirror(GvCtx* ctx)
                 // `left` is what remains for the host paths
                 std::vector<DirtyRanges::R> left;
                 uint64_t left_total = 0;
+                bool packet_flagged = false;  // the scattered packet flagged the blocks of `left` itself
                 for (const auto& r : ranges) {
                     const int one = upload_meshes_device(ctx, p, r.lo, r.hi);
                     if (one == GV_E_STATE) {
@@ -1338,7 +1329,10 @@ int sync_mirror(GvCtx* ctx)
                             if ((rc = upload_meshes(ctx, p, r.lo, r.hi)) != GV_OK)
                                 break;
                     } else {
-                        rc = upload_meshes_scattered(ctx, p, left);
+                        const uint64_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
+                        const bool flag_here = p.patch_valid && p.d_blk_dirty.ptr && total * 16 <= nb + 16 * 64;
+                        rc = upload_meshes_scattered(ctx, p, left, flag_here ? p.d_blk_dirty.ptr : nullptr);
+                        packet_flagged = flag_here;
                     }
                 }
                 if (rc != GV_OK)
@@ -1348,10 +1342,21 @@ int sync_mirror(GvCtx* ctx)
                     p.small_streak = 0;  // (small mesh edits leave the streak to the transform side: no double count)
                 if (p.patch_valid) {  // (see the transform side)
                     const bool most = !left.empty() && !p.inv.empty() && left_total * 2 > p.occupancy;
-                    if (most || p.mapping != kMapExact || total * 16 > nblocks + 16 * 64)
+                    if (most || p.mapping != kMapExact || total * 16 > nblocks + 16 * 64) {
                         p.patch_valid = false;
-                    else if (int mrc = mark_dirty_blocks(ctx, p, ranges, p.inv.empty() ? nullptr : p.d_inv.ptr))
-                        return mrc;
+                    } else {
+                        std::vector<DirtyRanges::R> unflagged;  // what did not travel in a packet that flags blocks itself
+                        if (!packet_flagged) {
+                            unflagged = ranges;
+                        } else {
+                            for (const auto& r : ranges)
+                                if (std::find_if(left.begin(), left.end(), [&](const DirtyRanges::R& l) { return l.lo == r.lo && l.hi == r.hi; }) == left.end())
+                                    unflagged.push_back(r);
+                        }
+                        if (!unflagged.empty())
+                            if (int mrc = mark_dirty_blocks(ctx, p, unflagged, p.inv.empty() ? nullptr : p.d_inv.ptr))
+                                return mrc;
+                    }
                 }
             }
             p.dirty.clear();

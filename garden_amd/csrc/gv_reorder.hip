@@ -192,6 +192,73 @@ __global__ __launch_bounds__(kThreads) void reorder_meshes_kernel(const uint32_t
 
 inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
 
+// ---- scattered dirty slots: one packet, one launch (gv_sort_kernels.hpp) ----
+__global__ __launch_bounds__(kThreads) void scatter_xf_packets_kernel(const XfPacket* __restrict__ packets, uint32_t count, XfAB* __restrict__ ab,
+                                                                      float2* __restrict__ c, uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
+                                                                      unsigned long long* __restrict__ active_bits, uint8_t* __restrict__ world_dirty,
+                                                                      const BlockFlagTargets blocks)
+{
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= count)
+        return;
+    const XfPacket p = packets[t];
+    const uint32_t e = p.entry;
+    XfAB rec;
+    rec.a = p.a;
+    rec.b = p.b;
+    ab[e] = rec;
+    c[e] = p.c;
+    flags[e] = (uint8_t)p.flags;
+    parent[e] = p.parent;
+    if (world_dirty)
+        world_dirty[e] = 1;
+    // the entry's bit of the active bit-plane (pack_active_kernel's rule), without a pass over the pool
+    const unsigned long long bit = 1ull << (e & 63u);
+    if (p.flags & kXfActive)
+        atomicOr(&active_bits[e >> 6], bit);
+    else
+        atomicAnd(&active_bits[e >> 6], ~bit);
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxFlaggedPools; k++)
+        if (blocks.flags[k] && e < blocks.occupancy[k])
+            blocks.flags[k][e / kCullBlock] = 1;
+}
+
+__global__ __launch_bounds__(kThreads) void scatter_mesh_packets_kernel(const MeshPacket* __restrict__ packets, uint32_t count, float4* __restrict__ a,
+                                                                        float2* __restrict__ b, uint32_t* __restrict__ link,
+                                                                        uint8_t* __restrict__ block_flags)
+{
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= count)
+        return;
+    const MeshPacket p = packets[t];
+    a[p.entry] = p.a;
+    b[p.entry] = p.b;
+    link[p.entry] = p.link;
+    if (block_flags)
+        block_flags[p.entry / kCullBlock] = 1;
+}
+
+}  // namespace
+
+hipError_t launch_scatter_xf_packets(const XfPacket* packets, uint32_t count, XfAB* ab, float2* c, uint8_t* flags, uint32_t* parent,
+                                     unsigned long long* active_bits, uint8_t* world_dirty, const BlockFlagTargets& blocks, hipStream_t stream)
+{
+    if (count)
+        hipLaunchKernelGGL(scatter_xf_packets_kernel, grid_for(count), dim3(kThreads), 0, stream, packets, count, ab, c, flags, parent, active_bits,
+                           world_dirty, blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_mesh_packets(const MeshPacket* packets, uint32_t count, float4* a, float2* b, uint32_t* link, uint8_t* block_flags,
+                                       hipStream_t stream)
+{
+    if (count)
+        hipLaunchKernelGGL(scatter_mesh_packets_kernel, grid_for(count), dim3(kThreads), 0, stream, packets, count, a, b, link, block_flags);
+    return hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 hipError_t launch_reorder_codes(const TransformMirror& xf, uint32_t* root, uint32_t* box, float* code, hipStream_t stream)

@@ -108,6 +108,34 @@ hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint3
 // stack (tools/sync_probe.hip); the polled word is there after one more kernel boundary.
 hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t stream);
 
+// Scattered dirty slots as ONE packet and ONE launch (gv_reorder.hip; gv_mirror.cpp upload_*_scattered): entry k of the packet is
+// written to its mirror entry — the record, the world-cache dirty byte, the entry's bit of the active bit-plane (an atomic or /
+// and: no pass over the pool afterwards), and the "this block holds a re-mirrored entry" flags of the pools whose block bounds are
+// being kept current. (It used to be a copy + a scatter launch per stream, a marking launch and a bit-plane pass over the whole
+// pool: ~12 runtime calls and ~40 us of device time for ten moved entities.)
+struct XfPacket {
+    float4 a, b;      // XfAB
+    float2 c;
+    uint32_t entry, flags, parent, pad[3];
+};
+static_assert(sizeof(XfPacket) == 64, "one sector per entry");
+struct MeshPacket {
+    float4 a;
+    float2 b;
+    uint32_t entry, link;
+};
+static_assert(sizeof(MeshPacket) == 32, "half a sector per entry");
+constexpr uint32_t kMaxFlaggedPools = 16;  // (== GV_MAX_POOLS, checked in gv_mirror.cpp)
+struct BlockFlagTargets {  // pools whose blocks get flagged for entry e < occupancy[k] (NULL: none)
+    uint8_t* flags[kMaxFlaggedPools];
+    uint32_t occupancy[kMaxFlaggedPools];
+};
+hipError_t launch_scatter_xf_packets(const XfPacket* packets, uint32_t count, XfAB* ab, float2* c, uint8_t* flags, uint32_t* parent,
+                                     unsigned long long* active_bits, uint8_t* world_dirty /* or NULL */, const BlockFlagTargets& blocks,
+                                     hipStream_t stream);
+hipError_t launch_scatter_mesh_packets(const MeshPacket* packets, uint32_t count, float4* a, float2* b, uint32_t* link,
+                                       uint8_t* block_flags /* or NULL */, hipStream_t stream);
+
 // gv_shard.hip: the visible list of a view as [draw_count | one bit per MIRROR entry]: a copy of the cull kernel's ballot words
 // (or, when `ballots` is NULL, built from the isVisible bytes in mirror order); words >= ceil(entries / 32), the rest is zeroed
 hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* bytes, const uint32_t* count, uint32_t entries, uint32_t* dst,
