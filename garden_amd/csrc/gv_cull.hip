@@ -20,6 +20,7 @@
 // All of it is HBM-bound streaming (DESIGN.md has bytes/entity per kernel); loads are 16- or 12-byte
 // per lane over SoA streams so each wave-instruction touches 1 KiB / 768 B contiguous.
 #include "gv_device.hpp"
+#include "gv_hiz_device.hpp"
 
 namespace gv {
 
@@ -1492,6 +1493,57 @@ template <bool SELF>
 __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 {
     emit_block<SELF>(args, blockIdx.x);
+}
+
+// A view's emit and the NEXT frame's first pyramid pass as ONE launch (gv_context.cpp: an emit behind an occlusion view is held
+// back until the next gv_hiz_build / gv_hiz_rebuild, or the first read of its records). The two do not depend on each other, one
+// is latency-bound (19 us at 3 % visible: three dependent round trips in a few hundred workgroups), the other bandwidth-bound
+// (15 us for 67 MB); back to back on one stream they cost their sum, on two streams more (event waits: measured). In one grid —
+// the emit's workgroups first, then one workgroup per 64 x 64 depth tile — the pyramid's loads fill the machine while the emit's
+// chains wait. Same device functions as the two kernels, same bits.
+struct EmitHizArgs {
+    EmitArgs emit;
+    const float* depth;
+    HizFusedDst dst;
+    uint32_t sw, sh, emit_blocks, tiles_x;
+};
+template <bool F16>
+__global__ __launch_bounds__(256) void emit_hiz_kernel(const EmitHizArgs a)
+{
+    if (blockIdx.x < a.emit_blocks) {
+        emit_block<true>(a.emit, blockIdx.x);
+        return;
+    }
+    const uint32_t t = blockIdx.x - a.emit_blocks;
+    hiz_fused_tile<false, F16>(a.depth, nullptr, a.dst, a.sw, a.sh, t % a.tiles_x, t / a.tiles_x);
+}
+
+hipError_t launch_emit_hiz(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out, uint32_t clear_chunks,
+                           const float4* world, const EmitSeed* seeds, const float* depth, const HizFusedDst& dst, uint32_t sw, uint32_t sh,
+                           bool rg16f, hipStream_t stream)
+{
+    EmitHizArgs a;
+    a.emit.world = world;
+    a.emit.seeds = seeds;
+    a.emit.direct_stores = 0;
+    a.emit.mesh = mesh;
+    a.emit.xf = xf;
+    a.emit.view = vp;
+    a.emit.out = out;
+    a.emit.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
+    a.emit.clear_chunks = clear_chunks;
+    a.depth = depth;
+    a.dst = dst;
+    a.sw = sw;
+    a.sh = sh;
+    a.emit_blocks = a.emit.nchunks * kEmitParts;
+    a.tiles_x = sw / 64;
+    const dim3 grid(a.emit_blocks + (sw / 64) * (sh / 64));
+    if (rg16f)
+        hipLaunchKernelGGL(emit_hiz_kernel<true>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(emit_hiz_kernel<false>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 // The views of one batched cull (main camera + shadow passes over a small pool, where every launch counts) emitted by

@@ -2,6 +2,7 @@
 // rule of shaders/hiz.frag:23-63.
 #include "gv_device.hpp"
 #include "gv_hiz_kernels.hpp"
+#include "gv_hiz_device.hpp"
 
 namespace gv {
 
@@ -21,20 +22,6 @@ __device__ __forceinline__ float2 hiz_src(const float* d, const float2* p, uint3
         return unpack_rg16f(reinterpret_cast<const uint32_t*>(p)[(size_t)y * sw + x]);
     return p[(size_t)y * sw + x];
 }
-template <bool F16>
-__device__ __forceinline__ void hiz_store(float2* level, size_t at, float2 mm)
-{
-    if (F16)
-        reinterpret_cast<uint32_t*>(level)[at] = pack_rg16f(mm);
-    else
-        level[at] = mm;
-}
-__device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
-{
-    mm.x = t.x < mm.x ? t.x : mm.x;  // MIN_DEPTH  depth.gsl:30-31
-    mm.y = t.y > mm.y ? t.y : mm.y;  // MAX_DEPTH  depth.gsl:32-33
-}
-
 // One destination texel of a level from the level before it; any size (hiz.frag:27-56 with the odd-size branches).
 // SRC(x, y) -> (min, max) of the source level's texel.
 template <class SRC>
@@ -379,103 +366,7 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
                                                         const float2* __restrict__ src_pairs, const HizFusedDst dst,
                                                         uint32_t sw, uint32_t sh)
 {
-    __shared__ float2 lds16[16][17];
-    __shared__ float2 lds8[8][9];
-    __shared__ float2 lds4[4][5];
-    __shared__ float2 lds2[2][3];
-    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-    const uint32_t ox = blockIdx.x * 64, oy = blockIdx.y * 64;
-    const uint32_t px = ox + 4 * tx, py = oy + 4 * ty;
-    float mn[4][4], mx[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (PAIRS && F16) {
-            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src_pairs) + (size_t)(py + r) * sw + px);
-            const float2 t0 = unpack_rg16f(t.x), t1 = unpack_rg16f(t.y), t2 = unpack_rg16f(t.z), t3 = unpack_rg16f(t.w);
-            mn[r][0] = t0.x; mx[r][0] = t0.y; mn[r][1] = t1.x; mx[r][1] = t1.y;
-            mn[r][2] = t2.x; mx[r][2] = t2.y; mn[r][3] = t3.x; mx[r][3] = t3.y;
-        } else if (PAIRS) {
-            const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
-            const float4 lo = row[0], hi = row[1];
-            mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
-            mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
-        } else {
-            const float4 v = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
-            mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
-            mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
-        }
-    }
-    // level +1: 2x2 texels per lane
-    float2 q[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            float2 mm = make_float2(mn[2 * a][2 * b], mx[2 * a][2 * b]);
-            hiz_acc(mm, make_float2(mn[2 * a][2 * b + 1], mx[2 * a][2 * b + 1]));
-            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b], mx[2 * a + 1][2 * b]));
-            hiz_acc(mm, make_float2(mn[2 * a + 1][2 * b + 1], mx[2 * a + 1][2 * b + 1]));
-            if (F16 && !PAIRS)  // the one place a value leaves fp32: from here on every level reduces representable halfs
-                mm = unpack_rg16f(pack_rg16f(mm));
-            q[a][b] = mm;
-        }
-    const uint32_t w1 = sw >> 1;
-    if (dst.level[0]) {  // null: the level stays virtual (queries reduce the source themselves)
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const size_t at = (size_t)(oy / 2 + 2 * ty + a) * w1 + ox / 2 + 2 * tx;
-            if (F16)
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(dst.level[0]) + at) = make_uint2(pack_rg16f(q[a][0]), pack_rg16f(q[a][1]));
-            else
-                *reinterpret_cast<float4*>(dst.level[0] + at) = make_float4(q[a][0].x, q[a][0].y, q[a][1].x, q[a][1].y);
-        }
-    }
-    // level +2: one texel per lane
-    float2 m2 = q[0][0];
-    hiz_acc(m2, q[0][1]);
-    hiz_acc(m2, q[1][0]);
-    hiz_acc(m2, q[1][1]);
-    hiz_store<F16>(dst.level[1], (size_t)(oy / 4 + ty) * (sw >> 2) + ox / 4 + tx, m2);
-    lds16[ty][tx] = m2;
-    __syncthreads();
-    if (threadIdx.x < 64) {  // level +3: 8x8
-        const uint32_t x = threadIdx.x & 7u, y = threadIdx.x >> 3;
-        float2 mm = lds16[2 * y][2 * x];
-        hiz_acc(mm, lds16[2 * y][2 * x + 1]);
-        hiz_acc(mm, lds16[2 * y + 1][2 * x]);
-        hiz_acc(mm, lds16[2 * y + 1][2 * x + 1]);
-        hiz_store<F16>(dst.level[2], (size_t)(oy / 8 + y) * (sw >> 3) + ox / 8 + x, mm);
-        lds8[y][x] = mm;
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {  // level +4: 4x4
-        const uint32_t x = threadIdx.x & 3u, y = threadIdx.x >> 2;
-        float2 mm = lds8[2 * y][2 * x];
-        hiz_acc(mm, lds8[2 * y][2 * x + 1]);
-        hiz_acc(mm, lds8[2 * y + 1][2 * x]);
-        hiz_acc(mm, lds8[2 * y + 1][2 * x + 1]);
-        hiz_store<F16>(dst.level[3], (size_t)(oy / 16 + y) * (sw >> 4) + ox / 16 + x, mm);
-        lds4[y][x] = mm;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {  // level +5: 2x2
-        const uint32_t x = threadIdx.x & 1u, y = threadIdx.x >> 1;
-        float2 mm = lds4[2 * y][2 * x];
-        hiz_acc(mm, lds4[2 * y][2 * x + 1]);
-        hiz_acc(mm, lds4[2 * y + 1][2 * x]);
-        hiz_acc(mm, lds4[2 * y + 1][2 * x + 1]);
-        hiz_store<F16>(dst.level[4], (size_t)(oy / 32 + y) * (sw >> 5) + ox / 32 + x, mm);
-        lds2[y][x] = mm;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // level +6: 1 texel
-        float2 mm = lds2[0][0];
-        hiz_acc(mm, lds2[0][1]);
-        hiz_acc(mm, lds2[1][0]);
-        hiz_acc(mm, lds2[1][1]);
-        hiz_store<F16>(dst.level[5], (size_t)(oy / 64) * (sw >> 6) + ox / 64, mm);
-    }
-    (void)sh;
+    hiz_fused_tile<PAIRS, F16>(src_depth, src_pairs, dst, sw, sh, blockIdx.x, blockIdx.y);
 }
 
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,

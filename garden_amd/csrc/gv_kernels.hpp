@@ -286,5 +286,10 @@ struct HizFusedDst {
 };
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
                             uint32_t sh, bool rg16f, hipStream_t stream);
+// A view's (self-prefixing) emit and the first fused pass of a pyramid build over a depth image as ONE launch (gv_cull.hip
+// emit_hiz_kernel): what launch_emit(..., self_prefix = true, ...) and launch_hiz_fused(depth, NULL, dst, sw, sh, ...) do.
+hipError_t launch_emit_hiz(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out, uint32_t clear_chunks,
+                           const float4* world, const EmitSeed* seeds, const float* depth, const HizFusedDst& dst, uint32_t sw, uint32_t sh,
+                           bool rg16f, hipStream_t stream);
 
 }  // namespace gv

@@ -1032,6 +1032,8 @@ int sync_mirror(GvCtx* ctx)
     if (!ctx->xf.bound)
         return ctx->fail(GV_E_STATE, "gv_sync: no transform pool bound");
     GV_HIP(ctx, hipSetDevice(ctx->device));
+    if (int frc = flush_deferred_emit(ctx))  // (it reads the mirror as it is now)
+        return frc;
     const uint32_t n = ctx->xf.occupancy;
     bool staged = false;
     const bool spatial = !(ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER);
