@@ -1510,12 +1510,18 @@ struct EmitHizArgs {
 template <bool F16>
 __global__ __launch_bounds__(256) void emit_hiz_kernel(const EmitHizArgs a)
 {
-    if (blockIdx.x < a.emit_blocks) {
-        emit_block<true>(a.emit, blockIdx.x);
+    // the two kinds of workgroup alternate while both last (dispatch follows blockIdx: the pyramid's tiles start streaming at once,
+    // beside the emit's chains, instead of behind all of the emit's workgroups), the longer kind's remainder follows
+    const uint32_t tiles = a.tiles_x * (a.sh / 64), both = min(a.emit_blocks, tiles);
+    const uint32_t b = blockIdx.x;
+    const bool paired = b < 2u * both;
+    const bool is_emit = paired ? (b & 1u) == 0u : a.emit_blocks > tiles;
+    const uint32_t index = paired ? b >> 1 : b - both;
+    if (is_emit) {
+        emit_block<true>(a.emit, index);
         return;
     }
-    const uint32_t t = blockIdx.x - a.emit_blocks;
-    hiz_fused_tile<false, F16>(a.depth, nullptr, a.dst, a.sw, a.sh, t % a.tiles_x, t / a.tiles_x);
+    hiz_fused_tile<false, F16>(a.depth, nullptr, a.dst, a.sw, a.sh, index % a.tiles_x, index / a.tiles_x);
 }
 
 hipError_t launch_emit_hiz(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out, uint32_t clear_chunks,

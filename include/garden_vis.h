@@ -197,7 +197,11 @@ typedef struct GvResult {
 
 /* Device-side cull of one pool against `view_count` views: frustum test (+ Hi-Z query) + compaction.
  * Asynchronous: returns once the work is enqueued on the context's stream. Replaces
- * MeshRenderSystem::prepareMeshes' threaded loop (mesh.cpp:331-553 -> :111-184). */
+ * MeshRenderSystem::prepareMeshes' threaded loop (mesh.cpp:331-553 -> :111-184).
+ * The record emission of a single occlusion (use_hiz) view of a large pool may be enqueued LATER than the cull itself: by the
+ * next gv_hiz_build / gv_hiz_rebuild (it then shares a launch with the pyramid's first pass), or by the first call that reads
+ * the view's results or changes what the emission reads (every gv_results_*, gv_sort, gv_wait, gv_sync, the next gv_cull, ...).
+ * Callers see no difference except through timing of their own on gv_stream(). */
 int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_count);
 /* Blocks until all enqueued work is done. */
 int gv_wait(GvCtx* ctx);
