@@ -1823,3 +1823,93 @@ def test_record_target_lifetime_through_the_bare_c_abi(case):
     assert f"{case}: 8 frames ok" in p.stdout
     if case == "early_free":
         assert "lost registration reported 8 times" in p.stdout
+
+
+def test_an_occlusion_views_emit_rides_with_the_next_pyramid_build(oracle):
+    """End of round 3: the emit of a single use_hiz view is held back and shares a launch with the next pyramid build's first pass
+    (emit_hiz_kernel) — or is launched by whatever reads the results or changes what it reads first. Every order of calls an
+    application can make gives the records, isVisible bytes and counts of the plain path: rebuild -> fetch, fetch at once, a new
+    depth image in between (the cull saw the old pyramid), dirty marks and the next cull in between, a sort, a second pool culled
+    in between, a view array of two (never held back), and a context destroyed with an emit still held."""
+    import torch
+    from garden_amd.lib import GpuVisibility
+    n = 280_000
+    sc = scene.flat_scene(n)
+    other = scene.flat_scene(90_000, seed=5)
+    view = scene.main_camera_view(use_hiz=1)
+    depth = scene.synthetic_depth(1024, 512)
+    depth2 = np.maximum(depth, np.float32(0.4))
+    rng = np.random.Generator(np.random.PCG64(8))
+
+    def expect(meshes, tr, e2t, v, hz):
+        m2 = meshes.copy()
+        exp = oracle.prepare_meshes(m2, tr, e2t, v, hiz=hz)
+        return exp, m2
+
+    def same(got, exp, m2, sorted_by_distance=False):
+        if sorted_by_distance:
+            o = np.argsort(exp["distance_sq"], kind="stable")
+            assert np.array_equal(np.sort(got["visible_idx"]), np.sort(exp["visible_idx"]))
+            assert np.array_equal(got["distance_sq"], exp["distance_sq"][o])
+        else:
+            assert np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
+            o = np.argsort(exp["visible_idx"], kind="stable")
+            assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32))
+        assert np.array_equal(got["is_visible"], m2["isVisible"])
+
+    with GpuVisibility(device=0) as vis:
+        vis.hiz_build(depth)
+        hz, hz2 = oracle.Hiz(depth), oracle.Hiz(depth2)
+        vis.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vis.bind_pool(0, sc.meshes)
+        vis.hierarchy_rebuild()
+        exp, m2 = expect(sc.meshes, sc.transforms, sc.entity_to_transform, view, hz)
+        # frames of an engine: cull, next frame's pyramid, cull, ... and a fetch at the end
+        for _ in range(3):
+            vis.cull(0, [view])
+            vis.hiz_rebuild()
+        same(vis.fetch(0, write_back=False, occupancy=n), exp, m2)
+        # fetch straight after the cull
+        vis.cull(0, [view])
+        same(vis.fetch(0, write_back=False, occupancy=n), exp, m2)
+        # a NEW depth image between the cull and the fetch: the cull saw the old pyramid, the held-back emit only compacts
+        vis.cull(0, [view])
+        vis.hiz_build(depth2)
+        same(vis.fetch(0, write_back=False, occupancy=n), exp, m2)
+        exp2, m22 = expect(sc.meshes, sc.transforms, sc.entity_to_transform, view, hz2)
+        vis.cull(0, [view])
+        same(vis.fetch(0, write_back=False, occupancy=n), exp2, m22)
+        # dirty marks and the next cull while an emit is held
+        vis.cull(0, [view])
+        for s in rng.integers(0, n, 40):
+            sc.transforms["position"][s, :3] += np.float32(7)
+            vis.mark_dirty(0, int(s), 1)
+        vis.cull(0, [view])
+        vis.hiz_rebuild()
+        exp3, m23 = expect(sc.meshes, sc.transforms, sc.entity_to_transform, view, hz2)
+        same(vis.fetch(0, write_back=False, occupancy=n), exp3, m23)
+        # a sort of the held-back records
+        vis.cull(0, [view])
+        vis.sort(0)
+        same(vis.fetch(0, write_back=False, occupancy=n, order="raw"), exp3, m23, sorted_by_distance=True)
+        # another pool culled in between, device-side copies of the first one's list afterwards
+        vis.bind_pool(1, other.meshes)
+        vis.cull(0, [view])
+        vis.cull(1, [dict(view, use_hiz=0)])
+        got1 = vis.fetch(0, write_back=False, occupancy=other.count, pool_id=1)
+        e1m = other.meshes.copy()
+        e1 = oracle.prepare_meshes(e1m, sc.transforms, sc.entity_to_transform, dict(view, use_hiz=0))
+        assert np.array_equal(got1["visible_idx"], np.sort(e1["visible_idx"]))
+        same(vis.fetch(0, write_back=False, occupancy=n, pool_id=0), exp3, m23)
+        vis.cull(0, [view])
+        buf = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
+        vis.copy_shard_device(0, buf.data_ptr(), n, index_base=0)
+        vis.wait()
+        host = buf.cpu().numpy()
+        assert host[0] == exp3["draw_count"] and np.array_equal(np.sort(host[1:1 + host[0]]), np.sort(exp3["visible_idx"]))
+        # two views: never held back
+        shadow = scene.cascade_view(index=0, size=4000.0)
+        vis.cull(0, [view, shadow])
+        vis.hiz_rebuild()
+        same(vis.fetch(0, write_back=False, occupancy=n), exp3, m23)
+        vis.cull(0, [view])  # ... and a context destroyed with an emit still held
