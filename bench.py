@@ -62,22 +62,31 @@ HIZ_SIZE = 4096
 
 
 def make_tile_scene(wl, n_local, rank, world):
-    """Rank `rank`'s spatial tile of the world cube (side 100 * N_total^(1/3)); camera at the world centre."""
+    """What rank `rank` owns of the world cube (side 100 * N_total^(1/3); camera at the world centre): the cube is cut into
+    cell_grid(world) cells (8 x 8 x 8 for 8 GPUs), the cells are dealt to the ranks round-robin in Morton order
+    (garden_amd/multi.py::cell_owners — the rule of gv_scene_extract_rank) and the rank's n_local roots are spread evenly over
+    ITS cells, concatenated into one pool: every rank holds a share of every region, so every rank has its share of whatever
+    the camera looks at (round 3 gave each rank one octant: half the ranks had nothing in view)."""
     from garden_amd import scene
     sc = scene.hierarchy_scene(n_local, seed=scene.SEED + rank) if wl["hier"] else scene.flat_scene(n_local, seed=scene.SEED + rank)
     if world > 1:
+        from garden_amd.multi import cell_grid, cell_owners
         side = 100.0 * (n_local * world) ** (1.0 / 3.0)
         local_side = 100.0 * n_local ** (1.0 / 3.0)
-        from garden_amd.multi import tile_grid
-        g = tile_grid(world)
-        cell = [rank % g[0], (rank // g[0]) % g[1], rank // (g[0] * g[1])]
+        g = cell_grid(world)
+        mine = np.nonzero(cell_owners(g, world) == rank)[0]  # linear cell ids x + y * gx + z * gx * gy
+        k = mine.shape[0]
         roots = sc.transforms["parent"] == 0
         pos = sc.transforms["position"]
-        for a in range(3):
-            ext = side / g[a]
-            lo = -0.5 * side + cell[a] * ext
-            # roots were drawn uniform in [-local_side/2, local_side/2): remap into this tile's box
-            pos[roots, a] = ((pos[roots, a] / local_side + 0.5) * ext + lo).astype(np.float32)
+        # roots were drawn uniform in [-local_side/2, local_side/2)^3: x picks the cell (k equal slabs of the local cube) and the
+        # place inside it, y and z the place inside the cell
+        u = (pos[roots, :3].astype(np.float64) / local_side + 0.5).clip(0.0, np.nextafter(1.0, 0.0))
+        j = np.minimum((u[:, 0] * k).astype(np.int64), k - 1)
+        u[:, 0] = u[:, 0] * k - j
+        cell = mine[j]
+        cxyz = np.stack([cell % g[0], (cell // g[0]) % g[1], cell // (g[0] * g[1])], axis=1).astype(np.float64)
+        ext = side / np.array(g, dtype=np.float64)
+        pos[roots, :3] = (-0.5 * side + (cxyz + u) * ext).astype(np.float32)
     return sc
 
 

@@ -383,6 +383,23 @@ struct Context {
     int exchange_rank = 0, exchange_world = 1;
     uint32_t exchange_mode = GV_EXCHANGE_ALLGATHER;  // GvExchangeMode
     DeviceBuf<uint32_t> d_shard;       // [count, indices...] of this rank
+    // gv_exchange_visible: library-owned rows, sized from the headers of earlier frames (gv_exchange.cpp)
+    struct ExchangeSlot {
+        DeviceBuf<uint32_t> rows;      // [world][row_words]
+        PinnedBuf<uint32_t> hdr;       // [world] counts + [1] sequence word, written by exchange_headers_kernel
+        uint32_t row_words = 0;
+        uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};  // list entries rank r's row had room for in this slot's frame
+        uint64_t frame = 0;
+        bool in_flight = false;
+    } exchange_slots[2];
+    uint64_t exchange_frame = 0;                        // the next frame's number
+    uint32_t exchange_room[GV_EXCHANGE_MAX_RANKS] = {};  // room the next frame gives each rank
+    bool exchange_need_exact = true;                    // size the next frame from its own counts
+    uint64_t exchange_counts_frame = UINT64_MAX;        // latest retired frame: its counts and which rows were cut
+    uint32_t exchange_counts[GV_EXCHANGE_MAX_RANKS] = {};
+    uint64_t exchange_cut = 0;
+    DeviceBuf<uint32_t> d_xcounts;     // the exact path's count all-gather
+    PinnedBuf<uint32_t> h_xcounts;
 
     // ---- profiling ----
     std::vector<PendingEvent> pending;

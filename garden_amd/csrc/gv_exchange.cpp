@@ -9,7 +9,12 @@
 // with every peer (each shard crosses exactly one link), or one ncclBroadcast per root. Same bytes in the same place.
 //
 // RCCL is bound at run time (dlopen): a process that already carries an RCCL — PyTorch bundles one — keeps using that
-// copy, and libgarden_vis.so has no link-time dependency on it.
+// copy, and libgarden_vis.so has no link-time dependency on it. GV_RCCL_LIBRARY names another library with the same
+// entry points (a site's own RCCL build; the tests' shared-memory transport, tests/cpp/rccl_stub, which lets N ranks share
+// one GPU — RCCL itself refuses two ranks on one device).
+//
+// gv_exchange_visible is the per-frame form the engine calls: the library owns the rows and sizes them from the headers
+// of earlier frames, which reach the host through pinned memory (exchange_headers_kernel) — see include/garden_vis.h.
 #include <dlfcn.h>
 
 #include "gv_ctx.hpp"
@@ -42,10 +47,17 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;
+        if (const char* named = getenv("GV_RCCL_LIBRARY")) {
+            h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                r.why = std::string("GV_RCCL_LIBRARY=") + named + " not loadable: " + (dlerror() ? dlerror() : "?");
+                return;
+            }
+        }
         for (const char* name : {"librccl.so", "librccl.so.1"}) {  // an already loaded copy first
-            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (h)
                 break;
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         }
         if (!h)
             for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -90,6 +102,18 @@ void exchange_release(GvCtx* ctx)
         ctx->exchange_comm = nullptr;
     }
     ctx->d_shard.release();
+    for (auto& slot : ctx->exchange_slots) {
+        slot.rows.release();
+        slot.hdr.release();
+        slot.in_flight = false;
+        slot.row_words = 0;
+    }
+    ctx->d_xcounts.release();
+    ctx->h_xcounts.release();
+    ctx->exchange_frame = 0;
+    ctx->exchange_need_exact = true;
+    ctx->exchange_counts_frame = UINT64_MAX;
+    ctx->exchange_cut = 0;
 }
 
 }  // namespace gv
@@ -114,8 +138,8 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!unique_id || world_size < 1 || rank < 0 || rank >= world_size)
-        return ctx->fail(GV_E_ARG, "gv_exchange_init: bad rank %d / world %d", rank, world_size);
+    if (!unique_id || world_size < 1 || world_size > (int)GV_EXCHANGE_MAX_RANKS || rank < 0 || rank >= world_size)
+        return ctx->fail(GV_E_ARG, "gv_exchange_init: bad rank %d / world %d (at most %u ranks)", rank, world_size, GV_EXCHANGE_MAX_RANKS);
     Rccl& r = rccl();
     if (!r.ok)
         return ctx->fail(GV_E_RCCL, "gv_exchange_init: %s", r.why.c_str());
@@ -153,32 +177,38 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
     return GV_OK;
 }
 
-// ctx->d_shard[0 .. words) of every rank into rows [rank * words ...) of gathered_device, by the configured pattern
-static int exchange_rows(GvCtx* ctx, size_t words, void* gathered_device, const char* what)
+// ctx->d_shard of every rank into rows [rank * row_words ...) of gathered_device, by the configured pattern. travel[r] (NULL:
+// row_words for all) = the leading words of rank r's row that matter: the direct patterns move exactly those, the equal-size
+// all-gather always moves whole rows.
+static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, void* gathered_device, const char* what)
 {
     Rccl& r = rccl();
     uint32_t* rows = static_cast<uint32_t*>(gathered_device);
     const int me = ctx->exchange_rank, world = ctx->exchange_world;
+    auto words_of = [&](int rank) -> size_t { return travel ? std::min<size_t>(travel[rank], row_words) : row_words; };
     if (ctx->exchange_mode == GV_EXCHANGE_ALLGATHER) {
-        const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, words, kNcclUint32, ctx->exchange_comm, ctx->stream);
+        const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, row_words, kNcclUint32, ctx->exchange_comm, ctx->stream);
         if (nrc != 0)
             return ctx->fail(GV_E_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(nrc));
         return GV_OK;
     }
     // the direct forms place this rank's own row with a device copy; the peers' rows arrive over the links
-    GV_HIP(ctx, hipMemcpyAsync(rows + (size_t)me * words, ctx->d_shard.ptr, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(rows + (size_t)me * row_words, ctx->d_shard.ptr, words_of(me) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               ctx->stream));
+    if (world == 1)
+        return GV_OK;
     int nrc = r.GroupStart();
     if (ctx->exchange_mode == GV_EXCHANGE_P2P) {
         // one send/recv pair per peer inside one group: every shard crosses exactly one xGMI link, all links at once
         for (int d = 1; d < world && nrc == 0; d++) {
             const int to = (me + d) % world, from = (me - d + world) % world;
-            nrc = r.Send(ctx->d_shard.ptr, words, kNcclUint32, to, ctx->exchange_comm, ctx->stream);
+            nrc = r.Send(ctx->d_shard.ptr, words_of(me), kNcclUint32, to, ctx->exchange_comm, ctx->stream);
             if (nrc == 0)
-                nrc = r.Recv(rows + (size_t)from * words, words, kNcclUint32, from, ctx->exchange_comm, ctx->stream);
+                nrc = r.Recv(rows + (size_t)from * row_words, words_of(from), kNcclUint32, from, ctx->exchange_comm, ctx->stream);
         }
     } else {
         for (int root = 0; root < world && nrc == 0; root++)
-            nrc = r.Broadcast(root == me ? ctx->d_shard.ptr : rows + (size_t)root * words, rows + (size_t)root * words, words,
+            nrc = r.Broadcast(root == me ? ctx->d_shard.ptr : rows + (size_t)root * row_words, rows + (size_t)root * row_words, words_of(root),
                               kNcclUint32, root, ctx->exchange_comm, ctx->stream);
     }
     const int erc = r.GroupEnd();
@@ -200,7 +230,8 @@ static int reserve_shard(GvCtx* ctx, size_t words)
     return GV_OK;
 }
 
-int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device)
+int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const uint32_t* capacities, uint32_t index_base,
+                       void* gathered_device)
 {
     if (!ctx)
         return GV_E_ARG;
@@ -208,12 +239,183 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint3
         return ctx->fail(GV_E_STATE, "gv_exchange_shards: gv_exchange_init has not run");
     if (!gathered_device || capacity == 0)
         return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
+    uint32_t travel[GV_EXCHANGE_MAX_RANKS];
+    if (capacities)
+        for (int r = 0; r < ctx->exchange_world; r++) {
+            if (capacities[r] > capacity)
+                return ctx->fail(GV_E_ARG, "gv_exchange_shards: capacities[%d] = %u above the row capacity %u", r, capacities[r], capacity);
+            travel[r] = 1u + capacities[r];
+        }
     GV_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = reserve_shard(ctx, (size_t)capacity + 1))
         return rc;
-    if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, capacity, index_base))
+    const uint32_t own = capacities ? capacities[ctx->exchange_rank] : capacity;
+    if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, own, index_base))
         return rc;
-    return exchange_rows(ctx, (size_t)capacity + 1, gathered_device, "gv_exchange_shards");
+    return exchange_rows(ctx, (size_t)capacity + 1, capacities ? travel : nullptr, gathered_device, "gv_exchange_shards");
+}
+
+// ---- gv_exchange_visible: rows owned and sized by the library ----
+
+// room for a list of `count` entries: count + max(count / 8, 1024), rounded up to 1024 words
+static uint32_t room_for(uint32_t count)
+{
+    uint64_t c = (uint64_t)count + std::max<uint64_t>(count / 8u, 1024u);
+    c = (c + 1023u) & ~1023ull;
+    return (uint32_t)std::min<uint64_t>(c, 0xFFFFFC00u);
+}
+
+// the headers of `slot`'s frame, once they are on the host: counts, cut rows, and the room the coming frames give each rank
+static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
+{
+    if (!slot.in_flight)
+        return GV_OK;
+    const int world = ctx->exchange_world;
+    const uint32_t seq = (uint32_t)(slot.frame + 1);
+    volatile uint32_t* word = slot.hdr.ptr + world;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *word != seq; spins++) {
+        // (normally written two frames ago; a host that runs far ahead of the device waits here, which is what bounds it)
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (*word != seq)
+                return ctx->fail(GV_E_RCCL, "exchange frame %llu: the row headers never reached the host (sequence word %u, expected %u)",
+                                 (unsigned long long)slot.frame, *word, seq);
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    slot.in_flight = false;
+    if (ctx->exchange_counts_frame != UINT64_MAX && slot.frame <= ctx->exchange_counts_frame)
+        return GV_OK;  // (retired out of order by gv_exchange_counts: the newer frame's verdict stands)
+    ctx->exchange_counts_frame = slot.frame;
+    ctx->exchange_cut = 0;
+    for (int r = 0; r < world; r++) {
+        const uint32_t count = slot.hdr.ptr[r];
+        ctx->exchange_counts[r] = count;
+        if (count > slot.room[r]) {
+            ctx->exchange_cut |= 1ull << r;
+            ctx->exchange_need_exact = true;
+        }
+        const uint32_t want = room_for(count);
+        if (want > ctx->exchange_room[r] || (uint64_t)want * 4u < (uint64_t)ctx->exchange_room[r] * 3u)
+            ctx->exchange_room[r] = want;
+    }
+    return GV_OK;
+}
+
+int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_visible: gv_exchange_init has not run");
+    if (!out || (flags & ~GV_EXCHANGE_EXACT))
+        return ctx->fail(GV_E_ARG, "gv_exchange_visible: NULL frame or unknown flags 0x%x", flags);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    Rccl& r = rccl();
+    const int me = ctx->exchange_rank, world = ctx->exchange_world;
+    const uint64_t frame = ctx->exchange_frame;
+    gv::Context::ExchangeSlot& slot = ctx->exchange_slots[frame & 1u];
+    if (int rc = retire_slot(ctx, slot))  // frame - 2: its rows may be overwritten now, its headers size this frame
+        return rc;
+    GvDeviceResult dres{};
+    if (int rc = gv_pool_results_device(ctx, ctx->last_pool, view_index, &dres))
+        return rc;
+    if (!dres.visible_idx)
+        return ctx->fail(GV_E_ARG, "gv_exchange_visible: view %u has no emitted records", view_index);
+    const bool exact = ctx->exchange_need_exact || (flags & GV_EXCHANGE_EXACT);
+    if (exact) {
+        // this frame's own counts to every rank first (one word each), read on the host: the one synchronising step
+        GV_HIP(ctx, ctx->d_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
+        GV_HIP(ctx, ctx->h_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
+        const int nrc = r.AllGather(dres.draw_count, ctx->d_xcounts.ptr, 1, kNcclUint32, ctx->exchange_comm, ctx->stream);
+        if (nrc != 0)
+            return ctx->fail(GV_E_RCCL, "gv_exchange_visible: ncclAllGather of the counts: %s", r.GetErrorString(nrc));
+        GV_HIP(ctx, hipMemcpyAsync(ctx->h_xcounts.ptr, ctx->d_xcounts.ptr, (size_t)world * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < world; k++)
+            ctx->exchange_room[k] = std::max(ctx->exchange_room[k], room_for(ctx->h_xcounts.ptr[k]));
+        ctx->exchange_need_exact = false;
+    }
+    uint32_t widest = 0;
+    for (int k = 0; k < world; k++)
+        widest = std::max(widest, ctx->exchange_room[k]);
+    const size_t row_words = (size_t)widest + 1;
+    if ((size_t)world * row_words > slot.rows.cap) {  // grown by half again: a list that creeps up does not reallocate every time
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (consumers of the old rows were enqueued on this stream)
+        GV_HIP(ctx, slot.rows.reserve(std::max((size_t)world * row_words, slot.rows.cap + slot.rows.cap / 2)));
+    }
+    if (!slot.hdr.ptr) {
+        GV_HIP(ctx, slot.hdr.reserve(GV_EXCHANGE_MAX_RANKS + 1));
+        memset(slot.hdr.ptr, 0, (GV_EXCHANGE_MAX_RANKS + 1) * sizeof(uint32_t));
+    }
+    if (int rc = reserve_shard(ctx, row_words))
+        return rc;
+    uint32_t travel[GV_EXCHANGE_MAX_RANKS];
+    for (int k = 0; k < world; k++) {
+        slot.room[k] = ctx->exchange_room[k];
+        travel[k] = 1u + ctx->exchange_room[k];
+    }
+    if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, ctx->exchange_room[me], index_base))
+        return rc;
+    if (int rc = exchange_rows(ctx, row_words, travel, slot.rows.ptr, "gv_exchange_visible"))
+        return rc;
+    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, (uint32_t)row_words, (uint32_t)world, slot.hdr.ptr, (uint32_t)(frame + 1), ctx->stream));
+    slot.row_words = (uint32_t)row_words;
+    slot.frame = frame;
+    slot.in_flight = true;
+    ctx->exchange_frame = frame + 1;
+
+    memset(out, 0, sizeof(*out));
+    out->gathered_device = slot.rows.ptr;
+    out->row_words = (uint32_t)row_words;
+    out->world_size = (uint32_t)world;
+    out->frame = frame;
+    for (int k = 0; k < world; k++) {
+        out->room[k] = slot.room[k];
+        out->travelled_words[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : travel[k];
+        out->counts[k] = ctx->exchange_counts[k];
+    }
+    out->counts_frame = ctx->exchange_counts_frame;
+    out->cut_ranks = ctx->exchange_cut;
+    out->exact = exact ? 1u : 0u;
+    out->mode = ctx->exchange_mode;
+    return GV_OK;
+}
+
+int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_counts: gv_exchange_init has not run");
+    if (!counts || frame >= ctx->exchange_frame || frame + 2 < ctx->exchange_frame)
+        return ctx->fail(GV_E_ARG, "gv_exchange_counts: frame %llu is not one of the last two exchanged (next: %llu)",
+                         (unsigned long long)frame, (unsigned long long)ctx->exchange_frame);
+    gv::Context::ExchangeSlot& slot = ctx->exchange_slots[frame & 1u];
+    if (slot.frame != frame)
+        return ctx->fail(GV_E_STATE, "gv_exchange_counts: frame %llu's rows have been reused", (unsigned long long)frame);
+    if (slot.in_flight) {
+        // every frame up to this one, oldest first: the room decisions must see the frames in order on every rank
+        gv::Context::ExchangeSlot& older = ctx->exchange_slots[(frame & 1u) ^ 1u];
+        if (older.in_flight && older.frame < frame)
+            if (int rc = retire_slot(ctx, older))
+                return rc;
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (int rc = retire_slot(ctx, slot))
+            return rc;
+    }
+    uint64_t cut = 0;
+    for (int k = 0; k < ctx->exchange_world; k++) {
+        counts[k] = slot.hdr.ptr[k];
+        if (counts[k] > slot.room[k])
+            cut |= 1ull << k;
+    }
+    if (cut_ranks)
+        *cut_ranks = cut;
+    return GV_OK;
 }
 
 int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device)
@@ -229,7 +431,7 @@ int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void
         return rc;
     if (int rc = gv_results_copy_mask_device(ctx, view_index, ctx->d_shard.ptr, word_count))
         return rc;
-    return exchange_rows(ctx, (size_t)word_count + 1, gathered_device, "gv_exchange_masks");
+    return exchange_rows(ctx, (size_t)word_count + 1, nullptr, gathered_device, "gv_exchange_masks");
 }
 
 int gv_exchange_shutdown(GvCtx* ctx)

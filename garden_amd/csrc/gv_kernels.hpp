@@ -184,6 +184,11 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
                            const uint32_t* map, hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                              const uint32_t* map, hipStream_t stream);
+// gv_exchange_visible: the headers (true counts) of all `world` gathered rows, then `seq`, into pinned host memory
+// (host_words[0 .. world) = rows[r * row_words], host_words[world] = seq with system-scope release): the host learns the
+// counts of a frame without an event record or a synchronisation — it looks at the word a frame or two later
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+                                   hipStream_t stream);
 // gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
 constexpr uint32_t kPublishMaxSlots = 262144;

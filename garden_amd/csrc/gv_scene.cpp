@@ -965,11 +965,14 @@ int gv_scene_bind(GvCtx* ctx, GvScene* scene)
 // free slots and meshes without a transform go to tile 0; inside a tile slots keep their order, entity ids are
 // renumbered from 1 (live transforms in slot order, then mesh entities without a transform in ascending old id), parents
 // are remapped (a parent without a transform stays an id nothing maps to).
-int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double side, uint32_t tile, GvScene** out_tile)
+}  // extern "C"
+
+// owner[cell]: which tile each cell of the grid belongs to (identity: one tile per cell; cells dealt to ranks: see
+// gv_scene_extract_rank); `tile` is the one to cut out
+// spread_strays > 0: free transform slots and meshes without a transform go to tile slot % spread_strays instead of tile 0
+static int extract_owned(const GvScene* scene, const uint32_t grid[3], double side, const std::vector<uint32_t>& owner, uint32_t tile,
+                         uint32_t spread_strays, GvScene** out_tile)
 {
-    if (!scene || !grid || !out_tile || !(side > 0.0) || grid[0] == 0 || grid[1] == 0 || grid[2] == 0 ||
-        (uint64_t)grid[0] * grid[1] * grid[2] > 4096u || tile >= grid[0] * grid[1] * grid[2])
-        return GV_E_ARG;
     *out_tile = nullptr;
     GvScene* out = nullptr;
     try {  // (the vectors and the map below allocate: nothing may escape into C / ctypes callers)
@@ -981,8 +984,10 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
     // root ancestor of every transform slot (chains are short; a cycle — the loader cannot produce one — ends at 64 steps)
     std::vector<uint32_t> xf_tile(nt, 0);
     for (uint32_t s = 0; s < nt; s++) {
-        if (scene->entity[s] == 0)
-            continue;  // free slot: tile 0
+        if (scene->entity[s] == 0) {
+            xf_tile[s] = spread_strays ? s % spread_strays : 0u;  // free slot
+            continue;
+        }
         uint32_t root = s;
         for (int hop = 0; hop < 64; hop++) {
             const uint32_t ps = slot_of(scene->parent[root]);
@@ -1000,7 +1005,7 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
             t += (uint32_t)c * mul;
             mul *= grid[a];
         }
-        xf_tile[s] = t;
+        xf_tile[s] = owner[t];
     }
     out = new (std::nothrow) GvScene();
     if (!out)
@@ -1023,7 +1028,7 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
         out->pools[pid].mapped = src.mapped;
         for (uint32_t i = 0; i < src.entity.size(); i++) {
             const uint32_t ts = slot_of(src.entity[i]);
-            const uint32_t mt = (ts != kNone && ts < nt) ? xf_tile[ts] : 0u;
+            const uint32_t mt = (ts != kNone && ts < nt) ? xf_tile[ts] : (spread_strays ? i % spread_strays : 0u);
             if (mt != tile)
                 continue;
             out->mesh_global[pid].push_back(i);
@@ -1095,6 +1100,53 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
     return GV_OK;
     } catch (...) {  // std::bad_alloc
         delete out;
+        return GV_E_OOM;
+    }
+}
+
+extern "C" {
+
+int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double side, uint32_t tile, GvScene** out_tile)
+{
+    if (!scene || !grid || !out_tile || !(side > 0.0) || grid[0] == 0 || grid[1] == 0 || grid[2] == 0 ||
+        (uint64_t)grid[0] * grid[1] * grid[2] > 4096u || tile >= grid[0] * grid[1] * grid[2])
+        return GV_E_ARG;
+    try {
+        std::vector<uint32_t> owner((size_t)grid[0] * grid[1] * grid[2]);
+        for (uint32_t c = 0; c < owner.size(); c++)
+            owner[c] = c;
+        return extract_owned(scene, grid, side, owner, tile, 0, out_tile);
+    } catch (...) {
+        return GV_E_OOM;
+    }
+}
+
+// Cells in Morton (Z-curve) order of their (x, y, z) coordinates, dealt in rounds of world_size with a rotation that changes
+// from round to round: cell k of that order belongs to rank (k + h(k / world_size)) % world_size. The same table as
+// garden_amd/multi.py::cell_owners (tests compare them; the docstring there says why not plain k % world_size).
+int gv_scene_extract_rank(const GvScene* scene, const uint32_t grid[3], double side, uint32_t rank, uint32_t world_size, GvScene** out_tile)
+{
+    if (!scene || !grid || !out_tile || !(side > 0.0) || grid[0] == 0 || grid[1] == 0 || grid[2] == 0 ||
+        (uint64_t)grid[0] * grid[1] * grid[2] > 32768u || world_size == 0 || rank >= world_size)
+        return GV_E_ARG;
+    try {
+        const uint32_t cells = grid[0] * grid[1] * grid[2];
+        std::vector<std::pair<uint64_t, uint32_t>> order(cells);
+        for (uint32_t c = 0; c < cells; c++) {
+            const uint32_t x = c % grid[0], y = (c / grid[0]) % grid[1], z = c / (grid[0] * grid[1]);
+            uint64_t code = 0;
+            for (uint32_t b = 0; b < 12; b++)
+                code |= (uint64_t)((x >> b) & 1u) << (3 * b) | (uint64_t)((y >> b) & 1u) << (3 * b + 1) | (uint64_t)((z >> b) & 1u) << (3 * b + 2);
+            order[c] = {code, c};
+        }
+        std::sort(order.begin(), order.end());
+        std::vector<uint32_t> owner(cells);
+        for (uint32_t k = 0; k < cells; k++) {  // one cell per rank per round; the rotation changes from round to round
+            const uint32_t turn = (uint32_t)(((uint64_t)(k / world_size) * 2654435761ull) & 0xFFFFFFFFull) >> 16;
+            owner[order[k].second] = (uint32_t)(((uint64_t)k + turn) % world_size);
+        }
+        return extract_owned(scene, grid, side, owner, rank, world_size, out_tile);
+    } catch (...) {
         return GV_E_OOM;
     }
 }

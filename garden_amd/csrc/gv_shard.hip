@@ -45,4 +45,24 @@ hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* b
     return hipGetLastError();
 }
 
+// The count header of every gathered row -> pinned host memory, then the frame's sequence number behind a system-scope
+// release: what gv_exchange_visible sizes the next frames' shards from (gv_exchange.cpp). One wave.
+__global__ __launch_bounds__(64) void exchange_headers_kernel(const uint32_t* __restrict__ rows, uint32_t row_words, uint32_t world,
+                                                             uint32_t* __restrict__ host_words, uint32_t seq)
+{
+    for (uint32_t r = threadIdx.x; r < world; r += 64)
+        __hip_atomic_store(host_words + r, rows[(size_t)r * row_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(host_words + world, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+                                   hipStream_t stream)
+{
+    hipLaunchKernelGGL(exchange_headers_kernel, dim3(1), dim3(64), 0, stream, rows, row_words, world, host_words, seq);
+    return hipGetLastError();
+}
+
 }  // namespace gv

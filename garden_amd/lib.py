@@ -72,6 +72,16 @@ class GvStats(C.Structure):
                 ("bounds_blocks_examined", C.c_uint64), ("mirror_reorders", C.c_uint64)]
 
 
+GV_EXCHANGE_MAX_RANKS = 64
+GV_EXCHANGE_EXACT = 1
+
+
+class GvExchangeFrame(C.Structure):
+    _fields_ = [("gathered_device", C.c_void_p), ("row_words", C.c_uint32), ("world_size", C.c_uint32), ("frame", C.c_uint64),
+                ("room", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("travelled_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("counts_frame", C.c_uint64),
+                ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64), ("exact", C.c_uint32), ("mode", C.c_uint32)]
+
+
 class GvColumn(C.Structure):
     _fields_ = [("data", C.c_void_p), ("stride", C.c_uint32)]
 
@@ -111,8 +121,8 @@ EXPORTS = [
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
-    "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_scene_tile_maps",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_counts", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -185,10 +195,13 @@ def load():
     lib.gv_scene_mesh_columns.argtypes = [P, u32, C.POINTER(GvMeshColumns), C.POINTER(u32)]
     lib.gv_scene_bind.argtypes = [P, P]
     lib.gv_scene_extract_tile.argtypes = [P, C.POINTER(C.c_uint32 * 3), C.c_double, u32, C.POINTER(P)]
+    lib.gv_scene_extract_rank.argtypes = [P, C.POINTER(C.c_uint32 * 3), C.c_double, u32, u32, C.POINTER(P)]
     lib.gv_scene_tile_maps.argtypes = [P, u32, C.POINTER(P), C.POINTER(u32), C.POINTER(P), C.POINTER(u32)]
     lib.gv_exchange_unique_id.argtypes = [P]
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
-    lib.gv_exchange_shards.argtypes = [P, u32, u32, u32, P]
+    lib.gv_exchange_shards.argtypes = [P, u32, u32, P, u32, P]
+    lib.gv_exchange_visible.argtypes = [P, u32, u32, u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_counts.argtypes = [P, C.c_uint64, P, C.POINTER(C.c_uint64)]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]
     lib.gv_exchange_set_mode.argtypes = [P, u32]
@@ -472,8 +485,32 @@ class GpuVisibility:
     def exchange_init(self, unique_id, rank, world_size):
         self._check(self.lib.gv_exchange_init(self.ctx, unique_id, rank, world_size))
 
-    def exchange_shards(self, view_index, capacity, index_base, gathered_ptr):
-        self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, index_base, gathered_ptr))
+    def exchange_shards(self, view_index, capacity, index_base, gathered_ptr, capacities=None):
+        """Caller-owned rows [world, 1 + capacity]; capacities (one per rank, the same list on every rank): what of each
+        rank's row travels under the direct patterns."""
+        caps = None
+        if capacities is not None:
+            caps = (C.c_uint32 * len(capacities))(*[int(c) for c in capacities])
+        self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, caps, index_base, gathered_ptr))
+
+    def exchange_visible(self, view_index=0, index_base=0, exact=False):
+        """The per-frame exchange with library-owned, library-sized rows (gv_exchange_visible). Returns a dict: ptr (device address
+        of the uint32 rows [world, row_words]), row_words, world, frame, room, travelled_words, counts_frame (None: no frame's
+        headers have reached the host yet), counts, cut_ranks (list of ranks), exact, mode."""
+        f = GvExchangeFrame()
+        self._check(self.lib.gv_exchange_visible(self.ctx, view_index, index_base, GV_EXCHANGE_EXACT if exact else 0, C.byref(f)))
+        w = f.world_size
+        return dict(ptr=f.gathered_device, row_words=f.row_words, world=w, frame=int(f.frame),
+                    room=[int(f.room[r]) for r in range(w)], travelled_words=[int(f.travelled_words[r]) for r in range(w)],
+                    counts_frame=None if f.counts_frame == 0xFFFFFFFFFFFFFFFF else int(f.counts_frame),
+                    counts=[int(f.counts[r]) for r in range(w)], cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1],
+                    exact=bool(f.exact), mode=int(f.mode))
+
+    def exchange_counts(self, frame, world):
+        """Blocks until frame `frame`'s row headers are on the host: (counts per rank, ranks whose rows were cut)."""
+        counts, cut = (C.c_uint32 * world)(), C.c_uint64()
+        self._check(self.lib.gv_exchange_counts(self.ctx, frame, counts, C.byref(cut)))
+        return [int(c) for c in counts], [r for r in range(world) if (cut.value >> r) & 1]
 
     def exchange_masks(self, view_index, word_count, gathered_ptr):
         """All ranks' [draw_count, one bit per mirror entry] shards into gathered_ptr ([world, 1 + word_count] uint32, device)."""
@@ -626,6 +663,18 @@ class Scene:
         rc = self.lib.gv_scene_extract_tile(self.handle, C.byref(g), float(side), int(tile), C.byref(handle))
         if rc != 0:
             raise GvError(rc, "gv_scene_extract_tile failed")
+        t = Scene.__new__(Scene)
+        t.lib, t.handle, t.pools = self.lib, handle, dict(self.pools)
+        return t
+
+    def extract_rank(self, grid, side, rank, world):
+        """Everything rank `rank` of `world` owns (the grid's cells in Morton order, dealt round-robin) as one Scene
+        (gv_scene_extract_rank; multi.py::cell_owners is the same table)."""
+        handle = C.c_void_p()
+        g = (C.c_uint32 * 3)(*[int(x) for x in grid])
+        rc = self.lib.gv_scene_extract_rank(self.handle, C.byref(g), float(side), int(rank), int(world), C.byref(handle))
+        if rc != 0:
+            raise GvError(rc, "gv_scene_extract_rank failed")
         t = Scene.__new__(Scene)
         t.lib, t.handle, t.pools = self.lib, handle, dict(self.pools)
         return t

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 1u
+#define GV_ABI_VERSION 2u /* 2: gv_exchange_shards takes per-rank capacities; gv_exchange_visible / _counts */
 #define GV_NONE 0xFFFFFFFFu
 #define GV_MAX_POOLS 16u
 #define GV_MAX_VIEWS 8u
@@ -317,27 +317,67 @@ int gv_pool_result_count(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint
 int gv_pool_results_device(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, GvDeviceResult* out);
 int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descending);
 
-/* ---- multi-GPU exchange without torch.distributed (one process per GPU) ----
+/* ---- multi-GPU exchange (one process per GPU): the all-gatherv of the compacted visible lists over RCCL.
+ * Replaces what the reference does inside one address space — every worker appends its range's records to the shared
+ * array with `drawCount.fetch_add` + memcpy into combinedMeshes (source/system/render/mesh.cpp:177-183).
  * Rank 0 calls gv_exchange_unique_id and hands the 128 bytes to the other ranks by its own means (the engine's IPC, a
- * file, MPI ...); every rank then calls gv_exchange_init with its own context. gv_exchange_shards enqueues, on the
- * context's stream: this rank's shard [draw_count, visible_idx + index_base ...] (capacity + 1 uint32, see
- * gv_results_copy_shard_device) and ONE ncclAllGather of all shards into gathered_device (world_size * (capacity + 1)
- * uint32, caller-owned device memory; row r = rank r's shard). No host synchronisation: consumers order themselves
- * behind gv_stream(ctx) and read the counts from the headers (a header above `capacity` = that rank's list was cut).
- * RCCL is dlopen'ed at the first call; failures return GV_E_RCCL with the RCCL text in gv_last_error. */
+ * file, MPI ...); every rank then calls gv_exchange_init with its own context. RCCL is dlopen'ed at the first call — the
+ * copy already in the process if there is one, else librccl.so.1, or the library the environment variable GV_RCCL_LIBRARY
+ * names; failures return GV_E_RCCL with the RCCL text in gv_last_error. All ranks make the same calls in the same order. */
 #define GV_EXCHANGE_ID_BYTES 128
+#define GV_EXCHANGE_MAX_RANKS 64u
 int gv_exchange_unique_id(void* out_id_128_bytes);
 int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int world_size);
-int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, uint32_t index_base, void* gathered_device);
-/* The same exchange with bit shards (gv_results_copy_mask_device): row r of gathered_device = rank r's [draw_count, one bit per
+
+/* The per-frame exchange, sized by the library: enqueues on the context's stream this rank's shard [draw_count, visible_idx +
+ * index_base ...] (gv_results_copy_shard_device; the pool's gv_pool_set_index_map table applies) and its gather into a
+ * library-owned device buffer of world_size rows (row r = rank r's shard, out->row_words uint32 apart). No host
+ * synchronisation in the steady state: consumers order themselves behind gv_stream(ctx) and read the counts from the row
+ * headers. How much of each rank's row travels is decided from the headers of an EARLIER frame, which every rank holds and which
+ * reach the host through pinned memory two frames later (no event, no synchronisation): rank r's list gets
+ * count + max(count / 8, 1024) words of room, rounded up to 1024 — grown at once, given back when the list has shrunk by a
+ * quarter. Every rank sees the same headers, so every rank derives the same sizes. Frame 0 — and the frame after a row was found
+ * cut (a header above the room its row had: out->cut_ranks names them, out->counts_frame the frame), and any frame called with
+ * GV_EXCHANGE_EXACT (a camera cut) — first all-gathers the counts themselves (one word per rank) and sizes from those; such a
+ * frame synchronises the host with the stream once. Buffers alternate: a frame's rows stay valid until the exchange after the next.
+ * flags must be the same on every rank. */
+typedef struct GvExchangeFrame {
+    const void* gathered_device; /* uint32 [world_size][row_words], device memory owned by the library */
+    uint32_t row_words;          /* 1 + the largest room of any rank this frame */
+    uint32_t world_size;
+    uint64_t frame;              /* 0, 1, 2 ... since gv_exchange_init */
+    uint32_t room[GV_EXCHANGE_MAX_RANKS];            /* list entries rank r's row holds at most this frame: a header above it =
+                                                        that list was cut to its leading room[r] entries */
+    uint32_t travelled_words[GV_EXCHANGE_MAX_RANKS]; /* of rank r's row, the words that crossed a link this frame (header included;
+                                                        the equal-size all-gather moves whole rows whatever the rooms) */
+    uint64_t counts_frame;       /* the latest frame whose headers have reached the host (UINT64_MAX: none yet) ... */
+    uint32_t counts[GV_EXCHANGE_MAX_RANKS];          /* ... its draw counts, rank by rank ... */
+    uint64_t cut_ranks;          /* ... and bit r set when rank r's list did not fit the room its row had in that frame */
+    uint32_t exact;              /* 1: this frame was sized from its own counts (host-synchronising) */
+    uint32_t mode;               /* GvExchangeMode the rows travelled by */
+} GvExchangeFrame;
+#define GV_EXCHANGE_EXACT 1u
+int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
+/* Blocks until frame `frame`'s headers have reached the host (one of the last two frames); counts[world_size]. */
+int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks);
+
+/* The same exchange with caller-owned buffers and caller-chosen sizes: row r of gathered_device (world_size * (capacity + 1)
+ * uint32, device memory) = rank r's shard. capacities == NULL: every row travels whole (capacity + 1 words). Otherwise
+ * capacities[world_size], each <= capacity and the same list on every rank: the direct patterns (GV_EXCHANGE_P2P /
+ * _BROADCAST) move 1 + capacities[r] words of rank r's row, and this rank's shard is cut to capacities[rank] entries; the
+ * equal-size all-gather moves capacity + 1 words per row regardless. No host synchronisation; a header above the row's room =
+ * that rank's list was cut. */
+int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const uint32_t* capacities, uint32_t index_base,
+                       void* gathered_device);
+/* The exchange with bit shards (gv_results_copy_mask_device): row r of gathered_device = rank r's [draw_count, one bit per
  * mirror entry] (word_count + 1 uint32 per row; word_count the same on every rank, >= ceil(occupancy / 32) of the largest
  * pool). A fixed size whatever the view — the encoding for dense views (1/32 word per entry). */
 int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device);
 int gv_exchange_shutdown(GvCtx* ctx);
-/* How gv_exchange_shards moves the shards (same result rows either way). The node's xGMI fabric is point to point and
- * fully connected: a ring all-gather serialises world-1 hops, the direct forms use every link at
- * once. Default GV_EXCHANGE_ALLGATHER, or the environment variable GV_EXCHANGE_MODE (allgather | p2p | broadcast) read
- * by gv_exchange_init. */
+/* How the rows travel (same result rows either way). The node's xGMI fabric is point to point and fully connected
+ * (SURVEY.md §5, §8e): a ring all-gather serialises world-1 hops, the direct forms use every link at once and move only
+ * what each rank's list needs. Default GV_EXCHANGE_ALLGATHER, or the environment variable GV_EXCHANGE_MODE (allgather | p2p |
+ * broadcast) read by gv_exchange_init. */
 typedef enum GvExchangeMode {
     GV_EXCHANGE_ALLGATHER = 0, /* one equal-size ncclAllGather */
     GV_EXCHANGE_P2P = 1,       /* one ncclGroup of ncclSend/ncclRecv pairs with every peer */
@@ -411,6 +451,17 @@ int gv_scene_bind(GvCtx* ctx, GvScene* scene);
  * Each rank of a multi-GPU run parses the scene, keeps its own tile, binds it and culls; gv_scene_tile_maps gives the
  * tile-local -> world slot tables (what a gathered visible index means). Destroy with gv_scene_destroy. */
 int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double side, uint32_t tile, GvScene** out_tile);
+/* What ONE RANK of `world_size` owns, as one scene: the cells of the same grid are put in Morton (Z-curve) order of their
+ * (x, y, z) coordinates and dealt to the ranks in rounds — every `world_size` consecutive cells of that order (a compact block
+ * of space) give one cell to every rank, in an order that rotates from round to round: the k-th cell goes to rank
+ * (k + ((k / world_size * 2654435761 mod 2^32) >> 16)) % world_size — and the cells of `rank` are cut out together: one pool,
+ * one cull launch per rank. With many more cells than ranks (16 x 16 x 16 for 8 GPUs) every rank holds an even share of
+ * whatever region a view looks at: one cell per rank leaves the ranks behind the camera idle and the frame waiting for the one
+ * in front of it. The reference's split is even by construction (equal contiguous index ranges,
+ * source/thread-pool.cpp:180-194). Everything else as gv_scene_extract_tile (roots decide, descendants follow, ids
+ * renumbered; gv_scene_tile_maps gives the local -> world slot tables), except that free slots and meshes without a
+ * transform are dealt out too (slot % world_size) instead of piling up on rank 0. grid: at most 32768 cells. */
+int gv_scene_extract_rank(const GvScene* scene, const uint32_t grid[3], double side, uint32_t rank, uint32_t world_size, GvScene** out_tile);
 int gv_scene_tile_maps(const GvScene* tile, uint32_t pool_id, const uint32_t** transform_global, uint32_t* transform_count,
                        const uint32_t** mesh_global, uint32_t* mesh_count);
 

@@ -16,7 +16,8 @@ def _built():
     orc = os.path.join(ROOT, "oracle", "build", "libgv_oracle.so")
     tick = os.path.join(ROOT, "tests", "cpp", "build", "headless_tick")
     ranks = os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks")
-    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(tick) and os.path.exists(ranks)):
+    stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
+    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(tick) and os.path.exists(ranks) and os.path.exists(stub)):
         import __graft_entry__
         __graft_entry__.build()
 

@@ -1,9 +1,17 @@
 // exchange_ranks.cpp — TEST / worked example: the multi-GPU exchange step through the C-ABI alone (no Python, no
 // torch.distributed), one process per GPU as SURVEY.md §8e asks. The parent forks R ranks BEFORE anything touches the
-// GPU; rank 0 creates the RCCL unique id and the parent relays its 128 bytes to the other ranks over pipes (an engine
-// would use its own IPC). Every rank culls its own tile and calls gv_exchange_shards; each checks that its row of the
-// gathered buffer is its own list and that every row's header is a plausible count.
-//   exchange_ranks --ranks R [--entities N]        (R > 1 needs R GPUs: RCCL refuses two ranks on one device)
+// GPU; rank 0 creates the unique id and the parent relays its 128 bytes to the other ranks over pipes (an engine would
+// use its own IPC). Every rank culls its own slab of the world each frame against a camera that turns — and, half way,
+// cuts to the opposite direction — and calls gv_exchange_visible (rows owned and sized by the library, no host
+// synchronisation in the steady state); the last frames go through gv_exchange_shards with per-rank capacities. After every
+// frame each rank summarises (count, delivered entries, sum, xor) every row it received and its own list; the parent
+// checks that all ranks received the same rows and that row r is rank r's list (whole, or — where the library reports the
+// row as cut — its leading part). The transport patterns take turns.
+//   exchange_ranks --ranks R|auto [--entities N] [--frames F] [--mode all|allgather|p2p|broadcast]
+// R > 1 needs R GPUs with RCCL (it refuses two ranks on one device); with GV_RCCL_LIBRARY=<tests/cpp/build/librccl_stub.so>
+// the ranks share the GPUs there are (ranks are dealt round-robin over them) and the rows travel through shared memory.
+// "auto": min(GPUs, 8) ranks.
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -35,6 +43,19 @@ struct alignas(16) Mesh {  // MeshRenderComponent (render/mesh.hpp:45-55)
 };
 static_assert(sizeof(Transform) == 80 && sizeof(Mesh) == 48, "component layouts");
 
+constexpr int kMaxRanks = 8, kMaxFrames = 32;
+struct RowSummary {
+    uint64_t count, delivered, sum, x;
+};
+struct FrameSummary {
+    RowSummary own, rows[kMaxRanks];
+    uint32_t exact, cut_seen, mode, valid;
+    uint32_t travelled[kMaxRanks];
+};
+struct Shared {
+    FrameSummary frames[kMaxRanks][kMaxFrames];
+};
+
 bool write_all(int fd, const void* p, size_t n) { return write(fd, p, n) == (ssize_t)n; }
 bool read_all(int fd, void* p, size_t n)
 {
@@ -48,7 +69,37 @@ bool read_all(int fd, void* p, size_t n)
     return true;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int id_in, int id_out)
+RowSummary summarise(const uint32_t* entries, uint64_t count, uint64_t room, uint32_t add)
+{
+    RowSummary s{count, count < room ? count : room, 0, 0};
+    for (uint64_t k = 0; k < s.delivered; k++) {
+        const uint32_t v = entries[k] + add;
+        s.sum += v;
+        s.x ^= (uint64_t)v * 0x9E3779B97F4A7C15ull;
+    }
+    return s;
+}
+
+// camera at the origin, 90 degree field of view, 16:9, infinite reversed-Z; yaw about +y
+void make_view(float yaw, GvView* view)
+{
+    memset(view, 0, sizeof(*view));
+    const float c = std::cos(yaw), s = std::sin(yaw);
+    // projection (columns): x' = (9/16) x, y' = -y, z' = near, w' = z ; view = rotation by -yaw about y
+    const float P[16] = {9.0f / 16.0f, 0, 0, 0, 0, -1.0f, 0, 0, 0, 0, 0, 1.0f, 0, 0, 0.01f, 0};
+    const float V[16] = {c, 0, s, 0, 0, 1, 0, 0, -s, 0, c, 0, 0, 0, 0, 1};
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; k++)
+                acc += P[k * 4 + row] * V[col * 4 + k];
+            view->view_proj[col * 4 + row] = acc;
+        }
+    view->shadow_pass = -1;
+    view->emit_records = 1;
+}
+
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -66,7 +117,7 @@ int run_rank(int rank, int ranks, uint32_t n, int id_in, int id_out)
     if (gv_create(&config, &ctx) != GV_OK)
         return die("gv_create", nullptr);
 
-    // this rank's tile: a slab of the world along x, camera at the origin looking down +z
+    // this rank's share of the world: a slab along x
     std::vector<Transform> tr(n);
     std::vector<Mesh> me(n);
     std::vector<uint32_t> e2t(n + 1, GV_NONE);
@@ -95,10 +146,6 @@ int run_rank(int rank, int ranks, uint32_t n, int id_in, int id_out)
     if (gv_transform_bind(ctx, tr.data(), sizeof(Transform), n, &tl, e2t.data(), n + 1) != GV_OK ||
         gv_pool_bind(ctx, 0, me.data(), sizeof(Mesh), n, &ml) != GV_OK)
         return die("bind", ctx);
-    GvView view{};
-    view.view_proj[0] = 9.0f / 16.0f; view.view_proj[5] = -1.0f; view.view_proj[11] = 1.0f; view.view_proj[14] = 0.01f;
-    view.shadow_pass = -1;
-    view.emit_records = 1;
 
     // unique id: rank 0 makes it and hands it to the parent; everybody else reads theirs from the parent
     unsigned char id[GV_EXCHANGE_ID_BYTES];
@@ -112,55 +159,142 @@ int run_rank(int rank, int ranks, uint32_t n, int id_in, int id_out)
     if (gv_exchange_init(ctx, id, rank, ranks) != GV_OK)
         return die("gv_exchange_init", ctx);
 
-    const uint32_t capacity = n;  // worst case: everything visible
-    uint32_t* gathered = nullptr;
-    if (hipMalloc((void**)&gathered, (size_t)ranks * (capacity + 1) * 4) != hipSuccess)
+    hipStream_t stream = (hipStream_t)gv_stream(ctx);
+    const uint32_t base = (uint32_t)rank * n;
+    std::vector<uint32_t> host;
+    uint32_t last_counts[kMaxRanks] = {};
+    uint32_t* own_rows = nullptr;  // caller-owned rows of the gv_exchange_shards frames
+    const uint32_t shards_capacity = n;
+    if (hipMalloc((void**)&own_rows, (size_t)ranks * (shards_capacity + 1) * 4) != hipSuccess)
         return 1;
-    for (int frame = 0; frame < 3; frame++)
-        if (gv_cull(ctx, 0, &view, 1) != GV_OK || gv_exchange_shards(ctx, 0, capacity, (uint32_t)rank * n, gathered) != GV_OK)
-            return die("cull / exchange", ctx);
-    if (gv_wait(ctx) != GV_OK)
-        return die("gv_wait", ctx);
-    GvResult res{};
-    if (gv_results_fetch(ctx, 0, 0, &res) != GV_OK)
-        return die("gv_results_fetch", ctx);
-    std::vector<uint32_t> host((size_t)ranks * (capacity + 1));
-    if (hipMemcpy(host.data(), gathered, host.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return 1;
-    bool ok = host[(size_t)rank * (capacity + 1)] == res.draw_count;
-    for (uint32_t k = 0; k < res.draw_count && ok; k++)
-        ok = host[(size_t)rank * (capacity + 1) + 1 + k] == res.visible_idx[k] + (uint32_t)rank * n;
-    uint64_t total = 0;
-    for (int r = 0; r < ranks && ok; r++) {
-        const uint32_t count = host[(size_t)r * (capacity + 1)];
-        ok = count <= n;
-        total += count;
-        for (uint32_t k = 0; k < count && ok; k++) {
-            const uint32_t g = host[(size_t)r * (capacity + 1) + 1 + k];
-            ok = g >= (uint32_t)r * n && g < (uint32_t)(r + 1) * n;  // every index lies in its owner's tile range
+    const int sized_frames = frames - 2;  // the last two frames: gv_exchange_shards with per-rank capacities
+    for (int frame = 0; frame < frames; frame++) {
+        // the camera turns a little every frame; half way it cuts to the opposite direction (lists jump: rows get cut)
+        GvView view;
+        make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &view);
+        const uint32_t mode = mode_arg >= 0 ? (uint32_t)mode_arg : (uint32_t)(frame % 3);
+        if (gv_exchange_set_mode(ctx, mode) != GV_OK || gv_cull(ctx, 0, &view, 1) != GV_OK)
+            return die("cull", ctx);
+        FrameSummary& fs = shared->frames[rank][frame];
+        const uint32_t* rows = nullptr;
+        size_t row_words = 0;
+        uint32_t room[kMaxRanks];
+        if (frame < sized_frames) {
+            GvExchangeFrame xf;
+            if (gv_exchange_visible(ctx, 0, base, 0, &xf) != GV_OK)
+                return die("gv_exchange_visible", ctx);
+            if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode)
+                return die("gv_exchange_visible: frame fields", ctx);
+            rows = (const uint32_t*)xf.gathered_device;
+            row_words = xf.row_words;
+            fs.exact = xf.exact;
+            fs.cut_seen = xf.cut_ranks != 0;
+            for (int r = 0; r < ranks; r++) {
+                room[r] = xf.room[r];
+                if (xf.travelled_words[r] != (mode == GV_EXCHANGE_ALLGATHER ? xf.row_words : xf.room[r] + 1) || xf.room[r] + 1 > xf.row_words)
+                    return die("travelled words / room / row words disagree", ctx);
+                fs.travelled[r] = xf.travelled_words[r];
+            }
+        } else {
+            uint32_t caps[kMaxRanks];
+            for (int r = 0; r < ranks; r++) {  // sized by the caller, from the counts every rank saw in the frame before
+                caps[r] = std::min(shards_capacity, last_counts[r] + last_counts[r] / 4 + 256);
+                room[r] = caps[r];  // (the all-gather moves whole rows, but every rank cuts its own shard to its capacity)
+                fs.travelled[r] = mode == GV_EXCHANGE_ALLGATHER ? shards_capacity + 1 : caps[r] + 1;
+            }
+            if (gv_exchange_shards(ctx, 0, shards_capacity, caps, base, own_rows) != GV_OK)
+                return die("gv_exchange_shards", ctx);
+            rows = own_rows;
+            row_words = (size_t)shards_capacity + 1;
+        }
+        // test-side inspection of this frame (the library's own sizing decisions do not depend on it)
+        if (hipStreamSynchronize(stream) != hipSuccess)
+            return 1;
+        host.resize((size_t)ranks * row_words);
+        if (hipMemcpy(host.data(), rows, host.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return 1;
+        GvResult res{};
+        if (gv_results_fetch(ctx, 0, 0, &res) != GV_OK)
+            return die("gv_results_fetch", ctx);
+        fs.own = summarise(res.visible_idx, res.draw_count, room[rank], base);
+        for (int r = 0; r < ranks; r++) {
+            const uint32_t* row = host.data() + (size_t)r * row_words;
+            fs.rows[r] = summarise(row + 1, row[0], room[r], 0);
+            last_counts[r] = row[0];
+            for (uint64_t k = 0; k < fs.rows[r].delivered; k++)
+                if (row[1 + k] < (uint32_t)r * n || row[1 + k] >= (uint32_t)(r + 1) * n) {
+                    fprintf(stderr, "rank %d frame %d: row %d entry %llu = %u outside its owner's range\n", rank, frame, r,
+                            (unsigned long long)k, row[1 + k]);
+                    return 1;
+                }
+        }
+        fs.mode = mode;
+        fs.valid = 1;
+        if (frame < sized_frames && frame % 4 == 3) {  // now and then: the blocking count query agrees with the headers
+            uint32_t counts[kMaxRanks];
+            uint64_t cut = 0;
+            if (gv_exchange_counts(ctx, (uint64_t)frame, counts, &cut) != GV_OK)
+                return die("gv_exchange_counts", ctx);
+            for (int r = 0; r < ranks; r++)
+                if (counts[r] != fs.rows[r].count || (((cut >> r) & 1) != 0) != (fs.rows[r].count > fs.rows[r].delivered)) {
+                    fprintf(stderr, "rank %d frame %d: gv_exchange_counts disagrees with row %d's header\n", rank, frame, r);
+                    return 1;
+                }
         }
     }
-    printf("{\"rank\": %d, \"ranks\": %d, \"visible\": %u, \"gathered\": %llu, \"ok\": %s}\n", rank, ranks, res.draw_count,
-           (unsigned long long)total, ok ? "true" : "false");
-    fflush(stdout);  // the rank leaves through _exit
-    (void)hipFree(gathered);
-    gv_exchange_shutdown(ctx);
+    (void)hipFree(own_rows);
+    if (gv_exchange_shutdown(ctx) != GV_OK)
+        return die("gv_exchange_shutdown", ctx);
     gv_destroy(ctx);
-    return ok ? 0 : 1;
+    return 0;
 }
 
 }  // namespace
 
 int main(int argc, char** argv)
 {
-    int ranks = 1;
+    int ranks = 1, frames = 12, mode = -1;
+    bool auto_ranks = false;
     uint32_t n = 100000;
     for (int i = 1; i < argc; i++) {
-        if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
-        else if (!strcmp(argv[i], "--entities") && i + 1 < argc) n = (uint32_t)atoi(argv[++i]);
+        if (!strcmp(argv[i], "--ranks") && i + 1 < argc) {
+            if (!strcmp(argv[++i], "auto"))
+                auto_ranks = true;
+            else
+                ranks = atoi(argv[i]);
+        } else if (!strcmp(argv[i], "--entities") && i + 1 < argc) {
+            n = (uint32_t)atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--frames") && i + 1 < argc) {
+            frames = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--mode") && i + 1 < argc) {
+            const char* m = argv[++i];
+            mode = !strcmp(m, "allgather") ? 0 : !strcmp(m, "p2p") ? 1 : !strcmp(m, "broadcast") ? 2 : -1;
+        }
     }
-    if (ranks < 1 || ranks > 64)
+    if (auto_ranks) {
+        // counting devices in a child: this process must not have touched the GPU when it forks the ranks
+        int fds[2];
+        if (pipe(fds) != 0)
+            return 2;
+        const pid_t pid = fork();
+        if (pid == 0) {
+            int devices = 0;
+            if (hipGetDeviceCount(&devices) != hipSuccess)
+                devices = 0;
+            (void)write_all(fds[1], &devices, sizeof(devices));
+            _exit(0);
+        }
+        int devices = 0;
+        (void)read_all(fds[0], &devices, sizeof(devices));
+        waitpid(pid, nullptr, 0);
+        ranks = devices < 1 ? 1 : (devices > kMaxRanks ? kMaxRanks : devices);
+    }
+    if (ranks < 1 || ranks > kMaxRanks || frames < 4 || frames > kMaxFrames)
         return 2;
+    Shared* shared = (Shared*)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (shared == MAP_FAILED)
+        return 2;
+    memset(shared, 0, sizeof(Shared));
     // pipes: child r -> parent (only rank 0 uses it), parent -> child r
     std::vector<int> to_parent(2 * ranks), to_child(2 * ranks);
     for (int r = 0; r < ranks; r++)
@@ -170,7 +304,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, to_child[2 * r], to_parent[2 * r + 1]));
+            _exit(run_rank(r, ranks, n, frames, mode, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];
@@ -184,5 +318,42 @@ int main(int argc, char** argv)
         if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
             failed++;
     }
-    return failed ? 1 : 0;
+    // every rank received the same rows, and row r is rank r's own list (its leading part where the row was cut)
+    int mismatches = 0, exact_frames = 0, cut_rows = 0, cut_reports = 0;
+    uint64_t gathered_last = 0, link_words = 0, list_words = 0;
+    for (int f = 0; f < frames && !failed; f++) {
+        for (int r = 0; r < ranks; r++) {
+            const FrameSummary& mine = shared->frames[r][f];
+            if (!mine.valid) {
+                mismatches++;
+                continue;
+            }
+            for (int q = 0; q < ranks; q++) {
+                const RowSummary& got = mine.rows[q];
+                const RowSummary& want = shared->frames[q][f].own;
+                if (memcmp(&got, &want, sizeof(RowSummary)) != 0) {
+                    fprintf(stderr, "frame %d: rank %d holds row %d as (count %llu, delivered %llu), rank %d's own list is (count %llu, delivered %llu)%s\n",
+                            f, r, q, (unsigned long long)got.count, (unsigned long long)got.delivered, q, (unsigned long long)want.count,
+                            (unsigned long long)want.delivered, got.count == want.count && got.delivered == want.delivered ? ": contents differ" : "");
+                    mismatches++;
+                }
+            }
+        }
+        const FrameSummary& f0 = shared->frames[0][f];
+        exact_frames += f0.exact ? 1 : 0;
+        cut_reports += f0.cut_seen ? 1 : 0;
+        gathered_last = 0;
+        for (int q = 0; q < ranks; q++) {
+            cut_rows += f0.rows[q].count > f0.rows[q].delivered ? 1 : 0;
+            gathered_last += f0.rows[q].delivered;
+            link_words += f0.travelled[q];
+            list_words += 1 + f0.rows[q].count;
+        }
+    }
+    const bool ok = !failed && !mismatches;
+    printf("{\"ranks\": %d, \"frames\": %d, \"entities_per_rank\": %u, \"ok\": %s, \"failed_ranks\": %d, \"mismatches\": %d, \"exact_frames\": %d, "
+           "\"cut_rows\": %d, \"frames_reporting_a_cut\": %d, \"gathered_last_frame\": %llu, \"words_on_links_over_list_words\": %.3f}\n",
+           ranks, frames, n, ok ? "true" : "false", failed, mismatches, exact_frames, cut_rows, cut_reports, (unsigned long long)gathered_last,
+           list_words ? (double)link_words / (double)list_words : 0.0);
+    return ok ? 0 : 1;
 }

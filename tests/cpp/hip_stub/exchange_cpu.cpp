@@ -1,0 +1,41 @@
+// TEST-ONLY (see hip/hip_runtime.h): host stand-ins for the three launch functions the exchange step's HOST half depends on
+// for its decisions — the shard copy and the row headers that size later frames (garden_amd/csrc/gv_exchange.cpp) — so that
+// gv_exchange_visible / gv_exchange_shards run for real under the sanitizers with several ranks (threads) over
+// tests/cpp/rccl_stub. "Device" memory is host memory here. Never linked into the product library.
+#include <algorithm>
+#include <atomic>
+
+#include "gv_kernels.hpp"
+
+namespace gv {
+
+hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                           const uint32_t* map, hipStream_t)
+{
+    const uint32_t n = std::min(*count, capacity);
+    for (uint32_t i = 0; i < n; i++)
+        dst[i] = (map ? map[src[i]] : src[i]) + base;
+    return hipSuccess;
+}
+
+hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
+                             const uint32_t* map, hipStream_t)
+{
+    const uint32_t total = *count, n = std::min(total, capacity);
+    dst[0] = total;
+    for (uint32_t i = 0; i < n; i++)
+        dst[1 + i] = (map ? map[src[i]] : src[i]) + base;
+    return hipSuccess;
+}
+
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+                                   hipStream_t)
+{
+    for (uint32_t r = 0; r < world; r++)
+        host_words[r] = rows[(size_t)r * row_words];
+    std::atomic_thread_fence(std::memory_order_release);
+    host_words[world] = seq;
+    return hipSuccess;
+}
+
+}  // namespace gv

@@ -14,7 +14,7 @@ typedef int hipError_t;
 enum : int { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
 typedef struct HipStubStream* hipStream_t;
 typedef struct HipStubEvent* hipEvent_t;
-enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum : unsigned { hipHostMallocDefault = 0, hipHostRegisterDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
 struct float2 { float x, y; };
@@ -46,6 +46,7 @@ static inline hipError_t hipHostRegister(void* p, size_t n, unsigned)
 static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memmove(dst, src, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) { if (n) std::memmove(dst, src, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { if (n) std::memset(dst, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* dst, int v, size_t n) { if (n) std::memset(dst, v, n); return hipSuccess; }
 typedef void* hipDeviceptr_t;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/garden_vis.h"
@@ -495,6 +496,165 @@ static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
     gv_destroy(ctx);
 }
 
+// ---- the exchange step with several ranks: one context per thread over tests/cpp/rccl_stub (GV_RCCL_LIBRARY) ----
+// Kernels are no-ops here, so every rank WRITES the list it wants to exchange into its view's result buffers ("device" memory
+// is host memory in this build): rank r's list in frame f has count(r, f) entries value(r, f, k). Lists creep, jump (rows get
+// cut, the library reports it two frames later and re-sizes from an exact count exchange) and collapse (room is given back);
+// every rank checks every row of every frame against those formulas, under all three travel patterns.
+static uint32_t list_count(int rank, int frame, uint32_t n)
+{
+    const uint32_t base = 200u + 150u * (uint32_t)rank;
+    if (frame >= 14)
+        return base / 8u;                                       // collapse: room is given back
+    if (frame >= 7)
+        return std::min(n, base * 9u + 37u * (uint32_t)frame);  // jump: every rank's list outgrows its room
+    return base + 11u * (uint32_t)frame * (uint32_t)(rank + 1);  // creep
+}
+static uint32_t list_value(int rank, int frame, uint32_t k) { return (uint32_t)rank * 1000003u + (uint32_t)frame * 7919u + k; }
+
+static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, int* failures)
+{
+    auto fail = [&](const char* what, int frame, int row) {
+        std::fprintf(stderr, "exchange rank %d frame %d row %d: %s\n", rank, frame, row, what);
+        ++*failures;
+    };
+    World w;
+    w.rng.seed(777u + (uint32_t)rank);
+    const uint32_t n = 6000;
+    w.build(n, 0);
+    GvConfig config{};
+    config.struct_size = sizeof(config);
+    GvCtx* ctx = nullptr;
+    if (gv_create(&config, &ctx) != GV_OK) {
+        fail("gv_create", -1, -1);
+        return;
+    }
+    bind_all(ctx, w);
+    CHECK(gv_exchange_init(ctx, id, rank, ranks));
+    GvView v = make_view(-1, 0, 1);
+    uint32_t room_seen[GV_EXCHANGE_MAX_RANKS] = {};
+    int cut_reports = 0, exact_frames = 0;
+    for (int frame = 0; frame < 20; frame++) {
+        const uint32_t mode = (uint32_t)(frame % 3);
+        CHECK(gv_exchange_set_mode(ctx, mode));
+        CHECK(gv_cull(ctx, 0, &v, 1));
+        GvDeviceResult dr{};
+        CHECK(gv_results_device(ctx, 0, &dr));
+        const uint32_t mine = list_count(rank, frame, n);
+        *(uint32_t*)dr.draw_count = mine;
+        for (uint32_t k = 0; k < mine; k++)
+            ((uint32_t*)dr.visible_idx)[k] = list_value(rank, frame, k);
+        GvExchangeFrame xf;
+        CHECK(gv_exchange_visible(ctx, 0, 0, frame == 17 ? GV_EXCHANGE_EXACT : 0, &xf));
+        if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode)
+            fail("frame fields", frame, -1);
+        exact_frames += xf.exact ? 1 : 0;
+        cut_reports += xf.cut_ranks ? 1 : 0;
+        if (xf.counts_frame != UINT64_MAX) {
+            if (xf.counts_frame + 2 < (uint64_t)frame || xf.counts_frame >= (uint64_t)frame)
+                fail("counts_frame is not one of the last two frames", frame, -1);
+            for (int r = 0; r < ranks; r++) {
+                if (xf.counts[r] != list_count(r, (int)xf.counts_frame, n))
+                    fail("retired counts", frame, r);
+            }
+        } else if (frame >= 2) {
+            fail("no retired frame by frame 2", frame, -1);
+        }
+        const uint32_t* rows = (const uint32_t*)xf.gathered_device;
+        for (int r = 0; r < ranks; r++) {
+            const uint32_t* row = rows + (size_t)r * xf.row_words;
+            const uint32_t count = list_count(r, frame, n), room = xf.room[r];
+            if (xf.travelled_words[r] != (mode == GV_EXCHANGE_ALLGATHER ? xf.row_words : room + 1) || room + 1 > xf.row_words)
+                fail("travelled words", frame, r);
+            if (row[0] != count)
+                fail("header", frame, r);
+            for (uint32_t k = 0; k < std::min(count, room); k++)  // (what a row holds beyond its rank's room is not defined)
+                if (row[1 + k] != list_value(r, frame, k)) {
+                    fail("entry", frame, r);
+                    break;
+                }
+            if (xf.exact && count > room)
+                fail("an exactly sized row is cut", frame, r);
+            room_seen[r] = room;
+        }
+        if (frame % 5 == 4) {  // the blocking query: this frame's own headers
+            uint32_t counts[GV_EXCHANGE_MAX_RANKS];
+            uint64_t cut = 0;
+            CHECK(gv_exchange_counts(ctx, (uint64_t)frame, counts, &cut));
+            for (int r = 0; r < ranks; r++)
+                if (counts[r] != list_count(r, frame, n))
+                    fail("gv_exchange_counts", frame, r);
+        }
+    }
+    if (exact_frames < 3)  // frame 0, the frame after the jump was noticed, frame 17 (asked for)
+        fail("too few exactly sized frames", exact_frames, -1);
+    if (cut_reports < 1)
+        fail("the jump was never reported as a cut", -1, -1);
+    // caller-sized form: per-rank capacities
+    {
+        const uint32_t capacity = n;
+        std::vector<uint32_t> rows((size_t)ranks * (capacity + 1), 0xDEADBEEFu);
+        uint32_t caps[GV_EXCHANGE_MAX_RANKS];
+        for (int r = 0; r < ranks; r++)
+            caps[r] = 100u + 40u * (uint32_t)r;
+        for (uint32_t mode = 0; mode < 3; mode++) {
+            CHECK(gv_exchange_set_mode(ctx, mode));
+            CHECK(gv_cull(ctx, 0, &v, 1));
+            GvDeviceResult dr{};
+            CHECK(gv_results_device(ctx, 0, &dr));
+            const uint32_t mine = 120u + 30u * (uint32_t)rank;
+            *(uint32_t*)dr.draw_count = mine;
+            for (uint32_t k = 0; k < mine; k++)
+                ((uint32_t*)dr.visible_idx)[k] = list_value(rank, 99, k);
+            CHECK(gv_exchange_shards(ctx, 0, capacity, caps, 5, rows.data()));
+            for (int r = 0; r < ranks; r++) {
+                const uint32_t* row = rows.data() + (size_t)r * (capacity + 1);
+                const uint32_t count = 120u + 30u * (uint32_t)r;
+                if (row[0] != count)
+                    fail("shards header", (int)mode, r);
+                for (uint32_t k = 0; k < std::min(count, caps[r]); k++)
+                    if (row[1 + k] != list_value(r, 99, k) + 5u) {
+                        fail("shards entry", (int)mode, r);
+                        break;
+                    }
+            }
+        }
+        caps[0] = capacity + 1;
+        EXPECT(gv_exchange_shards(ctx, 0, capacity, caps, 0, rows.data()), GV_E_ARG);
+    }
+    GvExchangeFrame none;
+    EXPECT(gv_exchange_visible(ctx, 0, 0, 0x80, &none), GV_E_ARG);
+    CHECK(gv_exchange_shutdown(ctx));
+    EXPECT(gv_exchange_visible(ctx, 0, 0, 0, &none), GV_E_STATE);
+    gv_destroy(ctx);
+    (void)room_seen;
+}
+
+static void exchange_in_threads(int ranks)
+{
+    if (!std::getenv("GV_RCCL_LIBRARY")) {
+        std::printf("exchange over the stub transport: skipped (GV_RCCL_LIBRARY not set)\n");
+        return;
+    }
+    unsigned char id[GV_EXCHANGE_ID_BYTES];
+    if (gv_exchange_unique_id(id) != GV_OK) {
+        std::fprintf(stderr, "gv_exchange_unique_id failed\n");
+        std::exit(1);
+    }
+    std::vector<int> failures(ranks, 0);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < ranks; r++)
+        threads.emplace_back(exchange_rank_thread, r, ranks, id, &failures[r]);
+    for (auto& t : threads)
+        t.join();
+    for (int r = 0; r < ranks; r++)
+        if (failures[r]) {
+            std::fprintf(stderr, "exchange with %d ranks: rank %d reported %d failures\n", ranks, r, failures[r]);
+            std::exit(1);
+        }
+    std::printf("exchange over the stub transport, %d ranks: ok\n", ranks);
+}
+
 int main()
 {
     // spatially ordered mirror (default), pool-slot order, forced block bounds, linear scan; flat and 4-deep
@@ -503,6 +663,8 @@ int main()
     exercise(GV_CONFIG_BLOCK_BOUNDS | GV_CONFIG_PROFILE_EVENTS, 30000, 2);
     exercise(GV_CONFIG_BLOCK_BOUNDS, 20000, 0);  // flat + exactly paired: block bounds / emit seeds patched per dirty block (mark_dirty_blocks)
     exercise(GV_CONFIG_LINEAR_SCAN | GV_CONFIG_HIZ_RG16F | GV_CONFIG_KEEP_SLOT_ORDER, 300000, 3);  // (above the device-gather and auto-bounds sizes)
+    for (int ranks : {1, 2, 3, 8})
+        exchange_in_threads(ranks);
     std::printf("host orchestration: ok\n");
     return 0;
 }

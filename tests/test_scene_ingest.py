@@ -439,6 +439,43 @@ def test_native_tile_extraction_equals_partition_world(grid):
     whole.close()
 
 
+@pytest.mark.parametrize("grid,world", [((4, 4, 4), 8), ((8, 8, 8), 8), ((4, 2, 2), 3), ((2, 2, 2), 1)])
+def test_native_rank_extraction_equals_partition_world_with_ranks(grid, world):
+    """gv_scene_extract_rank — many cells per rank, the grid's cells in Morton order dealt round-robin — against
+    partition_world(..., ranks=world) on the same scene: the slot tables, the renumbered ids and parents, every mesh column;
+    every slot lands on exactly one rank (how even the shares are: test_host_logic.py)."""
+    from garden_amd.multi import partition_world
+    src = scene.hierarchy_scene(6000, depth=3, fanout=4)
+    src = scene.shuffled_scene(src, fraction=0.4)
+    text = sj.write_scene(src.transforms, {"Model": src.meshes}, src.entity_to_transform)
+    whole = Scene(text, {"Model": 0})
+    aos = _scene_as_aos(whole)
+    side = 100.0 * 6000 ** (1.0 / 3.0)
+    part = partition_world(aos, grid, side=side, ranks=world)
+    assert len(part.tiles) == world
+    seen_t, seen_m = [], []
+    for r in range(world):
+        tile = whole.extract_rank(grid, side, r, world)
+        exp = part.tiles[r]
+        tg, mg = tile.tile_maps(0)
+        assert np.array_equal(tg.astype(np.int64), part.transform_global[r]) and np.array_equal(mg.astype(np.int64), part.mesh_global[r])
+        c = tile.transform_columns()
+        assert np.array_equal(c["entity"], exp.transforms["entity"]) and np.array_equal(c["parent"], exp.transforms["parent"])
+        assert np.array_equal(c["entity_to_transform"], exp.entity_to_transform)
+        assert np.array_equal(c["position"].view(np.uint32), np.ascontiguousarray(exp.transforms["position"][:, :3]).view(np.uint32))
+        m = tile.mesh_columns(0)
+        assert np.array_equal(m["entity"], exp.meshes["entity"]) and np.array_equal(m["is_enabled"], exp.meshes["isEnabled"])
+        assert np.array_equal(m["aabb_max"].view(np.uint32), np.ascontiguousarray(exp.meshes["aabbMax"][:, :3]).view(np.uint32))
+        seen_t.append(tg)
+        seen_m.append(mg)
+        tile.close()
+    assert sorted(np.concatenate(seen_t).tolist()) == list(range(aos.transforms.shape[0]))
+    assert sorted(np.concatenate(seen_m).tolist()) == list(range(aos.count))
+    with pytest.raises(GvError):
+        whole.extract_rank(grid, side, world, world)  # no such rank
+    whole.close()
+
+
 def test_tile_extraction_of_positions_no_cell_can_hold():
     """Root positions that are +-inf (1e300 in the file), huge but finite, or far outside the world cube: the native extraction
     puts them where partition_world's numpy arithmetic puts them (astype(int64) of a value outside the int64 range is INT64_MIN
