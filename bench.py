@@ -284,6 +284,10 @@ def main():
                     choices=["allgather", "p2p", "broadcast"],
                     help="N > 1: how the padded shards travel — one equal-size all-gather (default), grouped point-to-point "
                          "send/recv to every peer, or one broadcast per root (A/B for the fully connected xGMI node)")
+    ap.add_argument("--exchange-path", default=os.environ.get("GV_BENCH_EXCHANGE_PATH", "c-abi"), choices=["c-abi", "torch"],
+                    help="N > 1: who runs the exchange — the library's own C-ABI step (default: gv_exchange_init / gv_exchange_visible, "
+                         "RCCL bound by the library, rows owned and sized by it: what a C++ engine calls), or torch.distributed over "
+                         "buffers this script owns (garden_amd/multi.py; timed beside the headline as config.torch_variant)")
     ap.add_argument("--payload", default=os.environ.get("GV_BENCH_EXCHANGE_PAYLOAD", "indices"), choices=["auto", "indices", "mask"],
                     help="N > 1: what a shard carries — the compacted uint32 index list (default: the all-gatherv of the visible list "
                          "BASELINE.json names), or one bit per mirror entry behind the count (1/32 word per entry whatever the view: ~7x "
@@ -292,6 +296,8 @@ def main():
                          "form has been checked against the exact all-gatherv on every rank. The gathered sets of the timed frames are "
                          "checked against the exact all-gatherv either way")
     ap.add_argument("--no-mask-variant", action="store_true", help="N > 1: skip the bit-shard frames timed beside the index lists")
+    ap.add_argument("--no-mode-variants", action="store_true", help="N > 1, c-abi path: skip the frames timed with the other travel patterns")
+    ap.add_argument("--no-torch-variant", action="store_true", help="N > 1, c-abi path: skip the frames timed through torch.distributed")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): the workload's entity count PER GPU; strong: --entities-total cut into N spatial tiles")
     ap.add_argument("--entities-total", type=int, default=100_000_000, help="--scaling strong: entities of the whole world")
@@ -405,11 +411,30 @@ def main():
             vis.sweep({"mfma": GV_SWEEP_MFMA, "valu": GV_SWEEP_VALU, "fused": GV_SWEEP_WITH_CULL, "fused-valu": GV_SWEEP_WITH_CULL_VALU}[args.sweep])
         vis.cull(0, view_array)
 
+    native = [False]       # the exchange runs through the library's own C-ABI step (gv_exchange_visible / gv_exchange_masks)
+    native_rows = [None]   # caller-owned rows [world, 1 + words] of the native bit-shard exchange
+    EXCHANGE_MODES = {"allgather": 0, "p2p": 1, "broadcast": 2}
+
+    def device_words(ptr, count):
+        """int32 view (no copy) of `count` words of library-owned device memory at `ptr`."""
+        class _Span:
+            pass
+        span = _Span()
+        span.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(span, device=f"cuda:{local_rank}")
+
     def step():
-        """One frame. With an exchange: the tile's list goes out as a fixed-capacity shard [count, indices...] and all
-        ranks gather the shards (one equal-size all-gather, or the --exchange alternative) enqueued behind the library's
-        stream — no host synchronisation, so the next frame is culled while this one's list is still on the links."""
+        """One frame. With an exchange: the rank's list goes out as a shard [count, indices...] and all ranks gather the shards
+        (one equal-size all-gather, or the --exchange alternative) enqueued behind the library's stream — no host
+        synchronisation, so the next frame is culled while this one's list is still on the links. --exchange-path c-abi (default):
+        the library's own step — it owns the rows and sizes every rank's from the headers of earlier frames; torch: this script's
+        buffers and torch.distributed (garden_amd/multi.py)."""
         compute()
+        if native[0]:
+            if args.payload == "mask":
+                vis.exchange_masks(0, mask_words(n), native_rows[0].data_ptr())
+                return native_rows[0]
+            return vis.exchange_visible(0, index_base=rank * n)
         if ex[0] is not None:
             shard = ex[0].next_shard()
             if args.payload == "mask":
@@ -444,8 +469,24 @@ def main():
         return g, c, problem
 
     def check_padded(padded, exact, exact_counts):
-        """The per-frame padded exchange delivered the same lists as the exact one (static scene)."""
-        ex[0].drain()  # raises if any frame of the run overflowed its shard
+        """The per-frame exchange delivered the same lists as the exact one (static scene)."""
+        if isinstance(padded, dict):  # a frame of gv_exchange_visible: library-owned rows, counts through the blocking query
+            counts, cut = vis.exchange_counts(padded["frame"], world)
+            if cut:
+                return f"c-abi exchange: rows of ranks {cut} were cut (room {padded['room']}, counts {counts})"
+            if not np.array_equal(np.asarray(counts, dtype=np.int64), exact_counts):
+                return "c-abi exchange: counts differ from the exact all-gatherv"
+            torch.cuda.synchronize()
+            rows = device_words(padded["ptr"], world * padded["row_words"]).view(world, padded["row_words"]).cpu().numpy().view(np.uint32)
+            off = 0
+            for r in range(world):
+                c = int(exact_counts[r])
+                if int(rows[r, 0]) != c or not np.array_equal(rows[r, 1:1 + c].astype(np.int64), exact[off:off + c]):
+                    return f"c-abi exchange: rank {r}'s row differs from the exact all-gatherv"
+                off += c
+            return None
+        if not native[0]:
+            ex[0].drain()  # raises if any frame of the run overflowed its shard
         if args.payload == "mask":  # bits per mirror entry: the same SETS per rank (a mask has no order)
             torch.cuda.synchronize()
             d, counts = expand_mask_rows(padded, n, entry_tables=entry_tables[0])
@@ -502,33 +543,63 @@ def main():
         gathered_total = int(exact_counts.sum())
         producer = lib_stream if backend == "nccl" else None
 
+        def share_entry_tables():
+            """Once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit shards
+            needs to name the entities; the static scene never rebuilds its mirror)."""
+            if tables_ready[0]:
+                return
+            mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
+            tables = [torch.empty_like(mine) for _ in range(world)]
+            if backend == "nccl":
+                dev_tables = [t.to(f"cuda:{local_rank}") for t in tables]
+                dist.all_gather(dev_tables, mine.to(f"cuda:{local_rank}"))
+                tables = [t.cpu() for t in dev_tables]
+            else:
+                dist.all_gather(tables, mine)
+            entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
+            tables_ready[0] = True
+
         def make_exchange(payload):
-            """The frame loop's exchange object for `payload` (and, for bit shards, every rank's entry -> slot table)."""
+            """The frame loop's exchange for `payload`: the torch object (and, for bit shards, every rank's entry -> slot table), or
+            with the C-ABI path the rows a bit-shard exchange writes (index lists: the library owns the rows). Returns the torch
+            object or None."""
             args.payload = payload
-            if payload == "mask" and not tables_ready[0]:
-                # once per mirror build: every rank learns every rank's entry -> pool-slot table (what a consumer of the bit
-                # shards needs to name the entities; the static scene never rebuilds its mirror)
-                mine = torch.from_numpy(vis.mirror_slots(0, n).astype(np.int32))
-                tables = [torch.empty_like(mine) for _ in range(world)]
-                if backend == "nccl":
-                    dev_tables = [t.to(f"cuda:{local_rank}") for t in tables]
-                    dist.all_gather(dev_tables, mine.to(f"cuda:{local_rank}"))
-                    tables = [t.cpu() for t in dev_tables]
-                else:
-                    dist.all_gather(tables, mine)
-                entry_tables[0] = [t.numpy().view(np.uint32) for t in tables]
-                tables_ready[0] = True
+            if payload == "mask":
+                share_entry_tables()
+            if native[0]:
+                if payload == "mask":
+                    native_rows[0] = torch.zeros(world, 1 + mask_words(n), dtype=torch.int32, device=f"cuda:{local_rank}")
+                return None
             capacity = mask_words(n) if payload == "mask" else shard_capacity(int(exact_counts.max()))
             # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
             per_rank = ([shard_capacity(int(c)) for c in exact_counts] if payload == "indices" and args.exchange != "allgather" else None)
             return VisibleListExchange(dist, f"cuda:{local_rank}", capacity, stream=producer, mode=args.exchange, payload=payload,
                                        capacities=per_rank)
 
-        def shard_words_per_rank(x):
+        def shard_words_per_rank(x, frame=None):
             """uint32 words rank r's shard puts on each link per frame (header included) under the exchange's pattern."""
+            if isinstance(frame, dict):
+                return list(frame["travelled_words"])
+            if x is None:  # native bit shards
+                return [1 + mask_words(n)] * world
             if x.capacities is not None and x.mode != "allgather":
                 return [1 + c for c in x.capacities]
             return [1 + x.capacity] * world
+
+        transport_note = None
+        if args.exchange_path == "c-abi":
+            # the product's own exchange step: RCCL bound by the library, unique id handed round by the process group
+            if backend != "nccl" and "GV_RCCL_LIBRARY" not in os.environ:
+                # N ranks on one GPU (GV_BENCH_BACKEND=gloo): RCCL refuses that; the rows travel through the tests' shared-memory
+                # transport — a functional run of the product's exchange logic, never a measurement
+                os.environ["GV_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
+            if os.environ.get("GV_RCCL_LIBRARY"):
+                transport_note = "GV_RCCL_LIBRARY=" + os.environ["GV_RCCL_LIBRARY"]
+            ids = [GpuVisibility.exchange_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            vis.exchange_init(ids[0], rank, world)
+            vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
+            native[0] = True
 
         payload_note = None
         if args.payload == "auto":
@@ -605,7 +676,8 @@ def main():
     # With an exchange: the same frames WITHOUT it (same ranks, same run) = what one GPU does with one tile of this workload
     # (`n1_same_workload`), and so what the collective costs and what the scaling efficiency is; one ISOLATED exchange (nothing
     # overlapped: shard copy + collective + completion, host clock); and the other shard encoding timed the same way.
-    no_exchange = exchange_ms = mask_variant = None
+    no_exchange = exchange_ms = mask_variant = torch_variant = mode_variants = None
+    timed_native, timed_frame = native[0], (last if isinstance(last, dict) else None)
     if exchange:
         for _ in range(3):
             compute()
@@ -620,37 +692,67 @@ def main():
             compute()
             fence()
             t0 = time.perf_counter()
-            shard = ex[0].next_shard()
-            if args.payload == "mask":
-                vis.copy_mask_device(0, shard.data_ptr(), ex[0].capacity)
+            if native[0]:
+                if args.payload == "mask":
+                    vis.exchange_masks(0, mask_words(n), native_rows[0].data_ptr())
+                else:
+                    vis.exchange_visible(0, index_base=rank * n)
             else:
-                vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
-            ex[0].exchange()
-            ex[0].drain()
+                shard = ex[0].next_shard()
+                if args.payload == "mask":
+                    vis.copy_mask_device(0, shard.data_ptr(), ex[0].capacity)
+                else:
+                    vis.copy_shard_device(0, shard.data_ptr(), ex[0].capacity, index_base=rank * n)
+                ex[0].exchange()
+                ex[0].drain()
             vis.wait()
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
         exchange_ms = max_over_ranks(float(np.median(lat)) * 1e3)
-        if timed_payload == "indices" and not args.no_mask_variant:
-            mv_problem = None
+
+        def timed_variant(describe):
+            """args.steps frames of step() as currently configured, checked against the exact all-gatherv; a failing variant is
+            reported, it does not take the headline with it."""
+            problem, out = None, None
             try:
-                ex[0] = make_exchange("mask")
                 for _ in range(3):
                     step()
-                e3, per3, last3 = timed_steps(step, args.steps, mark_group)
-                mv_problem = check_padded(last3, exact, exact_counts)
+                e3, _, last3 = timed_steps(step, args.steps, mark_group)
+                problem = check_padded(last3, exact, exact_counts)
                 e3 = max_over_ranks(e3)
-                mask_variant = dict(ms_per_step=e3 / args.steps * 1e3, value=n * world * args.steps / e3,
-                                    shard_bytes_per_rank=[4 * w for w in shard_words_per_rank(ex[0])],
-                                    delivers="every rank holds every rank's [count, one bit per mirror entry]; the entry -> pool slot "
-                                             "tables travelled once at set-up (a consumer that wants the index list expands the rows)",
-                                    checked_against_exact_allgatherv=mv_problem is None)
-            except Exception as e:  # noqa: BLE001 — a failing variant is reported, it does not take the headline with it
-                mv_problem = f"{type(e).__name__}: {e}"
-            ok = all_agree(mv_problem is None)
-            if not ok:
-                mask_variant = dict(error=mv_problem or "failed on another rank")
+                out = dict(ms_per_step=e3 / args.steps * 1e3, value=n * world * args.steps / e3,
+                           shard_bytes_per_rank=[4 * w for w in shard_words_per_rank(ex[0], last3)],
+                           checked_against_exact_allgatherv=problem is None, **describe)
+            except Exception as e:  # noqa: BLE001
+                problem = f"{type(e).__name__}: {e}"
+            if not all_agree(problem is None):
+                out = dict(error=problem or "failed on another rank", **describe)
+            return out
+
+        if timed_payload == "indices" and not args.no_mask_variant:
+            ex[0] = make_exchange("mask")
+            mask_variant = timed_variant(dict(
+                delivers="every rank holds every rank's [count, one bit per mirror entry]; the entry -> pool slot tables travelled "
+                         "once at set-up (a consumer that wants the index list expands the rows)",
+                exchange_path="c-abi (gv_exchange_masks)" if native[0] else "torch.distributed"))
             args.payload, ex[0] = timed_payload, timed_exchange
+        if timed_native and timed_payload == "indices" and world > 1 and not args.no_mode_variants:
+            # the same frames with the rows travelling by the other patterns (A/B for the fully connected xGMI node) ...
+            mode_variants = {}
+            for mode in ("allgather", "p2p", "broadcast"):
+                if mode == args.exchange:
+                    continue
+                vis.exchange_set_mode(EXCHANGE_MODES[mode])
+                mode_variants[mode] = timed_variant(dict(exchange_path="c-abi (gv_exchange_visible)"))
+            vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
+        if timed_native and timed_payload == "indices" and not args.no_torch_variant:
+            # ... and through torch.distributed over this script's own buffers (what round 3 timed as the headline)
+            native[0] = False
+            ex[0] = make_exchange("indices")
+            torch_variant = timed_variant(dict(exchange_path="torch.distributed (garden_amd/multi.py::VisibleListExchange)",
+                                               capacity_words=ex[0].capacity))
+            ex[0].drain()
+            native[0], ex[0] = True, timed_exchange
 
     # SURVEY.md §8d: also report the rate when every TRS is re-uploaded each frame (host AoS -> mirror gather + PCIe
     # + cull). Outside the timed region; never `value`.
@@ -854,10 +956,20 @@ def main():
                        "scaling_mode": (f"strong: one world of {n * world} entities cut into {world} spatial tile(s)" if args.scaling == "strong"
                                         else f"weak: {n} entities per GPU"),
                        "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,
-                       "exchange": (f"per frame: " + ("shards [count, one bit per mirror entry] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
-                                    f"(capacity {ex[0].capacity} words) travel by "
-                                    f"{ex[0].describe()} behind the cull stream, no host sync ({backend}); "
-                                    f"{gathered_total} indices gathered per rank; checked against the exact all-gatherv") if exchange else None,
+                       "exchange": ((f"per frame, through the library's C-ABI (gv_exchange_visible): shard [count, uint32 indices...] of every rank "
+                                     f"into library-owned rows (row stride {timed_frame['row_words']} words; room per rank {timed_frame['room']}, sized from the "
+                                     f"headers of earlier frames, which reach the host through pinned memory) by {args.exchange} behind the cull "
+                                     f"stream, no host sync; RCCL bound by the library"
+                                     + (f" [{transport_note}: N ranks share a GPU, functional only]" if transport_note else "") +
+                                     f"; {gathered_total} indices gathered per rank; checked against the exact all-gatherv")
+                                    if timed_frame else
+                                    (f"per frame: " + ("shards [count, one bit per mirror entry] " if args.payload == "mask" else "padded shards [count, uint32 indices...] ") +
+                                     (f"(capacity {ex[0].capacity} words) travel by {ex[0].describe()} behind the cull stream, no host sync ({backend})"
+                                      if ex[0] is not None else f"({mask_words(n)} words) through the library's C-ABI (gv_exchange_masks) by {args.exchange}") +
+                                     f"; {gathered_total} indices gathered per rank; checked against the exact all-gatherv")) if exchange else None,
+                       # who runs the timed exchange: the product's own C-ABI step, or torch.distributed over this script's buffers
+                       "exchange_path": (("c-abi" if timed_native else "torch") if exchange else None),
+                       "exchange_transport": ((transport_note or "RCCL (dlopen'ed by the library)") if exchange and timed_native else ("torch.distributed " + backend if exchange else None)),
                        "exchange_mode": args.exchange if exchange else None,
                        "exchange_payload": (args.payload + (f" ({payload_note})" if payload_note else "")) if exchange else None,
                        "same_frames_without_exchange": no_exchange,
@@ -866,9 +978,14 @@ def main():
                        # what the exchange adds to a frame when it runs behind the next frame's cull (two slots in flight)
                        "exchange_overhead_ms_per_step": (elapsed / args.steps * 1e3 - no_exchange["ms_per_step"]) if no_exchange else None,
                        # bytes rank r's shard puts on each link per frame as it travels (padding included) / of those, list entries
-                       "shard_bytes_per_rank": [4 * w for w in shard_words_per_rank(ex[0])] if exchange else None,
+                       "shard_bytes_per_rank": [4 * w for w in shard_words_per_rank(ex[0], timed_frame)] if exchange else None,
                        "list_bytes_per_rank": ([4 * (1 + int(c)) for c in exact_counts] if exchange else None),
-                       "gathered_bytes_per_rank": (4 * sum(shard_words_per_rank(ex[0]))) if exchange else None,
+                       "gathered_bytes_per_rank": (4 * sum(shard_words_per_rank(ex[0], timed_frame))) if exchange else None,
+                       "gathered_over_list_bytes": ((sum(shard_words_per_rank(ex[0], timed_frame)) / float(sum(1 + int(c) for c in exact_counts)))
+                                                    if exchange and timed_payload == "indices" else None),
+                       "visible_max_over_mean_by_rank": (float(exact_counts.max() / max(1.0, exact_counts.mean())) if exchange else None),
+                       # the same frames by the other travel patterns / through torch.distributed (same run, each checked)
+                       "exchange_mode_variants": mode_variants, "torch_variant": torch_variant,
                        "mask_variant": mask_variant,
                        # per frame, in the TIMED region: only the bracketed kernels appear (default: the dominant one; --profile-all: all)
                        "kernel_ms": {k: (st["device_ms"][k] * (st["launches"][k] / max(1, timed[k])) / max(1, args.steps))

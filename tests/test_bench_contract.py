@@ -56,6 +56,12 @@ def test_bench_gpus_2_starts_its_own_ranks(mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("cfg5") and d["config"]["entities_total"] == 600000
     assert d["config"]["exchange"] is not None and d["config"]["exchange_mode"] == mode
+    # the timed exchange is the library's own C-ABI step (here over the shared-memory transport: two ranks share the GPU);
+    # the torch.distributed form and the other travel patterns are timed beside it, each checked against the exact lists
+    assert d["config"]["exchange_path"] == "c-abi" and "GV_RCCL_LIBRARY" in d["config"]["exchange_transport"]
+    assert d["config"]["torch_variant"]["checked_against_exact_allgatherv"] and d["config"]["torch_variant"]["ms_per_step"] > 0
+    assert set(d["config"]["exchange_mode_variants"]) == {"allgather", "p2p", "broadcast"} - {mode}
+    assert all(v["checked_against_exact_allgatherv"] for v in d["config"]["exchange_mode_variants"].values())
     assert d["parity"]["visible_set_bit_identical"] and d["parity"]["baked_model_bit_identical"]
     assert d["config"]["same_frames_without_exchange"]["value"] > 0
     # the compacted index list is what travels by default (BASELINE.json's north_star); the bit shards are a timed variant
@@ -82,7 +88,13 @@ def test_bench_gpus_8_every_field_of_the_scaling_line():
     d = _run_bench(["--gpus", "8", "--entities", "200000", "--steps", "4", "--warmup", "1"], {"GV_BENCH_BACKEND": "gloo"})
     c = d["config"]
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and c["workload"].startswith("cfg5") and c["entities_total"] == 1_600_000
-    assert c["exchange_payload"] == "indices" and c["exchange_mode"] == "allgather"
+    assert c["exchange_payload"] == "indices" and c["exchange_mode"] == "allgather" and c["exchange_path"] == "c-abi"
+    # every rank owns a share of every region (cells dealt in Morton order): all of them have work, none waits long for another,
+    # and the gather moves little more than the lists ([.., 0, 0, 0, 0], 3.6 x)
+    vis_by_rank = d["parity"]["visible_by_rank"]
+    assert min(vis_by_rank) > 0 and max(vis_by_rank) / (sum(vis_by_rank) / 8.0) <= 1.5 and c["visible_max_over_mean_by_rank"] <= 1.5
+    assert c["gathered_over_list_bytes"] <= 1.3, c["gathered_over_list_bytes"]
+    assert c["torch_variant"]["checked_against_exact_allgatherv"] and len(c["exchange_mode_variants"]) == 2
     assert d["n1_same_workload"]["value"] > 0 and d["n1_same_workload"]["entities"] == 200000
     assert 0 < d["scaling_efficiency"] < 1.5
     assert abs(d["scaling_efficiency"] - d["value"] / (8 * d["n1_same_workload"]["value"])) < 1e-9
@@ -130,4 +142,14 @@ def test_bench_mask_payload(ranks):
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["config"]["exchange_payload"] == "mask" and "one bit per mirror entry" in d["config"]["exchange"]
     assert d["config"]["mask_variant"] is None  # the variant is only timed beside the index lists
+    assert d["config"]["exchange_path"] == "c-abi" and "gv_exchange_masks" in d["config"]["exchange"]
     assert d["parity"]["visible_set_bit_identical"] and "error" not in d
+
+
+@pytest.mark.gpu
+def test_bench_torch_exchange_path_still_runs():
+    """--exchange-path torch: the round-3 form (torch.distributed over the script's buffers) as the timed exchange."""
+    d = _run_bench(["--gpus", "2", "--entities", "200000", "--steps", "3", "--warmup", "1", "--exchange-path", "torch", "--no-mask-variant"],
+                   {"GV_BENCH_BACKEND": "gloo"})
+    assert d["config"]["exchange_path"] == "torch" and d["config"]["torch_variant"] is None and d["config"]["exchange_mode_variants"] is None
+    assert d["parity"]["visible_set_bit_identical"]
