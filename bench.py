@@ -301,6 +301,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): the workload's entity count PER GPU; strong: --entities-total cut into N spatial tiles")
     ap.add_argument("--entities-total", type=int, default=100_000_000, help="--scaling strong: entities of the whole world")
+    ap.add_argument("--depth", default="walls", choices=["walls", "noise"],
+                    help="cfg3 depth image: SURVEY.md §8d's 256 walls (default), or per-8x8-block occluders among the entities "
+                         "(scene.noise_depth: the coarse-level exits of the occlusion query decide almost nothing; timed beside the "
+                         "headline as config.hard_depth_variant when the headline runs on the walls)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -381,7 +385,8 @@ def main():
         n = args.entities_total // world
     sc = make_tile_scene(wl, n, rank, world)
     view = scene.main_camera_view(use_hiz=1 if wl["hiz"] else 0)
-    depth = scene.synthetic_depth(HIZ_SIZE, HIZ_SIZE) if wl["hiz"] else None
+    depth = ((scene.noise_depth(HIZ_SIZE, HIZ_SIZE) if args.depth == "noise" else scene.synthetic_depth(HIZ_SIZE, HIZ_SIZE))
+             if wl["hiz"] else None)
 
     # hipEvents bracket only the dominant kernel inside the timed region (each event record costs ~2 us of
     # stream time); --profile-all brackets every kernel for the per-kernel breakdown in config.kernel_ms
@@ -785,10 +790,96 @@ def main():
             compute()
         s2 = vis.stats()
         frame_kernel_ms = {k: s2["device_ms"][k] / breakdown_frames for k in s2["device_ms"] if s2["device_ms"][k] > 0}
-        if wl["hiz"] and "emit" not in frame_kernel_ms:
-            # an occlusion view's emit is held back and runs as ONE launch with the next frame's first pyramid pass (emit_hiz_kernel)
-            frame_kernel_ms["hiz_includes_previous_frames_emit"] = True
         vis.profile_kernels(["cull"])
+
+    # The frame as an ENGINE runs it: the reference consumes a frame's list in that same frame — prepareMeshes
+    # waits for its tasks and sorts (mesh.cpp:548-553), the render passes draw from the list (:556-600) — before the next frame's
+    # depth exists. (a) the host waits for every frame's list (gv_result_count: a 4-byte read-back behind the frame's work);
+    # (b) a device-side consumer ordered on the library's stream reads every frame's count (no host wait; since round 4 this IS the
+    # headline's schedule: gv_cull enqueues everything a view's results consist of).
+    engine_flow = None
+    if world == 1:
+        flow_frames = max(5, min(args.steps, 100))
+
+        def flow(consume):
+            for _ in range(3):
+                compute()
+                consume()
+            vis.wait()
+            t_flow = time.perf_counter()
+            for _ in range(flow_frames):
+                compute()
+                consume()
+            vis.wait()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_flow) / flow_frames
+
+        host_s = flow(lambda: vis.result_count(0))
+        dres = vis.results_device(0)
+        count_word = device_words(dres.draw_count, 1)
+        total = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}")
+
+        def device_consumer():
+            with torch.cuda.stream(lib_stream):
+                total.add_(count_word)
+
+        dev_s = flow(device_consumer)
+        engine_flow = dict(frames=flow_frames,
+                           host_waits_for_every_list=dict(ms_per_step=host_s * 1e3, value=n / host_s,
+                                                          consumer="gv_result_count after every gv_cull (the host blocks until the frame's list is complete, "
+                                                                   "as MeshRenderSystem::prepareMeshes waits for its tasks, mesh.cpp:548)"),
+                           device_consumer_on_the_stream=dict(ms_per_step=dev_s * 1e3, value=n / dev_s,
+                                                              consumer="a one-word kernel on gv_stream() reads every frame's draw_count through the "
+                                                                       "pointers of gv_results_device (fetched once); no host wait"),
+                           note="`value` is the plain frame loop: the same schedule as device_consumer_on_the_stream minus the consumer's launch")
+
+    # cfg3 on a HARD depth image: per-8x8-block occluders among the entities instead of 256 walls centimetres from
+    # the camera — what the occlusion query costs when its coarse-level exits stop deciding. Own context, same pools and view.
+    hard_depth = None
+    if world == 1 and wl["hiz"] and args.depth == "walls" and not args.block_bounds:
+        hard = scene.noise_depth(HIZ_SIZE, HIZ_SIZE)
+        vh = GpuVisibility(device=local_rank, profile_cull_only=True, linear_scan=True, hiz_rg16f=args.hiz_rg16f)
+        vh.bind_transforms(sc.transforms, sc.entity_to_transform)
+        vh.bind_pool(0, sc.meshes)
+        vh.hierarchy_rebuild()
+        vh.hiz_build(hard)
+
+        def hard_step():
+            vh.hiz_rebuild()
+            vh.cull(0, view_array)
+
+        for _ in range(5):
+            hard_step()
+        vh.wait()
+        vh.stats_reset()
+        vh.profile_sampling(8)
+        frames, t4 = 40, time.perf_counter()
+        for _ in range(frames):
+            hard_step()
+        vh.wait()
+        dt = time.perf_counter() - t4
+        sh, th = vh.stats(), vh.profile_samples()
+        gh = vh.fetch(0, write_back=False, occupancy=n)
+        vh.close()
+        hard_depth = dict(depth="scene.noise_depth: one occluder per 8 x 8 pixel block, distance log-uniform in [50 m, 20 km] (among the entities)",
+                          ms_per_step=dt / frames * 1e3, value=n * frames / dt, cull_kernel_ms=sh["device_ms"]["cull"] / max(1, th["cull"]),
+                          visible_fraction=gh["draw_count"] / n, traffic=None)
+        if not args.no_parity:
+            from oracle import oracle_py as _orc
+            th_threads = max(1, os.cpu_count() or 1)
+            m3 = sc.meshes.copy()
+            eh = _orc.prepare_meshes(m3, sc.transforms, sc.entity_to_transform, view,
+                                     hiz=_orc.Hiz(hard, threads=th_threads, rg16f=args.hiz_rg16f), threads=th_threads)
+            oh = np.argsort(eh["visible_idx"], kind="stable")
+            hard_depth["visible_set_bit_identical"] = bool(np.array_equal(gh["visible_idx"], eh["visible_idx"][oh]) and
+                                                           np.array_equal(gh["is_visible"], m3["isVisible"]))
+            survivors_h = _orc.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, dict(view, use_hiz=0), threads=th_threads)["draw_count"]
+            ab_h = algorithmic_bytes(wl, n, survivors_h, gh["draw_count"], hard)
+            hard_depth["frac"] = ab_h["cull"] / (hard_depth["cull_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if hard_depth["cull_kernel_ms"] > 0 else None
+            hard_depth["algorithmic_bytes_per_launch"] = ab_h["cull"]
+            if not hard_depth["visible_set_bit_identical"]:
+                emit({"error": "cfg3 on the hard depth image: results differ from the CPU oracle", "variant": hard_depth})
+                leave(1)
 
     # correctness gate + algorithmic byte counts
     got = vis.fetch(0, write_back=False, occupancy=n)
@@ -952,7 +1043,8 @@ def main():
                                     f"{args.workload}-strong: ONE world of {n * world} entities cut into {world} spatial tile(s), "
                                     f"{n} per GPU; per tile as {wl['name']}"), "sweep": args.sweep if wl["sweep"] else None,
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
-                       "block_bounds_variant": bounds_variant, "valu_variant": valu_variant, "entities_per_gpu": n, "entities_total": n * world,
+                       "block_bounds_variant": bounds_variant, "valu_variant": valu_variant,
+                       "engine_flow_variant": engine_flow, "hard_depth_variant": hard_depth, "depth": args.depth if wl["hiz"] else None, "entities_per_gpu": n, "entities_total": n * world,
                        "scaling_mode": (f"strong: one world of {n * world} entities cut into {world} spatial tile(s)" if args.scaling == "strong"
                                         else f"weak: {n} entities per GPU"),
                        "visible_fraction": visible / n, "hiz": (f"{HIZ_SIZE}x{HIZ_SIZE}" + (" RG16F" if args.hiz_rg16f else "")) if wl["hiz"] else None,

@@ -337,18 +337,6 @@ struct Context {
     uint32_t tick_turn = 0;
     DeviceBuf<uint8_t> d_tick;
 
-    // ---- an emit held back for the next pyramid build (gv_context.cpp flush_deferred_emit, hiz_reduce) ----
-    struct DeferredEmit {
-        bool pending = false;
-        MeshMirror mesh{};
-        TransformMirror xf{};
-        ViewParams vp{};
-        ViewBuffers out{};
-        uint32_t clear_chunks = 0;
-        const float4* world = nullptr;
-        const EmitSeed* seeds = nullptr;
-    } deferred_emit;
-
     // ---- world-matrix cache (gv_sweep) ----
     DeviceBuf<float4> d_world;
     bool world_valid = false;          // d_world holds the world matrices of the current mirror, except ...
@@ -486,10 +474,6 @@ void drain_events(GvCtx* ctx);
 
 // gv_exchange.cpp
 void exchange_release(GvCtx* ctx);            // destroys the communicator, if any
-
-// gv_context.cpp: an emit held back behind an occlusion view (Context::deferred_emit) is launched now — before anything reads the
-// view's records or changes what the emit reads (mirror, world matrices)
-int flush_deferred_emit(GvCtx* ctx);
 
 // gv_mirror.cpp
 int sync_mirror(GvCtx* ctx);                 // brings the device mirror up to date with the bound pools + dirty ranges

@@ -867,9 +867,13 @@ hipError_t launch_block_patch(const MeshMirror& mesh, const TransformMirror& xf,
 }
 
 // flags[entry >> 8] = 1 for every entry re-mirrored by a sync: thread t is the t-th dirty slot of the sync's ranges (start[k] = slots
-// in the ranges before range k, first[k] = its first slot); inv: pool slot -> mirror entry (NULL: the mirror is in slot order)
+// in the ranges before range k, first[k] = its first slot); inv: slot -> mirror entry, a table of `slots` elements (NULL: the
+// mirror is in slot order). The ranges may be TRANSFORM slots (transform-side syncs flag the exactly paired mesh pools through the
+// transform pool's own table): a slot is bounded by the table it indexes, the ENTRY by the flagged pool's occupancy — a paired
+// pool with fewer meshes than transforms maps transform slots beyond its occupancy to entries inside it.
 __global__ __launch_bounds__(256) void mark_dirty_blocks_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ first, uint32_t nranges,
-                                                                const uint32_t* __restrict__ inv, uint32_t entries, uint8_t* __restrict__ flags)
+                                                                const uint32_t* __restrict__ inv, uint32_t slots, uint32_t entries,
+                                                                uint8_t* __restrict__ flags)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= start[nranges])
@@ -883,7 +887,7 @@ __global__ __launch_bounds__(256) void mark_dirty_blocks_kernel(const uint32_t* 
             hi = mid;
     }
     const uint32_t slot = first[lo] + (t - start[lo]);
-    if (slot >= entries)
+    if (slot >= slots)
         return;
     const uint32_t entry = inv ? inv[slot] : slot;
     if (entry < entries)
@@ -891,11 +895,11 @@ __global__ __launch_bounds__(256) void mark_dirty_blocks_kernel(const uint32_t* 
 }
 
 hipError_t launch_mark_dirty_blocks(const uint32_t* start, const uint32_t* first, uint32_t nranges, uint32_t total, const uint32_t* inv,
-                                    uint32_t entries, uint8_t* flags, hipStream_t stream)
+                                    uint32_t slots, uint32_t entries, uint8_t* flags, hipStream_t stream)
 {
     if (total == 0 || nranges == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(mark_dirty_blocks_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, start, first, nranges, inv, entries, flags);
+    hipLaunchKernelGGL(mark_dirty_blocks_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, start, first, nranges, inv, slots, entries, flags);
     return hipGetLastError();
 }
 
@@ -1493,63 +1497,6 @@ template <bool SELF>
 __global__ __launch_bounds__(256) void emit_kernel(const EmitArgs args)
 {
     emit_block<SELF>(args, blockIdx.x);
-}
-
-// A view's emit and the NEXT frame's first pyramid pass as ONE launch (gv_context.cpp: an emit behind an occlusion view is held
-// back until the next gv_hiz_build / gv_hiz_rebuild, or the first read of its records). The two do not depend on each other, one
-// is latency-bound (19 us at 3 % visible: three dependent round trips in a few hundred workgroups), the other bandwidth-bound
-// (15 us for 67 MB); back to back on one stream they cost their sum, on two streams more (event waits: measured). In one grid —
-// the emit's workgroups first, then one workgroup per 64 x 64 depth tile — the pyramid's loads fill the machine while the emit's
-// chains wait. Same device functions as the two kernels, same bits.
-struct EmitHizArgs {
-    EmitArgs emit;
-    const float* depth;
-    HizFusedDst dst;
-    uint32_t sw, sh, emit_blocks, tiles_x;
-};
-template <bool F16>
-__global__ __launch_bounds__(256) void emit_hiz_kernel(const EmitHizArgs a)
-{
-    // the two kinds of workgroup alternate while both last (dispatch follows blockIdx: the pyramid's tiles start streaming at once,
-    // beside the emit's chains, instead of behind all of the emit's workgroups), the longer kind's remainder follows
-    const uint32_t tiles = a.tiles_x * (a.sh / 64), both = min(a.emit_blocks, tiles);
-    const uint32_t b = blockIdx.x;
-    const bool paired = b < 2u * both;
-    const bool is_emit = paired ? (b & 1u) == 0u : a.emit_blocks > tiles;
-    const uint32_t index = paired ? b >> 1 : b - both;
-    if (is_emit) {
-        emit_block<true>(a.emit, index);
-        return;
-    }
-    hiz_fused_tile<false, F16>(a.depth, nullptr, a.dst, a.sw, a.sh, index % a.tiles_x, index / a.tiles_x);
-}
-
-hipError_t launch_emit_hiz(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out, uint32_t clear_chunks,
-                           const float4* world, const EmitSeed* seeds, const float* depth, const HizFusedDst& dst, uint32_t sw, uint32_t sh,
-                           bool rg16f, hipStream_t stream)
-{
-    EmitHizArgs a;
-    a.emit.world = world;
-    a.emit.seeds = seeds;
-    a.emit.direct_stores = 0;
-    a.emit.mesh = mesh;
-    a.emit.xf = xf;
-    a.emit.view = vp;
-    a.emit.out = out;
-    a.emit.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
-    a.emit.clear_chunks = clear_chunks;
-    a.depth = depth;
-    a.dst = dst;
-    a.sw = sw;
-    a.sh = sh;
-    a.emit_blocks = a.emit.nchunks * kEmitParts;
-    a.tiles_x = sw / 64;
-    const dim3 grid(a.emit_blocks + (sw / 64) * (sh / 64));
-    if (rg16f)
-        hipLaunchKernelGGL(emit_hiz_kernel<true>, grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(emit_hiz_kernel<false>, grid, dim3(256), 0, stream, a);
-    return hipGetLastError();
 }
 
 // The views of one batched cull (main camera + shadow passes over a small pool, where every launch counts) emitted by

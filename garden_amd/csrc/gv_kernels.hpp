@@ -128,7 +128,7 @@ hipError_t launch_block_patch(const MeshMirror& mesh, const TransformMirror& xf,
                               hipStream_t stream);
 // the dirty slot ranges of a sync (start[nranges + 1]: running slot counts, first[nranges]: first slots; device memory) -> flags
 hipError_t launch_mark_dirty_blocks(const uint32_t* start, const uint32_t* first, uint32_t nranges, uint32_t total, const uint32_t* inv,
-                                    uint32_t entries, uint8_t* flags, hipStream_t stream);
+                                    uint32_t slots, uint32_t entries, uint8_t* flags, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                        const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
 // Block bounds as classify (+ window test for Hi-Z views) + cull over the listed workgroups (two or three launches; same outputs
@@ -291,10 +291,5 @@ struct HizFusedDst {
 };
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
                             uint32_t sh, bool rg16f, hipStream_t stream);
-// A view's (self-prefixing) emit and the first fused pass of a pyramid build over a depth image as ONE launch (gv_cull.hip
-// emit_hiz_kernel): what launch_emit(..., self_prefix = true, ...) and launch_hiz_fused(depth, NULL, dst, sw, sh, ...) do.
-hipError_t launch_emit_hiz(const MeshMirror& mesh, const TransformMirror& xf, const ViewParams& vp, const ViewBuffers& out, uint32_t clear_chunks,
-                           const float4* world, const EmitSeed* seeds, const float* depth, const HizFusedDst& dst, uint32_t sw, uint32_t sh,
-                           bool rg16f, hipStream_t stream);
 
 }  // namespace gv

@@ -906,6 +906,7 @@ int reorder_transforms_device(GvCtx* ctx, KeySorter& ks, DeviceBuf<uint32_t>& xn
     GV_HIP(ctx, launch_reorder_remap(ctx->d_xinv.ptr, n, xnewpos.ptr, xinv_new.ptr, perm.ptr, ctx->stream));  // (nothing of the old mirror is written: a failure below leaves it whole)
     // the new tables and parent links come home; the staging records double as the pinned bounce buffer (stale from here on)
     uint32_t* bounce = reinterpret_cast<uint32_t*>(ctx->h_xab.ptr);  // 8 words per entry
+    ctx->staging_stale.add(0, n);  // (from the first word written: an early return below must not leave the records looking current)
     if (int rc = download_words(ctx, xinv_new.ptr, bounce, n)) return rc;
     if (int rc = download_words(ctx, perm.ptr, bounce + n, n)) return rc;
     if (int rc = download_words(ctx, parent.ptr, bounce + 2 * (size_t)n, n)) return rc;
@@ -965,6 +966,7 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
     GV_HIP(ctx, launch_reorder_meshes(order.ptr, n, xnewpos, ctx->xf_mirrored, p.d_a.ptr, p.d_b.ptr, p.d_link.ptr, p.d_orig.ptr, a.ptr, b.ptr, link.ptr,
                                       orig.ptr, inv.ptr, ctx->d_flag.ptr, ctx->stream));
     uint32_t* bounce = reinterpret_cast<uint32_t*>(p.h_a.ptr);  // 4 words per entry
+    p.staging_stale.add(0, n);  // (an early return below must not leave the staging records looking current)
     if (int rc = download_words(ctx, orig.ptr, bounce, n)) return rc;
     if (int rc = download_words(ctx, inv.ptr, bounce + n, n)) return rc;
     GV_HIP(ctx, hipMemcpyAsync(ctx->h_flag.ptr, ctx->d_flag.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -997,8 +999,9 @@ int reorder_meshes_device(GvCtx* ctx, PoolState& p, KeySorter& ks, const uint32_
 
 
 // The blocks of pool `p` that hold an entry of the slot ranges `ranges` get their flag set (PoolState::d_blk_dirty): what the
-// next cull has to re-derive of the pool's block bounds and emit seeds. inv: slot -> mirror entry of those slots on the device.
-int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges, const uint32_t* inv)
+// next cull has to re-derive of the pool's block bounds and emit seeds. inv: slot -> mirror entry of those slots on the device, a
+// table of `slots` elements (the transform pool's for transform-side ranges, the mesh pool's own otherwise).
+int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R>& ranges, const uint32_t* inv, uint32_t slots)
 {
     const uint32_t nr = (uint32_t)ranges.size();
     if (nr == 0 || !p.d_blk_dirty.ptr)
@@ -1020,7 +1023,7 @@ int mark_dirty_blocks(GvCtx* ctx, PoolState& p, const std::vector<DirtyRanges::R
     }
     start[nr] = total;
     GV_HIP(ctx, hipMemcpyAsync(ctx->d_ranges.ptr, ctx->h_ranges.ptr, (2 * (size_t)nr + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    GV_HIP(ctx, launch_mark_dirty_blocks(ctx->d_ranges.ptr, ctx->d_ranges.ptr + nr + 1, nr, total, inv, p.occupancy, p.d_blk_dirty.ptr, ctx->stream));
+    GV_HIP(ctx, launch_mark_dirty_blocks(ctx->d_ranges.ptr, ctx->d_ranges.ptr + nr + 1, nr, total, inv, slots, p.occupancy, p.d_blk_dirty.ptr, ctx->stream));
     return record_uploads(ctx);
 }
 
@@ -1032,8 +1035,6 @@ int sync_mirror(GvCtx* ctx)
     if (!ctx->xf.bound)
         return ctx->fail(GV_E_STATE, "gv_sync: no transform pool bound");
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    if (int frc = flush_deferred_emit(ctx))  // (it reads the mirror as it is now)
-        return frc;
     const uint32_t n = ctx->xf.occupancy;
     bool staged = false;
     const bool spatial = !(ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER);
@@ -1202,7 +1203,7 @@ int sync_mirror(GvCtx* ctx)
             if (flagging && !unflagged.empty())
                 for (uint32_t k = 0; k < GV_MAX_POOLS; k++)
                     if (targets.flags[k])
-                        if (int mrc = mark_dirty_blocks(ctx, ctx->pools[k], unflagged, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr))
+                        if (int mrc = mark_dirty_blocks(ctx, ctx->pools[k], unflagged, ctx->xinv.empty() ? nullptr : ctx->d_xinv.ptr, ctx->xf.occupancy))
                             return mrc;
             if (ctx->xf_links_dirty) {  // setParent (transform.cpp:130-195): chains changed length, maybe closed a cycle
                 uint32_t depth = 0;
@@ -1356,7 +1357,7 @@ int sync_mirror(GvCtx* ctx)
                                     unflagged.push_back(r);
                         }
                         if (!unflagged.empty())
-                            if (int mrc = mark_dirty_blocks(ctx, p, unflagged, p.inv.empty() ? nullptr : p.d_inv.ptr))
+                            if (int mrc = mark_dirty_blocks(ctx, p, unflagged, p.inv.empty() ? nullptr : p.d_inv.ptr, p.occupancy))
                                 return mrc;
                     }
                 }
@@ -1391,6 +1392,16 @@ int sync_mirror(GvCtx* ctx)
                 p.need_full = true;
                 again = true;
             } else if (rc != GV_OK) {
+                if (reorder_xf) {
+                    // the transform mirror is already in its new order: this pool and every pool behind it still name OLD transform
+                    // entries in their links. Nothing re-fires the re-order, so they are rebuilt from the bound pools at the next
+                    // sync (the next gv_cull must not run on stale links after a failed scratch allocation)
+                    for (PoolState* q = &p; q != ctx->pools + GV_MAX_POOLS; q++)
+                        if (q->bound && !q->need_full) {
+                            q->need_full = true;
+                            q->order_epoch++;
+                        }
+                }
                 return rc;
             }
         }

@@ -348,6 +348,11 @@ struct MeshBuffer {
 };
 struct UnsortedBuffer final : public MeshBuffer {
     std::vector<UnsortedMesh> combinedMeshes;
+    // What the render passes read — `const auto meshes = unsortedBuffer->combinedMeshes.data()` in the reference
+    // (mesh.cpp:581,611). NULL: the vector itself; otherwise records [0, drawCount) that live elsewhere for this frame: the
+    // drop-in's own page-locked result buffer (GpuVisibilitySystem::recordSpans — no copy into the vector at all).
+    const UnsortedMesh* span = nullptr;
+    const UnsortedMesh* meshes() const noexcept { return span ? span : combinedMeshes.data(); }
 };
 // render/mesh.hpp:198-205,218: translucent / UI meshes of ALL such systems share one array per kind
 // (transSortedMeshes / uiSortedMeshes, mesh.hpp:222-223), drawn back to front; bufferIndex names the system.

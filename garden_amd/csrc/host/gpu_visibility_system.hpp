@@ -80,6 +80,12 @@ public:
     // (gv_pool_set_record_target): the fetch leaves the records in the vector itself — no copy loop in the shim
     bool recordTargets = true;
     size_t recordTargetMaxBytes = size_t(256) << 20;  // larger arrays are not made targets: their records are copied after the fetch
+    // true (with recordStructs): an unsorted buffer's records are NOT copied anywhere — UnsortedBuffer::meshes() hands the render
+    // passes the library's own page-locked result buffer for this frame (valid until the pool's next gv_cull, i.e. through the
+    // frame's render phase). The one change on the consumer's side: `unsortedBuffer->meshes()` where the reference reads
+    // `unsortedBuffer->combinedMeshes.data()` (mesh.cpp:581,611). The vector is left alone (the engine's own array is never
+    // page-locked — round 3 — so filling it costs a second copy: 53 us of a 216 us tick at 100 k entities).
+    bool recordSpans = false;
     // true: also produce combinedMeshes records (bakedModel, distanceSq); false: isVisible + counters only
     bool emitRecords = true;
     // true: sortMeshes (mesh.cpp:265-328) runs on the device too: unsorted buffers ascending distanceSq
@@ -249,6 +255,7 @@ private:
         buffer->meshSystem = meshSystem;
         buffer->drawCount = r.draw_count;
         buffer->instanceCount = r.instance_count;
+        buffer->span = nullptr;
         if (!emitRecords)
             return;
         if (r.draw_count && !r.visible_idx) {
@@ -257,6 +264,10 @@ private:
             check(gv_pool_results_records(ctx, pool, viewIndex, &records, &count), "gv_pool_results_records");
             if (records == static_cast<const void*>(buffer->combinedMeshes.data()))
                 return;  // written in place by the device (recordTargets)
+            if (recordSpans && recordStructs) {
+                buffer->span = static_cast<const UnsortedMesh*>(records);  // read where they are (UnsortedBuffer::meshes())
+                return;
+            }
         }
         if (buffer->combinedMeshes.size() < r.draw_count)
             buffer->combinedMeshes.resize(r.draw_count);  // grown, never shrunk (mesh.cpp:377-395)
@@ -415,7 +426,7 @@ private:
                 const size_t occupancy = meshSystem->getMeshComponentOccupancy();
                 for (uint32_t v = 0; v < views.size(); v++) {
                     UnsortedBuffer* buffer = v == 0 ? unsortedBuffers[bufferIndex] : sb[v - 1];
-                    const bool target = inPlace && occupancy && occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
+                    const bool target = inPlace && !recordSpans && occupancy && occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
                     if (target && buffer->combinedMeshes.size() < occupancy) {
                         // growing re-allocates: let the old range go while it is still allocated
                         check(gv_pool_set_record_target(ctx, p, v, nullptr, 0), "gv_pool_set_record_target");

@@ -69,7 +69,7 @@ class GvStats(C.Structure):
     _fields_ = [("launches", C.c_uint64 * GV_K_COUNT), ("device_ms", C.c_double * GV_K_COUNT),
                 ("upload_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("transform_count", C.c_uint32),
                 ("mesh_count", C.c_uint32 * GV_MAX_POOLS), ("bounds_blocks_total", C.c_uint64),
-                ("bounds_blocks_examined", C.c_uint64), ("mirror_reorders", C.c_uint64)]
+                ("bounds_blocks_examined", C.c_uint64), ("mirror_reorders", C.c_uint64), ("record_targets_lost", C.c_uint64)]
 
 
 GV_EXCHANGE_MAX_RANKS = 64
@@ -568,7 +568,8 @@ class GpuVisibility:
         self._check(self.lib.gv_stats(self.ctx, C.byref(s)))
         return dict(launches={k: int(s.launches[i]) for i, k in enumerate(KERNEL_NAMES)},
                     device_ms={k: float(s.device_ms[i]) for i, k in enumerate(KERNEL_NAMES)},
-                    upload_bytes=int(s.upload_bytes), mirror_reorders=int(s.mirror_reorders), max_depth=int(s.max_depth),
+                    upload_bytes=int(s.upload_bytes), mirror_reorders=int(s.mirror_reorders), record_targets_lost=int(s.record_targets_lost),
+                    max_depth=int(s.max_depth),
                     transform_count=int(s.transform_count), bounds_blocks_total=int(s.bounds_blocks_total),
                     bounds_blocks_examined=int(s.bounds_blocks_examined))
 

@@ -202,6 +202,19 @@ def synthetic_depth(width, height, seed=SEED, rects=256):
     return d
 
 
+def noise_depth(width, height, seed=SEED, block=8, near=0.01, nearest=50.0, farthest=20000.0):
+    """A HARD depth image for the occlusion query: every `block` x `block` pixel block holds an occluder at
+    its own distance, log-uniform in [nearest, farthest] metres — reversed-Z infinite projection: depth = near / distance — i.e.
+    right among the entities of the 10 M world (cube of 21.5 km), not centimetres from the camera like synthetic_depth's walls.
+    A coarse pyramid texel then spans many occluder distances, its (min, max) straddles nearly every box's zNear, the early
+    accept / reject of hiz_occluded (gv_device.hpp) decides almost nothing and the queries go down to levels 0-2."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x9E15E))
+    bw, bh = (width + block - 1) // block, (height + block - 1) // block
+    dist = np.exp(rng.uniform(np.log(nearest), np.log(farthest), size=(bh, bw)))
+    d = (np.float32(near) / dist.astype(np.float32)).astype(np.float32)
+    return np.ascontiguousarray(np.repeat(np.repeat(d, block, axis=0), block, axis=1)[:height, :width])
+
+
 def shuffled_scene(sc, fraction=1.0, seed=SEED, drop_transforms=0.0):
     """Same entities, but the transform pool is permuted relative to the mesh pool (ECS pools are independent:
     an entity's mesh slot and transform slot need not match) for `fraction` of the slots; `drop_transforms`

@@ -198,10 +198,9 @@ typedef struct GvResult {
 /* Device-side cull of one pool against `view_count` views: frustum test (+ Hi-Z query) + compaction.
  * Asynchronous: returns once the work is enqueued on the context's stream. Replaces
  * MeshRenderSystem::prepareMeshes' threaded loop (mesh.cpp:331-553 -> :111-184).
- * The record emission of a single occlusion (use_hiz) view of a large pool may be enqueued LATER than the cull itself: by the
- * next gv_hiz_build / gv_hiz_rebuild (it then shares a launch with the pyramid's first pass), or by the first call that reads
- * the view's results or changes what the emission reads (every gv_results_*, gv_sort, gv_wait, gv_sync, the next gv_cull, ...).
- * Callers see no difference except through timing of their own on gv_stream(). */
+ * Everything a view's results consist of is enqueued by this call, in stream order: a consumer on gv_stream() may use the
+ * pointers of gv_results_device without calling into the library again (round 3 held a single occlusion view's record emission
+ * back until the next gv_hiz_build; withdrawn in round 4 — only a loop that never looks at its results gained from it). */
 int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_count);
 /* Blocks until all enqueued work is done. */
 int gv_wait(GvCtx* ctx);
@@ -289,8 +288,10 @@ int gv_pool_results_records(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, c
  * array had been freed and its addresses reused (round 3: 4 of 16 runs of the GPU test tier). The pool needs a
  * record layout; `bytes` >= occupancy * stride of every pool culled while the target is set (GV_E_ARG at the fetch otherwise);
  * `records` 16-byte aligned. The range must stay allocated until it is replaced (another call for the same pool and view),
- * removed (records == NULL) or the context is destroyed: a range that is found unmapped when it is let go or written is
- * reported with GV_E_STATE (a freed heap block that is still mapped cannot be told from a live one). */
+ * removed (records == NULL) or the context is destroyed. A range that is found unmapped when it is WRITTEN fails that fetch with
+ * GV_E_STATE; one found unmapped when it is let go is counted in GvStats::record_targets_lost and described in gv_last_error —
+ * the call that replaces it succeeds, the new target is in place (a freed heap block that is still mapped cannot be told from a
+ * live one). */
 int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* records, size_t bytes);
 
 /* The first instance index of every fetched record: bases[k] = sum of the ready counts (gv_pool_bind_ready; 1 per record
@@ -524,6 +525,9 @@ typedef struct GvStats {
     uint64_t bounds_blocks_examined; /* ... and how many of them had to run the per-entity path */
     uint64_t mirror_reorders;        /* spatial re-orders of the transform mirror done ON the device since gv_create (an unsorted
                                         tail of created entities past 1/8 of the pool; no PCIe re-upload) */
+    uint64_t record_targets_lost;    /* gv_pool_set_record_target calls since gv_create that found the PREVIOUS target's range unmapped
+                                        when they let it go (the caller freed it too early; text in gv_last_error). The call itself
+                                        succeeds: the new target is in place */
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -78,7 +78,14 @@ static std::vector<IMeshRenderSystem*> allMeshSystems(Manager& manager)
 }
 
 template <class M>
+static void addList(Snapshot& s, const M* meshes, uint32_t count, bool mustBeOrdered, const char* name);
+template <class M>
 static void addList(Snapshot& s, const std::vector<M>& meshes, uint32_t count, bool mustBeOrdered, const char* name)
+{
+    addList(s, meshes.data(), count, mustBeOrdered, name);
+}
+template <class M>
+static void addList(Snapshot& s, const M* meshes, uint32_t count, bool mustBeOrdered, const char* name)
 {
     std::vector<Record> list(count);
     for (uint32_t k = 0; k < count; k++) {
@@ -111,12 +118,12 @@ static Snapshot snapshot(Manager& manager, const SystemT* system, uint32_t passC
     for (uint32_t b = 0; b < system->getUnsortedBufferCount(); b++) {
         auto buffer = system->getUnsortedBuffers()[b];
         const bool sorted = buffer->meshSystem->getMeshRenderType() != MeshRenderType::OIT;  // mesh.cpp:273-277
-        addList(s, buffer->combinedMeshes, buffer->drawCount, sorted, "unsorted buffer");
+        addList(s, buffer->meshes(), buffer->drawCount, sorted, "unsorted buffer");  // what the render passes read (mesh.cpp:581)
         s.counters.push_back(buffer->drawCount);
         s.counters.push_back(buffer->instanceCount);
         for (uint32_t pass = 0; pass < passCount; pass++) {
             auto shadow = system->getShadowBuffers(b)[pass];
-            addList(s, shadow->combinedMeshes, shadow->drawCount, sorted, "shadow unsorted buffer");
+            addList(s, shadow->meshes(), shadow->drawCount, sorted, "shadow unsorted buffer");
             s.counters.push_back(shadow->drawCount);
             s.counters.push_back(shadow->instanceCount);
         }
@@ -168,6 +175,7 @@ int main(int argc, char** argv)
                             // checks gv_get_world of every transform slot against the oracle's chain walk, bit for bit
     bool itemised = false;  // --itemised: --animate reports the moved entities one by one (TransformSystem::markMoved)
     bool copyRecords = false;  // --copy-records: records arrive in the library's buffer and are copied into combinedMeshes (no record target)
+    bool spanRecords = false;  // --span-records: the render passes read the library's page-locked buffer (UnsortedBuffer::meshes()), no copy
     bool soaRecords = false;  // --soa-records: the GPU system fetches three arrays and fills combinedMeshes itself (no record layout)
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
     for (int i = 1; i < argc; i++) {
@@ -186,6 +194,7 @@ int main(int argc, char** argv)
         else if (a == "--itemised") itemised = true;
         else if (a == "--soa-records") soaRecords = true;
         else if (a == "--copy-records") copyRecords = true;
+        else if (a == "--span-records") spanRecords = true;
         else if (a == "--avx2") avx2 = true;  // CPU system: AVX2+FMA SoA path (bit-identical to the scalar loop)
         else if (a == "--bounds") bounds = true;  // GV_CONFIG_BLOCK_BOUNDS in the GPU system
         else if (a == "--toggle") toggle = mutate = true;  // second round: only setActive / setParent (ranged re-mirror)
@@ -224,6 +233,7 @@ int main(int argc, char** argv)
         if (gpu) {
             gpu->recordStructs = !soaRecords;
             gpu->recordTargets = !copyRecords;
+            gpu->recordSpans = spanRecords;
         }
         if (gpu && world)
             gpu->sweepWorldMatrices = gpu->sweepIncremental = true;

@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <random>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -655,8 +657,152 @@ static void exchange_in_threads(int ranks)
     std::printf("exchange over the stub transport, %d ranks: ok\n", ranks);
 }
 
-int main()
+// ---- random schedules over the held-back mechanisms: the text tests/schedules.py generates (the GPU tier replays the same
+// schedules against the oracle, tests/test_gpu_fuzz.py). Kernels do nothing here; what is checked is that every call returns
+// GV_OK and that the host orchestration behind it — recorded culls, deferred sorts, published views, flushes forced by dirty
+// marks / re-binds / pyramid builds — stays inside its buffers (ASan) whatever the order of calls. ----
+static void replay_schedule(const std::string& path)
 {
+    std::ifstream in(path);
+    std::string line;
+    if (!std::getline(in, line)) {
+        std::fprintf(stderr, "schedule %s: empty\n", path.c_str());
+        std::exit(1);
+    }
+    std::istringstream head(line);
+    std::string word;
+    uint32_t n_xf = 0;
+    head >> word >> n_xf;
+    std::vector<uint32_t> sizes;
+    for (uint32_t v; head >> v;)
+        sizes.push_back(v);
+    World w;
+    w.build(n_xf, 0);
+    std::vector<std::vector<Mesh>> pools;
+    for (uint32_t n : sizes)
+        pools.emplace_back(w.meshes.begin(), w.meshes.begin() + n);
+    std::vector<Transform> xf = w.xf;
+    GvConfig config{};
+    config.struct_size = sizeof(config);
+    GvCtx* ctx = nullptr;
+    if (gv_create(&config, &ctx) != GV_OK) {
+        std::fprintf(stderr, "schedule %s: gv_create\n", path.c_str());
+        std::exit(1);
+    }
+    const GvTransformLayout tl = transform_layout();
+    const GvMeshLayout ml = mesh_layout();
+    const GvRecordLayout rl = {64, 0, 8, 56, GV_NONE, (uint32_t)sizeof(Mesh), 0};
+    CHECK(gv_transform_bind(ctx, xf.data(), sizeof(Transform), n_xf, &tl, w.e2t.data(), (uint32_t)w.e2t.size()));
+    for (uint32_t p = 0; p < pools.size(); p++) {
+        CHECK(gv_pool_bind(ctx, p, pools[p].data(), sizeof(Mesh), (uint32_t)pools[p].size(), &ml));
+        if (p % 2 == 1)
+            CHECK(gv_pool_set_record_layout(ctx, p, &rl));
+    }
+    CHECK(gv_hierarchy_rebuild(ctx));
+    uint32_t last_pool = 0;
+    std::vector<float> depth;
+    std::vector<uint32_t> scratch;
+    while (std::getline(in, line)) {
+        std::istringstream ops(line);
+        std::string op;
+        ops >> op;
+        std::vector<std::string> a;
+        for (std::string t; ops >> t;)
+            a.push_back(t);
+        auto num = [&](size_t k) { return (uint32_t)std::stoul(a.at(k)); };
+        if (op == "begin") {
+            CHECK(gv_cull_batch_begin(ctx));
+        } else if (op == "end") {
+            CHECK(gv_cull_batch_end(ctx));
+        } else if (op == "wait") {
+            CHECK(gv_wait(ctx));
+        } else if (op == "sync") {
+            CHECK(gv_sync(ctx));
+        } else if (op == "cull") {
+            GvView views[GV_MAX_VIEWS];
+            uint32_t nv = 0;
+            for (size_t k = 1; k < a.size(); k++) {
+                const char kind = a[k][0];
+                views[nv] = make_view(kind == 's' ? (int8_t)(k - 1) : (int8_t)-1, kind == 'h', 1);
+                views[nv].distance_2d = kind == 'u';
+                nv++;
+            }
+            CHECK(gv_cull(ctx, num(0), views, nv));
+            last_pool = num(0);
+        } else if (op == "sort") {
+            CHECK(gv_pool_sort(ctx, num(0), num(1), (int)num(2)));
+        } else if (op == "dirty_xf") {
+            for (uint32_t s = num(0); s < num(0) + num(1); s++)
+                xf[s].position[0] += 1.0f;
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, num(0), num(1)));
+        } else if (op == "dirty_mesh") {
+            for (uint32_t s = num(1); s < num(1) + num(2); s++)
+                pools[num(0)][s].aabbMax[0] += 0.25f;
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, (num(0) << 28) | num(1), num(2)));
+        } else if (op == "move") {
+            std::vector<Mesh> moved(pools[num(0)]);
+            pools[num(0)].swap(moved);  // (the old storage is freed at the end of this scope: the library must not touch it again)
+            CHECK(gv_pool_bind(ctx, num(0), pools[num(0)].data(), sizeof(Mesh), (uint32_t)pools[num(0)].size(), &ml));
+        } else if (op == "grow") {
+            std::vector<Mesh> grown(pools[num(0)]);
+            for (uint32_t k = 0; k < num(1); k++)
+                grown.push_back(w.meshes[grown.size()]);
+            pools[num(0)].swap(grown);
+            CHECK(gv_pool_bind(ctx, num(0), pools[num(0)].data(), sizeof(Mesh), (uint32_t)pools[num(0)].size(), &ml));
+        } else if (op == "move_xf") {
+            std::vector<Transform> moved(xf);
+            xf.swap(moved);
+            CHECK(gv_transform_bind(ctx, xf.data(), sizeof(Transform), n_xf, &tl, w.e2t.data(), (uint32_t)w.e2t.size()));
+        } else if (op == "hiz") {
+            depth.assign((size_t)num(0) * num(1), 0.25f);
+            CHECK(gv_hiz_build(ctx, depth.data(), num(0), num(1), GV_MEM_HOST));
+        } else if (op == "hiz_rebuild") {
+            CHECK(gv_hiz_rebuild(ctx));
+        } else if (op == "sweep") {
+            CHECK(gv_sweep(ctx, num(0)));
+            float world[12 * 8];
+            CHECK(gv_get_world(ctx, 0, 8, world));
+        } else if (op == "fetch" || op == "records") {
+            GvResult r{};
+            CHECK(gv_pool_results_fetch(ctx, num(0), num(1), op == "fetch" ? (int)num(2) : 0, &r));
+            if (num(0) % 2 == 1) {
+                const void* records = nullptr;
+                uint32_t count = 0;
+                CHECK(gv_pool_results_records(ctx, num(0), num(1), &records, &count));
+            }
+        } else if (op == "count") {
+            uint32_t count = 0;
+            CHECK(gv_pool_result_count(ctx, num(0), num(1), &count));
+        } else if (op == "device") {
+            GvDeviceResult d{};
+            CHECK(gv_pool_results_device(ctx, num(0), num(1), &d));
+        } else if (op == "bases") {
+            const uint32_t* bases = nullptr;
+            uint32_t count = 0;
+            CHECK(gv_pool_results_instance_bases(ctx, num(0), num(1), &bases, &count));
+        } else if (op == "shard" || op == "mask") {
+            const size_t n = pools[last_pool].size();
+            scratch.assign(n + 2, 0);
+            if (op == "shard")
+                CHECK(gv_results_copy_shard_device(ctx, 0, scratch.data(), (uint32_t)n, 7));
+            else
+                CHECK(gv_results_copy_mask_device(ctx, 0, scratch.data(), (uint32_t)((n + 31) / 32)));
+        } else {
+            std::fprintf(stderr, "schedule %s: unknown operation '%s'\n", path.c_str(), op.c_str());
+            std::exit(1);
+        }
+    }
+    gv_destroy(ctx);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1) {  // schedule files (tests/schedules.py): replayed instead of the fixed exercise
+        for (int k = 1; k < argc; k++)
+            replay_schedule(argv[k]);
+        std::printf("schedules: %d replayed ok\n", argc - 1);
+        return 0;
+    }
     // spatially ordered mirror (default), pool-slot order, forced block bounds, linear scan; flat and 4-deep
     exercise(0, 40000, 3);
     exercise(GV_CONFIG_KEEP_SLOT_ORDER, 30000, 0);

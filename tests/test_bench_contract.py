@@ -35,8 +35,7 @@ def test_bench_prints_one_json_line(exchange):
     assert d["parity"]["visible_set_bit_identical"] and d["config"]["workload"].startswith("cfg3")
     assert (d["config"]["exchange"] is not None) == exchange
     # every kernel of a frame, measured outside the timed region; the timed region brackets the dominant kernel only
-    # (the emit of an occlusion view rides in the next frame's first pyramid launch: its time is inside "hiz")
-    assert set(("cull", "hiz")) <= set(d["config"]["frame_kernel_ms"]) and set(d["config"]["kernel_ms"]) == {"cull"}
+    assert set(("cull", "hiz", "emit")) <= set(d["config"]["frame_kernel_ms"]) and set(d["config"]["kernel_ms"]) == {"cull"}
     assert d["value_with_block_bounds"] == d["config"]["block_bounds_variant"]["value"]
 
 

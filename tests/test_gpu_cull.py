@@ -1825,12 +1825,13 @@ def test_record_target_lifetime_through_the_bare_c_abi(case):
         assert "lost registration reported 8 times" in p.stdout
 
 
-def test_an_occlusion_views_emit_rides_with_the_next_pyramid_build(oracle):
-    """End of round 3: the emit of a single use_hiz view is held back and shares a launch with the next pyramid build's first pass
-    (emit_hiz_kernel) — or is launched by whatever reads the results or changes what it reads first. Every order of calls an
-    application can make gives the records, isVisible bytes and counts of the plain path: rebuild -> fetch, fetch at once, a new
-    depth image in between (the cull saw the old pyramid), dirty marks and the next cull in between, a sort, a second pool culled
-    in between, a view array of two (never held back), and a context destroyed with an emit still held."""
+def test_an_occlusion_views_results_in_every_order_of_calls(oracle):
+    """Every order of calls an application can make around the cull of a single use_hiz view gives the records, isVisible bytes
+    and counts of the plain path: rebuild -> fetch, fetch at once, a new depth image in between (the cull saw the old pyramid),
+    dirty marks and the next cull in between, a sort, a second pool culled in between, a view array of two, and a context destroyed
+    right after a cull. (Written in round 3 for an emit that was held back until the next pyramid build; that mechanism was
+    withdrawn in round 4 — gv_cull enqueues everything itself again — and the last block checks exactly that: a device-side
+    consumer that cached the pointers of gv_results_device sees each frame's list without calling into the library again.)"""
     import torch
     from garden_amd.lib import GpuVisibility
     n = 280_000
@@ -1912,4 +1913,22 @@ def test_an_occlusion_views_emit_rides_with_the_next_pyramid_build(oracle):
         vis.cull(0, [view, shadow])
         vis.hiz_rebuild()
         same(vis.fetch(0, write_back=False, occupancy=n), exp3, m23)
-        vis.cull(0, [view])  # ... and a context destroyed with an emit still held
+        # a device-side consumer with cached pointers: nothing but gv_cull between the frames
+        dres = vis.results_device(0)
+
+        class _Span:
+            pass
+        span = _Span()
+        span.__cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (int(dres.draw_count), False), "version": 2}
+        count = torch.as_tensor(span, device="cuda:0")
+        lib_stream = torch.cuda.ExternalStream(vis.stream(), device=torch.device("cuda", 0))
+        seen = []
+        for frame_view, frame_exp in ((view, exp3), (dict(view, use_hiz=0), None), (view, exp3)):
+            vis.cull(0, [frame_view])
+            assert vis.results_device(0).draw_count == dres.draw_count  # (same buffers from frame to frame)
+            with torch.cuda.stream(lib_stream):
+                seen.append(count.clone())
+        lib_stream.synchronize()
+        e_nohiz = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, dict(view, use_hiz=0))
+        assert [int(t.item()) for t in seen] == [exp3["draw_count"], e_nohiz["draw_count"], exp3["draw_count"]]
+        vis.cull(0, [view])  # ... and a context destroyed right after a cull

@@ -102,6 +102,32 @@ def test_cfg3_10m_hiz_properties_and_oracle(gpu, oracle, flat10m):
     assert same_records(hz1, exp) and np.array_equal(hz1["is_visible"], m2["isVisible"])
 
 
+@pytest.mark.parametrize("rg16f", [False, True])
+def test_cfg3_10m_against_a_hard_depth_image(oracle, flat10m, rg16f):
+    """cfg3's 10 M entities against scene.noise_depth (one occluder per 8 x 8 pixel block, at distances among the entities): the
+    coarse-level early exits of the occlusion query decide almost nothing here, so every frustum survivor's answer comes from
+    levels 0-2 of the pyramid — level 1 is virtual, i.e. reduced from the depth image on the fly — where cfg3's own walls are
+    decided four levels up. Bit for bit against the oracle, fp32 and RG16F pyramids; both exits of the query are used."""
+    from garden_amd.lib import GpuVisibility
+    sc = flat10m
+    depth = scene.noise_depth(HIZ, HIZ)
+    view = scene.main_camera_view(use_hiz=1)
+    with GpuVisibility(device=0, hiz_rg16f=rg16f, linear_scan=True) as vis:
+        bind(vis, sc)
+        vis.hiz_build(depth)
+        vis.cull(0, [view])
+        got = vis.fetch(0, write_back=False, occupancy=sc.count)
+    check_self_consistent(got, sc.count)
+    m2 = sc.meshes.copy()
+    exp = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, hiz=oracle.Hiz(depth, rg16f=rg16f, threads=THREADS), threads=THREADS)
+    o = np.argsort(exp["visible_idx"], kind="stable")
+    exp = {k: (v[o] if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    assert same_records(got, exp) and np.array_equal(got["is_visible"], m2["isVisible"])
+    frustum = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, dict(view, use_hiz=0), threads=THREADS)["draw_count"]
+    # a real mix: the image hides a good part of the frustum's survivors and keeps a good part
+    assert 0.05 * frustum < got["draw_count"] < 0.95 * frustum, (got["draw_count"], frustum)
+
+
 def test_cfg3_10m_against_the_rg16f_pyramid(oracle, flat10m):
     """GV_CONFIG_HIZ_RG16F at BASELINE's size: 10 M entities against the 4096^2 pyramid kept in the reference's image
     format (min rounded toward -inf, max toward +inf; level 1 virtual): the oracle's set bit for bit, a superset of the
@@ -299,3 +325,50 @@ def test_identity_parent_leaves_the_visible_set_unchanged(gpu):
     assert np.array_equal(flat["visible_idx"], hung["visible_idx"])
     assert np.array_equal(flat["is_visible"], hung["is_visible"])
     assert np.array_equal(flat["baked_model"] + 0.0, hung["baked_model"] + 0.0)  # equal up to the sign of zero
+
+
+def test_moved_transforms_beyond_a_smaller_paired_mesh_pool_keep_block_bounds_current(oracle):
+    """the transform pool has MORE slots than the exactly paired mesh pool (its first million slots are free), the
+    mirror is in spatial order, and a stretch of transform slots ABOVE the mesh pool's occupancy — long enough for the device-side
+    gather of dirty AoS ranges, short enough to count as "a few" — moves every frame. Those slots map to mirror entries INSIDE the
+    mesh pool: the blocks holding them must be flagged so that the next cull re-derives their boxes and emit seeds
+    (mark_dirty_blocks_kernel bounded the slot by the mesh pool's occupancy and dropped them). The moved entities jump from behind
+    the camera to right in front of it: with stale boxes their workgroups would be skipped. Against the oracle every frame."""
+    from garden_amd.lib import GV_DIRTY_TRANSFORM, GpuVisibility
+    n_mesh, shift = 8_600_000, 1_000_000
+    base = scene.flat_scene(n_mesh)
+    tr = np.zeros(n_mesh + shift, dtype=base.transforms.dtype)  # slots [0, shift) stay free
+    tr[shift:] = base.transforms
+    e2t = np.asarray(base.entity_to_transform, dtype=np.uint32).copy()
+    live = e2t != 0xFFFFFFFF
+    e2t[live] += shift
+    meshes = base.meshes
+    view = scene.main_camera_view()
+    first, count = n_mesh + 200_000, 3000  # transform slots above the mesh pool's occupancy
+    with GpuVisibility(device=0) as vis:  # default configuration: block bounds for pools of this size
+        vis.bind_transforms(tr, e2t)
+        vis.bind_pool(0, meshes)
+        vis.hierarchy_rebuild()
+        fwd = got = None
+        for frame in range(8):
+            if frame >= 1:
+                # onto a line of sight, a little farther each frame (frame 1: from wherever they were, mostly out of view)
+                rows = tr[first:first + count]
+                if fwd is None:  # a direction inside the frustum: towards an entity the first frame saw (the camera sits at the origin)
+                    p0 = tr["position"][int(got["visible_idx"][got["draw_count"] // 2]) + shift, :3].astype(np.float64)
+                    fwd = (p0 / np.linalg.norm(p0)).astype(np.float32)
+                rows["position"][:, :3] = fwd * np.float32(300.0 + 40.0 * frame) + np.linspace(-20, 20, count, dtype=np.float32)[:, None]
+                vis.mark_dirty(GV_DIRTY_TRANSFORM, first, count)
+            vis.cull(0, [view])
+            got = vis.fetch(0, write_back=False, occupancy=n_mesh)
+            m2 = meshes.copy()
+            exp = oracle.prepare_meshes(m2, tr, e2t, view, threads=THREADS)
+            o = np.argsort(exp["visible_idx"], kind="stable")
+            assert np.array_equal(got["visible_idx"], exp["visible_idx"][o]), frame
+            assert np.array_equal(got["baked_model"].view(np.uint32), exp["baked_model"][o].view(np.uint32)), frame
+            assert np.array_equal(got["is_visible"], m2["isVisible"]), frame
+            if frame >= 1:
+                moved = np.arange(first - shift, first - shift + count)
+                assert np.isin(moved, got["visible_idx"]).mean() > 0.5, frame  # they really are in view now
+        st = vis.stats()
+        assert st["bounds_blocks_total"] > 0  # the culls did run with block bounds

@@ -188,3 +188,241 @@ def test_random_worlds_match_the_oracle(gpu, gpu_slot_order, gpu_bounds, oracle,
         vis.sweep(1)
         assert np.array_equal(vis.get_world(0, nt + add_t).view(np.uint32),
                               oracle.world_matrices(grown.transforms, grown.entity_to_transform).view(np.uint32))
+
+
+# ---- random schedules over the held-back mechanisms (tests/schedules.py; the same text runs under ASan in the CPU tier) ----
+RECORD_DTYPE = np.dtype({"names": ["componentOffset", "bakedModel", "distanceSq"], "formats": ["<u8", ("<f4", 12), "<f4"],
+                         "offsets": [0, 8, 56], "itemsize": 64})
+
+
+class ScheduleReplay:
+    """Replays one schedule on a context and checks every reader against the oracle evaluated on the state AT THE gv_cull it
+    reads (recorded culls see the pools and the pyramid as they were when they were recorded)."""
+
+    def __init__(self, vis, oracle, schedule, seed):
+        import torch
+        self.torch = torch
+        self.vis, self.oracle = vis, oracle
+        self.rng = np.random.Generator(np.random.PCG64(0xBEEF + seed))
+        _, n_xf, *sizes = schedule[0]
+        base = scene.flat_scene(n_xf, seed=100 + seed)
+        self.tr, self.e2t = base.transforms, np.asarray(base.entity_to_transform, dtype=np.uint32)
+        self.pools = []
+        for p, n in enumerate(sizes):
+            m = base.meshes[:n].copy()
+            if p % 3 == 2:  # an independent order
+                m = m[self.rng.permutation(n)]
+            self.pools.append(m)
+        self.hz = self.depth = None
+        self.culls = {}   # pool -> dict(meshes, tr, views, hz, sorted[view], expected[view] (lazily))
+        self.last_pool = None
+        self.camera = tuple(float(x) for x in self.rng.normal(0, 300.0, 3).astype(np.float32))
+        vis.bind_transforms(self.tr, self.e2t)
+        for p, m in enumerate(self.pools):
+            vis.bind_pool(p, m)
+            vis.set_record_layout(p, RECORD_DTYPE if p % 2 == 1 else None, component_stride=m.dtype.itemsize)
+        vis.hierarchy_rebuild()
+        self.readers = 0
+
+    def view_of(self, kind, k):
+        cam = np.asarray([*self.camera, 0.0], np.float32)
+        if kind == "s":
+            v = scene.cascade_view(seed=int(self.rng.integers(1 << 30)), size=float(self.rng.uniform(2000, 30000)), depth=60000.0, index=k % 4)
+            return dict(v, camera_position=cam)
+        v = scene.main_camera_view(seed=int(self.rng.integers(1 << 30)), camera_position=self.camera)
+        return dict(v, use_hiz=1 if kind == "h" else 0, distance_2d=1 if kind == "u" else 0)
+
+    def expected(self, pool, view):
+        c = self.culls[pool]
+        if view not in c["expected"]:
+            m2 = c["meshes"].copy()
+            v = c["views"][view]
+            exp = self.oracle.prepare_meshes(m2, c["tr"], self.e2t, v, hiz=c["hz"] if v.get("use_hiz") else None)
+            o = np.argsort(exp["visible_idx"], kind="stable")
+            c["expected"][view] = dict(idx=exp["visible_idx"][o], model=exp["baked_model"][o], dist=exp["distance_sq"][o],
+                                       count=exp["draw_count"], is_visible=m2["isVisible"].copy())
+        return c["expected"][view]
+
+    def read(self, pool, view, write_back):
+        """(visible_idx, baked_model, distance_sq) in the order the library delivers them, + is_visible (main pass)."""
+        n = self.pools[pool].shape[0]
+        got = self.vis.fetch(view, write_back=bool(write_back), occupancy=n, order="raw", pool_id=pool)
+        if pool % 2 == 1 and got["draw_count"]:
+            rec = self.vis.records(pool, view, RECORD_DTYPE)
+            assert rec.shape[0] == got["draw_count"]
+            stride = self.pools[pool].dtype.itemsize
+            assert np.all(rec["componentOffset"] % stride == 0)
+            got["visible_idx"] = (rec["componentOffset"] // stride).astype(np.uint32)
+            got["baked_model"], got["distance_sq"] = rec["bakedModel"].copy(), rec["distanceSq"].copy()
+        return got
+
+    def check_fetch(self, pool, view, write_back):
+        c, exp = self.culls[pool], self.expected(pool, view)
+        got = self.read(pool, view, write_back)
+        assert got["draw_count"] == exp["count"], (pool, view, got["draw_count"], exp["count"])
+        order = c["sorted"].get(view)
+        idx, model, dist = got["visible_idx"], got["baked_model"], got["distance_sq"]
+        if exp["count"]:
+            if order is not None:
+                assert np.all(dist[:-1] >= dist[1:]) if order else np.all(dist[:-1] <= dist[1:]), (pool, view, order)
+            k = np.argsort(idx, kind="stable")
+            assert np.array_equal(idx[k], exp["idx"]), (pool, view)
+            assert np.array_equal(model[k].view(np.uint32), exp["model"].view(np.uint32)), (pool, view)
+            assert np.array_equal(dist[k].view(np.uint32), exp["dist"].view(np.uint32)), (pool, view)
+            if order is None:  # unsorted results come in a deterministic order: mirror order, which a slot sort must not need twice
+                assert np.unique(idx).shape[0] == idx.shape[0]
+        if c["views"][view]["shadow_pass"] < 0:
+            assert np.array_equal(got["is_visible"], exp["is_visible"]), (pool, view)
+
+    def run(self, schedule):
+        vis, rng, torch = self.vis, self.rng, self.torch
+        for op, *a in schedule[1:]:
+            if op == "begin":
+                vis.cull_batch_begin()
+            elif op == "end":
+                vis.cull_batch_end()
+            elif op == "wait":
+                vis.wait()
+            elif op == "sync":
+                vis.sync()
+            elif op == "cull":
+                p, kinds = int(a[0]), a[1:]
+                views = [self.view_of(k, i) for i, k in enumerate(kinds)]
+                vis.cull(p, views)
+                self.culls[p] = dict(meshes=self.pools[p].copy(), tr=self.tr.copy(), views=views, hz=self.hz, sorted={}, expected={})
+                self.last_pool = p
+            elif op == "sort":
+                p, v, desc = int(a[0]), int(a[1]), int(a[2])
+                vis.sort(v, descending=bool(desc), pool_id=p)
+                self.culls[p]["sorted"][v] = bool(desc)
+            elif op == "dirty_xf":
+                first, count = int(a[0]), int(a[1])
+                self.tr["position"][first:first + count, :3] += rng.normal(0, 40.0, (count, 3)).astype(np.float32)
+                self.tr["selfActive"][first:first + count] ^= (rng.random(count) < 0.05).astype(np.uint8)
+                vis.mark_dirty(0, first, count)
+            elif op == "dirty_mesh":
+                p, first, count = int(a[0]), int(a[1]), int(a[2])
+                self.pools[p]["aabbMax"][first:first + count, :3] += np.float32(0.25)
+                self.pools[p]["isEnabled"][first:first + count] ^= (rng.random(count) < 0.1).astype(np.uint8)
+                vis.mark_dirty(2, first, count, pool_id=p)
+            elif op == "move":
+                p = int(a[0])
+                self.pools[p] = self.pools[p].copy()
+                vis.bind_pool(p, self.pools[p])
+                self.culls.pop(p, None)
+            elif op == "grow":
+                p, extra = int(a[0]), int(a[1])
+                old = self.pools[p]
+                n = old.shape[0]
+                new = np.concatenate([old, np.zeros(extra, old.dtype)])
+                new["entity"][n:] = self.tr["entity"][n:n + extra]
+                new["aabbMin"][n:, :3], new["aabbMax"][n:, :3], new["isEnabled"][n:] = -0.5, 0.5, 1
+                self.pools[p] = new
+                vis.bind_pool(p, new)
+                self.culls.pop(p, None)
+            elif op == "move_xf":
+                self.tr = self.tr.copy()
+                vis.bind_transforms(self.tr, self.e2t)
+                self.culls.clear()
+            elif op == "hiz":
+                self.depth = scene.synthetic_depth(int(a[0]), int(a[1]), seed=int(a[2]), rects=12)
+                vis.hiz_build(self.depth)
+                self.hz = self.oracle.Hiz(self.depth)
+            elif op == "hiz_rebuild":
+                vis.hiz_rebuild()
+            elif op == "sweep":
+                vis.sweep(int(a[0]))
+                lo = int(rng.integers(0, self.tr.shape[0] - 64))
+                exp_w = self.oracle.world_matrices(self.tr, self.e2t, lo, 64)
+                assert np.array_equal(vis.get_world(lo, 64).view(np.uint32), exp_w.view(np.uint32))
+            elif op == "fetch":
+                self.check_fetch(int(a[0]), int(a[1]), int(a[2]))
+                self.readers += 1
+            elif op == "count":
+                n = pool_result_count(vis, int(a[0]), int(a[1]))
+                assert n == self.expected(int(a[0]), int(a[1]))["count"]
+                self.readers += 1
+            elif op == "device":
+                p, v = int(a[0]), int(a[1])
+                d = dev_result(vis, p, v)
+                word = device_words(torch, d.draw_count, 1)
+                torch.cuda.synchronize()
+                vis.wait()
+                assert int(word.cpu()[0]) == self.expected(p, v)["count"]
+                self.readers += 1
+            elif op == "records":
+                self.check_fetch(int(a[0]), int(a[1]), 0)
+                self.readers += 1
+            elif op == "bases":
+                p, v = int(a[0]), int(a[1])
+                bases = vis.instance_bases(p, v)
+                assert np.array_equal(bases, np.arange(self.expected(p, v)["count"] + 1, dtype=np.uint32))
+                self.readers += 1
+            elif op in ("shard", "mask"):
+                p = self.last_pool
+                if p not in self.culls:
+                    continue
+                exp = self.expected(p, 0)
+                n = self.pools[p].shape[0]
+                if op == "shard":
+                    buf = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
+                    vis.copy_shard_device(0, buf.data_ptr(), n, index_base=7)
+                    vis.wait()
+                    host = buf.cpu().numpy().view(np.uint32)
+                    assert host[0] == exp["count"] and np.array_equal(np.sort(host[1:1 + host[0]]), exp["idx"] + 7)
+                else:
+                    words = (n + 31) // 32
+                    buf = torch.zeros(words + 1, dtype=torch.int32, device="cuda:0")
+                    vis.copy_mask_device(0, buf.data_ptr(), words)
+                    vis.wait()
+                    host = buf.cpu().numpy().view(np.uint32)
+                    bits = np.unpackbits(host[1:].view(np.uint8), bitorder="little")[:n]
+                    slots = np.sort(vis.mirror_slots(p, n)[np.flatnonzero(bits)])
+                    assert host[0] == exp["count"] and np.array_equal(slots, exp["idx"])
+                self.readers += 1
+            else:
+                raise AssertionError(f"unknown schedule operation {op}")
+
+
+def pool_result_count(vis, pool, view):
+    import ctypes
+    n = ctypes.c_uint32()
+    vis._check(vis.lib.gv_pool_result_count(vis.ctx, pool, view, ctypes.byref(n)))
+    return n.value
+
+
+def dev_result(vis, pool, view):
+    import ctypes
+    from garden_amd.lib import GvDeviceResult
+    d = GvDeviceResult()
+    vis._check(vis.lib.gv_pool_results_device(vis.ctx, pool, view, ctypes.byref(d)))
+    return d
+
+
+def device_words(torch, ptr, count):
+    class _Span:
+        pass
+    span = _Span()
+    span.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(span, device="cuda:0")
+
+
+@pytest.mark.parametrize("block", range(25))
+def test_random_schedules_of_held_back_work_match_the_oracle(oracle, block):
+    """200 random schedules (25 blocks of 8; tests/schedules.py) interleaving gv_cull_batch_begin / _end, recorded culls, deferred
+    small-pool sorts, dirty marks, moved / grown pools, pyramid builds, sweeps and readers of every kind, in two context
+    configurations; after EVERY reader the result equals the oracle's for the state at the gv_cull it reads."""
+    from garden_amd.lib import GpuVisibility
+    import schedules  # tests/schedules.py (the tests directory is on sys.path under pytest)
+    readers = 0
+    for k in range(8):
+        seed = block * 8 + k
+        schedule = schedules.generate(seed)
+        with GpuVisibility(device=0, keep_slot_order=bool(seed & 1)) as vis:
+            replay = ScheduleReplay(vis, oracle, schedule, seed)
+            try:
+                replay.run(schedule)
+            except AssertionError as e:
+                raise AssertionError(f"schedule {seed}: {e}\n{schedules.to_text(schedule)}") from e
+            readers += replay.readers
+    assert readers > 40

@@ -98,6 +98,10 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "12000", "--animate", "5", "--hier", "--mixed", "--bounds", "--ticks", "6"],
     # shadow passes from calcLightViewProj (csm_lite.hpp): three cascades batched with the main camera
     ["--entities", "150000", "--csm"],
+    # record spans: the render passes read the library's page-locked result buffer (UnsortedBuffer::meshes()), nothing is copied
+    ["--entities", "100000", "--span-records", "--ticks", "4"],
+    ["--entities", "40000", "--mixed", "--csm", "--span-records", "--mutate"],
+    ["--entities", "9000", "--animate", "2", "--span-records", "--churn", "4", "--ticks", "5"],
     ["--entities", "30000", "--csm", "--mixed", "--hier", "--mutate"],
     ["--entities", "14000", "--csm", "--animate", "2", "--ticks", "4"],
     # the kept world-matrix cache (GV_SWEEP_INCREMENTAL), checked against the oracle's chain walk every tick: itemised moves

@@ -505,3 +505,12 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, GV_RCCL_LIBRARY=transport))
     assert run.returncode == 0 and "host orchestration: ok" in run.stdout, (run.stdout + run.stderr)[-4000:]
     assert "exchange over the stub transport, 8 ranks: ok" in run.stdout, run.stdout[-2000:]
+    # the random schedules the GPU tier checks against the oracle (tests/schedules.py), replayed here under the sanitizers
+    import schedules
+    paths = []
+    for seed in range(200):
+        path = tmp_path / f"schedule_{seed}.txt"
+        path.write_text(schedules.to_text(schedules.generate(seed)))
+        paths.append(str(path))
+    replay = subprocess.run([exe, *paths], capture_output=True, text=True, timeout=1800)
+    assert replay.returncode == 0 and "schedules: 200 replayed ok" in replay.stdout, (replay.stdout + replay.stderr)[-4000:]

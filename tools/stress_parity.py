@@ -26,11 +26,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--hiz-share", type=int, default=3, help="every N-th view is a perspective view with Hi-Z on (3: a third of the views; 1: all of them)")
     ap.add_argument("--depth", default="1024x512", help="frame size of the depth image, WxH (sizes not divisible by 64 take the any-size pyramid kernels)")
+    ap.add_argument("--depth-kind", default="walls", choices=["walls", "noise"],
+                    help="walls: scene.synthetic_depth (cfg3's image); noise: scene.noise_depth — per-block occluders among the entities, so "
+                         "that the occlusion queries are decided at levels 0-2 instead of by the coarse-level exits")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     threads = os.cpu_count() or 1
     dw, dh = (int(v) for v in args.depth.lower().split("x"))
-    depth = scene.synthetic_depth(dw, dh)
+    depth = scene.noise_depth(dw, dh, seed=scene.SEED + args.seed) if args.depth_kind == "noise" else scene.synthetic_depth(dw, dh)
     hz = oracle.Hiz(depth)
     hz16 = oracle.Hiz(depth, rg16f=True)
     checked = failures = 0
