@@ -513,9 +513,13 @@ def main():
         return None
 
     def fence():
+        # (drain first: the library's exchange runs on its own RCCL communicator and stream; a torch.distributed collective is never
+        # enqueued while kernels of the other communicator are still in flight — two communicators' kernels resident at once have no
+        # agreed order between the ranks)
+        torch.cuda.synchronize()
         if exchange:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def timed_steps(run, steps, group=1):
         """Wall clock over `steps` frames between two fences (the contract's number) + one event per `group` frames on the
@@ -877,6 +881,12 @@ def main():
             ab_h = algorithmic_bytes(wl, n, survivors_h, gh["draw_count"], hard)
             hard_depth["frac"] = ab_h["cull"] / (hard_depth["cull_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if hard_depth["cull_kernel_ms"] > 0 else None
             hard_depth["algorithmic_bytes_per_launch"] = ab_h["cull"]
+            try:  # counter bytes of the same kernel on this image, collected by tools/collect_traffic.sh (only while the kernel sources match)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if tj.get("_kernel_source_sha") == kernel_source_sha() and "cfg3_hard_depth" in tj and n == tj["cfg3_hard_depth"].get("entities"):
+                    hard_depth["traffic"] = tj["cfg3_hard_depth"]["cull_kernel_hbm_bytes_per_launch"]
+            except (OSError, ValueError):
+                pass
             if not hard_depth["visible_set_bit_identical"]:
                 emit({"error": "cfg3 on the hard depth image: results differ from the CPU oracle", "variant": hard_depth})
                 leave(1)
@@ -1002,6 +1012,8 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = {"cfg5": "cfg2_at_10M", "cfg2": "cfg2_at_10M"}.get(args.workload, args.workload)
+                if args.workload == "cfg3" and args.depth == "noise":
+                    key = "cfg3_hard_depth"
                 entry = tj.get(key, {})
                 now = kernel_source_sha()
                 traffic_source = {"file": "profiles/traffic.json", "entry": key, "collected": tj.get("_collected"),

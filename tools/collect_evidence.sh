@@ -47,12 +47,22 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
 } > $out/sort_probe.txt 2>&1
 {
   echo "# tests/cpp/headless_tick --mode gpu --ticks 2000 <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the drop-in's prepare phase)"
-  for a in "--entities 2000" "--entities 10000" "--entities 10000 --copy-records" "--entities 100000" "--entities 100000 --copy-records" "--entities 10000 --mixed" "--entities 10000 --mixed --csm" "--entities 10000 --hier --world --animate 50 --itemised"; do
+  for a in "--entities 2000" "--entities 10000" "--entities 10000 --span-records" "--entities 10000 --copy-records" "--entities 100000" "--entities 100000 --span-records" "--entities 100000 --copy-records" "--entities 10000 --mixed" "--entities 10000 --mixed --span-records" "--entities 10000 --mixed --csm" "--entities 10000 --hier --world --animate 50 --itemised"; do
     echo "## $a"
     GV_TICK_BREAKDOWN=1 ./tests/cpp/build/headless_tick --mode gpu --ticks 2000 $a 2>&1 | grep -E "prepare us"
   done
-  echo "# round 1 (profiles/r01k_tick_*): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203; round 2 (profiles/r02_tick.txt, records into page-locked engine vectors): 2 k 21-22, 10 k 33.8-36, 100 k 161-173, --mixed --csm 76-86"
-} > $out/r03_tick.txt 2>&1
+  echo "# --span-records (round 4): the render passes read the library's page-locked result buffer (UnsortedBuffer::meshes()); nothing is copied into combinedMeshes"
+  echo "# round 1 (profiles/r01k_tick_*): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203; round 2 (profiles/r02_tick.txt, records into page-locked engine vectors): 2 k 21-22, 10 k 33.8-36, 100 k 161-173, --mixed --csm 76-86; round 3 (profiles/r03_tick.txt, engine vectors never page-locked): 100 k 216"
+} > $out/r04_tick.txt 2>&1
+{
+  echo "# cfg3 on the HARD depth image (bench.py --depth noise: per-8x8-block occluders among the entities), level 1 of the pyramid virtual (default) / stored"
+  for e in "" "GV_DEBUG_STORE_HIZ_LEVEL1=1"; do
+    echo "## ${e:-default (level 1 virtual)}"
+    env $e python3 bench.py --depth noise --no-cpu-baseline --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f  cull kernel %.4f ms  frac %.3f  visible %.4f  frame kernels %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['visible_fraction'], d['config']['frame_kernel_ms']))"
+    echo "## ${e:-default (level 1 virtual)}, the walls (SURVEY.md 8d)"
+    env $e python3 bench.py --no-cpu-baseline --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f  cull kernel %.4f ms  frac %.3f  visible %.4f  frame kernels %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['visible_fraction'], d['config']['frame_kernel_ms']))"
+  done
+} > $out/r04_hard_depth.txt 2>&1
 {
   echo "# tools/hiz_sizes.py: pyramid rebuild by frame size, wall clock over 300 back-to-back rebuilds (us)"
   timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
@@ -62,10 +72,10 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
   GV_DEBUG_HIZ_NO_FUSED3=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
   echo "# ... and without the tail kernel either (GV_DEBUG_HIZ_NO_TAIL=1: one launch per level all the way, the round-1 form for such sizes)"
   GV_DEBUG_HIZ_NO_FUSED3=1 GV_DEBUG_HIZ_NO_TAIL=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-} > $out/r03_hiz_sizes.txt 2>&1
+} > $out/r04_hiz_sizes.txt 2>&1
 {
   echo "# tools/multiview_bench.py: main camera + 3 cascades over 10 M entities, one batched pass vs one pass per view (ms per frame; kernel us per frame)"
   timeout 300 python3 tools/multiview_bench.py 2>&1 | grep -E "batched|separate"
-} > $out/r03_multiview.txt 2>&1
+} > $out/r04_multiview.txt 2>&1
 python3 bench.py > $out/default_bench_line.json 2> $out/default.err
 tail -c 600 $out/default.err

@@ -6,8 +6,8 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc
 mkdir -p gpurun_out/pmc
-for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds" "cfg4"; do
-  tag=$(echo $wl | cut -d" " -f1); case "$wl" in *block-bounds*) tag=${tag}bb;; esac
+for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds" "cfg4" "cfg3 --depth noise"; do
+  tag=$(echo $wl | cut -d" " -f1); case "$wl" in *block-bounds*) tag=${tag}bb;; *noise*) tag=${tag}hard;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc/${tag}_$c -- python3 bench.py --workload $wl --no-cpu-baseline --no-parity --steps 5 --warmup 2 > gpurun_out/pmc/${tag}_$c.log 2>&1
   done

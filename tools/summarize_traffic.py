@@ -54,6 +54,12 @@ w3, _ = counter_mean("cfg3", "WRITE_SIZE", PLAIN)
 out["cfg3"] = {"entities": N, "FETCH_SIZE_KB": f3, "WRITE_SIZE_KB": w3, "launches": n3,
                "cull_kernel_hbm_bytes_per_launch": f3 * 1024 * factor + w3 * 1024,
                "cull_kernel_hbm_bytes_per_launch_uncalibrated": f3 * 1024 + w3 * 1024}
+if newest("cfg3hard_FETCH_SIZE/*/*counter_collection.csv"):  # cfg3 on scene.noise_depth (bench.py --depth noise): the queries reach levels 0-2
+    fh, nh = counter_mean("cfg3hard", "FETCH_SIZE", PLAIN)
+    wh, _ = counter_mean("cfg3hard", "WRITE_SIZE", PLAIN)
+    out["cfg3_hard_depth"] = {"entities": N, "FETCH_SIZE_KB": fh, "WRITE_SIZE_KB": wh, "launches": nh,
+                              "cull_kernel_hbm_bytes_per_launch": fh * 1024 * factor + wh * 1024,
+                              "cull_kernel_hbm_bytes_per_launch_uncalibrated": fh * 1024 + wh * 1024}
 if newest("cfg3bb_FETCH_SIZE/*/*counter_collection.csv"):
     fb, nb = counter_mean("cfg3bb", "FETCH_SIZE", BOUNDED)
     wb, _ = counter_mean("cfg3bb", "WRITE_SIZE", BOUNDED)
@@ -70,7 +76,7 @@ print(json.dumps(out, indent=1))
 
 with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
     fo.write("workload,kernel,counter,mean_value_KB,launches\n")
-    for wl in ("cfg2", "cfg3", "cfg3bb", "cfg4"):
+    for wl in ("cfg2", "cfg3", "cfg3hard", "cfg3bb", "cfg4"):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             f = newest(f"{wl}_{counter}/*/*counter_collection.csv")
             if not f:
