@@ -305,6 +305,9 @@ def main():
                     help="cfg3 depth image: SURVEY.md §8d's 256 walls (default), or per-8x8-block occluders among the entities "
                          "(scene.noise_depth: the coarse-level exits of the occlusion query decide almost nothing; timed beside the "
                          "headline as config.hard_depth_variant when the headline runs on the walls)")
+    ap.add_argument("--no-hard-depth-variant", action="store_true",
+                    help="skip config.hard_depth_variant. Skipped by itself under rocprofv3: its launches are the dominant kernel under the "
+                         "same name, on another depth image — they would mix into the profiler's per-kernel average and counters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -840,7 +843,13 @@ def main():
     # cfg3 on a HARD depth image: per-8x8-block occluders among the entities instead of 256 walls centimetres from
     # the camera — what the occlusion query costs when its coarse-level exits stop deciding. Own context, same pools and view.
     hard_depth = None
-    if world == 1 and wl["hiz"] and args.depth == "walls" and not args.block_bounds:
+    under_profiler = "ROCPROF_OUTPUT_PATH" in os.environ or "rocprofiler-sdk-tool" in os.environ.get("LD_PRELOAD", "") or \
+        any(k.startswith("ROCPROF_") for k in os.environ)
+    if world == 1 and wl["hiz"] and args.depth == "walls" and not args.block_bounds and (args.no_hard_depth_variant or under_profiler):
+        hard_depth = dict(skipped="--no-hard-depth-variant" if args.no_hard_depth_variant else
+                          "under rocprofv3: the variant's launches are the dominant kernel under the same name on another depth image and would mix "
+                          "into the profiler's per-kernel average; run `bench.py --depth noise` under the profiler for them (profiles/r04_cfg3hard_*)")
+    elif world == 1 and wl["hiz"] and args.depth == "walls" and not args.block_bounds:
         hard = scene.noise_depth(HIZ_SIZE, HIZ_SIZE)
         vh = GpuVisibility(device=local_rank, profile_cull_only=True, linear_scan=True, hiz_rg16f=args.hiz_rg16f)
         vh.bind_transforms(sc.transforms, sc.entity_to_transform)

@@ -374,12 +374,16 @@ struct Context {
     // gv_exchange_visible: library-owned rows, sized from the headers of earlier frames (gv_exchange.cpp)
     struct ExchangeSlot {
         DeviceBuf<uint32_t> rows;      // [world][row_words]
+        DeviceBuf<uint32_t> shard;     // this rank's [count, indices ...] of the slot's frame (read by the collective on exchange_stream)
+        hipEvent_t produced = nullptr; // on ctx->stream behind the shard copy: exchange_stream waits for it
+        hipEvent_t done = nullptr;     // on exchange_stream behind collective + headers: GvExchangeFrame::ready_event
         PinnedBuf<uint32_t> hdr;       // [world] counts + [1] sequence word, written by exchange_headers_kernel
         uint32_t row_words = 0;
         uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};  // list entries rank r's row had room for in this slot's frame
         uint64_t frame = 0;
         bool in_flight = false;
     } exchange_slots[2];
+    hipStream_t exchange_stream = nullptr;              // gv_exchange_visible's collectives run here: the next frame's cull (ctx->stream) does not wait for the links
     uint64_t exchange_frame = 0;                        // the next frame's number
     uint32_t exchange_room[GV_EXCHANGE_MAX_RANKS] = {};  // room the next frame gives each rank
     bool exchange_need_exact = true;                    // size the next frame from its own counts

@@ -102,12 +102,23 @@ void exchange_release(GvCtx* ctx)
         ctx->exchange_comm = nullptr;
     }
     ctx->d_shard.release();
+    if (ctx->exchange_stream)
+        (void)hipStreamSynchronize(ctx->exchange_stream);
     for (auto& slot : ctx->exchange_slots) {
         slot.rows.release();
+        slot.shard.release();
         slot.hdr.release();
+        if (slot.produced)
+            (void)hipEventDestroy(slot.produced);
+        if (slot.done)
+            (void)hipEventDestroy(slot.done);
+        slot.produced = slot.done = nullptr;
         slot.in_flight = false;
         slot.row_words = 0;
     }
+    if (ctx->exchange_stream)
+        (void)hipStreamDestroy(ctx->exchange_stream);
+    ctx->exchange_stream = nullptr;
     ctx->d_xcounts.release();
     ctx->h_xcounts.release();
     ctx->exchange_frame = 0;
@@ -154,6 +165,11 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
     ctx->exchange_comm = comm;
     ctx->exchange_rank = rank;
     ctx->exchange_world = world_size;
+    GV_HIP(ctx, hipStreamCreateWithFlags(&ctx->exchange_stream, hipStreamNonBlocking));
+    for (auto& slot : ctx->exchange_slots) {
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.produced, hipEventDisableTiming));
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    }
     if (const char* m = getenv("GV_EXCHANGE_MODE")) {
         if (!strcmp(m, "p2p"))
             ctx->exchange_mode = GV_EXCHANGE_P2P;
@@ -180,21 +196,26 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
 // ctx->d_shard of every rank into rows [rank * row_words ...) of gathered_device, by the configured pattern. travel[r] (NULL:
 // row_words for all) = the leading words of rank r's row that matter: the direct patterns move exactly those, the equal-size
 // all-gather always moves whole rows.
-static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, void* gathered_device, const char* what)
+static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, void* gathered_device, const char* what,
+                         const uint32_t* shard = nullptr, hipStream_t stream = nullptr)
 {
     Rccl& r = rccl();
+    if (!shard)
+        shard = ctx->d_shard.ptr;
+    if (!stream)
+        stream = ctx->stream;
     uint32_t* rows = static_cast<uint32_t*>(gathered_device);
     const int me = ctx->exchange_rank, world = ctx->exchange_world;
     auto words_of = [&](int rank) -> size_t { return travel ? std::min<size_t>(travel[rank], row_words) : row_words; };
     if (ctx->exchange_mode == GV_EXCHANGE_ALLGATHER) {
-        const int nrc = r.AllGather(ctx->d_shard.ptr, gathered_device, row_words, kNcclUint32, ctx->exchange_comm, ctx->stream);
+        const int nrc = r.AllGather(shard, gathered_device, row_words, kNcclUint32, ctx->exchange_comm, stream);
         if (nrc != 0)
             return ctx->fail(GV_E_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(nrc));
         return GV_OK;
     }
     // the direct forms place this rank's own row with a device copy; the peers' rows arrive over the links
-    GV_HIP(ctx, hipMemcpyAsync(rows + (size_t)me * row_words, ctx->d_shard.ptr, words_of(me) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
-                               ctx->stream));
+    GV_HIP(ctx, hipMemcpyAsync(rows + (size_t)me * row_words, shard, words_of(me) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               stream));
     if (world == 1)
         return GV_OK;
     int nrc = r.GroupStart();
@@ -202,14 +223,14 @@ static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, v
         // one send/recv pair per peer inside one group: every shard crosses exactly one xGMI link, all links at once
         for (int d = 1; d < world && nrc == 0; d++) {
             const int to = (me + d) % world, from = (me - d + world) % world;
-            nrc = r.Send(ctx->d_shard.ptr, words_of(me), kNcclUint32, to, ctx->exchange_comm, ctx->stream);
+            nrc = r.Send(shard, words_of(me), kNcclUint32, to, ctx->exchange_comm, stream);
             if (nrc == 0)
-                nrc = r.Recv(rows + (size_t)from * row_words, words_of(from), kNcclUint32, from, ctx->exchange_comm, ctx->stream);
+                nrc = r.Recv(rows + (size_t)from * row_words, words_of(from), kNcclUint32, from, ctx->exchange_comm, stream);
         }
     } else {
         for (int root = 0; root < world && nrc == 0; root++)
-            nrc = r.Broadcast(root == me ? ctx->d_shard.ptr : rows + (size_t)root * row_words, rows + (size_t)root * row_words, words_of(root),
-                              kNcclUint32, root, ctx->exchange_comm, ctx->stream);
+            nrc = r.Broadcast(root == me ? shard : rows + (size_t)root * row_words, rows + (size_t)root * row_words, words_of(root),
+                              kNcclUint32, root, ctx->exchange_comm, stream);
     }
     const int erc = r.GroupEnd();
     if (nrc == 0)
@@ -277,7 +298,7 @@ static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
     for (uint32_t spins = 0; *word != seq; spins++) {
         // (normally written two frames ago; a host that runs far ahead of the device waits here, which is what bounds it)
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-            GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
             if (*word != seq)
                 return ctx->fail(GV_E_RCCL, "exchange frame %llu: the row headers never reached the host (sequence word %u, expected %u)",
                                  (unsigned long long)slot.frame, *word, seq);
@@ -342,26 +363,40 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
     for (int k = 0; k < world; k++)
         widest = std::max(widest, ctx->exchange_room[k]);
     const size_t row_words = (size_t)widest + 1;
-    if ((size_t)world * row_words > slot.rows.cap) {  // grown by half again: a list that creeps up does not reallocate every time
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (consumers of the old rows were enqueued on this stream)
-        GV_HIP(ctx, slot.rows.reserve(std::max((size_t)world * row_words, slot.rows.cap + slot.rows.cap / 2)));
+    if ((size_t)world * row_words > slot.rows.cap || row_words > slot.shard.cap) {
+        // grown by half again: a list that creeps up does not reallocate every time. (The slot's previous frame is retired — its
+        // collective has run — but consumers of its rows may still be queued on the context's stream.)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
+        if ((size_t)world * row_words > slot.rows.cap)
+            GV_HIP(ctx, slot.rows.reserve(std::max((size_t)world * row_words, slot.rows.cap + slot.rows.cap / 2)));
+        if (row_words > slot.shard.cap) {
+            GV_HIP(ctx, slot.shard.reserve(std::max(row_words, slot.shard.cap + slot.shard.cap / 2)));
+            GV_HIP(ctx, hipMemsetAsync(slot.shard.ptr, 0, slot.shard.cap * sizeof(uint32_t), ctx->stream));  // (the all-gather reads whole rows)
+        }
     }
     if (!slot.hdr.ptr) {
         GV_HIP(ctx, slot.hdr.reserve(GV_EXCHANGE_MAX_RANKS + 1));
         memset(slot.hdr.ptr, 0, (GV_EXCHANGE_MAX_RANKS + 1) * sizeof(uint32_t));
     }
-    if (int rc = reserve_shard(ctx, row_words))
-        return rc;
     uint32_t travel[GV_EXCHANGE_MAX_RANKS];
     for (int k = 0; k < world; k++) {
         slot.room[k] = ctx->exchange_room[k];
         travel[k] = 1u + ctx->exchange_room[k];
     }
-    if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, ctx->exchange_room[me], index_base))
+    // The shard is the last thing the context's stream does for this frame's list; the links are the exchange stream's business.
+    // The next frame's pyramid and cull go on behind the shard copy at once, while this list is still travelling. (The slot's shard
+    // and rows are free: retire_slot saw the headers of the frame that used them last, which its collective precedes; and work that
+    // was enqueued on the context's stream to CONSUME those rows completes in front of `produced`, which the exchange stream waits for.)
+    if (int rc = gv_results_copy_shard_device(ctx, view_index, slot.shard.ptr, ctx->exchange_room[me], index_base))
         return rc;
-    if (int rc = exchange_rows(ctx, row_words, travel, slot.rows.ptr, "gv_exchange_visible"))
+    GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));
+    GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, slot.produced, 0));
+    if (int rc = exchange_rows(ctx, row_words, travel, slot.rows.ptr, "gv_exchange_visible", slot.shard.ptr, ctx->exchange_stream))
         return rc;
-    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, (uint32_t)row_words, (uint32_t)world, slot.hdr.ptr, (uint32_t)(frame + 1), ctx->stream));
+    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, (uint32_t)row_words, (uint32_t)world, slot.hdr.ptr, (uint32_t)(frame + 1),
+                                            ctx->exchange_stream));
+    GV_HIP(ctx, hipEventRecord(slot.done, ctx->exchange_stream));
     slot.row_words = (uint32_t)row_words;
     slot.frame = frame;
     slot.in_flight = true;
@@ -381,6 +416,21 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
     out->cut_ranks = ctx->exchange_cut;
     out->exact = exact ? 1u : 0u;
     out->mode = ctx->exchange_mode;
+    out->ready_event = slot.done;
+    return GV_OK;
+}
+
+int gv_exchange_acquire(GvCtx* ctx, uint64_t frame)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "gv_exchange_acquire: gv_exchange_init has not run");
+    if (frame >= ctx->exchange_frame || frame + 2 < ctx->exchange_frame || ctx->exchange_slots[frame & 1u].frame != frame)
+        return ctx->fail(GV_E_ARG, "gv_exchange_acquire: frame %llu is not one of the last two exchanged (next: %llu)",
+                         (unsigned long long)frame, (unsigned long long)ctx->exchange_frame);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->exchange_slots[frame & 1u].done, 0));
     return GV_OK;
 }
 
@@ -403,7 +453,7 @@ int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* c
             if (int rc = retire_slot(ctx, older))
                 return rc;
         GV_HIP(ctx, hipSetDevice(ctx->device));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
         if (int rc = retire_slot(ctx, slot))
             return rc;
     }
@@ -440,6 +490,8 @@ int gv_exchange_shutdown(GvCtx* ctx)
         return GV_E_ARG;
     GV_HIP(ctx, hipSetDevice(ctx->device));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->exchange_stream)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
     gv::exchange_release(ctx);
     return GV_OK;
 }

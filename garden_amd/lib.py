@@ -79,7 +79,8 @@ GV_EXCHANGE_EXACT = 1
 class GvExchangeFrame(C.Structure):
     _fields_ = [("gathered_device", C.c_void_p), ("row_words", C.c_uint32), ("world_size", C.c_uint32), ("frame", C.c_uint64),
                 ("room", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("travelled_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("counts_frame", C.c_uint64),
-                ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64), ("exact", C.c_uint32), ("mode", C.c_uint32)]
+                ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64), ("exact", C.c_uint32), ("mode", C.c_uint32),
+                ("ready_event", C.c_void_p)]
 
 
 class GvColumn(C.Structure):
@@ -122,7 +123,7 @@ EXPORTS = [
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_counts", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_acquire", "gv_exchange_counts", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -201,6 +202,7 @@ def load():
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
     lib.gv_exchange_shards.argtypes = [P, u32, u32, P, u32, P]
     lib.gv_exchange_visible.argtypes = [P, u32, u32, u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_acquire.argtypes = [P, C.c_uint64]
     lib.gv_exchange_counts.argtypes = [P, C.c_uint64, P, C.POINTER(C.c_uint64)]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]
@@ -504,7 +506,11 @@ class GpuVisibility:
                     room=[int(f.room[r]) for r in range(w)], travelled_words=[int(f.travelled_words[r]) for r in range(w)],
                     counts_frame=None if f.counts_frame == 0xFFFFFFFFFFFFFFFF else int(f.counts_frame),
                     counts=[int(f.counts[r]) for r in range(w)], cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1],
-                    exact=bool(f.exact), mode=int(f.mode))
+                    exact=bool(f.exact), mode=int(f.mode), ready_event=f.ready_event)
+
+    def exchange_acquire(self, frame):
+        """Work enqueued on the context's stream after this call sees frame `frame`'s gathered rows (no host wait)."""
+        self._check(self.lib.gv_exchange_acquire(self.ctx, frame))
 
     def exchange_counts(self, frame, world):
         """Blocks until frame `frame`'s row headers are on the host: (counts per rank, ranks whose rows were cut)."""

@@ -332,9 +332,11 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int 
 
 /* The per-frame exchange, sized by the library: enqueues on the context's stream this rank's shard [draw_count, visible_idx +
  * index_base ...] (gv_results_copy_shard_device; the pool's gv_pool_set_index_map table applies) and its gather into a
- * library-owned device buffer of world_size rows (row r = rank r's shard, out->row_words uint32 apart). No host
- * synchronisation in the steady state: consumers order themselves behind gv_stream(ctx) and read the counts from the row
- * headers. How much of each rank's row travels is decided from the headers of an EARLIER frame, which every rank holds and which
+ * library-owned device buffer of world_size rows (row r = rank r's shard, out->row_words uint32 apart). The shard copy is the
+ * last thing gv_stream(ctx) does for the frame; the rows travel on a second stream of the library's, so the caller's next
+ * gv_hiz_build / gv_cull run while this frame's list is still on the links. No host synchronisation in the steady state: a
+ * consumer orders itself behind out->ready_event (hipStreamWaitEvent on its own stream), or calls gv_exchange_acquire(ctx,
+ * out->frame) to make gv_stream(ctx) wait, and reads the counts from the row headers. How much of each rank's row travels is decided from the headers of an EARLIER frame, which every rank holds and which
  * reach the host through pinned memory two frames later (no event, no synchronisation): rank r's list gets
  * count + max(count / 8, 1024) words of room, rounded up to 1024 — grown at once, given back when the list has shrunk by a
  * quarter. Every rank sees the same headers, so every rank derives the same sizes. Frame 0 — and the frame after a row was found
@@ -356,9 +358,13 @@ typedef struct GvExchangeFrame {
     uint64_t cut_ranks;          /* ... and bit r set when rank r's list did not fit the room its row had in that frame */
     uint32_t exact;              /* 1: this frame was sized from its own counts (host-synchronising) */
     uint32_t mode;               /* GvExchangeMode the rows travelled by */
+    void* ready_event;           /* hipEvent_t recorded behind this frame's rows: hipStreamWaitEvent(consumer stream, ready_event) */
 } GvExchangeFrame;
 #define GV_EXCHANGE_EXACT 1u
 int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
+/* Work enqueued on gv_stream(ctx) after this call sees frame `frame`'s rows (one of the last two frames): the stream waits
+ * for that frame's ready_event. No host wait. */
+int gv_exchange_acquire(GvCtx* ctx, uint64_t frame);
 /* Blocks until frame `frame`'s headers have reached the host (one of the last two frames); counts[world_size]. */
 int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks);
 

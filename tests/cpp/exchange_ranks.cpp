@@ -183,7 +183,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int id_i
             GvExchangeFrame xf;
             if (gv_exchange_visible(ctx, 0, base, 0, &xf) != GV_OK)
                 return die("gv_exchange_visible", ctx);
-            if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode)
+            if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode || !xf.ready_event)
                 return die("gv_exchange_visible: frame fields", ctx);
             rows = (const uint32_t*)xf.gathered_device;
             row_words = xf.row_words;
@@ -207,7 +207,10 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int id_i
             rows = own_rows;
             row_words = (size_t)shards_capacity + 1;
         }
-        // test-side inspection of this frame (the library's own sizing decisions do not depend on it)
+        // test-side inspection of this frame (the library's own sizing decisions do not depend on it): the rows of
+        // gv_exchange_visible travel on the library's second stream — the context's stream is told to wait for them
+        if (frame < sized_frames && gv_exchange_acquire(ctx, (uint64_t)frame) != GV_OK)
+            return die("gv_exchange_acquire", ctx);
         if (hipStreamSynchronize(stream) != hipSuccess)
             return 1;
         host.resize((size_t)ranks * row_words);

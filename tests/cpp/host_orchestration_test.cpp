@@ -548,8 +548,11 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
             ((uint32_t*)dr.visible_idx)[k] = list_value(rank, frame, k);
         GvExchangeFrame xf;
         CHECK(gv_exchange_visible(ctx, 0, 0, frame == 17 ? GV_EXCHANGE_EXACT : 0, &xf));
-        if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode)
+        if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode || !xf.ready_event)
             fail("frame fields", frame, -1);
+        CHECK(gv_exchange_acquire(ctx, (uint64_t)frame));
+        if (frame >= 3)
+            EXPECT(gv_exchange_acquire(ctx, (uint64_t)frame - 3), GV_E_ARG);  // rows long since reused
         exact_frames += xf.exact ? 1 : 0;
         cut_reports += xf.cut_ranks ? 1 : 0;
         if (xf.counts_frame != UINT64_MAX) {

@@ -77,5 +77,19 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
   echo "# tools/multiview_bench.py: main camera + 3 cascades over 10 M entities, one batched pass vs one pass per view (ms per frame; kernel us per frame)"
   timeout 300 python3 tools/multiview_bench.py 2>&1 | grep -E "batched|separate"
 } > $out/r04_multiview.txt 2>&1
+# the line an 8-GPU run prints, with 8 ranks SHARING this box's one GPU (torch over gloo, the library's exchange over the tests'
+# shared-memory transport): functional, never a measurement — what it shows is the balance of the ranks and the bytes on the links
+GV_BENCH_BACKEND=gloo timeout 1500 python3 bench.py --gpus 8 --entities 1500000 --steps 10 --warmup 2 > $out/r04_gloo8_sample_line.json 2> $out/gloo8.err
+python3 - $out/r04_gloo8_sample_line.json <<'EOF' > $out/r04_gloo8_summary.txt 2>&1
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+c = d["config"]
+print("8 ranks on ONE GPU (functional): exchange_path", c["exchange_path"], "| transport", c["exchange_transport"])
+print("visible_by_rank", d["parity"]["visible_by_rank"], "max/mean %.3f" % c["visible_max_over_mean_by_rank"])
+print("list_bytes_per_rank", c["list_bytes_per_rank"])
+print("shard_bytes_per_rank", c["shard_bytes_per_rank"], "gathered/list bytes %.3f" % c["gathered_over_list_bytes"])
+print("mode variants", {k: v.get("shard_bytes_per_rank") for k, v in (c["exchange_mode_variants"] or {}).items()})
+print("parity", {k: d["parity"][k] for k in ("visible_set_bit_identical", "is_visible_identical", "baked_model_bit_identical", "checked_ranks")})
+EOF
 python3 bench.py > $out/default_bench_line.json 2> $out/default.err
 tail -c 600 $out/default.err

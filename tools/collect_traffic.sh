@@ -13,6 +13,10 @@ for wl in "cfg3" "cfg2 --entities 10000000" "cfg3 --block-bounds" "cfg4" "cfg3 -
   done
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3 -- python3 bench.py --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3hard -- python3 bench.py --depth noise --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3hard.log 2>&1
+# the driver's own command under the profiler
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/pmc/stats_driver.log 2>&1
+env | grep -i -E "rocprof|LD_PRELOAD" > gpurun_out/pmc/plain_env.txt; rocprofv3 --kernel-trace -d gpurun_out/pmc/envprobe -- python3 -c "import os; print({k: v for k, v in os.environ.items() if 'ROCP' in k.upper() or k == 'LD_PRELOAD'})" > gpurun_out/pmc/profiler_env.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg4 -- python3 bench.py --workload cfg4 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg2 -- python3 bench.py --workload cfg2 --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/stats_cfg3bb -- python3 bench.py --block-bounds --no-cpu-baseline --no-parity > gpurun_out/pmc/stats_cfg3bb.log 2>&1

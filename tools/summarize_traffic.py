@@ -89,7 +89,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), "w") as fo:
                 if k.startswith("gv::") or "gv::" in k:
                     fo.write(f'{wl}{"@10M" if wl == "cfg2" else ""},"{k}",{counter},{sum(v) / len(v):.3f},{len(v)}\n')
 
-for wl in ("cfg2", "cfg3", "cfg4", "cfg3bb", "cfg4valu", "cfg2_10M", "cfg5shape", "default"):
+for wl in ("cfg2", "cfg3", "cfg3hard", "cfg4", "cfg3bb", "cfg4valu", "cfg2_10M", "cfg5shape", "driver", "default"):
     ks = newest(f"stats_{wl}/*/*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
