@@ -383,7 +383,8 @@ struct Context {
         uint64_t frame = 0;
         bool in_flight = false;
     } exchange_slots[2];
-    hipStream_t exchange_stream = nullptr;              // gv_exchange_visible's collectives run here: the next frame's cull (ctx->stream) does not wait for the links
+    hipStream_t exchange_stream = nullptr;              // EVERY collective of the communicator runs here (one communicator, one stream): the next frame's cull (ctx->stream) does not wait for the links
+    hipEvent_t exchange_in = nullptr, exchange_out = nullptr;  // hand-over events of the caller-owned forms (gv_exchange_shards / _masks) and the exact count exchange
     uint64_t exchange_frame = 0;                        // the next frame's number
     uint32_t exchange_room[GV_EXCHANGE_MAX_RANKS] = {};  // room the next frame gives each rank
     bool exchange_need_exact = true;                    // size the next frame from its own counts

@@ -119,6 +119,11 @@ void exchange_release(GvCtx* ctx)
     if (ctx->exchange_stream)
         (void)hipStreamDestroy(ctx->exchange_stream);
     ctx->exchange_stream = nullptr;
+    if (ctx->exchange_in)
+        (void)hipEventDestroy(ctx->exchange_in);
+    if (ctx->exchange_out)
+        (void)hipEventDestroy(ctx->exchange_out);
+    ctx->exchange_in = ctx->exchange_out = nullptr;
     ctx->d_xcounts.release();
     ctx->h_xcounts.release();
     ctx->exchange_frame = 0;
@@ -166,6 +171,8 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
     ctx->exchange_rank = rank;
     ctx->exchange_world = world_size;
     GV_HIP(ctx, hipStreamCreateWithFlags(&ctx->exchange_stream, hipStreamNonBlocking));
+    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_in, hipEventDisableTiming));
+    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_out, hipEventDisableTiming));
     for (auto& slot : ctx->exchange_slots) {
         GV_HIP(ctx, hipEventCreateWithFlags(&slot.produced, hipEventDisableTiming));
         GV_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
@@ -251,6 +258,22 @@ static int reserve_shard(GvCtx* ctx, size_t words)
     return GV_OK;
 }
 
+// The caller-owned forms promise their rows in the order of gv_stream(ctx). The collective itself still runs on the exchange stream
+// — every operation of the communicator is issued on ONE stream, in the same order on every rank — between two hand-overs: the
+// exchange stream waits for what gv_stream has produced, gv_stream waits for the rows.
+static int hand_to_exchange_stream(GvCtx* ctx)
+{
+    GV_HIP(ctx, hipEventRecord(ctx->exchange_in, ctx->stream));
+    GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, ctx->exchange_in, 0));
+    return GV_OK;
+}
+static int hand_back_from_exchange_stream(GvCtx* ctx)
+{
+    GV_HIP(ctx, hipEventRecord(ctx->exchange_out, ctx->exchange_stream));
+    GV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->exchange_out, 0));
+    return GV_OK;
+}
+
 int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const uint32_t* capacities, uint32_t index_base,
                        void* gathered_device)
 {
@@ -273,7 +296,12 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const
     const uint32_t own = capacities ? capacities[ctx->exchange_rank] : capacity;
     if (int rc = gv_results_copy_shard_device(ctx, view_index, ctx->d_shard.ptr, own, index_base))
         return rc;
-    return exchange_rows(ctx, (size_t)capacity + 1, capacities ? travel : nullptr, gathered_device, "gv_exchange_shards");
+    if (int rc = hand_to_exchange_stream(ctx))
+        return rc;
+    if (int rc = exchange_rows(ctx, (size_t)capacity + 1, capacities ? travel : nullptr, gathered_device, "gv_exchange_shards", ctx->d_shard.ptr,
+                               ctx->exchange_stream))
+        return rc;
+    return hand_back_from_exchange_stream(ctx);
 }
 
 // ---- gv_exchange_visible: rows owned and sized by the library ----
@@ -350,11 +378,14 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
         // this frame's own counts to every rank first (one word each), read on the host: the one synchronising step
         GV_HIP(ctx, ctx->d_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
         GV_HIP(ctx, ctx->h_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
-        const int nrc = r.AllGather(dres.draw_count, ctx->d_xcounts.ptr, 1, kNcclUint32, ctx->exchange_comm, ctx->stream);
+        if (int rc = hand_to_exchange_stream(ctx))  // (the count is the emit's output, on the context's stream)
+            return rc;
+        const int nrc = r.AllGather(dres.draw_count, ctx->d_xcounts.ptr, 1, kNcclUint32, ctx->exchange_comm, ctx->exchange_stream);
         if (nrc != 0)
             return ctx->fail(GV_E_RCCL, "gv_exchange_visible: ncclAllGather of the counts: %s", r.GetErrorString(nrc));
-        GV_HIP(ctx, hipMemcpyAsync(ctx->h_xcounts.ptr, ctx->d_xcounts.ptr, (size_t)world * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GV_HIP(ctx, hipMemcpyAsync(ctx->h_xcounts.ptr, ctx->d_xcounts.ptr, (size_t)world * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   ctx->exchange_stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
         for (int k = 0; k < world; k++)
             ctx->exchange_room[k] = std::max(ctx->exchange_room[k], room_for(ctx->h_xcounts.ptr[k]));
         ctx->exchange_need_exact = false;
@@ -481,7 +512,11 @@ int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void
         return rc;
     if (int rc = gv_results_copy_mask_device(ctx, view_index, ctx->d_shard.ptr, word_count))
         return rc;
-    return exchange_rows(ctx, (size_t)word_count + 1, nullptr, gathered_device, "gv_exchange_masks");
+    if (int rc = hand_to_exchange_stream(ctx))
+        return rc;
+    if (int rc = exchange_rows(ctx, (size_t)word_count + 1, nullptr, gathered_device, "gv_exchange_masks", ctx->d_shard.ptr, ctx->exchange_stream))
+        return rc;
+    return hand_back_from_exchange_stream(ctx);
 }
 
 int gv_exchange_shutdown(GvCtx* ctx)
