@@ -1121,6 +1121,40 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
     }
 }
 
+// owner[cell] of the dealing rule below, for every cell of the grid (linear id x + y * gx + z * gx * gy)
+static void deal_cells(const uint32_t grid[3], uint32_t world_size, std::vector<uint32_t>& owner)
+{
+    const uint32_t cells = grid[0] * grid[1] * grid[2];
+    std::vector<std::pair<uint64_t, uint32_t>> order(cells);
+    for (uint32_t c = 0; c < cells; c++) {
+        const uint32_t x = c % grid[0], y = (c / grid[0]) % grid[1], z = c / (grid[0] * grid[1]);
+        uint64_t code = 0;
+        for (uint32_t b = 0; b < 12; b++)
+            code |= (uint64_t)((x >> b) & 1u) << (3 * b) | (uint64_t)((y >> b) & 1u) << (3 * b + 1) | (uint64_t)((z >> b) & 1u) << (3 * b + 2);
+        order[c] = {code, c};
+    }
+    std::sort(order.begin(), order.end());
+    owner.assign(cells, 0);
+    for (uint32_t k = 0; k < cells; k++) {  // one cell per rank per round; the rotation changes from round to round
+        const uint32_t turn = (uint32_t)(((uint64_t)(k / world_size) * 2654435761ull) & 0xFFFFFFFFull) >> 16;
+        owner[order[k].second] = (uint32_t)(((uint64_t)k + turn) % world_size);
+    }
+}
+
+// the cell a position falls in (the rule of extract_owned / multi.py::tile_of_positions)
+static uint32_t cell_of(const uint32_t grid[3], double side, const float position[3])
+{
+    uint32_t t = 0, mul = 1;
+    for (int a = 0; a < 3; a++) {
+        const double cell = ((double)position[a] / side + 0.5) * (double)grid[a];
+        long long c = (cell > -9.2e18 && cell < 9.2e18) ? (long long)cell : 0;
+        c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
+        t += (uint32_t)c * mul;
+        mul *= grid[a];
+    }
+    return t;
+}
+
 // Cells in Morton (Z-curve) order of their (x, y, z) coordinates, dealt in rounds of world_size with a rotation that changes
 // from round to round: cell k of that order belongs to rank (k + h(k / world_size)) % world_size. The same table as
 // garden_amd/multi.py::cell_owners (tests compare them; the docstring there says why not plain k % world_size).
@@ -1130,22 +1164,26 @@ int gv_scene_extract_rank(const GvScene* scene, const uint32_t grid[3], double s
         (uint64_t)grid[0] * grid[1] * grid[2] > 32768u || world_size == 0 || rank >= world_size)
         return GV_E_ARG;
     try {
-        const uint32_t cells = grid[0] * grid[1] * grid[2];
-        std::vector<std::pair<uint64_t, uint32_t>> order(cells);
-        for (uint32_t c = 0; c < cells; c++) {
-            const uint32_t x = c % grid[0], y = (c / grid[0]) % grid[1], z = c / (grid[0] * grid[1]);
-            uint64_t code = 0;
-            for (uint32_t b = 0; b < 12; b++)
-                code |= (uint64_t)((x >> b) & 1u) << (3 * b) | (uint64_t)((y >> b) & 1u) << (3 * b + 1) | (uint64_t)((z >> b) & 1u) << (3 * b + 2);
-            order[c] = {code, c};
-        }
-        std::sort(order.begin(), order.end());
-        std::vector<uint32_t> owner(cells);
-        for (uint32_t k = 0; k < cells; k++) {  // one cell per rank per round; the rotation changes from round to round
-            const uint32_t turn = (uint32_t)(((uint64_t)(k / world_size) * 2654435761ull) & 0xFFFFFFFFull) >> 16;
-            owner[order[k].second] = (uint32_t)(((uint64_t)k + turn) % world_size);
-        }
+        std::vector<uint32_t> owner;
+        deal_cells(grid, world_size, owner);
         return extract_owned(scene, grid, side, owner, rank, world_size, out_tile);
+    } catch (...) {
+        return GV_E_OOM;
+    }
+}
+
+int gv_cell_owner(const uint32_t grid[3], double side, uint32_t world_size, const float* positions, uint32_t stride, uint32_t count,
+                  uint32_t* owners)
+{
+    if (!grid || !(side > 0.0) || grid[0] == 0 || grid[1] == 0 || grid[2] == 0 || (uint64_t)grid[0] * grid[1] * grid[2] > 32768u ||
+        world_size == 0 || (count && (!positions || !owners || stride < 12)))
+        return GV_E_ARG;
+    try {
+        std::vector<uint32_t> owner;
+        deal_cells(grid, world_size, owner);
+        for (uint32_t i = 0; i < count; i++)
+            owners[i] = owner[cell_of(grid, side, reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(positions) + (size_t)i * stride))];
+        return GV_OK;
     } catch (...) {
         return GV_E_OOM;
     }

@@ -122,7 +122,7 @@ EXPORTS = [
     "gv_hiz_build", "gv_hiz_rebuild", "gv_hiz_read_level", "gv_hiz_mip_count", "gv_stats", "gv_stats_reset",
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
-    "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_scene_tile_maps",
+    "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_acquire", "gv_exchange_counts", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
@@ -197,6 +197,7 @@ def load():
     lib.gv_scene_bind.argtypes = [P, P]
     lib.gv_scene_extract_tile.argtypes = [P, C.POINTER(C.c_uint32 * 3), C.c_double, u32, C.POINTER(P)]
     lib.gv_scene_extract_rank.argtypes = [P, C.POINTER(C.c_uint32 * 3), C.c_double, u32, u32, C.POINTER(P)]
+    lib.gv_cell_owner.argtypes = [C.POINTER(C.c_uint32 * 3), C.c_double, u32, P, u32, u32, P]
     lib.gv_scene_tile_maps.argtypes = [P, u32, C.POINTER(P), C.POINTER(u32), C.POINTER(P), C.POINTER(u32)]
     lib.gv_exchange_unique_id.argtypes = [P]
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
@@ -601,6 +602,17 @@ class GpuVisibility:
         a = (C.c_uint64 * GV_K_COUNT)()
         self._check(self.lib.gv_profile_samples(self.ctx, C.byref(a)))
         return {k: int(a[i]) for i, k in enumerate(KERNEL_NAMES)}
+
+
+def cell_owner(grid, side, world, positions):
+    """Rank that owns each position (float32 [n, >= 3]) under the dealing rule of gv_scene_extract_rank (gv_cell_owner)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    out = np.empty(pos.shape[0], dtype=np.uint32)
+    g = (C.c_uint32 * 3)(*[int(x) for x in grid])
+    rc = load().gv_cell_owner(C.byref(g), float(side), int(world), pos.ctypes.data, pos.strides[0], pos.shape[0], out.ctypes.data)
+    if rc != GV_OK:
+        raise GvError(rc, "gv_cell_owner: bad argument")
+    return out
 
 
 class Scene:

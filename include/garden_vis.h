@@ -469,6 +469,13 @@ int gv_scene_extract_tile(const GvScene* scene, const uint32_t grid[3], double s
  * renumbered; gv_scene_tile_maps gives the local -> world slot tables), except that free slots and meshes without a
  * transform are dealt out too (slot % world_size) instead of piling up on rank 0. grid: at most 32768 cells. */
 int gv_scene_extract_rank(const GvScene* scene, const uint32_t grid[3], double side, uint32_t rank, uint32_t world_size, GvScene** out_tile);
+/* The same dealing rule for positions an engine holds itself: owners[i] = the rank whose cells contain position i (3 floats at
+ * positions + i * stride bytes). Ownership is a matter of BALANCE, not of correctness — an entity is culled the same wherever it
+ * lives — so a moving scene re-bins at its leisure: compare a root's owner with the rank it lives on now and then, and migrate
+ * (destroy there, create here: the pools' own dirty marks) only the roots that have crossed into another rank's cell (SURVEY.md
+ * §8e: "re-bin only roots whose position crosses a cell"). Host-only, no context needed. */
+int gv_cell_owner(const uint32_t grid[3], double side, uint32_t world_size, const float* positions, uint32_t stride, uint32_t count,
+                  uint32_t* owners);
 int gv_scene_tile_maps(const GvScene* tile, uint32_t pool_id, const uint32_t** transform_global, uint32_t* transform_count,
                        const uint32_t** mesh_global, uint32_t* mesh_count);
 

@@ -476,6 +476,25 @@ def test_native_rank_extraction_equals_partition_world_with_ranks(grid, world):
     whole.close()
 
 
+def test_cell_owner_is_the_dealing_rule_of_the_partitioners():
+    """gv_cell_owner (what an engine asks when an entity has moved: whose cell is it in now?) == cell_owners()[tile_of_positions()]
+    of garden_amd/multi.py, for positions inside, on the faces of and far outside the world cube, several grids and rank counts."""
+    from garden_amd.lib import cell_owner
+    from garden_amd.multi import cell_grid, cell_owners, tile_of_positions
+    rng = np.random.Generator(np.random.PCG64(77))
+    side = 4000.0
+    pos = rng.uniform(-0.7 * side, 0.7 * side, (20000, 4)).astype(np.float32)
+    pos[:50, :3] = 0.5 * side
+    pos[50:100, :3] = -0.5 * side
+    pos[100:110, 0] = np.float32(1e30)
+    for grid, world in ((cell_grid(8), 8), ((4, 4, 2), 3), ((1, 1, 1), 1), ((16, 8, 8), 5)):
+        with np.errstate(invalid="ignore"):  # (1e30: astype(int64) of a value outside the range, which the native side reproduces)
+            want = cell_owners(grid, world)[tile_of_positions(pos[:, :3].astype(np.float64), side, grid)]
+        assert np.array_equal(cell_owner(grid, side, world, pos).astype(np.int64), want), (grid, world)
+    with pytest.raises(GvError):
+        cell_owner((0, 1, 1), side, 2, pos)
+
+
 def test_tile_extraction_of_positions_no_cell_can_hold():
     """Root positions that are +-inf (1e300 in the file), huge but finite, or far outside the world cube: the native extraction
     puts them where partition_world's numpy arithmetic puts them (astype(int64) of a value outside the int64 range is INT64_MIN
