@@ -581,6 +581,7 @@ def main():
             if native[0]:
                 if payload == "mask":
                     native_rows[0] = torch.zeros(world, 1 + mask_words(n), dtype=torch.int32, device=f"cuda:{local_rank}")
+                    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's streams are non-blocking)
                 return None
             capacity = mask_words(n) if payload == "mask" else shard_capacity(int(exact_counts.max()))
             # the direct patterns move only what each rank's list needs (every rank knows every count); the all-gather cannot
@@ -825,6 +826,7 @@ def main():
         dres = vis.results_device(0)
         count_word = device_words(dres.draw_count, 1)
         total = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; lib_stream is non-blocking)
 
         def device_consumer():
             with torch.cuda.stream(lib_stream):

@@ -340,6 +340,8 @@ class VisibleListExchange:
         self.headers = [torch.zeros(self.world, dtype=torch.int32, pin_memory=self.native) for _ in range(slots)]
         self.header_events = [None] * slots
         self.in_flight = [False] * slots
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # the zero fills ran on torch's stream; the producer stream is not ordered behind it
 
     def describe(self):
         return {"allgather": "one equal-size all-gather", "p2p": "one group of send/recv pairs with every peer",

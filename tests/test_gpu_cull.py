@@ -526,12 +526,14 @@ def test_device_side_result_accessors(gpu, oracle):
     assert k > 100
     base = 7_000_000
     dst = torch.full((sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
     gpu.copy_idx_device(0, dst.data_ptr(), sc.count, index_base=base)
     assert gpu.result_count(0) == k  # readback on the library's stream: fences the copy
     got = dst.cpu().numpy()
     assert np.array_equal(got[:k].astype(np.int64), raw["visible_idx"].astype(np.int64) + base) and np.all(got[k:] == -1)
 
     shard = torch.full((1 + sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
     gpu.copy_shard_device(0, shard.data_ptr(), sc.count, index_base=base)
     gpu.wait()
     got = shard.cpu().numpy()
@@ -540,6 +542,7 @@ def test_device_side_result_accessors(gpu, oracle):
 
     cap = 64  # too small: header still carries the true count, body is clamped
     small = torch.full((1 + cap + 8,), -1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
     gpu.copy_shard_device(0, small.data_ptr(), cap, index_base=0)
     gpu.wait()
     got = small.cpu().numpy()
@@ -801,6 +804,7 @@ def test_the_mirror_is_reordered_on_the_device_after_entity_churn(gpu, oracle, k
         assert np.array_equal(np.sort(table), np.arange(k))
         gpu.cull(0, [view])
         shard = torch.full((1 + mask_words(k),), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
         gpu.copy_mask_device(0, shard.data_ptr(), mask_words(k))
         gpu.wait()
         exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view)
@@ -1019,6 +1023,7 @@ def test_native_rccl_exchange_single_rank(oracle):
         vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
         cap = 16_384
         gathered = torch.full((1 * (1 + cap),), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
         for frame in range(3):
             vis.cull(0, [view])
             vis.exchange_shards(0, cap, 5_000_000, gathered.data_ptr())
@@ -1035,6 +1040,7 @@ def test_native_rccl_exchange_single_rank(oracle):
         for mode in (0, 1, 2):
             vis.exchange_set_mode(mode)
             rows = torch.full((1, 1 + words), -1, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
             vis.cull(0, [view])
             vis.exchange_masks(0, words, rows.data_ptr())
             vis.wait()
@@ -1113,6 +1119,7 @@ def test_deferred_sorts_of_a_small_pool_reach_every_reader(gpu, oracle):
         gpu.sort(k, descending=(k == 1))
     # 1. a device accessor of view 1 is the first reader
     dst = torch.full((sc.count,), -1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
     gpu.copy_idx_device(1, dst.data_ptr(), sc.count)
     n1 = gpu.result_count(1)
     got1 = gpu.fetch(1, write_back=False, occupancy=sc.count, order="raw")
@@ -1698,6 +1705,7 @@ def test_mask_shard_is_the_visible_list_as_bits(oracle, n, keep_slot_order):
         table = vis.mirror_slots(0, n)
         assert np.array_equal(np.sort(table), np.arange(n)) and (not keep_slot_order or np.array_equal(table, np.arange(n)))
         shard = torch.full((1 + words,), -1, dtype=torch.int32, device="cuda:0")  # poison
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
         for views, vi in (([main], 0), ([main, shadow], 1), ([main, shadow], 0)):
             vis.cull(0, views)
             torch.cuda.synchronize()
@@ -1904,6 +1912,7 @@ def test_an_occlusion_views_results_in_every_order_of_calls(oracle):
         same(vis.fetch(0, write_back=False, occupancy=n, pool_id=0), exp3, m23)
         vis.cull(0, [view])
         buf = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
         vis.copy_shard_device(0, buf.data_ptr(), n, index_base=0)
         vis.wait()
         host = buf.cpu().numpy()

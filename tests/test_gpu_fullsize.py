@@ -152,49 +152,60 @@ def test_cfg3_10m_against_the_rg16f_pyramid(oracle, flat10m):
     print(f"rg16f pyramid: {got['draw_count']} visible vs {fp32['draw_count']} with the fp32 pyramid")
 
 
-def test_cfg5_one_world_cut_into_spatial_tiles_through_the_exchange(oracle, hier10m):
-    """cfg5 pattern on one GPU: ONE 10 M hierarchical world -> partition_world -> 8 spatial tiles (roots by position,
-    descendants follow, ids remapped), each tile culled as its own pools, its list pushed through the native exchange
-    (1-rank RCCL communicator, every transport pattern) with the tile's slot -> global-slot table applied on the
-    device — the mapped union must be the whole-world ORACLE set, isVisible included."""
+def test_cfg5_one_world_dealt_to_eight_ranks_through_the_exchange(oracle, hier10m):
+    """cfg5 pattern on one GPU: ONE 10 M hierarchical world -> partition_world(ranks=8): 16 x 16 x 16 Morton-ordered cells dealt to
+    8 ranks in rotating rounds (roots by position, descendants follow, ids remapped), each rank's cells culled as ONE pool, its list
+    pushed through the library-sized exchange (gv_exchange_visible on a 1-rank RCCL communicator, every travel pattern) with
+    the rank's slot -> world-slot table applied on the device — the mapped union must be the whole-world ORACLE set, isVisible
+    included; every rank has its share of the view (round 3's octants left half the ranks with nothing to show)."""
     import torch
 
     from garden_amd.lib import GpuVisibility
-    from garden_amd.multi import partition_world, shard_capacity
+    from garden_amd.multi import cell_grid, partition_world
     sc = hier10m
     view = scene.main_camera_view()
     m2 = sc.meshes.copy()
     whole = oracle.prepare_meshes(m2, sc.transforms, sc.entity_to_transform, view, threads=THREADS)
     exp = np.sort(whole["visible_idx"].astype(np.int64))
-    part = partition_world(sc, (2, 2, 2))
-    sizes = [t.count for t in part.tiles]
-    assert sum(sizes) == sc.count and min(sizes) > sc.count // 16  # eight real tiles
-    union, is_visible = [], np.full(sc.count, 255, np.uint8)
+    part = partition_world(sc, cell_grid(8), ranks=8)
+    sizes = np.array([t.count for t in part.tiles], dtype=np.float64)
+    assert sizes.sum() == sc.count and sizes.max() / sizes.mean() < 1.1  # eight even shares (trees of 1 000 go with their roots)
+    union, counts, is_visible = [], [], np.full(sc.count, 255, np.uint8)
     with GpuVisibility(device=0) as vis:
-        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
         for t, tile in enumerate(part.tiles):
+            vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)  # (a fresh communicator per "rank": frame 0 sizes exactly)
             vis.bind_transforms(tile.transforms, tile.entity_to_transform)
             vis.bind_pool(0, tile.meshes)
             vis.hierarchy_rebuild()
             vis.set_index_map(0, part.mesh_global[t])
             vis.exchange_set_mode(t % 3)  # all-gather, grouped send/recv, per-root broadcast in turn
-            vis.cull(0, [view])
+            for frame in range(3):  # frame 0 exact, frames 1-2 sized from the headers
+                vis.cull(0, [view])
+                f = vis.exchange_visible(0, index_base=0)
+                assert f["frame"] == frame and f["exact"] == (frame == 0) and not f["cut_ranks"]
             got = vis.fetch(0, write_back=False, occupancy=tile.count)
-            cap = shard_capacity(got["draw_count"])
-            gathered = torch.zeros(1 + cap, dtype=torch.int32, device="cuda:0")
-            vis.exchange_shards(0, cap, 0, gathered.data_ptr())
-            vis.wait()
-            row = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            frame_counts, cut = vis.exchange_counts(f["frame"], 1)
+            assert frame_counts == [got["draw_count"]] and not cut and f["room"][0] >= got["draw_count"]
+
+            class _Span:
+                pass
+            span = _Span()
+            span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
+            torch.cuda.synchronize()
+            row = torch.as_tensor(span, device="cuda:0").cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             assert row[0] == got["draw_count"]
             ids = row[1:1 + row[0]]
             # the device-side table gives what the host-side map gives
             assert np.array_equal(np.sort(ids), np.sort(part.to_global(t, got["visible_idx"])))
             union.append(ids)
+            counts.append(got["draw_count"])
             is_visible[part.mesh_global[t]] = got["is_visible"]
-        vis.exchange_shutdown()
+            vis.exchange_shutdown()
     union = np.sort(np.concatenate(union))
     assert np.array_equal(union, exp) and exp.shape[0] > 100_000
     assert np.array_equal(is_visible, m2["isVisible"])
+    counts = np.array(counts, dtype=np.float64)
+    assert counts.min() > 0 and counts.max() / counts.mean() <= 1.5, counts
 
 
 def test_10m_sort_is_sorted_permutation(gpu, flat10m):

@@ -366,6 +366,7 @@ class ScheduleReplay:
                 n = self.pools[p].shape[0]
                 if op == "shard":
                     buf = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda:0")
+                    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
                     vis.copy_shard_device(0, buf.data_ptr(), n, index_base=7)
                     vis.wait()
                     host = buf.cpu().numpy().view(np.uint32)
@@ -373,6 +374,7 @@ class ScheduleReplay:
                 else:
                     words = (n + 31) // 32
                     buf = torch.zeros(words + 1, dtype=torch.int32, device="cuda:0")
+                    torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
                     vis.copy_mask_device(0, buf.data_ptr(), words)
                     vis.wait()
                     host = buf.cpu().numpy().view(np.uint32)

@@ -197,6 +197,7 @@ def test_scene_file_to_spatial_tiles_to_cull_to_exchange(oracle):
                 count = vis.result_count(0)
                 cap = shard_capacity(count)
                 gathered = torch.zeros(1 + cap, dtype=torch.int32, device="cuda:0")
+                torch.cuda.synchronize()  # (the fill runs on torch's stream; the library's stream is non-blocking: no implicit order between them)
                 vis.exchange_shards(0, cap, 0, gathered.data_ptr())
                 vis.wait()
                 row = gathered.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
