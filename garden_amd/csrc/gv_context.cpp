@@ -1259,32 +1259,6 @@ int gv_pool_result_count(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint
         return rc;
     ViewState& vs = *view_of(ctx, pool_id, view_index);
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    static const bool use_flag = getenv("GV_DEBUG_NO_DONE_FLAG") == nullptr;
-    if (use_flag && ctx->pending.empty()) {
-        // the count and a sequence word arrive in pinned memory behind everything enqueued so far; the host polls the word (6-11 us
-        // sooner than a 4-byte copy + hipStreamSynchronize on this stack: the engine-flow frame of bench.py, mesh.cpp:548)
-        if (!ctx->h_done.ptr) {
-            GV_HIP(ctx, ctx->h_done.reserve(16));
-            memset(ctx->h_done.ptr, 0, 16 * sizeof(uint32_t));
-        }
-        uint32_t* words = ctx->h_done.ptr + 4;  // (word 0 is wait_for_stream's)
-        const uint32_t seq = ++ctx->done_seq;
-        GV_HIP(ctx, launch_count_flag(vs.draw_count.ptr, words, seq, ctx->stream));
-        volatile uint32_t* word = words + 1;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool arrived = true;
-        for (uint32_t spins = 0; *word != seq; spins++)
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-                GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                arrived = *word == seq;
-                break;
-            }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (arrived) {
-            *draw_count = words[0];
-            return GV_OK;
-        }
-    }
     GV_HIP(ctx, hipMemcpyAsync(vs.h_draw_count.ptr, vs.draw_count.ptr, 4, hipMemcpyDeviceToHost, ctx->stream));
     GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain_events(ctx);

@@ -696,21 +696,6 @@ hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t str
     return hipGetLastError();
 }
 
-// gv_result_count: a view's draw count and, behind it, a sequence word into pinned host memory — the host polls the word instead
-// of paying a device-to-host copy and a stream synchronisation for four bytes (the frame of an engine whose host waits for every
-// frame's list, mesh.cpp:548)
-__global__ void count_flag_kernel(const uint32_t* __restrict__ count, uint32_t* host_words, uint32_t value)
-{
-    __hip_atomic_store(host_words, *count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_words + 1, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-hipError_t launch_count_flag(const uint32_t* count, uint32_t* host_words, uint32_t value, hipStream_t stream)
-{
-    hipLaunchKernelGGL(count_flag_kernel, dim3(1), dim3(1), 0, stream, count, host_words, value);
-    return hipGetLastError();
-}
-
 hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint32_t capacity, hipStream_t stream)
 {
     if (capacity == 0 || views == 0)

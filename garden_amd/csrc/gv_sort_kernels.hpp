@@ -107,8 +107,6 @@ hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint3
 // next one starts), the host polls that word. hipStreamSynchronize returns 6-11 us after the last store is visible on this
 // stack (tools/sync_probe.hip); the polled word is there after one more kernel boundary.
 hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t stream);
-// host_words[0] = *count, then host_words[1] = value behind a system-scope release (gv_result_count's polled read-back)
-hipError_t launch_count_flag(const uint32_t* count, uint32_t* host_words, uint32_t value, hipStream_t stream);
 
 // Scattered dirty slots as ONE packet and ONE launch (gv_reorder.hip; gv_mirror.cpp upload_*_scattered): entry k of the packet is
 // written to its mirror entry — the record, the world-cache dirty byte, the entry's bit of the active bit-plane (an atomic or /

@@ -11,6 +11,12 @@
  * include/garden/error.hpp:32-55 — the C++ shim converts). Not re-entrant per context; call from
  * the thread that runs Manager::update() (source/system/input.cpp:361-379). Matrices are
  * column-major float[16] (c0..c3), quaternions xyzw, as in include/garden/system/physics-impl.hpp:45-63.
+ *
+ * Streams: all device work is enqueued on the context's own stream (gv_stream; created hipStreamNonBlocking: it is NOT
+ * ordered against the null stream or any stream of the caller's). Device memory the caller hands in — a GV_MEM_DEVICE depth
+ * image, the destination of gv_results_copy_*_device / gv_exchange_shards / gv_exchange_masks — must be ready (its last
+ * writer finished, e.g. a fill on another stream) when the call is made, or the caller orders gv_stream() behind its producer
+ * itself (hipStreamWaitEvent(gv_stream(ctx), event)); consumers of device results order themselves behind gv_stream().
  */
 #ifndef GARDEN_VIS_H
 #define GARDEN_VIS_H
