@@ -20,7 +20,6 @@
 // All of it is HBM-bound streaming (DESIGN.md has bytes/entity per kernel); loads are 16- or 12-byte
 // per lane over SoA streams so each wave-instruction touches 1 KiB / 768 B contiguous.
 #include "gv_device.hpp"
-#include "gv_hiz_device.hpp"
 
 namespace gv {
 

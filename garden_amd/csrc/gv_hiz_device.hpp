@@ -1,6 +1,5 @@
-// gv_hiz_device.hpp — the fused six-level reduction of one 64 x 64 source tile as a device function, shared by
-// hiz_fused_kernel (gv_hiz.hip) and the launch that runs a view's deferred emit beside the next pyramid's first pass
-// (emit_hiz_kernel, gv_cull.hip). HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167), shaders/hiz.frag:23-63.
+// gv_hiz_device.hpp — the fused six-level reduction of one 64 x 64 source tile as a device function (hiz_fused_kernel,
+// gv_hiz.hip). HizRenderSystem::downsampleHiz (source/system/render/hiz.cpp:104-167), shaders/hiz.frag:23-63.
 #pragma once
 #include "gv_device.hpp"
 #include "gv_hiz_kernels.hpp"
