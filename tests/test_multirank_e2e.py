@@ -1,0 +1,109 @@
+"""The multi-GPU path end to end, one PROCESS per rank, through the product's own pieces only: every rank builds the same world,
+keeps what the dealing rule gives it (partition_world(ranks=): many Morton cells per rank — the Python twin of
+gv_scene_extract_rank), binds it with its local -> world slot table (gv_pool_set_index_map), culls, and calls
+gv_exchange_visible; every rank then holds every rank's list in WORLD slots, and their union must be the whole world's oracle
+set — for a camera that turns, cuts and comes back. The ranks share the box's GPU(s), so the rows travel through the tests'
+shared-memory transport (tests/cpp/rccl_stub, GV_RCCL_LIBRARY): everything but RCCL's own wire is the product path."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r})
+rank, world, n, frames, tmp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+import torch
+from garden_amd import scene
+from garden_amd.lib import GpuVisibility
+from garden_amd.multi import cell_grid, partition_world
+from oracle import oracle_py  # (the checker)
+
+sc = scene.shuffled_scene(scene.hierarchy_scene(n, depth=3, fanout=6, seed=9), fraction=0.3)
+part = partition_world(sc, cell_grid(world, 64), ranks=world)   # every rank cuts the same world the same way ...
+mine = part.tiles[rank]                                         # ... and keeps its own share
+devices = torch.cuda.device_count()
+id_path = os.path.join(tmp, "unique_id.bin")
+with GpuVisibility(device=rank % devices) as vis:
+    if rank == 0:
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(GpuVisibility.exchange_unique_id())
+        os.rename(id_path + ".tmp", id_path)
+    t0 = time.time()
+    while not os.path.exists(id_path):
+        if time.time() - t0 > 120:
+            raise SystemExit("no unique id from rank 0")
+        time.sleep(0.01)
+    vis.exchange_init(open(id_path, "rb").read(), rank, world)
+    vis.bind_transforms(mine.transforms, mine.entity_to_transform)
+    vis.bind_pool(0, mine.meshes)
+    vis.hierarchy_rebuild()
+    vis.set_index_map(0, part.mesh_global[rank])
+
+    class _Span:
+        pass
+
+    report = []
+    for frame in range(frames):
+        # the camera turns a little, cuts to another direction half way (lists jump: rows may be cut), then comes back
+        seed = scene.SEED + (0 if frame < frames // 2 else 777) + (frame % 3)
+        view = scene.main_camera_view(seed=seed)
+        vis.exchange_set_mode(frame % 3)
+        vis.cull(0, [view])
+        f = vis.exchange_visible(0, index_base=0)
+        counts, cut = vis.exchange_counts(f["frame"], world)  # (blocking: the test reads every frame at once)
+        vis.exchange_acquire(f["frame"])
+        vis.wait()
+        span = _Span()
+        span.__cuda_array_interface__ = {{"shape": (world * f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}}
+        rows = torch.as_tensor(span, device="cuda:%d" % (rank % devices)).cpu().numpy().view(np.uint32).reshape(world, f["row_words"])
+        whole = oracle_py.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, threads=2)
+        exp = np.sort(whole["visible_idx"].astype(np.int64))
+        got, complete = [], True
+        for r in range(world):
+            c = int(rows[r, 0])
+            assert c == counts[r]
+            delivered = min(c, f["room"][r])
+            complete = complete and delivered == c and r not in cut
+            got.append(rows[r, 1:1 + delivered].astype(np.int64))
+        union = np.sort(np.concatenate(got))
+        ok = bool(np.array_equal(union, exp)) if complete else bool(np.isin(union, exp).all() and np.unique(union).shape[0] == union.shape[0])
+        report.append(dict(frame=frame, exact=f["exact"], complete=complete, cut=cut, ok=ok, visible=int(exp.shape[0]), counts=counts,
+                           mine=int(counts[rank]), mode=f["mode"]))
+    vis.exchange_shutdown()
+print("REPORT " + json.dumps(dict(rank=rank, frames=report, share=int(mine.count))))
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(tmp_path, world):
+    stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
+    script = tmp_path / "rank.py"
+    script.write_text(WORKER.format(root=ROOT))
+    n, frames = 120_000, 8
+    env = dict(os.environ, GV_RCCL_LIBRARY=stub)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    reports = sorted((json.loads(out.split("REPORT ", 1)[1]) for out, _ in outs), key=lambda d: d["rank"])
+    shares = np.array([d["share"] for d in reports], dtype=np.float64)
+    assert shares.sum() == n and shares.max() / shares.mean() < 1.3  # (trees of 43 go with their roots)
+    complete_frames = 0
+    for k in range(frames):
+        per_rank = [d["frames"][k] for d in reports]
+        assert all(f["ok"] for f in per_rank), per_rank
+        # every rank saw the same counts and made the same decisions
+        assert len({json.dumps([f["counts"], f["exact"], f["complete"], f["cut"], f["mode"]]) for f in per_rank}) == 1, per_rank
+        assert sum(per_rank[0]["counts"]) == per_rank[0]["visible"] > 0
+        assert min(per_rank[0]["counts"]) > 0  # every rank has a share of every view
+        complete_frames += per_rank[0]["complete"]
+    assert reports[0]["frames"][0]["exact"] and complete_frames >= frames - 3  # (the cut may leave a frame or two with cut rows)
