@@ -742,30 +742,35 @@ def main():
                 out = dict(error=problem or "failed on another rank", **describe)
             return out
 
-        if timed_payload == "indices" and not args.no_mask_variant:
-            ex[0] = make_exchange("mask")
-            mask_variant = timed_variant(dict(
-                delivers="every rank holds every rank's [count, one bit per mirror entry]; the entry -> pool slot tables travelled "
-                         "once at set-up (a consumer that wants the index list expands the rows)",
-                exchange_path="c-abi (gv_exchange_masks)" if native[0] else "torch.distributed"))
-            args.payload, ex[0] = timed_payload, timed_exchange
-        if timed_native and timed_payload == "indices" and world > 1 and not args.no_mode_variants:
-            # the same frames with the rows travelling by the other patterns (A/B for the fully connected xGMI node) ...
-            mode_variants = {}
-            for mode in ("allgather", "p2p", "broadcast"):
-                if mode == args.exchange:
-                    continue
-                vis.exchange_set_mode(EXCHANGE_MODES[mode])
-                mode_variants[mode] = timed_variant(dict(exchange_path="c-abi (gv_exchange_visible)"))
-            vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
-        if timed_native and timed_payload == "indices" and not args.no_torch_variant:
-            # ... and through torch.distributed over this script's own buffers (what round 3 timed as the headline)
-            native[0] = False
-            ex[0] = make_exchange("indices")
-            torch_variant = timed_variant(dict(exchange_path="torch.distributed (garden_amd/multi.py::VisibleListExchange)",
-                                               capacity_words=ex[0].capacity))
-            ex[0].drain()
-            native[0], ex[0] = True, timed_exchange
+        def run_exchange_variants():
+            """The same frames as bit shards, by the other travel patterns and through torch.distributed — run LAST, under a watchdog
+            (guarded below): the travel patterns other than the headline's first meet real links inside this function, and a
+            collective that never returns must not take the measured line with it."""
+            nonlocal mask_variant, mode_variants, torch_variant
+            if timed_payload == "indices" and not args.no_mask_variant:
+                ex[0] = make_exchange("mask")
+                mask_variant = timed_variant(dict(
+                    delivers="every rank holds every rank's [count, one bit per mirror entry]; the entry -> pool slot tables travelled "
+                             "once at set-up (a consumer that wants the index list expands the rows)",
+                    exchange_path="c-abi (gv_exchange_masks)" if native[0] else "torch.distributed"))
+                args.payload, ex[0] = timed_payload, timed_exchange
+            if timed_native and timed_payload == "indices" and world > 1 and not args.no_mode_variants:
+                # the same frames with the rows travelling by the other patterns (A/B for the fully connected xGMI node) ...
+                mode_variants = {}
+                for mode in ("allgather", "p2p", "broadcast"):
+                    if mode == args.exchange:
+                        continue
+                    vis.exchange_set_mode(EXCHANGE_MODES[mode])
+                    mode_variants[mode] = timed_variant(dict(exchange_path="c-abi (gv_exchange_visible)"))
+                vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
+            if timed_native and timed_payload == "indices" and not args.no_torch_variant:
+                # ... and through torch.distributed over this script's own buffers (what round 3 timed as the headline)
+                native[0] = False
+                ex[0] = make_exchange("indices")
+                torch_variant = timed_variant(dict(exchange_path="torch.distributed (garden_amd/multi.py::VisibleListExchange)",
+                                                   capacity_words=ex[0].capacity))
+                ex[0].drain()
+                native[0], ex[0] = True, timed_exchange
 
     # SURVEY.md §8d: also report the rate when every TRS is re-uploaded each frame (host AoS -> mirror gather + PCIe
     # + cull). Outside the timed region; never `value`.
@@ -1122,6 +1127,26 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, sc, view, depth)
+    if exchange:
+        import threading
+
+        def bark():  # a variant's collective never came back: the line goes out with what had been measured, every rank leaves
+            if rank == 0:
+                out["config"]["variants_aborted"] = ("a variant timed beside the headline (bit shards / other travel patterns / torch.distributed) did "
+                                                     "not finish within 300 s; the line carries what had been measured before it")
+                emit(out)
+            os._exit(0)
+
+        watchdog = threading.Timer(300.0, bark)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            run_exchange_variants()
+        finally:
+            watchdog.cancel()
+        if rank == 0:
+            out["config"].update(mask_variant=mask_variant, exchange_mode_variants=mode_variants, torch_variant=torch_variant)
+    if rank == 0:
         emit(out)
     vis.close()
     leave(0)
