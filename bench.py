@@ -600,6 +600,7 @@ def main():
             return [1 + x.capacity] * world
 
         transport_note = None
+        path_fallback = [None]
         if args.exchange_path == "c-abi":
             # the product's own exchange step: RCCL bound by the library, unique id handed round by the process group
             if backend != "nccl" and "GV_RCCL_LIBRARY" not in os.environ:
@@ -608,11 +609,31 @@ def main():
                 os.environ["GV_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
             if os.environ.get("GV_RCCL_LIBRARY"):
                 transport_note = "GV_RCCL_LIBRARY=" + os.environ["GV_RCCL_LIBRARY"]
-            ids = [GpuVisibility.exchange_unique_id() if rank == 0 else None]
+            init_problem = None
+            try:
+                ids = [GpuVisibility.exchange_unique_id() if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001 — reported below, on every rank
+                ids, init_problem = [None], f"{type(e).__name__}: {e}"
             dist.broadcast_object_list(ids, src=0)
-            vis.exchange_init(ids[0], rank, world)
-            vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
-            native[0] = True
+            if ids[0] is not None:
+                try:
+                    vis.exchange_init(ids[0], rank, world)
+                    vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
+                    # one frame through it, against the exact lists, before it is trusted with the timed frames
+                    native[0] = True
+                    requested, args.payload = args.payload, "indices"
+                    try:
+                        init_problem = check_padded(step(), exact, exact_counts)
+                    finally:
+                        args.payload = requested
+                except Exception as e:  # noqa: BLE001
+                    init_problem = f"{type(e).__name__}: {e}"
+            if not all_agree(init_problem is None and ids[0] is not None):
+                # the library's own exchange did not come up on some rank: the line is still measured — through torch.distributed —
+                # and says so loudly (exchange_path "torch", exchange_path_fallback = what went wrong)
+                native[0] = False
+                path_fallback[0] = init_problem or "the library's exchange failed on another rank"
+                print(f"bench.py: rank {rank}: C-ABI exchange unavailable ({path_fallback[0]}); timing the torch.distributed path", file=sys.stderr)
 
         payload_note = None
         if args.payload == "auto":
@@ -1089,6 +1110,7 @@ def main():
                                      f"; {gathered_total} indices gathered per rank; checked against the exact all-gatherv")) if exchange else None,
                        # who runs the timed exchange: the product's own C-ABI step, or torch.distributed over this script's buffers
                        "exchange_path": (("c-abi" if timed_native else "torch") if exchange else None),
+                       "exchange_path_fallback": (path_fallback[0] if exchange else None),
                        "exchange_transport": ((transport_note or "RCCL (dlopen'ed by the library)") if exchange and timed_native else ("torch.distributed " + backend if exchange else None)),
                        "exchange_mode": args.exchange if exchange else None,
                        "exchange_payload": (args.payload + (f" ({payload_note})" if payload_note else "")) if exchange else None,

@@ -50,7 +50,8 @@ Rccl& rccl()
         if (const char* named = getenv("GV_RCCL_LIBRARY")) {
             h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
             if (!h) {
-                r.why = std::string("GV_RCCL_LIBRARY=") + named + " not loadable: " + (dlerror() ? dlerror() : "?");
+                const char* why = dlerror();  // (once: the call clears the message)
+                r.why = std::string("GV_RCCL_LIBRARY=") + named + " not loadable: " + (why ? why : "?");
                 return;
             }
         }
@@ -66,7 +67,8 @@ Rccl& rccl()
                     break;
             }
         if (!h) {
-            r.why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?");
+            const char* why = dlerror();  // (once: the call clears the message — asking twice handed std::string a NULL)
+            r.why = std::string("librccl not loadable: ") + (why ? why : "?");
             return;
         }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));

@@ -82,3 +82,16 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(GvError) as e:
         GpuVisibility(device=0)
     assert e.value.code == GV_E_NODEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_a_missing_rccl_library_is_an_error_code_not_a_crash():
+    """GV_RCCL_LIBRARY names a library that does not exist: gv_exchange_unique_id returns GV_E_RCCL (the loader asked dlerror()
+    twice — the second answer is NULL — and built a std::string from it: a segfault, found by bench.py's fallback test in round 4).
+    In a child process: the loader's verdict is per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from garden_amd import lib; h = lib.load(); b = ctypes.create_string_buffer(128); "
+            "rc = h.gv_exchange_unique_id(b); print('rc', rc); sys.exit(0 if rc == lib.GV_E_RCCL else 1)" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GV_RCCL_LIBRARY="/nonexistent/librccl_nowhere.so"))
+    assert p.returncode == 0, (p.stdout, p.stderr[-2000:])
