@@ -152,3 +152,14 @@ def test_bench_torch_exchange_path_still_runs():
                    {"GV_BENCH_BACKEND": "gloo"})
     assert d["config"]["exchange_path"] == "torch" and d["config"]["torch_variant"] is None and d["config"]["exchange_mode_variants"] is None
     assert d["parity"]["visible_set_bit_identical"]
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_the_torch_path_loudly_when_the_library_exchange_cannot_come_up():
+    """The library's exchange cannot load its transport (GV_RCCL_LIBRARY names nothing): the line is still measured — through
+    torch.distributed — and says so: exchange_path "torch", exchange_path_fallback = what went wrong; parity on every rank."""
+    d = _run_bench(["--gpus", "2", "--entities", "100000", "--steps", "3", "--warmup", "1", "--no-mask-variant"],
+                   {"GV_BENCH_BACKEND": "gloo", "GV_RCCL_LIBRARY": "/nonexistent/librccl_nowhere.so"})
+    c = d["config"]
+    assert c["exchange_path"] == "torch" and "gv_exchange_unique_id" in c["exchange_path_fallback"]
+    assert c["torch_variant"] is None and c["exchange_mode_variants"] is None and d["parity"]["visible_set_bit_identical"]
