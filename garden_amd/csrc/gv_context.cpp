@@ -411,7 +411,6 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             vs.tile_ticket_base += (uint32_t)nb;
             for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
                 ctx->views[pool_id][v].valid = false;
-            ctx->last_pool = pool_id;
             return GV_OK;
         }
         for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
@@ -460,8 +459,8 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     }
     for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)
         ctx->views[pool_id][v].valid = false;
-    ctx->last_pool = pool_id;
-    return GV_OK;
+    return GV_OK;  // (ctx->last_pool is gv_cull's to set: a recorded cull launched later — by a reader of ANOTHER pool's results — must not
+                   // turn the view-indexed calls towards its own pool; round 4, found by tools/schedule_soak.py)
 }
 
 // The culls recorded since gv_cull_batch_begin: ONE cull launch for all of them (blockIdx.y = job) and ONE emit launch
@@ -1214,6 +1213,7 @@ int gv_cull(GvCtx* ctx, uint32_t pool_id, const GvView* views, uint32_t view_cou
             return GV_OK;
         }
     }
+    ctx->last_pool = pool_id;
     return cull_launch(ctx, pool_id, vps, view_count, batched);
 }
 

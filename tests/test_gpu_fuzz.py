@@ -428,3 +428,17 @@ def test_random_schedules_of_held_back_work_match_the_oracle(oracle, block):
                 raise AssertionError(f"schedule {seed}: {e}\n{schedules.to_text(schedule)}") from e
             readers += replay.readers
     assert readers > 40
+
+
+@pytest.mark.parametrize("seed,ops", [(290, 80), (257, 80), (830, 80), (1005, 80)])
+def test_schedules_that_once_failed(oracle, seed, ops):
+    """Found by tools/schedule_soak.py (1 500 schedules, round 4): a recorded cull that is launched later — by a reader of ANOTHER
+    pool's results — turned the view-indexed calls (gv_results_copy_shard_device / _mask_device ...) towards its own pool, because
+    the launch, not gv_cull, set "the pool of the most recent gv_cull"."""
+    from garden_amd.lib import GpuVisibility
+    import schedules
+    schedule = schedules.generate(seed, ops=ops)
+    with GpuVisibility(device=0, keep_slot_order=bool(seed & 1), block_bounds=bool(seed % 5 == 3)) as vis:
+        replay = ScheduleReplay(vis, oracle, schedule, seed)
+        replay.run(schedule)
+    assert replay.readers > 5
