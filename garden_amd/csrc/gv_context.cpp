@@ -1776,6 +1776,11 @@ int gv_sweep(GvCtx* ctx, uint32_t mode)
     if (!ctx)
         return GV_E_ARG;
     if (mode == GV_SWEEP_WITH_CULL || mode == GV_SWEEP_WITH_CULL_VALU) {  // nothing to launch now: the next gv_cull carries the sweep
+        // "the next gv_cull" is a cull ISSUED from here on: culls recorded earlier in a batch are launched first, so that none of
+        // them takes the request when it is launched later (round 4, tools/schedule_soak.py: the sweep then ran over the mirror of
+        // the earlier moment and the cull it was meant for went without)
+        if (int rc = flush_recorded_culls(ctx, GV_MAX_POOLS))
+            return rc;
         ctx->sweep_with_cull = true;
         ctx->sweep_with_cull_mfma = mode == GV_SWEEP_WITH_CULL;
         return GV_OK;

@@ -703,6 +703,7 @@ static void replay_schedule(const std::string& path)
     }
     CHECK(gv_hierarchy_rebuild(ctx));
     uint32_t last_pool = 0;
+    std::vector<bool> count_only(pools.size(), false);  // the pool's last cull was a count-only view (no records to ask for)
     std::vector<float> depth;
     std::vector<uint32_t> scratch;
     while (std::getline(in, line)) {
@@ -721,17 +722,24 @@ static void replay_schedule(const std::string& path)
             CHECK(gv_wait(ctx));
         } else if (op == "sync") {
             CHECK(gv_sync(ctx));
+        } else if (op == "rebuild") {
+            CHECK(gv_hierarchy_rebuild(ctx));
+        } else if (op == "reparent") {
+            for (uint32_t s = num(0); s < num(0) + num(1); s++)
+                xf[s].parent = xf[s / 2].entity;  // a lower slot: no cycles
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, num(0), num(1)));
         } else if (op == "cull") {
             GvView views[GV_MAX_VIEWS];
             uint32_t nv = 0;
             for (size_t k = 1; k < a.size(); k++) {
                 const char kind = a[k][0];
-                views[nv] = make_view(kind == 's' ? (int8_t)(k - 1) : (int8_t)-1, kind == 'h', 1);
+                views[nv] = make_view(kind == 's' ? (int8_t)(k - 1) : (int8_t)-1, kind == 'h', kind != 'c');
                 views[nv].distance_2d = kind == 'u';
                 nv++;
             }
             CHECK(gv_cull(ctx, num(0), views, nv));
             last_pool = num(0);
+            count_only[num(0)] = a[1][0] == 'c';
         } else if (op == "sort") {
             CHECK(gv_pool_sort(ctx, num(0), num(1), (int)num(2)));
         } else if (op == "dirty_xf") {
@@ -764,11 +772,12 @@ static void replay_schedule(const std::string& path)
         } else if (op == "sweep") {
             CHECK(gv_sweep(ctx, num(0)));
             float world[12 * 8];
-            CHECK(gv_get_world(ctx, 0, 8, world));
+            if (num(0) != GV_SWEEP_WITH_CULL && num(0) != GV_SWEEP_WITH_CULL_VALU)  // (those are deferred to the next cull)
+                CHECK(gv_get_world(ctx, 0, 8, world));
         } else if (op == "fetch" || op == "records") {
             GvResult r{};
             CHECK(gv_pool_results_fetch(ctx, num(0), num(1), op == "fetch" ? (int)num(2) : 0, &r));
-            if (num(0) % 2 == 1) {
+            if (num(0) % 2 == 1 && !count_only[num(0)]) {
                 const void* records = nullptr;
                 uint32_t count = 0;
                 CHECK(gv_pool_results_records(ctx, num(0), num(1), &records, &count));

@@ -11,7 +11,9 @@ readers of every kind. ONE generator, two replayers:
 
 Text form, one operation per line (first line: `world <transforms> <pool sizes...>`):
     begin | end | wait | sync | rebuild
-    cull <pool> <kind>...          kind: m main camera, h main camera + Hi-Z, s shadow cascade, u UI-like 2-D key (1-3 views)
+    cull <pool> <kind>...          kind: m main camera, h main camera + Hi-Z, s shadow cascade, u UI-like 2-D key, c main camera
+                                   count-only (emit_records = 0: isVisible + count, no records) (1-3 views)
+    reparent <first> <count>       these transform slots were re-parented (setParent towards a lower slot): ranged GV_DIRTY_HIERARCHY
     sort <pool> <view> <0|1>       ascending | descending
     dirty_xf <first> <count>       the caller edited these transform slots (the replayer edits, then marks)
     dirty_mesh <pool> <first> <count>
@@ -19,7 +21,7 @@ Text form, one operation per line (first line: `world <transforms> <pool sizes..
     grow <pool> <extra>            slots appended (entities created): re-bind with the larger occupancy
     move_xf                        the transform pool's storage moved: re-bind
     hiz <w> <h> <seed> | hiz_rebuild
-    sweep <mode>                   GvSweepMode 0, 1, 4
+    sweep <mode>                   GvSweepMode 0, 1, 4; 2, 3: the NEXT cull also produces the world matrices (checked behind it)
     fetch <pool> <view> <0|1>      gv_pool_results_fetch (write_back)
     count <pool> <view>            gv_pool_result_count
     device <pool> <view>           gv_pool_results_device
@@ -40,6 +42,8 @@ def generate(seed, ops=60):
     # sorts, one-launch cull + emit); one pool may be larger (always launched at once)
     choices = [300, 2500, 9000, 16384, 16390, 20000, 32768, 33000, 70000]
     sizes = [int(rng.choice(choices)) for _ in range(n_pools)]
+    if rng.random() < 0.15:  # above the size at which pools at rest get block bounds by default (262 144 slots)
+        sizes[int(rng.integers(0, n_pools))] = 270000
     n_xf = max(sizes) + int(rng.integers(0, 500))
     out = [("world", n_xf, *sizes)]
     culled = {}  # pool -> list of view kinds of its last cull (still valid)
@@ -61,7 +65,7 @@ def generate(seed, ops=60):
             kinds = []
             for v in range(nviews):
                 if v == 0:
-                    kinds.append("h" if hiz and rng.random() < 0.4 else ("u" if rng.random() < 0.15 else "m"))
+                    kinds.append("h" if hiz and rng.random() < 0.4 else ("u" if rng.random() < 0.15 else ("c" if rng.random() < 0.1 and nviews == 1 else "m")))
                 else:
                     kinds.append("s")
             out.append(("cull", p, *kinds))
@@ -69,7 +73,8 @@ def generate(seed, ops=60):
             last_pool = p
         elif r < 0.44 and culled:
             p = pick_culled()
-            out.append(("sort", p, int(rng.integers(0, len(culled[p]))), int(rng.integers(0, 2))))
+            if culled[p][0] != "c":
+                out.append(("sort", p, int(rng.integers(0, len(culled[p]))), int(rng.integers(0, 2))))
         elif r < 0.52:
             first = int(rng.integers(0, n_xf))
             out.append(("dirty_xf", first, int(rng.integers(1, min(n_xf - first, 4000) + 1))))
@@ -98,13 +103,20 @@ def generate(seed, ops=60):
                 out.append(("hiz", int(rng.choice([64, 96, 256])), int(rng.choice([64, 80, 128])), int(rng.integers(0, 1000))))
                 hiz = True
         elif r < 0.74:
-            out.append(("sweep", int(rng.choice([0, 1, 4]))))
+            out.append(("sweep", int(rng.choice([0, 1, 4, 4, 2, 3]))))
         elif r < 0.76:
-            out.append((str(rng.choice(["wait", "sync"])),))
+            out.append((str(rng.choice(["wait", "sync", "rebuild"])),))
+            if out[-1][0] == "rebuild":
+                culled.clear()
+        elif r < 0.775:
+            first = int(rng.integers(1, n_xf - 1))
+            out.append(("reparent", first, int(rng.integers(1, min(n_xf - first, 24) + 1))))
         elif culled:
             p = pick_culled()
             v = int(rng.integers(0, len(culled[p])))
             kind = rng.random()
+            if culled[p][0] == "c":  # count-only: the count and the bytes are all there is
+                kind = min(kind, 0.59)
             if kind < 0.45:
                 out.append(("fetch", p, v, int(rng.integers(0, 2))))
             elif kind < 0.6:
@@ -115,7 +127,7 @@ def generate(seed, ops=60):
                 out.append(("records", p, v))
             elif kind < 0.88:
                 out.append(("bases", p, v))
-            elif last_pool in culled:
+            elif last_pool in culled and culled[last_pool][0] != "c":
                 out.append((str(rng.choice(["shard", "mask"])),))
     if batching:
         out.append(("end",))
@@ -127,3 +139,13 @@ def generate(seed, ops=60):
 
 def to_text(schedule):
     return "\n".join(" ".join(str(a) for a in op) for op in schedule) + "\n"
+
+
+def from_text(text):
+    """The inverse of to_text (numbers become ints): schedules kept as fixtures (tests/golden/schedule_*.txt)."""
+    out = []
+    for line in text.splitlines():
+        parts = line.split()
+        if parts and not parts[0].startswith("#"):
+            out.append(tuple(int(a) if a.lstrip("-").isdigit() else a for a in parts))
+    return out

@@ -223,6 +223,12 @@ class ScheduleReplay:
             vis.set_record_layout(p, RECORD_DTYPE if p % 2 == 1 else None, component_stride=m.dtype.itemsize)
         vis.hierarchy_rebuild()
         self.readers = 0
+        self.sweep_pending = False
+
+    def check_world(self):
+        lo = int(self.rng.integers(0, self.tr.shape[0] - 64))
+        exp_w = self.oracle.world_matrices(self.tr, self.e2t, lo, 64)
+        assert np.array_equal(self.vis.get_world(lo, 64).view(np.uint32), exp_w.view(np.uint32)), "world matrices"
 
     def view_of(self, kind, k):
         cam = np.asarray([*self.camera, 0.0], np.float32)
@@ -230,7 +236,7 @@ class ScheduleReplay:
             v = scene.cascade_view(seed=int(self.rng.integers(1 << 30)), size=float(self.rng.uniform(2000, 30000)), depth=60000.0, index=k % 4)
             return dict(v, camera_position=cam)
         v = scene.main_camera_view(seed=int(self.rng.integers(1 << 30)), camera_position=self.camera)
-        return dict(v, use_hiz=1 if kind == "h" else 0, distance_2d=1 if kind == "u" else 0)
+        return dict(v, use_hiz=1 if kind == "h" else 0, distance_2d=1 if kind == "u" else 0, emit_records=0 if kind == "c" else 1)
 
     def expected(self, pool, view):
         c = self.culls[pool]
@@ -258,6 +264,10 @@ class ScheduleReplay:
 
     def check_fetch(self, pool, view, write_back):
         c, exp = self.culls[pool], self.expected(pool, view)
+        if not c["views"][view].get("emit_records", 1):  # count-only view: the count and the isVisible bytes
+            got = self.vis.fetch(view, write_back=bool(write_back), occupancy=self.pools[pool].shape[0], order="raw", pool_id=pool)
+            assert got["draw_count"] == exp["count"] and np.array_equal(got["is_visible"], exp["is_visible"]), (pool, view)
+            return
         got = self.read(pool, view, write_back)
         assert got["draw_count"] == exp["count"], (pool, view, got["draw_count"], exp["count"])
         order = c["sorted"].get(view)
@@ -291,6 +301,9 @@ class ScheduleReplay:
                 vis.cull(p, views)
                 self.culls[p] = dict(meshes=self.pools[p].copy(), tr=self.tr.copy(), views=views, hz=self.hz, sorted={}, expected={})
                 self.last_pool = p
+                if self.sweep_pending:  # GV_SWEEP_WITH_CULL[_VALU]: this cull also left the world matrices
+                    self.sweep_pending = False
+                    self.check_world()
             elif op == "sort":
                 p, v, desc = int(a[0]), int(a[1]), int(a[2])
                 vis.sort(v, descending=bool(desc), pool_id=p)
@@ -332,9 +345,19 @@ class ScheduleReplay:
                 vis.hiz_rebuild()
             elif op == "sweep":
                 vis.sweep(int(a[0]))
-                lo = int(rng.integers(0, self.tr.shape[0] - 64))
-                exp_w = self.oracle.world_matrices(self.tr, self.e2t, lo, 64)
-                assert np.array_equal(vis.get_world(lo, 64).view(np.uint32), exp_w.view(np.uint32))
+                if int(a[0]) in (2, 3):
+                    self.sweep_pending = True
+                else:
+                    self.sweep_pending = False
+                    self.check_world()
+            elif op == "rebuild":
+                vis.hierarchy_rebuild()
+                self.culls.clear()
+            elif op == "reparent":
+                first, count = int(a[0]), int(a[1])
+                for s_ in range(first, first + count):  # towards a lower slot: no cycles; chains grow
+                    self.tr["parent"][s_] = self.tr["entity"][int(rng.integers(0, s_))]
+                vis.mark_dirty(1, first, count)
             elif op == "fetch":
                 self.check_fetch(int(a[0]), int(a[1]), int(a[2]))
                 self.readers += 1
@@ -430,14 +453,17 @@ def test_random_schedules_of_held_back_work_match_the_oracle(oracle, block):
     assert readers > 40
 
 
-@pytest.mark.parametrize("seed,ops", [(290, 80), (257, 80), (830, 80), (1005, 80)])
-def test_schedules_that_once_failed(oracle, seed, ops):
-    """Found by tools/schedule_soak.py (1 500 schedules, round 4): a recorded cull that is launched later — by a reader of ANOTHER
-    pool's results — turned the view-indexed calls (gv_results_copy_shard_device / _mask_device ...) towards its own pool, because
-    the launch, not gv_cull, set "the pool of the most recent gv_cull"."""
+@pytest.mark.parametrize("seed", [290, 257, 830, 960])
+def test_schedules_that_once_failed(oracle, seed):
+    """Found by tools/schedule_soak.py (1 500 schedules, round 4; kept as text: tests/golden/schedule_<seed>.txt): a recorded cull
+    that is launched later — by a reader of ANOTHER pool's results — turned the view-indexed calls (gv_results_copy_shard_device /
+    _mask_device ...) towards its own pool, because the launch, not gv_cull, set "the pool of the most recent gv_cull". Schedule 960: a cull recorded BEFORE
+    gv_sweep(GV_SWEEP_WITH_CULL) took the request when it was launched later, and the cull it was meant for left no world matrices."""
+    import os
     from garden_amd.lib import GpuVisibility
     import schedules
-    schedule = schedules.generate(seed, ops=ops)
+    path = os.path.join(os.path.dirname(__file__), "golden", f"schedule_{seed}.txt")
+    schedule = schedules.from_text(open(path).read())
     with GpuVisibility(device=0, keep_slot_order=bool(seed & 1), block_bounds=bool(seed % 5 == 3)) as vis:
         replay = ScheduleReplay(vis, oracle, schedule, seed)
         replay.run(schedule)
