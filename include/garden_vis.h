@@ -153,7 +153,10 @@ int gv_pool_bind_columns(GvCtx* ctx, uint32_t pool_id, const GvMeshColumns* colu
  * A slot whose count is 0 is treated exactly like the reference treats readyCount == 0 (mesh.cpp:158-165): not drawn,
  * isVisible = false; GvResult.instance_count becomes the sum of the counts of the drawn meshes (mesh.cpp:174).
  * Same lifetime rules as gv_pool_bind (re-issue when the storage may have moved); changed counts are reported with
- * gv_mark_dirty(GV_DIRTY_MESH). data == NULL removes the column (every slot counts 1 again). */
+ * gv_mark_dirty(GV_DIRTY_MESH). data == NULL removes the column (every slot counts 1 again).
+ * Which meshes are DRAWN is decided by the counts as mirrored at the cull; instance_count and the instance bases are summed on the
+ * host from the column as it stands when the results are fetched (the reference reads getInstancesAsync at draw time too,
+ * mesh.cpp:596): change counts between frames — after a frame's results have been read, before the next gv_cull — not in between. */
 int gv_pool_bind_ready(GvCtx* ctx, uint32_t pool_id, const void* data, uint32_t stride, uint32_t width);
 
 typedef enum GvDirtyKind {

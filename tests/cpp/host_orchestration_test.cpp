@@ -666,6 +666,7 @@ static void exchange_in_threads(int ranks)
 // marks / re-binds / pyramid builds — stays inside its buffers (ASan) whatever the order of calls. ----
 static void replay_schedule(const std::string& path)
 {
+    auto aligned = [](std::vector<uint8_t>& v) { return reinterpret_cast<void*>(((uintptr_t)v.data() + 15) & ~(uintptr_t)15); };
     std::ifstream in(path);
     std::string line;
     if (!std::getline(in, line)) {
@@ -677,8 +678,14 @@ static void replay_schedule(const std::string& path)
     uint32_t n_xf = 0;
     head >> word >> n_xf;
     std::vector<uint32_t> sizes;
-    for (uint32_t v; head >> v;)
-        sizes.push_back(v);
+    bool exchange = false;
+    for (std::string t; head >> t;) {
+        if (t == "x")
+            exchange = true;
+        else
+            sizes.push_back((uint32_t)std::stoul(t));
+    }
+    exchange = exchange && std::getenv("GV_RCCL_LIBRARY") != nullptr;  // (the shared-memory transport of the tests)
     World w;
     w.build(n_xf, 0);
     std::vector<std::vector<Mesh>> pools;
@@ -701,7 +708,24 @@ static void replay_schedule(const std::string& path)
         if (p % 2 == 1)
             CHECK(gv_pool_set_record_layout(ctx, p, &rl));
     }
+    std::vector<std::vector<uint8_t>> ready(pools.size());
+    for (uint32_t p = 0; p < pools.size(); p++)
+        if (p % 4 == 2) {
+            ready[p].assign(pools[p].size(), 1);
+            for (size_t i = 0; i < ready[p].size(); i += 7)
+                ready[p][i] = (uint8_t)(i % 4);
+            CHECK(gv_pool_bind_ready(ctx, p, ready[p].data(), 1, 1));
+        }
     CHECK(gv_hierarchy_rebuild(ctx));
+    if (exchange) {
+        unsigned char id[GV_EXCHANGE_ID_BYTES];
+        if (gv_exchange_unique_id(id) != GV_OK) {
+            std::fprintf(stderr, "schedule %s: gv_exchange_unique_id\n", path.c_str());
+            std::exit(1);
+        }
+        CHECK(gv_exchange_init(ctx, id, 0, 1));
+    }
+    std::vector<std::vector<uint8_t>> targets(pools.size() * GV_MAX_VIEWS);  // the caller's record arrays, [pool * GV_MAX_VIEWS + view]
     uint32_t last_pool = 0;
     std::vector<bool> count_only(pools.size(), false);  // the pool's last cull was a count-only view (no records to ask for)
     std::vector<float> depth;
@@ -759,7 +783,16 @@ static void replay_schedule(const std::string& path)
             for (uint32_t k = 0; k < num(1); k++)
                 grown.push_back(w.meshes[grown.size()]);
             pools[num(0)].swap(grown);
+            for (uint32_t v = 0; v < GV_MAX_VIEWS; v++)  // record targets are too small for the grown pool: let them go first
+                if (!targets[num(0) * GV_MAX_VIEWS + v].empty()) {
+                    CHECK(gv_pool_set_record_target(ctx, num(0), v, nullptr, 0));
+                    targets[num(0) * GV_MAX_VIEWS + v].clear();
+                }
             CHECK(gv_pool_bind(ctx, num(0), pools[num(0)].data(), sizeof(Mesh), (uint32_t)pools[num(0)].size(), &ml));
+            if (!ready[num(0)].empty()) {
+                ready[num(0)].resize(pools[num(0)].size(), 1);
+                CHECK(gv_pool_bind_ready(ctx, num(0), ready[num(0)].data(), 1, 1));
+            }
         } else if (op == "move_xf") {
             std::vector<Transform> moved(xf);
             xf.swap(moved);
@@ -792,6 +825,27 @@ static void replay_schedule(const std::string& path)
             const uint32_t* bases = nullptr;
             uint32_t count = 0;
             CHECK(gv_pool_results_instance_bases(ctx, num(0), num(1), &bases, &count));
+        } else if (op == "ready") {
+            for (uint32_t k = num(1); k < num(1) + num(2); k++)
+                ready[num(0)][k] = (uint8_t)((k * 7u) % 4u);
+            CHECK(gv_mark_dirty(ctx, GV_DIRTY_MESH, (num(0) << 28) | num(1), num(2)));
+        } else if (op == "target") {
+            std::vector<uint8_t>& t = targets[num(0) * GV_MAX_VIEWS + num(1)];
+            if (num(2)) {
+                std::vector<uint8_t> fresh(pools[num(0)].size() * 64 + 16);
+                CHECK(gv_pool_set_record_target(ctx, num(0), num(1), aligned(fresh), pools[num(0)].size() * 64));
+                t.swap(fresh);  // (the previous array is let go only now: the call above replaced it as the target)
+            } else {
+                CHECK(gv_pool_set_record_target(ctx, num(0), num(1), nullptr, 0));
+                t.clear();
+            }
+        } else if (op == "exch") {
+            if (exchange) {
+                GvExchangeFrame xf;
+                CHECK(gv_exchange_visible(ctx, 0, 11, 0, &xf));
+                uint32_t counts[GV_EXCHANGE_MAX_RANKS];
+                CHECK(gv_exchange_counts(ctx, xf.frame, counts, nullptr));
+            }
         } else if (op == "shard" || op == "mask") {
             const size_t n = pools[last_pool].size();
             scratch.assign(n + 2, 0);

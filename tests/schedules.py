@@ -28,6 +28,12 @@ Text form, one operation per line (first line: `world <transforms> <pool sizes..
     records <pool> <view>          gv_pool_results_records (pools with a record layout: every odd pool id)
     bases <pool> <view>            gv_pool_results_instance_bases
     shard | mask                   gv_results_copy_shard_device / _mask_device of view 0 of the most recently culled pool
+    ready <pool> <first> <count>   per-slot ready counts changed (pools with id % 4 == 2 carry a ready column, gv_pool_bind_ready)
+    target <pool> <view> <0|1>     gv_pool_set_record_target: the caller's own array for the view's records (1) / removed (0);
+                                   pools with a record layout only (odd ids)
+    exch                           gv_exchange_visible of view 0 of the most recently culled pool (1-rank communicator; contexts of
+                                   schedules whose first line ends in `x`)
+First line: `world <transforms> <pool sizes...> [x]`.
 """
 import numpy as np
 
@@ -45,7 +51,8 @@ def generate(seed, ops=60):
     if rng.random() < 0.15:  # above the size at which pools at rest get block bounds by default (262 144 slots)
         sizes[int(rng.integers(0, n_pools))] = 270000
     n_xf = max(sizes) + int(rng.integers(0, 500))
-    out = [("world", n_xf, *sizes)]
+    exchange = rng.random() < 0.2
+    out = [("world", n_xf, *sizes, "x")] if exchange else [("world", n_xf, *sizes)]
     culled = {}  # pool -> list of view kinds of its last cull (still valid)
     batching = False
     last_pool = None
@@ -111,6 +118,18 @@ def generate(seed, ops=60):
         elif r < 0.775:
             first = int(rng.integers(1, n_xf - 1))
             out.append(("reparent", first, int(rng.integers(1, min(n_xf - first, 24) + 1))))
+        elif r < 0.79:
+            with_ready = [p for p in range(n_pools) if p % 4 == 2]
+            if with_ready:
+                p = int(rng.choice(with_ready))
+                first = int(rng.integers(0, sizes[p]))
+                out.append(("ready", p, first, int(rng.integers(1, min(sizes[p] - first, 2000) + 1))))
+                culled.pop(p, None)  # instance counts / bases are summed from the column as it stands at the fetch: results of this
+                                     # pool are read before its counts change or after its next cull (include/garden_vis.h)
+        elif r < 0.805:
+            odd = [p for p in range(n_pools) if p % 2 == 1]
+            if odd:
+                out.append(("target", int(rng.choice(odd)), int(rng.integers(0, 3)), int(rng.integers(0, 2))))
         elif culled:
             p = pick_culled()
             v = int(rng.integers(0, len(culled[p])))
@@ -128,7 +147,7 @@ def generate(seed, ops=60):
             elif kind < 0.88:
                 out.append(("bases", p, v))
             elif last_pool in culled and culled[last_pool][0] != "c":
-                out.append((str(rng.choice(["shard", "mask"])),))
+                out.append((str(rng.choice(["shard", "mask", "exch"] if exchange else ["shard", "mask"])),))
     if batching:
         out.append(("end",))
     for p in sorted(culled):  # every result still standing is read at the end

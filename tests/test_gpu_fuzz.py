@@ -205,6 +205,9 @@ class ScheduleReplay:
         self.vis, self.oracle = vis, oracle
         self.rng = np.random.Generator(np.random.PCG64(0xBEEF + seed))
         _, n_xf, *sizes = schedule[0]
+        self.exchange = bool(sizes) and sizes[-1] == "x"
+        if self.exchange:
+            sizes = sizes[:-1]
         base = scene.flat_scene(n_xf, seed=100 + seed)
         self.tr, self.e2t = base.transforms, np.asarray(base.entity_to_transform, dtype=np.uint32)
         self.pools = []
@@ -214,6 +217,8 @@ class ScheduleReplay:
                 m = m[self.rng.permutation(n)]
             self.pools.append(m)
         self.hz = self.depth = None
+        self.ready = {p: self.rng.choice(np.array([0, 1, 1, 2, 3], np.uint8), m.shape[0]) for p, m in enumerate(self.pools) if p % 4 == 2}
+        self.targets = {}  # (pool, view) -> the caller's record array (gv_pool_set_record_target)
         self.culls = {}   # pool -> dict(meshes, tr, views, hz, sorted[view], expected[view] (lazily))
         self.last_pool = None
         self.camera = tuple(float(x) for x in self.rng.normal(0, 300.0, 3).astype(np.float32))
@@ -221,7 +226,11 @@ class ScheduleReplay:
         for p, m in enumerate(self.pools):
             vis.bind_pool(p, m)
             vis.set_record_layout(p, RECORD_DTYPE if p % 2 == 1 else None, component_stride=m.dtype.itemsize)
+            if p in self.ready:
+                vis.bind_ready(p, self.ready[p])
         vis.hierarchy_rebuild()
+        if self.exchange:
+            vis.exchange_init(type(vis).exchange_unique_id(), 0, 1)
         self.readers = 0
         self.sweep_pending = False
 
@@ -243,10 +252,10 @@ class ScheduleReplay:
         if view not in c["expected"]:
             m2 = c["meshes"].copy()
             v = c["views"][view]
-            exp = self.oracle.prepare_meshes(m2, c["tr"], self.e2t, v, hiz=c["hz"] if v.get("use_hiz") else None)
+            exp = self.oracle.prepare_meshes(m2, c["tr"], self.e2t, v, hiz=c["hz"] if v.get("use_hiz") else None, ready=c["ready"])
             o = np.argsort(exp["visible_idx"], kind="stable")
             c["expected"][view] = dict(idx=exp["visible_idx"][o], model=exp["baked_model"][o], dist=exp["distance_sq"][o],
-                                       count=exp["draw_count"], is_visible=m2["isVisible"].copy())
+                                       count=exp["draw_count"], is_visible=m2["isVisible"].copy(), instances=exp["instance_count"])
         return c["expected"][view]
 
     def read(self, pool, view, write_back):
@@ -256,6 +265,9 @@ class ScheduleReplay:
         if pool % 2 == 1 and got["draw_count"]:
             rec = self.vis.records(pool, view, RECORD_DTYPE)
             assert rec.shape[0] == got["draw_count"]
+            if (pool, view) in self.targets:  # the fetch left them in the caller's own array
+                mine = self.targets[(pool, view)][:rec.shape[0]]
+                assert np.array_equal(mine.view(np.uint8), rec.view(np.uint8)), ("record target", pool, view)
             stride = self.pools[pool].dtype.itemsize
             assert np.all(rec["componentOffset"] % stride == 0)
             got["visible_idx"] = (rec["componentOffset"] // stride).astype(np.uint32)
@@ -270,6 +282,7 @@ class ScheduleReplay:
             return
         got = self.read(pool, view, write_back)
         assert got["draw_count"] == exp["count"], (pool, view, got["draw_count"], exp["count"])
+        assert got["instance_count"] == exp["instances"], (pool, view, got["instance_count"], exp["instances"])
         order = c["sorted"].get(view)
         idx, model, dist = got["visible_idx"], got["baked_model"], got["distance_sq"]
         if exp["count"]:
@@ -299,7 +312,8 @@ class ScheduleReplay:
                 p, kinds = int(a[0]), a[1:]
                 views = [self.view_of(k, i) for i, k in enumerate(kinds)]
                 vis.cull(p, views)
-                self.culls[p] = dict(meshes=self.pools[p].copy(), tr=self.tr.copy(), views=views, hz=self.hz, sorted={}, expected={})
+                self.culls[p] = dict(meshes=self.pools[p].copy(), tr=self.tr.copy(), views=views, hz=self.hz, sorted={}, expected={},
+                                     ready=self.ready[p].copy() if p in self.ready else None)
                 self.last_pool = p
                 if self.sweep_pending:  # GV_SWEEP_WITH_CULL[_VALU]: this cull also left the world matrices
                     self.sweep_pending = False
@@ -331,7 +345,13 @@ class ScheduleReplay:
                 new["entity"][n:] = self.tr["entity"][n:n + extra]
                 new["aabbMin"][n:, :3], new["aabbMax"][n:, :3], new["isEnabled"][n:] = -0.5, 0.5, 1
                 self.pools[p] = new
+                for key in [k for k in self.targets if k[0] == p]:  # the arrays are too small for the grown pool: let them go first
+                    vis.set_record_target(key[0], key[1], None)
+                    del self.targets[key]
                 vis.bind_pool(p, new)
+                if p in self.ready:
+                    self.ready[p] = np.concatenate([self.ready[p], np.ones(extra, np.uint8)])
+                    vis.bind_ready(p, self.ready[p])
                 self.culls.pop(p, None)
             elif op == "move_xf":
                 self.tr = self.tr.copy()
@@ -379,7 +399,14 @@ class ScheduleReplay:
             elif op == "bases":
                 p, v = int(a[0]), int(a[1])
                 bases = vis.instance_bases(p, v)
-                assert np.array_equal(bases, np.arange(self.expected(p, v)["count"] + 1, dtype=np.uint32))
+                exp = self.expected(p, v)
+                if self.culls[p]["ready"] is None:
+                    assert np.array_equal(bases, np.arange(exp["count"] + 1, dtype=np.uint32))
+                else:  # first instance of every record, in the order the records are delivered
+                    got = self.read(p, v, 0)
+                    per = self.culls[p]["ready"][got["visible_idx"]].astype(np.uint64) if exp["count"] else np.zeros(0, np.uint64)
+                    assert np.array_equal(bases.astype(np.uint64), np.concatenate([[0], np.cumsum(per)]))
+                    assert int(bases[-1]) == exp["instances"]
                 self.readers += 1
             elif op in ("shard", "mask"):
                 p = self.last_pool
@@ -404,6 +431,33 @@ class ScheduleReplay:
                     bits = np.unpackbits(host[1:].view(np.uint8), bitorder="little")[:n]
                     slots = np.sort(vis.mirror_slots(p, n)[np.flatnonzero(bits)])
                     assert host[0] == exp["count"] and np.array_equal(slots, exp["idx"])
+                self.readers += 1
+            elif op == "ready":
+                p, first, count = int(a[0]), int(a[1]), int(a[2])
+                self.ready[p][first:first + count] = rng.choice(np.array([0, 1, 1, 2, 3], np.uint8), count)
+                vis.mark_dirty(2, first, count, pool_id=p)
+                self.culls.pop(p, None)
+            elif op == "target":
+                p, v, on = int(a[0]), int(a[1]), int(a[2])
+                if on:
+                    arr = np.zeros(self.pools[p].shape[0], RECORD_DTYPE)
+                    vis.set_record_target(p, v, arr)
+                    self.targets[(p, v)] = arr
+                else:
+                    vis.set_record_target(p, v, None)
+                    self.targets.pop((p, v), None)
+            elif op == "exch":
+                p = self.last_pool
+                if p not in self.culls or not self.exchange:
+                    continue
+                exp = self.expected(p, 0)
+                f = vis.exchange_visible(0, index_base=11)
+                counts, cut = vis.exchange_counts(f["frame"], 1)
+                torch.cuda.synchronize()
+                row = device_words(torch, f["ptr"], f["row_words"]).cpu().numpy().view(np.uint32)
+                assert counts == [exp["count"]] and row[0] == exp["count"]
+                if not cut:
+                    assert np.array_equal(np.sort(row[1:1 + row[0]]), exp["idx"] + 11)
                 self.readers += 1
             else:
                 raise AssertionError(f"unknown schedule operation {op}")
