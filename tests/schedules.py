@@ -84,11 +84,13 @@ def generate(seed, ops=60):
                 out.append(("sort", p, int(rng.integers(0, len(culled[p]))), int(rng.integers(0, 2))))
         elif r < 0.52:
             first = int(rng.integers(0, n_xf))
-            out.append(("dirty_xf", first, int(rng.integers(1, min(n_xf - first, 4000) + 1))))
+            most = n_xf // 2 if rng.random() < 0.12 else 4000  # now and then a range long enough for the device-side gather of AoS ranges
+            out.append(("dirty_xf", first, int(rng.integers(1, min(n_xf - first, most) + 1))))
         elif r < 0.59:
             p = int(rng.integers(0, n_pools))
             first = int(rng.integers(0, sizes[p]))
-            out.append(("dirty_mesh", p, first, int(rng.integers(1, min(sizes[p] - first, 3000) + 1))))
+            most = sizes[p] // 2 if rng.random() < 0.12 else 3000
+            out.append(("dirty_mesh", p, first, int(rng.integers(1, min(sizes[p] - first, most) + 1))))
         elif r < 0.62:
             p = int(rng.integers(0, n_pools))
             out.append(("move", p))
