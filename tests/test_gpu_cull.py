@@ -393,6 +393,52 @@ def test_empty_and_tiny_pools_and_derived_stride(gpu, oracle):
     assert_same(got, gv, exp, ev)
 
 
+def test_a_rank_that_owns_nothing_still_takes_part_in_the_exchange():
+    """More ranks than cells (or an empty region of the world): a rank with EMPTY pools culls nothing and still makes its
+    gv_exchange_visible calls — header 0, no entries — frame after frame, in every travel pattern; a pool that then gets entities
+    is sized up from the headers like any other."""
+    import torch
+    from garden_amd.lib import GpuVisibility
+    from garden_amd.pools import MESH_DTYPE, TRANSFORM_DTYPE
+    v = scene.main_camera_view()
+    empty = scene.Scene(np.zeros(0, MESH_DTYPE), np.zeros(0, TRANSFORM_DTYPE), np.full(1, 0xFFFFFFFF, np.uint32))
+    full = scene.flat_scene(30_000, seed=3)
+
+    class _Span:
+        pass
+
+    with GpuVisibility(device=0) as vis:
+        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
+        vis.bind_transforms(empty.transforms, empty.entity_to_transform)
+        vis.bind_pool(0, empty.meshes)
+        vis.hierarchy_rebuild()
+        for frame in range(4):
+            vis.exchange_set_mode(frame % 3)
+            vis.cull(0, [v])
+            f = vis.exchange_visible(0, index_base=5)
+            counts, cut = vis.exchange_counts(f["frame"], 1)
+            assert counts == [0] and not cut and f["row_words"] >= 1
+        vis.bind_transforms(full.transforms, full.entity_to_transform)
+        vis.bind_pool(0, full.meshes)
+        vis.hierarchy_rebuild()
+        seen_cut = False
+        for frame in range(4):
+            vis.cull(0, [v])
+            f = vis.exchange_visible(0, index_base=5)
+            counts, cut = vis.exchange_counts(f["frame"], 1)
+            got = vis.fetch(0, write_back=False, occupancy=full.count)
+            assert counts == [got["draw_count"]] and got["draw_count"] > 1024
+            seen_cut = seen_cut or bool(cut)
+            if not cut:
+                span = _Span()
+                span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
+                torch.cuda.synchronize()
+                row = torch.as_tensor(span, device="cuda:0").cpu().numpy().view(np.uint32)
+                assert row[0] == got["draw_count"] and np.array_equal(np.sort(row[1:1 + row[0]]), got["visible_idx"] + 5)
+        assert seen_cut and not cut  # the first frame with entities outgrew the empty pool's room; the library said so and re-sized
+        vis.exchange_shutdown()
+
+
 def test_hierarchy_cycle_is_rejected(gpu):
     from garden_amd.lib import GV_E_ARG, GvError
     sc = scene.hierarchy_scene(100, depth=3, fanout=3, defects=False)
