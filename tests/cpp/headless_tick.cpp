@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records]
+//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
@@ -178,6 +178,7 @@ int main(int argc, char** argv)
     bool spanRecords = false;  // --span-records: the render passes read the library's page-locked buffer (UnsortedBuffer::meshes()), no copy
     bool soaRecords = false;  // --soa-records: the GPU system fetches three arrays and fills combinedMeshes itself (no record layout)
     uint32_t churn = 0;  // --churn R: R extra rounds that destroy and create entities (itemised: no mirror rebuild asked for)
+    uint64_t seed = 0;   // --seed S: another world and another sequence of mutations (tools/tick_soak.sh)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--mode" && i + 1 < argc) mode = argv[++i];
@@ -188,6 +189,7 @@ int main(int argc, char** argv)
         else if (a == "--mutate") mutate = true;
         else if (a == "--mixed") mixed = true;
         else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
+        else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
         else if (a == "--world") world = true;
@@ -241,6 +243,7 @@ int main(int argc, char** argv)
 
         // scene: SURVEY.md §8d distribution (cube side 100 * N^(1/3), scale [0.5,2], half-extent [0.25,1])
         Rng rng;
+        rng.state += seed * 0x9E3779B97F4A7C15ull;
         const float side = 100.0f * std::cbrt((float)entities);
         std::vector<ID<Entity>> ents;
         auto spawn = [&](uint32_t i) {
@@ -371,6 +374,7 @@ int main(int argc, char** argv)
             }
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         };
+        std::vector<bool> gone(entities, false);  // destroyed: its handle in ents[] is stale (the id may be handed out again)
         auto doMutate = [&]() {
             if (toggle) {  // nothing but active-flag and parent-link changes: the systems' ranged update paths
                 for (uint32_t i = 5; i < entities; i += 53)
@@ -394,6 +398,8 @@ int main(int argc, char** argv)
                     transformSystem->setParent(ents[i], ents[i / 8]);
             for (uint32_t i = 7; i < entities; i += 101) {
                 manager.destroy(ents[i]);
+                gone[i] = true;  // (a later churn round must not take the stale handle for a live parent: with the id recycled it
+                                 //  could be the very entity being parented — "setParent: cycle", tools/tick_soak.sh seed 10)
             }
             meshSystem->markMeshesChanged();
             if (mixed) {
@@ -408,7 +414,6 @@ int main(int argc, char** argv)
         std::string why;
         double seconds = 0;
         uint32_t drawCount = 0, sortedDrawCount = 0;
-        std::vector<bool> gone(entities, false);
         auto doChurn = [&]() {  // ~1 % destroyed, ~2 % created (some under existing parents), a few flags flipped
             const uint32_t count = (uint32_t)ents.size();
             for (uint32_t k = 0; k < count / 100 + 1; k++) {

@@ -1,0 +1,31 @@
+#!/bin/bash
+# GPU box: the headless tick driver (CPU reference-path system vs the GPU drop-in, every buffer compared every tick) over many
+# seeds and flag combinations — the mirror's maintenance paths under entity churn, re-parenting, toggles, moving scenes.
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 12 flag sets)
+set -u
+cd "$(dirname "$0")/.."
+make -s -C tests/cpp
+seeds=${1:-40}
+bad=0; runs=0
+sets=(
+  "--entities 30000 --hier --mutate --churn 6"
+  "--entities 20000 --mixed --hier --churn 5 --bounds"
+  "--entities 40000 --mixed --csm --mutate"
+  "--entities 12000 --animate 5 --hier --mixed --bounds --ticks 6"
+  "--entities 9000 --animate 2 --span-records --churn 4 --ticks 5"
+  "--entities 50000 --hier --toggle"
+  "--entities 30000 --hier --animate 11 --itemised --world --mutate --ticks 4"
+  "--entities 20000 --hier --mixed --animate 5 --itemised --world --churn 3 --ticks 3"
+  "--entities 3000 --mutate --churn 9 --mixed"
+  "--entities 70000 --churn 4 --copy-records"
+  "--entities 33000 --mixed --csm --animate 7 --ticks 5 --soa-records"
+  "--entities 300000 --animate 64 --churn 2 --ticks 3"
+)
+for s in $(seq 1 "$seeds"); do
+  for a in "${sets[@]}"; do
+    runs=$((runs + 1))
+    out=$(./tests/cpp/build/headless_tick --mode both --seed "$s" $a 2>&1 | tail -1)
+    if ! echo "$out" | grep -q '"ok": true'; then bad=$((bad + 1)); echo "seed $s $a: $out" | cut -c1-600; fi
+  done
+done
+echo "tick soak: $runs runs ($seeds seeds x ${#sets[@]} flag sets), $bad failed"
