@@ -18,7 +18,7 @@ WORKER = r'''
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, {root!r})
-rank, world, n, frames, tmp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+rank, world, n, frames, tmp, how = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
 import torch
 from garden_amd import scene
 from garden_amd.lib import GpuVisibility
@@ -26,8 +26,23 @@ from garden_amd.multi import cell_grid, partition_world
 from oracle import oracle_py  # (the checker)
 
 sc = scene.shuffled_scene(scene.hierarchy_scene(n, depth=3, fanout=6, seed=9), fraction=0.3)
-part = partition_world(sc, cell_grid(world, 64), ranks=world)   # every rank cuts the same world the same way ...
-mine = part.tiles[rank]                                         # ... and keeps its own share
+grid = cell_grid(world, 64)
+side = 100.0 * n ** (1.0 / 3.0)
+if how == "native":
+    # the C-ABI's own chain: every rank parses the scene FILE, keeps its share (gv_scene_extract_rank) and binds it (gv_scene_bind
+    # installs the local -> world slot tables); the oracle culls the scene as the loader built it
+    sys.path.insert(0, os.path.join({root!r}, "tests"))
+    from garden_amd.lib import Scene
+    from oracle import scene_json_py as sj
+    from test_scene_ingest import _scene_as_aos
+    whole = Scene(sj.write_scene(sc.transforms, {{"Model": sc.meshes}}, sc.entity_to_transform), {{"Model": 0}})
+    sc = _scene_as_aos(whole)
+    mine_native = whole.extract_rank(grid, side, rank, world)
+    share = mine_native.info()["mesh_count"][0]
+else:
+    part = partition_world(sc, grid, side=side, ranks=world)   # every rank cuts the same world the same way ...
+    mine = part.tiles[rank]                                    # ... and keeps its own share
+    share = mine.count
 devices = torch.cuda.device_count()
 id_path = os.path.join(tmp, "unique_id.bin")
 with GpuVisibility(device=rank % devices) as vis:
@@ -41,10 +56,13 @@ with GpuVisibility(device=rank % devices) as vis:
             raise SystemExit("no unique id from rank 0")
         time.sleep(0.01)
     vis.exchange_init(open(id_path, "rb").read(), rank, world)
-    vis.bind_transforms(mine.transforms, mine.entity_to_transform)
-    vis.bind_pool(0, mine.meshes)
-    vis.hierarchy_rebuild()
-    vis.set_index_map(0, part.mesh_global[rank])
+    if how == "native":
+        mine_native.bind(vis)
+    else:
+        vis.bind_transforms(mine.transforms, mine.entity_to_transform)
+        vis.bind_pool(0, mine.meshes)
+        vis.hierarchy_rebuild()
+        vis.set_index_map(0, part.mesh_global[rank])
 
     class _Span:
         pass
@@ -63,8 +81,8 @@ with GpuVisibility(device=rank % devices) as vis:
         span = _Span()
         span.__cuda_array_interface__ = {{"shape": (world * f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}}
         rows = torch.as_tensor(span, device="cuda:%d" % (rank % devices)).cpu().numpy().view(np.uint32).reshape(world, f["row_words"])
-        whole = oracle_py.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, threads=2)
-        exp = np.sort(whole["visible_idx"].astype(np.int64))
+        world_result = oracle_py.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, threads=2)
+        exp = np.sort(world_result["visible_idx"].astype(np.int64))
         got, complete = [], True
         for r in range(world):
             c = int(rows[r, 0])
@@ -77,26 +95,26 @@ with GpuVisibility(device=rank % devices) as vis:
         report.append(dict(frame=frame, exact=f["exact"], complete=complete, cut=cut, ok=ok, visible=int(exp.shape[0]), counts=counts,
                            mine=int(counts[rank]), mode=f["mode"]))
     vis.exchange_shutdown()
-print("REPORT " + json.dumps(dict(rank=rank, frames=report, share=int(mine.count))))
+print("REPORT " + json.dumps(dict(rank=rank, frames=report, share=int(share), total=int(sc.count))))
 '''
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(tmp_path, world):
+@pytest.mark.parametrize("world,how", [(2, "python"), (4, "python"), (3, "native"), (8, "native")])
+def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(tmp_path, world, how):
     stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
     script = tmp_path / "rank.py"
     script.write_text(WORKER.format(root=ROOT))
     n, frames = 120_000, 8
     env = dict(os.environ, GV_RCCL_LIBRARY=stub)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path)], env=env,
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path), how], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (out, err) in zip(procs, outs):
         assert p.returncode == 0, err[-3000:]
     reports = sorted((json.loads(out.split("REPORT ", 1)[1]) for out, _ in outs), key=lambda d: d["rank"])
     shares = np.array([d["share"] for d in reports], dtype=np.float64)
-    assert shares.sum() == n and shares.max() / shares.mean() < 1.3  # (trees of 43 go with their roots)
+    assert shares.sum() == reports[0]["total"] and shares.max() / shares.mean() < 1.3  # (trees of 43 go with their roots)
     complete_frames = 0
     for k in range(frames):
         per_rank = [d["frames"][k] for d in reports]
