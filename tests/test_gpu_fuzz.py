@@ -199,10 +199,10 @@ class ScheduleReplay:
     """Replays one schedule on a context and checks every reader against the oracle evaluated on the state AT THE gv_cull it
     reads (recorded culls see the pools and the pyramid as they were when they were recorded)."""
 
-    def __init__(self, vis, oracle, schedule, seed):
+    def __init__(self, vis, oracle, schedule, seed, rg16f=False):
         import torch
         self.torch = torch
-        self.vis, self.oracle = vis, oracle
+        self.vis, self.oracle, self.rg16f = vis, oracle, rg16f
         self.rng = np.random.Generator(np.random.PCG64(0xBEEF + seed))
         _, n_xf, *sizes = schedule[0]
         self.exchange = bool(sizes) and sizes[-1] == "x"
@@ -360,7 +360,7 @@ class ScheduleReplay:
             elif op == "hiz":
                 self.depth = scene.synthetic_depth(int(a[0]), int(a[1]), seed=int(a[2]), rects=12)
                 vis.hiz_build(self.depth)
-                self.hz = self.oracle.Hiz(self.depth)
+                self.hz = self.oracle.Hiz(self.depth, rg16f=self.rg16f)
             elif op == "hiz_rebuild":
                 vis.hiz_rebuild()
             elif op == "sweep":

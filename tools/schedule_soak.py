@@ -30,8 +30,10 @@ def main():
     for seed in range(args.first, args.first + args.count):
         schedule = schedules.generate(seed, ops=args.ops)
         try:
-            with GpuVisibility(device=0, keep_slot_order=bool(seed & 1), block_bounds=bool(seed % 5 == 3)) as vis:
-                replay = ScheduleReplay(vis, oracle_py, schedule, seed)
+            rg16f, linear = seed % 7 == 1, seed % 11 == 2
+            with GpuVisibility(device=0, keep_slot_order=bool(seed & 1), block_bounds=bool(seed % 5 == 3) and not linear, hiz_rg16f=rg16f,
+                               linear_scan=linear) as vis:
+                replay = ScheduleReplay(vis, oracle_py, schedule, seed, rg16f=rg16f)
                 replay.run(schedule)
                 readers += replay.readers
         except Exception as e:  # noqa: BLE001
