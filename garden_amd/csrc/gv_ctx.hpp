@@ -480,6 +480,16 @@ void drain_events(GvCtx* ctx);
 // gv_exchange.cpp
 void exchange_release(GvCtx* ctx);            // destroys the communicator, if any
 
+// gv_context.cpp (the cull side)
+int flush_culls(GvCtx* ctx);                             // launches the culls recorded since gv_cull_batch_begin; ends the batch
+int flush_recorded_culls(GvCtx* ctx, uint32_t pool);    // ... those that read `pool` (GV_MAX_POOLS: any), recording goes on
+ViewBuffers view_buffers(ViewState& vs);
+// gv_results.cpp (the reader side)
+int flush_sorts(GvCtx* ctx);                             // flush_culls + the sorts of small pools that were asked for and not launched yet
+int wait_for_stream(GvCtx* ctx);                         // until the stream has drained (a polled word; hipStreamSynchronize as fallback)
+ViewState* view_of(GvCtx* ctx, uint32_t pool_id, uint32_t view_index);  // NULL: no valid results
+bool release_record_target(PoolState::RecordTarget& target);            // false: the range was found unmapped
+
 // gv_mirror.cpp
 int sync_mirror(GvCtx* ctx);                 // brings the device mirror up to date with the bound pools + dirty ranges
 TransformMirror xf_mirror(const GvCtx* ctx);  // the transform mirror as the kernels see it

@@ -477,7 +477,7 @@ def test_dirty_ranges_under_address_and_ub_sanitizers(tmp_path):
 
 
 def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
-    """The 2.8 k lines of host orchestration behind the C-ABI (garden_amd/csrc/gv_context.cpp, gv_mirror.cpp, gv_exchange.cpp,
+    """The 2.8 k lines of host orchestration behind the C-ABI (garden_amd/csrc/gv_context.cpp, gv_results.cpp, gv_mirror.cpp, gv_exchange.cpp,
     + gv_scene.cpp, gv_workers.cpp) are otherwise only ever compiled as HIP. Here they are built as plain C++ against
     tests/cpp/hip_stub (device memory = zeroed host memory, copies = memcpy, kernels = generated no-ops; the mirror re-order's
     kernels as plain loops, reorder_cpu.cpp, so that its host half sees real tables) with
@@ -499,7 +499,7 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
              "-I" + stub, "-I" + csrc]
     sources = [str(stubs), os.path.join(stub, "reorder_cpu.cpp"), os.path.join(stub, "exchange_cpu.cpp"),
                os.path.join(root, "tests", "cpp", "host_orchestration_test.cpp")] + \
-              [os.path.join(csrc, f) for f in ("gv_context.cpp", "gv_mirror.cpp", "gv_exchange.cpp", "gv_scene.cpp", "gv_workers.cpp")]
+              [os.path.join(csrc, f) for f in ("gv_context.cpp", "gv_results.cpp", "gv_mirror.cpp", "gv_exchange.cpp", "gv_scene.cpp", "gv_workers.cpp")]
     objects = []
     builds = []
     for src in sources:  # compiled side by side
