@@ -34,9 +34,33 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "stub error"; }
 
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// Fault injection (tests/cpp/host_orchestration_test.cpp::allocation_failures): when the countdown reaches 1 the allocation it
+// lands on fails with hipErrorOutOfMemory (once). 0: never. One counter for every translation unit of the stub build.
+inline long& gv_stub_fail_countdown() { static long countdown = 0; return countdown; }
+inline long& gv_stub_allocations() { static long count = 0; return count; }
+static inline bool gv_stub_allocation_fails()
+{
+    gv_stub_allocations()++;
+    long& c = gv_stub_fail_countdown();
+    return c > 0 && --c == 0;
+}
+static inline hipError_t hipMalloc(void** p, size_t n)
+{
+    *p = nullptr;
+    if (gv_stub_allocation_fails())
+        return hipErrorOutOfMemory;
+    *p = std::calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned)
+{
+    *p = nullptr;
+    if (gv_stub_allocation_fails())
+        return hipErrorOutOfMemory;
+    *p = std::calloc(n ? n : 1, 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostRegister(void* p, size_t n, unsigned)
 {   // touch both ends: a range the caller does not own is a sanitizer report here, where the real call would pin it

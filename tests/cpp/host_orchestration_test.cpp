@@ -861,6 +861,195 @@ static void replay_schedule(const std::string& path)
     gv_destroy(ctx);
 }
 
+// ---- allocation failures: every device / pinned allocation of a small frame sequence fails once, in turn ----
+// The k-th allocation of the sequence returns hipErrorOutOfMemory (tests/cpp/hip_stub fault injection). Whatever call it lands in
+// must come back with an error CODE (GV_E_OOM / GV_E_HIP) — no crash, no leak (ASan), no use of a half-made buffer — and the
+// context must still be usable: with the injection off, the same sequence runs through on the same context, and gv_destroy is clean.
+#include <hip/hip_runtime.h>
+static int frame_sequence(GvCtx* ctx, World& w, const std::vector<float>& depth, bool tolerate)
+{
+    const GvTransformLayout tl = transform_layout();
+    const GvMeshLayout ml = mesh_layout();
+    const GvRecordLayout rl = {64, 0, 8, 56, GV_NONE, (uint32_t)sizeof(Mesh), 0};
+    auto step = [&](int rc) { return tolerate ? rc : (rc == GV_OK ? GV_OK : (std::fprintf(stderr, "frame_sequence: %d (%s)\n", rc, gv_last_error(ctx)), std::exit(1), rc)); };
+    int rc;
+    if ((rc = step(gv_transform_bind(ctx, w.xf.data(), sizeof(Transform), (uint32_t)w.xf.size(), &tl, w.e2t.data(), (uint32_t)w.e2t.size()))))
+        return rc;
+    if ((rc = step(gv_pool_bind(ctx, 0, w.meshes.data(), sizeof(Mesh), (uint32_t)w.meshes.size(), &ml))))
+        return rc;
+    if ((rc = step(gv_pool_bind(ctx, 1, w.big.data(), sizeof(BigMesh), (uint32_t)w.big.size(), &ml))))
+        return rc;
+    if ((rc = step(gv_pool_set_record_layout(ctx, 1, &rl))))
+        return rc;
+    if ((rc = step(gv_hierarchy_rebuild(ctx))))
+        return rc;
+    if ((rc = step(gv_hiz_build(ctx, depth.data(), 96, 80, GV_MEM_HOST))))
+        return rc;
+    GvView views[3] = {make_view(-1, 1, 1), make_view(0, 0, 1), make_view(1, 0, 1)};
+    for (int frame = 0; frame < 2; frame++) {
+        if ((rc = step(gv_mark_dirty(ctx, GV_DIRTY_TRANSFORM, 10, 300))))
+            return rc;
+        if ((rc = step(gv_sweep(ctx, GV_SWEEP_INCREMENTAL))))
+            return rc;
+        if ((rc = step(gv_cull_batch_begin(ctx))))
+            return rc;
+        if ((rc = step(gv_cull(ctx, 0, views, 3))))
+            return rc;
+        if ((rc = step(gv_cull(ctx, 1, views, 1))))
+            return rc;
+        if ((rc = step(gv_pool_sort(ctx, 0, 0, 0))))
+            return rc;
+        if ((rc = step(gv_pool_sort(ctx, 1, 0, 1))))
+            return rc;
+        GvResult r{};
+        for (uint32_t v = 0; v < 3; v++)
+            if ((rc = step(gv_pool_results_fetch(ctx, 0, v, 1, &r))))
+                return rc;
+        if ((rc = step(gv_pool_results_fetch(ctx, 1, 0, 0, &r))))
+            return rc;
+        const uint32_t* bases = nullptr;
+        uint32_t count = 0;
+        if ((rc = step(gv_pool_results_instance_bases(ctx, 0, 0, &bases, &count))))
+            return rc;
+        float world[12 * 4];
+        if ((rc = step(gv_get_world(ctx, 0, 4, world))))
+            return rc;
+    }
+    return GV_OK;
+}
+
+// the mirror grows by half (entities created) and is put back into spatial order on the device: the path ADVICE r3 asked about
+// (a failure after the transform side has been re-ordered must leave the mesh pools marked for rebuild, not pointing at old entries)
+static int growth_sequence(GvCtx* ctx, World& small, World& grown, bool tolerate)
+{
+    const GvTransformLayout tl = transform_layout();
+    const GvMeshLayout ml = mesh_layout();
+    auto step = [&](int rc) { return tolerate ? rc : (rc == GV_OK ? GV_OK : (std::fprintf(stderr, "growth_sequence: %d (%s)\n", rc, gv_last_error(ctx)), std::exit(1), rc)); };
+    GvView v = make_view(-1, 0, 1);
+    GvResult r{};
+    int rc;
+    if ((rc = step(gv_transform_bind(ctx, small.xf.data(), sizeof(Transform), (uint32_t)small.xf.size(), &tl, small.e2t.data(), (uint32_t)small.e2t.size()))))
+        return rc;
+    if ((rc = step(gv_pool_bind(ctx, 0, small.meshes.data(), sizeof(Mesh), (uint32_t)small.meshes.size(), &ml))))
+        return rc;
+    if ((rc = step(gv_hierarchy_rebuild(ctx))))
+        return rc;
+    if ((rc = step(gv_cull(ctx, 0, &v, 1))))
+        return rc;
+    if ((rc = step(gv_results_fetch(ctx, 0, 1, &r))))
+        return rc;
+    // the same pools, half as many slots again (the first slots are the same entities): appended, then re-ordered
+    if ((rc = step(gv_transform_bind(ctx, grown.xf.data(), sizeof(Transform), (uint32_t)grown.xf.size(), &tl, grown.e2t.data(), (uint32_t)grown.e2t.size()))))
+        return rc;
+    if ((rc = step(gv_pool_bind(ctx, 0, grown.meshes.data(), sizeof(Mesh), (uint32_t)grown.meshes.size(), &ml))))
+        return rc;
+    for (int frame = 0; frame < 2; frame++) {
+        if ((rc = step(gv_cull(ctx, 0, &v, 1))))
+            return rc;
+        if ((rc = step(gv_results_fetch(ctx, 0, 1, &r))))
+            return rc;
+    }
+    return GV_OK;
+}
+
+static void allocation_failures()
+{
+    {
+        World small, grown;
+        grown.build(9000, 0);
+        small.xf.assign(grown.xf.begin(), grown.xf.begin() + 6000);
+        small.meshes.assign(grown.meshes.begin(), grown.meshes.begin() + 6000);
+        small.e2t = grown.e2t;
+        for (uint32_t e = 0; e < small.e2t.size(); e++)
+            if (small.e2t[e] != GV_NONE && small.e2t[e] >= 6000)
+                small.e2t[e] = GV_NONE;
+        GvConfig config{};
+        config.struct_size = sizeof(config);
+        GvCtx* probe = nullptr;
+        if (gv_create(&config, &probe) != GV_OK)
+            std::exit(1);
+        const long before = gv_stub_allocations();
+        growth_sequence(probe, small, grown, false);
+        const long total = gv_stub_allocations() - before;
+        GvStats stats{};
+        if (gv_stats(probe, &stats) != GV_OK || stats.mirror_reorders == 0) {
+            std::fprintf(stderr, "growth_sequence: the mirror was not re-ordered on the device (%llu)\n", (unsigned long long)stats.mirror_reorders);
+            std::exit(1);
+        }
+        gv_destroy(probe);
+        int failed_calls = 0;
+        for (long k = 1; k <= total; k++) {
+            GvCtx* ctx = nullptr;
+            if (gv_create(&config, &ctx) != GV_OK)
+                std::exit(1);
+            gv_stub_fail_countdown() = k;
+            const int rc = growth_sequence(ctx, small, grown, true);
+            gv_stub_fail_countdown() = 0;
+            if (rc != GV_OK) {
+                failed_calls++;
+                if (rc != GV_E_OOM && rc != GV_E_HIP) {
+                    std::fprintf(stderr, "growth: allocation %ld of %ld failing: %d (%s)\n", k, total, rc, gv_last_error(ctx));
+                    std::exit(1);
+                }
+                // carry on from where it stopped, as an engine's next frame would: the grown pools, nothing failing
+                const GvTransformLayout tl = transform_layout();
+                const GvMeshLayout ml = mesh_layout();
+                GvView v = make_view(-1, 0, 1);
+                GvResult r{};
+                CHECK(gv_transform_bind(ctx, grown.xf.data(), sizeof(Transform), (uint32_t)grown.xf.size(), &tl, grown.e2t.data(), (uint32_t)grown.e2t.size()));
+                CHECK(gv_pool_bind(ctx, 0, grown.meshes.data(), sizeof(Mesh), (uint32_t)grown.meshes.size(), &ml));
+                CHECK(gv_cull(ctx, 0, &v, 1));
+                CHECK(gv_results_fetch(ctx, 0, 1, &r));
+                check_permutation(ctx, 0, (uint32_t)grown.meshes.size());
+            }
+            gv_destroy(ctx);
+        }
+        std::printf("allocation failures while the mirror grows and is re-ordered: %ld allocations failed in turn, %d calls reported it, every context carried on: ok\n",
+                    total, failed_calls);
+    }
+    World w;
+    w.build(5000, 2);
+    const std::vector<float> depth(96 * 80, 0.25f);
+    // how many allocations the sequence makes on a fresh context
+    GvConfig config{};
+    config.struct_size = sizeof(config);
+    GvCtx* probe = nullptr;
+    if (gv_create(&config, &probe) != GV_OK)
+        std::exit(1);
+    const long before = gv_stub_allocations();
+    frame_sequence(probe, w, depth, false);
+    const long total = gv_stub_allocations() - before;
+    gv_destroy(probe);
+    int failed_calls = 0;
+    for (long k = 1; k <= total; k++) {
+        GvCtx* ctx = nullptr;
+        if (gv_create(&config, &ctx) != GV_OK)
+            std::exit(1);
+        gv_stub_fail_countdown() = k;
+        const int rc = frame_sequence(ctx, w, depth, true);
+        gv_stub_fail_countdown() = 0;
+        if (rc != GV_OK) {
+            failed_calls++;
+            if (rc != GV_E_OOM && rc != GV_E_HIP) {
+                std::fprintf(stderr, "allocation %ld of %ld failing: the call returned %d (%s), not GV_E_OOM / GV_E_HIP\n", k, total, rc, gv_last_error(ctx));
+                std::exit(1);
+            }
+            if (!*gv_last_error(ctx)) {
+                std::fprintf(stderr, "allocation %ld: error code %d without a message\n", k, rc);
+                std::exit(1);
+            }
+        }
+        // the context is still usable: the same sequence, nothing failing (re-bound, rebuilt)
+        const int again = frame_sequence(ctx, w, depth, true);
+        if (again != GV_OK) {
+            std::fprintf(stderr, "allocation %ld of %ld failing once: the context did not recover: %d (%s)\n", k, total, again, gv_last_error(ctx));
+            std::exit(1);
+        }
+        gv_destroy(ctx);
+    }
+    std::printf("allocation failures: %ld allocations failed in turn, %d calls reported it, every context recovered: ok\n", total, failed_calls);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) {  // schedule files (tests/schedules.py): replayed instead of the fixed exercise
@@ -877,6 +1066,7 @@ int main(int argc, char** argv)
     exercise(GV_CONFIG_LINEAR_SCAN | GV_CONFIG_HIZ_RG16F | GV_CONFIG_KEEP_SLOT_ORDER, 300000, 3);  // (above the device-gather and auto-bounds sizes)
     for (int ranks : {1, 2, 3, 8})
         exchange_in_threads(ranks);
+    allocation_failures();
     std::printf("host orchestration: ok\n");
     return 0;
 }

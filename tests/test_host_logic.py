@@ -521,6 +521,9 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, GV_RCCL_LIBRARY=transport))
     assert run.returncode == 0 and "host orchestration: ok" in run.stdout, (run.stdout + run.stderr)[-4000:]
     assert "exchange over the stub transport, 8 ranks: ok" in run.stdout, run.stdout[-2000:]
+    # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
+    assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
+    print(run.stdout[-600:])
     # the random schedules the GPU tier checks against the oracle (tests/schedules.py), replayed here under the sanitizers
     import schedules
     paths = []
