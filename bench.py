@@ -664,11 +664,19 @@ def main():
     # W warm-up frames the contract asks for, for a fixed 0.3 s of wall clock (GV_BENCH_PREWARM_MS=0 switches them off for A/Bs).
     prewarm_ms, prewarm_frames = float(os.environ.get("GV_BENCH_PREWARM_MS", "300")), 0
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+    # (with an exchange every frame is a collective: the ranks decide TOGETHER after each 50 frames whether to go on — clocks that
+    # disagree by a millisecond must not leave one rank a chunk ahead, waiting in a collective nobody else enters)
+    while prewarm_ms > 0:
         for _ in range(50):
             step()
         vis.wait()
         prewarm_frames += 50
+        more = (time.perf_counter() - t_pre) * 1e3 < prewarm_ms
+        if world > 1:
+            torch.cuda.synchronize()
+            more = all_agree(more)
+        if not more:
+            break
     for _ in range(args.warmup):
         step()
     fence()
