@@ -1,8 +1,9 @@
 // gv_exchange.cpp — the multi-GPU exchange step of SURVEY.md §8e in the C-ABI, for hosts without torch.distributed
 // (a C++ engine, one process per GPU): every rank's compact visible list goes out as a fixed-capacity shard
 // [draw_count, global indices ...] and all ranks gather the shards with ONE equal-size ncclAllGather enqueued on the
-// context's stream — no host synchronisation; counts are read from the shard headers. Same wire format as
-// garden_amd/multi.py::VisibleListExchange (which does this through torch.distributed in bench.py).
+// library's exchange stream (every operation of the communicator goes on that one stream, ordered against the context's stream
+// by events) — no host synchronisation; counts are read from the shard headers. Same wire format as
+// garden_amd/multi.py::VisibleListExchange (the torch.distributed variant in bench.py).
 // The node's xGMI fabric is fully connected point to point, and a ring all-gather serialises world-1 hops over it, so
 // two direct patterns sit beside the all-gather for an A/B on real hardware (gv_exchange_set_mode, or the environment
 // variable GV_EXCHANGE_MODE = allgather | p2p | broadcast read at gv_exchange_init): one ncclGroup of send/recv pairs
@@ -316,14 +317,11 @@ static uint32_t room_for(uint32_t count)
     return (uint32_t)std::min<uint64_t>(c, 0xFFFFFC00u);
 }
 
-// the headers of `slot`'s frame, once they are on the host: counts, cut rows, and the room the coming frames give each rank
-static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
+// waits until the headers of `slot`'s frame are on the host (written by exchange_headers_kernel behind the frame's collective)
+static int wait_for_headers(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
 {
-    if (!slot.in_flight)
-        return GV_OK;
-    const int world = ctx->exchange_world;
     const uint32_t seq = (uint32_t)(slot.frame + 1);
-    volatile uint32_t* word = slot.hdr.ptr + world;
+    volatile uint32_t* word = slot.hdr.ptr + ctx->exchange_world;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0; *word != seq; spins++) {
         // (normally written two frames ago; a host that runs far ahead of the device waits here, which is what bounds it)
@@ -336,12 +334,23 @@ static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    return GV_OK;
+}
+
+// The headers of `slot`'s frame decide the room the coming frames give each rank. Only gv_exchange_visible calls this, for the
+// frame two before the one it is about to send: every rank applies every frame's headers at the same point of the same sequence,
+// whatever else it asked in between (gv_exchange_counts reads headers early and decides nothing) — the row sizes of a collective
+// must agree on all ranks.
+static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
+{
+    if (!slot.in_flight)
+        return GV_OK;
+    if (int rc = wait_for_headers(ctx, slot))
+        return rc;
     slot.in_flight = false;
-    if (ctx->exchange_counts_frame != UINT64_MAX && slot.frame <= ctx->exchange_counts_frame)
-        return GV_OK;  // (retired out of order by gv_exchange_counts: the newer frame's verdict stands)
     ctx->exchange_counts_frame = slot.frame;
     ctx->exchange_cut = 0;
-    for (int r = 0; r < world; r++) {
+    for (int r = 0; r < ctx->exchange_world; r++) {
         const uint32_t count = slot.hdr.ptr[r];
         ctx->exchange_counts[r] = count;
         if (count > slot.room[r]) {
@@ -479,15 +488,10 @@ int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* c
     gv::Context::ExchangeSlot& slot = ctx->exchange_slots[frame & 1u];
     if (slot.frame != frame)
         return ctx->fail(GV_E_STATE, "gv_exchange_counts: frame %llu's rows have been reused", (unsigned long long)frame);
-    if (slot.in_flight) {
-        // every frame up to this one, oldest first: the room decisions must see the frames in order on every rank
-        gv::Context::ExchangeSlot& older = ctx->exchange_slots[(frame & 1u) ^ 1u];
-        if (older.in_flight && older.frame < frame)
-            if (int rc = retire_slot(ctx, older))
-                return rc;
+    if (slot.in_flight) {  // (not yet retired: its collective may still be running)
         GV_HIP(ctx, hipSetDevice(ctx->device));
         GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-        if (int rc = retire_slot(ctx, slot))
+        if (int rc = wait_for_headers(ctx, slot))
             return rc;
     }
     uint64_t cut = 0;

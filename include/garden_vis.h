@@ -362,7 +362,7 @@ typedef struct GvExchangeFrame {
                                                         that list was cut to its leading room[r] entries */
     uint32_t travelled_words[GV_EXCHANGE_MAX_RANKS]; /* of rank r's row, the words that crossed a link this frame (header included;
                                                         the equal-size all-gather moves whole rows whatever the rooms) */
-    uint64_t counts_frame;       /* the latest frame whose headers have reached the host (UINT64_MAX: none yet) ... */
+    uint64_t counts_frame;       /* the latest frame whose headers this frame's sizes follow: frame - 2 (UINT64_MAX: none yet) ... */
     uint32_t counts[GV_EXCHANGE_MAX_RANKS];          /* ... its draw counts, rank by rank ... */
     uint64_t cut_ranks;          /* ... and bit r set when rank r's list did not fit the room its row had in that frame */
     uint32_t exact;              /* 1: this frame was sized from its own counts (host-synchronising) */
@@ -374,7 +374,8 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
 /* Work enqueued on gv_stream(ctx) after this call sees frame `frame`'s rows (one of the last two frames): the stream waits
  * for that frame's ready_event. No host wait. */
 int gv_exchange_acquire(GvCtx* ctx, uint64_t frame);
-/* Blocks until frame `frame`'s headers have reached the host (one of the last two frames); counts[world_size]. */
+/* Blocks until frame `frame`'s headers have reached the host (one of the last two frames); counts[world_size]. A query only:
+ * the sizes of later frames do not depend on whether, or on which ranks, it was called. */
 int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks);
 
 /* The same exchange with caller-owned buffers and caller-chosen sizes: row r of gathered_device (world_size * (capacity + 1)

@@ -36,6 +36,7 @@ struct Header {
     std::atomic<uint32_t> failed;      // some rank gave up: everybody leaves their barriers with an error
     uint32_t world;
     uint64_t want[kMaxRanks];          // per rank: its largest message of the current call
+    uint64_t sent[kMaxRanks][kMaxRanks];  // [from][to]: bytes of the current call's message (what the receiver must expect too)
 };
 
 struct Comm {
@@ -117,8 +118,22 @@ int run(Comm* c, std::vector<Message>& msgs)
             return 1;
     }
     c->hdr->want[c->rank] = mine;
+    for (int r = 0; r < c->world; r++)
+        c->hdr->sent[c->rank][r] = 0;
+    for (const Message& m : msgs)
+        if (m.send)
+            c->hdr->sent[c->rank][m.peer] = m.bytes;
     if (!barrier(c))
         return 3;
+    // RCCL would hang or corrupt memory when the two ends of a transfer disagree about its size: here it is an error on the
+    // receiving rank (ranks that sized a frame's rows differently are exactly what the exchange tests look for)
+    bool sizes_agree = true;
+    for (const Message& m : msgs)
+        if (!m.send && c->hdr->sent[m.peer][c->rank] != m.bytes) {
+            std::fprintf(stderr, "rccl_stub: rank %d expects %zu bytes from rank %d, which sends %llu\n", c->rank, m.bytes, m.peer,
+                         (unsigned long long)c->hdr->sent[m.peer][c->rank]);
+            sizes_agree = false;
+        }
     uint64_t most = 0;
     for (int r = 0; r < c->world; r++)
         most = c->hdr->want[r] > most ? c->hdr->want[r] : most;
@@ -144,7 +159,7 @@ int run(Comm* c, std::vector<Message>& msgs)
     }
     // (a final barrier is implied: every round ends with one, and a call without rounds moved nothing)
     msgs.clear();
-    return 0;
+    return sizes_agree ? 0 : 4;  // ncclInvalidArgument, after the rounds: nobody is left waiting in a barrier
 }
 
 int submit(Comm* c, Message m)
