@@ -967,6 +967,22 @@ int gv_scene_bind(GvCtx* ctx, GvScene* scene)
 // are remapped (a parent without a transform stays an id nothing maps to).
 }  // extern "C"
 
+// the cell a position falls in (the rule of extract_owned / multi.py::tile_of_positions)
+static uint32_t cell_of(const uint32_t grid[3], double side, const float position[3])
+{
+    uint32_t t = 0, mul = 1;
+    for (int a = 0; a < 3; a++) {
+        const double cell = ((double)position[a] / side + 0.5) * (double)grid[a];
+        // truncation, as numpy's astype(int64) — whose result for NaN and for values outside the int64 range is INT64_MIN
+        // (x86 cvttsd2si), i.e. cell 0 after the clamp; decided in double here: the cast itself would be undefined behaviour
+        long long c = (cell > -9.2e18 && cell < 9.2e18) ? (long long)cell : 0;
+        c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
+        t += (uint32_t)c * mul;
+        mul *= grid[a];
+    }
+    return t;
+}
+
 // owner[cell]: which tile each cell of the grid belongs to (identity: one tile per cell; cells dealt to ranks: see
 // gv_scene_extract_rank); `tile` is the one to cut out
 // spread_strays > 0: free transform slots and meshes without a transform go to tile slot % spread_strays instead of tile 0
@@ -995,17 +1011,7 @@ static int extract_owned(const GvScene* scene, const uint32_t grid[3], double si
                 break;
             root = ps;
         }
-        uint32_t t = 0, mul = 1;
-        for (int a = 0; a < 3; a++) {
-            const double cell = ((double)scene->position[(size_t)root * 3 + a] / side + 0.5) * (double)grid[a];
-            // truncation, as numpy's astype(int64) — whose result for NaN and for values outside the int64 range is INT64_MIN
-            // (x86 cvttsd2si), i.e. cell 0 after the clamp; decided in double here: the cast itself would be undefined behaviour
-            long long c = (cell > -9.2e18 && cell < 9.2e18) ? (long long)cell : 0;
-            c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
-            t += (uint32_t)c * mul;
-            mul *= grid[a];
-        }
-        xf_tile[s] = owner[t];
+        xf_tile[s] = owner[cell_of(grid, side, &scene->position[(size_t)root * 3])];
     }
     out = new (std::nothrow) GvScene();
     if (!out)
@@ -1139,20 +1145,6 @@ static void deal_cells(const uint32_t grid[3], uint32_t world_size, std::vector<
         const uint32_t turn = (uint32_t)(((uint64_t)(k / world_size) * 2654435761ull) & 0xFFFFFFFFull) >> 16;
         owner[order[k].second] = (uint32_t)(((uint64_t)k + turn) % world_size);
     }
-}
-
-// the cell a position falls in (the rule of extract_owned / multi.py::tile_of_positions)
-static uint32_t cell_of(const uint32_t grid[3], double side, const float position[3])
-{
-    uint32_t t = 0, mul = 1;
-    for (int a = 0; a < 3; a++) {
-        const double cell = ((double)position[a] / side + 0.5) * (double)grid[a];
-        long long c = (cell > -9.2e18 && cell < 9.2e18) ? (long long)cell : 0;
-        c = c < 0 ? 0 : (c > (long long)grid[a] - 1 ? (long long)grid[a] - 1 : c);
-        t += (uint32_t)c * mul;
-        mul *= grid[a];
-    }
-    return t;
 }
 
 // Cells in Morton (Z-curve) order of their (x, y, z) coordinates, dealt in rounds of world_size with a rotation that changes
