@@ -323,6 +323,8 @@ def main():
                                    f"torch.distributed.run --nproc-per-node {args.gpus}, or run plain "
                                    f"`python bench.py --gpus {args.gpus}` (it starts the ranks itself)"}), flush=True)
         sys.exit(2)
+    if os.environ.get("GV_BENCH_FALLBACK_REASON"):  # the child a hung C-ABI exchange left behind (exchange watchdog below)
+        args.exchange_path = "torch"
     if args.workload is None:  # (strong scaling: the same workload at every N, N = 1 included)
         args.workload = "cfg5" if args.gpus > 1 or args.scaling == "strong" else "cfg3"
 
@@ -359,6 +361,42 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+
+    class ExchangeWatchdog:
+        """The library's exchange has only ever met real RCCL with one rank (no multi-GPU node was available to this build): if a
+        collective of it never comes back on the first real node, the run must still print a line. Armed while the C-ABI exchange
+        is the timed path and petted at every milestone; `seconds` without one and every rank (they all hang in the same
+        collective) starts this script again as a CHILD with --exchange-path torch on a fresh rendezvous port, hands it the
+        result descriptor and leaves with its exit code — the hung process cannot be repaired from inside, its stream is stuck
+        behind the collective. The child's line says exchange_path "torch" and exchange_path_fallback = what happened."""
+
+        def __init__(self, seconds):
+            self.seconds, self.where, self.timer = seconds, None, None
+
+        def pet(self, where):
+            import threading
+            self.stop()
+            self.where = where
+            self.timer = threading.Timer(self.seconds, self.bark)
+            self.timer.daemon = True
+            self.timer.start()
+
+        def stop(self):
+            if self.timer is not None:
+                self.timer.cancel()
+                self.timer = None
+
+        def bark(self):
+            import subprocess
+            reason = f"the library's exchange made no progress for {self.seconds:.0f} s after '{self.where}' (rank {rank}): timed through torch.distributed by a child run"
+            print("bench.py: " + reason, file=sys.stderr, flush=True)
+            port = 1024 + (int(os.environ.get("MASTER_PORT", "29533")) + 17 - 1024) % 64000
+            env = dict(os.environ, GV_BENCH_FALLBACK_REASON=reason, MASTER_PORT=str(port))
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (the child's rank 0 serves its own rendezvous store on the new port)
+            rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=result_fd)
+            os._exit(rc)
+
+    exchange_watchdog = ExchangeWatchdog(float(os.environ.get("GV_BENCH_EXCHANGE_WATCHDOG_S", "240")))
 
     def leave(code):
         """Every rank leaves through here, together."""
@@ -600,8 +638,9 @@ def main():
             return [1 + x.capacity] * world
 
         transport_note = None
-        path_fallback = [None]
+        path_fallback = [os.environ.get("GV_BENCH_FALLBACK_REASON")]
         if args.exchange_path == "c-abi":
+            exchange_watchdog.pet("start of the C-ABI exchange set-up")
             # the product's own exchange step: RCCL bound by the library, unique id handed round by the process group
             if backend != "nccl" and "GV_RCCL_LIBRARY" not in os.environ:
                 # N ranks on one GPU (GV_BENCH_BACKEND=gloo): RCCL refuses that; the rows travel through the tests' shared-memory
@@ -628,10 +667,12 @@ def main():
                         args.payload = requested
                 except Exception as e:  # noqa: BLE001
                     init_problem = f"{type(e).__name__}: {e}"
+            exchange_watchdog.pet("the trial frame")
             if not all_agree(init_problem is None and ids[0] is not None):
                 # the library's own exchange did not come up on some rank: the line is still measured — through torch.distributed —
                 # and says so loudly (exchange_path "torch", exchange_path_fallback = what went wrong)
                 native[0] = False
+                exchange_watchdog.stop()
                 path_fallback[0] = init_problem or "the library's exchange failed on another rank"
                 print(f"bench.py: rank {rank}: C-ABI exchange unavailable ({path_fallback[0]}); timing the torch.distributed path", file=sys.stderr)
 
@@ -671,6 +712,8 @@ def main():
             step()
         vis.wait()
         prewarm_frames += 50
+        if native[0]:
+            exchange_watchdog.pet(f"{prewarm_frames} untimed frames")
         more = (time.perf_counter() - t_pre) * 1e3 < prewarm_ms
         if world > 1:
             torch.cuda.synchronize()
@@ -691,6 +734,8 @@ def main():
     vis.profile_sampling(sample_every)
     mark_group = max(1, args.steps // (2 if short else 5))
     elapsed, per_step_ms, last = timed_steps(step, args.steps, mark_group)
+    if native[0]:
+        exchange_watchdog.pet("the timed frames")
     st = vis.stats()
     timed = vis.profile_samples()
     vis.profile_sampling(1)
@@ -765,6 +810,7 @@ def main():
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
         exchange_ms = max_over_ranks(float(np.median(lat)) * 1e3)
+        exchange_watchdog.stop()  # (the library's exchange is not called again before the variants, which have their own guard)
 
         def timed_variant(describe):
             """args.steps frames of step() as currently configured, checked against the exact all-gatherv; a failing variant is

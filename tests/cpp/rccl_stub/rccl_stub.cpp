@@ -104,6 +104,13 @@ int run(Comm* c, std::vector<Message>& msgs)
 {
     if (msgs.empty())
         return 0;
+    // RCCL_STUB_HANG_AT=n: the n-th transfer call of this process never returns (what a collective looks like when a peer never
+    // enters it) — for the tests of what the callers do about that (bench.py's exchange watchdog)
+    static const long hang_at = getenv("RCCL_STUB_HANG_AT") ? atol(getenv("RCCL_STUB_HANG_AT")) : 0;
+    static std::atomic<long> calls{0};
+    if (hang_at > 0 && ++calls == hang_at)
+        for (;;)
+            sleep(1);
     uint64_t mine = 0;
     bool seen_send[kMaxRanks] = {}, seen_recv[kMaxRanks] = {};
     for (const Message& m : msgs) {
