@@ -476,7 +476,7 @@ class GpuVisibility:
         self._check(self.lib.gv_pool_mirror_slots(self.ctx, pool_id, out.ctypes.data, occupancy))
         return out
 
-    # ---- native RCCL exchange (C++ engines; bench.py goes through torch.distributed instead) ----
+    # ---- native RCCL exchange (what a C++ engine calls; bench.py --gpus N times it: config.exchange_path "c-abi") ----
     @staticmethod
     def exchange_unique_id():
         buf = C.create_string_buffer(128)
