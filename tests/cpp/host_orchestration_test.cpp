@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -503,8 +504,25 @@ static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
 // is host memory in this build): rank r's list in frame f has count(r, f) entries value(r, f, k). Lists creep, jump (rows get
 // cut, the library reports it two frames later and re-sizes from an exact count exchange) and collapse (room is given back);
 // every rank checks every row of every frame against those formulas, under all three travel patterns.
+static std::atomic<int> g_cut_reports{0}, g_exact_frames{0};  // (summed over the ranks of a run, for the log)
+static int g_list_seed = 0;  // 0: the scripted sequence below; otherwise lists that jump at random between empty and the whole pool
+static uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
 static uint32_t list_count(int rank, int frame, uint32_t n)
 {
+    if (g_list_seed) {
+        // a scale that holds for a few frames (shared by the ranks: a camera), a rank's own share of it, a per-frame wobble;
+        // now and then nothing at all, or everything
+        const uint32_t era = mix32((uint32_t)g_list_seed * 977u + (uint32_t)(frame / 3));
+        const uint32_t scales[6] = {0u, 40u, 700u, 2600u, n / 2u, n};
+        const uint32_t scale = scales[era % 6u];
+        const uint32_t share = 50u + mix32((uint32_t)g_list_seed * 31u + (uint32_t)rank) % 100u;                    // 50 .. 149 %
+        const uint32_t wobble = 90u + mix32((uint32_t)g_list_seed * 131071u + (uint32_t)rank * 8191u + (uint32_t)frame) % 21u;  // 90 .. 110 %
+        return (uint32_t)std::min<uint64_t>(n, (uint64_t)scale * share * wobble / 10000u);
+    }
     const uint32_t base = 200u + 150u * (uint32_t)rank;
     if (frame >= 14)
         return base / 8u;                                       // collapse: room is given back
@@ -580,6 +598,8 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
                 }
             if (xf.exact && count > room)
                 fail("an exactly sized row is cut", frame, r);
+            if (frame >= 2 && room < list_count(r, frame - 2, n))  // (rooms follow the headers of two frames ago, never below them)
+                fail("room below the list of two frames ago", frame, r);
             room_seen[r] = room;
         }
         // the blocking query: this frame's own headers — asked on DIFFERENT frames by different ranks: it decides nothing, the
@@ -594,9 +614,11 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
                     fail("gv_exchange_counts", frame, r);
         }
     }
-    if (exact_frames < 3)  // frame 0, the frame after the jump was noticed, frame 17 (asked for)
+    g_cut_reports += cut_reports;
+    g_exact_frames += exact_frames;
+    if (exact_frames < (g_list_seed ? 2 : 3))  // frame 0, the frame after the jump was noticed (scripted sequence), frame 17 (asked for)
         fail("too few exactly sized frames", exact_frames, -1);
-    if (cut_reports < 1)
+    if (cut_reports < 1 && !g_list_seed)
         fail("the jump was never reported as a cut", -1, -1);
     // caller-sized form: per-rank capacities
     {
@@ -638,8 +660,11 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
     (void)room_seen;
 }
 
-static void exchange_in_threads(int ranks)
+static void exchange_in_threads(int ranks, int list_seed = 0)
 {
+    g_list_seed = list_seed;
+    g_cut_reports = 0;
+    g_exact_frames = 0;
     if (!std::getenv("GV_RCCL_LIBRARY")) {
         std::printf("exchange over the stub transport: skipped (GV_RCCL_LIBRARY not set)\n");
         return;
@@ -660,7 +685,8 @@ static void exchange_in_threads(int ranks)
             std::fprintf(stderr, "exchange with %d ranks: rank %d reported %d failures\n", ranks, r, failures[r]);
             std::exit(1);
         }
-    std::printf("exchange over the stub transport, %d ranks: ok\n", ranks);
+    std::printf("exchange over the stub transport, %d ranks, list sequence %d: ok (per rank: %d of 20 frames exactly sized, %d reported a cut)\n", ranks,
+                list_seed, g_exact_frames.load() / ranks, g_cut_reports.load() / ranks);
 }
 
 // ---- random schedules over the held-back mechanisms: the text tests/schedules.py generates (the GPU tier replays the same
@@ -1069,6 +1095,8 @@ int main(int argc, char** argv)
     exercise(GV_CONFIG_LINEAR_SCAN | GV_CONFIG_HIZ_RG16F | GV_CONFIG_KEEP_SLOT_ORDER, 300000, 3);  // (above the device-gather and auto-bounds sizes)
     for (int ranks : {1, 2, 3, 8})
         exchange_in_threads(ranks);
+    for (int seed = 1; seed <= 24; seed++)  // lists that jump at random between empty and the whole pool
+        exchange_in_threads(2 + seed % 4, seed);
     allocation_failures();
     std::printf("host orchestration: ok\n");
     return 0;

@@ -520,7 +520,10 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     assert tb.returncode == 0, tb.stderr[-3000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, GV_RCCL_LIBRARY=transport))
     assert run.returncode == 0 and "host orchestration: ok" in run.stdout, (run.stdout + run.stderr)[-4000:]
-    assert "exchange over the stub transport, 8 ranks: ok" in run.stdout, run.stdout[-2000:]
+    assert "exchange over the stub transport, 8 ranks, list sequence 0: ok" in run.stdout, run.stdout[-2000:]
+    # ... and 24 sequences of lists that jump at random between empty and the whole pool, 2-5 ranks
+    assert run.stdout.count("exchange over the stub transport") == 4 + 24 and "list sequence 24: ok" in run.stdout, run.stdout[-2000:]
+    print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange over")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
     print(run.stdout[-600:])
