@@ -172,7 +172,7 @@ def test_bench_hands_over_to_a_child_run_when_a_collective_of_the_library_exchan
     untimed frames): after GV_BENCH_EXCHANGE_WATCHDOG_S seconds every rank starts the torch.distributed form as a child, which
     prints the line — exchange_path "torch", exchange_path_fallback says what happened — and the ranks leave with its exit code."""
     d = _run_bench(["--gpus", "2", "--entities", "100000", "--steps", "3", "--warmup", "1", "--no-mask-variant"],
-                   {"GV_BENCH_BACKEND": "gloo", "RCCL_STUB_HANG_AT": "80", "GV_BENCH_EXCHANGE_WATCHDOG_S": "10"})
+                   {"GV_BENCH_BACKEND": "gloo", "RCCL_STUB_HANG_AT": "80", "GV_BENCH_EXCHANGE_WATCHDOG_S": "20"})
     c = d["config"]
     assert c["exchange_path"] == "torch" and "no progress" in c["exchange_path_fallback"] and "untimed frames" in c["exchange_path_fallback"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity"]["visible_set_bit_identical"]
