@@ -469,6 +469,18 @@ def main():
         span.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(span, device=f"cuda:{local_rank}")
 
+    sent_frame = [None]
+
+    def native_frame():
+        """gv_exchange_visible for this frame, then the PREVIOUS frame acquired, the way a consumer one frame behind does: the send
+        has settled that frame (a short row completed by a second exchange inside the call), so the acquire is a stream wait —
+        every frame of the timed region is handed out complete."""
+        f = vis.exchange_visible(0, index_base=rank * n)
+        if sent_frame[0] is not None:
+            vis.exchange_acquire(sent_frame[0])
+        sent_frame[0] = f["frame"]
+        return f
+
     def step():
         """One frame. With an exchange: the rank's list goes out as a shard [count, indices...] and all ranks gather the shards
         (one equal-size all-gather, or the --exchange alternative) enqueued behind the library's stream — no host
@@ -480,7 +492,7 @@ def main():
             if args.payload == "mask":
                 vis.exchange_masks(0, mask_words(n), native_rows[0].data_ptr())
                 return native_rows[0]
-            return vis.exchange_visible(0, index_base=rank * n)
+            return native_frame()
         if ex[0] is not None:
             shard = ex[0].next_shard()
             if args.payload == "mask":
@@ -516,10 +528,11 @@ def main():
 
     def check_padded(padded, exact, exact_counts):
         """The per-frame exchange delivered the same lists as the exact one (static scene)."""
-        if isinstance(padded, dict):  # a frame of gv_exchange_visible: library-owned rows, counts through the blocking query
-            counts, cut = vis.exchange_counts(padded["frame"], world)
-            if cut:
-                return f"c-abi exchange: rows of ranks {cut} were cut (room {padded['room']}, counts {counts})"
+        if isinstance(padded, dict):  # a frame of gv_exchange_visible: library-owned rows, handed out complete by the acquire
+            padded = vis.exchange_acquire(padded["frame"])
+            counts = padded["counts"]
+            if not padded["complete"]:
+                return "c-abi exchange: an acquired frame is not complete"
             if not np.array_equal(np.asarray(counts, dtype=np.int64), exact_counts):
                 return "c-abi exchange: counts differ from the exact all-gatherv"
             torch.cuda.synchronize()
@@ -797,7 +810,7 @@ def main():
                 if args.payload == "mask":
                     vis.exchange_masks(0, mask_words(n), native_rows[0].data_ptr())
                 else:
-                    vis.exchange_visible(0, index_base=rank * n)
+                    vis.exchange_acquire(native_frame()["frame"])
             else:
                 shard = ex[0].next_shard()
                 if args.payload == "mask":

@@ -371,28 +371,32 @@ struct Context {
     int exchange_rank = 0, exchange_world = 1;
     uint32_t exchange_mode = GV_EXCHANGE_ALLGATHER;  // GvExchangeMode
     DeviceBuf<uint32_t> d_shard;       // [count, indices...] of this rank
-    // gv_exchange_visible: library-owned rows, sized from the headers of earlier frames (gv_exchange.cpp)
+    // gv_exchange_visible: library-owned rows, sized from the previous frame's headers, completed when a list outgrew its room
     struct ExchangeSlot {
         DeviceBuf<uint32_t> rows;      // [world][row_words]
-        DeviceBuf<uint32_t> shard;     // this rank's [count, indices ...] of the slot's frame (read by the collective on exchange_stream)
+        DeviceBuf<uint32_t> shard;     // this rank's WHOLE [count, indices ...] of the slot's frame: the first exchange reads its leading
+                                       // 1 + room[me] words, a completing exchange the tail behind them (both on exchange_stream)
         hipEvent_t produced = nullptr; // on ctx->stream behind the shard copy: exchange_stream waits for it
-        hipEvent_t done = nullptr;     // on exchange_stream behind collective + headers: GvExchangeFrame::ready_event
+        hipEvent_t done = nullptr;     // on exchange_stream behind collective + headers (+ tails): GvExchangeFrame::ready_event
         PinnedBuf<uint32_t> hdr;       // [world] counts + [1] sequence word, written by exchange_headers_kernel
         uint32_t row_words = 0;
-        uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};  // list entries rank r's row had room for in this slot's frame
+        uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};        // list entries rank r's row was predicted to need in this slot's frame
+        uint32_t travelled[GV_EXCHANGE_MAX_RANKS] = {};   // words of row r on the links in the first exchange
+        uint32_t counts[GV_EXCHANGE_MAX_RANKS] = {};      // settled: the frame's own headers
+        uint32_t tail_words[GV_EXCHANGE_MAX_RANKS] = {};  // settled: what the completing exchange carried
+        uint64_t cut = 0;              // settled: ranks whose list outgrew its room
         uint64_t frame = 0;
-        bool in_flight = false;
+        uint32_t mode = 0;
+        bool in_flight = false;        // sent; its headers have not been read yet
+        bool settled = false;          // headers read, rooms updated, tails delivered: the rows are complete behind `done`
     } exchange_slots[2];
     hipStream_t exchange_stream = nullptr;              // EVERY collective of the communicator runs here (one communicator, one stream): the next frame's cull (ctx->stream) does not wait for the links
-    hipEvent_t exchange_in = nullptr, exchange_out = nullptr;  // hand-over events of the caller-owned forms (gv_exchange_shards / _masks) and the exact count exchange
+    hipEvent_t exchange_in = nullptr, exchange_out = nullptr;  // hand-over events of the caller-owned forms (gv_exchange_shards / _masks)
     uint64_t exchange_frame = 0;                        // the next frame's number
     uint32_t exchange_room[GV_EXCHANGE_MAX_RANKS] = {};  // room the next frame gives each rank
-    bool exchange_need_exact = true;                    // size the next frame from its own counts
-    uint64_t exchange_counts_frame = UINT64_MAX;        // latest retired frame: its counts and which rows were cut
-    uint32_t exchange_counts[GV_EXCHANGE_MAX_RANKS] = {};
-    uint64_t exchange_cut = 0;
-    DeviceBuf<uint32_t> d_xcounts;     // the exact path's count all-gather
-    PinnedBuf<uint32_t> h_xcounts;
+    uint32_t exchange_timeout_ms = 30000;               // bound of every host wait of the exchange (gv_exchange_set_timeout)
+    bool exchange_broken = false;                       // a wait ran out: the communicator is aborted, not destroyed
+    bool exchange_by_group = false;                     // made by gv_exchange_init_all: driven through the *_all forms only
 
     // ---- profiling ----
     std::vector<PendingEvent> pending;

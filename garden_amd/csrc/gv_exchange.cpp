@@ -14,8 +14,11 @@
 // entry points (a site's own RCCL build; the tests' shared-memory transport, tests/cpp/rccl_stub, which lets N ranks share
 // one GPU — RCCL itself refuses two ranks on one device).
 //
-// gv_exchange_visible is the per-frame form the engine calls: the library owns the rows and sizes them from the headers
-// of earlier frames, which reach the host through pinned memory (exchange_headers_kernel) — see include/garden_vis.h.
+// gv_exchange_visible is the per-frame form the engine calls: the library owns the rows, predicts how much of each travels from
+// the previous frame's headers (pinned memory, exchange_headers_kernel) and — the reference's gather never drops a record,
+// mesh.cpp:177-183 — completes the rows whose list outgrew the prediction with a second, exactly sized exchange before the frame
+// is handed out (settle_*, tails_*). The *_all forms drive the N contexts of one process from one thread inside one ncclGroup.
+// See include/garden_vis.h.
 #include <dlfcn.h>
 
 #include "gv_ctx.hpp"
@@ -31,6 +34,8 @@ struct Rccl {
     int (*GetUniqueId)(NcclId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;  // optional
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -75,6 +80,8 @@ Rccl& rccl()
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
         r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
@@ -98,15 +105,28 @@ namespace gv {
 
 void exchange_release(GvCtx* ctx)
 {
+    // what is still queued on the exchange stream goes first: gv_stream never waits for a frame's collective, so the communicator
+    // would otherwise be destroyed under a queued all-gather. (After a timeout the stream may never drain: abort instead.)
+    if (ctx->exchange_stream && !ctx->exchange_broken)
+        (void)hipStreamSynchronize(ctx->exchange_stream);
+    bool hung = false;  // a collective that will never finish and cannot be aborted: its stream is left alone (and leaked)
     if (ctx->exchange_comm) {
         Rccl& r = rccl();
-        if (r.ok)
-            (void)r.CommDestroy(ctx->exchange_comm);
+        if (r.ok) {
+            if (ctx->exchange_broken && r.CommAbort)
+                (void)r.CommAbort(ctx->exchange_comm);
+            else if (ctx->exchange_broken)
+                hung = true;
+            else
+                (void)r.CommDestroy(ctx->exchange_comm);
+        }
         ctx->exchange_comm = nullptr;
     }
-    ctx->d_shard.release();
+    if (hung)
+        ctx->exchange_stream = nullptr;
     if (ctx->exchange_stream)
         (void)hipStreamSynchronize(ctx->exchange_stream);
+    ctx->d_shard.release();
     for (auto& slot : ctx->exchange_slots) {
         slot.rows.release();
         slot.shard.release();
@@ -116,8 +136,14 @@ void exchange_release(GvCtx* ctx)
         if (slot.done)
             (void)hipEventDestroy(slot.done);
         slot.produced = slot.done = nullptr;
-        slot.in_flight = false;
+        slot.in_flight = slot.settled = false;
         slot.row_words = 0;
+        slot.frame = 0;
+        slot.cut = 0;
+        memset(slot.room, 0, sizeof(slot.room));
+        memset(slot.counts, 0, sizeof(slot.counts));
+        memset(slot.tail_words, 0, sizeof(slot.tail_words));
+        memset(slot.travelled, 0, sizeof(slot.travelled));
     }
     if (ctx->exchange_stream)
         (void)hipStreamDestroy(ctx->exchange_stream);
@@ -127,15 +153,64 @@ void exchange_release(GvCtx* ctx)
     if (ctx->exchange_out)
         (void)hipEventDestroy(ctx->exchange_out);
     ctx->exchange_in = ctx->exchange_out = nullptr;
-    ctx->d_xcounts.release();
-    ctx->h_xcounts.release();
+    // a communicator starts from nothing: the rooms of an earlier one (other ranks, another history) must not size its rows —
+    // ranks with different pasts would enter frame 0's collective with rows of different lengths
     ctx->exchange_frame = 0;
-    ctx->exchange_need_exact = true;
-    ctx->exchange_counts_frame = UINT64_MAX;
-    ctx->exchange_cut = 0;
+    memset(ctx->exchange_room, 0, sizeof(ctx->exchange_room));
+    ctx->exchange_broken = false;
+    ctx->exchange_by_group = false;
+    ctx->exchange_rank = 0;
+    ctx->exchange_world = 1;
 }
 
 }  // namespace gv
+
+namespace {
+
+using Slot = gv::Context::ExchangeSlot;
+
+// streams, events, mode and timeout of a communicator about to be made — BEFORE the communicator exists, so that a failure here
+// leaves no communicator behind that later calls would drive with a NULL stream
+int exchange_setup(GvCtx* ctx, int rank, int world_size)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    gv::exchange_release(ctx);
+    ctx->exchange_rank = rank;
+    ctx->exchange_world = world_size;
+    GV_HIP(ctx, hipStreamCreateWithFlags(&ctx->exchange_stream, hipStreamNonBlocking));
+    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_in, hipEventDisableTiming));
+    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_out, hipEventDisableTiming));
+    for (auto& slot : ctx->exchange_slots) {
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.produced, hipEventDisableTiming));
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    }
+    if (const char* m = getenv("GV_EXCHANGE_MODE")) {
+        if (!strcmp(m, "p2p"))
+            ctx->exchange_mode = GV_EXCHANGE_P2P;
+        else if (!strcmp(m, "broadcast"))
+            ctx->exchange_mode = GV_EXCHANGE_BROADCAST;
+        else if (!strcmp(m, "allgather"))
+            ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
+        else
+            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast)", m);
+    }
+    if (const char* t = getenv("GV_EXCHANGE_TIMEOUT_MS")) {
+        const long ms = atol(t);
+        if (ms > 0)
+            ctx->exchange_timeout_ms = (uint32_t)std::min<long>(ms, 0x7FFFFFFFl);
+    }
+    return GV_OK;
+}
+
+int exchange_setup_failed(GvCtx* ctx, int rc)
+{
+    const std::string why = ctx->error;  // (the release resets nothing of the error text, but keep it explicit)
+    gv::exchange_release(ctx);
+    ctx->error = why;
+    return rc;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -162,35 +237,67 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
     Rccl& r = rccl();
     if (!r.ok)
         return ctx->fail(GV_E_RCCL, "gv_exchange_init: %s", r.why.c_str());
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    gv::exchange_release(ctx);
+    if (int rc = exchange_setup(ctx, rank, world_size))
+        return exchange_setup_failed(ctx, rc);
     NcclId id{};
     memcpy(id.bytes, unique_id, GV_EXCHANGE_ID_BYTES);
     ncclComm_t comm = nullptr;
     const int rc = r.CommInitRank(&comm, world_size, id, rank);
     if (rc != 0)
-        return ctx->fail(GV_E_RCCL, "ncclCommInitRank: %s", r.GetErrorString(rc));
+        return exchange_setup_failed(ctx, ctx->fail(GV_E_RCCL, "ncclCommInitRank: %s", r.GetErrorString(rc)));
     ctx->exchange_comm = comm;
-    ctx->exchange_rank = rank;
-    ctx->exchange_world = world_size;
-    GV_HIP(ctx, hipStreamCreateWithFlags(&ctx->exchange_stream, hipStreamNonBlocking));
-    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_in, hipEventDisableTiming));
-    GV_HIP(ctx, hipEventCreateWithFlags(&ctx->exchange_out, hipEventDisableTiming));
-    for (auto& slot : ctx->exchange_slots) {
-        GV_HIP(ctx, hipEventCreateWithFlags(&slot.produced, hipEventDisableTiming));
-        GV_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
-    }
-    if (const char* m = getenv("GV_EXCHANGE_MODE")) {
-        if (!strcmp(m, "p2p"))
-            ctx->exchange_mode = GV_EXCHANGE_P2P;
-        else if (!strcmp(m, "broadcast"))
-            ctx->exchange_mode = GV_EXCHANGE_BROADCAST;
-        else if (!strcmp(m, "allgather"))
-            ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
-        else
-            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast)", m);
-    }
     return GV_OK;
+}
+
+int gv_exchange_init_all(GvCtx* const* contexts, int world_size)
+{
+    if (!contexts || world_size < 1 || world_size > (int)GV_EXCHANGE_MAX_RANKS)
+        return GV_E_ARG;
+    for (int k = 0; k < world_size; k++) {
+        if (!contexts[k])
+            return GV_E_ARG;
+        for (int j = 0; j < k; j++)
+            if (contexts[j] == contexts[k])
+                return contexts[k]->fail(GV_E_ARG, "gv_exchange_init_all: context %d is listed twice", k);
+    }
+    GvCtx* first = contexts[0];
+    Rccl& r = rccl();
+    if (!r.ok)
+        return first->fail(GV_E_RCCL, "gv_exchange_init_all: %s", r.why.c_str());
+    NcclId id{};
+    if (r.GetUniqueId(&id) != 0)
+        return first->fail(GV_E_RCCL, "gv_exchange_init_all: ncclGetUniqueId failed");
+    int rc = GV_OK;
+    for (int k = 0; k < world_size && rc == GV_OK; k++)
+        rc = exchange_setup(contexts[k], k, world_size);
+    ncclComm_t comms[GV_EXCHANGE_MAX_RANKS] = {};
+    if (rc == GV_OK) {
+        // one thread, N devices: the N ncclCommInitRank calls meet inside ONE group (each would otherwise wait for the others)
+        int nrc = r.GroupStart();
+        for (int k = 0; k < world_size && nrc == 0; k++) {
+            if (hipSetDevice(contexts[k]->device) != hipSuccess) {
+                rc = contexts[k]->fail(GV_E_HIP, "gv_exchange_init_all: hipSetDevice(%d)", contexts[k]->device);
+                break;
+            }
+            nrc = r.CommInitRank(&comms[k], world_size, id, k);
+        }
+        const int erc = r.GroupEnd();
+        if (nrc == 0)
+            nrc = erc;
+        if (nrc != 0 && rc == GV_OK)
+            rc = first->fail(GV_E_RCCL, "gv_exchange_init_all: ncclCommInitRank: %s", r.GetErrorString(nrc));
+    }
+    for (int k = 0; k < world_size; k++) {
+        contexts[k]->exchange_comm = comms[k];  // (a failed start: released below, communicator included)
+        contexts[k]->exchange_by_group = true;
+    }
+    if (rc != GV_OK) {
+        const std::string why = first->error;
+        for (int k = 0; k < world_size; k++)
+            gv::exchange_release(contexts[k]);
+        first->error = why;
+    }
+    return rc;
 }
 
 int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
@@ -203,17 +310,25 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
     return GV_OK;
 }
 
-// ctx->d_shard of every rank into rows [rank * row_words ...) of gathered_device, by the configured pattern. travel[r] (NULL:
+int gv_exchange_set_timeout(GvCtx* ctx, uint32_t milliseconds)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    ctx->exchange_timeout_ms = milliseconds ? milliseconds : 30000u;
+    return GV_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// `shard` of every rank into rows [rank * row_words ...) of gathered_device, by the configured pattern. travel[r] (NULL:
 // row_words for all) = the leading words of rank r's row that matter: the direct patterns move exactly those, the equal-size
 // all-gather always moves whole rows.
-static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, void* gathered_device, const char* what,
-                         const uint32_t* shard = nullptr, hipStream_t stream = nullptr)
+int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, void* gathered_device, const char* what, const uint32_t* shard,
+                  hipStream_t stream)
 {
     Rccl& r = rccl();
-    if (!shard)
-        shard = ctx->d_shard.ptr;
-    if (!stream)
-        stream = ctx->stream;
     uint32_t* rows = static_cast<uint32_t*>(gathered_device);
     const int me = ctx->exchange_rank, world = ctx->exchange_world;
     auto words_of = [&](int rank) -> size_t { return travel ? std::min<size_t>(travel[rank], row_words) : row_words; };
@@ -251,8 +366,8 @@ static int exchange_rows(GvCtx* ctx, size_t row_words, const uint32_t* travel, v
     return GV_OK;
 }
 
-// the rank's staging shard, every byte defined (the collective reads all of it)
-static int reserve_shard(GvCtx* ctx, size_t words)
+// the rank's staging shard of the caller-sized forms, every byte defined (the collective reads all of it)
+int reserve_shard(GvCtx* ctx, size_t words)
 {
     const uint32_t* before = ctx->d_shard.ptr;
     GV_HIP(ctx, ctx->d_shard.reserve(words));
@@ -264,26 +379,416 @@ static int reserve_shard(GvCtx* ctx, size_t words)
 // The caller-owned forms promise their rows in the order of gv_stream(ctx). The collective itself still runs on the exchange stream
 // — every operation of the communicator is issued on ONE stream, in the same order on every rank — between two hand-overs: the
 // exchange stream waits for what gv_stream has produced, gv_stream waits for the rows.
-static int hand_to_exchange_stream(GvCtx* ctx)
+int hand_to_exchange_stream(GvCtx* ctx)
 {
     GV_HIP(ctx, hipEventRecord(ctx->exchange_in, ctx->stream));
     GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, ctx->exchange_in, 0));
     return GV_OK;
 }
-static int hand_back_from_exchange_stream(GvCtx* ctx)
+int hand_back_from_exchange_stream(GvCtx* ctx)
 {
     GV_HIP(ctx, hipEventRecord(ctx->exchange_out, ctx->exchange_stream));
     GV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->exchange_out, 0));
     return GV_OK;
 }
 
+int usable(GvCtx* ctx, const char* what, bool by_group)
+{
+    if (ctx->exchange_broken)
+        return ctx->fail(GV_E_STATE, "%s: the communicator timed out earlier and was aborted (gv_exchange_shutdown, then gv_exchange_init again)", what);
+    if (!ctx->exchange_comm)
+        return ctx->fail(GV_E_STATE, "%s: gv_exchange_init has not run", what);
+    if (!by_group && ctx->exchange_by_group && ctx->exchange_world > 1)
+        return ctx->fail(GV_E_STATE, "%s: this communicator was made by gv_exchange_init_all — one thread drives its %d ranks through the "
+                         "*_all calls (a per-rank call would wait for ranks the same thread has not reached yet)", what, ctx->exchange_world);
+    return GV_OK;
+}
+
+// ---- gv_exchange_visible: rows owned and sized by the library ----
+
+// room for a list of `count` entries: count + max(count / 8, 1024), rounded up to 1024 words
+uint32_t room_for(uint32_t count)
+{
+    uint64_t c = (uint64_t)count + std::max<uint64_t>(count / 8u, 1024u);
+    c = (c + 1023u) & ~1023ull;
+    return (uint32_t)std::min<uint64_t>(c, 0xFFFFFC00u);
+}
+
+// words between two rows that hold up to `entries` list entries behind their header: a multiple of 4 (16-byte rows)
+size_t row_words_for(uint32_t entries)
+{
+    return ((size_t)entries + 1u + 3u) & ~(size_t)3u;
+}
+
+// The communicator can no longer be trusted (a wait ran out, or RCCL reported an asynchronous error): a collective that will never
+// finish must not keep the device — and with it every hipFree / synchronise of the process — waiting, so it is aborted on the spot.
+int give_up(GvCtx* ctx, int code, const char* text)
+{
+    ctx->exchange_broken = true;
+    Rccl& r = rccl();
+    if (r.CommAbort && ctx->exchange_comm) {
+        (void)r.CommAbort(ctx->exchange_comm);
+        ctx->exchange_comm = nullptr;
+    }
+    ctx->error = text;
+    return code;
+}
+
+// what RCCL has to say about the collectives already enqueued (ncclCommGetAsyncError: a peer that died, a transport error)
+int async_error(GvCtx* ctx)
+{
+    Rccl& r = rccl();
+    int async = 0;
+    if (!r.CommGetAsyncError || !ctx->exchange_comm || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
+        return 0;
+    return async;
+}
+
+// Waits until the headers of `slot`'s frame are on the host (written by exchange_headers_kernel behind the frame's collective).
+// Bounded: a peer that never enters the collective leaves it spinning on the device for ever — the host gets a status code. Rows
+// behind a collective that RCCL reports as failed are not handed out either.
+int wait_for_headers(GvCtx* ctx, Slot& slot)
+{
+    const uint32_t seq = (uint32_t)(slot.frame + 1);
+    volatile uint32_t* word = slot.hdr.ptr + ctx->exchange_world;
+    const auto t0 = std::chrono::steady_clock::now();
+    char text[384];
+    for (uint32_t spins = 0; *word != seq; spins++) {
+        if ((spins & 255u) != 255u)
+            continue;
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(ctx->exchange_timeout_ms)) {
+            snprintf(text, sizeof(text), "exchange frame %llu: the row headers did not reach the host within %u ms (sequence word %u, expected %u): "
+                     "a peer rank stalled or left; the communicator has been aborted", (unsigned long long)slot.frame, ctx->exchange_timeout_ms, *word, seq);
+            return give_up(ctx, GV_E_TIMEOUT, text);
+        }
+        if (waited > std::chrono::milliseconds(2)) {
+            if (const int async = async_error(ctx)) {
+                snprintf(text, sizeof(text), "exchange frame %llu: RCCL reports an asynchronous error while its rows travel: %s; the communicator has been aborted",
+                         (unsigned long long)slot.frame, rccl().GetErrorString(async));
+                return give_up(ctx, GV_E_RCCL, text);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (const int async = async_error(ctx)) {  // (the stream went on behind a collective that did not complete: its rows are not the lists)
+        snprintf(text, sizeof(text), "exchange frame %llu: RCCL reports an asynchronous error behind its rows: %s; the communicator has been aborted",
+                 (unsigned long long)slot.frame, rccl().GetErrorString(async));
+        return give_up(ctx, GV_E_RCCL, text);
+    }
+    return GV_OK;
+}
+
+// Reads the frame's own headers: which rows are short, and what room the NEXT frame gives each rank. Every rank holds the same
+// headers and settles every frame exactly once, in front of the next frame's sizing: the sizes of a collective agree on all ranks.
+int settle_read(GvCtx* ctx, Slot& slot)
+{
+    if (!slot.in_flight)
+        return GV_OK;
+    if (int rc = wait_for_headers(ctx, slot))
+        return rc;
+    slot.in_flight = false;
+    slot.cut = 0;
+    for (int r = 0; r < ctx->exchange_world; r++) {
+        const uint32_t count = slot.hdr.ptr[r];
+        slot.counts[r] = count;
+        slot.tail_words[r] = 0;
+        if (count > slot.room[r]) {
+            slot.cut |= 1ull << r;
+            slot.tail_words[r] = count - slot.room[r];
+        }
+        const uint32_t want = room_for(count);
+        if (want > ctx->exchange_room[r] || (uint64_t)want * 4u < (uint64_t)ctx->exchange_room[r] * 3u)
+            ctx->exchange_room[r] = want;
+    }
+    slot.settled = slot.cut == 0;
+    return GV_OK;
+}
+
+// A frame with short rows, step 1 of 3: rows wide enough for the longest list. (The exchange stream is idle: the frame's headers
+// have been read, and nobody holds the rows — an unsettled frame has not been handed out.)
+int tails_stage(GvCtx* ctx, Slot& slot)
+{
+    if (slot.settled)
+        return GV_OK;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t longest = 0;
+    for (int r = 0; r < ctx->exchange_world; r++)
+        longest = std::max(longest, std::max(slot.room[r], slot.counts[r]));
+    const size_t need = row_words_for(longest), world = (size_t)ctx->exchange_world;
+    if (need > slot.row_words) {
+        gv::DeviceBuf<uint32_t> wider;
+        GV_HIP(ctx, wider.reserve(world * need));
+        hipError_t e = hipSuccess;
+        for (size_t r = 0; r < world && e == hipSuccess; r++)
+            e = hipMemcpyAsync(wider.ptr + r * need, slot.rows.ptr + r * slot.row_words, (size_t)slot.row_words * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, ctx->exchange_stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->exchange_stream);
+        if (e != hipSuccess) {
+            wider.release();
+            return ctx->hip_fail(e, "gv_exchange: widening the rows of a frame with short rows");
+        }
+        std::swap(wider.ptr, slot.rows.ptr);
+        std::swap(wider.cap, slot.rows.cap);
+        wider.release();
+        slot.row_words = (uint32_t)need;
+    }
+    return GV_OK;
+}
+
+// ... step 2: every short rank broadcasts the tail of its list — out of the staging shard, which holds the whole list until the
+// slot's next frame — to its place in everybody's rows. Exactly sized: every rank knows every count.
+int tails_collective(GvCtx* ctx, Slot& slot)
+{
+    if (slot.settled)
+        return GV_OK;
+    Rccl& r = rccl();
+    const int me = ctx->exchange_rank;
+    int nrc = r.GroupStart();
+    for (int root = 0; root < ctx->exchange_world && nrc == 0; root++) {
+        if (!((slot.cut >> root) & 1ull))
+            continue;
+        uint32_t* place = slot.rows.ptr + (size_t)root * slot.row_words + 1u + slot.room[root];
+        nrc = r.Broadcast(root == me ? slot.shard.ptr + 1u + slot.room[root] : place, place, slot.tail_words[root], kNcclUint32, root,
+                          ctx->exchange_comm, ctx->exchange_stream);
+    }
+    const int erc = r.GroupEnd();
+    if (nrc == 0)
+        nrc = erc;
+    if (nrc != 0)
+        return ctx->fail(GV_E_RCCL, "gv_exchange: completing the short rows of frame %llu: ncclBroadcast: %s", (unsigned long long)slot.frame,
+                         r.GetErrorString(nrc));
+    return GV_OK;
+}
+
+// ... step 3: the frame's ready event moves behind the tails.
+int tails_finish(GvCtx* ctx, Slot& slot)
+{
+    if (slot.settled)
+        return GV_OK;
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    GV_HIP(ctx, hipEventRecord(slot.done, ctx->exchange_stream));
+    slot.settled = true;
+    return GV_OK;
+}
+
+// The three steps for all the contexts of a call (one for the per-rank forms): the collectives of all of them inside one group.
+int settle(GvCtx* const* ctxs, int n, unsigned which)
+{
+    Rccl& r = rccl();
+    for (int k = 0; k < n; k++)
+        if (int rc = settle_read(ctxs[k], ctxs[k]->exchange_slots[which]))
+            return rc;
+    bool short_rows = false;
+    for (int k = 0; k < n; k++) {
+        Slot& slot = ctxs[k]->exchange_slots[which];
+        short_rows = short_rows || !slot.settled;
+        if (slot.settled != ctxs[0]->exchange_slots[which].settled)  // (every rank reads the same headers)
+            return ctxs[k]->fail(GV_E_STATE, "gv_exchange: the ranks of one call disagree about frame %llu's headers", (unsigned long long)slot.frame);
+    }
+    if (!short_rows)
+        return GV_OK;
+    for (int k = 0; k < n; k++)
+        if (int rc = tails_stage(ctxs[k], ctxs[k]->exchange_slots[which]))
+            return rc;
+    int rc = GV_OK;
+    (void)r.GroupStart();
+    for (int k = 0; k < n && rc == GV_OK; k++) {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess)
+            rc = ctxs[k]->fail(GV_E_HIP, "hipSetDevice(%d)", ctxs[k]->device);
+        else
+            rc = tails_collective(ctxs[k], ctxs[k]->exchange_slots[which]);
+    }
+    const int erc = r.GroupEnd();
+    if (rc == GV_OK && erc != 0)
+        rc = ctxs[0]->fail(GV_E_RCCL, "gv_exchange: ncclGroupEnd: %s", r.GetErrorString(erc));
+    for (int k = 0; k < n && rc == GV_OK; k++)
+        rc = tails_finish(ctxs[k], ctxs[k]->exchange_slots[which]);
+    return rc;
+}
+
+// A new frame, step 1 of 3: buffers, and this rank's whole list into the slot's staging shard on the context's stream.
+int frame_stage(GvCtx* ctx, uint32_t view_index, uint32_t index_base, Slot& slot)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const int me = ctx->exchange_rank, world = ctx->exchange_world;
+    gv::ViewState* vs = gv::view_of(ctx, ctx->last_pool, view_index);
+    if (!vs || !vs->emitted)
+        return ctx->fail(GV_E_ARG, "gv_exchange_visible: view %u has no emitted records", view_index);
+    uint32_t widest = 0;
+    for (int k = 0; k < world; k++)
+        widest = std::max(widest, ctx->exchange_room[k]);
+    const size_t row_words = row_words_for(widest);
+    // the shard holds the WHOLE list (what a short prediction leaves behind travels later, from here); the equal-size all-gather
+    // reads row_words words of it whatever the list's length
+    const size_t shard_words = std::max(row_words, (size_t)vs->occupancy + 1u);
+    if ((size_t)world * row_words > slot.rows.cap || shard_words > slot.shard.cap) {
+        // grown by half again: a list that creeps up does not reallocate every time. (The slot's previous frame is settled — its
+        // collectives have run — but consumers of its rows may still be queued on the context's stream.)
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
+        if ((size_t)world * row_words > slot.rows.cap)
+            GV_HIP(ctx, slot.rows.reserve(std::max((size_t)world * row_words, slot.rows.cap + slot.rows.cap / 2)));
+        if (shard_words > slot.shard.cap) {
+            GV_HIP(ctx, slot.shard.reserve(std::max(shard_words, slot.shard.cap + slot.shard.cap / 2)));
+            GV_HIP(ctx, hipMemsetAsync(slot.shard.ptr, 0, slot.shard.cap * sizeof(uint32_t), ctx->stream));  // (the all-gather reads whole rows)
+        }
+    }
+    if (!slot.hdr.ptr) {
+        GV_HIP(ctx, slot.hdr.reserve(GV_EXCHANGE_MAX_RANKS + 1));
+        memset(slot.hdr.ptr, 0, (GV_EXCHANGE_MAX_RANKS + 1) * sizeof(uint32_t));
+    }
+    for (int k = 0; k < world; k++) {
+        slot.room[k] = ctx->exchange_room[k];
+        slot.travelled[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : 1u + ctx->exchange_room[k];
+        slot.counts[k] = slot.tail_words[k] = 0;
+    }
+    slot.cut = 0;
+    slot.row_words = (uint32_t)row_words;
+    slot.mode = ctx->exchange_mode;
+    // The shard is the last thing the context's stream does for this frame's list; the links are the exchange stream's business.
+    // The next frame's pyramid and cull go on behind the shard copy at once, while this list is still travelling. (The slot's shard
+    // and rows are free: the frame that used them last is settled, which its collectives precede; and work that was enqueued on the
+    // context's stream to CONSUME those rows completes in front of `produced`, which the exchange stream waits for.)
+    if (int rc = gv_results_copy_shard_device(ctx, view_index, slot.shard.ptr, vs->occupancy, index_base))
+        return rc;
+    GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));
+    GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, slot.produced, 0));
+    (void)me;
+    return GV_OK;
+}
+
+// ... step 2: the predicted part of every row travels.
+int frame_collective(GvCtx* ctx, Slot& slot)
+{
+    uint32_t travel[GV_EXCHANGE_MAX_RANKS];
+    for (int k = 0; k < ctx->exchange_world; k++)
+        travel[k] = 1u + slot.room[k];
+    return exchange_rows(ctx, slot.row_words, travel, slot.rows.ptr, "gv_exchange_visible", slot.shard.ptr, ctx->exchange_stream);
+}
+
+void describe(const GvCtx* ctx, const Slot& slot, GvExchangeFrame* out)
+{
+    if (!out)
+        return;
+    memset(out, 0, sizeof(*out));
+    out->row_words = slot.row_words;
+    out->world_size = (uint32_t)ctx->exchange_world;
+    out->frame = slot.frame;
+    out->mode = slot.mode;
+    for (int k = 0; k < ctx->exchange_world; k++) {
+        out->room[k] = slot.room[k];
+        out->travelled_words[k] = slot.travelled[k];
+    }
+    if (!slot.settled)
+        return;  // (sent, not handed out: a completing exchange may still move the rows)
+    out->gathered_device = slot.rows.ptr;
+    out->ready_event = slot.done;
+    out->cut_ranks = slot.cut;
+    out->complete = 1;
+    for (int k = 0; k < ctx->exchange_world; k++) {
+        out->counts[k] = slot.counts[k];
+        out->tail_words[k] = slot.tail_words[k];
+    }
+}
+
+// ... step 3: the headers reach the host behind the rows.
+int frame_finish(GvCtx* ctx, Slot& slot, GvExchangeFrame* out)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t frame = ctx->exchange_frame;
+    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, slot.row_words, (uint32_t)ctx->exchange_world, slot.hdr.ptr, (uint32_t)(frame + 1),
+                                            ctx->exchange_stream));
+    GV_HIP(ctx, hipEventRecord(slot.done, ctx->exchange_stream));
+    slot.frame = frame;
+    slot.in_flight = true;
+    slot.settled = false;
+    ctx->exchange_frame = frame + 1;
+    describe(ctx, slot, out);
+    return GV_OK;
+}
+
+int visible_all(GvCtx* const* ctxs, int n, const uint32_t* views, const uint32_t* bases, GvExchangeFrame* outs, bool by_group)
+{
+    Rccl& r = rccl();
+    const uint64_t frame = ctxs[0]->exchange_frame;
+    for (int k = 0; k < n; k++) {
+        if (int rc = usable(ctxs[k], "gv_exchange_visible", by_group))
+            return rc;
+        if (ctxs[k]->exchange_frame != frame || (by_group && (ctxs[k]->exchange_rank != k || ctxs[k]->exchange_world != n)))
+            return ctxs[k]->fail(GV_E_ARG, "gv_exchange_visible_all: contexts[%d] is rank %d of %d at frame %llu (expected rank %d of %d at frame %llu)", k,
+                                 ctxs[k]->exchange_rank, ctxs[k]->exchange_world, (unsigned long long)ctxs[k]->exchange_frame, k, n, (unsigned long long)frame);
+    }
+    // the previous frame first: its headers size this one, and rows it left short are completed in front of this frame's collective
+    // — at the same point of the communicator's sequence on every rank, whether or not a rank acquired it in between
+    if (frame > 0)
+        if (int rc = settle(ctxs, n, (unsigned)((frame - 1) & 1u)))
+            return rc;
+    const unsigned which = (unsigned)(frame & 1u);
+    for (int k = 0; k < n; k++)
+        if (int rc = frame_stage(ctxs[k], views[k], bases ? bases[k] : 0u, ctxs[k]->exchange_slots[which]))
+            return rc;
+    int rc = GV_OK;
+    (void)r.GroupStart();
+    for (int k = 0; k < n && rc == GV_OK; k++) {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess)
+            rc = ctxs[k]->fail(GV_E_HIP, "hipSetDevice(%d)", ctxs[k]->device);
+        else
+            rc = frame_collective(ctxs[k], ctxs[k]->exchange_slots[which]);
+    }
+    const int erc = r.GroupEnd();
+    if (rc == GV_OK && erc != 0)
+        rc = ctxs[0]->fail(GV_E_RCCL, "gv_exchange_visible: ncclGroupEnd: %s", r.GetErrorString(erc));
+    for (int k = 0; k < n && rc == GV_OK; k++)
+        rc = frame_finish(ctxs[k], ctxs[k]->exchange_slots[which], outs ? outs + k : nullptr);
+    return rc;
+}
+
+int acquire_all(GvCtx* const* ctxs, int n, uint64_t frame, GvExchangeFrame* outs, bool by_group)
+{
+    const unsigned which = (unsigned)(frame & 1u);
+    for (int k = 0; k < n; k++) {
+        GvCtx* ctx = ctxs[k];
+        if (int rc = usable(ctx, "gv_exchange_acquire", by_group))
+            return rc;
+        if (frame >= ctx->exchange_frame || frame + 2 < ctx->exchange_frame || ctx->exchange_slots[which].frame != frame)
+            return ctx->fail(GV_E_ARG, "gv_exchange_acquire: frame %llu is not one of the last two exchanged (next: %llu)", (unsigned long long)frame,
+                             (unsigned long long)ctx->exchange_frame);
+    }
+    if (int rc = settle(ctxs, n, which))
+        return rc;
+    for (int k = 0; k < n; k++) {
+        GvCtx* ctx = ctxs[k];
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        GV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->exchange_slots[which].done, 0));
+        describe(ctx, ctx->exchange_slots[which], outs ? outs + k : nullptr);
+    }
+    return GV_OK;
+}
+
+int all_args(GvCtx* const* contexts, int world_size)
+{
+    if (!contexts || world_size < 1 || world_size > (int)GV_EXCHANGE_MAX_RANKS)
+        return GV_E_ARG;
+    for (int k = 0; k < world_size; k++)
+        if (!contexts[k])
+            return GV_E_ARG;
+    return GV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const uint32_t* capacities, uint32_t index_base,
                        void* gathered_device)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_shards: gv_exchange_init has not run");
+    if (int rc = usable(ctx, "gv_exchange_shards", false))
+        return rc;
     if (!gathered_device || capacity == 0)
         return ctx->fail(GV_E_ARG, "gv_exchange_shards: NULL buffer or zero capacity");
     uint32_t travel[GV_EXCHANGE_MAX_RANKS];
@@ -307,210 +812,45 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const
     return hand_back_from_exchange_stream(ctx);
 }
 
-// ---- gv_exchange_visible: rows owned and sized by the library ----
-
-// room for a list of `count` entries: count + max(count / 8, 1024), rounded up to 1024 words
-static uint32_t room_for(uint32_t count)
-{
-    uint64_t c = (uint64_t)count + std::max<uint64_t>(count / 8u, 1024u);
-    c = (c + 1023u) & ~1023ull;
-    return (uint32_t)std::min<uint64_t>(c, 0xFFFFFC00u);
-}
-
-// waits until the headers of `slot`'s frame are on the host (written by exchange_headers_kernel behind the frame's collective)
-static int wait_for_headers(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
-{
-    const uint32_t seq = (uint32_t)(slot.frame + 1);
-    volatile uint32_t* word = slot.hdr.ptr + ctx->exchange_world;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; *word != seq; spins++) {
-        // (normally written two frames ago; a host that runs far ahead of the device waits here, which is what bounds it)
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-            GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-            if (*word != seq)
-                return ctx->fail(GV_E_RCCL, "exchange frame %llu: the row headers never reached the host (sequence word %u, expected %u)",
-                                 (unsigned long long)slot.frame, *word, seq);
-            break;
-        }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return GV_OK;
-}
-
-// The headers of `slot`'s frame decide the room the coming frames give each rank. Only gv_exchange_visible calls this, for the
-// frame two before the one it is about to send: every rank applies every frame's headers at the same point of the same sequence,
-// whatever else it asked in between (gv_exchange_counts reads headers early and decides nothing) — the row sizes of a collective
-// must agree on all ranks.
-static int retire_slot(GvCtx* ctx, gv::Context::ExchangeSlot& slot)
-{
-    if (!slot.in_flight)
-        return GV_OK;
-    if (int rc = wait_for_headers(ctx, slot))
-        return rc;
-    slot.in_flight = false;
-    ctx->exchange_counts_frame = slot.frame;
-    ctx->exchange_cut = 0;
-    for (int r = 0; r < ctx->exchange_world; r++) {
-        const uint32_t count = slot.hdr.ptr[r];
-        ctx->exchange_counts[r] = count;
-        if (count > slot.room[r]) {
-            ctx->exchange_cut |= 1ull << r;
-            ctx->exchange_need_exact = true;
-        }
-        const uint32_t want = room_for(count);
-        if (want > ctx->exchange_room[r] || (uint64_t)want * 4u < (uint64_t)ctx->exchange_room[r] * 3u)
-            ctx->exchange_room[r] = want;
-    }
-    return GV_OK;
-}
-
 int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_visible: gv_exchange_init has not run");
-    if (!out || (flags & ~GV_EXCHANGE_EXACT))
-        return ctx->fail(GV_E_ARG, "gv_exchange_visible: NULL frame or unknown flags 0x%x", flags);
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    Rccl& r = rccl();
-    const int me = ctx->exchange_rank, world = ctx->exchange_world;
-    const uint64_t frame = ctx->exchange_frame;
-    gv::Context::ExchangeSlot& slot = ctx->exchange_slots[frame & 1u];
-    if (int rc = retire_slot(ctx, slot))  // frame - 2: its rows may be overwritten now, its headers size this frame
-        return rc;
-    GvDeviceResult dres{};
-    if (int rc = gv_pool_results_device(ctx, ctx->last_pool, view_index, &dres))
-        return rc;
-    if (!dres.visible_idx)
-        return ctx->fail(GV_E_ARG, "gv_exchange_visible: view %u has no emitted records", view_index);
-    const bool exact = ctx->exchange_need_exact || (flags & GV_EXCHANGE_EXACT);
-    if (exact) {
-        // this frame's own counts to every rank first (one word each), read on the host: the one synchronising step
-        GV_HIP(ctx, ctx->d_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
-        GV_HIP(ctx, ctx->h_xcounts.reserve(GV_EXCHANGE_MAX_RANKS));
-        if (int rc = hand_to_exchange_stream(ctx))  // (the count is the emit's output, on the context's stream)
-            return rc;
-        const int nrc = r.AllGather(dres.draw_count, ctx->d_xcounts.ptr, 1, kNcclUint32, ctx->exchange_comm, ctx->exchange_stream);
-        if (nrc != 0)
-            return ctx->fail(GV_E_RCCL, "gv_exchange_visible: ncclAllGather of the counts: %s", r.GetErrorString(nrc));
-        GV_HIP(ctx, hipMemcpyAsync(ctx->h_xcounts.ptr, ctx->d_xcounts.ptr, (size_t)world * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                   ctx->exchange_stream));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-        for (int k = 0; k < world; k++)
-            ctx->exchange_room[k] = std::max(ctx->exchange_room[k], room_for(ctx->h_xcounts.ptr[k]));
-        ctx->exchange_need_exact = false;
-    }
-    uint32_t widest = 0;
-    for (int k = 0; k < world; k++)
-        widest = std::max(widest, ctx->exchange_room[k]);
-    const size_t row_words = (size_t)widest + 1;
-    if ((size_t)world * row_words > slot.rows.cap || row_words > slot.shard.cap) {
-        // grown by half again: a list that creeps up does not reallocate every time. (The slot's previous frame is retired — its
-        // collective has run — but consumers of its rows may still be queued on the context's stream.)
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-        if ((size_t)world * row_words > slot.rows.cap)
-            GV_HIP(ctx, slot.rows.reserve(std::max((size_t)world * row_words, slot.rows.cap + slot.rows.cap / 2)));
-        if (row_words > slot.shard.cap) {
-            GV_HIP(ctx, slot.shard.reserve(std::max(row_words, slot.shard.cap + slot.shard.cap / 2)));
-            GV_HIP(ctx, hipMemsetAsync(slot.shard.ptr, 0, slot.shard.cap * sizeof(uint32_t), ctx->stream));  // (the all-gather reads whole rows)
-        }
-    }
-    if (!slot.hdr.ptr) {
-        GV_HIP(ctx, slot.hdr.reserve(GV_EXCHANGE_MAX_RANKS + 1));
-        memset(slot.hdr.ptr, 0, (GV_EXCHANGE_MAX_RANKS + 1) * sizeof(uint32_t));
-    }
-    uint32_t travel[GV_EXCHANGE_MAX_RANKS];
-    for (int k = 0; k < world; k++) {
-        slot.room[k] = ctx->exchange_room[k];
-        travel[k] = 1u + ctx->exchange_room[k];
-    }
-    // The shard is the last thing the context's stream does for this frame's list; the links are the exchange stream's business.
-    // The next frame's pyramid and cull go on behind the shard copy at once, while this list is still travelling. (The slot's shard
-    // and rows are free: retire_slot saw the headers of the frame that used them last, which its collective precedes; and work that
-    // was enqueued on the context's stream to CONSUME those rows completes in front of `produced`, which the exchange stream waits for.)
-    if (int rc = gv_results_copy_shard_device(ctx, view_index, slot.shard.ptr, ctx->exchange_room[me], index_base))
-        return rc;
-    GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));
-    GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, slot.produced, 0));
-    if (int rc = exchange_rows(ctx, row_words, travel, slot.rows.ptr, "gv_exchange_visible", slot.shard.ptr, ctx->exchange_stream))
-        return rc;
-    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, (uint32_t)row_words, (uint32_t)world, slot.hdr.ptr, (uint32_t)(frame + 1),
-                                            ctx->exchange_stream));
-    GV_HIP(ctx, hipEventRecord(slot.done, ctx->exchange_stream));
-    slot.row_words = (uint32_t)row_words;
-    slot.frame = frame;
-    slot.in_flight = true;
-    ctx->exchange_frame = frame + 1;
-
-    memset(out, 0, sizeof(*out));
-    out->gathered_device = slot.rows.ptr;
-    out->row_words = (uint32_t)row_words;
-    out->world_size = (uint32_t)world;
-    out->frame = frame;
-    for (int k = 0; k < world; k++) {
-        out->room[k] = slot.room[k];
-        out->travelled_words[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : travel[k];
-        out->counts[k] = ctx->exchange_counts[k];
-    }
-    out->counts_frame = ctx->exchange_counts_frame;
-    out->cut_ranks = ctx->exchange_cut;
-    out->exact = exact ? 1u : 0u;
-    out->mode = ctx->exchange_mode;
-    out->ready_event = slot.done;
-    return GV_OK;
+    if (!out || flags)
+        return ctx->fail(GV_E_ARG, "gv_exchange_visible: NULL frame or flags 0x%x (none are defined)", flags);
+    return visible_all(&ctx, 1, &view_index, &index_base, out, false);
 }
 
-int gv_exchange_acquire(GvCtx* ctx, uint64_t frame)
+int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32_t* view_indices, const uint32_t* index_bases, uint32_t flags,
+                            GvExchangeFrame* frames)
+{
+    if (int rc = all_args(contexts, world_size))
+        return rc;
+    if (!view_indices || !frames || flags)
+        return contexts[0]->fail(GV_E_ARG, "gv_exchange_visible_all: NULL view indices / frames, or flags 0x%x (none are defined)", flags);
+    return visible_all(contexts, world_size, view_indices, index_bases, frames, true);
+}
+
+int gv_exchange_acquire(GvCtx* ctx, uint64_t frame, GvExchangeFrame* out)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_acquire: gv_exchange_init has not run");
-    if (frame >= ctx->exchange_frame || frame + 2 < ctx->exchange_frame || ctx->exchange_slots[frame & 1u].frame != frame)
-        return ctx->fail(GV_E_ARG, "gv_exchange_acquire: frame %llu is not one of the last two exchanged (next: %llu)",
-                         (unsigned long long)frame, (unsigned long long)ctx->exchange_frame);
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    GV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->exchange_slots[frame & 1u].done, 0));
-    return GV_OK;
+    return acquire_all(&ctx, 1, frame, out, false);
 }
 
-int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks)
+int gv_exchange_acquire_all(GvCtx* const* contexts, int world_size, uint64_t frame, GvExchangeFrame* frames)
 {
-    if (!ctx)
-        return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_counts: gv_exchange_init has not run");
-    if (!counts || frame >= ctx->exchange_frame || frame + 2 < ctx->exchange_frame)
-        return ctx->fail(GV_E_ARG, "gv_exchange_counts: frame %llu is not one of the last two exchanged (next: %llu)",
-                         (unsigned long long)frame, (unsigned long long)ctx->exchange_frame);
-    gv::Context::ExchangeSlot& slot = ctx->exchange_slots[frame & 1u];
-    if (slot.frame != frame)
-        return ctx->fail(GV_E_STATE, "gv_exchange_counts: frame %llu's rows have been reused", (unsigned long long)frame);
-    if (slot.in_flight) {  // (not yet retired: its collective may still be running)
-        GV_HIP(ctx, hipSetDevice(ctx->device));
-        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-        if (int rc = wait_for_headers(ctx, slot))
-            return rc;
-    }
-    uint64_t cut = 0;
-    for (int k = 0; k < ctx->exchange_world; k++) {
-        counts[k] = slot.hdr.ptr[k];
-        if (counts[k] > slot.room[k])
-            cut |= 1ull << k;
-    }
-    if (cut_ranks)
-        *cut_ranks = cut;
-    return GV_OK;
+    if (int rc = all_args(contexts, world_size))
+        return rc;
+    return acquire_all(contexts, world_size, frame, frames, true);
 }
 
 int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!ctx->exchange_comm)
-        return ctx->fail(GV_E_STATE, "gv_exchange_masks: gv_exchange_init has not run");
+    if (int rc = usable(ctx, "gv_exchange_masks", false))
+        return rc;
     if (!gathered_device || word_count == 0)
         return ctx->fail(GV_E_ARG, "gv_exchange_masks: NULL buffer or zero word count");
     GV_HIP(ctx, hipSetDevice(ctx->device));
@@ -530,9 +870,11 @@ int gv_exchange_shutdown(GvCtx* ctx)
     if (!ctx)
         return GV_E_ARG;
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->exchange_stream)
-        GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
+    if (!ctx->exchange_broken) {
+        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->exchange_stream)
+            GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
+    }
     gv::exchange_release(ctx);
     return GV_OK;
 }

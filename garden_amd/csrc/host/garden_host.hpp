@@ -142,7 +142,11 @@ public:
         reparentHi = std::max(reparentHi, slot + 1);
         reparentVersion++;
     }
-    // transform.cpp:75-127: flips selfActive and pushes ancestorsActive down the subtree
+    // TransformComponent::setActive, transform.cpp:75-127, walk for walk. Activating: nothing moves below an entity whose own
+    // ancestors are inactive (:86-87); otherwise children become ancestorsActive = true, and the walk does NOT descend through a
+    // child that is itself inactive (:94-95 `continue`): the bytes below it are left as they are — which is what makes the stored
+    // byte history-dependent (a grandchild deactivated by an earlier walk stays so). Deactivating: every descendant, whatever
+    // its own state (:110-124).
     void setActive(ID<Entity> entity, bool isActive)
     {
         auto view = tryGetOf(entity);
@@ -150,9 +154,36 @@ public:
             return;
         view->selfActive = isActive;
         touchFlags((uint32_t)(*view - components.getData()));
-        if (view->ancestorsActive)
-            for (uint32_t i = 0, n = view->childCount(); i < n; i++)
-                propagateActive(view->childs[i], isActive);
+        std::vector<ID<Entity>> stack{entity};
+        if (isActive) {
+            if (!view->ancestorsActive)
+                return;
+            while (!stack.empty()) {
+                auto v = tryGetOf(stack.back());
+                stack.pop_back();
+                if (!v || !v->selfActive)
+                    continue;
+                for (uint32_t i = 0, n = v->childCount(); i < n; i++)
+                    if (auto child = tryGetOf(v->childs[i])) {
+                        child->ancestorsActive = true;
+                        touchFlags((uint32_t)(*child - components.getData()));
+                        stack.push_back(v->childs[i]);
+                    }
+            }
+        } else {
+            while (!stack.empty()) {
+                auto v = tryGetOf(stack.back());
+                stack.pop_back();
+                if (!v)
+                    continue;
+                for (uint32_t i = 0, n = v->childCount(); i < n; i++)
+                    if (auto child = tryGetOf(v->childs[i])) {
+                        child->ancestorsActive = false;
+                        touchFlags((uint32_t)(*child - components.getData()));
+                        stack.push_back(v->childs[i]);
+                    }
+            }
+        }
     }
     void markTransformsChanged() noexcept { transformVersion++; }
     // Itemised form for writers that know what they moved (an animation / physics system walking its own list): the
@@ -220,22 +251,6 @@ private:
         flagsHi = std::max(flagsHi, slot + 1);
         flagsVersion++;
     }
-    void propagateActive(ID<Entity> entity, bool ancestors)
-    {
-        std::vector<std::pair<ID<Entity>, bool>> stack{{entity, ancestors}};
-        while (!stack.empty()) {
-            auto [e, a] = stack.back();
-            stack.pop_back();
-            auto v = tryGetOf(e);
-            if (!v)
-                continue;
-            v->ancestorsActive = a;
-            touchFlags((uint32_t)(*v - components.getData()));
-            const bool below = a && v->selfActive;
-            for (uint32_t i = 0, n = v->childCount(); i < n; i++)
-                stack.push_back({v->childs[i], below});
-        }
-    }
 };
 
 // render/mesh.hpp:45-55 — 48 bytes; derived components are larger, hence getMeshComponentSize().
@@ -254,15 +269,28 @@ static_assert(sizeof(MeshRenderComponent) == 48, "MeshRenderComponent must keep 
 
 enum class MeshRenderType : uint8_t { Color, Opaque, Translucent, OIT, Refracted, TransDepth, UI, Count };
 
-// render/mesh.hpp:60-147 (only the members the prepare phase consumes).
+// render/mesh.hpp:60-147 — the members the prepare phase consumes, with the reference's names, signatures and access: isDrawReady is
+// protected and reached through `friend class MeshRenderSystem` (mesh.hpp:69,118); the two classes that stand where
+// MeshRenderSystem stands here are its friends instead.
+class GpuVisibilitySystem;
+class CpuMeshRenderSystem;
 class IMeshRenderSystem {
 public:
     using MeshRenderPool = LinearPool<MeshRenderComponent, false>;
     virtual ~IMeshRenderSystem() = default;
-    virtual MeshRenderType getMeshRenderType() const = 0;
-    virtual uint8_t* getMeshComponentData() const = 0;       // getMeshComponentPool().getData()
-    virtual uint32_t getMeshComponentOccupancy() const = 0;  // getMeshComponentPool().getOccupancy()
-    virtual size_t getMeshComponentSize() const = 0;
+
+protected:
+    // "Is mesh system ready for rendering. (All resources loaded, etc.)" shadowPass: shadow pass index, light pass = -1
+    // (mesh.hpp:64-69; pass-dependent in InstanceRenderSystem::isDrawReady, instance.cpp:61-…, UiLabelSystem, label.cpp:262-269)
+    virtual bool isDrawReady(int8_t shadowPass) = 0;
+
+public:
+    virtual MeshRenderType getMeshRenderType() const = 0;         // mesh.hpp:123
+    virtual MeshRenderPool& getMeshComponentPool() const = 0;     // mesh.hpp:127: walked with getMeshComponentSize() as byte stride
+    virtual size_t getMeshComponentSize() const = 0;              // mesh.hpp:131
+
+    friend class GpuVisibilitySystem;
+    friend class CpuMeshRenderSystem;
 };
 
 // One mesh system per component type, as in the engine (ModelRenderSystem, SpriteRenderSystem, ... each own a pool
@@ -282,8 +310,15 @@ public:
     }
     void clearMeshRange() noexcept { meshLo = UINT32_MAX; meshHi = 0; }
 };
+// stand-in for "all resources loaded": what a system's isDrawReady answers for the light pass and for each shadow pass
+class ReadinessSwitch {
+public:
+    bool readyMain = true;
+    uint32_t readyShadowMask = ~0u;  // bit s = shadow pass s
+    bool drawReady(int8_t shadowPass) const noexcept { return shadowPass < 0 ? readyMain : ((readyShadowMask >> shadowPass) & 1u) != 0; }
+};
 template <class C, MeshRenderType TYPE>
-class MeshSystemOf : public ComponentSystem<C, false>, public IMeshRenderSystem, public VersionedMeshSystem {
+class MeshSystemOf : public ComponentSystem<C, false>, public IMeshRenderSystem, public VersionedMeshSystem, public ReadinessSwitch {
     static_assert(std::is_base_of<MeshRenderComponent, C>::value, "mesh components derive from MeshRenderComponent");
 
 public:
@@ -306,9 +341,18 @@ public:
         ComponentSystem<C, false>::disposeComponents();
     }
     MeshRenderType getMeshRenderType() const override { return TYPE; }
-    uint8_t* getMeshComponentData() const override { return reinterpret_cast<uint8_t*>(this->components.getData()); }
-    uint32_t getMeshComponentOccupancy() const override { return this->components.getOccupancy(); }
+    // the engine's own spelling (instance.hpp:108, sprite.hpp:192, 9-slice.hpp:120): the pool of the derived component type, seen
+    // as a pool of the base type — data, occupancy and count do not depend on the element type
+    // (the engine's own cast; a translation unit that calls this is built with -fno-strict-aliasing, like tests/cpp/Makefile)
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wstrict-aliasing"
+    MeshRenderPool& getMeshComponentPool() const override { return *((MeshRenderPool*)&this->components); }
+#pragma GCC diagnostic pop
     size_t getMeshComponentSize() const override { return sizeof(C); }
+
+
+protected:
+    bool isDrawReady(int8_t shadowPass) override { return drawReady(shadowPass); }
 };
 using OpaqueMeshSystem = MeshSystemOf<MeshRenderComponent, MeshRenderType::Opaque>;
 
@@ -324,6 +368,15 @@ struct alignas(16) OitMeshComponent final : public MeshRenderComponent {
 struct alignas(16) UiMeshComponent final : public MeshRenderComponent {
     float uvSize[2] = {1, 1}, uvOffset[2] = {0, 0};
 };
+struct alignas(16) RefractedMeshComponent final : public MeshRenderComponent {
+    float indexOfRefraction[4] = {1.33f, 0, 0, 0};
+};
+struct alignas(16) TransDepthMeshComponent final : public MeshRenderComponent {
+    float colorFactor[4] = {1, 1, 1, 0.25f};
+    float depthBias[4] = {0, 0, 0, 0};
+};
+using RefractedMeshSystem = MeshSystemOf<RefractedMeshComponent, MeshRenderType::Refracted>;
+using TransDepthMeshSystem = MeshSystemOf<TransDepthMeshComponent, MeshRenderType::TransDepth>;
 using TranslucentMeshSystem = MeshSystemOf<TranslucentMeshComponent, MeshRenderType::Translucent>;
 using OitMeshSystem = MeshSystemOf<OitMeshComponent, MeshRenderType::OIT>;
 using UiMeshSystem = MeshSystemOf<UiMeshComponent, MeshRenderType::UI>;

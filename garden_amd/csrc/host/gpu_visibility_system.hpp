@@ -50,6 +50,8 @@ private:
     std::vector<std::vector<UnsortedBuffer*>> shadowBuffers;    // [unsorted buffer][pass]
     std::vector<std::vector<SortedMesh>> shadowTransMeshes;     // [pass]: the reference re-runs prepareMeshes per
     std::vector<uint32_t> shadowTransDrawIndex;                 // pass and draws at once; here every pass is kept
+    std::vector<std::vector<SortedBuffer*>> shadowSortedBuffers; // [pass][bufferIndex of that pass]: the counters of sortedBuffers in a shadow pass
+    bool hasAnyRefr = false, hasAnyOIT = false, hasAnyTD = false;  // mesh.hpp:232-234, set by the light pass (mesh.cpp:339,488-490)
     f32x4x4 uiViewProj;                                          // calcUiProjView(), mesh.cpp:851-859
     uint64_t seenHierarchy = ~0ull, seenTransform = ~0ull, seenReparent = 0, seenFlags = 0;
     std::vector<uint64_t> seenMesh;
@@ -124,9 +126,18 @@ public:
         for (auto& v : shadowBuffers)
             for (auto b : v)
                 delete b;
+        for (auto& v : shadowSortedBuffers)
+            for (auto b : v)
+                delete b;
     }
 
     GvCtx* getContext() const noexcept { return ctx; }
+    // what preRefrRender / the OIT and TransDepth passes ask (mesh.cpp:917-923): did the light pass prepare any such system?
+    bool getHasAnyRefr() const noexcept { return hasAnyRefr; }
+    bool getHasAnyOIT() const noexcept { return hasAnyOIT; }
+    bool getHasAnyTD() const noexcept { return hasAnyTD; }
+    // sortedBuffers as shadow pass `pass` leaves them (Translucent systems only: a UI system takes no bufferIndex there, mesh.cpp:416-419)
+    const std::vector<SortedBuffer*>& getShadowSortedBuffers(uint32_t pass) const { return shadowSortedBuffers.at(pass); }
     const std::vector<UnsortedBuffer*>& getUnsortedBuffers() const noexcept { return unsortedBuffers; }
     uint32_t getUnsortedBufferCount() const noexcept { return unsortedBufferCount; }
     const std::vector<SortedBuffer*>& getSortedBuffers() const noexcept { return sortedBuffers; }
@@ -316,6 +327,7 @@ private:
         auto graphicsSystem = GraphicsSystem::Instance::get();
         Stopwatch whole(tickSeconds.total);
         prepareSystems();
+        bool sweepRequested = false;
 
         // Pools may have moved (create() can reallocate): re-bind every frame, as `gv_pool_bind` documents.
         static const GvTransformLayout transformLayout = {
@@ -360,39 +372,58 @@ private:
 
         const auto& cc = graphicsSystem->getCommonConstants();
         const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
-        transDrawIndex = uiDrawIndex = 0;
+        transDrawIndex = uiDrawIndex = 0;                  // mesh.cpp:337
+        hasAnyRefr = hasAnyOIT = hasAnyTD = false;         // mesh.cpp:339
         shadowTransMeshes.resize(passCount);
         shadowTransDrawIndex.assign(passCount, 0);
+        shadowSortedBuffers.resize(passCount);
         std::vector<uint32_t> transRuns, uiRuns;
         std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
-        uint32_t unsortedBufferIndex = 0, sortedBufferIndex = 0;
 
         // Phase 1 — every mesh system's cull (and sort request) is issued before any result is read: results are kept
         // per (pool, view), so the device works through the systems back to back while the host only enqueues; the
         // reference dispatches every system's tasks to its thread pool and waits once, too (mesh.cpp:408-546, :548).
-        std::vector<uint32_t> viewCounts(meshSystems.size(), 0);
-        uint32_t sortedSeen = 0, unsortedSeen = 0;
+        // viewPass[p][v] = the pass view v of system p's cull stands for (-1 the light pass, s >= 0 shadow pass s): only passes
+        // that get through the reference's gate are culled at all (mesh.cpp:426,482).
+        std::vector<std::vector<int8_t>> viewPass(meshSystems.size());
+        struct Indices {
+            uint32_t main = 0, shadow = 0;  // bufferIndex in the light pass / in a shadow pass
+        };
+        std::vector<Indices> indices(meshSystems.size());
+        uint32_t sortedSeen = 0, shadowSortedSeen = 0, unsortedSeen = 0;
         check(gv_cull_batch_begin(ctx), "gv_cull_batch_begin");  // engine-sized pools: one cull / emit / sort / publish launch per tick
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
-            check(gv_pool_bind(ctx, p, meshSystem->getMeshComponentData(), meshSystem->getMeshComponentSize(),
-                               meshSystem->getMeshComponentOccupancy(), &meshLayout), "gv_pool_bind");
+            const auto& componentPool = meshSystem->getMeshComponentPool();        // mesh.cpp:410
+            const uint32_t componentCount = componentPool.getCount();              // mesh.cpp:411
+            const uint32_t occupancy = componentPool.getOccupancy();
+            const bool sorted = isSortedType(renderType);
+            // bufferIndex: in the light pass Translucent and UI systems count (mesh.cpp:419); in a shadow pass a UI system leaves the
+            // loop before it takes one (:416-417), so a Translucent system's index there counts Translucent systems only
+            if (sorted) {
+                indices[p].main = sortedSeen++;
+                if (renderType == MeshRenderType::Translucent)
+                    indices[p].shadow = shadowSortedSeen++;
+            } else {
+                indices[p].main = indices[p].shadow = unsortedSeen++;
+            }
+            // the pool is bound and its changes are taken over whether or not the system is drawn this frame: a system that
+            // becomes ready later is culled from the pool as it is then
+            check(gv_pool_bind(ctx, p, componentPool.getData(), meshSystem->getMeshComponentSize(), occupancy, &meshLayout), "gv_pool_bind");
             bool inPlace = false;
             {
                 GvRecordLayout layout;
-                const bool sorted = isSortedType(renderType);
                 const bool expressible = sorted
-                    ? recordLayoutOf<SortedMesh>(layout, meshSystem->getMeshComponentSize(), (uint32_t)offsetof(SortedMesh, bufferIndex), sortedSeen)
+                    ? recordLayoutOf<SortedMesh>(layout, meshSystem->getMeshComponentSize(), (uint32_t)offsetof(SortedMesh, bufferIndex), indices[p].main)
                     : recordLayoutOf<UnsortedMesh>(layout, meshSystem->getMeshComponentSize(), GV_NONE, 0);
-                sortedSeen += sorted ? 1 : 0;  // == the bufferIndex phase 2 gives this system
                 check(gv_pool_set_record_layout(ctx, p, emitRecords && recordStructs && expressible ? &layout : nullptr),
                       "gv_pool_set_record_layout");
                 inPlace = !sorted && emitRecords && recordStructs && expressible && recordTargets;
             }
             if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem)) {
                 if (seenMesh[p] != versioned->meshVersion) {
-                    check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
+                    check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, occupancy), "gv_mark_dirty");
                     seenMesh[p] = versioned->meshVersion;
                 } else if (versioned->meshLo < versioned->meshHi) {  // created / destroyed / edited components only
                     check(gv_mark_dirty(ctx, GV_DIRTY_MESH, (p << 28) | versioned->meshLo, versioned->meshHi - versioned->meshLo),
@@ -400,33 +431,44 @@ private:
                 }
                 versioned->clearMeshRange();
             } else {  // unknown writer: re-mirror the pool every frame (always correct)
-                check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, meshSystem->getMeshComponentOccupancy()), "gv_mark_dirty");
+                check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, occupancy), "gv_mark_dirty");
             }
 
-            // view 0 = main camera (shadowPass -1: writes isVisible), views 1.. = shadow passes (mesh.cpp:809-843).
-            // UI: its own ortho frustum, camera at the origin, 2D distance key, no shadow passes (mesh.cpp:416,436-442)
+            // The gate of mesh.cpp:426 / :482, pass by pass: `componentCount == 0 || !meshSystem->isDrawReady(shadowPass)` leaves the
+            // system's counters at 0 for that pass and touches nothing else — in the light pass isVisible keeps last frame's bytes.
+            // The light pass (shadowPass -1: writes isVisible), then the shadow passes (mesh.cpp:809-843). UI: its own ortho
+            // frustum, camera at the origin, 2D distance key, no shadow passes (mesh.cpp:416,436-442).
             std::vector<GvView> views;
-            if (renderType == MeshRenderType::UI) {
-                views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
-            } else {
-                views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
-                for (uint32_t s = 0; s < passCount; s++)
-                    views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset,
-                                             (int8_t)s, false, emitRecords));
+            auto& passes = viewPass[p];
+            const bool lightPass = componentCount != 0 && meshSystem->isDrawReady(-1);
+            if (lightPass) {
+                if (renderType == MeshRenderType::UI)
+                    views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
+                else
+                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
+                passes.push_back(-1);
+                if (!sorted) {  // mesh.cpp:488-490
+                    hasAnyRefr |= renderType == MeshRenderType::Refracted;
+                    hasAnyOIT |= renderType == MeshRenderType::OIT;
+                    hasAnyTD |= renderType == MeshRenderType::TransDepth;
+                }
             }
-            viewCounts[p] = (uint32_t)views.size();
-            if (!isSortedType(renderType)) {
+            if (renderType != MeshRenderType::UI)
+                for (uint32_t s = 0; s < passCount; s++)
+                    if (componentCount != 0 && meshSystem->isDrawReady((int8_t)s)) {
+                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false, emitRecords));
+                        passes.push_back((int8_t)s);
+                    }
+            if (!sorted) {
                 // An unsorted system's buffers are its own (mesh.hpp:213-217), sized before its tasks run like the
                 // reference's scratch (mesh.cpp:377-395; here to the occupancy, which bounds any draw count): the device
                 // writes the records where renderUnsorted reads them. Shared sorted arrays keep the append + merge.
-                const uint32_t bufferIndex = unsortedSeen++;  // == the bufferIndex phase 2 gives this system
-                auto& sb = shadowBuffers[bufferIndex];
-                while (sb.size() + 1 < views.size())
+                auto& sb = shadowBuffers[indices[p].main];
+                while (sb.size() < passCount)
                     sb.push_back(new UnsortedBuffer());
-                const size_t occupancy = meshSystem->getMeshComponentOccupancy();
                 for (uint32_t v = 0; v < views.size(); v++) {
-                    UnsortedBuffer* buffer = v == 0 ? unsortedBuffers[bufferIndex] : sb[v - 1];
-                    const bool target = inPlace && !recordSpans && occupancy && occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
+                    UnsortedBuffer* buffer = passes[v] < 0 ? unsortedBuffers[indices[p].main] : sb[passes[v]];
+                    const bool target = inPlace && !recordSpans && occupancy && (size_t)occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
                     if (target && buffer->combinedMeshes.size() < occupancy) {
                         // growing re-allocates: let the old range go while it is still allocated
                         check(gv_pool_set_record_target(ctx, p, v, nullptr, 0), "gv_pool_set_record_target");
@@ -440,8 +482,12 @@ private:
                     }
                 }
             }
-            if (sweepWorldMatrices && p == 0)
+            if (views.empty())
+                continue;  // no pass draws this system this frame: nothing is culled, sorted or read for it
+            if (sweepWorldMatrices && !sweepRequested) {
                 check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_WITH_CULL), "gv_sweep");
+                sweepRequested = true;
+            }
             {
                 Stopwatch watch(tickSeconds.cull);
                 check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
@@ -451,36 +497,65 @@ private:
             if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT) {
                 Stopwatch watch(tickSeconds.sort);
                 for (uint32_t v = 0; v < views.size(); v++)
-                    check(gv_pool_sort(ctx, p, v, isSortedType(renderType) ? 1 : 0), "gv_pool_sort");
+                    check(gv_pool_sort(ctx, p, v, sorted ? 1 : 0), "gv_pool_sort");
             }
         }
+        for (uint32_t s = 0; s < passCount; s++)
+            while (shadowSortedBuffers[s].size() < shadowSortedSeen)
+                shadowSortedBuffers[s].push_back(new SortedBuffer());
+        if (sweepWorldMatrices && !sweepRequested)  // no system is drawn this frame: the cache is kept current all the same
+            check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_VALU), "gv_sweep");
 
-        // Phase 2 — read the results (the first fetch publishes every small pool's views at once).
+        // Phase 2 — read the results (the first fetch publishes every small pool's views at once). Every buffer of every pass is
+        // first put in the state mesh.cpp:420-424 / :476-480 leave it in — its system, both counters 0 — and only the passes
+        // that were culled fill theirs.
+        auto reset = [](MeshBuffer* buffer, IMeshRenderSystem* meshSystem) {
+            buffer->meshSystem = meshSystem;
+            buffer->drawCount = 0;
+            buffer->instanceCount = 0;
+        };
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
-            const uint32_t viewCount = viewCounts[p];
+            const auto& passes = viewPass[p];
             if (isSortedType(renderType)) {
-                const uint32_t bufferIndex = sortedBufferIndex++;
-                for (uint32_t v = 1; v < viewCount; v++) {
-                    append(shadowTransMeshes[v - 1], shadowTransDrawIndex[v - 1], nullptr, meshSystem, p, v, false, bufferIndex);
-                    shadowTransRuns[v - 1].push_back(shadowTransDrawIndex[v - 1]);
-                }
-                if (renderType == MeshRenderType::UI) {
-                    append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, 0, true, bufferIndex);
-                    uiRuns.push_back(uiDrawIndex);
-                } else {
-                    append(transSortedMeshes, transDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, 0, true, bufferIndex);
-                    transRuns.push_back(transDrawIndex);
+                const uint32_t bufferIndex = indices[p].main, shadowIndex = indices[p].shadow;
+                reset(sortedBuffers[bufferIndex], meshSystem);
+                if (renderType == MeshRenderType::Translucent)
+                    for (uint32_t s = 0; s < passCount; s++)
+                        reset(shadowSortedBuffers[s][shadowIndex], meshSystem);
+                for (uint32_t v = 0; v < passes.size(); v++) {
+                    if (passes[v] >= 0) {
+                        const uint32_t s = (uint32_t)passes[v], first = shadowTransDrawIndex[s];
+                        const uint32_t added = append(shadowTransMeshes[s], shadowTransDrawIndex[s], shadowSortedBuffers[s][shadowIndex], meshSystem, p, v,
+                                                      false, shadowIndex);
+                        if (shadowIndex != bufferIndex)  // (records built on the device carry the light pass's index)
+                            for (uint32_t k = 0; k < added; k++)
+                                shadowTransMeshes[s][first + k].bufferIndex = shadowIndex;
+                        shadowTransRuns[s].push_back(shadowTransDrawIndex[s]);
+                    } else if (renderType == MeshRenderType::UI) {
+                        append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, v, true, bufferIndex);
+                        uiRuns.push_back(uiDrawIndex);
+                    } else {
+                        append(transSortedMeshes, transDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, v, true, bufferIndex);
+                        transRuns.push_back(transDrawIndex);
+                    }
                 }
             } else {
-                const uint32_t bufferIndex = unsortedBufferIndex++;
+                const uint32_t bufferIndex = indices[p].main;
                 auto& sb = shadowBuffers[bufferIndex];
-                while (sb.size() + 1 < viewCount)
-                    sb.push_back(new UnsortedBuffer());
-                for (uint32_t v = 1; v < viewCount; v++)
-                    fill(sb[v - 1], meshSystem, p, v, false);
-                fill(unsortedBuffers[bufferIndex], meshSystem, p, 0, true);
+                reset(unsortedBuffers[bufferIndex], meshSystem);
+                unsortedBuffers[bufferIndex]->span = nullptr;
+                for (uint32_t s = 0; s < passCount; s++) {
+                    reset(sb[s], meshSystem);
+                    sb[s]->span = nullptr;
+                }
+                for (uint32_t v = 0; v < passes.size(); v++)
+                    if (passes[v] >= 0)
+                        fill(sb[passes[v]], meshSystem, p, v, false);
+                for (uint32_t v = 0; v < passes.size(); v++)
+                    if (passes[v] < 0)
+                        fill(unsortedBuffers[bufferIndex], meshSystem, p, v, true);
             }
         }
         if (emitRecords && sortOnDevice) {

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GV_LIB_PATH") or os.path.join(_HERE, "lib", "libgarden_vis.so")
 
 GV_MAX_POOLS, GV_MAX_VIEWS, GV_MAX_MIPS, GV_K_COUNT = 16, 8, 16, 6
-GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+GV_OK, GV_E_ARG, GV_E_HIP, GV_E_OOM, GV_E_RCCL, GV_E_STATE, GV_E_NODEVICE, GV_E_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 GV_HIZ_RULE_REFERENCE, GV_HIZ_RULE_CONSERVATIVE = 0, 1
 GV_CONFIG_PROFILE_EVENTS = 1
 GV_CONFIG_PROFILE_CULL_ONLY = 2
@@ -73,14 +73,13 @@ class GvStats(C.Structure):
 
 
 GV_EXCHANGE_MAX_RANKS = 64
-GV_EXCHANGE_EXACT = 1
 
 
 class GvExchangeFrame(C.Structure):
     _fields_ = [("gathered_device", C.c_void_p), ("row_words", C.c_uint32), ("world_size", C.c_uint32), ("frame", C.c_uint64),
-                ("room", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("travelled_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("counts_frame", C.c_uint64),
-                ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64), ("exact", C.c_uint32), ("mode", C.c_uint32),
-                ("ready_event", C.c_void_p)]
+                ("room", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("travelled_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS),
+                ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("tail_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64),
+                ("complete", C.c_uint32), ("mode", C.c_uint32), ("ready_event", C.c_void_p)]
 
 
 class GvColumn(C.Structure):
@@ -123,7 +122,7 @@ EXPORTS = [
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_acquire", "gv_exchange_counts", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -203,8 +202,11 @@ def load():
     lib.gv_exchange_init.argtypes = [P, P, C.c_int, C.c_int]
     lib.gv_exchange_shards.argtypes = [P, u32, u32, P, u32, P]
     lib.gv_exchange_visible.argtypes = [P, u32, u32, u32, C.POINTER(GvExchangeFrame)]
-    lib.gv_exchange_acquire.argtypes = [P, C.c_uint64]
-    lib.gv_exchange_counts.argtypes = [P, C.c_uint64, P, C.POINTER(C.c_uint64)]
+    lib.gv_exchange_acquire.argtypes = [P, C.c_uint64, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_init_all.argtypes = [C.POINTER(P), C.c_int]
+    lib.gv_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_acquire_all.argtypes = [C.POINTER(P), C.c_int, C.c_uint64, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_set_timeout.argtypes = [P, u32]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]
     lib.gv_exchange_set_mode.argtypes = [P, u32]
@@ -488,36 +490,42 @@ class GpuVisibility:
     def exchange_init(self, unique_id, rank, world_size):
         self._check(self.lib.gv_exchange_init(self.ctx, unique_id, rank, world_size))
 
-    def exchange_shards(self, view_index, capacity, index_base, gathered_ptr, capacities=None):
+    def exchange_shards(self, view_index, capacity, index_base, gathered_ptr, capacities=None, world=None):
         """Caller-owned rows [world, 1 + capacity]; capacities (one per rank, the same list on every rank): what of each
-        rank's row travels under the direct patterns."""
+        rank's row travels under the direct patterns. (gv_exchange_shards reads one capacity per rank of the communicator: pass
+        `world` to have the list's length checked here.)"""
         caps = None
         if capacities is not None:
-            caps = (C.c_uint32 * len(capacities))(*[int(c) for c in capacities])
+            if world is not None and len(capacities) != world:
+                raise ValueError(f"exchange_shards: {len(capacities)} capacities for {world} ranks")
+            caps = (C.c_uint32 * max(len(capacities), GV_EXCHANGE_MAX_RANKS))(*[int(c) for c in capacities])
         self._check(self.lib.gv_exchange_shards(self.ctx, view_index, capacity, caps, index_base, gathered_ptr))
 
-    def exchange_visible(self, view_index=0, index_base=0, exact=False):
-        """The per-frame exchange with library-owned, library-sized rows (gv_exchange_visible). Returns a dict: ptr (device address
-        of the uint32 rows [world, row_words]), row_words, world, frame, room, travelled_words, counts_frame (None: no frame's
-        headers have reached the host yet), counts, cut_ranks (list of ranks), exact, mode."""
-        f = GvExchangeFrame()
-        self._check(self.lib.gv_exchange_visible(self.ctx, view_index, index_base, GV_EXCHANGE_EXACT if exact else 0, C.byref(f)))
+    @staticmethod
+    def _exchange_frame(f):
         w = f.world_size
-        return dict(ptr=f.gathered_device, row_words=f.row_words, world=w, frame=int(f.frame),
+        return dict(ptr=f.gathered_device, row_words=f.row_words, world=w, frame=int(f.frame), complete=bool(f.complete),
                     room=[int(f.room[r]) for r in range(w)], travelled_words=[int(f.travelled_words[r]) for r in range(w)],
-                    counts_frame=None if f.counts_frame == 0xFFFFFFFFFFFFFFFF else int(f.counts_frame),
-                    counts=[int(f.counts[r]) for r in range(w)], cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1],
-                    exact=bool(f.exact), mode=int(f.mode), ready_event=f.ready_event)
+                    counts=[int(f.counts[r]) for r in range(w)], tail_words=[int(f.tail_words[r]) for r in range(w)],
+                    cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1], mode=int(f.mode), ready_event=f.ready_event)
+
+    def exchange_visible(self, view_index=0, index_base=0):
+        """Sends the frame (gv_exchange_visible): library-owned rows, sized from the previous frame's headers. Returns a dict:
+        frame, row_words, world, room, travelled_words, mode — the rows themselves are handed out by exchange_acquire."""
+        f = GvExchangeFrame()
+        self._check(self.lib.gv_exchange_visible(self.ctx, view_index, index_base, 0, C.byref(f)))
+        return self._exchange_frame(f)
 
     def exchange_acquire(self, frame):
-        """Work enqueued on the context's stream after this call sees frame `frame`'s gathered rows (no host wait)."""
-        self._check(self.lib.gv_exchange_acquire(self.ctx, frame))
+        """Frame `frame` complete — every rank's WHOLE list, short predictions made good by a second exchange — and the context's
+        stream ordered behind it (gv_exchange_acquire). Returns the frame's dict: ptr (device address of the uint32 rows
+        [world, row_words]), counts, cut_ranks / tail_words (statistics), ready_event."""
+        f = GvExchangeFrame()
+        self._check(self.lib.gv_exchange_acquire(self.ctx, frame, C.byref(f)))
+        return self._exchange_frame(f)
 
-    def exchange_counts(self, frame, world):
-        """Blocks until frame `frame`'s row headers are on the host: (counts per rank, ranks whose rows were cut)."""
-        counts, cut = (C.c_uint32 * world)(), C.c_uint64()
-        self._check(self.lib.gv_exchange_counts(self.ctx, frame, counts, C.byref(cut)))
-        return [int(c) for c in counts], [r for r in range(world) if (cut.value >> r) & 1]
+    def exchange_set_timeout(self, milliseconds):
+        self._check(self.lib.gv_exchange_set_timeout(self.ctx, milliseconds))
 
     def exchange_masks(self, view_index, word_count, gathered_ptr):
         """All ranks' [draw_count, one bit per mirror entry] shards into gathered_ptr ([world, 1 + word_count] uint32, device)."""

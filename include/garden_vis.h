@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 2u /* 2: gv_exchange_shards takes per-rank capacities; gv_exchange_visible / _counts */
+#define GV_ABI_VERSION 3u /* 3: every exchanged frame is complete (gv_exchange_acquire fills the frame; GV_EXCHANGE_EXACT and
+                             gv_exchange_counts are gone); one thread can drive N contexts (gv_exchange_*_all); GV_E_TIMEOUT */
 #define GV_NONE 0xFFFFFFFFu
 #define GV_MAX_POOLS 16u
 #define GV_MAX_VIEWS 8u
@@ -41,7 +42,8 @@ typedef enum GvStatus {
     GV_E_OOM = -3,     /* host or device allocation failed */
     GV_E_RCCL = -4,    /* collective failed (multi-GPU exchange) */
     GV_E_STATE = -5,   /* call out of order (e.g. cull before bind, Hi-Z query before build) */
-    GV_E_NODEVICE = -6 /* no gfx950 device / kernels not loadable: there is NO CPU fallback */
+    GV_E_NODEVICE = -6, /* no gfx950 device / kernels not loadable: there is NO CPU fallback */
+    GV_E_TIMEOUT = -7   /* a bounded wait ran out (a peer rank of the exchange stalled or left): gv_exchange_set_timeout */
 } GvStatus;
 
 typedef struct GvCtx GvCtx;
@@ -339,51 +341,71 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
 int gv_exchange_unique_id(void* out_id_128_bytes);
 int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int world_size);
 
-/* The per-frame exchange, sized by the library: enqueues on the context's stream this rank's shard [draw_count, visible_idx +
- * index_base ...] (gv_results_copy_shard_device; the pool's gv_pool_set_index_map table applies) and its gather into a
- * library-owned device buffer of world_size rows (row r = rank r's shard, out->row_words uint32 apart). The shard copy is the
- * last thing gv_stream(ctx) does for the frame; the rows travel on a second stream of the library's, so the caller's next
- * gv_hiz_build / gv_cull run while this frame's list is still on the links. No host synchronisation in the steady state: a
- * consumer orders itself behind out->ready_event (hipStreamWaitEvent on its own stream), or calls gv_exchange_acquire(ctx,
- * out->frame) to make gv_stream(ctx) wait, and reads the counts from the row headers. How much of each rank's row travels is decided from the headers of an EARLIER frame, which every rank holds and which
- * reach the host through pinned memory two frames later (no event, no synchronisation): rank r's list gets
- * count + max(count / 8, 1024) words of room, rounded up to 1024 — grown at once, given back when the list has shrunk by a
- * quarter. Every rank sees the same headers, so every rank derives the same sizes. Frame 0 — and the frame after a row was found
- * cut (a header above the room its row had: out->cut_ranks names them, out->counts_frame the frame), and any frame called with
- * GV_EXCHANGE_EXACT (a camera cut) — first all-gathers the counts themselves (one word per rank) and sizes from those; such a
- * frame synchronises the host with the stream once. Buffers alternate: a frame's rows stay valid until the exchange after the next.
- * flags must be the same on every rank. */
+/* One host thread, N GPUs (the reference is ONE process with ONE Manager, source/editor/entry.cpp:135): the *_all forms take the
+ * N contexts of the node's GPUs (contexts[r] = rank r) and issue their collectives inside ONE ncclGroupStart / ncclGroupEnd, which is
+ * what RCCL requires of a thread that drives several devices. gv_exchange_init_all makes the unique id itself. A communicator
+ * started with one form is used through that form only (per-rank calls from N threads or processes, or the *_all calls from one). */
+int gv_exchange_init_all(GvCtx* const* contexts, int world_size);
+
+/* The per-frame exchange — the gather of mesh.cpp:177-183, which never loses a record: EVERY frame a consumer can acquire holds
+ * every rank's complete list.
+ *
+ * gv_exchange_visible enqueues, on the context's stream, this rank's WHOLE shard [draw_count, visible_idx + index_base ...] into a
+ * library-owned staging buffer (gv_results_copy_shard_device; the pool's gv_pool_set_index_map table applies) — the last thing
+ * gv_stream(ctx) does for the frame, so the caller's next gv_hiz_build / gv_cull run while this list is still on the links — and,
+ * on a second stream of the library's, the gather into library-owned rows (row r = rank r's shard). How many words of each rank's
+ * row travel is PREDICTED from the previous frame's row headers, which every rank holds (they reach the host through pinned memory
+ * behind that frame's collective): rank r gets count + max(count / 8, 1024) entries of room, rounded up to 1024 — grown at once,
+ * given back when the list has shrunk by a quarter. Every rank sees the same headers, so every rank derives the same sizes.
+ *
+ * A prediction can be short (a camera cut). The frame is SETTLED — by gv_exchange_acquire of that frame or by the next
+ * gv_exchange_visible, whichever comes first, and before any later collective of the communicator on every rank — by reading its
+ * own headers on the host: where a header exceeds the room its row had, the missing tails travel in a second, exactly sized
+ * exchange (one grouped ncclBroadcast per short rank, out of the staging buffer that still holds the whole list) to their place in
+ * the rows, and only then is the frame handed out. out->cut_ranks is a statistic, not a caveat.
+ *
+ * Host waits: settling polls a pinned word that the frame's own collective writes — bounded (gv_exchange_set_timeout, default
+ * 30 s; GV_E_TIMEOUT: a peer stalled), never a device-wide synchronisation. A caller that enqueues the next frame's cull before it
+ * acquires this frame's rows keeps the device busy throughout. flags must be 0. Buffers alternate: a frame's rows stay valid until
+ * the exchange after the next. */
 typedef struct GvExchangeFrame {
-    const void* gathered_device; /* uint32 [world_size][row_words], device memory owned by the library */
-    uint32_t row_words;          /* 1 + the largest room of any rank this frame */
+    const void* gathered_device; /* uint32 [world_size][row_words], device memory owned by the library; NULL until the frame has
+                                    been acquired (a second exchange may move the rows) */
+    uint32_t row_words;          /* words between two rows, a multiple of 4 (>= 1 + the largest list) */
     uint32_t world_size;
     uint64_t frame;              /* 0, 1, 2 ... since gv_exchange_init */
-    uint32_t room[GV_EXCHANGE_MAX_RANKS];            /* list entries rank r's row holds at most this frame: a header above it =
-                                                        that list was cut to its leading room[r] entries */
-    uint32_t travelled_words[GV_EXCHANGE_MAX_RANKS]; /* of rank r's row, the words that crossed a link this frame (header included;
-                                                        the equal-size all-gather moves whole rows whatever the rooms) */
-    uint64_t counts_frame;       /* the latest frame whose headers this frame's sizes follow: frame - 2 (UINT64_MAX: none yet) ... */
-    uint32_t counts[GV_EXCHANGE_MAX_RANKS];          /* ... its draw counts, rank by rank ... */
-    uint64_t cut_ranks;          /* ... and bit r set when rank r's list did not fit the room its row had in that frame */
-    uint32_t exact;              /* 1: this frame was sized from its own counts (host-synchronising) */
+    uint32_t room[GV_EXCHANGE_MAX_RANKS];            /* list entries rank r's row was PREDICTED to need (what travelled first) */
+    uint32_t travelled_words[GV_EXCHANGE_MAX_RANKS]; /* of rank r's row, the words that crossed a link in the first exchange (header
+                                                        included; the equal-size all-gather moves whole rows whatever the rooms) */
+    uint32_t counts[GV_EXCHANGE_MAX_RANKS];          /* acquired frames: rank r's draw count = the entries behind row r's header */
+    uint32_t tail_words[GV_EXCHANGE_MAX_RANKS];      /* acquired frames: words of rank r's list that travelled in the second exchange */
+    uint64_t cut_ranks;          /* acquired frames: bit r = rank r's list outgrew its room and was completed (statistic) */
+    uint32_t complete;           /* 1: acquired — every row holds its rank's whole list */
     uint32_t mode;               /* GvExchangeMode the rows travelled by */
-    void* ready_event;           /* hipEvent_t recorded behind this frame's rows: hipStreamWaitEvent(consumer stream, ready_event) */
+    void* ready_event;           /* acquired frames: hipEvent_t behind the complete rows (hipStreamWaitEvent on a consumer's stream) */
 } GvExchangeFrame;
-#define GV_EXCHANGE_EXACT 1u
 int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
-/* Work enqueued on gv_stream(ctx) after this call sees frame `frame`'s rows (one of the last two frames): the stream waits
- * for that frame's ready_event. No host wait. */
-int gv_exchange_acquire(GvCtx* ctx, uint64_t frame);
-/* Blocks until frame `frame`'s headers have reached the host (one of the last two frames); counts[world_size]. A query only:
- * the sizes of later frames do not depend on whether, or on which ranks, it was called. */
-int gv_exchange_counts(GvCtx* ctx, uint64_t frame, uint32_t* counts, uint64_t* cut_ranks);
+/* view_index / index_base: [world_size] (index_bases NULL: all 0); frames: [world_size] outputs. */
+int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32_t* view_indices, const uint32_t* index_bases,
+                            uint32_t flags, GvExchangeFrame* frames);
+/* Settles frame `frame` (one of the last two) if that has not happened yet — waits for its headers on the host, completes cut rows —
+ * makes gv_stream(ctx) wait for the complete rows and fills *out (NULL: not wanted). Every rank acquires, or none does: the
+ * completing exchange is a collective (ranks that skip it meet it inside their next gv_exchange_visible). */
+int gv_exchange_acquire(GvCtx* ctx, uint64_t frame, GvExchangeFrame* out);
+int gv_exchange_acquire_all(GvCtx* const* contexts, int world_size, uint64_t frame, GvExchangeFrame* frames);
+/* Upper bound of every host wait of the exchange, in milliseconds (0: the default, 30 000; also GV_EXCHANGE_TIMEOUT_MS at
+ * gv_exchange_init). A wait that runs out aborts the communicator on the spot (ncclCommAbort: the collective that will never finish
+ * must not keep the device — and with it every hipFree / synchronise of the process — waiting) and returns GV_E_TIMEOUT; later
+ * exchange calls return GV_E_STATE until gv_exchange_shutdown + gv_exchange_init. */
+int gv_exchange_set_timeout(GvCtx* ctx, uint32_t milliseconds);
 
 /* The same exchange with caller-owned buffers and caller-chosen sizes: row r of gathered_device (world_size * (capacity + 1)
  * uint32, device memory) = rank r's shard. capacities == NULL: every row travels whole (capacity + 1 words). Otherwise
  * capacities[world_size], each <= capacity and the same list on every rank: the direct patterns (GV_EXCHANGE_P2P /
  * _BROADCAST) move 1 + capacities[r] words of rank r's row, and this rank's shard is cut to capacities[rank] entries; the
  * equal-size all-gather moves capacity + 1 words per row regardless. No host synchronisation; a header above the row's room =
- * that rank's list was cut. */
+ * that rank's list was cut — this form is the caller's own sizing, with nothing behind it: use gv_exchange_visible for lists that
+ * must arrive whole. */
 int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const uint32_t* capacities, uint32_t index_base,
                        void* gathered_device);
 /* The exchange with bit shards (gv_results_copy_mask_device): row r of gathered_device = rank r's [draw_count, one bit per

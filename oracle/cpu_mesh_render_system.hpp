@@ -30,12 +30,14 @@ private:
     std::vector<std::vector<UnsortedBuffer*>> shadowBuffers;  // [unsorted buffer][pass]
     std::vector<std::vector<SortedMesh>> shadowTransMeshes;   // [pass]
     std::vector<uint32_t> shadowTransDrawIndex;
+    std::vector<std::vector<SortedBuffer*>> shadowSortedBuffers;  // [pass][bufferIndex of that pass]
+    bool hasAnyRefr = false, hasAnyOIT = false, hasAnyTD = false;  // mesh.hpp:232-234
     std::vector<uint32_t> idx;
     std::vector<float> baked, dist;
 
 public:
     bool isEnabled = true;
-    bool sortMeshes = true;  // mesh.cpp:548-551: prepareMeshes ends with sortMeshes()
+    bool sortMeshesEnabled = true;  // mesh.cpp:548-551: prepareMeshes ends with sortMeshes()
     bool useAvx2 = false;    // 8-wide AVX2+FMA SoA path instead of the scalar AoS loop (bit-identical)
     uint32_t threads = 1;    // asyncPreparing (mesh.cpp:399): >1 fans out like ThreadPool::addItems
     f32x4x4 uiViewProj;      // calcUiProjView(), mesh.cpp:851-859 (set by the driver)
@@ -50,7 +52,14 @@ public:
         for (auto& v : shadowBuffers)
             for (auto b : v)
                 delete b;
+        for (auto& v : shadowSortedBuffers)
+            for (auto b : v)
+                delete b;
     }
+    bool getHasAnyRefr() const noexcept { return hasAnyRefr; }
+    bool getHasAnyOIT() const noexcept { return hasAnyOIT; }
+    bool getHasAnyTD() const noexcept { return hasAnyTD; }
+    const std::vector<SortedBuffer*>& getShadowSortedBuffers(uint32_t pass) const { return shadowSortedBuffers.at(pass); }
     const std::vector<UnsortedBuffer*>& getUnsortedBuffers() const noexcept { return unsortedBuffers; }
     uint32_t getUnsortedBufferCount() const noexcept { return unsortedBufferCount; }
     const std::vector<SortedBuffer*>& getSortedBuffers() const noexcept { return sortedBuffers; }
@@ -100,24 +109,25 @@ private:
         }
         return out;
     }
-    void fill(UnsortedBuffer* buffer, IMeshRenderSystem* ms, const GvoCullOut& out, size_t stride)
+    // the tail of prepareUnsortedMeshes (mesh.cpp:168-183): the range's records behind the ones already there, both counters added
+    void fill(UnsortedBuffer* buffer, const GvoCullOut& out, size_t stride)
     {
-        buffer->meshSystem = ms;
-        buffer->drawCount = out.draw_count;
-        buffer->instanceCount = out.instance_count;
-        if (buffer->combinedMeshes.size() < out.draw_count)
-            buffer->combinedMeshes.resize(out.draw_count);
+        const uint32_t drawOffset = buffer->drawCount.fetch_add(out.draw_count);
+        buffer->instanceCount.fetch_add(out.instance_count);
+        if (buffer->combinedMeshes.size() < (size_t)drawOffset + out.draw_count)
+            buffer->combinedMeshes.resize((size_t)drawOffset + out.draw_count);
         for (uint32_t k = 0; k < out.draw_count; k++) {
-            auto& m = buffer->combinedMeshes[k];
-            m.componentOffset = (size_t)idx[k] * stride;
-            memcpy(m.bakedModel.m, baked.data() + (size_t)k * 12, 48);
-            m.distanceSq = dist[k];
+            auto& m = buffer->combinedMeshes[drawOffset + k];
+            m.componentOffset = (size_t)idx[k] * stride;                  // mesh.cpp:170
+            memcpy(m.bakedModel.m, baked.data() + (size_t)k * 12, 48);    // mesh.cpp:171
+            m.distanceSq = dist[k];                                       // mesh.cpp:172
         }
-        if (sortMeshes && ms->getMeshRenderType() != MeshRenderType::OIT)  // mesh.cpp:273-277
-            std::sort(buffer->combinedMeshes.begin(), buffer->combinedMeshes.begin() + out.draw_count);
     }
-    void append(std::vector<SortedMesh>& combined, uint32_t& drawIndex, const GvoCullOut& out, size_t stride, uint32_t bufferIndex)
+    // ... of prepareSortedMeshes (mesh.cpp:246-261): into the array all systems of the kind share, tagged with bufferIndex
+    void append(std::vector<SortedMesh>& combined, uint32_t& drawIndex, SortedBuffer* buffer, const GvoCullOut& out, size_t stride, uint32_t bufferIndex)
     {
+        buffer->drawCount.fetch_add(out.draw_count);
+        buffer->instanceCount.fetch_add(out.instance_count);
         if (combined.size() < (size_t)drawIndex + out.draw_count)
             combined.resize((size_t)drawIndex + out.draw_count);
         for (uint32_t k = 0; k < out.draw_count; k++) {
@@ -125,29 +135,118 @@ private:
             m.componentOffset = (size_t)idx[k] * stride;
             memcpy(m.bakedModel.m, baked.data() + (size_t)k * 12, 48);
             m.distanceSq = dist[k];
-            m.bufferIndex = bufferIndex;
+            m.bufferIndex = bufferIndex;                                  // mesh.cpp:252
         }
         drawIndex += out.draw_count;
     }
 
-    void preDeferredRender()
+    // MeshRenderSystem::sortMeshes, mesh.cpp:265-328
+    void sortMeshes()
+    {
+        for (uint32_t i = 0; i < unsortedBufferCount; i++) {
+            auto unsortedBuffer = unsortedBuffers[i];
+            if (unsortedBuffer->meshSystem->getMeshRenderType() == MeshRenderType::OIT || unsortedBuffer->drawCount.load() == 0)
+                continue;  // :273-277 "No need to sort OIT meshes at all."
+            auto& meshes = unsortedBuffer->combinedMeshes;
+            std::sort(meshes.begin(), meshes.begin() + unsortedBuffer->drawCount.load());
+        }
+        if (transDrawIndex > 0)
+            std::sort(transSortedMeshes.begin(), transSortedMeshes.begin() + transDrawIndex);
+        if (uiDrawIndex > 0)
+            std::sort(uiSortedMeshes.begin(), uiSortedMeshes.begin() + uiDrawIndex);
+    }
+
+    // MeshRenderSystem::prepareMeshes, mesh.cpp:331-553, statement by statement (the thread pool's range split is inside
+    // gvo_prepare_meshes; editor counters and debug asserts have no counterpart here). uiViewProj stands for uiFrustum.
+    void prepareMeshes(const f32x4x4& viewProj, const f32x4x4* uiViewProj, f32x4 cameraOffset, int8_t shadowPass, const GvoTransformPool& tp)
+    {
+        uint32_t transMeshMaxCount = 0, uiMeshMaxCount = 0;                                     // :336
+        transDrawIndex = 0; uiDrawIndex = 0;                                                    // :337
+        unsortedBufferCount = sortedBufferCount = 0;                                            // :338
+        hasAnyRefr = hasAnyOIT = hasAnyTD = false;                                              // :339
+        for (auto meshSystem : meshSystems) {                                                   // :341-375
+            auto renderType = meshSystem->getMeshRenderType();
+            if (renderType == MeshRenderType::Translucent) {
+                transMeshMaxCount += meshSystem->getMeshComponentPool().getCount();
+                sortedBufferCount++;
+            } else if (renderType == MeshRenderType::UI) {
+                if (shadowPass < 0) {
+                    uiMeshMaxCount += meshSystem->getMeshComponentPool().getCount();
+                    sortedBufferCount++;
+                }
+            } else {
+                unsortedBufferCount++;
+            }
+        }
+        while (unsortedBuffers.size() < unsortedBufferCount)                                    // :377-384
+            unsortedBuffers.push_back(new UnsortedBuffer());
+        while (sortedBuffers.size() < sortedBufferCount)                                        // :385-391
+            sortedBuffers.push_back(new SortedBuffer());
+        if (transSortedMeshes.size() < transMeshMaxCount)                                       // :393-396
+            transSortedMeshes.resize(transMeshMaxCount);
+        if (uiSortedMeshes.size() < uiMeshMaxCount)
+            uiSortedMeshes.resize(uiMeshMaxCount);
+        const auto& cc = GraphicsSystem::Instance::get()->getCommonConstants();                 // :401
+        const f32x4 cameraPosition = cc.cameraPos;                                              // :402
+        uint32_t unsortedBufferIndex = 0, sortedBufferIndex = 0;                                // :403
+        for (auto meshSystem : meshSystems) {                                                   // :408
+            const auto& componentPool = meshSystem->getMeshComponentPool();
+            auto componentCount = componentPool.getCount();
+            auto renderType = meshSystem->getMeshRenderType();
+            GvoMeshPool mp{};
+            mp.base = reinterpret_cast<uint8_t*>(componentPool.getData());
+            mp.stride = meshSystem->getMeshComponentSize();
+            mp.occupancy = componentPool.getOccupancy();
+            mp.off_entity = offsetof(MeshRenderComponent, entity);
+            mp.off_is_enabled = offsetof(MeshRenderComponent, isEnabled);
+            mp.off_is_visible = offsetof(MeshRenderComponent, isVisible);
+            mp.off_aabb_min = offsetof(MeshRenderComponent, aabb.min);
+            mp.off_aabb_max = offsetof(MeshRenderComponent, aabb.max);
+            if (renderType == MeshRenderType::Translucent || renderType == MeshRenderType::UI) {
+                if (renderType == MeshRenderType::UI && shadowPass >= 0)                        // :416-417
+                    continue;
+                auto bufferIndex = sortedBufferIndex++;                                         // :419
+                auto sortedBuffer = sortedBuffers[bufferIndex];
+                sortedBuffer->meshSystem = meshSystem;                                          // :421
+                sortedBuffer->drawCount.store(0);
+                sortedBuffer->instanceCount.store(0);
+                if (componentCount == 0 || !meshSystem->isDrawReady(shadowPass))                // :426
+                    continue;
+                if (renderType == MeshRenderType::Translucent) {                                // :432-435: the view frustum, the camera, 3-D key
+                    auto out = run(mp, tp, makeView(viewProj, cameraPosition, cameraOffset, shadowPass, false));
+                    append(transSortedMeshes, transDrawIndex, sortedBuffer, out, mp.stride, bufferIndex);
+                } else {                                                                        // :438-441: the UI frustum, camera at the origin, 2-D key
+                    auto out = run(mp, tp, makeView(*uiViewProj, f32x4(), cameraOffset, shadowPass, true));
+                    append(uiSortedMeshes, uiDrawIndex, sortedBuffer, out, mp.stride, bufferIndex);
+                }
+            } else {
+                auto unsortedBuffer = unsortedBuffers[unsortedBufferIndex++];                   // :475
+                unsortedBuffer->meshSystem = meshSystem;
+                unsortedBuffer->drawCount.store(0);
+                unsortedBuffer->instanceCount.store(0);
+                if (componentCount == 0 || !meshSystem->isDrawReady(shadowPass))                // :482
+                    continue;
+                if (unsortedBuffer->combinedMeshes.size() < componentCount)                     // :485-486
+                    unsortedBuffer->combinedMeshes.resize(componentCount);
+                hasAnyRefr |= renderType == MeshRenderType::Refracted;                          // :488-490
+                hasAnyOIT |= renderType == MeshRenderType::OIT;
+                hasAnyTD |= renderType == MeshRenderType::TransDepth;
+                auto out = run(mp, tp, makeView(viewProj, cameraPosition, cameraOffset, shadowPass, false));
+                fill(unsortedBuffer, out, mp.stride);
+            }
+        }
+        if (!meshSystems.empty() && sortMeshesEnabled)                                          // :546-552
+            sortMeshes();
+    }
+
+    void preDeferredRender()  // mesh.cpp:893-903: prepareSystems(); renderShadows(); prepareMeshes(light pass)
     {
         if (!isEnabled)
             return;
-        meshSystems.clear();
+        meshSystems.clear();  // prepareSystems, mesh.cpp:69-108
         for (auto& sys : Manager::Instance::get()->getSystems())
             if (auto ms = dynamic_cast<IMeshRenderSystem*>(sys.get()))
                 meshSystems.push_back(ms);
-        unsortedBufferCount = sortedBufferCount = 0;
-        for (auto ms : meshSystems) {
-            const auto type = ms->getMeshRenderType();
-            ((type == MeshRenderType::Translucent || type == MeshRenderType::UI) ? sortedBufferCount : unsortedBufferCount)++;
-        }
-        while (unsortedBuffers.size() < unsortedBufferCount)
-            unsortedBuffers.push_back(new UnsortedBuffer());
-        while (sortedBuffers.size() < sortedBufferCount)
-            sortedBuffers.push_back(new SortedBuffer());
-        shadowBuffers.resize(unsortedBufferCount);
         auto transformSystem = TransformSystem::Instance::get();
         const auto& cc = GraphicsSystem::Instance::get()->getCommonConstants();
         auto& tpool = transformSystem->getComponents();
@@ -167,61 +266,38 @@ private:
         tp.entity_to_transform = emap.data();
         tp.entity_capacity = (uint32_t)emap.size();
 
+        // renderShadows, mesh.cpp:795-847: one prepareMeshes per shadow pass, drawn at once there — KEPT here, pass by pass,
+        // so that the drop-in (which prepares all passes of a frame together) can be compared with every one of them
         const uint32_t passCount = (uint32_t)shadowPasses.size();
-        transDrawIndex = uiDrawIndex = 0;
         shadowTransMeshes.resize(passCount);
         shadowTransDrawIndex.assign(passCount, 0);
-        uint32_t unsortedBufferIndex = 0, sortedBufferIndex = 0;
-        for (size_t p = 0; p < meshSystems.size(); p++) {
-            auto ms = meshSystems[p];
-            const auto type = ms->getMeshRenderType();
-            GvoMeshPool mp{};
-            mp.base = ms->getMeshComponentData();
-            mp.stride = ms->getMeshComponentSize();
-            mp.occupancy = ms->getMeshComponentOccupancy();
-            mp.off_entity = offsetof(MeshRenderComponent, entity);
-            mp.off_is_enabled = offsetof(MeshRenderComponent, isEnabled);
-            mp.off_is_visible = offsetof(MeshRenderComponent, isVisible);
-            mp.off_aabb_min = offsetof(MeshRenderComponent, aabb.min);
-            mp.off_aabb_max = offsetof(MeshRenderComponent, aabb.max);
-            // renderShadows() first (mesh.cpp:795-847), then the main camera (mesh.cpp:899-902)
-            if (type == MeshRenderType::UI) {  // mesh.cpp:416,436-442: main pass only, UI frustum, camera at the origin
-                const uint32_t bufferIndex = sortedBufferIndex++;
-                auto out = run(mp, tp, makeView(uiViewProj, f32x4(), f32x4(), -1, true));
-                sortedBuffers[bufferIndex]->meshSystem = ms;
-                sortedBuffers[bufferIndex]->drawCount = out.draw_count;
-                sortedBuffers[bufferIndex]->instanceCount = out.instance_count;
-                append(uiSortedMeshes, uiDrawIndex, out, mp.stride, bufferIndex);
-            } else if (type == MeshRenderType::Translucent) {
-                const uint32_t bufferIndex = sortedBufferIndex++;
-                for (uint32_t s = 0; s < passCount; s++) {
-                    auto out = run(mp, tp, makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false));
-                    append(shadowTransMeshes[s], shadowTransDrawIndex[s], out, mp.stride, bufferIndex);
-                }
-                auto out = run(mp, tp, makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, false));
-                sortedBuffers[bufferIndex]->meshSystem = ms;
-                sortedBuffers[bufferIndex]->drawCount = out.draw_count;
-                sortedBuffers[bufferIndex]->instanceCount = out.instance_count;
-                append(transSortedMeshes, transDrawIndex, out, mp.stride, bufferIndex);
-            } else {
-                const uint32_t bufferIndex = unsortedBufferIndex++;
-                auto& sb = shadowBuffers[bufferIndex];
+        shadowSortedBuffers.resize(passCount);
+        for (uint32_t s = 0; s < passCount; s++) {
+            prepareMeshes(shadowPasses[s].viewProj, nullptr, shadowPasses[s].cameraOffset, (int8_t)s, tp);  // :814
+            if (shadowBuffers.size() < unsortedBufferCount)
+                shadowBuffers.resize(unsortedBufferCount);
+            for (uint32_t b = 0; b < unsortedBufferCount; b++) {
+                auto& sb = shadowBuffers[b];
                 while (sb.size() < passCount)
                     sb.push_back(new UnsortedBuffer());
-                for (uint32_t s = 0; s < passCount; s++) {
-                    auto out = run(mp, tp, makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false));
-                    fill(sb[s], ms, out, mp.stride);
-                }
-                auto out = run(mp, tp, makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, false));
-                fill(unsortedBuffers[bufferIndex], ms, out, mp.stride);
+                sb[s]->meshSystem = unsortedBuffers[b]->meshSystem;
+                sb[s]->drawCount = unsortedBuffers[b]->drawCount.load();
+                sb[s]->instanceCount = unsortedBuffers[b]->instanceCount.load();
+                sb[s]->combinedMeshes.assign(unsortedBuffers[b]->combinedMeshes.begin(), unsortedBuffers[b]->combinedMeshes.begin() + sb[s]->drawCount);
             }
+            while (shadowSortedBuffers[s].size() < sortedBufferCount)
+                shadowSortedBuffers[s].push_back(new SortedBuffer());
+            for (uint32_t b = 0; b < sortedBufferCount; b++) {
+                shadowSortedBuffers[s][b]->meshSystem = sortedBuffers[b]->meshSystem;
+                shadowSortedBuffers[s][b]->drawCount = sortedBuffers[b]->drawCount.load();
+                shadowSortedBuffers[s][b]->instanceCount = sortedBuffers[b]->instanceCount.load();
+            }
+            shadowTransMeshes[s].assign(transSortedMeshes.begin(), transSortedMeshes.begin() + transDrawIndex);
+            shadowTransDrawIndex[s] = transDrawIndex;
         }
-        if (sortMeshes) {  // mesh.cpp:296-326
-            std::sort(transSortedMeshes.begin(), transSortedMeshes.begin() + transDrawIndex);
-            std::sort(uiSortedMeshes.begin(), uiSortedMeshes.begin() + uiDrawIndex);
-            for (uint32_t s = 0; s < passCount; s++)
-                std::sort(shadowTransMeshes[s].begin(), shadowTransMeshes[s].begin() + shadowTransDrawIndex[s]);
-        }
+        prepareMeshes(cc.viewProj, &uiViewProj, f32x4(), -1, tp);  // :899-902
+        if (shadowBuffers.size() < unsortedBufferCount)
+            shadowBuffers.resize(unsortedBufferCount);
     }
 };
 

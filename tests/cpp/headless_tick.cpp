@@ -3,9 +3,17 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
+//   headless_tick --mode cpu|gpu|both [--gate never|shadow|reverse|empty] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
+// --gate (with --mixed): the per-system gate of mesh.cpp:426 / :482 — `componentCount == 0 || !isDrawReady(shadowPass)`:
+//   never: the OIT, the Refracted and the second Translucent system are never ready; shadow: the Opaque and the first Translucent
+//   system are ready for the light pass and shadow pass 0, not for shadow pass 1 (InstanceRenderSystem::isDrawReady answers per
+//   pass, instance.cpp:61-…); reverse: the TransDepth system is ready for the shadow passes only; empty: the OIT and the second
+//   Translucent system have lost all their components (occupancy > 0, count 0). Besides the comparison of the two systems, each
+//   system's results are checked against the reference TEXT (gateHolds below): a system that is not drawn in a pass has its
+//   counters at 0 for that pass, contributes no record, and — light pass — its isVisible bytes are exactly what they were before
+//   the tick (every tick starts from a pattern no cull would leave behind).
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
 #include <algorithm>
 #include <chrono>
@@ -61,12 +69,18 @@ struct Record {
     }
 };
 struct Snapshot {
+    bool hasAnyRefr = false, hasAnyOIT = false, hasAnyTD = false;  // mesh.hpp:232-234
     std::vector<std::vector<uint8_t>> isVisible;  // [mesh system][slot]
     std::vector<std::vector<Record>> lists;       // unsorted buffers, their shadow buffers, trans, ui, shadow trans
     std::vector<uint32_t> counters;               // drawCount / instanceCount of every MeshBuffer, in the same walk
     bool ordered = true;                          // every list obeys its operator< (mesh.hpp:196,204)
     std::string disorder;
 };
+
+static MeshRenderComponent* componentAt(IMeshRenderSystem* ms, uint32_t slot)  // mesh.cpp:120,139: base + i * componentSize
+{
+    return reinterpret_cast<MeshRenderComponent*>(reinterpret_cast<uint8_t*>(ms->getMeshComponentPool().getData()) + (size_t)slot * ms->getMeshComponentSize());
+}
 
 static std::vector<IMeshRenderSystem*> allMeshSystems(Manager& manager)
 {
@@ -109,10 +123,14 @@ template <class SystemT>
 static Snapshot snapshot(Manager& manager, const SystemT* system, uint32_t passCount)
 {
     Snapshot s;
+    s.hasAnyRefr = system->getHasAnyRefr();
+    s.hasAnyOIT = system->getHasAnyOIT();
+    s.hasAnyTD = system->getHasAnyTD();
     for (auto ms : allMeshSystems(manager)) {
-        std::vector<uint8_t> vis(ms->getMeshComponentOccupancy());
+        const auto& pool = ms->getMeshComponentPool();
+        std::vector<uint8_t> vis(pool.getOccupancy());
         for (uint32_t i = 0; i < vis.size(); i++)
-            vis[i] = reinterpret_cast<const MeshRenderComponent*>(ms->getMeshComponentData() + (size_t)i * ms->getMeshComponentSize())->isVisible;
+            vis[i] = componentAt(ms, i)->isVisible;
         s.isVisible.push_back(std::move(vis));
     }
     for (uint32_t b = 0; b < system->getUnsortedBufferCount(); b++) {
@@ -132,6 +150,11 @@ static Snapshot snapshot(Manager& manager, const SystemT* system, uint32_t passC
         s.counters.push_back(system->getSortedBuffers()[b]->drawCount);
         s.counters.push_back(system->getSortedBuffers()[b]->instanceCount);
     }
+    for (uint32_t pass = 0; pass < passCount; pass++)  // sortedBuffers as each shadow pass leaves them (Translucent systems only)
+        for (auto buffer : system->getShadowSortedBuffers(pass)) {
+            s.counters.push_back(buffer->drawCount);
+            s.counters.push_back(buffer->instanceCount);
+        }
     addList(s, system->getTransSortedMeshes(), system->getTransDrawCount(), true, "transSortedMeshes");
     addList(s, system->getUiSortedMeshes(), system->getUiDrawCount(), true, "uiSortedMeshes");
     for (uint32_t pass = 0; pass < passCount; pass++)
@@ -141,6 +164,7 @@ static Snapshot snapshot(Manager& manager, const SystemT* system, uint32_t passC
 
 static bool same(const Snapshot& a, const Snapshot& b, std::string& why)
 {
+    if (a.hasAnyRefr != b.hasAnyRefr || a.hasAnyOIT != b.hasAnyOIT || a.hasAnyTD != b.hasAnyTD) { why = "hasAnyRefr / hasAnyOIT / hasAnyTD differ"; return false; }
     if (a.isVisible != b.isVisible) { why = "isVisible differs"; return false; }
     if (a.counters != b.counters) { why = "counters differ"; return false; }
     if (a.lists.size() != b.lists.size()) { why = "buffer count differs"; return false; }
@@ -157,11 +181,93 @@ static bool same(const Snapshot& a, const Snapshot& b, std::string& why)
     return true;
 }
 
-static void clearVisible(Manager& manager)
+// Every tick starts from isVisible bytes no cull would leave behind: a system that is drawn in the light pass rewrites every one
+// of its slots (each exit of mesh.cpp:140-166 stores the byte), a system that is not must leave them exactly like this.
+static bool patternAt(size_t system, uint32_t slot) { return ((slot * 7u + (uint32_t)system * 3u + 3u) % 5u) == 0; }
+static void poisonVisible(Manager& manager)
 {
-    for (auto ms : allMeshSystems(manager))
-        for (uint32_t i = 0; i < ms->getMeshComponentOccupancy(); i++)
-            reinterpret_cast<MeshRenderComponent*>(ms->getMeshComponentData() + (size_t)i * ms->getMeshComponentSize())->isVisible = false;
+    size_t k = 0;
+    for (auto ms : allMeshSystems(manager)) {
+        for (uint32_t i = 0; i < ms->getMeshComponentPool().getOccupancy(); i++)
+            componentAt(ms, i)->isVisible = patternAt(k, i);
+        k++;
+    }
+}
+
+// The gate of prepareMeshes, checked against the reference TEXT (not against the other system): for every mesh system and pass with
+// `componentCount == 0 || !isDrawReady(shadowPass)` (mesh.cpp:426,482) the buffer of that pass names the system and has both counters
+// at 0 (:419-424, :475-480), no record of the shared sorted arrays carries its bufferIndex, and — light pass — every isVisible byte
+// is the one the tick started from. hasAnyRefr / hasAnyOIT / hasAnyTD are what :339,488-490 compute. Empty string: holds.
+template <class SystemT>
+static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t passCount)
+{
+    uint32_t unsortedIndex = 0, sortedIndex = 0, shadowSortedIndex = 0;
+    bool anyRefr = false, anyOit = false, anyTd = false;
+    size_t k = 0;
+    for (auto ms : allMeshSystems(manager)) {
+        const auto type = ms->getMeshRenderType();
+        const auto ready = dynamic_cast<const ReadinessSwitch*>(ms);
+        const uint32_t count = ms->getMeshComponentPool().getCount(), occupancy = ms->getMeshComponentPool().getOccupancy();
+        const bool sorted = type == MeshRenderType::Translucent || type == MeshRenderType::UI;
+        const bool light = count != 0 && (!ready || ready->drawReady(-1));
+        const std::string name = "mesh system " + std::to_string(k);
+        if (!light)
+            for (uint32_t i = 0; i < occupancy; i++)
+                if ((bool)componentAt(ms, i)->isVisible != patternAt(k, i))
+                    return name + " is not drawn in the light pass, yet isVisible of slot " + std::to_string(i) + " was written";
+        if (sorted) {
+            const uint32_t index = sortedIndex++;
+            const uint32_t shadowIndex = type == MeshRenderType::Translucent ? shadowSortedIndex++ : 0u;
+            const auto buffer = system->getSortedBuffers()[index];
+            if (buffer->meshSystem != ms)
+                return name + ": sortedBuffers[bufferIndex] does not name it";
+            if (!light) {
+                if (buffer->drawCount != 0 || buffer->instanceCount != 0)
+                    return name + " is not drawn in the light pass, yet its sorted buffer counts draws";
+                const auto& list = type == MeshRenderType::UI ? system->getUiSortedMeshes() : system->getTransSortedMeshes();
+                const uint32_t n = type == MeshRenderType::UI ? system->getUiDrawCount() : system->getTransDrawCount();
+                for (uint32_t r = 0; r < n; r++)
+                    if (list[r].bufferIndex == index)
+                        return name + " is not drawn in the light pass, yet the shared sorted array holds a record of it";
+            }
+            if (type == MeshRenderType::Translucent)
+                for (uint32_t s = 0; s < passCount; s++) {
+                    const auto shadow = system->getShadowSortedBuffers(s).at(shadowIndex);
+                    if (shadow->meshSystem != ms)
+                        return name + ": a shadow pass's sortedBuffers[bufferIndex] does not name it";
+                    if (count != 0 && (!ready || ready->drawReady((int8_t)s)))
+                        continue;
+                    if (shadow->drawCount != 0 || shadow->instanceCount != 0)
+                        return name + " is not drawn in shadow pass " + std::to_string(s) + ", yet its sorted buffer counts draws";
+                    for (uint32_t r = 0; r < system->getShadowTransDrawCount(s); r++)
+                        if (system->getShadowTransMeshes(s)[r].bufferIndex == shadowIndex)
+                            return name + " is not drawn in shadow pass " + std::to_string(s) + ", yet that pass's sorted array holds a record of it";
+                }
+        } else {
+            const uint32_t index = unsortedIndex++;
+            const auto buffer = system->getUnsortedBuffers()[index];
+            if (buffer->meshSystem != ms)
+                return name + ": unsortedBuffers[index] does not name it";
+            if (!light && (buffer->drawCount != 0 || buffer->instanceCount != 0))
+                return name + " is not drawn in the light pass, yet its unsorted buffer counts draws";
+            if (light) {
+                anyRefr = anyRefr || type == MeshRenderType::Refracted;
+                anyOit = anyOit || type == MeshRenderType::OIT;
+                anyTd = anyTd || type == MeshRenderType::TransDepth;
+            }
+            for (uint32_t s = 0; s < passCount; s++) {
+                if (count != 0 && (!ready || ready->drawReady((int8_t)s)))
+                    continue;
+                const auto shadow = system->getShadowBuffers(index).at(s);
+                if (shadow->drawCount != 0 || shadow->instanceCount != 0)
+                    return name + " is not drawn in shadow pass " + std::to_string(s) + ", yet its unsorted buffer counts draws";
+            }
+        }
+        k++;
+    }
+    if (system->getHasAnyRefr() != anyRefr || system->getHasAnyOIT() != anyOit || system->getHasAnyTD() != anyTd)
+        return "hasAnyRefr / hasAnyOIT / hasAnyTD are not what mesh.cpp:339,488-490 compute";
+    return "";
 }
 
 int main(int argc, char** argv)
@@ -169,6 +275,7 @@ int main(int argc, char** argv)
     std::string mode = "cpu";
     uint32_t entities = 10000, ticks = 20, threads = 1;
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
+    std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
@@ -192,6 +299,7 @@ int main(int argc, char** argv)
         else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
+        else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
         else if (a == "--soa-records") soaRecords = true;
@@ -210,6 +318,8 @@ int main(int argc, char** argv)
         auto meshSystem = manager.createSystem<OpaqueMeshSystem>();
         manager.registerComponents<MeshRenderComponent>(meshSystem);
         OitMeshSystem* oitSystem = nullptr;
+        RefractedMeshSystem* refrSystem = nullptr;
+        TransDepthMeshSystem* tdSystem = nullptr;
         TranslucentMeshSystem* transSystem = nullptr;
         GlassMeshSystem* glassSystem = nullptr;
         UiMeshSystem* uiSystem = nullptr;
@@ -222,6 +332,22 @@ int main(int argc, char** argv)
             manager.registerComponents<UiMeshComponent>(uiSystem);
             glassSystem = manager.createSystem<GlassMeshSystem>();
             manager.registerComponents<GlassMeshComponent>(glassSystem);
+            refrSystem = manager.createSystem<RefractedMeshSystem>();
+            manager.registerComponents<RefractedMeshComponent>(refrSystem);
+            tdSystem = manager.createSystem<TransDepthMeshSystem>();
+            manager.registerComponents<TransDepthMeshComponent>(tdSystem);
+            // the gate of mesh.cpp:426 / :482 (see the head of this file)
+            if (gate == "never")
+                oitSystem->readyMain = refrSystem->readyMain = glassSystem->readyMain = false,
+                oitSystem->readyShadowMask = refrSystem->readyShadowMask = glassSystem->readyShadowMask = 0;
+            else if (gate == "shadow")
+                meshSystem->readyShadowMask = transSystem->readyShadowMask = ~2u;
+            else if (gate == "reverse")
+                tdSystem->readyMain = false;
+        }
+        if (!gate.empty() && !mixed) {
+            printf("{\"ok\": false, \"why\": \"--gate needs --mixed\"}\n");
+            return 1;
         }
         CpuMeshRenderSystem* cpu = nullptr;
         GpuVisibilitySystem* gpu = nullptr;
@@ -259,7 +385,9 @@ int main(int argc, char** argv)
             t->uid = i + 1;
             MeshRenderComponent* m = nullptr;
             const uint32_t kind = mixed ? i % 8 : 0;
-            if (kind == 4) m = *oitSystem->add(e);
+            if (kind == 2) m = *refrSystem->add(e);
+            else if (kind == 3) m = *tdSystem->add(e);
+            else if (kind == 4) m = *oitSystem->add(e);
             else if (kind == 5) m = *transSystem->add(e);
             else if (kind == 6) m = *glassSystem->add(e);
             else if (kind == 7) {
@@ -286,6 +414,11 @@ int main(int argc, char** argv)
             }
         for (uint32_t i = 0; i < entities; i += 97)
             transformSystem->setActive(ents[i], false);
+        if (gate == "empty") {  // two systems lose every component: occupancy stays, getCount() == 0 once the frame has disposed of them
+            for (uint32_t i = 0; i < entities; i++)
+                if (i % 8 == 4) oitSystem->removeOf(ents[i]);
+                else if (i % 8 == 6) glassSystem->removeOf(ents[i]);
+        }
 
         // camera: looks down +z from the origin, FOV 90, 16:9, near 0.01, infinite reversed-Z (camera.hpp:111-121)
         f32x4x4 viewProj;
@@ -405,6 +538,7 @@ int main(int argc, char** argv)
             if (mixed) {
                 transSystem->markMeshesChanged(); oitSystem->markMeshesChanged();
                 uiSystem->markMeshesChanged(); glassSystem->markMeshesChanged();
+                refrSystem->markMeshesChanged(); tdSystem->markMeshesChanged();
             }
             // destroying entities needs no rebuild request: TransformSystem / the mesh systems itemise the slots
             graphicsSystem->setCamera(viewProj, f32x4(12.5f, -3.0f, 40.0f));
@@ -439,24 +573,43 @@ int main(int argc, char** argv)
                     transformSystem->setActive(ents[i], (k & 1) != 0);
             }
         };
+        if (gate == "empty")
+            run(false, false, 1);  // (one frame with neither system: the removed components are disposed of at its end)
         int rounds = (mutate ? 2 : 1) + (int)churn;
         for (int round = 0; round < rounds && ok; round++) {
             if (round == 1 && mutate)
                 doMutate();
             else if (round >= 1)
                 doChurn();
+            if (round >= 1 && !gate.empty())
+                run(false, false, 1);  // (components destroyed above are disposed of at the end of a frame — T(): isVisible = false — also in
+                                       //  pools no system draws: that frame is kept out of the two ticks whose isVisible bytes are compared)
             if (mode == "both") {
                 // --animate: every tick is compared (the scene moves, the CPU system ticks, the GPU system ticks on the
                 // same state through its dirty-range path); otherwise one CPU tick against `ticks` GPU ticks
                 const uint32_t compared = animate ? ticks : 1;
                 Snapshot a, b;
                 for (uint32_t c = 0; c < compared && ok; c++) {
+                    poisonVisible(manager);
                     run(true, false, 1);
                     a = snapshot(manager, cpu, passCount);
-                    clearVisible(manager);
-                    seconds += run(false, true, animate ? 1 : ticks, false);
+                    const std::string cpuGate = gateHolds(manager, cpu, passCount);
+                    poisonVisible(manager);
+                    seconds += run(false, true, 1, false);
+                    const std::string gpuGate = gateHolds(manager, gpu, passCount);  // (after ONE tick from the pattern: a later tick
+                    if (!animate && ticks > 1)                                        //  would find a non-drawn system's bytes unchanged anyway)
+                        seconds += run(false, true, ticks - 1, false);
                     b = snapshot(manager, gpu, passCount);
-                    ok = same(a, b, why);
+                    // first each system against the reference text, then the two against each other
+                    if (!cpuGate.empty()) {
+                        ok = false;
+                        why = "CPU system vs mesh.cpp:419-427,476-483: " + cpuGate;
+                    } else if (!gpuGate.empty()) {
+                        ok = false;
+                        why = "GPU system vs mesh.cpp:419-427,476-483: " + gpuGate;
+                    } else {
+                        ok = same(a, b, why);
+                    }
                     if (ok && world) {  // the kept cache == TransformComponent::calcModel() of every slot (transform.hpp:197-214)
                         auto& tpool = transformSystem->getComponents();
                         auto& emap = transformSystem->getEntityMap();
@@ -497,8 +650,16 @@ int main(int argc, char** argv)
                 sortedDrawCount = gpu->getTransDrawCount() + gpu->getUiDrawCount();
             } else {
                 if (round == 0) {  // untimed first tick: the GPU system builds its device mirror, the CPU system its scratch
+                    poisonVisible(manager);
                     run(mode == "cpu", mode == "gpu", 1);
                     if (gpu) gpu->tickSeconds = {};
+                    // the gate of mesh.cpp:426 / :482 against the reference text, for the one system that ran
+                    const std::string held = cpu ? gateHolds(manager, cpu, passCount) : gateHolds(manager, gpu, passCount);
+                    if (!held.empty()) {
+                        ok = false;
+                        why = std::string(cpu ? "CPU" : "GPU") + " system vs mesh.cpp:419-427,476-483: " + held;
+                        break;
+                    }
                 }
                 seconds += run(mode == "cpu", mode == "gpu", ticks);
                 drawCount = (cpu ? cpu->getUnsortedBuffers()[0] : gpu->getUnsortedBuffers()[0])->drawCount;

@@ -6,6 +6,7 @@
 // product: the real library is built by garden_amd/csrc/Makefile against the real runtime and returns GV_E_NODEVICE
 // without a gfx950 device.
 #pragma once
+#define GV_HIP_STUB 1
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,7 @@ struct hipDeviceProp_t { char gcnArchName[256]; };
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::strcpy(p->gcnArchName, "gfx950:stub"); return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "stub error"; }

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <random>
 #include <sstream>
 #include <string>
@@ -499,12 +500,13 @@ static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
     gv_destroy(ctx);
 }
 
-// ---- the exchange step with several ranks: one context per thread over tests/cpp/rccl_stub (GV_RCCL_LIBRARY) ----
+// ---- the exchange step with several ranks over tests/cpp/rccl_stub (GV_RCCL_LIBRARY): one context per thread, or ONE thread that
+// drives all the contexts through the *_all forms ----
 // Kernels are no-ops here, so every rank WRITES the list it wants to exchange into its view's result buffers ("device" memory
-// is host memory in this build): rank r's list in frame f has count(r, f) entries value(r, f, k). Lists creep, jump (rows get
-// cut, the library reports it two frames later and re-sizes from an exact count exchange) and collapse (room is given back);
-// every rank checks every row of every frame against those formulas, under all three travel patterns.
-static std::atomic<int> g_cut_reports{0}, g_exact_frames{0};  // (summed over the ranks of a run, for the log)
+// is host memory in this build): rank r's list in frame f has count(r, f) entries value(r, f, k). Lists creep, jump (the
+// prediction is short: the frame is completed by a second exchange before it is handed out) and collapse (room is given back);
+// every rank checks that EVERY row of EVERY frame holds its rank's whole list, under all three travel patterns.
+static std::atomic<int> g_cut_frames{0}, g_tail_words{0};  // (summed over the ranks of a run, for the log)
 static int g_list_seed = 0;  // 0: the scripted sequence below; otherwise lists that jump at random between empty and the whole pool
 static uint32_t mix32(uint32_t x)
 {
@@ -532,30 +534,36 @@ static uint32_t list_count(int rank, int frame, uint32_t n)
 }
 static uint32_t list_value(int rank, int frame, uint32_t k) { return (uint32_t)rank * 1000003u + (uint32_t)frame * 7919u + k; }
 
-static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, int* failures)
-{
-    auto fail = [&](const char* what, int frame, int row) {
-        std::fprintf(stderr, "exchange rank %d frame %d row %d: %s\n", rank, frame, row, what);
-        ++*failures;
-    };
+struct ExchangeRank {
     World w;
-    w.rng.seed(777u + (uint32_t)rank);
-    const uint32_t n = 6000;
-    w.build(n, 0);
-    GvConfig config{};
-    config.struct_size = sizeof(config);
     GvCtx* ctx = nullptr;
-    if (gv_create(&config, &ctx) != GV_OK) {
-        fail("gv_create", -1, -1);
-        return;
+    int rank = 0, ranks = 1, failures = 0, cut_frames = 0;
+    uint64_t tail_words = 0;
+    static constexpr uint32_t n = 6000;
+    void fail(const char* what, int frame, int row)
+    {
+        std::fprintf(stderr, "exchange rank %d frame %d row %d: %s\n", rank, frame, row, what);
+        ++failures;
     }
-    bind_all(ctx, w);
-    CHECK(gv_exchange_init(ctx, id, rank, ranks));
-    GvView v = make_view(-1, 0, 1);
-    uint32_t room_seen[GV_EXCHANGE_MAX_RANKS] = {};
-    int cut_reports = 0, exact_frames = 0;
-    for (int frame = 0; frame < 20; frame++) {
-        const uint32_t mode = (uint32_t)(frame % 3);
+    bool create(int rank_, int ranks_)
+    {
+        rank = rank_;
+        ranks = ranks_;
+        w.rng.seed(777u + (uint32_t)rank);
+        w.build(n, 0);
+        GvConfig config{};
+        config.struct_size = sizeof(config);
+        if (gv_create(&config, &ctx) != GV_OK) {
+            fail("gv_create", -1, -1);
+            return false;
+        }
+        bind_all(ctx, w);
+        return true;
+    }
+    // the frame's list, written where the (no-op) emit would have left it
+    void produce(int frame, uint32_t mode)
+    {
+        GvView v = make_view(-1, 0, 1);
         CHECK(gv_exchange_set_mode(ctx, mode));
         CHECK(gv_cull(ctx, 0, &v, 1));
         GvDeviceResult dr{};
@@ -564,64 +572,53 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
         *(uint32_t*)dr.draw_count = mine;
         for (uint32_t k = 0; k < mine; k++)
             ((uint32_t*)dr.visible_idx)[k] = list_value(rank, frame, k);
-        GvExchangeFrame xf;
-        CHECK(gv_exchange_visible(ctx, 0, 0, frame == 17 ? GV_EXCHANGE_EXACT : 0, &xf));
-        if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode || !xf.ready_event)
-            fail("frame fields", frame, -1);
-        CHECK(gv_exchange_acquire(ctx, (uint64_t)frame));
-        if (frame >= 3)
-            EXPECT(gv_exchange_acquire(ctx, (uint64_t)frame - 3), GV_E_ARG);  // rows long since reused
-        exact_frames += xf.exact ? 1 : 0;
-        cut_reports += xf.cut_ranks ? 1 : 0;
-        if (xf.counts_frame != UINT64_MAX) {
-            if (xf.counts_frame + 2 != (uint64_t)frame)  // whatever this rank queried in between (below)
-                fail("counts_frame is not the frame two before this one", frame, -1);
-            for (int r = 0; r < ranks; r++) {
-                if (xf.counts[r] != list_count(r, (int)xf.counts_frame, n))
-                    fail("retired counts", frame, r);
-            }
-        } else if (frame >= 2) {
-            fail("no retired frame by frame 2", frame, -1);
+    }
+    void check_sent(const GvExchangeFrame& xf, int frame, uint32_t mode)
+    {
+        if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode || xf.complete || xf.gathered_device || xf.ready_event)
+            fail("fields of a frame that was sent, not acquired", frame, -1);
+        if (xf.row_words % 4u)
+            fail("row stride is not a multiple of 4 words", frame, -1);
+        for (int r = 0; r < ranks; r++) {
+            if (xf.travelled_words[r] != (mode == GV_EXCHANGE_ALLGATHER ? xf.row_words : xf.room[r] + 1) || xf.room[r] + 1 > xf.row_words)
+                fail("travelled words", frame, r);
+            if (frame >= 1 && xf.room[r] < list_count(r, frame - 1, n))  // (rooms follow the previous frame's headers, never below them)
+                fail("room below the previous frame's list", frame, r);
         }
+    }
+    // an acquired frame: complete, whatever the prediction was
+    void check_acquired(const GvExchangeFrame& sent, const GvExchangeFrame& xf, int frame)
+    {
+        if (!xf.complete || !xf.gathered_device || !xf.ready_event || xf.frame != (uint64_t)frame || xf.world_size != (uint32_t)ranks || xf.mode != sent.mode ||
+            xf.row_words % 4u || xf.row_words < sent.row_words)
+            fail("fields of an acquired frame", frame, -1);
         const uint32_t* rows = (const uint32_t*)xf.gathered_device;
+        bool cut = false;
         for (int r = 0; r < ranks; r++) {
             const uint32_t* row = rows + (size_t)r * xf.row_words;
-            const uint32_t count = list_count(r, frame, n), room = xf.room[r];
-            if (xf.travelled_words[r] != (mode == GV_EXCHANGE_ALLGATHER ? xf.row_words : room + 1) || room + 1 > xf.row_words)
-                fail("travelled words", frame, r);
-            if (row[0] != count)
-                fail("header", frame, r);
-            for (uint32_t k = 0; k < std::min(count, room); k++)  // (what a row holds beyond its rank's room is not defined)
+            const uint32_t count = list_count(r, frame, n);
+            if (xf.room[r] != sent.room[r] || xf.travelled_words[r] != sent.travelled_words[r])
+                fail("an acquired frame reports other rooms than it was sent with", frame, r);
+            if (row[0] != count || xf.counts[r] != count)
+                fail("header / count", frame, r);
+            if ((size_t)count + 1 > xf.row_words)
+                fail("a list longer than its row", frame, r);
+            for (uint32_t k = 0; k < count; k++)  // the WHOLE list: no row of an acquired frame is short
                 if (row[1 + k] != list_value(r, frame, k)) {
                     fail("entry", frame, r);
                     break;
                 }
-            if (xf.exact && count > room)
-                fail("an exactly sized row is cut", frame, r);
-            if (frame >= 2 && room < list_count(r, frame - 2, n))  // (rooms follow the headers of two frames ago, never below them)
-                fail("room below the list of two frames ago", frame, r);
-            room_seen[r] = room;
+            const bool short_row = count > xf.room[r];
+            if (short_row != (((xf.cut_ranks >> r) & 1u) != 0) || xf.tail_words[r] != (short_row ? count - xf.room[r] : 0u))
+                fail("cut statistics", frame, r);
+            cut = cut || short_row;
+            tail_words += xf.tail_words[r];
         }
-        // the blocking query: this frame's own headers — asked on DIFFERENT frames by different ranks: it decides nothing, the
-        // row sizes of the frames that follow agree on every rank all the same (a rank that sized from what it had just read
-        // would enter the next collective with rows of another length)
-        if ((frame + rank) % 5 == 4 || (rank == 0 && frame % 2 == 0)) {
-            uint32_t counts[GV_EXCHANGE_MAX_RANKS];
-            uint64_t cut = 0;
-            CHECK(gv_exchange_counts(ctx, (uint64_t)frame, counts, &cut));
-            for (int r = 0; r < ranks; r++)
-                if (counts[r] != list_count(r, frame, n))
-                    fail("gv_exchange_counts", frame, r);
-        }
+        cut_frames += cut ? 1 : 0;
     }
-    g_cut_reports += cut_reports;
-    g_exact_frames += exact_frames;
-    if (exact_frames < (g_list_seed ? 2 : 3))  // frame 0, the frame after the jump was noticed (scripted sequence), frame 17 (asked for)
-        fail("too few exactly sized frames", exact_frames, -1);
-    if (cut_reports < 1 && !g_list_seed)
-        fail("the jump was never reported as a cut", -1, -1);
-    // caller-sized form: per-rank capacities
+    void check_shards()
     {
+        GvView v = make_view(-1, 0, 1);
         const uint32_t capacity = n;
         std::vector<uint32_t> rows((size_t)ranks * (capacity + 1), 0xDEADBEEFu);
         uint32_t caps[GV_EXCHANGE_MAX_RANKS];
@@ -652,25 +649,102 @@ static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, i
         caps[0] = capacity + 1;
         EXPECT(gv_exchange_shards(ctx, 0, capacity, caps, 0, rows.data()), GV_E_ARG);
     }
+};
+
+static void exchange_rank_thread(int rank, int ranks, const unsigned char* id, int* failures)
+{
+    std::unique_ptr<ExchangeRank> owner(new ExchangeRank());
+    if (!owner->create(rank, ranks)) {
+        ++*failures;
+        return;
+    }
+    GvCtx* ctx = owner->ctx;
+    ExchangeRank& x = *owner;
+    CHECK(gv_exchange_init(ctx, id, rank, ranks));
+    GvExchangeFrame previous{};
+    for (int frame = 0; frame < 20; frame++) {
+        const uint32_t mode = (uint32_t)(frame % 3);
+        x.produce(frame, mode);
+        GvExchangeFrame sent, got;
+        CHECK(gv_exchange_visible(ctx, 0, 0, 0, &sent));
+        x.check_sent(sent, frame, mode);
+        // ranks acquire at different points — at once, or a frame late (the next gv_exchange_visible has then completed the
+        // frame already) — the same on every rank for a given frame: acquiring is a collective where rows were short
+        if (frame % 4 != 1) {
+            CHECK(gv_exchange_acquire(ctx, (uint64_t)frame, &got));
+            x.check_acquired(sent, got, frame);
+            CHECK(gv_exchange_acquire(ctx, (uint64_t)frame, &got));  // (again: nothing left to do, the same answer)
+            if (!got.complete)
+                x.fail("second acquire", frame, -1);
+        }
+        if (frame >= 1 && (frame - 1) % 4 == 1) {
+            CHECK(gv_exchange_acquire(ctx, (uint64_t)frame - 1, &got));
+            x.check_acquired(previous, got, frame - 1);
+        }
+        if (frame >= 3)
+            EXPECT(gv_exchange_acquire(ctx, (uint64_t)frame - 3, nullptr), GV_E_ARG);  // rows long since reused
+        previous = sent;
+    }
+    g_cut_frames += x.cut_frames;
+    g_tail_words += (int)x.tail_words;
+    if (x.cut_frames < 1 && !g_list_seed)
+        x.fail("the jump of the scripted sequence never outgrew a prediction", -1, -1);
+    x.check_shards();
     GvExchangeFrame none;
     EXPECT(gv_exchange_visible(ctx, 0, 0, 0x80, &none), GV_E_ARG);
+    EXPECT(gv_exchange_visible(ctx, 0, 0, 1, &none), GV_E_ARG);  // (round 4's GV_EXCHANGE_EXACT: gone, not ignored)
     CHECK(gv_exchange_shutdown(ctx));
     EXPECT(gv_exchange_visible(ctx, 0, 0, 0, &none), GV_E_STATE);
+    EXPECT(gv_exchange_acquire(ctx, 0, &none), GV_E_STATE);
+    // a second communicator on the same context starts from nothing: no room of the first one sizes its rows (ranks whose
+    // contexts have different pasts — this one keeps its history, rank 1 below is given a FRESH context — must agree on frame 0)
+    int carried = x.failures;
+    if (ranks > 1 && rank == 1) {
+        gv_destroy(ctx);
+        owner.reset(new ExchangeRank());
+        if (!owner->create(rank, ranks)) {
+            ++*failures;
+            return;
+        }
+        ctx = owner->ctx;
+    } else {
+        owner->failures = 0;
+    }
+    ExchangeRank& y = *owner;
+    unsigned char id2[GV_EXCHANGE_ID_BYTES];
+    memcpy(id2, id + GV_EXCHANGE_ID_BYTES, GV_EXCHANGE_ID_BYTES);
+    CHECK(gv_exchange_init(ctx, id2, rank, ranks));
+    for (int frame = 0; frame < 3; frame++) {
+        y.produce(frame + 5, GV_EXCHANGE_P2P);
+        GvExchangeFrame sent, got;
+        CHECK(gv_exchange_visible(ctx, 0, 0, 0, &sent));
+        for (int r = 0; r < ranks; r++)
+            if (frame == 0 && sent.room[r] != 0)
+                y.fail("frame 0 of a new communicator is sized from an earlier one's rooms", frame, r);
+        CHECK(gv_exchange_acquire(ctx, (uint64_t)frame, &got));
+        if (!got.complete)
+            y.fail("re-init: acquire", frame, -1);
+        const uint32_t* rows = (const uint32_t*)got.gathered_device;
+        for (int r = 0; r < ranks; r++)
+            if (rows[(size_t)r * got.row_words] != list_count(r, frame + 5, ExchangeRank::n))
+                y.fail("re-init: header", frame, r);
+    }
+    CHECK(gv_exchange_shutdown(ctx));
+    *failures += carried + y.failures;
     gv_destroy(ctx);
-    (void)room_seen;
 }
 
 static void exchange_in_threads(int ranks, int list_seed = 0)
 {
     g_list_seed = list_seed;
-    g_cut_reports = 0;
-    g_exact_frames = 0;
+    g_cut_frames = 0;
+    g_tail_words = 0;
     if (!std::getenv("GV_RCCL_LIBRARY")) {
         std::printf("exchange over the stub transport: skipped (GV_RCCL_LIBRARY not set)\n");
         return;
     }
-    unsigned char id[GV_EXCHANGE_ID_BYTES];
-    if (gv_exchange_unique_id(id) != GV_OK) {
+    unsigned char id[2 * GV_EXCHANGE_ID_BYTES];  // (two communicators, one after the other)
+    if (gv_exchange_unique_id(id) != GV_OK || gv_exchange_unique_id(id + GV_EXCHANGE_ID_BYTES) != GV_OK) {
         std::fprintf(stderr, "gv_exchange_unique_id failed\n");
         std::exit(1);
     }
@@ -685,8 +759,61 @@ static void exchange_in_threads(int ranks, int list_seed = 0)
             std::fprintf(stderr, "exchange with %d ranks: rank %d reported %d failures\n", ranks, r, failures[r]);
             std::exit(1);
         }
-    std::printf("exchange over the stub transport, %d ranks, list sequence %d: ok (per rank: %d of 20 frames exactly sized, %d reported a cut)\n", ranks,
-                list_seed, g_exact_frames.load() / ranks, g_cut_reports.load() / ranks);
+    std::printf("exchange over the stub transport, %d ranks, list sequence %d: ok — every row of every frame complete (per rank: %d of 20 frames needed a "
+                "second exchange, %d words in tails)\n", ranks, list_seed, g_cut_frames.load() / ranks, g_tail_words.load() / ranks);
+}
+
+// ONE thread, N contexts (the reference's shape: one process, one Manager — source/editor/entry.cpp:135): gv_exchange_init_all /
+// _visible_all / _acquire_all put the ranks' collectives inside one group, so that a single thread can issue all of them.
+static void exchange_in_one_thread(int ranks, int list_seed)
+{
+    g_list_seed = list_seed;
+    if (!std::getenv("GV_RCCL_LIBRARY")) {
+        std::printf("exchange driven by one thread: skipped (GV_RCCL_LIBRARY not set)\n");
+        return;
+    }
+    std::vector<ExchangeRank> xs(ranks);
+    std::vector<GvCtx*> ctxs;
+    for (int r = 0; r < ranks; r++) {
+        if (!xs[r].create(r, ranks))
+            std::exit(1);
+        ctxs.push_back(xs[r].ctx);
+    }
+    GvCtx* ctx = ctxs[0];  // (CHECK prints its error text)
+    CHECK(gv_exchange_init_all(ctxs.data(), ranks));
+    std::vector<uint32_t> views(ranks, 0u);
+    std::vector<GvExchangeFrame> sent(ranks), got(ranks);
+    GvExchangeFrame one;
+    if (ranks > 1)  // a per-rank call on a communicator one thread drives would wait for ranks the thread has not reached
+        EXPECT(gv_exchange_visible(ctxs[0], 0, 0, 0, &one), GV_E_STATE);
+    int cut_frames = 0;
+    for (int frame = 0; frame < 12; frame++) {
+        const uint32_t mode = (uint32_t)(frame % 3);
+        for (int r = 0; r < ranks; r++)
+            xs[r].produce(frame, mode);
+        CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+        for (int r = 0; r < ranks; r++)
+            xs[r].check_sent(sent[r], frame, mode);
+        if (frame % 3 != 2) {  // (every third frame is left to the next gv_exchange_visible_all to complete)
+            CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+            for (int r = 0; r < ranks; r++)
+                xs[r].check_acquired(sent[r], got[r], frame);
+        }
+    }
+    int failures = 0;
+    for (int r = 0; r < ranks; r++) {
+        failures += xs[r].failures;
+        cut_frames += xs[r].cut_frames;
+        ctx = xs[r].ctx;
+        CHECK(gv_exchange_shutdown(ctx));
+        gv_destroy(ctx);
+    }
+    if (failures) {
+        std::fprintf(stderr, "exchange driven by one thread, %d ranks: %d failures\n", ranks, failures);
+        std::exit(1);
+    }
+    std::printf("exchange driven by ONE thread, %d ranks, list sequence %d: ok — every acquired frame complete (%d frames per rank needed a second exchange)\n",
+                ranks, list_seed, cut_frames / ranks);
 }
 
 // ---- random schedules over the held-back mechanisms: the text tests/schedules.py generates (the GPU tier replays the same
@@ -872,8 +999,12 @@ static void replay_schedule(const std::string& path)
             if (exchange) {
                 GvExchangeFrame xf;
                 CHECK(gv_exchange_visible(ctx, 0, 11, 0, &xf));
-                uint32_t counts[GV_EXCHANGE_MAX_RANKS];
-                CHECK(gv_exchange_counts(ctx, xf.frame, counts, nullptr));
+                GvExchangeFrame got;
+                CHECK(gv_exchange_acquire(ctx, xf.frame, &got));
+                if (!got.complete || !got.gathered_device) {
+                    std::fprintf(stderr, "schedule %s: an acquired frame is not complete\n", path.c_str());
+                    std::exit(1);
+                }
             }
         } else if (op == "shard" || op == "mask") {
             const size_t n = pools[last_pool].size();
@@ -1097,6 +1228,10 @@ int main(int argc, char** argv)
         exchange_in_threads(ranks);
     for (int seed = 1; seed <= 24; seed++)  // lists that jump at random between empty and the whole pool
         exchange_in_threads(2 + seed % 4, seed);
+    for (int ranks : {1, 3, 4})
+        exchange_in_one_thread(ranks, 0);
+    for (int seed = 1; seed <= 6; seed++)
+        exchange_in_one_thread(2 + seed % 3, seed);
     allocation_failures();
     std::printf("host orchestration: ok\n");
     return 0;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()
     for name in header_functions():
         assert hasattr(handle, name), f"libgarden_vis.so does not export {name}"
-    assert handle.gv_abi_version() == 2
+    assert handle.gv_abi_version() == 3
 
 
 def test_struct_sizes_match_header():

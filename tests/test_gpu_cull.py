@@ -396,7 +396,8 @@ def test_empty_and_tiny_pools_and_derived_stride(gpu, oracle):
 def test_a_rank_that_owns_nothing_still_takes_part_in_the_exchange():
     """More ranks than cells (or an empty region of the world): a rank with EMPTY pools culls nothing and still makes its
     gv_exchange_visible calls — header 0, no entries — frame after frame, in every travel pattern; a pool that then gets entities
-    is sized up from the headers like any other."""
+    outgrows the room its empty past predicted: the frame is completed by a second exchange before it is handed out, the next
+    ones are sized from its headers."""
     import torch
     from garden_amd.lib import GpuVisibility
     from garden_amd.pools import MESH_DTYPE, TRANSFORM_DTYPE
@@ -415,27 +416,28 @@ def test_a_rank_that_owns_nothing_still_takes_part_in_the_exchange():
         for frame in range(4):
             vis.exchange_set_mode(frame % 3)
             vis.cull(0, [v])
-            f = vis.exchange_visible(0, index_base=5)
-            counts, cut = vis.exchange_counts(f["frame"], 1)
-            assert counts == [0] and not cut and f["row_words"] >= 1
+            f = vis.exchange_acquire(vis.exchange_visible(0, index_base=5)["frame"])
+            assert f["complete"] and f["counts"] == [0] and not f["cut_ranks"] and f["row_words"] >= 4 and f["row_words"] % 4 == 0
         vis.bind_transforms(full.transforms, full.entity_to_transform)
         vis.bind_pool(0, full.meshes)
         vis.hierarchy_rebuild()
-        seen_cut = False
+        completed = 0
         for frame in range(4):
             vis.cull(0, [v])
-            f = vis.exchange_visible(0, index_base=5)
-            counts, cut = vis.exchange_counts(f["frame"], 1)
+            sent = vis.exchange_visible(0, index_base=5)
+            f = vis.exchange_acquire(sent["frame"])
             got = vis.fetch(0, write_back=False, occupancy=full.count)
-            assert counts == [got["draw_count"]] and got["draw_count"] > 1024
-            seen_cut = seen_cut or bool(cut)
-            if not cut:
-                span = _Span()
-                span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
-                torch.cuda.synchronize()
-                row = torch.as_tensor(span, device="cuda:0").cpu().numpy().view(np.uint32)
-                assert row[0] == got["draw_count"] and np.array_equal(np.sort(row[1:1 + row[0]]), got["visible_idx"] + 5)
-        assert seen_cut and not cut  # the first frame with entities outgrew the empty pool's room; the library said so and re-sized
+            assert f["complete"] and f["counts"] == [got["draw_count"]] and got["draw_count"] > 1024
+            completed += bool(f["cut_ranks"])
+            # whatever room the prediction gave the row, the acquired frame holds the WHOLE list
+            span = _Span()
+            span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
+            vis.wait()
+            row = torch.as_tensor(span, device="cuda:0").cpu().numpy().view(np.uint32)
+            assert row[0] == got["draw_count"] and np.array_equal(np.sort(row[1:1 + row[0]]), got["visible_idx"] + 5)
+            assert f["tail_words"] == [max(0, got["draw_count"] - sent["room"][0])]
+        # the first frame with entities outgrew the empty pool's room and was completed inside the frame; the next ones were predicted
+        assert completed == 1 and not f["cut_ranks"]
         vis.exchange_shutdown()
 
 

@@ -173,25 +173,25 @@ def test_cfg5_one_world_dealt_to_eight_ranks_through_the_exchange(oracle, hier10
     union, counts, is_visible = [], [], np.full(sc.count, 255, np.uint8)
     with GpuVisibility(device=0) as vis:
         for t, tile in enumerate(part.tiles):
-            vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)  # (a fresh communicator per "rank": frame 0 sizes exactly)
+            vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)  # (a fresh communicator per "rank": frame 0 predicts nothing)
             vis.bind_transforms(tile.transforms, tile.entity_to_transform)
             vis.bind_pool(0, tile.meshes)
             vis.hierarchy_rebuild()
             vis.set_index_map(0, part.mesh_global[t])
             vis.exchange_set_mode(t % 3)  # all-gather, grouped send/recv, per-root broadcast in turn
-            for frame in range(3):  # frame 0 exact, frames 1-2 sized from the headers
+            for frame in range(3):  # frame 0 completed by a second exchange, frames 1-2 predicted from the headers
                 vis.cull(0, [view])
-                f = vis.exchange_visible(0, index_base=0)
-                assert f["frame"] == frame and f["exact"] == (frame == 0) and not f["cut_ranks"]
+                sent = vis.exchange_visible(0, index_base=0)
+                f = vis.exchange_acquire(sent["frame"])
+                assert f["frame"] == frame and f["complete"] and bool(f["cut_ranks"]) == (frame == 0)
             got = vis.fetch(0, write_back=False, occupancy=tile.count)
-            frame_counts, cut = vis.exchange_counts(f["frame"], 1)
-            assert frame_counts == [got["draw_count"]] and not cut and f["room"][0] >= got["draw_count"]
+            assert f["counts"] == [got["draw_count"]] and f["room"][0] >= got["draw_count"]
 
             class _Span:
                 pass
             span = _Span()
             span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
-            torch.cuda.synchronize()
+            vis.wait()  # (the acquire ordered the context's stream behind the rows)
             row = torch.as_tensor(span, device="cuda:0").cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             assert row[0] == got["draw_count"]
             ids = row[1:1 + row[0]]

@@ -451,13 +451,12 @@ class ScheduleReplay:
                 if p not in self.culls or not self.exchange:
                     continue
                 exp = self.expected(p, 0)
-                f = vis.exchange_visible(0, index_base=11)
-                counts, cut = vis.exchange_counts(f["frame"], 1)
-                torch.cuda.synchronize()
+                f = vis.exchange_acquire(vis.exchange_visible(0, index_base=11)["frame"])
+                vis.wait()  # (the acquire ordered the context's stream behind the rows)
                 row = device_words(torch, f["ptr"], f["row_words"]).cpu().numpy().view(np.uint32)
-                assert counts == [exp["count"]] and row[0] == exp["count"]
-                if not cut:
-                    assert np.array_equal(np.sort(row[1:1 + row[0]]), exp["idx"] + 11)
+                assert f["complete"] and f["counts"] == [exp["count"]] and row[0] == exp["count"]
+                # whatever the previous frames predicted, an acquired frame holds the whole list
+                assert np.array_equal(np.sort(row[1:1 + row[0]]), exp["idx"] + 11)
                 self.readers += 1
             else:
                 raise AssertionError(f"unknown schedule operation {op}")

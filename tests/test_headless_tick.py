@@ -50,6 +50,15 @@ def test_cpu_mixed_mesh_systems_sorted_and_unsorted_buffers(tick):
     assert out["draw_count"] > 0 and out["sorted_draw_count"] > 0
 
 
+@pytest.mark.parametrize("gate", ["never", "shadow", "reverse", "empty"])
+def test_cpu_system_gate_of_prepare_meshes_against_the_reference_text(tick, gate):
+    """mesh.cpp:426 / :482 on the CPU reference-path system (the comparator of the GPU tier): a system with no components, or one
+    whose isDrawReady(shadowPass) says no, has its counters at 0 for that pass, contributes no record and — light pass — keeps
+    the isVisible bytes the tick started from; hasAnyRefr / hasAnyOIT / hasAnyTD follow :339,488-490 (headless_tick gateHolds)."""
+    _, out = tick("--mode", "cpu", "--entities", "8000", "--ticks", "2", "--mixed", "--gate", gate, "--hier")
+    assert out["ok"] and out["draw_count"] > 0, out
+
+
 def test_cpu_entity_churn(tick):
     """Entities destroyed and created between frames (incl. re-parented orphans, re-used slots, pool growth)."""
     _, out = tick("--mode", "cpu", "--entities", "6000", "--ticks", "2", "--hier", "--mixed", "--churn", "4")
@@ -111,15 +120,27 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "30000", "--hier", "--animate", "11", "--itemised", "--world", "--mutate", "--ticks", "4"],
     ["--entities", "20000", "--hier", "--mixed", "--animate", "5", "--itemised", "--world", "--churn", "3", "--ticks", "3"],
     ["--entities", "9000", "--animate", "4", "--itemised", "--world", "--ticks", "5"],
+    # the per-system gate of prepareMeshes (mesh.cpp:426 / :482: `componentCount == 0 || !isDrawReady(shadowPass)`) and the
+    # hasAnyRefr / hasAnyOIT / hasAnyTD outputs (:339,488-490): systems that are never ready, ready for some passes only
+    # (light pass + shadow pass 0 but not shadow pass 1, as InstanceRenderSystem::isDrawReady can answer; shadow passes but not
+    # the light pass), pools that have lost all their components. Both systems are ALSO checked against the reference text:
+    # counters 0, no record, and isVisible of a system that is not drawn keeps the bytes the tick started from
+    ["--entities", "30000", "--mixed", "--gate", "never"],
+    ["--entities", "30000", "--mixed", "--gate", "shadow", "--hier"],
+    ["--entities", "30000", "--mixed", "--gate", "reverse", "--mutate"],
+    ["--entities", "30000", "--mixed", "--gate", "empty"],
+    ["--entities", "20000", "--mixed", "--gate", "never", "--hier", "--mutate", "--span-records"],
+    ["--entities", "20000", "--mixed", "--gate", "shadow", "--animate", "3", "--ticks", "4", "--copy-records"],
+    ["--entities", "12000", "--mixed", "--gate", "empty", "--churn", "2", "--soa-records"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
     assert out["draw_count"] > 0
 
 
-def _exchange_ranks(ranks, entities, env=None):
+def _exchange_ranks(ranks, entities, env=None, extra=()):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
-    p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks"), "--ranks", str(ranks), "--entities", str(entities)],
+    p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks"), "--ranks", str(ranks), "--entities", str(entities), *extra],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1 and lines[0]["ok"], (p.stdout, p.stderr[-3000:])
@@ -131,22 +152,36 @@ def test_native_exchange_driver_one_process_per_gpu():
     """tests/cpp/exchange_ranks: the exchange through the C-ABI alone (fork per rank, unique id over pipes, RCCL bound at
     run time) with one rank per GPU of the box — `--ranks auto` = min(GPUs, 8): a 1-rank communicator on the 1-GPU boxes of the
     GPU test tier, real RCCL traffic between ranks wherever the tier runs on a multi-GPU node, without anyone editing the test.
-    Twelve frames of gv_exchange_visible (rows owned and sized by the library) behind a camera that turns and cuts, then
-    gv_exchange_shards with per-rank capacities; every rank's rows are checked against every owner's list."""
+    Frames of gv_exchange_visible + gv_exchange_acquire (rows owned and sized by the library) behind a camera that turns and cuts, then
+    gv_exchange_shards with per-rank capacities; every rank's rows are checked against every owner's list — WHOLE in every
+    frame the library sized, the one right after the cut included."""
     out = _exchange_ranks("auto", 200000)
-    assert out["ranks"] >= 1 and out["exact_frames"] >= 1 and out["gathered_last_frame"] > 0
+    assert out["ranks"] >= 1 and out["frames_with_a_second_exchange"] >= 1 and out["gathered_last_frame"] > 0
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_native_exchange_logic_with_several_ranks_on_one_gpu(ranks):
     """The same driver with N ranks SHARING the GPU(s) of the box: RCCL refuses two ranks on one device, so the rows travel
-    through tests/cpp/rccl_stub (RCCL's entry points over shared memory, named with GV_RCCL_LIBRARY). Everything but RCCL's own
-    wire is the product path: per-rank room sized from the headers of earlier frames, rows cut by the camera cut reported and
-    re-sized from an exact count exchange, the three travel patterns, per-rank capacities in the caller-sized form."""
+    through tests/cpp/rccl_stub (RCCL's entry points over shared memory, named with GV_RCCL_LIBRARY; one rank per process: its
+    DEVICE transport — a call only enqueues a kernel on the caller's stream, as RCCL does, so the events and the two streams the
+    library orders a frame with are exercised for real). Everything but RCCL's own wire is the product path: per-rank room
+    predicted from the previous frame's headers, predictions that the camera cut leaves short completed by a second exchange
+    INSIDE the frame, the three travel patterns, frames acquired at once or a frame late, per-rank capacities in the
+    caller-sized form. exchange_ranks fails unless every rank holds every owner's whole list in every frame."""
     out = _exchange_ranks(ranks, 60000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")})
-    assert out["ranks"] == ranks
-    # the camera cut swaps which slabs are in view: rows were cut, the library said so and answered with an exactly sized frame
-    assert out["cut_rows"] >= 1 and out["frames_reporting_a_cut"] >= 1 and out["exact_frames"] >= 2, out
-    # the direct patterns move little more than the lists themselves (head-room 1/8 + up to 2 x 1024 words per row)
+    assert out["ranks"] == ranks and out["mismatches"] == 0
+    # the camera cut swaps which slabs are in view: rows came up short and were completed (a counter now, not a caveat)
+    assert out["short_rows_completed"] >= 1 and out["tail_words"] > 0, out
+    # the direct patterns move little more than the lists themselves (head-room 1/8 + up to 2 x 1024 words per row, tails included)
     assert out["words_on_links_over_list_words"] < 3.0, out
+
+
+@pytest.mark.gpu
+def test_a_stalled_peer_is_a_status_code_not_a_hang():
+    """One of three ranks stops calling half way. The others' next gv_exchange_visible / gv_exchange_acquire waits for headers
+    that never come: GV_E_TIMEOUT after the bound (2 s here, gv_exchange_set_timeout), the communicator aborted by
+    gv_exchange_shutdown — every frame acquired before that was whole."""
+    out = _exchange_ranks(3, 30000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
+                          extra=["--stall-rank", "1", "--frames", "10"])
+    assert out["timed_out_ranks"] == 2 and out["mismatches"] == 0, out

@@ -523,7 +523,11 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     assert "exchange over the stub transport, 8 ranks, list sequence 0: ok" in run.stdout, run.stdout[-2000:]
     # ... and 24 sequences of lists that jump at random between empty and the whole pool, 2-5 ranks
     assert run.stdout.count("exchange over the stub transport") == 4 + 24 and "list sequence 24: ok" in run.stdout, run.stdout[-2000:]
-    print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange over")))
+    assert run.stdout.count("every row of every frame complete") == 4 + 24  # (no frame is ever handed out short)
+    # ONE thread driving 1 / 3 / 4 contexts through gv_exchange_init_all / _visible_all / _acquire_all (the reference's shape: one
+    # process, one Manager), scripted and random list sequences
+    assert run.stdout.count("exchange driven by ONE thread") == 3 + 6 and "exchange driven by ONE thread, 4 ranks, list sequence 0: ok" in run.stdout
+    print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange ")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
     print(run.stdout[-600:])
