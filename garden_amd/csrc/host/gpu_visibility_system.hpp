@@ -14,6 +14,7 @@
 #pragma once
 #include <chrono>
 #include <algorithm>
+#include <functional>
 #include <stdexcept>
 #include <type_traits>
 #include <string>
@@ -21,6 +22,7 @@
 
 #include "../../../include/garden_vis.h"
 #include "garden_host.hpp"
+#include "rank_shares.hpp"
 
 namespace garden {
 
@@ -38,6 +40,18 @@ public:
 
 private:
     GvCtx* ctx = nullptr;
+    // ONE process, N GPUs (the reference's shape: one Manager, source/editor/entry.cpp:135): contexts[r] = rank r's context on
+    // device devices[r]; ctx == contexts[0]. One context: everything below runs as before.
+    std::vector<GvCtx*> contexts;
+    RankShares rankShares;
+    uint32_t rankGrid[3] = {1, 1, 1};
+    double worldSide = 0.0;
+    struct RanksSeen {  // what the shares were dealt from: any change re-deals
+        uint64_t hierarchy = ~0ull, reparent = ~0ull;
+        uint32_t transformOccupancy = ~0u, transformCount = ~0u;
+        std::vector<uint64_t> meshVersion, meshRange;
+        std::vector<uint32_t> meshOccupancy, meshCount;
+    } ranksSeen;
     std::vector<IMeshRenderSystem*> meshSystems;  // prepareSystems(), mesh.cpp:69-108
     // mesh.hpp:219-223: one UnsortedBuffer per Color/Opaque/OIT/Refracted/TransDepth system; Translucent and UI
     // systems get a SortedBuffer each (counters) and share transSortedMeshes / uiSortedMeshes (records)
@@ -100,24 +114,58 @@ public:
     // frame without transform changes, only the subtrees under moved / re-parented transforms are re-swept otherwise)
     bool sweepIncremental = false;
 
+    // Multi-GPU mode: called after every (mesh system, pass) of a frame has been gathered — frames[r] is rank r's acquired
+    // GvExchangeFrame: on every device, every rank's complete list of WORLD mesh slots for that pass (rows valid until the exchange
+    // after the next). A GPU-driven renderer enqueues its per-device work here; the host-side buffers are filled afterwards.
+    std::function<void(uint32_t meshSystemIndex, int8_t shadowPass, const GvExchangeFrame* frames, uint32_t ranks)> onGathered;
+
     // blockBounds: GV_CONFIG_BLOCK_BOUNDS — worth it when most of the world is static (same results either way)
     explicit GpuVisibilitySystem(int device = 0, bool profile = false, bool blockBounds = false)
+        : GpuVisibilitySystem(std::vector<int>{device}, 0.0, profile, blockBounds)
     {
-        GvConfig config{};
-        config.struct_size = sizeof(GvConfig);
-        config.device = device;
-        config.hiz_rule = GV_HIZ_RULE_REFERENCE;
-        config.flags = (profile ? GV_CONFIG_PROFILE_EVENTS : 0) | (blockBounds ? GV_CONFIG_BLOCK_BOUNDS : 0);
-        if (gv_create(&config, &ctx) != GV_OK)
-            throw GardenError(std::string("GpuVisibilitySystem: ") + gv_last_error(nullptr));
+    }
+    // One context per entry of `devices` (the GPUs of the node; the same ordinal may appear more than once — ranks that share a
+    // device, as the tests do on a one-GPU box). More than one: the pools are dealt to the ranks by the spatial rule of SURVEY.md
+    // §8e (rank_shares.hpp; worldSide = the side of the world cube the cells are cut from), every rank culls its share, the
+    // lists are gathered on the devices (gv_exchange_visible_all / _acquire_all: one thread drives all ranks) and the engine's
+    // buffers — isVisible of the whole pools, combinedMeshes, the shared sorted arrays — are filled from the ranks' results.
+    GpuVisibilitySystem(const std::vector<int>& devices, double worldSide, bool profile = false, bool blockBounds = false) : worldSide(worldSide)
+    {
+        if (devices.empty() || devices.size() > GV_EXCHANGE_MAX_RANKS)
+            throw GardenError("GpuVisibilitySystem: between 1 and GV_EXCHANGE_MAX_RANKS devices");
+        for (int device : devices) {
+            GvConfig config{};
+            config.struct_size = sizeof(GvConfig);
+            config.device = device;
+            config.hiz_rule = GV_HIZ_RULE_REFERENCE;
+            config.flags = (profile ? GV_CONFIG_PROFILE_EVENTS : 0) | (blockBounds ? GV_CONFIG_BLOCK_BOUNDS : 0);
+            GvCtx* made = nullptr;
+            if (gv_create(&config, &made) != GV_OK) {
+                for (auto c : contexts)
+                    gv_destroy(c);
+                throw GardenError(std::string("GpuVisibilitySystem: ") + gv_last_error(nullptr));
+            }
+            contexts.push_back(made);
+        }
+        ctx = contexts[0];
+        if (contexts.size() > 1) {  // >= 512 cells per rank, doubling x, y, z in turn (garden_amd/multi.py::cell_grid: 8 ranks -> 16 x 16 x 16)
+            for (uint32_t axis = 0; (uint64_t)rankGrid[0] * rankGrid[1] * rankGrid[2] < 512ull * contexts.size(); axis = (axis + 1) % 3)
+                rankGrid[axis] *= 2;
+            if (!(worldSide > 0.0))
+                throw GardenError("GpuVisibilitySystem: several ranks need the side of the world cube");
+        }
         setUiSize(1.0f, 1.0f);
         ECSM_SUBSCRIBE_TO_EVENT("Init", GpuVisibilitySystem::init);
     }
     ~GpuVisibilitySystem() override
     {
-        // the context first: gv_destroy synchronises the stream and un-registers every record target, so no queued publish /
+        // the contexts first: gv_destroy synchronises the stream and un-registers every record target, so no queued publish /
         // sort can still write into a combinedMeshes array (GV_DEBUG_RECORD_TARGET_PAGE_LOCK) and no target outlives its array
-        gv_destroy(ctx);
+        if (contexts.size() > 1)
+            for (auto c : contexts)
+                (void)gv_exchange_shutdown(c);
+        for (auto c : contexts)
+            gv_destroy(c);
         ctx = nullptr;
         for (auto b : unsortedBuffers)
             delete b;
@@ -132,6 +180,9 @@ public:
     }
 
     GvCtx* getContext() const noexcept { return ctx; }
+    uint32_t getRankCount() const noexcept { return (uint32_t)contexts.size(); }
+    GvCtx* getContext(uint32_t rank) const { return contexts.at(rank); }
+    const RankShares& getRankShares() const noexcept { return rankShares; }
     // what preRefrRender / the OIT and TransDepth passes ask (mesh.cpp:917-923): did the light pass prepare any such system?
     bool getHasAnyRefr() const noexcept { return hasAnyRefr; }
     bool getHasAnyOIT() const noexcept { return hasAnyOIT; }
@@ -181,6 +232,8 @@ private:
             ECSM_SUBSCRIBE_TO_EVENT("PreForwardRender", GpuVisibilitySystem::preRender);
         if (manager->hasEvent("PreDeferredRender"))
             ECSM_SUBSCRIBE_TO_EVENT("PreDeferredRender", GpuVisibilitySystem::preRender);
+        if (contexts.size() > 1)  // one thread, N ranks: the communicator is made inside one group
+            check(gv_exchange_init_all(contexts.data(), (int)contexts.size()), "gv_exchange_init_all");
     }
 
     static bool isSortedType(MeshRenderType type) noexcept
@@ -323,6 +376,10 @@ private:
     {
         if (!isEnabled)
             return;
+        if (contexts.size() > 1) {
+            preRenderRanks();
+            return;
+        }
         auto transformSystem = TransformSystem::Instance::get();
         auto graphicsSystem = GraphicsSystem::Instance::get();
         Stopwatch whole(tickSeconds.total);
@@ -558,6 +615,302 @@ private:
                         fill(unsortedBuffers[bufferIndex], meshSystem, p, v, true);
             }
         }
+        if (emitRecords && sortOnDevice) {
+            mergeRuns(transSortedMeshes, transRuns);
+            mergeRuns(uiSortedMeshes, uiRuns);
+            for (uint32_t s = 0; s < passCount; s++)
+                mergeRuns(shadowTransMeshes[s], shadowTransRuns[s]);
+        }
+    }
+
+    // ---- ONE process, N GPUs ----
+    void checkRank(uint32_t rank, int rc, const char* what)
+    {
+        if (rc != GV_OK)
+            throw GardenError(std::string(what) + " failed on rank " + std::to_string(rank) + ": " + gv_last_error(contexts[rank]));
+    }
+
+    // Deals the pools again when anything structural changed (entities or components came or went, a parent link moved); otherwise
+    // copies the transforms that changed into their ranks' pools. Binds every rank's share.
+    void syncRanks(TransformSystem* transformSystem)
+    {
+        const uint32_t ranks = (uint32_t)contexts.size();
+        auto& pool = transformSystem->getComponents();
+        bool structural = ranksSeen.hierarchy != transformSystem->hierarchyVersion || ranksSeen.reparent != transformSystem->reparentVersion ||
+                          ranksSeen.transformOccupancy != pool.getOccupancy() || ranksSeen.transformCount != pool.getCount() ||
+                          ranksSeen.meshVersion.size() != meshSystems.size();
+        ranksSeen.meshVersion.resize(meshSystems.size(), ~0ull);
+        ranksSeen.meshRange.resize(meshSystems.size(), ~0ull);
+        ranksSeen.meshOccupancy.resize(meshSystems.size(), ~0u);
+        ranksSeen.meshCount.resize(meshSystems.size(), ~0u);
+        for (size_t p = 0; p < meshSystems.size(); p++) {
+            const auto& meshPool = meshSystems[p]->getMeshComponentPool();
+            auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
+            const uint64_t version = versioned ? versioned->meshVersion : 0, range = versioned ? versioned->rangeVersion : 0;
+            structural = structural || !versioned || ranksSeen.meshVersion[p] != version || ranksSeen.meshRange[p] != range ||
+                         ranksSeen.meshOccupancy[p] != meshPool.getOccupancy() || ranksSeen.meshCount[p] != meshPool.getCount();
+            ranksSeen.meshVersion[p] = version;
+            ranksSeen.meshRange[p] = range;
+            ranksSeen.meshOccupancy[p] = meshPool.getOccupancy();
+            ranksSeen.meshCount[p] = meshPool.getCount();
+            if (versioned)
+                versioned->clearMeshRange();
+        }
+        ranksSeen.hierarchy = transformSystem->hierarchyVersion;
+        ranksSeen.reparent = transformSystem->reparentVersion;
+        ranksSeen.transformOccupancy = pool.getOccupancy();
+        ranksSeen.transformCount = pool.getCount();
+        static const GvTransformLayout transformLayout = {
+            (uint32_t)offsetof(TransformComponent, entity), (uint32_t)offsetof(TransformComponent, parent),
+            (uint32_t)offsetof(TransformComponent, posChildCount), (uint32_t)offsetof(TransformComponent, scaleChildCap),
+            (uint32_t)offsetof(TransformComponent, rotation), (uint32_t)offsetof(TransformComponent, selfActive),
+            (uint32_t)offsetof(TransformComponent, ancestorsActive),
+            (uint32_t)offsetof(TransformComponent, modelWithAncestors)};
+        static const GvMeshLayout meshLayout = {
+            (uint32_t)offsetof(MeshRenderComponent, entity), (uint32_t)offsetof(MeshRenderComponent, isEnabled),
+            (uint32_t)offsetof(MeshRenderComponent, isVisible), (uint32_t)offsetof(MeshRenderComponent, aabb.min),
+            (uint32_t)offsetof(MeshRenderComponent, aabb.max)};
+        if (structural) {
+            rankShares.deal(transformSystem, meshSystems, ranks, rankGrid, worldSide);
+            seenTransform = transformSystem->transformVersion;
+            seenFlags = transformSystem->flagsVersion;
+        }
+        // what moved since the last frame (content only): every slot, or the itemised ones
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> dirty(ranks);  // per rank: (local slot, count)
+        auto touch = [&](uint32_t worldSlot) {
+            const uint32_t rank = worldSlot < rankShares.rankOfTransform.size() ? rankShares.rankOfTransform[worldSlot] : GV_NONE;
+            if (rank == GV_NONE)
+                return;
+            rankShares.copyTransform(transformSystem, worldSlot);
+            const uint32_t local = rankShares.localOfTransform[worldSlot];
+            auto& ranges = dirty[rank];
+            if (!ranges.empty() && ranges.back().first + ranges.back().second == local)
+                ranges.back().second++;
+            else
+                ranges.push_back({local, 1u});
+        };
+        bool everything = false;
+        if (!structural) {
+            if (seenTransform != transformSystem->transformVersion) {
+                everything = true;
+                for (uint32_t i = 0; i < pool.getOccupancy(); i++)
+                    rankShares.copyTransform(transformSystem, i);
+            } else {
+                for (const auto& moved : transformSystem->movedRanges)
+                    for (uint32_t i = 0; i < moved.second; i++)
+                        touch(moved.first + i);
+                if (seenFlags != transformSystem->flagsVersion)
+                    for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
+                        touch(i);
+            }
+            seenTransform = transformSystem->transformVersion;
+            seenFlags = transformSystem->flagsVersion;
+        }
+        transformSystem->clearReparentRange();
+        transformSystem->clearFlagsRange();
+        transformSystem->clearMovedRanges();
+        for (uint32_t r = 0; r < ranks; r++) {
+            auto& share = rankShares.shares[r];
+            checkRank(r, gv_transform_bind(contexts[r], share.transforms.data(), sizeof(TransformComponent), (uint32_t)share.transforms.size(), &transformLayout,
+                                           share.entityToTransform.data(), (uint32_t)share.entityToTransform.size()), "gv_transform_bind");
+            for (uint32_t p = 0; p < meshSystems.size(); p++) {
+                auto& mesh = share.meshes[p];
+                checkRank(r, gv_pool_bind(contexts[r], p, mesh.components.data(), (uint32_t)mesh.stride, mesh.occupancy(), &meshLayout), "gv_pool_bind");
+                checkRank(r, gv_pool_set_record_layout(contexts[r], p, nullptr), "gv_pool_set_record_layout");
+                if (structural) {
+                    checkRank(r, gv_pool_set_index_map(contexts[r], p, mesh.worldSlot.data(), mesh.occupancy()), "gv_pool_set_index_map");
+                    checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_MESH, p << 28, mesh.occupancy()), "gv_mark_dirty");
+                }
+            }
+            if (structural) {
+                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_HIERARCHY, 0, 0), "gv_mark_dirty");
+            } else if (everything) {
+                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, 0, (uint32_t)share.transforms.size()), "gv_mark_dirty");
+            } else {
+                for (const auto& range : dirty[r])
+                    checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, range.first, range.second), "gv_mark_dirty");
+            }
+        }
+    }
+
+    // The frame with several ranks. The same classification, gate and buffers as preRender(); per (mesh system, pass): every rank
+    // culls (and sorts) its share, the ranks' lists are gathered on the devices, and the engine's buffers are filled from the
+    // ranks' results — a rank holds the models of the entities it owns, the host holds all of them:
+    //   isVisible      rank r's light-pass bytes, scattered to the engine's pool through the local -> world slot table
+    //   records        componentOffset = WORLD slot * componentSize; each rank's run arrives sorted, the runs are merged
+    //   counters       summed over the ranks
+    void preRenderRanks()
+    {
+        auto transformSystem = TransformSystem::Instance::get();
+        auto graphicsSystem = GraphicsSystem::Instance::get();
+        Stopwatch whole(tickSeconds.total);
+        prepareSystems();
+        syncRanks(transformSystem);
+        const uint32_t ranks = (uint32_t)contexts.size();
+        const auto& cc = graphicsSystem->getCommonConstants();
+        const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
+        transDrawIndex = uiDrawIndex = 0;
+        hasAnyRefr = hasAnyOIT = hasAnyTD = false;
+        shadowTransMeshes.resize(passCount);
+        shadowTransDrawIndex.assign(passCount, 0);
+        shadowSortedBuffers.resize(passCount);
+        std::vector<uint32_t> transRuns, uiRuns;
+        std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
+        uint32_t sortedSeen = 0, shadowSortedSeen = 0, unsortedSeen = 0;
+        auto reset = [](MeshBuffer* buffer, IMeshRenderSystem* meshSystem) {
+            buffer->meshSystem = meshSystem;
+            buffer->drawCount = 0;
+            buffer->instanceCount = 0;
+        };
+        std::vector<GvExchangeFrame> frames(ranks);
+        std::vector<uint32_t> viewIndices(ranks);
+        for (uint32_t p = 0; p < meshSystems.size(); p++) {
+            auto meshSystem = meshSystems[p];
+            const auto renderType = meshSystem->getMeshRenderType();
+            const auto& componentPool = meshSystem->getMeshComponentPool();
+            const uint32_t componentCount = componentPool.getCount();
+            const size_t componentSize = meshSystem->getMeshComponentSize();
+            const bool sorted = isSortedType(renderType);
+            uint32_t bufferIndex = 0, shadowIndex = 0;
+            if (sorted) {
+                bufferIndex = sortedSeen++;
+                if (renderType == MeshRenderType::Translucent) {
+                    shadowIndex = shadowSortedSeen++;
+                    for (uint32_t s = 0; s < passCount; s++) {
+                        while (shadowSortedBuffers[s].size() <= shadowIndex)
+                            shadowSortedBuffers[s].push_back(new SortedBuffer());
+                        reset(shadowSortedBuffers[s][shadowIndex], meshSystem);
+                    }
+                }
+                reset(sortedBuffers[bufferIndex], meshSystem);
+            } else {
+                bufferIndex = unsortedSeen++;
+                auto& sb = shadowBuffers[bufferIndex];
+                while (sb.size() < passCount)
+                    sb.push_back(new UnsortedBuffer());
+                reset(unsortedBuffers[bufferIndex], meshSystem);
+                unsortedBuffers[bufferIndex]->span = nullptr;
+                for (uint32_t s = 0; s < passCount; s++) {
+                    reset(sb[s], meshSystem);
+                    sb[s]->span = nullptr;
+                }
+            }
+            // the gate of mesh.cpp:426 / :482, pass by pass (see preRender)
+            std::vector<GvView> views;
+            std::vector<int8_t> passes;
+            if (componentCount != 0 && meshSystem->isDrawReady(-1)) {
+                if (renderType == MeshRenderType::UI)
+                    views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
+                else
+                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, false, emitRecords));
+                passes.push_back(-1);
+                if (!sorted) {
+                    hasAnyRefr |= renderType == MeshRenderType::Refracted;
+                    hasAnyOIT |= renderType == MeshRenderType::OIT;
+                    hasAnyTD |= renderType == MeshRenderType::TransDepth;
+                }
+            }
+            if (renderType != MeshRenderType::UI)
+                for (uint32_t s = 0; s < passCount; s++)
+                    if (componentCount != 0 && meshSystem->isDrawReady((int8_t)s)) {
+                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false, emitRecords));
+                        passes.push_back((int8_t)s);
+                    }
+            if (views.empty())
+                continue;
+            {
+                Stopwatch watch(tickSeconds.cull);
+                for (uint32_t r = 0; r < ranks; r++) {
+                    checkRank(r, gv_cull(contexts[r], p, views.data(), (uint32_t)views.size()), "gv_cull");
+                    if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
+                        for (uint32_t v = 0; v < views.size(); v++)
+                            checkRank(r, gv_pool_sort(contexts[r], p, v, sorted ? 1 : 0), "gv_pool_sort");
+                }
+            }
+            // the gather (mesh.cpp:177-183: every worker's records into the shared array): on every device, every rank's list of
+            // WORLD slots for the pass — complete in every frame (gv_exchange_acquire_all)
+            if (emitRecords)
+                for (uint32_t v = 0; v < views.size(); v++) {
+                    std::fill(viewIndices.begin(), viewIndices.end(), v);
+                    check(gv_exchange_visible_all(contexts.data(), (int)ranks, viewIndices.data(), nullptr, 0, frames.data()), "gv_exchange_visible_all");
+                    check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
+                    if (onGathered)
+                        onGathered(p, passes[v], frames.data(), ranks);
+                }
+            // the engine's buffers from the ranks' results
+            for (uint32_t v = 0; v < views.size(); v++) {
+                const int8_t pass = passes[v];
+                std::vector<uint32_t> runs;
+                // every rank's results of the pass (library-owned host memory, valid until the pool's next gv_cull on that rank); the
+                // light pass also writes the rank's isVisible bytes into its share, from where they go to the engine's pool
+                std::vector<GvResult> results(ranks);
+                uint32_t total = 0, instances = 0;
+                for (uint32_t r = 0; r < ranks; r++) {
+                    {
+                        Stopwatch watch(tickSeconds.fetch);
+                        checkRank(r, gv_pool_results_fetch(contexts[r], p, v, pass < 0 ? 1 : 0, &results[r]), "gv_pool_results_fetch");
+                    }
+                    total += results[r].draw_count;
+                    instances += results[r].instance_count;
+                    if (pass < 0) {  // mesh.cpp:144-166, through the local -> world slot table
+                        Stopwatch watch(tickSeconds.records);
+                        const auto& share = rankShares.shares[r].meshes[p];
+                        uint8_t* world = reinterpret_cast<uint8_t*>(componentPool.getData());
+                        for (uint32_t j = 0; j < share.occupancy(); j++)
+                            reinterpret_cast<MeshRenderComponent*>(world + (size_t)share.worldSlot[j] * componentSize)->isVisible =
+                                reinterpret_cast<const MeshRenderComponent*>(share.components.data() + (size_t)j * componentSize)->isVisible;
+                    }
+                }
+                auto takeRank = [&](uint32_t r, auto* meshes, uint32_t first, uint32_t sortedBufferIndex) {
+                    Stopwatch watch(tickSeconds.records);
+                    const GvResult& res = results[r];
+                    const auto& share = rankShares.shares[r].meshes[p];
+                    for (uint32_t k = 0; k < res.draw_count; k++) {
+                        auto& m = meshes[first + k];
+                        m.componentOffset = (size_t)share.worldSlot[res.visible_idx[k]] * componentSize;  // mesh.cpp:170, in WORLD slots
+                        memcpy(m.bakedModel.m, res.baked_model + (size_t)k * 12, 48);                    // mesh.cpp:171
+                        m.distanceSq = res.distance_sq[k];                                               // mesh.cpp:172 / :249-251
+                        if constexpr (std::is_same<std::remove_reference_t<decltype(m)>, SortedMesh>::value)
+                            m.bufferIndex = sortedBufferIndex;                                           // mesh.cpp:252
+                    }
+                    (void)sortedBufferIndex;
+                };
+                if (sorted) {
+                    const bool ui = renderType == MeshRenderType::UI;
+                    auto& combined = pass >= 0 ? shadowTransMeshes[pass] : ui ? uiSortedMeshes : transSortedMeshes;
+                    uint32_t& drawIndex = pass >= 0 ? shadowTransDrawIndex[pass] : ui ? uiDrawIndex : transDrawIndex;
+                    auto& allRuns = pass >= 0 ? shadowTransRuns[pass] : ui ? uiRuns : transRuns;
+                    MeshBuffer* counters = pass >= 0 ? static_cast<MeshBuffer*>(shadowSortedBuffers[pass][shadowIndex]) : sortedBuffers[bufferIndex];
+                    if (emitRecords && combined.size() < (size_t)drawIndex + total)
+                        combined.resize((size_t)drawIndex + total);
+                    for (uint32_t r = 0; r < ranks && emitRecords; r++) {
+                        takeRank(r, combined.data(), drawIndex, pass >= 0 ? shadowIndex : bufferIndex);
+                        drawIndex += results[r].draw_count;
+                        allRuns.push_back(drawIndex);
+                    }
+                    counters->drawCount = total;
+                    counters->instanceCount = instances;
+                } else {
+                    UnsortedBuffer* buffer = pass >= 0 ? shadowBuffers[bufferIndex][pass] : unsortedBuffers[bufferIndex];
+                    if (emitRecords && buffer->combinedMeshes.size() < total)
+                        buffer->combinedMeshes.resize(total);  // grown, never shrunk (mesh.cpp:377-395)
+                    uint32_t at = 0;
+                    for (uint32_t r = 0; r < ranks && emitRecords; r++) {
+                        takeRank(r, buffer->combinedMeshes.data(), at, 0);
+                        at += results[r].draw_count;
+                        runs.push_back(at);
+                    }
+                    buffer->drawCount = total;
+                    buffer->instanceCount = instances;
+                    if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)  // the ranks' sorted runs -> one sorted list
+                        for (size_t i = 1; i < runs.size(); i++)
+                            std::inplace_merge(buffer->combinedMeshes.begin(), buffer->combinedMeshes.begin() + runs[i - 1], buffer->combinedMeshes.begin() + runs[i]);
+                }
+            }
+        }
+        for (uint32_t s = 0; s < passCount; s++)
+            while (shadowSortedBuffers[s].size() < shadowSortedSeen)
+                shadowSortedBuffers[s].push_back(new SortedBuffer());
         if (emitRecords && sortOnDevice) {
             mergeRuns(transSortedMeshes, transRuns);
             mergeRuns(uiSortedMeshes, uiRuns);

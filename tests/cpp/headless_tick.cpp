@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--gate never|shadow|reverse|empty] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
+//   headless_tick --mode cpu|gpu|both [--ranks R] [--gate never|shadow|reverse|empty] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // --gate (with --mixed): the per-system gate of mesh.cpp:426 / :482 — `componentCount == 0 || !isDrawReady(shadowPass)`:
@@ -14,13 +14,21 @@
 //   system's results are checked against the reference TEXT (gateHolds below): a system that is not drawn in a pass has its
 //   counters at 0 for that pass, contributes no record, and — light pass — its isVisible bytes are exactly what they were before
 //   the tick (every tick starts from a pattern no cull would leave behind).
+// --ranks R: the GPU drop-in's own multi-GPU mode — ONE process, ONE thread, R contexts (all on device 0 here: with R > 1 the rows
+// travel through the test transport named by GV_RCCL_LIBRARY): the pools are dealt to the ranks, every rank culls its share, the
+// lists are gathered on the devices (every rank's rows are read back and compared: all ranks hold the same rows, their union is the
+// set of WORLD slots the pass's buffer holds) and the engine's buffers are filled from the ranks' results — compared with the CPU
+// system's like any other run.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
+
+#include <hip/hip_runtime.h>
 
 #include "../../garden_amd/csrc/host/gpu_visibility_system.hpp"
 #include "../../garden_amd/csrc/host/csm_lite.hpp"
@@ -276,6 +284,7 @@ int main(int argc, char** argv)
     uint32_t entities = 10000, ticks = 20, threads = 1;
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
+    uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
@@ -300,6 +309,7 @@ int main(int argc, char** argv)
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
+        else if (a == "--ranks" && i + 1 < argc) ranks = (uint32_t)atoi(argv[++i]);
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
         else if (a == "--soa-records") soaRecords = true;
@@ -356,8 +366,46 @@ int main(int argc, char** argv)
             cpu->threads = threads;
             cpu->useAvx2 = avx2;
         }
-        if (mode == "gpu" || mode == "both")
-            gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
+        // what the devices held after the gather of each (mesh system, pass) of the last tick: the union of the ranks' rows
+        std::map<std::pair<uint32_t, int>, std::vector<uint32_t>> gathered;
+        std::string gatherProblem;
+        if (mode == "gpu" || mode == "both") {
+            if (ranks > 1)
+                gpu = manager.createSystem<GpuVisibilitySystem>(std::vector<int>(ranks, 0), (double)(100.0f * std::cbrt((float)entities)), false, bounds);
+            else
+                gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
+        }
+        if (gpu && ranks > 1)
+            gpu->onGathered = [&](uint32_t meshSystemIndex, int8_t pass, const GvExchangeFrame* frames, uint32_t n) {
+                std::vector<std::vector<uint32_t>> rows(n);
+                for (uint32_t r = 0; r < n; r++) {
+                    const GvExchangeFrame& f = frames[r];
+                    if (!f.complete || !f.gathered_device || f.world_size != n) {
+                        gatherProblem = "a gathered frame is not complete";
+                        return;
+                    }
+                    rows[r].resize((size_t)n * f.row_words);
+                    if (hipStreamSynchronize((hipStream_t)gv_stream(gpu->getContext(r))) != hipSuccess ||  // (acquire ordered the stream behind the rows)
+                        hipMemcpy(rows[r].data(), f.gathered_device, rows[r].size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                        gatherProblem = "reading the gathered rows back failed";
+                        return;
+                    }
+                }
+                std::vector<uint32_t> all;
+                for (uint32_t q = 0; q < n; q++) {
+                    const uint32_t* mine = rows[0].data() + (size_t)q * frames[0].row_words;
+                    for (uint32_t r = 1; r < n; r++) {
+                        const uint32_t* theirs = rows[r].data() + (size_t)q * frames[r].row_words;
+                        if (theirs[0] != mine[0] || memcmp(theirs + 1, mine + 1, (size_t)mine[0] * 4) != 0)
+                            gatherProblem = "ranks hold different rows after the gather";
+                    }
+                    if (mine[0] != frames[0].counts[q])
+                        gatherProblem = "a row's header is not the count the frame reports";
+                    all.insert(all.end(), mine + 1, mine + 1 + mine[0]);
+                }
+                std::sort(all.begin(), all.end());
+                gathered[{meshSystemIndex, (int)pass}] = std::move(all);
+            };
         if (gpu) {
             gpu->recordStructs = !soaRecords;
             gpu->recordTargets = !copyRecords;
@@ -600,6 +648,33 @@ int main(int argc, char** argv)
                     if (!animate && ticks > 1)                                        //  would find a non-drawn system's bytes unchanged anyway)
                         seconds += run(false, true, ticks - 1, false);
                     b = snapshot(manager, gpu, passCount);
+                    if (ranks > 1 && ok) {
+                        // the gather against what the render phase will read: for every unsorted mesh system and pass, the union of
+                        // the rows every device holds == the WORLD slots of the records in that pass's buffer
+                        if (!gatherProblem.empty()) {
+                            ok = false;
+                            why = gatherProblem;
+                        }
+                        auto systems = allMeshSystems(manager);
+                        for (uint32_t bi = 0; bi < gpu->getUnsortedBufferCount() && ok; bi++) {
+                            auto buffer = gpu->getUnsortedBuffers()[bi];
+                            const uint32_t p = (uint32_t)(std::find(systems.begin(), systems.end(), buffer->meshSystem) - systems.begin());
+                            for (int pass = -1; pass < (int)passCount && ok; pass++) {
+                                const UnsortedBuffer* pb = pass < 0 ? buffer : gpu->getShadowBuffers(bi)[pass];
+                                std::vector<uint32_t> slots(pb->drawCount);
+                                for (uint32_t k = 0; k < pb->drawCount; k++)
+                                    slots[k] = (uint32_t)(pb->meshes()[k].componentOffset / buffer->meshSystem->getMeshComponentSize());
+                                std::sort(slots.begin(), slots.end());
+                                auto it = gathered.find({p, pass});
+                                if (it == gathered.end() ? !slots.empty() : it->second != slots) {
+                                    ok = false;
+                                    why = "the rows gathered on the devices are not the world slots of the pass's records (mesh system " + std::to_string(p) +
+                                          ", pass " + std::to_string(pass) + ")";
+                                }
+                            }
+                        }
+                        gathered.clear();
+                    }
                     // first each system against the reference text, then the two against each other
                     if (!cpuGate.empty()) {
                         ok = false;
@@ -675,6 +750,12 @@ int main(int argc, char** argv)
             shadowCounts += std::string(pass ? ", " : "") + std::to_string(pass < sb.size() ? (uint32_t)sb[pass]->drawCount : 0u);
         }
         shadowCounts += "]";
+        if (gpu && ranks > 1) {
+            std::string shares = "[";
+            for (uint32_t r = 0; r < ranks; r++)
+                shares += std::string(r ? ", " : "") + std::to_string(gpu->getRankShares().shares[r].transforms.size());
+            fprintf(stderr, "ranks %u: transforms per rank %s]\n", ranks, shares.c_str());
+        }
         printf("{\"mode\": \"%s\", \"entities\": %u, \"ticks\": %u, \"threads\": %u, \"hier\": %s, \"shadow_draw_counts\": %s, \"draw_count\": %u, "
                "\"sorted_draw_count\": %u, \"is_visible_set\": %u, \"culls_per_s\": %.1f, \"ok\": %s, \"why\": \"%s\"}\n",
                mode.c_str(), entities, ticks * rounds, threads, hier ? "true" : "false", shadowCounts.c_str(), drawCount, sortedDrawCount, visibleFlags,

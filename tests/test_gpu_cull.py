@@ -441,6 +441,54 @@ def test_a_rank_that_owns_nothing_still_takes_part_in_the_exchange():
         vis.exchange_shutdown()
 
 
+def test_two_contexts_alive_in_one_process_share_no_state(oracle):
+    """One process, several GPUs = several contexts in one address space (the drop-in's multi-GPU mode: gpu_visibility_system.hpp).
+    Two REAL contexts on the same device, different worlds, different configurations, their calls interleaved — binds, pyramid
+    builds, culls, sorts, sweeps, fetches, a rebind with another size — each against the oracle after every step: nothing one context
+    does may show in the other (no static buffer, no shared stream, no cached launch state)."""
+    from garden_amd.lib import GpuVisibility
+    a_scene = scene.hierarchy_scene(150_000, depth=4, fanout=8, seed=5)
+    b_scene = scene.flat_scene(400_000, seed=6)
+    depth = scene.synthetic_depth(512, 256)
+    va, vb = scene.main_camera_view(seed=11, use_hiz=1), scene.main_camera_view(seed=12)
+
+    def check(vis, sc, view, hiz=None):
+        got = vis.fetch(0, write_back=False, occupancy=sc.count)
+        exp = oracle.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, view, hiz=hiz)
+        assert got["draw_count"] == exp["draw_count"] > 0
+        order = np.argsort(got["visible_idx"], kind="stable")
+        assert np.array_equal(got["visible_idx"][order], exp["visible_idx"])
+        assert np.array_equal(got["baked_model"][order].view(np.uint32), exp["baked_model"].view(np.uint32))
+
+    with GpuVisibility(device=0, block_bounds=True) as a, GpuVisibility(device=0, keep_slot_order=True) as b:
+        assert a.stream() != b.stream()
+        a.bind_transforms(a_scene.transforms, a_scene.entity_to_transform)
+        b.bind_transforms(b_scene.transforms, b_scene.entity_to_transform)
+        a.bind_pool(0, a_scene.meshes)
+        a.hiz_build(depth)
+        b.bind_pool(0, b_scene.meshes)
+        hz = oracle.Hiz(depth)
+        for frame in range(3):
+            a.cull(0, [va])
+            b.cull(0, [vb])       # (between a's cull and a's fetch)
+            a.sort(0)
+            check(b, b_scene, vb)
+            b.sweep(1)
+            check(a, a_scene, va, hiz=hz)
+            world_b = b.get_world(0, b_scene.count)
+            a.hiz_rebuild()
+        assert np.array_equal(world_b.view(np.uint32), oracle.world_matrices(b_scene.transforms, b_scene.entity_to_transform).view(np.uint32))
+        # b is re-bound to a smaller world while a keeps going
+        c_scene = scene.flat_scene(90_000, seed=7)
+        b.bind_transforms(c_scene.transforms, c_scene.entity_to_transform)
+        b.bind_pool(0, c_scene.meshes)
+        b.hierarchy_rebuild()
+        a.cull(0, [va])
+        b.cull(0, [vb])
+        check(a, a_scene, va, hiz=hz)
+        check(b, c_scene, vb)
+
+
 def test_hierarchy_cycle_is_rejected(gpu):
     from garden_amd.lib import GV_E_ARG, GvError
     sc = scene.hierarchy_scene(100, depth=3, fanout=3, defects=False)

@@ -138,6 +138,37 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     assert out["draw_count"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [
+    ["--entities", "40000", "--ranks", "4"],
+    ["--entities", "30000", "--ranks", "4", "--mixed", "--hier"],
+    ["--entities", "30000", "--ranks", "3", "--mixed", "--gate", "shadow"],
+    ["--entities", "30000", "--ranks", "2", "--hier", "--mutate"],
+    ["--entities", "20000", "--ranks", "4", "--hier", "--animate", "3", "--itemised", "--ticks", "4"],
+    ["--entities", "20000", "--ranks", "3", "--mixed", "--hier", "--churn", "3"],
+    ["--entities", "60000", "--ranks", "8", "--csm"],
+    ["--entities", "20000", "--ranks", "2", "--mixed", "--gate", "never", "--toggle", "--hier"],
+])
+def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
+    """The drop-in's own multi-GPU mode — ONE process, ONE thread, N contexts (the reference is one process with one Manager,
+    source/editor/entry.cpp:135): the pools are dealt to the ranks (rank_shares.hpp: roots by position, descendants follow), every
+    rank culls its share, the lists are gathered on the devices through gv_exchange_visible_all / _acquire_all (here all ranks
+    share the box's GPU and the rows travel through the test transport) and the engine's buffers are filled from the ranks'
+    results. Checked: every buffer and isVisible of the whole pools == the CPU system's (headless_tick --mode both), every rank
+    holds the same gathered rows, and their union is the set of world slots the pass's buffer holds."""
+    stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
+    env_before = os.environ.get("GV_RCCL_LIBRARY")
+    os.environ["GV_RCCL_LIBRARY"] = stub
+    try:
+        _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
+    finally:
+        if env_before is None:
+            os.environ.pop("GV_RCCL_LIBRARY", None)
+        else:
+            os.environ["GV_RCCL_LIBRARY"] = env_before
+    assert out["ok"] and out["draw_count"] > 0, out
+
+
 def _exchange_ranks(ranks, entities, env=None, extra=()):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")], check=True)
     p = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "exchange_ranks"), "--ranks", str(ranks), "--entities", str(entities), *extra],

@@ -17,7 +17,7 @@ grep -c "isDrawReady" "$tmp/garden_amd/csrc/host/gpu_visibility_system.hpp" | se
 cd "$tmp/tests/cpp"
 gcc -O2 -march=haswell -ffp-contract=off -fno-fast-math -std=c11 -pthread -c ../../oracle/gv_oracle.c -o gv_oracle.o
 gcc -O2 -march=haswell -ffp-contract=off -fno-fast-math -std=c11 -pthread -c ../../oracle/gv_oracle_avx2.c -o gv_oracle_avx2.o
-g++ -O2 -std=c++17 -Wno-invalid-offsetof -fno-strict-aliasing -march=haswell -ffp-contract=off -pthread headless_tick.cpp gv_oracle.o gv_oracle_avx2.o \
+g++ -O2 -std=c++17 -Wno-invalid-offsetof -fno-strict-aliasing -march=haswell -ffp-contract=off -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include headless_tick.cpp gv_oracle.o gv_oracle_avx2.o \
     -o headless_tick_without_the_gate -L"$root/garden_amd/lib" -lgarden_vis -Wl,-rpath,"$root/garden_amd/lib" -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64 -lm -lpthread || exit 2
 for gate in never shadow reverse empty; do
     echo "== --gate $gate, shim WITHOUT the gate (f2bf690's behaviour) =="
