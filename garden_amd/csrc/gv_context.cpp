@@ -154,13 +154,8 @@ int hiz_reduce(GvCtx* ctx)
             HizFusedDst dst;
             for (int l = 0; l < 6; l++)
                 dst.level[l] = mip_ptr(ctx, k + l);
-            dst.tiled0 = nullptr;
             if (k == 1 && ctx->hiz_level1_virtual)
                 dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
-            if (k == 1 && ctx->hiz_depth_tiled) {
-                GV_HIP(ctx, ctx->d_depth_tiled.reserve((size_t)sw * sh));
-                dst.tiled0 = ctx->d_depth_tiled.ptr;
-            }
             GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, rg16f, ctx->stream));
             k += 6;
         } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels && use_tail) {
@@ -235,7 +230,6 @@ HizDevice hiz_device(const GvCtx* ctx)
         hz.nested = ctx->hiz_nested ? 1u : 0u;
         hz.rg16f = (ctx->config.flags & GV_CONFIG_HIZ_RG16F) ? 1u : 0u;
         hz.level1_virtual = ctx->hiz_level1_virtual ? 1u : 0u;
-        hz.depth_tiled = ctx->hiz_depth_tiled ? ctx->d_depth_tiled.ptr : nullptr;
     }
     return hz;
 }
@@ -673,7 +667,7 @@ void gv_destroy(GvCtx* ctx)
         ctx->upload_done = nullptr;
     }
     ctx->d_xinv.release(); ctx->sc_xf.release(); ctx->dsc_xf.release(); ctx->sc_mesh.release(); ctx->dsc_mesh.release(); ctx->dsc_a.release(); ctx->dsc_c.release();
-    ctx->d_depth.release(); ctx->d_depth_tiled.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release(); ctx->h_done.release();
+    ctx->d_depth.release(); ctx->d_mips.release(); ctx->d_mip_offset.release(); ctx->d_tick.release(); ctx->h_done.release();
     for (int k = 0; k < 2; k++) {
         ctx->h_tick[k].release();
         if (ctx->tick_done[k])
@@ -1063,9 +1057,6 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
     }
     // level 1 stays virtual when the first six levels come from the fused kernel (sizes divisible by 64: plain 2x2 rule)
     ctx->hiz_level1_virtual = width % 64 == 0 && height % 64 == 0 && mips > 6 && getenv("GV_DEBUG_STORE_HIZ_LEVEL1") == nullptr;
-    // experiment (profiles/withdrawn.md): the first pyramid launch also writes the depth texels in 8 x 8 tiles and level-0 / virtual
-    // level-1 queries read those — a 2 x 2 footprint then sits in one 64-byte piece instead of two rows 16 KB apart
-    ctx->hiz_depth_tiled = width % 64 == 0 && height % 64 == 0 && mips > 6 && getenv("GV_DEBUG_HIZ_TILED_DEPTH") != nullptr;
     // (RG16F texels are half the size: the same buffer type, half the elements)
     GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>((ctx->config.flags & GV_CONFIG_HIZ_RG16F) ? (off + 1) / 2 : off, 1)));
     GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));

@@ -363,8 +363,6 @@ struct Context {
     PinnedBuf<uint32_t> h_done;  // the word the done-flag kernel writes (wait_for_stream)
     uint32_t done_seq = 0;
     bool publish_sync_pending = false;  // a small-pool sort has published its views; nobody has synchronised the stream since
-    bool hiz_depth_tiled = false;      // GV_DEBUG_HIZ_TILED_DEPTH (experiment): d_depth_tiled holds the depth texels in 8 x 8 tiles
-    DeviceBuf<float> d_depth_tiled;
     bool hiz_level1_virtual = false;   // decided in gv_hiz_build: sizes whose first six levels take the fused kernel
     bool hiz_level1_stored = false;    // ... and whether gv_hiz_read_level has materialised it since the last build
 

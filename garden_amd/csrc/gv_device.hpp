@@ -94,21 +94,13 @@ __device__ __forceinline__ Mat34 chain_model(const TransformMirror& xf, Mat34 m,
 // have no inter-workgroup reuse and ancestor lines are shared through the Infinity Cache anyway).
 __device__ __forceinline__ float hiz_min_texel(const HizDevice& hz, uint32_t level, uint32_t lw, uint32_t x, uint32_t y)
 {
-    if (level == 0) {
-        if (hz.depth_tiled)  // (uniform)
-            return hz.depth_tiled[((size_t)(y >> 3) * (hz.width >> 3) + (x >> 3)) * 64u + ((y & 7u) << 3) + (x & 7u)];
+    if (level == 0)
         return hz.depth[(size_t)y * hz.width + x];
-    }
     if (level == 1 && hz.level1_virtual) {
         // Level 1 is the biggest level to write (half of all pyramid bytes) and the least read: with even sizes its
         // texel is just the 2x2 reduction of the depth image, in the build's own order (hiz.frag:29-33, MIN_DEPTH).
         const float2* row0 = reinterpret_cast<const float2*>(hz.depth + (size_t)(2 * y) * hz.width + 2 * x);
         const float2* row1 = reinterpret_cast<const float2*>(hz.depth + (size_t)(2 * y + 1) * hz.width + 2 * x);
-        if (hz.depth_tiled) {  // (uniform) the 2 x 2 block never straddles a tile: two 8-byte pieces 32 bytes apart
-            const float* tile = hz.depth_tiled + ((size_t)((2 * y) >> 3) * (hz.width >> 3) + ((2 * x) >> 3)) * 64u + (((2 * y) & 7u) << 3) + ((2 * x) & 7u);
-            row0 = reinterpret_cast<const float2*>(tile);
-            row1 = reinterpret_cast<const float2*>(tile + 8);
-        }
         const float2 a = *row0, b = *row1;
         float m = a.x;
         m = a.y < m ? a.y : m;

@@ -47,8 +47,6 @@ __device__ __forceinline__ void hiz_fused_tile(const float* __restrict__ src_dep
             mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
         } else {
             const float4 v = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
-            if (dst.tiled0)  // (uniform) the lane's 4 x 4 block is a quarter of an 8 x 8 tile: four 16-byte pieces, 32 bytes apart
-                *reinterpret_cast<float4*>(dst.tiled0 + ((size_t)(py >> 3) * (sw >> 3) + (px >> 3)) * 64u + (((py & 7u) + r) << 3) + (px & 7u)) = v;
             mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
             mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
         }

@@ -50,7 +50,6 @@ struct MeshMirror {
 
 struct HizDevice {
     const float* depth;          // mip 0
-    const float* depth_tiled;    // NULL, or mip 0 once more in 8 x 8-texel tiles (GV_DEBUG_HIZ_TILED_DEPTH: a 2 x 2 footprint in one 64-byte piece)
     const float2* mips;          // levels >= 1, (min,max); rg16f: the same texels as packed binary16 pairs (uint32_t each)
     const uint64_t* mip_offset;  // device array [GV_MAX_MIPS], in texels
     uint32_t width, height, mip_count;
@@ -289,7 +288,6 @@ hipError_t launch_hiz_tail(const HizTailArgs& args, bool rg16f, hipStream_t stre
 // dst[l] = level (src+1+l), l = 0..5.
 struct HizFusedDst {
     float2* level[6];
-    float* tiled0;  // NULL, or where the source depth texels go once more in 8 x 8-texel tiles (first launch only)
 };
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
                             uint32_t sh, bool rg16f, hipStream_t stream);
