@@ -1,6 +1,9 @@
-for n in 1000000 2000000; do
-  for e in "" "GV_DEBUG_FUSED_EMIT_MAX=4194304"; do
-    echo "## entities $n ${e:-default (cull + emit, two launches)}"
+#!/bin/bash
+# GPU box: cfg2 (flat, frustum-only) at several sizes: cull + emit as two launches (default), in one launch with the look-back chain
+# (GV_DEBUG_FUSED_EMIT_MAX) and in one launch with the two-level count sums (+ GV_DEBUG_FUSED_TWO_LEVEL_MIN=0). Parity is bench.py's own.
+for n in 20000 100000 300000 1000000 2000000 10000000; do
+  for e in "GV_DEBUG_FUSED_EMIT_MAX=0" "GV_DEBUG_FUSED_EMIT_MAX=16777216" "GV_DEBUG_FUSED_EMIT_MAX=16777216 GV_DEBUG_FUSED_TWO_LEVEL_MIN=0"; do
+    echo "## entities $n  $e"
     env $e python3 bench.py --workload cfg2 --entities $n --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
