@@ -390,13 +390,11 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         }
         // one view, records wanted, pool small enough for the look-back form to win: cull + emit in ONE launch
         static const uint32_t fused_emit_max = getenv("GV_DEBUG_FUSED_EMIT_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_FUSED_EMIT_MAX")) : kFusedEmitMaxSlots;
-        // ... beyond that size the tiles add up each other's counts in two levels instead of handing a prefix down a chain
-        static const uint32_t two_level_min = getenv("GV_DEBUG_FUSED_TWO_LEVEL_MIN") ? (uint32_t)atoi(getenv("GV_DEBUG_FUSED_TWO_LEVEL_MIN")) : kFusedTwoLevelMinSlots;
         if (!batched && !fused && !use_bounds && view_count == 1 && ctx->views[pool_id][0].emitted && p.occupancy <= fused_emit_max) {
             ViewState& vs = ctx->views[pool_id][0];
             const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
-            if (cull_emit_status_words(nb) > vs.tile_status.cap || !vs.tile_ticket.ptr) {
-                GV_HIP(ctx, vs.tile_status.reserve(cull_emit_status_words(nb)));
+            if (nb > vs.tile_status.cap || !vs.tile_ticket.ptr) {
+                GV_HIP(ctx, vs.tile_status.reserve(nb));
                 GV_HIP(ctx, vs.tile_ticket.reserve(1));
                 GV_HIP(ctx, hipMemsetAsync(vs.tile_status.ptr, 0, vs.tile_status.cap * sizeof(unsigned long long), ctx->stream));
                 GV_HIP(ctx, hipMemsetAsync(vs.tile_ticket.ptr, 0, sizeof(uint32_t), ctx->stream));
@@ -409,7 +407,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             {
                 KernelTimer t(ctx, GV_K_CULL);
                 GV_HIP(ctx, launch_cull_emit(mesh, xf, hz, vps[0], vbs[0], vs.tile_status.ptr, vs.tile_ticket.ptr, vs.tile_ticket_base,
-                                             vs.tile_epoch, ctx->stream, p.occupancy >= two_level_min));
+                                             vs.tile_epoch, ctx->stream));
             }
             vs.tile_ticket_base += (uint32_t)nb;
             for (uint32_t v = view_count; v < GV_MAX_VIEWS; v++)

@@ -554,37 +554,20 @@ size_t cull_list_entry_bytes() { return sizeof(BlockWindow); }
 // ------------------------------------------------------------------------------------------------
 struct FusedEmit {
     unsigned long long* status;  // one word per tile
-    unsigned long long* chunk_status;  // TWO_LEVEL: one word per group of kTilesPerGroup tiles (the group's total), same stamps
     uint32_t* ticket;            // running ticket counter (never reset: ticket_base is its value before this launch)
     uint32_t ticket_base;
     uint32_t epoch;              // != 0, different from the previous launches that used these words
 };
 constexpr unsigned long long kTileAggregate = 1ull << 30, kTilePrefix = 2ull << 30, kTileFlagMask = 3ull << 30, kTileCountMask = (1ull << 30) - 1ull;
 
-// TWO_LEVEL (pools beyond a few hundred tiles): no look-back CHAIN. A tile publishes its count; the last tile of every group of 16
-// adds up its group and publishes the group's total; a tile's base is then the sum of the totals of the groups before its own plus
-// the counts of the tiles before it inside its group — every word it reads is a plain count that depends on at most one other
-// word, where the look-back form hands a running prefix from tile to tile (16 ns per tile: 64 us of waiting at 1 M entities). A
-// tile waits only for tiles with smaller tickets, which are running.
-constexpr uint32_t kTilesPerGroup = 16;
-__device__ __forceinline__ uint32_t wait_for_count(const unsigned long long* word, uint32_t epoch)
-{
-    unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t spins = 0; (uint32_t)(v >> 32) != epoch && spins < (1u << 24); spins++) {  // (bounded: a wrong count fails a test, a hang takes the box)
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return (uint32_t)(v & kTileCountMask);
-}
-
-template <bool HIZ, uint32_t MAP, bool TWO_LEVEL>
+template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_emit_kernel(const CullArgs args, const FusedEmit fe)
 {
     __shared__ uint32_t wave_count[kCullBlock / 64];
     __shared__ uint32_t tile_s, base_s;
     __shared__ float4 stage[kCullBlock * 3];
     if (threadIdx.x == 0)
-        tile_s = fe.ticket ? atomicAdd(fe.ticket, 1u) - fe.ticket_base : blockIdx.x;  // (NULL: experiment — dispatch order taken on trust)
+        tile_s = atomicAdd(fe.ticket, 1u) - fe.ticket_base;
     __syncthreads();
     const uint32_t lb = tile_s;  // < nblocks: the grid has exactly nblocks workgroups
     const uint32_t i = lb * kCullBlock + threadIdx.x;
@@ -620,31 +603,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_emit_kernel(const CullArgs ar
         wave_prefix += w < wave ? wave_count[w] : 0u;
         total += wave_count[w];
     }
-    if (TWO_LEVEL && wave == 0) {
-        const unsigned long long stamp = (unsigned long long)fe.epoch << 32;
-        if (lane == 0)
-            __hip_atomic_store(&fe.status[lb], stamp | kTileAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t group = lb / kTilesPerGroup, first = group * kTilesPerGroup;
-        uint32_t part = first + lane < lb ? wait_for_count(&fe.status[first + lane], fe.epoch) : 0u;  // (lanes 0 .. 14 at most)
-#pragma unroll
-        for (uint32_t d = 8; d >= 1; d >>= 1)
-            part += __shfl_xor(part, d, 64);
-        const uint32_t in_group = __shfl(part, 0, 64);
-        if (lane == 0 && (lb % kTilesPerGroup == kTilesPerGroup - 1u || lb + 1 == args.nblocks))
-            __hip_atomic_store(&fe.chunk_status[group], stamp | kTilePrefix | (in_group + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t groups_before = 0;
-        for (uint32_t g = lane; g < group; g += 64)
-            groups_before += wait_for_count(&fe.chunk_status[g], fe.epoch);
-#pragma unroll
-        for (uint32_t d = 32; d >= 1; d >>= 1)
-            groups_before += __shfl_xor(groups_before, d, 64);
-        if (lane == 0) {
-            base_s = groups_before + in_group;
-            if (lb + 1 == args.nblocks)
-                *args.out.draw_count = groups_before + in_group + total;
-        }
-    }
-    if (!TWO_LEVEL && wave == 0) {  // look-back: 64 predecessors per step
+    if (wave == 0) {  // look-back: 64 predecessors per step
         const unsigned long long stamp = (unsigned long long)fe.epoch << 32;
         uint32_t before = 0;
         if (lb == 0) {
@@ -705,7 +664,7 @@ __global__ __launch_bounds__(kCullBlock) void cull_emit_kernel(const CullArgs ar
 
 hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                             const ViewBuffers& out, unsigned long long* status, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch,
-                            hipStream_t stream, bool two_level)
+                            hipStream_t stream)
 {
     if (mesh.count == 0)
         return hipSuccess;
@@ -716,24 +675,18 @@ hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, c
     a.view = vp;
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
-    // (the group words live behind the tile words: cull_emit_status_words() of them were allocated)
-    static const bool static_ids = getenv("GV_DEBUG_FUSED_STATIC_IDS") != nullptr;  // experiment (profiles/withdrawn.md): no ticket
-    const FusedEmit fe{status, status + a.nblocks, static_ids ? nullptr : ticket, ticket_base, epoch};
+    const FusedEmit fe{status, ticket, ticket_base, epoch};
     const dim3 grid(a.nblocks), block(kCullBlock);
-#define GV_LAUNCH_FUSED(HIZ, TWO)                                                                                          \
-    switch (mesh.mapping) {                                                                                               \
-    case kMapExact: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapExact, TWO>), grid, block, 0, stream, a, fe); break;         \
-    case kMapSpeculate: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapSpeculate, TWO>), grid, block, 0, stream, a, fe); break; \
-    default: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapGeneral, TWO>), grid, block, 0, stream, a, fe); break;              \
+#define GV_LAUNCH_FUSED(HIZ)                                                                                          \
+    switch (mesh.mapping) {                                                                                          \
+    case kMapExact: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapExact>), grid, block, 0, stream, a, fe); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a, fe); break; \
+    default: hipLaunchKernelGGL((cull_emit_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a, fe); break;              \
     }
-    if (vp.use_hiz && two_level) {
-        GV_LAUNCH_FUSED(true, true)
-    } else if (vp.use_hiz) {
-        GV_LAUNCH_FUSED(true, false)
-    } else if (two_level) {
-        GV_LAUNCH_FUSED(false, true)
+    if (vp.use_hiz) {
+        GV_LAUNCH_FUSED(true)
     } else {
-        GV_LAUNCH_FUSED(false, false)
+        GV_LAUNCH_FUSED(false)
     }
 #undef GV_LAUNCH_FUSED
     return hipGetLastError();

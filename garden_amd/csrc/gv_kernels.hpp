@@ -63,7 +63,6 @@ constexpr uint32_t kCullBlock = 256;   // slots per cull workgroup (4 waves)
 constexpr uint32_t kFusedEmitMaxSlots = 32768;  // pools up to this size cull + emit in one launch: the look-back chain costs
                                                 // ~16 ns per tile, so it only pays while a launch costs more (6.9 vs 9.8 us at 10 k
                                                 // slots, equal at 100 k, 64 vs 24 us at 1 M; profiles/r02i_fused_emit.txt)
-constexpr uint32_t kFusedTwoLevelMinSlots = 0xFFFFFFFFu;  // (set by measurement below)
 constexpr uint32_t kAutoBoundsMinSlots = 262144;  // pools above this size get block bounds unless GV_CONFIG_LINEAR_SCAN (smaller
                                                   // ones are launch-bound and keep the one-launch / batched paths)
 constexpr uint32_t kEmitChunk = 4096;  // slots per compaction chunk = 64 ballot words
@@ -145,8 +144,7 @@ hipError_t launch_cull_listed(const MeshMirror& mesh, const TransformMirror& xf,
 // counter whose value before this launch is ticket_base.
 hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
                             const ViewBuffers& out, unsigned long long* status, uint32_t* ticket, uint32_t ticket_base, uint32_t epoch,
-                            hipStream_t stream, bool two_level);
-inline size_t cull_emit_status_words(size_t tiles) { return tiles + (tiles + 15) / 16; }  // one word per tile + one per group of 16 tiles
+                            hipStream_t stream);
 // One pass over the streams for up to kMaxBatchViews views that share views[0].cam (Hi-Z only on view 0).
 constexpr uint32_t kMaxBatchViews = 8;
 struct MultiViewPlanes {
