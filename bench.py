@@ -388,7 +388,8 @@ def main():
 
         def bark(self):
             import subprocess
-            reason = f"the library's exchange made no progress for {self.seconds:.0f} s after '{self.where}' (rank {rank}): timed through torch.distributed by a child run"
+            reason = (f"the library's exchange made no progress for {self.seconds:.0f} s after '{self.where}' (rank {rank}): timed through torch.distributed "
+                      f"by a child run, which shared this GPU with the parent it replaced (its memory, and a collective kernel that may still be spinning)")
             print("bench.py: " + reason, file=sys.stderr, flush=True)
             port = 1024 + (int(os.environ.get("MASTER_PORT", "29533")) + 17 - 1024) % 64000
             env = dict(os.environ, GV_BENCH_FALLBACK_REASON=reason, MASTER_PORT=str(port))
@@ -671,6 +672,9 @@ def main():
                 try:
                     vis.exchange_init(ids[0], rank, world)
                     vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
+                    # (the library's own waits are bounded — GV_E_TIMEOUT — and would end this run without a line; here the watchdog
+                    # above is the one that acts, by handing over to a child run: the library's bound is set behind it)
+                    vis.exchange_set_timeout(int(2000 * exchange_watchdog.seconds))
                     # one frame through it, against the exact lists, before it is trusted with the timed frames
                     native[0] = True
                     requested, args.payload = args.payload, "indices"
@@ -714,9 +718,10 @@ def main():
             ex[0] = make_exchange(args.payload)
     # Clocks: a freshly initialised GPU needs tens of milliseconds of work before it runs at its sustained clocks, and the driver's 5
     # warm-up frames are 0.7 ms (measured, same box, --steps 20 --warmup 5: 0.149 ms per frame cold, 0.147 / 0.143 after 60 frames,
-    # 0.141 after 300). The frames below are part of bringing the device up, like the mirror upload above: untimed, in front of the
-    # W warm-up frames the contract asks for, for a fixed 0.3 s of wall clock (GV_BENCH_PREWARM_MS=0 switches them off for A/Bs).
-    prewarm_ms, prewarm_frames = float(os.environ.get("GV_BENCH_PREWARM_MS", "300")), 0
+    # 0.141 after 300). Round 4 ran 0.3 s of extra untimed frames here by default; the contract says W warm-up frames, so the
+    # default is now exactly those — GV_BENCH_PREWARM_MS=300 brings the extra frames back for A/Bs at sustained clocks
+    # (config.prewarm_frames says how many ran).
+    prewarm_ms, prewarm_frames = float(os.environ.get("GV_BENCH_PREWARM_MS", "0")), 0
     t_pre = time.perf_counter()
     # (with an exchange every frame is a collective: the ranks decide TOGETHER after each 50 frames whether to go on — clocks that
     # disagree by a millisecond must not leave one rank a chunk ahead, waiting in a collective nobody else enters)

@@ -441,7 +441,7 @@ int async_error(GvCtx* ctx)
     int async = 0;
     if (!r.CommGetAsyncError || !ctx->exchange_comm || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
         return 0;
-    return async;
+    return async == 7 ? 0 : async;  // (ncclInProgress, rccl.h: a non-blocking communicator still at work — not an error)
 }
 
 // Waits until the headers of `slot`'s frame are on the host (written by exchange_headers_kernel behind the frame's collective).

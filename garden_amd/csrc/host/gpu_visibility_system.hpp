@@ -219,7 +219,9 @@ public:
     // HizRenderSystem::downsampleHiz stand-in: hand over this frame's reversed-Z depth (host memory).
     void setHizDepth(const float* depth, uint32_t width, uint32_t height)
     {
-        check(gv_hiz_build(ctx, depth, width, height, GV_MEM_HOST), "gv_hiz_build");
+        for (uint32_t r = 0; r < contexts.size(); r++)  // the pyramid is screen space: every rank builds the whole of it
+            if (gv_hiz_build(contexts[r], depth, width, height, GV_MEM_HOST) != GV_OK)
+                throw GardenError(std::string("gv_hiz_build failed: ") + gv_last_error(contexts[r]));
         useHiz = true;
     }
 
@@ -802,7 +804,7 @@ private:
                 if (renderType == MeshRenderType::UI)
                     views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
                 else
-                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, false, emitRecords));
+                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
                 passes.push_back(-1);
                 if (!sorted) {
                     hasAnyRefr |= renderType == MeshRenderType::Refracted;

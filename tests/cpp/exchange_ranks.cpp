@@ -8,7 +8,9 @@
 // (count, delivered entries, sum, xor) every row it received and its own list; the parent checks that all ranks received
 // the same rows and that row r is rank r's WHOLE list in EVERY frame of gv_exchange_visible — the camera cut included
 // (the caller-sized frames may be short: that form is the caller's own sizing). The transport patterns take turns.
-//   exchange_ranks --ranks R|auto [--entities N] [--frames F] [--mode all|allgather|p2p|broadcast] [--stall-rank R]
+//   exchange_ranks --ranks R|auto [--entities N] [--frames F] [--mode all|allgather|p2p|broadcast] [--stall-rank R] [--random-camera SEED]
+// --random-camera SEED: every frame looks somewhere else through another lens (field of view 20 .. 160 degrees): the lists jump by an
+// order of magnitude from frame to frame in both directions — predictions are short or far too generous most of the time.
 // --stall-rank R: rank R stops calling half way (a stalled peer): every other rank must come back with a status code — not hang:
 // GV_E_TIMEOUT from a bounded wait (2 s here) on the rank that notices first (it aborts the communicator), GV_E_TIMEOUT or
 // GV_E_RCCL (ncclCommGetAsyncError: a rank has left) on the others — and shut its communicator down.
@@ -85,12 +87,12 @@ RowSummary summarise(const uint32_t* entries, uint64_t count, uint64_t room, uin
 }
 
 // camera at the origin, 90 degree field of view, 16:9, infinite reversed-Z; yaw about +y
-void make_view(float yaw, GvView* view)
+void make_view(float yaw, GvView* view, float zoom = 1.0f)
 {
     memset(view, 0, sizeof(*view));
     const float c = std::cos(yaw), s = std::sin(yaw);
-    // projection (columns): x' = (9/16) x, y' = -y, z' = near, w' = z ; view = rotation by -yaw about y
-    const float P[16] = {9.0f / 16.0f, 0, 0, 0, 0, -1.0f, 0, 0, 0, 0, 0, 1.0f, 0, 0, 0.01f, 0};
+    // projection (columns): x' = zoom (9/16) x, y' = -zoom y, z' = near, w' = z ; view = rotation by -yaw about y
+    const float P[16] = {zoom * 9.0f / 16.0f, 0, 0, 0, 0, -zoom, 0, 0, 0, 0, 0, 1.0f, 0, 0, 0.01f, 0};
     const float V[16] = {c, 0, s, 0, 0, 1, 0, 0, -s, 0, c, 0, 0, 0, 0, 1};
     for (int col = 0; col < 4; col++)
         for (int row = 0; row < 4; row++) {
@@ -103,7 +105,7 @@ void make_view(float yaw, GvView* view)
     view->emit_records = 1;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, int id_in, int id_out, Shared* shared)
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -247,7 +249,15 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
         }
         // the camera turns a little every frame; half way it cuts to the opposite direction (lists jump: predictions fall short)
         GvView view;
-        make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &view);
+        if (camera_seed) {  // (the same camera on every rank: a hash of the seed and the frame)
+            uint32_t h = camera_seed * 2654435761u + (uint32_t)frame * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+            const float yaw = 6.2831853f * (float)(h & 0xFFFFu) / 65536.0f;
+            const float zoom = std::exp(3.47f * ((float)((h >> 16) & 0xFFFFu) / 65536.0f) - 1.735f);  // 0.18 .. 5.7: 160 .. 20 degrees
+            make_view(yaw, &view, zoom);
+        } else {
+            make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &view);
+        }
         const uint32_t mode = mode_arg >= 0 ? (uint32_t)mode_arg : (uint32_t)(frame % 3);
         if (gv_exchange_set_mode(ctx, mode) != GV_OK || gv_cull(ctx, 0, &view, 1) != GV_OK)
             return die("cull", ctx);
@@ -324,6 +334,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
+    uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
     for (int i = 1; i < argc; i++) {
@@ -336,6 +347,8 @@ int main(int argc, char** argv)
             n = (uint32_t)atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--frames") && i + 1 < argc) {
             frames = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--random-camera") && i + 1 < argc) {
+            camera_seed = (uint32_t)atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--stall-rank") && i + 1 < argc) {
             stall_rank = atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--mode") && i + 1 < argc) {
@@ -376,7 +389,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, to_child[2 * r], to_parent[2 * r + 1], shared));
+            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];
