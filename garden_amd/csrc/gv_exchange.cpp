@@ -579,8 +579,14 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
 {
     Rccl& r = rccl();
     for (int k = 0; k < n; k++)
-        if (int rc = settle_read(ctxs[k], ctxs[k]->exchange_slots[which]))
+        if (int rc = settle_read(ctxs[k], ctxs[k]->exchange_slots[which])) {
+            // a wait that ran out on one rank of the call: the collective hangs on all of them — none is left holding the device
+            if (rc == GV_E_TIMEOUT || rc == GV_E_RCCL)
+                for (int j = 0; j < n; j++)
+                    if (j != k && !ctxs[j]->exchange_broken)
+                        (void)give_up(ctxs[j], rc, ctxs[k]->error.c_str());
             return rc;
+        }
     bool short_rows = false;
     for (int k = 0; k < n; k++) {
         Slot& slot = ctxs[k]->exchange_slots[which];
@@ -717,6 +723,9 @@ int visible_all(GvCtx* const* ctxs, int n, const uint32_t* views, const uint32_t
     for (int k = 0; k < n; k++) {
         if (int rc = usable(ctxs[k], "gv_exchange_visible", by_group))
             return rc;
+        if (ctxs[k]->exchange_mode != ctxs[0]->exchange_mode)
+            return ctxs[k]->fail(GV_E_ARG, "gv_exchange_visible_all: contexts[%d] travels by mode %u, contexts[0] by mode %u (gv_exchange_set_mode: the same on every rank)", k,
+                                 ctxs[k]->exchange_mode, ctxs[0]->exchange_mode);
         if (ctxs[k]->exchange_frame != frame || (by_group && (ctxs[k]->exchange_rank != k || ctxs[k]->exchange_world != n)))
             return ctxs[k]->fail(GV_E_ARG, "gv_exchange_visible_all: contexts[%d] is rank %d of %d at frame %llu (expected rank %d of %d at frame %llu)", k,
                                  ctxs[k]->exchange_rank, ctxs[k]->exchange_world, (unsigned long long)ctxs[k]->exchange_frame, k, n, (unsigned long long)frame);
@@ -741,6 +750,13 @@ int visible_all(GvCtx* const* ctxs, int n, const uint32_t* views, const uint32_t
     const int erc = r.GroupEnd();
     if (rc == GV_OK && erc != 0)
         rc = ctxs[0]->fail(GV_E_RCCL, "gv_exchange_visible: ncclGroupEnd: %s", r.GetErrorString(erc));
+    if (rc == GV_E_RCCL) {  // some ranks' collectives are queued, others' are not: nothing later on this communicator can match
+        const std::string why = ctxs[0]->error;
+        for (int k = 0; k < n; k++)
+            if (!ctxs[k]->exchange_broken)
+                (void)give_up(ctxs[k], rc, (ctxs[k]->error.empty() ? why : ctxs[k]->error).c_str());
+        return rc;
+    }
     for (int k = 0; k < n && rc == GV_OK; k++)
         rc = frame_finish(ctxs[k], ctxs[k]->exchange_slots[which], outs ? outs + k : nullptr);
     return rc;

@@ -1112,6 +1112,89 @@ static int growth_sequence(GvCtx* ctx, World& small, World& grown, bool tolerate
     return GV_OK;
 }
 
+// The exchange under allocation failures: a 1-rank communicator (everything on this thread: the countdown is deterministic), lists
+// that creep, jump (a short prediction: the rows are widened for the tails) and collapse. Whatever allocation fails, the call says
+// GV_E_OOM, nothing leaks (ASan), and the SAME frame can be tried again: every acquired frame holds the whole list.
+static long g_exchange_fail = 0, g_exchange_allocations = 0;
+static int exchange_sequence(GvCtx* ctx, ExchangeRank& x, bool stop_at_failure, int* completed_frames)
+{
+    for (int frame = 0; frame < 10; frame++) {
+        x.produce(frame < 5 ? frame : frame + 4, (uint32_t)(frame % 3));  // (frames 7.. of the scripted sequence jump)
+        const int list_frame = frame < 5 ? frame : frame + 4;
+        GvExchangeFrame sent, got;
+        bool was_sent = false;
+        for (int attempt = 0;; attempt++) {
+            // (only the exchange's own allocations are made to fail: the k-th of them over the whole sequence)
+            auto guarded = [&](auto&& call) {
+                gv_stub_fail_countdown() = g_exchange_fail > g_exchange_allocations ? g_exchange_fail - g_exchange_allocations : 0;
+                const long before = gv_stub_allocations();
+                const int result = call();
+                g_exchange_allocations += gv_stub_allocations() - before;
+                gv_stub_fail_countdown() = 0;
+                return result;
+            };
+            int rc = was_sent ? GV_OK : guarded([&] { return gv_exchange_visible(ctx, 0, 0, 0, &sent); });
+            was_sent = was_sent || rc == GV_OK;
+            if (rc == GV_OK)
+                rc = guarded([&] { return gv_exchange_acquire(ctx, sent.frame, &got); });
+            if (rc == GV_OK)
+                break;
+            if (rc != GV_E_OOM && rc != GV_E_HIP) {
+                std::fprintf(stderr, "exchange under allocation failures: frame %d: %d (%s)\n", frame, rc, gv_last_error(ctx));
+                std::exit(1);
+            }
+            if (stop_at_failure && attempt == 0)
+                ++*completed_frames;  // (counts the failed calls)
+            if (attempt > 3) {
+                std::fprintf(stderr, "exchange under allocation failures: frame %d does not recover\n", frame);
+                std::exit(1);
+            }
+            // (a frame whose send succeeded and whose acquire failed is acquired again; one whose send failed is sent again)
+        }
+        const uint32_t* row = (const uint32_t*)got.gathered_device;
+        const uint32_t count = list_count(0, list_frame, ExchangeRank::n);
+        if (!got.complete || row[0] != count) {
+            std::fprintf(stderr, "exchange under allocation failures: frame %d header %u, expected %u\n", frame, row ? row[0] : 0u, count);
+            std::exit(1);
+        }
+        for (uint32_t k = 0; k < count; k++)
+            if (row[1 + k] != list_value(0, list_frame, k)) {
+                std::fprintf(stderr, "exchange under allocation failures: frame %d entry %u\n", frame, k);
+                std::exit(1);
+            }
+    }
+    return GV_OK;
+}
+
+static void exchange_allocation_failures()
+{
+    if (!std::getenv("GV_RCCL_LIBRARY"))
+        return;
+    g_list_seed = 0;
+    long total = 0;
+    int failed_calls = 0;
+    for (long k = 0;; k++) {
+        ExchangeRank x;
+        if (!x.create(0, 1))
+            std::exit(1);
+        GvCtx* ctx = x.ctx;
+        unsigned char id[GV_EXCHANGE_ID_BYTES];
+        CHECK(gv_exchange_unique_id(id));
+        CHECK(gv_exchange_init(ctx, id, 0, 1));
+        g_exchange_fail = k;  // 0: nothing fails (that run counts the exchange's allocations)
+        g_exchange_allocations = 0;
+        exchange_sequence(ctx, x, true, &failed_calls);
+        if (k == 0)
+            total = g_exchange_allocations;
+        CHECK(gv_exchange_shutdown(ctx));
+        gv_destroy(ctx);
+        if (k >= total)
+            break;
+    }
+    std::printf("allocation failures in the exchange: %ld allocations failed in turn, %d calls reported it, every frame was acquired whole all the same: ok\n",
+                total, failed_calls);
+}
+
 static void allocation_failures()
 {
     {
@@ -1233,6 +1316,7 @@ int main(int argc, char** argv)
     for (int seed = 1; seed <= 6; seed++)
         exchange_in_one_thread(2 + seed % 3, seed);
     allocation_failures();
+    exchange_allocation_failures();
     std::printf("host orchestration: ok\n");
     return 0;
 }
