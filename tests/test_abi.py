@@ -95,3 +95,23 @@ def test_a_missing_rccl_library_is_an_error_code_not_a_crash():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, GV_RCCL_LIBRARY="/nonexistent/librccl_nowhere.so"))
     assert p.returncode == 0, (p.stdout, p.stderr[-2000:])
+
+
+def test_integration_statement_table_points_at_the_shim_lines_it_names():
+    """INTEGRATION.md §2a maps every statement of prepareMeshes (mesh.cpp:331-553) to a line of the shim: the rows of the gate
+    (mesh.cpp:426 / :482), of the flags (:339, :488-490) and of the pool accessor (:410) must still name lines that do that."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "garden_amd", "csrc", "host", "gpu_visibility_system.hpp")).read().splitlines()
+    rows = {line.split("|")[1].strip(): line for line in open(os.path.join(root, "INTEGRATION.md")) if line.startswith("| ")}
+
+    def named(row):
+        last_column = rows[row].rstrip().rstrip("|").rsplit("|", 1)[1]  # (a cell of the middle column may hold an escaped pipe)
+        return [shim[int(n) - 1] for n in re.findall(r"`:(\d+)`", last_column)]
+
+    gate = named("**426**")
+    assert len(gate) >= 3 and "isDrawReady(-1)" in gate[0] and "isDrawReady((int8_t)s)" in gate[1] and "continue" in gate[2], gate
+    assert "hasAnyRefr = hasAnyOIT = hasAnyTD = false" in named("339")[0]
+    assert "hasAnyRefr |=" in named("488-490")[0]
+    assert "getMeshComponentPool()" in named("410-412")[0]
+    assert "shadowIndex != bufferIndex" in named("252 (in `prepareSortedMeshes`)")[0]

@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU box: the headless tick driver (CPU reference-path system vs the GPU drop-in, every buffer compared every tick) over many
 # seeds and flag combinations — the mirror's maintenance paths under entity churn, re-parenting, toggles, moving scenes.
-#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 12 flag sets)
+# Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
+# against the reference text) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 20 flag sets)
 set -u
 cd "$(dirname "$0")/.."
 make -s -C tests/cpp
@@ -20,7 +22,16 @@ sets=(
   "--entities 70000 --churn 4 --copy-records"
   "--entities 33000 --mixed --csm --animate 7 --ticks 5 --soa-records"
   "--entities 300000 --animate 64 --churn 2 --ticks 3"
+  "--entities 20000 --mixed --gate never --hier --mutate --churn 3"
+  "--entities 20000 --mixed --gate shadow --animate 4 --ticks 4 --csm"
+  "--entities 16000 --mixed --gate reverse --toggle --hier"
+  "--entities 16000 --mixed --gate empty --churn 4 --span-records"
+  "--entities 30000 --ranks 4 --hier --mutate --churn 4"
+  "--entities 20000 --ranks 3 --mixed --hier --animate 5 --itemised --ticks 4"
+  "--entities 24000 --ranks 8 --mixed --csm --churn 2"
+  "--entities 12000 --ranks 2 --mixed --gate shadow --toggle --hier"
 )
+export GV_RCCL_LIBRARY=${GV_RCCL_LIBRARY:-$PWD/tests/cpp/build/librccl_stub.so}  # (--ranks N > 1: N contexts share this box's GPU)
 for s in $(seq 1 "$seeds"); do
   for a in "${sets[@]}"; do
     runs=$((runs + 1))
