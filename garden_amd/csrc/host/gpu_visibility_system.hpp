@@ -746,6 +746,8 @@ private:
         auto transformSystem = TransformSystem::Instance::get();
         auto graphicsSystem = GraphicsSystem::Instance::get();
         Stopwatch whole(tickSeconds.total);
+        if (sweepWorldMatrices)  // (a rank keeps the world matrices of ITS entities: gv_sweep / gv_get_world on getContext(rank), in local slots)
+            throw GardenError("GpuVisibilitySystem: sweepWorldMatrices is a one-context option; with several ranks ask each rank's context");
         prepareSystems();
         syncRanks(transformSystem);
         const uint32_t ranks = (uint32_t)contexts.size();
