@@ -90,6 +90,7 @@ public:
     };
 
     bool isEnabled = true;
+    bool isNonTranslucent = false;  // mesh.hpp:275 "Render only non translucent meshes": prepareSystems keeps Color / Opaque / UI systems (mesh.cpp:89-101)
     // true: records arrive as UnsortedMesh / SortedMesh structs (gv_pool_set_record_layout), combinedMeshes is one memcpy
     bool recordStructs = true;
     // true (with recordStructs): the device writes an unsorted buffer's records straight into its combinedMeshes
@@ -247,8 +248,12 @@ private:
     {
         meshSystems.clear();
         for (auto& sys : Manager::Instance::get()->getSystems())
-            if (auto ms = dynamic_cast<IMeshRenderSystem*>(sys.get()))
+            if (auto ms = dynamic_cast<IMeshRenderSystem*>(sys.get())) {
+                const auto renderType = ms->getMeshRenderType();
+                if (isNonTranslucent && renderType != MeshRenderType::Color && renderType != MeshRenderType::Opaque && renderType != MeshRenderType::UI)
+                    continue;  // mesh.cpp:89-101: "Render only non translucent meshes" keeps Color, Opaque and UI systems
                 meshSystems.push_back(ms);
+            }
         if (meshSystems.size() > GV_MAX_POOLS)
             throw GardenError("GpuVisibilitySystem: more mesh systems than GV_MAX_POOLS");
         unsortedBufferCount = sortedBufferCount = 0;

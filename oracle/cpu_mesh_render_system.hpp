@@ -37,6 +37,7 @@ private:
 
 public:
     bool isEnabled = true;
+    bool isNonTranslucent = false;  // mesh.hpp:275
     bool sortMeshesEnabled = true;  // mesh.cpp:548-551: prepareMeshes ends with sortMeshes()
     bool useAvx2 = false;    // 8-wide AVX2+FMA SoA path instead of the scalar AoS loop (bit-identical)
     uint32_t threads = 1;    // asyncPreparing (mesh.cpp:399): >1 fans out like ThreadPool::addItems
@@ -245,8 +246,15 @@ private:
             return;
         meshSystems.clear();  // prepareSystems, mesh.cpp:69-108
         for (auto& sys : Manager::Instance::get()->getSystems())
-            if (auto ms = dynamic_cast<IMeshRenderSystem*>(sys.get()))
-                meshSystems.push_back(ms);
+            if (auto meshSystem = dynamic_cast<IMeshRenderSystem*>(sys.get())) {
+                if (isNonTranslucent) {  // :89-101
+                    auto renderType = meshSystem->getMeshRenderType();
+                    if (renderType == MeshRenderType::Color || renderType == MeshRenderType::Opaque || renderType == MeshRenderType::UI)
+                        meshSystems.push_back(meshSystem);
+                } else {
+                    meshSystems.push_back(meshSystem);  // :103-107
+                }
+            }
         auto transformSystem = TransformSystem::Instance::get();
         const auto& cc = GraphicsSystem::Instance::get()->getCommonConstants();
         auto& tpool = transformSystem->getComponents();

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--ranks R] [--gate never|shadow|reverse|empty] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
+//   headless_tick --mode cpu|gpu|both [--ranks R] [--gate never|shadow|reverse|empty] [--non-translucent] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // --gate (with --mixed): the per-system gate of mesh.cpp:426 / :482 — `componentCount == 0 || !isDrawReady(shadowPass)`:
@@ -14,6 +14,8 @@
 //   system's results are checked against the reference TEXT (gateHolds below): a system that is not drawn in a pass has its
 //   counters at 0 for that pass, contributes no record, and — light pass — its isVisible bytes are exactly what they were before
 //   the tick (every tick starts from a pattern no cull would leave behind).
+// --non-translucent: MeshRenderSystem::isNonTranslucent (mesh.hpp:275): prepareSystems keeps Color / Opaque / UI systems only
+// (mesh.cpp:89-101) — the others get no buffer and their isVisible bytes are never touched.
 // --ranks R: the GPU drop-in's own multi-GPU mode — ONE process, ONE thread, R contexts (all on device 0 here: with R > 1 the rows
 // travel through the test transport named by GV_RCCL_LIBRARY): the pools are dealt to the ranks, every rank culls its share, the
 // lists are gathered on the devices (every rank's rows are read back and compared: all ranks hold the same rows, their union is the
@@ -191,6 +193,7 @@ static bool same(const Snapshot& a, const Snapshot& b, std::string& why)
 
 // Every tick starts from isVisible bytes no cull would leave behind: a system that is drawn in the light pass rewrites every one
 // of its slots (each exit of mesh.cpp:140-166 stores the byte), a system that is not must leave them exactly like this.
+static bool g_nonTranslucent = false;  // --non-translucent: prepareSystems keeps Color / Opaque / UI systems only (mesh.cpp:89-101)
 static bool patternAt(size_t system, uint32_t slot) { return ((slot * 7u + (uint32_t)system * 3u + 3u) % 5u) == 0; }
 static void poisonVisible(Manager& manager)
 {
@@ -217,12 +220,17 @@ static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t p
         const auto ready = dynamic_cast<const ReadinessSwitch*>(ms);
         const uint32_t count = ms->getMeshComponentPool().getCount(), occupancy = ms->getMeshComponentPool().getOccupancy();
         const bool sorted = type == MeshRenderType::Translucent || type == MeshRenderType::UI;
-        const bool light = count != 0 && (!ready || ready->drawReady(-1));
+        const bool kept = !g_nonTranslucent || type == MeshRenderType::Color || type == MeshRenderType::Opaque || type == MeshRenderType::UI;
+        const bool light = kept && count != 0 && (!ready || ready->drawReady(-1));
         const std::string name = "mesh system " + std::to_string(k);
         if (!light)
             for (uint32_t i = 0; i < occupancy; i++)
                 if ((bool)componentAt(ms, i)->isVisible != patternAt(k, i))
                     return name + " is not drawn in the light pass, yet isVisible of slot " + std::to_string(i) + " was written";
+        if (!kept) {  // not among meshSystems at all (mesh.cpp:89-101): no buffer, no index
+            k++;
+            continue;
+        }
         if (sorted) {
             const uint32_t index = sortedIndex++;
             const uint32_t shadowIndex = type == MeshRenderType::Translucent ? shadowSortedIndex++ : 0u;
@@ -309,6 +317,7 @@ int main(int argc, char** argv)
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
+        else if (a == "--non-translucent") g_nonTranslucent = true;
         else if (a == "--ranks" && i + 1 < argc) ranks = (uint32_t)atoi(argv[++i]);
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
@@ -406,7 +415,9 @@ int main(int argc, char** argv)
                 std::sort(all.begin(), all.end());
                 gathered[{meshSystemIndex, (int)pass}] = std::move(all);
             };
+        if (cpu) cpu->isNonTranslucent = g_nonTranslucent;
         if (gpu) {
+            gpu->isNonTranslucent = g_nonTranslucent;
             gpu->recordStructs = !soaRecords;
             gpu->recordTargets = !copyRecords;
             gpu->recordSpans = spanRecords;
@@ -629,7 +640,7 @@ int main(int argc, char** argv)
                 doMutate();
             else if (round >= 1)
                 doChurn();
-            if (round >= 1 && !gate.empty())
+            if (round >= 1 && (!gate.empty() || g_nonTranslucent))
                 run(false, false, 1);  // (components destroyed above are disposed of at the end of a frame — T(): isVisible = false — also in
                                        //  pools no system draws: that frame is kept out of the two ticks whose isVisible bytes are compared)
             if (mode == "both") {

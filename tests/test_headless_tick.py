@@ -57,6 +57,9 @@ def test_cpu_system_gate_of_prepare_meshes_against_the_reference_text(tick, gate
     the isVisible bytes the tick started from; hasAnyRefr / hasAnyOIT / hasAnyTD follow :339,488-490 (headless_tick gateHolds)."""
     _, out = tick("--mode", "cpu", "--entities", "8000", "--ticks", "2", "--mixed", "--gate", gate, "--hier")
     assert out["ok"] and out["draw_count"] > 0, out
+    # ... and behind prepareSystems' isNonTranslucent filter (mesh.cpp:89-101): Color / Opaque / UI systems only
+    _, kept = tick("--mode", "cpu", "--entities", "8000", "--ticks", "2", "--mixed", "--gate", gate, "--hier", "--non-translucent")
+    assert kept["ok"] and kept["draw_count"] == out["draw_count"] and kept["sorted_draw_count"] < out["sorted_draw_count"], (out, kept)
 
 
 def test_cpu_entity_churn(tick):
@@ -132,6 +135,10 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "20000", "--mixed", "--gate", "never", "--hier", "--mutate", "--span-records"],
     ["--entities", "20000", "--mixed", "--gate", "shadow", "--animate", "3", "--ticks", "4", "--copy-records"],
     ["--entities", "12000", "--mixed", "--gate", "empty", "--churn", "2", "--soa-records"],
+    # MeshRenderSystem::isNonTranslucent (mesh.hpp:275): prepareSystems keeps the Color / Opaque / UI systems only (mesh.cpp:89-101);
+    # the others get no buffer and keep the isVisible bytes the tick started from
+    ["--entities", "30000", "--mixed", "--non-translucent", "--hier", "--mutate"],
+    ["--entities", "20000", "--mixed", "--non-translucent", "--gate", "shadow", "--csm"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
