@@ -386,10 +386,12 @@ def main():
                 self.timer.cancel()
                 self.timer = None
 
-        def bark(self):
+        def bark(self, error=None):
             import subprocess
-            reason = (f"the library's exchange made no progress for {self.seconds:.0f} s after '{self.where}' (rank {rank}): timed through torch.distributed "
-                      f"by a child run, which shared this GPU with the parent it replaced (its memory, and a collective kernel that may still be spinning)")
+            what = (f"the library's exchange failed after '{self.where}' (rank {rank}): {error}" if error else
+                    f"the library's exchange made no progress for {self.seconds:.0f} s after '{self.where}' (rank {rank})")
+            reason = (what + ": timed through torch.distributed by a child run, which shared this GPU with the parent it replaced (its memory, "
+                      "and a collective kernel that may still be spinning)")
             print("bench.py: " + reason, file=sys.stderr, flush=True)
             port = 1024 + (int(os.environ.get("MASTER_PORT", "29533")) + 17 - 1024) % 64000
             env = dict(os.environ, GV_BENCH_FALLBACK_REASON=reason, MASTER_PORT=str(port))
@@ -418,7 +420,7 @@ def main():
         return int(t.item()) == 0
 
     from garden_amd import scene
-    from garden_amd.lib import GpuVisibility, GV_SWEEP_MFMA, GV_SWEEP_VALU, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
+    from garden_amd.lib import GpuVisibility, GvError, GV_SWEEP_MFMA, GV_SWEEP_VALU, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU
     from garden_amd.multi import VisibleListExchange, allgatherv_indices, shard_capacity, mask_words, expand_mask_rows
 
     wl = WORKLOADS[args.workload]
@@ -477,11 +479,18 @@ def main():
         """gv_exchange_visible for this frame, then the PREVIOUS frame acquired, the way a consumer one frame behind does: the send
         has settled that frame (a short row completed by a second exchange inside the call), so the acquire is a stream wait —
         every frame of the timed region is handed out complete."""
-        f = vis.exchange_visible(0, index_base=rank * n)
-        if sent_frame[0] is not None:
-            acquired = vis.exchange_acquire(sent_frame[0])
-            exchange_frames[0] += 1
-            exchange_frames[1] += 1 if acquired["cut_ranks"] else 0
+        try:
+            f = vis.exchange_visible(0, index_base=rank * n)
+            if sent_frame[0] is not None:
+                acquired = vis.exchange_acquire(sent_frame[0])
+                exchange_frames[0] += 1
+                exchange_frames[1] += 1 if acquired["cut_ranks"] else 0
+        except GvError as e:
+            # a status code from the library's exchange in the middle of the run (GV_E_TIMEOUT, GV_E_RCCL: it has never met real RCCL
+            # with several ranks): like a collective that never returns, the line is handed to a child run through torch.distributed
+            if world > 1 and not os.environ.get("GV_BENCH_FALLBACK_REASON"):
+                exchange_watchdog.bark(error=str(e))
+            raise
         sent_frame[0] = f["frame"]
         return f
 
@@ -677,7 +686,7 @@ def main():
                     vis.exchange_set_mode(EXCHANGE_MODES[args.exchange])
                     # (the library's own waits are bounded — GV_E_TIMEOUT — and would end this run without a line; here the watchdog
                     # above is the one that acts, by handing over to a child run: the library's bound is set behind it)
-                    vis.exchange_set_timeout(int(2000 * exchange_watchdog.seconds))
+                    vis.exchange_set_timeout(int(os.environ.get("GV_BENCH_EXCHANGE_TIMEOUT_MS", 2000 * exchange_watchdog.seconds)))
                     # one frame through it, against the exact lists, before it is trusted with the timed frames
                     native[0] = True
                     requested, args.payload = args.payload, "indices"

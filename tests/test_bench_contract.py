@@ -180,3 +180,16 @@ def test_bench_hands_over_to_a_child_run_when_a_collective_of_the_library_exchan
     c = d["config"]
     assert c["exchange_path"] == "torch" and "no progress" in c["exchange_path_fallback"] and "shared this GPU" in c["exchange_path_fallback"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity"]["visible_set_bit_identical"]
+
+
+@pytest.mark.gpu
+def test_bench_hands_over_when_the_library_exchange_returns_an_error_in_the_middle_of_the_run():
+    """A STATUS CODE from the library's exchange, not a hang: one of the transport's transfers stops completing and the library's
+    own bounded wait (3 s here, GV_BENCH_EXCHANGE_TIMEOUT_MS) ends long before the watchdog (60 s): the ranks get GV_E_TIMEOUT
+    (or GV_E_RCCL from ncclCommGetAsyncError once a peer has aborted) from gv_exchange_visible / _acquire and hand the line to a
+    child run through torch.distributed at once — exchange_path "torch", exchange_path_fallback = the library's error text."""
+    d = _run_bench(["--gpus", "2", "--entities", "100000", "--steps", "3", "--warmup", "1", "--no-mask-variant"],
+                   {"GV_BENCH_BACKEND": "gloo", "RCCL_STUB_HANG_AT": "8", "GV_BENCH_EXCHANGE_WATCHDOG_S": "60", "GV_BENCH_EXCHANGE_TIMEOUT_MS": "3000"})
+    c = d["config"]
+    assert c["exchange_path"] == "torch" and "failed after" in c["exchange_path_fallback"] and "libgarden_vis error" in c["exchange_path_fallback"], c["exchange_path_fallback"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity"]["visible_set_bit_identical"]
