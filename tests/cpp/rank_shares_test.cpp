@@ -1,0 +1,170 @@
+// rank_shares_test.cpp — TEST: garden_amd/csrc/host/rank_shares.hpp (what each rank of the drop-in's multi-GPU mode holds of the
+// engine's pools) on the CPU, under AddressSanitizer + UndefinedBehaviorSanitizer: worlds with hierarchies, free slots, meshes
+// without a transform, destroyed entities, re-parenting; ranks 1 .. 8. Checked after every deal:
+//   * every live transform lives on exactly one rank, on the rank gv_cell_owner gives its ROOT's position; a parent is on its
+//     child's rank and the local parent id names it; local entity ids are slot + 1; the copied bytes are the world's
+//   * every slot of every mesh pool lives on exactly one rank (free slots and meshes without a transform included), its local entity
+//     id resolves to the transform the world's entity resolves to (or to nothing), the world slot table is a permutation
+//   * copyTransform refreshes a moved transform in place
+// Links libgarden_vis.so for gv_cell_owner (host-only; no device is touched).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../../garden_amd/csrc/host/rank_shares.hpp"
+
+using namespace garden;
+
+struct alignas(16) WideMeshComponent final : public MeshRenderComponent {
+    float payload[8] = {};
+};
+using WideMeshSystem = MeshSystemOf<WideMeshComponent, MeshRenderType::Translucent>;
+
+static int failures = 0;
+#define EXPECT(cond, ...)                          \
+    do {                                           \
+        if (!(cond)) {                             \
+            std::fprintf(stderr, __VA_ARGS__);     \
+            std::fprintf(stderr, "\n");            \
+            failures++;                            \
+        }                                          \
+    } while (0)
+
+static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem*>& meshSystems, const RankShares& shares, uint32_t ranks,
+                  const uint32_t grid[3], double side, const char* what)
+{
+    auto& pool = const_cast<TransformSystem*>(ts)->getComponents();
+    const auto& emap = ts->getEntityMap();
+    const uint32_t occupancy = pool.getOccupancy();
+    const TransformComponent* world = pool.getData();
+    std::vector<uint32_t> owners(occupancy ? occupancy : 1);
+    if (occupancy)
+        EXPECT(gv_cell_owner(grid, side, ranks, reinterpret_cast<const float*>(&world[0].posChildCount), sizeof(TransformComponent), occupancy, owners.data()) == GV_OK,
+               "%s: gv_cell_owner", what);
+    std::vector<uint32_t> seen(occupancy, 0);
+    for (uint32_t r = 0; r < ranks; r++) {
+        const auto& share = shares.shares[r];
+        EXPECT(share.transforms.size() == share.transformWorldSlot.size() && share.entityToTransform.size() == share.transforms.size() + 2, "%s: rank %u sizes", what, r);
+        for (uint32_t k = 0; k < share.transforms.size(); k++) {
+            const uint32_t w = share.transformWorldSlot[k];
+            seen[w]++;
+            const TransformComponent& local = share.transforms[k];
+            EXPECT(*local.entity == k + 1 && share.entityToTransform[k + 1] == k, "%s: rank %u local entity id of slot %u", what, r, k);
+            EXPECT(std::memcmp(&local.posChildCount, &world[w].posChildCount, 12) == 0 && std::memcmp(&local.rotation, &world[w].rotation, 16) == 0 &&
+                       local.selfActive == world[w].selfActive && local.ancestorsActive == world[w].ancestorsActive, "%s: rank %u slot %u is not the world's transform", what, r, k);
+            uint32_t root = w;  // the world's root of w
+            for (uint32_t guard = 0; *world[root].parent && guard < occupancy; guard++)
+                root = emap[*world[root].parent];
+            EXPECT(owners[root] == r, "%s: transform %u lives on rank %u, its root's cell belongs to rank %u", what, w, r, owners[root]);
+            if (*world[w].parent) {
+                const uint32_t parentSlot = emap[*world[w].parent];
+                EXPECT(shares.rankOfTransform[parentSlot] == r && *local.parent == shares.localOfTransform[parentSlot] + 1, "%s: parent link of transform %u", what, w);
+            } else {
+                EXPECT(*local.parent == 0, "%s: a root with a parent", what);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < occupancy; i++)
+        EXPECT(seen[i] == (*world[i].entity ? 1u : 0u), "%s: transform slot %u is held %u times", what, i, seen[i]);
+    for (size_t p = 0; p < meshSystems.size(); p++) {
+        const auto& meshPool = meshSystems[p]->getMeshComponentPool();
+        const size_t stride = meshSystems[p]->getMeshComponentSize();
+        const uint8_t* data = reinterpret_cast<const uint8_t*>(meshPool.getData());
+        std::vector<uint32_t> held(meshPool.getOccupancy(), 0);
+        for (uint32_t r = 0; r < ranks; r++) {
+            const auto& mesh = shares.shares[r].meshes[p];
+            EXPECT(mesh.stride == stride && mesh.components.size() == (size_t)mesh.occupancy() * stride, "%s: pool %zu rank %u sizes", what, p, r);
+            for (uint32_t j = 0; j < mesh.occupancy(); j++) {
+                const uint32_t w = mesh.worldSlot[j];
+                held[w]++;
+                const auto* local = reinterpret_cast<const MeshRenderComponent*>(mesh.components.data() + (size_t)j * stride);
+                const auto* global = reinterpret_cast<const MeshRenderComponent*>(data + (size_t)w * stride);
+                EXPECT(std::memcmp(&local->aabb, &global->aabb, sizeof(Aabb)) == 0 && local->isEnabled == global->isEnabled, "%s: pool %zu slot %u is not the world's component", what, p, w);
+                const uint32_t entity = *global->entity;
+                const uint32_t transformSlot = entity && entity < emap.size() ? emap[entity] : GV_NONE;
+                const uint32_t localEntity = *local->entity;
+                if (!entity) {
+                    EXPECT(localEntity == 0, "%s: a free mesh slot with an entity", what);
+                } else if (transformSlot == GV_NONE) {
+                    EXPECT(localEntity < shares.shares[r].entityToTransform.size() && shares.shares[r].entityToTransform[localEntity] == GV_NONE,
+                           "%s: a mesh without a transform resolves to one on its rank", what);
+                } else {
+                    EXPECT(shares.rankOfTransform[transformSlot] == r && shares.shares[r].entityToTransform[localEntity] == shares.localOfTransform[transformSlot],
+                           "%s: pool %zu slot %u does not resolve to its entity's transform on rank %u", what, p, w, r);
+                }
+            }
+        }
+        for (uint32_t j = 0; j < meshPool.getOccupancy(); j++)
+            EXPECT(held[j] == 1, "%s: pool %zu slot %u is held %u times", what, p, j, held[j]);
+    }
+}
+
+int main()
+{
+    std::mt19937 rng(20261004u);
+    auto uniform = [&](float lo, float hi) { return lo + (hi - lo) * (float)(rng() >> 8) * (1.0f / 16777216.0f); };
+    for (uint32_t ranks : {1u, 2u, 3u, 8u}) {
+        Manager manager;
+        auto transformSystem = manager.createSystem<TransformSystem>();
+        manager.registerComponents<TransformComponent>(transformSystem);
+        auto opaque = manager.createSystem<OpaqueMeshSystem>();
+        manager.registerComponents<MeshRenderComponent>(opaque);
+        auto wide = manager.createSystem<WideMeshSystem>();
+        manager.registerComponents<WideMeshComponent>(wide);
+        manager.initialize();
+        const uint32_t n = 6000;
+        const double side = 100.0 * std::cbrt((double)n);
+        uint32_t grid[3] = {1, 1, 1};
+        for (uint32_t axis = 0; (uint64_t)grid[0] * grid[1] * grid[2] < 512ull * ranks; axis = (axis + 1) % 3)
+            grid[axis] *= 2;
+        std::vector<ID<Entity>> ents;
+        for (uint32_t i = 0; i < n; i++) {
+            auto e = manager.createEntity();
+            ents.push_back(e);
+            MeshRenderComponent* m = (i % 3 == 0) ? static_cast<MeshRenderComponent*>(*wide->add(e)) : *opaque->add(e);
+            m->aabb.min = f32x4(-1, -1, -1);
+            m->aabb.max = f32x4(uniform(0.1f, 2.0f), 1, 1);
+            if (i % 41 == 0)
+                continue;  // a mesh whose entity has no transform (mesh.cpp:149-153)
+            auto t = transformSystem->add(e);
+            t->setPosition(uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side));
+            t->setScale(1, 1, 1);
+            t->setRotation(quat(0, 0, 0, 1));
+        }
+        for (uint32_t i = n / 10; i < n; i++)  // depth ~4 trees
+            if (i % 41 != 0) {
+                uint32_t parent = rng() % (i / 4 + 1);
+                if (parent % 41 == 0)
+                    parent++;
+                if (parent != i && parent % 41 != 0 && transformSystem->tryGetOf(ents[parent]))
+                    transformSystem->setParent(ents[i], ents[parent]);
+            }
+        std::vector<IMeshRenderSystem*> meshSystems{opaque, wide};
+        RankShares shares;
+        shares.deal(transformSystem, meshSystems, ranks, grid, side);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "first deal");
+        // entities go (free slots once the frame has disposed of them), subtrees are re-parented, a few move: deal again
+        for (uint32_t i = 7; i < n; i += 13)
+            if (i % 41 != 0)
+                manager.destroy(ents[i]);
+        manager.update();
+        for (uint32_t i = n / 2; i < n; i += 29)
+            if (i % 41 != 0 && i % 13 != 7 && (i / 8) % 41 != 0 && (i / 8) % 13 != 7 && transformSystem->tryGetOf(ents[i]) && transformSystem->tryGetOf(ents[i / 8]))
+                transformSystem->setParent(ents[i], ents[i / 8]);
+        shares.deal(transformSystem, meshSystems, ranks, grid, side);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "after destruction and re-parenting");
+        // a transform moves (inside its cell or not: ownership is re-examined by the next deal only): its rank's copy follows
+        for (uint32_t i = 1; i < n; i += 97)
+            if (auto t = transformSystem->tryGetOf(ents[i])) {
+                t->setPosition(uniform(-10, 10), uniform(-10, 10), uniform(-10, 10));
+                const uint32_t slot = (uint32_t)(*t - transformSystem->getComponents().getData());
+                shares.copyTransform(transformSystem, slot);
+                const uint32_t rank = shares.rankOfTransform[slot];
+                EXPECT(rank != GV_NONE && std::memcmp(&shares.shares[rank].transforms[shares.localOfTransform[slot]].posChildCount, &t->posChildCount, 12) == 0,
+                       "copyTransform: slot %u", slot);
+            }
+    }
+    std::printf("{\"ok\": %s, \"failures\": %d}\n", failures ? "false" : "true", failures);
+    return failures ? 1 : 0;
+}

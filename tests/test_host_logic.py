@@ -476,6 +476,23 @@ def test_dirty_ranges_under_address_and_ub_sanitizers(tmp_path):
     assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr
 
 
+def test_rank_shares_under_address_and_ub_sanitizers(tmp_path):
+    """garden_amd/csrc/host/rank_shares.hpp — what each rank of the drop-in's multi-GPU mode (one process, N contexts) holds of the
+    engine's pools — on the CPU under -fsanitize=address,undefined (tests/cpp/rank_shares_test.cpp): hierarchies, free slots, meshes
+    without a transform, destroyed entities, re-parenting, 1 / 2 / 3 / 8 ranks: every transform on exactly one rank (the one
+    gv_cell_owner gives its root's position), parents co-located and renumbered, every mesh slot on exactly one rank."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "rank_shares_test")
+    lib_dir = os.path.join(root, "garden_amd", "lib")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wno-invalid-offsetof",
+                            "-fno-strict-aliasing", os.path.join(root, "tests/cpp/rank_shares_test.cpp"), "-o", exe, "-L" + lib_dir, "-lgarden_vis",
+                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and '"ok": true' in run.stdout, (run.stdout + run.stderr)[-3000:]
+
+
 def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     """The 2.8 k lines of host orchestration behind the C-ABI (garden_amd/csrc/gv_context.cpp, gv_results.cpp, gv_mirror.cpp, gv_exchange.cpp,
     + gv_scene.cpp, gv_workers.cpp) are otherwise only ever compiled as HIP. Here they are built as plain C++ against
