@@ -50,7 +50,8 @@ typedef struct GvCtx GvCtx;
 
 typedef struct GvConfig {
     uint32_t struct_size; /* = sizeof(GvConfig) */
-    int32_t device;       /* HIP device ordinal (one context per process per GPU) */
+    int32_t device;       /* HIP device ordinal: one context per GPU; the contexts of a node's GPUs may live in one process and be
+                             driven by one thread (gv_exchange_*_all) */
     uint32_t hiz_rule;    /* GvHizRule */
     uint32_t flags;       /* GvConfigFlags */
 } GvConfig;
