@@ -34,8 +34,24 @@ private:
     bool hasAnyRefr = false, hasAnyOIT = false, hasAnyTD = false;  // mesh.hpp:232-234
     std::vector<uint32_t> idx;
     std::vector<float> baked, dist;
+    // the build-defined per-AABB occlusion query (SURVEY.md 8a-7'; the reference has none): when a depth image has been handed
+    // over, the light pass of the non-UI systems runs it after the frustum test — the same rule the drop-in applies (GvView.use_hiz)
+    GvoHiz hiz{};
+    std::vector<float> hizDepth, hizMips;
+    bool useHiz = false;
 
 public:
+    // HizRenderSystem::downsampleHiz stand-in (hiz.cpp:104-167, hiz.frag:23-63): this frame's reversed-Z depth
+    void setHizDepth(const float* depth, uint32_t width, uint32_t height)
+    {
+        hizDepth.assign(depth, depth + (size_t)width * height);
+        const uint64_t pairs = gvo_hiz_layout(width, height, &hiz);
+        hizMips.assign((size_t)pairs * 2 + 2, 0.0f);
+        hiz.depth = hizDepth.data();
+        hiz.mips = hizMips.data();
+        gvo_hiz_build(&hiz, hizMips.data(), GVO_HIZ_RULE_REFERENCE);
+        useHiz = true;
+    }
     bool isEnabled = true;
     bool isNonTranslucent = false;  // mesh.hpp:275
     bool sortMeshesEnabled = true;  // mesh.cpp:548-551: prepareMeshes ends with sortMeshes()
@@ -95,18 +111,21 @@ private:
     // one prepareUnsortedMeshes / prepareSortedMeshes dispatch (mesh.cpp:111-262) through the oracle: the scalar loop over
     // the AoS pools, or (useAvx2) the 8-wide AVX2+FMA loop over an SoA copy of them, rebuilt per dispatch — the reference
     // build targets -march=haswell (cmake/compile-options.cmake:34-36); both give the same bits
-    GvoCullOut run(const GvoMeshPool& mp, const GvoTransformPool& tp, const GvoView& view)
+    GvoCullOut run(const GvoMeshPool& mp, const GvoTransformPool& tp, GvoView view)
     {
+        // occlusion queries: the camera's light pass only (UI and shadow views have no depth image of their own)
+        const GvoHiz* pyramid = useHiz && view.shadow_pass < 0 && !view.distance_2d ? &hiz : nullptr;
+        view.use_hiz = pyramid ? 1 : 0;
         const size_t n = mp.occupancy ? mp.occupancy : 1;
         idx.resize(n); baked.resize(n * 12); dist.resize(n);
         GvoCullOut out{idx.data(), baked.data(), dist.data(), 0, 0};
         if (useAvx2) {
             GvoSoa* soa = gvo_soa_build(&mp, &tp);
-            gvo_prepare_meshes_avx2(soa, &mp, &view, nullptr, threads, &out);
+            gvo_prepare_meshes_avx2(soa, &mp, &view, pyramid, threads, &out);
             gvo_soa_free(soa);
             // the AVX2 path reports records in slot order per thread range too: same contract as the scalar one
         } else {
-            gvo_prepare_meshes(&mp, &tp, &view, nullptr, threads, &out);
+            gvo_prepare_meshes(&mp, &tp, &view, pyramid, threads, &out);
         }
         return out;
     }

@@ -3,7 +3,7 @@
 // (oracle-backed, BASELINE.json configs[0]) or the GPU drop-in (GpuVisibilitySystem over libgarden_vis.so),
 // and, in `both` mode, a bit-for-bit comparison of what each leaves behind for the render phase.
 //
-//   headless_tick --mode cpu|gpu|both [--ranks R] [--gate never|shadow|reverse|empty] [--non-translucent] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
+//   headless_tick --mode cpu|gpu|both [--ranks R] [--gate never|shadow|reverse|empty] [--non-translucent] [--hiz] [--entities N] [--ticks T] [--threads K] [--hier] [--mutate] [--mixed] [--toggle] [--bounds] [--churn R] [--avx2] [--animate K] [--itemised] [--world] [--csm] [--soa-records] [--copy-records] [--span-records] [--seed S]
 // --mixed spreads the meshes over Opaque, OIT, two Translucent and one UI system and adds two shadow passes, so the
 // unsorted/sorted classification of prepareMeshes (mesh.cpp:341-546) and sortMeshes (mesh.cpp:265-328) are compared too.
 // --gate (with --mixed): the per-system gate of mesh.cpp:426 / :482 — `componentCount == 0 || !isDrawReady(shadowPass)`:
@@ -293,6 +293,8 @@ int main(int argc, char** argv)
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
+    bool hiz = false;        // --hiz: a depth image with walls is handed to both systems: the light pass of the non-UI systems runs the
+                             // per-AABB occlusion query behind the frustum test (with --ranks: the pyramid is built on every rank)
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
@@ -318,6 +320,7 @@ int main(int argc, char** argv)
         else if (a == "--csm") csmPasses = true;
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
         else if (a == "--non-translucent") g_nonTranslucent = true;
+        else if (a == "--hiz") hiz = true;
         else if (a == "--ranks" && i + 1 < argc) ranks = (uint32_t)atoi(argv[++i]);
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
@@ -545,6 +548,20 @@ int main(int argc, char** argv)
             passCount = cascades;
         }
 
+        if (hiz) {  // reversed-Z depth (1 = near, 0 = far): an empty background with a few walls at different depths, 480 x 272
+            const uint32_t dw = 480, dh = 272;
+            std::vector<float> depth((size_t)dw * dh, 0.0f);
+            Rng walls;
+            for (int k = 0; k < 24; k++) {
+                const uint32_t x0 = walls.next() % dw, y0 = walls.next() % dh, w = 20 + walls.next() % 120, h = 16 + walls.next() % 90;
+                const float d = walls.uniform(0.00002f, 0.002f);  // near / distance: walls 5 .. 500 units away (near plane 0.01)
+                for (uint32_t y = y0; y < std::min(dh, y0 + h); y++)
+                    for (uint32_t x = x0; x < std::min(dw, x0 + w); x++)
+                        depth[(size_t)y * dw + x] = std::max(depth[(size_t)y * dw + x], d);
+            }
+            if (cpu) cpu->setHizDepth(depth.data(), dw, dh);
+            if (gpu) gpu->setHizDepth(depth.data(), dw, dh);
+        }
         uint32_t animateTick = 0;
         auto run = [&](bool useCpu, bool useGpu, uint32_t n, bool moving = true) {
             if (cpu) cpu->isEnabled = useCpu;

@@ -139,6 +139,11 @@ def test_gpu_system_fails_loudly_without_device(tick):
     # the others get no buffer and keep the isVisible bytes the tick started from
     ["--entities", "30000", "--mixed", "--non-translucent", "--hier", "--mutate"],
     ["--entities", "20000", "--mixed", "--non-translucent", "--gate", "shadow", "--csm"],
+    # a depth image is handed over (setHizDepth, where HizRenderSystem::preHdrRender runs, hiz.cpp:170-174): the light pass of the
+    # non-UI systems runs the per-AABB occlusion query behind the frustum test; shadow passes and the UI pass do not
+    ["--entities", "60000", "--hiz"],
+    ["--entities", "40000", "--hiz", "--mixed", "--hier", "--mutate"],
+    ["--entities", "30000", "--hiz", "--mixed", "--csm", "--animate", "4", "--ticks", "4", "--span-records"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
@@ -155,6 +160,7 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "20000", "--ranks", "3", "--mixed", "--hier", "--churn", "3"],
     ["--entities", "60000", "--ranks", "8", "--csm"],
     ["--entities", "20000", "--ranks", "2", "--mixed", "--gate", "never", "--toggle", "--hier"],
+    ["--entities", "50000", "--ranks", "4", "--hiz", "--mixed", "--hier"],  # the pyramid is built on every rank
 ])
 def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
     """The drop-in's own multi-GPU mode — ONE process, ONE thread, N contexts (the reference is one process with one Manager,
