@@ -1407,8 +1407,7 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     // i): the gathers of round k + 1 are issued before round k's records go through LDS and out, so that a round waits for its
     // stores and the next round's loads together instead of one after the other (a quarter of a full chunk is four rounds). Same-box A/B: emit 53.5 -> 51.2 us at 2.6 M records, 45.3 -> 43.8 us at 2.06 M (a barrier that
     // orders LDS only, so that the gathers fly across it, measured the same).
-    const bool keys_only = args.direct_stores == 2u;  // experiment (profiles/withdrawn.md 39): slot + distance key only, no model
-    const bool pipelined = GV_EMIT_PIPELINED && !use_seed && !args.world && (!args.direct_stores || keys_only) && args.xf.max_depth == 0 &&
+    const bool pipelined = GV_EMIT_PIPELINED && !use_seed && !args.world && !args.direct_stores && args.xf.max_depth == 0 &&
                            args.mesh.mapping == kMapExact;  // uniform
     if (pipelined) {
         uint32_t r0 = prefix[wlo];
@@ -1418,10 +1417,8 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
         if (r0 + threadIdx.x < total) {
             i_cur = entry_of(r0 + threadIdx.x);
             a_cur = args.xf.ab[i_cur].a;
-            if (!keys_only) {
-                b_cur = args.xf.ab[i_cur].b;
-                c_cur = args.xf.c[i_cur];
-            }
+            b_cur = args.xf.ab[i_cur].b;
+            c_cur = args.xf.c[i_cur];
             orig_cur = args.mesh.orig ? args.mesh.orig[i_cur] : i_cur;
         }
         for (; r0 < total; r0 += 256) {
@@ -1431,22 +1428,9 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             if (r0 + 256u + threadIdx.x < total) {
                 i_nxt = entry_of(r0 + 256u + threadIdx.x);
                 a_nxt = args.xf.ab[i_nxt].a;
-                if (!keys_only) {
-                    b_nxt = args.xf.ab[i_nxt].b;
-                    c_nxt = args.xf.c[i_nxt];
-                }
+                b_nxt = args.xf.ab[i_nxt].b;
+                c_nxt = args.xf.c[i_nxt];
                 orig_nxt = args.mesh.orig ? args.mesh.orig[i_nxt] : i_nxt;
-            }
-            if (keys_only) {  // (the distance key needs the translation only: position - camera)
-                if (i_cur != 0xFFFFFFFFu) {
-                    Mat34 m = {};
-                    m.c3x = a_cur.x - args.view.cam[0], m.c3y = a_cur.y - args.view.cam[1], m.c3z = a_cur.z - args.view.cam[2];
-                    const size_t rank = (size_t)base + r0 + threadIdx.x;
-                    args.out.visible_idx[rank] = orig_cur;
-                    args.out.distance_sq[rank] = record_distance(args, m);
-                }
-                i_cur = i_nxt, orig_cur = orig_nxt, a_cur = a_nxt;
-                continue;
             }
             if (i_cur != 0xFFFFFFFFu) {
                 XfRecord rec;
@@ -1604,7 +1588,7 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     EmitArgs a;
     a.world = world;
     a.seeds = seeds;
-    static const uint32_t direct = getenv("GV_DEBUG_EMIT_KEYS_ONLY") ? 2u : getenv("GV_DEBUG_EMIT_DIRECT_STORES") ? 1u : 0u;
+    static const uint32_t direct = getenv("GV_DEBUG_EMIT_DIRECT_STORES") ? 1u : 0u;
     a.direct_stores = direct;
     a.mesh = mesh;
     a.xf = xf;
