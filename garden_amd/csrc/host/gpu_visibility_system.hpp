@@ -90,6 +90,9 @@ public:
     };
 
     bool isEnabled = true;
+    // HizRenderSystem::isEnabled (hiz.cpp:107-115): a disabled system clears its pyramid to zero — farthest everywhere, nothing is
+    // occluded; here the light pass simply runs without the occlusion query while this is false (the same visible set)
+    bool isHizEnabled = true;
     bool isNonTranslucent = false;  // mesh.hpp:275 "Render only non translucent meshes": prepareSystems keeps Color / Opaque / UI systems (mesh.cpp:89-101)
     // true: records arrive as UnsortedMesh / SortedMesh structs (gv_pool_set_record_layout), combinedMeshes is one memcpy
     bool recordStructs = true;
@@ -509,7 +512,7 @@ private:
                 if (renderType == MeshRenderType::UI)
                     views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
                 else
-                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
+                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz && isHizEnabled, emitRecords));
                 passes.push_back(-1);
                 if (!sorted) {  // mesh.cpp:488-490
                     hasAnyRefr |= renderType == MeshRenderType::Refracted;
@@ -811,7 +814,7 @@ private:
                 if (renderType == MeshRenderType::UI)
                     views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
                 else
-                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz, emitRecords));
+                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz && isHizEnabled, emitRecords));
                 passes.push_back(-1);
                 if (!sorted) {
                     hasAnyRefr |= renderType == MeshRenderType::Refracted;
