@@ -666,6 +666,10 @@ private:
             if (versioned)
                 versioned->clearMeshRange();
         }
+        // a slot that was freed and handed to another entity since the deal (same occupancy, same count) is structural too
+        if (!structural && seenFlags != transformSystem->flagsVersion)
+            for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi && !structural; i++)
+                structural = !rankShares.sameEntity(transformSystem, i);
         ranksSeen.hierarchy = transformSystem->hierarchyVersion;
         ranksSeen.reparent = transformSystem->reparentVersion;
         ranksSeen.transformOccupancy = pool.getOccupancy();

@@ -35,6 +35,13 @@ struct RankShares {
     };
     std::vector<Share> shares;
     std::vector<uint32_t> rankOfTransform, localOfTransform;  // world transform slot -> rank, local slot (GV_NONE: a free slot)
+    std::vector<uint32_t> entityOfTransform;                  // world transform slot -> the entity it held when the pools were dealt
+
+    // true: slot still holds the entity it was dealt with (a slot that was freed and handed to another entity since must be dealt again)
+    bool sameEntity(const TransformSystem* ts, uint32_t worldSlot) const noexcept
+    {
+        return worldSlot < entityOfTransform.size() && entityOfTransform[worldSlot] == *worldTransform(ts, worldSlot)->entity;
+    }
 
     static const TransformComponent* worldTransform(const TransformSystem* ts, uint32_t slot) noexcept
     {
@@ -98,6 +105,9 @@ struct RankShares {
         shares.assign(ranks, Share{});
         rankOfTransform.assign(occupancy, GV_NONE);
         localOfTransform.assign(occupancy, GV_NONE);
+        entityOfTransform.assign(occupancy, 0u);
+        for (uint32_t i = 0; i < occupancy; i++)
+            entityOfTransform[i] = *world[i].entity;
         for (uint32_t i = 0; i < occupancy; i++) {
             if (!*world[i].entity)
                 continue;
