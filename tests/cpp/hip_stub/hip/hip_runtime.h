@@ -7,6 +7,7 @@
 // without a gfx950 device.
 #pragma once
 #define GV_HIP_STUB 1
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -38,13 +39,20 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 
 // Fault injection (tests/cpp/host_orchestration_test.cpp::allocation_failures): when the countdown reaches 1 the allocation it
 // lands on fails with hipErrorOutOfMemory (once). 0: never. One counter for every translation unit of the stub build.
-inline long& gv_stub_fail_countdown() { static long countdown = 0; return countdown; }
-inline long& gv_stub_allocations() { static long count = 0; return count; }
+// (atomics: the exchange tests allocate from several rank threads at once; the countdown itself is only armed by single-threaded tests)
+struct GvStubCounter {
+    std::atomic<long> value{0};
+    GvStubCounter& operator=(long v) { value.store(v, std::memory_order_relaxed); return *this; }
+    operator long() const { return value.load(std::memory_order_relaxed); }
+    long operator++(int) { return value.fetch_add(1, std::memory_order_relaxed); }
+};
+inline GvStubCounter& gv_stub_fail_countdown() { static GvStubCounter countdown; return countdown; }
+inline GvStubCounter& gv_stub_allocations() { static GvStubCounter count; return count; }
 static inline bool gv_stub_allocation_fails()
 {
     gv_stub_allocations()++;
-    long& c = gv_stub_fail_countdown();
-    return c > 0 && --c == 0;
+    std::atomic<long>& c = gv_stub_fail_countdown().value;
+    return c.load(std::memory_order_relaxed) > 0 && c.fetch_sub(1, std::memory_order_relaxed) == 1;
 }
 static inline hipError_t hipMalloc(void** p, size_t n)
 {

@@ -476,6 +476,45 @@ def test_dirty_ranges_under_address_and_ub_sanitizers(tmp_path):
     assert run.returncode == 0 and '"ok": true' in run.stdout, run.stdout + run.stderr
 
 
+def test_host_orchestration_and_exchange_under_thread_sanitizer(tmp_path):
+    """The same host build (tests/cpp/hip_stub) and the same driver under -fsanitize=thread: the exchange with one context per rank
+    THREAD (1 / 2 / 3 / 8 ranks, 24 random list sequences) and with ONE thread driving 1-4 contexts over tests/cpp/rccl_stub's worker
+    threads, the host worker pool, the frame sequences — libgarden_vis keeps no unsynchronised state between contexts (the
+    process-wide pieces are the RCCL binding, made once, and the worker pool behind its lock). Zero reports."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    csrc, stub = os.path.join(root, "garden_amd", "csrc"), os.path.join(root, "tests", "cpp", "hip_stub")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    stubs = tmp_path / "kernel_stubs.cpp"
+    gen = subprocess.run([sys.executable, os.path.join(stub, "make_kernel_stubs.py"), csrc], capture_output=True, text=True)
+    assert gen.returncode == 0, gen.stderr
+    stubs.write_text(gen.stdout)
+    flags = ["-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + stub, "-I" + csrc]
+    sources = [str(stubs), os.path.join(stub, "reorder_cpu.cpp"), os.path.join(stub, "exchange_cpu.cpp"),
+               os.path.join(root, "tests", "cpp", "host_orchestration_test.cpp")] + \
+              [os.path.join(csrc, f) for f in ("gv_context.cpp", "gv_results.cpp", "gv_mirror.cpp", "gv_exchange.cpp", "gv_scene.cpp", "gv_workers.cpp")]
+    builds, objects = [], []
+    for src in sources:
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        objects.append(obj)
+        builds.append(subprocess.Popen([clang, *flags, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for b in builds:
+        out, _ = b.communicate(timeout=900)
+        assert b.returncode == 0, out[-3000:]
+    exe = str(tmp_path / "host_orchestration_test_tsan")
+    link = subprocess.run([clang, "-fsanitize=thread", *objects, "-o", exe, "-lpthread", "-ldl"], capture_output=True, text=True)
+    assert link.returncode == 0, link.stderr[-3000:]
+    transport = str(tmp_path / "librccl_stub_tsan.so")
+    tb = subprocess.run([clang, *flags, "-fPIC", "-shared", os.path.join(root, "tests", "cpp", "rccl_stub", "rccl_stub.cpp"), "-o", transport,
+                         "-lrt", "-lpthread"], capture_output=True, text=True)
+    assert tb.returncode == 0, tb.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, GV_RCCL_LIBRARY=transport, TSAN_OPTIONS="halt_on_error=0"))
+    text = run.stdout + run.stderr
+    assert run.returncode == 0 and "host orchestration: ok" in run.stdout and "ThreadSanitizer" not in text, text[-4000:]
+    assert run.stdout.count("exchange over the stub transport") == 4 + 24 and run.stdout.count("exchange driven by ONE thread") == 3 + 6
+
+
 def test_rank_shares_under_address_and_ub_sanitizers(tmp_path):
     """garden_amd/csrc/host/rank_shares.hpp — what each rank of the drop-in's multi-GPU mode (one process, N contexts) holds of the
     engine's pools — on the CPU under -fsanitize=address,undefined (tests/cpp/rank_shares_test.cpp): hierarchies, free slots, meshes
