@@ -493,6 +493,7 @@ int flush_sorts(GvCtx* ctx);                             // flush_culls + the so
 int wait_for_stream(GvCtx* ctx);                         // until the stream has drained (a polled word; hipStreamSynchronize as fallback)
 ViewState* view_of(GvCtx* ctx, uint32_t pool_id, uint32_t view_index);  // NULL: no valid results
 bool release_record_target(PoolState::RecordTarget& target);            // false: the range was found unmapped
+int copy_shard_of_pool(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* dst_device, uint32_t capacity, uint32_t index_base);
 
 // gv_mirror.cpp
 int sync_mirror(GvCtx* ctx);                 // brings the device mirror up to date with the bound pools + dirty ranges

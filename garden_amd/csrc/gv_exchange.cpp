@@ -616,13 +616,15 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
 }
 
 // A new frame, step 1 of 3: buffers, and this rank's whole list into the slot's staging shard on the context's stream.
-int frame_stage(GvCtx* ctx, uint32_t view_index, uint32_t index_base, Slot& slot)
+int frame_stage(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t index_base, Slot& slot)
 {
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const int me = ctx->exchange_rank, world = ctx->exchange_world;
-    gv::ViewState* vs = gv::view_of(ctx, ctx->last_pool, view_index);
+    if (pool_id == GV_NONE)
+        pool_id = ctx->last_pool;  // the view-indexed forms address the pool of the most recent gv_cull
+    gv::ViewState* vs = pool_id < GV_MAX_POOLS ? gv::view_of(ctx, pool_id, view_index) : nullptr;
     if (!vs || !vs->emitted)
-        return ctx->fail(GV_E_ARG, "gv_exchange_visible: view %u has no emitted records", view_index);
+        return ctx->fail(GV_E_ARG, "gv_exchange_visible: pool %u view %u has no emitted records", pool_id, view_index);
     uint32_t widest = 0;
     for (int k = 0; k < world; k++)
         widest = std::max(widest, ctx->exchange_room[k]);
@@ -658,7 +660,7 @@ int frame_stage(GvCtx* ctx, uint32_t view_index, uint32_t index_base, Slot& slot
     // The next frame's pyramid and cull go on behind the shard copy at once, while this list is still travelling. (The slot's shard
     // and rows are free: the frame that used them last is settled, which its collectives precede; and work that was enqueued on the
     // context's stream to CONSUME those rows completes in front of `produced`, which the exchange stream waits for.)
-    if (int rc = gv_results_copy_shard_device(ctx, view_index, slot.shard.ptr, vs->occupancy, index_base))
+    if (int rc = gv::copy_shard_of_pool(ctx, pool_id, view_index, slot.shard.ptr, vs->occupancy, index_base))
         return rc;
     GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));
     GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, slot.produced, 0));
@@ -716,7 +718,7 @@ int frame_finish(GvCtx* ctx, Slot& slot, GvExchangeFrame* out)
     return GV_OK;
 }
 
-int visible_all(GvCtx* const* ctxs, int n, const uint32_t* views, const uint32_t* bases, GvExchangeFrame* outs, bool by_group)
+int visible_all(GvCtx* const* ctxs, int n, uint32_t pool_id, const uint32_t* views, const uint32_t* bases, GvExchangeFrame* outs, bool by_group)
 {
     Rccl& r = rccl();
     const uint64_t frame = ctxs[0]->exchange_frame;
@@ -737,7 +739,7 @@ int visible_all(GvCtx* const* ctxs, int n, const uint32_t* views, const uint32_t
             return rc;
     const unsigned which = (unsigned)(frame & 1u);
     for (int k = 0; k < n; k++)
-        if (int rc = frame_stage(ctxs[k], views[k], bases ? bases[k] : 0u, ctxs[k]->exchange_slots[which]))
+        if (int rc = frame_stage(ctxs[k], pool_id, views[k], bases ? bases[k] : 0u, ctxs[k]->exchange_slots[which]))
             return rc;
     int rc = GV_OK;
     (void)r.GroupStart();
@@ -834,7 +836,16 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
         return GV_E_ARG;
     if (!out || flags)
         return ctx->fail(GV_E_ARG, "gv_exchange_visible: NULL frame or flags 0x%x (none are defined)", flags);
-    return visible_all(&ctx, 1, &view_index, &index_base, out, false);
+    return visible_all(&ctx, 1, GV_NONE, &view_index, &index_base, out, false);
+}
+
+int gv_pool_exchange_visible(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (!out || flags || pool_id >= GV_MAX_POOLS)
+        return ctx->fail(GV_E_ARG, "gv_pool_exchange_visible: NULL frame, flags 0x%x (none are defined) or pool %u", flags, pool_id);
+    return visible_all(&ctx, 1, pool_id, &view_index, &index_base, out, false);
 }
 
 int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32_t* view_indices, const uint32_t* index_bases, uint32_t flags,
@@ -844,7 +855,17 @@ int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32
         return rc;
     if (!view_indices || !frames || flags)
         return contexts[0]->fail(GV_E_ARG, "gv_exchange_visible_all: NULL view indices / frames, or flags 0x%x (none are defined)", flags);
-    return visible_all(contexts, world_size, view_indices, index_bases, frames, true);
+    return visible_all(contexts, world_size, GV_NONE, view_indices, index_bases, frames, true);
+}
+
+int gv_pool_exchange_visible_all(GvCtx* const* contexts, int world_size, uint32_t pool_id, const uint32_t* view_indices, const uint32_t* index_bases,
+                                 uint32_t flags, GvExchangeFrame* frames)
+{
+    if (int rc = all_args(contexts, world_size))
+        return rc;
+    if (!view_indices || !frames || flags || pool_id >= GV_MAX_POOLS)
+        return contexts[0]->fail(GV_E_ARG, "gv_pool_exchange_visible_all: NULL view indices / frames, flags 0x%x (none are defined) or pool %u", flags, pool_id);
+    return visible_all(contexts, world_size, pool_id, view_indices, index_bases, frames, true);
 }
 
 int gv_exchange_acquire(GvCtx* ctx, uint64_t frame, GvExchangeFrame* out)

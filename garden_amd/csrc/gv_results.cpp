@@ -734,16 +734,7 @@ int gv_results_copy_shard_device(GvCtx* ctx, uint32_t view_index, void* dst_devi
 {
     if (!ctx)
         return GV_E_ARG;
-    if (!dst_device || !view_of(ctx, ctx->last_pool, view_index) || !view_of(ctx, ctx->last_pool, view_index)->emitted)
-        return ctx->fail(GV_E_ARG, "gv_results_copy_shard_device: view %u has no emitted records", view_index);
-    if (int rc = flush_sorts(ctx))
-        return rc;
-    ViewState& vs = *view_of(ctx, ctx->last_pool, view_index);
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    const PoolState& pool = ctx->pools[vs.pool_id];
-    GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
-                                  index_base, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr, ctx->stream));
-    return GV_OK;
+    return gv::copy_shard_of_pool(ctx, ctx->last_pool, view_index, dst_device, capacity, index_base);
 }
 
 int gv_results_copy_mask_device(GvCtx* ctx, uint32_t view_index, void* dst_device, uint32_t word_count)
@@ -838,3 +829,23 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
 }
 
 }  // extern "C"
+
+namespace gv {
+
+// (pool, view)'s shard [draw_count, visible_idx + index_base ...] into dst_device: gv_results_copy_shard_device for the pool of the most
+// recent cull, the exchange for the pool it is asked for (several mesh systems culled in one batch, each exchanged afterwards)
+int copy_shard_of_pool(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* dst_device, uint32_t capacity, uint32_t index_base)
+{
+    if (!dst_device || !view_of(ctx, pool_id, view_index) || !view_of(ctx, pool_id, view_index)->emitted)
+        return ctx->fail(GV_E_ARG, "exchange shard: pool %u view %u has no emitted records", pool_id, view_index);
+    if (int rc = flush_sorts(ctx))
+        return rc;
+    ViewState& vs = *view_of(ctx, pool_id, view_index);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const PoolState& pool = ctx->pools[vs.pool_id];
+    GV_HIP(ctx, launch_copy_shard(vs.visible_idx.ptr, vs.draw_count.ptr, static_cast<uint32_t*>(dst_device), capacity,
+                                  index_base, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr, ctx->stream));
+    return GV_OK;
+}
+
+}  // namespace gv

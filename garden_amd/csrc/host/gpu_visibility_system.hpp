@@ -848,7 +848,7 @@ private:
             if (emitRecords)
                 for (uint32_t v = 0; v < views.size(); v++) {
                     std::fill(viewIndices.begin(), viewIndices.end(), v);
-                    check(gv_exchange_visible_all(contexts.data(), (int)ranks, viewIndices.data(), nullptr, 0, frames.data()), "gv_exchange_visible_all");
+                    check(gv_pool_exchange_visible_all(contexts.data(), (int)ranks, p, viewIndices.data(), nullptr, 0, frames.data()), "gv_pool_exchange_visible_all");
                     check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
                     if (onGathered)
                         onGathered(p, passes[v], frames.data(), ranks);

@@ -122,7 +122,7 @@ EXPORTS = [
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_pool_exchange_visible", "gv_pool_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -205,6 +205,8 @@ def load():
     lib.gv_exchange_acquire.argtypes = [P, C.c_uint64, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_init_all.argtypes = [C.POINTER(P), C.c_int]
     lib.gv_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_pool_exchange_visible.argtypes = [P, u32, u32, u32, u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_pool_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, u32, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_acquire_all.argtypes = [C.POINTER(P), C.c_int, C.c_uint64, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_set_timeout.argtypes = [P, u32]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
@@ -509,11 +511,15 @@ class GpuVisibility:
                     counts=[int(f.counts[r]) for r in range(w)], tail_words=[int(f.tail_words[r]) for r in range(w)],
                     cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1], mode=int(f.mode), ready_event=f.ready_event)
 
-    def exchange_visible(self, view_index=0, index_base=0):
-        """Sends the frame (gv_exchange_visible): library-owned rows, sized from the previous frame's headers. Returns a dict:
-        frame, row_words, world, room, travelled_words, mode — the rows themselves are handed out by exchange_acquire."""
+    def exchange_visible(self, view_index=0, index_base=0, pool_id=None):
+        """Sends the frame (gv_exchange_visible; pool_id: gv_pool_exchange_visible for a named pool): library-owned rows, sized from
+        the previous frame's headers. Returns a dict: frame, row_words, world, room, travelled_words, mode — the rows themselves are
+        handed out by exchange_acquire."""
         f = GvExchangeFrame()
-        self._check(self.lib.gv_exchange_visible(self.ctx, view_index, index_base, 0, C.byref(f)))
+        if pool_id is None:
+            self._check(self.lib.gv_exchange_visible(self.ctx, view_index, index_base, 0, C.byref(f)))
+        else:
+            self._check(self.lib.gv_pool_exchange_visible(self.ctx, pool_id, view_index, index_base, 0, C.byref(f)))
         return self._exchange_frame(f)
 
     def exchange_acquire(self, frame):

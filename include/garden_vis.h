@@ -389,6 +389,11 @@ int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, ui
 /* view_index / index_base: [world_size] (index_bases NULL: all 0); frames: [world_size] outputs. */
 int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32_t* view_indices, const uint32_t* index_bases,
                             uint32_t flags, GvExchangeFrame* frames);
+/* The same for a pool that is named (the view-indexed forms above address the pool of the most recent gv_cull): a frame that culls
+ * several mesh systems first — gv_cull_batch_begin — exchanges each system's views afterwards. pool_id is the same on every rank. */
+int gv_pool_exchange_visible(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
+int gv_pool_exchange_visible_all(GvCtx* const* contexts, int world_size, uint32_t pool_id, const uint32_t* view_indices,
+                                 const uint32_t* index_bases, uint32_t flags, GvExchangeFrame* frames);
 /* Settles frame `frame` (one of the last two) if that has not happened yet — waits for its headers on the host, completes cut rows —
  * makes gv_stream(ctx) wait for the complete rows and fills *out (NULL: not wanted). Every rank acquires, or none does: the
  * completing exchange is a collective (ranks that skip it meet it inside their next gv_exchange_visible). */

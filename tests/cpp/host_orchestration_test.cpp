@@ -573,6 +573,18 @@ struct ExchangeRank {
         for (uint32_t k = 0; k < mine; k++)
             ((uint32_t*)dr.visible_idx)[k] = list_value(rank, frame, k);
     }
+    // another mesh system culled AFTER the list was produced (gv_results_device and the view-indexed exchange now address pool 1)
+    static constexpr uint32_t other_count = 7;
+    void cull_other_pool()
+    {
+        GvView v = make_view(-1, 0, 1);
+        CHECK(gv_cull(ctx, 1, &v, 1));
+        GvDeviceResult dr{};
+        CHECK(gv_results_device(ctx, 0, &dr));
+        *(uint32_t*)dr.draw_count = other_count;
+        for (uint32_t k = 0; k < other_count; k++)
+            ((uint32_t*)dr.visible_idx)[k] = 4200u + (uint32_t)rank + k;
+    }
     void check_sent(const GvExchangeFrame& xf, int frame, uint32_t mode)
     {
         if (xf.world_size != (uint32_t)ranks || xf.frame != (uint64_t)frame || xf.mode != mode || xf.complete || xf.gathered_device || xf.ready_event)
@@ -799,6 +811,42 @@ static void exchange_in_one_thread(int ranks, int list_seed)
             for (int r = 0; r < ranks; r++)
                 xs[r].check_acquired(sent[r], got[r], frame);
         }
+    }
+    // several mesh systems per frame: pool 0's list is exchanged AFTER pool 1 was culled (gv_pool_exchange_visible_all names the
+    // pool; the view-indexed form then carries pool 1's list, the pool of the most recent cull)
+    for (int frame = 12; frame < 14; frame++) {
+        for (int r = 0; r < ranks; r++) {
+            xs[r].produce(frame, GV_EXCHANGE_P2P);
+            xs[r].cull_other_pool();
+        }
+        if (frame == 12) {
+            CHECK(gv_pool_exchange_visible_all(ctxs.data(), ranks, 0, views.data(), nullptr, 0, sent.data()));
+            CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+            for (int r = 0; r < ranks; r++)
+                xs[r].check_acquired(sent[r], got[r], frame);
+        } else {
+            CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+            CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+            for (int r = 0; r < ranks; r++) {
+                const uint32_t* rows = (const uint32_t*)got[r].gathered_device;
+                for (int q = 0; q < ranks; q++) {
+                    const uint32_t* row = rows + (size_t)q * got[r].row_words;
+                    if (!got[r].complete || row[0] != ExchangeRank::other_count || row[1] != 4200u + (uint32_t)q || row[ExchangeRank::other_count] != 4200u + (uint32_t)q + ExchangeRank::other_count - 1)
+                        xs[r].fail("the view-indexed exchange after a cull of pool 1 does not carry pool 1's list", frame, q);
+                }
+            }
+        }
+    }
+    EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, GV_MAX_POOLS, views.data(), nullptr, 0, sent.data()), GV_E_ARG);
+    EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, 0, views.data(), nullptr, 2, sent.data()), GV_E_ARG);
+    EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, 5, views.data(), nullptr, 0, sent.data()), GV_E_ARG);  // a pool never bound / culled
+    if (ranks == 1) {
+        xs[0].produce(14, GV_EXCHANGE_P2P);
+        xs[0].cull_other_pool();
+        CHECK(gv_pool_exchange_visible(ctxs[0], 0, 0, 0, 0, &sent[0]));
+        CHECK(gv_exchange_acquire(ctxs[0], 14, &got[0]));
+        xs[0].check_acquired(sent[0], got[0], 14);
+        EXPECT(gv_pool_exchange_visible(ctxs[0], GV_MAX_POOLS, 0, 0, 0, &sent[0]), GV_E_ARG);
     }
     int failures = 0;
     for (int r = 0; r < ranks; r++) {
