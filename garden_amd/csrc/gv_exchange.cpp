@@ -1,9 +1,9 @@
 // gv_exchange.cpp — the multi-GPU exchange step of SURVEY.md §8e in the C-ABI, for hosts without torch.distributed
-// (a C++ engine, one process per GPU): every rank's compact visible list goes out as a fixed-capacity shard
-// [draw_count, global indices ...] and all ranks gather the shards with ONE equal-size ncclAllGather enqueued on the
-// library's exchange stream (every operation of the communicator goes on that one stream, ordered against the context's stream
-// by events) — no host synchronisation; counts are read from the shard headers. Same wire format as
-// garden_amd/multi.py::VisibleListExchange (the torch.distributed variant in bench.py).
+// (a C++ engine: one process per GPU, or one process whose one thread drives N contexts): every rank's compact visible list goes
+// out as a shard [draw_count, global indices ...] and all ranks gather the shards into rows on the library's exchange stream (every
+// operation of the communicator goes on that one stream, ordered against the context's stream by events). Counts are read from
+// the row headers (pinned host words written behind the rows): in the steady state the host waits for nothing but the PREVIOUS
+// frame's header words, which size the next frame's rows.
 // The node's xGMI fabric is fully connected point to point, and a ring all-gather serialises world-1 hops over it, so
 // two direct patterns sit beside the all-gather for an A/B on real hardware (gv_exchange_set_mode, or the environment
 // variable GV_EXCHANGE_MODE = allgather | p2p | broadcast read at gv_exchange_init): one ncclGroup of send/recv pairs
@@ -99,6 +99,62 @@ Rccl& rccl()
 
 constexpr int kNcclUint32 = 3;  // ncclUint32 (rccl.h: ncclDataType_t)
 
+// The communicator can no longer be trusted (a wait ran out, or RCCL reported an asynchronous error): a collective that will never
+// finish must not keep the device — and with it every hipFree / synchronise of the process — waiting, so it is aborted on the spot.
+int give_up(GvCtx* ctx, int code, const char* text)
+{
+    ctx->exchange_broken = true;
+    Rccl& r = rccl();
+    if (r.CommAbort && ctx->exchange_comm) {
+        (void)r.CommAbort(ctx->exchange_comm);
+        ctx->exchange_comm = nullptr;
+    }
+    ctx->error = text;
+    return code;
+}
+
+// what RCCL has to say about the collectives already enqueued (ncclCommGetAsyncError: a peer that died, a transport error)
+int async_error(GvCtx* ctx)
+{
+    Rccl& r = rccl();
+    int async = 0;
+    if (!r.CommGetAsyncError || !ctx->exchange_comm || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
+        return 0;
+    return async == 7 ? 0 : async;  // (ncclInProgress, rccl.h: a non-blocking communicator still at work — not an error)
+}
+
+// Waits — bounded, like every wait of the exchange — until everything queued on the exchange stream has run: what stands in front of
+// a shutdown, a re-init or gv_destroy. A frame that was sent and never acquired may sit behind a peer that has left; synchronising
+// the stream would then never return.
+int drain_exchange_stream(GvCtx* ctx)
+{
+    if (!ctx->exchange_stream || ctx->exchange_broken)
+        return GV_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    char text[384];
+    for (;;) {
+        const hipError_t e = hipStreamQuery(ctx->exchange_stream);
+        if (e == hipSuccess)
+            return GV_OK;
+        if (e != hipErrorNotReady)
+            return ctx->hip_fail(e, "gv_exchange: draining the exchange stream");
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(ctx->exchange_timeout_ms)) {
+            snprintf(text, sizeof(text), "exchange: the collectives still queued did not finish within %u ms (a frame that was sent and never acquired, "
+                     "behind a peer rank that stalled or left); the communicator has been aborted", ctx->exchange_timeout_ms);
+            return give_up(ctx, GV_E_TIMEOUT, text);
+        }
+        if (waited > std::chrono::milliseconds(2)) {
+            if (const int async = async_error(ctx)) {
+                snprintf(text, sizeof(text), "exchange: RCCL reports an asynchronous error behind the collectives still queued: %s; the communicator has been aborted",
+                         rccl().GetErrorString(async));
+                return give_up(ctx, GV_E_RCCL, text);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+}
+
 }  // namespace
 
 namespace gv {
@@ -107,8 +163,7 @@ void exchange_release(GvCtx* ctx)
 {
     // what is still queued on the exchange stream goes first: gv_stream never waits for a frame's collective, so the communicator
     // would otherwise be destroyed under a queued all-gather. (After a timeout the stream may never drain: abort instead.)
-    if (ctx->exchange_stream && !ctx->exchange_broken)
-        (void)hipStreamSynchronize(ctx->exchange_stream);
+    (void)drain_exchange_stream(ctx);  // (bounded: a timeout marks the communicator broken, and it is aborted below)
     bool hung = false;  // a collective that will never finish and cannot be aborted: its stream is left alone (and leaked)
     if (ctx->exchange_comm) {
         Rccl& r = rccl();
@@ -418,30 +473,6 @@ uint32_t room_for(uint32_t count)
 size_t row_words_for(uint32_t entries)
 {
     return ((size_t)entries + 1u + 3u) & ~(size_t)3u;
-}
-
-// The communicator can no longer be trusted (a wait ran out, or RCCL reported an asynchronous error): a collective that will never
-// finish must not keep the device — and with it every hipFree / synchronise of the process — waiting, so it is aborted on the spot.
-int give_up(GvCtx* ctx, int code, const char* text)
-{
-    ctx->exchange_broken = true;
-    Rccl& r = rccl();
-    if (r.CommAbort && ctx->exchange_comm) {
-        (void)r.CommAbort(ctx->exchange_comm);
-        ctx->exchange_comm = nullptr;
-    }
-    ctx->error = text;
-    return code;
-}
-
-// what RCCL has to say about the collectives already enqueued (ncclCommGetAsyncError: a peer that died, a transport error)
-int async_error(GvCtx* ctx)
-{
-    Rccl& r = rccl();
-    int async = 0;
-    if (!r.CommGetAsyncError || !ctx->exchange_comm || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
-        return 0;
-    return async == 7 ? 0 : async;  // (ncclInProgress, rccl.h: a non-blocking communicator still at work — not an error)
 }
 
 // Waits until the headers of `slot`'s frame are on the host (written by exchange_headers_kernel behind the frame's collective).
@@ -907,13 +938,16 @@ int gv_exchange_shutdown(GvCtx* ctx)
     if (!ctx)
         return GV_E_ARG;
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->exchange_broken) {
+    // the exchange stream first, with the bounded wait (gv_stream may be waiting for a frame's rows behind it); GV_E_TIMEOUT /
+    // GV_E_RCCL: the communicator was aborted instead of drained — everything is released all the same
+    const int rc = drain_exchange_stream(ctx);
+    const std::string why = ctx->error;
+    if (rc == GV_OK)
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->exchange_stream)
-            GV_HIP(ctx, hipStreamSynchronize(ctx->exchange_stream));
-    }
     gv::exchange_release(ctx);
-    return GV_OK;
+    if (rc != GV_OK)
+        ctx->error = why;
+    return rc;
 }
 
 }  // extern "C"

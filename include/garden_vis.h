@@ -418,6 +418,9 @@ int gv_exchange_shards(GvCtx* ctx, uint32_t view_index, uint32_t capacity, const
  * mirror entry] (word_count + 1 uint32 per row; word_count the same on every rank, >= ceil(occupancy / 32) of the largest
  * pool). A fixed size whatever the view — the encoding for dense views (1/32 word per entry). */
 int gv_exchange_masks(GvCtx* ctx, uint32_t view_index, uint32_t word_count, void* gathered_device);
+/* Drains what is still queued (the same bounded wait: a frame that was sent and never acquired may sit behind a peer that has left —
+ * GV_E_TIMEOUT / GV_E_RCCL then, the communicator aborted instead of drained) and releases the communicator, streams and rows in every
+ * case; gv_destroy and a second gv_exchange_init do the same. */
 int gv_exchange_shutdown(GvCtx* ctx);
 /* How the rows travel (same result rows either way). The node's xGMI fabric is point to point and fully connected
  * (SURVEY.md §5, §8e): a ring all-gather serialises world-1 hops, the direct forms use every link at once and move only

@@ -11,6 +11,8 @@
 //   exchange_ranks --ranks R|auto [--entities N] [--frames F] [--mode all|allgather|p2p|broadcast] [--stall-rank R] [--random-camera SEED]
 // --random-camera SEED: every frame looks somewhere else through another lens (field of view 20 .. 160 degrees): the lists jump by an
 // order of magnitude from frame to frame in both directions — predictions are short or far too generous most of the time.
+// --abandon (with --stall-rank): the other ranks send the frame the stalled peer never joins and shut down WITHOUT acquiring it:
+// gv_exchange_shutdown comes back with GV_E_TIMEOUT inside the limit instead of synchronising a stream that never drains.
 // --stall-rank R: rank R stops calling half way (a stalled peer): every other rank must come back with a status code — not hang:
 // GV_E_TIMEOUT from a bounded wait (2 s here) on the rank that notices first (it aborts the communicator), GV_E_TIMEOUT or
 // GV_E_RCCL (ncclCommGetAsyncError: a rank has left) on the others — and shut its communicator down.
@@ -21,6 +23,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -105,7 +108,7 @@ void make_view(float yaw, GvView* view, float zoom = 1.0f)
     view->emit_records = 1;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -283,6 +286,23 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
                     return die("travelled words / room / row words disagree", ctx);
                 fs.travelled[r] = xf.travelled_words[r];
             }
+            if (abandon && stall_rank >= 0 && frame == frames / 2) {
+                // the frame the stalled peer never joins is sent and NOT acquired: shutting down must not wait for it for ever
+                const auto t0 = std::chrono::steady_clock::now();
+                const int src = gv_exchange_shutdown(ctx);
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if ((src != GV_E_TIMEOUT && src != GV_E_RCCL) || waited > 10.0) {
+                    fprintf(stderr, "rank %d: gv_exchange_shutdown behind an abandoned frame -> %d after %.1f s (expected GV_E_TIMEOUT within the 2 s limit): %s\n", rank, src,
+                            waited, gv_last_error(ctx));
+                    return 1;
+                }
+                GvExchangeFrame none;
+                if (gv_exchange_visible(ctx, 0, base, 0, &none) != GV_E_STATE)  // (released: a new gv_exchange_init would be needed)
+                    return die("gv_exchange_visible after the shutdown", ctx);
+                fs.timed_out = src == GV_E_TIMEOUT ? 1 : 2;
+                timed_out = true;
+                break;
+            }
             if (late >= 0) {  // the previous frame, acquired a frame late: gv_exchange_visible above has completed it already
                 const int arc = acquire(late);
                 if (arc == GV_E_TIMEOUT) {
@@ -334,6 +354,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
+    bool abandon = false;
     uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
@@ -351,6 +372,8 @@ int main(int argc, char** argv)
             camera_seed = (uint32_t)atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--stall-rank") && i + 1 < argc) {
             stall_rank = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--abandon")) {
+            abandon = true;
         } else if (!strcmp(argv[i], "--mode") && i + 1 < argc) {
             const char* m = argv[++i];
             mode = !strcmp(m, "allgather") ? 0 : !strcmp(m, "p2p") ? 1 : !strcmp(m, "broadcast") ? 2 : -1;
@@ -389,7 +412,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
+            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];

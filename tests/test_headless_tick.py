@@ -229,3 +229,13 @@ def test_a_stalled_peer_is_a_status_code_not_a_hang():
     out = _exchange_ranks(3, 30000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
                           extra=["--stall-rank", "1", "--frames", "10"])
     assert out["timed_out_ranks"] == 2 and out["mismatches"] == 0, out
+
+
+@pytest.mark.gpu
+def test_shutdown_behind_a_frame_a_stalled_peer_never_joined_is_bounded_too():
+    """The other ranks SEND the frame the stalled peer never joins and shut down without acquiring it: gv_exchange_shutdown drains
+    the exchange stream with the same bounded wait (GV_E_TIMEOUT, communicator aborted, everything released) instead of
+    synchronising a stream that never drains; exchange_ranks fails if it takes longer than 10 s or returns GV_OK."""
+    out = _exchange_ranks(3, 30000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
+                          extra=["--stall-rank", "2", "--abandon", "--frames", "10"])
+    assert out["timed_out_ranks"] == 2 and out["mismatches"] == 0, out
