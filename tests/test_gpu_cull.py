@@ -1151,6 +1151,48 @@ def test_native_rccl_exchange_single_rank(oracle):
 
 
 @pytest.mark.gpu
+def test_exchange_of_a_named_pool_after_another_system_was_culled(oracle):
+    """Two mesh systems culled one after the other, THEN exchanged (an engine that batches its culls): gv_pool_exchange_visible
+    carries the named pool's list, the view-indexed gv_exchange_visible the list of the pool culled last. Real RCCL, one rank;
+    every travel pattern; rows == the oracle's visible set of that pool."""
+    import torch
+    from garden_amd.lib import GpuVisibility
+    big, small = scene.flat_scene(100_000), scene.flat_scene(3_000, seed=scene.SEED + 5)
+    view = scene.main_camera_view()
+    class _Span:
+        pass
+
+    exp = {}
+    for pid, sc in ((0, big), (1, small)):
+        e = oracle.prepare_meshes(sc.meshes.copy(), big.transforms, big.entity_to_transform, view)
+        exp[pid] = np.sort(e["visible_idx"]).astype(np.int64)
+    assert len(exp[0]) > 4 * len(exp[1]) > 0
+    with GpuVisibility(device=0) as vis:
+        vis.bind_transforms(big.transforms, big.entity_to_transform)
+        vis.bind_pool(0, big.meshes)
+        vis.bind_pool(1, small.meshes)
+        vis.hierarchy_rebuild()
+        vis.exchange_init(GpuVisibility.exchange_unique_id(), 0, 1)
+
+        for mode in (0, 1, 2):
+            vis.exchange_set_mode(mode)
+            vis.cull(0, [view])
+            vis.cull(1, [view])
+            for pool_id, want in ((0, exp[0]), (None, exp[1]), (1, exp[1])):
+                sent = vis.exchange_visible(0, index_base=7, pool_id=pool_id)
+                f = vis.exchange_acquire(sent["frame"])
+                vis.wait()
+                assert f["complete"] and int(f["counts"][0]) == len(want), (mode, pool_id)
+                span = _Span()
+                span.__cuda_array_interface__ = {"shape": (f["row_words"],), "typestr": "<i4", "data": (int(f["ptr"]), False), "version": 2}
+                row = torch.as_tensor(span, device="cuda:0").cpu().numpy().view(np.uint32)[:1 + len(want)]
+                assert row[0] == len(want) and np.array_equal(np.sort(row[1:].astype(np.int64)), want + 7), (mode, pool_id)
+        with pytest.raises(Exception):
+            vis.exchange_visible(0, pool_id=5)  # never bound
+        vis.exchange_shutdown()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hier", [False, True])
 def test_sphere_pretest_agrees_with_the_exact_test_around_every_plane(gpu, oracle, hier):
     """The cull kernels decide entries away from the planes by a sphere bound and run the exact 8-corner test only in
