@@ -1043,10 +1043,13 @@ static void replay_schedule(const std::string& path)
                 CHECK(gv_pool_set_record_target(ctx, num(0), num(1), nullptr, 0));
                 t.clear();
             }
-        } else if (op == "exch") {
+        } else if (op == "exch" || op == "exchp") {
             if (exchange) {
                 GvExchangeFrame xf;
-                CHECK(gv_exchange_visible(ctx, 0, 11, 0, &xf));
+                if (op == "exchp")  // a named pool's view 0, whatever was culled since
+                    CHECK(gv_pool_exchange_visible(ctx, num(0), 0, 11, 0, &xf));
+                else
+                    CHECK(gv_exchange_visible(ctx, 0, 11, 0, &xf));
                 GvExchangeFrame got;
                 CHECK(gv_exchange_acquire(ctx, xf.frame, &got));
                 if (!got.complete || !got.gathered_device) {

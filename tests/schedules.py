@@ -31,6 +31,7 @@ Text form, one operation per line (first line: `world <transforms> <pool sizes..
     ready <pool> <first> <count>   per-slot ready counts changed (pools with id % 4 == 2 carry a ready column, gv_pool_bind_ready)
     target <pool> <view> <0|1>     gv_pool_set_record_target: the caller's own array for the view's records (1) / removed (0);
                                    pools with a record layout only (odd ids)
+    exchp p                        gv_pool_exchange_visible of view 0 of pool p — culled some time ago, other pools culled since
     exch                           gv_exchange_visible of view 0 of the most recently culled pool (1-rank communicator; contexts of
                                    schedules whose first line ends in `x`)
 First line: `world <transforms> <pool sizes...> [x]`.
@@ -148,6 +149,8 @@ def generate(seed, ops=60):
                 out.append(("records", p, v))
             elif kind < 0.88:
                 out.append(("bases", p, v))
+            elif exchange and kind >= 0.94:
+                out.append(("exchp", p))
             elif last_pool in culled and culled[last_pool][0] != "c":
                 out.append((str(rng.choice(["shard", "mask", "exch"] if exchange else ["shard", "mask"])),))
     if batching:

@@ -446,12 +446,12 @@ class ScheduleReplay:
                 else:
                     vis.set_record_target(p, v, None)
                     self.targets.pop((p, v), None)
-            elif op == "exch":
-                p = self.last_pool
+            elif op in ("exch", "exchp"):
+                p = self.last_pool if op == "exch" else int(a[0])
                 if p not in self.culls or not self.exchange:
                     continue
                 exp = self.expected(p, 0)
-                f = vis.exchange_acquire(vis.exchange_visible(0, index_base=11)["frame"])
+                f = vis.exchange_acquire(vis.exchange_visible(0, index_base=11, pool_id=None if op == "exch" else p)["frame"])
                 vis.wait()  # (the acquire ordered the context's stream behind the rows)
                 row = device_words(torch, f["ptr"], f["row_words"]).cpu().numpy().view(np.uint32)
                 assert f["complete"] and f["counts"] == [exp["count"]] and row[0] == exp["count"]

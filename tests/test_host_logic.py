@@ -597,5 +597,6 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
         path = tmp_path / f"schedule_{seed}.txt"
         path.write_text(schedules.to_text(schedules.generate(seed)))
         paths.append(str(path))
-    replay = subprocess.run([exe, *paths], capture_output=True, text=True, timeout=1800)
+    # (with the transport named, so that the exch / exchp operations of the schedules run instead of being skipped)
+    replay = subprocess.run([exe, *paths], capture_output=True, text=True, timeout=1800, env=dict(os.environ, GV_RCCL_LIBRARY=transport))
     assert replay.returncode == 0 and "schedules: 200 replayed ok" in replay.stdout, (replay.stdout + replay.stderr)[-4000:]
