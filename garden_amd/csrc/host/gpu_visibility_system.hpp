@@ -80,7 +80,7 @@ private:
 public:
     // host wall time of the prepare phase, accumulated over ticks ("Meshes Prepare" zone of the reference, by step)
     struct TickSeconds {
-        double total = 0, cull = 0, sort = 0, fetch = 0, records = 0;  // records: filling combinedMeshes from the fetch
+        double total = 0, cull = 0, sort = 0, fetch = 0, records = 0, share = 0, gather = 0;  // records: filling combinedMeshes from the fetch; share / gather: several ranks
     } tickSeconds;
     struct Stopwatch {
         double& sink;
@@ -761,7 +761,10 @@ private:
         if (sweepWorldMatrices)  // (a rank keeps the world matrices of ITS entities: gv_sweep / gv_get_world on getContext(rank), in local slots)
             throw GardenError("GpuVisibilitySystem: sweepWorldMatrices is a one-context option; with several ranks ask each rank's context");
         prepareSystems();
-        syncRanks(transformSystem);
+        {
+            Stopwatch watch(tickSeconds.share);
+            syncRanks(transformSystem);
+        }
         const uint32_t ranks = (uint32_t)contexts.size();
         const auto& cc = graphicsSystem->getCommonConstants();
         const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
@@ -780,12 +783,21 @@ private:
         };
         std::vector<GvExchangeFrame> frames(ranks);
         std::vector<uint32_t> viewIndices(ranks);
+        // Phase 1 — as in preRender(): every system's cull (and sort request) goes to every rank before any result is read, so each
+        // device works through the systems back to back (engine-sized pools: one launch per tick, gv_cull_batch_begin) while the host
+        // only enqueues. issued[p]: the passes system p was culled for, and its buffers.
+        struct Issued {
+            std::vector<int8_t> passes;
+            uint32_t bufferIndex = 0, shadowIndex = 0;
+        };
+        std::vector<Issued> issued(meshSystems.size());
+        for (uint32_t r = 0; r < ranks; r++)
+            checkRank(r, gv_cull_batch_begin(contexts[r]), "gv_cull_batch_begin");
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             auto meshSystem = meshSystems[p];
             const auto renderType = meshSystem->getMeshRenderType();
             const auto& componentPool = meshSystem->getMeshComponentPool();
             const uint32_t componentCount = componentPool.getCount();
-            const size_t componentSize = meshSystem->getMeshComponentSize();
             const bool sorted = isSortedType(renderType);
             uint32_t bufferIndex = 0, shadowIndex = 0;
             if (sorted) {
@@ -832,21 +844,37 @@ private:
                         views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false, emitRecords));
                         passes.push_back((int8_t)s);
                     }
+            issued[p].bufferIndex = bufferIndex;
+            issued[p].shadowIndex = shadowIndex;
             if (views.empty())
                 continue;
-            {
-                Stopwatch watch(tickSeconds.cull);
-                for (uint32_t r = 0; r < ranks; r++) {
-                    checkRank(r, gv_cull(contexts[r], p, views.data(), (uint32_t)views.size()), "gv_cull");
-                    if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
-                        for (uint32_t v = 0; v < views.size(); v++)
-                            checkRank(r, gv_pool_sort(contexts[r], p, v, sorted ? 1 : 0), "gv_pool_sort");
-                }
+            issued[p].passes = passes;
+            Stopwatch watch(tickSeconds.cull);
+            for (uint32_t r = 0; r < ranks; r++) {
+                checkRank(r, gv_cull(contexts[r], p, views.data(), (uint32_t)views.size()), "gv_cull");
+                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
+                    for (uint32_t v = 0; v < views.size(); v++)
+                        checkRank(r, gv_pool_sort(contexts[r], p, v, sorted ? 1 : 0), "gv_pool_sort");
             }
+        }
+        // Phase 2 — system by system: the gather, then the engine's buffers from the ranks' results (the first reader on a rank
+        // launches what that rank recorded).
+        for (uint32_t p = 0; p < meshSystems.size(); p++) {
+            const auto& passes = issued[p].passes;
+            if (passes.empty())
+                continue;
+            auto meshSystem = meshSystems[p];
+            const auto renderType = meshSystem->getMeshRenderType();
+            const auto& componentPool = meshSystem->getMeshComponentPool();
+            const size_t componentSize = meshSystem->getMeshComponentSize();
+            const bool sorted = isSortedType(renderType);
+            const uint32_t bufferIndex = issued[p].bufferIndex, shadowIndex = issued[p].shadowIndex;
             // the gather (mesh.cpp:177-183: every worker's records into the shared array): on every device, every rank's list of
-            // WORLD slots for the pass — complete in every frame (gv_exchange_acquire_all)
+            // WORLD slots for the pass — complete in every frame (gv_exchange_acquire_all); the pool is named: other systems have
+            // been culled since
             if (emitRecords)
-                for (uint32_t v = 0; v < views.size(); v++) {
+                for (uint32_t v = 0; v < passes.size(); v++) {
+                    Stopwatch watch(tickSeconds.gather);
                     std::fill(viewIndices.begin(), viewIndices.end(), v);
                     check(gv_pool_exchange_visible_all(contexts.data(), (int)ranks, p, viewIndices.data(), nullptr, 0, frames.data()), "gv_pool_exchange_visible_all");
                     check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
@@ -854,7 +882,7 @@ private:
                         onGathered(p, passes[v], frames.data(), ranks);
                 }
             // the engine's buffers from the ranks' results
-            for (uint32_t v = 0; v < views.size(); v++) {
+            for (uint32_t v = 0; v < passes.size(); v++) {
                 const int8_t pass = passes[v];
                 std::vector<uint32_t> runs;
                 // every rank's results of the pass (library-owned host memory, valid until the pool's next gv_cull on that rank); the

@@ -791,8 +791,9 @@ int main(int argc, char** argv)
         if (gpu && getenv("GV_TICK_BREAKDOWN")) {
             const auto& t = gpu->tickSeconds;
             const double n = (double)ticks * rounds * 1e-6;  // -> microseconds per tick
-            fprintf(stderr, "gpu prepare us/tick: total %.1f = cull %.1f + sort %.1f + fetch %.1f + records %.1f + other %.1f\n", t.total / n,
-                    t.cull / n, t.sort / n, t.fetch / n, t.records / n, (t.total - t.cull - t.sort - t.fetch - t.records) / n);
+            fprintf(stderr, "gpu prepare us/tick: total %.1f = cull %.1f + sort %.1f + fetch %.1f + records %.1f + shares %.1f + gather %.1f + other %.1f\n", t.total / n,
+                    t.cull / n, t.sort / n, t.fetch / n, t.records / n, t.share / n, t.gather / n,
+                    (t.total - t.cull - t.sort - t.fetch - t.records - t.share - t.gather) / n);
         }
         return ok ? 0 : 1;
     } catch (const std::exception& e) {
