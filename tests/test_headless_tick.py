@@ -161,6 +161,12 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "60000", "--ranks", "8", "--csm"],
     ["--entities", "20000", "--ranks", "2", "--mixed", "--gate", "never", "--toggle", "--hier"],
     ["--entities", "50000", "--ranks", "4", "--hiz", "--mixed", "--hier"],  # the pyramid is built on every rank
+    # BASELINE sizes through the drop-in's own multi-GPU mode: 10 M entities dealt to 8 / 4 contexts (hierarchies follow their roots;
+    # the occlusion query on every rank), five mesh systems + three cascades at 4 M — every buffer and isVisible byte of the whole
+    # pools == the CPU system's
+    ["--entities", "10000000", "--ranks", "8", "--hier", "--ticks", "2", "--threads", "16"],
+    ["--entities", "10000000", "--ranks", "4", "--hiz", "--ticks", "2", "--threads", "16"],
+    ["--entities", "4000000", "--ranks", "8", "--mixed", "--csm", "--ticks", "2", "--threads", "16"],
 ])
 def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
     """The drop-in's own multi-GPU mode — ONE process, ONE thread, N contexts (the reference is one process with one Manager,
