@@ -119,14 +119,25 @@ print("REPORT " + json.dumps(dict(rank=rank, frames=report, share=int(share), to
 @pytest.mark.parametrize("world,how,pattern", [(2, "python", "turns"), (4, "python", "p2p"), (3, "native", "broadcast"), (8, "native", "turns"),
                                                (2, "native", "allgather"), (3, "python", "allgather"), (4, "native", "broadcast"), (8, "python", "p2p")])
 def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(tmp_path, world, how, pattern):
+    _deal_cull_exchange(tmp_path, world, how, pattern, 120_000, 8, 3)
+
+
+@pytest.mark.gpu
+def test_a_ten_million_entity_world_dealt_to_eight_rank_processes(tmp_path):
+    """The same chain at BASELINE's 10^7: one hierarchy world (trees of 43) cut into 8 ranks' shares by the cell rule, every rank a
+    process with its own context, four frames with the cut to the centre in the middle, the travel pattern turning — on every rank
+    and in every frame the union of the gathered rows == the oracle's visible set of the WHOLE world."""
+    _deal_cull_exchange(tmp_path, 8, "python", "turns", 10_000_000, 4, 2)
+
+
+def _deal_cull_exchange(tmp_path, world, how, pattern, n, frames, min_completed):
     stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
     script = tmp_path / "rank.py"
     script.write_text(WORKER.format(root=ROOT))
-    n, frames = 120_000, 8
     env = dict(os.environ, GV_RCCL_LIBRARY=stub)
     procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path), how, pattern], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=900) for p in procs]
+    outs = [p.communicate(timeout=1500) for p in procs]
     for p, (out, err) in zip(procs, outs):
         assert p.returncode == 0, err[-3000:]
     reports = sorted((json.loads(out.split("REPORT ", 1)[1]) for out, _ in outs), key=lambda d: d["rank"])
@@ -146,5 +157,7 @@ def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(t
     # frame 0 has no history, frame 1 sees three times as much, the cut to the centre changes every rank's list: predictions fell
     # short in THOSE frames (tails travelled in a second exchange), and they arrived whole like all the others
     cut_frame = reports[0]["frames"][frames // 2]
-    assert cut_frame["cut"] and sum(cut_frame["tails"]) > 0 and reports[0]["frames"][0]["cut"] and completed >= 3, \
+    # (the 10 M world's corner camera already sees millions: the centre's lists fit the rooms it left — there only frames 0 and 1 are short)
+    centre_cut = cut_frame["cut"] and sum(cut_frame["tails"]) > 0
+    assert (centre_cut or min_completed < 3) and reports[0]["frames"][0]["cut"] and completed >= min_completed, \
         [(f["visible"], f["cut"]) for f in reports[0]["frames"]]
