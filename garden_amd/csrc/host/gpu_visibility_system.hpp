@@ -36,6 +36,11 @@ public:
     struct ShadowPass {  // IShadowMeshRenderSystem::prepareShadowRender outputs (mesh.hpp:166, csm.cpp:260-343)
         f32x4x4 viewProj;
         f32x4 cameraOffset;
+        // The shadow system's own number of the pass: what isDrawReady(shadowPass) is asked with. renderShadows (mesh.cpp:809-815)
+        // leaves out a pass whose prepareShadowRender says no and goes on counting — list the passes that were prepared, each with
+        // its number. -1: the position in the list (no pass was left out).
+        int8_t passIndex = -1;
+        int8_t index(uint32_t position) const noexcept { return passIndex >= 0 ? passIndex : (int8_t)position; }
     };
 
 private:
@@ -522,8 +527,8 @@ private:
             }
             if (renderType != MeshRenderType::UI)
                 for (uint32_t s = 0; s < passCount; s++)
-                    if (componentCount != 0 && meshSystem->isDrawReady((int8_t)s)) {
-                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false, emitRecords));
+                    if (componentCount != 0 && meshSystem->isDrawReady(shadowPasses[s].index(s))) {
+                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), false, emitRecords));
                         passes.push_back((int8_t)s);
                     }
             if (!sorted) {
@@ -840,8 +845,8 @@ private:
             }
             if (renderType != MeshRenderType::UI)
                 for (uint32_t s = 0; s < passCount; s++)
-                    if (componentCount != 0 && meshSystem->isDrawReady((int8_t)s)) {
-                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, (int8_t)s, false, emitRecords));
+                    if (componentCount != 0 && meshSystem->isDrawReady(shadowPasses[s].index(s))) {
+                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), false, emitRecords));
                         passes.push_back((int8_t)s);
                     }
             issued[p].bufferIndex = bufferIndex;

@@ -17,6 +17,8 @@ public:
     struct ShadowPass {
         f32x4x4 viewProj;
         f32x4 cameraOffset;
+        int8_t passIndex = -1;  // the shadow system's own number of the pass (mesh.cpp:809-815); -1: the position in the list
+        int8_t index(uint32_t position) const noexcept { return passIndex >= 0 ? passIndex : (int8_t)position; }
     };
 
 private:
@@ -300,7 +302,8 @@ private:
         shadowTransDrawIndex.assign(passCount, 0);
         shadowSortedBuffers.resize(passCount);
         for (uint32_t s = 0; s < passCount; s++) {
-            prepareMeshes(shadowPasses[s].viewProj, nullptr, shadowPasses[s].cameraOffset, (int8_t)s, tp);  // :814
+            // (mesh.cpp:812-815: a pass whose prepareShadowRender said no is not in the list; the others keep their passIndex)
+            prepareMeshes(shadowPasses[s].viewProj, nullptr, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), tp);
             if (shadowBuffers.size() < unsortedBufferCount)
                 shadowBuffers.resize(unsortedBufferCount);
             for (uint32_t b = 0; b < unsortedBufferCount; b++) {

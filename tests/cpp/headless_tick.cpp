@@ -209,6 +209,7 @@ static void poisonVisible(Manager& manager)
 // `componentCount == 0 || !isDrawReady(shadowPass)` (mesh.cpp:426,482) the buffer of that pass names the system and has both counters
 // at 0 (:419-424, :475-480), no record of the shared sorted arrays carries its bufferIndex, and — light pass — every isVisible byte
 // is the one the tick started from. hasAnyRefr / hasAnyOIT / hasAnyTD are what :339,488-490 compute. Empty string: holds.
+static std::vector<int8_t> g_passIndex;  // by position in the list of prepared shadow passes: the pass's own number (--skip-pass)
 template <class SystemT>
 static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t passCount)
 {
@@ -251,7 +252,7 @@ static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t p
                     const auto shadow = system->getShadowSortedBuffers(s).at(shadowIndex);
                     if (shadow->meshSystem != ms)
                         return name + ": a shadow pass's sortedBuffers[bufferIndex] does not name it";
-                    if (count != 0 && (!ready || ready->drawReady((int8_t)s)))
+                    if (count != 0 && (!ready || ready->drawReady(g_passIndex.at(s))))
                         continue;
                     if (shadow->drawCount != 0 || shadow->instanceCount != 0)
                         return name + " is not drawn in shadow pass " + std::to_string(s) + ", yet its sorted buffer counts draws";
@@ -272,7 +273,7 @@ static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t p
                 anyTd = anyTd || type == MeshRenderType::TransDepth;
             }
             for (uint32_t s = 0; s < passCount; s++) {
-                if (count != 0 && (!ready || ready->drawReady((int8_t)s)))
+                if (count != 0 && (!ready || ready->drawReady(g_passIndex.at(s))))
                     continue;
                 const auto shadow = system->getShadowBuffers(index).at(s);
                 if (shadow->drawCount != 0 || shadow->instanceCount != 0)
@@ -296,6 +297,8 @@ int main(int argc, char** argv)
     bool hiz = false;        // --hiz: a depth image with walls is handed to both systems: the light pass of the non-UI systems runs the
                              // per-AABB occlusion query behind the frustum test (with --ranks: the pyramid is built on every rank)
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
+    int skipPass = -1;       // --skip-pass K: the shadow system's prepareShadowRender says no for pass K (renderShadows, mesh.cpp:812-813:
+                             // `continue`): the pass is not prepared, the others keep their numbers — isDrawReady is asked with THOSE
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
                             // checks gv_get_world of every transform slot against the oracle's chain walk, bit for bit
@@ -318,6 +321,7 @@ int main(int argc, char** argv)
         else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--csm") csmPasses = true;
+        else if (a == "--skip-pass" && i + 1 < argc) skipPass = atoi(argv[++i]);
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
         else if (a == "--non-translucent") g_nonTranslucent = true;
         else if (a == "--hiz") hiz = true;
@@ -500,20 +504,24 @@ int main(int argc, char** argv)
             std::vector<GpuVisibilitySystem::ShadowPass> gpuPasses;
             std::vector<CpuMeshRenderSystem::ShadowPass> cpuPasses;
             for (int c = 0; c < 2; c++) {
+                if (c == skipPass)
+                    continue;
                 const float size = side * (c == 0 ? 0.25f : 0.6f), nearPlane = -side, farPlane = side;
                 f32x4x4 vp;
                 memset(vp.m, 0, sizeof(vp.m));
                 vp.m[0] = 2.0f / size; vp.m[5] = -2.0f / size; vp.m[10] = -1.0f / (farPlane - nearPlane);
                 vp.m[14] = farPlane / (farPlane - nearPlane); vp.m[15] = 1.0f;
                 const f32x4 offset(3.0f * (float)(c + 1), -7.0f, 11.0f);
-                gpuPasses.push_back({vp, offset});
-                cpuPasses.push_back({vp, offset});
+                gpuPasses.push_back({vp, offset, (int8_t)c});
+                cpuPasses.push_back({vp, offset, (int8_t)c});
+                g_passIndex.push_back((int8_t)c);
             }
             if (gpu) gpu->setShadowPasses(gpuPasses);
             if (cpu) cpu->setShadowPasses(cpuPasses);
-            passCount = 2;
+            passCount = (uint32_t)gpuPasses.size();
         }
         if (csmPasses) {
+            g_passIndex.clear();
             // CsmRenderSystem::prepareShadowRender (csm.cpp:308-325) for the camera above (identity view, FOV 90, 16:9,
             // near 0.01): three cascades over the nearest eighth of the world, light from above and behind
             const float splits[2] = {0.1f, 0.35f}, distance = 0.125f * side, zCoeff = 10.0f;
@@ -525,8 +533,11 @@ int main(int argc, char** argv)
             float nearPlane = 0.01f;
             for (uint32_t c = 0; c < cascades; c++) {
                 const auto cs = csm::cascade(c, cascades, splits, distance, f32x4x4(), lightDir, 1.5707963f, 16.0f / 9.0f, 0.01f, zCoeff, mapSize);
-                gpuPasses.push_back({cs.viewProj, cs.cameraOffset});
-                cpuPasses.push_back({cs.viewProj, cs.cameraOffset});
+                if ((int)c != skipPass) {
+                    gpuPasses.push_back({cs.viewProj, cs.cameraOffset, (int8_t)c});
+                    cpuPasses.push_back({cs.viewProj, cs.cameraOffset, (int8_t)c});
+                    g_passIndex.push_back((int8_t)c);
+                }
                 // property of calcLightViewProj: the slice's corners lie in the light's box (up to the texel snap)
                 const float farPlane = c + 1 < cascades ? distance * splits[c] : distance;
                 const float eps = 4.0f / (float)mapSize + 1e-3f;
@@ -545,7 +556,7 @@ int main(int argc, char** argv)
             }
             if (gpu) gpu->setShadowPasses(gpuPasses);
             if (cpu) cpu->setShadowPasses(cpuPasses);
-            passCount = cascades;
+            passCount = (uint32_t)gpuPasses.size();
         }
 
         if (hiz) {  // reversed-Z depth (1 = near, 0 = far): an empty background with a few walls at different depths, 480 x 272

@@ -110,7 +110,7 @@ def test_integration_statement_table_points_at_the_shim_lines_it_names():
         return [shim[int(n) - 1] for n in re.findall(r"`:(\d+)`", last_column)]
 
     gate = named("**426**")
-    assert len(gate) >= 3 and "isDrawReady(-1)" in gate[0] and "isDrawReady((int8_t)s)" in gate[1] and "continue" in gate[2], gate
+    assert len(gate) >= 3 and "isDrawReady(-1)" in gate[0] and "isDrawReady(shadowPasses[s].index(s))" in gate[1] and "continue" in gate[2], gate
     assert "hasAnyRefr = hasAnyOIT = hasAnyTD = false" in named("339")[0]
     assert "hasAnyRefr |=" in named("488-490")[0]
     assert "getMeshComponentPool()" in named("410-412")[0]

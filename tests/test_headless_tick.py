@@ -62,6 +62,16 @@ def test_cpu_system_gate_of_prepare_meshes_against_the_reference_text(tick, gate
     assert kept["ok"] and kept["draw_count"] == out["draw_count"] and kept["sorted_draw_count"] < out["sorted_draw_count"], (out, kept)
 
 
+def test_cpu_shadow_pass_left_out_by_prepare_shadow_render_keeps_the_numbering(tick):
+    """renderShadows (mesh.cpp:809-815): a pass whose prepareShadowRender says no is not prepared, and the passes behind it keep
+    their numbers — isDrawReady(shadowPass) is asked with the NUMBER. --gate shadow makes two systems not ready for pass 1 only;
+    with pass 0 left out, pass 1 is the first (and only) entry of the list and they must not be drawn in it."""
+    _, out = tick("--mode", "cpu", "--entities", "20000", "--ticks", "2", "--mixed", "--gate", "shadow", "--skip-pass", "0")
+    assert out["ok"] and out["shadow_draw_counts"] == [0], out
+    _, out = tick("--mode", "cpu", "--entities", "20000", "--ticks", "2", "--mixed", "--gate", "shadow", "--skip-pass", "1")
+    assert out["ok"] and out["shadow_draw_counts"][0] > 0, out
+
+
 def test_cpu_entity_churn(tick):
     """Entities destroyed and created between frames (incl. re-parented orphans, re-used slots, pool growth)."""
     _, out = tick("--mode", "cpu", "--entities", "6000", "--ticks", "2", "--hier", "--mixed", "--churn", "4")
@@ -144,6 +154,10 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "60000", "--hiz"],
     ["--entities", "40000", "--hiz", "--mixed", "--hier", "--mutate"],
     ["--entities", "30000", "--hiz", "--mixed", "--csm", "--animate", "4", "--ticks", "4", "--span-records"],
+    # a shadow pass left out by prepareShadowRender (mesh.cpp:812-813): the others keep their numbers, isDrawReady is asked with those
+    ["--entities", "30000", "--mixed", "--gate", "shadow", "--skip-pass", "0"],
+    ["--entities", "30000", "--mixed", "--csm", "--gate", "shadow", "--skip-pass", "1", "--hier", "--mutate"],
+    ["--entities", "30000", "--mixed", "--csm", "--gate", "reverse", "--skip-pass", "0", "--churn", "3"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
@@ -161,6 +175,7 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "60000", "--ranks", "8", "--csm"],
     ["--entities", "20000", "--ranks", "2", "--mixed", "--gate", "never", "--toggle", "--hier"],
     ["--entities", "50000", "--ranks", "4", "--hiz", "--mixed", "--hier"],  # the pyramid is built on every rank
+    ["--entities", "30000", "--ranks", "3", "--mixed", "--csm", "--gate", "shadow", "--skip-pass", "0"],
     # BASELINE sizes through the drop-in's own multi-GPU mode: 10 M entities dealt to 8 / 4 contexts (hierarchies follow their roots;
     # the occlusion query on every rank), five mesh systems + three cascades at 4 M — every buffer and isVisible byte of the whole
     # pools == the CPU system's

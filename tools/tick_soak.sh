@@ -2,8 +2,8 @@
 # GPU box: the headless tick driver (CPU reference-path system vs the GPU drop-in, every buffer compared every tick) over many
 # seeds and flag combinations — the mirror's maintenance paths under entity churn, re-parenting, toggles, moving scenes.
 # Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
-# against the reference text) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
-#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 20 flag sets)
+# against the reference text; --skip-pass: a shadow pass left out by prepareShadowRender) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 22 flag sets)
 set -u
 cd "$(dirname "$0")/.."
 make -s -C tests/cpp
@@ -30,6 +30,8 @@ sets=(
   "--entities 20000 --ranks 3 --mixed --hier --animate 5 --itemised --ticks 4"
   "--entities 24000 --ranks 8 --mixed --csm --churn 2"
   "--entities 12000 --ranks 2 --mixed --gate shadow --toggle --hier"
+  "--entities 20000 --mixed --csm --gate shadow --skip-pass 1 --churn 3"
+  "--entities 16000 --mixed --gate reverse --skip-pass 0 --hier --mutate"
 )
 export GV_RCCL_LIBRARY=${GV_RCCL_LIBRARY:-$PWD/tests/cpp/build/librccl_stub.so}  # (--ranks N > 1: N contexts share this box's GPU)
 for s in $(seq 1 "$seeds"); do
