@@ -837,7 +837,7 @@ namespace gv {
 int copy_shard_of_pool(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, void* dst_device, uint32_t capacity, uint32_t index_base)
 {
     if (!dst_device || !view_of(ctx, pool_id, view_index) || !view_of(ctx, pool_id, view_index)->emitted)
-        return ctx->fail(GV_E_ARG, "exchange shard: pool %u view %u has no emitted records", pool_id, view_index);
+        return ctx->fail(GV_E_ARG, "shard copy: pool %u view %u has no emitted records", pool_id, view_index);
     if (int rc = flush_sorts(ctx))
         return rc;
     ViewState& vs = *view_of(ctx, pool_id, view_index);
