@@ -629,6 +629,9 @@ void gv_destroy(GvCtx* ctx)
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
+    // the exchange stream first, with its bounded wait: the context's stream may be waiting for a frame's rows behind a collective
+    // that a peer has left (a timeout aborts the communicator, which lets both streams run out)
+    (void)exchange_drain(ctx);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);

@@ -483,6 +483,7 @@ void drain_events(GvCtx* ctx);
 
 // gv_exchange.cpp
 void exchange_release(GvCtx* ctx);            // destroys the communicator, if any
+int exchange_drain(GvCtx* ctx);    // bounded wait for what is queued on the exchange stream; a timeout aborts the communicator (GV_E_TIMEOUT)
 
 // gv_context.cpp (the cull side)
 int flush_culls(GvCtx* ctx);                             // launches the culls recorded since gv_cull_batch_begin; ends the batch

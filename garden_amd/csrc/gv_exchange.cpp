@@ -159,6 +159,8 @@ int drain_exchange_stream(GvCtx* ctx)
 
 namespace gv {
 
+int exchange_drain(GvCtx* ctx) { return drain_exchange_stream(ctx); }
+
 void exchange_release(GvCtx* ctx)
 {
     // what is still queued on the exchange stream goes first: gv_stream never waits for a frame's collective, so the communicator

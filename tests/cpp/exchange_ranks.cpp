@@ -12,7 +12,8 @@
 // --random-camera SEED: every frame looks somewhere else through another lens (field of view 20 .. 160 degrees): the lists jump by an
 // order of magnitude from frame to frame in both directions — predictions are short or far too generous most of the time.
 // --abandon (with --stall-rank): the other ranks send the frame the stalled peer never joins and shut down WITHOUT acquiring it:
-// gv_exchange_shutdown comes back with GV_E_TIMEOUT inside the limit instead of synchronising a stream that never drains.
+// gv_exchange_shutdown comes back with GV_E_TIMEOUT inside the limit instead of synchronising a stream that never drains
+// (--abandon-by-destroy: they call gv_destroy straight away, which must come back inside the limit too).
 // --stall-rank R: rank R stops calling half way (a stalled peer): every other rank must come back with a status code — not hang:
 // GV_E_TIMEOUT from a bounded wait (2 s here) on the rank that notices first (it aborts the communicator), GV_E_TIMEOUT or
 // GV_E_RCCL (ncclCommGetAsyncError: a rank has left) on the others — and shut its communicator down.
@@ -108,7 +109,7 @@ void make_view(float yaw, GvView* view, float zoom = 1.0f)
     view->emit_records = 1;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -289,6 +290,17 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
             if (abandon && stall_rank >= 0 && frame == frames / 2) {
                 // the frame the stalled peer never joins is sent and NOT acquired: shutting down must not wait for it for ever
                 const auto t0 = std::chrono::steady_clock::now();
+                if (abandon_by_destroy) {  // ... and so must gv_destroy, which has no status to return: it comes back inside the limit
+                    gv_destroy(ctx);
+                    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (waited > 10.0) {
+                        fprintf(stderr, "rank %d: gv_destroy behind an abandoned frame took %.1f s (limit 2 s)\n", rank, waited);
+                        return 1;
+                    }
+                    fs.timed_out = 1;
+                    (void)hipFree(own_rows);
+                    return 0;
+                }
                 const int src = gv_exchange_shutdown(ctx);
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if ((src != GV_E_TIMEOUT && src != GV_E_RCCL) || waited > 10.0) {
@@ -354,7 +366,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
-    bool abandon = false;
+    bool abandon = false, abandon_by_destroy = false;
     uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
@@ -374,6 +386,8 @@ int main(int argc, char** argv)
             stall_rank = atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--abandon")) {
             abandon = true;
+        } else if (!strcmp(argv[i], "--abandon-by-destroy")) {
+            abandon = abandon_by_destroy = true;
         } else if (!strcmp(argv[i], "--mode") && i + 1 < argc) {
             const char* m = argv[++i];
             mode = !strcmp(m, "allgather") ? 0 : !strcmp(m, "p2p") ? 1 : !strcmp(m, "broadcast") ? 2 : -1;
@@ -412,7 +426,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
+            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, abandon_by_destroy, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];

@@ -260,6 +260,10 @@ def test_shutdown_behind_a_frame_a_stalled_peer_never_joined_is_bounded_too():
     out = _exchange_ranks(3, 30000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
                           extra=["--stall-rank", "2", "--abandon", "--frames", "10"])
     assert out["timed_out_ranks"] == 2 and out["mismatches"] == 0, out
+    # ... and gv_destroy straight away (no shutdown call): bounded the same way
+    out = _exchange_ranks(3, 30000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
+                          extra=["--stall-rank", "0", "--abandon-by-destroy", "--frames", "10"])
+    assert out["timed_out_ranks"] == 2 and out["mismatches"] == 0, out
 
 
 @pytest.mark.gpu
