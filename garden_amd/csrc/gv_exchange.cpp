@@ -607,6 +607,38 @@ int tails_finish(GvCtx* ctx, Slot& slot)
     return GV_OK;
 }
 
+// ... and the host sees the tails arrive, with the bounded wait: a frame is handed out only behind collectives that are known to
+// have finished (a peer that left between the headers and the tails would otherwise hang the first synchronisation of the context's
+// stream, which the acquire orders behind `done`). Frames with short rows are host-synchronising anyway, and rare.
+int tails_arrived(GvCtx* ctx, Slot& slot)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    char text[320];
+    for (;;) {
+        const hipError_t e = hipEventQuery(slot.done);
+        if (e == hipSuccess)
+            return GV_OK;
+        if (e != hipErrorNotReady)
+            return ctx->hip_fail(e, "gv_exchange: waiting for the tails of a frame with short rows");
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::milliseconds(ctx->exchange_timeout_ms)) {
+            snprintf(text, sizeof(text), "exchange frame %llu: the tails of its short rows did not arrive within %u ms: a peer rank stalled or left; the "
+                     "communicator has been aborted", (unsigned long long)slot.frame, ctx->exchange_timeout_ms);
+            slot.settled = false;
+            return give_up(ctx, GV_E_TIMEOUT, text);
+        }
+        if (waited > std::chrono::milliseconds(2)) {
+            if (const int async = async_error(ctx)) {
+                snprintf(text, sizeof(text), "exchange frame %llu: RCCL reports an asynchronous error while the tails of its short rows travel: %s; the communicator "
+                         "has been aborted", (unsigned long long)slot.frame, rccl().GetErrorString(async));
+                slot.settled = false;
+                return give_up(ctx, GV_E_RCCL, text);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+}
+
 // The three steps for all the contexts of a call (one for the per-rank forms): the collectives of all of them inside one group.
 int settle(GvCtx* const* ctxs, int n, unsigned which)
 {
@@ -645,6 +677,13 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
         rc = ctxs[0]->fail(GV_E_RCCL, "gv_exchange: ncclGroupEnd: %s", r.GetErrorString(erc));
     for (int k = 0; k < n && rc == GV_OK; k++)
         rc = tails_finish(ctxs[k], ctxs[k]->exchange_slots[which]);
+    for (int k = 0; k < n && rc == GV_OK; k++) {
+        rc = tails_arrived(ctxs[k], ctxs[k]->exchange_slots[which]);
+        if (rc == GV_E_TIMEOUT || rc == GV_E_RCCL)  // (as above: none of the call's ranks is left holding its device)
+            for (int j = 0; j < n; j++)
+                if (j != k && !ctxs[j]->exchange_broken)
+                    (void)give_up(ctxs[j], rc, ctxs[k]->error.c_str());
+    }
     return rc;
 }
 
