@@ -130,6 +130,7 @@ int drain_exchange_stream(GvCtx* ctx)
 {
     if (!ctx->exchange_stream || ctx->exchange_broken)
         return GV_OK;
+    (void)hipSetDevice(ctx->device);
     const auto t0 = std::chrono::steady_clock::now();
     char text[384];
     for (;;) {
@@ -612,6 +613,7 @@ int tails_finish(GvCtx* ctx, Slot& slot)
 // stream, which the acquire orders behind `done`). Frames with short rows are host-synchronising anyway, and rare.
 int tails_arrived(GvCtx* ctx, Slot& slot)
 {
+    GV_HIP(ctx, hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
     char text[320];
     for (;;) {
