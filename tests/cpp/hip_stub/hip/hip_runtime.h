@@ -94,8 +94,11 @@ static inline hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t wor
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(std::malloc(1)); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+// "Work that never finishes" for the bounded waits of the exchange (host_orchestration_test.cpp::exchange_bounded_waits): bit 0 — no
+// stream ever drains, bit 1 — no event ever completes. 0: everything has always run already (the stub executes at enqueue).
+inline GvStubCounter& gv_stub_never_ready() { static GvStubCounter bits; return bits; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return ((long)gv_stub_never_ready() & 1) ? hipErrorNotReady : hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return ((long)gv_stub_never_ready() & 2) ? hipErrorNotReady : hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(std::malloc(1)); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }

@@ -10,6 +10,7 @@
 // inside what it allocated, and that the status codes are the documented ones. TEST-ONLY: the product library still
 // returns GV_E_NODEVICE without a gfx950 device.
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -1344,6 +1345,84 @@ static void allocation_failures()
     std::printf("allocation failures: %ld allocations failed in turn, %d calls reported it, every context recovered: ok\n", total, failed_calls);
 }
 
+// The exchange's bounded waits when the work behind them NEVER finishes (the stub's streams / events can be told so): status codes
+// inside the limit, every context of the call marked broken, later calls GV_E_STATE, shutdown / destroy still release everything
+// (ASan: no leak, nothing freed twice, no use after the abort).
+static void exchange_bounded_waits()
+{
+    if (!std::getenv("GV_RCCL_LIBRARY")) {
+        std::printf("exchange, bounded waits: skipped (GV_RCCL_LIBRARY not set)\n");
+        return;
+    }
+    g_list_seed = 0;
+    const int ranks = 2;
+    std::vector<ExchangeRank> xs(ranks);
+    std::vector<GvCtx*> ctxs;
+    for (int r = 0; r < ranks; r++) {
+        if (!xs[r].create(r, ranks))
+            std::exit(1);
+        ctxs.push_back(xs[r].ctx);
+    }
+    GvCtx* ctx = ctxs[0];
+    std::vector<uint32_t> views(ranks, 0u);
+    std::vector<GvExchangeFrame> sent(ranks), got(ranks);
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    // (1) the tails of a frame with short rows never arrive: frame 0 has no history, every row is short
+    CHECK(gv_exchange_init_all(ctxs.data(), ranks));
+    for (int r = 0; r < ranks; r++) {
+        CHECK(gv_exchange_set_timeout(ctxs[r], 40));
+        xs[r].produce(0, GV_EXCHANGE_P2P);
+    }
+    CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+    gv_stub_never_ready() = 2;
+    auto t0 = std::chrono::steady_clock::now();
+    EXPECT(gv_exchange_acquire_all(ctxs.data(), ranks, 0, got.data()), GV_E_TIMEOUT);
+    if (since(t0) > 5.0 || !strstr(gv_last_error(ctxs[0]), "tails")) {
+        std::fprintf(stderr, "bounded waits: the tails' wait took %.1f s / says: %s\n", since(t0), gv_last_error(ctxs[0]));
+        std::exit(1);
+    }
+    gv_stub_never_ready() = 0;
+    EXPECT(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()), GV_E_STATE);  // every context of the call is broken
+    EXPECT(gv_exchange_acquire_all(ctxs.data(), ranks, 0, got.data()), GV_E_STATE);
+    for (int r = 0; r < ranks; r++) {
+        ctx = ctxs[r];
+        CHECK(gv_exchange_shutdown(ctx));  // (nothing left to drain: the communicator was aborted on the spot)
+    }
+    // (2) a frame that was sent and never acquired, on a stream that never drains: shutdown reports it and releases all the same
+    CHECK(gv_exchange_init_all(ctxs.data(), ranks));
+    for (int r = 0; r < ranks; r++) {
+        CHECK(gv_exchange_set_timeout(ctxs[r], 40));
+        xs[r].produce(0, GV_EXCHANGE_ALLGATHER);
+    }
+    CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+    gv_stub_never_ready() = 1;
+    t0 = std::chrono::steady_clock::now();
+    EXPECT(gv_exchange_shutdown(ctxs[0]), GV_E_TIMEOUT);
+    EXPECT(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()), GV_E_STATE);  // rank 0 has no communicator any more
+    gv_destroy(ctxs[1]);  // (no status to return: comes back inside the limit, everything released)
+    if (since(t0) > 5.0) {
+        std::fprintf(stderr, "bounded waits: shutdown + destroy behind a stream that never drains took %.1f s\n", since(t0));
+        std::exit(1);
+    }
+    gv_stub_never_ready() = 0;
+    // (3) ... and a context is as good as new afterwards
+    ctx = ctxs[0];
+    CHECK(gv_exchange_init_all(ctxs.data(), 1));
+    xs[0].ranks = 1;
+    xs[0].produce(0, GV_EXCHANGE_BROADCAST);
+    CHECK(gv_exchange_visible_all(ctxs.data(), 1, views.data(), nullptr, 0, sent.data()));
+    CHECK(gv_exchange_acquire_all(ctxs.data(), 1, 0, got.data()));
+    xs[0].check_acquired(sent[0], got[0], 0);
+    if (xs[0].failures) {
+        std::fprintf(stderr, "bounded waits: the context did not recover\n");
+        std::exit(1);
+    }
+    CHECK(gv_exchange_shutdown(ctx));
+    gv_destroy(ctx);
+    std::printf("exchange, bounded waits: tails that never arrive -> GV_E_TIMEOUT on every context of the call; a stream that never drains -> shutdown "
+                "GV_E_TIMEOUT, destroy returns; the context recovers: ok\n");
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) {  // schedule files (tests/schedules.py): replayed instead of the fixed exercise
@@ -1368,6 +1447,7 @@ int main(int argc, char** argv)
         exchange_in_one_thread(2 + seed % 3, seed);
     allocation_failures();
     exchange_allocation_failures();
+    exchange_bounded_waits();
     std::printf("host orchestration: ok\n");
     return 0;
 }
