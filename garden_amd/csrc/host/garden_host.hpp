@@ -297,6 +297,9 @@ public:
 // of their MeshRenderComponent-derived struct and report a MeshRenderType, render/mesh.hpp:60-147).
 class VersionedMeshSystem {
 public:
+    // false: the system behaves like the engine's own mesh systems (sprite.cpp, 9-slice, label.cpp, instance.cpp: no counter at
+    // all) — consumers must find out themselves what changed (headless_tick --unversioned)
+    bool reportsChanges = true;
     uint64_t meshVersion = 0;  // bumped by markMeshesChanged(): consumers re-mirror the whole pool
     void markMeshesChanged() noexcept { meshVersion++; }
     // itemised changes (components created / destroyed / edited through touchMesh): only [meshLo, meshHi) moves

@@ -493,7 +493,8 @@ private:
                       "gv_pool_set_record_layout");
                 inPlace = !sorted && emitRecords && recordStructs && expressible && recordTargets;
             }
-            if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem)) {
+            auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem);
+            if (versioned && versioned->reportsChanges) {
                 if (seenMesh[p] != versioned->meshVersion) {
                     check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, occupancy), "gv_mark_dirty");
                     seenMesh[p] = versioned->meshVersion;
@@ -661,6 +662,8 @@ private:
         for (size_t p = 0; p < meshSystems.size(); p++) {
             const auto& meshPool = meshSystems[p]->getMeshComponentPool();
             auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
+            if (versioned && !versioned->reportsChanges)
+                versioned = nullptr;
             const uint64_t version = versioned ? versioned->meshVersion : 0, range = versioned ? versioned->rangeVersion : 0;
             structural = structural || !versioned || ranksSeen.meshVersion[p] != version || ranksSeen.meshRange[p] != range ||
                          ranksSeen.meshOccupancy[p] != meshPool.getOccupancy() || ranksSeen.meshCount[p] != meshPool.getCount();

@@ -294,6 +294,7 @@ int main(int argc, char** argv)
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
+    bool unversioned = false;  // --unversioned: the mesh systems carry no change counters (like every mesh system of the reference)
     bool hiz = false;        // --hiz: a depth image with walls is handed to both systems: the light pass of the non-UI systems runs the
                              // per-AABB occlusion query behind the frustum test (with --ranks: the pyramid is built on every rank)
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
@@ -325,6 +326,7 @@ int main(int argc, char** argv)
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
         else if (a == "--non-translucent") g_nonTranslucent = true;
         else if (a == "--hiz") hiz = true;
+        else if (a == "--unversioned") unversioned = true;
         else if (a == "--ranks" && i + 1 < argc) ranks = (uint32_t)atoi(argv[++i]);
         else if (a == "--world") world = true;
         else if (a == "--itemised") itemised = true;
@@ -431,6 +433,10 @@ int main(int argc, char** argv)
         }
         if (gpu && world)
             gpu->sweepWorldMatrices = gpu->sweepIncremental = true;
+        if (unversioned)
+            for (auto ms : allMeshSystems(manager))
+                if (auto versioned = dynamic_cast<VersionedMeshSystem*>(ms))
+                    versioned->reportsChanges = false;
         manager.initialize();
 
         // scene: SURVEY.md §8d distribution (cube side 100 * N^(1/3), scale [0.5,2], half-extent [0.25,1])
