@@ -1175,6 +1175,7 @@ int gv_stats_reset(GvCtx* ctx)
     memset(ctx->stats.launches, 0, sizeof(ctx->stats.launches));
     memset(ctx->stats.device_ms, 0, sizeof(ctx->stats.device_ms));
     ctx->stats.upload_bytes = 0;
+    ctx->stats.exchanges = ctx->stats.exchange_tail_rounds = 0;
     ctx->bounds_blocks_total = 0;
     memset(ctx->profile_seen, 0, sizeof(ctx->profile_seen));
     memset(ctx->profile_timed, 0, sizeof(ctx->profile_timed));
@@ -1259,5 +1260,11 @@ int gv_debug_stream_peak(GvCtx* ctx, uint32_t pool_id, uint32_t launches, double
 }
 
 void* gv_stream(GvCtx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+void gv_host_parallel_ranges(uint32_t first, uint32_t count, void (*fn)(void* user, uint32_t lo, uint32_t hi), void* user)
+{
+    if (fn && count)
+        parallel_ranges(first, count, [&](uint32_t lo, uint32_t hi) { fn(user, lo, hi); });
+}
 
 }  // extern "C"

@@ -200,6 +200,12 @@ struct PoolState {
     DirtyRange staging_stale;    // slots whose host staging entries lag behind the device (written by that path)
     DeviceBuf<uint32_t> d_index_map;  // gv_pool_set_index_map: pool slot -> the caller's global id (exchange shards)
     uint32_t index_map_count = 0;     // 0: none
+    std::vector<uint32_t> h_index_map;  // the same table on the host (the mapped write-back of isVisible walks it)
+    // gv_pool_set_result_mapping: results in the caller's WORLD numbering
+    uint32_t result_flags = 0;          // GV_RESULTS_MAP_*
+    uint8_t* visible_base = nullptr;    // GV_RESULTS_MAP_VISIBLE: byte of slot i -> visible_base + h_index_map[i] * visible_stride
+    size_t visible_stride = 0;
+    uint32_t visible_count = 0;
     // GV_CONFIG_BLOCK_BOUNDS: per-workgroup world boxes, valid for (bounds_xf_epoch, bounds_epoch)
     DeviceBuf<float4> d_blk_lo, d_blk_hi;
     DeviceBuf<uint8_t> d_blk_dirty;  // one byte per block: holds an entry re-mirrored since the boxes (and seeds) were last current
@@ -378,7 +384,12 @@ struct Context {
                                        // 1 + room[me] words, a completing exchange the tail behind them (both on exchange_stream)
         hipEvent_t produced = nullptr; // on ctx->stream behind the shard copy: exchange_stream waits for it
         hipEvent_t done = nullptr;     // on exchange_stream behind collective + headers (+ tails): GvExchangeFrame::ready_event
-        PinnedBuf<uint32_t> hdr;       // [world] counts + [1] sequence word, written by exchange_headers_kernel
+        PinnedBuf<uint32_t> hdr;       // [1] sequence word + [world][hdr_words] leading words of every row, written by exchange_headers_kernel
+        uint32_t hdr_words = 1;        // 1 (the count header) + the lists of a gv_exchange_views frame
+        uint32_t items = 0;            // gv_exchange_views: lists per rank in this slot's frame (0: a single-list frame)
+        std::vector<uint32_t> item_counts;  // settled: [world][items] per-list counts (GvExchangeFrame::item_counts)
+        PinnedBuf<ShardItem> h_items;  // the frame's list descriptors on their way to d_items
+        DeviceBuf<ShardItem> d_items;
         uint32_t row_words = 0;
         uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};        // list entries rank r's row was predicted to need in this slot's frame
         uint32_t travelled[GV_EXCHANGE_MAX_RANKS] = {};   // words of row r on the links in the first exchange

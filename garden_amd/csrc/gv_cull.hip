@@ -1839,7 +1839,7 @@ __device__ __forceinline__ void pack_records_chunk(uint4* stage, const uint32_t*
     if (threadIdx.x < live) {
         const uint32_t j = first + threadIdx.x;
         uint8_t* rec = reinterpret_cast<uint8_t*>(stage) + threadIdx.x * L.stride;
-        const unsigned long long offset = (unsigned long long)idx[j] * L.component_stride;  // componentOffset  mesh.cpp:170
+        const unsigned long long offset = (unsigned long long)record_slot(L, idx[j]) * L.component_stride;  // componentOffset  mesh.cpp:170
         uint32_t* w = reinterpret_cast<uint32_t*>(rec + L.component_offset);
         w[0] = (uint32_t)offset;
         w[1] = (uint32_t)(offset >> 32);

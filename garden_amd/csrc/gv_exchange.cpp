@@ -189,6 +189,11 @@ void exchange_release(GvCtx* ctx)
         slot.rows.release();
         slot.shard.release();
         slot.hdr.release();
+        slot.h_items.release();
+        slot.d_items.release();
+        slot.items = 0;
+        slot.hdr_words = 1;
+        slot.item_counts.clear();
         if (slot.produced)
             (void)hipEventDestroy(slot.produced);
         if (slot.done)
@@ -484,7 +489,7 @@ size_t row_words_for(uint32_t entries)
 int wait_for_headers(GvCtx* ctx, Slot& slot)
 {
     const uint32_t seq = (uint32_t)(slot.frame + 1);
-    volatile uint32_t* word = slot.hdr.ptr + ctx->exchange_world;
+    volatile uint32_t* word = slot.hdr.ptr;  // (a fixed place: whatever an earlier frame of another shape left there is an older number)
     const auto t0 = std::chrono::steady_clock::now();
     char text[384];
     for (uint32_t spins = 0; *word != seq; spins++) {
@@ -524,8 +529,12 @@ int settle_read(GvCtx* ctx, Slot& slot)
         return rc;
     slot.in_flight = false;
     slot.cut = 0;
+    slot.item_counts.assign((size_t)ctx->exchange_world * slot.items, 0u);
     for (int r = 0; r < ctx->exchange_world; r++) {
-        const uint32_t count = slot.hdr.ptr[r];
+        const uint32_t* row_head = slot.hdr.ptr + 1u + (size_t)r * slot.hdr_words;
+        const uint32_t count = row_head[0];
+        for (uint32_t i = 0; i < slot.items; i++)
+            slot.item_counts[(size_t)r * slot.items + i] = row_head[1u + i];
         slot.counts[r] = count;
         slot.tail_words[r] = 0;
         if (count > slot.room[r]) {
@@ -537,6 +546,8 @@ int settle_read(GvCtx* ctx, Slot& slot)
             ctx->exchange_room[r] = want;
     }
     slot.settled = slot.cut == 0;
+    if (slot.cut)
+        ctx->stats.exchange_tail_rounds++;
     return GV_OK;
 }
 
@@ -620,8 +631,10 @@ int tails_arrived(GvCtx* ctx, Slot& slot)
         const hipError_t e = hipEventQuery(slot.done);
         if (e == hipSuccess)
             return GV_OK;
-        if (e != hipErrorNotReady)
+        if (e != hipErrorNotReady) {
+            slot.settled = false;  // (rows whose tails are not known to have arrived are never handed out)
             return ctx->hip_fail(e, "gv_exchange: waiting for the tails of a frame with short rows");
+        }
         const auto waited = std::chrono::steady_clock::now() - t0;
         if (waited > std::chrono::milliseconds(ctx->exchange_timeout_ms)) {
             snprintf(text, sizeof(text), "exchange frame %llu: the tails of its short rows did not arrive within %u ms: a peer rank stalled or left; the "
@@ -689,23 +702,31 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
     return rc;
 }
 
-// A new frame, step 1 of 3: buffers, and this rank's whole list into the slot's staging shard on the context's stream.
-int frame_stage(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t index_base, Slot& slot)
+// A new frame, step 1 of 3: buffers, and this rank's whole list — or, batched (gv_exchange_views), ALL the frame's lists behind their
+// count table — into the slot's staging shard on the context's stream. items / item_count: the frame's (pool, view) pairs;
+// batched == false: one pair, no table (the single-list forms; pool GV_NONE = the pool of the most recent gv_cull).
+int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bool batched, Slot& slot)
 {
     GV_HIP(ctx, hipSetDevice(ctx->device));
-    const int me = ctx->exchange_rank, world = ctx->exchange_world;
-    if (pool_id == GV_NONE)
-        pool_id = ctx->last_pool;  // the view-indexed forms address the pool of the most recent gv_cull
-    gv::ViewState* vs = pool_id < GV_MAX_POOLS ? gv::view_of(ctx, pool_id, view_index) : nullptr;
-    if (!vs || !vs->emitted)
-        return ctx->fail(GV_E_ARG, "gv_exchange_visible: pool %u view %u has no emitted records", pool_id, view_index);
+    const int world = ctx->exchange_world;
+    size_t list_words = 0;  // what the whole shard can need: every list at its pool's occupancy
+    uint32_t widest_pool = 0;
+    for (uint32_t i = 0; i < item_count; i++) {
+        const uint32_t pool_id = items[i].pool_id == GV_NONE ? ctx->last_pool : items[i].pool_id;  // the view-indexed forms address the pool of the most recent gv_cull
+        gv::ViewState* vs = pool_id < GV_MAX_POOLS ? gv::view_of(ctx, pool_id, items[i].view_index) : nullptr;
+        if (!vs || !vs->emitted)
+            return ctx->fail(GV_E_ARG, "gv_exchange_visible: pool %u view %u has no emitted records", pool_id, items[i].view_index);
+        list_words += vs->occupancy;
+        widest_pool = std::max(widest_pool, vs->occupancy);
+    }
+    const uint32_t table_words = batched ? item_count : 0u;
     uint32_t widest = 0;
     for (int k = 0; k < world; k++)
         widest = std::max(widest, ctx->exchange_room[k]);
     const size_t row_words = row_words_for(widest);
     // the shard holds the WHOLE list (what a short prediction leaves behind travels later, from here); the equal-size all-gather
     // reads row_words words of it whatever the list's length
-    const size_t shard_words = std::max(row_words, (size_t)vs->occupancy + 1u);
+    const size_t shard_words = std::max(row_words, list_words + table_words + 1u);
     if ((size_t)world * row_words > slot.rows.cap || shard_words > slot.shard.cap) {
         // grown by half again: a list that creeps up does not reallocate every time. (The slot's previous frame is settled — its
         // collectives have run — but consumers of its rows may still be queued on the context's stream.)
@@ -719,8 +740,9 @@ int frame_stage(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t inde
         }
     }
     if (!slot.hdr.ptr) {
-        GV_HIP(ctx, slot.hdr.reserve(GV_EXCHANGE_MAX_RANKS + 1));
-        memset(slot.hdr.ptr, 0, (GV_EXCHANGE_MAX_RANKS + 1) * sizeof(uint32_t));
+        constexpr size_t kHdrWords = 1u + (size_t)GV_EXCHANGE_MAX_RANKS * (1u + GV_EXCHANGE_MAX_ITEMS);
+        GV_HIP(ctx, slot.hdr.reserve(kHdrWords));
+        memset(slot.hdr.ptr, 0, kHdrWords * sizeof(uint32_t));
     }
     for (int k = 0; k < world; k++) {
         slot.room[k] = ctx->exchange_room[k];
@@ -730,15 +752,35 @@ int frame_stage(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t inde
     slot.cut = 0;
     slot.row_words = (uint32_t)row_words;
     slot.mode = ctx->exchange_mode;
-    // The shard is the last thing the context's stream does for this frame's list; the links are the exchange stream's business.
+    slot.items = table_words;
+    slot.hdr_words = 1u + table_words;
+    slot.item_counts.clear();
+    // The shard is the last thing the context's stream does for this frame's lists; the links are the exchange stream's business.
     // The next frame's pyramid and cull go on behind the shard copy at once, while this list is still travelling. (The slot's shard
     // and rows are free: the frame that used them last is settled, which its collectives precede; and work that was enqueued on the
     // context's stream to CONSUME those rows completes in front of `produced`, which the exchange stream waits for.)
-    if (int rc = gv::copy_shard_of_pool(ctx, pool_id, view_index, slot.shard.ptr, vs->occupancy, index_base))
-        return rc;
+    if (!batched) {
+        const uint32_t pool_id = items[0].pool_id == GV_NONE ? ctx->last_pool : items[0].pool_id;
+        if (int rc = gv::copy_shard_of_pool(ctx, pool_id, items[0].view_index, slot.shard.ptr, gv::view_of(ctx, pool_id, items[0].view_index)->occupancy,
+                                            items[0].index_base))
+            return rc;
+    } else {
+        if (int rc = gv::flush_sorts(ctx))  // (recorded culls and deferred sorts of every list first)
+            return rc;
+        GV_HIP(ctx, slot.h_items.reserve(GV_EXCHANGE_MAX_ITEMS));
+        GV_HIP(ctx, slot.d_items.reserve(GV_EXCHANGE_MAX_ITEMS));
+        for (uint32_t i = 0; i < item_count; i++) {
+            const gv::ViewState& vs = *gv::view_of(ctx, items[i].pool_id, items[i].view_index);
+            const gv::PoolState& pool = ctx->pools[vs.pool_id];
+            slot.h_items.ptr[i] = gv::ShardItem{vs.visible_idx.ptr, vs.draw_count.ptr, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr,
+                                                items[i].index_base, vs.occupancy};
+        }
+        // (h_items of this slot is free: the copy that read it last ran in front of the slot's previous frame, which is settled)
+        GV_HIP(ctx, hipMemcpyAsync(slot.d_items.ptr, slot.h_items.ptr, (size_t)item_count * sizeof(gv::ShardItem), hipMemcpyHostToDevice, ctx->stream));
+        GV_HIP(ctx, gv::launch_copy_shard_batch(slot.d_items.ptr, item_count, widest_pool, slot.shard.ptr, ctx->stream));
+    }
     GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));
     GV_HIP(ctx, hipStreamWaitEvent(ctx->exchange_stream, slot.produced, 0));
-    (void)me;
     return GV_OK;
 }
 
@@ -760,6 +802,7 @@ void describe(const GvCtx* ctx, const Slot& slot, GvExchangeFrame* out)
     out->world_size = (uint32_t)ctx->exchange_world;
     out->frame = slot.frame;
     out->mode = slot.mode;
+    out->items = slot.items;
     for (int k = 0; k < ctx->exchange_world; k++) {
         out->room[k] = slot.room[k];
         out->travelled_words[k] = slot.travelled[k];
@@ -768,6 +811,7 @@ void describe(const GvCtx* ctx, const Slot& slot, GvExchangeFrame* out)
         return;  // (sent, not handed out: a completing exchange may still move the rows)
     out->gathered_device = slot.rows.ptr;
     out->ready_event = slot.done;
+    out->item_counts = slot.items ? slot.item_counts.data() : nullptr;
     out->cut_ranks = slot.cut;
     out->complete = 1;
     for (int k = 0; k < ctx->exchange_world; k++) {
@@ -781,18 +825,20 @@ int frame_finish(GvCtx* ctx, Slot& slot, GvExchangeFrame* out)
 {
     GV_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t frame = ctx->exchange_frame;
-    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, slot.row_words, (uint32_t)ctx->exchange_world, slot.hdr.ptr, (uint32_t)(frame + 1),
-                                            ctx->exchange_stream));
+    GV_HIP(ctx, gv::launch_exchange_headers(slot.rows.ptr, slot.row_words, (uint32_t)ctx->exchange_world, slot.hdr_words, slot.hdr.ptr,
+                                            (uint32_t)(frame + 1), ctx->exchange_stream));
     GV_HIP(ctx, hipEventRecord(slot.done, ctx->exchange_stream));
     slot.frame = frame;
     slot.in_flight = true;
     slot.settled = false;
     ctx->exchange_frame = frame + 1;
+    ctx->stats.exchanges++;
     describe(ctx, slot, out);
     return GV_OK;
 }
 
-int visible_all(GvCtx* const* ctxs, int n, uint32_t pool_id, const uint32_t* views, const uint32_t* bases, GvExchangeFrame* outs, bool by_group)
+// items_of(k): the lists rank k's frame carries (batched: the same table-fronted row shape on every rank)
+int exchange_all(GvCtx* const* ctxs, int n, const GvExchangeItem* const* items_of, uint32_t item_count, bool batched, GvExchangeFrame* outs, bool by_group)
 {
     Rccl& r = rccl();
     const uint64_t frame = ctxs[0]->exchange_frame;
@@ -813,7 +859,7 @@ int visible_all(GvCtx* const* ctxs, int n, uint32_t pool_id, const uint32_t* vie
             return rc;
     const unsigned which = (unsigned)(frame & 1u);
     for (int k = 0; k < n; k++)
-        if (int rc = frame_stage(ctxs[k], pool_id, views[k], bases ? bases[k] : 0u, ctxs[k]->exchange_slots[which]))
+        if (int rc = frame_stage(ctxs[k], items_of[k], item_count, batched, ctxs[k]->exchange_slots[which]))
             return rc;
     int rc = GV_OK;
     (void)r.GroupStart();
@@ -836,6 +882,31 @@ int visible_all(GvCtx* const* ctxs, int n, uint32_t pool_id, const uint32_t* vie
     for (int k = 0; k < n && rc == GV_OK; k++)
         rc = frame_finish(ctxs[k], ctxs[k]->exchange_slots[which], outs ? outs + k : nullptr);
     return rc;
+}
+
+int visible_all(GvCtx* const* ctxs, int n, uint32_t pool_id, const uint32_t* views, const uint32_t* bases, GvExchangeFrame* outs, bool by_group)
+{
+    GvExchangeItem single[GV_EXCHANGE_MAX_RANKS];
+    const GvExchangeItem* items_of[GV_EXCHANGE_MAX_RANKS];
+    for (int k = 0; k < n; k++) {
+        single[k] = GvExchangeItem{pool_id, views[k], bases ? bases[k] : 0u};
+        items_of[k] = &single[k];
+    }
+    return exchange_all(ctxs, n, items_of, 1, false, outs, by_group);
+}
+
+int views_all(GvCtx* const* ctxs, int n, const GvExchangeItem* items, uint32_t item_count, uint32_t flags, GvExchangeFrame* outs, bool by_group)
+{
+    if (!items || !outs || flags || item_count == 0 || item_count > GV_EXCHANGE_MAX_ITEMS)
+        return ctxs[0]->fail(GV_E_ARG, "gv_exchange_views: NULL items / frames, flags 0x%x (none are defined) or %u items (1 .. %u)", flags, item_count,
+                             GV_EXCHANGE_MAX_ITEMS);
+    for (uint32_t i = 0; i < item_count; i++)
+        if (items[i].pool_id >= GV_MAX_POOLS || items[i].view_index >= GV_MAX_VIEWS)
+            return ctxs[0]->fail(GV_E_ARG, "gv_exchange_views: item %u names pool %u view %u", i, items[i].pool_id, items[i].view_index);
+    const GvExchangeItem* items_of[GV_EXCHANGE_MAX_RANKS];
+    for (int k = 0; k < n; k++)
+        items_of[k] = items;
+    return exchange_all(ctxs, n, items_of, item_count, true, outs, by_group);
 }
 
 int acquire_all(GvCtx* const* ctxs, int n, uint64_t frame, GvExchangeFrame* outs, bool by_group)
@@ -940,6 +1011,21 @@ int gv_pool_exchange_visible_all(GvCtx* const* contexts, int world_size, uint32_
     if (!view_indices || !frames || flags || pool_id >= GV_MAX_POOLS)
         return contexts[0]->fail(GV_E_ARG, "gv_pool_exchange_visible_all: NULL view indices / frames, flags 0x%x (none are defined) or pool %u", flags, pool_id);
     return visible_all(contexts, world_size, pool_id, view_indices, index_bases, frames, true);
+}
+
+int gv_exchange_views(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, uint32_t flags, GvExchangeFrame* out)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    return views_all(&ctx, 1, items, item_count, flags, out, false);
+}
+
+int gv_exchange_views_all(GvCtx* const* contexts, int world_size, const GvExchangeItem* items, uint32_t item_count, uint32_t flags,
+                          GvExchangeFrame* frames)
+{
+    if (int rc = all_args(contexts, world_size))
+        return rc;
+    return views_all(contexts, world_size, items, item_count, flags, frames, true);
 }
 
 int gv_exchange_acquire(GvCtx* ctx, uint64_t frame, GvExchangeFrame* out)

@@ -184,10 +184,19 @@ hipError_t launch_copy_idx(const uint32_t* src, const uint32_t* count, uint32_t*
                            const uint32_t* map, hipStream_t stream);
 hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_t* dst, uint32_t capacity, uint32_t base,
                              const uint32_t* map, hipStream_t stream);
-// gv_exchange_visible: the headers (true counts) of all `world` gathered rows, then `seq`, into pinned host memory
-// (host_words[0 .. world) = rows[r * row_words], host_words[world] = seq with system-scope release): the host learns the
-// counts of a frame without an event record or a synchronisation — it looks at the word a frame or two later
-hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+// gv_exchange_views: every list of a frame into ONE shard [n + total, c_0 .. c_{n-1}, list 0, list 1 ...] (gv_shard.hip)
+struct ShardItem {
+    const uint32_t* src;    // the view's visible_idx
+    const uint32_t* count;  // its device draw count
+    const uint32_t* map;    // pool slot -> caller's global id (NULL: identity)
+    uint32_t base, capacity;
+};
+hipError_t launch_copy_shard_batch(const ShardItem* device_items, uint32_t n, uint32_t widest, uint32_t* dst, hipStream_t stream);
+// gv_exchange_visible / _views: the leading hdr_words words of all `world` gathered rows (the true counts; the per-list counts of
+// a batched frame), then `seq`, into pinned host memory (host_words[1 + r * hdr_words + w] = rows[r * row_words + w], host_words[0]
+// = seq with system-scope release): the host learns the counts of a frame without an event record or a synchronisation — it
+// looks at the word a frame or two later
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t hdr_words, uint32_t* host_words, uint32_t seq,
                                    hipStream_t stream);
 // gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
@@ -196,7 +205,11 @@ constexpr uint32_t kPublishLdsSlots = 32768;
 // the caller's record struct (GvRecordLayout); stride == 0: none
 struct RecordLayout {
     uint32_t stride, component_offset, baked_model, distance_sq, buffer_index, component_stride, buffer_index_value;
+    uint32_t pad_;
+    const uint32_t* slot_map;  // GV_RESULTS_MAP_RECORDS: componentOffset = slot_map[slot] * component_stride (NULL: slot itself); filled in
+                               // when results are delivered, never kept in PoolState::record_layout
 };
+__host__ __device__ inline uint32_t record_slot(const RecordLayout& L, uint32_t slot) { return L.slot_map ? L.slot_map[slot] : slot; }
 constexpr uint32_t kMaxRecordStride = 128;
 struct PublishArgs {
     const uint32_t* count;  // device draw_count

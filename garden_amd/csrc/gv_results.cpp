@@ -125,6 +125,7 @@ int wait_for_stream(GvCtx* ctx)
 // pool's record structs — in the library's pinned buffer or the caller's own page-locked array) and, for a main pass, the
 // isVisible bytes in pool-slot order. Buffers are reserved here; used by the publish launch of gv_pool_results_fetch and by the
 // small-pool sort, which publishes what it has just sorted.
+static int delivered_layout(GvCtx* ctx, const PoolState& pool, uint32_t pool_id, uint32_t occupancy, RecordLayout& L);
 int publish_args_of(GvCtx* ctx, uint32_t pid, uint32_t v, PublishArgs& a)
 {
     PoolState& wp = ctx->pools[pid];
@@ -153,7 +154,8 @@ int publish_args_of(GvCtx* ctx, uint32_t pid, uint32_t v, PublishArgs& a)
         }
         w.records_at = target.host ? target.host : w.h_records.ptr;
         w.records_staged = target.host && !target.dev;  // not page-locked: filled from h_records after the synchronisation
-        a.layout = wp.record_layout;
+        if (int rc = delivered_layout(ctx, wp, pid, w.occupancy, a.layout))
+            return rc;
         w.records_fetched = true;
     } else if (w.emitted) {
         GV_HIP(ctx, w.h_visible_idx.reserve(w.occupancy));
@@ -257,6 +259,20 @@ int flush_sorts(GvCtx* ctx)
             }
         }
     }
+}
+
+// The pool's record layout as the kernels take it: with GV_RESULTS_MAP_RECORDS the records carry the caller's WORLD slots.
+static int delivered_layout(GvCtx* ctx, const PoolState& pool, uint32_t pool_id, uint32_t occupancy, RecordLayout& L)
+{
+    L = pool.record_layout;
+    L.slot_map = nullptr;
+    if (pool.result_flags & GV_RESULTS_MAP_RECORDS) {
+        if (pool.index_map_count < occupancy)
+            return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u delivers records in world slots (gv_pool_set_result_mapping), but its index map covers %u of "
+                             "%u slots", pool_id, pool.index_map_count, occupancy);
+        L.slot_map = pool.d_index_map.ptr;
+    }
+    return GV_OK;
 }
 
 ViewState* view_of(GvCtx* ctx, uint32_t pool_id, uint32_t view_index)
@@ -427,7 +443,10 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         if (vs.emitted && count && pool.record_layout.stride) {  // packed on the device, one copy
             const size_t bytes = (size_t)count * pool.record_layout.stride;
             GV_HIP(ctx, vs.d_records.reserve((size_t)vs.occupancy * pool.record_layout.stride));
-            GV_HIP(ctx, launch_pack_records(vs.draw_count.ptr, vs.visible_idx.ptr, vs.baked_model.ptr, vs.distance_sq.ptr, pool.record_layout,
+            RecordLayout delivered;
+            if ((rc = delivered_layout(ctx, pool, pool_id, vs.occupancy, delivered)) != GV_OK)
+                return rc;
+            GV_HIP(ctx, launch_pack_records(vs.draw_count.ptr, vs.visible_idx.ptr, vs.baked_model.ptr, vs.distance_sq.ptr, delivered,
                                             count, vs.d_records.ptr, ctx->stream));
             uint8_t* dst = target.dev ? target.host : vs.h_records.ptr;
             staged_for = target.host && !target.dev ? target.host : nullptr;
@@ -466,6 +485,9 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
         out->baked_model = vs.h_baked_model.ptr;
         out->distance_sq = vs.h_distance_sq.ptr;
     }
+    if (pool.ready.ptr && pool.result_flags)
+        return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u has a ready column AND a result mapping (records / isVisible in world slots): not available "
+                         "together", pool_id);
     if (pool.ready.ptr && pool.bound && pool.occupancy == vs.occupancy && count) {
         // instanceCount += readyCount (mesh.cpp:174): the drawn meshes' own counts, summed over the fetched list (or, for
         // a count-only main pass, over the isVisible bytes); a count-only shadow view keeps draw_count
@@ -516,7 +538,22 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             component_stride = pool.is_visible_stride;
         }
         uint8_t* out_vis = vs.h_is_visible.ptr;
-        if (component_vis)
+        if (write_back && (pool.result_flags & GV_RESULTS_MAP_VISIBLE)) {
+            // straight into the caller's WORLD pool, through the share's slot -> world slot table (holes and slots past the world's
+            // occupancy are skipped); ranks own disjoint world slots
+            if (pool.h_index_map.size() < vs.occupancy || !pool.visible_base)
+                return ctx->fail(GV_E_STATE, "gv_results_fetch: pool %u writes isVisible through its index map (gv_pool_set_result_mapping), which covers %zu "
+                                 "of %u slots", pool_id, pool.h_index_map.size(), vs.occupancy);
+            const uint32_t* map = pool.h_index_map.data();
+            uint8_t* base = pool.visible_base;
+            const size_t stride = pool.visible_stride;
+            const uint32_t limit = pool.visible_count;
+            parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
+                for (uint32_t i = a; i < b; i++)
+                    if (map[i] < limit)  // (GV_NONE: a hole)
+                        base[(size_t)map[i] * stride] = out_vis[i];
+            });
+        } else if (component_vis)
             parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
                 for (uint32_t i = a; i < b; i++)
                     component_vis[(size_t)i * component_stride] = out_vis[i];
@@ -550,7 +587,7 @@ int gv_pool_set_record_layout(GvCtx* ctx, uint32_t pool_id, const GvRecordLayout
                              "fields must be 4-byte aligned, inside the record and disjoint", stride, kMaxRecordStride,
                              layout->component_offset, layout->baked_model, layout->distance_sq, layout->buffer_index);
         L = RecordLayout{stride, layout->component_offset, layout->baked_model, layout->distance_sq, layout->buffer_index,
-                         layout->component_stride, layout->buffer_index_value};
+                         layout->component_stride, layout->buffer_index_value, 0u, nullptr};
     }
     if (memcmp(&ctx->pools[pool_id].record_layout, &L, sizeof(L)) == 0)
         return GV_OK;  // set every frame by callers that re-bind every frame
@@ -802,6 +839,53 @@ int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_i
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's (pageable) table may go away
     }
     p.index_map_count = count;
+    p.h_index_map.assign(global_ids, global_ids + count);
+    for (uint32_t v = 0; v < GV_MAX_VIEWS; v++)  // records that carry mapped slots are delivered again
+        if (p.result_flags & GV_RESULTS_MAP_RECORDS)
+            ctx->views[pool_id][v].published = false, ctx->views[pool_id][v].records_fetched = false;
+    return GV_OK;
+}
+
+int gv_pool_update_index_map(GvCtx* ctx, uint32_t pool_id, uint32_t first, const uint32_t* global_ids, uint32_t count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || (count && !global_ids) || (uint64_t)first + count > 0xFFFFFFFFull)
+        return ctx->fail(GV_E_ARG, "gv_pool_update_index_map: bad argument (pool %u, first %u, count %u)", pool_id, first, count);
+    if (count == 0)
+        return GV_OK;
+    PoolState& p = ctx->pools[pool_id];
+    if (first > p.index_map_count)
+        return ctx->fail(GV_E_ARG, "gv_pool_update_index_map: first %u leaves a gap behind the table's %u entries", first, p.index_map_count);
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t end = first + count;
+    if (end > p.index_map_count) {
+        GV_HIP(ctx, p.d_index_map.grow(end, p.index_map_count, ctx->stream));
+        p.index_map_count = end;
+        p.h_index_map.resize(end, GV_NONE);
+    }
+    std::copy(global_ids, global_ids + count, p.h_index_map.begin() + first);
+    // (out of the library's own host copy, which stays put; stream order keeps queued readers of the old entries in front)
+    GV_HIP(ctx, hipMemcpyAsync(p.d_index_map.ptr + first, p.h_index_map.data() + first, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (pageable source: the runtime may still be reading it)
+    return GV_OK;
+}
+
+int gv_pool_set_result_mapping(GvCtx* ctx, uint32_t pool_id, uint32_t flags, void* visible_base, size_t visible_stride, uint32_t visible_count)
+{
+    if (!ctx)
+        return GV_E_ARG;
+    if (pool_id >= GV_MAX_POOLS || (flags & ~(GV_RESULTS_MAP_RECORDS | GV_RESULTS_MAP_VISIBLE)) ||
+        ((flags & GV_RESULTS_MAP_VISIBLE) && (!visible_base || !visible_stride)))
+        return ctx->fail(GV_E_ARG, "gv_pool_set_result_mapping: pool %u, flags 0x%x, visible base %p stride %zu", pool_id, flags, visible_base, visible_stride);
+    PoolState& p = ctx->pools[pool_id];
+    if ((p.result_flags ^ flags) & GV_RESULTS_MAP_RECORDS)
+        for (uint32_t v = 0; v < GV_MAX_VIEWS; v++)  // the next fetch delivers this pool's records again, in the other numbering
+            ctx->views[pool_id][v].published = false, ctx->views[pool_id][v].records_fetched = false;
+    p.result_flags = flags;
+    p.visible_base = (flags & GV_RESULTS_MAP_VISIBLE) ? static_cast<uint8_t*>(visible_base) : nullptr;
+    p.visible_stride = (flags & GV_RESULTS_MAP_VISIBLE) ? visible_stride : 0;
+    p.visible_count = (flags & GV_RESULTS_MAP_VISIBLE) ? visible_count : 0;
     return GV_OK;
 }
 

@@ -45,23 +45,70 @@ hipError_t launch_mask_shard(const unsigned long long* ballots, const uint8_t* b
     return hipGetLastError();
 }
 
-// The count header of every gathered row -> pinned host memory, then the frame's sequence number behind a system-scope
-// release: what gv_exchange_visible sizes the next frames' shards from (gv_exchange.cpp). One wave.
-__global__ __launch_bounds__(64) void exchange_headers_kernel(const uint32_t* __restrict__ rows, uint32_t row_words, uint32_t world,
-                                                             uint32_t* __restrict__ host_words, uint32_t seq)
+// gv_exchange_views: ALL the lists of a frame into one shard — dst = [n + total, c_0 .. c_{n-1}, list 0, list 1 ...], every list
+// as copy_shard_kernel writes it (index map, base). blockIdx.y = item; each workgroup derives its list's place from the counts in
+// front of it (n <= 128 words: one wave).
+__global__ __launch_bounds__(256) void copy_shard_batch_kernel(const ShardItem* __restrict__ items, uint32_t n, uint32_t* __restrict__ dst)
 {
-    for (uint32_t r = threadIdx.x; r < world; r += 64)
-        __hip_atomic_store(host_words + r, rows[(size_t)r * row_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ uint32_t s_offset, s_count;
+    const uint32_t i = blockIdx.y;
+    if (threadIdx.x < 64) {
+        uint32_t before = 0, total = 0;
+        for (uint32_t k = threadIdx.x; k < n; k += 64) {
+            const uint32_t c = min(*items[k].count, items[k].capacity);
+            total += c;
+            before += k < i ? c : 0u;
+        }
+        for (int off = 32; off; off >>= 1) {
+            before += __shfl_down(before, off);
+            total += __shfl_down(total, off);
+        }
+        if (threadIdx.x == 0) {
+            s_offset = 1u + n + before;
+            s_count = min(*items[i].count, items[i].capacity);
+            if (blockIdx.x == 0) {
+                dst[1u + i] = s_count;
+                if (i == 0)
+                    dst[0] = n + total;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t* __restrict__ src = items[i].src;
+    const uint32_t* __restrict__ map = items[i].map;
+    const uint32_t base = items[i].base, count = s_count;
+    uint32_t* __restrict__ out = dst + s_offset;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256)
+        out[j] = (map ? map[src[j]] : src[j]) + base;
+}
+
+hipError_t launch_copy_shard_batch(const ShardItem* device_items, uint32_t n, uint32_t widest, uint32_t* dst, hipStream_t stream)
+{
+    const uint32_t blocks = std::max(1u, std::min(2048u, (widest + 255u) / 256u));
+    hipLaunchKernelGGL(copy_shard_batch_kernel, dim3(blocks, n), dim3(256), 0, stream, device_items, n, dst);
+    return hipGetLastError();
+}
+
+// The leading `hdr_words` words of every gathered row (the count header, and behind it the per-list counts of a gv_exchange_views
+// frame) -> pinned host memory, then the frame's sequence number behind a system-scope release: what gv_exchange_visible sizes the
+// next frames' shards from (gv_exchange.cpp). host_words[0] = seq, host_words[1 + r * hdr_words + w] = word w of row r.
+__global__ __launch_bounds__(256) void exchange_headers_kernel(const uint32_t* __restrict__ rows, uint32_t row_words, uint32_t world, uint32_t hdr_words,
+                                                              uint32_t* __restrict__ host_words, uint32_t seq)
+{
+    for (uint32_t k = threadIdx.x; k < world * hdr_words; k += 256) {
+        const uint32_t r = k / hdr_words, w = k - r * hdr_words;
+        __hip_atomic_store(host_words + 1u + k, rows[(size_t)r * row_words + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store(host_words + world, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t hdr_words, uint32_t* host_words, uint32_t seq,
                                    hipStream_t stream)
 {
-    hipLaunchKernelGGL(exchange_headers_kernel, dim3(1), dim3(64), 0, stream, rows, row_words, world, host_words, seq);
+    hipLaunchKernelGGL(exchange_headers_kernel, dim3(1), dim3(256), 0, stream, rows, row_words, world, hdr_words, host_words, seq);
     return hipGetLastError();
 }
 

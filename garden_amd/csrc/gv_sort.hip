@@ -471,7 +471,7 @@ __device__ __forceinline__ void publish_record(const PublishArgs& a, uint32_t ra
         const uint32_t words = L.stride >> 2;
         for (uint32_t k = 0; k < words; k++)
             stage[k] = 0;
-        const unsigned long long offset = (unsigned long long)idx * L.component_stride;  // componentOffset  mesh.cpp:170
+        const unsigned long long offset = (unsigned long long)record_slot(L, idx) * L.component_stride;  // componentOffset  mesh.cpp:170
         stage[L.component_offset >> 2] = (uint32_t)offset;
         stage[(L.component_offset >> 2) + 1] = (uint32_t)(offset >> 32);
         uint32_t* bm = stage + (L.baked_model >> 2);

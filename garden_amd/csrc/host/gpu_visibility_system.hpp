@@ -51,12 +51,15 @@ private:
     RankShares rankShares;
     uint32_t rankGrid[3] = {1, 1, 1};
     double worldSide = 0.0;
-    struct RanksSeen {  // what the shares were dealt from: any change re-deals
+    struct RanksSeen {  // what the shares were dealt from: entities / components that came or went, or a parent link that moved, re-deal
         uint64_t hierarchy = ~0ull, reparent = ~0ull;
         uint32_t transformOccupancy = ~0u, transformCount = ~0u;
-        std::vector<uint64_t> meshVersion, meshRange;
+        std::vector<IMeshRenderSystem*> meshSystems;
+        std::vector<uint64_t> meshVersion;  // VersionedMeshSystem::meshVersion ("the whole pool may have changed": compared slot by slot)
         std::vector<uint32_t> meshOccupancy, meshCount;
     } ranksSeen;
+    RankShares::Changes rankChanges;
+    bool exchangeModeChosen = false;
     std::vector<IMeshRenderSystem*> meshSystems;  // prepareSystems(), mesh.cpp:69-108
     // mesh.hpp:219-223: one UnsortedBuffer per Color/Opaque/OIT/Refracted/TransDepth system; Translucent and UI
     // systems get a SortedBuffer each (counters) and share transSortedMeshes / uiSortedMeshes (records)
@@ -78,8 +81,14 @@ private:
 
     void check(int rc, const char* what)
     {
-        if (rc != GV_OK)
-            throw GardenError(std::string(what) + " failed: " + gv_last_error(ctx));
+        if (rc == GV_OK)
+            return;
+        // a call over all ranks (gv_exchange_*_all) leaves its text on the context of the rank that failed
+        const char* text = gv_last_error(ctx);
+        for (auto c : contexts)
+            if (text[0] == 0 && gv_last_error(c)[0] != 0)
+                text = gv_last_error(c);
+        throw GardenError(std::string(what) + " failed: " + text);
     }
 
 public:
@@ -87,6 +96,9 @@ public:
     struct TickSeconds {
         double total = 0, cull = 0, sort = 0, fetch = 0, records = 0, share = 0, gather = 0;  // records: filling combinedMeshes from the fetch; share / gather: several ranks
     } tickSeconds;
+    struct RankCounters {  // several ranks: what keeping the shares current took since the system was made
+        uint64_t frames = 0, deals = 0, exchanges = 0, movedTrees = 0, movedTransforms = 0, editedMeshes = 0, copiedTransforms = 0;
+    } rankCounters;
     struct Stopwatch {
         double& sink;
         std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
@@ -123,10 +135,23 @@ public:
     // frame without transform changes, only the subtrees under moved / re-parented transforms are re-swept otherwise)
     bool sweepIncremental = false;
 
-    // Multi-GPU mode: called after every (mesh system, pass) of a frame has been gathered — frames[r] is rank r's acquired
-    // GvExchangeFrame: on every device, every rank's complete list of WORLD mesh slots for that pass (rows valid until the exchange
-    // after the next). A GPU-driven renderer enqueues its per-device work here; the host-side buffers are filled afterwards.
-    std::function<void(uint32_t meshSystemIndex, int8_t shadowPass, const GvExchangeFrame* frames, uint32_t ranks)> onGathered;
+    // Multi-GPU mode: called ONCE per frame, after the frame's one exchange (gv_exchange_views_all) has been acquired — list i of the
+    // frame is (mesh system lists[i].meshSystemIndex, pass lists[i].shadowPass: -1 the light pass); frames[r] is rank r's acquired
+    // GvExchangeFrame: on every device, every rank's complete lists of WORLD mesh slots (row layout: include/garden_vis.h,
+    // gv_exchange_views). A GPU-driven renderer enqueues its per-device work here ON gv_stream(getContext(r)) — the acquire has ordered
+    // that stream behind the rows, and the rows stay valid until the exchange after the next, i.e. through the next frame; a
+    // consumer on a stream of its own waits for frames[r].ready_event and must be done before the frame after the next is sent.
+    // The host-side buffers are filled afterwards.
+    struct GatheredList {
+        uint32_t meshSystemIndex;
+        int8_t shadowPass;
+    };
+    std::function<void(const GatheredList* lists, uint32_t listCount, const GvExchangeFrame* frames, uint32_t ranks)> onGathered;
+    // Several ranks: time each travel pattern of the exchange (all-gather / send-recv pairs / one broadcast per root) over the first
+    // frames and keep the fastest (SURVEY.md §8e argues for the direct patterns on a fully connected node; only a node can tell).
+    bool probeExchangeMode = false;
+    // Several ranks: roots whose position has crossed into a cell of another rank take their trees there (rank_shares.hpp moveTree)
+    bool rebinMovedRoots = true;
 
     // blockBounds: GV_CONFIG_BLOCK_BOUNDS — worth it when most of the world is static (same results either way)
     explicit GpuVisibilitySystem(int device = 0, bool profile = false, bool blockBounds = false)
@@ -168,8 +193,7 @@ public:
     }
     ~GpuVisibilitySystem() override
     {
-        // the contexts first: gv_destroy synchronises the stream and un-registers every record target, so no queued publish /
-        // sort can still write into a combinedMeshes array (GV_DEBUG_RECORD_TARGET_PAGE_LOCK) and no target outlives its array
+        // the contexts first: gv_destroy synchronises the stream and lets every record target go: no target outlives its array
         if (contexts.size() > 1)
             for (auto c : contexts)
                 (void)gv_exchange_shutdown(c);
@@ -386,6 +410,134 @@ private:
             std::inplace_merge(combined.begin(), combined.begin() + runEnds[i - 1], combined.begin() + runEnds[i]);
     }
 
+    // ---- what a frame culls ----
+    // One entry per mesh system, in meshSystems order: prepareMeshes' classification (mesh.cpp:341-375, :414), the bufferIndex each
+    // system takes (:416-421), the gate pass by pass (:426 / :482) and, behind it, the views that are culled. BOTH frame paths (one
+    // context, several ranks) are driven by this table.
+    struct SystemPlan {
+        IMeshRenderSystem* meshSystem = nullptr;
+        MeshRenderType type = MeshRenderType::Opaque;
+        bool sorted = false;
+        uint32_t bufferIndex = 0;   // in the light pass: Translucent and UI systems count (mesh.cpp:419)
+        uint32_t shadowIndex = 0;   // in a shadow pass: a UI system leaves the loop before it takes one (:416-417)
+        uint32_t occupancy = 0;
+        std::vector<GvView> views;   // the passes that get through the gate, the light pass first
+        std::vector<int8_t> passes;  // views[v] stands for: -1 the light pass, s >= 0 shadow pass s (position in shadowPasses)
+    };
+    std::vector<SystemPlan> plan;
+    uint32_t planPassCount = 0;
+
+    void classifyAndGate()
+    {
+        const auto& cc = GraphicsSystem::Instance::get()->getCommonConstants();
+        const uint32_t passCount = planPassCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
+        transDrawIndex = uiDrawIndex = 0;                  // mesh.cpp:337
+        hasAnyRefr = hasAnyOIT = hasAnyTD = false;         // mesh.cpp:339
+        shadowTransMeshes.resize(passCount);
+        shadowTransDrawIndex.assign(passCount, 0);
+        shadowSortedBuffers.resize(passCount);
+        plan.assign(meshSystems.size(), SystemPlan{});
+        uint32_t sortedSeen = 0, shadowSortedSeen = 0, unsortedSeen = 0;
+        for (uint32_t p = 0; p < meshSystems.size(); p++) {
+            SystemPlan& sp = plan[p];
+            auto meshSystem = sp.meshSystem = meshSystems[p];
+            const auto renderType = sp.type = meshSystem->getMeshRenderType();
+            const auto& componentPool = meshSystem->getMeshComponentPool();        // mesh.cpp:410
+            const uint32_t componentCount = componentPool.getCount();              // mesh.cpp:411
+            sp.occupancy = componentPool.getOccupancy();
+            sp.sorted = isSortedType(renderType);
+            // bufferIndex: in the light pass Translucent and UI systems count (mesh.cpp:419); in a shadow pass a UI system leaves the
+            // loop before it takes one (:416-417), so a Translucent system's index there counts Translucent systems only
+            if (sp.sorted) {
+                sp.bufferIndex = sortedSeen++;
+                if (renderType == MeshRenderType::Translucent)
+                    sp.shadowIndex = shadowSortedSeen++;
+            } else {
+                sp.bufferIndex = sp.shadowIndex = unsortedSeen++;
+                auto& sb = shadowBuffers[sp.bufferIndex];
+                while (sb.size() < passCount)
+                    sb.push_back(new UnsortedBuffer());
+            }
+            // The gate of mesh.cpp:426 / :482, pass by pass: `componentCount == 0 || !meshSystem->isDrawReady(shadowPass)` leaves the
+            // system's counters at 0 for that pass and touches nothing else — in the light pass isVisible keeps last frame's bytes.
+            // The light pass (shadowPass -1: writes isVisible), then the shadow passes (mesh.cpp:809-843). UI: its own ortho
+            // frustum, camera at the origin, 2D distance key, no shadow passes (mesh.cpp:416,436-442).
+            const bool lightPass = componentCount != 0 && meshSystem->isDrawReady(-1);
+            if (lightPass) {
+                if (renderType == MeshRenderType::UI)
+                    sp.views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
+                else
+                    sp.views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz && isHizEnabled, emitRecords));
+                sp.passes.push_back(-1);
+                if (!sp.sorted) {  // mesh.cpp:488-490
+                    hasAnyRefr |= renderType == MeshRenderType::Refracted;
+                    hasAnyOIT |= renderType == MeshRenderType::OIT;
+                    hasAnyTD |= renderType == MeshRenderType::TransDepth;
+                }
+            }
+            if (renderType != MeshRenderType::UI)
+                for (uint32_t s = 0; s < passCount; s++)
+                    if (componentCount != 0 && meshSystem->isDrawReady(shadowPasses[s].index(s))) {
+                        sp.views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), false, emitRecords));
+                        sp.passes.push_back((int8_t)s);
+                    }
+            // (no view: no pass draws this system this frame — nothing is culled, sorted or read for it: `continue`, mesh.cpp:427 / :483)
+        }
+        for (uint32_t s = 0; s < passCount; s++)
+            while (shadowSortedBuffers[s].size() < shadowSortedSeen)
+                shadowSortedBuffers[s].push_back(new SortedBuffer());
+        // Every buffer of every pass in the state mesh.cpp:420-424 / :476-480 leave it in — its system, both counters 0; only the
+        // passes that are culled fill theirs.
+        auto reset = [](MeshBuffer* buffer, IMeshRenderSystem* meshSystem) {
+            buffer->meshSystem = meshSystem;
+            buffer->drawCount = 0;
+            buffer->instanceCount = 0;
+        };
+        for (const SystemPlan& sp : plan) {
+            if (sp.sorted) {
+                reset(sortedBuffers[sp.bufferIndex], sp.meshSystem);
+                if (sp.type == MeshRenderType::Translucent)
+                    for (uint32_t s = 0; s < passCount; s++)
+                        reset(shadowSortedBuffers[s][sp.shadowIndex], sp.meshSystem);
+            } else {
+                reset(unsortedBuffers[sp.bufferIndex], sp.meshSystem);
+                unsortedBuffers[sp.bufferIndex]->span = nullptr;
+                for (uint32_t s = 0; s < passCount; s++) {
+                    reset(shadowBuffers[sp.bufferIndex][s], sp.meshSystem);
+                    shadowBuffers[sp.bufferIndex][s]->span = nullptr;
+                }
+            }
+        }
+    }
+
+    // the engine's record struct of system p as the library's layout; false: not expressible (the three-array fetch is kept)
+    bool recordLayoutOfSystem(const SystemPlan& sp, GvRecordLayout& layout) const
+    {
+        const size_t componentSize = sp.meshSystem->getMeshComponentSize();
+        const bool expressible = sp.sorted ? recordLayoutOf<SortedMesh>(layout, componentSize, (uint32_t)offsetof(SortedMesh, bufferIndex), sp.bufferIndex)
+                                           : recordLayoutOf<UnsortedMesh>(layout, componentSize, GV_NONE, 0);
+        return emitRecords && recordStructs && expressible;
+    }
+
+    static const GvTransformLayout& transformLayout()
+    {
+        static const GvTransformLayout layout = {
+            (uint32_t)offsetof(TransformComponent, entity), (uint32_t)offsetof(TransformComponent, parent),
+            (uint32_t)offsetof(TransformComponent, posChildCount), (uint32_t)offsetof(TransformComponent, scaleChildCap),
+            (uint32_t)offsetof(TransformComponent, rotation), (uint32_t)offsetof(TransformComponent, selfActive),
+            (uint32_t)offsetof(TransformComponent, ancestorsActive),
+            (uint32_t)offsetof(TransformComponent, modelWithAncestors)};
+        return layout;
+    }
+    static const GvMeshLayout& meshLayout()
+    {
+        static const GvMeshLayout layout = {
+            (uint32_t)offsetof(MeshRenderComponent, entity), (uint32_t)offsetof(MeshRenderComponent, isEnabled),
+            (uint32_t)offsetof(MeshRenderComponent, isVisible), (uint32_t)offsetof(MeshRenderComponent, aabb.min),
+            (uint32_t)offsetof(MeshRenderComponent, aabb.max)};
+        return layout;
+    }
+
     // preForwardRender / preDeferredRender, mesh.cpp:860-903: shadows first, then the main camera.
     void preRender()
     {
@@ -396,25 +548,14 @@ private:
             return;
         }
         auto transformSystem = TransformSystem::Instance::get();
-        auto graphicsSystem = GraphicsSystem::Instance::get();
         Stopwatch whole(tickSeconds.total);
         prepareSystems();
         bool sweepRequested = false;
 
         // Pools may have moved (create() can reallocate): re-bind every frame, as `gv_pool_bind` documents.
-        static const GvTransformLayout transformLayout = {
-            (uint32_t)offsetof(TransformComponent, entity), (uint32_t)offsetof(TransformComponent, parent),
-            (uint32_t)offsetof(TransformComponent, posChildCount), (uint32_t)offsetof(TransformComponent, scaleChildCap),
-            (uint32_t)offsetof(TransformComponent, rotation), (uint32_t)offsetof(TransformComponent, selfActive),
-            (uint32_t)offsetof(TransformComponent, ancestorsActive),
-            (uint32_t)offsetof(TransformComponent, modelWithAncestors)};
-        static const GvMeshLayout meshLayout = {
-            (uint32_t)offsetof(MeshRenderComponent, entity), (uint32_t)offsetof(MeshRenderComponent, isEnabled),
-            (uint32_t)offsetof(MeshRenderComponent, isVisible), (uint32_t)offsetof(MeshRenderComponent, aabb.min),
-            (uint32_t)offsetof(MeshRenderComponent, aabb.max)};
         auto& pool = transformSystem->getComponents();
         auto& entityMap = transformSystem->getEntityMap();
-        check(gv_transform_bind(ctx, pool.getData(), sizeof(TransformComponent), pool.getOccupancy(), &transformLayout,
+        check(gv_transform_bind(ctx, pool.getData(), sizeof(TransformComponent), pool.getOccupancy(), &transformLayout(),
                                 entityMap.data(), (uint32_t)entityMap.size()), "gv_transform_bind");
         if (seenHierarchy != transformSystem->hierarchyVersion) {
             check(gv_mark_dirty(ctx, GV_DIRTY_HIERARCHY, 0, 0), "gv_mark_dirty");  // entities came or went
@@ -442,57 +583,26 @@ private:
         transformSystem->clearFlagsRange();
         transformSystem->clearMovedRanges();
 
-        const auto& cc = graphicsSystem->getCommonConstants();
-        const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
-        transDrawIndex = uiDrawIndex = 0;                  // mesh.cpp:337
-        hasAnyRefr = hasAnyOIT = hasAnyTD = false;         // mesh.cpp:339
-        shadowTransMeshes.resize(passCount);
-        shadowTransDrawIndex.assign(passCount, 0);
-        shadowSortedBuffers.resize(passCount);
+        classifyAndGate();
+        const uint32_t passCount = planPassCount;
         std::vector<uint32_t> transRuns, uiRuns;
         std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
 
         // Phase 1 — every mesh system's cull (and sort request) is issued before any result is read: results are kept
         // per (pool, view), so the device works through the systems back to back while the host only enqueues; the
         // reference dispatches every system's tasks to its thread pool and waits once, too (mesh.cpp:408-546, :548).
-        // viewPass[p][v] = the pass view v of system p's cull stands for (-1 the light pass, s >= 0 shadow pass s): only passes
-        // that get through the reference's gate are culled at all (mesh.cpp:426,482).
-        std::vector<std::vector<int8_t>> viewPass(meshSystems.size());
-        struct Indices {
-            uint32_t main = 0, shadow = 0;  // bufferIndex in the light pass / in a shadow pass
-        };
-        std::vector<Indices> indices(meshSystems.size());
-        uint32_t sortedSeen = 0, shadowSortedSeen = 0, unsortedSeen = 0;
         check(gv_cull_batch_begin(ctx), "gv_cull_batch_begin");  // engine-sized pools: one cull / emit / sort / publish launch per tick
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
-            auto meshSystem = meshSystems[p];
-            const auto renderType = meshSystem->getMeshRenderType();
-            const auto& componentPool = meshSystem->getMeshComponentPool();        // mesh.cpp:410
-            const uint32_t componentCount = componentPool.getCount();              // mesh.cpp:411
-            const uint32_t occupancy = componentPool.getOccupancy();
-            const bool sorted = isSortedType(renderType);
-            // bufferIndex: in the light pass Translucent and UI systems count (mesh.cpp:419); in a shadow pass a UI system leaves the
-            // loop before it takes one (:416-417), so a Translucent system's index there counts Translucent systems only
-            if (sorted) {
-                indices[p].main = sortedSeen++;
-                if (renderType == MeshRenderType::Translucent)
-                    indices[p].shadow = shadowSortedSeen++;
-            } else {
-                indices[p].main = indices[p].shadow = unsortedSeen++;
-            }
+            const SystemPlan& sp = plan[p];
+            auto meshSystem = sp.meshSystem;
+            const uint32_t occupancy = sp.occupancy;
             // the pool is bound and its changes are taken over whether or not the system is drawn this frame: a system that
             // becomes ready later is culled from the pool as it is then
-            check(gv_pool_bind(ctx, p, componentPool.getData(), meshSystem->getMeshComponentSize(), occupancy, &meshLayout), "gv_pool_bind");
-            bool inPlace = false;
-            {
-                GvRecordLayout layout;
-                const bool expressible = sorted
-                    ? recordLayoutOf<SortedMesh>(layout, meshSystem->getMeshComponentSize(), (uint32_t)offsetof(SortedMesh, bufferIndex), indices[p].main)
-                    : recordLayoutOf<UnsortedMesh>(layout, meshSystem->getMeshComponentSize(), GV_NONE, 0);
-                check(gv_pool_set_record_layout(ctx, p, emitRecords && recordStructs && expressible ? &layout : nullptr),
-                      "gv_pool_set_record_layout");
-                inPlace = !sorted && emitRecords && recordStructs && expressible && recordTargets;
-            }
+            check(gv_pool_bind(ctx, p, meshSystem->getMeshComponentPool().getData(), meshSystem->getMeshComponentSize(), occupancy, &meshLayout()), "gv_pool_bind");
+            GvRecordLayout layout;
+            const bool structs = recordLayoutOfSystem(sp, layout);
+            check(gv_pool_set_record_layout(ctx, p, structs ? &layout : nullptr), "gv_pool_set_record_layout");
+            const bool inPlace = !sp.sorted && structs && recordTargets;
             auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystem);
             if (versioned && versioned->reportsChanges) {
                 if (seenMesh[p] != versioned->meshVersion) {
@@ -506,41 +616,13 @@ private:
             } else {  // unknown writer: re-mirror the pool every frame (always correct)
                 check(gv_mark_dirty(ctx, GV_DIRTY_MESH, p << 28, occupancy), "gv_mark_dirty");
             }
-
-            // The gate of mesh.cpp:426 / :482, pass by pass: `componentCount == 0 || !meshSystem->isDrawReady(shadowPass)` leaves the
-            // system's counters at 0 for that pass and touches nothing else — in the light pass isVisible keeps last frame's bytes.
-            // The light pass (shadowPass -1: writes isVisible), then the shadow passes (mesh.cpp:809-843). UI: its own ortho
-            // frustum, camera at the origin, 2D distance key, no shadow passes (mesh.cpp:416,436-442).
-            std::vector<GvView> views;
-            auto& passes = viewPass[p];
-            const bool lightPass = componentCount != 0 && meshSystem->isDrawReady(-1);
-            if (lightPass) {
-                if (renderType == MeshRenderType::UI)
-                    views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
-                else
-                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz && isHizEnabled, emitRecords));
-                passes.push_back(-1);
-                if (!sorted) {  // mesh.cpp:488-490
-                    hasAnyRefr |= renderType == MeshRenderType::Refracted;
-                    hasAnyOIT |= renderType == MeshRenderType::OIT;
-                    hasAnyTD |= renderType == MeshRenderType::TransDepth;
-                }
-            }
-            if (renderType != MeshRenderType::UI)
-                for (uint32_t s = 0; s < passCount; s++)
-                    if (componentCount != 0 && meshSystem->isDrawReady(shadowPasses[s].index(s))) {
-                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), false, emitRecords));
-                        passes.push_back((int8_t)s);
-                    }
-            if (!sorted) {
+            if (!sp.sorted) {
                 // An unsorted system's buffers are its own (mesh.hpp:213-217), sized before its tasks run like the
                 // reference's scratch (mesh.cpp:377-395; here to the occupancy, which bounds any draw count): the device
                 // writes the records where renderUnsorted reads them. Shared sorted arrays keep the append + merge.
-                auto& sb = shadowBuffers[indices[p].main];
-                while (sb.size() < passCount)
-                    sb.push_back(new UnsortedBuffer());
-                for (uint32_t v = 0; v < views.size(); v++) {
-                    UnsortedBuffer* buffer = passes[v] < 0 ? unsortedBuffers[indices[p].main] : sb[passes[v]];
+                auto& sb = shadowBuffers[sp.bufferIndex];
+                for (uint32_t v = 0; v < sp.views.size(); v++) {
+                    UnsortedBuffer* buffer = sp.passes[v] < 0 ? unsortedBuffers[sp.bufferIndex] : sb[sp.passes[v]];
                     const bool target = inPlace && !recordSpans && occupancy && (size_t)occupancy * sizeof(UnsortedMesh) <= recordTargetMaxBytes;
                     if (target && buffer->combinedMeshes.size() < occupancy) {
                         // growing re-allocates: let the old range go while it is still allocated
@@ -555,7 +637,7 @@ private:
                     }
                 }
             }
-            if (views.empty())
+            if (sp.views.empty())
                 continue;  // no pass draws this system this frame: nothing is culled, sorted or read for it
             if (sweepWorldMatrices && !sweepRequested) {
                 check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_WITH_CULL), "gv_sweep");
@@ -563,40 +645,26 @@ private:
             }
             {
                 Stopwatch watch(tickSeconds.cull);
-                check(gv_cull(ctx, p, views.data(), (uint32_t)views.size()), "gv_cull");
+                check(gv_cull(ctx, p, sp.views.data(), (uint32_t)sp.views.size()), "gv_cull");
             }
             // sortMeshes, mesh.cpp:270-295: unsorted buffers front to back (UnsortedMesh::operator<, mesh.hpp:196), OIT is
             // not sorted; sorted systems back to front (SortedMesh::operator<, mesh.hpp:204)
-            if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT) {
+            if (emitRecords && sortOnDevice && sp.type != MeshRenderType::OIT) {
                 Stopwatch watch(tickSeconds.sort);
-                for (uint32_t v = 0; v < views.size(); v++)
-                    check(gv_pool_sort(ctx, p, v, sorted ? 1 : 0), "gv_pool_sort");
+                for (uint32_t v = 0; v < sp.views.size(); v++)
+                    check(gv_pool_sort(ctx, p, v, sp.sorted ? 1 : 0), "gv_pool_sort");
             }
         }
-        for (uint32_t s = 0; s < passCount; s++)
-            while (shadowSortedBuffers[s].size() < shadowSortedSeen)
-                shadowSortedBuffers[s].push_back(new SortedBuffer());
         if (sweepWorldMatrices && !sweepRequested)  // no system is drawn this frame: the cache is kept current all the same
             check(gv_sweep(ctx, sweepIncremental ? GV_SWEEP_INCREMENTAL : GV_SWEEP_VALU), "gv_sweep");
 
-        // Phase 2 — read the results (the first fetch publishes every small pool's views at once). Every buffer of every pass is
-        // first put in the state mesh.cpp:420-424 / :476-480 leave it in — its system, both counters 0 — and only the passes
-        // that were culled fill theirs.
-        auto reset = [](MeshBuffer* buffer, IMeshRenderSystem* meshSystem) {
-            buffer->meshSystem = meshSystem;
-            buffer->drawCount = 0;
-            buffer->instanceCount = 0;
-        };
+        // Phase 2 — read the results (the first fetch publishes every small pool's views at once).
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
-            auto meshSystem = meshSystems[p];
-            const auto renderType = meshSystem->getMeshRenderType();
-            const auto& passes = viewPass[p];
-            if (isSortedType(renderType)) {
-                const uint32_t bufferIndex = indices[p].main, shadowIndex = indices[p].shadow;
-                reset(sortedBuffers[bufferIndex], meshSystem);
-                if (renderType == MeshRenderType::Translucent)
-                    for (uint32_t s = 0; s < passCount; s++)
-                        reset(shadowSortedBuffers[s][shadowIndex], meshSystem);
+            const SystemPlan& sp = plan[p];
+            auto meshSystem = sp.meshSystem;
+            const auto& passes = sp.passes;
+            if (sp.sorted) {
+                const uint32_t bufferIndex = sp.bufferIndex, shadowIndex = sp.shadowIndex;
                 for (uint32_t v = 0; v < passes.size(); v++) {
                     if (passes[v] >= 0) {
                         const uint32_t s = (uint32_t)passes[v], first = shadowTransDrawIndex[s];
@@ -606,7 +674,7 @@ private:
                             for (uint32_t k = 0; k < added; k++)
                                 shadowTransMeshes[s][first + k].bufferIndex = shadowIndex;
                         shadowTransRuns[s].push_back(shadowTransDrawIndex[s]);
-                    } else if (renderType == MeshRenderType::UI) {
+                    } else if (sp.type == MeshRenderType::UI) {
                         append(uiSortedMeshes, uiDrawIndex, sortedBuffers[bufferIndex], meshSystem, p, v, true, bufferIndex);
                         uiRuns.push_back(uiDrawIndex);
                     } else {
@@ -615,20 +683,13 @@ private:
                     }
                 }
             } else {
-                const uint32_t bufferIndex = indices[p].main;
-                auto& sb = shadowBuffers[bufferIndex];
-                reset(unsortedBuffers[bufferIndex], meshSystem);
-                unsortedBuffers[bufferIndex]->span = nullptr;
-                for (uint32_t s = 0; s < passCount; s++) {
-                    reset(sb[s], meshSystem);
-                    sb[s]->span = nullptr;
-                }
+                auto& sb = shadowBuffers[sp.bufferIndex];
                 for (uint32_t v = 0; v < passes.size(); v++)
                     if (passes[v] >= 0)
                         fill(sb[passes[v]], meshSystem, p, v, false);
                 for (uint32_t v = 0; v < passes.size(); v++)
                     if (passes[v] < 0)
-                        fill(unsortedBuffers[bufferIndex], meshSystem, p, v, true);
+                        fill(unsortedBuffers[sp.bufferIndex], meshSystem, p, v, true);
             }
         }
         if (emitRecords && sortOnDevice) {
@@ -646,323 +707,360 @@ private:
             throw GardenError(std::string(what) + " failed on rank " + std::to_string(rank) + ": " + gv_last_error(contexts[rank]));
     }
 
-    // Deals the pools again when anything structural changed (entities or components came or went, a parent link moved); otherwise
-    // copies the transforms that changed into their ranks' pools. Binds every rank's share.
+    // Brings every rank's share up to date with the engine's pools and tells the ranks what changed (rank_shares.hpp). The pools are
+    // dealt again only when entities or components came or went or a parent link moved; a mesh system that cannot say what changed
+    // (the reference's have no counters) is compared with the ranks' copies instead of being dealt again.
     void syncRanks(TransformSystem* transformSystem)
     {
         const uint32_t ranks = (uint32_t)contexts.size();
         auto& pool = transformSystem->getComponents();
         bool structural = ranksSeen.hierarchy != transformSystem->hierarchyVersion || ranksSeen.reparent != transformSystem->reparentVersion ||
                           ranksSeen.transformOccupancy != pool.getOccupancy() || ranksSeen.transformCount != pool.getCount() ||
-                          ranksSeen.meshVersion.size() != meshSystems.size();
+                          ranksSeen.meshSystems != meshSystems;
         ranksSeen.meshVersion.resize(meshSystems.size(), ~0ull);
-        ranksSeen.meshRange.resize(meshSystems.size(), ~0ull);
         ranksSeen.meshOccupancy.resize(meshSystems.size(), ~0u);
         ranksSeen.meshCount.resize(meshSystems.size(), ~0u);
         for (size_t p = 0; p < meshSystems.size(); p++) {
             const auto& meshPool = meshSystems[p]->getMeshComponentPool();
-            auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
-            if (versioned && !versioned->reportsChanges)
-                versioned = nullptr;
-            const uint64_t version = versioned ? versioned->meshVersion : 0, range = versioned ? versioned->rangeVersion : 0;
-            structural = structural || !versioned || ranksSeen.meshVersion[p] != version || ranksSeen.meshRange[p] != range ||
-                         ranksSeen.meshOccupancy[p] != meshPool.getOccupancy() || ranksSeen.meshCount[p] != meshPool.getCount();
-            ranksSeen.meshVersion[p] = version;
-            ranksSeen.meshRange[p] = range;
-            ranksSeen.meshOccupancy[p] = meshPool.getOccupancy();
-            ranksSeen.meshCount[p] = meshPool.getCount();
-            if (versioned)
-                versioned->clearMeshRange();
+            structural = structural || ranksSeen.meshOccupancy[p] != meshPool.getOccupancy() || ranksSeen.meshCount[p] != meshPool.getCount();
         }
         // a slot that was freed and handed to another entity since the deal (same occupancy, same count) is structural too
         if (!structural && seenFlags != transformSystem->flagsVersion)
             for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi && !structural; i++)
                 structural = !rankShares.sameEntity(transformSystem, i);
+        rankChanges.reset(ranks, meshSystems.size());
+        // mesh components: the slots a system names, or — no counters, or "the whole pool may have changed" — every slot, compared
+        // with the ranks' copies in the bytes the cull reads (a slot that changed hands: deal again)
+        for (size_t p = 0; p < meshSystems.size() && !structural; p++) {
+            auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
+            const uint32_t occupancy = meshSystems[p]->getMeshComponentPool().getOccupancy();
+            uint32_t lo = 0, hi = occupancy;
+            if (versioned && versioned->reportsChanges && ranksSeen.meshVersion[p] == versioned->meshVersion) {
+                lo = std::min(versioned->meshLo, versioned->meshHi);
+                hi = std::min(versioned->meshHi, occupancy);
+            }
+            structural = !rankShares.syncMeshes((uint32_t)p, meshSystems[p], lo, hi, rankChanges);
+        }
+        std::vector<uint32_t> moved;
+        bool everything = false;
+        if (!structural) {  // transforms: every slot, or the itemised ones; roots that crossed into another rank's cell take their trees along
+            if (seenTransform != transformSystem->transformVersion) {
+                everything = true;
+                rankShares.syncAllTransforms(transformSystem, rankChanges);
+                rankCounters.copiedTransforms += pool.getOccupancy();
+            } else {
+                for (const auto& range : transformSystem->movedRanges)
+                    for (uint32_t i = 0; i < range.second; i++) {
+                        rankShares.syncTransform(transformSystem, range.first + i, rankChanges);
+                        moved.push_back(range.first + i);
+                    }
+                if (seenFlags != transformSystem->flagsVersion)
+                    for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
+                        rankShares.syncTransform(transformSystem, i, rankChanges);
+                rankCounters.copiedTransforms += moved.size();
+            }
+            if (rebinMovedRoots && (everything || !moved.empty()))
+                rankShares.rebin(transformSystem, moved, everything, ranks, rankGrid, worldSide, rankChanges);
+        }
+        if (structural) {
+            rankShares.deal(transformSystem, meshSystems, ranks, rankGrid, worldSide);
+            rankChanges.reset(ranks, meshSystems.size());
+            rankCounters.deals++;
+        }
+        rankCounters.movedTrees += rankChanges.movedTrees;
+        rankCounters.movedTransforms += rankChanges.movedTransforms;
         ranksSeen.hierarchy = transformSystem->hierarchyVersion;
         ranksSeen.reparent = transformSystem->reparentVersion;
         ranksSeen.transformOccupancy = pool.getOccupancy();
         ranksSeen.transformCount = pool.getCount();
-        static const GvTransformLayout transformLayout = {
-            (uint32_t)offsetof(TransformComponent, entity), (uint32_t)offsetof(TransformComponent, parent),
-            (uint32_t)offsetof(TransformComponent, posChildCount), (uint32_t)offsetof(TransformComponent, scaleChildCap),
-            (uint32_t)offsetof(TransformComponent, rotation), (uint32_t)offsetof(TransformComponent, selfActive),
-            (uint32_t)offsetof(TransformComponent, ancestorsActive),
-            (uint32_t)offsetof(TransformComponent, modelWithAncestors)};
-        static const GvMeshLayout meshLayout = {
-            (uint32_t)offsetof(MeshRenderComponent, entity), (uint32_t)offsetof(MeshRenderComponent, isEnabled),
-            (uint32_t)offsetof(MeshRenderComponent, isVisible), (uint32_t)offsetof(MeshRenderComponent, aabb.min),
-            (uint32_t)offsetof(MeshRenderComponent, aabb.max)};
-        if (structural) {
-            rankShares.deal(transformSystem, meshSystems, ranks, rankGrid, worldSide);
-            seenTransform = transformSystem->transformVersion;
-            seenFlags = transformSystem->flagsVersion;
-        }
-        // what moved since the last frame (content only): every slot, or the itemised ones
-        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> dirty(ranks);  // per rank: (local slot, count)
-        auto touch = [&](uint32_t worldSlot) {
-            const uint32_t rank = worldSlot < rankShares.rankOfTransform.size() ? rankShares.rankOfTransform[worldSlot] : GV_NONE;
-            if (rank == GV_NONE)
-                return;
-            rankShares.copyTransform(transformSystem, worldSlot);
-            const uint32_t local = rankShares.localOfTransform[worldSlot];
-            auto& ranges = dirty[rank];
-            if (!ranges.empty() && ranges.back().first + ranges.back().second == local)
-                ranges.back().second++;
-            else
-                ranges.push_back({local, 1u});
-        };
-        bool everything = false;
-        if (!structural) {
-            if (seenTransform != transformSystem->transformVersion) {
-                everything = true;
-                for (uint32_t i = 0; i < pool.getOccupancy(); i++)
-                    rankShares.copyTransform(transformSystem, i);
-            } else {
-                for (const auto& moved : transformSystem->movedRanges)
-                    for (uint32_t i = 0; i < moved.second; i++)
-                        touch(moved.first + i);
-                if (seenFlags != transformSystem->flagsVersion)
-                    for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
-                        touch(i);
+        ranksSeen.meshSystems = meshSystems;
+        for (size_t p = 0; p < meshSystems.size(); p++) {
+            const auto& meshPool = meshSystems[p]->getMeshComponentPool();
+            ranksSeen.meshOccupancy[p] = meshPool.getOccupancy();
+            ranksSeen.meshCount[p] = meshPool.getCount();
+            if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p])) {
+                ranksSeen.meshVersion[p] = versioned->meshVersion;
+                versioned->clearMeshRange();
             }
-            seenTransform = transformSystem->transformVersion;
-            seenFlags = transformSystem->flagsVersion;
         }
+        seenTransform = transformSystem->transformVersion;
+        seenFlags = transformSystem->flagsVersion;
         transformSystem->clearReparentRange();
         transformSystem->clearFlagsRange();
         transformSystem->clearMovedRanges();
+        // bind every rank's share (vectors may have grown: slots appended by a tree that moved in) and tell the rank what changed
         for (uint32_t r = 0; r < ranks; r++) {
             auto& share = rankShares.shares[r];
-            checkRank(r, gv_transform_bind(contexts[r], share.transforms.data(), sizeof(TransformComponent), (uint32_t)share.transforms.size(), &transformLayout,
+            auto& changed = rankChanges.ranks[r];
+            checkRank(r, gv_transform_bind(contexts[r], share.transforms.data(), sizeof(TransformComponent), (uint32_t)share.transforms.size(), &transformLayout(),
                                            share.entityToTransform.data(), (uint32_t)share.entityToTransform.size()), "gv_transform_bind");
             for (uint32_t p = 0; p < meshSystems.size(); p++) {
                 auto& mesh = share.meshes[p];
-                checkRank(r, gv_pool_bind(contexts[r], p, mesh.components.data(), (uint32_t)mesh.stride, mesh.occupancy(), &meshLayout), "gv_pool_bind");
-                checkRank(r, gv_pool_set_record_layout(contexts[r], p, nullptr), "gv_pool_set_record_layout");
+                const auto& worldPool = meshSystems[p]->getMeshComponentPool();
+                checkRank(r, gv_pool_bind(contexts[r], p, mesh.components.data(), (uint32_t)mesh.stride, mesh.occupancy(), &meshLayout()), "gv_pool_bind");
+                // the rank's results in the WORLD's slots: isVisible straight into the engine's pool (mesh.cpp:144-166)
+                uint8_t* worldVisible = reinterpret_cast<uint8_t*>(worldPool.getData()) + offsetof(MeshRenderComponent, isVisible);
+                rankMapping(r, p, worldVisible, mesh.stride, worldPool.getOccupancy());
                 if (structural) {
                     checkRank(r, gv_pool_set_index_map(contexts[r], p, mesh.worldSlot.data(), mesh.occupancy()), "gv_pool_set_index_map");
                     checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_MESH, p << 28, mesh.occupancy()), "gv_mark_dirty");
+                    continue;
                 }
+                for (const auto& run : RankShares::Changes::runs(changed.maps[p]))
+                    checkRank(r, gv_pool_update_index_map(contexts[r], p, run.first, mesh.worldSlot.data() + run.first, run.second), "gv_pool_update_index_map");
+                rankCounters.editedMeshes += changed.meshes[p].size();
+                for (const auto& run : RankShares::Changes::runs(changed.meshes[p]))
+                    checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_MESH, (p << 28) | run.first, run.second), "gv_mark_dirty");
             }
             if (structural) {
                 checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_HIERARCHY, 0, 0), "gv_mark_dirty");
-            } else if (everything) {
-                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, 0, (uint32_t)share.transforms.size()), "gv_mark_dirty");
-            } else {
-                for (const auto& range : dirty[r])
-                    checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, range.first, range.second), "gv_mark_dirty");
+                continue;
             }
+            if (changed.allTransforms)
+                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, 0, (uint32_t)share.transforms.size()), "gv_mark_dirty");
+            for (const auto& run : RankShares::Changes::runs(changed.transforms))
+                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_TRANSFORM, run.first, run.second), "gv_mark_dirty");
+            for (const auto& run : RankShares::Changes::runs(changed.links))  // parent links of the slots a tree moved into
+                checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_HIERARCHY, run.first, run.second), "gv_mark_dirty");
         }
     }
 
-    // The frame with several ranks. The same classification, gate and buffers as preRender(); per (mesh system, pass): every rank
-    // culls (and sorts) its share, the ranks' lists are gathered on the devices, and the engine's buffers are filled from the
-    // ranks' results — a rank holds the models of the entities it owns, the host holds all of them:
-    //   isVisible      rank r's light-pass bytes, scattered to the engine's pool through the local -> world slot table
-    //   records        componentOffset = WORLD slot * componentSize; each rank's run arrives sorted, the runs are merged
+    // rank r's results of pool p in the engine's own numbering (gv_pool_set_result_mapping); records: decided per frame (the layout)
+    std::vector<uint32_t> rankMappingFlags;  // [rank * GV_MAX_POOLS + pool]: GV_RESULTS_MAP_RECORDS wanted
+    void rankMapping(uint32_t r, uint32_t p, uint8_t* worldVisible, size_t stride, uint32_t worldOccupancy)
+    {
+        rankMappingFlags.resize((size_t)contexts.size() * GV_MAX_POOLS, 0u);
+        checkRank(r, gv_pool_set_result_mapping(contexts[r], p, GV_RESULTS_MAP_VISIBLE | rankMappingFlags[(size_t)r * GV_MAX_POOLS + p], worldVisible, stride,
+                                                worldOccupancy), "gv_pool_set_result_mapping");
+    }
+
+    // Several ranks, first frame: the same exchange by each travel pattern — one untimed frame, then five between fences — and the
+    // fastest is kept (GvExchangeMode). exchangeModeProbeMs: what each took.
+    void chooseExchangeMode(const std::vector<GvExchangeItem>& items, std::vector<GvExchangeFrame>& frames)
+    {
+        const int ranks = (int)contexts.size();
+        auto fence = [&]() {
+            for (uint32_t r = 0; r < contexts.size(); r++)
+                checkRank(r, gv_wait(contexts[r]), "gv_wait");
+        };
+        uint32_t best = GV_EXCHANGE_ALLGATHER;
+        for (uint32_t mode = GV_EXCHANGE_ALLGATHER; mode <= GV_EXCHANGE_BROADCAST; mode++) {
+            for (uint32_t r = 0; r < contexts.size(); r++)
+                checkRank(r, gv_exchange_set_mode(contexts[r], mode), "gv_exchange_set_mode");
+            double seconds = 0;
+            for (int rep = 0; rep < 6; rep++) {
+                fence();
+                const auto t0 = std::chrono::steady_clock::now();
+                check(gv_exchange_views_all(contexts.data(), ranks, items.data(), (uint32_t)items.size(), 0, frames.data()), "gv_exchange_views_all");
+                check(gv_exchange_acquire_all(contexts.data(), ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
+                fence();
+                if (rep > 0)
+                    seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            exchangeModeProbeMs[mode] = seconds / 5 * 1e3;
+            if (exchangeModeProbeMs[mode] < exchangeModeProbeMs[best])
+                best = mode;
+        }
+        for (uint32_t r = 0; r < contexts.size(); r++)
+            checkRank(r, gv_exchange_set_mode(contexts[r], best), "gv_exchange_set_mode");
+        exchangeMode = best;
+    }
+
+public:
+    double exchangeModeProbeMs[3] = {0, 0, 0};  // probeExchangeMode: milliseconds per exchange by GvExchangeMode (0: not probed)
+    uint32_t exchangeMode = GV_EXCHANGE_ALLGATHER;
+
+private:
+    // The ranks' runs of one list -> dst[0, total): each rank's records arrive in sortMeshes order (gv_pool_sort), so one pass that
+    // always takes the smallest head (operator< of the record: ascending distanceSq for unsorted buffers, descending for sorted
+    // ones, mesh.hpp:196,204) leaves the whole list in that order; not ordered (OIT, or the engine sorts itself): the runs back to back.
+    template <class Mesh>
+    static void mergeRanks(Mesh* dst, const Mesh* const* runs, const uint32_t* counts, uint32_t ranks, bool ordered)
+    {
+        if (!ordered) {
+            for (uint32_t r = 0; r < ranks; r++) {
+                memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[r]), (size_t)counts[r] * sizeof(Mesh));
+                dst += counts[r];
+            }
+            return;
+        }
+        uint32_t at[GV_EXCHANGE_MAX_RANKS] = {}, live[GV_EXCHANGE_MAX_RANKS], n = 0;
+        for (uint32_t r = 0; r < ranks; r++)
+            if (counts[r])
+                live[n++] = r;
+        while (n > 1) {
+            uint32_t best = 0;
+            for (uint32_t k = 1; k < n; k++)
+                if (runs[live[k]][at[live[k]]] < runs[live[best]][at[live[best]]])
+                    best = k;
+            const uint32_t r = live[best];
+            memcpy(static_cast<void*>(dst++), static_cast<const void*>(runs[r] + at[r]), sizeof(Mesh));
+            if (++at[r] == counts[r])
+                live[best] = live[--n];
+        }
+        if (n == 1)
+            memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[live[0]] + at[live[0]]), (size_t)(counts[live[0]] - at[live[0]]) * sizeof(Mesh));
+    }
+
+    // The frame with several ranks. The same classification, gate and buffers as preRender() (classifyAndGate); every rank culls (and
+    // sorts) its share of every system, ALL the frame's lists are gathered on the devices by ONE exchange — the reference dispatches
+    // every system's tasks and waits once (mesh.cpp:408-546, :548) — and the engine's buffers are filled from the ranks' results — a
+    // rank holds the models of the entities it owns, the host holds all of them:
+    //   isVisible      rank r's light-pass bytes go straight to the engine's pool through the share's slot -> world slot table
+    //   records        arrive as the engine's structs with componentOffset in WORLD slots; each rank's run is sorted, the runs are merged
     //   counters       summed over the ranks
     void preRenderRanks()
     {
         auto transformSystem = TransformSystem::Instance::get();
-        auto graphicsSystem = GraphicsSystem::Instance::get();
         Stopwatch whole(tickSeconds.total);
         if (sweepWorldMatrices)  // (a rank keeps the world matrices of ITS entities: gv_sweep / gv_get_world on getContext(rank), in local slots)
             throw GardenError("GpuVisibilitySystem: sweepWorldMatrices is a one-context option; with several ranks ask each rank's context");
         prepareSystems();
+        classifyAndGate();
+        const uint32_t ranks = (uint32_t)contexts.size();
+        // records as the engine's structs, in world slots, for the systems whose struct the library can express
+        std::vector<GvRecordLayout> layouts(meshSystems.size());
+        std::vector<uint8_t> structs(meshSystems.size(), 0);
+        rankMappingFlags.assign((size_t)ranks * GV_MAX_POOLS, 0u);
+        for (uint32_t p = 0; p < meshSystems.size(); p++) {
+            structs[p] = recordLayoutOfSystem(plan[p], layouts[p]) ? 1 : 0;
+            for (uint32_t r = 0; r < ranks; r++)
+                rankMappingFlags[(size_t)r * GV_MAX_POOLS + p] = structs[p] ? GV_RESULTS_MAP_RECORDS : 0u;
+        }
         {
             Stopwatch watch(tickSeconds.share);
             syncRanks(transformSystem);
         }
-        const uint32_t ranks = (uint32_t)contexts.size();
-        const auto& cc = graphicsSystem->getCommonConstants();
-        const uint32_t passCount = (uint32_t)std::min<size_t>(shadowPasses.size(), GV_MAX_VIEWS - 1);
-        transDrawIndex = uiDrawIndex = 0;
-        hasAnyRefr = hasAnyOIT = hasAnyTD = false;
-        shadowTransMeshes.resize(passCount);
-        shadowTransDrawIndex.assign(passCount, 0);
-        shadowSortedBuffers.resize(passCount);
+        rankCounters.frames++;
+        const uint32_t passCount = planPassCount;
         std::vector<uint32_t> transRuns, uiRuns;
         std::vector<std::vector<uint32_t>> shadowTransRuns(passCount);
-        uint32_t sortedSeen = 0, shadowSortedSeen = 0, unsortedSeen = 0;
-        auto reset = [](MeshBuffer* buffer, IMeshRenderSystem* meshSystem) {
-            buffer->meshSystem = meshSystem;
-            buffer->drawCount = 0;
-            buffer->instanceCount = 0;
-        };
         std::vector<GvExchangeFrame> frames(ranks);
-        std::vector<uint32_t> viewIndices(ranks);
         // Phase 1 — as in preRender(): every system's cull (and sort request) goes to every rank before any result is read, so each
         // device works through the systems back to back (engine-sized pools: one launch per tick, gv_cull_batch_begin) while the host
-        // only enqueues. issued[p]: the passes system p was culled for, and its buffers.
-        struct Issued {
-            std::vector<int8_t> passes;
-            uint32_t bufferIndex = 0, shadowIndex = 0;
-        };
-        std::vector<Issued> issued(meshSystems.size());
+        // only enqueues.
         for (uint32_t r = 0; r < ranks; r++)
             checkRank(r, gv_cull_batch_begin(contexts[r]), "gv_cull_batch_begin");
-        for (uint32_t p = 0; p < meshSystems.size(); p++) {
-            auto meshSystem = meshSystems[p];
-            const auto renderType = meshSystem->getMeshRenderType();
-            const auto& componentPool = meshSystem->getMeshComponentPool();
-            const uint32_t componentCount = componentPool.getCount();
-            const bool sorted = isSortedType(renderType);
-            uint32_t bufferIndex = 0, shadowIndex = 0;
-            if (sorted) {
-                bufferIndex = sortedSeen++;
-                if (renderType == MeshRenderType::Translucent) {
-                    shadowIndex = shadowSortedSeen++;
-                    for (uint32_t s = 0; s < passCount; s++) {
-                        while (shadowSortedBuffers[s].size() <= shadowIndex)
-                            shadowSortedBuffers[s].push_back(new SortedBuffer());
-                        reset(shadowSortedBuffers[s][shadowIndex], meshSystem);
-                    }
-                }
-                reset(sortedBuffers[bufferIndex], meshSystem);
-            } else {
-                bufferIndex = unsortedSeen++;
-                auto& sb = shadowBuffers[bufferIndex];
-                while (sb.size() < passCount)
-                    sb.push_back(new UnsortedBuffer());
-                reset(unsortedBuffers[bufferIndex], meshSystem);
-                unsortedBuffers[bufferIndex]->span = nullptr;
-                for (uint32_t s = 0; s < passCount; s++) {
-                    reset(sb[s], meshSystem);
-                    sb[s]->span = nullptr;
+        try {
+            for (uint32_t p = 0; p < meshSystems.size(); p++) {
+                const SystemPlan& sp = plan[p];
+                for (uint32_t r = 0; r < ranks; r++)
+                    checkRank(r, gv_pool_set_record_layout(contexts[r], p, structs[p] ? &layouts[p] : nullptr), "gv_pool_set_record_layout");
+                if (sp.views.empty())
+                    continue;
+                Stopwatch watch(tickSeconds.cull);
+                for (uint32_t r = 0; r < ranks; r++) {
+                    checkRank(r, gv_cull(contexts[r], p, sp.views.data(), (uint32_t)sp.views.size()), "gv_cull");
+                    if (emitRecords && sortOnDevice && sp.type != MeshRenderType::OIT)
+                        for (uint32_t v = 0; v < sp.views.size(); v++)
+                            checkRank(r, gv_pool_sort(contexts[r], p, v, sp.sorted ? 1 : 0), "gv_pool_sort");
                 }
             }
-            // the gate of mesh.cpp:426 / :482, pass by pass (see preRender)
-            std::vector<GvView> views;
-            std::vector<int8_t> passes;
-            if (componentCount != 0 && meshSystem->isDrawReady(-1)) {
-                if (renderType == MeshRenderType::UI)
-                    views.push_back(makeView(uiViewProj, f32x4(), f32x4(), -1, false, emitRecords, true));
-                else
-                    views.push_back(makeView(cc.viewProj, cc.cameraPos, f32x4(), -1, useHiz && isHizEnabled, emitRecords));
-                passes.push_back(-1);
-                if (!sorted) {
-                    hasAnyRefr |= renderType == MeshRenderType::Refracted;
-                    hasAnyOIT |= renderType == MeshRenderType::OIT;
-                    hasAnyTD |= renderType == MeshRenderType::TransDepth;
+        } catch (...) {
+            for (auto c : contexts)  // no rank is left recording: the next frame starts from a clean batch
+                (void)gv_cull_batch_end(c);
+            throw;
+        }
+        // Phase 2 — the gather (mesh.cpp:177-183: every worker's records into the shared array): ONE exchange carries every list of the
+        // frame; on every device, every rank's lists of WORLD slots, complete (gv_exchange_acquire_all).
+        if (emitRecords) {
+            std::vector<GvExchangeItem> items;
+            std::vector<GatheredList> lists;
+            for (uint32_t p = 0; p < meshSystems.size(); p++)
+                for (uint32_t v = 0; v < plan[p].passes.size(); v++) {
+                    items.push_back(GvExchangeItem{p, v, 0u});
+                    lists.push_back(GatheredList{p, plan[p].passes[v]});
                 }
-            }
-            if (renderType != MeshRenderType::UI)
-                for (uint32_t s = 0; s < passCount; s++)
-                    if (componentCount != 0 && meshSystem->isDrawReady(shadowPasses[s].index(s))) {
-                        views.push_back(makeView(shadowPasses[s].viewProj, cc.cameraPos, shadowPasses[s].cameraOffset, shadowPasses[s].index(s), false, emitRecords));
-                        passes.push_back((int8_t)s);
-                    }
-            issued[p].bufferIndex = bufferIndex;
-            issued[p].shadowIndex = shadowIndex;
-            if (views.empty())
-                continue;
-            issued[p].passes = passes;
-            Stopwatch watch(tickSeconds.cull);
-            for (uint32_t r = 0; r < ranks; r++) {
-                checkRank(r, gv_cull(contexts[r], p, views.data(), (uint32_t)views.size()), "gv_cull");
-                if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)
-                    for (uint32_t v = 0; v < views.size(); v++)
-                        checkRank(r, gv_pool_sort(contexts[r], p, v, sorted ? 1 : 0), "gv_pool_sort");
+            if (!items.empty()) {
+                Stopwatch watch(tickSeconds.gather);
+                if (probeExchangeMode && !exchangeModeChosen) {
+                    chooseExchangeMode(items, frames);
+                    exchangeModeChosen = true;
+                }
+                check(gv_exchange_views_all(contexts.data(), (int)ranks, items.data(), (uint32_t)items.size(), 0, frames.data()), "gv_exchange_views_all");
+                check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
+                rankCounters.exchanges++;
+                if (onGathered)
+                    onGathered(lists.data(), (uint32_t)lists.size(), frames.data(), ranks);
             }
         }
-        // Phase 2 — system by system: the gather, then the engine's buffers from the ranks' results (the first reader on a rank
-        // launches what that rank recorded).
+        // Phase 3 — the engine's buffers from the ranks' results (library-owned host memory, valid until the pool's next gv_cull on that
+        // rank); the light pass's fetch also writes the rank's isVisible bytes into the engine's pool
+        std::vector<GvResult> results(ranks);
+        std::vector<uint32_t> counts(ranks);
+        std::vector<const void*> runs(ranks);
+        std::vector<std::vector<uint8_t>> built(ranks);  // a system whose struct the library cannot express: records built here
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
-            const auto& passes = issued[p].passes;
-            if (passes.empty())
-                continue;
-            auto meshSystem = meshSystems[p];
-            const auto renderType = meshSystem->getMeshRenderType();
-            const auto& componentPool = meshSystem->getMeshComponentPool();
-            const size_t componentSize = meshSystem->getMeshComponentSize();
-            const bool sorted = isSortedType(renderType);
-            const uint32_t bufferIndex = issued[p].bufferIndex, shadowIndex = issued[p].shadowIndex;
-            // the gather (mesh.cpp:177-183: every worker's records into the shared array): on every device, every rank's list of
-            // WORLD slots for the pass — complete in every frame (gv_exchange_acquire_all); the pool is named: other systems have
-            // been culled since
-            if (emitRecords)
-                for (uint32_t v = 0; v < passes.size(); v++) {
-                    Stopwatch watch(tickSeconds.gather);
-                    std::fill(viewIndices.begin(), viewIndices.end(), v);
-                    check(gv_pool_exchange_visible_all(contexts.data(), (int)ranks, p, viewIndices.data(), nullptr, 0, frames.data()), "gv_pool_exchange_visible_all");
-                    check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
-                    if (onGathered)
-                        onGathered(p, passes[v], frames.data(), ranks);
-                }
-            // the engine's buffers from the ranks' results
-            for (uint32_t v = 0; v < passes.size(); v++) {
-                const int8_t pass = passes[v];
-                std::vector<uint32_t> runs;
-                // every rank's results of the pass (library-owned host memory, valid until the pool's next gv_cull on that rank); the
-                // light pass also writes the rank's isVisible bytes into its share, from where they go to the engine's pool
-                std::vector<GvResult> results(ranks);
+            const SystemPlan& sp = plan[p];
+            const size_t componentSize = sp.meshSystem->getMeshComponentSize();
+            const bool ordered = emitRecords && sortOnDevice && sp.type != MeshRenderType::OIT;
+            for (uint32_t v = 0; v < sp.passes.size(); v++) {
+                const int8_t pass = sp.passes[v];
                 uint32_t total = 0, instances = 0;
                 for (uint32_t r = 0; r < ranks; r++) {
-                    {
-                        Stopwatch watch(tickSeconds.fetch);
-                        checkRank(r, gv_pool_results_fetch(contexts[r], p, v, pass < 0 ? 1 : 0, &results[r]), "gv_pool_results_fetch");
-                    }
+                    Stopwatch watch(tickSeconds.fetch);
+                    checkRank(r, gv_pool_results_fetch(contexts[r], p, v, pass < 0 ? 1 : 0, &results[r]), "gv_pool_results_fetch");
                     total += results[r].draw_count;
                     instances += results[r].instance_count;
-                    if (pass < 0) {  // mesh.cpp:144-166, through the local -> world slot table
-                        Stopwatch watch(tickSeconds.records);
-                        const auto& share = rankShares.shares[r].meshes[p];
-                        uint8_t* world = reinterpret_cast<uint8_t*>(componentPool.getData());
-                        for (uint32_t j = 0; j < share.occupancy(); j++)
-                            reinterpret_cast<MeshRenderComponent*>(world + (size_t)share.worldSlot[j] * componentSize)->isVisible =
-                                reinterpret_cast<const MeshRenderComponent*>(share.components.data() + (size_t)j * componentSize)->isVisible;
+                    counts[r] = emitRecords ? results[r].draw_count : 0u;
+                    runs[r] = nullptr;
+                    if (emitRecords && structs[p]) {
+                        uint32_t n = 0;
+                        checkRank(r, gv_pool_results_records(contexts[r], p, v, &runs[r], &n), "gv_pool_results_records");
                     }
                 }
-                auto takeRank = [&](uint32_t r, auto* meshes, uint32_t first, uint32_t sortedBufferIndex) {
-                    Stopwatch watch(tickSeconds.records);
-                    const GvResult& res = results[r];
-                    const auto& share = rankShares.shares[r].meshes[p];
-                    for (uint32_t k = 0; k < res.draw_count; k++) {
-                        auto& m = meshes[first + k];
-                        m.componentOffset = (size_t)share.worldSlot[res.visible_idx[k]] * componentSize;  // mesh.cpp:170, in WORLD slots
-                        memcpy(m.bakedModel.m, res.baked_model + (size_t)k * 12, 48);                    // mesh.cpp:171
-                        m.distanceSq = res.distance_sq[k];                                               // mesh.cpp:172 / :249-251
-                        if constexpr (std::is_same<std::remove_reference_t<decltype(m)>, SortedMesh>::value)
-                            m.bufferIndex = sortedBufferIndex;                                           // mesh.cpp:252
+                Stopwatch watch(tickSeconds.records);
+                const uint32_t sortedIndex = pass >= 0 ? sp.shadowIndex : sp.bufferIndex;
+                auto gatherRuns = [&](auto* dst) {
+                    using Mesh = std::remove_pointer_t<decltype(dst)>;
+                    std::vector<const Mesh*> typed(ranks);
+                    for (uint32_t r = 0; r < ranks; r++) {
+                        if (!structs[p] && counts[r]) {  // three arrays, the rank's own slots: through the share's table (mesh.cpp:170-172)
+                            built[r].resize((size_t)counts[r] * sizeof(Mesh));
+                            Mesh* meshes = reinterpret_cast<Mesh*>(built[r].data());
+                            const auto& worldSlot = rankShares.shares[r].meshes[p].worldSlot;
+                            for (uint32_t k = 0; k < counts[r]; k++) {
+                                new (&meshes[k]) Mesh();
+                                meshes[k].componentOffset = (size_t)worldSlot[results[r].visible_idx[k]] * componentSize;
+                                memcpy(meshes[k].bakedModel.m, results[r].baked_model + (size_t)k * 12, 48);
+                                meshes[k].distanceSq = results[r].distance_sq[k];
+                            }
+                            runs[r] = meshes;
+                        }
+                        typed[r] = static_cast<const Mesh*>(runs[r]);
                     }
-                    (void)sortedBufferIndex;
+                    mergeRanks(dst, typed.data(), counts.data(), ranks, ordered);
                 };
-                if (sorted) {
-                    const bool ui = renderType == MeshRenderType::UI;
+                if (sp.sorted) {
+                    const bool ui = sp.type == MeshRenderType::UI;
                     auto& combined = pass >= 0 ? shadowTransMeshes[pass] : ui ? uiSortedMeshes : transSortedMeshes;
                     uint32_t& drawIndex = pass >= 0 ? shadowTransDrawIndex[pass] : ui ? uiDrawIndex : transDrawIndex;
                     auto& allRuns = pass >= 0 ? shadowTransRuns[pass] : ui ? uiRuns : transRuns;
-                    MeshBuffer* counters = pass >= 0 ? static_cast<MeshBuffer*>(shadowSortedBuffers[pass][shadowIndex]) : sortedBuffers[bufferIndex];
-                    if (emitRecords && combined.size() < (size_t)drawIndex + total)
-                        combined.resize((size_t)drawIndex + total);
-                    for (uint32_t r = 0; r < ranks && emitRecords; r++) {
-                        takeRank(r, combined.data(), drawIndex, pass >= 0 ? shadowIndex : bufferIndex);
-                        drawIndex += results[r].draw_count;
+                    MeshBuffer* counters = pass >= 0 ? static_cast<MeshBuffer*>(shadowSortedBuffers[pass][sp.shadowIndex]) : sortedBuffers[sp.bufferIndex];
+                    if (emitRecords) {
+                        if (combined.size() < (size_t)drawIndex + total)
+                            combined.resize((size_t)drawIndex + total);
+                        gatherRuns(combined.data() + drawIndex);
+                        if (!structs[p] || sortedIndex != sp.bufferIndex)  // mesh.cpp:252 (records built on the device carry the light pass's index)
+                            for (uint32_t k = 0; k < total; k++)
+                                combined[drawIndex + k].bufferIndex = sortedIndex;
+                        drawIndex += total;
                         allRuns.push_back(drawIndex);
                     }
                     counters->drawCount = total;
                     counters->instanceCount = instances;
                 } else {
-                    UnsortedBuffer* buffer = pass >= 0 ? shadowBuffers[bufferIndex][pass] : unsortedBuffers[bufferIndex];
-                    if (emitRecords && buffer->combinedMeshes.size() < total)
-                        buffer->combinedMeshes.resize(total);  // grown, never shrunk (mesh.cpp:377-395)
-                    uint32_t at = 0;
-                    for (uint32_t r = 0; r < ranks && emitRecords; r++) {
-                        takeRank(r, buffer->combinedMeshes.data(), at, 0);
-                        at += results[r].draw_count;
-                        runs.push_back(at);
+                    UnsortedBuffer* buffer = pass >= 0 ? shadowBuffers[sp.bufferIndex][pass] : unsortedBuffers[sp.bufferIndex];
+                    if (emitRecords) {
+                        if (buffer->combinedMeshes.size() < total)
+                            buffer->combinedMeshes.resize(total);  // grown, never shrunk (mesh.cpp:377-395)
+                        gatherRuns(buffer->combinedMeshes.data());
                     }
                     buffer->drawCount = total;
                     buffer->instanceCount = instances;
-                    if (emitRecords && sortOnDevice && renderType != MeshRenderType::OIT)  // the ranks' sorted runs -> one sorted list
-                        for (size_t i = 1; i < runs.size(); i++)
-                            std::inplace_merge(buffer->combinedMeshes.begin(), buffer->combinedMeshes.begin() + runs[i - 1], buffer->combinedMeshes.begin() + runs[i]);
                 }
             }
         }
-        for (uint32_t s = 0; s < passCount; s++)
-            while (shadowSortedBuffers[s].size() < shadowSortedSeen)
-                shadowSortedBuffers[s].push_back(new SortedBuffer());
         if (emitRecords && sortOnDevice) {
             mergeRuns(transSortedMeshes, transRuns);
             mergeRuns(uiSortedMeshes, uiRuns);

@@ -1,17 +1,33 @@
-// rank_shares.hpp — ONE process, N GPUs: what each rank (GPU) holds of the engine's component pools.
+// rank_shares.hpp — ONE process, N GPUs: what each rank (GPU) holds of the engine's component pools, and how that follows the engine
+// from frame to frame without being dealt again.
 //
-// The reference is one process with one Manager (source/editor/entry.cpp:135) whose workers split every pool into index ranges
-// (ThreadPool::addItems, source/thread-pool.cpp:180-194). Ranks split the WORLD instead: the world cube is cut
-// into many more cells than ranks, dealt in rotating rounds (gv_cell_owner: the rule gv_scene_extract_rank and
-// garden_amd/multi.py::partition_world use); a ROOT transform's position decides, its descendants follow — no parent chain is
-// cut, so a rank computes the world's matrices bit for bit (TransformComponent::calcModel, transform.hpp:197-214).
+// The reference is one process with one Manager (source/editor/entry.cpp:135) whose workers index the pools IN PLACE
+// (source/system/render/mesh.cpp:119-120,139: componentData + i * componentSize; ranges from ThreadPool::addItems,
+// source/thread-pool.cpp:180-194). A GPU cannot: it needs its part of the pools in its own memory. Ranks split the WORLD
+// (SURVEY.md §8e): the world cube is cut into many more cells than ranks, dealt in rotating rounds (gv_cell_owner: the rule
+// gv_scene_extract_rank and garden_amd/multi.py::partition_world use); a ROOT transform's position decides, its descendants follow —
+// no parent chain is cut, so a rank computes the world's matrices bit for bit (TransformComponent::calcModel, transform.hpp:197-214).
 //
 // A share is a set of pools in the engine's own layouts (TransformComponent / MeshRenderComponent-derived, same byte strides), with
 // entity ids renumbered per rank (local transform slot i <-> entity i + 1) and, per pool, the local slot -> WORLD slot table that
-// gv_pool_set_index_map takes: exchanged lists carry the engine's own slots. Every slot of every mesh pool lives on exactly one
-// rank — free slots and meshes without a transform included: the light pass writes isVisible of ALL of them (mesh.cpp:140-153).
+// gv_pool_set_index_map takes: exchanged lists, records and isVisible bytes carry the engine's own slots. Every slot of every mesh
+// pool lives on exactly one rank — free slots and meshes without a transform included: the light pass writes isVisible of ALL of
+// them (mesh.cpp:140-153).
+//
+// Frame to frame (round 6): deal() runs when entities or components came or went or a parent link moved. Everything else is
+// carried over slot by slot — the tables below say where every world slot lives:
+//   * a transform that moved / changed its flags: copied to its rank (copyTransform);
+//   * a mesh component that was edited — or, for a mesh system that cannot say what changed (every one of the reference's:
+//     sprite.cpp, 9-slice, label.cpp, instance.cpp carry no counter), whichever slots turn out to differ from the rank's copy in the
+//     bytes the cull reads (entity, isEnabled, aabb: syncMeshes compares them on the worker threads): copied to its rank;
+//   * a ROOT whose position crossed into a cell of another rank (SURVEY.md §8e "re-bin only roots whose position crosses a cell";
+//     physics writes positions every tick, source/system/physics.cpp:1033-1034): its tree's transforms and their meshes move from
+//     one share to the other (moveTree) — holes are left behind and reused, nothing else is touched.
+// What changed where is recorded per rank (Changes) in the units gv_mark_dirty / gv_pool_update_index_map take.
 #pragma once
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -21,21 +37,68 @@
 namespace garden {
 
 struct RankShares {
+    // a live mesh whose entity has no transform (mesh.cpp:149-153): an entity id beyond every rank's entity map
+    static constexpr uint32_t kNoTransformEntity = 0x7FFFFFFFu;
+
     struct MeshShare {
-        std::vector<uint8_t> components;  // local pool, the engine's stride
-        std::vector<uint32_t> worldSlot;  // local slot -> slot of the engine's pool
+        std::vector<uint8_t> components;   // local pool, the engine's stride
+        std::vector<uint32_t> worldSlot;   // local slot -> slot of the engine's pool (GV_NONE: a hole left by a tree that moved away)
+        std::vector<uint32_t> freeSlots;   // the holes
         size_t stride = 0;
         uint32_t occupancy() const noexcept { return (uint32_t)worldSlot.size(); }
+        MeshRenderComponent* at(uint32_t local) noexcept { return reinterpret_cast<MeshRenderComponent*>(components.data() + (size_t)local * stride); }
     };
     struct Share {
         std::vector<TransformComponent> transforms;  // local transform pool (childs = NULL: the cull path never reads it)
-        std::vector<uint32_t> transformWorldSlot;    // local -> world transform slot
-        std::vector<uint32_t> entityToTransform;     // local entity id -> local transform slot (GV_NONE: none)
+        std::vector<uint32_t> transformWorldSlot;    // local -> world transform slot (GV_NONE: a hole)
+        std::vector<uint32_t> entityToTransform;     // local entity id -> local transform slot: [0] = none, [k + 1] = k
+        std::vector<uint32_t> freeTransforms;
         std::vector<MeshShare> meshes;               // one per mesh system, in meshSystems order
+        uint32_t liveTransforms() const noexcept { return (uint32_t)(transforms.size() - freeTransforms.size()); }
     };
     std::vector<Share> shares;
     std::vector<uint32_t> rankOfTransform, localOfTransform;  // world transform slot -> rank, local slot (GV_NONE: a free slot)
     std::vector<uint32_t> entityOfTransform;                  // world transform slot -> the entity it held when the pools were dealt
+    struct MeshTable {                                        // per world mesh slot of one pool
+        std::vector<uint32_t> rank, local, entity;            // where it lives; the entity it held when the pools were dealt
+    };
+    std::vector<MeshTable> meshTables;
+    // world transform slot -> the mesh components of its entity: refs [meshStart[t], meshStart[t + 1]) = (pool << 28) | mesh slot
+    std::vector<uint32_t> meshStart, meshRefs;
+
+    // What a frame's synchronisation changed on each rank, in LOCAL slots: what gv_mark_dirty (GV_DIRTY_TRANSFORM, ranged
+    // GV_DIRTY_HIERARCHY, GV_DIRTY_MESH) and gv_pool_update_index_map are told.
+    struct Changes {
+        struct PerRank {
+            std::vector<uint32_t> transforms, links;
+            std::vector<std::vector<uint32_t>> meshes, maps;  // [pool]
+            bool allTransforms = false;
+        };
+        std::vector<PerRank> ranks;
+        uint32_t movedTrees = 0, movedTransforms = 0;
+        void reset(uint32_t rankCount, size_t pools)
+        {
+            ranks.assign(rankCount, PerRank{});
+            for (auto& r : ranks) {
+                r.meshes.assign(pools, {});
+                r.maps.assign(pools, {});
+            }
+            movedTrees = movedTransforms = 0;
+        }
+        // sorted, without duplicates, as (first, count) runs
+        static std::vector<std::pair<uint32_t, uint32_t>> runs(std::vector<uint32_t>& slots)
+        {
+            std::sort(slots.begin(), slots.end());
+            slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+            std::vector<std::pair<uint32_t, uint32_t>> out;
+            for (uint32_t s : slots)
+                if (!out.empty() && out.back().first + out.back().second == s)
+                    out.back().second++;
+                else
+                    out.push_back({s, 1u});
+            return out;
+        }
+    };
 
     // true: slot still holds the entity it was dealt with (a slot that was freed and handed to another entity since must be dealt again)
     bool sameEntity(const TransformSystem* ts, uint32_t worldSlot) const noexcept
@@ -51,9 +114,14 @@ struct RankShares {
     // one world transform into its rank's pool: the same bytes, ids renumbered
     void copyTransform(const TransformSystem* ts, uint32_t worldSlot)
     {
+        if (!tryCopyTransform(ts, worldSlot))
+            throw std::runtime_error("RankShares: a parent without a transform, or on another rank than its child");
+    }
+    bool tryCopyTransform(const TransformSystem* ts, uint32_t worldSlot) noexcept
+    {
         const uint32_t rank = rankOfTransform[worldSlot];
         if (rank == GV_NONE)
-            return;
+            return true;
         const uint32_t local = localOfTransform[worldSlot];
         const auto& emap = ts->getEntityMap();
         TransformComponent& dst = shares[rank].transforms[local];
@@ -64,9 +132,10 @@ struct RankShares {
         if (parent) {
             const uint32_t parentSlot = parent < emap.size() ? emap[parent] : GV_NONE;
             if (parentSlot == GV_NONE || rankOfTransform[parentSlot] != rank)
-                throw std::runtime_error("RankShares: a parent without a transform, or on another rank than its child");
+                return false;
             dst.parent = ID<Entity>(localOfTransform[parentSlot] + 1);
         }
+        return true;
     }
 
     // Deals the engine's pools to `ranks` shares. grid / side: the cell grid over the world cube [-side/2, side/2]^3.
@@ -120,18 +189,24 @@ struct RankShares {
             Share& share = shares[r];
             const uint32_t n = (uint32_t)share.transformWorldSlot.size();
             share.transforms.resize(n);
-            share.entityToTransform.assign((size_t)n + 2, GV_NONE);  // id 0 = null, ids 1..n, id n + 1 = "an entity without a transform"
+            share.entityToTransform.assign((size_t)n + 1, GV_NONE);  // id 0 = null, ids 1..n
             for (uint32_t k = 0; k < n; k++)
                 share.entityToTransform[k + 1] = k;
             share.meshes.assign(meshSystems.size(), MeshShare{});
         }
         for (uint32_t i = 0; i < occupancy; i++)
             copyTransform(ts, i);
+        meshTables.assign(meshSystems.size(), MeshTable{});
+        meshStart.assign((size_t)occupancy + 1, 0u);
         for (size_t p = 0; p < meshSystems.size(); p++) {
             const auto& meshPool = meshSystems[p]->getMeshComponentPool();
             const size_t stride = meshSystems[p]->getMeshComponentSize();
             const uint8_t* data = reinterpret_cast<const uint8_t*>(meshPool.getData());
             const uint32_t meshOccupancy = meshPool.getOccupancy();
+            MeshTable& table = meshTables[p];
+            table.rank.assign(meshOccupancy, 0u);
+            table.local.assign(meshOccupancy, 0u);
+            table.entity.assign(meshOccupancy, 0u);
             for (uint32_t r = 0; r < ranks; r++)
                 shares[r].meshes[p].stride = stride;
             for (uint32_t j = 0; j < meshOccupancy; j++) {
@@ -149,10 +224,213 @@ struct RankShares {
                 else if (transformSlot != GV_NONE)
                     local->entity = ID<Entity>(localOfTransform[transformSlot] + 1);
                 else
-                    local->entity = ID<Entity>((uint32_t)shares[rank].transforms.size() + 1);  // alive, no transform (mesh.cpp:149-153)
+                    local->entity = ID<Entity>(kNoTransformEntity);  // alive, no transform (mesh.cpp:149-153)
+                table.rank[j] = rank;
+                table.local[j] = share.occupancy();
+                table.entity[j] = entity;
                 share.worldSlot.push_back(j);
+                if (transformSlot != GV_NONE)
+                    meshStart[transformSlot + 1]++;
             }
         }
+        // transform -> its meshes (what follows a tree from share to share)
+        for (uint32_t t = 0; t < occupancy; t++)
+            meshStart[t + 1] += meshStart[t];
+        meshRefs.assign(meshStart[occupancy], 0u);
+        std::vector<uint32_t> fill(meshStart.begin(), meshStart.end() - 1);
+        for (size_t p = 0; p < meshSystems.size(); p++) {
+            const MeshTable& table = meshTables[p];
+            for (uint32_t j = 0; j < (uint32_t)table.entity.size(); j++) {
+                const uint32_t entity = table.entity[j];
+                const uint32_t transformSlot = entity && entity < emap.size() ? emap[entity] : GV_NONE;
+                if (transformSlot != GV_NONE)
+                    meshRefs[fill[transformSlot]++] = ((uint32_t)p << 28) | j;
+            }
+        }
+    }
+
+    // ---- frame to frame ----
+
+    // Mesh slots [lo, hi) of pool p against the ranks' copies, in the bytes the cull reads — entity (mesh.cpp:142,149), isEnabled
+    // (:142), aabb (:140-141,158): what differs is copied and recorded. false: a slot holds another entity than it was dealt with (a
+    // component came or went): the caller deals again. Runs on the library's worker threads for long ranges.
+    bool syncMeshes(uint32_t p, IMeshRenderSystem* meshSystem, uint32_t lo, uint32_t hi, Changes& changes)
+    {
+        struct Job {
+            RankShares* self;
+            uint32_t p;
+            const uint8_t* world;
+            size_t stride;
+            Changes* changes;
+            std::mutex merge;
+            bool structural = false;
+        } job{this, p, reinterpret_cast<const uint8_t*>(meshSystem->getMeshComponentPool().getData()), meshSystem->getMeshComponentSize(), &changes, {}, false};
+        hi = std::min<uint32_t>(hi, (uint32_t)meshTables[p].entity.size());
+        if (lo >= hi)
+            return true;
+        gv_host_parallel_ranges(lo, hi - lo, [](void* user, uint32_t a, uint32_t b) {
+            Job& j = *static_cast<Job*>(user);
+            const MeshTable& table = j.self->meshTables[j.p];
+            std::vector<std::pair<uint32_t, uint32_t>> edited;  // (rank, local)
+            bool structural = false;
+            constexpr size_t kAabb = offsetof(MeshRenderComponent, aabb);
+            for (uint32_t s = a; s < b; s++) {
+                const auto* w = reinterpret_cast<const MeshRenderComponent*>(j.world + (size_t)s * j.stride);
+                if (*w->entity != table.entity[s]) {
+                    structural = true;
+                    break;
+                }
+                MeshRenderComponent* c = j.self->shares[table.rank[s]].meshes[j.p].at(table.local[s]);
+                if (c->isEnabled == w->isEnabled && std::memcmp(&c->aabb, &w->aabb, sizeof(Aabb)) == 0)
+                    continue;
+                c->isEnabled = w->isEnabled;
+                std::memcpy(reinterpret_cast<uint8_t*>(c) + kAabb, reinterpret_cast<const uint8_t*>(w) + kAabb, sizeof(Aabb));
+                edited.push_back({table.rank[s], table.local[s]});
+            }
+            if (!structural && edited.empty())
+                return;
+            std::lock_guard<std::mutex> lock(j.merge);
+            j.structural = j.structural || structural;
+            for (const auto& e : edited)
+                j.changes->ranks[e.first].meshes[j.p].push_back(e.second);
+        }, &job);
+        return !job.structural;
+    }
+
+    // One transform that moved or changed its flags: its bytes to its rank.
+    void syncTransform(const TransformSystem* ts, uint32_t worldSlot, Changes& changes)
+    {
+        const uint32_t rank = worldSlot < rankOfTransform.size() ? rankOfTransform[worldSlot] : GV_NONE;
+        if (rank == GV_NONE)
+            return;
+        copyTransform(ts, worldSlot);
+        changes.ranks[rank].transforms.push_back(localOfTransform[worldSlot]);
+    }
+    // Every transform (a writer that does not say what it moved), on the worker threads.
+    void syncAllTransforms(const TransformSystem* ts, Changes& changes)
+    {
+        struct Job {
+            RankShares* self;
+            const TransformSystem* ts;
+            std::atomic<bool> broken;
+        } job{this, ts, {false}};
+        gv_host_parallel_ranges(0, (uint32_t)rankOfTransform.size(), [](void* user, uint32_t a, uint32_t b) {
+            Job& j = *static_cast<Job*>(user);
+            for (uint32_t s = a; s < b; s++)
+                if (!j.self->tryCopyTransform(j.ts, s))  // (no exception may leave a worker thread)
+                    j.broken = true;
+        }, &job);
+        if (job.broken)
+            throw std::runtime_error("RankShares: a parent without a transform, or on another rank than its child");
+        for (auto& r : changes.ranks)
+            r.allTransforms = true;
+    }
+
+    // ROOTS among `slots` (world transform slots that moved; empty + all == true: every root) whose position now lies in a cell of
+    // another rank: their trees change shares. SURVEY.md §8e: ownership is a matter of balance, not of correctness.
+    void rebin(const TransformSystem* ts, const std::vector<uint32_t>& slots, bool all, uint32_t ranks, const uint32_t grid[3], double side, Changes& changes)
+    {
+        auto& pool = const_cast<TransformSystem*>(ts)->getComponents();
+        const TransformComponent* world = pool.getData();
+        const uint32_t occupancy = (uint32_t)rankOfTransform.size();
+        std::vector<std::pair<uint32_t, uint32_t>> moves;  // (root slot, new rank)
+        if (all) {
+            std::vector<uint32_t> owner(occupancy ? occupancy : 1);
+            if (occupancy && gv_cell_owner(grid, side, ranks, reinterpret_cast<const float*>(&world[0].posChildCount), (uint32_t)sizeof(TransformComponent), occupancy,
+                                           owner.data()) != GV_OK)
+                throw std::runtime_error("RankShares: gv_cell_owner failed");
+            for (uint32_t s = 0; s < occupancy; s++)
+                if (rankOfTransform[s] != GV_NONE && !*world[s].parent && owner[s] != rankOfTransform[s])
+                    moves.push_back({s, owner[s]});
+        } else {
+            for (uint32_t s : slots) {
+                if (s >= occupancy || rankOfTransform[s] == GV_NONE || *world[s].parent)
+                    continue;
+                uint32_t owner = 0;
+                if (gv_cell_owner(grid, side, ranks, reinterpret_cast<const float*>(&world[s].posChildCount), (uint32_t)sizeof(TransformComponent), 1, &owner) != GV_OK)
+                    throw std::runtime_error("RankShares: gv_cell_owner failed");
+                if (owner != rankOfTransform[s])
+                    moves.push_back({s, owner});
+            }
+        }
+        for (const auto& m : moves)
+            if (rankOfTransform[m.first] != m.second)  // (a slot listed twice has moved already)
+                moveTree(ts, m.first, m.second, changes);
+    }
+
+    // The tree under world transform slot `root` from its rank to `to`: transforms parents first, each with its meshes.
+    void moveTree(const TransformSystem* ts, uint32_t root, uint32_t to, Changes& changes)
+    {
+        const auto& emap = ts->getEntityMap();
+        const uint32_t from = rankOfTransform[root];
+        std::vector<uint32_t> tree{root};
+        for (size_t k = 0; k < tree.size(); k++) {  // (breadth first: a parent is always in front of its children)
+            const TransformComponent* t = worldTransform(ts, tree[k]);
+            for (uint32_t c = 0, n = t->childCount(); c < n; c++) {
+                const uint32_t child = *t->childs[c];
+                const uint32_t slot = child && child < emap.size() ? emap[child] : GV_NONE;
+                if (slot != GV_NONE && rankOfTransform[slot] == from)
+                    tree.push_back(slot);
+            }
+            if (tree.size() > rankOfTransform.size())
+                throw std::runtime_error("RankShares: a cycle in the transform hierarchy");
+        }
+        Share& src = shares[from];
+        Share& dst = shares[to];
+        for (uint32_t s : tree) {
+            const uint32_t was = localOfTransform[s];
+            src.transforms[was] = TransformComponent();  // a free slot (entity = null)
+            src.transformWorldSlot[was] = GV_NONE;
+            src.freeTransforms.push_back(was);
+            changes.ranks[from].transforms.push_back(was);
+            uint32_t now;
+            if (!dst.freeTransforms.empty()) {
+                now = dst.freeTransforms.back();
+                dst.freeTransforms.pop_back();
+            } else {
+                now = (uint32_t)dst.transforms.size();
+                dst.transforms.emplace_back();
+                dst.transformWorldSlot.push_back(GV_NONE);
+                dst.entityToTransform.push_back(now);  // entity now + 1
+            }
+            dst.transformWorldSlot[now] = s;
+            rankOfTransform[s] = to;
+            localOfTransform[s] = now;
+            copyTransform(ts, s);
+            changes.ranks[to].transforms.push_back(now);
+            if (*dst.transforms[now].parent)
+                changes.ranks[to].links.push_back(now);
+            for (uint32_t k = meshStart[s]; k < meshStart[s + 1]; k++) {
+                const uint32_t p = meshRefs[k] >> 28, j = meshRefs[k] & 0x0FFFFFFFu;
+                MeshTable& table = meshTables[p];
+                MeshShare& ms = src.meshes[p];
+                MeshShare& md = dst.meshes[p];
+                const uint32_t lwas = table.local[j];
+                uint32_t lnow;
+                if (!md.freeSlots.empty()) {
+                    lnow = md.freeSlots.back();
+                    md.freeSlots.pop_back();
+                } else {
+                    lnow = md.occupancy();
+                    md.worldSlot.push_back(GV_NONE);
+                    md.components.resize(md.components.size() + md.stride);
+                }
+                std::memcpy(md.components.data() + (size_t)lnow * md.stride, ms.components.data() + (size_t)lwas * ms.stride, md.stride);
+                md.at(lnow)->entity = ID<Entity>(now + 1);
+                md.worldSlot[lnow] = j;
+                ms.at(lwas)->entity = ID<Entity>();  // a free slot on the rank it left (mesh.cpp:142)
+                ms.worldSlot[lwas] = GV_NONE;
+                ms.freeSlots.push_back(lwas);
+                table.rank[j] = to;
+                table.local[j] = lnow;
+                changes.ranks[from].meshes[p].push_back(lwas);
+                changes.ranks[from].maps[p].push_back(lwas);
+                changes.ranks[to].meshes[p].push_back(lnow);
+                changes.ranks[to].maps[p].push_back(lnow);
+            }
+        }
+        changes.movedTrees++;
+        changes.movedTransforms += (uint32_t)tree.size();
     }
 };
 

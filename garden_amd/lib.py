@@ -69,7 +69,8 @@ class GvStats(C.Structure):
     _fields_ = [("launches", C.c_uint64 * GV_K_COUNT), ("device_ms", C.c_double * GV_K_COUNT),
                 ("upload_bytes", C.c_uint64), ("max_depth", C.c_uint32), ("transform_count", C.c_uint32),
                 ("mesh_count", C.c_uint32 * GV_MAX_POOLS), ("bounds_blocks_total", C.c_uint64),
-                ("bounds_blocks_examined", C.c_uint64), ("mirror_reorders", C.c_uint64), ("record_targets_lost", C.c_uint64)]
+                ("bounds_blocks_examined", C.c_uint64), ("mirror_reorders", C.c_uint64), ("record_targets_lost", C.c_uint64),
+                ("exchanges", C.c_uint64), ("exchange_tail_rounds", C.c_uint64)]
 
 
 GV_EXCHANGE_MAX_RANKS = 64
@@ -79,7 +80,16 @@ class GvExchangeFrame(C.Structure):
     _fields_ = [("gathered_device", C.c_void_p), ("row_words", C.c_uint32), ("world_size", C.c_uint32), ("frame", C.c_uint64),
                 ("room", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("travelled_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS),
                 ("counts", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("tail_words", C.c_uint32 * GV_EXCHANGE_MAX_RANKS), ("cut_ranks", C.c_uint64),
-                ("complete", C.c_uint32), ("mode", C.c_uint32), ("ready_event", C.c_void_p)]
+                ("complete", C.c_uint32), ("mode", C.c_uint32), ("ready_event", C.c_void_p),
+                ("items", C.c_uint32), ("item_counts", C.POINTER(C.c_uint32))]
+
+
+GV_EXCHANGE_MAX_ITEMS = 128
+GV_RESULTS_MAP_RECORDS, GV_RESULTS_MAP_VISIBLE = 1, 2
+
+
+class GvExchangeItem(C.Structure):
+    _fields_ = [("pool_id", C.c_uint32), ("view_index", C.c_uint32), ("index_base", C.c_uint32)]
 
 
 class GvColumn(C.Structure):
@@ -123,6 +133,7 @@ EXPORTS = [
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_pool_exchange_visible", "gv_pool_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_views", "gv_exchange_views_all", "gv_pool_update_index_map", "gv_pool_set_result_mapping", "gv_host_parallel_ranges",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -208,6 +219,12 @@ def load():
     lib.gv_pool_exchange_visible.argtypes = [P, u32, u32, u32, u32, C.POINTER(GvExchangeFrame)]
     lib.gv_pool_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, u32, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_acquire_all.argtypes = [C.POINTER(P), C.c_int, C.c_uint64, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_views.argtypes = [P, C.POINTER(GvExchangeItem), u32, u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_exchange_views_all.argtypes = [C.POINTER(P), C.c_int, C.POINTER(GvExchangeItem), u32, u32, C.POINTER(GvExchangeFrame)]
+    lib.gv_pool_update_index_map.argtypes = [P, u32, u32, C.POINTER(u32), u32]
+    lib.gv_pool_set_result_mapping.argtypes = [P, u32, u32, C.c_void_p, C.c_size_t, u32]
+    lib.gv_host_parallel_ranges.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
+    lib.gv_host_parallel_ranges.restype = None
     lib.gv_exchange_set_timeout.argtypes = [P, u32]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]

@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define GV_ABI_VERSION 3u /* 3: every exchanged frame is complete (gv_exchange_acquire fills the frame; GV_EXCHANGE_EXACT and
-                             gv_exchange_counts are gone); one thread can drive N contexts (gv_exchange_*_all); GV_E_TIMEOUT */
+#define GV_ABI_VERSION 4u /* 3: every exchanged frame is complete (gv_exchange_acquire fills the frame; GV_EXCHANGE_EXACT and
+                             gv_exchange_counts are gone); one thread can drive N contexts (gv_exchange_*_all); GV_E_TIMEOUT
+                             4: ONE exchange per frame for all its (pool, view) lists (gv_exchange_views[_all]); a rank's results in
+                             the WORLD's slots (gv_pool_set_result_mapping, gv_pool_update_index_map); GvStats grew; GvExchangeFrame grew */
 #define GV_NONE 0xFFFFFFFFu
 #define GV_MAX_POOLS 16u
 #define GV_MAX_VIEWS 8u
@@ -264,6 +266,26 @@ int gv_pool_mirror_epoch(GvCtx* ctx, uint32_t pool_id, uint64_t* epoch);
  * gv_results_copy_idx_device / gv_results_copy_shard_device / gv_exchange_shards write global_ids[visible_idx] +
  * index_base instead of visible_idx + index_base whenever the table covers the culled pool. count == 0 removes it. */
 int gv_pool_set_index_map(GvCtx* ctx, uint32_t pool_id, const uint32_t* global_ids, uint32_t count);
+/* Entries [first, first + count) of that table replaced (a few slots of a rank's share changed hands: a root crossed into another
+ * rank's cell and its tree moved, SURVEY.md §8e "re-bin only roots whose position crosses a cell"); first + count may exceed the
+ * table's size — it grows (slots appended to the share). GV_NONE marks a slot that stands for no world slot (a hole in the share:
+ * never visible, skipped by the write-back below). Ordered on gv_stream(ctx) behind the work already queued. */
+int gv_pool_update_index_map(GvCtx* ctx, uint32_t pool_id, uint32_t first, const uint32_t* global_ids, uint32_t count);
+/* A rank's results delivered in the WORLD's numbering (one process, N contexts: the host fills the engine's buffers from every
+ * rank's results, mesh.cpp:144-183). flags:
+ *   GV_RESULTS_MAP_RECORDS  records in the pool's record layout (gv_pool_set_record_layout) carry componentOffset =
+ *                           index_map[slot] * component_stride (mesh.cpp:170 in the engine's own pool): a rank's records are copied
+ *                           into combinedMeshes as they are
+ *   GV_RESULTS_MAP_VISIBLE  the write-back of gv_pool_results_fetch(write_back != 0) stores slot i's isVisible byte at
+ *                           visible_base + index_map[i] * visible_stride — straight into the engine's pool (mesh.cpp:144,152,161,
+ *                           166), wherever the rank's share keeps slot i — instead of into the bound share; entries that are GV_NONE
+ *                           or >= visible_count are skipped. The caller guarantees [visible_base, + visible_count * visible_stride)
+ *                           until the fetch returns; ranks write disjoint slots.
+ * Both need the pool's index map (GV_E_STATE at the fetch while it does not cover the culled pool). GvResult.is_visible stays in
+ * the share's own slots. Not available together with gv_pool_bind_ready (GV_E_STATE). flags == 0 removes the mapping. */
+#define GV_RESULTS_MAP_RECORDS 1u
+#define GV_RESULTS_MAP_VISIBLE 2u
+int gv_pool_set_result_mapping(GvCtx* ctx, uint32_t pool_id, uint32_t flags, void* visible_base, size_t visible_stride, uint32_t visible_count);
 
 /* Results are kept per (pool, view). The view-indexed calls above address the pool of the most recent gv_cull; these
  * name the pool, so that a frame can issue the culls (and sort requests) of ALL its mesh systems first and read the
@@ -384,6 +406,12 @@ typedef struct GvExchangeFrame {
     uint32_t complete;           /* 1: acquired — every row holds its rank's whole list */
     uint32_t mode;               /* GvExchangeMode the rows travelled by */
     void* ready_event;           /* acquired frames: hipEvent_t behind the complete rows (hipStreamWaitEvent on a consumer's stream) */
+    /* gv_exchange_views (0 for the single-list forms): the frame carries `items` lists per rank. Row r = [items + total, c_0 ..
+     * c_{items-1}, list 0 (c_0 entries), list 1 ...]: the header counts the table too, so counts[] / room[] / tail_words[] above
+     * are in words behind the header. item_counts (acquired frames; library-owned host memory, valid as long as the rows):
+     * item_counts[r * items + i] = c_i of rank r. */
+    uint32_t items;
+    const uint32_t* item_counts;
 } GvExchangeFrame;
 int gv_exchange_visible(GvCtx* ctx, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
 /* view_index / index_base: [world_size] (index_bases NULL: all 0); frames: [world_size] outputs. */
@@ -394,6 +422,20 @@ int gv_exchange_visible_all(GvCtx* const* contexts, int world_size, const uint32
 int gv_pool_exchange_visible(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, uint32_t index_base, uint32_t flags, GvExchangeFrame* out);
 int gv_pool_exchange_visible_all(GvCtx* const* contexts, int world_size, uint32_t pool_id, const uint32_t* view_indices,
                                  const uint32_t* index_bases, uint32_t flags, GvExchangeFrame* frames);
+/* ONE exchange for ALL the lists of a frame — the reference dispatches every mesh system's tasks and waits once
+ * (source/system/render/mesh.cpp:408-546, :548): `items` names the (pool, view) pairs of the frame, the same list on every rank; a
+ * rank's row is [item_count + total entries, c_0 .. c_{item_count-1}, list 0, list 1 ...] (lists packed back to back, each as
+ * gv_pool_exchange_visible would send it: the pool's index map applied, index_base added), sized, completed and acquired as ONE
+ * frame exactly like the single-list forms (the room prediction works on the row's words; a cut row's tail is one contiguous piece).
+ * item_count <= GV_EXCHANGE_MAX_ITEMS. A consumer finds list i of rank r at row r + 1 + item_count + sum(c_0 .. c_{i-1}).
+ * GvStats::exchanges counts frames sent, whatever their form. */
+#define GV_EXCHANGE_MAX_ITEMS 128u
+typedef struct GvExchangeItem {
+    uint32_t pool_id, view_index, index_base;
+} GvExchangeItem;
+int gv_exchange_views(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, uint32_t flags, GvExchangeFrame* out);
+int gv_exchange_views_all(GvCtx* const* contexts, int world_size, const GvExchangeItem* items, uint32_t item_count, uint32_t flags,
+                          GvExchangeFrame* frames);
 /* Settles frame `frame` (one of the last two) if that has not happened yet — waits for its headers on the host, completes cut rows —
  * makes gv_stream(ctx) wait for the complete rows and fills *out (NULL: not wanted). Every rank acquires, or none does: the
  * completing exchange is a collective (ranks that skip it meet it inside their next gv_exchange_visible). */
@@ -582,6 +624,8 @@ typedef struct GvStats {
     uint64_t record_targets_lost;    /* gv_pool_set_record_target calls since gv_create that found the PREVIOUS target's range unmapped
                                         when they let it go (the caller freed it too early; text in gv_last_error). The call itself
                                         succeeds: the new target is in place */
+    uint64_t exchanges;              /* exchange frames sent since gv_stats_reset (gv_exchange_visible* / gv_exchange_views*: one per call) */
+    uint64_t exchange_tail_rounds;   /* ... and how many of them needed the second, exactly sized exchange (a short prediction) */
 } GvStats;
 int gv_stats(GvCtx* ctx, GvStats* out);
 int gv_stats_reset(GvCtx* ctx);
@@ -604,6 +648,10 @@ int gv_profile_samples(GvCtx* ctx, uint64_t samples[GV_K_COUNT]);
 int gv_debug_stream_peak(GvCtx* ctx, uint32_t pool_id, uint32_t launches, double* gb_per_s);
 /* The HIP stream all work is enqueued on (hipStream_t as void*), for callers timing with their own events. */
 void* gv_stream(GvCtx* ctx);
+/* The library's parked host workers for a caller's own O(N) passes over its pools (the reference runs such loops on its
+ * ThreadPool, source/thread-pool.cpp:173-200: contiguous ranges, the calling thread takes part): fn(user, lo, hi) over contiguous
+ * pieces of [first, first + count); one piece on the calling thread for short ranges. Returns when all pieces are done. */
+void gv_host_parallel_ranges(uint32_t first, uint32_t count, void (*fn)(void* user, uint32_t lo, uint32_t hi), void* user);
 
 #ifdef __cplusplus
 }

@@ -294,12 +294,15 @@ int main(int argc, char** argv)
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
+    bool probeExchange = false;  // --probe-exchange (with --ranks): the drop-in times the three travel patterns on its first frame and keeps the fastest
+    bool noRebin = false;        // --no-rebin (with --ranks): roots that cross cells stay on their rank (the balance decays; results are the same)
     bool unversioned = false;  // --unversioned: the mesh systems carry no change counters (like every mesh system of the reference)
     bool hiz = false;        // --hiz: a depth image with walls is handed to both systems: the light pass of the non-UI systems runs the
                              // per-AABB occlusion query behind the frustum test (with --ranks: the pyramid is built on every rank)
     bool csmPasses = false;  // --csm: three cascades from calcLightViewProj (csm_lite.hpp) as the shadow passes
     int skipPass = -1;       // --skip-pass K: the shadow system's prepareShadowRender says no for pass K (renderShadows, mesh.cpp:812-813:
                              // `continue`): the pass is not prepared, the others keep their numbers — isDrawReady is asked with THOSE
+    float animateStep = 0.25f;  // --animate-step S: how far a moved entity goes per tick (large steps: roots cross cells, with --ranks their trees change ranks)
     uint32_t animate = 0;  // --animate K: before every tick, every K-th entity moves (a dynamic scene: the mirror follows every frame)
     bool world = false;     // --world: the GPU system keeps the world-matrix cache (incremental sweep); every compared tick
                             // checks gv_get_world of every transform slot against the oracle's chain walk, bit for bit
@@ -321,6 +324,9 @@ int main(int argc, char** argv)
         else if (a == "--churn" && i + 1 < argc) churn = (uint32_t)atoi(argv[++i]);
         else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
+        else if (a == "--animate-step" && i + 1 < argc) animateStep = (float)atof(argv[++i]);
+        else if (a == "--probe-exchange") probeExchange = true;
+        else if (a == "--no-rebin") noRebin = true;
         else if (a == "--csm") csmPasses = true;
         else if (a == "--skip-pass" && i + 1 < argc) skipPass = atoi(argv[++i]);
         else if (a == "--gate" && i + 1 < argc) gate = argv[++i];
@@ -387,6 +393,7 @@ int main(int argc, char** argv)
         // what the devices held after the gather of each (mesh system, pass) of the last tick: the union of the ranks' rows
         std::map<std::pair<uint32_t, int>, std::vector<uint32_t>> gathered;
         std::string gatherProblem;
+        uint64_t exchangesSeen = 0;
         if (mode == "gpu" || mode == "both") {
             if (ranks > 1)
                 gpu = manager.createSystem<GpuVisibilitySystem>(std::vector<int>(ranks, 0), (double)(100.0f * std::cbrt((float)entities)), false, bounds);
@@ -394,11 +401,12 @@ int main(int argc, char** argv)
                 gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
         }
         if (gpu && ranks > 1)
-            gpu->onGathered = [&](uint32_t meshSystemIndex, int8_t pass, const GvExchangeFrame* frames, uint32_t n) {
+            gpu->onGathered = [&](const GpuVisibilitySystem::GatheredList* lists, uint32_t listCount, const GvExchangeFrame* frames, uint32_t n) {
+                // ONE frame of the exchange carries every list of the tick: row q = [listCount + total, c_0 .. c_{listCount-1}, list 0, list 1 ...]
                 std::vector<std::vector<uint32_t>> rows(n);
                 for (uint32_t r = 0; r < n; r++) {
                     const GvExchangeFrame& f = frames[r];
-                    if (!f.complete || !f.gathered_device || f.world_size != n) {
+                    if (!f.complete || !f.gathered_device || f.world_size != n || f.items != listCount || !f.item_counts) {
                         gatherProblem = "a gathered frame is not complete";
                         return;
                     }
@@ -409,7 +417,7 @@ int main(int argc, char** argv)
                         return;
                     }
                 }
-                std::vector<uint32_t> all;
+                std::vector<std::vector<uint32_t>> all(listCount);
                 for (uint32_t q = 0; q < n; q++) {
                     const uint32_t* mine = rows[0].data() + (size_t)q * frames[0].row_words;
                     for (uint32_t r = 1; r < n; r++) {
@@ -419,10 +427,27 @@ int main(int argc, char** argv)
                     }
                     if (mine[0] != frames[0].counts[q])
                         gatherProblem = "a row's header is not the count the frame reports";
-                    all.insert(all.end(), mine + 1, mine + 1 + mine[0]);
+                    uint32_t at = 1 + listCount, sum = 0;
+                    for (uint32_t i = 0; i < listCount; i++) {
+                        const uint32_t c = mine[1 + i];
+                        if (c != frames[0].item_counts[(size_t)q * listCount + i])
+                            gatherProblem = "a row's count table is not what the frame reports";
+                        if (at + c > 1 + mine[0]) {
+                            gatherProblem = "a row's count table runs past its header";
+                            return;
+                        }
+                        all[i].insert(all[i].end(), mine + at, mine + at + c);
+                        at += c;
+                        sum += c;
+                    }
+                    if (mine[0] != listCount + sum)
+                        gatherProblem = "a row's header is not the size of its table and lists";
                 }
-                std::sort(all.begin(), all.end());
-                gathered[{meshSystemIndex, (int)pass}] = std::move(all);
+                for (uint32_t i = 0; i < listCount; i++) {
+                    std::sort(all[i].begin(), all[i].end());
+                    gathered[{lists[i].meshSystemIndex, (int)lists[i].shadowPass}] = std::move(all[i]);
+                }
+                exchangesSeen++;
             };
         if (cpu) cpu->isNonTranslucent = g_nonTranslucent;
         if (gpu) {
@@ -430,6 +455,8 @@ int main(int argc, char** argv)
             gpu->recordStructs = !soaRecords;
             gpu->recordTargets = !copyRecords;
             gpu->recordSpans = spanRecords;
+            gpu->probeExchangeMode = probeExchange;
+            gpu->rebinMovedRoots = !noRebin;
         }
         if (gpu && world)
             gpu->sweepWorldMatrices = gpu->sweepIncremental = true;
@@ -588,7 +615,9 @@ int main(int argc, char** argv)
                 if (animate && moving) {  // timed with the tick: the engine's own systems would be doing this
                     for (uint32_t k = animateTick % animate; k < (uint32_t)ents.size(); k += animate)
                         if (auto t = transformSystem->tryGetOf(ents[k])) {
-                            t->posChildCount.x += 0.25f;
+                            t->posChildCount.x += animateStep;
+                            if (std::fabs(t->posChildCount.x) > 0.5f * side)  // (stay inside the world cube: wrap around)
+                                t->posChildCount.x -= std::copysign(side, t->posChildCount.x);
                             if (itemised)
                                 transformSystem->markMoved(ents[k]);
                         }
@@ -801,16 +830,37 @@ int main(int argc, char** argv)
                 shares += std::string(r ? ", " : "") + std::to_string(gpu->getRankShares().shares[r].transforms.size());
             fprintf(stderr, "ranks %u: transforms per rank %s]\n", ranks, shares.c_str());
         }
+        std::string rankJson;
+        if (gpu && ranks > 1) {
+            const auto& c = gpu->rankCounters;
+            char text[512];
+            snprintf(text, sizeof(text), "\"ranks\": %u, \"rank_frames\": %llu, \"exchanges\": %llu, \"exchanges_seen\": %llu, \"deals\": %llu, \"moved_trees\": %llu, "
+                     "\"moved_transforms\": %llu, \"edited_meshes\": %llu, \"exchange_mode\": %u, \"exchange_mode_probe_ms\": [%.4f, %.4f, %.4f], ", ranks,
+                     (unsigned long long)c.frames, (unsigned long long)c.exchanges, (unsigned long long)exchangesSeen, (unsigned long long)c.deals,
+                     (unsigned long long)c.movedTrees, (unsigned long long)c.movedTransforms, (unsigned long long)c.editedMeshes, gpu->exchangeMode,
+                     gpu->exchangeModeProbeMs[0], gpu->exchangeModeProbeMs[1], gpu->exchangeModeProbeMs[2]);
+            rankJson = text;
+        }
         printf("{\"mode\": \"%s\", \"entities\": %u, \"ticks\": %u, \"threads\": %u, \"hier\": %s, \"shadow_draw_counts\": %s, \"draw_count\": %u, "
-               "\"sorted_draw_count\": %u, \"is_visible_set\": %u, \"culls_per_s\": %.1f, \"ok\": %s, \"why\": \"%s\"}\n",
+               "\"sorted_draw_count\": %u, \"is_visible_set\": %u, \"culls_per_s\": %.1f, %s\"ok\": %s, \"why\": \"%s\"}\n",
                mode.c_str(), entities, ticks * rounds, threads, hier ? "true" : "false", shadowCounts.c_str(), drawCount, sortedDrawCount, visibleFlags,
-               (double)entities * ticks * rounds / seconds, ok ? "true" : "false", why.c_str());
+               (double)entities * ticks * rounds / seconds, rankJson.c_str(), ok ? "true" : "false", why.c_str());
         if (gpu && getenv("GV_TICK_BREAKDOWN")) {
             const auto& t = gpu->tickSeconds;
             const double n = (double)ticks * rounds * 1e-6;  // -> microseconds per tick
             fprintf(stderr, "gpu prepare us/tick: total %.1f = cull %.1f + sort %.1f + fetch %.1f + records %.1f + shares %.1f + gather %.1f + other %.1f\n", t.total / n,
                     t.cull / n, t.sort / n, t.fetch / n, t.records / n, t.share / n, t.gather / n,
                     (t.total - t.cull - t.sort - t.fetch - t.records - t.share - t.gather) / n);
+            if (ranks > 1) {
+                const auto& c = gpu->rankCounters;
+                GvStats stats{};
+                gv_stats(gpu->getContext(0), &stats);
+                fprintf(stderr, "ranks: %llu frames, exchanges per frame %.2f (gv_stats of rank 0: %llu sent, %llu with a second exchange), deals %llu, trees moved %llu "
+                        "(%llu transforms), mesh slots edited %llu, transforms copied %llu\n", (unsigned long long)c.frames,
+                        c.frames ? (double)c.exchanges / (double)c.frames : 0.0, (unsigned long long)stats.exchanges, (unsigned long long)stats.exchange_tail_rounds,
+                        (unsigned long long)c.deals, (unsigned long long)c.movedTrees, (unsigned long long)c.movedTransforms, (unsigned long long)c.editedMeshes,
+                        (unsigned long long)c.copiedTransforms);
+            }
         }
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

@@ -28,13 +28,29 @@ hipError_t launch_copy_shard(const uint32_t* src, const uint32_t* count, uint32_
     return hipSuccess;
 }
 
-hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t* host_words, uint32_t seq,
+hipError_t launch_copy_shard_batch(const ShardItem* items, uint32_t n, uint32_t, uint32_t* dst, hipStream_t)
+{
+    uint32_t at = 1u + n, total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = std::min(*items[i].count, items[i].capacity);
+        dst[1u + i] = c;
+        for (uint32_t k = 0; k < c; k++)
+            dst[at + k] = (items[i].map ? items[i].map[items[i].src[k]] : items[i].src[k]) + items[i].base;
+        at += c;
+        total += c;
+    }
+    dst[0] = n + total;
+    return hipSuccess;
+}
+
+hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t hdr_words, uint32_t* host_words, uint32_t seq,
                                    hipStream_t)
 {
     for (uint32_t r = 0; r < world; r++)
-        host_words[r] = rows[(size_t)r * row_words];
+        for (uint32_t w = 0; w < hdr_words; w++)
+            host_words[1u + (size_t)r * hdr_words + w] = rows[(size_t)r * row_words + w];
     std::atomic_thread_fence(std::memory_order_release);
-    host_words[world] = seq;
+    host_words[0] = seq;
     return hipSuccess;
 }
 

@@ -7,6 +7,8 @@
 // without a gfx950 device.
 #pragma once
 #define GV_HIP_STUB 1
+#define __host__
+#define __device__
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>

@@ -838,6 +838,63 @@ static void exchange_in_one_thread(int ranks, int list_seed)
             }
         }
     }
+    // ONE exchange for ALL the lists of a frame (gv_exchange_views_all): pool 0's list and pool 1's (index_base 5) behind a count
+    // table, in one row per rank; the lists alternate between short and long, so that batched frames are completed by a second
+    // exchange too
+    {
+        const GvExchangeItem items[2] = {{0u, 0u, 0u}, {1u, 0u, 5u}};
+        GvStats before{};
+        CHECK(gv_stats(ctxs[0], &before));
+        int batched = 0, batched_cut = 0;
+        for (int frame = 14; frame < 22; frame++) {
+            const int list = frame % 2 ? 9 : 3;  // (list_count's scripted sequence: 3 = creeping, 9 = after the jump)
+            for (int r = 0; r < ranks; r++) {
+                xs[r].produce(list, (uint32_t)(frame % 3));
+                xs[r].cull_other_pool();
+            }
+            CHECK(gv_exchange_views_all(ctxs.data(), ranks, items, 2, 0, sent.data()));
+            if (frame % 4 == 3)
+                continue;  // (left to the next exchange to complete)
+            CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+            batched++;
+            for (int r = 0; r < ranks; r++) {
+                const GvExchangeFrame& f = got[r];
+                if (!f.complete || !f.gathered_device || f.items != 2 || !f.item_counts || f.frame != (uint64_t)frame || sent[r].items != 2 || sent[r].item_counts)
+                    xs[r].fail("fields of a batched frame", frame, -1);
+                const uint32_t* rows = (const uint32_t*)f.gathered_device;
+                for (int q = 0; q < ranks && f.complete; q++) {
+                    const uint32_t* row = rows + (size_t)q * f.row_words;
+                    const uint32_t c0 = list_count(q, list, ExchangeRank::n), c1 = ExchangeRank::other_count;
+                    if (row[0] != 2 + c0 + c1 || f.counts[q] != row[0] || row[1] != c0 || row[2] != c1 || f.item_counts[q * 2] != c0 || f.item_counts[q * 2 + 1] != c1)
+                        xs[r].fail("header / count table of a batched row", frame, q);
+                    for (uint32_t k = 0; k < c0; k++)
+                        if (row[3 + k] != list_value(q, list, k)) {
+                            xs[r].fail("entry of the first list of a batched row", frame, q);
+                            break;
+                        }
+                    for (uint32_t k = 0; k < c1; k++)
+                        if (row[3 + c0 + k] != 4200u + (uint32_t)q + k + 5u) {
+                            xs[r].fail("entry of the second list of a batched row (index_base 5)", frame, q);
+                            break;
+                        }
+                }
+                if (r == 0 && f.cut_ranks)
+                    batched_cut++;
+            }
+        }
+        GvStats after{};
+        CHECK(gv_stats(ctxs[0], &after));
+        if (after.exchanges - before.exchanges != 8)
+            xs[0].fail("GvStats::exchanges does not count one per gv_exchange_views_all", -1, -1);
+        if (ranks > 1 && g_list_seed == 0 && batched_cut == 0)  // (the scripted sequence: list 9 is nine times list 3)
+            xs[0].fail("no batched frame needed a second exchange: the tail path of the batched form was not exercised", -1, -1);
+        EXPECT(gv_exchange_views_all(ctxs.data(), ranks, items, 0, 0, sent.data()), GV_E_ARG);
+        EXPECT(gv_exchange_views_all(ctxs.data(), ranks, items, GV_EXCHANGE_MAX_ITEMS + 1, 0, sent.data()), GV_E_ARG);
+        EXPECT(gv_exchange_views_all(ctxs.data(), ranks, nullptr, 2, 0, sent.data()), GV_E_ARG);
+        const GvExchangeItem bad[1] = {{GV_MAX_POOLS, 0u, 0u}};
+        EXPECT(gv_exchange_views_all(ctxs.data(), ranks, bad, 1, 0, sent.data()), GV_E_ARG);
+        std::printf("batched exchange (gv_exchange_views_all), %d ranks: %d frames acquired, %d of them completed by a second exchange\n", ranks, batched, batched_cut);
+    }
     EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, GV_MAX_POOLS, views.data(), nullptr, 0, sent.data()), GV_E_ARG);
     EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, 0, views.data(), nullptr, 2, sent.data()), GV_E_ARG);
     EXPECT(gv_pool_exchange_visible_all(ctxs.data(), ranks, 5, views.data(), nullptr, 0, sent.data()), GV_E_ARG);  // a pool never bound / culled
@@ -845,8 +902,14 @@ static void exchange_in_one_thread(int ranks, int list_seed)
         xs[0].produce(14, GV_EXCHANGE_P2P);
         xs[0].cull_other_pool();
         CHECK(gv_pool_exchange_visible(ctxs[0], 0, 0, 0, 0, &sent[0]));
-        CHECK(gv_exchange_acquire(ctxs[0], 14, &got[0]));
+        CHECK(gv_exchange_acquire(ctxs[0], 22, &got[0]));
+        got[0].frame = sent[0].frame = 14;  // (check_acquired derives the expected list from the frame number: list 14 travelled as frame 22)
         xs[0].check_acquired(sent[0], got[0], 14);
+        const GvExchangeItem alone[1] = {{0u, 0u, 0u}};
+        CHECK(gv_exchange_views(ctxs[0], alone, 1, 0, &sent[0]));  // the per-rank form of the batched exchange
+        CHECK(gv_exchange_acquire(ctxs[0], 23, &got[0]));
+        if (!got[0].complete || got[0].items != 1 || ((const uint32_t*)got[0].gathered_device)[1] != list_count(0, 14, ExchangeRank::n))
+            xs[0].fail("gv_exchange_views of one rank", 23, 0);
         EXPECT(gv_pool_exchange_visible(ctxs[0], GV_MAX_POOLS, 0, 0, 0, &sent[0]), GV_E_ARG);
     }
     int failures = 0;

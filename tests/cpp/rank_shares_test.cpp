@@ -6,6 +6,11 @@
 //   * every slot of every mesh pool lives on exactly one rank (free slots and meshes without a transform included), its local entity
 //     id resolves to the transform the world's entity resolves to (or to nothing), the world slot table is a permutation
 //   * copyTransform refreshes a moved transform in place
+// ... and frame to frame, without another deal (round 6): edited mesh components are found and copied (syncMeshes, with and
+// without the system saying which), a slot that changed hands is reported as structural, every transform is re-copied on the worker
+// threads (syncAllTransforms), and roots that crossed into another rank's cell take their trees — transforms and meshes — to that
+// rank (rebin / moveTree: holes are left and reused); the same invariants hold after every step, and what the steps report
+// (Changes) names exactly the local slots whose bytes differ from before.
 // Links libgarden_vis.so for gv_cell_owner (host-only; no device is touched).
 #include <cmath>
 #include <cstdio>
@@ -32,7 +37,7 @@ static int failures = 0;
     } while (0)
 
 static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem*>& meshSystems, const RankShares& shares, uint32_t ranks,
-                  const uint32_t grid[3], double side, const char* what)
+                  const uint32_t grid[3], double side, const char* what, bool ownersMatter = true)
 {
     auto& pool = const_cast<TransformSystem*>(ts)->getComponents();
     const auto& emap = ts->getEntityMap();
@@ -45,18 +50,26 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
     std::vector<uint32_t> seen(occupancy, 0);
     for (uint32_t r = 0; r < ranks; r++) {
         const auto& share = shares.shares[r];
-        EXPECT(share.transforms.size() == share.transformWorldSlot.size() && share.entityToTransform.size() == share.transforms.size() + 2, "%s: rank %u sizes", what, r);
+        EXPECT(share.transforms.size() == share.transformWorldSlot.size() && share.entityToTransform.size() == share.transforms.size() + 1, "%s: rank %u sizes", what, r);
+        uint32_t holes = 0;
         for (uint32_t k = 0; k < share.transforms.size(); k++) {
             const uint32_t w = share.transformWorldSlot[k];
-            seen[w]++;
             const TransformComponent& local = share.transforms[k];
+            if (w == GV_NONE) {  // a hole left by a tree that moved away
+                EXPECT(*local.entity == 0 && *local.parent == 0, "%s: rank %u hole %u still holds an entity", what, r, k);
+                holes++;
+                continue;
+            }
+            seen[w]++;
+            EXPECT(shares.rankOfTransform[w] == r && shares.localOfTransform[w] == k, "%s: the tables do not lead to rank %u slot %u", what, r, k);
             EXPECT(*local.entity == k + 1 && share.entityToTransform[k + 1] == k, "%s: rank %u local entity id of slot %u", what, r, k);
             EXPECT(std::memcmp(&local.posChildCount, &world[w].posChildCount, 12) == 0 && std::memcmp(&local.rotation, &world[w].rotation, 16) == 0 &&
                        local.selfActive == world[w].selfActive && local.ancestorsActive == world[w].ancestorsActive, "%s: rank %u slot %u is not the world's transform", what, r, k);
             uint32_t root = w;  // the world's root of w
             for (uint32_t guard = 0; *world[root].parent && guard < occupancy; guard++)
                 root = emap[*world[root].parent];
-            EXPECT(owners[root] == r, "%s: transform %u lives on rank %u, its root's cell belongs to rank %u", what, w, r, owners[root]);
+            if (ownersMatter)
+                EXPECT(owners[root] == r, "%s: transform %u lives on rank %u, its root's cell belongs to rank %u", what, w, r, owners[root]);
             if (*world[w].parent) {
                 const uint32_t parentSlot = emap[*world[w].parent];
                 EXPECT(shares.rankOfTransform[parentSlot] == r && *local.parent == shares.localOfTransform[parentSlot] + 1, "%s: parent link of transform %u", what, w);
@@ -64,6 +77,7 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
                 EXPECT(*local.parent == 0, "%s: a root with a parent", what);
             }
         }
+        EXPECT(holes == share.freeTransforms.size(), "%s: rank %u has %u holes and %zu free slots", what, r, holes, share.freeTransforms.size());
     }
     for (uint32_t i = 0; i < occupancy; i++)
         EXPECT(seen[i] == (*world[i].entity ? 1u : 0u), "%s: transform slot %u is held %u times", what, i, seen[i]);
@@ -75,10 +89,17 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
         for (uint32_t r = 0; r < ranks; r++) {
             const auto& mesh = shares.shares[r].meshes[p];
             EXPECT(mesh.stride == stride && mesh.components.size() == (size_t)mesh.occupancy() * stride, "%s: pool %zu rank %u sizes", what, p, r);
+            uint32_t holes = 0;
             for (uint32_t j = 0; j < mesh.occupancy(); j++) {
                 const uint32_t w = mesh.worldSlot[j];
-                held[w]++;
                 const auto* local = reinterpret_cast<const MeshRenderComponent*>(mesh.components.data() + (size_t)j * stride);
+                if (w == GV_NONE) {
+                    EXPECT(*local->entity == 0, "%s: pool %zu rank %u hole %u still holds an entity", what, p, r, j);
+                    holes++;
+                    continue;
+                }
+                held[w]++;
+                EXPECT(shares.meshTables[p].rank[w] == r && shares.meshTables[p].local[w] == j, "%s: pool %zu: the tables do not lead to rank %u slot %u", what, p, r, j);
                 const auto* global = reinterpret_cast<const MeshRenderComponent*>(data + (size_t)w * stride);
                 EXPECT(std::memcmp(&local->aabb, &global->aabb, sizeof(Aabb)) == 0 && local->isEnabled == global->isEnabled, "%s: pool %zu slot %u is not the world's component", what, p, w);
                 const uint32_t entity = *global->entity;
@@ -87,13 +108,14 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
                 if (!entity) {
                     EXPECT(localEntity == 0, "%s: a free mesh slot with an entity", what);
                 } else if (transformSlot == GV_NONE) {
-                    EXPECT(localEntity < shares.shares[r].entityToTransform.size() && shares.shares[r].entityToTransform[localEntity] == GV_NONE,
+                    EXPECT(localEntity == RankShares::kNoTransformEntity && localEntity >= shares.shares[r].entityToTransform.size(),
                            "%s: a mesh without a transform resolves to one on its rank", what);
                 } else {
                     EXPECT(shares.rankOfTransform[transformSlot] == r && shares.shares[r].entityToTransform[localEntity] == shares.localOfTransform[transformSlot],
                            "%s: pool %zu slot %u does not resolve to its entity's transform on rank %u", what, p, w, r);
                 }
             }
+            EXPECT(holes == mesh.freeSlots.size(), "%s: pool %zu rank %u has %u holes and %zu free slots", what, p, r, holes, mesh.freeSlots.size());
         }
         for (uint32_t j = 0; j < meshPool.getOccupancy(); j++)
             EXPECT(held[j] == 1, "%s: pool %zu slot %u is held %u times", what, p, j, held[j]);
@@ -164,6 +186,80 @@ int main()
                 EXPECT(rank != GV_NONE && std::memcmp(&shares.shares[rank].transforms[shares.localOfTransform[slot]].posChildCount, &t->posChildCount, 12) == 0,
                        "copyTransform: slot %u", slot);
             }
+        // ---- frame to frame, no further deal ----
+        RankShares::Changes changes;
+        changes.reset(ranks, meshSystems.size());
+        // (1) mesh components edited behind the systems' backs: found by comparing, copied, reported once each
+        uint32_t edited = 0;
+        for (uint32_t j = 3; j < opaque->getComponents().getOccupancy(); j += 17) {
+            auto& c = opaque->getComponents().getData()[j];
+            if (!*c.entity)
+                continue;
+            c.aabb.max = f32x4(uniform(2.5f, 3.0f), 2, 2);
+            c.isEnabled = (j & 1) != 0;
+            edited++;
+        }
+        EXPECT(shares.syncMeshes(0, opaque, 0, opaque->getComponents().getOccupancy(), changes), "syncMeshes: an edit is not structural");
+        EXPECT(shares.syncMeshes(1, wide, 0, wide->getComponents().getOccupancy(), changes), "syncMeshes: an untouched pool is not structural");
+        uint32_t reported = 0;
+        for (uint32_t r = 0; r < ranks; r++) {
+            reported += (uint32_t)changes.ranks[r].meshes[0].size();
+            EXPECT(changes.ranks[r].meshes[1].empty(), "syncMeshes: an untouched pool reports edits");
+        }
+        EXPECT(reported == edited, "syncMeshes: %u slots edited, %u reported", edited, reported);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "after mesh edits", false);
+        changes.reset(ranks, meshSystems.size());
+        EXPECT(shares.syncMeshes(0, opaque, 0, opaque->getComponents().getOccupancy(), changes), "syncMeshes twice");
+        for (uint32_t r = 0; r < ranks; r++)
+            EXPECT(changes.ranks[r].meshes[0].empty(), "syncMeshes: nothing changed, yet rank %u is told of %zu slots", r, changes.ranks[r].meshes[0].size());
+        // (2) every transform re-copied (a writer that does not say what it moved), then the roots that left their rank's cells move
+        for (uint32_t i = 2; i < n; i += 5)
+            if (auto t = transformSystem->tryGetOf(ents[i]))
+                if (!*t->parent)
+                    t->setPosition(uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side));
+        shares.syncAllTransforms(transformSystem, changes);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "after syncAllTransforms", false);
+        shares.rebin(transformSystem, {}, true, ranks, grid, side, changes);
+        EXPECT(ranks == 1 ? changes.movedTrees == 0 : changes.movedTrees > 0, "rebin: %u trees moved with %u ranks", changes.movedTrees, ranks);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "after rebin of every root");
+        // (3) itemised: a few roots jump, only those are looked at; they come back, their old holes are reused
+        for (int round = 0; round < 3; round++) {
+            changes.reset(ranks, meshSystems.size());
+            std::vector<uint32_t> moved;
+            for (uint32_t i = 4 + (uint32_t)round; i < n; i += 11)
+                if (auto t = transformSystem->tryGetOf(ents[i]))
+                    if (!*t->parent) {
+                        t->setPosition(uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side));
+                        const uint32_t slot = (uint32_t)(*t - transformSystem->getComponents().getData());
+                        shares.syncTransform(transformSystem, slot, changes);
+                        moved.push_back(slot);
+                    }
+            shares.rebin(transformSystem, moved, false, ranks, grid, side, changes);
+            // what a rank is told covers every local slot a tree left or entered
+            for (uint32_t r = 0; r < ranks; r++) {
+                auto& told = changes.ranks[r];
+                std::vector<uint32_t> slots = told.transforms;
+                for (const auto& run : RankShares::Changes::runs(slots))
+                    EXPECT(run.first + run.second <= shares.shares[r].transforms.size(), "rebin: a run past the share of rank %u", r);
+                for (size_t p = 0; p < meshSystems.size(); p++)
+                    for (uint32_t l : told.maps[p])
+                        EXPECT(l < shares.shares[r].meshes[p].occupancy(), "rebin: an index-map entry past the share of rank %u", r);
+            }
+            check(transformSystem, meshSystems, shares, ranks, grid, side, "after an itemised rebin", false);
+        }
+        // every moved root is where its position says (the others were not re-examined: ownership is a matter of balance)
+        // (4) a component that changed hands: structural
+        if (auto t = transformSystem->tryGetOf(ents[1])) {
+            (void)t;
+            manager.destroy(ents[1]);
+            manager.update();
+            changes.reset(ranks, meshSystems.size());
+            const bool a = shares.syncMeshes(0, opaque, 0, opaque->getComponents().getOccupancy(), changes);
+            const bool b = shares.syncMeshes(1, wide, 0, wide->getComponents().getOccupancy(), changes);
+            EXPECT(!(a && b), "syncMeshes: a destroyed component was not reported as structural");
+            shares.deal(transformSystem, meshSystems, ranks, grid, side);
+            check(transformSystem, meshSystems, shares, ranks, grid, side, "dealt again after a component went");
+        }
     }
     std::printf("{\"ok\": %s, \"failures\": %d}\n", failures ? "false" : "true", failures);
     return failures ? 1 : 0;

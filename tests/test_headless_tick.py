@@ -176,6 +176,15 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "20000", "--ranks", "2", "--mixed", "--gate", "never", "--toggle", "--hier"],
     ["--entities", "50000", "--ranks", "4", "--hiz", "--mixed", "--hier"],  # the pyramid is built on every rank
     ["--entities", "30000", "--ranks", "3", "--mixed", "--csm", "--gate", "shadow", "--skip-pass", "0"],
+    # mesh systems without change counters (every one of the reference's): what changed is found by comparing with the ranks' copies
+    ["--entities", "30000", "--ranks", "3", "--mixed", "--unversioned", "--hier", "--mutate"],
+    ["--entities", "30000", "--ranks", "4", "--mixed", "--csm", "--unversioned", "--animate", "3", "--ticks", "5"],
+    # roots that cross cells take their trees to another rank (SURVEY.md §8e "re-bin only roots whose position crosses a cell")
+    ["--entities", "20000", "--ranks", "4", "--hier", "--animate", "2", "--animate-step", "157.5", "--itemised", "--ticks", "8", "--expect-moved-trees"],
+    ["--entities", "20000", "--ranks", "4", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--expect-moved-trees"],
+    ["--entities", "20000", "--ranks", "3", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--no-rebin"],
+    ["--entities", "20000", "--ranks", "4", "--mixed", "--csm", "--probe-exchange"],
+    ["--entities", "20000", "--ranks", "2", "--soa-records", "--mixed", "--hier"],  # records through the three-array fetch
     # BASELINE sizes through the drop-in's own multi-GPU mode: 10 M entities dealt to 8 / 4 contexts (hierarchies follow their roots;
     # the occlusion query on every rank), five mesh systems + three cascades at 4 M — every buffer and isVisible byte of the whole
     # pools == the CPU system's
@@ -186,13 +195,15 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
 def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
     """The drop-in's own multi-GPU mode — ONE process, ONE thread, N contexts (the reference is one process with one Manager,
     source/editor/entry.cpp:135): the pools are dealt to the ranks (rank_shares.hpp: roots by position, descendants follow), every
-    rank culls its share, the lists are gathered on the devices through gv_exchange_visible_all / _acquire_all (here all ranks
+    rank culls its share, ALL the frame's lists are gathered on the devices by ONE gv_exchange_views_all / _acquire_all (here all ranks
     share the box's GPU and the rows travel through the test transport) and the engine's buffers are filled from the ranks'
     results. Checked: every buffer and isVisible of the whole pools == the CPU system's (headless_tick --mode both), every rank
     holds the same gathered rows, and their union is the set of world slots the pass's buffer holds."""
     stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
     env_before = os.environ.get("GV_RCCL_LIBRARY")
     os.environ["GV_RCCL_LIBRARY"] = stub
+    expect_moved = "--expect-moved-trees" in args
+    args = [a for a in args if a != "--expect-moved-trees"]
     try:
         _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
     finally:
@@ -201,6 +212,18 @@ def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
         else:
             os.environ["GV_RCCL_LIBRARY"] = env_before
     assert out["ok"] and out["draw_count"] > 0, out
+    # ONE exchange per frame (the reference waits once per prepareMeshes, mesh.cpp:548), seen by the consumer's callback too
+    assert out["exchanges"] == out["rank_frames"] == out["exchanges_seen"] or "--probe-exchange" in args, out
+    if "--probe-exchange" in args:
+        assert out["exchanges"] == out["rank_frames"] and all(ms > 0 for ms in out["exchange_mode_probe_ms"]), out
+        assert out["exchange_mode"] == min(range(3), key=lambda m: out["exchange_mode_probe_ms"][m]), out
+    # the pools are dealt once; only entities / components that come or go, or parent links that move, deal them again
+    if not any(a in args for a in ("--mutate", "--toggle", "--churn", "--gate")):
+        assert out["deals"] == 1, out
+    if expect_moved:
+        assert out["moved_trees"] > 0 and out["deals"] == 1, out
+    if "--no-rebin" in args:
+        assert out["moved_trees"] == 0, out
 
 
 def _exchange_ranks(ranks, entities, env=None, extra=()):

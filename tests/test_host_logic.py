@@ -583,6 +583,9 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     # ONE thread driving 1 / 3 / 4 contexts through gv_exchange_init_all / _visible_all / _acquire_all (the reference's shape: one
     # process, one Manager), scripted and random list sequences
     assert run.stdout.count("exchange driven by ONE thread") == 3 + 6 and "exchange driven by ONE thread, 4 ranks, list sequence 0: ok" in run.stdout
+    # ... and ONE exchange for all the lists of a frame (gv_exchange_views_all): count table + lists per row, short predictions completed
+    batched = [l for l in run.stdout.splitlines() if l.startswith("batched exchange (gv_exchange_views_all)")]
+    assert len(batched) == 3 + 6 and all("6 frames acquired" in l for l in batched), batched
     print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange ")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
