@@ -111,8 +111,7 @@ ViewBuffers view_buffers(ViewState& vs)
 // the scan-path emit, new buffers) every quarter is marked "may hold a non-zero" and the emit rewrites it once.
 int emit_flags_ready(GvCtx* ctx, ViewState& vs)
 {
-    static const bool sparse = getenv("GV_DEBUG_EMIT_NO_SPARSE") == nullptr;  // debug A/B: every workgroup always writes its bytes
-    if ((!vs.vis_flags_current || !sparse) && vs.vis_flags.ptr)
+    if (!vs.vis_flags_current && vs.vis_flags.ptr)
         GV_HIP(ctx, hipMemsetAsync(vs.vis_flags.ptr, 1, vs.vis_flags.cap, ctx->stream));
     vs.vis_flags_current = true;
     return GV_OK;
@@ -143,8 +142,6 @@ int hiz_reduce(GvCtx* ctx)
     ctx->hiz_level1_stored = false;
     ZoneScope zone("HiZ Downsample");
     KernelTimer timer(ctx, GV_K_HIZ);
-    static const bool use_tail = getenv("GV_DEBUG_HIZ_NO_TAIL") == nullptr, use_fused3 = getenv("GV_DEBUG_HIZ_NO_FUSED3") == nullptr,
-                      use_fused4 = use_fused3 && getenv("GV_DEBUG_HIZ_NO_FUSED4") == nullptr;
     uint32_t k = 1;
     while (k < ctx->hiz_mips) {
         const uint32_t sw = ctx->mip_w[k - 1], sh = ctx->mip_h[k - 1];
@@ -158,7 +155,7 @@ int hiz_reduce(GvCtx* ctx)
                 dst.level[0] = nullptr;  // not written: 3/4 of the pyramid's bytes (gv_hiz_read_level materialises it on demand)
             GV_HIP(ctx, launch_hiz_fused(src_d, src_p, dst, sw, sh, rg16f, ctx->stream));
             k += 6;
-        } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels && use_tail) {
+        } else if ((uint64_t)ctx->mip_w[k] * ctx->mip_h[k] <= kHizTailTexels) {
             // the rest of the pyramid is small: one workgroup, one launch (frame sizes are rarely divisible by 64)
             static_assert(GV_MAX_MIPS <= 16, "HizTailArgs holds 16 levels");
             HizTailArgs tail{};
@@ -174,7 +171,7 @@ int hiz_reduce(GvCtx* ctx)
             tail.rule = ctx->config.hiz_rule;
             GV_HIP(ctx, launch_hiz_tail(tail, rg16f, ctx->stream));
             k = ctx->hiz_mips;
-        } else if (k + 3 < ctx->hiz_mips && sw >= 2 && sh >= 2 && use_fused4 &&
+        } else if (k + 3 < ctx->hiz_mips && sw >= 2 && sh >= 2 &&
                    ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) >= 96 &&
                    ((ctx->mip_w[k] + 63) / 64) * ((ctx->mip_h[k] + 63) / 64) <= 200 &&
                    (uint64_t)ctx->mip_w[k + 2] * ctx->mip_h[k + 2] > kHizTailTexels && (uint64_t)ctx->mip_w[k + 3] * ctx->mip_h[k + 3] > kHizTailTexels / 2) {
@@ -194,7 +191,7 @@ int hiz_reduce(GvCtx* ctx)
             f.rule = ctx->config.hiz_rule;
             GV_HIP(ctx, launch_hiz_fused4(f, rg16f, ctx->stream));
             k += 4;
-        } else if (k + 2 < ctx->hiz_mips && sw >= 2 && sh >= 2 && use_fused3) {
+        } else if (k + 2 < ctx->hiz_mips && sw >= 2 && sh >= 2) {
             // any size: three levels per launch, a rim of the two intermediate levels recomputed per workgroup (gv_hiz.hip)
             HizFused3Args f{};
             f.depth = src_d;
@@ -249,8 +246,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     for (uint32_t v = 0; v < view_count; v++) {
         vbs[v] = view_buffers(ctx->views[pool_id][v]);
         cvps[v] = vps[v];
-        static const bool cull_writes = getenv("GV_DEBUG_CULL_WRITES_IS_VISIBLE") != nullptr;  // debug A/B: both kernels store the bytes
-        if (ctx->views[pool_id][v].emitted && !cull_writes)
+        if (ctx->views[pool_id][v].emitted)
             cvps[v].write_is_visible = 0;
         if (cvps[v].write_is_visible)
             ctx->views[pool_id][v].vis_flags_current = false;  // the cull stores the bytes itself
@@ -279,10 +275,9 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     // ... or keeps changing only a little (kMinSmallStreak syncs in a row that re-mirrored a few entries each): then it gets them
     // once more and they are patched from there on (below)
     constexpr uint32_t kMinSmallStreak = 4;
-    static const bool patching = getenv("GV_DEBUG_NO_BOUNDS_PATCH") == nullptr;
     // (only pools whose boxes can then be patched — entry i <-> transform entry i, no chains —: any other would be rebuilt every frame)
     const bool patchable = mesh.mapping == kMapExact && xf.max_depth == 0 && mesh.count <= xf.count;
-    const bool may_rebuild = !(changed && p.changed_prev) || (patching && patchable && changed && p.small_streak >= kMinSmallStreak);
+    const bool may_rebuild = !(changed && p.changed_prev) || (patchable && changed && p.small_streak >= kMinSmallStreak);
     p.changed_prev = changed;
     p.seen_epoch = p.epoch;
     p.seen_xf_epoch = ctx->xf_epoch;
@@ -292,7 +287,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
                                (!(ctx->config.flags & GV_CONFIG_LINEAR_SCAN) && p.occupancy > kAutoBoundsMinSlots);
     if (bounds_wanted && p.occupancy != 0 && !fused) {
         bool current = p.bounds_epoch == p.epoch && p.bounds_xf_epoch == ctx->xf_epoch;
-        if (!current && patching && p.patch_valid && patchable && p.d_blk_lo.ptr && p.d_blk_dirty.ptr) {
+        if (!current && p.patch_valid && patchable && p.d_blk_lo.ptr && p.d_blk_dirty.ptr) {
             // every change since the boxes were current is on record (sync_mirror flagged the blocks): re-derive those blocks — and
             // their entries' emit seeds when the seeds were in step with the boxes — instead of culling without boxes until the
             // pool comes to rest (a scene in which a few entities move every frame never does)
@@ -335,11 +330,10 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     }
     // emit seeds: a flat, exactly paired pool of some size whose views want records (gv_kernels.hpp)
     const EmitSeed* seeds = nullptr;
-    static const bool seeds_allowed = getenv("GV_DEBUG_NO_EMIT_SEEDS") == nullptr;
     bool wants_records = false;
     for (uint32_t v = 0; v < view_count; v++)
         wants_records = wants_records || ctx->views[pool_id][v].emitted;
-    if (seeds_allowed && wants_records && !batched && p.occupancy >= kEmitSeedMinSlots && mesh.mapping == kMapExact && xf.max_depth == 0 &&
+    if (wants_records && !batched && p.occupancy >= kEmitSeedMinSlots && mesh.mapping == kMapExact && xf.max_depth == 0 &&
         mesh.count <= xf.count) {
         bool current = p.seed_epoch == p.epoch && p.seed_xf_epoch == ctx->xf_epoch && p.d_seed.cap >= p.occupancy;
         if (!current && may_rebuild) {
@@ -355,8 +349,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
     }
     // records take the resident world matrices when a sweep of the current mirror has written them (this call's fused
     // or leading sweep, or an earlier gv_sweep with no transform change since): same bits as the chain walk
-    static const bool emit_from_world = getenv("GV_DEBUG_EMIT_CHAIN") == nullptr;
-    const float4* emit_world = (ctx->world_valid && !ctx->world_partial && emit_from_world && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
+    const float4* emit_world = (ctx->world_valid && !ctx->world_partial && ctx->max_depth != 0) ? ctx->d_world.ptr : nullptr;
     if (p.occupancy != 0) {
         if (use_bounds) {
             bounds.lo = p.d_blk_lo.ptr;
@@ -368,7 +361,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             KernelTimer t(ctx, GV_K_CULL);
             GV_HIP(ctx, launch_cull_multi(mesh, xf, hz, cvps, vbs, view_count, ctx->stream, use_bounds ? &bounds : nullptr));
         }
-        static const uint32_t self_max = getenv("GV_DEBUG_SELF_PREFIX_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_SELF_PREFIX_MAX")) : kSelfPrefixMaxChunks;
+        constexpr uint32_t self_max = kSelfPrefixMaxChunks;
         // a batched cull whose views all want records: ONE self-prefixing emit launch for all of them
         bool emit_batched = batched && chunks <= self_max;
         for (uint32_t v = 0; v < view_count && emit_batched; v++)
@@ -389,8 +382,7 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
             GV_HIP(ctx, launch_emit_batch(mesh, xf, vps, vbs, clear, view_count, ctx->stream, emit_world));
         }
         // one view, records wanted, pool small enough for the look-back form to win: cull + emit in ONE launch
-        static const uint32_t fused_emit_max = getenv("GV_DEBUG_FUSED_EMIT_MAX") ? (uint32_t)atoi(getenv("GV_DEBUG_FUSED_EMIT_MAX")) : kFusedEmitMaxSlots;
-        if (!batched && !fused && !use_bounds && view_count == 1 && ctx->views[pool_id][0].emitted && p.occupancy <= fused_emit_max) {
+        if (!batched && !fused && !use_bounds && view_count == 1 && ctx->views[pool_id][0].emitted && p.occupancy <= kFusedEmitMaxSlots) {
             ViewState& vs = ctx->views[pool_id][0];
             const size_t nb = (p.occupancy + kCullBlock - 1) / kCullBlock;
             if (nb > vs.tile_status.cap || !vs.tile_ticket.ptr) {
@@ -417,18 +409,16 @@ int cull_launch(GvCtx* ctx, uint32_t pool_id, const ViewParams* vps, uint32_t vi
         for (uint32_t v = 0; v < view_count && !emit_batched; v++) {
             if (!batched) {
                 KernelTimer t(ctx, GV_K_CULL);
-                // bounds: classify the workgroups first and cull the kept ones from a list (GV_DEBUG_BOUNDS_IN_KERNEL: the
-                // round-2 form, every workgroup tests its own box inside the cull kernel)
-                static const bool listed = getenv("GV_DEBUG_BOUNDS_IN_KERNEL") == nullptr;
+                // bounds: classify the workgroups first and cull the kept ones from a list
                 if (fused && v == 0)
                     GV_HIP(ctx, launch_sweep_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->d_world.ptr, ctx->sweep_with_cull_mfma, ctx->stream));
-                else if (use_bounds && listed) {
+                else if (use_bounds) {
                     uint32_t* counters = p.d_kept.ptr;
                     GV_HIP(ctx, launch_cull_listed(mesh, xf, hz, cvps[v], vbs[v], bounds, counters + p.kept_parity, counters + (p.kept_parity ^ 1u),
                                                    counters + 4, p.d_kept_flag.ptr, ctx->stream));
                     p.kept_parity ^= 1u;
                 } else {
-                    GV_HIP(ctx, launch_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->stream, use_bounds ? &bounds : nullptr));
+                    GV_HIP(ctx, launch_cull(mesh, xf, hz, cvps[v], vbs[v], ctx->stream));
                 }
             }
             if (ctx->views[pool_id][v].emitted && chunks <= self_max) {
@@ -1059,7 +1049,7 @@ int gv_hiz_build(GvCtx* ctx, const float* depth, uint32_t width, uint32_t height
                 ctx->hiz_nested = false;
     }
     // level 1 stays virtual when the first six levels come from the fused kernel (sizes divisible by 64: plain 2x2 rule)
-    ctx->hiz_level1_virtual = width % 64 == 0 && height % 64 == 0 && mips > 6 && getenv("GV_DEBUG_STORE_HIZ_LEVEL1") == nullptr;
+    ctx->hiz_level1_virtual = width % 64 == 0 && height % 64 == 0 && mips > 6;
     // (RG16F texels are half the size: the same buffer type, half the elements)
     GV_HIP(ctx, ctx->d_mips.reserve(std::max<uint64_t>((ctx->config.flags & GV_CONFIG_HIZ_RG16F) ? (off + 1) / 2 : off, 1)));
     GV_HIP(ctx, ctx->d_mip_offset.reserve(GV_MAX_MIPS));

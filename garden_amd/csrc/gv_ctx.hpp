@@ -179,7 +179,6 @@ struct PoolState {
     struct RecordTarget {        // gv_pool_set_record_target: the caller's own array for a view's records
         uint8_t* host = nullptr;
         size_t bytes = 0;
-        uint8_t* dev = nullptr;  // the page-locked range as the device addresses it (NULL: not lockable -> host copy at the fetch)
     };
     RecordTarget record_target[GV_MAX_VIEWS];
     Column ready;              // gv_pool_bind_ready: per-slot ready count (ptr NULL: none, every slot counts 1)
@@ -316,7 +315,6 @@ struct Context {
     DeviceBuf<uint32_t> d_e2t;     // entity -> transform slot table on the device, refreshed by every device-side mesh gather
     DeviceBuf<uint32_t> d_flag;    // one word: "a candidate no longer pairs with its own index" (aos_meshes_kernel)
     PinnedBuf<uint32_t> h_flag;
-    bool device_gather = getenv("GV_NO_DEVICE_GATHER") == nullptr;  // the env switches the path off (debugging)
     // scratch of the scattered (dirty-range) host upload path
     PinnedBuf<XfPacket> sc_xf;       // one packet of {entry, record} per sync and side (gv_sort_kernels.hpp)
     DeviceBuf<XfPacket> dsc_xf;

@@ -9,7 +9,7 @@
 //                 (mesh.cpp:177-183) with an order-stable compaction (ballot words + block prefix).
 //   cull_multi_kernel   the same for up to 8 views that share cameraPosition (main camera + shadow cascades,
 //                 mesh.cpp:795-847) in one pass over the streams.
-//   block_bounds_kernel + the BOUNDS variants   opt-in workgroup boxes: conservative block-level frustum rejection.
+//   block_bounds_kernel, block_classify / _window / cull_list_kernel   workgroup boxes: conservative block-level rejection.
 //   sort_* / radix_*   sortMeshes (mesh.cpp:265-328): stable radix sort of the compact records by distanceSq.
 //   sweep_*       TransformComponent::calcModel() for every transform slot (transform.hpp:197-214);
 //                 the MFMA form runs the 4x4 chain on v_mfma_f32_4x4x1_16b_f32.
@@ -59,99 +59,6 @@ __device__ __forceinline__ bool block_behind_planes(const float4 lo, const float
 __device__ __forceinline__ bool block_behind_frustum(const float4 lo, const float4 hi, const ViewParams& view, uint32_t max_depth)
 {
     return block_behind_planes(lo, hi, view.planes, view.plane_count, view.cam, max_depth);
-}
-
-// Block-level Hi-Z: true when EVERY candidate of the workgroup would be found occluded by its own query (hiz_occluded), so the
-// workgroup can skip its streams like one behind a frustum plane. Called by all 256 lanes (workgroup-uniform arguments).
-//
-// An entity e is occluded iff zNear_e < zFar_e, zNear_e = max z/w over its 8 corners, zFar_e = min over the <= 2x2 texels
-// that cover its pixel rect R_e at its level L_e. For the block:
-//   * the box [lo, hi] holds every corner of every candidate (world space); inflated by the rounding margin of
-//     block_behind_planes it also holds them as the per-frame arithmetic computes them (camera-relative products, fma order), and
-//     the margin's effect on every projected quantity (>= 1e-7 relative: margin >= 0.01, w <= 1e5) dominates the fp32 rounding
-//     of both evaluations. x/w, y/w, z/w are monotone along any segment with w > 0, so their extrema over the box are at its
-//     corners: zNear_b = max z/w >= zNear_e, and the block's pixel rect R_b (one more pixel each way) contains every R_e;
-//     a box that reaches w <= 0 is never tested (its entities may take the "cannot bound: visible" exit).
-//   * lo.w = the largest sphere reach r of the block's candidates (block_bounds_kernel): two corners of one entity differ by
-//     <= 2 r in L1, so its rect spans at most n_max pixels (below) and its level is at most L_max = floor(log2 n_max) + 1.
-//   * at any level L_b >= L_max of a NESTED pyramid every texel of level L_e <= L_b that touches R_e lies inside a level-L_b texel
-//     that touches R_b, and a texel's min bounds everything under it: zFar_b = min over ALL level-L_b texels touching R_b <= zFar_e.
-//   So zNear_b < zFar_b  =>  zNear_e <= zNear_b < zFar_b <= zFar_e for every candidate: all occluded. L_b is also raised until R_b
-//   spans <= 16 x 16 texels: one texel per lane, one reduction. A NaN texel (an entity's own compare would fail on it) or any
-//   non-finite intermediate declines the shortcut.
-__device__ __forceinline__ bool block_occluded(const HizDevice& hz, const ViewParams& view, const float4 lo, const float4 hi,
-                                               uint32_t max_depth, float* wave_min /* LDS [kCullBlock / 64] */)
-{
-    if (!hz.nested)
-        return false;
-    const float (&vp)[16] = view.vp;
-    const float mag = fmaxf(fabsf(lo.x), fabsf(hi.x)) + fmaxf(fabsf(lo.y), fabsf(hi.y)) + fmaxf(fabsf(lo.z), fabsf(hi.z)) +
-                      fabsf(view.cam[0]) + fabsf(view.cam[1]) + fabsf(view.cam[2]);
-    const float margin = 0.01f + 4e-5f * (float)(max_depth + 1u) * mag;
-    const float bx[2] = {lo.x - view.cam[0] - margin, hi.x - view.cam[0] + margin};
-    const float by[2] = {lo.y - view.cam[1] - margin, hi.y - view.cam[1] + margin};
-    const float bz[2] = {lo.z - view.cam[2] - margin, hi.z - view.cam[2] + margin};
-    const float inf = __builtin_huge_valf();
-    float nx0 = inf, nx1 = -inf, ny0 = inf, ny1 = -inf, znear = -inf, wmin = inf;
-    bool bounded = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const float x = bx[k & 1], y = by[(k >> 1) & 1], z = bz[k >> 2];
-        const float clx = fmaf(vp[0], x, fmaf(vp[4], y, fmaf(vp[8], z, vp[12])));
-        const float cly = fmaf(vp[1], x, fmaf(vp[5], y, fmaf(vp[9], z, vp[13])));
-        const float clz = fmaf(vp[2], x, fmaf(vp[6], y, fmaf(vp[10], z, vp[14])));
-        const float clw = fmaf(vp[3], x, fmaf(vp[7], y, fmaf(vp[11], z, vp[15])));
-        bounded = bounded && (clw > 0.0f);
-        const float rcp = 1.0f / clw;
-        const float ndx = clx * rcp, ndy = cly * rcp, ndz = clz * rcp;
-        nx0 = fminf(nx0, ndx); nx1 = fmaxf(nx1, ndx);
-        ny0 = fminf(ny0, ndy); ny1 = fmaxf(ny1, ndy);
-        znear = fmaxf(znear, ndz);
-        wmin = fminf(wmin, clw);
-    }
-    if (!bounded)
-        return false;
-    // the largest pixel extent one candidate's rect can have, from its reach r: |x1/w1 - x2/w2| <= (|x1 - x2| + |x2/w2| |w2 - w1|) / w1
-    const float r = lo.w;
-    const float r0 = fmaxf(fmaxf(fabsf(vp[0]), fabsf(vp[4])), fabsf(vp[8])), r1 = fmaxf(fmaxf(fabsf(vp[1]), fabsf(vp[5])), fabsf(vp[9]));
-    const float r3 = fmaxf(fmaxf(fabsf(vp[3]), fabsf(vp[7])), fabsf(vp[11]));
-    const float span = 2.0f * r / wmin;
-    const float ext_x = 0.5f * (float)hz.width * span * fmaf(fmaxf(fabsf(nx0), fabsf(nx1)), r3, r0) + 3.0f;
-    const float ext_y = 0.5f * (float)hz.height * span * fmaf(fmaxf(fabsf(ny0), fabsf(ny1)), r3, r1) + 3.0f;
-    const float n_max = fmaxf(ext_x, ext_y);
-    if (!(n_max < 32768.0f))  // also NaN / inf (a box or reach that is not finite)
-        return false;
-    const uint32_t l_max = (31u - (uint32_t)__clz((int)n_max)) + 1u;  // n_max >= 3
-    const int W = (int)hz.width, H = (int)hz.height;
-    const float umin = clamp01(fmaf(nx0, 0.5f, 0.5f)), umax = clamp01(fmaf(nx1, 0.5f, 0.5f));
-    const float vmin = clamp01(fmaf(ny0, 0.5f, 0.5f)), vmax = clamp01(fmaf(ny1, 0.5f, 0.5f));
-    const int ix0 = max((int)(umin * (float)W) - 1, 0), ix1 = min((int)(umax * (float)W) + 1, W - 1);
-    const int iy0 = max((int)(vmin * (float)H) - 1, 0), iy1 = min((int)(vmax * (float)H) + 1, H - 1);
-    uint32_t level = min(l_max, hz.mip_count - 1u);
-    while (level + 1u < hz.mip_count && (((ix1 >> level) - (ix0 >> level)) > 15 || ((iy1 >> level) - (iy0 >> level)) > 15))
-        level++;
-    const int lw = max(W >> level, 1), lh = max(H >> level, 1);
-    const int tx0 = min(ix0 >> level, lw - 1), tx1 = min(ix1 >> level, lw - 1);
-    const int ty0 = min(iy0 >> level, lh - 1), ty1 = min(iy1 >> level, lh - 1);
-    if (tx1 - tx0 > 15 || ty1 - ty0 > 15)  // (only when the top level is wider than 16 texels: cannot happen for a full pyramid)
-        return false;
-    const int tx = tx0 + (int)(threadIdx.x & 15u), ty = ty0 + (int)(threadIdx.x >> 4);
-    float t = inf;
-    if (tx <= tx1 && ty <= ty1)
-        t = hiz_min_texel(hz, level, (uint32_t)lw, (uint32_t)tx, (uint32_t)ty);
-    const bool nan = t != t;
-    float m = nan ? inf : t;
-#pragma unroll
-    for (uint32_t d = 32; d >= 1; d >>= 1)
-        m = fminf(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63u) == 0)
-        wave_min[threadIdx.x >> 6] = m;
-    const int any_nan = __syncthreads_or(nan ? 1 : 0);
-    float zfar = wave_min[0];
-#pragma unroll
-    for (uint32_t w = 1; w < kCullBlock / 64; w++)
-        zfar = fminf(zfar, wave_min[w]);
-    return !any_nan && fmaf(fabsf(znear), 2e-6f, znear) < zfar;
 }
 
 // the kernel's first argument (a CullArgs at the start of the kernarg segment), read again through a pointer the compiler cannot
@@ -221,7 +128,7 @@ __device__ __forceinline__ void cull_block(const CullArgs& args0, uint32_t lb, u
     }
     __syncthreads();
     // the tile's four ballot words leave as ONE 32-byte store (small stores are what a bandwidth-bound read kernel pays for:
-    // tools/read_probe.hip), the tile's count as one atomic
+    // round-3 probe tools/read_probe.hip, in the history), the tile's count as one atomic
     if (tid < kCullBlock / 64)
         out_args.out.mask[(size_t)lb * (kCullBlock / 64) + tid] = wave_word[tid];
     if (tid == 0) {
@@ -234,43 +141,21 @@ __device__ __forceinline__ void cull_block(const CullArgs& args0, uint32_t lb, u
     }
 }
 
-// BOUNDS (GV_CONFIG_BLOCK_BOUNDS): the workgroup first tests its box; when the box is behind a plane every entity in it
-// is invisible, the outputs say so and the streams stay untouched.
-template <bool HIZ, uint32_t MAP, bool BOUNDS>
+template <bool HIZ, uint32_t MAP>
 __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 {
     __shared__ uint32_t wave_count[kCullBlock / 64];
     const uint32_t lb = tile_of_workgroup(blockIdx.x, args.xcd_run);
     if (lb >= args.nblocks)
         return;
-    if (BOUNDS) {  // workgroup-uniform
-        const uint32_t i = lb * kCullBlock + threadIdx.x;
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const float4 lo = args.bounds.lo[lb], hi = args.bounds.hi[lb];
-        const bool empty = lo.x > hi.x;  // no candidate at all (+inf / -inf)
-        bool skip = empty || block_behind_frustum(lo, hi, args.view, args.xf.max_depth);
-        if (HIZ && !skip) {  // inside the frustum: is the whole box behind what the pyramid holds over its footprint?
-            __shared__ float wave_min[kCullBlock / 64];
-            skip = block_occluded(args.hiz, args.view, lo, hi, args.xf.max_depth, wave_min);
-        }
-        if (threadIdx.x == 0)  // statistics: a plain store per workgroup (a shared counter would serialise ~10^4 atomics)
-            args.bounds.examined[lb] = skip ? 0 : 1;
-        if (skip) {
-            if (args.view.write_is_visible && i < args.mesh.count)
-                args.out.is_visible[i] = 0;
-            if (lane == 0)
-                args.out.mask[(size_t)lb * (kCullBlock / 64) + wave] = 0ull;
-            return;
-        }
-    }
     cull_block<HIZ, MAP>(args, lb, wave_count);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block bounds as two launches (round 3): classify, then cull the kept workgroups only.
-// Inside the cull kernel the block tests are a latency chain in front of every workgroup (box load -> 8 projections ->
-// texel loads -> reduction) and 30 k skipped workgroups are still 30 k dispatches: with every frustum-surviving workgroup
-// found occluded the bounded kernel still took 60 us (tools/block_hiz_probe.py). block_classify_kernel runs the same two
+// Block bounds (GV_CONFIG_BLOCK_BOUNDS) as two or three launches: classify, then cull the kept workgroups only.
+// (Round 2 tested the box inside the cull kernel: a latency chain in front of every workgroup — box load -> 8 projections ->
+// texel loads -> reduction — and 30 k skipped workgroups were still 30 k dispatches: with every frustum-surviving workgroup
+// found occluded that kernel still took 60 us; profiles/withdrawn.md.) block_classify_kernel runs the
 // frustum test with ONE LANE per 256-entry block (block_classify_kernel: 5 us at 39 k blocks), lists the survivors (one atomic per
 // wave of 64 blocks) and, for a Hi-Z view, the texel window of each; block_window_kernel then reads every listed window with one
 // WAVE per block (a lane walking its own window measured 66 us, a wave per block for the whole test 25 us: the launch-to-decision
@@ -278,7 +163,25 @@ __global__ __launch_bounds__(kCullBlock) void cull_kernel(const CullArgs args)
 // Skipped blocks get their outputs (zero ballot words; zero isVisible bytes when the cull owns them) from whichever launch
 // decides them. Same tests, same outputs.
 // ------------------------------------------------------------------------------------------------
-// What block_occluded needs from the block's box for one view, worked out by ONE LANE (block_classify_kernel runs a lane per
+// Block-level Hi-Z: a block is skipped when EVERY candidate of the workgroup would be found occluded by its own query (hiz_occluded),
+// like one behind a frustum plane. block_window works out what to compare (one lane per block), block_window_kernel reads the texels.
+//
+// An entity e is occluded iff zNear_e < zFar_e, zNear_e = max z/w over its 8 corners, zFar_e = min over the <= 2x2 texels
+// that cover its pixel rect R_e at its level L_e. For the block:
+//   * the box [lo, hi] holds every corner of every candidate (world space); inflated by the rounding margin of
+//     block_behind_planes it also holds them as the per-frame arithmetic computes them (camera-relative products, fma order), and
+//     the margin's effect on every projected quantity (>= 1e-7 relative: margin >= 0.01, w <= 1e5) dominates the fp32 rounding
+//     of both evaluations. x/w, y/w, z/w are monotone along any segment with w > 0, so their extrema over the box are at its
+//     corners: zNear_b = max z/w >= zNear_e, and the block's pixel rect R_b (one more pixel each way) contains every R_e;
+//     a box that reaches w <= 0 is never tested (its entities may take the "cannot bound: visible" exit).
+//   * lo.w = the largest sphere reach r of the block's candidates (block_bounds_kernel): two corners of one entity differ by
+//     <= 2 r in L1, so its rect spans at most n_max pixels (below) and its level is at most L_max = floor(log2 n_max) + 1.
+//   * at any level L_b >= L_max of a NESTED pyramid every texel of level L_e <= L_b that touches R_e lies inside a level-L_b texel
+//     that touches R_b, and a texel's min bounds everything under it: zFar_b = min over ALL level-L_b texels touching R_b <= zFar_e.
+//   So zNear_b < zFar_b  =>  zNear_e <= zNear_b < zFar_b <= zFar_e for every candidate: all occluded. L_b is also raised until R_b
+//   spans <= 16 x 16 texels: four texels per lane of one wave, one reduction. A NaN texel (an entity's own compare would fail on it) or any
+//   non-finite intermediate declines the shortcut.
+// What that test needs from the block's box for one view, worked out by ONE LANE (block_classify_kernel runs a lane per
 // block): the texel window (level, first texel, extent <= 16 x 16) and the box's nearest depth. level 0xFF: the block cannot
 // be tested (pyramid not nested, box reaches w <= 0, non-finite, window too large) and is kept.
 struct BlockWindow {
@@ -402,7 +305,7 @@ __global__ __launch_bounds__(64) void block_classify_kernel(const ClassifyArgs a
         a.kept[base + (uint32_t)__popcll(keep & ((1ull << threadIdx.x) - 1ull))] = win;
 }
 
-// launch 2 (Hi-Z views): one WAVE per listed block reads its window, four texels per lane, and decides (block_occluded's test).
+// launch 2 (Hi-Z views): one WAVE per listed block reads its window, four texels per lane, and decides.
 __global__ __launch_bounds__(256) void block_window_kernel(const ClassifyArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -693,7 +596,7 @@ hipError_t launch_cull_emit(const MeshMirror& mesh, const TransformMirror& xf, c
 }
 
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
-                       const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds)
+                       const ViewBuffers& out, hipStream_t stream)
 {
     if (mesh.count == 0)
         return hipSuccess;
@@ -704,24 +607,19 @@ hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const 
     a.view = vp;
     a.out = out;
     a.nblocks = (mesh.count + kCullBlock - 1) / kCullBlock;
-    a.bounds = bounds ? *bounds : BlockBounds{};
-    // measured: the frustum-only scan gains 6 % from per-XCD runs, the Hi-Z and block-bounds variants do not
-    a.xcd_run = vp.use_hiz || bounds ? 0 : xcd_run_for_tiles(a.nblocks);
+    // measured: the frustum-only scan gains 6 % from per-XCD runs, the Hi-Z variant does not
+    a.xcd_run = vp.use_hiz ? 0 : xcd_run_for_tiles(a.nblocks);
     const dim3 grid(grid_for_tiles(a.nblocks, a.xcd_run)), block(kCullBlock);
-#define GV_LAUNCH_CULL(HIZ, BOUNDS)                                                                                       \
-    switch (mesh.mapping) {                                                                                              \
-    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact, BOUNDS>), grid, block, 0, stream, a); break;         \
-    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate, BOUNDS>), grid, block, 0, stream, a); break; \
-    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral, BOUNDS>), grid, block, 0, stream, a); break;              \
+#define GV_LAUNCH_CULL(HIZ)                                                                                       \
+    switch (mesh.mapping) {                                                                                      \
+    case kMapExact: hipLaunchKernelGGL((cull_kernel<HIZ, kMapExact>), grid, block, 0, stream, a); break;         \
+    case kMapSpeculate: hipLaunchKernelGGL((cull_kernel<HIZ, kMapSpeculate>), grid, block, 0, stream, a); break; \
+    default: hipLaunchKernelGGL((cull_kernel<HIZ, kMapGeneral>), grid, block, 0, stream, a); break;              \
     }
-    if (vp.use_hiz && bounds) {
-        GV_LAUNCH_CULL(true, true)
-    } else if (vp.use_hiz) {
-        GV_LAUNCH_CULL(true, false)
-    } else if (bounds) {
-        GV_LAUNCH_CULL(false, true)
+    if (vp.use_hiz) {
+        GV_LAUNCH_CULL(true)
     } else {
-        GV_LAUNCH_CULL(false, false)
+        GV_LAUNCH_CULL(false)
     }
 #undef GV_LAUNCH_CULL
     return hipGetLastError();
@@ -736,7 +634,7 @@ __device__ __forceinline__ void block_bounds_of(const MeshMirror& mesh, const Tr
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float inf = __builtin_huge_valf();
     float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
-    float reach = 0.0f;  // the largest sphere reach of the workgroup's candidates (block_occluded: bounds an entity's pixel extent)
+    float reach = 0.0f;  // the largest sphere reach of the workgroup's candidates (block_window: bounds an entity's pixel extent)
     if (i < mesh.count) {
         Mat34 m;
         Corners c;
@@ -1196,7 +1094,6 @@ struct EmitArgs {
     ViewBuffers out;
     uint32_t nchunks;
     uint32_t clear_chunks;  // SELF: entries of chunk_count_next to clear (a larger pool may have used it last)
-    uint32_t direct_stores; // debug A/B: every lane stores its own 48-byte model (the round-1 form)
     const float4* world;    // world matrices of every transform entry (3 float4 each) when a sweep of the CURRENT mirror
                             // has just written them (gv_sweep / the fused sweep + cull), else NULL
     const EmitSeed* seeds;  // one 64-byte record per mirror entry of a flat, exactly paired pool at rest (gv_kernels.hpp), else NULL
@@ -1407,7 +1304,7 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
     // i): the gathers of round k + 1 are issued before round k's records go through LDS and out, so that a round waits for its
     // stores and the next round's loads together instead of one after the other (a quarter of a full chunk is four rounds). Same-box A/B: emit 53.5 -> 51.2 us at 2.6 M records, 45.3 -> 43.8 us at 2.06 M (a barrier that
     // orders LDS only, so that the gathers fly across it, measured the same).
-    const bool pipelined = GV_EMIT_PIPELINED && !use_seed && !args.world && !args.direct_stores && args.xf.max_depth == 0 &&
+    const bool pipelined = GV_EMIT_PIPELINED && !use_seed && !args.world && args.xf.max_depth == 0 &&
                            args.mesh.mapping == kMapExact;  // uniform
     if (pipelined) {
         uint32_t r0 = prefix[wlo];
@@ -1476,13 +1373,11 @@ __device__ __forceinline__ void emit_block(const EmitArgs& args, const uint32_t 
             // pool slot: componentOffset = slot * componentSize  mesh.cpp:170
             args.out.visible_idx[rank] = use_seed ? args.seeds[i].orig : (args.mesh.orig ? args.mesh.orig[i] : i);
             args.out.distance_sq[rank] = record_distance(args, m);
-            float4* row = args.direct_stores ? reinterpret_cast<float4*>(args.out.baked_model) + rank * 3 : stage + threadIdx.x * 3;
+            float4* row = stage + threadIdx.x * 3;
             row[0] = make_float4(m.c0x, m.c0y, m.c0z, m.c1x);
             row[1] = make_float4(m.c1y, m.c1z, m.c2x, m.c2y);
             row[2] = make_float4(m.c2z, m.c3x, m.c3y, m.c3z);
         }
-        if (args.direct_stores)  // uniform (debug A/B: GV_DEBUG_EMIT_DIRECT_STORES)
-            continue;
         __syncthreads();
         const uint32_t quads = min(256u, total - r0) * 3u;
         float4* dst = reinterpret_cast<float4*>(args.out.baked_model) + ((size_t)base + r0) * 3;
@@ -1520,7 +1415,6 @@ __global__ __launch_bounds__(256) void emit_batch_kernel(const EmitBatchArgs bat
     args.clear_chunks = batch.clear_chunks[blockIdx.y];
     args.world = batch.world;
     args.seeds = nullptr;
-    args.direct_stores = 0;
     emit_block<true>(args, blockIdx.x);
 }
 
@@ -1546,7 +1440,6 @@ void fill_emit_table_entry(void* entry, const MeshMirror& mesh, const TransformM
     a.out = out;
     a.nchunks = (mesh.count + kEmitChunk - 1) / kEmitChunk;
     a.clear_chunks = clear_chunks;
-    a.direct_stores = 0;
     a.world = world;
     a.seeds = nullptr;
 }
@@ -1588,8 +1481,6 @@ hipError_t launch_emit(const MeshMirror& mesh, const TransformMirror& xf, const 
     EmitArgs a;
     a.world = world;
     a.seeds = seeds;
-    static const uint32_t direct = getenv("GV_DEBUG_EMIT_DIRECT_STORES") ? 1u : 0u;
-    a.direct_stores = direct;
     a.mesh = mesh;
     a.xf = xf;
     a.view = vp;

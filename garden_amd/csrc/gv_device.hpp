@@ -15,7 +15,7 @@ namespace gv {
 // shared device helpers
 // ------------------------------------------------------------------------------------------------
 // The mirror streams are read once per frame: nontemporal loads (no L2/MALL allocation priority) measured
-// +20 % on this access pattern (tools/kbench.hip: 6.1 -> 7.1 TB/s). Ancestor re-reads use plain loads.
+// +20 % on this access pattern (round-1 probe tools/kbench.hip, in the history: 6.1 -> 7.1 TB/s). Ancestor re-reads use plain loads.
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef float f32x2n __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 stream_load(const float4* p)
@@ -266,7 +266,6 @@ struct CullArgs {
     ViewParams view;
     ViewBuffers out;
     uint32_t nblocks;
-    BlockBounds bounds;  // BOUNDS variants only
     uint32_t xcd_run;    // tile_of_workgroup(); 0 = workgroup b takes tile b
 };
 

@@ -17,7 +17,7 @@ constexpr uint32_t kXfLive = 4u;           // entity != 0
 constexpr uint32_t kMeshCandidate = 1u << 28;  // entity != 0 && isEnabled (mesh.cpp:142), in MeshMirror::link
 
 // One 32-byte record per transform entry: {pos.xyz, scale.x | quat xyzw}. Kept together because every reader wants
-// both halves: the streaming kernels read the pair at full rate (tools/stream_probe.hip: 6.8 TB/s interleaved vs
+// both halves: the streaming kernels read the pair at full rate (round-1 probe tools/stream_probe.hip, in the history: 6.8 TB/s interleaved vs
 // 6.7 TB/s as two arrays) and every gather (emit, ancestor walks) pays one 64-byte sector instead of two.
 struct XfAB {
     float4 a;  // (pos.x, pos.y, pos.z, scale.x)
@@ -77,7 +77,7 @@ struct ViewParams {
     uint32_t write_is_visible;  // main pass. The cull kernels store the bytes only when no emit follows the launch (count-only
                                 // views, the one-launch cull + emit): with records requested the emit kernel expands them from
                                 // the ballot words it reads anyway, as whole sectors — the byte stores cost the bandwidth-bound
-                                // cull kernel 5-7 us of 105 at 10 M entities for 1.5 % of its bytes (tools/read_probe.hip)
+                                // cull kernel 5-7 us of 105 at 10 M entities for 1.5 % of its bytes (round-3 probe tools/read_probe.hip, in the history)
     uint32_t use_hiz;
     uint32_t distance_2d;
 };
@@ -116,7 +116,7 @@ hipError_t launch_emit_seeds(const MeshMirror& mesh, const TransformMirror& xf, 
 // the rounding margin skips its streams: every entity in it would have failed that plane in the per-entity test.
 struct BlockBounds {
     const float4* lo = nullptr;   // xyz = min corner (+inf when the block has no candidate; -inf when a member is non-finite);
-                                  // w = the largest sphere reach of its candidates (block_occluded; +inf likewise)
+                                  // w = the largest sphere reach of its candidates (block_window; +inf likewise)
     const float4* hi = nullptr;   // xyz = max corner (-inf / +inf likewise)
     uint8_t* examined = nullptr;  // per workgroup: 1 = ran the per-entity path, 0 = skipped (statistics)
 };
@@ -130,9 +130,9 @@ hipError_t launch_block_patch(const MeshMirror& mesh, const TransformMirror& xf,
 hipError_t launch_mark_dirty_blocks(const uint32_t* start, const uint32_t* first, uint32_t nranges, uint32_t total, const uint32_t* inv,
                                     uint32_t slots, uint32_t entries, uint8_t* flags, hipStream_t stream);
 hipError_t launch_cull(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,
-                       const ViewBuffers& out, hipStream_t stream, const BlockBounds* bounds = nullptr);
+                       const ViewBuffers& out, hipStream_t stream);
 // Block bounds as classify (+ window test for Hi-Z views) + cull over the listed workgroups (two or three launches; same outputs
-// as launch_cull with bounds). kept_count / next_count: two alternating device counters (both zero before the first use; each
+// as a cull of every workgroup). kept_count / next_count: two alternating device counters (both zero before the first use; each
 // launch clears the other one for the next); kept_list: cull_list_entry_bytes() per workgroup; kept_flag: a byte per workgroup.
 size_t cull_list_entry_bytes();
 hipError_t launch_cull_listed(const MeshMirror& mesh, const TransformMirror& xf, const HizDevice& hiz, const ViewParams& vp,

@@ -443,7 +443,7 @@ int upload_transforms_device(GvCtx* ctx, uint32_t lo, uint32_t hi)
     const uint8_t* base = nullptr;
     AosTransformLayout L{};
     uint32_t extent = 0;
-    if (!ctx->device_gather || hi <= lo || !aos_transform_layout(ctx->xf, &base, &L, &extent))
+    if (hi <= lo || !aos_transform_layout(ctx->xf, &base, &L, &extent))
         return GV_E_STATE;
     const uint32_t count = hi - lo;
     const size_t bytes = (size_t)(count - 1) * L.stride + extent;
@@ -495,7 +495,7 @@ int upload_meshes_device(GvCtx* ctx, PoolState& p, uint32_t lo, uint32_t hi)
     AosMeshLayout L{};
     uint32_t extent = 0;
     const uint32_t count = hi > lo ? hi - lo : 0;
-    if (!ctx->device_gather || count < 2048 || (uint64_t)count * 12 < ctx->xf.entity_capacity || p.ready.ptr ||
+    if (count < 2048 || (uint64_t)count * 12 < ctx->xf.entity_capacity || p.ready.ptr ||
         !aos_mesh_layout(p, &base, &L, &extent))
         return GV_E_STATE;
     const size_t bytes = (size_t)(count - 1) * L.stride + extent;
@@ -1039,12 +1039,11 @@ int sync_mirror(GvCtx* ctx)
     bool staged = false;
     const bool spatial = !(ctx->config.flags & GV_CONFIG_KEEP_SLOT_ORDER);
     // Too much of a pool sits in the unsorted tail: back into spatial order — on the device (the new slots are appended first, like
-    // any growth, then the mirror is permuted where it lies: reorder_*_device), or as a full host rebuild with GV_DEBUG_HOST_REORDER
-    static const bool device_reorder = getenv("GV_DEBUG_HOST_REORDER") == nullptr;
+    // any growth, then the mirror is permuted where it lies: reorder_*_device)
     bool reorder_xf = false;
     if (!ctx->xf_need_full && n > ctx->xf_mirrored && spatial &&
         ((uint64_t)ctx->xf_appended + (n - ctx->xf_mirrored)) * 8 > n && n >= 1024) {
-        if (device_reorder && !ctx->xperm.empty())
+        if (!ctx->xperm.empty())
             reorder_xf = true;
         else
             ctx->xf_need_full = true;
@@ -1234,7 +1233,7 @@ int sync_mirror(GvCtx* ctx)
             continue;
         if (!p.need_full && p.occupancy > p.mirrored && spatial &&
             ((uint64_t)p.appended + (p.occupancy - p.mirrored)) * 8 > p.occupancy && p.occupancy >= 1024) {
-            if (device_reorder && !p.perm.empty())
+            if (!p.perm.empty())
                 reorder_pool[&p - ctx->pools] = true;
             else
                 p.need_full = true;

@@ -71,8 +71,7 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
     if (int rc = sort_buffers_of(ctx, vs, b))
         return rc;
     // the previous frame's count says what to enqueue for a mid-sized pool: a short list gets the rank sort alone
-    static const bool hints = getenv("GV_DEBUG_SORT_NO_HINT") == nullptr;
-    const SortMode mode = !hints || vs.count_hint == 0xFFFFFFFFu ? kSortBoth
+    const SortMode mode = vs.count_hint == 0xFFFFFFFFu ? kSortBoth
                           : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
                           : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
     if (!sort_is_rank_only((uint32_t)n, mode))
@@ -94,12 +93,11 @@ static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
 // passes each cost one launch, not twenty.
 // Everything queued on the context's stream has finished — where hipStreamSynchronize would do, for the end of an engine-sized
 // tick: a one-lane kernel behind the queue writes a sequence number into pinned memory and the host polls it
-// (launch_done_flag). Falls back to the synchronisation when profiling events wait to be read, when the word does not arrive
-// within 2 ms (a long queue: let the runtime sleep) or with GV_DEBUG_NO_DONE_FLAG.
+// (launch_done_flag). Falls back to the synchronisation when profiling events wait to be read or when the word does not arrive
+// within 2 ms (a long queue: let the runtime sleep).
 int wait_for_stream(GvCtx* ctx)
 {
-    static const bool use_flag = getenv("GV_DEBUG_NO_DONE_FLAG") == nullptr;
-    if (!use_flag || !ctx->pending.empty()) {
+    if (!ctx->pending.empty()) {
         GV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return GV_OK;
     }
@@ -146,14 +144,10 @@ int publish_args_of(GvCtx* ctx, uint32_t pid, uint32_t v, PublishArgs& a)
         if (target.host && target.bytes < need)
             return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu", pid, v,
                              target.bytes, need);
-        if (target.dev) {  // the device writes the caller's array
-            a.host_records = target.dev;
-        } else {
-            GV_HIP(ctx, w.h_records.reserve(need));
-            a.host_records = w.h_records.ptr;
-        }
+        GV_HIP(ctx, w.h_records.reserve(need));
+        a.host_records = w.h_records.ptr;
         w.records_at = target.host ? target.host : w.h_records.ptr;
-        w.records_staged = target.host && !target.dev;  // not page-locked: filled from h_records after the synchronisation
+        w.records_staged = target.host != nullptr;  // (never page-locked: filled from h_records after the synchronisation)
         if (int rc = delivered_layout(ctx, wp, pid, w.occupancy, a.layout))
             return rc;
         w.records_fetched = true;
@@ -191,8 +185,7 @@ int flush_sorts(GvCtx* ctx)
         // The sort publishes what it has sorted (count, records at their sorted places, isVisible: one kernel boundary and the
         // publish kernel's own dependent loads less per tick) — unless other small views wait for a publish launch anyway
         // (a tick with unsorted OIT buffers): then that launch takes these views along and the sort stays lean.
-        static const bool fuse_allowed = getenv("GV_DEBUG_SORT_NO_PUBLISH") == nullptr;
-        bool fuse_publish = fuse_allowed;
+        bool fuse_publish = true;
         for (uint32_t pool = 0; pool < GV_MAX_POOLS && fuse_publish; pool++)
             for (uint32_t v = 0; v < GV_MAX_VIEWS; v++) {
                 const ViewState& w = ctx->views[pool][v];
@@ -299,10 +292,6 @@ bool release_record_target(PoolState::RecordTarget& target)
     bool intact = true;
     if (target.host)
         intact = range_mapped(target.host, target.bytes);
-    if (target.dev) {  // (GV_DEBUG_RECORD_TARGET_PAGE_LOCK only)
-        intact = (hipHostUnregister(target.host) == hipSuccess) && intact;
-        (void)hipGetLastError();
-    }
     target = PoolState::RecordTarget{};
     return intact;
 }
@@ -436,8 +425,7 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
             if (target.host && target.bytes < need)
                 return ctx->fail(GV_E_ARG, "gv_results_fetch: the record target of pool %u view %u holds %zu bytes, occupancy * stride = %zu",
                                  pool_id, view_index, target.bytes, need);
-            if (!target.dev)
-                GV_HIP(ctx, vs.h_records.reserve(need));
+            GV_HIP(ctx, vs.h_records.reserve(need));
             vs.records_at = target.host ? target.host : vs.h_records.ptr;
         }
         if (vs.emitted && count && pool.record_layout.stride) {  // packed on the device, one copy
@@ -448,9 +436,8 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
                 return rc;
             GV_HIP(ctx, launch_pack_records(vs.draw_count.ptr, vs.visible_idx.ptr, vs.baked_model.ptr, vs.distance_sq.ptr, delivered,
                                             count, vs.d_records.ptr, ctx->stream));
-            uint8_t* dst = target.dev ? target.host : vs.h_records.ptr;
-            staged_for = target.host && !target.dev ? target.host : nullptr;
-            GV_HIP(ctx, hipMemcpyAsync(dst, vs.d_records.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            staged_for = target.host;
+            GV_HIP(ctx, hipMemcpyAsync(vs.h_records.ptr, vs.d_records.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
         } else if (vs.emitted && count) {
             if ((rc = reserve_records()) != GV_OK)
                 return rc;
@@ -608,9 +595,6 @@ int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index,
     PoolState::RecordTarget& target = ctx->pools[pool_id].record_target[view_index];
     if (target.host == records && (target.bytes == bytes || !records))
         return GV_OK;  // set every frame by callers that re-bind every frame
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    if (target.dev)
-        GV_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still write the range that is let go
     const bool intact = release_record_target(target);
     ViewState& vs = ctx->views[pool_id][view_index];
     vs.published = false, vs.records_fetched = false;  // the next fetch delivers this view's records again, to the new place
@@ -629,20 +613,9 @@ int gv_pool_set_record_target(GvCtx* ctx, uint32_t pool_id, uint32_t view_index,
     // The caller's array is NOT page-locked: the records arrive in the library's own pinned buffer and the fetch copies them
     // into the array (one memcpy of draw_count records: 3.4 us at 10 k entities, ~50 us for the 1.4 MB of a 100 k-entity pool).
     // Round 2 let the device write the array in place (hipHostRegister once per address): 4 us less per tick at 10 k entities —
-    // and, measured in round 3, the GPU test tier then ABORTED inside the runtime in 4 of 16 runs (tools/suite_soak.sh;
-    // profiles/r03_record_target_soak.txt), in an unrelated later copy into pageable memory that reused the addresses of an
-    // array that had been registered and un-registered: the same failure the mirror path showed in round 2 with page-locked
-    // application memory (3 of 10). Application memory is therefore never registered. GV_DEBUG_RECORD_TARGET_PAGE_LOCK=1
-    // brings the in-place form back for A/Bs.
-    static const bool page_lock = getenv("GV_DEBUG_RECORD_TARGET_PAGE_LOCK") != nullptr;
-    void* dev = nullptr;
-    if (page_lock && hipHostRegister(records, bytes, hipHostRegisterDefault) == hipSuccess) {
-        if (hipHostGetDevicePointer(&dev, records, 0) == hipSuccess && dev)
-            target.dev = static_cast<uint8_t*>(dev);
-        else
-            (void)hipHostUnregister(records);
-    }
-    (void)hipGetLastError();
+    // and, measured in round 3, the GPU test tier then ABORTED inside the runtime in 4 of 16 runs (profiles/r03_record_target_soak.txt),
+    // in an unrelated later copy into pageable memory that reused the addresses of an array that had been registered and
+    // un-registered. Application memory is therefore never registered (profiles/withdrawn.md).
     return GV_OK;
 }
 

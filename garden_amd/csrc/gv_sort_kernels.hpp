@@ -105,7 +105,7 @@ hipError_t launch_sort_small_batch(const SortBatch& batch, uint32_t views, uint3
 // The end of a tick's device chain without a stream synchronisation: a one-lane kernel behind everything queued so far
 // writes `value` into pinned host memory (kernels of one stream run in order, and a kernel's stores have landed when the
 // next one starts), the host polls that word. hipStreamSynchronize returns 6-11 us after the last store is visible on this
-// stack (tools/sync_probe.hip); the polled word is there after one more kernel boundary.
+// stack (round-2 probe tools/sync_probe.hip, in the history); the polled word is there after one more kernel boundary.
 hipError_t launch_done_flag(uint32_t* host_flag, uint32_t value, hipStream_t stream);
 
 // Scattered dirty slots as ONE packet and ONE launch (gv_reorder.hip; gv_mirror.cpp upload_*_scattered): entry k of the packet is

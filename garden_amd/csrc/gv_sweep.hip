@@ -269,87 +269,6 @@ __global__ __launch_bounds__(256) void sweep_mfma_kernel(const TransformMirror x
 }
 
 // ------------------------------------------------------------------------------------------------
-// world-matrix sweep, MFMA form with FOUR LANES PER SLOT END TO END (round 3, the one layout round 2 had not tried; debug
-// switch GV_DEBUG_SWEEP_MFMA4, not a default): no LDS tile and no crossing between a 1-lane and a 4-lane side — lane (e, q)
-// loads the TRS of slot 16r + e itself (the four lanes of a quad read the same addresses: one request), builds the local
-// model and KEEPS column q (its B operand / running product); per ancestor it builds the parent's local model and takes
-// ROW q (its four A operands). Lanes of a wave execute one instruction stream, and the canonical expressions of calcModel
-// (gv_device_math.hpp) are not symmetric under a permutation of x, y, z — r00 = 1 - fma(y, y2, z * z2) but r11 = 1 - fma(x,
-// x2, z * z2) — so a lane cannot compute "its quarter" of a model with code its neighbours share: every lane builds the
-// whole model and selects. The quaternion products are therefore done four times per slot; what disappears are the LDS
-// hand-overs. Measured: profiles/r03_mfma4.txt.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pick4(uint32_t q, float a0, float a1, float a2, float a3)
-{
-    return q == 0 ? a0 : (q == 1 ? a1 : (q == 2 ? a2 : a3));
-}
-
-__global__ __launch_bounds__(256) void sweep_mfma4_kernel(const TransformMirror xf, float* __restrict__ world)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t q = lane & 3u, e = lane >> 2;
-    const uint32_t wave_first = blockIdx.x * 256 + wave * 64;
-    float4 x[4];        // [round]: column q of the running product of slot wave_first + 16 r + e (w: bottom-row element)
-    uint32_t p[4];      // next ancestor (kSlotNone: the chain has ended)
-    bool live[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t s = wave_first + 16 * r + e;
-        x[r] = make_float4(0.0f, 0.0f, 0.0f, q == 3 ? 1.0f : 0.0f);
-        p[r] = kSlotNone;
-        live[r] = false;
-        if (s < xf.count) {
-            const XfRecord rec = stream_xf(xf, s);
-            const Mat34 m = local_model(rec);
-            live[r] = (rec.flags & kXfLive) != 0;
-            x[r].x = pick4(q, m.c0x, m.c1x, m.c2x, m.c3x);
-            x[r].y = pick4(q, m.c0y, m.c1y, m.c2y, m.c3y);
-            x[r].z = pick4(q, m.c0z, m.c1z, m.c2z, m.c3z);
-            if (live[r] && xf.max_depth != 0 && (rec.flags & kXfWithAncestors))
-                p[r] = xf.parent[s];
-        }
-    }
-    for (uint32_t d = 0; d < xf.max_depth; d++) {
-        const bool any = p[0] != kSlotNone || p[1] != kSlotNone || p[2] != kSlotNone || p[3] != kSlotNone;
-        if (!__any(any))
-            break;  // wave-uniform exit (MFMA ignores EXEC)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const bool step = p[r] != kSlotNone;
-            float4 row = make_float4(0.0f, 0.0f, 0.0f, q == 3 ? 1.0f : 0.0f);  // (row 3 of an affine model)
-            uint32_t next = kSlotNone;
-            if (step) {
-                const Mat34 pm = local_model(load_xf(xf, p[r]));
-                next = xf.parent[p[r]];
-                if (q != 3)
-                    row = make_float4(pick4(q, pm.c0x, pm.c0y, pm.c0z, 0.0f), pick4(q, pm.c1x, pm.c1y, pm.c1z, 0.0f),
-                                      pick4(q, pm.c2x, pm.c2y, pm.c2z, 0.0f), pick4(q, pm.c3x, pm.c3y, pm.c3z, 1.0f));
-            }
-            f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, x[r].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, x[r].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, x[r].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(row.w, x[r].w, acc, 0, 0, 0);
-            x[r].x = step ? acc[0] : x[r].x;
-            x[r].y = step ? acc[1] : x[r].y;
-            x[r].z = step ? acc[2] : x[r].z;
-            p[r] = next;
-        }
-    }
-    // float4x3 order: column q's xyz at 12 floats per slot — lane (e, q) stores 12 bytes, a quad 48 contiguous ones, a round 768
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t s = wave_first + 16 * r + e;
-        if (s < xf.count) {
-            float* dst = world + (size_t)s * 12 + q * 3;
-            __builtin_nontemporal_store(live[r] ? x[r].x : 0.0f, dst);
-            __builtin_nontemporal_store(live[r] ? x[r].y : 0.0f, dst + 1);
-            __builtin_nontemporal_store(live[r] ? x[r].z : 0.0f, dst + 2);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // MFMA sweep + cull in one pass (cfg4: "hierarchy recomputed each frame + cull"). For a mesh pool that is exactly
 // paired with the transform pool the world matrix of slot s IS the model of mesh entry s before the camera translate
 // (transform.hpp:211-213), so the sweep's product is handed back to the memory side through the wave's LDS tile,
@@ -576,11 +495,6 @@ hipError_t launch_sweep_cull(const MeshMirror& mesh, const TransformMirror& xf, 
 
 hipError_t launch_sweep_mfma(const TransformMirror& xf, float4* world, hipStream_t stream)
 {
-    static const bool four_lanes = getenv("GV_DEBUG_SWEEP_MFMA4") != nullptr;  // round-3 experiment (sweep_mfma4_kernel)
-    if (four_lanes && xf.count) {
-        hipLaunchKernelGGL(sweep_mfma4_kernel, dim3((xf.count + 255) / 256), dim3(256), 0, stream, xf, reinterpret_cast<float*>(world));
-        return hipGetLastError();
-    }
     if (xf.count == 0)
         return hipSuccess;
     hipLaunchKernelGGL(sweep_mfma_kernel, dim3((xf.count + 255) / 256), dim3(256), 0, stream, xf,

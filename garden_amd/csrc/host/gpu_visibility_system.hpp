@@ -731,15 +731,19 @@ private:
         rankChanges.reset(ranks, meshSystems.size());
         // mesh components: the slots a system names, or — no counters, or "the whole pool may have changed" — every slot, compared
         // with the ranks' copies in the bytes the cull reads (a slot that changed hands: deal again)
-        for (size_t p = 0; p < meshSystems.size() && !structural; p++) {
-            auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
-            const uint32_t occupancy = meshSystems[p]->getMeshComponentPool().getOccupancy();
-            uint32_t lo = 0, hi = occupancy;
-            if (versioned && versioned->reportsChanges && ranksSeen.meshVersion[p] == versioned->meshVersion) {
-                lo = std::min(versioned->meshLo, versioned->meshHi);
-                hi = std::min(versioned->meshHi, occupancy);
+        if (!structural) {
+            std::vector<RankShares::MeshPiece> pieces;
+            for (size_t p = 0; p < meshSystems.size(); p++) {
+                auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
+                const uint32_t occupancy = meshSystems[p]->getMeshComponentPool().getOccupancy();
+                uint32_t lo = 0, hi = occupancy;
+                if (versioned && versioned->reportsChanges && ranksSeen.meshVersion[p] == versioned->meshVersion) {
+                    lo = std::min(versioned->meshLo, versioned->meshHi);
+                    hi = std::min(versioned->meshHi, occupancy);
+                }
+                pieces.push_back(RankShares::MeshPiece{(uint32_t)p, lo, hi, meshSystems[p]});
             }
-            structural = !rankShares.syncMeshes((uint32_t)p, meshSystems[p], lo, hi, rankChanges);
+            structural = !rankShares.syncMeshes(pieces, rankChanges);
         }
         std::vector<uint32_t> moved;
         bool everything = false;

@@ -251,50 +251,76 @@ struct RankShares {
 
     // ---- frame to frame ----
 
-    // Mesh slots [lo, hi) of pool p against the ranks' copies, in the bytes the cull reads — entity (mesh.cpp:142,149), isEnabled
-    // (:142), aabb (:140-141,158): what differs is copied and recorded. false: a slot holds another entity than it was dealt with (a
-    // component came or went): the caller deals again. Runs on the library's worker threads for long ranges.
-    bool syncMeshes(uint32_t p, IMeshRenderSystem* meshSystem, uint32_t lo, uint32_t hi, Changes& changes)
+    // Mesh slots against the ranks' copies, in the bytes the cull reads — entity (mesh.cpp:142,149), isEnabled (:142), aabb
+    // (:140-141,158): what differs is copied and recorded. pieces: per pool, the slots [lo, hi) to look at; ALL pieces are walked in
+    // ONE pass over the library's worker threads (a frame of seven systems of 10^5 components each is one pass over 7 * 10^5 slots,
+    // not seven short ones on the calling thread). false: a slot holds another entity than it was dealt with (a component came or
+    // went): the caller deals again.
+    struct MeshPiece {
+        uint32_t pool, lo, hi;
+        IMeshRenderSystem* meshSystem;
+    };
+    bool syncMeshes(const std::vector<MeshPiece>& pieces, Changes& changes)
     {
         struct Job {
             RankShares* self;
-            uint32_t p;
-            const uint8_t* world;
-            size_t stride;
+            std::vector<MeshPiece> pieces;
+            std::vector<uint32_t> start;  // running slot counts: piece k covers [start[k], start[k + 1]) of the pass
             Changes* changes;
             std::mutex merge;
             bool structural = false;
-        } job{this, p, reinterpret_cast<const uint8_t*>(meshSystem->getMeshComponentPool().getData()), meshSystem->getMeshComponentSize(), &changes, {}, false};
-        hi = std::min<uint32_t>(hi, (uint32_t)meshTables[p].entity.size());
-        if (lo >= hi)
+        } job;
+        job.self = this;
+        job.changes = &changes;
+        job.start.push_back(0u);
+        for (MeshPiece piece : pieces) {
+            piece.hi = std::min<uint32_t>(piece.hi, (uint32_t)meshTables[piece.pool].entity.size());
+            if (piece.lo >= piece.hi)
+                continue;
+            job.pieces.push_back(piece);
+            job.start.push_back(job.start.back() + (piece.hi - piece.lo));
+        }
+        if (job.pieces.empty())
             return true;
-        gv_host_parallel_ranges(lo, hi - lo, [](void* user, uint32_t a, uint32_t b) {
+        gv_host_parallel_ranges(0, job.start.back(), [](void* user, uint32_t a, uint32_t b) {
             Job& j = *static_cast<Job*>(user);
-            const MeshTable& table = j.self->meshTables[j.p];
-            std::vector<std::pair<uint32_t, uint32_t>> edited;  // (rank, local)
+            std::vector<uint32_t> edited;  // (pool << 28 | rank << 24 ...) would not fit: triples, flattened
             bool structural = false;
             constexpr size_t kAabb = offsetof(MeshRenderComponent, aabb);
-            for (uint32_t s = a; s < b; s++) {
-                const auto* w = reinterpret_cast<const MeshRenderComponent*>(j.world + (size_t)s * j.stride);
-                if (*w->entity != table.entity[s]) {
-                    structural = true;
-                    break;
+            size_t k = (size_t)(std::upper_bound(j.start.begin(), j.start.end(), a) - j.start.begin()) - 1;
+            for (uint32_t at = a; at < b && !structural; k++) {
+                const MeshPiece& piece = j.pieces[k];
+                const uint32_t end = std::min(b, j.start[k + 1]);
+                const MeshTable& table = j.self->meshTables[piece.pool];
+                const uint8_t* world = reinterpret_cast<const uint8_t*>(piece.meshSystem->getMeshComponentPool().getData());
+                const size_t stride = piece.meshSystem->getMeshComponentSize();
+                for (uint32_t s = piece.lo + (at - j.start[k]), e = piece.lo + (end - j.start[k]); s < e; s++) {
+                    const auto* w = reinterpret_cast<const MeshRenderComponent*>(world + (size_t)s * stride);
+                    if (*w->entity != table.entity[s]) {
+                        structural = true;
+                        break;
+                    }
+                    MeshRenderComponent* c = j.self->shares[table.rank[s]].meshes[piece.pool].at(table.local[s]);
+                    if (c->isEnabled == w->isEnabled && std::memcmp(&c->aabb, &w->aabb, sizeof(Aabb)) == 0)
+                        continue;
+                    c->isEnabled = w->isEnabled;
+                    std::memcpy(reinterpret_cast<uint8_t*>(c) + kAabb, reinterpret_cast<const uint8_t*>(w) + kAabb, sizeof(Aabb));
+                    edited.insert(edited.end(), {piece.pool, table.rank[s], table.local[s]});
                 }
-                MeshRenderComponent* c = j.self->shares[table.rank[s]].meshes[j.p].at(table.local[s]);
-                if (c->isEnabled == w->isEnabled && std::memcmp(&c->aabb, &w->aabb, sizeof(Aabb)) == 0)
-                    continue;
-                c->isEnabled = w->isEnabled;
-                std::memcpy(reinterpret_cast<uint8_t*>(c) + kAabb, reinterpret_cast<const uint8_t*>(w) + kAabb, sizeof(Aabb));
-                edited.push_back({table.rank[s], table.local[s]});
+                at = end;
             }
             if (!structural && edited.empty())
                 return;
             std::lock_guard<std::mutex> lock(j.merge);
             j.structural = j.structural || structural;
-            for (const auto& e : edited)
-                j.changes->ranks[e.first].meshes[j.p].push_back(e.second);
+            for (size_t e = 0; e + 2 < edited.size(); e += 3)
+                j.changes->ranks[edited[e + 1]].meshes[edited[e]].push_back(edited[e + 2]);
         }, &job);
         return !job.structural;
+    }
+    bool syncMeshes(uint32_t p, IMeshRenderSystem* meshSystem, uint32_t lo, uint32_t hi, Changes& changes)
+    {
+        return syncMeshes(std::vector<MeshPiece>{MeshPiece{p, lo, hi, meshSystem}}, changes);
     }
 
     // One transform that moved or changed its flags: its bytes to its rank.
@@ -343,15 +369,20 @@ struct RankShares {
                 if (rankOfTransform[s] != GV_NONE && !*world[s].parent && owner[s] != rankOfTransform[s])
                     moves.push_back({s, owner[s]});
         } else {
+            std::vector<uint32_t> roots;
+            std::vector<float> positions;  // (one call for all of them: gv_cell_owner deals the cells anew every time it is asked)
             for (uint32_t s : slots) {
                 if (s >= occupancy || rankOfTransform[s] == GV_NONE || *world[s].parent)
                     continue;
-                uint32_t owner = 0;
-                if (gv_cell_owner(grid, side, ranks, reinterpret_cast<const float*>(&world[s].posChildCount), (uint32_t)sizeof(TransformComponent), 1, &owner) != GV_OK)
-                    throw std::runtime_error("RankShares: gv_cell_owner failed");
-                if (owner != rankOfTransform[s])
-                    moves.push_back({s, owner});
+                roots.push_back(s);
+                positions.insert(positions.end(), {world[s].posChildCount.x, world[s].posChildCount.y, world[s].posChildCount.z});
             }
+            std::vector<uint32_t> owner(roots.size() ? roots.size() : 1);
+            if (!roots.empty() && gv_cell_owner(grid, side, ranks, positions.data(), 12, (uint32_t)roots.size(), owner.data()) != GV_OK)
+                throw std::runtime_error("RankShares: gv_cell_owner failed");
+            for (size_t k = 0; k < roots.size(); k++)
+                if (owner[k] != rankOfTransform[roots[k]])
+                    moves.push_back({roots[k], owner[k]});
         }
         for (const auto& m : moves)
             if (rankOfTransform[m.first] != m.second)  // (a slot listed twice has moved already)

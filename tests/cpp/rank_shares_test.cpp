@@ -126,7 +126,7 @@ int main()
 {
     std::mt19937 rng(20261004u);
     auto uniform = [&](float lo, float hi) { return lo + (hi - lo) * (float)(rng() >> 8) * (1.0f / 16777216.0f); };
-    for (uint32_t ranks : {1u, 2u, 3u, 8u}) {
+    for (uint32_t ranks : {1u, 2u, 3u, 8u, 4u}) {
         Manager manager;
         auto transformSystem = manager.createSystem<TransformSystem>();
         manager.registerComponents<TransformComponent>(transformSystem);
@@ -135,7 +135,7 @@ int main()
         auto wide = manager.createSystem<WideMeshSystem>();
         manager.registerComponents<WideMeshComponent>(wide);
         manager.initialize();
-        const uint32_t n = 6000;
+        const uint32_t n = ranks == 4 ? 210000 : 6000;  // (the last world is long enough for the passes to spread over the worker threads)
         const double side = 100.0 * std::cbrt((double)n);
         uint32_t grid[3] = {1, 1, 1};
         for (uint32_t axis = 0; (uint64_t)grid[0] * grid[1] * grid[2] < 512ull * ranks; axis = (axis + 1) % 3)

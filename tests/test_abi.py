@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib.load()
     for name in header_functions():
         assert hasattr(handle, name), f"libgarden_vis.so does not export {name}"
-    assert handle.gv_abi_version() == 3
+    assert handle.gv_abi_version() == 4
 
 
 def test_struct_sizes_match_header():
@@ -40,7 +40,7 @@ def test_header_is_plain_c_and_the_binding_structs_match_it(tmp_path):
     the sizes / field offsets the C compiler gives every struct equal the ctypes mirror's (garden_amd/lib.py)."""
     import subprocess
     from garden_amd import lib
-    structs = ["GvConfig", "GvView", "GvTransformLayout", "GvMeshLayout", "GvResult", "GvDeviceResult", "GvRecordLayout", "GvStats", "GvExchangeFrame"]
+    structs = ["GvConfig", "GvView", "GvTransformLayout", "GvMeshLayout", "GvResult", "GvDeviceResult", "GvRecordLayout", "GvStats", "GvExchangeFrame", "GvExchangeItem"]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "garden_vis.h"', "int main(void) {"]
     for name in structs:
         cls = getattr(lib, name)

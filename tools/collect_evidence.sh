@@ -53,34 +53,26 @@ run_probe() {  # run_probe <binary> <arguments...>: only a binary build_probe ha
   done
   echo "# --span-records (round 4): the render passes read the library's page-locked result buffer (UnsortedBuffer::meshes()); nothing is copied into combinedMeshes"
   echo "# round 1 (profiles/r01k_tick_*): 2 k 32-35, 10 k 49-52, 100 k 263, 10 k --mixed 210, --mixed --csm 203; round 2 (profiles/r02_tick.txt, records into page-locked engine vectors): 2 k 21-22, 10 k 33.8-36, 100 k 161-173, --mixed --csm 76-86; round 3 (profiles/r03_tick.txt, engine vectors never page-locked): 100 k 216"
-} > $out/r05_tick.txt 2>&1
+} > $out/r06_tick.txt 2>&1
 {
-  echo "# cfg3 on the HARD depth image (bench.py --depth noise: per-8x8-block occluders among the entities), level 1 of the pyramid virtual (default) / stored"
-  for e in "" "GV_DEBUG_STORE_HIZ_LEVEL1=1"; do
-    echo "## ${e:-default (level 1 virtual)}"
-    env $e python3 bench.py --depth noise --no-cpu-baseline --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f  cull kernel %.4f ms  frac %.3f  visible %.4f  frame kernels %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['visible_fraction'], d['config']['frame_kernel_ms']))"
-    echo "## ${e:-default (level 1 virtual)}, the walls (SURVEY.md 8d)"
-    env $e python3 bench.py --no-cpu-baseline --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f  cull kernel %.4f ms  frac %.3f  visible %.4f  frame kernels %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['visible_fraction'], d['config']['frame_kernel_ms']))"
+  echo "# cfg3 on the HARD depth image (bench.py --depth noise: per-8x8-block occluders among the entities), then on the walls (SURVEY.md 8d)"
+  for d in "--depth noise" ""; do
+    echo "## bench.py $d"
+    python3 bench.py $d --no-cpu-baseline --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.4f  cull kernel %.4f ms  frac %.3f  visible %.4f  frame kernels %s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['visible_fraction'], d['config']['frame_kernel_ms']))"
   done
-} > $out/r05_hard_depth.txt 2>&1
+} > $out/r06_hard_depth.txt 2>&1
 {
   echo "# tools/hiz_sizes.py: pyramid rebuild by frame size, wall clock over 300 back-to-back rebuilds (us)"
   timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-  echo "# the same with three levels per launch only (GV_DEBUG_HIZ_NO_FUSED4=1: 1920x1080 and 1600x900 are the sizes that take four)"
-  GV_DEBUG_HIZ_NO_FUSED4=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-  echo "# the same without the any-size fused kernel (GV_DEBUG_HIZ_NO_FUSED3=1: one launch per level down to the tail)"
-  GV_DEBUG_HIZ_NO_FUSED3=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-  echo "# ... and without the tail kernel either (GV_DEBUG_HIZ_NO_TAIL=1: one launch per level all the way, the round-1 form for such sizes)"
-  GV_DEBUG_HIZ_NO_FUSED3=1 GV_DEBUG_HIZ_NO_TAIL=1 timeout 120 python3 tools/hiz_sizes.py 2>&1 | grep rebuild
-} > $out/r05_hiz_sizes.txt 2>&1
+} > $out/r06_hiz_sizes.txt 2>&1
 {
   echo "# tools/multiview_bench.py: main camera + 3 cascades over 10 M entities, one batched pass vs one pass per view (ms per frame; kernel us per frame)"
   timeout 300 python3 tools/multiview_bench.py 2>&1 | grep -E "batched|separate"
-} > $out/r05_multiview.txt 2>&1
+} > $out/r06_multiview.txt 2>&1
 # the line an 8-GPU run prints, with 8 ranks SHARING this box's one GPU (torch over gloo, the library's exchange over the tests'
 # shared-memory transport): functional, never a measurement — what it shows is the balance of the ranks and the bytes on the links
-GV_BENCH_BACKEND=gloo timeout 1500 python3 bench.py --gpus 8 --entities 1500000 --steps 10 --warmup 2 > $out/r05_gloo8_sample_line.json 2> $out/gloo8.err
-python3 - $out/r05_gloo8_sample_line.json <<'EOF' > $out/r05_gloo8_summary.txt 2>&1
+GV_BENCH_BACKEND=gloo timeout 1500 python3 bench.py --gpus 8 --entities 1500000 --steps 10 --warmup 2 > $out/r06_gloo8_sample_line.json 2> $out/gloo8.err
+python3 - $out/r06_gloo8_sample_line.json <<'EOF' > $out/r06_gloo8_summary.txt 2>&1
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 c = d["config"]

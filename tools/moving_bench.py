@@ -1,7 +1,7 @@
 """A 10 M-entity flat scene in which K scattered entities move EVERY frame (round 3: the block bounds and emit seeds of the pool are
 kept current by re-deriving only the 256-entry blocks that hold a moved entity). Per frame: K single-slot dirty marks + cull (+ emit)
-with a Hi-Z pyramid; wall clock per frame and the device time per kernel kind, with the patching (default) and without
-(GV_DEBUG_NO_BOUNDS_PATCH=1: a pool that changes every frame is culled without boxes, the round-2 behaviour).
+with a Hi-Z pyramid; wall clock per frame and the device time per kernel kind. (The round-2 behaviour — a pool that changes every
+frame is culled without boxes — was measured beside it in profiles/r03_moving.txt and is in the history.)
    python tools/moving_bench.py [entities = 10_000_000]"""
 import os
 import subprocess
@@ -19,7 +19,7 @@ def one(n):
     view = dict(scene.main_camera_view(), use_hiz=1)
     depth = scene.synthetic_depth(4096, 4096)
     rng = np.random.Generator(np.random.PCG64(3))
-    mode = "without patching (GV_DEBUG_NO_BOUNDS_PATCH)" if os.environ.get("GV_DEBUG_NO_BOUNDS_PATCH") else "blocks patched"
+    mode = "blocks patched"
     with GpuVisibility(profile_events=True) as vis:
         vis.hiz_build(depth)
         vis.bind_transforms(sc.transforms, sc.entity_to_transform)
@@ -57,8 +57,4 @@ if __name__ == "__main__":
         one(int(sys.argv[1]))
         sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    for off in (False, True):
-        env = dict(os.environ, GV_MOVING_BENCH_CHILD="1")
-        if off:
-            env["GV_DEBUG_NO_BOUNDS_PATCH"] = "1"
-        subprocess.run([sys.executable, __file__, str(n)], env=env, check=False)
+    subprocess.run([sys.executable, __file__, str(n)], env=dict(os.environ, GV_MOVING_BENCH_CHILD="1"), check=False)

@@ -1,6 +1,6 @@
 """The spatial re-order after entity churn: a pool of N entities grows by N/8 + 1 created entities (re-bound with the
 larger occupancy, no rebuild request), which puts more than 1/8 of it into the mirror's unsorted tail — the next sync re-orders.
-Times that sync (growth + re-order) on the device (default) and as the full host rebuild (GV_DEBUG_HOST_REORDER=1), and the
+Times that sync (growth + re-order) on the device (the full host rebuild it replaced: profiles/r03_reorder.txt), and the
 frame after it; checks the visible set against the oracle's both times. Dev tool / evidence (profiles/r03_reorder.txt).
    python tools/reorder_bench.py [entities after growth = 10_000_000] [flat|hier]"""
 import os
@@ -52,7 +52,7 @@ def one(n_total, kind):
         got = vis.fetch(0, write_back=False, occupancy=n_total)
         exp = oracle_py.prepare_meshes(b.meshes.copy(), b.transforms, b.entity_to_transform, view, threads=os.cpu_count())
         ok = np.array_equal(got["visible_idx"], np.sort(exp["visible_idx"]))
-        mode = "host rebuild (GV_DEBUG_HOST_REORDER)" if os.environ.get("GV_DEBUG_HOST_REORDER") else "device re-order"
+        mode = "device re-order"
         print(f"{kind} {n0} -> {n_total} entities, {mode}: sync (append {n_total - n0} + re-order) {t_sync * 1e3:8.1f} ms, "
               f"device re-orders {reorders}, frame afterwards {t_frame * 1e3:.3f} ms, visible set == oracle: {ok}", flush=True)
 
@@ -64,8 +64,4 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     kinds = [sys.argv[2]] if len(sys.argv) > 2 else ["flat", "hier"]
     for kind in kinds:
-        for host in (False, True):
-            env = dict(os.environ, GV_REORDER_BENCH_CHILD="1", GV_DEBUG_TIMING="1")
-            if host:
-                env["GV_DEBUG_HOST_REORDER"] = "1"
-            subprocess.run([sys.executable, __file__, str(n), kind], env=env, check=False)
+        subprocess.run([sys.executable, __file__, str(n), kind], env=dict(os.environ, GV_REORDER_BENCH_CHILD="1", GV_DEBUG_TIMING="1"), check=False)
