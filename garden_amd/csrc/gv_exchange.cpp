@@ -180,8 +180,18 @@ void exchange_release(GvCtx* ctx)
         }
         ctx->exchange_comm = nullptr;
     }
-    if (hung)
+    if (hung) {
+        // ... and so is everything the collective may still touch: hipFree waits for the device, i.e. for ever. Leaked, like the stream.
         ctx->exchange_stream = nullptr;
+        ctx->d_shard.ptr = nullptr;
+        ctx->d_shard.cap = 0;
+        for (auto& slot : ctx->exchange_slots) {
+            slot.rows.ptr = slot.shard.ptr = nullptr;
+            slot.rows.cap = slot.shard.cap = 0;
+            slot.d_items.ptr = nullptr;
+            slot.d_items.cap = 0;
+        }
+    }
     if (ctx->exchange_stream)
         (void)hipStreamSynchronize(ctx->exchange_stream);
     ctx->d_shard.release();
@@ -334,22 +344,33 @@ int gv_exchange_init_all(GvCtx* const* contexts, int world_size)
     for (int k = 0; k < world_size && rc == GV_OK; k++)
         rc = exchange_setup(contexts[k], k, world_size);
     ncclComm_t comms[GV_EXCHANGE_MAX_RANKS] = {};
+    // every device is selected once BEFORE the group opens: nothing but ncclCommInitRank itself can fail between ncclGroupStart and
+    // ncclGroupEnd (a group closed over fewer than world_size ranks would wait for the missing ones for ever)
+    for (int k = 0; k < world_size && rc == GV_OK; k++)
+        if (hipSetDevice(contexts[k]->device) != hipSuccess)
+            rc = contexts[k]->fail(GV_E_HIP, "gv_exchange_init_all: hipSetDevice(%d)", contexts[k]->device);
+    bool started = false;
     if (rc == GV_OK) {
         // one thread, N devices: the N ncclCommInitRank calls meet inside ONE group (each would otherwise wait for the others)
         int nrc = r.GroupStart();
+        started = nrc == 0;
         for (int k = 0; k < world_size && nrc == 0; k++) {
-            if (hipSetDevice(contexts[k]->device) != hipSuccess) {
-                rc = contexts[k]->fail(GV_E_HIP, "gv_exchange_init_all: hipSetDevice(%d)", contexts[k]->device);
-                break;
-            }
+            (void)hipSetDevice(contexts[k]->device);  // (checked above)
             nrc = r.CommInitRank(&comms[k], world_size, id, k);
         }
         const int erc = r.GroupEnd();
         if (nrc == 0)
             nrc = erc;
-        if (nrc != 0 && rc == GV_OK)
+        if (nrc != 0)
             rc = first->fail(GV_E_RCCL, "gv_exchange_init_all: ncclCommInitRank: %s", r.GetErrorString(nrc));
     }
+    if (rc != GV_OK && started)  // a group that failed half way: its communicators never met — aborted, not destroyed (a destroy may wait for peers)
+        for (int k = 0; k < world_size; k++)
+            if (comms[k]) {
+                if (r.CommAbort)
+                    (void)r.CommAbort(comms[k]);
+                comms[k] = nullptr;
+            }
     for (int k = 0; k < world_size; k++) {
         contexts[k]->exchange_comm = comms[k];  // (a failed start: released below, communicator included)
         contexts[k]->exchange_by_group = true;

@@ -142,45 +142,49 @@ public:
         reparentHi = std::max(reparentHi, slot + 1);
         reparentVersion++;
     }
-    // TransformComponent::setActive, transform.cpp:75-127, walk for walk. Activating: nothing moves below an entity whose own
-    // ancestors are inactive (:86-87); otherwise children become ancestorsActive = true, and the walk does NOT descend through a
-    // child that is itself inactive (:94-95 `continue`): the bytes below it are left as they are — which is what makes the stored
-    // byte history-dependent (a grandchild deactivated by an earlier walk stays so). Deactivating: every descendant, whatever
-    // its own state (:110-124).
+    // TransformComponent::setActive, transform.cpp:75-127, walk for walk — including its stack, which is `static thread_local`
+    // (transform.cpp:27) and is NOT emptied by the early return of an activation under inactive ancestors (:86-87): the entity stays
+    // on it, and the NEXT setActive of any entity — after its own subtree — also walks the subtree of that left-over entity, in ITS
+    // direction (an activation marks the left-over's children ancestorsActive = true although the left-over's own ancestors are
+    // inactive; a deactivation marks them false). Activating: children become ancestorsActive = true, and the walk does NOT descend
+    // through a child that is itself inactive (:94-95 `continue`): the bytes below it are left as they are — which is what makes the
+    // stored byte history-dependent. Deactivating: every descendant, whatever its own state (:110-124). The cull reads the stored
+    // bytes (isActive = selfActive && ancestorsActive, transform.hpp:110): whatever history leaves there is what both systems see.
     void setActive(ID<Entity> entity, bool isActive)
     {
+        static thread_local std::vector<ID<Entity>> entityStack;  // transform.cpp:27
         auto view = tryGetOf(entity);
         if (!view || view->selfActive == isActive)
             return;
         view->selfActive = isActive;
         touchFlags((uint32_t)(*view - components.getData()));
-        std::vector<ID<Entity>> stack{entity};
+        entityStack.push_back(entity);
         if (isActive) {
             if (!view->ancestorsActive)
-                return;
-            while (!stack.empty()) {
-                auto v = tryGetOf(stack.back());
-                stack.pop_back();
-                if (!v || !v->selfActive)
+                return;  // (the entity stays on the stack, as in the reference)
+            while (!entityStack.empty()) {
+                auto v = tryGetOf(entityStack.back());
+                entityStack.pop_back();
+                if (!v || !v->selfActive)  // (!v: a left-over entity that has been destroyed since — the reference would read freed memory)
                     continue;
                 for (uint32_t i = 0, n = v->childCount(); i < n; i++)
                     if (auto child = tryGetOf(v->childs[i])) {
                         child->ancestorsActive = true;
                         touchFlags((uint32_t)(*child - components.getData()));
-                        stack.push_back(v->childs[i]);
+                        entityStack.push_back(v->childs[i]);
                     }
             }
         } else {
-            while (!stack.empty()) {
-                auto v = tryGetOf(stack.back());
-                stack.pop_back();
+            while (!entityStack.empty()) {
+                auto v = tryGetOf(entityStack.back());
+                entityStack.pop_back();
                 if (!v)
                     continue;
                 for (uint32_t i = 0, n = v->childCount(); i < n; i++)
                     if (auto child = tryGetOf(v->childs[i])) {
                         child->ancestorsActive = false;
                         touchFlags((uint32_t)(*child - components.getData()));
-                        stack.push_back(v->childs[i]);
+                        entityStack.push_back(v->childs[i]);
                     }
             }
         }

@@ -20,6 +20,10 @@
 // R > 1 needs R GPUs with RCCL (it refuses two ranks on one device); with GV_RCCL_LIBRARY=<tests/cpp/build/librccl_stub.so>
 // the ranks share the GPUs there are (ranks are dealt round-robin over them) and the rows travel through shared memory.
 // "auto": min(GPUs, 8) ranks.
+// --check-oracle: on frame 0 and on the frame of the camera cut every rank ALSO runs the CPU oracle (oracle/gv_oracle.c:
+// gvo_prepare_meshes_range, mesh.cpp:111-184) over its own share and compares its own list with the oracle's as a set; the parent
+// already proves that every rank holds every owner's whole list, so union over the ranks == the oracle's visible set of the
+// world follows. (A test driver may link the oracle; the product library never does.)
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -32,9 +36,14 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 #include <hip/hip_runtime.h>
 
 #include "../../include/garden_vis.h"
+#include "../../oracle/gv_oracle.h"
 
 namespace {
 
@@ -60,6 +69,7 @@ struct RowSummary {
 struct FrameSummary {
     RowSummary own, rows[kMaxRanks];
     uint32_t short_rows, tail_words, mode, valid, sized_by_library, timed_out;
+    uint32_t oracle_checked, oracle_mismatch;  // --check-oracle: this rank's own list of the frame against the CPU oracle
     uint32_t travelled[kMaxRanks];
 };
 struct Shared {
@@ -109,7 +119,56 @@ void make_view(float yaw, GvView* view, float zoom = 1.0f)
     view->emit_records = 1;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, int id_in, int id_out, Shared* shared)
+// The CPU oracle's visible slots of one rank's share for `view`, ascending: gvo_prepare_meshes_range over contiguous pieces of the pool
+// on `threads` threads (ThreadPool::addItems, thread-pool.cpp:180-194), each piece with output arrays of its own size.
+std::vector<uint32_t> oracle_visible(std::vector<Transform>& tr, std::vector<Mesh>& me, const std::vector<uint32_t>& e2t, const GvView& view, uint32_t threads)
+{
+    GvoMeshPool mp{};
+    mp.base = reinterpret_cast<uint8_t*>(me.data());
+    mp.stride = sizeof(Mesh);
+    mp.occupancy = (uint32_t)me.size();
+    mp.off_entity = 0; mp.off_is_enabled = 14; mp.off_is_visible = 15; mp.off_aabb_min = 16; mp.off_aabb_max = 32;
+    GvoTransformPool tp{};
+    tp.base = reinterpret_cast<const uint8_t*>(tr.data());
+    tp.stride = sizeof(Transform);
+    tp.occupancy = (uint32_t)tr.size();
+    tp.off_entity = 0; tp.off_parent = 4; tp.off_position = 16; tp.off_scale = 32; tp.off_rotation = 48;
+    tp.off_self_active = 72; tp.off_ancestors_active = 73; tp.off_model_with_ancestors = 74;
+    tp.entity_to_transform = e2t.data();
+    tp.entity_capacity = (uint32_t)e2t.size();
+    GvoView ov{};
+    memcpy(ov.view_proj, view.view_proj, sizeof(ov.view_proj));
+    memcpy(ov.camera_position, view.camera_position, sizeof(ov.camera_position));
+    memcpy(ov.camera_offset, view.camera_offset, sizeof(ov.camera_offset));
+    ov.shadow_pass = view.shadow_pass;
+    GvoFrustum frustum;
+    gvo_frustum_from_view_proj(ov.view_proj, &frustum);
+    constexpr uint32_t kPiece = 1u << 18;
+    const uint32_t pieces = (mp.occupancy + kPiece - 1) / kPiece;
+    std::vector<std::vector<uint32_t>> found(pieces);
+    std::vector<std::thread> workers;
+    std::atomic<uint32_t> next{0};
+    for (uint32_t t = 0; t < std::max(1u, threads); t++)
+        workers.emplace_back([&] {
+            std::vector<uint32_t> idx(kPiece);
+            std::vector<float> model((size_t)kPiece * 12), dist(kPiece);
+            for (uint32_t piece = next++; piece < pieces; piece = next++) {
+                GvoCullOut out{idx.data(), model.data(), dist.data(), 0, 0};
+                gvo_prepare_meshes_range(&mp, &tp, &ov, &frustum, nullptr, piece * kPiece, std::min(mp.occupancy, (piece + 1) * kPiece), &out);
+                found[piece].assign(idx.begin(), idx.begin() + out.draw_count);
+            }
+        });
+    for (auto& w : workers)
+        w.join();
+    std::vector<uint32_t> all;
+    for (auto& f : found)
+        all.insert(all.end(), f.begin(), f.end());
+    std::sort(all.begin(), all.end());
+    return all;
+}
+
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, bool check_oracle,
+             int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -269,6 +328,20 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
         fs.mode = mode;
         if (!summarise_own(fs))
             return die("gv_results_fetch", ctx);
+        if (check_oracle && (frame == 0 || frame == frames / 2)) {
+            GvResult res{};
+            if (gv_results_fetch(ctx, 0, 0, &res) != GV_OK)
+                return die("gv_results_fetch", ctx);
+            std::vector<uint32_t> mine(res.visible_idx, res.visible_idx + res.draw_count);
+            std::sort(mine.begin(), mine.end());
+            const uint32_t threads = std::max(2u, std::thread::hardware_concurrency() / (uint32_t)ranks);
+            const std::vector<uint32_t> want = oracle_visible(tr, me, e2t, view, threads);
+            fs.oracle_checked = 1;
+            fs.oracle_mismatch = mine == want ? 0u : 1u;
+            if (fs.oracle_mismatch)
+                fprintf(stderr, "rank %d frame %d: the rank's list (%zu slots) is not the oracle's visible set of its share (%zu slots)\n", rank, frame, mine.size(),
+                        want.size());
+        }
         if (frame < sized_frames) {
             fs.sized_by_library = 1;
             GvExchangeFrame xf;
@@ -366,7 +439,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
-    bool abandon = false, abandon_by_destroy = false;
+    bool abandon = false, abandon_by_destroy = false, check_oracle = false;
     uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
@@ -384,6 +457,8 @@ int main(int argc, char** argv)
             camera_seed = (uint32_t)atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--stall-rank") && i + 1 < argc) {
             stall_rank = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--check-oracle")) {
+            check_oracle = true;
         } else if (!strcmp(argv[i], "--abandon")) {
             abandon = true;
         } else if (!strcmp(argv[i], "--abandon-by-destroy")) {
@@ -426,7 +501,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, abandon_by_destroy, camera_seed, to_child[2 * r], to_parent[2 * r + 1], shared));
+            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, abandon_by_destroy, camera_seed, check_oracle, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];
@@ -490,10 +565,23 @@ int main(int argc, char** argv)
         }
         link_words += f0.tail_words;
     }
+    // --check-oracle: frames on which EVERY rank compared its own list with the CPU oracle's visible set of its share
+    int oracle_checked_frames = 0;
+    for (int f = 0; f < frames; f++) {
+        bool all = true;
+        for (int r = 0; r < ranks; r++) {
+            all = all && shared->frames[r][f].oracle_checked;
+            mismatches += (int)shared->frames[r][f].oracle_mismatch;
+        }
+        oracle_checked_frames += all ? 1 : 0;
+    }
+    if (check_oracle && stall_rank < 0 && oracle_checked_frames < 2)
+        mismatches++;
     const bool ok = !failed && !mismatches;
     printf("{\"ranks\": %d, \"frames\": %d, \"entities_per_rank\": %u, \"ok\": %s, \"failed_ranks\": %d, \"mismatches\": %d, \"frames_with_a_second_exchange\": %d, "
-           "\"short_rows_completed\": %d, \"tail_words\": %llu, \"timed_out_ranks\": %d, \"gathered_last_frame\": %llu, \"words_on_links_over_list_words\": %.3f}\n",
+           "\"short_rows_completed\": %d, \"tail_words\": %llu, \"timed_out_ranks\": %d, \"gathered_last_frame\": %llu, \"words_on_links_over_list_words\": %.3f, "
+           "\"oracle_checked_frames\": %d}\n",
            ranks, frames, n, ok ? "true" : "false", failed, mismatches, frames_completed, short_rows, (unsigned long long)tail_words, timed_out_ranks,
-           (unsigned long long)gathered_last, list_words ? (double)link_words / (double)list_words : 0.0);
+           (unsigned long long)gathered_last, list_words ? (double)link_words / (double)list_words : 0.0, oracle_checked_frames);
     return ok ? 0 : 1;
 }

@@ -287,6 +287,108 @@ static std::string gateHolds(Manager& manager, const SystemT* system, uint32_t p
     return "";
 }
 
+// What prepareSortedMeshes / prepareUnsortedMeshes / sortMeshes leave behind, checked against the reference TEXT (not against the other
+// system), for one system's buffers after a tick:
+//  (i)   mesh.cpp:252,419-421  every record of transSortedMeshes / uiSortedMeshes carries a bufferIndex that names a sortedBuffers entry
+//        whose meshSystem OWNS componentOffset: a whole number of components inside that system's pool, on a live, enabled component
+//        that the light pass has just marked visible (:166,170)
+//  (ii)  mesh.cpp:416-419      a shadow pass prepares no UI system (`continue` before the index is taken): its sorted array holds records
+//        of Translucent systems only, and their bufferIndex counts Translucent systems only — it indexes that pass's sortedBuffers
+//  (iii) mesh.cpp:270-295, mesh.hpp:196,204   unsorted buffers ascending distanceSq (OIT: not sorted, any order), shared sorted arrays descending
+//  (iv)  mesh.cpp:255-259      sum of drawCount over the buffers that share an array == that array's draw index
+// Empty string: holds.
+template <class SystemT>
+static std::string sortedArraysHold(Manager& manager, const SystemT* system, uint32_t passCount)
+{
+    (void)manager;
+    auto owns = [](const MeshBuffer* buffer, size_t componentOffset, bool mustBeVisible) -> const char* {
+        if (!buffer || !buffer->meshSystem)
+            return "the buffer names no mesh system";
+        const size_t size = buffer->meshSystem->getMeshComponentSize();
+        const auto& pool = buffer->meshSystem->getMeshComponentPool();
+        if (componentOffset % size != 0 || componentOffset / size >= pool.getOccupancy())
+            return "componentOffset is not a component of the system the bufferIndex names";
+        const auto* c = reinterpret_cast<const MeshRenderComponent*>(reinterpret_cast<const uint8_t*>(pool.getData()) + componentOffset);
+        if (!*c->entity || !c->isEnabled)
+            return "componentOffset names a free or disabled component";
+        if (mustBeVisible && !c->isVisible)
+            return "a record of the light pass names a component whose isVisible is false";
+        return nullptr;
+    };
+    // (i) + (iii) + (iv), the light pass's shared arrays
+    for (int ui = 0; ui < 2; ui++) {
+        const auto& list = ui ? system->getUiSortedMeshes() : system->getTransSortedMeshes();
+        const uint32_t n = ui ? system->getUiDrawCount() : system->getTransDrawCount();
+        const char* name = ui ? "uiSortedMeshes" : "transSortedMeshes";
+        uint64_t sum = 0;
+        for (uint32_t b = 0; b < system->getSortedBufferCount(); b++) {
+            const auto buffer = system->getSortedBuffers()[b];
+            if ((buffer->meshSystem->getMeshRenderType() == MeshRenderType::UI) == (ui != 0))
+                sum += buffer->drawCount;
+        }
+        if (sum != n)
+            return std::string(name) + ": the buffers' drawCounts sum to " + std::to_string(sum) + ", the array's draw index is " + std::to_string(n) + " (mesh.cpp:255-259)";
+        std::vector<uint32_t> perBuffer(system->getSortedBufferCount(), 0);
+        for (uint32_t k = 0; k < n; k++) {
+            const SortedMesh& m = list[k];
+            if (m.bufferIndex >= system->getSortedBufferCount())
+                return std::string(name) + ": a record's bufferIndex is past sortedBuffers (mesh.cpp:252)";
+            const auto buffer = system->getSortedBuffers()[m.bufferIndex];
+            if ((buffer->meshSystem->getMeshRenderType() == MeshRenderType::UI) != (ui != 0))
+                return std::string(name) + ": a record's bufferIndex names a system of the other kind (mesh.cpp:414-421)";
+            if (const char* why = owns(buffer, m.componentOffset, true))
+                return std::string(name) + ": record " + std::to_string(k) + ": " + why + " (mesh.cpp:170,252)";
+            perBuffer[m.bufferIndex]++;
+            if (k > 0 && list[k - 1].distanceSq < m.distanceSq)
+                return std::string(name) + ": not in descending distanceSq order at record " + std::to_string(k) + " (mesh.hpp:204, mesh.cpp:296-326)";
+        }
+        for (uint32_t b = 0; b < system->getSortedBufferCount(); b++) {
+            const auto buffer = system->getSortedBuffers()[b];
+            if ((buffer->meshSystem->getMeshRenderType() == MeshRenderType::UI) == (ui != 0) && perBuffer[b] != buffer->drawCount)
+                return std::string(name) + ": sortedBuffers[" + std::to_string(b) + "] counts " + std::to_string((uint32_t)buffer->drawCount) + " draws, the array holds " +
+                       std::to_string(perBuffer[b]) + " records with its index (mesh.cpp:255-259)";
+        }
+    }
+    // (ii) + (iii) + (iv), every shadow pass's sorted array
+    for (uint32_t s = 0; s < passCount; s++) {
+        const auto& buffers = system->getShadowSortedBuffers(s);
+        const auto& list = system->getShadowTransMeshes(s);
+        const uint32_t n = system->getShadowTransDrawCount(s);
+        uint64_t sum = 0;
+        for (auto buffer : buffers) {
+            if (buffer->meshSystem->getMeshRenderType() != MeshRenderType::Translucent)
+                return "shadow pass " + std::to_string(s) + ": its sortedBuffers hold a system that is not Translucent (a UI system takes no index there, mesh.cpp:416-419)";
+            sum += buffer->drawCount;
+        }
+        if (sum != n)
+            return "shadow pass " + std::to_string(s) + ": the buffers' drawCounts sum to " + std::to_string(sum) + ", the array's draw index is " + std::to_string(n);
+        for (uint32_t k = 0; k < n; k++) {
+            const SortedMesh& m = list[k];
+            if (m.bufferIndex >= buffers.size())
+                return "shadow pass " + std::to_string(s) + ": a record's bufferIndex counts more than the Translucent systems (mesh.cpp:416-419)";
+            if (const char* why = owns(buffers[m.bufferIndex], m.componentOffset, false))
+                return "shadow pass " + std::to_string(s) + ": record " + std::to_string(k) + ": " + why + " (mesh.cpp:170,252)";
+            if (k > 0 && list[k - 1].distanceSq < m.distanceSq)
+                return "shadow pass " + std::to_string(s) + ": its sorted array is not in descending distanceSq order (mesh.hpp:204)";
+        }
+    }
+    // (i) + (iii) for the unsorted buffers: records on their own system's components, ascending (OIT: any order)
+    for (uint32_t b = 0; b < system->getUnsortedBufferCount(); b++) {
+        for (int pass = -1; pass < (int)passCount; pass++) {
+            const UnsortedBuffer* buffer = pass < 0 ? system->getUnsortedBuffers()[b] : system->getShadowBuffers(b)[pass];
+            const bool sorted = buffer->meshSystem->getMeshRenderType() != MeshRenderType::OIT;  // mesh.cpp:273-277
+            const UnsortedMesh* meshes = buffer->meshes();
+            for (uint32_t k = 0; k < buffer->drawCount; k++) {
+                if (const char* why = owns(buffer, meshes[k].componentOffset, pass < 0))
+                    return "unsorted buffer " + std::to_string(b) + " pass " + std::to_string(pass) + ": record " + std::to_string(k) + ": " + why + " (mesh.cpp:170)";
+                if (sorted && k > 0 && meshes[k].distanceSq < meshes[k - 1].distanceSq)
+                    return "unsorted buffer " + std::to_string(b) + " pass " + std::to_string(pass) + ": not in ascending distanceSq order (mesh.hpp:196, mesh.cpp:270-295)";
+            }
+        }
+    }
+    return "";
+}
+
 int main(int argc, char** argv)
 {
     std::string mode = "cpu";
@@ -715,11 +817,15 @@ int main(int argc, char** argv)
                     poisonVisible(manager);
                     run(true, false, 1);
                     a = snapshot(manager, cpu, passCount);
-                    const std::string cpuGate = gateHolds(manager, cpu, passCount);
+                    std::string cpuGate = gateHolds(manager, cpu, passCount);
+                    if (cpuGate.empty())
+                        cpuGate = sortedArraysHold(manager, cpu, passCount);
                     poisonVisible(manager);
                     seconds += run(false, true, 1, false);
-                    const std::string gpuGate = gateHolds(manager, gpu, passCount);  // (after ONE tick from the pattern: a later tick
-                    if (!animate && ticks > 1)                                        //  would find a non-drawn system's bytes unchanged anyway)
+                    std::string gpuGate = gateHolds(manager, gpu, passCount);  // (after ONE tick from the pattern: a later tick
+                    if (gpuGate.empty())                                        //  would find a non-drawn system's bytes unchanged anyway)
+                        gpuGate = sortedArraysHold(manager, gpu, passCount);
+                    if (!animate && ticks > 1)
                         seconds += run(false, true, ticks - 1, false);
                     b = snapshot(manager, gpu, passCount);
                     if (ranks > 1 && ok) {
@@ -752,10 +858,10 @@ int main(int argc, char** argv)
                     // first each system against the reference text, then the two against each other
                     if (!cpuGate.empty()) {
                         ok = false;
-                        why = "CPU system vs mesh.cpp:419-427,476-483: " + cpuGate;
+                        why = "CPU system vs the text of mesh.cpp:187-328,408-490: " + cpuGate;
                     } else if (!gpuGate.empty()) {
                         ok = false;
-                        why = "GPU system vs mesh.cpp:419-427,476-483: " + gpuGate;
+                        why = "GPU system vs the text of mesh.cpp:187-328,408-490: " + gpuGate;
                     } else {
                         ok = same(a, b, why);
                     }
@@ -803,10 +909,12 @@ int main(int argc, char** argv)
                     run(mode == "cpu", mode == "gpu", 1);
                     if (gpu) gpu->tickSeconds = {};
                     // the gate of mesh.cpp:426 / :482 against the reference text, for the one system that ran
-                    const std::string held = cpu ? gateHolds(manager, cpu, passCount) : gateHolds(manager, gpu, passCount);
+                    std::string held = cpu ? gateHolds(manager, cpu, passCount) : gateHolds(manager, gpu, passCount);
+                    if (held.empty())
+                        held = cpu ? sortedArraysHold(manager, cpu, passCount) : sortedArraysHold(manager, gpu, passCount);
                     if (!held.empty()) {
                         ok = false;
-                        why = std::string(cpu ? "CPU" : "GPU") + " system vs mesh.cpp:419-427,476-483: " + held;
+                        why = std::string(cpu ? "CPU" : "GPU") + " system vs the text of mesh.cpp:187-328,408-490: " + held;
                         break;
                     }
                 }

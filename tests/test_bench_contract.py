@@ -54,7 +54,7 @@ def test_bench_gpus_2_starts_its_own_ranks(mode):
     assert len(lines) == 1, p.stdout[:2000]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("cfg5") and d["config"]["entities_total"] == 600000
-    assert d["config"]["exchange"] is not None and d["config"]["exchange_mode"] == mode
+    assert d["config"]["exchange"] is not None and d["config"]["exchange_mode"] == mode and d["config"]["exchange_mode_probe_ms"] is None  # (forced: no probe)
     # the timed exchange is the library's own C-ABI step (here over the shared-memory transport: two ranks share the GPU);
     # the torch.distributed form and the other travel patterns are timed beside it, each checked against the exact lists
     assert d["config"]["exchange_path"] == "c-abi" and "GV_RCCL_LIBRARY" in d["config"]["exchange_transport"]
@@ -87,7 +87,13 @@ def test_bench_gpus_8_every_field_of_the_scaling_line():
     d = _run_bench(["--gpus", "8", "--entities", "200000", "--steps", "4", "--warmup", "1"], {"GV_BENCH_BACKEND": "gloo"})
     c = d["config"]
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and c["workload"].startswith("cfg5") and c["entities_total"] == 1_600_000
-    assert c["exchange_payload"] == "indices" and c["exchange_mode"] == "allgather" and c["exchange_path"] == "c-abi"
+    assert c["exchange_payload"] == "indices" and c["exchange_path"] == "c-abi"
+    # no --exchange: five frames of each travel pattern were timed before the warm-up (slowest rank's clock, all-reduced) and the
+    # fastest one carried the timed frames — the first real 8-GPU run chooses its pattern instead of inheriting one chosen blind
+    probe = c["exchange_mode_probe_ms"]
+    assert set(probe) == {"allgather", "p2p", "broadcast"} and all(ms > 0 for ms in probe.values()), probe
+    assert c["exchange_mode"] == min(probe, key=probe.get) and c["exchange_mode"] in c["exchange"], c["exchange_mode"]
+    assert set(c["exchange_mode_variants"]) == {"allgather", "p2p", "broadcast"} - {c["exchange_mode"]}
     # every rank owns a share of every region (cells dealt in Morton order): all of them have work, none waits long for another,
     # and the gather moves little more than the lists ([.., 0, 0, 0, 0], 3.6 x)
     vis_by_rank = d["parity"]["visible_by_rank"]

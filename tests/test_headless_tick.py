@@ -296,8 +296,11 @@ def test_cfg5_in_its_shape_eight_ranks_of_twelve_and_a_half_million():
     all), every one a full product context through the C-ABI, the exchange over the test transport (RCCL refuses two ranks on a
     device). 6 frames behind a camera that turns and cuts: every rank must hold every owner's WHOLE list in every frame — about
     2.6 M entries per rank, 2 * 10^7 gathered per frame, tails of millions of words on the cut. Needs ~15 GB of host memory for the
-    eight scenes (the GPU boxes have terabytes); ~30 s."""
+    eight scenes (the GPU boxes have terabytes); ~30 s. --check-oracle: on frame 0 and on the cut every rank also runs the CPU
+    oracle over its own 12.5 M entities and compares its own list with it; with every rank holding every owner's whole list, the
+    union over the ranks is the oracle's visible set of the 10^8-entity world."""
     out = _exchange_ranks(8, 12_500_000, env={"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")},
-                          extra=["--frames", "6"])
+                          extra=["--frames", "6", "--check-oracle"])
     assert out["ranks"] == 8 and out["mismatches"] == 0 and out["timed_out_ranks"] == 0, out
+    assert out["oracle_checked_frames"] >= 2, out
     assert out["gathered_last_frame"] > 10_000_000 and out["short_rows_completed"] >= 1 and out["tail_words"] > 1_000_000, out
