@@ -20,6 +20,9 @@
 // R > 1 needs R GPUs with RCCL (it refuses two ranks on one device); with GV_RCCL_LIBRARY=<tests/cpp/build/librccl_stub.so>
 // the ranks share the GPUs there are (ranks are dealt round-robin over them) and the rows travel through shared memory.
 // "auto": min(GPUs, 8) ranks.
+// --batched: every frame culls TWO views (the camera, and the camera turned by a quarter) and sends both lists in ONE exchange
+// (gv_exchange_views: row = [2 + total, c_0, c_1, list 0, list 1]) — the per-rank form of what the drop-in's one-process mode does
+// with gv_exchange_views_all; same checks: every rank holds every owner's whole row in every frame.
 // --check-oracle: on frame 0 and on the frame of the camera cut every rank ALSO runs the CPU oracle (oracle/gv_oracle.c:
 // gvo_prepare_meshes_range, mesh.cpp:111-184) over its own share and compares its own list with the oracle's as a set; the parent
 // already proves that every rank holds every owner's whole list, so union over the ranks == the oracle's visible set of the
@@ -168,7 +171,7 @@ std::vector<uint32_t> oracle_visible(std::vector<Transform>& tr, std::vector<Mes
 }
 
 int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, bool check_oracle,
-             int id_in, int id_out, Shared* shared)
+             bool batched, int id_in, int id_out, Shared* shared)
 {
     auto die = [&](const char* what, GvCtx* ctx) {
         fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
@@ -238,13 +241,27 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
         return 1;
     if (stall_rank >= 0 && gv_exchange_set_timeout(ctx, 2000) != GV_OK)
         return die("gv_exchange_set_timeout", ctx);
-    const int sized_frames = stall_rank >= 0 ? frames : frames - 2;  // the last two frames: gv_exchange_shards with per-rank capacities
+    const int sized_frames = stall_rank >= 0 || batched ? frames : frames - 2;  // the last two frames: gv_exchange_shards with per-rank capacities
     // this rank's own list of a frame, summarised when the frame is culled (a frame acquired late is compared with it then)
     auto summarise_own = [&](FrameSummary& fs) {
         GvResult res{};
         if (gv_results_fetch(ctx, 0, 0, &res) != GV_OK)
             return false;
-        fs.own = summarise(res.visible_idx, res.draw_count, res.draw_count, base);
+        if (!batched) {
+            fs.own = summarise(res.visible_idx, res.draw_count, res.draw_count, base);
+            return true;
+        }
+        // the row this rank's two lists make: [c_0, c_1, list 0 + base, list 1 + base] behind the header
+        std::vector<uint32_t> row{res.draw_count, 0u};
+        for (uint32_t k = 0; k < res.draw_count; k++)
+            row.push_back(res.visible_idx[k] + base);
+        GvResult second{};
+        if (gv_results_fetch(ctx, 1, 0, &second) != GV_OK)
+            return false;
+        row[1] = second.draw_count;
+        for (uint32_t k = 0; k < second.draw_count; k++)
+            row.push_back(second.visible_idx[k] + base);
+        fs.own = summarise(row.data(), row.size(), row.size(), 0);
         return true;
     };
     // every row of an acquired frame, read back: whole lists (the library's frames), or up to the caller's capacity
@@ -262,7 +279,11 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
                 fprintf(stderr, "rank %d frame %d: row %d holds %llu entries in %zu words\n", rank, frame, r, (unsigned long long)fs.rows[r].delivered, row_words);
                 return false;
             }
-            for (uint64_t k = 0; k < fs.rows[r].delivered; k++)
+            if (batched && (row[0] < 2 || row[0] != 2u + row[1] + row[2])) {
+                fprintf(stderr, "rank %d frame %d: row %d's header %u is not its table (%u, %u) plus 2\n", rank, frame, r, row[0], row[1], row[2]);
+                return false;
+            }
+            for (uint64_t k = batched ? 2 : 0; k < fs.rows[r].delivered; k++)
                 if (row[1 + k] < (uint32_t)r * n || row[1 + k] >= (uint32_t)(r + 1) * n) {
                     fprintf(stderr, "rank %d frame %d: row %d entry %llu = %u outside its owner's range\n", rank, frame, r,
                             (unsigned long long)k, row[1 + k]);
@@ -281,7 +302,8 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
         }
         if (rc != GV_OK)
             return rc;
-        if (!got.complete || !got.gathered_device || !got.ready_event || got.frame != (uint64_t)frame || got.row_words % 4u) {
+        if (!got.complete || !got.gathered_device || !got.ready_event || got.frame != (uint64_t)frame || got.row_words % 4u ||
+            got.items != (batched ? 2u : 0u) || (batched && !got.item_counts)) {
             fprintf(stderr, "rank %d frame %d: fields of an acquired frame\n", rank, frame);
             return (int)GV_E_STATE;
         }
@@ -322,7 +344,14 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
             make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &view);
         }
         const uint32_t mode = mode_arg >= 0 ? (uint32_t)mode_arg : (uint32_t)(frame % 3);
-        if (gv_exchange_set_mode(ctx, mode) != GV_OK || gv_cull(ctx, 0, &view, 1) != GV_OK)
+        GvView both[2] = {view, view};
+        if (batched) {  // the second list: the same lens turned by a quarter
+            if (camera_seed)
+                make_view(1.5707963f + 0.37f * (float)frame, &both[1]);
+            else
+                make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f) + 1.5707963f, &both[1]);
+        }
+        if (gv_exchange_set_mode(ctx, mode) != GV_OK || gv_cull(ctx, 0, both, batched ? 2 : 1) != GV_OK)
             return die("cull", ctx);
         FrameSummary& fs = shared->frames[rank][frame];
         fs.mode = mode;
@@ -345,7 +374,8 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
         if (frame < sized_frames) {
             fs.sized_by_library = 1;
             GvExchangeFrame xf;
-            const int rc = gv_exchange_visible(ctx, 0, base, 0, &xf);
+            const GvExchangeItem items[2] = {{0u, 0u, base}, {0u, 1u, base}};
+            const int rc = batched ? gv_exchange_views(ctx, items, 2, 0, &xf) : gv_exchange_visible(ctx, 0, base, 0, &xf);
             if (rc == GV_E_TIMEOUT || (rc == GV_E_RCCL && stall_rank >= 0)) {
                 fs.timed_out = rc == GV_E_TIMEOUT ? 1 : 2;
                 timed_out = true;
@@ -439,7 +469,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
-    bool abandon = false, abandon_by_destroy = false, check_oracle = false;
+    bool abandon = false, abandon_by_destroy = false, check_oracle = false, batched = false;
     uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
@@ -457,6 +487,8 @@ int main(int argc, char** argv)
             camera_seed = (uint32_t)atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--stall-rank") && i + 1 < argc) {
             stall_rank = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--batched")) {
+            batched = true;
         } else if (!strcmp(argv[i], "--check-oracle")) {
             check_oracle = true;
         } else if (!strcmp(argv[i], "--abandon")) {
@@ -501,7 +533,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();  // before any HIP call in this process
         if (pid == 0)
-            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, abandon_by_destroy, camera_seed, check_oracle, to_child[2 * r], to_parent[2 * r + 1], shared));
+            _exit(run_rank(r, ranks, n, frames, mode, stall_rank, abandon, abandon_by_destroy, camera_seed, check_oracle, batched, to_child[2 * r], to_parent[2 * r + 1], shared));
         pids.push_back(pid);
     }
     unsigned char id[GV_EXCHANGE_ID_BYTES];

@@ -290,6 +290,20 @@ def test_shutdown_behind_a_frame_a_stalled_peer_never_joined_is_bounded_too():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_native_batched_exchange_one_frame_carries_two_lists(ranks):
+    """gv_exchange_views, one process per rank (the per-rank form of the drop-in's one exchange per frame): every frame culls two
+    views and sends both lists in ONE exchange — row = [2 + total, c_0, c_1, list 0, list 1] — through the test transport's device
+    form; a camera that turns and cuts (short predictions completed by a second exchange) and a random-lens camera. exchange_ranks
+    fails unless every rank holds every owner's whole row — table and both lists — in every frame."""
+    env = {"GV_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")}
+    out = _exchange_ranks(ranks, 60000, env=env, extra=["--batched", "--frames", "12"])
+    assert out["ranks"] == ranks and out["mismatches"] == 0 and out["short_rows_completed"] >= 1, out
+    out = _exchange_ranks(ranks, 60000, env=env, extra=["--batched", "--frames", "16", "--random-camera", "7", "--check-oracle"])
+    assert out["ranks"] == ranks and out["mismatches"] == 0 and out["oracle_checked_frames"] >= 2, out
+
+
+@pytest.mark.gpu
 def test_cfg5_in_its_shape_eight_ranks_of_twelve_and_a_half_million():
     """BASELINE.json configs[4] (cfg5) is 10^8 entities over 8 ranks with an all-gatherv of the visible lists. No 8-GPU node is
     available to the test tier, so the SHAPE runs on the one GPU there is: 8 rank processes of 12.5 M entities each (10^8 in
