@@ -810,7 +810,10 @@ private:
                     checkRank(r, gv_mark_dirty(contexts[r], GV_DIRTY_MESH, p << 28, mesh.occupancy()), "gv_mark_dirty");
                     continue;
                 }
-                for (const auto& run : RankShares::Changes::runs(changed.maps[p]))
+                auto mapRuns = RankShares::Changes::runs(changed.maps[p]);
+                if (mapRuns.size() > 4)  // (every call ends in a synchronisation: many scattered entries travel as the one span that holds them)
+                    mapRuns = {{mapRuns.front().first, mapRuns.back().first + mapRuns.back().second - mapRuns.front().first}};
+                for (const auto& run : mapRuns)
                     checkRank(r, gv_pool_update_index_map(contexts[r], p, run.first, mesh.worldSlot.data() + run.first, run.second), "gv_pool_update_index_map");
                 rankCounters.editedMeshes += changed.meshes[p].size();
                 for (const auto& run : RankShares::Changes::runs(changed.meshes[p]))
@@ -874,24 +877,69 @@ public:
     double exchangeModeProbeMs[3] = {0, 0, 0};  // probeExchangeMode: milliseconds per exchange by GvExchangeMode (0: not probed)
     uint32_t exchangeMode = GV_EXCHANGE_ALLGATHER;
 
-private:
+    // (public for tests/cpp/rank_shares_test.cpp: the merge is checked on the CPU against std::sort)
     // The ranks' runs of one list -> dst[0, total): each rank's records arrive in sortMeshes order (gv_pool_sort), so one pass that
     // always takes the smallest head (operator< of the record: ascending distanceSq for unsorted buffers, descending for sorted
     // ones, mesh.hpp:196,204) leaves the whole list in that order; not ordered (OIT, or the engine sorts itself): the runs back to back.
-    template <class Mesh>
-    static void mergeRanks(Mesh* dst, const Mesh* const* runs, const uint32_t* counts, uint32_t ranks, bool ordered)
+    // Long lists are merged on the library's worker threads: every worker takes a piece [a, b) of the OUTPUT, finds where that piece
+    // begins and ends in every run (splitRuns) and merges its sub-runs — the pieces are independent.
+    static uint32_t orderKey(float distanceSq, bool descending) noexcept  // monotone in the records' order
     {
-        if (!ordered) {
+        uint32_t u;
+        memcpy(&u, &distanceSq, 4);
+        u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+        return descending ? ~u : u;
+    }
+    // cuts[r]: how many records of run r lie in front of output position `position` (sum of cuts == position; records with equal keys
+    // are taken run by run, so that two positions always give nested cuts)
+    template <class Mesh>
+    static void splitRuns(const Mesh* const* runs, const uint32_t* counts, uint32_t ranks, uint64_t position, uint32_t* cuts)
+    {
+        constexpr bool descending = std::is_same<Mesh, SortedMesh>::value;
+        auto inFront = [&](uint32_t key, bool orEqual, uint32_t* out) {  // per run: records whose key is < key (<= key)
+            uint64_t total = 0;
             for (uint32_t r = 0; r < ranks; r++) {
-                memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[r]), (size_t)counts[r] * sizeof(Mesh));
-                dst += counts[r];
+                uint32_t lo = 0, hi = counts[r];
+                while (lo < hi) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    const uint32_t k = orderKey(runs[r][mid].distanceSq, descending);
+                    if (k < key || (orEqual && k == key))
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                out[r] = lo;
+                total += lo;
             }
-            return;
+            return total;
+        };
+        uint32_t scratch[GV_EXCHANGE_MAX_RANKS];
+        uint32_t lo = 0, hi = 0xFFFFFFFFu;  // the smallest key with at least `position` records at or in front of it
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (inFront(mid, true, scratch) >= position)
+                hi = mid;
+            else
+                lo = mid + 1;
         }
-        uint32_t at[GV_EXCHANGE_MAX_RANKS] = {}, live[GV_EXCHANGE_MAX_RANKS], n = 0;
-        for (uint32_t r = 0; r < ranks; r++)
-            if (counts[r])
+        uint32_t upTo[GV_EXCHANGE_MAX_RANKS];
+        inFront(lo, true, upTo);
+        uint64_t left = position - std::min<uint64_t>(position, inFront(lo, false, cuts));
+        for (uint32_t r = 0; r < ranks; r++) {  // the records with exactly that key: run by run
+            const uint32_t take = (uint32_t)std::min<uint64_t>(left, upTo[r] - cuts[r]);
+            cuts[r] += take;
+            left -= take;
+        }
+    }
+    template <class Mesh>
+    static void mergePiece(Mesh* dst, const Mesh* const* runs, const uint32_t* from, const uint32_t* to, uint32_t ranks)
+    {
+        uint32_t at[GV_EXCHANGE_MAX_RANKS], live[GV_EXCHANGE_MAX_RANKS], n = 0;
+        for (uint32_t r = 0; r < ranks; r++) {
+            at[r] = from[r];
+            if (from[r] < to[r])
                 live[n++] = r;
+        }
         while (n > 1) {
             uint32_t best = 0;
             for (uint32_t k = 1; k < n; k++)
@@ -899,13 +947,46 @@ private:
                     best = k;
             const uint32_t r = live[best];
             memcpy(static_cast<void*>(dst++), static_cast<const void*>(runs[r] + at[r]), sizeof(Mesh));
-            if (++at[r] == counts[r])
+            if (++at[r] == to[r])
                 live[best] = live[--n];
         }
         if (n == 1)
-            memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[live[0]] + at[live[0]]), (size_t)(counts[live[0]] - at[live[0]]) * sizeof(Mesh));
+            memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[live[0]] + at[live[0]]), (size_t)(to[live[0]] - at[live[0]]) * sizeof(Mesh));
+    }
+    template <class Mesh>
+    static void mergeRanks(Mesh* dst, const Mesh* const* runs, const uint32_t* counts, uint32_t ranks, bool ordered)
+    {
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < ranks; r++)
+            total += counts[r];
+        if (!ordered) {
+            for (uint32_t r = 0; r < ranks; r++) {
+                memcpy(static_cast<void*>(dst), static_cast<const void*>(runs[r]), (size_t)counts[r] * sizeof(Mesh));
+                dst += counts[r];
+            }
+            return;
+        }
+        struct Job {
+            Mesh* dst;
+            const Mesh* const* runs;
+            const uint32_t* counts;
+            uint32_t ranks;
+            uint64_t total;
+        } job{dst, runs, counts, ranks, total};
+        gv_host_parallel_ranges(0, (uint32_t)total, [](void* user, uint32_t a, uint32_t b) {
+            const Job& j = *static_cast<const Job*>(user);
+            uint32_t from[GV_EXCHANGE_MAX_RANKS] = {}, to[GV_EXCHANGE_MAX_RANKS];
+            if (a != 0)
+                splitRuns(j.runs, j.counts, j.ranks, a, from);
+            if (b == j.total)
+                std::copy(j.counts, j.counts + j.ranks, to);
+            else
+                splitRuns(j.runs, j.counts, j.ranks, b, to);
+            mergePiece(j.dst + a, j.runs, from, to, j.ranks);
+        }, &job);
     }
 
+private:
     // The frame with several ranks. The same classification, gate and buffers as preRender() (classifyAndGate); every rank culls (and
     // sorts) its share of every system, ALL the frame's lists are gathered on the devices by ONE exchange — the reference dispatches
     // every system's tasks and waits once (mesh.cpp:408-546, :548) — and the engine's buffers are filled from the ranks' results — a

@@ -17,7 +17,7 @@
 #include <cstring>
 #include <random>
 
-#include "../../garden_amd/csrc/host/rank_shares.hpp"
+#include "../../garden_amd/csrc/host/gpu_visibility_system.hpp"
 
 using namespace garden;
 
@@ -122,8 +122,60 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
     }
 }
 
+// GpuVisibilitySystem::mergeRanks: the ranks' sorted runs of one list -> one sorted list, long lists in pieces on the worker threads
+// (splitRuns finds where an output position falls in every run). Random runs with many equal keys, negative keys, empty runs: the
+// output is a permutation of the input in the records' order (mesh.hpp:196,204), piece boundaries included.
+template <class Mesh>
+static void checkMerge(std::mt19937& rng, uint32_t ranks, uint32_t perRank, uint32_t distinctKeys, const char* what)
+{
+    std::vector<std::vector<Mesh>> runs(ranks);
+    std::vector<const Mesh*> ptrs(ranks);
+    std::vector<uint32_t> counts(ranks);
+    size_t total = 0;
+    for (uint32_t r = 0; r < ranks; r++) {
+        const uint32_t n = (r == 1 && ranks > 2) ? 0u : perRank / 2 + rng() % (perRank + 1);
+        runs[r].resize(n);
+        for (uint32_t k = 0; k < n; k++) {
+            runs[r][k].componentOffset = ((size_t)r << 32) | k;
+            runs[r][k].distanceSq = (float)(int)(rng() % distinctKeys) * 0.25f - (distinctKeys > 8 ? 3.0f : 0.0f);
+        }
+        std::stable_sort(runs[r].begin(), runs[r].end());  // (the record's own operator<)
+        ptrs[r] = runs[r].data();
+        counts[r] = n;
+        total += n;
+    }
+    std::vector<Mesh> merged(total);
+    GpuVisibilitySystem::mergeRanks(merged.data(), ptrs.data(), counts.data(), ranks, true);
+    std::vector<uint8_t> seen(total, 0);
+    std::vector<size_t> base(ranks, 0);
+    for (uint32_t r = 1; r < ranks; r++)
+        base[r] = base[r - 1] + counts[r - 1];
+    for (size_t k = 0; k < total; k++) {
+        EXPECT(k == 0 || !(merged[k] < merged[k - 1]), "%s: record %zu is out of order", what, k);
+        const uint32_t r = (uint32_t)(merged[k].componentOffset >> 32), j = (uint32_t)merged[k].componentOffset;
+        EXPECT(r < ranks && j < counts[r] && !seen[base[r] + j], "%s: record %zu is not one of the input's, or appears twice", what, k);
+        if (r < ranks && j < counts[r])
+            seen[base[r] + j] = 1;
+    }
+    // (every input record appears: `seen` has `total` distinct hits)
+    size_t hits = 0;
+    for (uint8_t v : seen)
+        hits += v;
+    EXPECT(hits == total, "%s: %zu of %zu records arrived", what, hits, total);
+}
+
 int main()
 {
+    {
+        std::mt19937 mergeRng(99u);
+        for (uint32_t ranks : {1u, 2u, 4u, 8u}) {
+            checkMerge<UnsortedMesh>(mergeRng, ranks, 3000, 1u << 20, "short ascending runs");
+            checkMerge<SortedMesh>(mergeRng, ranks, 3000, 5, "short descending runs, five distinct keys");
+            checkMerge<UnsortedMesh>(mergeRng, ranks, 300000 / ranks, 7, "long ascending runs, seven distinct keys (pieces on the workers)");
+            checkMerge<SortedMesh>(mergeRng, ranks, 300000 / ranks, 1u << 22, "long descending runs (pieces on the workers)");
+            checkMerge<SortedMesh>(mergeRng, ranks, 300000 / ranks, 1, "long runs of ONE key");
+        }
+    }
     std::mt19937 rng(20261004u);
     auto uniform = [&](float lo, float hi) { return lo + (hi - lo) * (float)(rng() >> 8) * (1.0f / 16777216.0f); };
     for (uint32_t ranks : {1u, 2u, 3u, 8u, 4u}) {

@@ -13,7 +13,9 @@ runs=0; bad=0; frames=0; second=0; rows=0; tails=0
 for ranks in 2 3 4 8; do
   for seed in $(seq 1 $seeds); do
     for mode in all allgather p2p broadcast; do
-      line=$(timeout 300 ./tests/cpp/build/exchange_ranks --ranks $ranks --entities 40000 --frames 32 --mode $mode --random-camera $((seed * 131 + ranks)) 2>>$out.err | tail -1)
+      # (every other seed: two lists per frame in ONE exchange, gv_exchange_views)
+      batched=""; [ $((seed % 2)) = 0 ] && batched="--batched"
+      line=$(timeout 300 ./tests/cpp/build/exchange_ranks --ranks $ranks --entities 40000 --frames 32 --mode $mode --random-camera $((seed * 131 + ranks)) $batched 2>>$out.err | tail -1)
       runs=$((runs + 1))
       ok=$(echo "$line" | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(int(d['ok'] and d['mismatches']==0), d['frames'], d['frames_with_a_second_exchange'], d['short_rows_completed'], d['tail_words'])" 2>/dev/null || echo "0 0 0 0 0")
       set -- $ok
@@ -22,4 +24,4 @@ for ranks in 2 3 4 8; do
     done
   done
 done
-echo "exchange soak: $runs runs (2 / 3 / 4 / 8 ranks x $seeds random cameras x 4 travel settings, 32 frames each, 40 000 entities per rank): $bad failed; $frames frames, $second of them needed a second exchange ($rows short rows completed, $tails words in tails); every row of every frame == its owner's whole list on every rank" | tee -a $out
+echo "exchange soak: $runs runs (2 / 3 / 4 / 8 ranks x $seeds random cameras x 4 travel settings, 32 frames each, 40 000 entities per rank; every other camera with two lists per frame in one exchange): $bad failed; $frames frames, $second of them needed a second exchange ($rows short rows completed, $tails words in tails); every row of every frame == its owner's whole list on every rank" | tee -a $out

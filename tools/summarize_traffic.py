@@ -31,9 +31,9 @@ N = 10_000_000
 sys.path.insert(0, ROOT)
 import datetime  # noqa: E402
 
-from bench import kernel_source_sha  # noqa: E402  (bench.py reports traffic only while this hash still matches)
+from garden_amd.benchlib.workloads import kernel_source_sha  # noqa: E402  (bench.py reports traffic only while this hash still matches)
 
-out = {"_kernel_source_sha": kernel_source_sha(), "_collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ") + f" ({tag})",
+out = {"_kernel_source_sha": kernel_source_sha(ROOT), "_collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ") + f" ({tag})",
        "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_traffic.sh, "
        "tools/summarize_traffic.py). gfx950 FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md: 1/2 for "
        "16 B/lane; other widths uncalibrated), so the read side is calibrated on this kernel's own access pattern: the "
@@ -41,7 +41,7 @@ out = {"_kernel_source_sha": kernel_source_sha(), "_collected": datetime.datetim
        "word per wave) -> factor = known bytes / (FETCH_SIZE KB * 1024); WRITE_SIZE taken as reported (KB * 1024). Per "
        "launch of gv::cull_kernel. The factor is applied to all reads of cfg3 too, which over-counts its 8-byte Hi-Z "
        "texel gathers (narrow reads are reported closer to 1:1): cfg3's figure is an upper bound."}
-PLAIN, BOUNDED = "false>(gv::CullArgs)", "gv::cull_list_kernel"  # cull_kernel<HIZ, MAP, BOUNDS = false>; the bounded path's per-entity kernel (round 3: the kept-block list form)
+PLAIN, BOUNDED = "gv::cull_kernel<", "gv::cull_list_kernel"  # cull_kernel<HIZ, MAP>; the bounded path's per-entity kernel (the kept-block list form)
 f2, n2 = counter_mean("cfg2", "FETCH_SIZE", PLAIN)
 w2, _ = counter_mean("cfg2", "WRITE_SIZE", PLAIN)
 known = N * 65 + N / 64 * 8

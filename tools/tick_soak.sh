@@ -1,9 +1,10 @@
 #!/bin/bash
 # GPU box: the headless tick driver (CPU reference-path system vs the GPU drop-in, every buffer compared every tick) over many
 # seeds and flag combinations — the mirror's maintenance paths under entity churn, re-parenting, toggles, moving scenes.
-# Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
+# Round 6: the multi-GPU mode kept current slot by slot (--unversioned: mesh systems without change counters; --animate-step: roots
+# that cross cells take their trees to another rank). Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
 # against the reference text; --skip-pass: a shadow pass left out by prepareShadowRender) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
-#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 22 flag sets)
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 27 flag sets)
 set -u
 cd "$(dirname "$0")/.."
 make -s -C tests/cpp
@@ -30,6 +31,11 @@ sets=(
   "--entities 20000 --ranks 3 --mixed --hier --animate 5 --itemised --ticks 4"
   "--entities 24000 --ranks 8 --mixed --csm --churn 2"
   "--entities 12000 --ranks 2 --mixed --gate shadow --toggle --hier"
+  "--entities 24000 --ranks 3 --mixed --unversioned --hier --mutate --churn 2"
+  "--entities 20000 --ranks 4 --mixed --csm --unversioned --animate 3 --ticks 5"
+  "--entities 16000 --ranks 4 --hier --animate 2 --animate-step 170 --itemised --ticks 7"
+  "--entities 16000 --ranks 2 --hier --mixed --animate 3 --animate-step 230 --ticks 5 --churn 2"
+  "--entities 20000 --ranks 3 --hiz --mixed --csm --unversioned --toggle --hier"
   "--entities 20000 --mixed --csm --gate shadow --skip-pass 1 --churn 3"
   "--entities 16000 --mixed --gate reverse --skip-pass 0 --hier --mutate"
 )
