@@ -12,7 +12,7 @@ elif [ "$what" = tier ]; then
   python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/r06/gpu_tests.txt
   python3 bench.py > gpurun_out/r06/default_bench_line.json 2> gpurun_out/r06/default.err; tail -c 300 gpurun_out/r06/default.err; cut -c1-600 gpurun_out/r06/default_bench_line.json
   bash tools/tick_ranks.sh after > /dev/null 2>&1; grep -E "^##|prepare us|^ranks" gpurun_out/tick_ranks_after.txt
-else
+elif [ "$what" = evidence ]; then
   # the line an 8-GPU run prints, with 8 ranks SHARING this box's one GPU (torch over gloo, the library's exchange over the tests'
   # shared-memory transport): functional, never a measurement — the probe of the travel patterns, the choice, parity on all ranks
   GV_BENCH_BACKEND=gloo timeout 1500 python3 bench.py --gpus 8 --entities 1500000 --steps 10 --warmup 2 > gpurun_out/r06/gloo8_sample_line.json 2> gpurun_out/r06/gloo8.err
@@ -28,4 +28,9 @@ print("mode variants", {k: v.get("ms_per_step") for k, v in (c["exchange_mode_va
 print("parity", {k: d["parity"][k] for k in ("visible_set_bit_identical", "is_visible_identical", "baked_model_bit_identical", "checked_ranks")})
 PY
   bash tools/collect_traffic.sh > gpurun_out/r06/collect_traffic.log 2>&1; tail -3 gpurun_out/r06/collect_traffic.log
+fi
+if [ "$what" = soak ]; then
+  bash tools/tick_soak.sh ${2:-8} 2>&1 | tail -12 | tee gpurun_out/r06/tick_soak.txt
+  bash tools/exchange_soak.sh ${3:-4} 2>&1 | tail -3 | tee gpurun_out/r06/exchange_soak.txt
+  bash tools/stress_round.sh > /dev/null 2>&1; cp gpurun_out/r06_stress_parity.txt gpurun_out/r06/stress_parity.txt; tail -12 gpurun_out/r06/stress_parity.txt
 fi
