@@ -526,7 +526,10 @@ class GpuVisibility:
         return dict(ptr=f.gathered_device, row_words=f.row_words, world=w, frame=int(f.frame), complete=bool(f.complete),
                     room=[int(f.room[r]) for r in range(w)], travelled_words=[int(f.travelled_words[r]) for r in range(w)],
                     counts=[int(f.counts[r]) for r in range(w)], tail_words=[int(f.tail_words[r]) for r in range(w)],
-                    cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1], mode=int(f.mode), ready_event=f.ready_event)
+                    cut_ranks=[r for r in range(w) if (f.cut_ranks >> r) & 1], mode=int(f.mode), ready_event=f.ready_event,
+                    # gv_exchange_views: lists per rank in the frame (0: a single-list frame) and, once acquired, item_counts[r][i]
+                    items=int(f.items), item_counts=([[int(f.item_counts[r * f.items + i]) for i in range(f.items)] for r in range(w)]
+                                                     if f.items and f.item_counts else None))
 
     def exchange_visible(self, view_index=0, index_base=0, pool_id=None):
         """Sends the frame (gv_exchange_visible; pool_id: gv_pool_exchange_visible for a named pool): library-owned rows, sized from
@@ -538,6 +541,25 @@ class GpuVisibility:
         else:
             self._check(self.lib.gv_pool_exchange_visible(self.ctx, pool_id, view_index, index_base, 0, C.byref(f)))
         return self._exchange_frame(f)
+
+    def exchange_views(self, items):
+        """ONE exchange for ALL the lists of a frame (gv_exchange_views): items = [(pool_id, view_index, index_base), ...], the same
+        list on every rank. Row r of the acquired frame = [len(items) + total, c_0 .. c_k, list 0, list 1 ...]."""
+        arr = (GvExchangeItem * len(items))(*[GvExchangeItem(int(p), int(v), int(b)) for p, v, b in items])
+        f = GvExchangeFrame()
+        self._check(self.lib.gv_exchange_views(self.ctx, arr, len(items), 0, C.byref(f)))
+        return self._exchange_frame(f)
+
+    def update_index_map(self, pool_id, first, global_ids):
+        ids = np.ascontiguousarray(global_ids, dtype=np.uint32)
+        self._check(self.lib.gv_pool_update_index_map(self.ctx, pool_id, int(first), ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.shape[0]))
+
+    def set_result_mapping(self, pool_id, flags, visible=None, stride=1):
+        """gv_pool_set_result_mapping: records in world slots (GV_RESULTS_MAP_RECORDS) and / or the write-back of isVisible through the
+        index map into `visible` (a uint8 array the caller keeps alive; element i at visible + i * stride)."""
+        base = visible.ctypes.data if visible is not None else None
+        count = (visible.nbytes // stride) if visible is not None else 0
+        self._check(self.lib.gv_pool_set_result_mapping(self.ctx, pool_id, int(flags), base, int(stride), int(count)))
 
     def exchange_acquire(self, frame):
         """Frame `frame` complete — every rank's WHOLE list, short predictions made good by a second exchange — and the context's

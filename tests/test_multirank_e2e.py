@@ -21,6 +21,7 @@ import json, os, sys, time
 import numpy as np
 sys.path.insert(0, {root!r})
 rank, world, n, frames, tmp, how, pattern = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6], sys.argv[7]
+batched = len(sys.argv) > 8 and sys.argv[8] == "batched"  # two views per frame, both lists in ONE exchange (gv_exchange_views)
 import torch
 from garden_amd import scene
 from garden_amd.lib import GpuVisibility
@@ -70,7 +71,7 @@ with GpuVisibility(device=rank % devices) as vis:
         pass
 
     report = []
-    views, sent = {{}}, {{}}
+    views, views2, sent = {{}}, {{}}, {{}}
 
     def check(frame):
         f = vis.exchange_acquire(frame)
@@ -80,14 +81,24 @@ with GpuVisibility(device=rank % devices) as vis:
         rows = torch.as_tensor(span, device="cuda:%d" % (rank % devices)).cpu().numpy().view(np.uint32).reshape(world, f["row_words"])
         world_result = oracle_py.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, views[frame], threads=2)
         exp = np.sort(world_result["visible_idx"].astype(np.int64))
-        got = []
+        got, got2 = [], []
         for r in range(world):
             c = int(rows[r, 0])
             assert c == f["counts"][r] and c + 1 <= f["row_words"]
-            got.append(rows[r, 1:1 + c].astype(np.int64))
+            if batched:  # row = [2 + total, c_0, c_1, list 0, list 1]
+                c0, c1 = int(rows[r, 1]), int(rows[r, 2])
+                assert f["items"] == 2 and c == 2 + c0 + c1 and f["item_counts"][r] == [c0, c1]
+                got.append(rows[r, 3:3 + c0].astype(np.int64))
+                got2.append(rows[r, 3 + c0:3 + c0 + c1].astype(np.int64))
+            else:
+                got.append(rows[r, 1:1 + c].astype(np.int64))
         union = np.sort(np.concatenate(got))
         # the reference's gather never loses a record (mesh.cpp:177-183): the union of the rows IS the world's visible set
         ok = bool(f["complete"] and np.array_equal(union, exp))
+        if batched:  # ... of BOTH views
+            second = oracle_py.prepare_meshes(sc.meshes.copy(), sc.transforms, sc.entity_to_transform, views2[frame], threads=2)
+            ok = ok and bool(np.array_equal(np.sort(np.concatenate(got2)), np.sort(second["visible_idx"].astype(np.int64))))
+            exp = np.concatenate([exp, second["visible_idx"].astype(np.int64), np.zeros(2 * world, dtype=np.int64)])  # (a row's count includes its table's two words)
         report.append(dict(frame=frame, complete=f["complete"], cut=f["cut_ranks"], tails=f["tail_words"], ok=ok, visible=int(exp.shape[0]),
                            counts=f["counts"], room=sent[frame]["room"], mine=int(f["counts"][rank]), mode=f["mode"], pattern=pattern))
 
@@ -99,8 +110,13 @@ with GpuVisibility(device=rank % devices) as vis:
         corner = (0.47 * side, 0.47 * side, 0.47 * side) if frame < frames // 2 else (0.0, 0.0, 0.0)
         views[frame] = scene.main_camera_view(seed=seed, camera_position=corner)
         vis.exchange_set_mode(frame % 3 if pattern == "turns" else {{"allgather": 0, "p2p": 1, "broadcast": 2}}[pattern])
-        vis.cull(0, [views[frame]])
-        sent[frame] = vis.exchange_visible(0, index_base=0)
+        if batched:  # a second camera that looks elsewhere (a shadow cascade would be the engine's second view), same cut
+            views2[frame] = scene.main_camera_view(seed=seed + 31, camera_position=corner)
+            vis.cull(0, [views[frame], views2[frame]])
+            sent[frame] = vis.exchange_views([(0, 0, 0), (0, 1, 0)])
+        else:
+            vis.cull(0, [views[frame]])
+            sent[frame] = vis.exchange_visible(0, index_base=0)
         assert not sent[frame]["complete"] and sent[frame]["ptr"] is None
         if late is not None:       # the previous frame, acquired only now: this frame's send has completed it already
             check(late)
@@ -123,6 +139,15 @@ def test_one_world_dealt_to_rank_processes_culled_and_exchanged_in_world_slots(t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,how,pattern", [(2, "python", "turns"), (3, "native", "p2p"), (8, "python", "allgather")])
+def test_two_views_per_frame_travel_in_one_exchange(tmp_path, world, how, pattern):
+    """gv_exchange_views with one process per rank: every frame culls two views and sends both lists in ONE exchange; on every rank
+    and in every frame — the cut included — the union of the gathered first lists == the oracle's visible set of the WHOLE world for
+    the first view, and the union of the second lists == the oracle's for the second."""
+    _deal_cull_exchange(tmp_path, world, how, pattern, 120_000, 8, 2, extra=["batched"])
+
+
+@pytest.mark.gpu
 def test_a_ten_million_entity_world_dealt_to_eight_rank_processes(tmp_path):
     """The same chain at BASELINE's 10^7: one hierarchy world (trees of 43) cut into 8 ranks' shares by the cell rule, every rank a
     process with its own context, four frames with the cut to the centre in the middle, the travel pattern turning — on every rank
@@ -130,12 +155,12 @@ def test_a_ten_million_entity_world_dealt_to_eight_rank_processes(tmp_path):
     _deal_cull_exchange(tmp_path, 8, "python", "turns", 10_000_000, 4, 2)
 
 
-def _deal_cull_exchange(tmp_path, world, how, pattern, n, frames, min_completed):
+def _deal_cull_exchange(tmp_path, world, how, pattern, n, frames, min_completed, extra=()):
     stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
     script = tmp_path / "rank.py"
     script.write_text(WORKER.format(root=ROOT))
     env = dict(os.environ, GV_RCCL_LIBRARY=stub)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path), how, pattern], env=env,
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(n), str(frames), str(tmp_path), how, pattern, *extra], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=1500) for p in procs]
     for p, (out, err) in zip(procs, outs):
