@@ -51,12 +51,10 @@ private:
     RankShares rankShares;
     uint32_t rankGrid[3] = {1, 1, 1};
     double worldSide = 0.0;
-    struct RanksSeen {  // what the shares were dealt from: entities / components that came or went, or a parent link that moved, re-deal
+    struct RanksSeen {  // what the shares have followed so far (unitemised changes — hierarchyVersion, another set of systems — deal again)
         uint64_t hierarchy = ~0ull, reparent = ~0ull;
-        uint32_t transformOccupancy = ~0u, transformCount = ~0u;
         std::vector<IMeshRenderSystem*> meshSystems;
         std::vector<uint64_t> meshVersion;  // VersionedMeshSystem::meshVersion ("the whole pool may have changed": compared slot by slot)
-        std::vector<uint32_t> meshOccupancy, meshCount;
     } ranksSeen;
     RankShares::Changes rankChanges;
     bool exchangeModeChosen = false;
@@ -708,31 +706,22 @@ private:
     }
 
     // Brings every rank's share up to date with the engine's pools and tells the ranks what changed (rank_shares.hpp). The pools are
-    // dealt again only when entities or components came or went or a parent link moved; a mesh system that cannot say what changed
-    // (the reference's have no counters) is compared with the ranks' copies instead of being dealt again.
+    // dealt ONCE; entities and components that come or go, parent links that move, edits and moves are followed slot by slot; a mesh
+    // system that cannot say what changed (the reference's have no counters) is compared with the ranks' copies. Dealt again only
+    // for changes nobody itemised (hierarchyVersion), another set of mesh systems, or something followEntities cannot follow.
     void syncRanks(TransformSystem* transformSystem)
     {
         const uint32_t ranks = (uint32_t)contexts.size();
         auto& pool = transformSystem->getComponents();
-        bool structural = ranksSeen.hierarchy != transformSystem->hierarchyVersion || ranksSeen.reparent != transformSystem->reparentVersion ||
-                          ranksSeen.transformOccupancy != pool.getOccupancy() || ranksSeen.transformCount != pool.getCount() ||
-                          ranksSeen.meshSystems != meshSystems;
+        // dealt: once, and again only for changes nobody itemised (hierarchyVersion) or another set of mesh systems
+        bool structural = rankShares.shares.size() != ranks || ranksSeen.hierarchy != transformSystem->hierarchyVersion || ranksSeen.meshSystems != meshSystems;
         ranksSeen.meshVersion.resize(meshSystems.size(), ~0ull);
-        ranksSeen.meshOccupancy.resize(meshSystems.size(), ~0u);
-        ranksSeen.meshCount.resize(meshSystems.size(), ~0u);
-        for (size_t p = 0; p < meshSystems.size(); p++) {
-            const auto& meshPool = meshSystems[p]->getMeshComponentPool();
-            structural = structural || ranksSeen.meshOccupancy[p] != meshPool.getOccupancy() || ranksSeen.meshCount[p] != meshPool.getCount();
-        }
-        // a slot that was freed and handed to another entity since the deal (same occupancy, same count) is structural too
-        if (!structural && seenFlags != transformSystem->flagsVersion)
-            for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi && !structural; i++)
-                structural = !rankShares.sameEntity(transformSystem, i);
         rankChanges.reset(ranks, meshSystems.size());
-        // mesh components: the slots a system names, or — no counters, or "the whole pool may have changed" — every slot, compared
-        // with the ranks' copies in the bytes the cull reads (a slot that changed hands: deal again)
         if (!structural) {
+            // Mesh components: the slots a system names, or — no counters, or "the whole pool may have changed" — every slot, compared
+            // with the ranks' copies in the bytes the cull reads; a slot that holds another entity than the shares know is listed
             std::vector<RankShares::MeshPiece> pieces;
+            std::vector<std::vector<uint32_t>> changedHands(meshSystems.size());
             for (size_t p = 0; p < meshSystems.size(); p++) {
                 auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p]);
                 const uint32_t occupancy = meshSystems[p]->getMeshComponentPool().getOccupancy();
@@ -742,8 +731,27 @@ private:
                     hi = std::min(versioned->meshHi, occupancy);
                 }
                 pieces.push_back(RankShares::MeshPiece{(uint32_t)p, lo, hi, meshSystems[p]});
+                for (uint32_t j = (uint32_t)rankShares.meshTables[p].entity.size(); j < occupancy; j++)
+                    changedHands[p].push_back(j);  // slots the pool has grown by
             }
-            structural = !rankShares.syncMeshes(pieces, rankChanges);
+            (void)rankShares.syncMeshes(pieces, rankChanges, &changedHands);
+            // Entities and components that came or went, parent links that moved: followed slot by slot (rank_shares.hpp followEntities)
+            std::vector<uint32_t> transformSlots;
+            if (seenFlags != transformSystem->flagsVersion)  // (entities created / destroyed, setActive: the slots they touched)
+                for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
+                    transformSlots.push_back(i);
+            const bool relinked = ranksSeen.reparent != transformSystem->reparentVersion;
+            if (relinked)
+                for (uint32_t i = transformSystem->reparentLo; i < transformSystem->reparentHi; i++)
+                    transformSlots.push_back(i);
+            for (uint32_t i = (uint32_t)rankShares.rankOfTransform.size(); i < pool.getOccupancy(); i++)
+                transformSlots.push_back(i);
+            bool anything = !transformSlots.empty();
+            for (const auto& slots : changedHands)
+                anything = anything || !slots.empty();
+            if (anything)
+                structural = !rankShares.followEntities(transformSystem, meshSystems, ranks, rankGrid, worldSide, std::move(transformSlots), changedHands,
+                                                        relinked ? transformSystem->reparentLo : 0u, relinked ? transformSystem->reparentHi : 0u, rankChanges);
         }
         std::vector<uint32_t> moved;
         bool everything = false;
@@ -758,9 +766,6 @@ private:
                         rankShares.syncTransform(transformSystem, range.first + i, rankChanges);
                         moved.push_back(range.first + i);
                     }
-                if (seenFlags != transformSystem->flagsVersion)
-                    for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
-                        rankShares.syncTransform(transformSystem, i, rankChanges);
                 rankCounters.copiedTransforms += moved.size();
             }
             if (rebinMovedRoots && (everything || !moved.empty()))
@@ -775,13 +780,8 @@ private:
         rankCounters.movedTransforms += rankChanges.movedTransforms;
         ranksSeen.hierarchy = transformSystem->hierarchyVersion;
         ranksSeen.reparent = transformSystem->reparentVersion;
-        ranksSeen.transformOccupancy = pool.getOccupancy();
-        ranksSeen.transformCount = pool.getCount();
         ranksSeen.meshSystems = meshSystems;
         for (size_t p = 0; p < meshSystems.size(); p++) {
-            const auto& meshPool = meshSystems[p]->getMeshComponentPool();
-            ranksSeen.meshOccupancy[p] = meshPool.getOccupancy();
-            ranksSeen.meshCount[p] = meshPool.getCount();
             if (auto versioned = dynamic_cast<VersionedMeshSystem*>(meshSystems[p])) {
                 ranksSeen.meshVersion[p] = versioned->meshVersion;
                 versioned->clearMeshRange();

@@ -14,15 +14,18 @@
 // pool lives on exactly one rank — free slots and meshes without a transform included: the light pass writes isVisible of ALL of
 // them (mesh.cpp:140-153).
 //
-// Frame to frame (round 6): deal() runs when entities or components came or went or a parent link moved. Everything else is
-// carried over slot by slot — the tables below say where every world slot lives:
+// Frame to frame (round 6): deal() runs once — and again only for changes nobody itemised (hierarchyVersion, another set of mesh
+// systems). Everything else is carried over slot by slot — the tables below say where every world slot lives:
 //   * a transform that moved / changed its flags: copied to its rank (copyTransform);
 //   * a mesh component that was edited — or, for a mesh system that cannot say what changed (every one of the reference's:
 //     sprite.cpp, 9-slice, label.cpp, instance.cpp carry no counter), whichever slots turn out to differ from the rank's copy in the
 //     bytes the cull reads (entity, isEnabled, aabb: syncMeshes compares them on the worker threads): copied to its rank;
 //   * a ROOT whose position crossed into a cell of another rank (SURVEY.md §8e "re-bin only roots whose position crosses a cell";
 //     physics writes positions every tick, source/system/physics.cpp:1033-1034): its tree's transforms and their meshes move from
-//     one share to the other (moveTree) — holes are left behind and reused, nothing else is touched.
+//     one share to the other (moveTree) — holes are left behind and reused, nothing else is touched;
+//   * entities and components that came or went, parent links that moved (followEntities): a transform that went leaves a hole in its
+//     share, one that came takes a hole (or a new slot) on its parent's rank — a root: on the rank its position falls to —, a mesh
+//     component follows its entity's transform, a subtree whose new parent lives on another rank moves there (moveTree).
 // What changed where is recorded per rank (Changes) in the units gv_mark_dirty / gv_pool_update_index_map take.
 #pragma once
 #include <algorithm>
@@ -60,11 +63,85 @@ struct RankShares {
     std::vector<uint32_t> rankOfTransform, localOfTransform;  // world transform slot -> rank, local slot (GV_NONE: a free slot)
     std::vector<uint32_t> entityOfTransform;                  // world transform slot -> the entity it held when the pools were dealt
     struct MeshTable {                                        // per world mesh slot of one pool
-        std::vector<uint32_t> rank, local, entity;            // where it lives; the entity it held when the pools were dealt
-    };
+        std::vector<uint32_t> rank, local, entity;            // where it lives; the entity it holds as far as the shares know
+        std::vector<uint32_t> transform, next;                // the world transform slot it is linked to (GV_NONE: none; kLoose: a live
+    };                                                        // entity without a transform), the next ref of that transform's list
     std::vector<MeshTable> meshTables;
-    // world transform slot -> the mesh components of its entity: refs [meshStart[t], meshStart[t + 1]) = (pool << 28) | mesh slot
-    std::vector<uint32_t> meshStart, meshRefs;
+    // world transform slot -> the mesh components of its entity, as a list through MeshTable::next: ref = (pool << 28) | mesh slot
+    std::vector<uint32_t> firstMesh;
+    std::vector<uint32_t> looseMeshes;  // refs of live meshes whose entity has no transform (mesh.cpp:149-153): picked up when one arrives
+    static constexpr uint32_t kLoose = 0xFFFFFFFEu;
+    static uint32_t refOf(uint32_t pool, uint32_t slot) noexcept { return (pool << 28) | slot; }
+
+    void linkMesh(uint32_t transformSlot, uint32_t pool, uint32_t slot)
+    {
+        MeshTable& table = meshTables[pool];
+        table.transform[slot] = transformSlot;
+        table.next[slot] = firstMesh[transformSlot];
+        firstMesh[transformSlot] = refOf(pool, slot);
+    }
+    void unlinkMesh(uint32_t pool, uint32_t slot)
+    {
+        MeshTable& table = meshTables[pool];
+        const uint32_t t = table.transform[slot];
+        if (t == kLoose) {
+            auto it = std::find(looseMeshes.begin(), looseMeshes.end(), refOf(pool, slot));
+            if (it != looseMeshes.end()) {
+                *it = looseMeshes.back();
+                looseMeshes.pop_back();
+            }
+        } else if (t != GV_NONE) {
+            uint32_t* at = &firstMesh[t];
+            while (*at != GV_NONE && *at != refOf(pool, slot))
+                at = &meshTables[*at >> 28].next[*at & 0x0FFFFFFFu];
+            if (*at != GV_NONE)
+                *at = table.next[slot];
+        }
+        table.transform[slot] = GV_NONE;
+        table.next[slot] = GV_NONE;
+    }
+    // share slots: holes are reused before the pools grow
+    static uint32_t allocTransform(Share& share, uint32_t worldSlot)
+    {
+        uint32_t local;
+        if (!share.freeTransforms.empty()) {
+            local = share.freeTransforms.back();
+            share.freeTransforms.pop_back();
+        } else {
+            local = (uint32_t)share.transforms.size();
+            share.transforms.emplace_back();
+            share.transformWorldSlot.push_back(GV_NONE);
+            share.entityToTransform.push_back(local);  // entity local + 1
+        }
+        share.transformWorldSlot[local] = worldSlot;
+        return local;
+    }
+    static void freeTransform(Share& share, uint32_t local)
+    {
+        share.transforms[local] = TransformComponent();  // a free slot (entity = null)
+        share.transformWorldSlot[local] = GV_NONE;
+        share.freeTransforms.push_back(local);
+    }
+    static uint32_t allocMesh(MeshShare& mesh, uint32_t worldSlot)
+    {
+        uint32_t local;
+        if (!mesh.freeSlots.empty()) {
+            local = mesh.freeSlots.back();
+            mesh.freeSlots.pop_back();
+        } else {
+            local = mesh.occupancy();
+            mesh.worldSlot.push_back(GV_NONE);
+            mesh.components.resize(mesh.components.size() + mesh.stride);
+        }
+        mesh.worldSlot[local] = worldSlot;
+        return local;
+    }
+    static void freeMesh(MeshShare& mesh, uint32_t local)
+    {
+        mesh.at(local)->entity = ID<Entity>();  // a free slot on the rank it left (mesh.cpp:142)
+        mesh.worldSlot[local] = GV_NONE;
+        mesh.freeSlots.push_back(local);
+    }
 
     // What a frame's synchronisation changed on each rank, in LOCAL slots: what gv_mark_dirty (GV_DIRTY_TRANSFORM, ranged
     // GV_DIRTY_HIERARCHY, GV_DIRTY_MESH) and gv_pool_update_index_map are told.
@@ -197,7 +274,8 @@ struct RankShares {
         for (uint32_t i = 0; i < occupancy; i++)
             copyTransform(ts, i);
         meshTables.assign(meshSystems.size(), MeshTable{});
-        meshStart.assign((size_t)occupancy + 1, 0u);
+        firstMesh.assign(occupancy, GV_NONE);
+        looseMeshes.clear();
         for (size_t p = 0; p < meshSystems.size(); p++) {
             const auto& meshPool = meshSystems[p]->getMeshComponentPool();
             const size_t stride = meshSystems[p]->getMeshComponentSize();
@@ -207,12 +285,14 @@ struct RankShares {
             table.rank.assign(meshOccupancy, 0u);
             table.local.assign(meshOccupancy, 0u);
             table.entity.assign(meshOccupancy, 0u);
+            table.transform.assign(meshOccupancy, GV_NONE);
+            table.next.assign(meshOccupancy, GV_NONE);
             for (uint32_t r = 0; r < ranks; r++)
                 shares[r].meshes[p].stride = stride;
             for (uint32_t j = 0; j < meshOccupancy; j++) {
                 const auto* component = reinterpret_cast<const MeshRenderComponent*>(data + (size_t)j * stride);
                 const uint32_t entity = *component->entity;
-                const uint32_t transformSlot = entity && entity < emap.size() ? emap[entity] : GV_NONE;
+                const uint32_t transformSlot = entity && entity < emap.size() && emap[entity] < occupancy ? emap[entity] : GV_NONE;
                 const uint32_t rank = transformSlot != GV_NONE ? rankOfTransform[transformSlot] : j % ranks;
                 MeshShare& share = shares[rank].meshes[p];
                 const size_t at = share.components.size();
@@ -229,22 +309,12 @@ struct RankShares {
                 table.local[j] = share.occupancy();
                 table.entity[j] = entity;
                 share.worldSlot.push_back(j);
-                if (transformSlot != GV_NONE)
-                    meshStart[transformSlot + 1]++;
-            }
-        }
-        // transform -> its meshes (what follows a tree from share to share)
-        for (uint32_t t = 0; t < occupancy; t++)
-            meshStart[t + 1] += meshStart[t];
-        meshRefs.assign(meshStart[occupancy], 0u);
-        std::vector<uint32_t> fill(meshStart.begin(), meshStart.end() - 1);
-        for (size_t p = 0; p < meshSystems.size(); p++) {
-            const MeshTable& table = meshTables[p];
-            for (uint32_t j = 0; j < (uint32_t)table.entity.size(); j++) {
-                const uint32_t entity = table.entity[j];
-                const uint32_t transformSlot = entity && entity < emap.size() ? emap[entity] : GV_NONE;
-                if (transformSlot != GV_NONE)
-                    meshRefs[fill[transformSlot]++] = ((uint32_t)p << 28) | j;
+                if (transformSlot != GV_NONE) {
+                    linkMesh(transformSlot, (uint32_t)p, j);  // (what follows a tree from share to share)
+                } else if (entity) {
+                    table.transform[j] = kLoose;
+                    looseMeshes.push_back(refOf((uint32_t)p, j));
+                }
             }
         }
     }
@@ -254,24 +324,26 @@ struct RankShares {
     // Mesh slots against the ranks' copies, in the bytes the cull reads — entity (mesh.cpp:142,149), isEnabled (:142), aabb
     // (:140-141,158): what differs is copied and recorded. pieces: per pool, the slots [lo, hi) to look at; ALL pieces are walked in
     // ONE pass over the library's worker threads (a frame of seven systems of 10^5 components each is one pass over 7 * 10^5 slots,
-    // not seven short ones on the calling thread). false: a slot holds another entity than it was dealt with (a component came or
-    // went): the caller deals again.
+    // not seven short ones on the calling thread). Slots that hold another entity than the shares know (a component came or went)
+    // are left alone and listed in changedEntity[pool] (NULL: false is returned at the first one instead): followEntities takes them.
     struct MeshPiece {
         uint32_t pool, lo, hi;
         IMeshRenderSystem* meshSystem;
     };
-    bool syncMeshes(const std::vector<MeshPiece>& pieces, Changes& changes)
+    bool syncMeshes(const std::vector<MeshPiece>& pieces, Changes& changes, std::vector<std::vector<uint32_t>>* changedEntity = nullptr)
     {
         struct Job {
             RankShares* self;
             std::vector<MeshPiece> pieces;
             std::vector<uint32_t> start;  // running slot counts: piece k covers [start[k], start[k + 1]) of the pass
             Changes* changes;
+            std::vector<std::vector<uint32_t>>* changedEntity;
             std::mutex merge;
             bool structural = false;
         } job;
         job.self = this;
         job.changes = &changes;
+        job.changedEntity = changedEntity;
         job.start.push_back(0u);
         for (MeshPiece piece : pieces) {
             piece.hi = std::min<uint32_t>(piece.hi, (uint32_t)meshTables[piece.pool].entity.size());
@@ -285,10 +357,11 @@ struct RankShares {
         gv_host_parallel_ranges(0, job.start.back(), [](void* user, uint32_t a, uint32_t b) {
             Job& j = *static_cast<Job*>(user);
             std::vector<uint32_t> edited;  // (pool << 28 | rank << 24 ...) would not fit: triples, flattened
+            std::vector<uint32_t> handsChanged;  // pairs (pool, slot)
             bool structural = false;
             constexpr size_t kAabb = offsetof(MeshRenderComponent, aabb);
             size_t k = (size_t)(std::upper_bound(j.start.begin(), j.start.end(), a) - j.start.begin()) - 1;
-            for (uint32_t at = a; at < b && !structural; k++) {
+            for (uint32_t at = a; at < b && (!structural || j.changedEntity); k++) {
                 const MeshPiece& piece = j.pieces[k];
                 const uint32_t end = std::min(b, j.start[k + 1]);
                 const MeshTable& table = j.self->meshTables[piece.pool];
@@ -298,7 +371,10 @@ struct RankShares {
                     const auto* w = reinterpret_cast<const MeshRenderComponent*>(world + (size_t)s * stride);
                     if (*w->entity != table.entity[s]) {
                         structural = true;
-                        break;
+                        if (!j.changedEntity)
+                            break;
+                        handsChanged.insert(handsChanged.end(), {piece.pool, s});
+                        continue;
                     }
                     MeshRenderComponent* c = j.self->shares[table.rank[s]].meshes[piece.pool].at(table.local[s]);
                     if (c->isEnabled == w->isEnabled && std::memcmp(&c->aabb, &w->aabb, sizeof(Aabb)) == 0)
@@ -315,6 +391,8 @@ struct RankShares {
             j.structural = j.structural || structural;
             for (size_t e = 0; e + 2 < edited.size(); e += 3)
                 j.changes->ranks[edited[e + 1]].meshes[edited[e]].push_back(edited[e + 2]);
+            for (size_t e = 0; e + 1 < handsChanged.size(); e += 2)
+                (*j.changedEntity)[handsChanged[e]].push_back(handsChanged[e + 1]);
         }, &job);
         return !job.structural;
     }
@@ -389,6 +467,210 @@ struct RankShares {
                 moveTree(ts, m.first, m.second, changes);
     }
 
+    // Mesh slot (pool, slot) to rank `to` (nothing happens when it lives there already), its local entity id set to `localEntity`.
+    void moveMesh(uint32_t p, uint32_t slot, uint32_t to, uint32_t localEntity, Changes& changes)
+    {
+        MeshTable& table = meshTables[p];
+        const uint32_t from = table.rank[slot];
+        if (from != to) {
+            MeshShare& ms = shares[from].meshes[p];
+            MeshShare& md = shares[to].meshes[p];
+            const uint32_t was = table.local[slot], now = allocMesh(md, slot);
+            std::memcpy(md.components.data() + (size_t)now * md.stride, ms.components.data() + (size_t)was * ms.stride, md.stride);
+            freeMesh(ms, was);
+            table.rank[slot] = to;
+            table.local[slot] = now;
+            changes.ranks[from].meshes[p].push_back(was);
+            changes.ranks[from].maps[p].push_back(was);
+            changes.ranks[to].maps[p].push_back(now);
+        }
+        shares[to].meshes[p].at(table.local[slot])->entity = ID<Entity>(localEntity);
+        changes.ranks[to].meshes[p].push_back(table.local[slot]);
+    }
+
+    // Entities and components that came or went, parent links that moved — followed slot by slot instead of dealing the pools again.
+    //   transformSlots  world transform slots that may hold another entity than the shares know, or whose parent link may have moved
+    //                   (the engine's flags / re-parent ranges, slots the pool has grown by)
+    //   meshSlots[p]    the same for mesh pool p (what syncMeshes found, slots the pool has grown by)
+    // A transform that went leaves a hole on its rank (its entity's remaining meshes become "no transform", mesh.cpp:149-153); one
+    // that came goes to its parent's rank — a root: where gv_cell_owner puts its position —; a subtree whose new parent lives on
+    // another rank moves there (moveTree); a mesh component follows its entity's transform. false: something that cannot be followed
+    // (a parent without a place, a pool that shrank): the caller deals again.
+    // [linkLo, linkHi): the slots whose parent link may have moved (the engine's re-parent range): the ranks re-validate those links.
+    bool followEntities(const TransformSystem* ts, const std::vector<IMeshRenderSystem*>& meshSystems, uint32_t ranks, const uint32_t grid[3], double side,
+                        std::vector<uint32_t> transformSlots, const std::vector<std::vector<uint32_t>>& meshSlots, uint32_t linkLo, uint32_t linkHi,
+                        Changes& changes)
+    {
+        auto& pool = const_cast<TransformSystem*>(ts)->getComponents();
+        const auto& emap = ts->getEntityMap();
+        const TransformComponent* world = pool.getData();
+        const uint32_t occupancy = pool.getOccupancy();
+        if (occupancy < rankOfTransform.size() || meshSystems.size() != meshTables.size() || shares.size() != ranks)
+            return false;
+        rankOfTransform.resize(occupancy, GV_NONE);
+        localOfTransform.resize(occupancy, GV_NONE);
+        entityOfTransform.resize(occupancy, 0u);
+        firstMesh.resize(occupancy, GV_NONE);
+        auto slotOf = [&](uint32_t entity) { return entity && entity < emap.size() && emap[entity] < occupancy ? emap[entity] : GV_NONE; };
+        std::sort(transformSlots.begin(), transformSlots.end());
+        transformSlots.erase(std::unique(transformSlots.begin(), transformSlots.end()), transformSlots.end());
+        while (!transformSlots.empty() && transformSlots.back() >= occupancy)
+            transformSlots.pop_back();
+        // 1. transforms that went (or whose slot changed hands)
+        std::vector<uint32_t> arrivals, kept;
+        for (uint32_t s : transformSlots) {
+            const uint32_t now = *world[s].entity, was = entityOfTransform[s];
+            if (was && now != was) {
+                for (uint32_t ref = firstMesh[s]; ref != GV_NONE;) {  // its entity's meshes: whatever is still alive has no transform now
+                    const uint32_t p = ref >> 28, j = ref & 0x0FFFFFFFu;
+                    MeshTable& table = meshTables[p];
+                    ref = table.next[j];
+                    table.transform[j] = table.next[j] = GV_NONE;
+                    const auto* component = reinterpret_cast<const MeshRenderComponent*>(
+                        reinterpret_cast<const uint8_t*>(meshSystems[p]->getMeshComponentPool().getData()) + (size_t)j * meshSystems[p]->getMeshComponentSize());
+                    if (j < meshSystems[p]->getMeshComponentPool().getOccupancy() && *component->entity == table.entity[j] && table.entity[j]) {
+                        shares[table.rank[j]].meshes[p].at(table.local[j])->entity = ID<Entity>(kNoTransformEntity);
+                        changes.ranks[table.rank[j]].meshes[p].push_back(table.local[j]);
+                        table.transform[j] = kLoose;
+                        looseMeshes.push_back(refOf(p, j));
+                    }  // (else: the component went or changed hands too — step 4 takes it from there)
+                }
+                firstMesh[s] = GV_NONE;
+                freeTransform(shares[rankOfTransform[s]], localOfTransform[s]);
+                changes.ranks[rankOfTransform[s]].transforms.push_back(localOfTransform[s]);
+                rankOfTransform[s] = localOfTransform[s] = GV_NONE;
+                entityOfTransform[s] = 0u;
+            }
+            if (now && now != was)
+                arrivals.push_back(s);
+            else if (now)
+                kept.push_back(s);
+        }
+        // 2. transforms that came: roots where their position falls (one gv_cell_owner call), children on their parent's rank
+        {
+            std::vector<float> positions;
+            std::vector<uint32_t> roots;
+            for (uint32_t s : arrivals)
+                if (slotOf(*world[s].parent) == GV_NONE) {
+                    roots.push_back(s);
+                    positions.insert(positions.end(), {world[s].posChildCount.x, world[s].posChildCount.y, world[s].posChildCount.z});
+                }
+            std::vector<uint32_t> owner(roots.size() ? roots.size() : 1);
+            if (!roots.empty() && gv_cell_owner(grid, side, ranks, positions.data(), 12, (uint32_t)roots.size(), owner.data()) != GV_OK)
+                throw std::runtime_error("RankShares: gv_cell_owner failed");
+            auto place = [&](uint32_t s, uint32_t rank) {
+                rankOfTransform[s] = rank;
+                localOfTransform[s] = allocTransform(shares[rank], s);
+                entityOfTransform[s] = *world[s].entity;
+            };
+            for (size_t k = 0; k < roots.size(); k++)
+                place(roots[k], owner[k]);
+            std::vector<uint32_t> chain;
+            for (uint32_t s : arrivals) {  // a child whose parent arrived in this frame too waits for it
+                chain.clear();
+                for (uint32_t c = s; rankOfTransform[c] == GV_NONE; c = slotOf(*world[c].parent)) {
+                    chain.push_back(c);
+                    const uint32_t up = slotOf(*world[c].parent);
+                    if (up == GV_NONE || (rankOfTransform[up] == GV_NONE && !*world[up].entity) || chain.size() > occupancy)
+                        return false;  // (a parent without a place, or a cycle)
+                    if (rankOfTransform[up] == GV_NONE && !std::binary_search(arrivals.begin(), arrivals.end(), up))
+                        return false;
+                }
+                for (size_t k = chain.size(); k-- > 0;)
+                    place(chain[k], rankOfTransform[slotOf(*world[chain[k]].parent)]);
+            }
+            for (uint32_t s : arrivals) {
+                if (!tryCopyTransform(ts, s))
+                    return false;
+                changes.ranks[rankOfTransform[s]].transforms.push_back(localOfTransform[s]);
+                if (*world[s].parent)
+                    changes.ranks[rankOfTransform[s]].links.push_back(localOfTransform[s]);
+            }
+        }
+        // 3. transforms that stayed: a parent link that now leads to another rank takes the subtree there; the others are refreshed in place
+        for (uint32_t s : kept) {
+            if (rankOfTransform[s] == GV_NONE)
+                return false;
+            const uint32_t up = slotOf(*world[s].parent);
+            if (*world[s].parent && (up == GV_NONE || rankOfTransform[up] == GV_NONE))
+                return false;
+            if (up != GV_NONE && rankOfTransform[up] != rankOfTransform[s]) {
+                moveTree(ts, s, rankOfTransform[up], changes);
+                continue;
+            }
+            if (!tryCopyTransform(ts, s))
+                return false;
+            changes.ranks[rankOfTransform[s]].transforms.push_back(localOfTransform[s]);
+            if (s >= linkLo && s < linkHi)
+                changes.ranks[rankOfTransform[s]].links.push_back(localOfTransform[s]);
+        }
+        // 4. mesh components that came, went or changed hands: each follows its entity's transform
+        for (size_t p = 0; p < meshSystems.size(); p++) {
+            const auto& meshPool = meshSystems[p]->getMeshComponentPool();
+            const size_t stride = meshSystems[p]->getMeshComponentSize();
+            const uint8_t* data = reinterpret_cast<const uint8_t*>(meshPool.getData());
+            const uint32_t meshOccupancy = meshPool.getOccupancy();
+            MeshTable& table = meshTables[p];
+            if (meshOccupancy < table.entity.size())
+                return false;
+            table.rank.resize(meshOccupancy, GV_NONE);
+            table.local.resize(meshOccupancy, GV_NONE);
+            table.entity.resize(meshOccupancy, 0u);
+            table.transform.resize(meshOccupancy, GV_NONE);
+            table.next.resize(meshOccupancy, GV_NONE);
+            for (uint32_t j : meshSlots[p]) {
+                if (j >= meshOccupancy)
+                    continue;
+                const auto* component = reinterpret_cast<const MeshRenderComponent*>(data + (size_t)j * stride);
+                placeMesh((uint32_t)p, j, component, slotOf(*component->entity), ranks, changes);
+            }
+        }
+        // 5. a transform that came for an entity whose meshes were waiting without one
+        if (!looseMeshes.empty() && !arrivals.empty()) {
+            const std::vector<uint32_t> waiting = looseMeshes;
+            for (uint32_t ref : waiting) {
+                const uint32_t p = ref >> 28, j = ref & 0x0FFFFFFFu;
+                const uint32_t t = slotOf(meshTables[p].entity[j]);
+                if (t == GV_NONE || rankOfTransform[t] == GV_NONE)
+                    continue;
+                const auto* component = reinterpret_cast<const MeshRenderComponent*>(
+                    reinterpret_cast<const uint8_t*>(meshSystems[p]->getMeshComponentPool().getData()) + (size_t)j * meshSystems[p]->getMeshComponentSize());
+                placeMesh(p, j, component, t, ranks, changes);
+            }
+        }
+        return true;
+    }
+
+    // Mesh slot (p, j) as the engine holds it now: on the rank of its entity's transform `t` (GV_NONE: it stays where it is — a slot the
+    // pool has grown by goes to rank j % ranks), the engine's bytes, the local entity id, the list of its transform.
+    void placeMesh(uint32_t p, uint32_t j, const MeshRenderComponent* component, uint32_t t, uint32_t ranks, Changes& changes)
+    {
+        MeshTable& table = meshTables[p];
+        unlinkMesh(p, j);
+        const uint32_t entity = *component->entity;
+        if (t != GV_NONE && rankOfTransform[t] == GV_NONE)
+            t = GV_NONE;
+        const bool fresh = table.rank[j] == GV_NONE;
+        const uint32_t want = t != GV_NONE ? rankOfTransform[t] : fresh ? j % ranks : table.rank[j];
+        if (fresh) {
+            table.rank[j] = want;
+            table.local[j] = allocMesh(shares[want].meshes[p], j);
+            changes.ranks[want].maps[p].push_back(table.local[j]);
+        }
+        const uint32_t localEntity = !entity ? 0u : t != GV_NONE ? localOfTransform[t] + 1 : kNoTransformEntity;
+        moveMesh(p, j, want, localEntity, changes);
+        MeshShare& share = shares[want].meshes[p];
+        std::memcpy(share.components.data() + (size_t)table.local[j] * share.stride, component, share.stride);
+        share.at(table.local[j])->entity = ID<Entity>(localEntity);
+        table.entity[j] = entity;
+        if (t != GV_NONE) {
+            linkMesh(t, p, j);
+        } else if (entity) {
+            table.transform[j] = kLoose;
+            looseMeshes.push_back(refOf(p, j));
+        }
+    }
+
     // The tree under world transform slot `root` from its rank to `to`: transforms parents first, each with its meshes.
     void moveTree(const TransformSystem* ts, uint32_t root, uint32_t to, Changes& changes)
     {
@@ -410,55 +692,17 @@ struct RankShares {
         Share& dst = shares[to];
         for (uint32_t s : tree) {
             const uint32_t was = localOfTransform[s];
-            src.transforms[was] = TransformComponent();  // a free slot (entity = null)
-            src.transformWorldSlot[was] = GV_NONE;
-            src.freeTransforms.push_back(was);
+            freeTransform(src, was);
             changes.ranks[from].transforms.push_back(was);
-            uint32_t now;
-            if (!dst.freeTransforms.empty()) {
-                now = dst.freeTransforms.back();
-                dst.freeTransforms.pop_back();
-            } else {
-                now = (uint32_t)dst.transforms.size();
-                dst.transforms.emplace_back();
-                dst.transformWorldSlot.push_back(GV_NONE);
-                dst.entityToTransform.push_back(now);  // entity now + 1
-            }
-            dst.transformWorldSlot[now] = s;
+            const uint32_t now = allocTransform(dst, s);
             rankOfTransform[s] = to;
             localOfTransform[s] = now;
             copyTransform(ts, s);
             changes.ranks[to].transforms.push_back(now);
             if (*dst.transforms[now].parent)
                 changes.ranks[to].links.push_back(now);
-            for (uint32_t k = meshStart[s]; k < meshStart[s + 1]; k++) {
-                const uint32_t p = meshRefs[k] >> 28, j = meshRefs[k] & 0x0FFFFFFFu;
-                MeshTable& table = meshTables[p];
-                MeshShare& ms = src.meshes[p];
-                MeshShare& md = dst.meshes[p];
-                const uint32_t lwas = table.local[j];
-                uint32_t lnow;
-                if (!md.freeSlots.empty()) {
-                    lnow = md.freeSlots.back();
-                    md.freeSlots.pop_back();
-                } else {
-                    lnow = md.occupancy();
-                    md.worldSlot.push_back(GV_NONE);
-                    md.components.resize(md.components.size() + md.stride);
-                }
-                std::memcpy(md.components.data() + (size_t)lnow * md.stride, ms.components.data() + (size_t)lwas * ms.stride, md.stride);
-                md.at(lnow)->entity = ID<Entity>(now + 1);
-                md.worldSlot[lnow] = j;
-                ms.at(lwas)->entity = ID<Entity>();  // a free slot on the rank it left (mesh.cpp:142)
-                ms.worldSlot[lwas] = GV_NONE;
-                ms.freeSlots.push_back(lwas);
-                table.rank[j] = to;
-                table.local[j] = lnow;
-                changes.ranks[from].meshes[p].push_back(lwas);
-                changes.ranks[from].maps[p].push_back(lwas);
-                changes.ranks[to].meshes[p].push_back(lnow);
-                changes.ranks[to].maps[p].push_back(lnow);
-            }
+            for (uint32_t ref = firstMesh[s]; ref != GV_NONE; ref = meshTables[ref >> 28].next[ref & 0x0FFFFFFFu])
+                moveMesh(ref >> 28, ref & 0x0FFFFFFFu, to, now + 1, changes);
         }
         changes.movedTrees++;
         changes.movedTransforms += (uint32_t)tree.size();

@@ -74,7 +74,7 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
                 const uint32_t parentSlot = emap[*world[w].parent];
                 EXPECT(shares.rankOfTransform[parentSlot] == r && *local.parent == shares.localOfTransform[parentSlot] + 1, "%s: parent link of transform %u", what, w);
             } else {
-                EXPECT(*local.parent == 0, "%s: a root with a parent", what);
+                EXPECT(*local.parent == 0, "%s: a root with a parent (world slot %u entity %u, rank %u local %u, local parent id %u)", what, w, *world[w].entity, r, k, *local.parent);
             }
         }
         EXPECT(holes == share.freeTransforms.size(), "%s: rank %u has %u holes and %zu free slots", what, r, holes, share.freeTransforms.size());
@@ -112,7 +112,10 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
                            "%s: a mesh without a transform resolves to one on its rank", what);
                 } else {
                     EXPECT(shares.rankOfTransform[transformSlot] == r && shares.shares[r].entityToTransform[localEntity] == shares.localOfTransform[transformSlot],
-                           "%s: pool %zu slot %u does not resolve to its entity's transform on rank %u", what, p, w, r);
+                           "%s: pool %zu slot %u does not resolve to its entity's transform on rank %u (entity %u, transform slot %u on rank %u local %u; local entity %u; linked to %u which holds entity %u / known as %u)", what, p, w, r,
+                           entity, transformSlot, shares.rankOfTransform[transformSlot], shares.localOfTransform[transformSlot], localEntity, shares.meshTables[p].transform[w],
+                           shares.meshTables[p].transform[w] < occupancy ? *world[shares.meshTables[p].transform[w]].entity : 0u,
+                           shares.meshTables[p].transform[w] < occupancy ? shares.entityOfTransform[shares.meshTables[p].transform[w]] : 0u);
                 }
             }
             EXPECT(holes == mesh.freeSlots.size(), "%s: pool %zu rank %u has %u holes and %zu free slots", what, p, r, holes, mesh.freeSlots.size());
@@ -300,18 +303,108 @@ int main()
             check(transformSystem, meshSystems, shares, ranks, grid, side, "after an itemised rebin", false);
         }
         // every moved root is where its position says (the others were not re-examined: ownership is a matter of balance)
-        // (4) a component that changed hands: structural
-        if (auto t = transformSystem->tryGetOf(ents[1])) {
-            (void)t;
-            manager.destroy(ents[1]);
-            manager.update();
+        // (4) entities and components that come and go, parent links that move, pools that grow: followed, never dealt again
+        auto follow = [&](const char* what) {
             changes.reset(ranks, meshSystems.size());
-            const bool a = shares.syncMeshes(0, opaque, 0, opaque->getComponents().getOccupancy(), changes);
-            const bool b = shares.syncMeshes(1, wide, 0, wide->getComponents().getOccupancy(), changes);
-            EXPECT(!(a && b), "syncMeshes: a destroyed component was not reported as structural");
-            shares.deal(transformSystem, meshSystems, ranks, grid, side);
-            check(transformSystem, meshSystems, shares, ranks, grid, side, "dealt again after a component went");
+            std::vector<std::vector<uint32_t>> changedHands(meshSystems.size());
+            std::vector<RankShares::MeshPiece> pieces;
+            for (uint32_t p = 0; p < meshSystems.size(); p++) {
+                const uint32_t occupancy = meshSystems[p]->getMeshComponentPool().getOccupancy();
+                pieces.push_back(RankShares::MeshPiece{p, 0u, occupancy, meshSystems[p]});
+                for (uint32_t j = (uint32_t)shares.meshTables[p].entity.size(); j < occupancy; j++)
+                    changedHands[p].push_back(j);
+            }
+            (void)shares.syncMeshes(pieces, changes, &changedHands);
+            std::vector<uint32_t> slots;
+            for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
+                slots.push_back(i);
+            for (uint32_t i = transformSystem->reparentLo; i < transformSystem->reparentHi; i++)
+                slots.push_back(i);
+            for (uint32_t i = (uint32_t)shares.rankOfTransform.size(); i < transformSystem->getComponents().getOccupancy(); i++)
+                slots.push_back(i);
+            const bool followed = shares.followEntities(transformSystem, meshSystems, ranks, grid, side, slots, changedHands, transformSystem->reparentLo,
+                                                        transformSystem->reparentHi, changes);
+            EXPECT(followed, "%s: followEntities gave up", what);
+            transformSystem->clearFlagsRange();
+            transformSystem->clearReparentRange();
+            for (auto sys : {static_cast<VersionedMeshSystem*>(opaque), static_cast<VersionedMeshSystem*>(wide)})
+                sys->clearMeshRange();
+            check(transformSystem, meshSystems, shares, ranks, grid, side, what, false);
+            // what the ranks are told stays inside their shares
+            for (uint32_t r = 0; r < ranks; r++) {
+                for (uint32_t l : changes.ranks[r].transforms)
+                    EXPECT(l < shares.shares[r].transforms.size(), "%s: a transform mark past the share of rank %u", what, r);
+                for (size_t p = 0; p < meshSystems.size(); p++)
+                    for (uint32_t l : changes.ranks[r].meshes[p])
+                        EXPECT(l < shares.shares[r].meshes[p].occupancy(), "%s: a mesh mark past the share of rank %u", what, r);
+            }
+        };
+        transformSystem->clearFlagsRange();
+        transformSystem->clearReparentRange();
+        std::vector<bool> dead(ents.size(), false);
+        for (uint32_t i = 7; i < n; i += 13)  // (destroyed further up: their handles are stale, the ids may have been handed out again)
+            dead[i] = i % 41 != 0;
+        for (int round = 0; round < 6; round++) {
+            // entities go (with their subtrees' links: children become roots) ...
+            for (uint32_t k = 0; k < n / 60 + 3; k++) {
+                const uint32_t i = rng() % (uint32_t)ents.size();
+                if (!dead[i]) {
+                    manager.destroy(ents[i]);
+                    dead[i] = true;
+                }
+            }
+            manager.update();  // (the components are wiped at the end of the frame)
+            // ... entities come: roots, children of old entities, children of entities that came in this very round, some without a
+            // transform, some without a mesh; the pools grow past what was dealt
+            const uint32_t before = (uint32_t)ents.size();
+            for (uint32_t k = 0; k < n / 40 + 5; k++) {
+                auto e = manager.createEntity();
+                ents.push_back(e);
+                dead.push_back(false);
+                if (k % 7 != 3) {
+                    MeshRenderComponent* m = (k % 3 == 0) ? static_cast<MeshRenderComponent*>(*wide->add(e)) : *opaque->add(e);
+                    m->aabb.max = f32x4(uniform(0.1f, 2.0f), 1, 1);
+                }
+                if (k % 11 == 5)
+                    continue;  // a mesh whose entity has no transform
+                auto t = transformSystem->add(e);
+                t->setPosition(uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side), uniform(-0.5f * (float)side, 0.5f * (float)side));
+                if (k % 2) {
+                    const uint32_t parent = (k % 4 == 1 && ents.size() - before > 2) ? before + rng() % (uint32_t)(ents.size() - before - 1) : rng() % before;
+                    if (!dead[parent] && transformSystem->tryGetOf(ents[parent]) && !(ents[parent] == e))
+                        transformSystem->setParent(e, ents[parent]);
+                }
+            }
+            // ... subtrees are handed to parents that live elsewhere, some become roots again, flags flip
+            for (uint32_t k = 0; k < n / 50 + 3; k++) {
+                const uint32_t i = rng() % (uint32_t)ents.size(), q = rng() % (uint32_t)ents.size();
+                if (dead[i] || dead[q] || i == q || !transformSystem->tryGetOf(ents[i]) || !transformSystem->tryGetOf(ents[q]))
+                    continue;
+                bool cycle = false;
+                for (auto up = ents[q]; up; up = transformSystem->tryGetOf(up)->parent)
+                    cycle = cycle || up == ents[i];
+                if (!cycle)
+                    transformSystem->setParent(ents[i], k % 5 == 0 ? ID<Entity>() : ents[q]);
+                transformSystem->setActive(ents[q], (k & 1) != 0);
+            }
+            // ... a transform is taken from an entity that keeps its mesh, another entity gets one at last
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t i = rng() % (uint32_t)ents.size();
+                if (dead[i])
+                    continue;
+                if (auto t = transformSystem->tryGetOf(ents[i])) {
+                    if (t->childCount() == 0 && round % 2 == 0)
+                        transformSystem->removeOf(ents[i]);
+                } else {
+                    transformSystem->add(ents[i])->setPosition(uniform(-100, 100), uniform(-100, 100), uniform(-100, 100));
+                }
+            }
+            manager.update();
+            follow("entities came and went");
         }
+        // ... and after all that a deal gives shares that satisfy the same invariants (the tables were kept consistent: nothing depends on it)
+        shares.deal(transformSystem, meshSystems, ranks, grid, side);
+        check(transformSystem, meshSystems, shares, ranks, grid, side, "dealt again at the end");
     }
     std::printf("{\"ok\": %s, \"failures\": %d}\n", failures ? "false" : "true", failures);
     return failures ? 1 : 0;

@@ -217,9 +217,9 @@ def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
     if "--probe-exchange" in args:
         assert out["exchanges"] == out["rank_frames"] and all(ms > 0 for ms in out["exchange_mode_probe_ms"]), out
         assert out["exchange_mode"] == min(range(3), key=lambda m: out["exchange_mode_probe_ms"][m]), out
-    # the pools are dealt once; only entities / components that come or go, or parent links that move, deal them again
-    if not any(a in args for a in ("--mutate", "--toggle", "--churn", "--gate")):
-        assert out["deals"] == 1, out
+    # the pools are dealt ONCE: entities and components that come or go (--mutate, --churn, --gate empty), parent links that move
+    # (--toggle --hier), edits and moves are all followed slot by slot (rank_shares.hpp followEntities)
+    assert out["deals"] == 1, out
     if expect_moved:
         assert out["moved_trees"] > 0 and out["deals"] == 1, out
     if "--no-rebin" in args:
