@@ -741,9 +741,14 @@ int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bo
         widest_pool = std::max(widest_pool, vs->occupancy);
     }
     const uint32_t table_words = batched ? item_count : 0u;
+    // (a row's count table always travels with its header: the direct patterns move 1 + room words, and the first frame of a
+    // communicator has no history — room 0 — so the room is never smaller than the table)
+    uint32_t rooms[GV_EXCHANGE_MAX_RANKS];
     uint32_t widest = 0;
-    for (int k = 0; k < world; k++)
-        widest = std::max(widest, ctx->exchange_room[k]);
+    for (int k = 0; k < world; k++) {
+        rooms[k] = std::max(ctx->exchange_room[k], table_words);
+        widest = std::max(widest, rooms[k]);
+    }
     const size_t row_words = row_words_for(widest);
     // the shard holds the WHOLE list (what a short prediction leaves behind travels later, from here); the equal-size all-gather
     // reads row_words words of it whatever the list's length
@@ -766,8 +771,8 @@ int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bo
         memset(slot.hdr.ptr, 0, kHdrWords * sizeof(uint32_t));
     }
     for (int k = 0; k < world; k++) {
-        slot.room[k] = ctx->exchange_room[k];
-        slot.travelled[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : 1u + ctx->exchange_room[k];
+        slot.room[k] = rooms[k];
+        slot.travelled[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : 1u + rooms[k];
         slot.counts[k] = slot.tail_words[k] = 0;
     }
     slot.cut = 0;

@@ -928,6 +928,53 @@ static void exchange_in_one_thread(int ranks, int list_seed)
                 ranks, list_seed, cut_frames / ranks);
 }
 
+// The FIRST frame of a communicator carries several lists (gv_exchange_views_all) under a direct travel pattern: there is no history,
+// every room is 0 — the count tables must still arrive with the headers (round 6: they travelled with the tails, and the frame
+// reported the counts of whatever the rows had held before).
+static void batched_first_frame(int ranks, uint32_t mode)
+{
+    g_list_seed = 0;
+    if (!std::getenv("GV_RCCL_LIBRARY"))
+        return;
+    std::vector<ExchangeRank> xs(ranks);
+    std::vector<GvCtx*> ctxs;
+    for (int r = 0; r < ranks; r++) {
+        if (!xs[r].create(r, ranks))
+            std::exit(1);
+        ctxs.push_back(xs[r].ctx);
+    }
+    GvCtx* ctx = ctxs[0];
+    CHECK(gv_exchange_init_all(ctxs.data(), ranks));
+    const GvExchangeItem items[2] = {{0u, 0u, 0u}, {1u, 0u, 0u}};
+    std::vector<GvExchangeFrame> sent(ranks), got(ranks);
+    for (int frame = 0; frame < 2; frame++) {
+        for (int r = 0; r < ranks; r++) {
+            xs[r].produce(frame, mode);
+            xs[r].cull_other_pool();
+        }
+        CHECK(gv_exchange_views_all(ctxs.data(), ranks, items, 2, 0, sent.data()));
+        CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+        for (int r = 0; r < ranks; r++)
+            for (int q = 0; q < ranks; q++) {
+                const uint32_t* row = (const uint32_t*)got[r].gathered_device + (size_t)q * got[r].row_words;
+                const uint32_t c0 = list_count(q, frame, ExchangeRank::n), c1 = ExchangeRank::other_count;
+                if (!got[r].complete || got[r].items != 2 || row[0] != 2 + c0 + c1 || row[1] != c0 || row[2] != c1 || got[r].item_counts[q * 2] != c0 ||
+                    got[r].item_counts[q * 2 + 1] != c1 || row[3] != list_value(q, frame, 0) || row[3 + c0] != 4200u + (uint32_t)q)
+                    xs[r].fail("the first batched frame of a communicator under a direct travel pattern", frame, q);
+            }
+    }
+    int failures = 0;
+    for (int r = 0; r < ranks; r++) {
+        failures += xs[r].failures;
+        ctx = xs[r].ctx;
+        CHECK(gv_exchange_shutdown(ctx));
+        gv_destroy(ctx);
+    }
+    if (failures)
+        std::exit(1);
+    std::printf("first batched frame of a communicator, %d ranks, travel pattern %u: ok\n", ranks, mode);
+}
+
 // ---- random schedules over the held-back mechanisms: the text tests/schedules.py generates (the GPU tier replays the same
 // schedules against the oracle, tests/test_gpu_fuzz.py). Kernels do nothing here; what is checked is that every call returns
 // GV_OK and that the host orchestration behind it — recorded culls, deferred sorts, published views, flushes forced by dirty
@@ -1508,6 +1555,8 @@ int main(int argc, char** argv)
         exchange_in_one_thread(ranks, 0);
     for (int seed = 1; seed <= 6; seed++)
         exchange_in_one_thread(2 + seed % 3, seed);
+    for (uint32_t mode : {GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST, GV_EXCHANGE_ALLGATHER})
+        batched_first_frame(3, mode);
     allocation_failures();
     exchange_allocation_failures();
     exchange_bounded_waits();

@@ -301,6 +301,10 @@ def test_native_batched_exchange_one_frame_carries_two_lists(ranks):
     assert out["ranks"] == ranks and out["mismatches"] == 0 and out["short_rows_completed"] >= 1, out
     out = _exchange_ranks(ranks, 60000, env=env, extra=["--batched", "--frames", "16", "--random-camera", "7", "--check-oracle"])
     assert out["ranks"] == ranks and out["mismatches"] == 0 and out["oracle_checked_frames"] >= 2, out
+    # a direct travel pattern from the communicator's first frame on (no history: the count tables still arrive with the headers)
+    for mode in ("p2p", "broadcast"):
+        out = _exchange_ranks(ranks, 30000, env=env, extra=["--batched", "--frames", "6", "--mode", mode])
+        assert out["ranks"] == ranks and out["mismatches"] == 0, out
 
 
 @pytest.mark.gpu

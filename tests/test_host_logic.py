@@ -586,6 +586,7 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     # ... and ONE exchange for all the lists of a frame (gv_exchange_views_all): count table + lists per row, short predictions completed
     batched = [l for l in run.stdout.splitlines() if l.startswith("batched exchange (gv_exchange_views_all)")]
     assert len(batched) == 3 + 6 and all("6 frames acquired" in l for l in batched), batched
+    assert run.stdout.count("first batched frame of a communicator, 3 ranks") == 3  # (p2p / broadcast / all-gather from frame 0: the tables arrive with the headers)
     print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange ")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
