@@ -11,12 +11,14 @@ make -s -C tests/cpp >/dev/null 2>&1
 export GV_RCCL_LIBRARY=$PWD/tests/cpp/build/librccl_stub.so
 {
   echo "# tests/cpp/headless_tick --mode gpu --ranks 4 <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the prepare phase, by step) — $label"
+  echo "# (--churn R: R rounds, each destroys ~1 % and creates ~2 % of the entities, some under existing parents, then --ticks frames: the breakdown averages over all of them)"
   echo "# $(git rev-parse --short HEAD 2>/dev/null || echo snapshot) $(date -u +%FT%TZ)"
   for a in "--entities 10000 --mixed --csm --ticks 500" "--entities 10000 --mixed --csm --ticks 500 --unversioned" \
            "--entities 1000000 --mixed --csm --ticks 200" "--entities 1000000 --mixed --csm --ticks 100 --unversioned" \
            "--entities 10000 --mixed --csm --ticks 500 --unversioned --animate 50 --itemised" \
            "--entities 1000000 --mixed --csm --ticks 100 --unversioned --animate 50 --itemised" \
-           "--entities 1000000 --ticks 200" "--entities 1000000 --ticks 100 --unversioned"; do
+           "--entities 1000000 --ticks 200" "--entities 1000000 --ticks 100 --unversioned" \
+           "--entities 100000 --mixed --hier --churn 30 --ticks 20" "--entities 1000000 --hier --churn 10 --ticks 10"; do
     echo "## --ranks 4 $a"
     GV_TICK_BREAKDOWN=1 timeout 600 ./tests/cpp/build/headless_tick --mode gpu --ranks 4 $a 2>&1 | grep -E "prepare us|exchanges|\"ok\"" | cut -c1-400
   done
