@@ -1251,6 +1251,19 @@ int gv_debug_stream_peak(GvCtx* ctx, uint32_t pool_id, uint32_t launches, double
 
 void* gv_stream(GvCtx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
+void gv_host_parallel_tasks(uint32_t count, void (*fn)(void* user, uint32_t task), void* user)
+{
+    if (!fn || !count)
+        return;
+    static const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t parts = std::min(count, std::min(hw, 16u));
+    std::atomic<uint32_t> next{0};
+    run_parts(parts, [&](uint32_t) {  // every part takes tasks until none is left
+        for (uint32_t task = next.fetch_add(1, std::memory_order_relaxed); task < count; task = next.fetch_add(1, std::memory_order_relaxed))
+            fn(user, task);
+    });
+}
+
 void gv_host_parallel_ranges(uint32_t first, uint32_t count, void (*fn)(void* user, uint32_t lo, uint32_t hi), void* user)
 {
     if (fn && count)

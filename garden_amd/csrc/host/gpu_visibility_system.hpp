@@ -705,6 +705,39 @@ private:
             throw GardenError(std::string(what) + " failed on rank " + std::to_string(rank) + ": " + gv_last_error(contexts[rank]));
     }
 
+    // One gathered list of the frame into its place: the ranks' runs as the engine's structs (or built here from the three arrays, through
+    // the share's slot table, for a struct the library cannot express), merged; mesh.cpp:252 for a shadow pass's sorted records.
+    template <class Mesh, class List>
+    void mergeList(Mesh* dst, List& g, const SystemPlan& sp, bool structs, bool ordered, uint32_t ranks)
+    {
+        const size_t componentSize = sp.meshSystem->getMeshComponentSize();
+        std::vector<std::vector<uint8_t>> built;
+        std::vector<const Mesh*> typed(ranks);
+        for (uint32_t r = 0; r < ranks; r++) {
+            if (!structs && g.counts[r]) {  // three arrays, the rank's own slots: through the share's table (mesh.cpp:170-172)
+                built.resize(ranks);
+                built[r].resize((size_t)g.counts[r] * sizeof(Mesh));
+                Mesh* meshes = reinterpret_cast<Mesh*>(built[r].data());
+                const auto& worldSlot = rankShares.shares[r].meshes[g.p].worldSlot;
+                for (uint32_t k = 0; k < g.counts[r]; k++) {
+                    new (&meshes[k]) Mesh();
+                    meshes[k].componentOffset = (size_t)worldSlot[g.results[r].visible_idx[k]] * componentSize;
+                    memcpy(meshes[k].bakedModel.m, g.results[r].baked_model + (size_t)k * 12, 48);
+                    meshes[k].distanceSq = g.results[r].distance_sq[k];
+                }
+                g.runs[r] = meshes;
+            }
+            typed[r] = static_cast<const Mesh*>(g.runs[r]);
+        }
+        mergeRanks(dst, typed.data(), g.counts.data(), ranks, ordered);
+        if constexpr (std::is_same<Mesh, SortedMesh>::value) {
+            const uint32_t sortedIndex = g.pass >= 0 ? sp.shadowIndex : sp.bufferIndex;
+            if (!structs || sortedIndex != sp.bufferIndex)  // mesh.cpp:252 (records built on the device carry the light pass's index)
+                for (uint32_t k = 0; k < g.total; k++)
+                    dst[k].bufferIndex = sortedIndex;
+        }
+    }
+
     // Brings every rank's share up to date with the engine's pools and tells the ranks what changed (rank_shares.hpp). The pools are
     // dealt ONCE; entities and components that come or go, parent links that move, edits and moves are followed slot by slot; a mesh
     // system that cannot say what changed (the reference's have no counters) is compared with the ranks' copies. Dealt again only
@@ -1070,82 +1103,105 @@ private:
             }
         }
         // Phase 3 — the engine's buffers from the ranks' results (library-owned host memory, valid until the pool's next gv_cull on that
-        // rank); the light pass's fetch also writes the rank's isVisible bytes into the engine's pool
-        std::vector<GvResult> results(ranks);
-        std::vector<uint32_t> counts(ranks);
-        std::vector<const void*> runs(ranks);
-        std::vector<std::vector<uint8_t>> built(ranks);  // a system whose struct the library cannot express: records built here
+        // rank); the light pass's fetch also writes the rank's isVisible bytes into the engine's pool. (a) every list is fetched from
+        // every rank: counters, totals, each list's place in its array; (b) the arrays are sized; (c) the ranks' runs are merged into
+        // place — the lists are independent: short ones side by side on the library's worker threads, long ones one after the other,
+        // each in pieces on those threads.
+        struct Gathered {
+            uint32_t p, v, total = 0, first = 0;  // first: where the list starts in a shared sorted array
+            int8_t pass;
+            std::vector<GvResult> results;
+            std::vector<const void*> runs;
+            std::vector<uint32_t> counts;
+            void* destination = nullptr;
+        };
+        std::vector<Gathered> lists;
         for (uint32_t p = 0; p < meshSystems.size(); p++) {
             const SystemPlan& sp = plan[p];
-            const size_t componentSize = sp.meshSystem->getMeshComponentSize();
-            const bool ordered = emitRecords && sortOnDevice && sp.type != MeshRenderType::OIT;
             for (uint32_t v = 0; v < sp.passes.size(); v++) {
-                const int8_t pass = sp.passes[v];
-                uint32_t total = 0, instances = 0;
+                Gathered g;
+                g.p = p, g.v = v, g.pass = sp.passes[v];
+                g.results.resize(ranks), g.runs.assign(ranks, nullptr), g.counts.assign(ranks, 0u);
+                uint32_t instances = 0;
                 for (uint32_t r = 0; r < ranks; r++) {
                     Stopwatch watch(tickSeconds.fetch);
-                    checkRank(r, gv_pool_results_fetch(contexts[r], p, v, pass < 0 ? 1 : 0, &results[r]), "gv_pool_results_fetch");
-                    total += results[r].draw_count;
-                    instances += results[r].instance_count;
-                    counts[r] = emitRecords ? results[r].draw_count : 0u;
-                    runs[r] = nullptr;
+                    checkRank(r, gv_pool_results_fetch(contexts[r], p, v, g.pass < 0 ? 1 : 0, &g.results[r]), "gv_pool_results_fetch");
+                    g.total += g.results[r].draw_count;
+                    instances += g.results[r].instance_count;
+                    g.counts[r] = emitRecords ? g.results[r].draw_count : 0u;
                     if (emitRecords && structs[p]) {
                         uint32_t n = 0;
-                        checkRank(r, gv_pool_results_records(contexts[r], p, v, &runs[r], &n), "gv_pool_results_records");
+                        checkRank(r, gv_pool_results_records(contexts[r], p, v, &g.runs[r], &n), "gv_pool_results_records");
                     }
                 }
-                Stopwatch watch(tickSeconds.records);
-                const uint32_t sortedIndex = pass >= 0 ? sp.shadowIndex : sp.bufferIndex;
-                auto gatherRuns = [&](auto* dst) {
-                    using Mesh = std::remove_pointer_t<decltype(dst)>;
-                    std::vector<const Mesh*> typed(ranks);
-                    for (uint32_t r = 0; r < ranks; r++) {
-                        if (!structs[p] && counts[r]) {  // three arrays, the rank's own slots: through the share's table (mesh.cpp:170-172)
-                            built[r].resize((size_t)counts[r] * sizeof(Mesh));
-                            Mesh* meshes = reinterpret_cast<Mesh*>(built[r].data());
-                            const auto& worldSlot = rankShares.shares[r].meshes[p].worldSlot;
-                            for (uint32_t k = 0; k < counts[r]; k++) {
-                                new (&meshes[k]) Mesh();
-                                meshes[k].componentOffset = (size_t)worldSlot[results[r].visible_idx[k]] * componentSize;
-                                memcpy(meshes[k].bakedModel.m, results[r].baked_model + (size_t)k * 12, 48);
-                                meshes[k].distanceSq = results[r].distance_sq[k];
-                            }
-                            runs[r] = meshes;
-                        }
-                        typed[r] = static_cast<const Mesh*>(runs[r]);
-                    }
-                    mergeRanks(dst, typed.data(), counts.data(), ranks, ordered);
-                };
+                MeshBuffer* counters;
                 if (sp.sorted) {
                     const bool ui = sp.type == MeshRenderType::UI;
-                    auto& combined = pass >= 0 ? shadowTransMeshes[pass] : ui ? uiSortedMeshes : transSortedMeshes;
-                    uint32_t& drawIndex = pass >= 0 ? shadowTransDrawIndex[pass] : ui ? uiDrawIndex : transDrawIndex;
-                    auto& allRuns = pass >= 0 ? shadowTransRuns[pass] : ui ? uiRuns : transRuns;
-                    MeshBuffer* counters = pass >= 0 ? static_cast<MeshBuffer*>(shadowSortedBuffers[pass][sp.shadowIndex]) : sortedBuffers[sp.bufferIndex];
-                    if (emitRecords) {
-                        if (combined.size() < (size_t)drawIndex + total)
-                            combined.resize((size_t)drawIndex + total);
-                        gatherRuns(combined.data() + drawIndex);
-                        if (!structs[p] || sortedIndex != sp.bufferIndex)  // mesh.cpp:252 (records built on the device carry the light pass's index)
-                            for (uint32_t k = 0; k < total; k++)
-                                combined[drawIndex + k].bufferIndex = sortedIndex;
-                        drawIndex += total;
+                    uint32_t& drawIndex = g.pass >= 0 ? shadowTransDrawIndex[g.pass] : ui ? uiDrawIndex : transDrawIndex;
+                    auto& allRuns = g.pass >= 0 ? shadowTransRuns[g.pass] : ui ? uiRuns : transRuns;
+                    counters = g.pass >= 0 ? static_cast<MeshBuffer*>(shadowSortedBuffers[g.pass][sp.shadowIndex]) : sortedBuffers[sp.bufferIndex];
+                    if (emitRecords) {  // prepareSortedMeshes' tail (mesh.cpp:246-261): behind the records already in the shared array
+                        g.first = drawIndex;
+                        drawIndex += g.total;
                         allRuns.push_back(drawIndex);
                     }
-                    counters->drawCount = total;
-                    counters->instanceCount = instances;
                 } else {
-                    UnsortedBuffer* buffer = pass >= 0 ? shadowBuffers[sp.bufferIndex][pass] : unsortedBuffers[sp.bufferIndex];
-                    if (emitRecords) {
-                        if (buffer->combinedMeshes.size() < total)
-                            buffer->combinedMeshes.resize(total);  // grown, never shrunk (mesh.cpp:377-395)
-                        gatherRuns(buffer->combinedMeshes.data());
-                    }
-                    buffer->drawCount = total;
-                    buffer->instanceCount = instances;
+                    counters = g.pass >= 0 ? shadowBuffers[sp.bufferIndex][g.pass] : unsortedBuffers[sp.bufferIndex];
                 }
+                counters->drawCount = g.total;
+                counters->instanceCount = instances;
+                if (emitRecords && g.total)
+                    lists.push_back(std::move(g));
             }
         }
+        Stopwatch watch(tickSeconds.records);
+        auto grown = [](auto& array, size_t records) {
+            if (array.size() < records)
+                array.resize(records);  // grown, never shrunk (mesh.cpp:377-395)
+        };
+        grown(transSortedMeshes, transDrawIndex);
+        grown(uiSortedMeshes, uiDrawIndex);
+        for (uint32_t s = 0; s < passCount; s++)
+            grown(shadowTransMeshes[s], shadowTransDrawIndex[s]);
+        for (Gathered& g : lists) {
+            const SystemPlan& sp = plan[g.p];
+            if (sp.sorted) {
+                auto& combined = g.pass >= 0 ? shadowTransMeshes[g.pass] : sp.type == MeshRenderType::UI ? uiSortedMeshes : transSortedMeshes;
+                g.destination = combined.data() + g.first;
+            } else {
+                UnsortedBuffer* buffer = g.pass >= 0 ? shadowBuffers[sp.bufferIndex][g.pass] : unsortedBuffers[sp.bufferIndex];
+                grown(buffer->combinedMeshes, g.total);
+                g.destination = buffer->combinedMeshes.data();
+            }
+        }
+        struct Merge {
+            GpuVisibilitySystem* self;
+            std::vector<Gathered>* lists;
+            const std::vector<uint8_t>* structs;
+            uint32_t ranks;
+            std::vector<uint32_t> order;  // which lists this call merges
+        } merge{this, &lists, &structs, ranks, {}};
+        auto mergeOne = [](void* user, uint32_t task) {
+            Merge& m = *static_cast<Merge*>(user);
+            Gathered& g = (*m.lists)[m.order[task]];
+            const SystemPlan& sp = m.self->plan[g.p];
+            const bool ordered = m.self->sortOnDevice && sp.type != MeshRenderType::OIT;
+            if (sp.sorted)
+                m.self->mergeList(static_cast<SortedMesh*>(g.destination), g, sp, (*m.structs)[g.p] != 0, ordered, m.ranks);
+            else
+                m.self->mergeList(static_cast<UnsortedMesh*>(g.destination), g, sp, (*m.structs)[g.p] != 0, ordered, m.ranks);
+        };
+        constexpr uint32_t kLongList = 1u << 17;  // (from here on mergeRanks itself spreads over the worker threads)
+        for (uint32_t k = 0; k < lists.size(); k++)
+            if (lists[k].total < kLongList)
+                merge.order.push_back(k);
+        gv_host_parallel_tasks((uint32_t)merge.order.size(), mergeOne, &merge);
+        merge.order.clear();
+        for (uint32_t k = 0; k < lists.size(); k++)
+            if (lists[k].total >= kLongList)
+                merge.order.push_back(k);
+        for (uint32_t task = 0; task < merge.order.size(); task++)
+            mergeOne(&merge, task);
         if (emitRecords && sortOnDevice) {
             mergeRuns(transSortedMeshes, transRuns);
             mergeRuns(uiSortedMeshes, uiRuns);

@@ -133,7 +133,7 @@ EXPORTS = [
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
     "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_pool_exchange_visible", "gv_pool_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
-    "gv_exchange_views", "gv_exchange_views_all", "gv_pool_update_index_map", "gv_pool_set_result_mapping", "gv_host_parallel_ranges",
+    "gv_exchange_views", "gv_exchange_views_all", "gv_pool_update_index_map", "gv_pool_set_result_mapping", "gv_host_parallel_ranges", "gv_host_parallel_tasks",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
     "gv_pool_results_instance_bases", "gv_profile_sampling", "gv_profile_samples", "gv_profile_kernels",
@@ -225,6 +225,8 @@ def load():
     lib.gv_pool_set_result_mapping.argtypes = [P, u32, u32, C.c_void_p, C.c_size_t, u32]
     lib.gv_host_parallel_ranges.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
     lib.gv_host_parallel_ranges.restype = None
+    lib.gv_host_parallel_tasks.argtypes = [u32, C.c_void_p, C.c_void_p]
+    lib.gv_host_parallel_tasks.restype = None
     lib.gv_exchange_set_timeout.argtypes = [P, u32]
     lib.gv_exchange_masks.argtypes = [P, u32, u32, P]
     lib.gv_exchange_shutdown.argtypes = [P]

@@ -652,6 +652,9 @@ void* gv_stream(GvCtx* ctx);
  * ThreadPool, source/thread-pool.cpp:173-200: contiguous ranges, the calling thread takes part): fn(user, lo, hi) over contiguous
  * pieces of [first, first + count); one piece on the calling thread for short ranges. Returns when all pieces are done. */
 void gv_host_parallel_ranges(uint32_t first, uint32_t count, void (*fn)(void* user, uint32_t lo, uint32_t hi), void* user);
+/* The same workers for `count` independent tasks of some size each (fn(user, task), task = 0 .. count - 1; the calling thread takes
+ * part; one task: on the calling thread). A task must not call back into gv_host_parallel_* (one run at a time per process). */
+void gv_host_parallel_tasks(uint32_t count, void (*fn)(void* user, uint32_t task), void* user);
 
 #ifdef __cplusplus
 }

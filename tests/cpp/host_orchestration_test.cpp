@@ -1557,6 +1557,31 @@ int main(int argc, char** argv)
         exchange_in_one_thread(2 + seed % 3, seed);
     for (uint32_t mode : {GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST, GV_EXCHANGE_ALLGATHER})
         batched_first_frame(3, mode);
+    {  // the host workers as the shim uses them: every task exactly once, every item of a range exactly once
+        std::vector<std::atomic<uint32_t>> ran(1000);
+        for (uint32_t count : {0u, 1u, 7u, 1000u}) {
+            for (auto& r : ran)
+                r = 0;
+            gv_host_parallel_tasks(count, [](void* user, uint32_t task) { (*static_cast<std::vector<std::atomic<uint32_t>>*>(user))[task]++; }, &ran);
+            for (uint32_t k = 0; k < 1000; k++)
+                if (ran[k] != (k < count ? 1u : 0u)) {
+                    std::fprintf(stderr, "gv_host_parallel_tasks(%u): task %u ran %u times\n", count, k, ran[k].load());
+                    std::exit(1);
+                }
+        }
+        std::vector<uint8_t> seen(300000, 0);
+        gv_host_parallel_ranges(5, 299990, [](void* user, uint32_t lo, uint32_t hi) {
+            auto& v = *static_cast<std::vector<uint8_t>*>(user);
+            for (uint32_t i = lo; i < hi; i++)
+                v[i]++;
+        }, &seen);
+        for (uint32_t i = 0; i < seen.size(); i++)
+            if (seen[i] != (i >= 5 && i < 299995 ? 1 : 0)) {
+                std::fprintf(stderr, "gv_host_parallel_ranges: item %u visited %u times\n", i, seen[i]);
+                std::exit(1);
+            }
+        std::printf("host workers (gv_host_parallel_tasks / _ranges): ok\n");
+    }
     allocation_failures();
     exchange_allocation_failures();
     exchange_bounded_waits();
