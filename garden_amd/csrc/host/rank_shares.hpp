@@ -177,10 +177,14 @@ struct RankShares {
         }
     };
 
-    // true: slot still holds the entity it was dealt with (a slot that was freed and handed to another entity since must be dealt again)
-    bool sameEntity(const TransformSystem* ts, uint32_t worldSlot) const noexcept
+    // The entity whose transform lives in `slot` as Manager::tryGet<TransformComponent>(entity) sees it (mesh.cpp:149) — 0: none. A
+    // component that was destroyed in this frame still sits in the pool until the frame's dispose() (docs/ECS/Entities.md:52-54), but
+    // the entity no longer resolves to it: for the cull it is gone already.
+    static uint32_t heldBy(const TransformSystem* ts, uint32_t slot) noexcept
     {
-        return worldSlot < entityOfTransform.size() && entityOfTransform[worldSlot] == *worldTransform(ts, worldSlot)->entity;
+        const uint32_t entity = *worldTransform(ts, slot)->entity;
+        const auto& emap = ts->getEntityMap();
+        return entity && entity < emap.size() && emap[entity] == slot ? entity : 0u;
     }
 
     static const TransformComponent* worldTransform(const TransformSystem* ts, uint32_t slot) noexcept
@@ -207,8 +211,12 @@ struct RankShares {
         dst.entity = ID<Entity>(local + 1);
         const uint32_t parent = *dst.parent;
         if (parent) {
-            const uint32_t parentSlot = parent < emap.size() ? emap[parent] : GV_NONE;
-            if (parentSlot == GV_NONE || rankOfTransform[parentSlot] != rank)
+            const uint32_t parentSlot = parent < emap.size() && emap[parent] < rankOfTransform.size() ? emap[parent] : GV_NONE;
+            if (parentSlot == GV_NONE) {
+                dst.parent = ID<Entity>();  // a link that leads nowhere (a parent destroyed in this frame: its children are orphaned at once,
+                return true;                //  transform.cpp:53-63 — only a transform that is itself on its way out still names it)
+            }
+            if (rankOfTransform[parentSlot] != rank)
                 return false;
             dst.parent = ID<Entity>(localOfTransform[parentSlot] + 1);
         }
@@ -230,15 +238,15 @@ struct RankShares {
         std::vector<uint32_t> rootOf(occupancy, GV_NONE);
         std::vector<uint32_t> chain;
         for (uint32_t i = 0; i < occupancy; i++) {
-            if (!*world[i].entity || rootOf[i] != GV_NONE)
+            if (!heldBy(ts, i) || rootOf[i] != GV_NONE)
                 continue;
             chain.clear();
             uint32_t s = i;
             while (rootOf[s] == GV_NONE) {
                 chain.push_back(s);
                 const uint32_t parent = *world[s].parent;
-                const uint32_t up = parent && parent < emap.size() ? emap[parent] : GV_NONE;
-                if (up == GV_NONE || chain.size() > occupancy) {
+                const uint32_t up = parent && parent < emap.size() && emap[parent] < occupancy ? emap[parent] : GV_NONE;
+                if (up == GV_NONE || !heldBy(ts, up) || chain.size() > occupancy) {
                     rootOf[s] = s;  // a root (or a broken link: treated as one)
                     break;
                 }
@@ -253,9 +261,9 @@ struct RankShares {
         localOfTransform.assign(occupancy, GV_NONE);
         entityOfTransform.assign(occupancy, 0u);
         for (uint32_t i = 0; i < occupancy; i++)
-            entityOfTransform[i] = *world[i].entity;
+            entityOfTransform[i] = heldBy(ts, i);
         for (uint32_t i = 0; i < occupancy; i++) {
-            if (!*world[i].entity)
+            if (!entityOfTransform[i])
                 continue;
             const uint32_t rank = ownerByPosition[rootOf[i]];
             rankOfTransform[i] = rank;
@@ -519,7 +527,7 @@ struct RankShares {
         // 1. transforms that went (or whose slot changed hands)
         std::vector<uint32_t> arrivals, kept;
         for (uint32_t s : transformSlots) {
-            const uint32_t now = *world[s].entity, was = entityOfTransform[s];
+            const uint32_t now = heldBy(ts, s), was = entityOfTransform[s];
             if (was && now != was) {
                 for (uint32_t ref = firstMesh[s]; ref != GV_NONE;) {  // its entity's meshes: whatever is still alive has no transform now
                     const uint32_t p = ref >> 28, j = ref & 0x0FFFFFFFu;
@@ -561,7 +569,7 @@ struct RankShares {
             auto place = [&](uint32_t s, uint32_t rank) {
                 rankOfTransform[s] = rank;
                 localOfTransform[s] = allocTransform(shares[rank], s);
-                entityOfTransform[s] = *world[s].entity;
+                entityOfTransform[s] = heldBy(ts, s);
             };
             for (size_t k = 0; k < roots.size(); k++)
                 place(roots[k], owner[k]);
@@ -571,7 +579,7 @@ struct RankShares {
                 for (uint32_t c = s; rankOfTransform[c] == GV_NONE; c = slotOf(*world[c].parent)) {
                     chain.push_back(c);
                     const uint32_t up = slotOf(*world[c].parent);
-                    if (up == GV_NONE || (rankOfTransform[up] == GV_NONE && !*world[up].entity) || chain.size() > occupancy)
+                    if (up == GV_NONE || (rankOfTransform[up] == GV_NONE && !heldBy(ts, up)) || chain.size() > occupancy)
                         return false;  // (a parent without a place, or a cycle)
                     if (rankOfTransform[up] == GV_NONE && !std::binary_search(arrivals.begin(), arrivals.end(), up))
                         return false;
@@ -592,7 +600,7 @@ struct RankShares {
             if (rankOfTransform[s] == GV_NONE)
                 return false;
             const uint32_t up = slotOf(*world[s].parent);
-            if (*world[s].parent && (up == GV_NONE || rankOfTransform[up] == GV_NONE))
+            if (up != GV_NONE && rankOfTransform[up] == GV_NONE)
                 return false;
             if (up != GV_NONE && rankOfTransform[up] != rankOfTransform[s]) {
                 moveTree(ts, s, rankOfTransform[up], changes);

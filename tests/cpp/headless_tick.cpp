@@ -21,6 +21,10 @@
 // lists are gathered on the devices (every rank's rows are read back and compared: all ranks hold the same rows, their union is the
 // set of WORLD slots the pass's buffer holds) and the engine's buffers are filled from the ranks' results — compared with the CPU
 // system's like any other run.
+// --same-frame (with --mode both): the two systems run in the SAME Manager::update() — the CPU system, a hook that takes its snapshot,
+// then the GPU drop-in — instead of a frame each. Entities destroyed since the last frame are then still in their pools (components are
+// wiped at the END of a frame, docs/ECS/Entities.md:52-54) while Manager::tryGet no longer finds them: the state an engine really
+// presents on the frame after a destroy, which a CPU frame in front of the GPU frame would have disposed of.
 // Prints one JSON line; exit code 0 = ok, 1 = mismatch/failure.
 #include <algorithm>
 #include <chrono>
@@ -64,6 +68,21 @@ struct alignas(16) GlassMeshComponent final : public MeshRenderComponent {
     uint32_t materialId = 0;
 };
 using GlassMeshSystem = MeshSystemOf<GlassMeshComponent, MeshRenderType::Translucent>;
+
+// --same-frame: runs between the CPU system and the GPU drop-in (systems are called in the order they were created)
+class MidFrameHook final : public System {
+public:
+    std::function<void()> between;
+    MidFrameHook() { ECSM_SUBSCRIBE_TO_EVENT("Init", MidFrameHook::init); }
+
+private:
+    void init() { ECSM_SUBSCRIBE_TO_EVENT("PreDeferredRender", MidFrameHook::run); }
+    void run()
+    {
+        if (between)
+            between();
+    }
+};
 
 // What a prepare phase leaves behind for the render phase. Record arrays are compared as sets (the reference's order
 // is fetch_add arrival order before sortMeshes and unspecified among equal keys after it): canonical order here is
@@ -396,6 +415,7 @@ int main(int argc, char** argv)
     bool hier = false, mutate = false, mixed = false, toggle = false, bounds = false, avx2 = false;
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
+    bool sameFrame = false;      // --same-frame: both systems in one Manager::update() (see the head of this file)
     bool probeExchange = false;  // --probe-exchange (with --ranks): the drop-in times the three travel patterns on its first frame and keeps the fastest
     bool noRebin = false;        // --no-rebin (with --ranks): roots that cross cells stay on their rank (the balance decays; results are the same)
     bool unversioned = false;  // --unversioned: the mesh systems carry no change counters (like every mesh system of the reference)
@@ -428,6 +448,7 @@ int main(int argc, char** argv)
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--animate-step" && i + 1 < argc) animateStep = (float)atof(argv[++i]);
         else if (a == "--probe-exchange") probeExchange = true;
+        else if (a == "--same-frame") sameFrame = true;
         else if (a == "--no-rebin") noRebin = true;
         else if (a == "--csm") csmPasses = true;
         else if (a == "--skip-pass" && i + 1 < argc) skipPass = atoi(argv[++i]);
@@ -492,6 +513,7 @@ int main(int argc, char** argv)
             cpu->threads = threads;
             cpu->useAvx2 = avx2;
         }
+        MidFrameHook* hook = mode == "both" ? manager.createSystem<MidFrameHook>() : nullptr;
         // what the devices held after the gather of each (mesh system, pass) of the last tick: the union of the ranks' rows
         std::map<std::pair<uint32_t, int>, std::vector<uint32_t>> gathered;
         std::string gatherProblem;
@@ -814,16 +836,29 @@ int main(int argc, char** argv)
                 const uint32_t compared = animate ? ticks : 1;
                 Snapshot a, b;
                 for (uint32_t c = 0; c < compared && ok; c++) {
+                    std::string cpuGate, gpuGate;
                     poisonVisible(manager);
-                    run(true, false, 1);
-                    a = snapshot(manager, cpu, passCount);
-                    std::string cpuGate = gateHolds(manager, cpu, passCount);
-                    if (cpuGate.empty())
-                        cpuGate = sortedArraysHold(manager, cpu, passCount);
-                    poisonVisible(manager);
-                    seconds += run(false, true, 1, false);
-                    std::string gpuGate = gateHolds(manager, gpu, passCount);  // (after ONE tick from the pattern: a later tick
-                    if (gpuGate.empty())                                        //  would find a non-drawn system's bytes unchanged anyway)
+                    if (sameFrame) {  // one frame: the CPU system, its snapshot, the pattern again, the GPU drop-in
+                        hook->between = [&]() {
+                            a = snapshot(manager, cpu, passCount);
+                            cpuGate = gateHolds(manager, cpu, passCount);
+                            if (cpuGate.empty())
+                                cpuGate = sortedArraysHold(manager, cpu, passCount);
+                            poisonVisible(manager);
+                        };
+                        seconds += run(true, true, 1);
+                        hook->between = nullptr;
+                    } else {
+                        run(true, false, 1);
+                        a = snapshot(manager, cpu, passCount);
+                        cpuGate = gateHolds(manager, cpu, passCount);
+                        if (cpuGate.empty())
+                            cpuGate = sortedArraysHold(manager, cpu, passCount);
+                        poisonVisible(manager);
+                        seconds += run(false, true, 1, false);
+                    }
+                    gpuGate = gateHolds(manager, gpu, passCount);  // (after ONE tick from the pattern: a later tick
+                    if (gpuGate.empty())                           //  would find a non-drawn system's bytes unchanged anyway)
                         gpuGate = sortedArraysHold(manager, gpu, passCount);
                     if (!animate && ticks > 1)
                         seconds += run(false, true, ticks - 1, false);

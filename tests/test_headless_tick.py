@@ -158,6 +158,11 @@ def test_gpu_system_fails_loudly_without_device(tick):
     ["--entities", "30000", "--mixed", "--gate", "shadow", "--skip-pass", "0"],
     ["--entities", "30000", "--mixed", "--csm", "--gate", "shadow", "--skip-pass", "1", "--hier", "--mutate"],
     ["--entities", "30000", "--mixed", "--csm", "--gate", "reverse", "--skip-pass", "0", "--churn", "3"],
+    # both systems in the SAME frame: entities destroyed since the last frame are still in their pools (wiped at the end of the frame,
+    # docs/ECS/Entities.md:52-54) while Manager::tryGet no longer finds them — what an engine presents on the frame after a destroy
+    ["--entities", "30000", "--hier", "--mutate", "--churn", "5", "--same-frame"],
+    ["--entities", "24000", "--mixed", "--hier", "--csm", "--churn", "4", "--same-frame", "--bounds"],
+    ["--entities", "20000", "--mixed", "--gate", "empty", "--churn", "3", "--same-frame", "--animate", "4", "--ticks", "4"],
 ])
 def test_gpu_dropin_matches_cpu_system(tick, args):
     _, out = tick("--mode", "both", *(["--ticks", "3"] if "--ticks" not in args else []), *args)
@@ -185,6 +190,10 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "20000", "--ranks", "3", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--no-rebin"],
     ["--entities", "20000", "--ranks", "4", "--mixed", "--csm", "--probe-exchange"],
     ["--entities", "20000", "--ranks", "2", "--soa-records", "--mixed", "--hier"],  # records through the three-array fetch
+    # the frame after a destroy as the engine presents it (--same-frame): components still in their pools, entities gone
+    ["--entities", "30000", "--ranks", "4", "--hier", "--mutate", "--churn", "6", "--same-frame"],
+    ["--entities", "24000", "--ranks", "3", "--mixed", "--hier", "--csm", "--churn", "5", "--same-frame", "--unversioned"],
+    ["--entities", "60000", "--ranks", "8", "--hier", "--churn", "12", "--same-frame", "--ticks", "2"],
     # BASELINE sizes through the drop-in's own multi-GPU mode: 10 M entities dealt to 8 / 4 contexts (hierarchies follow their roots;
     # the occlusion query on every rank), five mesh systems + three cascades at 4 M — every buffer and isVisible byte of the whole
     # pools == the CPU system's

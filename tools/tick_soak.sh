@@ -4,7 +4,7 @@
 # Round 6: the multi-GPU mode kept current slot by slot (--unversioned: mesh systems without change counters; --animate-step: roots
 # that cross cells take their trees to another rank). Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
 # against the reference text; --skip-pass: a shadow pass left out by prepareShadowRender) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
-#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 27 flag sets)
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 30 flag sets)
 set -u
 cd "$(dirname "$0")/.."
 make -s -C tests/cpp
@@ -36,6 +36,9 @@ sets=(
   "--entities 16000 --ranks 4 --hier --animate 2 --animate-step 170 --itemised --ticks 7"
   "--entities 16000 --ranks 2 --hier --mixed --animate 3 --animate-step 230 --ticks 5 --churn 2"
   "--entities 20000 --ranks 3 --hiz --mixed --csm --unversioned --toggle --hier"
+  "--entities 30000 --hier --mutate --churn 6 --same-frame"
+  "--entities 20000 --mixed --hier --csm --churn 4 --same-frame --ranks 4"
+  "--entities 40000 --hier --churn 8 --same-frame --ranks 3 --unversioned --ticks 2"
   "--entities 20000 --mixed --csm --gate shadow --skip-pass 1 --churn 3"
   "--entities 16000 --mixed --gate reverse --skip-pass 0 --hier --mutate"
 )
