@@ -769,16 +769,14 @@ private:
             }
             (void)rankShares.syncMeshes(pieces, rankChanges, &changedHands);
             // Entities and components that came or went, parent links that moved: followed slot by slot (rank_shares.hpp followEntities)
-            std::vector<uint32_t> transformSlots;
-            if (seenFlags != transformSystem->flagsVersion)  // (entities created / destroyed, setActive: the slots they touched)
-                for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
-                    transformSlots.push_back(i);
-            const bool relinked = ranksSeen.reparent != transformSystem->reparentVersion;
+            std::vector<std::pair<uint32_t, uint32_t>> transformSlots;  // [first, end)
+            if (seenFlags != transformSystem->flagsVersion && transformSystem->flagsLo < transformSystem->flagsHi)  // (entities created / destroyed, setActive)
+                transformSlots.push_back({transformSystem->flagsLo, transformSystem->flagsHi});
+            const bool relinked = ranksSeen.reparent != transformSystem->reparentVersion && transformSystem->reparentLo < transformSystem->reparentHi;
             if (relinked)
-                for (uint32_t i = transformSystem->reparentLo; i < transformSystem->reparentHi; i++)
-                    transformSlots.push_back(i);
-            for (uint32_t i = (uint32_t)rankShares.rankOfTransform.size(); i < pool.getOccupancy(); i++)
-                transformSlots.push_back(i);
+                transformSlots.push_back({transformSystem->reparentLo, transformSystem->reparentHi});
+            if (rankShares.rankOfTransform.size() < pool.getOccupancy())
+                transformSlots.push_back({(uint32_t)rankShares.rankOfTransform.size(), pool.getOccupancy()});
             bool anything = !transformSlots.empty();
             for (const auto& slots : changedHands)
                 anything = anything || !slots.empty();

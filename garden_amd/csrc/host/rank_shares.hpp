@@ -497,8 +497,10 @@ struct RankShares {
     }
 
     // Entities and components that came or went, parent links that moved — followed slot by slot instead of dealing the pools again.
-    //   transformSlots  world transform slots that may hold another entity than the shares know, or whose parent link may have moved
-    //                   (the engine's flags / re-parent ranges, slots the pool has grown by)
+    //   transformRanges world transform slots [first, end) that may hold another entity than the shares know, or whose flags / parent
+    //                   link may have changed (the engine's flags / re-parent ranges — hulls: most slots in them are as they were —,
+    //                   slots the pool has grown by); they are classified in ONE pass on the library's worker threads: went / came /
+    //                   changed / as it was (the last kind, nearly all of a hull, costs a compare and nothing else)
     //   meshSlots[p]    the same for mesh pool p (what syncMeshes found, slots the pool has grown by)
     // A transform that went leaves a hole on its rank (its entity's remaining meshes become "no transform", mesh.cpp:149-153); one
     // that came goes to its parent's rank — a root: where gv_cell_owner puts its position —; a subtree whose new parent lives on
@@ -506,8 +508,8 @@ struct RankShares {
     // (a parent without a place, a pool that shrank): the caller deals again.
     // [linkLo, linkHi): the slots whose parent link may have moved (the engine's re-parent range): the ranks re-validate those links.
     bool followEntities(const TransformSystem* ts, const std::vector<IMeshRenderSystem*>& meshSystems, uint32_t ranks, const uint32_t grid[3], double side,
-                        std::vector<uint32_t> transformSlots, const std::vector<std::vector<uint32_t>>& meshSlots, uint32_t linkLo, uint32_t linkHi,
-                        Changes& changes)
+                        std::vector<std::pair<uint32_t, uint32_t>> transformRanges, const std::vector<std::vector<uint32_t>>& meshSlots, uint32_t linkLo,
+                        uint32_t linkHi, Changes& changes)
     {
         auto& pool = const_cast<TransformSystem*>(ts)->getComponents();
         const auto& emap = ts->getEntityMap();
@@ -520,15 +522,72 @@ struct RankShares {
         entityOfTransform.resize(occupancy, 0u);
         firstMesh.resize(occupancy, GV_NONE);
         auto slotOf = [&](uint32_t entity) { return entity && entity < emap.size() && emap[entity] < occupancy ? emap[entity] : GV_NONE; };
-        std::sort(transformSlots.begin(), transformSlots.end());
-        transformSlots.erase(std::unique(transformSlots.begin(), transformSlots.end()), transformSlots.end());
-        while (!transformSlots.empty() && transformSlots.back() >= occupancy)
-            transformSlots.pop_back();
+        // 0. what happened to every slot of the ranges: one pass over the worker threads
+        struct Classify {
+            RankShares* self;
+            const TransformSystem* ts;
+            std::vector<std::pair<uint32_t, uint32_t>> ranges;
+            std::vector<uint32_t> start;
+            std::mutex merge;
+            std::vector<uint32_t> went, came, changed;
+        } classify;
+        classify.self = this;
+        classify.ts = ts;
+        std::sort(transformRanges.begin(), transformRanges.end());
+        classify.start.push_back(0u);
+        for (auto range : transformRanges) {
+            range.second = std::min(range.second, occupancy);
+            if (!classify.ranges.empty() && range.first < classify.ranges.back().second)
+                range.first = classify.ranges.back().second;  // (the engine's hulls overlap)
+            if (range.first >= range.second)
+                continue;
+            classify.ranges.push_back(range);
+            classify.start.push_back(classify.start.back() + (range.second - range.first));
+        }
+        if (!classify.ranges.empty())
+            gv_host_parallel_ranges(0, classify.start.back(), [](void* user, uint32_t a, uint32_t b) {
+                Classify& c = *static_cast<Classify*>(user);
+                const RankShares& self = *c.self;
+                const auto& emap = c.ts->getEntityMap();
+                std::vector<uint32_t> went, came, changed;
+                size_t k = (size_t)(std::upper_bound(c.start.begin(), c.start.end(), a) - c.start.begin()) - 1;
+                for (uint32_t at = a; at < b; k++) {
+                    const uint32_t end = std::min(b, c.start[k + 1]);
+                    for (uint32_t s = c.ranges[k].first + (at - c.start[k]), e = c.ranges[k].first + (end - c.start[k]); s < e; s++) {
+                        const uint32_t now = heldBy(c.ts, s), was = self.entityOfTransform[s];
+                        if (was && now != was)
+                            went.push_back(s);
+                        if (now && now != was) {
+                            came.push_back(s);
+                        } else if (now) {  // the same entity: is the rank's copy still what the engine holds?
+                            const TransformComponent* w = worldTransform(c.ts, s);
+                            const uint32_t rank = self.rankOfTransform[s];
+                            const TransformComponent& mine = self.shares[rank].transforms[self.localOfTransform[s]];
+                            const uint32_t parent = *w->parent;
+                            const uint32_t up = parent && parent < emap.size() && emap[parent] < self.rankOfTransform.size() ? emap[parent] : GV_NONE;
+                            const uint32_t parentHere = up == GV_NONE ? 0u : self.rankOfTransform[up] == rank ? self.localOfTransform[up] + 1 : GV_NONE;
+                            if (parentHere != *mine.parent || std::memcmp(&mine.posChildCount, &w->posChildCount, 48) != 0 || mine.selfActive != w->selfActive ||
+                                mine.ancestorsActive != w->ancestorsActive || mine.modelWithAncestors != w->modelWithAncestors)
+                                changed.push_back(s);
+                        }
+                    }
+                    at = end;
+                }
+                if (went.empty() && came.empty() && changed.empty())
+                    return;
+                std::lock_guard<std::mutex> lock(c.merge);
+                c.went.insert(c.went.end(), went.begin(), went.end());
+                c.came.insert(c.came.end(), came.begin(), came.end());
+                c.changed.insert(c.changed.end(), changed.begin(), changed.end());
+            }, &classify);
+        std::sort(classify.went.begin(), classify.went.end());
+        std::sort(classify.came.begin(), classify.came.end());
+        std::sort(classify.changed.begin(), classify.changed.end());
+        std::vector<uint32_t>& arrivals = classify.came;
+        std::vector<uint32_t>& kept = classify.changed;
         // 1. transforms that went (or whose slot changed hands)
-        std::vector<uint32_t> arrivals, kept;
-        for (uint32_t s : transformSlots) {
-            const uint32_t now = heldBy(ts, s), was = entityOfTransform[s];
-            if (was && now != was) {
+        for (uint32_t s : classify.went) {
+            {
                 for (uint32_t ref = firstMesh[s]; ref != GV_NONE;) {  // its entity's meshes: whatever is still alive has no transform now
                     const uint32_t p = ref >> 28, j = ref & 0x0FFFFFFFu;
                     MeshTable& table = meshTables[p];
@@ -549,10 +608,6 @@ struct RankShares {
                 rankOfTransform[s] = localOfTransform[s] = GV_NONE;
                 entityOfTransform[s] = 0u;
             }
-            if (now && now != was)
-                arrivals.push_back(s);
-            else if (now)
-                kept.push_back(s);
         }
         // 2. transforms that came: roots where their position falls (one gv_cell_owner call), children on their parent's rank
         {

@@ -315,13 +315,13 @@ int main()
                     changedHands[p].push_back(j);
             }
             (void)shares.syncMeshes(pieces, changes, &changedHands);
-            std::vector<uint32_t> slots;
-            for (uint32_t i = transformSystem->flagsLo; i < transformSystem->flagsHi; i++)
-                slots.push_back(i);
-            for (uint32_t i = transformSystem->reparentLo; i < transformSystem->reparentHi; i++)
-                slots.push_back(i);
-            for (uint32_t i = (uint32_t)shares.rankOfTransform.size(); i < transformSystem->getComponents().getOccupancy(); i++)
-                slots.push_back(i);
+            std::vector<std::pair<uint32_t, uint32_t>> slots;
+            if (transformSystem->flagsLo < transformSystem->flagsHi)
+                slots.push_back({transformSystem->flagsLo, transformSystem->flagsHi});
+            if (transformSystem->reparentLo < transformSystem->reparentHi)
+                slots.push_back({transformSystem->reparentLo, transformSystem->reparentHi});
+            if (shares.rankOfTransform.size() < transformSystem->getComponents().getOccupancy())
+                slots.push_back({(uint32_t)shares.rankOfTransform.size(), transformSystem->getComponents().getOccupancy()});
             const bool followed = shares.followEntities(transformSystem, meshSystems, ranks, grid, side, slots, changedHands, transformSystem->reparentLo,
                                                         transformSystem->reparentHi, changes);
             EXPECT(followed, "%s: followEntities gave up", what);
