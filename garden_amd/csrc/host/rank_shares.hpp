@@ -84,12 +84,11 @@ struct RankShares {
     {
         MeshTable& table = meshTables[pool];
         const uint32_t t = table.transform[slot];
-        if (t == kLoose) {
-            auto it = std::find(looseMeshes.begin(), looseMeshes.end(), refOf(pool, slot));
-            if (it != looseMeshes.end()) {
-                *it = looseMeshes.back();
-                looseMeshes.pop_back();
-            }
+        if (t == kLoose) {  // (a loose mesh keeps its place in looseMeshes where a linked one keeps its list's next ref)
+            const uint32_t at = table.next[slot], last = looseMeshes.back();
+            looseMeshes[at] = last;
+            meshTables[last >> 28].next[last & 0x0FFFFFFFu] = at;
+            looseMeshes.pop_back();
         } else if (t != GV_NONE) {
             uint32_t* at = &firstMesh[t];
             while (*at != GV_NONE && *at != refOf(pool, slot))
@@ -99,6 +98,12 @@ struct RankShares {
         }
         table.transform[slot] = GV_NONE;
         table.next[slot] = GV_NONE;
+    }
+    void looseMesh(uint32_t pool, uint32_t slot)
+    {
+        meshTables[pool].transform[slot] = kLoose;
+        meshTables[pool].next[slot] = (uint32_t)looseMeshes.size();
+        looseMeshes.push_back(refOf(pool, slot));
     }
     // share slots: holes are reused before the pools grow
     static uint32_t allocTransform(Share& share, uint32_t worldSlot)
@@ -320,8 +325,7 @@ struct RankShares {
                 if (transformSlot != GV_NONE) {
                     linkMesh(transformSlot, (uint32_t)p, j);  // (what follows a tree from share to share)
                 } else if (entity) {
-                    table.transform[j] = kLoose;
-                    looseMeshes.push_back(refOf((uint32_t)p, j));
+                    looseMesh((uint32_t)p, j);
                 }
             }
         }
@@ -598,8 +602,7 @@ struct RankShares {
                     if (j < meshSystems[p]->getMeshComponentPool().getOccupancy() && *component->entity == table.entity[j] && table.entity[j]) {
                         shares[table.rank[j]].meshes[p].at(table.local[j])->entity = ID<Entity>(kNoTransformEntity);
                         changes.ranks[table.rank[j]].meshes[p].push_back(table.local[j]);
-                        table.transform[j] = kLoose;
-                        looseMeshes.push_back(refOf(p, j));
+                        looseMesh(p, j);
                     }  // (else: the component went or changed hands too — step 4 takes it from there)
                 }
                 firstMesh[s] = GV_NONE;
@@ -729,8 +732,7 @@ struct RankShares {
         if (t != GV_NONE) {
             linkMesh(t, p, j);
         } else if (entity) {
-            table.transform[j] = kLoose;
-            looseMeshes.push_back(refOf(p, j));
+            looseMesh(p, j);
         }
     }
 

@@ -81,6 +81,17 @@ static void check(const TransformSystem* ts, const std::vector<IMeshRenderSystem
     }
     for (uint32_t i = 0; i < occupancy; i++)
         EXPECT(seen[i] == (*world[i].entity ? 1u : 0u), "%s: transform slot %u is held %u times", what, i, seen[i]);
+    // the meshes that wait for a transform: each knows its place in the list, and the list holds nothing else
+    size_t flagged = 0;
+    for (const auto& table : shares.meshTables)
+        for (uint32_t t : table.transform)
+            flagged += t == RankShares::kLoose ? 1 : 0;
+    EXPECT(flagged == shares.looseMeshes.size(), "%s: %zu meshes are marked as waiting for a transform, the list holds %zu", what, flagged, shares.looseMeshes.size());
+    for (size_t k = 0; k < shares.looseMeshes.size(); k++) {
+        const uint32_t ref = shares.looseMeshes[k], p = ref >> 28, j = ref & 0x0FFFFFFFu;
+        EXPECT(p < shares.meshTables.size() && j < shares.meshTables[p].transform.size() && shares.meshTables[p].transform[j] == RankShares::kLoose &&
+                   shares.meshTables[p].next[j] == k, "%s: entry %zu of the waiting list", what, k);
+    }
     for (size_t p = 0; p < meshSystems.size(); p++) {
         const auto& meshPool = meshSystems[p]->getMeshComponentPool();
         const size_t stride = meshSystems[p]->getMeshComponentSize();
