@@ -369,9 +369,33 @@ __global__ __launch_bounds__(256) void hiz_fused_kernel(const float* __restrict_
     hiz_fused_tile<PAIRS, F16>(src_depth, src_pairs, dst, sw, sh, blockIdx.x, blockIdx.y);
 }
 
+// The same from the depth image with TWO tiles per workgroup, side by side: all eight row loads of a lane are in flight before the
+// first tile is reduced, so the second tile's bytes travel while the first goes through its four barriers — twice the bytes in
+// flight per resident workgroup, half as many workgroups (one round of them over the GPU at 4096 x 4096 instead of two). Round 6,
+// same box, 300 back-to-back builds at 4096 x 4096: one tile per workgroup 17.1 us, two 15.6, four 16.8 (profiles/withdrawn.md 42).
+template <bool F16, uint32_t TILES>
+__global__ __launch_bounds__(256) void hiz_fused_depth2_kernel(const float* __restrict__ src_depth, const HizFusedDst dst, uint32_t sw)
+{
+    float4 rows[TILES][4];
+#pragma unroll
+    for (uint32_t t = 0; t < TILES; t++)
+        hiz_load_depth_rows(src_depth, sw, TILES * blockIdx.x + t, blockIdx.y, rows[t]);
+#pragma unroll
+    for (uint32_t t = 0; t < TILES; t++)
+        hiz_reduce_depth_rows<F16>(rows[t], dst, sw, TILES * blockIdx.x + t, blockIdx.y);
+}
+
 hipError_t launch_hiz_fused(const float* src_depth, const float2* src_pairs, const HizFusedDst& dst, uint32_t sw,
                             uint32_t sh, bool rg16f, hipStream_t stream)
 {
+    if (src_depth && sw % 128 == 0 && (sw / 128) * (sh / 64) >= 1024) {  // (large images: enough pairs of tiles to fill the GPU)
+        const dim3 pairs(sw / 128, sh / 64);
+        if (rg16f)
+            hipLaunchKernelGGL((hiz_fused_depth2_kernel<true, 2>), pairs, dim3(256), 0, stream, src_depth, dst, sw);
+        else
+            hipLaunchKernelGGL((hiz_fused_depth2_kernel<false, 2>), pairs, dim3(256), 0, stream, src_depth, dst, sw);
+        return hipGetLastError();
+    }
     const dim3 grid(sw / 64, sh / 64);
     if (src_depth && rg16f)
         hipLaunchKernelGGL((hiz_fused_kernel<false, true>), grid, dim3(256), 0, stream, src_depth, src_pairs, dst, sw, sh);

@@ -21,9 +21,10 @@ __device__ __forceinline__ void hiz_acc(float2& mm, float2 t)
 }
 
 // Fused 6-level reduction of the 64 x 64 source tile (tile_x, tile_y) through LDS (256 lanes); dst.level[l] = level (src + 1 + l).
-template <bool PAIRS, bool F16>
-__device__ __forceinline__ void hiz_fused_tile(const float* __restrict__ src_depth, const float2* __restrict__ src_pairs, const HizFusedDst& dst,
-                                               uint32_t sw, uint32_t sh, uint32_t tile_x, uint32_t tile_y)
+// hiz_fused_reduce: from the lane's 4 x 4 source texels (mn / mx) on; FIRST: the source was the fp32 depth image.
+template <bool FIRST, bool F16>
+__device__ __forceinline__ void hiz_fused_reduce(const float (&mn)[4][4], const float (&mx)[4][4], const HizFusedDst& dst, uint32_t sw, uint32_t tile_x,
+                                                 uint32_t tile_y)
 {
     __shared__ float2 lds16[16][17];
     __shared__ float2 lds8[8][9];
@@ -31,26 +32,7 @@ __device__ __forceinline__ void hiz_fused_tile(const float* __restrict__ src_dep
     __shared__ float2 lds2[2][3];
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t ox = tile_x * 64, oy = tile_y * 64;
-    const uint32_t px = ox + 4 * tx, py = oy + 4 * ty;
-    float mn[4][4], mx[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (PAIRS && F16) {
-            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src_pairs) + (size_t)(py + r) * sw + px);
-            const float2 t0 = unpack_rg16f(t.x), t1 = unpack_rg16f(t.y), t2 = unpack_rg16f(t.z), t3 = unpack_rg16f(t.w);
-            mn[r][0] = t0.x; mx[r][0] = t0.y; mn[r][1] = t1.x; mx[r][1] = t1.y;
-            mn[r][2] = t2.x; mx[r][2] = t2.y; mn[r][3] = t3.x; mx[r][3] = t3.y;
-        } else if (PAIRS) {
-            const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
-            const float4 lo = row[0], hi = row[1];
-            mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
-            mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
-        } else {
-            const float4 v = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
-            mn[r][0] = mx[r][0] = v.x; mn[r][1] = mx[r][1] = v.y;
-            mn[r][2] = mx[r][2] = v.z; mn[r][3] = mx[r][3] = v.w;
-        }
-    }
+    constexpr bool PAIRS = !FIRST;
     // level +1: 2x2 texels per lane
     float2 q[2][2];
 #pragma unroll
@@ -121,7 +103,56 @@ __device__ __forceinline__ void hiz_fused_tile(const float* __restrict__ src_dep
         hiz_acc(mm, lds2[1][1]);
         hiz_store<F16>(dst.level[5], (size_t)(oy / 64) * (sw >> 6) + ox / 64, mm);
     }
+}
+
+// the lane's 4 x 4 source texels of tile (tile_x, tile_y): four 16-byte loads from the depth image
+__device__ __forceinline__ void hiz_load_depth_rows(const float* __restrict__ src_depth, uint32_t sw, uint32_t tile_x, uint32_t tile_y, float4 (&rows)[4])
+{
+    const uint32_t px = tile_x * 64 + 4 * (threadIdx.x & 15u), py = tile_y * 64 + 4 * (threadIdx.x >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        rows[r] = stream_load(reinterpret_cast<const float4*>(src_depth + (size_t)(py + r) * sw + px));
+}
+template <bool F16>
+__device__ __forceinline__ void hiz_reduce_depth_rows(const float4 (&rows)[4], const HizFusedDst& dst, uint32_t sw, uint32_t tile_x, uint32_t tile_y)
+{
+    float mn[4][4], mx[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        mn[r][0] = mx[r][0] = rows[r].x; mn[r][1] = mx[r][1] = rows[r].y;
+        mn[r][2] = mx[r][2] = rows[r].z; mn[r][3] = mx[r][3] = rows[r].w;
+    }
+    hiz_fused_reduce<true, F16>(mn, mx, dst, sw, tile_x, tile_y);
+}
+
+template <bool PAIRS, bool F16>
+__device__ __forceinline__ void hiz_fused_tile(const float* __restrict__ src_depth, const float2* __restrict__ src_pairs, const HizFusedDst& dst,
+                                               uint32_t sw, uint32_t sh, uint32_t tile_x, uint32_t tile_y)
+{
     (void)sh;
+    if (!PAIRS) {
+        float4 rows[4];
+        hiz_load_depth_rows(src_depth, sw, tile_x, tile_y, rows);
+        hiz_reduce_depth_rows<F16>(rows, dst, sw, tile_x, tile_y);
+        return;
+    }
+    const uint32_t px = tile_x * 64 + 4 * (threadIdx.x & 15u), py = tile_y * 64 + 4 * (threadIdx.x >> 4);
+    float mn[4][4], mx[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (F16) {
+            const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src_pairs) + (size_t)(py + r) * sw + px);
+            const float2 t0 = unpack_rg16f(t.x), t1 = unpack_rg16f(t.y), t2 = unpack_rg16f(t.z), t3 = unpack_rg16f(t.w);
+            mn[r][0] = t0.x; mx[r][0] = t0.y; mn[r][1] = t1.x; mx[r][1] = t1.y;
+            mn[r][2] = t2.x; mx[r][2] = t2.y; mn[r][3] = t3.x; mx[r][3] = t3.y;
+        } else {
+            const float4* row = reinterpret_cast<const float4*>(src_pairs + (size_t)(py + r) * sw + px);
+            const float4 lo = row[0], hi = row[1];
+            mn[r][0] = lo.x; mx[r][0] = lo.y; mn[r][1] = lo.z; mx[r][1] = lo.w;
+            mn[r][2] = hi.x; mx[r][2] = hi.y; mn[r][3] = hi.z; mx[r][3] = hi.w;
+        }
+    }
+    hiz_fused_reduce<false, F16>(mn, mx, dst, sw, tile_x, tile_y);
 }
 
 }  // namespace gv
