@@ -382,6 +382,10 @@ struct Context {
                                        // 1 + room[me] words, a completing exchange the tail behind them (both on exchange_stream)
         hipEvent_t produced = nullptr; // on ctx->stream behind the shard copy: exchange_stream waits for it
         hipEvent_t done = nullptr;     // on exchange_stream behind collective + headers (+ tails): GvExchangeFrame::ready_event
+        // GV_EXCHANGE_PEER (gv_exchange_init_peers): `sent` on this rank's exchange stream behind its stores into everybody's rows;
+        // on rank 0's exchange stream — the hub — `all_produced` behind every rank's `produced` (nobody still reads the rows about to
+        // be overwritten) and `all_sent` behind every rank's `sent` (every row has arrived everywhere)
+        hipEvent_t sent = nullptr, all_produced = nullptr, all_sent = nullptr;
         PinnedBuf<uint32_t> hdr;       // [1] sequence word + [world][hdr_words] leading words of every row, written by exchange_headers_kernel
         uint32_t hdr_words = 1;        // 1 (the count header) + the lists of a gv_exchange_views frame
         uint32_t items = 0;            // gv_exchange_views: lists per rank in this slot's frame (0: a single-list frame)
@@ -405,7 +409,8 @@ struct Context {
     uint32_t exchange_room[GV_EXCHANGE_MAX_RANKS] = {};  // room the next frame gives each rank
     uint32_t exchange_timeout_ms = 30000;               // bound of every host wait of the exchange (gv_exchange_set_timeout)
     bool exchange_broken = false;                       // a wait ran out: the communicator is aborted, not destroyed
-    bool exchange_by_group = false;                     // made by gv_exchange_init_all: driven through the *_all forms only
+    bool exchange_by_group = false;                     // made by gv_exchange_init_all / _init_peers: driven through the *_all forms only
+    std::vector<GvCtx*> exchange_peers;                 // gv_exchange_init_peers: the group's contexts by rank (empty: a communicator, or nothing)
 
     // ---- profiling ----
     std::vector<PendingEvent> pending;

@@ -18,6 +18,9 @@
 // the previous frame's headers (pinned memory, exchange_headers_kernel) and — the reference's gather never drops a record,
 // mesh.cpp:177-183 — completes the rows whose list outgrew the prediction with a second, exactly sized exchange before the frame
 // is handed out (settle_*, tails_*). The *_all forms drive the N contexts of one process from one thread inside one ncclGroup.
+// gv_exchange_init_peers (GV_EXCHANGE_PEER): the N contexts of ONE process need no communicator at all — every rank's list is stored
+// straight into its row of every rank's rows over xGMI (peer_scatter_kernel), ordered by events; rows are as wide as a rank's pools,
+// so nothing is predicted and no frame is ever short (peer_collective below). RCCL is not even loaded then.
 // See include/garden_vis.h.
 #include <dlfcn.h>
 
@@ -104,10 +107,12 @@ constexpr int kNcclUint32 = 3;  // ncclUint32 (rccl.h: ncclDataType_t)
 int give_up(GvCtx* ctx, int code, const char* text)
 {
     ctx->exchange_broken = true;
-    Rccl& r = rccl();
-    if (r.CommAbort && ctx->exchange_comm) {
-        (void)r.CommAbort(ctx->exchange_comm);
-        ctx->exchange_comm = nullptr;
+    if (ctx->exchange_comm) {  // (a peer group has none — and never loads RCCL)
+        Rccl& r = rccl();
+        if (r.CommAbort) {
+            (void)r.CommAbort(ctx->exchange_comm);
+            ctx->exchange_comm = nullptr;
+        }
     }
     ctx->error = text;
     return code;
@@ -116,9 +121,11 @@ int give_up(GvCtx* ctx, int code, const char* text)
 // what RCCL has to say about the collectives already enqueued (ncclCommGetAsyncError: a peer that died, a transport error)
 int async_error(GvCtx* ctx)
 {
+    if (!ctx->exchange_comm)
+        return 0;
     Rccl& r = rccl();
     int async = 0;
-    if (!r.CommGetAsyncError || !ctx->exchange_comm || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
+    if (!r.CommGetAsyncError || r.CommGetAsyncError(ctx->exchange_comm, &async) != 0)
         return 0;
     return async == 7 ? 0 : async;  // (ncclInProgress, rccl.h: a non-blocking communicator still at work — not an error)
 }
@@ -164,6 +171,18 @@ int exchange_drain(GvCtx* ctx) { return drain_exchange_stream(ctx); }
 
 void exchange_release(GvCtx* ctx)
 {
+    // A peer group (gv_exchange_init_peers) goes as a whole: the other members' scatter kernels store into THIS context's rows, so
+    // every member's exchange stream is drained before anything here is freed, and no member keeps a pointer to a context that may
+    // be destroyed next (the others answer GV_E_STATE until they are initialised again; their buffers go with their own release).
+    if (!ctx->exchange_peers.empty()) {
+        const std::vector<GvCtx*> members = ctx->exchange_peers;
+        for (GvCtx* m : members)
+            if (m != ctx)
+                (void)drain_exchange_stream(m);
+        for (GvCtx* m : members)
+            m->exchange_peers.clear();
+        (void)hipSetDevice(ctx->device);
+    }
     // what is still queued on the exchange stream goes first: gv_stream never waits for a frame's collective, so the communicator
     // would otherwise be destroyed under a queued all-gather. (After a timeout the stream may never drain: abort instead.)
     (void)drain_exchange_stream(ctx);  // (bounded: a timeout marks the communicator broken, and it is aborted below)
@@ -208,7 +227,10 @@ void exchange_release(GvCtx* ctx)
             (void)hipEventDestroy(slot.produced);
         if (slot.done)
             (void)hipEventDestroy(slot.done);
-        slot.produced = slot.done = nullptr;
+        for (hipEvent_t e : {slot.sent, slot.all_produced, slot.all_sent})
+            if (e)
+                (void)hipEventDestroy(e);
+        slot.produced = slot.done = slot.sent = slot.all_produced = slot.all_sent = nullptr;
         slot.in_flight = slot.settled = false;
         slot.row_words = 0;
         slot.frame = 0;
@@ -234,6 +256,8 @@ void exchange_release(GvCtx* ctx)
     ctx->exchange_by_group = false;
     ctx->exchange_rank = 0;
     ctx->exchange_world = 1;
+    if (ctx->exchange_mode == GV_EXCHANGE_PEER)  // (the pattern of a peer group only: a communicator made next starts from the default)
+        ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
 }
 
 }  // namespace gv
@@ -256,16 +280,21 @@ int exchange_setup(GvCtx* ctx, int rank, int world_size)
     for (auto& slot : ctx->exchange_slots) {
         GV_HIP(ctx, hipEventCreateWithFlags(&slot.produced, hipEventDisableTiming));
         GV_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.sent, hipEventDisableTiming));
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.all_produced, hipEventDisableTiming));
+        GV_HIP(ctx, hipEventCreateWithFlags(&slot.all_sent, hipEventDisableTiming));
     }
     if (const char* m = getenv("GV_EXCHANGE_MODE")) {
-        if (!strcmp(m, "p2p"))
+        if (!strcmp(m, "peer"))
+            ctx->exchange_mode = GV_EXCHANGE_PEER;  // (gv_exchange_init_peers only; the communicator forms refuse it)
+        else if (!strcmp(m, "p2p"))
             ctx->exchange_mode = GV_EXCHANGE_P2P;
         else if (!strcmp(m, "broadcast"))
             ctx->exchange_mode = GV_EXCHANGE_BROADCAST;
         else if (!strcmp(m, "allgather"))
             ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
         else
-            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast)", m);
+            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast | peer)", m);
     }
     if (const char* t = getenv("GV_EXCHANGE_TIMEOUT_MS")) {
         const long ms = atol(t);
@@ -312,6 +341,8 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
         return ctx->fail(GV_E_RCCL, "gv_exchange_init: %s", r.why.c_str());
     if (int rc = exchange_setup(ctx, rank, world_size))
         return exchange_setup_failed(ctx, rc);
+    if (ctx->exchange_mode == GV_EXCHANGE_PEER)
+        return exchange_setup_failed(ctx, ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=peer is the pattern of gv_exchange_init_peers (one process, no communicator)"));
     NcclId id{};
     memcpy(id.bytes, unique_id, GV_EXCHANGE_ID_BYTES);
     ncclComm_t comm = nullptr;
@@ -341,8 +372,11 @@ int gv_exchange_init_all(GvCtx* const* contexts, int world_size)
     if (r.GetUniqueId(&id) != 0)
         return first->fail(GV_E_RCCL, "gv_exchange_init_all: ncclGetUniqueId failed");
     int rc = GV_OK;
-    for (int k = 0; k < world_size && rc == GV_OK; k++)
+    for (int k = 0; k < world_size && rc == GV_OK; k++) {
         rc = exchange_setup(contexts[k], k, world_size);
+        if (rc == GV_OK && contexts[k]->exchange_mode == GV_EXCHANGE_PEER)
+            rc = first->fail(GV_E_ARG, "gv_exchange_init_all: GV_EXCHANGE_MODE=peer is the pattern of gv_exchange_init_peers (no communicator)");
+    }
     ncclComm_t comms[GV_EXCHANGE_MAX_RANKS] = {};
     // every device is selected once BEFORE the group opens: nothing but ncclCommInitRank itself can fail between ncclGroupStart and
     // ncclGroupEnd (a group closed over fewer than world_size ranks would wait for the missing ones for ever)
@@ -384,12 +418,82 @@ int gv_exchange_init_all(GvCtx* const* contexts, int world_size)
     return rc;
 }
 
+int gv_exchange_init_peers(GvCtx* const* contexts, int world_size)
+{
+    if (!contexts || world_size < 1 || world_size > (int)GV_EXCHANGE_MAX_RANKS)
+        return GV_E_ARG;
+    for (int k = 0; k < world_size; k++) {
+        if (!contexts[k])
+            return GV_E_ARG;
+        for (int j = 0; j < k; j++)
+            if (contexts[j] == contexts[k])
+                return contexts[k]->fail(GV_E_ARG, "gv_exchange_init_peers: context %d is listed twice", k);
+    }
+    GvCtx* first = contexts[0];
+    // every device must reach every other device's memory (xGMI within a node; contexts that share a device need nothing)
+    for (int a = 0; a < world_size; a++)
+        for (int b = 0; b < world_size; b++) {
+            const int da = contexts[a]->device, db = contexts[b]->device;
+            if (da == db)
+                continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                return first->fail(GV_E_STATE, "gv_exchange_init_peers: device %d cannot store into device %d's memory (no peer access): use gv_exchange_init_all", da, db);
+            }
+        }
+    int rc = GV_OK;
+    for (int k = 0; k < world_size && rc == GV_OK; k++)
+        rc = exchange_setup(contexts[k], k, world_size);  // (releases what was there, a former group included)
+    for (int a = 0; a < world_size && rc == GV_OK; a++) {
+        const int da = contexts[a]->device;
+        if (hipSetDevice(da) != hipSuccess) {
+            rc = contexts[a]->fail(GV_E_HIP, "gv_exchange_init_peers: hipSetDevice(%d)", da);
+            break;
+        }
+        for (int b = 0; b < world_size && rc == GV_OK; b++) {
+            const int db = contexts[b]->device;
+            bool seen = db == da;
+            for (int j = 0; j < b && !seen; j++)
+                seen = contexts[j]->device == db;
+            if (seen)
+                continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled)
+                (void)hipGetLastError();
+            else if (e != hipSuccess)
+                rc = contexts[a]->hip_fail(e, "gv_exchange_init_peers: hipDeviceEnablePeerAccess");
+        }
+    }
+    if (rc != GV_OK) {
+        const std::string why = contexts[0]->error.empty() ? std::string("gv_exchange_init_peers failed") : contexts[0]->error;
+        std::string text = why;
+        for (int k = 0; k < world_size; k++)
+            if (!contexts[k]->error.empty())
+                text = contexts[k]->error;
+        for (int k = 0; k < world_size; k++)
+            gv::exchange_release(contexts[k]);
+        first->error = text;
+        return rc;
+    }
+    const std::vector<GvCtx*> members(contexts, contexts + world_size);
+    for (int k = 0; k < world_size; k++) {
+        contexts[k]->exchange_peers = members;
+        contexts[k]->exchange_by_group = true;
+        contexts[k]->exchange_mode = GV_EXCHANGE_PEER;
+    }
+    return GV_OK;
+}
+
 int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode)
 {
     if (!ctx)
         return GV_E_ARG;
-    if (mode > GV_EXCHANGE_BROADCAST)
+    if (mode > GV_EXCHANGE_PEER)
         return ctx->fail(GV_E_ARG, "gv_exchange_set_mode: unknown mode %u", mode);
+    // a peer group travels by GV_EXCHANGE_PEER and nothing else (it has no communicator); a communicator by anything else
+    if (!ctx->exchange_peers.empty() ? mode != GV_EXCHANGE_PEER : mode == GV_EXCHANGE_PEER)
+        return ctx->fail(GV_E_ARG, "gv_exchange_set_mode: mode %u %s", mode, mode == GV_EXCHANGE_PEER ? "needs gv_exchange_init_peers" : "needs a communicator (this context belongs to a peer group)");
     ctx->exchange_mode = mode;
     return GV_OK;
 }
@@ -480,10 +584,10 @@ int usable(GvCtx* ctx, const char* what, bool by_group)
 {
     if (ctx->exchange_broken)
         return ctx->fail(GV_E_STATE, "%s: the communicator timed out earlier and was aborted (gv_exchange_shutdown, then gv_exchange_init again)", what);
-    if (!ctx->exchange_comm)
+    if (!ctx->exchange_comm && ctx->exchange_peers.empty())
         return ctx->fail(GV_E_STATE, "%s: gv_exchange_init has not run", what);
     if (!by_group && ctx->exchange_by_group && ctx->exchange_world > 1)
-        return ctx->fail(GV_E_STATE, "%s: this communicator was made by gv_exchange_init_all — one thread drives its %d ranks through the "
+        return ctx->fail(GV_E_STATE, "%s: this communicator was made by gv_exchange_init_all / _init_peers — one thread drives its %d ranks through the "
                          "*_all calls (a per-rank call would wait for ranks the same thread has not reached yet)", what, ctx->exchange_world);
     return GV_OK;
 }
@@ -558,6 +662,12 @@ int settle_read(GvCtx* ctx, Slot& slot)
             slot.item_counts[(size_t)r * slot.items + i] = row_head[1u + i];
         slot.counts[r] = count;
         slot.tail_words[r] = 0;
+        if (slot.mode == GV_EXCHANGE_PEER) {  // rows as wide as the pools: what a list holds is what travelled, whole
+            if (count > slot.room[r])
+                return ctx->fail(GV_E_STATE, "gv_exchange: rank %d's header (%u words) exceeds its row (%u) in a peer frame", r, count, slot.room[r]);
+            slot.travelled[r] = 1u + count;
+            continue;
+        }
         if (count > slot.room[r]) {
             slot.cut |= 1ull << r;
             slot.tail_words[r] = count - slot.room[r];
@@ -678,7 +788,6 @@ int tails_arrived(GvCtx* ctx, Slot& slot)
 // The three steps for all the contexts of a call (one for the per-rank forms): the collectives of all of them inside one group.
 int settle(GvCtx* const* ctxs, int n, unsigned which)
 {
-    Rccl& r = rccl();
     for (int k = 0; k < n; k++)
         if (int rc = settle_read(ctxs[k], ctxs[k]->exchange_slots[which])) {
             // a wait that ran out on one rank of the call: the collective hangs on all of them — none is left holding the device
@@ -697,6 +806,7 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
     }
     if (!short_rows)
         return GV_OK;
+    Rccl& r = rccl();
     for (int k = 0; k < n; k++)
         if (int rc = tails_stage(ctxs[k], ctxs[k]->exchange_slots[which]))
             return rc;
@@ -726,27 +836,38 @@ int settle(GvCtx* const* ctxs, int n, unsigned which)
 // A new frame, step 1 of 3: buffers, and this rank's whole list — or, batched (gv_exchange_views), ALL the frame's lists behind their
 // count table — into the slot's staging shard on the context's stream. items / item_count: the frame's (pool, view) pairs;
 // batched == false: one pair, no table (the single-list forms; pool GV_NONE = the pool of the most recent gv_cull).
-int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bool batched, Slot& slot)
+// what the frame's whole shard can need on this rank — every list at its pool's occupancy — and the widest of its pools
+int shard_need(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, size_t* list_words, uint32_t* widest_pool)
 {
-    GV_HIP(ctx, hipSetDevice(ctx->device));
-    const int world = ctx->exchange_world;
-    size_t list_words = 0;  // what the whole shard can need: every list at its pool's occupancy
-    uint32_t widest_pool = 0;
+    *list_words = 0;
+    *widest_pool = 0;
     for (uint32_t i = 0; i < item_count; i++) {
         const uint32_t pool_id = items[i].pool_id == GV_NONE ? ctx->last_pool : items[i].pool_id;  // the view-indexed forms address the pool of the most recent gv_cull
         gv::ViewState* vs = pool_id < GV_MAX_POOLS ? gv::view_of(ctx, pool_id, items[i].view_index) : nullptr;
         if (!vs || !vs->emitted)
             return ctx->fail(GV_E_ARG, "gv_exchange_visible: pool %u view %u has no emitted records", pool_id, items[i].view_index);
-        list_words += vs->occupancy;
-        widest_pool = std::max(widest_pool, vs->occupancy);
+        *list_words += vs->occupancy;
+        *widest_pool = std::max(*widest_pool, vs->occupancy);
     }
+    return GV_OK;
+}
+
+// peer_entries: GV_EXCHANGE_PEER — the entries every row has room for (the largest shard of the group); 0: rooms are predicted.
+int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bool batched, Slot& slot, uint32_t peer_entries = 0)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    const int world = ctx->exchange_world;
+    size_t list_words = 0;
+    uint32_t widest_pool = 0;
+    if (int rc = shard_need(ctx, items, item_count, &list_words, &widest_pool))
+        return rc;
     const uint32_t table_words = batched ? item_count : 0u;
     // (a row's count table always travels with its header: the direct patterns move 1 + room words, and the first frame of a
     // communicator has no history — room 0 — so the room is never smaller than the table)
     uint32_t rooms[GV_EXCHANGE_MAX_RANKS];
     uint32_t widest = 0;
     for (int k = 0; k < world; k++) {
-        rooms[k] = std::max(ctx->exchange_room[k], table_words);
+        rooms[k] = peer_entries ? peer_entries : std::max(ctx->exchange_room[k], table_words);
         widest = std::max(widest, rooms[k]);
     }
     const size_t row_words = row_words_for(widest);
@@ -772,7 +893,7 @@ int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bo
     }
     for (int k = 0; k < world; k++) {
         slot.room[k] = rooms[k];
-        slot.travelled[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : 1u + rooms[k];
+        slot.travelled[k] = ctx->exchange_mode == GV_EXCHANGE_ALLGATHER ? (uint32_t)row_words : peer_entries ? 0u : 1u + rooms[k];  // (peer: known once the headers are)
         slot.counts[k] = slot.tail_words[k] = 0;
     }
     slot.cut = 0;
@@ -817,6 +938,54 @@ int frame_collective(GvCtx* ctx, Slot& slot)
     for (int k = 0; k < ctx->exchange_world; k++)
         travel[k] = 1u + slot.room[k];
     return exchange_rows(ctx, slot.row_words, travel, slot.rows.ptr, "gv_exchange_visible", slot.shard.ptr, ctx->exchange_stream);
+}
+
+// ... step 2 of a peer group's frame (GV_EXCHANGE_PEER): no collective — rank k's scatter kernel stores its list into row k of every
+// member's rows. Two things order the ranks, both by events through rank 0's exchange stream (4 n waits per frame, not 2 n^2):
+// nobody overwrites rows a consumer of the frame before last may still read (all_produced: every member's context stream has
+// passed its `produced`, which follows whatever it enqueued to consume the slot's rows), and nobody's headers are read before every
+// row has arrived (all_sent). Kernel boundaries carry the data: no flag is polled on a device, nothing can wait for ever.
+static_assert(sizeof(gv::PeerRows::dst) / sizeof(uint32_t*) == GV_EXCHANGE_MAX_RANKS, "PeerRows holds one row pointer per rank");
+int peer_collective(GvCtx* const* ctxs, int n, unsigned which)
+{
+    GvCtx* hub = ctxs[0];
+    Slot& hs = hub->exchange_slots[which];
+    auto on = [&](int k) -> int {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess)
+            return ctxs[k]->fail(GV_E_HIP, "hipSetDevice(%d)", ctxs[k]->device);
+        return GV_OK;
+    };
+    // through the hub, every exchange stream waits for every `event_of(k)`; the hub's own stream order covers event 0
+    auto meet = [&](hipEvent_t Slot::*arrived, hipEvent_t all) -> int {
+        if (n == 1)
+            return GV_OK;
+        if (int rc = on(0))
+            return rc;
+        for (int k = 1; k < n; k++)
+            GV_HIP(hub, hipStreamWaitEvent(hub->exchange_stream, ctxs[k]->exchange_slots[which].*arrived, 0));
+        GV_HIP(hub, hipEventRecord(all, hub->exchange_stream));
+        for (int k = 1; k < n; k++) {
+            if (int rc = on(k))
+                return rc;
+            GV_HIP(ctxs[k], hipStreamWaitEvent(ctxs[k]->exchange_stream, all, 0));
+        }
+        return GV_OK;
+    };
+    if (int rc = meet(&Slot::produced, hs.all_produced))
+        return rc;
+    for (int k = 0; k < n; k++) {
+        GvCtx* ctx = ctxs[k];
+        Slot& slot = ctx->exchange_slots[which];
+        if (int rc = on(k))
+            return rc;
+        gv::PeerRows rows;
+        for (int j = 0; j < n; j++)
+            rows.dst[j] = ctxs[j]->exchange_slots[which].rows.ptr + (size_t)k * slot.row_words;
+        GV_HIP(ctx, gv::launch_peer_scatter(slot.shard.ptr, slot.row_words, rows, (uint32_t)n, ctx->exchange_stream));
+        if (n > 1)
+            GV_HIP(ctx, hipEventRecord(slot.sent, ctx->exchange_stream));
+    }
+    return meet(&Slot::sent, hs.all_sent);
 }
 
 void describe(const GvCtx* ctx, const Slot& slot, GvExchangeFrame* out)
@@ -866,7 +1035,6 @@ int frame_finish(GvCtx* ctx, Slot& slot, GvExchangeFrame* out)
 // items_of(k): the lists rank k's frame carries (batched: the same table-fronted row shape on every rank)
 int exchange_all(GvCtx* const* ctxs, int n, const GvExchangeItem* const* items_of, uint32_t item_count, bool batched, GvExchangeFrame* outs, bool by_group)
 {
-    Rccl& r = rccl();
     const uint64_t frame = ctxs[0]->exchange_frame;
     for (int k = 0; k < n; k++) {
         if (int rc = usable(ctxs[k], "gv_exchange_visible", by_group))
@@ -884,10 +1052,38 @@ int exchange_all(GvCtx* const* ctxs, int n, const GvExchangeItem* const* items_o
         if (int rc = settle(ctxs, n, (unsigned)((frame - 1) & 1u)))
             return rc;
     const unsigned which = (unsigned)(frame & 1u);
+    if (ctxs[0]->exchange_mode == GV_EXCHANGE_PEER) {
+        // the call names the whole group, in rank order: its members store into each other's rows
+        for (int k = 0; k < n; k++)
+            if ((int)ctxs[k]->exchange_peers.size() != n || ctxs[k]->exchange_peers[k] != ctxs[k] || ctxs[k]->exchange_peers != ctxs[0]->exchange_peers)
+                return ctxs[k]->fail(GV_E_ARG, "gv_exchange_visible_all: contexts[%d] is not rank %d of the peer group of contexts[0] (%d members)", k, k,
+                                     (int)ctxs[0]->exchange_peers.size());
+        size_t widest_shard = 0;  // rows as wide as the largest shard any member can produce: nothing to predict, nothing ever short
+        for (int k = 0; k < n; k++) {
+            size_t list_words = 0;
+            uint32_t widest_pool = 0;
+            if (int rc = shard_need(ctxs[k], items_of[k], item_count, &list_words, &widest_pool))
+                return rc;
+            widest_shard = std::max(widest_shard, list_words + (batched ? item_count : 0u));
+        }
+        if (widest_shard > 0xFFFFFC00u)
+            return ctxs[0]->fail(GV_E_ARG, "gv_exchange_visible_all: a frame of %zu words per rank", widest_shard);
+        const uint32_t entries = std::max<uint32_t>((uint32_t)widest_shard, 3u);
+        for (int k = 0; k < n; k++)
+            if (int rc = frame_stage(ctxs[k], items_of[k], item_count, batched, ctxs[k]->exchange_slots[which], entries))
+                return rc;
+        if (int rc = peer_collective(ctxs, n, which))
+            return rc;
+        for (int k = 0; k < n; k++)
+            if (int rc = frame_finish(ctxs[k], ctxs[k]->exchange_slots[which], outs ? outs + k : nullptr))
+                return rc;
+        return GV_OK;
+    }
     for (int k = 0; k < n; k++)
         if (int rc = frame_stage(ctxs[k], items_of[k], item_count, batched, ctxs[k]->exchange_slots[which]))
             return rc;
     int rc = GV_OK;
+    Rccl& r = rccl();
     (void)r.GroupStart();
     for (int k = 0; k < n && rc == GV_OK; k++) {
         if (hipSetDevice(ctxs[k]->device) != hipSuccess)

@@ -198,6 +198,12 @@ hipError_t launch_copy_shard_batch(const ShardItem* device_items, uint32_t n, ui
 // looks at the word a frame or two later
 hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uint32_t world, uint32_t hdr_words, uint32_t* host_words, uint32_t seq,
                                    hipStream_t stream);
+// GV_EXCHANGE_PEER: the 1 + shard[0] leading words of a rank's staging shard (at most cap_words) into its row of EVERY rank's rows
+// (rows.dst[r]: this rank's row in rank r's buffer — the rank's own, or a peer device's over xGMI), one launch
+struct PeerRows {
+    uint32_t* dst[64];  // GV_EXCHANGE_MAX_RANKS (garden_vis.h; asserted in gv_exchange.cpp)
+};
+hipError_t launch_peer_scatter(const uint32_t* shard, uint32_t cap_words, const PeerRows& rows, uint32_t world, hipStream_t stream);
 // gv_results_fetch of a pool of up to kPublishMaxSlots slots: device results -> pinned host buffers in one launch
 // (up to kPublishLdsSlots slots the isVisible bytes are put back into pool-slot order in LDS by the same kernel)
 constexpr uint32_t kPublishMaxSlots = 262144;

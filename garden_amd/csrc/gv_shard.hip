@@ -112,4 +112,33 @@ hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uin
     return hipGetLastError();
 }
 
+// GV_EXCHANGE_PEER (gv_exchange_init_peers): what an all-gatherv is on a fully connected node whose devices one process holds —
+// every rank stores its list into its row of every rank's rows. The length is read from the shard's own header (1 + shard[0] words:
+// the count, a batched frame's table, the lists), so only what the lists really hold crosses a link and the host predicts
+// nothing. 16-byte stores; a workgroup's piece goes to all destinations before the next piece (every link busy at once, the piece
+// read once). Shard and rows are 16-byte aligned (hipMalloc; row strides are multiples of 4 words).
+__global__ __launch_bounds__(256) void peer_scatter_kernel(const uint32_t* __restrict__ shard, uint32_t cap_words, PeerRows rows, uint32_t world)
+{
+    const uint32_t words = min(1u + shard[0], cap_words), quads = words >> 2;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(shard);
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < quads; q += gridDim.x * 256) {
+        const uint4 v = src[q];
+        for (uint32_t r = 0; r < world; r++)
+            reinterpret_cast<uint4*>(rows.dst[r])[q] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (words & 3u)) {
+        const uint32_t w = (quads << 2) + threadIdx.x, v = shard[w];
+        for (uint32_t r = 0; r < world; r++)
+            rows.dst[r][w] = v;
+    }
+}
+
+hipError_t launch_peer_scatter(const uint32_t* shard, uint32_t cap_words, const PeerRows& rows, uint32_t world, hipStream_t stream)
+{
+    // (the list's length is the device's knowledge: the grid covers the capacity at 16 quads per lane, workgroups beyond the list leave at once)
+    const uint32_t blocks = std::max(1u, std::min(1024u, (cap_words / 4u + 256u * 16u - 1u) / (256u * 16u)));
+    hipLaunchKernelGGL(peer_scatter_kernel, dim3(blocks), dim3(256), 0, stream, shard, cap_words, rows, world);
+    return hipGetLastError();
+}
+
 }  // namespace gv

@@ -148,6 +148,10 @@ public:
     // Several ranks: time each travel pattern of the exchange (all-gather / send-recv pairs / one broadcast per root) over the first
     // frames and keep the fastest (SURVEY.md §8e argues for the direct patterns on a fully connected node; only a node can tell).
     bool probeExchangeMode = false;
+    // Several ranks: how the lists travel between the devices of this one process. Auto: direct stores into every rank's rows
+    // (gv_exchange_init_peers — no communicator, nothing predicted, nothing to probe) where every device reaches every other, a
+    // communicator (gv_exchange_init_all: RCCL) otherwise. Set before the "Init" event.
+    enum class ExchangeTransport { Auto, Peers, Communicator } exchangeTransport = ExchangeTransport::Auto;
     // Several ranks: roots whose position has crossed into a cell of another rank take their trees there (rank_shares.hpp moveTree)
     bool rebinMovedRoots = true;
 
@@ -265,8 +269,16 @@ private:
             ECSM_SUBSCRIBE_TO_EVENT("PreForwardRender", GpuVisibilitySystem::preRender);
         if (manager->hasEvent("PreDeferredRender"))
             ECSM_SUBSCRIBE_TO_EVENT("PreDeferredRender", GpuVisibilitySystem::preRender);
-        if (contexts.size() > 1)  // one thread, N ranks: the communicator is made inside one group
-            check(gv_exchange_init_all(contexts.data(), (int)contexts.size()), "gv_exchange_init_all");
+        if (contexts.size() > 1) {
+            // one thread, N ranks: peer stores between the devices of this process, or a communicator made inside one group
+            int rc = exchangeTransport == ExchangeTransport::Communicator ? GV_E_STATE : gv_exchange_init_peers(contexts.data(), (int)contexts.size());
+            if (rc != GV_OK && (exchangeTransport == ExchangeTransport::Peers || rc != GV_E_STATE))
+                check(rc, "gv_exchange_init_peers");
+            if (rc == GV_OK)
+                exchangeMode = GV_EXCHANGE_PEER;
+            else
+                check(gv_exchange_init_all(contexts.data(), (int)contexts.size()), "gv_exchange_init_all");
+        }
     }
 
     static bool isSortedType(MeshRenderType type) noexcept
@@ -906,7 +918,7 @@ private:
 
 public:
     double exchangeModeProbeMs[3] = {0, 0, 0};  // probeExchangeMode: milliseconds per exchange by GvExchangeMode (0: not probed)
-    uint32_t exchangeMode = GV_EXCHANGE_ALLGATHER;
+    uint32_t exchangeMode = GV_EXCHANGE_ALLGATHER;  // GV_EXCHANGE_PEER: the ranks store into each other's rows (exchangeTransport)
 
     // (public for tests/cpp/rank_shares_test.cpp: the merge is checked on the CPU against std::sort)
     // The ranks' runs of one list -> dst[0, total): each rank's records arrive in sortMeshes order (gv_pool_sort), so one pass that
@@ -1089,7 +1101,7 @@ private:
                 }
             if (!items.empty()) {
                 Stopwatch watch(tickSeconds.gather);
-                if (probeExchangeMode && !exchangeModeChosen) {
+                if (probeExchangeMode && !exchangeModeChosen && exchangeMode != GV_EXCHANGE_PEER) {
                     chooseExchangeMode(items, frames);
                     exchangeModeChosen = true;
                 }

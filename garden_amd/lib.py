@@ -27,7 +27,7 @@ GV_CONFIG_LINEAR_SCAN = 32
 GV_DIRTY_TRANSFORM, GV_DIRTY_HIERARCHY, GV_DIRTY_MESH = 0, 1, 2
 GV_SWEEP_VALU, GV_SWEEP_MFMA, GV_SWEEP_WITH_CULL, GV_SWEEP_WITH_CULL_VALU, GV_SWEEP_INCREMENTAL = 0, 1, 2, 3, 4
 GV_MEM_HOST, GV_MEM_DEVICE = 0, 1
-GV_EXCHANGE_ALLGATHER, GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST = 0, 1, 2
+GV_EXCHANGE_ALLGATHER, GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST, GV_EXCHANGE_PEER = 0, 1, 2, 3
 KERNEL_NAMES = ["cull", "scan", "emit", "hiz", "sweep", "sort"]
 
 
@@ -132,7 +132,7 @@ EXPORTS = [
     "gv_stream", "gv_debug_stream_peak",
     "gv_scene_parse_json", "gv_scene_parse_bson", "gv_scene_destroy", "gv_scene_info", "gv_scene_transform_columns", "gv_scene_mesh_columns",
     "gv_scene_bind", "gv_scene_extract_tile", "gv_scene_extract_rank", "gv_cell_owner", "gv_scene_tile_maps",
-    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_pool_exchange_visible", "gv_pool_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
+    "gv_exchange_unique_id", "gv_exchange_init", "gv_exchange_init_all", "gv_exchange_init_peers", "gv_exchange_shards", "gv_exchange_visible", "gv_exchange_visible_all", "gv_pool_exchange_visible", "gv_pool_exchange_visible_all", "gv_exchange_acquire", "gv_exchange_acquire_all", "gv_exchange_set_timeout", "gv_exchange_masks", "gv_exchange_shutdown", "gv_exchange_set_mode", "gv_pool_set_index_map",
     "gv_exchange_views", "gv_exchange_views_all", "gv_pool_update_index_map", "gv_pool_set_result_mapping", "gv_host_parallel_ranges", "gv_host_parallel_tasks",
     "gv_pool_results_fetch", "gv_pool_result_count", "gv_pool_results_device", "gv_pool_sort",
     "gv_cull_batch_begin", "gv_cull_batch_end", "gv_pool_set_record_layout", "gv_pool_results_records", "gv_pool_set_record_target",
@@ -215,6 +215,7 @@ def load():
     lib.gv_exchange_visible.argtypes = [P, u32, u32, u32, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_acquire.argtypes = [P, C.c_uint64, C.POINTER(GvExchangeFrame)]
     lib.gv_exchange_init_all.argtypes = [C.POINTER(P), C.c_int]
+    lib.gv_exchange_init_peers.argtypes = [C.POINTER(P), C.c_int]
     lib.gv_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]
     lib.gv_pool_exchange_visible.argtypes = [P, u32, u32, u32, u32, C.POINTER(GvExchangeFrame)]
     lib.gv_pool_exchange_visible_all.argtypes = [C.POINTER(P), C.c_int, u32, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(GvExchangeFrame)]

@@ -370,6 +370,18 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id_128_bytes, int rank, int 
  * started with one form is used through that form only (per-rank calls from N threads or processes, or the *_all calls from one). */
 int gv_exchange_init_all(GvCtx* const* contexts, int world_size);
 
+/* One process, N GPUs, NO communicator: the devices of a node reach each other over xGMI with plain stores, so the ranks one thread
+ * drives need neither RCCL nor a size prediction. gv_exchange_init_peers checks and enables peer access between every pair of the
+ * contexts' devices (contexts may share a device) and fixes the travel pattern GV_EXCHANGE_PEER: per frame ONE kernel per rank
+ * writes the words its list really has — known on the device, never on the host — from its staging shard straight into its row of
+ * EVERY rank's rows (wide stores, all links at once), ordered between the ranks by events alone. Rows have room for a rank's whole
+ * pool, so no frame is ever cut and nothing travels twice: tail_words / cut_ranks stay 0, room[r] = the row's capacity in entries,
+ * travelled_words[r] (acquired frames) = 1 + counts[r]. Everything else — gv_exchange_visible_all / gv_exchange_views_all /
+ * gv_exchange_acquire_all, the headers on the host, the bounded waits, alternating buffers — is as for the other patterns.
+ * GV_E_STATE: some device cannot reach another (use gv_exchange_init_all). gv_exchange_shutdown / gv_destroy of ONE member drains
+ * every member's exchange stream and dissolves the group (the others return GV_E_STATE until they are initialised again). */
+int gv_exchange_init_peers(GvCtx* const* contexts, int world_size);
+
 /* The per-frame exchange — the gather of mesh.cpp:177-183, which never loses a record: EVERY frame a consumer can acquire holds
  * every rank's complete list.
  *
@@ -471,7 +483,8 @@ int gv_exchange_shutdown(GvCtx* ctx);
 typedef enum GvExchangeMode {
     GV_EXCHANGE_ALLGATHER = 0, /* one equal-size ncclAllGather */
     GV_EXCHANGE_P2P = 1,       /* one ncclGroup of ncclSend/ncclRecv pairs with every peer */
-    GV_EXCHANGE_BROADCAST = 2  /* one ncclBroadcast per root, grouped */
+    GV_EXCHANGE_BROADCAST = 2, /* one ncclBroadcast per root, grouped */
+    GV_EXCHANGE_PEER = 3       /* gv_exchange_init_peers only: direct stores into every rank's rows, no communicator */
 } GvExchangeMode;
 int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode);
 

@@ -416,6 +416,8 @@ int main(int argc, char** argv)
     std::string gate;        // --gate never|shadow|reverse|empty (see the head of this file)
     uint32_t ranks = 1;      // --ranks R: the drop-in's multi-GPU mode, R contexts driven by this one thread
     bool sameFrame = false;      // --same-frame: both systems in one Manager::update() (see the head of this file)
+    bool communicator = false;   // --communicator (with --ranks): the ranks' lists travel through a communicator (gv_exchange_init_all: RCCL, or the tests' transport named
+                                 // by GV_RCCL_LIBRARY) instead of the drop-in's default for the devices of one process, peer stores (gv_exchange_init_peers)
     bool probeExchange = false;  // --probe-exchange (with --ranks): the drop-in times the three travel patterns on its first frame and keeps the fastest
     bool noRebin = false;        // --no-rebin (with --ranks): roots that cross cells stay on their rank (the balance decays; results are the same)
     bool unversioned = false;  // --unversioned: the mesh systems carry no change counters (like every mesh system of the reference)
@@ -448,6 +450,7 @@ int main(int argc, char** argv)
         else if (a == "--animate" && i + 1 < argc) animate = (uint32_t)atoi(argv[++i]);
         else if (a == "--animate-step" && i + 1 < argc) animateStep = (float)atof(argv[++i]);
         else if (a == "--probe-exchange") probeExchange = true;
+        else if (a == "--communicator") communicator = true;
         else if (a == "--same-frame") sameFrame = true;
         else if (a == "--no-rebin") noRebin = true;
         else if (a == "--csm") csmPasses = true;
@@ -580,6 +583,8 @@ int main(int argc, char** argv)
             gpu->recordTargets = !copyRecords;
             gpu->recordSpans = spanRecords;
             gpu->probeExchangeMode = probeExchange;
+            if (communicator)
+                gpu->exchangeTransport = GpuVisibilitySystem::ExchangeTransport::Communicator;
             gpu->rebinMovedRoots = !noRebin;
         }
         if (gpu && world)

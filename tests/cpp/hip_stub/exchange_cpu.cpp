@@ -1,4 +1,4 @@
-// TEST-ONLY (see hip/hip_runtime.h): host stand-ins for the three launch functions the exchange step's HOST half depends on
+// TEST-ONLY (see hip/hip_runtime.h): host stand-ins for the launch functions the exchange step's HOST half depends on
 // for its decisions — the shard copy and the row headers that size later frames (garden_amd/csrc/gv_exchange.cpp) — so that
 // gv_exchange_visible / gv_exchange_shards run for real under the sanitizers with several ranks (threads) over
 // tests/cpp/rccl_stub. "Device" memory is host memory here. Never linked into the product library.
@@ -51,6 +51,14 @@ hipError_t launch_exchange_headers(const uint32_t* rows, uint32_t row_words, uin
             host_words[1u + (size_t)r * hdr_words + w] = rows[(size_t)r * row_words + w];
     std::atomic_thread_fence(std::memory_order_release);
     host_words[0] = seq;
+    return hipSuccess;
+}
+
+hipError_t launch_peer_scatter(const uint32_t* shard, uint32_t cap_words, const PeerRows& rows, uint32_t world, hipStream_t)
+{
+    const uint32_t words = std::min(1u + shard[0], cap_words);
+    for (uint32_t r = 0; r < world; r++)
+        std::copy(shard, shard + words, rows.dst[r]);
     return hipSuccess;
 }
 

@@ -15,7 +15,7 @@
 #include <cstring>
 
 typedef int hipError_t;
-enum : int { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600 };
+enum : int { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704 };
 typedef struct HipStubStream* hipStream_t;
 typedef struct HipStubEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -36,6 +36,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "stub error"; }
 

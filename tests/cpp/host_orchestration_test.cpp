@@ -928,6 +928,136 @@ static void exchange_in_one_thread(int ranks, int list_seed)
                 ranks, list_seed, cut_frames / ranks);
 }
 
+// ONE thread, N contexts, NO communicator (gv_exchange_init_peers, GV_EXCHANGE_PEER): every rank's list is stored straight into its row
+// of every member's rows. No transport library is loaded; rows are as wide as the pools, so no frame is ever short whatever the
+// lists do — every acquired frame complete with cut_ranks == 0, travelled_words == 1 + count.
+static void exchange_by_peers(int ranks, int list_seed)
+{
+    g_list_seed = list_seed;
+    std::vector<ExchangeRank> xs(ranks);
+    std::vector<GvCtx*> ctxs;
+    for (int r = 0; r < ranks; r++) {
+        if (!xs[r].create(r, ranks))
+            std::exit(1);
+        ctxs.push_back(xs[r].ctx);
+    }
+    GvCtx* ctx = ctxs[0];
+    std::vector<uint32_t> views(ranks, 0u);
+    std::vector<GvExchangeFrame> sent(ranks), got(ranks);
+    GvExchangeFrame one;
+    EXPECT(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()), GV_E_STATE);  // nothing initialised yet
+    EXPECT(gv_exchange_set_mode(ctxs[0], GV_EXCHANGE_PEER), GV_E_ARG);                                        // not without a peer group
+    CHECK(gv_exchange_init_peers(ctxs.data(), ranks));
+    EXPECT(gv_exchange_set_mode(ctxs[0], GV_EXCHANGE_ALLGATHER), GV_E_ARG);  // a peer group has no communicator to travel by
+    CHECK(gv_exchange_set_mode(ctxs[0], GV_EXCHANGE_PEER));
+    if (ranks > 1) {
+        EXPECT(gv_exchange_visible(ctxs[0], 0, 0, 0, &one), GV_E_STATE);  // one thread drives the group through the *_all calls
+        std::vector<GvCtx*> swapped = ctxs;
+        std::swap(swapped[0], swapped[1]);
+        for (int r = 0; r < ranks; r++)
+            xs[r].produce(0, GV_EXCHANGE_PEER);
+        EXPECT(gv_exchange_visible_all(swapped.data(), ranks, views.data(), nullptr, 0, sent.data()), GV_E_ARG);  // not in rank order
+    }
+    auto check_rows = [&](int frame, int list) {
+        for (int r = 0; r < ranks; r++) {
+            const GvExchangeFrame& f = got[r];
+            if (!f.complete || !f.gathered_device || !f.ready_event || f.frame != (uint64_t)frame || f.mode != GV_EXCHANGE_PEER || f.cut_ranks || f.row_words % 4u ||
+                f.world_size != (uint32_t)ranks)
+                xs[r].fail("fields of an acquired peer frame", frame, -1);
+            const uint32_t* rows = (const uint32_t*)f.gathered_device;
+            for (int q = 0; q < ranks; q++) {
+                const uint32_t* row = rows + (size_t)q * f.row_words;
+                const uint32_t count = list_count(q, list, ExchangeRank::n);
+                if (row[0] != count || f.counts[q] != count || f.tail_words[q] || f.travelled_words[q] != 1u + count || f.room[q] + 1u > f.row_words || count > f.room[q])
+                    xs[r].fail("header / count / statistics of a peer row", frame, q);
+                for (uint32_t k = 0; k < count; k++)
+                    if (row[1 + k] != list_value(q, list, k)) {
+                        xs[r].fail("entry of a peer row", frame, q);
+                        break;
+                    }
+            }
+        }
+    };
+    int frame = 0;
+    for (; frame < 18; frame++) {  // list_count's scripted sequence creeps, jumps ninefold at 7 and collapses at 14
+        for (int r = 0; r < ranks; r++)
+            xs[r].produce(frame, GV_EXCHANGE_PEER);
+        CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+        for (int r = 0; r < ranks; r++)
+            if (sent[r].complete || sent[r].gathered_device || sent[r].mode != GV_EXCHANGE_PEER || sent[r].frame != (uint64_t)frame)
+                xs[r].fail("fields of a peer frame that was sent, not acquired", frame, -1);
+        if (frame % 3 == 2)
+            continue;  // (settled by the next exchange; acquired a frame late below)
+        if (frame % 3 == 0 && frame > 0) {
+            CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame - 1, got.data()));
+            check_rows(frame - 1, frame - 1);
+        }
+        CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+        check_rows(frame, frame);
+    }
+    // ONE exchange for two lists per rank (gv_exchange_views_all): count table behind the header, lists back to back
+    const GvExchangeItem items[2] = {{0u, 0u, 0u}, {1u, 0u, 5u}};
+    for (; frame < 24; frame++) {
+        const int list = frame % 2 ? 9 : 3;
+        for (int r = 0; r < ranks; r++) {
+            xs[r].produce(list, GV_EXCHANGE_PEER);
+            xs[r].cull_other_pool();
+        }
+        CHECK(gv_exchange_views_all(ctxs.data(), ranks, items, 2, 0, sent.data()));
+        CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()));
+        for (int r = 0; r < ranks; r++) {
+            const GvExchangeFrame& f = got[r];
+            if (!f.complete || f.items != 2 || !f.item_counts || f.cut_ranks)
+                xs[r].fail("fields of a batched peer frame", frame, -1);
+            const uint32_t* rows = (const uint32_t*)f.gathered_device;
+            for (int q = 0; q < ranks && f.complete; q++) {
+                const uint32_t* row = rows + (size_t)q * f.row_words;
+                const uint32_t c0 = list_count(q, list, ExchangeRank::n), c1 = ExchangeRank::other_count;
+                bool ok = row[0] == 2 + c0 + c1 && f.counts[q] == row[0] && row[1] == c0 && row[2] == c1 && f.item_counts[q * 2] == c0 && f.item_counts[q * 2 + 1] == c1 &&
+                          f.travelled_words[q] == 1u + row[0];
+                for (uint32_t k = 0; k < c0 && ok; k++)
+                    ok = row[3 + k] == list_value(q, list, k);
+                for (uint32_t k = 0; k < c1 && ok; k++)
+                    ok = row[3 + c0 + k] == 4200u + (uint32_t)q + k + 5u;
+                if (!ok)
+                    xs[r].fail("a batched peer row", frame, q);
+            }
+        }
+    }
+    // one member leaves: the group is dissolved — the others answer GV_E_STATE until they are initialised again
+    ctx = ctxs[ranks - 1];
+    CHECK(gv_exchange_shutdown(ctx));
+    ctx = ctxs[0];
+    EXPECT(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()), GV_E_STATE);
+    CHECK(gv_exchange_init_peers(ctxs.data(), ranks));  // ... and a new group starts from frame 0
+    for (int r = 0; r < ranks; r++)
+        xs[r].produce(5, GV_EXCHANGE_PEER);
+    CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+    CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, 0, got.data()));
+    check_rows(0, 5);
+    if (std::getenv("GV_RCCL_LIBRARY")) {  // the same contexts under a communicator afterwards: the default pattern, not the group's
+        CHECK(gv_exchange_init_all(ctxs.data(), ranks));
+        for (int r = 0; r < ranks; r++)
+            xs[r].produce(6, GV_EXCHANGE_P2P);
+        CHECK(gv_exchange_visible_all(ctxs.data(), ranks, views.data(), nullptr, 0, sent.data()));
+        CHECK(gv_exchange_acquire_all(ctxs.data(), ranks, 0, got.data()));
+        for (int r = 0; r < ranks; r++) {
+            got[r].frame = sent[r].frame = 6;  // (check_acquired derives the expected list from the frame number: list 6 travelled as frame 0)
+            xs[r].check_acquired(sent[r], got[r], 6);
+        }
+    }
+    int failures = 0;
+    for (int r = 0; r < ranks; r++) {
+        failures += xs[r].failures;
+        gv_destroy(xs[r].ctx);  // (no shutdown first: destroying a member drains and dissolves the group itself)
+    }
+    if (failures) {
+        std::fprintf(stderr, "exchange by peer stores, %d ranks: %d failures\n", ranks, failures);
+        std::exit(1);
+    }
+    std::printf("exchange by peer stores (no communicator), ONE thread, %d ranks, list sequence %d: ok — 24 frames, none short\n", ranks, list_seed);
+}
+
 // The FIRST frame of a communicator carries several lists (gv_exchange_views_all) under a direct travel pattern: there is no history,
 // every room is 0 — the count tables must still arrive with the headers (round 6: they travelled with the tails, and the frame
 // reported the counts of whatever the rows had held before).
@@ -1557,6 +1687,10 @@ int main(int argc, char** argv)
         exchange_in_one_thread(2 + seed % 3, seed);
     for (uint32_t mode : {GV_EXCHANGE_P2P, GV_EXCHANGE_BROADCAST, GV_EXCHANGE_ALLGATHER})
         batched_first_frame(3, mode);
+    for (int ranks : {1, 2, 4, 8})
+        exchange_by_peers(ranks, 0);
+    for (int seed = 1; seed <= 6; seed++)
+        exchange_by_peers(2 + seed % 3, seed);
     {  // the host workers as the shim uses them: every task exactly once, every item of a range exactly once
         std::vector<std::atomic<uint32_t>> ran(1000);
         for (uint32_t count : {0u, 1u, 7u, 1000u}) {

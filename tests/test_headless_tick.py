@@ -188,7 +188,17 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
     ["--entities", "20000", "--ranks", "4", "--hier", "--animate", "2", "--animate-step", "157.5", "--itemised", "--ticks", "8", "--expect-moved-trees"],
     ["--entities", "20000", "--ranks", "4", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--expect-moved-trees"],
     ["--entities", "20000", "--ranks", "3", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--no-rebin"],
-    ["--entities", "20000", "--ranks", "4", "--mixed", "--csm", "--probe-exchange"],
+    ["--entities", "20000", "--ranks", "4", "--mixed", "--csm", "--probe-exchange", "--communicator"],
+    # the same mode with the lists travelling through a communicator (gv_exchange_init_all; here the tests' transport) instead of the
+    # peer stores one process uses by default: predicted rooms, rows completed by a second exchange
+    ["--entities", "40000", "--ranks", "4", "--communicator"],
+    ["--entities", "30000", "--ranks", "3", "--mixed", "--hier", "--communicator"],
+    ["--entities", "20000", "--ranks", "3", "--mixed", "--hier", "--churn", "3", "--communicator"],
+    ["--entities", "60000", "--ranks", "8", "--csm", "--communicator"],
+    ["--entities", "50000", "--ranks", "4", "--hiz", "--mixed", "--hier", "--communicator"],
+    ["--entities", "30000", "--ranks", "4", "--mixed", "--csm", "--unversioned", "--animate", "3", "--ticks", "5", "--communicator"],
+    ["--entities", "20000", "--ranks", "4", "--hier", "--mixed", "--animate", "3", "--animate-step", "211", "--ticks", "6", "--expect-moved-trees", "--communicator"],
+    ["--entities", "2000000", "--ranks", "8", "--mixed", "--csm", "--ticks", "2", "--threads", "16", "--communicator"],
     ["--entities", "20000", "--ranks", "2", "--soa-records", "--mixed", "--hier"],  # records through the three-array fetch
     # the frame after a destroy as the engine presents it (--same-frame): components still in their pools, entities gone
     ["--entities", "30000", "--ranks", "4", "--hier", "--mutate", "--churn", "6", "--same-frame"],
@@ -204,9 +214,10 @@ def test_gpu_dropin_matches_cpu_system(tick, args):
 def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
     """The drop-in's own multi-GPU mode — ONE process, ONE thread, N contexts (the reference is one process with one Manager,
     source/editor/entry.cpp:135): the pools are dealt to the ranks (rank_shares.hpp: roots by position, descendants follow), every
-    rank culls its share, ALL the frame's lists are gathered on the devices by ONE gv_exchange_views_all / _acquire_all (here all ranks
-    share the box's GPU and the rows travel through the test transport) and the engine's buffers are filled from the ranks'
-    results. Checked: every buffer and isVisible of the whole pools == the CPU system's (headless_tick --mode both), every rank
+    rank culls its share, ALL the frame's lists are gathered on the devices by ONE gv_exchange_views_all / _acquire_all — by default
+    with NO communicator: every rank's scatter kernel stores its lists into its row of every rank's rows (gv_exchange_init_peers; here
+    all ranks share the box's GPU, on a node the stores cross xGMI); with --communicator through gv_exchange_init_all and the test
+    transport — and the engine's buffers are filled from the ranks' results. Checked: every buffer and isVisible of the whole pools == the CPU system's (headless_tick --mode both), every rank
     holds the same gathered rows, and their union is the set of world slots the pass's buffer holds."""
     stub = os.path.join(ROOT, "tests", "cpp", "build", "librccl_stub.so")
     env_before = os.environ.get("GV_RCCL_LIBRARY")
@@ -221,6 +232,7 @@ def test_gpu_dropin_multi_gpu_mode_one_process_one_thread(tick, args):
         else:
             os.environ["GV_RCCL_LIBRARY"] = env_before
     assert out["ok"] and out["draw_count"] > 0, out
+    assert (out["exchange_mode"] == 3) == ("--communicator" not in args), out  # GV_EXCHANGE_PEER unless a communicator was asked for
     # ONE exchange per frame (the reference waits once per prepareMeshes, mesh.cpp:548), seen by the consumer's callback too
     assert out["exchanges"] == out["rank_frames"] == out["exchanges_seen"] or "--probe-exchange" in args, out
     if "--probe-exchange" in args:

@@ -513,6 +513,7 @@ def test_host_orchestration_and_exchange_under_thread_sanitizer(tmp_path):
     text = run.stdout + run.stderr
     assert run.returncode == 0 and "host orchestration: ok" in run.stdout and "ThreadSanitizer" not in text, text[-4000:]
     assert run.stdout.count("exchange over the stub transport") == 4 + 24 and run.stdout.count("exchange driven by ONE thread") == 3 + 6
+    assert run.stdout.count("exchange by peer stores (no communicator)") == 4 + 6
 
 
 def test_rank_shares_under_address_and_ub_sanitizers(tmp_path):
@@ -587,6 +588,9 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     batched = [l for l in run.stdout.splitlines() if l.startswith("batched exchange (gv_exchange_views_all)")]
     assert len(batched) == 3 + 6 and all("6 frames acquired" in l for l in batched), batched
     assert run.stdout.count("first batched frame of a communicator, 3 ranks") == 3  # (p2p / broadcast / all-gather from frame 0: the tables arrive with the headers)
+    # ... and the same calls with NO communicator (gv_exchange_init_peers: direct stores into every member's rows), 1 / 2 / 4 / 8 ranks +
+    # six random list sequences: no frame ever short, a member leaving dissolves the group, a new group / a communicator afterwards
+    assert run.stdout.count("exchange by peer stores (no communicator)") == 4 + 6 and "ONE thread, 8 ranks, list sequence 0: ok — 24 frames, none short" in run.stdout
     print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange ")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
