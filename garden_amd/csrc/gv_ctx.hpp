@@ -392,6 +392,7 @@ struct Context {
         std::vector<uint32_t> item_counts;  // settled: [world][items] per-list counts (GvExchangeFrame::item_counts)
         PinnedBuf<ShardItem> h_items;  // the frame's list descriptors on their way to d_items
         DeviceBuf<ShardItem> d_items;
+        std::vector<ShardItem> items_uploaded, items_wanted;  // what d_items holds (empty: unknown) / this frame's descriptors
         uint32_t row_words = 0;
         uint32_t room[GV_EXCHANGE_MAX_RANKS] = {};        // list entries rank r's row was predicted to need in this slot's frame
         uint32_t travelled[GV_EXCHANGE_MAX_RANKS] = {};   // words of row r on the links in the first exchange

@@ -223,6 +223,7 @@ void exchange_release(GvCtx* ctx)
         slot.items = 0;
         slot.hdr_words = 1;
         slot.item_counts.clear();
+        slot.items_uploaded.clear();
         if (slot.produced)
             (void)hipEventDestroy(slot.produced);
         if (slot.done)
@@ -916,14 +917,23 @@ int frame_stage(GvCtx* ctx, const GvExchangeItem* items, uint32_t item_count, bo
             return rc;
         GV_HIP(ctx, slot.h_items.reserve(GV_EXCHANGE_MAX_ITEMS));
         GV_HIP(ctx, slot.d_items.reserve(GV_EXCHANGE_MAX_ITEMS));
+        // the descriptors change when a pool grows or a view's buffers move — rarely: a frame whose descriptors are what this slot's
+        // device table already holds skips the copy (one small DMA less in front of every frame's shard)
+        std::vector<gv::ShardItem>& want = slot.items_wanted;
+        want.resize(item_count);
         for (uint32_t i = 0; i < item_count; i++) {
             const gv::ViewState& vs = *gv::view_of(ctx, items[i].pool_id, items[i].view_index);
             const gv::PoolState& pool = ctx->pools[vs.pool_id];
-            slot.h_items.ptr[i] = gv::ShardItem{vs.visible_idx.ptr, vs.draw_count.ptr, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr,
-                                                items[i].index_base, vs.occupancy};
+            want[i] = gv::ShardItem{vs.visible_idx.ptr, vs.draw_count.ptr, pool.index_map_count >= vs.occupancy ? pool.d_index_map.ptr : nullptr,
+                                    items[i].index_base, vs.occupancy};
         }
-        // (h_items of this slot is free: the copy that read it last ran in front of the slot's previous frame, which is settled)
-        GV_HIP(ctx, hipMemcpyAsync(slot.d_items.ptr, slot.h_items.ptr, (size_t)item_count * sizeof(gv::ShardItem), hipMemcpyHostToDevice, ctx->stream));
+        if (slot.items_uploaded.size() != want.size() || memcmp(slot.items_uploaded.data(), want.data(), want.size() * sizeof(gv::ShardItem)) != 0) {
+            // (h_items of this slot is free: the copy that read it last ran in front of the slot's previous frame, which is settled)
+            memcpy(slot.h_items.ptr, want.data(), want.size() * sizeof(gv::ShardItem));
+            slot.items_uploaded.clear();  // (not known to be there until the copy has been enqueued)
+            GV_HIP(ctx, hipMemcpyAsync(slot.d_items.ptr, slot.h_items.ptr, (size_t)item_count * sizeof(gv::ShardItem), hipMemcpyHostToDevice, ctx->stream));
+            slot.items_uploaded = want;
+        }
         GV_HIP(ctx, gv::launch_copy_shard_batch(slot.d_items.ptr, item_count, widest_pool, slot.shard.ptr, ctx->stream));
     }
     GV_HIP(ctx, hipEventRecord(slot.produced, ctx->stream));

@@ -762,6 +762,9 @@ private:
         bool structural = rankShares.shares.size() != ranks || ranksSeen.hierarchy != transformSystem->hierarchyVersion || ranksSeen.meshSystems != meshSystems;
         ranksSeen.meshVersion.resize(meshSystems.size(), ~0ull);
         rankChanges.reset(ranks, meshSystems.size());
+        std::vector<uint32_t> moved;
+        bool everything = false;
+        try {
         if (!structural) {
             // Mesh components: the slots a system names, or — no counters, or "the whole pool may have changed" — every slot, compared
             // with the ranks' copies in the bytes the cull reads; a slot that holds another entity than the shares know is listed
@@ -796,8 +799,6 @@ private:
                 structural = !rankShares.followEntities(transformSystem, meshSystems, ranks, rankGrid, worldSide, std::move(transformSlots), changedHands,
                                                         relinked ? transformSystem->reparentLo : 0u, relinked ? transformSystem->reparentHi : 0u, rankChanges);
         }
-        std::vector<uint32_t> moved;
-        bool everything = false;
         if (!structural) {  // transforms: every slot, or the itemised ones; roots that crossed into another rank's cell take their trees along
             if (seenTransform != transformSystem->transformVersion) {
                 everything = true;
@@ -813,6 +814,9 @@ private:
             }
             if (rebinMovedRoots && (everything || !moved.empty()))
                 rankShares.rebin(transformSystem, moved, everything, ranks, rankGrid, worldSide, rankChanges);
+        }
+        } catch (const std::runtime_error&) {
+            structural = true;  // a state the slot-by-slot steps cannot carry over (a link across ranks nobody announced): dealt again, never half-followed
         }
         if (structural) {
             rankShares.deal(transformSystem, meshSystems, ranks, rankGrid, worldSide);
@@ -1100,15 +1104,17 @@ private:
                     lists.push_back(GatheredList{p, plan[p].passes[v]});
                 }
             if (!items.empty()) {
-                Stopwatch watch(tickSeconds.gather);
-                if (probeExchangeMode && !exchangeModeChosen && exchangeMode != GV_EXCHANGE_PEER) {
-                    chooseExchangeMode(items, frames);
-                    exchangeModeChosen = true;
+                {
+                    Stopwatch watch(tickSeconds.gather);
+                    if (probeExchangeMode && !exchangeModeChosen && exchangeMode != GV_EXCHANGE_PEER) {
+                        chooseExchangeMode(items, frames);
+                        exchangeModeChosen = true;
+                    }
+                    check(gv_exchange_views_all(contexts.data(), (int)ranks, items.data(), (uint32_t)items.size(), 0, frames.data()), "gv_exchange_views_all");
+                    check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
+                    rankCounters.exchanges++;
                 }
-                check(gv_exchange_views_all(contexts.data(), (int)ranks, items.data(), (uint32_t)items.size(), 0, frames.data()), "gv_exchange_views_all");
-                check(gv_exchange_acquire_all(contexts.data(), (int)ranks, frames[0].frame, frames.data()), "gv_exchange_acquire_all");
-                rankCounters.exchanges++;
-                if (onGathered)
+                if (onGathered)  // (the consumer's own time: not the gather's)
                     onGathered(lists.data(), (uint32_t)lists.size(), frames.data(), ranks);
             }
         }

@@ -305,7 +305,9 @@ struct RankShares {
             for (uint32_t j = 0; j < meshOccupancy; j++) {
                 const auto* component = reinterpret_cast<const MeshRenderComponent*>(data + (size_t)j * stride);
                 const uint32_t entity = *component->entity;
-                const uint32_t transformSlot = entity && entity < emap.size() && emap[entity] < occupancy ? emap[entity] : GV_NONE;
+                uint32_t transformSlot = entity && entity < emap.size() && emap[entity] < occupancy ? emap[entity] : GV_NONE;
+                if (transformSlot != GV_NONE && rankOfTransform[transformSlot] == GV_NONE)
+                    transformSlot = GV_NONE;  // (a slot its entity no longer resolves to lives nowhere: the mesh has no transform, as in placeMesh)
                 const uint32_t rank = transformSlot != GV_NONE ? rankOfTransform[transformSlot] : j % ranks;
                 MeshShare& share = shares[rank].meshes[p];
                 const size_t at = share.components.size();

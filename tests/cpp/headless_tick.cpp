@@ -527,7 +527,9 @@ int main(int argc, char** argv)
             else
                 gpu = manager.createSystem<GpuVisibilitySystem>(0, false, bounds);
         }
-        if (gpu && ranks > 1)
+        // (a timing run — --mode gpu with GV_TICK_BREAKDOWN — does not read every rank's rows back every frame: that check, ~10 ms per
+        // frame at 10^6 entities, is --mode both's, which the tests run)
+        if (gpu && ranks > 1 && (mode == "both" || !getenv("GV_TICK_BREAKDOWN")))
             gpu->onGathered = [&](const GpuVisibilitySystem::GatheredList* lists, uint32_t listCount, const GvExchangeFrame* frames, uint32_t n) {
                 // ONE frame of the exchange carries every list of the tick: row q = [listCount + total, c_0 .. c_{listCount-1}, list 0, list 1 ...]
                 std::vector<std::vector<uint32_t>> rows(n);
