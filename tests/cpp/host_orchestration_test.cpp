@@ -1408,10 +1408,10 @@ static int growth_sequence(GvCtx* ctx, World& small, World& grown, bool tolerate
 // that creep, jump (a short prediction: the rows are widened for the tails) and collapse. Whatever allocation fails, the call says
 // GV_E_OOM, nothing leaks (ASan), and the SAME frame can be tried again: every acquired frame holds the whole list.
 static long g_exchange_fail = 0, g_exchange_allocations = 0;
-static int exchange_sequence(GvCtx* ctx, ExchangeRank& x, bool stop_at_failure, int* completed_frames)
+static int exchange_sequence(GvCtx* ctx, ExchangeRank& x, bool stop_at_failure, int* completed_frames, bool peers = false)
 {
     for (int frame = 0; frame < 10; frame++) {
-        x.produce(frame < 5 ? frame : frame + 4, (uint32_t)(frame % 3));  // (frames 7.. of the scripted sequence jump)
+        x.produce(frame < 5 ? frame : frame + 4, peers ? (uint32_t)GV_EXCHANGE_PEER : (uint32_t)(frame % 3));  // (frames 7.. of the scripted sequence jump)
         const int list_frame = frame < 5 ? frame : frame + 4;
         GvExchangeFrame sent, got;
         bool was_sent = false;
@@ -1458,9 +1458,9 @@ static int exchange_sequence(GvCtx* ctx, ExchangeRank& x, bool stop_at_failure, 
     return GV_OK;
 }
 
-static void exchange_allocation_failures()
+static void exchange_allocation_failures(bool peers)
 {
-    if (!std::getenv("GV_RCCL_LIBRARY"))
+    if (!peers && !std::getenv("GV_RCCL_LIBRARY"))
         return;
     g_list_seed = 0;
     long total = 0;
@@ -1470,12 +1470,16 @@ static void exchange_allocation_failures()
         if (!x.create(0, 1))
             std::exit(1);
         GvCtx* ctx = x.ctx;
-        unsigned char id[GV_EXCHANGE_ID_BYTES];
-        CHECK(gv_exchange_unique_id(id));
-        CHECK(gv_exchange_init(ctx, id, 0, 1));
+        if (peers) {
+            CHECK(gv_exchange_init_peers(&ctx, 1));  // (a group of one: the same rows, staged and scattered by the peer pattern)
+        } else {
+            unsigned char id[GV_EXCHANGE_ID_BYTES];
+            CHECK(gv_exchange_unique_id(id));
+            CHECK(gv_exchange_init(ctx, id, 0, 1));
+        }
         g_exchange_fail = k;  // 0: nothing fails (that run counts the exchange's allocations)
         g_exchange_allocations = 0;
-        exchange_sequence(ctx, x, true, &failed_calls);
+        exchange_sequence(ctx, x, true, &failed_calls, peers);
         if (k == 0)
             total = g_exchange_allocations;
         CHECK(gv_exchange_shutdown(ctx));
@@ -1483,8 +1487,8 @@ static void exchange_allocation_failures()
         if (k >= total)
             break;
     }
-    std::printf("allocation failures in the exchange: %ld allocations failed in turn, %d calls reported it, every frame was acquired whole all the same: ok\n",
-                total, failed_calls);
+    std::printf("allocation failures in the exchange%s: %ld allocations failed in turn, %d calls reported it, every frame was acquired whole all the same: ok\n",
+                peers ? " (peer stores)" : "", total, failed_calls);
 }
 
 static void allocation_failures()
@@ -1717,7 +1721,8 @@ int main(int argc, char** argv)
         std::printf("host workers (gv_host_parallel_tasks / _ranges): ok\n");
     }
     allocation_failures();
-    exchange_allocation_failures();
+    exchange_allocation_failures(false);
+    exchange_allocation_failures(true);
     exchange_bounded_waits();
     std::printf("host orchestration: ok\n");
     return 0;

@@ -597,6 +597,7 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     # ... and every allocation of the exchange step (rows, staging shard, widened rows for the tails) failing in turn: GV_E_OOM, the
     # same frame tried again, acquired whole
     assert "allocation failures in the exchange:" in run.stdout and "acquired whole all the same: ok" in run.stdout, run.stdout[-2000:]
+    assert "allocation failures in the exchange (peer stores):" in run.stdout, run.stdout[-2000:]  # ... and of a peer group's frames
     # ... and the bounded waits with work that NEVER finishes (streams that never drain, events that never complete): GV_E_TIMEOUT
     # inside the limit on every context of the call, GV_E_STATE afterwards, shutdown / destroy release everything, the context recovers
     assert "exchange, bounded waits:" in run.stdout and "the context recovers: ok" in run.stdout, run.stdout[-2000:]
