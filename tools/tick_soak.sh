@@ -3,8 +3,8 @@
 # seeds and flag combinations — the mirror's maintenance paths under entity churn, re-parenting, toggles, moving scenes.
 # Round 6: the multi-GPU mode kept current slot by slot (--unversioned: mesh systems without change counters; --animate-step: roots
 # that cross cells take their trees to another rank). Round 5: the prepareMeshes gate (--gate: systems that are not ready / ready for some passes only / empty, each system also checked
-# against the reference text; --skip-pass: a shadow pass left out by prepareShadowRender) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts, rows over the test transport).
-#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 30 flag sets)
+# against the reference text; --skip-pass: a shadow pass left out by prepareShadowRender) and the drop-in's multi-GPU mode (--ranks N: one thread, N contexts; the rows travel by peer stores, with --communicator over the test transport).
+#   tools/tick_soak.sh [SEEDS]      (default 40 seeds x 33 flag sets)
 set -u
 cd "$(dirname "$0")/.."
 make -s -C tests/cpp
@@ -39,6 +39,9 @@ sets=(
   "--entities 30000 --hier --mutate --churn 6 --same-frame"
   "--entities 20000 --mixed --hier --csm --churn 4 --same-frame --ranks 4"
   "--entities 40000 --hier --churn 8 --same-frame --ranks 3 --unversioned --ticks 2"
+  "--entities 24000 --ranks 4 --mixed --csm --churn 2 --communicator"
+  "--entities 20000 --ranks 3 --mixed --hier --animate 5 --itemised --ticks 4 --communicator"
+  "--entities 16000 --ranks 2 --hier --mixed --animate 3 --animate-step 230 --ticks 5 --churn 2 --communicator"
   "--entities 20000 --mixed --csm --gate shadow --skip-pass 1 --churn 3"
   "--entities 16000 --mixed --gate reverse --skip-pass 0 --hier --mutate"
 )
