@@ -170,29 +170,12 @@ std::vector<uint32_t> oracle_visible(std::vector<Transform>& tr, std::vector<Mes
     return all;
 }
 
-int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, bool check_oracle,
-             bool batched, int id_in, int id_out, Shared* shared)
+// rank `rank`'s share of the world: a slab along x, unit cubes at uniform positions
+void build_slab(int rank, int ranks, uint32_t n, std::vector<Transform>& tr, std::vector<Mesh>& me, std::vector<uint32_t>& e2t)
 {
-    auto die = [&](const char* what, GvCtx* ctx) {
-        fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
-        return 1;
-    };
-    int devices = 0;
-    if (hipGetDeviceCount(&devices) != hipSuccess || devices == 0) {
-        fprintf(stderr, "rank %d: no device\n", rank);
-        return 1;
-    }
-    GvConfig config{};
-    config.struct_size = sizeof(config);
-    config.device = rank % devices;
-    GvCtx* ctx = nullptr;
-    if (gv_create(&config, &ctx) != GV_OK)
-        return die("gv_create", nullptr);
-
-    // this rank's share of the world: a slab along x
-    std::vector<Transform> tr(n);
-    std::vector<Mesh> me(n);
-    std::vector<uint32_t> e2t(n + 1, GV_NONE);
+    tr.assign(n, Transform{});
+    me.assign(n, Mesh{});
+    e2t.assign((size_t)n + 1, GV_NONE);
     uint32_t seed = 12345u + 977u * (uint32_t)rank;
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) * (1.0f / 16777216.0f); };
     const float side = 100.0f * std::cbrt((float)n * (float)ranks), slab = side / (float)ranks;
@@ -213,6 +196,232 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
             me[i].mx[k] = 0.5f;
         }
     }
+}
+
+// The frame's camera: the same on every rank — a hash of the seed and the frame (a new lens and direction every frame), or a camera
+// that turns a little every frame and cuts to the opposite direction half way.
+void frame_views(uint32_t camera_seed, int frame, int frames, bool batched, GvView both[2])
+{
+    if (camera_seed) {
+        uint32_t h = camera_seed * 2654435761u + (uint32_t)frame * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float yaw = 6.2831853f * (float)(h & 0xFFFFu) / 65536.0f;
+        const float zoom = std::exp(3.47f * ((float)((h >> 16) & 0xFFFFu) / 65536.0f) - 1.735f);  // 0.18 .. 5.7: 160 .. 20 degrees
+        make_view(yaw, &both[0], zoom);
+    } else {
+        make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &both[0]);
+    }
+    both[1] = both[0];
+    if (batched) {  // the second list: the same lens turned by a quarter
+        if (camera_seed)
+            make_view(1.5707963f + 0.37f * (float)frame, &both[1]);
+        else
+            make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f) + 1.5707963f, &both[1]);
+    }
+}
+
+// --peers: ONE process, ONE thread, R contexts and NO communicator (gv_exchange_init_peers: every rank's scatter kernel stores its
+// lists into its row of every rank's rows) — the same frames as the per-process ranks below, asynchronously: every third frame is
+// acquired only after the next one has been sent. Everything lives in this process, so every row of every rank is compared WORD
+// FOR WORD with its owner's own fetched list(s); --check-oracle: frame 0 and the cut against the CPU oracle as well.
+int run_peers(int ranks, uint32_t n, int frames, uint32_t camera_seed, bool check_oracle, bool batched)
+{
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices == 0) {
+        fprintf(stderr, "no device\n");
+        return 1;
+    }
+    struct Rank {
+        GvCtx* ctx = nullptr;
+        std::vector<Transform> tr;
+        std::vector<Mesh> me;
+        std::vector<uint32_t> e2t;
+        std::vector<std::vector<uint32_t>> own;  // [frame & 3]: the row this rank's lists make, header included
+    };
+    std::vector<Rank> rs(ranks);
+    std::vector<GvCtx*> ctxs;
+    auto die = [&](const char* what, int r) {
+        fprintf(stderr, "peers, rank %d: %s: %s\n", r, what, gv_last_error(rs[r].ctx));
+        return 1;
+    };
+    const GvTransformLayout tl = {0, 4, 16, 32, 48, 72, 73, 74};
+    const GvMeshLayout ml = {0, 14, 15, 16, 32};
+    for (int r = 0; r < ranks; r++) {
+        GvConfig config{};
+        config.struct_size = sizeof(config);
+        config.device = r % devices;
+        if (gv_create(&config, &rs[r].ctx) != GV_OK)
+            return die("gv_create", r);
+        build_slab(r, ranks, n, rs[r].tr, rs[r].me, rs[r].e2t);
+        if (gv_transform_bind(rs[r].ctx, rs[r].tr.data(), sizeof(Transform), n, &tl, rs[r].e2t.data(), n + 1) != GV_OK ||
+            gv_pool_bind(rs[r].ctx, 0, rs[r].me.data(), sizeof(Mesh), n, &ml) != GV_OK)
+            return die("bind", r);
+        rs[r].own.resize(4);
+        ctxs.push_back(rs[r].ctx);
+    }
+    if (gv_exchange_init_peers(ctxs.data(), ranks) != GV_OK)
+        return die("gv_exchange_init_peers", 0);
+    int mismatches = 0, oracle_checked_frames = 0, acquired = 0;
+    uint64_t gathered_last = 0, list_words = 0, link_words = 0;
+    std::vector<GvExchangeFrame> sent(ranks), got(ranks);
+    std::vector<uint32_t> host;
+    auto acquire = [&](int frame) -> int {
+        if (gv_exchange_acquire_all(ctxs.data(), ranks, (uint64_t)frame, got.data()) != GV_OK)
+            return die("gv_exchange_acquire_all", 0);
+        gathered_last = 0;
+        for (int r = 0; r < ranks; r++) {
+            const GvExchangeFrame& f = got[r];
+            if (!f.complete || !f.gathered_device || !f.ready_event || f.frame != (uint64_t)frame || f.mode != GV_EXCHANGE_PEER || f.cut_ranks || f.row_words % 4u ||
+                f.items != (batched ? 2u : 0u)) {
+                fprintf(stderr, "peers, rank %d frame %d: fields of an acquired frame\n", r, frame);
+                return 1;
+            }
+            if (hipSetDevice(r % devices) != hipSuccess || hipStreamSynchronize((hipStream_t)gv_stream(ctxs[r])) != hipSuccess)
+                return 1;
+            for (int q = 0; q < ranks; q++) {
+                const std::vector<uint32_t>& want = rs[q].own[frame & 3];
+                // (rows are as wide as the pools: only what the frame says a row holds is read back, and one word more)
+                const size_t words = std::min<size_t>((size_t)f.counts[q] + 2u, f.row_words);
+                host.resize(words);
+                if (hipMemcpy(host.data(), (const uint32_t*)f.gathered_device + (size_t)q * f.row_words, words * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                    return 1;
+                const uint32_t* row = host.data();
+                if (f.counts[q] != want[0] || f.travelled_words[q] != 1u + want[0] || f.tail_words[q] || want.size() > f.row_words ||
+                    want.size() > words || memcmp(row, want.data(), want.size() * 4) != 0) {
+                    fprintf(stderr, "peers, frame %d: rank %d holds row %d with header %u (the frame says %u); rank %d's own list has %u words%s\n", frame, r, q, row[0],
+                            f.counts[q], q, want[0], row[0] == want[0] ? ": contents differ" : "");
+                    mismatches++;
+                }
+                if (r == 0) {
+                    gathered_last += want[0] - (batched ? 2u : 0u);
+                    list_words += want.size();
+                    link_words += f.travelled_words[q];
+                }
+            }
+        }
+        acquired++;
+        return 0;
+    };
+    int late = -1;
+    for (int frame = 0; frame < frames; frame++) {
+        GvView both[2];
+        frame_views(camera_seed, frame, frames, batched, both);
+        for (int r = 0; r < ranks; r++) {
+            if (gv_cull(ctxs[r], 0, both, batched ? 2 : 1) != GV_OK)
+                return die("gv_cull", r);
+        }
+        const bool with_oracle = check_oracle && (frame == 0 || frame == frames / 2);
+        for (int r = 0; r < ranks; r++) {  // the row this rank's lists make, from its own fetch
+            const uint32_t base = (uint32_t)r * n;
+            std::vector<uint32_t>& row = rs[r].own[frame & 3];
+            row.clear();
+            GvResult res{};
+            if (gv_results_fetch(ctxs[r], 0, 0, &res) != GV_OK)
+                return die("gv_results_fetch", r);
+            if (with_oracle) {
+                std::vector<uint32_t> mine(res.visible_idx, res.visible_idx + res.draw_count);
+                std::sort(mine.begin(), mine.end());
+                if (mine != oracle_visible(rs[r].tr, rs[r].me, rs[r].e2t, both[0], std::max(2u, std::thread::hardware_concurrency()))) {
+                    fprintf(stderr, "peers, rank %d frame %d: the rank's list is not the oracle's visible set of its share\n", r, frame);
+                    mismatches++;
+                }
+            }
+            if (!batched) {
+                row.push_back(res.draw_count);
+                for (uint32_t k = 0; k < res.draw_count; k++)
+                    row.push_back(res.visible_idx[k] + base);
+            } else {
+                row.assign({0u, res.draw_count, 0u});
+                for (uint32_t k = 0; k < res.draw_count; k++)
+                    row.push_back(res.visible_idx[k] + base);
+                GvResult second{};
+                if (gv_pool_results_fetch(ctxs[r], 0, 1, 0, &second) != GV_OK)
+                    return die("gv_results_fetch", r);
+                row[2] = second.draw_count;
+                for (uint32_t k = 0; k < second.draw_count; k++)
+                    row.push_back(second.visible_idx[k] + base);
+                row[0] = (uint32_t)row.size() - 1u;
+            }
+        }
+        oracle_checked_frames += with_oracle ? 1 : 0;
+        std::vector<uint32_t> views(ranks, 0u), bases(ranks);
+        for (int r = 0; r < ranks; r++)
+            bases[r] = (uint32_t)r * n;
+        int rc;
+        if (batched) {
+            // (one item list for all ranks: the per-rank base travels through the pool's index map instead — identity + r * n)
+            for (int r = 0; r < ranks && frame == 0; r++) {
+                std::vector<uint32_t> map(n);
+                for (uint32_t i = 0; i < n; i++)
+                    map[i] = i + bases[r];
+                if (gv_pool_set_index_map(ctxs[r], 0, map.data(), n) != GV_OK)
+                    return die("gv_pool_set_index_map", r);
+            }
+            const GvExchangeItem items[2] = {{0u, 0u, 0u}, {0u, 1u, 0u}};
+            rc = gv_exchange_views_all(ctxs.data(), ranks, items, 2, 0, sent.data());
+        } else {
+            rc = gv_exchange_visible_all(ctxs.data(), ranks, views.data(), bases.data(), 0, sent.data());
+        }
+        if (rc != GV_OK)
+            return die("gv_exchange_*_all", 0);
+        if (late >= 0) {  // the previous frame, acquired a frame late
+            if (acquire(late))
+                return 1;
+            late = -1;
+        }
+        if (frame % 3 == 2 && frame + 1 < frames)
+            late = frame;
+        else if (acquire(frame))
+            return 1;
+    }
+    // one member is destroyed without a shutdown: the group is drained and dissolved, the others answer GV_E_STATE
+    gv_destroy(ctxs[ranks - 1]);
+    if (ranks > 1) {
+        std::vector<uint32_t> views(ranks, 0u);
+        if (gv_exchange_visible_all(ctxs.data(), ranks - 1, views.data(), nullptr, 0, sent.data()) != GV_E_STATE) {
+            fprintf(stderr, "peers: a group that lost a member still exchanges\n");
+            mismatches++;
+        }
+    }
+    for (int r = 0; r + 1 < ranks; r++)
+        gv_destroy(ctxs[r]);
+    if (check_oracle && oracle_checked_frames < 2)
+        mismatches++;
+    if (acquired != frames)
+        mismatches++;
+    const bool ok = mismatches == 0;
+    printf("{\"ranks\": %d, \"frames\": %d, \"entities_per_rank\": %u, \"ok\": %s, \"failed_ranks\": 0, \"mismatches\": %d, \"frames_with_a_second_exchange\": 0, "
+           "\"short_rows_completed\": 0, \"tail_words\": 0, \"timed_out_ranks\": 0, \"gathered_last_frame\": %llu, \"words_on_links_over_list_words\": %.3f, "
+           "\"oracle_checked_frames\": %d, \"transport\": \"peer stores, one process\"}\n",
+           ranks, frames, n, ok ? "true" : "false", mismatches, (unsigned long long)gathered_last, list_words ? (double)link_words / (double)list_words : 0.0,
+           oracle_checked_frames);
+    return ok ? 0 : 1;
+}
+
+int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stall_rank, bool abandon, bool abandon_by_destroy, uint32_t camera_seed, bool check_oracle,
+             bool batched, int id_in, int id_out, Shared* shared)
+{
+    auto die = [&](const char* what, GvCtx* ctx) {
+        fprintf(stderr, "rank %d: %s: %s\n", rank, what, gv_last_error(ctx));
+        return 1;
+    };
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices == 0) {
+        fprintf(stderr, "rank %d: no device\n", rank);
+        return 1;
+    }
+    GvConfig config{};
+    config.struct_size = sizeof(config);
+    config.device = rank % devices;
+    GvCtx* ctx = nullptr;
+    if (gv_create(&config, &ctx) != GV_OK)
+        return die("gv_create", nullptr);
+
+    // this rank's share of the world: a slab along x
+    std::vector<Transform> tr;
+    std::vector<Mesh> me;
+    std::vector<uint32_t> e2t;
+    build_slab(rank, ranks, n, tr, me, e2t);
     const GvTransformLayout tl = {0, 4, 16, 32, 48, 72, 73, 74};
     const GvMeshLayout ml = {0, 14, 15, 16, 32};
     if (gv_transform_bind(ctx, tr.data(), sizeof(Transform), n, &tl, e2t.data(), n + 1) != GV_OK ||
@@ -333,24 +542,10 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
             break;
         }
         // the camera turns a little every frame; half way it cuts to the opposite direction (lists jump: predictions fall short)
-        GvView view;
-        if (camera_seed) {  // (the same camera on every rank: a hash of the seed and the frame)
-            uint32_t h = camera_seed * 2654435761u + (uint32_t)frame * 40503u;
-            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
-            const float yaw = 6.2831853f * (float)(h & 0xFFFFu) / 65536.0f;
-            const float zoom = std::exp(3.47f * ((float)((h >> 16) & 0xFFFFu) / 65536.0f) - 1.735f);  // 0.18 .. 5.7: 160 .. 20 degrees
-            make_view(yaw, &view, zoom);
-        } else {
-            make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f), &view);
-        }
         const uint32_t mode = mode_arg >= 0 ? (uint32_t)mode_arg : (uint32_t)(frame % 3);
-        GvView both[2] = {view, view};
-        if (batched) {  // the second list: the same lens turned by a quarter
-            if (camera_seed)
-                make_view(1.5707963f + 0.37f * (float)frame, &both[1]);
-            else
-                make_view(0.05f * (float)frame + (frame >= frames / 2 ? 3.14159265f : 0.0f) + 1.5707963f, &both[1]);
-        }
+        GvView both[2];
+        frame_views(camera_seed, frame, frames, batched, both);
+        const GvView view = both[0];
         if (gv_exchange_set_mode(ctx, mode) != GV_OK || gv_cull(ctx, 0, both, batched ? 2 : 1) != GV_OK)
             return die("cull", ctx);
         FrameSummary& fs = shared->frames[rank][frame];
@@ -469,7 +664,7 @@ int run_rank(int rank, int ranks, uint32_t n, int frames, int mode_arg, int stal
 int main(int argc, char** argv)
 {
     int ranks = 1, frames = 12, mode = -1, stall_rank = -1;
-    bool abandon = false, abandon_by_destroy = false, check_oracle = false, batched = false;
+    bool abandon = false, abandon_by_destroy = false, check_oracle = false, batched = false, peers = false;
     uint32_t camera_seed = 0;
     bool auto_ranks = false;
     uint32_t n = 100000;
@@ -489,6 +684,8 @@ int main(int argc, char** argv)
             stall_rank = atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--batched")) {
             batched = true;
+        } else if (!strcmp(argv[i], "--peers")) {
+            peers = true;
         } else if (!strcmp(argv[i], "--check-oracle")) {
             check_oracle = true;
         } else if (!strcmp(argv[i], "--abandon")) {
@@ -520,6 +717,8 @@ int main(int argc, char** argv)
     }
     if (ranks < 1 || ranks > kMaxRanks || frames < 4 || frames > kMaxFrames)
         return 2;
+    if (peers)  // one process, no communicator: nothing is forked
+        return run_peers(ranks, n, frames, camera_seed, check_oracle, batched);
     Shared* shared = (Shared*)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (shared == MAP_FAILED)
         return 2;

@@ -257,6 +257,30 @@ def _exchange_ranks(ranks, entities, env=None, extra=()):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,extra", [(1, ()), (2, ("--random-camera", "7")), (3, ("--batched",)), (4, ("--random-camera", "11", "--batched")),
+                                         (8, ("--random-camera", "5")), (8, ("--check-oracle", "--frames", "8"))])
+def test_native_exchange_by_peer_stores_one_process(ranks, extra):
+    """tests/cpp/exchange_ranks --peers: ONE process, ONE thread, N contexts and NO communicator (gv_exchange_init_peers /
+    GV_EXCHANGE_PEER) — every rank's scatter kernel stores its list(s) into its row of every rank's rows (here within the box's GPU; on a
+    node over xGMI). Frames behind a camera that turns and cuts (or a new lens and direction every frame), every third frame acquired
+    only after the next has been sent; every row of every rank is compared word for word with its owner's own fetched list(s); no
+    frame is ever short; a member destroyed without a shutdown dissolves the group."""
+    out = _exchange_ranks(ranks, 60000, extra=("--peers", *extra))
+    assert out["ranks"] == ranks and out["mismatches"] == 0 and out["transport"].startswith("peer stores") and out["gathered_last_frame"] > 0
+    assert out["frames_with_a_second_exchange"] == 0 and abs(out["words_on_links_over_list_words"] - 1.0) < 1e-9  # exactly the lists travel
+    if "--check-oracle" in extra:
+        assert out["oracle_checked_frames"] >= 2
+
+
+@pytest.mark.gpu
+def test_cfg5_in_its_shape_by_peer_stores_against_the_oracle():
+    """BASELINE cfg5 in its shape — 8 ranks of 12.5 M entities — through the one-process peer path: frame 0 and the cut against the CPU
+    oracle on every rank (oracle_checked_frames >= 2), every row of every rank word for word its owner's list."""
+    out = _exchange_ranks(8, 12_500_000, extra=("--peers", "--check-oracle", "--frames", "6"))
+    assert out["mismatches"] == 0 and out["oracle_checked_frames"] >= 2 and out["gathered_last_frame"] > 1_000_000
+
+
+@pytest.mark.gpu
 def test_native_exchange_driver_one_process_per_gpu():
     """tests/cpp/exchange_ranks: the exchange through the C-ABI alone (fork per rank, unique id over pipes, RCCL bound at
     run time) with one rank per GPU of the box — `--ranks auto` = min(GPUs, 8): a 1-rank communicator on the 1-GPU boxes of the

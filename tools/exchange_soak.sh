@@ -24,4 +24,16 @@ for ranks in 2 3 4 8; do
     done
   done
 done
+# the same cameras through the one-process peer path (gv_exchange_init_peers: no communicator; every row of every rank compared word
+# for word with its owner's own list)
+pruns=0; pbad=0
+for ranks in 2 3 4 8; do
+  for seed in $(seq 1 $seeds); do
+    batched=""; [ $((seed % 2)) = 0 ] && batched="--batched"
+    line=$(timeout 300 ./tests/cpp/build/exchange_ranks --peers --ranks $ranks --entities 40000 --frames 32 --random-camera $((seed * 131 + ranks)) $batched 2>>$out.err | tail -1)
+    pruns=$((pruns + 1))
+    echo "$line" | grep -q '"ok": true' || { pbad=$((pbad + 1)); echo "FAILED peers ranks $ranks seed $seed: $line" >> $out; }
+  done
+done
+echo "exchange soak, peer stores (one process, no communicator): $pruns runs (2 / 3 / 4 / 8 ranks x $seeds random cameras, 32 frames each, every other camera with two lists per frame): $pbad failed" | tee -a $out
 echo "exchange soak: $runs runs (2 / 3 / 4 / 8 ranks x $seeds random cameras x 4 travel settings, 32 frames each, 40 000 entities per rank; every other camera with two lists per frame in one exchange): $bad failed; $frames frames, $second of them needed a second exchange ($rows short rows completed, $tails words in tails); every row of every frame == its owner's whole list on every rank" | tee -a $out
