@@ -62,29 +62,42 @@ static int sort_buffers_of(GvCtx* ctx, ViewState& vs, SortBuffers& b)
     return GV_OK;
 }
 
-// gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort)
-static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
+// gv_sort of a pool too large for the one-launch batch: the record count on the device picks rank or radix sort (launch_sort).
+// sort_large_prepare: the view's buffers and what to enqueue for it; sort_large_done: the sorted records are the view's records.
+static int sort_large_prepare(GvCtx* ctx, ViewState& vs, bool descending, SortBatchEntry& e)
 {
-    GV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = vs.occupancy;
-    SortBuffers b;
-    if (int rc = sort_buffers_of(ctx, vs, b))
+    if (int rc = sort_buffers_of(ctx, vs, e.b))
         return rc;
     // the previous frame's count says what to enqueue for a mid-sized pool: a short list gets the rank sort alone
-    const SortMode mode = vs.count_hint == 0xFFFFFFFFu ? kSortBoth
-                          : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
-                          : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
-    if (!sort_is_rank_only((uint32_t)n, mode))
+    e.mode = vs.count_hint == 0xFFFFFFFFu ? kSortBoth
+             : vs.count_hint <= kRankOnlyHintRecords ? kSortRankOnly
+             : vs.count_hint > 2 * kRankSortMaxRecords ? kSortRadixOnly : kSortBoth;
+    e.capacity = (uint32_t)n;
+    e.descending = descending ? 1u : 0u;
+    if (!sort_is_rank_only((uint32_t)n, e.mode))
         vs.sort_parity ^= 1u;  // the radix passes leave the other set of counters zeroed for the next sort
-    {
-        KernelTimer t(ctx, GV_K_SORT);
-        GV_HIP(ctx, launch_sort(b, (uint32_t)n, descending, ctx->stream, mode));
-    }
+    return GV_OK;
+}
+static void sort_large_done(ViewState& vs)
+{
     vs.published = false, vs.records_fetched = false;
     // the sorted records now live in the alternate set: swap it in
     std::swap(vs.visible_idx, vs.alt_idx);
     std::swap(vs.baked_model, vs.alt_model);
     std::swap(vs.distance_sq, vs.alt_dist);
+}
+static int sort_large(GvCtx* ctx, ViewState& vs, bool descending)
+{
+    GV_HIP(ctx, hipSetDevice(ctx->device));
+    SortBatchEntry e{};
+    if (int rc = sort_large_prepare(ctx, vs, descending, e))
+        return rc;
+    {
+        KernelTimer t(ctx, GV_K_SORT);
+        GV_HIP(ctx, launch_sort(e.b, e.capacity, descending, ctx->stream, e.mode));
+    }
+    sort_large_done(vs);
     return GV_OK;
 }
 
@@ -178,6 +191,35 @@ int flush_sorts(GvCtx* ctx)
 {
     if (int rc = flush_culls(ctx))  // the records about to be sorted / read may still be waiting to be culled
         return rc;
+    // Mid-sized pools (beyond the one-launch batch, up to kMidSortMaxSlots slots): ALL the pending lists of the frame by ONE set of
+    // launches — the rank-sort launch and the eight radix launches with blockIdx.y = list (launch_sort_batch). A frame of seven mesh
+    // systems x four passes at 10^5 slots each was 150-250 short dependent launches, ~2 ms of a 4 ms tick.
+    for (;;) {
+        SortBatchEntry batch[kMaxSortBatch];
+        ViewState* taken[kMaxSortBatch];
+        uint32_t n = 0;
+        for (uint32_t pool = 0; pool < GV_MAX_POOLS && n < kMaxSortBatch; pool++)
+            for (uint32_t v = 0; v < GV_MAX_VIEWS && n < kMaxSortBatch; v++) {
+                ViewState& vs = ctx->views[pool][v];
+                if (!vs.valid || !vs.sort_pending || vs.occupancy <= kBatchSortMaxSlots)
+                    continue;
+                const bool descending = vs.sort_pending == 2;
+                vs.sort_pending = 0;
+                if (int rc = sort_large_prepare(ctx, vs, descending, batch[n]))
+                    return rc;
+                taken[n++] = &vs;
+            }
+        if (n == 0)
+            break;
+        GV_HIP(ctx, hipSetDevice(ctx->device));
+        {
+            ZoneScope zone("Meshes Sort");
+            KernelTimer t(ctx, GV_K_SORT);
+            GV_HIP(ctx, launch_sort_batch(batch, n, ctx->stream));
+        }
+        for (uint32_t k = 0; k < n; k++)
+            sort_large_done(*taken[k]);
+    }
     for (;;) {
         uint32_t widest = 0, views = 0;
         ViewState* taken[kMaxPublishViews];
@@ -202,13 +244,6 @@ int flush_sorts(GvCtx* ctx)
                 ViewState& vs = ctx->views[pool][v];
                 if (!vs.valid || !vs.sort_pending)
                     continue;
-                if (vs.occupancy > kBatchSortMaxSlots) {  // deferred (its cull may have been recorded), but not a batch member
-                    const bool descending = vs.sort_pending == 2;
-                    vs.sort_pending = 0;
-                    if (int rc = sort_large(ctx, vs, descending))
-                        return rc;
-                    continue;
-                }
                 const size_t n = vs.occupancy;
                 GV_HIP(ctx, vs.alt_idx.reserve(n));
                 GV_HIP(ctx, vs.alt_model.reserve(n * 12));
@@ -877,7 +912,9 @@ int gv_pool_sort(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int descendi
     ViewState& vs = *view_of(ctx, pool_id, view_index);
     if (vs.occupancy == 0)
         return GV_OK;
-    if (vs.occupancy <= kSmallSortMaxSlots) {  // launched with the other views' sorts when the records are asked for
+    // launched with the other views' sorts when the records are asked for: small pools share one launch, mid-sized ones one set of
+    // launches (flush_sorts)
+    if (vs.occupancy <= kMidSortMaxSlots) {
         vs.sort_pending = descending ? 2 : 1;
         vs.published = false, vs.records_fetched = false;
         return GV_OK;

@@ -223,7 +223,7 @@ __device__ __forceinline__ void sort_rank_tile(const SortPassArgs& a, const uint
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(kSortThreads) void sort_rank_kernel(const SortPassArgs a)
+__device__ __forceinline__ void sort_rank_body(const SortPassArgs& a)
 {
     __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counts of the tile
     const uint32_t n = min(*a.count, a.capacity);
@@ -236,6 +236,25 @@ __global__ __launch_bounds__(kSortThreads) void sort_rank_kernel(const SortPassA
         sort_rank_tile<FIRST, kShortTile>(a, n, wcount);
     else
         sort_rank_tile<FIRST, kSortTile>(a, n, wcount);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void sort_rank_kernel(const SortPassArgs a)
+{
+    sort_rank_body<FIRST>(a);
+}
+
+// Several lists per launch (launch_sort_batch): blockIdx.y picks the list, everything else is the single-list kernel — every list
+// has its own buffers, counters and device-side count; a list shorter than the grid's widest leaves its surplus workgroups at once.
+// N: entries in the argument (a launch pays for the size of its arguments).
+template <uint32_t N>
+struct SortPassBatch {
+    SortPassArgs list[N];
+};
+template <bool FIRST, uint32_t N>
+__global__ __launch_bounds__(kSortThreads) void sort_rank_batch_kernel(const SortPassBatch<N> batch)
+{
+    sort_rank_body<FIRST>(batch.list[blockIdx.y]);
 }
 
 struct SortScatterLds {
@@ -383,7 +402,7 @@ __device__ __forceinline__ void sort_scatter_tile(const SortPassArgs& a, const u
 }
 
 template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPassArgs a)
+__device__ __forceinline__ void sort_scatter_body(const SortPassArgs& a)
 {
     __shared__ SortScatterLds lds;
     const uint32_t n = min(*a.count, a.capacity);
@@ -393,6 +412,17 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPa
         sort_scatter_tile<FIRST, LAST, kShortTile>(a, n, lds);
     else
         sort_scatter_tile<FIRST, LAST, kSortTile>(a, n, lds);
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPassArgs a)
+{
+    sort_scatter_body<FIRST, LAST>(a);
+}
+template <bool FIRST, bool LAST, uint32_t N>
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_batch_kernel(const SortPassBatch<N> batch)
+{
+    sort_scatter_body<FIRST, LAST>(batch.list[blockIdx.y]);
 }
 
 // Small pools (up to kSmallSort records possible): ONE launch instead of fourteen — a tick of an engine-sized scene
@@ -618,34 +648,42 @@ __global__ __launch_bounds__(256) void sort_small_batch_kernel(const SortBatchN<
     sort_small_block(e, e.capacity, e.descending, blockIdx.x, 0xFFFFFFFFu, e.fused_publish ? &e.publish : nullptr);
 }
 
-hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode)
+// the rank-sort launch of launch_sort for several mid-sized lists at once (launch_sort_batch): blockIdx.y picks the list
+struct MidRankEntry {
+    SortBuffers b;
+    uint32_t capacity, descending, max_records, table;
+};
+template <uint32_t N>
+struct MidRankBatch {
+    MidRankEntry list[N];
+};
+template <uint32_t N>
+__global__ __launch_bounds__(256) void sort_mid_rank_batch_kernel(const MidRankBatch<N> batch)
 {
-    if (capacity == 0)
-        return hipSuccess;
-    // kSortRankOnly (the caller expects a short list: the previous frame's count): a mid-sized pool gets the rank-sort launch
-    // alone — the eight radix launches that would leave after one load each are ~16 us of an engine-sized tick — and a
-    // list that outgrew the key table after all is still sorted by it, from memory (count_before_global)
-    const bool rank_only = sort_is_rank_only(capacity, mode);
-    // Short lists sort in one launch whatever the pool's size: a pool of up to kMidSortSlots slots (where only the device
-    // knows how short the visible list is) gets the rank-sort launch AND the radix launches, and the live count decides on
-    // the device which of the two does the work — the other leaves after one load, ~2 us per launch, against 70 us for
-    // the eight radix launches on a few thousand records. Measured crossover: ~12 k records (rank 11 us at 2 k, 75 us at
-    // 16 k, 160 us at 32 k).
-    const bool rank_sort = capacity <= kMidSortSlots && (mode != kSortRadixOnly || capacity <= kSmallSort);
-    if (rank_sort) {
-        const uint32_t records = capacity <= kSmallSort ? capacity : (rank_only ? kRankOnlyTableRecords : kRankSortMaxRecords);
-        const uint32_t lds = ((records + 3u) & ~3u) * 4;  // the key table, beside the 1 KB of partial counts
-        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_kernel),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
-        if (raised != hipSuccess)
-            return raised;
-        hipLaunchKernelGGL(sort_small_kernel, dim3(((rank_only ? capacity : records) + 63) / 64), dim3(256), lds, stream, b, capacity,
-                           descending ? 1u : 0u, rank_only ? 0xFFFFFFFFu : records, records);
-        if (capacity <= kSmallSort || rank_only)
-            return hipGetLastError();
-    }
-    const uint32_t tiles = sort_tile_count(capacity);  // at full capacity (long or short tiles); the live count is on the device
-    SortPassArgs a{};
+    const MidRankEntry& e = batch.list[blockIdx.y];
+    sort_small_block(e.b, e.capacity, e.descending, blockIdx.x, e.max_records, nullptr, e.table);
+}
+
+// what launch_sort decides on the host for one list: whether it gets the rank-sort launch (and with which key table), whether the
+// radix launches, and what the device-side count leaves to which of the two
+struct SortPlan {
+    bool rank_only, rank_sort;
+    uint32_t rank_records;  // the rank-sort launch's key table (LDS words)
+    uint32_t rank_blocks;   // its workgroups
+};
+static SortPlan sort_plan(uint32_t capacity, SortMode mode)
+{
+    SortPlan p{};
+    p.rank_only = sort_is_rank_only(capacity, mode);
+    p.rank_sort = capacity <= kMidSortSlots && (mode != kSortRadixOnly || capacity <= kSmallSort);
+    p.rank_records = capacity <= kSmallSort ? capacity : (p.rank_only ? kRankOnlyTableRecords : kRankSortMaxRecords);
+    p.rank_blocks = ((p.rank_only ? capacity : p.rank_records) + 63) / 64;
+    return p;
+}
+
+static void sort_pass_args(const SortBuffers& b, uint32_t capacity, bool descending, bool rank_sort, SortPassArgs& a)
+{
+    a = SortPassArgs{};
     a.st.groups = sort_group_count(capacity);
     a.st.set_words = sort_set_words(capacity);
     a.st.group_hist = b.counters[b.parity];
@@ -662,15 +700,105 @@ hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending,
     a.model_out = b.model_out;
     a.dist_out = b.dist_out;
     a.ranks = b.ranks;
+}
+static void sort_pass_buffers(const SortBuffers& b, uint32_t pass, SortPassArgs& a)
+{
+    const uint32_t src = (pass & 1u) ^ 1u, dst = pass & 1u;  // pass 0 writes set 0, pass 1 set 1, ...
+    a.pass = pass;
+    a.keys_in = b.keys[src];
+    a.vals_in = b.vals[src];
+    a.keys_out = b.keys[dst];
+    a.vals_out = b.vals[dst];
+    a.slots_in = b.slots[src];
+    a.slots_out = b.slots[dst];
+}
+
+template <uint32_t N>
+static hipError_t launch_sort_batch_n(const SortBatchEntry* lists, uint32_t count, hipStream_t stream)
+{
+    // the rank-sort launch for every list that gets one (a list that does not: max_records 0 — its workgroups leave after one load)
+    MidRankBatch<N> ranks{};
+    uint32_t rank_blocks = 0, rank_lds = 0, radix_tiles = 0;
+    SortPassBatch<N> passes{};
+    for (uint32_t k = 0; k < count; k++) {
+        const SortBatchEntry& e = lists[k];
+        const SortPlan p = sort_plan(e.capacity, e.mode);
+        ranks.list[k] = MidRankEntry{e.b, e.capacity, e.descending, p.rank_sort ? (p.rank_only ? 0xFFFFFFFFu : p.rank_records) : 0u, p.rank_records};
+        if (p.rank_sort) {
+            rank_blocks = std::max(rank_blocks, p.rank_blocks);
+            rank_lds = std::max(rank_lds, ((p.rank_records + 3u) & ~3u) * 4u);
+        }
+        sort_pass_args(e.b, e.capacity, e.descending != 0, p.rank_sort, passes.list[k]);
+        if (p.rank_only)
+            passes.list[k].min_records = 0xFFFFFFFFu;  // the rank-sort launch alone: the radix launches leave this list at once
+        else
+            radix_tiles = std::max(radix_tiles, sort_tile_count(e.capacity));
+    }
+    if (rank_blocks) {
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_mid_rank_batch_kernel<N>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
+        if (raised != hipSuccess)
+            return raised;
+        hipLaunchKernelGGL(sort_mid_rank_batch_kernel<N>, dim3(rank_blocks, count), dim3(256), rank_lds, stream, ranks);
+    }
+    if (!radix_tiles)
+        return hipGetLastError();
+    const dim3 grid(radix_tiles, count), block(kSortThreads);
     for (uint32_t pass = 0; pass < 4; pass++) {
-        const uint32_t src = (pass & 1u) ^ 1u, dst = pass & 1u;  // pass 0 writes set 0, pass 1 set 1, ...
-        a.pass = pass;
-        a.keys_in = b.keys[src];
-        a.vals_in = b.vals[src];
-        a.keys_out = b.keys[dst];
-        a.vals_out = b.vals[dst];
-        a.slots_in = b.slots[src];
-        a.slots_out = b.slots[dst];
+        for (uint32_t k = 0; k < count; k++)
+            sort_pass_buffers(lists[k].b, pass, passes.list[k]);
+        if (pass == 0) {
+            hipLaunchKernelGGL((sort_rank_batch_kernel<true, N>), grid, block, 0, stream, passes);
+            hipLaunchKernelGGL((sort_scatter_batch_kernel<true, false, N>), grid, block, 0, stream, passes);
+        } else {
+            hipLaunchKernelGGL((sort_rank_batch_kernel<false, N>), grid, block, 0, stream, passes);
+            if (pass == 3)
+                hipLaunchKernelGGL((sort_scatter_batch_kernel<false, true, N>), grid, block, 0, stream, passes);
+            else
+                hipLaunchKernelGGL((sort_scatter_batch_kernel<false, false, N>), grid, block, 0, stream, passes);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_batch(const SortBatchEntry* lists, uint32_t count, hipStream_t stream)
+{
+    if (count == 0)
+        return hipSuccess;
+    if (count == 1)
+        return launch_sort(lists[0].b, lists[0].capacity, lists[0].descending != 0, stream, lists[0].mode);
+    return count <= 8 ? launch_sort_batch_n<8>(lists, count, stream) : launch_sort_batch_n<kMaxSortBatch>(lists, count, stream);
+}
+
+hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode)
+{
+    if (capacity == 0)
+        return hipSuccess;
+    // kSortRankOnly (the caller expects a short list: the previous frame's count): a mid-sized pool gets the rank-sort launch
+    // alone — the eight radix launches that would leave after one load each are ~16 us of an engine-sized tick — and a
+    // list that outgrew the key table after all is still sorted by it, from memory (count_before_global).
+    // Short lists sort in one launch whatever the pool's size: a pool of up to kMidSortSlots slots (where only the device
+    // knows how short the visible list is) gets the rank-sort launch AND the radix launches, and the live count decides on
+    // the device which of the two does the work — the other leaves after one load, ~2 us per launch, against 70 us for
+    // the eight radix launches on a few thousand records. Measured crossover: ~12 k records (rank 11 us at 2 k, 75 us at
+    // 16 k, 160 us at 32 k).
+    const SortPlan plan = sort_plan(capacity, mode);
+    if (plan.rank_sort) {
+        const uint32_t lds = ((plan.rank_records + 3u) & ~3u) * 4;  // the key table, beside the 1 KB of partial counts
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(sort_small_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSort * 4);
+        if (raised != hipSuccess)
+            return raised;
+        hipLaunchKernelGGL(sort_small_kernel, dim3(plan.rank_blocks), dim3(256), lds, stream, b, capacity, descending ? 1u : 0u,
+                           plan.rank_only ? 0xFFFFFFFFu : plan.rank_records, plan.rank_records);
+        if (capacity <= kSmallSort || plan.rank_only)
+            return hipGetLastError();
+    }
+    const uint32_t tiles = sort_tile_count(capacity);  // at full capacity (long or short tiles); the live count is on the device
+    SortPassArgs a;
+    sort_pass_args(b, capacity, descending, plan.rank_sort, a);
+    for (uint32_t pass = 0; pass < 4; pass++) {
+        sort_pass_buffers(b, pass, a);
         if (pass == 0) {
             hipLaunchKernelGGL(sort_rank_kernel<true>, dim3(tiles), dim3(kSortThreads), 0, stream, a);
             hipLaunchKernelGGL((sort_scatter_kernel<true, false>), dim3(tiles), dim3(kSortThreads), 0, stream, a);

@@ -53,6 +53,18 @@ constexpr uint32_t kRankOnlyMaxSlots = 65536;  // bounds the one slow frame afte
 constexpr uint32_t kRankOnlyHintRecords = 10240;  // (the rank-only launch's key table holds 16384: 60 % headroom before the slow form)
 constexpr uint32_t kRankOnlyTableRecords = 16384;
 hipError_t launch_sort(const SortBuffers& b, uint32_t capacity, bool descending, hipStream_t stream, SortMode mode = kSortBoth);
+// SEVERAL lists by ONE set of launches — a frame of many mid-sized mesh systems (10^5 slots each: too large for the one-launch batch
+// of small pools, too small to fill the device) is bound by its 9 launches per list, not by bytes: the rank-sort launch and the
+// eight radix launches of launch_sort with blockIdx.y = list (each list keeps its own buffers, counters, parity and device-side
+// count; same results). Lists of kBatchSortMaxSlots < capacity <= kMidSortMaxSlots, at most kMaxSortBatch per call.
+constexpr uint32_t kMaxSortBatch = 32;
+constexpr uint32_t kMidSortMaxSlots = 1u << 20;
+struct SortBatchEntry {
+    SortBuffers b;
+    uint32_t capacity, descending;
+    SortMode mode;
+};
+hipError_t launch_sort_batch(const SortBatchEntry* lists, uint32_t count, hipStream_t stream);
 // The same kernels as a sort of BARE KEYS: model_in / model_out NULL -> no record moves, idx_out receives the stable order
 // (idx_in NULL: of the identity, i.e. idx_out[k] = index of the k-th smallest key), dist_out may be NULL. Keys are the bit patterns
 // of NON-NEGATIVE floats (any uint32 below 2^31 read as a float: the kernels only ever look at the bits).

@@ -492,10 +492,12 @@ int gv_exchange_set_mode(GvCtx* ctx, uint32_t mode);
  * does for unsorted buffers — front to back, operator< at render/mesh.hpp:196 — or descending for the sorted /
  * translucent ones (render/mesh.hpp:204; mesh.cpp:265-328). Stable: equal keys keep the order the records were
  * emitted in (std::sort in the reference leaves ties unspecified).
- * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. For pools of up to 32768 slots
- * the launch is deferred to the first call that reads the records (gv_results_*, gv_wait), where the pending sorts of
- * all views of up to 16384 slots share one launch. Pools of up to 2^20 slots get a one-launch rank sort AND the radix
- * launches, and the record count on the device decides which of them works (short lists: one launch's worth of time). */
+ * Call after gv_cull (records requested), before gv_results_fetch / gv_results_device. For pools of up to 2^20 slots
+ * the launch is deferred to the first call that reads the records (gv_results_*, gv_exchange_*, gv_wait), where the pending
+ * sorts of ALL views of ALL pools share their launches: one launch for the views of up to 16384 slots; for the larger ones one
+ * set of launches — a one-launch rank sort AND the radix launches, list = blockIdx.y, the record count on the device deciding
+ * per list which of them works (short lists: one launch's worth of time). A frame of many mid-sized mesh systems is bound by
+ * its launches, not by bytes. Larger pools sort at once. */
 int gv_sort(GvCtx* ctx, uint32_t view_index, int descending);
 
 /* ---- scene ingest: a Garden scene file straight into column pools, no component AoS ----
