@@ -11,7 +11,17 @@ if [ "$what" = contract ]; then
 elif [ "$what" = tier ]; then
   python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/r06/gpu_tests.txt
   python3 bench.py > gpurun_out/r06/default_bench_line.json 2> gpurun_out/r06/default.err; tail -c 300 gpurun_out/r06/default.err; cut -c1-600 gpurun_out/r06/default_bench_line.json
-  bash tools/tick_ranks.sh after > /dev/null 2>&1; grep -E "^##|prepare us|^ranks" gpurun_out/tick_ranks_after.txt
+  bash tools/tick_ranks.sh peers > /dev/null 2>&1; bash tools/tick_ranks.sh communicator --communicator > /dev/null 2>&1
+  grep -E "^##|prepare us" gpurun_out/tick_ranks_peers.txt gpurun_out/tick_ranks_communicator.txt | cut -c1-200
+  {
+    echo "# tests/cpp/headless_tick --mode gpu <args>, GV_TICK_BREAKDOWN=1 (host us per tick of the drop-in's prepare phase), one context"
+    for a in "--entities 2000 --ticks 2000" "--entities 10000 --ticks 2000" "--entities 10000 --span-records --ticks 2000" "--entities 100000 --ticks 1000" "--entities 100000 --span-records --ticks 1000" \
+             "--entities 10000 --mixed --ticks 2000" "--entities 10000 --mixed --csm --ticks 2000" "--entities 10000 --hier --world --animate 50 --itemised --ticks 2000" \
+             "--entities 100000 --mixed --ticks 500" "--entities 300000 --mixed --csm --ticks 200" "--entities 1000000 --ticks 200" "--entities 1000000 --mixed --csm --ticks 200"; do
+      echo "## $a"
+      GV_TICK_BREAKDOWN=1 timeout 300 ./tests/cpp/build/headless_tick --mode gpu $a 2>&1 | grep -E "prepare us"
+    done
+  } > gpurun_out/r06/tick.txt 2>&1; cat gpurun_out/r06/tick.txt
 elif [ "$what" = evidence ]; then
   # the line an 8-GPU run prints, with 8 ranks SHARING this box's one GPU (torch over gloo, the library's exchange over the tests'
   # shared-memory transport): functional, never a measurement — the probe of the travel patterns, the choice, parity on all ranks
