@@ -444,10 +444,14 @@ int gv_exchange_init_peers(GvCtx* const* contexts, int world_size)
             }
         }
     int rc = GV_OK;
-    for (int k = 0; k < world_size && rc == GV_OK; k++)
+    GvCtx* culprit = first;  // the context whose text says what went wrong
+    for (int k = 0; k < world_size && rc == GV_OK; k++) {
         rc = exchange_setup(contexts[k], k, world_size);  // (releases what was there, a former group included)
+        culprit = contexts[k];
+    }
     for (int a = 0; a < world_size && rc == GV_OK; a++) {
         const int da = contexts[a]->device;
+        culprit = contexts[a];
         if (hipSetDevice(da) != hipSuccess) {
             rc = contexts[a]->fail(GV_E_HIP, "gv_exchange_init_peers: hipSetDevice(%d)", da);
             break;
@@ -467,14 +471,10 @@ int gv_exchange_init_peers(GvCtx* const* contexts, int world_size)
         }
     }
     if (rc != GV_OK) {
-        const std::string why = contexts[0]->error.empty() ? std::string("gv_exchange_init_peers failed") : contexts[0]->error;
-        std::string text = why;
-        for (int k = 0; k < world_size; k++)
-            if (!contexts[k]->error.empty())
-                text = contexts[k]->error;
+        const std::string why = culprit->error;
         for (int k = 0; k < world_size; k++)
             gv::exchange_release(contexts[k]);
-        first->error = text;
+        first->error = why;  // (callers of the *_all forms ask contexts[0])
         return rc;
     }
     const std::vector<GvCtx*> members(contexts, contexts + world_size);
@@ -988,7 +988,7 @@ int peer_collective(GvCtx* const* ctxs, int n, unsigned which)
         Slot& slot = ctx->exchange_slots[which];
         if (int rc = on(k))
             return rc;
-        gv::PeerRows rows;
+        gv::PeerRows rows{};
         for (int j = 0; j < n; j++)
             rows.dst[j] = ctxs[j]->exchange_slots[which].rows.ptr + (size_t)k * slot.row_words;
         GV_HIP(ctx, gv::launch_peer_scatter(slot.shard.ptr, slot.row_words, rows, (uint32_t)n, ctx->exchange_stream));
