@@ -286,16 +286,14 @@ int exchange_setup(GvCtx* ctx, int rank, int world_size)
         GV_HIP(ctx, hipEventCreateWithFlags(&slot.all_sent, hipEventDisableTiming));
     }
     if (const char* m = getenv("GV_EXCHANGE_MODE")) {
-        if (!strcmp(m, "peer"))
-            ctx->exchange_mode = GV_EXCHANGE_PEER;  // (gv_exchange_init_peers only; the communicator forms refuse it)
-        else if (!strcmp(m, "p2p"))
+        if (!strcmp(m, "p2p"))
             ctx->exchange_mode = GV_EXCHANGE_P2P;
         else if (!strcmp(m, "broadcast"))
             ctx->exchange_mode = GV_EXCHANGE_BROADCAST;
         else if (!strcmp(m, "allgather"))
             ctx->exchange_mode = GV_EXCHANGE_ALLGATHER;
         else
-            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast | peer)", m);
+            return ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=%s (allgather | p2p | broadcast: a communicator's travel patterns)", m);
     }
     if (const char* t = getenv("GV_EXCHANGE_TIMEOUT_MS")) {
         const long ms = atol(t);
@@ -342,8 +340,6 @@ int gv_exchange_init(GvCtx* ctx, const void* unique_id, int rank, int world_size
         return ctx->fail(GV_E_RCCL, "gv_exchange_init: %s", r.why.c_str());
     if (int rc = exchange_setup(ctx, rank, world_size))
         return exchange_setup_failed(ctx, rc);
-    if (ctx->exchange_mode == GV_EXCHANGE_PEER)
-        return exchange_setup_failed(ctx, ctx->fail(GV_E_ARG, "gv_exchange_init: GV_EXCHANGE_MODE=peer is the pattern of gv_exchange_init_peers (one process, no communicator)"));
     NcclId id{};
     memcpy(id.bytes, unique_id, GV_EXCHANGE_ID_BYTES);
     ncclComm_t comm = nullptr;
@@ -373,11 +369,8 @@ int gv_exchange_init_all(GvCtx* const* contexts, int world_size)
     if (r.GetUniqueId(&id) != 0)
         return first->fail(GV_E_RCCL, "gv_exchange_init_all: ncclGetUniqueId failed");
     int rc = GV_OK;
-    for (int k = 0; k < world_size && rc == GV_OK; k++) {
+    for (int k = 0; k < world_size && rc == GV_OK; k++)
         rc = exchange_setup(contexts[k], k, world_size);
-        if (rc == GV_OK && contexts[k]->exchange_mode == GV_EXCHANGE_PEER)
-            rc = first->fail(GV_E_ARG, "gv_exchange_init_all: GV_EXCHANGE_MODE=peer is the pattern of gv_exchange_init_peers (no communicator)");
-    }
     ncclComm_t comms[GV_EXCHANGE_MAX_RANKS] = {};
     // every device is selected once BEFORE the group opens: nothing but ncclCommInitRank itself can fail between ncclGroupStart and
     // ncclGroupEnd (a group closed over fewer than world_size ranks would wait for the missing ones for ever)
