@@ -293,6 +293,23 @@ def test_native_exchange_driver_one_process_per_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [("--batched",), ("--batched", "--random-camera", "3", "--mode", "p2p"), ("--random-camera", "9", "--mode", "broadcast"),
+                                   ("--peers", "--ranks", "auto", "--batched")])
+def test_native_exchange_driver_real_rccl_other_forms(extra):
+    """The same driver, one rank per GPU of the box over REAL RCCL (no test transport), in its other forms: ONE exchange for two lists
+    per frame (gv_exchange_views: count table + lists, completed by a second exchange after the cut), the direct travel patterns
+    behind a new lens every frame — and, last, the one-process peer path with one context per GPU of the box (on a multi-GPU node
+    its stores cross xGMI without anyone editing the test)."""
+    if "--peers" in extra:
+        rest = tuple(a for a in extra if a not in ("--ranks", "auto"))
+        out = _exchange_ranks("auto", 200000, extra=rest)
+        assert out["mismatches"] == 0 and out["transport"].startswith("peer stores")
+    else:
+        out = _exchange_ranks("auto", 200000, extra=extra)
+        assert out["ranks"] >= 1 and out["mismatches"] == 0 and out["gathered_last_frame"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_native_exchange_logic_with_several_ranks_on_one_gpu(ranks):
     """The same driver with N ranks SHARING the GPU(s) of the box: RCCL refuses two ranks on one device, so the rows travel
