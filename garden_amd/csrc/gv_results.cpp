@@ -198,27 +198,31 @@ int flush_sorts(GvCtx* ctx)
         SortBatchEntry batch[kMaxSortBatch];
         ViewState* taken[kMaxSortBatch];
         uint32_t n = 0;
-        for (uint32_t pool = 0; pool < GV_MAX_POOLS && n < kMaxSortBatch; pool++)
+        int failed = GV_OK;  // a view whose buffers could not be had keeps its request; the views in front of it are sorted all the same
+        for (uint32_t pool = 0; pool < GV_MAX_POOLS && n < kMaxSortBatch && failed == GV_OK; pool++)
             for (uint32_t v = 0; v < GV_MAX_VIEWS && n < kMaxSortBatch; v++) {
                 ViewState& vs = ctx->views[pool][v];
                 if (!vs.valid || !vs.sort_pending || vs.occupancy <= kBatchSortMaxSlots)
                     continue;
-                const bool descending = vs.sort_pending == 2;
+                if ((failed = sort_large_prepare(ctx, vs, vs.sort_pending == 2, batch[n])) != GV_OK)
+                    break;
                 vs.sort_pending = 0;
-                if (int rc = sort_large_prepare(ctx, vs, descending, batch[n]))
-                    return rc;
                 taken[n++] = &vs;
             }
+        if (n) {
+            GV_HIP(ctx, hipSetDevice(ctx->device));
+            {
+                ZoneScope zone("Meshes Sort");
+                KernelTimer t(ctx, GV_K_SORT);
+                GV_HIP(ctx, launch_sort_batch(batch, n, ctx->stream));
+            }
+            for (uint32_t k = 0; k < n; k++)
+                sort_large_done(*taken[k]);
+        }
+        if (failed != GV_OK)
+            return failed;
         if (n == 0)
             break;
-        GV_HIP(ctx, hipSetDevice(ctx->device));
-        {
-            ZoneScope zone("Meshes Sort");
-            KernelTimer t(ctx, GV_K_SORT);
-            GV_HIP(ctx, launch_sort_batch(batch, n, ctx->stream));
-        }
-        for (uint32_t k = 0; k < n; k++)
-            sort_large_done(*taken[k]);
     }
     for (;;) {
         uint32_t widest = 0, views = 0;

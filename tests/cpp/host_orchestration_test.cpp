@@ -457,6 +457,48 @@ static void exercise(uint32_t config_flags, uint32_t n, uint32_t depth)
         bind_all(ctx, w);
         CHECK(gv_hierarchy_rebuild(ctx));
     }
+    // ---- a frame of MID-SIZED pools (beyond the one-launch publish and the one-launch batch sort): their sorts wait for the first read
+    //      and go out together (launch_sort_batch); structs, three arrays and a record target side by side ----
+    {
+        World large;
+        large.build(40000, depth);
+        const GvTransformLayout tl = transform_layout();
+        const GvMeshLayout ml = mesh_layout();
+        CHECK(gv_transform_bind(ctx, large.xf.data(), sizeof(Transform), (uint32_t)large.xf.size(), &tl, large.e2t.data(), (uint32_t)large.e2t.size()));
+        for (uint32_t p = 0; p < 3; p++)
+            CHECK(gv_pool_bind(ctx, p, large.meshes.data(), sizeof(Mesh), (uint32_t)large.meshes.size() - p * 2000, &ml));
+        const GvRecordLayout layout = {64, 0, 8, 56, GV_NONE, sizeof(Mesh), 0};
+        CHECK(gv_pool_set_record_layout(ctx, 1, &layout));  // pool 1 delivers structs, the others the three arrays
+        CHECK(gv_pool_set_record_layout(ctx, 0, nullptr));
+        CHECK(gv_pool_set_record_layout(ctx, 2, nullptr));
+        std::vector<uint8_t> own_records((size_t)40000 * 64 + 16);
+        void* target = reinterpret_cast<void*>(((uintptr_t)own_records.data() + 15) & ~(uintptr_t)15);
+        for (int tick = 0; tick < 3; tick++) {
+            GvView views[3] = {make_view(-1, 0, 1), make_view(0, 0, 1), make_view(1, 0, 1)};
+            CHECK(gv_pool_set_record_target(ctx, 1, 0, tick == 1 ? target : nullptr, tick == 1 ? (size_t)40000 * 64 : 0));
+            for (uint32_t p = 0; p < 3; p++) {
+                CHECK(gv_cull(ctx, p, views, 1 + p));
+                for (uint32_t v = 0; v < 1 + p; v++)
+                    CHECK(gv_pool_sort(ctx, p, v, v & 1));
+            }
+            if (tick == 2)
+                CHECK(gv_pool_sort(ctx, 2, 1, 0));  // asked for twice before anyone reads: the later request stands
+            for (uint32_t p = 0; p < 3; p++)
+                for (uint32_t v = 0; v < 1 + p; v++) {
+                    GvResult r{};
+                    CHECK(gv_pool_results_fetch(ctx, p, v, v == 0, &r));
+                    const void* records = nullptr;
+                    uint32_t count = 0;
+                    if (p == 1)
+                        CHECK(gv_pool_results_records(ctx, p, v, &records, &count));
+                }
+        }
+        CHECK(gv_pool_set_record_target(ctx, 1, 0, nullptr, 0));
+        CHECK(gv_pool_set_record_layout(ctx, 1, nullptr));
+        CHECK(gv_pool_bind(ctx, 2, nullptr, sizeof(Mesh), 0, &ml));
+        bind_all(ctx, w);
+        CHECK(gv_hierarchy_rebuild(ctx));
+    }
     // ---- scene ingest -> columns -> bind; tiles ----
     {
         std::string text = "{\"version\":\"0.0.1\",\"entities\":[";
@@ -1587,6 +1629,68 @@ static void allocation_failures()
         gv_destroy(ctx);
     }
     std::printf("allocation failures: %ld allocations failed in turn, %d calls reported it, every context recovered: ok\n", total, failed_calls);
+    {
+        // ... and of a frame of mid-sized pools, whose sorts wait for the first read and go out together (flush_sorts / launch_sort_batch):
+        // a view whose sort buffers cannot be had keeps its request, the views in front of it are sorted all the same, the call says GV_E_OOM
+        World mid;
+        mid.build(40000, 0);
+        auto sequence = [&](GvCtx* ctx, bool tolerate) -> int {
+            const GvTransformLayout tl = transform_layout();
+            const GvMeshLayout ml = mesh_layout();
+            auto step = [&](int rc) { return tolerate ? rc : (rc == GV_OK ? GV_OK : (std::fprintf(stderr, "mid-sized frame: %d (%s)\n", rc, gv_last_error(ctx)), std::exit(1), rc)); };
+            int rc;
+            if ((rc = step(gv_transform_bind(ctx, mid.xf.data(), sizeof(Transform), (uint32_t)mid.xf.size(), &tl, mid.e2t.data(), (uint32_t)mid.e2t.size()))))
+                return rc;
+            for (uint32_t p = 0; p < 2; p++)
+                if ((rc = step(gv_pool_bind(ctx, p, mid.meshes.data(), sizeof(Mesh), (uint32_t)mid.meshes.size() - p * 2000, &ml))))
+                    return rc;
+            GvView views[2] = {make_view(-1, 0, 1), make_view(0, 0, 1)};
+            for (int frame = 0; frame < 2; frame++) {
+                for (uint32_t p = 0; p < 2; p++) {
+                    if ((rc = step(gv_cull(ctx, p, views, 2))))
+                        return rc;
+                    for (uint32_t v = 0; v < 2; v++)
+                        if ((rc = step(gv_pool_sort(ctx, p, v, (int)(v ^ p)))))
+                            return rc;
+                }
+                GvResult r{};
+                for (uint32_t p = 0; p < 2; p++)
+                    for (uint32_t v = 0; v < 2; v++)
+                        if ((rc = step(gv_pool_results_fetch(ctx, p, v, v == 0, &r))))
+                            return rc;
+            }
+            return GV_OK;
+        };
+        GvCtx* probe2 = nullptr;
+        if (gv_create(&config, &probe2) != GV_OK)
+            std::exit(1);
+        const long before2 = gv_stub_allocations();
+        sequence(probe2, false);
+        const long total2 = gv_stub_allocations() - before2;
+        gv_destroy(probe2);
+        int failed2 = 0;
+        for (long k = 1; k <= total2; k++) {
+            GvCtx* ctx = nullptr;
+            if (gv_create(&config, &ctx) != GV_OK)
+                std::exit(1);
+            gv_stub_fail_countdown() = k;
+            const int rc = sequence(ctx, true);
+            gv_stub_fail_countdown() = 0;
+            if (rc != GV_OK) {
+                failed2++;
+                if ((rc != GV_E_OOM && rc != GV_E_HIP) || !*gv_last_error(ctx)) {
+                    std::fprintf(stderr, "mid-sized frame, allocation %ld of %ld failing: %d (%s)\n", k, total2, rc, gv_last_error(ctx));
+                    std::exit(1);
+                }
+            }
+            if (sequence(ctx, true) != GV_OK) {
+                std::fprintf(stderr, "mid-sized frame, allocation %ld of %ld failing once: the context did not recover (%s)\n", k, total2, gv_last_error(ctx));
+                std::exit(1);
+            }
+            gv_destroy(ctx);
+        }
+        std::printf("allocation failures in a frame of mid-sized pools: %ld allocations failed in turn, %d calls reported it, every context recovered: ok\n", total2, failed2);
+    }
 }
 
 // The exchange's bounded waits when the work behind them NEVER finishes (the stub's streams / events can be told so): status codes

@@ -594,6 +594,7 @@ def test_host_orchestration_under_address_and_ub_sanitizers(tmp_path):
     print("\n".join(l for l in run.stdout.splitlines() if l.startswith("exchange ")))
     # every allocation of a small frame sequence failing once, in turn: error codes, no leaks, contexts that recover
     assert "allocation failures:" in run.stdout and "every context recovered: ok" in run.stdout, run.stdout[-2000:]
+    assert "allocation failures in a frame of mid-sized pools:" in run.stdout, run.stdout[-2000:]  # (sorts that wait for the first read, batched)
     # ... and every allocation of the exchange step (rows, staging shard, widened rows for the tails) failing in turn: GV_E_OOM, the
     # same frame tried again, acquired whole
     assert "allocation failures in the exchange:" in run.stdout and "acquired whole all the same: ok" in run.stdout, run.stdout[-2000:]
