@@ -31,7 +31,8 @@ extern "C" {
 #define GV_ABI_VERSION 4u /* 3: every exchanged frame is complete (gv_exchange_acquire fills the frame; GV_EXCHANGE_EXACT and
                              gv_exchange_counts are gone); one thread can drive N contexts (gv_exchange_*_all); GV_E_TIMEOUT
                              4: ONE exchange per frame for all its (pool, view) lists (gv_exchange_views[_all]); a rank's results in
-                             the WORLD's slots (gv_pool_set_result_mapping, gv_pool_update_index_map); GvStats grew; GvExchangeFrame grew */
+                             the WORLD's slots (gv_pool_set_result_mapping, gv_pool_update_index_map); GvStats grew; GvExchangeFrame grew;
+                             gv_exchange_init_peers / GV_EXCHANGE_PEER (one process, no communicator) */
 #define GV_NONE 0xFFFFFFFFu
 #define GV_MAX_POOLS 16u
 #define GV_MAX_VIEWS 8u
