@@ -381,6 +381,9 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
     return ctx ? gv_pool_results_fetch(ctx, ctx->last_pool, view_index, write_back, out) : GV_E_ARG;
 }
 
+// a byte per component at the component's stride: every store is a cache line of its own
+constexpr uint32_t kWriteBackFloor = 49152;
+
 int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int write_back, GvResult* out)
 {
     if (!ctx)
@@ -600,12 +603,12 @@ int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int
                 for (uint32_t i = a; i < b; i++)
                     if (map[i] < limit)  // (GV_NONE: a hole)
                         base[(size_t)map[i] * stride] = out_vis[i];
-            });
+            }, kWriteBackFloor);
         } else if (component_vis)
             parallel_ranges(0, vs.occupancy, [&](uint32_t a, uint32_t b) {
                 for (uint32_t i = a; i < b; i++)
                     component_vis[(size_t)i * component_stride] = out_vis[i];
-            });
+            }, kWriteBackFloor);
         out->is_visible = out_vis;
     }
     return GV_OK;

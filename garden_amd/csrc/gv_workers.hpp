@@ -25,11 +25,13 @@ inline uint32_t worker_parts(size_t count)
     return count < floor ? 1u : std::min(hw, 16u);
 }
 
-// fn(lo, hi) over contiguous sub-ranges of [first, first + count)  (ThreadPool::addItems, thread-pool.cpp:180-194)
+// fn(lo, hi) over contiguous sub-ranges of [first, first + count)  (ThreadPool::addItems, thread-pool.cpp:180-194).
+// floor_items: the pass is worth the workers from that many items up (default: worker_parts' 128 Ki — a pass whose items each
+// miss the cache, like the strided isVisible write-back, pays for the wake-up much earlier)
 template <typename F>
-void parallel_ranges(uint32_t first, uint32_t count, F&& fn)
+void parallel_ranges(uint32_t first, uint32_t count, F&& fn, uint32_t floor_items = 0)
 {
-    const uint32_t parts = worker_parts(count);
+    const uint32_t parts = floor_items && count >= floor_items ? worker_parts((size_t)1 << 30) : worker_parts(count);
     if (parts == 1) {
         fn(first, first + count);
         return;
