@@ -382,7 +382,10 @@ int gv_results_fetch(GvCtx* ctx, uint32_t view_index, int write_back, GvResult* 
 }
 
 // a byte per component at the component's stride: every store is a cache line of its own
-constexpr uint32_t kWriteBackFloor = 49152;
+#ifndef GV_WRITE_BACK_FLOOR  // (A/B builds)
+#define GV_WRITE_BACK_FLOOR 49152
+#endif
+constexpr uint32_t kWriteBackFloor = GV_WRITE_BACK_FLOOR;
 
 int gv_pool_results_fetch(GvCtx* ctx, uint32_t pool_id, uint32_t view_index, int write_back, GvResult* out)
 {
