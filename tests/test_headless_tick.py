@@ -304,6 +304,8 @@ def test_native_exchange_driver_real_rccl_other_forms(extra):
         rest = tuple(a for a in extra if a not in ("--ranks", "auto"))
         out = _exchange_ranks("auto", 200000, extra=rest)
         assert out["mismatches"] == 0 and out["transport"].startswith("peer stores")
+        if "unavailable" in out["transport"]:
+            pytest.skip(out["transport"])  # (GV_E_STATE: the box's devices cannot reach each other's memory)
     else:
         out = _exchange_ranks("auto", 200000, extra=extra)
         assert out["ranks"] >= 1 and out["mismatches"] == 0 and out["gathered_last_frame"] > 0
